@@ -1,0 +1,130 @@
+"""Pins oracle/nifty_oracle.py against vectors produced by the real reference."""
+import numpy as np
+import pytest
+
+from oracle import nifty_oracle as orc
+from tests import goldenlib as gl
+
+GEO_CASES = [((8,), None, "8"), ((7, 8), None, "7x8"), ((4, 5, 7), None, "4x5x7"), ((512,), None, "512"),
+             ((64, 64), None, "64x64"), ((16, 16, 16), None, "16x16x16"), ((16, 32), (0.3, 0.2), "16x32d"),
+             ((12,), (0.7,), "12d")]
+
+
+@pytest.mark.parametrize("shape,dist,tag", GEO_CASES)
+def test_geometry(shape, dist, tag):
+    z = gl.load("geometry")
+    g = orc.power_geometry(shape, dist)
+    assert np.array_equal(g.pindex, z[f"{tag}.pindex"])
+    np.testing.assert_allclose(g.k_lengths, z[f"{tag}.k_lengths"], rtol=1e-14)
+    np.testing.assert_allclose(g.dvol, z[f"{tag}.dvol"], rtol=1e-14)
+    np.testing.assert_allclose(orc.unique_k_lengths(shape, g.hdist), z[f"{tag}.unique_k"], rtol=1e-14)
+    np.testing.assert_allclose(g.total_volume, z[f"{tag}.total_volume"], rtol=1e-14)
+    np.testing.assert_allclose(g.h_dvol, z[f"{tag}.h_dvol"], rtol=1e-14)
+
+
+def test_power_space_known_answers():
+    # reference test/test_cl/test_spaces/test_power_space.py:59-99 (RGSpace((8,), harmonic=True))
+    g = orc.power_geometry((8,), 1.0 / 8)  # position distances 1/8 -> harmonic distances 1
+    assert list(g.pindex) == [0, 1, 2, 3, 4, 3, 2, 1]
+    np.testing.assert_allclose(g.k_lengths, [0, 1, 2, 3, 4])
+    assert list(g.rho) == [1, 2, 2, 2, 1]
+
+
+@pytest.mark.parametrize("tag", ["16f64", "512f64", "64x64f64", "32x32x32f64", "64x64f32", "8x4x16f64", "2048f32"])
+def test_transforms(tag):
+    z = gl.load("transforms")
+    x = z[f"{tag}.x"]
+    tol = 1e-5 if "f32" in tag else 1e-12
+    for conv in ("non_canonical_hartley", "canonical_hartley"):
+        assert gl.relerr(orc.hartley(x, convention=conv), z[f"{tag}.hartley.{conv}"]) < tol
+    xc = z[f"{tag}.xc"]
+    # FFTOperator(harmonic -> position): TIMES = N*ifftn (x dvol_h = 1), INVERSE_TIMES = fftn * dvol_pos
+    # (reference nifty/cl/operators/harmonic_operators.py:77-94)
+    assert gl.relerr(orc.ifftn(xc) * xc.size, z[f"{tag}.fft"]) < tol
+    assert gl.relerr(orc.fftn(xc) / xc.size, z[f"{tag}.ifft"]) < tol
+
+
+def build(z):
+    m = gl.meta(z)
+    cf = orc.CFModel(m["shape"], m["distances"], orc.CFParams(offset_mean=2.0))
+    icov = None
+    if m["kind"] == "gaussian":
+        icov = z["icov"]
+        icov = float(icov) if icov.shape == () else icov
+    lh = orc.Likelihood(m["kind"], z["data"], icov=icov, nonlin=m["nonlin"])
+    return m, cf, lh
+
+
+@pytest.mark.parametrize("case", gl.MODEL_CASES)
+def test_cf_model(case):
+    z = gl.load("model_" + case)
+    m, cf, lh = build(z)
+    x, v = gl.latent(z, "x"), gl.latent(z, "v")
+    st = cf.amplitude_state(x)
+    assert gl.relerr(st["a"], z["amplitude"]) < 1e-12
+    assert gl.relerr(cf.amplitude_jvp(st, v), z["amplitude_jvp"]) < 1e-11
+    avjp = cf.amplitude_vjp(st, z["wa"])
+    ref = gl.latent(z, "amplitude_vjp")
+    assert gl.lat_relerr({k: avjp[k] for k in ref}, ref) < 1e-11
+    assert gl.relerr(cf.forward(x, st), z["cf"]) < 1e-12
+    assert gl.relerr(cf.jvp(x, st, v), z["cf_jvp"]) < 1e-11
+    assert gl.lat_relerr(cf.vjp(x, st, z["w"]), gl.latent(z, "cf_vjp")) < 1e-11
+
+
+@pytest.mark.parametrize("case", gl.MODEL_CASES)
+def test_hamiltonian(case):
+    z = gl.load("model_" + case)
+    m, cf, lh = build(z)
+    x, v = gl.latent(z, "x"), gl.latent(z, "v")
+    lin = orc.Linearized(cf, lh, x)
+    val, grad = lin.value_grad()
+    assert abs(val - float(z["ham_value"])) < 1e-11 * abs(float(z["ham_value"]))
+    assert gl.lat_relerr(grad, gl.latent(z, "ham_grad")) < 1e-10
+    assert gl.lat_relerr(lin.metric(v), gl.latent(z, "ham_metric_v")) < 1e-10
+
+
+def _geo_min():
+    return lambda e: orc.newton_cg(e, orc.AbsDeltaEnergyController(0.5, iteration_limit=3, convergence_level=2),
+                                   max_cg_iterations=6)
+
+
+def _samples(z, m, cf, lh, x):
+    sseq = np.random.SeedSequence(m["seed"] + 1)
+    icf = lambda: orc.AbsDeltaEnergyController(0.05, iteration_limit=m["sampling_limit"])
+    return orc.draw_samples(cf, lh, x, m["n_samples"], True, sseq, icf,
+                            geo_minimizer=_geo_min() if m["geo"] else None)
+
+
+@pytest.mark.parametrize("case", gl.MODEL_CASES)
+def test_sampling_and_kl(case):
+    z = gl.load("model_" + case)
+    m, cf, lh = build(z)
+    x, v = gl.latent(z, "x"), gl.latent(z, "v")
+    res, negs = _samples(z, m, cf, lh, x)
+    assert len(res) == int(z["n_residuals"])
+    tol = 1e-6 if m["geo"] else 1e-9
+    for i, (r, neg) in enumerate(zip(res, negs)):
+        rr = orc.lv_scale(-1.0, r) if neg else r
+        assert gl.lat_relerr(rr, gl.latent(z, f"residual{i}")) < tol, i
+    kl = orc.SampledKL(cf, lh, x, res, negs)
+    assert abs(kl.value - float(z["kl_value"])) < 1e-9 * abs(float(z["kl_value"]))
+    assert gl.lat_relerr(kl.gradient, gl.latent(z, "kl_grad")) < 1e-8
+    assert gl.lat_relerr(kl.apply_metric(v), gl.latent(z, "kl_metric_v")) < 1e-8
+    ctrl = orc.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2)
+    kl2, _ = orc.newton_cg(kl, ctrl, max_cg_iterations=8)
+    assert abs(kl2.value - float(z["kl_min_value"])) < 1e-8 * abs(float(z["kl_min_value"]))
+    assert gl.lat_relerr(kl2.position, gl.latent(z, "kl_min_pos")) < 1e-7
+
+
+@pytest.mark.parametrize("case", ["g1d", "p2d_geo"])
+def test_optimize_kl(case):
+    z = gl.load("model_" + case)
+    m, cf, lh = build(z)
+    icf = lambda: orc.AbsDeltaEnergyController(0.05, iteration_limit=m["sampling_limit"])
+    mk = lambda: (lambda e: orc.newton_cg(e, orc.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2),
+                                          max_cg_iterations=8))
+    geo = (lambda: _geo_min()) if m["geo"] else None
+    # optimize_kl spawns its per-iteration seeds from the top of the stack = SeedSequence(seed+2)
+    mean, kl = orc.optimize_kl(cf, lh, 2, m["n_samples"], icf, mk, seed=m["seed"] + 2, geo_minimizer_factory=geo)
+    # two full geoVI iterations amplify rounding differences (see make_golden.py GEO_CG note)
+    assert gl.lat_relerr(mean, gl.latent(z, "okl_mean")) < (2e-3 if m["geo"] else 1e-6)
