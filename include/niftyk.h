@@ -1,0 +1,156 @@
+/* niftyk.h -- C ABI of libniftyk, the MI355X (gfx950) kernel library behind the nifty.cl MGVI/geoVI
+ * hot path.  This is the drop-in boundary: every entry point replaces one native-dispatch call site
+ * of the reference (file:line relative to the NIFTy source tree) and takes only plain pointers and
+ * sizes.  All pointers are BORROWED device pointers (hipMalloc'd / torch tensor .data_ptr()),
+ * contiguous C order; the caller owns memory and lifetime.  `stream` is a hipStream_t passed as
+ * void* (0 = default stream).  Every function returns 0 on success or a negative nk_status code and
+ * never throws; nk_last_error() returns a thread-local message for the last failure.
+ * Plans are immutable after creation; execution is ordered by the stream.  No entry point allocates
+ * device memory after plan creation (workspace is passed in; size from nk_plan_workspace_bytes).
+ */
+#ifndef NIFTYK_H
+#define NIFTYK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  NK_OK = 0,
+  NK_ERR_INVALID = -1,      /* bad argument (ValueError on the Python side) */
+  NK_ERR_UNSUPPORTED = -2,  /* shape / dtype not supported yet (NotImplementedError) */
+  NK_ERR_RUNTIME = -3,      /* HIP runtime failure (RuntimeError) */
+  NK_ERR_NOMEM = -4
+} nk_status;
+
+typedef enum { NK_F32 = 0, NK_F64 = 1 } nk_dtype;
+
+/* hartley conventions, nifty/config.py:42-78 */
+#define NK_HARTLEY_NON_CANONICAL 0 /* Re F + Im F : NIFTy default ("non_canonical_hartley") */
+#define NK_HARTLEY_CANONICAL 1     /* Re F - Im F */
+
+/* fused prologue (input side of a transform) */
+enum { NK_PRO_PLAIN = 0, NK_PRO_AMP = 1, NK_PRO_AMP_JVP = 2, NK_PRO_MUL = 3 };
+/* fused epilogue (output side of a transform) */
+enum { NK_EPI_AFFINE = 0, NK_EPI_MUL = 1, NK_EPI_VJP = 2, NK_EPI_LIKELIHOOD = 3, NK_EPI_NONLIN = 4 };
+enum { NK_LH_GAUSS = 0, NK_LH_POISSON = 1 };
+enum { NK_NL_ID = 0, NK_NL_EXP = 1, NK_NL_SIGMOID = 2 };
+
+/* Fusion descriptor for nk_hartley_fused.  T = the plan's real dtype.
+ *   prologue  x(i) fed into the transform:
+ *     PLAIN    in[i]
+ *     AMP      amp[pidx[i]] * in[i]                              (PowerDistributor gather x xi,
+ *                                                                  distributors.py:114-119 + diagonal multiply)
+ *     AMP_JVP  amp[pidx[i]] * in[i] + damp[pidx[i]] * in2[i]     (product rule, operator.py:579-582)
+ *     MUL      in[i] * in2[i]
+ *   epilogue  for transform output v at index o, t = v * scale:
+ *     AFFINE      out[o] = t + offset                            (scalar_dvol factor + Adder, adder.py:47-52)
+ *     MUL         out[o] = t * mul_scalar * mul[o]               (DiagonalOperator / ScalingOperator)
+ *     VJP         out[o] = amp[pidx[o]] * t (+ addend[o]);  abar[pidx[o]] += xi[o] * t
+ *                                                                (PowerDistributor adjoint, distributors.py:106-112)
+ *     LIKELIHOOD  s = t + offset, g = nonlin(s); Gaussian / Poisson energy -> *value (atomic),
+ *                 out[o] = dE/ds, out2[o] = g'(s)^2 * M_d (Fisher metric weight in s-space)
+ *                                                                (energy_operators.py:517-640)
+ *     NONLIN      out[o] = nonlin(t + offset), out2[o] = nonlin'(.)   (pointwise.py:134-159)
+ */
+typedef struct nk_fuse {
+  int pro;
+  const void* in;
+  const void* in2;
+  const int32_t* pidx;
+  const double* amp;
+  const double* damp;
+  int epi;
+  void* out;
+  double scale;
+  double offset;
+  const void* mul;
+  double mul_scalar;
+  const void* xi;
+  const void* addend;
+  double* abar;
+  int lh_kind, nonlin;
+  const void* data;
+  const void* icov;
+  double icov_scalar;
+  void* out2;
+  double* value;
+} nk_fuse;
+
+typedef struct nk_plan nk_plan;
+
+const char* nk_last_error(void);
+int nk_version(void);
+
+/* ---- transforms: replace ducc_dispatch.hartley / fftn / ifftn (nifty/cl/ducc_dispatch.py:116-142),
+ *      called from HartleyOperator._apply_cartesian and FFTOperator.apply
+ *      (nifty/cl/operators/harmonic_operators.py:77-94,144-161).  All `ndim` trailing axes of a
+ *      [batch, shape...] array are transformed; axis lengths must be powers of two (>=2 on the last axis). */
+int nk_plan_create(nk_plan** plan, int ndim, const int64_t* shape, int dtype, int64_t batch);
+int nk_plan_destroy(nk_plan* plan);
+size_t nk_plan_workspace_bytes(const nk_plan* plan);
+/* out = scale * Hartley(in); in == out is allowed */
+int nk_hartley(const nk_plan* plan, const void* in, void* out, double scale, int convention, void* workspace,
+               void* stream);
+int nk_hartley_fused(const nk_plan* plan, const nk_fuse* fuse, int convention, void* workspace, void* stream);
+/* complex-to-complex: in/out interleaved (re,im) of the plan dtype; inverse != 0 uses exp(+i..);
+ * result is multiplied by `scale` (pass 1/N for numpy-style ifftn).  in == out allowed. */
+int nk_fftn(const nk_plan* plan, const void* in, void* out, int inverse, double scale, void* workspace,
+            void* stream);
+
+/* ---- reductions: replace ducc_dispatch.vdot / AnyArray.vdot / norm / sum
+ *      (nifty/cl/ducc_dispatch.py:145-150, any_array.py:544-552).  fp64 accumulation for both dtypes;
+ *      result is written to a DEVICE double (no host sync).  `result` must be zeroed by the caller
+ *      unless accumulate == 0 (then the kernel chain zeroes it first). */
+int nk_vdot(int64_t n, const void* a, const void* b, int dtype, double* result, int accumulate, void* stream);
+int nk_sum(int64_t n, const void* a, int dtype, double* result, int accumulate, void* stream);
+
+/* ---- element-wise vector algebra used by Field/MultiField arithmetic and CG
+ *      (field.py:755-763, conjugate_gradient.py:100-124, quadratic_energy.py:31-39) */
+enum { NK_OP_ADD = 0, NK_OP_SUB = 1, NK_OP_MUL = 2, NK_OP_DIV = 3 };
+/* out = a (op) b ;  b == NULL -> out = a (op) bscalar ; a == NULL -> out = ascalar (op) b */
+int nk_binary(int op, int64_t n, const void* a, double ascalar, const void* b, double bscalar, void* out,
+              int dtype, void* stream);
+/* out = alpha * x + beta * y   (y may be NULL) */
+int nk_axpby(int64_t n, double alpha, const void* x, double beta, const void* y, void* out, int dtype,
+             void* stream);
+/* pointwise nonlinearity with optional derivative output (pointwise.py:134-159):
+ * fn: 0 exp, 1 log, 2 sqrt, 3 tanh, 4 sigmoid(0.5+0.5tanh), 5 reciprocal, 6 power(p), 7 abs, 8 log1p, 9 expm1 */
+int nk_pointwise(int fn, double param, int64_t n, const void* x, void* fx, void* dfx, int dtype, void* stream);
+/* gather / scatter-add by bin index (DOFDistributor, distributors.py:106-127): table/in/out are of `dtype`;
+ * the scatter accumulates into DOUBLE bins (np.bincount semantics, utilities.py:222-246), caller zeroes them */
+int nk_gather(int64_t n, const void* table, const int32_t* pidx, void* out, int dtype, void* stream);
+int nk_scatter_add(int64_t n, const void* in, const int32_t* pidx, int64_t nbins, void* bins, int dtype,
+                   void* stream);
+
+/* ---- fused CG updates with device-resident scalars (conjugate_gradient.py:85-126).
+ *      scal = device double[8]: [0] gamma_prev  [1] curv  [2] gamma  [3] x.r  [4] x.b  [5] alpha  [6] beta
+ *      nk_cg_curv : scal[1] = d.q
+ *      nk_cg_update: alpha = scal[0]/scal[1]; x -= alpha d; r -= alpha q; scal[2] = r.r; scal[3] = x.r;
+ *                    scal[4] = x.b  (b may be NULL)
+ *      nk_cg_direction: beta = max(0, scal[2]/scal[0]); d = beta d + r; scal[0] = scal[2] */
+int nk_cg_curv(int64_t n, const void* d, const void* q, int dtype, double* scal, void* stream);
+int nk_cg_update(int64_t n, void* x, void* r, const void* d, const void* q, const void* b, int dtype,
+                 double* scal, void* stream);
+int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, double* scal, void* stream);
+
+/* ---- amplitude model on the nb power bins (library/correlated_fields.py:89-208,277-386).
+ *      geo  = double[4*nb]: rel[nb], sc[nb], mult[nb], delta[nb] (delta uses the first nb-2 slots)
+ *      hyp  = double[11]: (logmean, logsigma) of fluctuations, flexibility, asperity, zeromode;
+ *                         (mean, sigma) of loglogavgslope; total volume V
+ *      lat  = device double[5 + 2*(nb-2)]: xi_asperity, xi_flexibility, xi_fluctuations, xi_slope,
+ *             xi_zeromode, then spectrum[2][nb-2]
+ *      state= device double[8*nb + 16] scratch kept between forward and jvp/vjp at the same point */
+int nk_amp_forward(int nb, const double* geo, const double* hyp, const double* lat, double* state, double* amp,
+                   void* stream);
+int nk_amp_jvp(int nb, const double* geo, const double* hyp, const double* lat, double* state, const double* dlat,
+               double* damp, void* stream);
+int nk_amp_vjp(int nb, const double* geo, const double* hyp, const double* lat, double* state, const double* abar,
+               double* latbar, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIFTYK_H */

@@ -1,0 +1,97 @@
+"""ctypes binding of libniftyk (the C ABI declared in include/niftyk.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950).  Loading
+fails loudly if it is missing: device code paths never fall back to anything else.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libniftyk.so")
+
+NK_OK, NK_ERR_INVALID, NK_ERR_UNSUPPORTED, NK_ERR_RUNTIME, NK_ERR_NOMEM = 0, -1, -2, -3, -4
+NK_F32, NK_F64 = 0, 1
+PRO_PLAIN, PRO_AMP, PRO_AMP_JVP, PRO_MUL = 0, 1, 2, 3
+EPI_AFFINE, EPI_MUL, EPI_VJP, EPI_LIKELIHOOD, EPI_NONLIN = 0, 1, 2, 3, 4
+LH_GAUSS, LH_POISSON = 0, 1
+NL_ID, NL_EXP, NL_SIGMOID = 0, 1, 2
+OP_ADD, OP_SUB, OP_MUL, OP_DIV = 0, 1, 2, 3
+
+_vp, _i, _i64, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_size_t
+
+
+class Fuse(ctypes.Structure):
+    """Mirror of ``struct nk_fuse`` (include/niftyk.h)."""
+
+    _fields_ = [
+        ("pro", _i), ("in_", _vp), ("in2", _vp), ("pidx", _vp), ("amp", _vp), ("damp", _vp),
+        ("epi", _i), ("out", _vp), ("scale", _d), ("offset", _d), ("mul", _vp), ("mul_scalar", _d),
+        ("xi", _vp), ("addend", _vp), ("abar", _vp), ("lh_kind", _i), ("nonlin", _i), ("data", _vp),
+        ("icov", _vp), ("icov_scalar", _d), ("out2", _vp), ("value", _vp),
+    ]
+
+
+# name -> (restype, argtypes); the list is checked against include/niftyk.h by tests/test_abi.py
+SIGNATURES = {
+    "nk_last_error": (ctypes.c_char_p, []),
+    "nk_version": (_i, []),
+    "nk_plan_create": (_i, [ctypes.POINTER(_vp), _i, ctypes.POINTER(_i64), _i, _i64]),
+    "nk_plan_destroy": (_i, [_vp]),
+    "nk_plan_workspace_bytes": (_sz, [_vp]),
+    "nk_hartley": (_i, [_vp, _vp, _vp, _d, _i, _vp, _vp]),
+    "nk_hartley_fused": (_i, [_vp, ctypes.POINTER(Fuse), _i, _vp, _vp]),
+    "nk_fftn": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp]),
+    "nk_vdot": (_i, [_i64, _vp, _vp, _i, _vp, _i, _vp]),
+    "nk_sum": (_i, [_i64, _vp, _i, _vp, _i, _vp]),
+    "nk_binary": (_i, [_i, _i64, _vp, _d, _vp, _d, _vp, _i, _vp]),
+    "nk_axpby": (_i, [_i64, _d, _vp, _d, _vp, _vp, _i, _vp]),
+    "nk_pointwise": (_i, [_i, _d, _i64, _vp, _vp, _vp, _i, _vp]),
+    "nk_gather": (_i, [_i64, _vp, _vp, _vp, _i, _vp]),
+    "nk_scatter_add": (_i, [_i64, _vp, _vp, _i64, _vp, _i, _vp]),
+    "nk_cg_curv": (_i, [_i64, _vp, _vp, _i, _vp, _vp]),
+    "nk_cg_update": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "nk_cg_direction": (_i, [_i64, _vp, _vp, _i, _vp, _vp]),
+    "nk_amp_forward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "nk_amp_jvp": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "nk_amp_vjp": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class NiftykError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libniftyk.so (once).  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NiftykError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). nifty_amd has no CPU fallback for device fields."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    """Translate an nk_status into the reference's exception types (SURVEY 8b 'Errors')."""
+    if rc == NK_OK:
+        return
+    msg = load().nk_last_error().decode(errors="replace")
+    text = f"{what}: {msg}" if what else msg
+    if rc == NK_ERR_INVALID:
+        raise ValueError(text)
+    if rc == NK_ERR_UNSUPPORTED:
+        raise NotImplementedError(text)
+    if rc == NK_ERR_NOMEM:
+        raise MemoryError(text)
+    raise NiftykError(text)

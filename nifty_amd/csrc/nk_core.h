@@ -1,0 +1,292 @@
+// nk_core.h -- device-side building blocks of libniftyk (gfx950 / MI355X).
+//
+// Every kernel in this library is written as a sequence of PHASES separated by workgroup
+// barriers.  A phase is a plain function  phase(tid, nthreads, block, lds, params)  that loops
+// over its work items with stride `nthreads`.  On the GPU the kernel calls the phases with
+// __syncthreads() in between; the test-only host emulation (tests/emu, -DNK_HOST_EMU) calls the
+// same phase for tid = 0..nthreads-1 sequentially.  That lets the index math, digit reversal,
+// twiddles and the fused prologue/epilogue be checked bit-for-bit on a CPU-only box.  The
+// emulation is never linked into the product library.
+#pragma once
+#include <stdint.h>
+#include "../../include/niftyk.h"
+
+#ifdef NK_HOST_EMU
+#include <cmath>
+#define NK_HD inline
+#define NK_ATOMIC_ADD(p, v) (*(p) += (v))
+#else
+#include <hip/hip_runtime.h>
+#define NK_HD __host__ __device__ __forceinline__
+#define NK_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#endif
+
+#define NK_MAX_STAGES 8
+
+template <typename T>
+struct alignas(2 * sizeof(T)) C2 {
+  T x, y;
+};
+
+template <typename T>
+NK_HD C2<T> cmul(C2<T> a, C2<T> b) {
+  return C2<T>{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+template <typename T>
+NK_HD C2<T> cadd(C2<T> a, C2<T> b) {
+  return C2<T>{a.x + b.x, a.y + b.y};
+}
+template <typename T>
+NK_HD C2<T> csub(C2<T> a, C2<T> b) {
+  return C2<T>{a.x - b.x, a.y - b.y};
+}
+// multiply by -i  (forward-transform rotation)
+template <typename T>
+NK_HD C2<T> cmul_mi(C2<T> a) {
+  return C2<T>{a.y, -a.x};
+}
+
+// ---------------------------------------------------------------------------------------------
+// line FFT plan: in-place decimation-in-frequency, mixed radix {8,4,2}; result is left in
+// digit-reversed order and un-reversed by the store phase.
+// ---------------------------------------------------------------------------------------------
+struct NkLinePlan {
+  int n;                       // complex line length (power of two, >= 1)
+  int nstage;                  // number of DIF stages
+  int radix[NK_MAX_STAGES];    // radices in execution order
+};
+
+NK_HD int nk_digit_reverse(const NkLinePlan& lp, int k) {
+  int p = 0, span = lp.n;
+  for (int s = 0; s < lp.nstage; ++s) {
+    const int R = lp.radix[s];
+    span /= R;
+    p += (k & (R - 1)) * span;
+    k /= R;
+  }
+  return p;
+}
+
+// LDS tile layout.  t_fastest: element (pos, t) at pos*tstride + t        (strided-axis tiles)
+//                   else     : element (pos, t) at t*lstride + pos + (pos >> 4)  (contiguous lines,
+//                              one pad slot per 16 elements keeps small-stride stages conflict-free)
+struct NkTile {
+  int tile;        // lines per workgroup
+  int t_fastest;   // 1: lanes run over t first
+  int tstride;     // t_fastest: row pitch (>= tile)
+  int lstride;     // !t_fastest: line pitch (>= n + n/16)
+};
+
+NK_HD int nk_lds_addr(const NkTile& tl, int pos, int t) {
+  return tl.t_fastest ? pos * tl.tstride + t : t * tl.lstride + pos + (pos >> 4);
+}
+
+template <typename T, int R>
+struct Butterfly;
+
+template <typename T>
+struct Butterfly<T, 2> {
+  static NK_HD void run(C2<T>* v) {
+    C2<T> a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+  }
+};
+
+template <typename T>
+struct Butterfly<T, 4> {
+  static NK_HD void run(C2<T>* v) {
+    C2<T> a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]);
+    C2<T> b0 = cadd(v[1], v[3]), b1 = cmul_mi(csub(v[1], v[3]));
+    v[0] = cadd(a0, b0);
+    v[2] = csub(a0, b0);
+    v[1] = cadd(a1, b1);
+    v[3] = csub(a1, b1);
+  }
+};
+
+template <typename T>
+struct Butterfly<T, 8> {
+  static NK_HD void run(C2<T>* v) {
+    const T h = (T)0.70710678118654752440;
+    // layer 1 (pairs q, q+4)
+    C2<T> a[8];
+    for (int q = 0; q < 4; ++q) {
+      a[q] = cadd(v[q], v[q + 4]);
+      a[q + 4] = csub(v[q], v[q + 4]);
+    }
+    // twiddle the odd half by w8^q
+    a[5] = C2<T>{(a[5].x + a[5].y) * h, (a[5].y - a[5].x) * h};
+    a[6] = cmul_mi(a[6]);
+    a[7] = C2<T>{(a[7].y - a[7].x) * h, -(a[7].x + a[7].y) * h};
+    // two radix-4 butterflies on (a0..a3) -> even outputs, (a4..a7) -> odd outputs
+    C2<T> e[4] = {a[0], a[1], a[2], a[3]};
+    C2<T> o[4] = {a[4], a[5], a[6], a[7]};
+    Butterfly<T, 4>::run(e);
+    Butterfly<T, 4>::run(o);
+    for (int q = 0; q < 4; ++q) {
+      v[2 * q] = e[q];
+      v[2 * q + 1] = o[q];
+    }
+  }
+};
+
+// one in-place DIF stage of radix R on sub-blocks of length L for all `tile` lines in LDS
+template <typename T, int R>
+NK_HD void nk_dif_stage(C2<T>* lds, int tid, int nthr, const NkLinePlan& lp, const NkTile& tl, int L,
+                        const C2<T>* __restrict__ tw) {
+  const int nbf = lp.n / R;  // butterflies per line
+  const int Lr = L / R;
+  const int total = nbf * tl.tile;
+  const int twstep = lp.n / L;
+  for (int idx = tid; idx < total; idx += nthr) {
+    int t, bf;
+    if (tl.t_fastest) {
+      t = idx % tl.tile;
+      bf = idx / tl.tile;
+    } else {
+      bf = idx % nbf;
+      t = idx / nbf;
+    }
+    const int j = bf & (Lr - 1);
+    const int base = (bf / Lr) * L + j;
+    C2<T> v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = lds[nk_lds_addr(tl, base + r * Lr, t)];
+    Butterfly<T, R>::run(v);
+    if (Lr > 1) {
+      const C2<T> w1 = tw[j * twstep];
+      C2<T> w = w1;
+#pragma unroll
+      for (int r = 1; r < R; ++r) {
+        v[r] = cmul(v[r], w);
+        if (r + 1 < R) w = cmul(w, w1);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) lds[nk_lds_addr(tl, base + r * Lr, t)] = v[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused prologue / epilogue descriptors (plain pointers: this struct crosses the C ABI)
+// ---------------------------------------------------------------------------------------------
+// descriptor + enums live in the public C header (the struct crosses the C ABI)
+typedef nk_fuse NkFuse;
+
+template <typename T>
+NK_HD T nk_prologue(const NkFuse& f, int64_t i) {
+  const T* in = (const T*)f.in;
+  switch (f.pro) {
+    case NK_PRO_AMP:
+      return (T)(f.amp[f.pidx[i]] * (double)in[i]);
+    case NK_PRO_AMP_JVP: {
+      const int32_t p = f.pidx[i];
+      return (T)(f.amp[p] * (double)in[i] + f.damp[p] * (double)((const T*)f.in2)[i]);
+    }
+    case NK_PRO_MUL:
+      return in[i] * ((const T*)f.in2)[i];
+    default:
+      return in[i];
+  }
+}
+
+NK_HD void nk_nonlin(int kind, double s, double& g, double& gp) {
+  if (kind == NK_NL_EXP) {
+    g = gp = exp(s);
+  } else if (kind == NK_NL_SIGMOID) {  // NIFTy's sigmoid = 0.5 + 0.5 tanh(s)
+    const double th = tanh(s);
+    g = 0.5 + 0.5 * th;
+    gp = 0.5 - 0.5 * th * th;
+  } else {
+    g = s;
+    gp = 1.0;
+  }
+}
+
+// single-output epilogue; `acc` collects the per-thread energy contribution
+template <typename T>
+NK_HD void nk_epilogue(const NkFuse& f, int64_t o, T v, double& acc) {
+  T* out = (T*)f.out;
+  switch (f.epi) {
+    case NK_EPI_MUL: {
+      double r = (double)v * f.scale * f.mul_scalar;
+      if (f.mul) r *= (double)((const T*)f.mul)[o];
+      out[o] = (T)r;
+    } break;
+    case NK_EPI_VJP: {
+      const double t = (double)v * f.scale;
+      const int32_t p = f.pidx[o];
+      double r = f.amp[p] * t;
+      if (f.addend) r += (double)((const T*)f.addend)[o];
+      out[o] = (T)r;
+      NK_ATOMIC_ADD(f.abar + p, (double)((const T*)f.xi)[o] * t);
+    } break;
+    case NK_EPI_LIKELIHOOD: {
+      const double s = (double)v * f.scale + f.offset;
+      double g, gp;
+      nk_nonlin(f.nonlin, s, g, gp);
+      double gs, w;
+      if (f.lh_kind == NK_LH_GAUSS) {
+        const double ic = f.icov ? (double)((const T*)f.icov)[o] : f.icov_scalar;
+        const double r = g - (double)((const T*)f.data)[o];
+        acc += 0.5 * ic * r * r;
+        gs = gp * ic * r;
+        w = gp * gp * ic;
+      } else {
+        const double d = (double)((const int64_t*)f.data)[o];
+        acc += g - d * log(g);
+        gs = gp * (1.0 - d / g);
+        w = gp * gp / g;
+      }
+      out[o] = (T)gs;
+      if (f.out2) ((T*)f.out2)[o] = (T)w;
+    } break;
+    case NK_EPI_NONLIN: {
+      const double s = (double)v * f.scale + f.offset;
+      double g, gp;
+      nk_nonlin(f.nonlin, s, g, gp);
+      out[o] = (T)g;
+      if (f.out2) ((T*)f.out2)[o] = (T)gp;
+    } break;
+    default:
+      out[o] = (T)((double)v * f.scale + f.offset);
+  }
+}
+
+// paired epilogue for the two mirror outputs (o1 = k, o2 = -k) of one Fourier coefficient; the two
+// points share their power bin, so the VJP scatter needs a single atomic.
+template <typename T>
+NK_HD void nk_epilogue_pair(const NkFuse& f, int64_t o1, T v1, int64_t o2, T v2, double& acc) {
+  if (f.epi == NK_EPI_VJP) {
+    T* out = (T*)f.out;
+    const double t1 = (double)v1 * f.scale, t2 = (double)v2 * f.scale;
+    const int32_t p = f.pidx[o1];
+    const double a = f.amp[p];
+    double r1 = a * t1, r2 = a * t2;
+    if (f.addend) {
+      r1 += (double)((const T*)f.addend)[o1];
+      r2 += (double)((const T*)f.addend)[o2];
+    }
+    out[o1] = (T)r1;
+    out[o2] = (T)r2;
+    const T* xi = (const T*)f.xi;
+    NK_ATOMIC_ADD(f.abar + p, (double)xi[o1] * t1 + (double)xi[o2] * t2);
+  } else {
+    nk_epilogue<T>(f, o1, v1, acc);
+    nk_epilogue<T>(f, o2, v2, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// transform geometry shared by the pass kernels
+// ---------------------------------------------------------------------------------------------
+struct NkGeom {
+  int ndim;          // 1, 2 or 3 transformed axes
+  int batch;         // leading batch count
+  int na;            // length of the FIRST transformed axis  (pass C; 1 if ndim == 1)
+  int nm;            // length of the MIDDLE transformed axis (pass B; 1 if ndim < 3)
+  int nl;            // length of the LAST (contiguous) transformed axis (pass A), nl = 2*h
+  int h;             // complex length of the packed half spectrum along the last axis
+  int sign;          // +1: Re F + Im F (non-canonical, NIFTy default)   -1: Re F - Im F
+};

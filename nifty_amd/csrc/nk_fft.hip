@@ -1,0 +1,430 @@
+// nk_fft.hip -- gfx950 kernels + C ABI for the genuine N-D Hartley transform and the c2c FFT.
+// See nk_fft_phases.h for the algorithm; nk_core.h for the LDS line FFT and fused prologue/epilogue.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "nk_plan.h"
+#include "nk_util.h"
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void nk_run_stages(C2<T>* lds, int tid, int nthr, const NkLinePlan& lp, const NkTile& tl,
+                                              const C2<T>* __restrict__ tw) {
+  int L = lp.n;
+  for (int s = 0; s < lp.nstage; ++s) {
+    const int R = lp.radix[s];
+    if (R == 8)
+      nk_dif_stage<T, 8>(lds, tid, nthr, lp, tl, L, tw);
+    else if (R == 4)
+      nk_dif_stage<T, 4>(lds, tid, nthr, lp, tl, L, tw);
+    else
+      nk_dif_stage<T, 2>(lds, tid, nthr, lp, tl, L, tw);
+    L /= R;
+    __syncthreads();
+  }
+}
+
+// block-wide fp64 sum of `acc`, one atomic per workgroup (only when the epilogue produces an energy)
+__device__ __forceinline__ void nk_flush_energy(const NkFuse& f, double acc, void* lds_raw) {
+  if (f.epi != NK_EPI_LIKELIHOOD || f.value == nullptr) return;
+  __syncthreads();  // LDS tile is dead from here on
+  double* red = (double*)lds_raw;
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) s += red[w];
+    atomicAdd(f.value, s);
+  }
+}
+
+template <typename T>
+__global__ void k_passA(NkPassA p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr,
+                        C2<T>* __restrict__ work) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  C2<T>* lds = (C2<T>*)smem;
+  nk_passA_load<T>(p, f, blockIdx.x, threadIdx.x, blockDim.x, lds);
+  __syncthreads();
+  nk_run_stages<T>(lds, threadIdx.x, blockDim.x, p.lp, p.tl, tw);
+  nk_passA_store<T>(p, blockIdx.x, threadIdx.x, blockDim.x, lds, twr, work);
+}
+
+template <typename T>
+__global__ void k_pass1d(NkPassA p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  C2<T>* lds = (C2<T>*)smem;
+  nk_passA_load<T>(p, f, blockIdx.x, threadIdx.x, blockDim.x, lds);
+  __syncthreads();
+  nk_run_stages<T>(lds, threadIdx.x, blockDim.x, p.lp, p.tl, tw);
+  double acc = 0.0;
+  nk_pass1d_store<T>(p, f, blockIdx.x, threadIdx.x, blockDim.x, lds, twr, acc);
+  nk_flush_energy(f, acc, smem);
+}
+
+template <typename T>
+__global__ void k_passB(NkPassS p, const C2<T>* __restrict__ tw, C2<T>* __restrict__ work) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  C2<T>* lds = (C2<T>*)smem;
+  nk_passS_load<T>(p, blockIdx.x, threadIdx.x, blockDim.x, lds, work);
+  __syncthreads();
+  nk_run_stages<T>(lds, threadIdx.x, blockDim.x, p.lp, p.tl, tw);
+  nk_passB_store<T>(p, blockIdx.x, threadIdx.x, blockDim.x, lds, work);
+}
+
+template <typename T>
+__global__ void k_passC(NkPassS p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work,
+                        C2<T>* __restrict__ scratch) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  C2<T>* lds = (C2<T>*)smem;
+  nk_passS_load<T>(p, blockIdx.x, threadIdx.x, blockDim.x, lds, work);
+  __syncthreads();
+  nk_run_stages<T>(lds, threadIdx.x, blockDim.x, p.lp, p.tl, tw);
+  double acc = 0.0;
+  nk_passC_store<T>(p, f, blockIdx.x, threadIdx.x, blockDim.x, lds, scratch, acc);
+  nk_flush_energy(f, acc, smem);
+}
+
+template <typename T>
+__global__ void k_passD(NkGeom g, NkFuse f, const C2<T>* __restrict__ scratch, int64_t total) {
+  __shared__ double red[16];
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = 0.0;
+  if (gid < total) nk_passD<T>(g, f, gid, scratch, acc);
+  nk_flush_energy(f, acc, red);
+}
+
+// ---- c2c passes -----------------------------------------------------------------------------------
+// contiguous-axis c2c pass: lines of n complex, `swap` exchanges re/im on load and store (inverse
+// transform through the forward kernel), result scaled.
+struct NkPassCC {
+  NkLinePlan lp;
+  NkTile tl;
+  int64_t nlines;
+  int swap;
+  double scale;
+};
+
+template <typename T>
+__global__ void k_c2c_contig(NkPassCC p, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ in,
+                             C2<T>* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  C2<T>* lds = (C2<T>*)smem;
+  const int n = p.lp.n, tile = p.tl.tile;
+  const int64_t line0 = (int64_t)blockIdx.x * tile;
+  for (int idx = threadIdx.x; idx < tile * n; idx += blockDim.x) {
+    const int j = idx % n, t = idx / n;
+    C2<T> z{(T)0, (T)0};
+    if (line0 + t < p.nlines) z = in[(line0 + t) * n + j];
+    if (p.swap) z = C2<T>{z.y, z.x};
+    lds[nk_lds_addr(p.tl, j, t)] = z;
+  }
+  __syncthreads();
+  nk_run_stages<T>(lds, threadIdx.x, blockDim.x, p.lp, p.tl, tw);
+  const T sc = (T)p.scale;
+  for (int idx = threadIdx.x; idx < tile * n; idx += blockDim.x) {
+    const int k = idx % n, t = idx / n;
+    if (line0 + t >= p.nlines) continue;
+    C2<T> z = lds[nk_lds_addr(p.tl, nk_digit_reverse(p.lp, k), t)];
+    if (p.swap) z = C2<T>{z.y, z.x};
+    out[(line0 + t) * n + k] = C2<T>{z.x * sc, z.y * sc};
+  }
+}
+
+// strided c2c pass in place on `data` viewed as [outer][n][inner]
+template <typename T>
+__global__ void k_c2c_strided(NkPassS p, int swap, const C2<T>* __restrict__ tw, C2<T>* __restrict__ data) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  C2<T>* lds = (C2<T>*)smem;
+  const int n = p.lp.n, tile = p.tl.tile;
+  const int64_t o = blockIdx.x / p.tiles_per_slab;
+  const int64_t c0 = (blockIdx.x % p.tiles_per_slab) * (int64_t)tile;
+  C2<T>* base = data + o * n * p.inner + c0;
+  for (int idx = threadIdx.x; idx < tile * n; idx += blockDim.x) {
+    const int t = idx % tile, j = idx / tile;
+    C2<T> z = base[(int64_t)j * p.inner + t];
+    if (swap) z = C2<T>{z.y, z.x};
+    lds[nk_lds_addr(p.tl, j, t)] = z;
+  }
+  __syncthreads();
+  nk_run_stages<T>(lds, threadIdx.x, blockDim.x, p.lp, p.tl, tw);
+  for (int idx = threadIdx.x; idx < tile * n; idx += blockDim.x) {
+    const int t = idx % tile, k = idx / tile;
+    C2<T> z = lds[nk_lds_addr(p.tl, nk_digit_reverse(p.lp, k), t)];
+    if (swap) z = C2<T>{z.y, z.x};
+    base[(int64_t)k * p.inner + t] = z;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan object
+// ------------------------------------------------------------------------------------------------
+struct nk_plan {
+  NkHostPlan hp;
+  int64_t shape[3];
+  int ndim;
+  int64_t batch;
+  void* d_tw_a = nullptr;   // tw (h) for pass A
+  void* d_twr_a = nullptr;  // untangle twiddles
+  void* d_tw_b = nullptr;
+  void* d_tw_c = nullptr;
+  // c2c: full-length contiguous-axis plan
+  NkPassCC cc{};
+  int threads_cc = 256;
+  size_t lds_cc = 0;
+  void* d_tw_cc = nullptr;
+  NkPassS c2c_mid{}, c2c_first{};
+  int threads_cm = 256, threads_cf = 256;
+  size_t lds_cm = 0, lds_cf = 0;
+};
+
+static int nk_upload_twiddle(void** dptr, const std::vector<double>& tw, int dtype) {
+  const size_t n = tw.size();
+  if (n == 0) {
+    *dptr = nullptr;
+    return NK_OK;
+  }
+  hipError_t e;
+  if (dtype == NK_F64) {
+    e = hipMalloc(dptr, n * sizeof(double));
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipMalloc(twiddle)");
+    e = hipMemcpy(*dptr, tw.data(), n * sizeof(double), hipMemcpyHostToDevice);
+  } else {
+    std::vector<float> f(n);
+    for (size_t i = 0; i < n; ++i) f[i] = (float)tw[i];
+    e = hipMalloc(dptr, n * sizeof(float));
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipMalloc(twiddle)");
+    e = hipMemcpy(*dptr, f.data(), n * sizeof(float), hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) return nk_set_hip_error(e, "hipMemcpy(twiddle)");
+  return NK_OK;
+}
+
+template <typename K>
+static int nk_allow_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(max dynamic LDS)");
+  }
+  return NK_OK;
+}
+
+extern "C" int nk_plan_create(nk_plan** out, int ndim, const int64_t* shape, int dtype, int64_t batch) {
+  if (!out || !shape) return nk_set_error(NK_ERR_INVALID, "nk_plan_create: null argument");
+  nk_plan* P = new (std::nothrow) nk_plan();
+  if (!P) return nk_set_error(NK_ERR_NOMEM, "nk_plan_create: out of host memory");
+  const char* msg = "";
+  int rc = nk_host_plan_init(P->hp, ndim, shape, dtype, batch, &msg);
+  if (rc != NK_OK) {
+    delete P;
+    return nk_set_error(rc, msg);
+  }
+  P->ndim = ndim;
+  P->batch = batch;
+  for (int d = 0; d < 3; ++d) P->shape[d] = d < ndim ? shape[d] : 1;
+  NkHostPlan& hp = P->hp;
+  rc = nk_upload_twiddle(&P->d_tw_a, hp.tw_a, dtype);
+  if (rc == NK_OK) rc = nk_upload_twiddle(&P->d_twr_a, hp.twr_a, dtype);
+  if (rc == NK_OK && ndim == 3) rc = nk_upload_twiddle(&P->d_tw_b, hp.tw_b, dtype);
+  if (rc == NK_OK && ndim >= 2) rc = nk_upload_twiddle(&P->d_tw_c, hp.tw_c, dtype);
+  // c2c plan pieces: contiguous last axis of full length nl, strided middle/first axes with inner = nl
+  if (rc == NK_OK) {
+    const NkGeom& g = hp.g;
+    const size_t cs = hp.csize;
+    if ((size_t)(g.nl + g.nl / 16 + 1) * cs > 144 * 1024) {
+      P->cc.lp.n = 0;  // c2c unsupported for this length (Hartley still fine)
+    } else {
+      P->cc.lp = nk_make_line_plan(g.nl);
+      const int lstride = g.nl + g.nl / 16 + 1;
+      const size_t line_bytes = (size_t)lstride * cs;
+      int64_t tile = (int64_t)(32 * 1024 / line_bytes);
+      const int64_t want = (2048 + g.nl - 1) / g.nl;
+      if (tile > want) tile = want;
+      if (tile < 1) tile = 1;
+      P->cc.nlines = batch * g.na * g.nm;
+      if (tile > P->cc.nlines) tile = P->cc.nlines;
+      P->cc.tl.tile = (int)tile;
+      P->cc.tl.t_fastest = 0;
+      P->cc.tl.lstride = lstride;
+      P->lds_cc = (size_t)tile * line_bytes;
+      P->threads_cc = nk_round_threads(tile * g.nl / 4);
+      std::vector<double> tw;
+      nk_fill_twiddle(tw, g.nl, g.nl);
+      rc = nk_upload_twiddle(&P->d_tw_cc, tw, dtype);
+      auto setup = [&](NkPassS& ps, int n, int64_t outer, int64_t inner, int& threads, size_t& lds) {
+        ps.g = g;
+        ps.lp = nk_make_line_plan(n);
+        ps.outer = outer;
+        ps.inner = inner;
+        const int T = nk_pick_strided_tile(n, inner, cs, "NK_TILE_C2C");
+        ps.tl.tile = T;
+        ps.tl.t_fastest = 1;
+        ps.tl.tstride = T;
+        ps.tiles_per_slab = (int)(inner / T);
+        lds = (size_t)n * T * cs;
+        threads = nk_round_threads((int64_t)n * T / 4);
+      };
+      if (ndim == 3) setup(P->c2c_mid, g.nm, batch * g.na, g.nl, P->threads_cm, P->lds_cm);
+      if (ndim >= 2) setup(P->c2c_first, g.na, batch, (int64_t)g.nm * g.nl, P->threads_cf, P->lds_cf);
+    }
+  }
+  // opt in to > 64 KiB dynamic LDS where the tiles need it
+  if (rc == NK_OK) {
+    if (dtype == NK_F32) {
+      rc = nk_allow_lds(k_passA<float>, hp.lds_a);
+      if (rc == NK_OK) rc = nk_allow_lds(k_pass1d<float>, hp.lds_a);
+      if (rc == NK_OK) rc = nk_allow_lds(k_passB<float>, hp.lds_b);
+      if (rc == NK_OK) rc = nk_allow_lds(k_passC<float>, hp.lds_c);
+      if (rc == NK_OK) rc = nk_allow_lds(k_c2c_contig<float>, P->lds_cc);
+      if (rc == NK_OK) rc = nk_allow_lds(k_c2c_strided<float>, P->lds_cm > P->lds_cf ? P->lds_cm : P->lds_cf);
+    } else {
+      rc = nk_allow_lds(k_passA<double>, hp.lds_a);
+      if (rc == NK_OK) rc = nk_allow_lds(k_pass1d<double>, hp.lds_a);
+      if (rc == NK_OK) rc = nk_allow_lds(k_passB<double>, hp.lds_b);
+      if (rc == NK_OK) rc = nk_allow_lds(k_passC<double>, hp.lds_c);
+      if (rc == NK_OK) rc = nk_allow_lds(k_c2c_contig<double>, P->lds_cc);
+      if (rc == NK_OK) rc = nk_allow_lds(k_c2c_strided<double>, P->lds_cm > P->lds_cf ? P->lds_cm : P->lds_cf);
+    }
+  }
+  if (rc != NK_OK) {
+    nk_plan_destroy(P);
+    return rc;
+  }
+  *out = P;
+  return NK_OK;
+}
+
+extern "C" int nk_plan_destroy(nk_plan* P) {
+  if (!P) return NK_OK;
+  void* ptrs[] = {P->d_tw_a, P->d_twr_a, P->d_tw_b, P->d_tw_c, P->d_tw_cc};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete P;
+  return NK_OK;
+}
+
+extern "C" size_t nk_plan_workspace_bytes(const nk_plan* P) {
+  if (!P) return 0;
+  // [work | scratch], scratch aligned to 256 B
+  size_t w = (P->hp.work_bytes + 255) / 256 * 256;
+  return w + P->hp.scratch_bytes + 256;
+}
+
+// ------------------------------------------------------------------------------------------------
+// execution
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, void* workspace, hipStream_t st) {
+  const NkHostPlan& hp = P->hp;
+  NkPassA pa = hp.pa;
+  pa.g.sign = convention == NK_HARTLEY_CANONICAL ? -1 : 1;
+  const C2<T>* tw_a = (const C2<T>*)P->d_tw_a;
+  const C2<T>* twr = (const C2<T>*)P->d_twr_a;
+  const int64_t blocks_a = (pa.nlines + pa.tl.tile - 1) / pa.tl.tile;
+  if (blocks_a > 0x7fffffffLL) return nk_set_error(NK_ERR_UNSUPPORTED, "too many lines for one launch");
+  if (hp.g.ndim == 1) {
+    hipLaunchKernelGGL(k_pass1d<T>, dim3((unsigned)blocks_a), dim3(hp.threads_a), hp.lds_a, st, pa, f, tw_a, twr);
+    return nk_check_launch("k_pass1d");
+  }
+  if (!workspace) return nk_set_error(NK_ERR_INVALID, "nk_hartley: workspace required for ndim >= 2");
+  C2<T>* work = (C2<T>*)workspace;
+  C2<T>* scratch = (C2<T>*)((char*)workspace + (hp.work_bytes + 255) / 256 * 256);
+  hipLaunchKernelGGL(k_passA<T>, dim3((unsigned)blocks_a), dim3(hp.threads_a), hp.lds_a, st, pa, f, tw_a, twr, work);
+  int rc = nk_check_launch("k_passA");
+  if (rc != NK_OK) return rc;
+  if (hp.g.ndim == 3) {
+    const int64_t blocks_b = hp.pb.outer * hp.pb.tiles_per_slab;
+    hipLaunchKernelGGL(k_passB<T>, dim3((unsigned)blocks_b), dim3(hp.threads_b), hp.lds_b, st, hp.pb,
+                       (const C2<T>*)P->d_tw_b, work);
+    rc = nk_check_launch("k_passB");
+    if (rc != NK_OK) return rc;
+  }
+  NkPassS pc = hp.pc;
+  pc.g.sign = pa.g.sign;
+  const int64_t blocks_c = pc.outer * pc.tiles_per_slab;
+  hipLaunchKernelGGL(k_passC<T>, dim3((unsigned)blocks_c), dim3(hp.threads_c), hp.lds_c, st, pc, f,
+                     (const C2<T>*)P->d_tw_c, (const C2<T>*)work, scratch);
+  rc = nk_check_launch("k_passC");
+  if (rc != NK_OK) return rc;
+  const int64_t total_d = (int64_t)hp.g.batch * hp.g.nm * hp.g.na;
+  hipLaunchKernelGGL(k_passD<T>, dim3((unsigned)((total_d + 255) / 256)), dim3(256), 0, st, pc.g, f,
+                     (const C2<T>*)scratch, total_d);
+  return nk_check_launch("k_passD");
+}
+
+extern "C" int nk_hartley_fused(const nk_plan* P, const nk_fuse* fuse, int convention, void* workspace,
+                                void* stream) {
+  if (!P || !fuse) return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: null argument");
+  if (!fuse->in || !fuse->out) return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: in/out must be set");
+  if (convention != NK_HARTLEY_NON_CANONICAL && convention != NK_HARTLEY_CANONICAL)
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: unknown hartley convention");
+  if ((fuse->pro == NK_PRO_AMP || fuse->pro == NK_PRO_AMP_JVP) && (!fuse->pidx || !fuse->amp))
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: AMP prologue needs pidx and amp");
+  if (fuse->pro == NK_PRO_AMP_JVP && (!fuse->damp || !fuse->in2))
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: AMP_JVP prologue needs damp and in2");
+  if (fuse->pro == NK_PRO_MUL && !fuse->in2)
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: MUL prologue needs in2");
+  if (fuse->epi == NK_EPI_VJP && (!fuse->pidx || !fuse->amp || !fuse->xi || !fuse->abar))
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: VJP epilogue needs pidx, amp, xi and abar");
+  if (fuse->epi == NK_EPI_LIKELIHOOD && (!fuse->data || !fuse->value))
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: LIKELIHOOD epilogue needs data and value");
+  hipStream_t st = (hipStream_t)stream;
+  if (P->hp.dtype == NK_F32) return nk_run_hartley<float>(P, *fuse, convention, workspace, st);
+  return nk_run_hartley<double>(P, *fuse, convention, workspace, st);
+}
+
+extern "C" int nk_hartley(const nk_plan* P, const void* in, void* out, double scale, int convention, void* workspace,
+                          void* stream) {
+  nk_fuse f;
+  memset(&f, 0, sizeof(f));
+  f.pro = NK_PRO_PLAIN;
+  f.in = in;
+  f.epi = NK_EPI_AFFINE;
+  f.out = out;
+  f.scale = scale;
+  f.offset = 0.0;
+  return nk_hartley_fused(P, &f, convention, workspace, stream);
+}
+
+template <typename T>
+static int nk_run_c2c(const nk_plan* P, const void* in, void* out, int inverse, double scale, hipStream_t st) {
+  if (P->cc.lp.n == 0) return nk_set_error(NK_ERR_UNSUPPORTED, "nk_fftn: last axis too long for the c2c kernel");
+  NkPassCC cc = P->cc;
+  cc.swap = inverse ? 1 : 0;
+  cc.scale = scale;
+  const int64_t blocks = (cc.nlines + cc.tl.tile - 1) / cc.tl.tile;
+  hipLaunchKernelGGL(k_c2c_contig<T>, dim3((unsigned)blocks), dim3(P->threads_cc), P->lds_cc, st, cc,
+                     (const C2<T>*)P->d_tw_cc, (const C2<T>*)in, (C2<T>*)out);
+  int rc = nk_check_launch("k_c2c_contig");
+  if (rc != NK_OK) return rc;
+  if (P->ndim == 3) {
+    const NkPassS& ps = P->c2c_mid;
+    hipLaunchKernelGGL(k_c2c_strided<T>, dim3((unsigned)(ps.outer * ps.tiles_per_slab)), dim3(P->threads_cm),
+                       P->lds_cm, st, ps, cc.swap, (const C2<T>*)P->d_tw_b, (C2<T>*)out);
+    rc = nk_check_launch("k_c2c_strided(mid)");
+    if (rc != NK_OK) return rc;
+  }
+  if (P->ndim >= 2) {
+    const NkPassS& ps = P->c2c_first;
+    hipLaunchKernelGGL(k_c2c_strided<T>, dim3((unsigned)(ps.outer * ps.tiles_per_slab)), dim3(P->threads_cf),
+                       P->lds_cf, st, ps, cc.swap, (const C2<T>*)P->d_tw_c, (C2<T>*)out);
+    rc = nk_check_launch("k_c2c_strided(first)");
+  }
+  return rc;
+}
+
+extern "C" int nk_fftn(const nk_plan* P, const void* in, void* out, int inverse, double scale, void* workspace,
+                       void* stream) {
+  (void)workspace;
+  if (!P || !in || !out) return nk_set_error(NK_ERR_INVALID, "nk_fftn: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (P->hp.dtype == NK_F32) return nk_run_c2c<float>(P, in, out, inverse, scale, st);
+  return nk_run_c2c<double>(P, in, out, inverse, scale, st);
+}

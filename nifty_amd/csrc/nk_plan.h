@@ -1,0 +1,185 @@
+// nk_plan.h -- host-side planning shared by the HIP library and the test-only host emulation:
+// radix decomposition, LDS tile selection for the three pass kinds, twiddle tables.
+#pragma once
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "nk_fft_phases.h"
+
+static inline bool nk_is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static inline NkLinePlan nk_make_line_plan(int n) {
+  NkLinePlan lp{};
+  lp.n = n;
+  lp.nstage = 0;
+  int rem = n;
+  while (rem > 1) {
+    int R = (rem % 8 == 0) ? 8 : (rem % 4 == 0) ? 4 : 2;
+    // avoid a trailing radix-2 after radix-8 stages when a 4x4 split is possible (8*2 -> 4*4)
+    if (R == 8 && rem == 16) R = 4;
+    lp.radix[lp.nstage++] = R;
+    rem /= R;
+  }
+  return lp;
+}
+
+static inline int nk_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+struct NkHostPlan {
+  NkGeom g{};
+  int dtype = 1;
+  size_t csize = 16;  // bytes per complex element
+  // pass A (last axis)
+  NkPassA pa{};
+  int threads_a = 256;
+  size_t lds_a = 0;
+  // pass B (middle axis, 3-D only) and pass C (first axis, ndim >= 2)
+  NkPassS pb{}, pc{};
+  int threads_b = 256, threads_c = 256;
+  size_t lds_b = 0, lds_c = 0;
+  // twiddles (as double pairs; converted to the plan dtype when uploaded)
+  std::vector<double> tw_a, twr_a, tw_b, tw_c;
+  size_t work_bytes = 0, scratch_bytes = 0;
+};
+
+static inline void nk_fill_twiddle(std::vector<double>& tw, int n, int denom) {
+  // tw[k] = exp(-2 pi i k / denom), k = 0..n-1
+  tw.resize(2 * (size_t)(n > 0 ? n : 1));
+  const long double w = -2.0L * 3.14159265358979323846264338327950288L / (long double)denom;
+  for (int k = 0; k < n; ++k) {
+    tw[2 * k] = (double)cosl(w * k);
+    tw[2 * k + 1] = (double)sinl(w * k);
+  }
+  if (n <= 0) tw[0] = 1.0, tw[1] = 0.0;
+}
+
+static inline int nk_round_threads(int64_t work) {
+  int64_t t = (work + 63) / 64 * 64;
+  if (t < 64) t = 64;
+  if (t > 1024) t = 1024;
+  return (int)t;
+}
+
+// strided tile: largest power-of-two T <= inner with n*T*csize <= budget and T*csize <= 256 B
+static inline int nk_pick_strided_tile(int n, int64_t inner, size_t csize, const char* env) {
+  int forced = nk_env_int(env, 0);
+  size_t budget = 64 * 1024;
+  int T = 1;
+  while ((int64_t)T * 2 <= inner && (size_t)n * (T * 2) * csize <= budget && (size_t)(T * 2) * csize <= 256) T *= 2;
+  if ((size_t)T * csize < 64) {  // rows shorter than 64 B: allow one workgroup per CU
+    budget = 128 * 1024;
+    while ((int64_t)T * 2 <= inner && (size_t)n * (T * 2) * csize <= budget && (size_t)(T * 2) * csize <= 256) T *= 2;
+  }
+  if (forced > 0) {
+    T = 1;
+    while (T * 2 <= forced && (int64_t)T * 2 <= inner && (size_t)n * (T * 2) * csize <= 152 * 1024) T *= 2;
+  }
+  return T;
+}
+
+// returns 0 on success, negative nk_status otherwise; msg receives a static description
+static inline int nk_host_plan_init(NkHostPlan& P, int ndim, const int64_t* shape, int dtype, int64_t batch,
+                                    const char** msg) {
+  *msg = "";
+  if (ndim < 1 || ndim > 3) {
+    *msg = "only 1, 2 or 3 transformed axes are supported";
+    return NK_ERR_UNSUPPORTED;
+  }
+  if (dtype != NK_F32 && dtype != NK_F64) {
+    *msg = "dtype must be NK_F32 or NK_F64";
+    return NK_ERR_INVALID;
+  }
+  if (batch < 1) {
+    *msg = "batch must be >= 1";
+    return NK_ERR_INVALID;
+  }
+  for (int d = 0; d < ndim; ++d) {
+    if (shape[d] < 1) {
+      *msg = "axis lengths must be positive";
+      return NK_ERR_INVALID;
+    }
+    if (!nk_is_pow2(shape[d])) {
+      *msg = "axis lengths must be powers of two (mixed radix is not implemented yet)";
+      return NK_ERR_UNSUPPORTED;
+    }
+  }
+  if (shape[ndim - 1] < 2) {
+    *msg = "last axis must have length >= 2";
+    return NK_ERR_UNSUPPORTED;
+  }
+  P.dtype = dtype;
+  P.csize = dtype == NK_F32 ? 8 : 16;
+  NkGeom& g = P.g;
+  g.ndim = ndim;
+  g.batch = (int)batch;
+  g.nl = (int)shape[ndim - 1];
+  g.h = g.nl / 2;
+  g.na = ndim >= 2 ? (int)shape[0] : 1;
+  g.nm = ndim == 3 ? (int)shape[1] : 1;
+  g.sign = 1;
+  const size_t max_line_bytes = 144 * 1024;
+  if ((size_t)(g.h + g.h / 16 + 1) * P.csize > max_line_bytes || (size_t)g.na * P.csize > max_line_bytes ||
+      (size_t)g.nm * P.csize > max_line_bytes) {
+    *msg = "axis too long for a single-LDS line transform";
+    return NK_ERR_UNSUPPORTED;
+  }
+  const int64_t n_total = batch * g.na * g.nm * g.nl;
+  if (n_total >= ((int64_t)1 << 40)) {
+    *msg = "array too large";
+    return NK_ERR_UNSUPPORTED;
+  }
+  // ---- pass A
+  P.pa.g = g;
+  P.pa.lp = nk_make_line_plan(g.h);
+  P.pa.nlines = batch * g.na * g.nm;
+  {
+    const int lstride = g.h + g.h / 16 + 1;
+    const size_t line_bytes = (size_t)lstride * P.csize;
+    int64_t tile = (int64_t)(32 * 1024 / line_bytes);
+    const int64_t want = (2048 + g.h - 1) / g.h;  // at least ~2048 complex elements per workgroup
+    if (tile > want) tile = want;
+    if (tile < 1) tile = 1;
+    if (tile > P.pa.nlines) tile = P.pa.nlines;
+    int forced = nk_env_int("NK_TILE_A", 0);
+    if (forced > 0 && (size_t)forced * line_bytes <= 152 * 1024) tile = forced;
+    P.pa.tl.tile = (int)tile;
+    P.pa.tl.t_fastest = 0;
+    P.pa.tl.tstride = 0;
+    P.pa.tl.lstride = lstride;
+    P.lds_a = (size_t)tile * line_bytes;
+    P.threads_a = nk_round_threads(tile * g.h / 4);
+    int ft = nk_env_int("NK_THREADS_A", 0);
+    if (ft >= 64) P.threads_a = ft;
+  }
+  nk_fill_twiddle(P.tw_a, g.h, g.h);
+  nk_fill_twiddle(P.twr_a, g.h / 2 + 1, g.nl);
+  // ---- pass B / C
+  auto setup_strided = [&](NkPassS& ps, int n, int64_t outer, int64_t inner, const char* env, int& threads,
+                           size_t& lds, std::vector<double>& tw) {
+    ps.g = g;
+    ps.lp = nk_make_line_plan(n);
+    ps.outer = outer;
+    ps.inner = inner;
+    const int T = nk_pick_strided_tile(n, inner, P.csize, env);
+    ps.tl.tile = T;
+    ps.tl.t_fastest = 1;
+    ps.tl.tstride = T;
+    ps.tl.lstride = 0;
+    ps.tiles_per_slab = (int)(inner / T);
+    lds = (size_t)n * T * P.csize;
+    threads = nk_round_threads((int64_t)n * T / 4);
+    int ft = nk_env_int("NK_THREADS_S", 0);
+    if (ft >= 64) threads = ft;
+    nk_fill_twiddle(tw, n, n);
+  };
+  if (ndim == 3) setup_strided(P.pb, g.nm, batch * g.na, g.h, "NK_TILE_B", P.threads_b, P.lds_b, P.tw_b);
+  if (ndim >= 2)
+    setup_strided(P.pc, g.na, batch, (int64_t)g.nm * g.h, "NK_TILE_C", P.threads_c, P.lds_c, P.tw_c);
+  P.work_bytes = (size_t)(n_total / 2) * P.csize;
+  P.scratch_bytes = ndim >= 2 ? (size_t)batch * g.nm * g.na * P.csize : 0;
+  return NK_OK;
+}

@@ -1,0 +1,461 @@
+// nk_vec.hip -- streaming vector kernels: reductions with wavefront (64-lane) shuffles and fp64
+// accumulation, element-wise algebra, pointwise nonlinearities with derivative, bin gather / scatter,
+// and the fused conjugate-gradient updates whose scalars never leave the device.
+// All kernels are HBM-bound: 16-byte vector loads/stores when the pointers allow, grid-stride loops,
+// at most 256 CUs x 8 workgroups.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "nk_util.h"
+
+static constexpr int NK_VEC_THREADS = 256;
+static constexpr int NK_MAX_BLOCKS = 256 * 8;
+
+static inline int nk_grid(int64_t nvec) {
+  int64_t b = (nvec + NK_VEC_THREADS - 1) / NK_VEC_THREADS;
+  if (b < 1) b = 1;
+  if (b > NK_MAX_BLOCKS) b = NK_MAX_BLOCKS;
+  return (int)b;
+}
+
+template <typename T>
+struct VecOf;
+template <>
+struct VecOf<float> {
+  typedef float4 type;
+  static constexpr int N = 4;
+};
+template <>
+struct VecOf<double> {
+  typedef double2 type;
+  static constexpr int N = 2;
+};
+
+template <typename T>
+__device__ __forceinline__ void nk_vload(const T* p, T (&v)[VecOf<T>::N]) {
+  typename VecOf<T>::type t = *reinterpret_cast<const typename VecOf<T>::type*>(p);
+  const T* q = reinterpret_cast<const T*>(&t);
+#pragma unroll
+  for (int i = 0; i < VecOf<T>::N; ++i) v[i] = q[i];
+}
+template <typename T>
+__device__ __forceinline__ void nk_vstore(T* p, const T (&v)[VecOf<T>::N]) {
+  typename VecOf<T>::type t;
+  T* q = reinterpret_cast<T*>(&t);
+#pragma unroll
+  for (int i = 0; i < VecOf<T>::N; ++i) q[i] = v[i];
+  *reinterpret_cast<typename VecOf<T>::type*>(p) = t;
+}
+
+static inline bool nk_aligned16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// wave64 shuffle reduction + one LDS hop, result valid in thread 0
+__device__ __forceinline__ double nk_block_sum(double v) {
+  __shared__ double red[NK_VEC_THREADS / 64];
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+  return s;
+}
+
+// ---- generic "map with up to 4 inputs, 3 outputs and 3 reductions" skeleton ---------------------------
+// F::apply(const T* in[..] values, T* outs, double* red) is called per element.
+template <typename T, typename F, bool VEC>
+__global__ void __launch_bounds__(NK_VEC_THREADS) k_map(int64_t n, F f) {
+  constexpr int V = VEC ? VecOf<T>::N : 1;
+  double red[F::NRED > 0 ? F::NRED : 1];
+#pragma unroll
+  for (int r = 0; r < (F::NRED > 0 ? F::NRED : 1); ++r) red[r] = 0.0;
+  const int64_t nvec = n / V;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) f.template run<V>(i * V, red);
+  if (VEC) {  // scalar tail
+    const int64_t tail0 = nvec * V;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < n - tail0) f.template run<1>(tail0 + gid, red);
+  }
+  if (F::NRED > 0) {
+#pragma unroll
+    for (int r = 0; r < F::NRED; ++r) {
+      const double s = nk_block_sum(red[r]);
+      if (threadIdx.x == 0) atomicAdd(f.result + r, s);
+    }
+  }
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void nk_ld(const T* p, int64_t i, T (&v)[V]) {
+  if constexpr (V == 1)
+    v[0] = p[i];
+  else
+    nk_vload<T>(p + i, v);
+}
+template <typename T, int V>
+__device__ __forceinline__ void nk_st(T* p, int64_t i, const T (&v)[V]) {
+  if constexpr (V == 1)
+    p[i] = v[0];
+  else
+    nk_vstore<T>(p + i, v);
+}
+
+template <typename T, typename F>
+static int nk_launch_map(int64_t n, const F& f, bool aligned, hipStream_t st, const char* what) {
+  if (n <= 0) return NK_OK;
+  if (aligned) {
+    const int64_t nvec = n / VecOf<T>::N;
+    hipLaunchKernelGGL((k_map<T, F, true>), dim3(nk_grid(nvec > 0 ? nvec : 1)), dim3(NK_VEC_THREADS), 0, st, n, f);
+  } else {
+    hipLaunchKernelGGL((k_map<T, F, false>), dim3(nk_grid(n)), dim3(NK_VEC_THREADS), 0, st, n, f);
+  }
+  return nk_check_launch(what);
+}
+
+// ---- functors ------------------------------------------------------------------------------------
+template <typename T>
+struct FDot {
+  static constexpr int NRED = 1;
+  const T *a, *b;
+  double* result;
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double* red) const {
+    T x[V], y[V];
+    nk_ld<T, V>(a, i, x);
+    nk_ld<T, V>(b, i, y);
+#pragma unroll
+    for (int k = 0; k < V; ++k) red[0] += (double)x[k] * (double)y[k];
+  }
+};
+
+template <typename T>
+struct FSum {
+  static constexpr int NRED = 1;
+  const T* a;
+  double* result;
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double* red) const {
+    T x[V];
+    nk_ld<T, V>(a, i, x);
+#pragma unroll
+    for (int k = 0; k < V; ++k) red[0] += (double)x[k];
+  }
+};
+
+template <typename T>
+struct FBinary {
+  static constexpr int NRED = 0;
+  int op;
+  const T *a, *b;
+  double as, bs;
+  T* out;
+  double* result;
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double*) const {
+    T x[V], y[V], r[V];
+    if (a) nk_ld<T, V>(a, i, x);
+    if (b) nk_ld<T, V>(b, i, y);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const T xv = a ? x[k] : (T)as, yv = b ? y[k] : (T)bs;
+      r[k] = op == NK_OP_ADD ? xv + yv : op == NK_OP_SUB ? xv - yv : op == NK_OP_MUL ? xv * yv : xv / yv;
+    }
+    nk_st<T, V>(out, i, r);
+  }
+};
+
+template <typename T>
+struct FAxpby {
+  static constexpr int NRED = 0;
+  double alpha, beta;
+  const T *x, *y;
+  T* out;
+  double* result;
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double*) const {
+    T a[V], b[V], r[V];
+    nk_ld<T, V>(x, i, a);
+    if (y) nk_ld<T, V>(y, i, b);
+#pragma unroll
+    for (int k = 0; k < V; ++k) r[k] = (T)(alpha * (double)a[k] + (y ? beta * (double)b[k] : 0.0));
+    nk_st<T, V>(out, i, r);
+  }
+};
+
+template <typename T>
+struct FPointwise {
+  static constexpr int NRED = 0;
+  int fn;
+  double param;
+  const T* x;
+  T *fx, *dfx;
+  double* result;
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double*) const {
+    T a[V], f[V], d[V];
+    nk_ld<T, V>(x, i, a);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const double v = (double)a[k];
+      double fv, dv;
+      switch (fn) {
+        case 0: fv = dv = exp(v); break;
+        case 1: fv = log(v); dv = 1.0 / v; break;
+        case 2: fv = sqrt(v); dv = 0.5 / fv; break;
+        case 3: fv = tanh(v); dv = 1.0 - fv * fv; break;
+        case 4: { const double th = tanh(v); fv = 0.5 + 0.5 * th; dv = 0.5 - 0.5 * th * th; } break;
+        case 5: fv = 1.0 / v; dv = -fv * fv; break;
+        case 6: fv = pow(v, param); dv = param * pow(v, param - 1.0); break;
+        case 7: fv = fabs(v); dv = v == 0.0 ? (double)NAN : (v > 0.0 ? 1.0 : -1.0); break;
+        case 8: fv = log1p(v); dv = 1.0 / (1.0 + v); break;
+        default: fv = expm1(v); dv = fv + 1.0; break;
+      }
+      f[k] = (T)fv;
+      d[k] = (T)dv;
+    }
+    if (fx) nk_st<T, V>(fx, i, f);
+    if (dfx) nk_st<T, V>(dfx, i, d);
+  }
+};
+
+template <typename T>
+struct FGather {
+  static constexpr int NRED = 0;
+  const T* table;
+  const int32_t* pidx;
+  T* out;
+  double* result;
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double*) const {
+    T r[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) r[k] = table[pidx[i + k]];
+    nk_st<T, V>(out, i, r);
+  }
+};
+
+template <typename T>
+struct FScatter {
+  static constexpr int NRED = 0;
+  const T* in;
+  const int32_t* pidx;
+  double* bins;
+  double* result;
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double*) const {
+    T a[V];
+    nk_ld<T, V>(in, i, a);
+#pragma unroll
+    for (int k = 0; k < V; ++k) atomicAdd(bins + pidx[i + k], (double)a[k]);
+  }
+};
+
+// CG: scal[1] = d.q
+template <typename T>
+struct FCgCurv {
+  static constexpr int NRED = 1;
+  const T *d, *q;
+  double* result;  // = scal + 1
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double* red) const {
+    T a[V], b[V];
+    nk_ld<T, V>(d, i, a);
+    nk_ld<T, V>(q, i, b);
+#pragma unroll
+    for (int k = 0; k < V; ++k) red[0] += (double)a[k] * (double)b[k];
+  }
+};
+
+// CG: x -= alpha d; r -= alpha q; reductions r.r, x.r, x.b -> scal[2..4]
+template <typename T>
+struct FCgUpdate {
+  static constexpr int NRED = 3;
+  T *x, *r;
+  const T *d, *q, *b;
+  const double* scal;
+  double* result;  // = scal + 2
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double* red) const {
+    const double alpha = scal[0] / scal[1];
+    T xv[V], rv[V], dv[V], qv[V], bv[V];
+    nk_ld<T, V>(x, i, xv);
+    nk_ld<T, V>(r, i, rv);
+    nk_ld<T, V>(d, i, dv);
+    nk_ld<T, V>(q, i, qv);
+    if (b) nk_ld<T, V>(b, i, bv);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const T xn = (T)((double)xv[k] - alpha * (double)dv[k]);
+      const T rn = (T)((double)rv[k] - alpha * (double)qv[k]);
+      xv[k] = xn;
+      rv[k] = rn;
+      red[0] += (double)rn * (double)rn;
+      red[1] += (double)xn * (double)rn;
+      if (b) red[2] += (double)xn * (double)bv[k];
+    }
+    nk_st<T, V>(x, i, xv);
+    nk_st<T, V>(r, i, rv);
+  }
+};
+
+// CG: d = max(0, gamma/gamma_prev) d + r
+template <typename T>
+struct FCgDir {
+  static constexpr int NRED = 0;
+  T* d;
+  const T* r;
+  const double* scal;
+  double* result;
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double*) const {
+    double beta = scal[2] / scal[0];
+    beta = beta > 0.0 ? beta : 0.0;
+    T dv[V], rv[V];
+    nk_ld<T, V>(d, i, dv);
+    nk_ld<T, V>(r, i, rv);
+#pragma unroll
+    for (int k = 0; k < V; ++k) dv[k] = (T)(beta * (double)dv[k] + (double)rv[k]);
+    nk_st<T, V>(d, i, dv);
+  }
+};
+
+__global__ void k_cg_roll(double* scal) {  // after the direction update: gamma_prev <- gamma
+  scal[5] = scal[0] / scal[1];
+  const double beta = scal[2] / scal[0];
+  scal[6] = beta > 0.0 ? beta : 0.0;
+  scal[0] = scal[2];
+}
+
+// ---- C ABI --------------------------------------------------------------------------------------
+#define NK_DISPATCH_DTYPE(dtype, ...)                                      \
+  if ((dtype) == NK_F32) {                                                  \
+    typedef float T;                                                        \
+    __VA_ARGS__;                                                            \
+  } else if ((dtype) == NK_F64) {                                           \
+    typedef double T;                                                       \
+    __VA_ARGS__;                                                            \
+  } else {                                                                  \
+    return nk_set_error(NK_ERR_INVALID, "dtype must be NK_F32 or NK_F64");  \
+  }
+
+static int nk_zero(double* p, int count, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(p, 0, sizeof(double) * count, st);
+  if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync");
+  return NK_OK;
+}
+
+extern "C" int nk_vdot(int64_t n, const void* a, const void* b, int dtype, double* result, int accumulate,
+                       void* stream) {
+  if (n < 0 || !result || (n > 0 && (!a || !b))) return nk_set_error(NK_ERR_INVALID, "nk_vdot: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    int rc = nk_zero(result, 1, st);
+    if (rc != NK_OK) return rc;
+  }
+  NK_DISPATCH_DTYPE(dtype, {
+    FDot<T> f{(const T*)a, (const T*)b, result};
+    return nk_launch_map<T>(n, f, nk_aligned16(a) && nk_aligned16(b), st, "nk_vdot");
+  })
+}
+
+extern "C" int nk_sum(int64_t n, const void* a, int dtype, double* result, int accumulate, void* stream) {
+  if (n < 0 || !result || (n > 0 && !a)) return nk_set_error(NK_ERR_INVALID, "nk_sum: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    int rc = nk_zero(result, 1, st);
+    if (rc != NK_OK) return rc;
+  }
+  NK_DISPATCH_DTYPE(dtype, {
+    FSum<T> f{(const T*)a, result};
+    return nk_launch_map<T>(n, f, nk_aligned16(a), st, "nk_sum");
+  })
+}
+
+extern "C" int nk_binary(int op, int64_t n, const void* a, double ascalar, const void* b, double bscalar, void* out,
+                         int dtype, void* stream) {
+  if (n < 0 || !out || op < 0 || op > 3 || (!a && !b)) return nk_set_error(NK_ERR_INVALID, "nk_binary: bad argument");
+  NK_DISPATCH_DTYPE(dtype, {
+    FBinary<T> f{op, (const T*)a, (const T*)b, ascalar, bscalar, (T*)out, nullptr};
+    return nk_launch_map<T>(n, f, nk_aligned16(a) && nk_aligned16(b) && nk_aligned16(out), (hipStream_t)stream,
+                            "nk_binary");
+  })
+}
+
+extern "C" int nk_axpby(int64_t n, double alpha, const void* x, double beta, const void* y, void* out, int dtype,
+                        void* stream) {
+  if (n < 0 || !out || !x) return nk_set_error(NK_ERR_INVALID, "nk_axpby: bad argument");
+  NK_DISPATCH_DTYPE(dtype, {
+    FAxpby<T> f{alpha, beta, (const T*)x, (const T*)y, (T*)out, nullptr};
+    return nk_launch_map<T>(n, f, nk_aligned16(x) && nk_aligned16(y) && nk_aligned16(out), (hipStream_t)stream,
+                            "nk_axpby");
+  })
+}
+
+extern "C" int nk_pointwise(int fn, double param, int64_t n, const void* x, void* fx, void* dfx, int dtype,
+                            void* stream) {
+  if (n < 0 || !x || (!fx && !dfx) || fn < 0 || fn > 9) return nk_set_error(NK_ERR_INVALID, "nk_pointwise: bad argument");
+  NK_DISPATCH_DTYPE(dtype, {
+    FPointwise<T> f{fn, param, (const T*)x, (T*)fx, (T*)dfx, nullptr};
+    return nk_launch_map<T>(n, f, nk_aligned16(x) && nk_aligned16(fx) && nk_aligned16(dfx), (hipStream_t)stream,
+                            "nk_pointwise");
+  })
+}
+
+extern "C" int nk_gather(int64_t n, const void* table, const int32_t* pidx, void* out, int dtype, void* stream) {
+  if (n < 0 || !table || !pidx || !out) return nk_set_error(NK_ERR_INVALID, "nk_gather: bad argument");
+  NK_DISPATCH_DTYPE(dtype, {
+    FGather<T> f{(const T*)table, pidx, (T*)out, nullptr};
+    return nk_launch_map<T>(n, f, nk_aligned16(out), (hipStream_t)stream, "nk_gather");
+  })
+}
+
+extern "C" int nk_scatter_add(int64_t n, const void* in, const int32_t* pidx, int64_t nbins, void* bins, int dtype,
+                              void* stream) {
+  if (n < 0 || !in || !pidx || !bins || nbins < 1) return nk_set_error(NK_ERR_INVALID, "nk_scatter_add: bad argument");
+  NK_DISPATCH_DTYPE(dtype, {
+    FScatter<T> f{(const T*)in, pidx, (double*)bins, nullptr};
+    return nk_launch_map<T>(n, f, nk_aligned16(in), (hipStream_t)stream, "nk_scatter_add");
+  })
+}
+
+extern "C" int nk_cg_curv(int64_t n, const void* d, const void* q, int dtype, double* scal, void* stream) {
+  if (n < 0 || !d || !q || !scal) return nk_set_error(NK_ERR_INVALID, "nk_cg_curv: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = nk_zero(scal + 1, 1, st);
+  if (rc != NK_OK) return rc;
+  NK_DISPATCH_DTYPE(dtype, {
+    FCgCurv<T> f{(const T*)d, (const T*)q, scal + 1};
+    return nk_launch_map<T>(n, f, nk_aligned16(d) && nk_aligned16(q), st, "nk_cg_curv");
+  })
+}
+
+extern "C" int nk_cg_update(int64_t n, void* x, void* r, const void* d, const void* q, const void* b, int dtype,
+                            double* scal, void* stream) {
+  if (n < 0 || !x || !r || !d || !q || !scal) return nk_set_error(NK_ERR_INVALID, "nk_cg_update: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = nk_zero(scal + 2, 3, st);
+  if (rc != NK_OK) return rc;
+  NK_DISPATCH_DTYPE(dtype, {
+    FCgUpdate<T> f{(T*)x, (T*)r, (const T*)d, (const T*)q, (const T*)b, scal, scal + 2};
+    return nk_launch_map<T>(
+        n, f, nk_aligned16(x) && nk_aligned16(r) && nk_aligned16(d) && nk_aligned16(q) && nk_aligned16(b), st,
+        "nk_cg_update");
+  })
+}
+
+extern "C" int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, double* scal, void* stream) {
+  if (n < 0 || !d || !r || !scal) return nk_set_error(NK_ERR_INVALID, "nk_cg_direction: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  NK_DISPATCH_DTYPE(dtype, {
+    FCgDir<T> f{(T*)d, (const T*)r, scal, nullptr};
+    rc = nk_launch_map<T>(n, f, nk_aligned16(d) && nk_aligned16(r), st, "nk_cg_direction");
+  })
+  if (rc != NK_OK) return rc;
+  hipLaunchKernelGGL(k_cg_roll, dim3(1), dim3(1), 0, st, scal);
+  return nk_check_launch("k_cg_roll");
+}

@@ -1,0 +1,99 @@
+// TEST-ONLY host emulation of the libniftyk transform kernels (see nk_core.h).  Runs the very same
+// phase functions the GPU kernels run, for tid = 0..nthreads-1 sequentially, on host memory.  Used by
+// tests/test_kernel_emulation.py to validate index math / twiddles / fusion on a CPU-only box.
+// Never linked into the product library and never used as a fallback.
+#define NK_HOST_EMU 1
+#include <cstring>
+#include <vector>
+
+#include "../../nifty_amd/csrc/nk_plan.h"
+
+template <typename T>
+static std::vector<C2<T>> conv_tw(const std::vector<double>& tw) {
+  std::vector<C2<T>> r(tw.size() / 2);
+  for (size_t i = 0; i < r.size(); ++i) r[i] = C2<T>{(T)tw[2 * i], (T)tw[2 * i + 1]};
+  return r;
+}
+
+template <typename T>
+static void run_stages(C2<T>* lds, int nthr, const NkLinePlan& lp, const NkTile& tl, const C2<T>* tw) {
+  int L = lp.n;
+  for (int s = 0; s < lp.nstage; ++s) {
+    const int R = lp.radix[s];
+    for (int tid = 0; tid < nthr; ++tid) {
+      if (R == 8) nk_dif_stage<T, 8>(lds, tid, nthr, lp, tl, L, tw);
+      else if (R == 4) nk_dif_stage<T, 4>(lds, tid, nthr, lp, tl, L, tw);
+      else nk_dif_stage<T, 2>(lds, tid, nthr, lp, tl, L, tw);
+    }
+    L /= R;
+  }
+}
+
+template <typename T>
+static int emu_run(int ndim, const int64_t* shape, int dtype, int64_t batch, const nk_fuse* f, int convention) {
+  NkHostPlan hp;
+  const char* msg;
+  int rc = nk_host_plan_init(hp, ndim, shape, dtype, batch, &msg);
+  if (rc != NK_OK) return rc;
+  auto tw_a = conv_tw<T>(hp.tw_a), twr = conv_tw<T>(hp.twr_a), tw_b = conv_tw<T>(hp.tw_b), tw_c = conv_tw<T>(hp.tw_c);
+  NkPassA pa = hp.pa;
+  pa.g.sign = convention == NK_HARTLEY_CANONICAL ? -1 : 1;
+  double energy = 0.0;
+  std::vector<C2<T>> lds(hp.lds_a / sizeof(C2<T>) + 16);
+  const int64_t blocks_a = (pa.nlines + pa.tl.tile - 1) / pa.tl.tile;
+  std::vector<C2<T>> work(hp.work_bytes / sizeof(C2<T>) + 1), scratch(hp.scratch_bytes / sizeof(C2<T>) + 1);
+  for (int64_t blk = 0; blk < blocks_a; ++blk) {
+    const int nthr = hp.threads_a;
+    for (int tid = 0; tid < nthr; ++tid) nk_passA_load<T>(pa, *f, blk, tid, nthr, lds.data());
+    run_stages<T>(lds.data(), nthr, pa.lp, pa.tl, tw_a.data());
+    for (int tid = 0; tid < nthr; ++tid) {
+      if (ndim == 1) nk_pass1d_store<T>(pa, *f, blk, tid, nthr, lds.data(), twr.data(), energy);
+      else nk_passA_store<T>(pa, blk, tid, nthr, lds.data(), twr.data(), work.data());
+    }
+  }
+  if (ndim == 3) {
+    lds.assign(hp.lds_b / sizeof(C2<T>) + 16, C2<T>{0, 0});
+    const int64_t blocks = hp.pb.outer * hp.pb.tiles_per_slab;
+    for (int64_t blk = 0; blk < blocks; ++blk) {
+      const int nthr = hp.threads_b;
+      for (int tid = 0; tid < nthr; ++tid) nk_passS_load<T>(hp.pb, blk, tid, nthr, lds.data(), work.data());
+      run_stages<T>(lds.data(), nthr, hp.pb.lp, hp.pb.tl, tw_b.data());
+      for (int tid = 0; tid < nthr; ++tid) nk_passB_store<T>(hp.pb, blk, tid, nthr, lds.data(), work.data());
+    }
+  }
+  if (ndim >= 2) {
+    NkPassS pc = hp.pc;
+    pc.g.sign = pa.g.sign;
+    lds.assign(hp.lds_c / sizeof(C2<T>) + 16, C2<T>{0, 0});
+    const int64_t blocks = pc.outer * pc.tiles_per_slab;
+    for (int64_t blk = 0; blk < blocks; ++blk) {
+      const int nthr = hp.threads_c;
+      for (int tid = 0; tid < nthr; ++tid) nk_passS_load<T>(pc, blk, tid, nthr, lds.data(), work.data());
+      run_stages<T>(lds.data(), nthr, pc.lp, pc.tl, tw_c.data());
+      for (int tid = 0; tid < nthr; ++tid)
+        nk_passC_store<T>(pc, *f, blk, tid, nthr, lds.data(), scratch.data(), energy);
+    }
+    const int64_t total_d = (int64_t)pc.g.batch * pc.g.nm * pc.g.na;
+    for (int64_t gid = 0; gid < total_d; ++gid) nk_passD<T>(pc.g, *f, gid, scratch.data(), energy);
+  }
+  if (f->epi == NK_EPI_LIKELIHOOD && f->value) *f->value += energy;
+  return NK_OK;
+}
+
+extern "C" int emu_hartley_fused(int ndim, const int64_t* shape, int dtype, int64_t batch, const nk_fuse* f,
+                                 int convention) {
+  if (dtype == NK_F32) return emu_run<float>(ndim, shape, dtype, batch, f, convention);
+  return emu_run<double>(ndim, shape, dtype, batch, f, convention);
+}
+
+extern "C" int emu_plan_info(int ndim, const int64_t* shape, int dtype, int64_t batch, int64_t* info) {
+  NkHostPlan hp;
+  const char* msg;
+  int rc = nk_host_plan_init(hp, ndim, shape, dtype, batch, &msg);
+  if (rc != NK_OK) return rc;
+  info[0] = hp.pa.tl.tile; info[1] = hp.threads_a; info[2] = (int64_t)hp.lds_a;
+  info[3] = hp.pb.tl.tile; info[4] = hp.threads_b; info[5] = (int64_t)hp.lds_b;
+  info[6] = hp.pc.tl.tile; info[7] = hp.threads_c; info[8] = (int64_t)hp.lds_c;
+  info[9] = (int64_t)hp.work_bytes; info[10] = (int64_t)hp.scratch_bytes;
+  return NK_OK;
+}
