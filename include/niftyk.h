@@ -48,8 +48,9 @@ enum { NK_NL_ID = 0, NK_NL_EXP = 1, NK_NL_SIGMOID = 2 };
  *   epilogue  for transform output v at index o, t = v * scale:
  *     AFFINE      out[o] = t + offset                            (scalar_dvol factor + Adder, adder.py:47-52)
  *     MUL         out[o] = t * mul_scalar * mul[o]               (DiagonalOperator / ScalingOperator)
- *     VJP         out[o] = amp[pidx[o]] * t (+ addend[o]);  abar[pidx[o]] += xi[o] * t
- *                                                                (PowerDistributor adjoint, distributors.py:106-112)
+ *     VJP         out[o] = amp[pidx[o]] * t (+ addend_scale * addend[o]) (+ out[o] if accumulate);
+ *                 abar[pidx[o]] += xi[o] * t                     (PowerDistributor adjoint, distributors.py:106-112;
+ *                                                                 accumulate = sum over samples, sample_list.py:212-270)
  *     LIKELIHOOD  s = t + offset, g = nonlin(s); Gaussian / Poisson energy -> *value (atomic),
  *                 out[o] = dE/ds, out2[o] = g'(s)^2 * M_d (Fisher metric weight in s-space)
  *                                                                (energy_operators.py:517-640)
@@ -70,6 +71,8 @@ typedef struct nk_fuse {
   double mul_scalar;
   const void* xi;
   const void* addend;
+  double addend_scale;
+  int accumulate;
   double* abar;
   int lh_kind, nonlin;
   const void* data;
@@ -125,16 +128,25 @@ int nk_gather(int64_t n, const void* table, const int32_t* pidx, void* out, int 
 int nk_scatter_add(int64_t n, const void* in, const int32_t* pidx, int64_t nbins, void* bins, int dtype,
                    void* stream);
 
+/* power-bin index of every grid point from integer k^2 (equal harmonic distances): pidx[i] = k2table[k^2(i)],
+ * rho[bin] += 1 (rho may be NULL, else zeroed by the caller).  Replaces the int64 full-grid searchsorted of
+ * PowerSpace.__init__ (domains/power_space.py:172-180) for natural binning. */
+int nk_pindex_from_k2(int ndim, const int64_t* shape, const int32_t* k2table, int32_t* pidx, int64_t* rho,
+                      void* stream);
+
 /* ---- fused CG updates with device-resident scalars (conjugate_gradient.py:85-126).
  *      scal = device double[8]: [0] gamma_prev  [1] curv  [2] gamma  [3] x.r  [4] x.b  [5] alpha  [6] beta
  *      nk_cg_curv : scal[1] = d.q
  *      nk_cg_update: alpha = scal[0]/scal[1]; x -= alpha d; r -= alpha q; scal[2] = r.r; scal[3] = x.r;
  *                    scal[4] = x.b  (b may be NULL)
- *      nk_cg_direction: beta = max(0, scal[2]/scal[0]); d = beta d + r; scal[0] = scal[2] */
-int nk_cg_curv(int64_t n, const void* d, const void* q, int dtype, double* scal, void* stream);
+ *      nk_cg_direction: beta = max(0, scal[2]/scal[0]); d = beta d + r
+ *      accumulate != 0: do not zero the reduction slots first (second segment of a split vector) */
+int nk_cg_curv(int64_t n, const void* d, const void* q, int dtype, double* scal, int accumulate, void* stream);
 int nk_cg_update(int64_t n, void* x, void* r, const void* d, const void* q, const void* b, int dtype,
-                 double* scal, void* stream);
-int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, double* scal, void* stream);
+                 double* scal, int accumulate, void* stream);
+/* roll != 0: after the update also do scal[5]=alpha, scal[6]=beta, scal[0]=scal[2] (call once per iteration,
+ * on the last segment of a multi-segment vector) */
+int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, double* scal, int roll, void* stream);
 
 /* ---- amplitude model on the nb power bins (library/correlated_fields.py:89-208,277-386).
  *      geo  = double[4*nb]: rel[nb], sc[nb], mult[nb], delta[nb] (delta uses the first nb-2 slots)

@@ -26,7 +26,7 @@ class Fuse(ctypes.Structure):
     _fields_ = [
         ("pro", _i), ("in_", _vp), ("in2", _vp), ("pidx", _vp), ("amp", _vp), ("damp", _vp),
         ("epi", _i), ("out", _vp), ("scale", _d), ("offset", _d), ("mul", _vp), ("mul_scalar", _d),
-        ("xi", _vp), ("addend", _vp), ("abar", _vp), ("lh_kind", _i), ("nonlin", _i), ("data", _vp),
+        ("xi", _vp), ("addend", _vp), ("addend_scale", _d), ("accumulate", _i), ("abar", _vp), ("lh_kind", _i), ("nonlin", _i), ("data", _vp),
         ("icov", _vp), ("icov_scalar", _d), ("out2", _vp), ("value", _vp),
     ]
 
@@ -48,9 +48,10 @@ SIGNATURES = {
     "nk_pointwise": (_i, [_i, _d, _i64, _vp, _vp, _vp, _i, _vp]),
     "nk_gather": (_i, [_i64, _vp, _vp, _vp, _i, _vp]),
     "nk_scatter_add": (_i, [_i64, _vp, _vp, _i64, _vp, _i, _vp]),
-    "nk_cg_curv": (_i, [_i64, _vp, _vp, _i, _vp, _vp]),
-    "nk_cg_update": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
-    "nk_cg_direction": (_i, [_i64, _vp, _vp, _i, _vp, _vp]),
+    "nk_pindex_from_k2": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp]),
+    "nk_cg_curv": (_i, [_i64, _vp, _vp, _i, _vp, _i, _vp]),
+    "nk_cg_update": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "nk_cg_direction": (_i, [_i64, _vp, _vp, _i, _vp, _i, _vp]),
     "nk_amp_forward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nk_amp_jvp": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nk_amp_vjp": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1,0 +1,184 @@
+"""Device backend: thin Python wrappers over the libniftyk C ABI for torch tensors on a GPU.
+
+This is the counterpart of the reference's native-dispatch seam ``nifty/cl/ducc_dispatch.py``
+(hartley / fftn / ifftn / vdot) plus the array-library call sites listed in SURVEY 2.1.  PyTorch is
+used for device memory and streams only; every number is produced by a HIP kernel.  There is no
+fallback: a CPU tensor handed to these functions raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from . import config
+
+_DT = {torch.float32: L.NK_F32, torch.float64: L.NK_F64}
+_plans = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_device(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("nifty_amd.backend: device kernels need GPU tensors (no CPU fallback)")
+
+
+def dtype_code(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype for device kernels: {t.dtype}")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class Plan:
+    """An nk_plan plus its workspace (immutable after creation, cached per shape/dtype/device)."""
+
+    def __init__(self, shape, dtype, batch, device):
+        lib = L.load()
+        self.shape, self.dtype, self.batch, self.device = tuple(shape), dtype, int(batch), device
+        self._p = ctypes.c_void_p()
+        shp = (ctypes.c_int64 * len(shape))(*shape)
+        with torch.cuda.device(device):
+            L.check(lib.nk_plan_create(ctypes.byref(self._p), len(shape), shp, _DT[dtype], self.batch), "nk_plan_create")
+            self.workspace = torch.empty(lib.nk_plan_workspace_bytes(self._p), dtype=torch.uint8, device=device)
+
+    @property
+    def handle(self):
+        return self._p
+
+    def __del__(self):
+        try:
+            if self._p:
+                L.load().nk_plan_destroy(self._p)
+        except Exception:
+            pass
+
+
+def get_plan(shape, dtype, batch=1, device=None):
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (tuple(int(s) for s in shape), dtype, int(batch), device.index)
+    p = _plans.get(key)
+    if p is None:
+        p = _plans[key] = Plan(key[0], dtype, batch, device)
+    return p
+
+
+def _convention():
+    return 0 if config.get("hartley_convention") == "non_canonical_hartley" else 1
+
+
+def hartley(x, ndim=None, scale=1.0, out=None):
+    """Genuine N-D Hartley transform over the last ``ndim`` axes (reference ducc_dispatch.hartley)."""
+    _require_device(x)
+    x = x.contiguous()
+    ndim = x.dim() if ndim is None else ndim
+    shape = x.shape[x.dim() - ndim:]
+    batch = x.numel() // max(1, int(torch.Size(shape).numel()))
+    plan = get_plan(shape, x.dtype, batch, x.device)
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.load().nk_hartley(plan.handle, x.data_ptr(), out.data_ptr(), float(scale), _convention(),
+                                plan.workspace.data_ptr(), _stream()), "nk_hartley")
+    return out
+
+
+def hartley_fused(plan, fuse):
+    L.check(L.load().nk_hartley_fused(plan.handle, ctypes.byref(fuse), _convention(), plan.workspace.data_ptr(),
+                                      _stream()), "nk_hartley_fused")
+
+
+def fftn(x, ndim=None, inverse=False, scale=1.0):
+    """c2c FFT over the last ``ndim`` axes of a complex tensor (reference ducc_dispatch.fftn / ifftn)."""
+    _require_device(x)
+    if not x.is_complex():
+        raise TypeError("fftn expects a complex tensor")
+    x = x.contiguous()
+    ndim = x.dim() if ndim is None else ndim
+    shape = x.shape[x.dim() - ndim:]
+    batch = x.numel() // max(1, int(torch.Size(shape).numel()))
+    rdt = torch.float32 if x.dtype == torch.complex64 else torch.float64
+    plan = get_plan(shape, rdt, batch, x.device)
+    out = torch.empty_like(x)
+    L.check(L.load().nk_fftn(plan.handle, torch.view_as_real(x).data_ptr(), torch.view_as_real(out).data_ptr(),
+                             1 if inverse else 0, float(scale), plan.workspace.data_ptr(), _stream()), "nk_fftn")
+    return out
+
+
+def new_scalar(device, n=1):
+    return torch.zeros(n, dtype=torch.float64, device=device)
+
+
+def vdot(a, b, result=None, accumulate=False):
+    """sum(a*b) with fp64 accumulation into a DEVICE double (no host sync)."""
+    _require_device(a, b)
+    if a.numel() != b.numel() or a.dtype != b.dtype:
+        raise ValueError("vdot: shape/dtype mismatch")
+    result = new_scalar(a.device) if result is None else result
+    L.check(L.load().nk_vdot(a.numel(), a.data_ptr(), b.data_ptr(), dtype_code(a), result.data_ptr(),
+                             1 if accumulate else 0, _stream()), "nk_vdot")
+    return result
+
+
+def vsum(a, result=None, accumulate=False):
+    _require_device(a)
+    result = new_scalar(a.device) if result is None else result
+    L.check(L.load().nk_sum(a.numel(), a.data_ptr(), dtype_code(a), result.data_ptr(), 1 if accumulate else 0,
+                            _stream()), "nk_sum")
+    return result
+
+
+def binary(op, a, b, out=None):
+    """a (op) b for tensors of identical shape/dtype, or tensor (op) python scalar."""
+    ta, tb = torch.is_tensor(a), torch.is_tensor(b)
+    ref = a if ta else b
+    _require_device(ref)
+    if ta and tb and (a.shape != b.shape or a.dtype != b.dtype):
+        raise ValueError("binary: shape/dtype mismatch")
+    out = torch.empty_like(ref) if out is None else out
+    L.check(L.load().nk_binary(op, ref.numel(), ptr(a) if ta else 0, 0.0 if ta else float(a), ptr(b) if tb else 0,
+                               0.0 if tb else float(b), out.data_ptr(), dtype_code(ref), _stream()), "nk_binary")
+    return out
+
+
+def axpby(alpha, x, beta=0.0, y=None, out=None):
+    _require_device(x, y)
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.load().nk_axpby(x.numel(), float(alpha), x.data_ptr(), float(beta), ptr(y), out.data_ptr(), dtype_code(x),
+                              _stream()), "nk_axpby")
+    return out
+
+
+POINTWISE = {"exp": 0, "log": 1, "sqrt": 2, "tanh": 3, "sigmoid": 4, "reciprocal": 5, "power": 6, "abs": 7,
+             "absolute": 7, "log1p": 8, "expm1": 9}
+
+
+def pointwise(name, x, param=0.0, want_derivative=False):
+    _require_device(x)
+    fx = torch.empty_like(x)
+    dfx = torch.empty_like(x) if want_derivative else None
+    L.check(L.load().nk_pointwise(POINTWISE[name], float(param), x.numel(), x.data_ptr(), fx.data_ptr(), ptr(dfx),
+                                  dtype_code(x), _stream()), "nk_pointwise")
+    return (fx, dfx) if want_derivative else fx
+
+
+def gather(table, pidx, out_shape):
+    _require_device(table, pidx)
+    out = torch.empty(out_shape, dtype=table.dtype, device=table.device)
+    L.check(L.load().nk_gather(out.numel(), table.data_ptr(), pidx.data_ptr(), out.data_ptr(), dtype_code(table),
+                               _stream()), "nk_gather")
+    return out
+
+
+def scatter_add(x, pidx, nbins):
+    """np.bincount(pidx, weights=x, minlength=nbins): fp64 bins."""
+    _require_device(x, pidx)
+    bins = torch.zeros(nbins, dtype=torch.float64, device=x.device)
+    L.check(L.load().nk_scatter_add(x.numel(), x.data_ptr(), pidx.data_ptr(), nbins, bins.data_ptr(), dtype_code(x),
+                                    _stream()), "nk_scatter_add")
+    return bins

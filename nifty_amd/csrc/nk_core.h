@@ -218,7 +218,8 @@ NK_HD void nk_epilogue(const NkFuse& f, int64_t o, T v, double& acc) {
       const double t = (double)v * f.scale;
       const int32_t p = f.pidx[o];
       double r = f.amp[p] * t;
-      if (f.addend) r += (double)((const T*)f.addend)[o];
+      if (f.addend) r += f.addend_scale * (double)((const T*)f.addend)[o];
+      if (f.accumulate) r += (double)out[o];
       out[o] = (T)r;
       NK_ATOMIC_ADD(f.abar + p, (double)((const T*)f.xi)[o] * t);
     } break;
@@ -265,8 +266,12 @@ NK_HD void nk_epilogue_pair(const NkFuse& f, int64_t o1, T v1, int64_t o2, T v2,
     const double a = f.amp[p];
     double r1 = a * t1, r2 = a * t2;
     if (f.addend) {
-      r1 += (double)((const T*)f.addend)[o1];
-      r2 += (double)((const T*)f.addend)[o2];
+      r1 += f.addend_scale * (double)((const T*)f.addend)[o1];
+      r2 += f.addend_scale * (double)((const T*)f.addend)[o2];
+    }
+    if (f.accumulate) {
+      r1 += (double)out[o1];
+      r2 += (double)out[o2];
     }
     out[o1] = (T)r1;
     out[o2] = (T)r2;

@@ -422,11 +422,14 @@ extern "C" int nk_scatter_add(int64_t n, const void* in, const int32_t* pidx, in
   })
 }
 
-extern "C" int nk_cg_curv(int64_t n, const void* d, const void* q, int dtype, double* scal, void* stream) {
+extern "C" int nk_cg_curv(int64_t n, const void* d, const void* q, int dtype, double* scal, int accumulate,
+                          void* stream) {
   if (n < 0 || !d || !q || !scal) return nk_set_error(NK_ERR_INVALID, "nk_cg_curv: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  int rc = nk_zero(scal + 1, 1, st);
-  if (rc != NK_OK) return rc;
+  if (!accumulate) {
+    int rc = nk_zero(scal + 1, 1, st);
+    if (rc != NK_OK) return rc;
+  }
   NK_DISPATCH_DTYPE(dtype, {
     FCgCurv<T> f{(const T*)d, (const T*)q, scal + 1};
     return nk_launch_map<T>(n, f, nk_aligned16(d) && nk_aligned16(q), st, "nk_cg_curv");
@@ -434,11 +437,13 @@ extern "C" int nk_cg_curv(int64_t n, const void* d, const void* q, int dtype, do
 }
 
 extern "C" int nk_cg_update(int64_t n, void* x, void* r, const void* d, const void* q, const void* b, int dtype,
-                            double* scal, void* stream) {
+                            double* scal, int accumulate, void* stream) {
   if (n < 0 || !x || !r || !d || !q || !scal) return nk_set_error(NK_ERR_INVALID, "nk_cg_update: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  int rc = nk_zero(scal + 2, 3, st);
-  if (rc != NK_OK) return rc;
+  if (!accumulate) {
+    int rc = nk_zero(scal + 2, 3, st);
+    if (rc != NK_OK) return rc;
+  }
   NK_DISPATCH_DTYPE(dtype, {
     FCgUpdate<T> f{(T*)x, (T*)r, (const T*)d, (const T*)q, (const T*)b, scal, scal + 2};
     return nk_launch_map<T>(
@@ -447,7 +452,7 @@ extern "C" int nk_cg_update(int64_t n, void* x, void* r, const void* d, const vo
   })
 }
 
-extern "C" int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, double* scal, void* stream) {
+extern "C" int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, double* scal, int roll, void* stream) {
   if (n < 0 || !d || !r || !scal) return nk_set_error(NK_ERR_INVALID, "nk_cg_direction: bad argument");
   hipStream_t st = (hipStream_t)stream;
   int rc;
@@ -455,7 +460,40 @@ extern "C" int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, dou
     FCgDir<T> f{(T*)d, (const T*)r, scal, nullptr};
     rc = nk_launch_map<T>(n, f, nk_aligned16(d) && nk_aligned16(r), st, "nk_cg_direction");
   })
-  if (rc != NK_OK) return rc;
+  if (rc != NK_OK || !roll) return rc;
   hipLaunchKernelGGL(k_cg_roll, dim3(1), dim3(1), 0, st, scal);
   return nk_check_launch("k_cg_roll");
+}
+
+// ---- power-bin index straight from integer k^2 (PowerSpace pindex for equal harmonic distances,
+//      nifty/cl/domains/power_space.py:172-180 + rg_space.py:116-128 without the 8 N-byte int64 array) ----
+struct NkShape3 {
+  int64_t n0, n1, n2;
+};
+__global__ void k_pindex_k2(NkShape3 s, const int32_t* __restrict__ table, int32_t* __restrict__ pidx,
+                            unsigned long long* __restrict__ rho, int64_t total) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t i2 = i % s.n2, r = i / s.n2;
+    const int64_t i1 = r % s.n1, i0 = r / s.n1;
+    const int64_t a = i0 < s.n0 - i0 ? i0 : s.n0 - i0;
+    const int64_t b = i1 < s.n1 - i1 ? i1 : s.n1 - i1;
+    const int64_t c = i2 < s.n2 - i2 ? i2 : s.n2 - i2;
+    const int32_t p = table[a * a + b * b + c * c];
+    pidx[i] = p;
+    if (rho) atomicAdd(rho + p, 1ULL);
+  }
+}
+
+extern "C" int nk_pindex_from_k2(int ndim, const int64_t* shape, const int32_t* k2table, int32_t* pidx, int64_t* rho,
+                                 void* stream) {
+  if (ndim < 1 || ndim > 3 || !shape || !k2table || !pidx) return nk_set_error(NK_ERR_INVALID, "nk_pindex_from_k2: bad argument");
+  NkShape3 s{1, 1, 1};
+  if (ndim == 1) s.n2 = shape[0];
+  if (ndim == 2) s.n1 = shape[0], s.n2 = shape[1];
+  if (ndim == 3) s.n0 = shape[0], s.n1 = shape[1], s.n2 = shape[2];
+  const int64_t total = s.n0 * s.n1 * s.n2;
+  hipLaunchKernelGGL(k_pindex_k2, dim3(nk_grid(total)), dim3(NK_VEC_THREADS), 0, (hipStream_t)stream, s, k2table, pidx,
+                     (unsigned long long*)rho, total);
+  return nk_check_launch("k_pindex_k2");
 }

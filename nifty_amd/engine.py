@@ -1,0 +1,532 @@
+"""Fused MGVI/geoVI engine: CorrelatedField model + likelihood + sampled KL on one GPU.
+
+This is the hot path of BASELINE.json's north_star with every N-sized operation fused into the
+transform kernels (nk_hartley_fused prologue/epilogue):
+
+    value+gradient of one sample  = amp_forward | HT[a(k) xi -> likelihood epilogue] | HT[dE/ds -> VJP epilogue] | amp_vjp
+    metric application, 1 sample  = amp_jvp | HT[a dxi + da xi -> x metric weight] | HT[-> VJP epilogue (+d)] | amp_vjp
+
+i.e. exactly one forward and one adjoint Hartley transform per sample (the reference re-linearises and
+needs 2 + 1), no other N-sized pass, and the sum over local samples accumulates inside the
+VJP epilogue.  It implements what the reference computes in
+nifty/cl/library/correlated_fields.py:713-764 (finalize), operators/energy_operators.py:517-640,
+890-931 (Gaussian/Poisson energy, StandardHamiltonian), operators/sampling_enabler.py:64-86 and
+minimization/kl_energies.py:91-159, 299-360, behind the Energy protocol of minimization.py.
+
+Latent vectors are ``LatentVec``: ``xi`` (the harmonic-space excitations, field dtype) and ``small``
+(float64: asperity, flexibility, fluctuations, loglogavgslope, zeromode, spectrum[2, nb-2]).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import backend as B
+from . import random
+from .domains import PowerSpace, RGSpace
+from .minimization import ConjugateGradient, Energy, QuadraticEnergy
+
+SMALL_KEYS = ("asperity", "flexibility", "fluctuations", "loglogavgslope", "zeromode")
+LATENT_KEYS = ("asperity", "flexibility", "fluctuations", "loglogavgslope", "spectrum", "xi", "zeromode")
+_NONLIN = {None: L.NL_ID, "": L.NL_ID, "exp": L.NL_EXP, "sigmoid": L.NL_SIGMOID}
+
+
+def lognormal_moments(mean, sigma):
+    """reference nifty/cl/utilities.py:500-513"""
+    mean, sigma = float(mean), float(sigma)
+    if not mean > 0:
+        raise ValueError(f"mean must be greater 0; got {mean!r}")
+    if not sigma > 0:
+        raise ValueError(f"sig must be greater 0; got {sigma!r}")
+    logsigma = math.sqrt(math.log1p((sigma / mean) ** 2))
+    return math.log(mean) - logsigma ** 2 / 2, logsigma
+
+
+# ------------------------------------------------------------------------------------------------
+# latent vectors
+# ------------------------------------------------------------------------------------------------
+class CgWorkspace:
+    """Device-resident CG scalars (see nk_cg_* in include/niftyk.h)."""
+
+    def __init__(self, device):
+        self.scal = torch.zeros(8, dtype=torch.float64, device=device)
+        self._host = torch.empty(8, dtype=torch.float64, pin_memory=True) if device.type == "cuda" else None
+
+    def set_gamma(self, gamma):
+        self.scal[0] = gamma
+
+    def _segments(self, *vecs):
+        return [[v.xi.reshape(-1) if v is not None else None for v in vecs],
+                [v.small if v is not None else None for v in vecs]]
+
+    def curv(self, d, q):
+        lib, st = L.load(), B._stream()
+        for i, (dd, qq) in enumerate(self._segments(d, q)):
+            L.check(lib.nk_cg_curv(dd.numel(), dd.data_ptr(), qq.data_ptr(), B.dtype_code(dd), self.scal.data_ptr(), i, st))
+
+    def update(self, x, r, d, q, b):
+        lib, st = L.load(), B._stream()
+        for i, (xx, rr, dd, qq, bb) in enumerate(self._segments(x, r, d, q, b)):
+            L.check(lib.nk_cg_update(xx.numel(), xx.data_ptr(), rr.data_ptr(), dd.data_ptr(), qq.data_ptr(), B.ptr(bb),
+                                     B.dtype_code(xx), self.scal.data_ptr(), i, st))
+
+    def refresh(self, x, r, b):
+        """After a residual refresh: gamma = r.r, x.r and x.b recomputed (device side)."""
+        for slot, (u, v) in ((2, (r, r)), (3, (x, r)), (4, (x, b))):
+            if v is None:
+                continue
+            res = self.scal[slot:slot + 1]
+            B.vdot(u.xi.reshape(-1), v.xi.reshape(-1), result=res, accumulate=False)
+            B.vdot(u.small, v.small, result=res, accumulate=True)
+
+    def direction(self, d, r):
+        lib, st = L.load(), B._stream()
+        segs = self._segments(d, r)
+        for i, (dd, rr) in enumerate(segs):
+            L.check(lib.nk_cg_direction(dd.numel(), dd.data_ptr(), rr.data_ptr(), B.dtype_code(dd), self.scal.data_ptr(),
+                                        1 if i == len(segs) - 1 else 0, st))
+
+    def fetch(self):
+        self._host.copy_(self.scal, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        s = self._host.numpy()
+        return dict(gamma_prev=float(s[0]), curv=float(s[1]), gamma=float(s[2]), xr=float(s[3]), xb=float(s[4]),
+                    alpha=float(s[0] / s[1]) if s[1] != 0 else float("nan"))
+
+
+class LatentVec:
+    """A point / tangent / cotangent of the latent space (vector protocol of minimization.py)."""
+
+    __slots__ = ("xi", "small")
+
+    def __init__(self, xi, small):
+        self.xi, self.small = xi, small
+
+    # -- construction -------------------------------------------------------------------------
+    @staticmethod
+    def zeros(model):
+        return LatentVec(torch.zeros(model.shape, dtype=model.tdtype, device=model.device),
+                         torch.zeros(model.nsmall, dtype=torch.float64, device=model.device))
+
+    @staticmethod
+    def from_dict(model, dct):
+        """Host dict (numpy arrays keyed like the reference's MultiField) -> device LatentVec."""
+        nb = model.nb
+        small = np.concatenate([[float(np.asarray(dct[k])) for k in SMALL_KEYS],
+                                np.asarray(dct["spectrum"], dtype=np.float64).reshape(2 * (nb - 2))])
+        xi = torch.from_numpy(np.ascontiguousarray(np.asarray(dct["xi"]).reshape(model.shape))).to(model.tdtype)
+        return LatentVec(xi.to(model.device), torch.from_numpy(small).to(model.device))
+
+    def to_dict(self):
+        s = self.small.cpu().numpy()
+        out = {k: np.array(s[i]) for i, k in enumerate(SMALL_KEYS)}
+        out["spectrum"] = s[5:].reshape(2, -1).copy()
+        out["xi"] = self.xi.cpu().numpy()
+        return out
+
+    def clone(self):
+        return LatentVec(self.xi.clone(), self.small.clone())
+
+    def cg_workspace(self):
+        return CgWorkspace(self.xi.device)
+
+    # -- vector protocol -----------------------------------------------------------------------
+    def _lin(self, alpha, other, beta):
+        """alpha*self + beta*other"""
+        return LatentVec(B.axpby(alpha, self.xi, beta, other.xi), B.axpby(alpha, self.small, beta, other.small))
+
+    def __add__(self, o):
+        return self._lin(1.0, o, 1.0)
+
+    def __sub__(self, o):
+        return self._lin(1.0, o, -1.0)
+
+    def __mul__(self, a):
+        if not np.isscalar(a):
+            return NotImplemented
+        return LatentVec(B.axpby(float(a), self.xi), B.axpby(float(a), self.small))
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return self * (-1.0)
+
+    def axpy(self, a, x):
+        """self + a*x"""
+        return x._lin(float(a), self, 1.0)
+
+    def dot_device(self, o, result=None):
+        res = B.vdot(self.xi.reshape(-1), o.xi.reshape(-1), result=result, accumulate=result is not None)
+        return B.vdot(self.small, o.small, result=res, accumulate=True)
+
+    def s_vdot(self, o):
+        return float(self.dot_device(o).item())
+
+    def norm(self, ord=2):
+        if ord != 2:
+            raise NotImplementedError
+        return math.sqrt(self.s_vdot(self))
+
+
+# ------------------------------------------------------------------------------------------------
+# the fused model
+# ------------------------------------------------------------------------------------------------
+class LinPoint:
+    """Everything cached about one latent point: amplitude tables and the s-space metric weight."""
+
+    __slots__ = ("x", "amp", "state", "mid", "mid_scalar", "value", "grad")
+
+    def __init__(self):
+        self.mid = None
+        self.mid_scalar = 1.0
+
+
+class FusedModel:
+    """offset + HT(a[pindex] xi) -> nonlinearity -> Gaussian / Poisson likelihood, plus the standard prior."""
+
+    def __init__(self, shape, distances=None, *, offset_mean=0.0, offset_std=(1e-1, 3e-2), fluctuations=(1.0, 5e-1),
+                 loglogavgslope=(-3.0, 2e-1), flexibility=(1.0, 2e-1), asperity=(5e-1, 5e-2),
+                 likelihood="gaussian", data=None, icov=1.0, nonlin=None, dtype=torch.float64, device="cuda:0"):
+        L.load()  # fail loudly without the HIP extension
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("FusedModel runs on a GPU only (no CPU fallback)")
+        self.tdtype = dtype
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.N = int(np.prod(self.shape))
+        pos = RGSpace(self.shape, distances)
+        self.position_space = pos
+        self.harmonic_space = hsp = pos.get_default_codomain()
+        self.power_space = ps = PowerSpace(hsp)
+        self.nb = nb = ps.shape[0]
+        if nb < 3:
+            raise ValueError("need at least 3 power bins")
+        self.nsmall = 5 + 2 * (nb - 2)
+        self.V = pos.total_volume
+        self.h_dvol = hsp.scalar_dvol
+        self.offset_mean = float(offset_mean)
+        with torch.cuda.device(self.device):
+            self.pidx = ps.device_pindex(self.device)
+            logk = np.log(ps.k_lengths[1:])
+            rel = np.insert(logk - logk[0], 0, 0.0)
+            delta = np.concatenate([logk[1:] - logk[:-1], [0.0, 0.0]])
+            mult = ps.rho.astype(np.float64).copy()
+            mult[0] = 0.0
+            geo = np.concatenate([rel, rel / rel[-1], mult, delta])
+            hyp = np.array([*lognormal_moments(*fluctuations), *lognormal_moments(*flexibility),
+                            *lognormal_moments(*asperity), *lognormal_moments(*offset_std),
+                            float(loglogavgslope[0]), float(loglogavgslope[1]), self.V])
+            self.geo = torch.from_numpy(geo).to(self.device)
+            self.hyp = torch.from_numpy(hyp).to(self.device)
+            self.plan = B.get_plan(self.shape, dtype, 1, self.device)
+            self.abar = torch.zeros(nb, dtype=torch.float64, device=self.device)
+            self.damp = torch.empty(nb, dtype=torch.float64, device=self.device)
+            self.latbar = torch.empty(self.nsmall, dtype=torch.float64, device=self.device)
+            self.tmp = torch.empty(self.shape, dtype=dtype, device=self.device)
+        # likelihood
+        if likelihood not in ("gaussian", "poisson"):
+            raise ValueError("likelihood must be 'gaussian' or 'poisson'")
+        self.lh_kind = L.LH_GAUSS if likelihood == "gaussian" else L.LH_POISSON
+        self.nonlin = _NONLIN[nonlin]
+        self.icov_field, self.icov_scalar = None, 1.0
+        if data is not None:
+            self.set_data(data, icov)
+        self.counters = dict(value_grad=0, metric=0, transforms=0, cg_iterations=0)
+
+    # -- data ---------------------------------------------------------------------------------
+    def set_data(self, data, icov=1.0):
+        data = torch.as_tensor(data)
+        if tuple(data.shape) != self.shape:
+            raise ValueError("data shape mismatch")
+        if self.lh_kind == L.LH_POISSON:
+            if data.dtype.is_floating_point:
+                raise TypeError("data is of invalid data-type; counts need to be integers")
+            if bool((data < 0).any()):
+                raise ValueError("count data is negative and thus can not be Poissonian")
+            self.data = data.to(torch.int64).to(self.device).contiguous()
+        else:
+            self.data = data.to(self.tdtype).to(self.device).contiguous()
+            if np.isscalar(icov):
+                self.icov_scalar, self.icov_field = float(icov), None
+            else:
+                self.icov_field = torch.as_tensor(icov).to(self.tdtype).to(self.device).contiguous()
+        self.const_mid = self.lh_kind == L.LH_GAUSS and self.nonlin == L.NL_ID and self.icov_field is None
+
+    # -- kernels --------------------------------------------------------------------------------
+    def _amp_forward(self, small):
+        amp = torch.empty(self.nb, dtype=torch.float64, device=self.device)
+        state = torch.empty(8 * self.nb + 16, dtype=torch.float64, device=self.device)
+        L.check(L.load().nk_amp_forward(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), small.data_ptr(),
+                                        state.data_ptr(), amp.data_ptr(), B._stream()), "nk_amp_forward")
+        return amp, state
+
+    def _fuse(self):
+        f = L.Fuse()
+        f.scale = self.h_dvol
+        f.mul_scalar = 1.0
+        f.addend_scale = 1.0
+        return f
+
+    def signal(self, x, want_derivative=False):
+        """nonlin(offset + HT(a xi)) as a device tensor (and optionally nonlin')."""
+        amp, _ = self._amp_forward(x.small)
+        f = self._fuse()
+        f.pro, f.in_, f.pidx, f.amp = L.PRO_AMP, x.xi.data_ptr(), self.pidx.data_ptr(), amp.data_ptr()
+        out = torch.empty(self.shape, dtype=self.tdtype, device=self.device)
+        d = torch.empty_like(out) if want_derivative else None
+        f.epi, f.out, f.out2, f.offset, f.nonlin = L.EPI_NONLIN, out.data_ptr(), B.ptr(d), self.offset_mean, self.nonlin
+        B.hartley_fused(self.plan, f)
+        self.counters["transforms"] += 1
+        return (out, d) if want_derivative else out
+
+    def _vjp(self, lp, w, scale, addend, addend_scale, accumulate, out_xi):
+        """out_xi (+)= a t + addend_scale*addend,  self.abar += scatter(xi t),  t = scale * HT(w)."""
+        f = self._fuse()
+        f.pro, f.in_ = L.PRO_PLAIN, w.data_ptr()
+        f.epi, f.out, f.scale = L.EPI_VJP, out_xi.data_ptr(), self.h_dvol * scale
+        f.pidx, f.amp, f.xi, f.abar = self.pidx.data_ptr(), lp.amp.data_ptr(), lp.x.xi.data_ptr(), self.abar.data_ptr()
+        f.addend, f.addend_scale, f.accumulate = B.ptr(addend), addend_scale, 1 if accumulate else 0
+        B.hartley_fused(self.plan, f)
+        self.counters["transforms"] += 1
+
+    def _amp_vjp(self, lp):
+        L.check(L.load().nk_amp_vjp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(),
+                                    lp.state.data_ptr(), self.abar.data_ptr(), self.latbar.data_ptr(), B._stream()),
+                "nk_amp_vjp")
+
+    def linearize(self, x, grad_acc=None, n_total=1, value_acc=None):
+        """Value and gradient of H = lh + 1/2|x|^2 at x, cached for metric applications.
+
+        With ``grad_acc``/``value_acc`` the sample average is accumulated in place (1/n_total weights).
+        """
+        lp = LinPoint()
+        lp.x = x
+        lp.amp, lp.state = self._amp_forward(x.small)
+        w = 1.0 / n_total
+        value = torch.zeros(1, dtype=torch.float64, device=self.device) if value_acc is None else value_acc
+        lhval = torch.zeros(1, dtype=torch.float64, device=self.device)
+        f = self._fuse()
+        f.pro, f.in_, f.pidx, f.amp = L.PRO_AMP, x.xi.data_ptr(), self.pidx.data_ptr(), lp.amp.data_ptr()
+        gs = self.tmp
+        if not self.const_mid:
+            lp.mid = torch.empty(self.shape, dtype=self.tdtype, device=self.device)
+        else:
+            lp.mid_scalar = self.icov_scalar
+        f.epi, f.out, f.out2 = L.EPI_LIKELIHOOD, gs.data_ptr(), B.ptr(lp.mid)
+        f.offset, f.lh_kind, f.nonlin = self.offset_mean, self.lh_kind, self.nonlin
+        f.data, f.icov, f.icov_scalar, f.value = self.data.data_ptr(), B.ptr(self.icov_field), self.icov_scalar, lhval.data_ptr()
+        B.hartley_fused(self.plan, f)
+        self.counters["transforms"] += 1
+        # gradient: J^T gs + x
+        first = grad_acc is None
+        grad = LatentVec(torch.empty_like(x.xi), None) if first else grad_acc
+        self.abar.zero_()
+        self._vjp(lp, gs, w, x.xi, w, not first, grad.xi)
+        self._amp_vjp(lp)
+        # (abar, hence latbar, already carries the 1/n_total weight)
+        if first:
+            grad.small = B.axpby(1.0, self.latbar, w, x.small)
+        else:
+            B.axpby(1.0, self.latbar, 1.0, grad.small, out=grad.small)
+            B.axpby(w, x.small, 1.0, grad.small, out=grad.small)
+        # value: lh + 1/2 x.x
+        prior = x.dot_device(x)
+        B.axpby(w, lhval, 1.0, value, out=value)
+        B.axpby(0.5 * w, prior, 1.0, value, out=value)
+        lp.value, lp.grad = value, grad
+        self.counters["value_grad"] += 1
+        return lp
+
+    def lh_metric_accumulate(self, lp, d, out, scale, first):
+        """out (+)= scale * J^T M J d   (likelihood Fisher metric pulled back to latent space)."""
+        L.check(L.load().nk_amp_jvp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(),
+                                    lp.state.data_ptr(), d.small.data_ptr(), self.damp.data_ptr(), B._stream()), "nk_amp_jvp")
+        f = self._fuse()
+        f.pro, f.in_, f.in2 = L.PRO_AMP_JVP, d.xi.data_ptr(), lp.x.xi.data_ptr()
+        f.pidx, f.amp, f.damp = self.pidx.data_ptr(), lp.amp.data_ptr(), self.damp.data_ptr()
+        f.epi, f.out, f.mul, f.mul_scalar = L.EPI_MUL, self.tmp.data_ptr(), B.ptr(lp.mid), lp.mid_scalar
+        B.hartley_fused(self.plan, f)
+        self.abar.zero_()
+        self._vjp(lp, self.tmp, scale, None, 0.0, not first, out.xi)
+        self.counters["transforms"] += 1
+        self._amp_vjp(lp)
+        if first:
+            out.small = B.axpby(1.0, self.latbar)
+        else:
+            B.axpby(1.0, self.latbar, 1.0, out.small, out=out.small)
+        self.counters["metric"] += 1
+
+    def metric(self, lp, d):
+        """(J^T M J + 1) d at the linearisation point lp."""
+        out = LatentVec(torch.empty_like(d.xi), None)
+        self.lh_metric_accumulate(lp, d, out, 1.0, True)
+        return out + d
+
+    def lh_metric(self, lp, d):
+        out = LatentVec(torch.empty_like(d.xi), None)
+        self.lh_metric_accumulate(lp, d, out, 1.0, True)
+        return out
+
+    # -- sampling (kl_energies.py:91-159, sampling_enabler.py:64-86) -------------------------------
+    def _upload(self, arr, dtype):
+        return torch.from_numpy(np.ascontiguousarray(arr)).to(dtype).to(self.device)
+
+    def draw_prior(self, device_rng=None):
+        """One standard-normal latent draw, keys in alphabetical order like MultiField.from_random."""
+        if device_rng is not None:
+            xi = torch.randn(self.shape, dtype=self.tdtype, device=self.device, generator=device_rng)
+            small = torch.randn(self.nsmall, dtype=torch.float64, device=self.device, generator=device_rng)
+            return LatentVec(xi, small)
+        nb = self.nb
+        parts = {}
+        for k in LATENT_KEYS:  # alphabetical = the reference's draw order
+            shp = (2, nb - 2) if k == "spectrum" else self.shape if k == "xi" else ()
+            parts[k] = random.current_rng().normal(0.0, 1.0, shp)
+        small = np.concatenate([[parts[k] for k in SMALL_KEYS], parts["spectrum"].ravel()])
+        return LatentVec(self._upload(parts["xi"], self.tdtype), self._upload(small, torch.float64))
+
+    def draw_lh_noise(self, lp, device_rng=None):
+        """J^T M_d^{1/2} eta with eta ~ N(0,1) in data space."""
+        if device_rng is not None:
+            eta = torch.randn(self.shape, dtype=self.tdtype, device=self.device, generator=device_rng)
+            if self.const_mid:
+                eta = B.axpby(math.sqrt(self.icov_scalar), eta)
+        elif self.const_mid:
+            eta = self._upload(random.current_rng().normal(0.0, math.sqrt(self.icov_scalar), self.shape), self.tdtype)
+        else:
+            eta = self._upload(random.current_rng().normal(0.0, 1.0, self.shape), self.tdtype)
+        if not self.const_mid:
+            eta = B.binary(L.OP_MUL, eta, B.pointwise("sqrt", lp.mid))
+        out = LatentVec(torch.empty(self.shape, dtype=self.tdtype, device=self.device), None)
+        self.abar.zero_()
+        self._vjp(lp, eta, 1.0, None, 0.0, False, out.xi)
+        self._amp_vjp(lp)
+        out.small = B.axpby(1.0, self.latbar)
+        return out
+
+    def draw_mgvi_sample(self, lp, controller, device_rng=None):
+        """Returns (b, y): y solves (J^T M J + 1) y = b = s + nj by CG started at the prior draw s."""
+        s = self.draw_prior(device_rng)
+        nj = self.draw_lh_noise(lp, device_rng)
+        b = s + nj
+        g0 = self.lh_metric(lp, s) - nj
+        A = _Callable(lambda v: self.metric(lp, v))
+        energy = QuadraticEnergy(s, A, b, _grad=g0)
+        energy, _ = ConjugateGradient(controller)(energy)
+        return b, energy.position
+
+
+class _Callable:
+    def __init__(self, fn):
+        self._fn = fn
+
+    def __call__(self, x):
+        return self._fn(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# sampled KL
+# ------------------------------------------------------------------------------------------------
+class FusedKL(Energy):
+    """SampledKLEnergyClass on the fused model (kl_energies.py:299-360).
+
+    ``residuals``/``negs`` are the LOCAL samples of this rank; ``n_total`` the global sample count.
+    ``comm`` (nifty_amd.parallel.Comm or None) sums value/gradient/metric over ranks.
+    """
+
+    def __init__(self, model, position, residuals, negs, n_total=None, comm=None, nanisinf=True):
+        super().__init__(position)
+        self.model, self.residuals, self.negs = model, residuals, negs
+        self.n_total = len(residuals) if n_total is None else n_total
+        self.comm, self.nanisinf = comm, nanisinf
+        self.lins = []
+        value = torch.zeros(1, dtype=torch.float64, device=model.device)
+        grad = None
+        for r, neg in zip(residuals, negs):
+            x = position - r if neg else position + r
+            lp = model.linearize(x, grad_acc=grad, n_total=self.n_total, value_acc=value)
+            grad = lp.grad
+            lp.grad = None
+            self.lins.append(lp)
+        if grad is None:  # a rank without samples
+            grad = LatentVec.zeros(model)
+        if comm is not None:
+            comm.allreduce_sum_([value, grad.xi, grad.small])
+        self._value = float(value.item())
+        if math.isnan(self._value) and nanisinf:
+            self._value = math.inf
+        self._grad = grad
+
+    @property
+    def value(self):
+        return self._value
+
+    @property
+    def gradient(self):
+        return self._grad
+
+    def at(self, position):
+        return FusedKL(self.model, position, self.residuals, self.negs, self.n_total, self.comm, self.nanisinf)
+
+    def apply_metric(self, d):
+        m = self.model
+        out = LatentVec(torch.empty_like(d.xi), None)
+        w = 1.0 / self.n_total
+        for i, lp in enumerate(self.lins):
+            m.lh_metric_accumulate(lp, d, out, w, i == 0)
+        nloc = len(self.lins)
+        if nloc == 0:
+            out = LatentVec.zeros(m)
+        if self.comm is not None:
+            # prior term: every rank adds its share nloc/n_total of d, the sum over ranks is d
+            out = out.axpy(nloc * w, d)
+            self.comm.allreduce_sum_([out.xi, out.small])
+            return out
+        return out.axpy(nloc * w, d)
+
+    @property
+    def metric(self):
+        return _Callable(self.apply_metric)
+
+    @property
+    def samples(self):
+        return [(self._position - r if neg else self._position + r) for r, neg in zip(self.residuals, self.negs)]
+
+
+def share_range(nwork, nshares, myshare):
+    """reference nifty/cl/utilities.py:282-306"""
+    nbase, additional = divmod(nwork, nshares)
+    lo = myshare * nbase + min(myshare, additional)
+    return lo, lo + nbase + int(myshare < additional)
+
+
+def draw_samples(model, position, n_samples, mirror_samples, controller_factory, comm=None, device_rng=None):
+    """MGVI samples of this rank (kl_energies.py:126-159): returns (residuals, negs, n_total)."""
+    sseq = random.spawn_sseq(n_samples)
+    if mirror_samples:
+        sseq = [s for ss in sseq for s in (ss, ss)]
+    ntask, rank = (1, 0) if comm is None else (comm.size, comm.rank)
+    lp = None
+    residuals, negs = [], []
+    y = None
+    lo, hi = share_range(len(sseq), ntask, rank)
+    for i in range(lo, hi):
+        with random.Context(sseq[i]):
+            neg = mirror_samples and i % 2 != 0
+            if not neg or y is None:
+                if lp is None:
+                    lp = model.linearize(position)
+                _, y = model.draw_mgvi_sample(lp, controller_factory(), device_rng)
+            residuals.append(y)
+            negs.append(neg)
+    return residuals, negs, len(sseq)
+
+
+def mgvi_iteration(model, mean, n_samples, controller_factory, kl_minimizer, mirror_samples=True, comm=None,
+                   device_rng=None):
+    """One pass of the optimize_kl loop body (optimize_kl.py:357-451, no I/O): sample, then minimise."""
+    residuals, negs, n_total = draw_samples(model, mean, n_samples, mirror_samples, controller_factory, comm, device_rng)
+    kl = FusedKL(model, mean, residuals, negs, n_total, comm)
+    kl, _ = kl_minimizer(kl)
+    return kl.position, kl

@@ -1,0 +1,658 @@
+"""Energies, iteration controllers, conjugate gradient, line search and descent minimizers.
+
+Counterpart of reference nifty/cl/minimization/{energy,quadratic_energy,conjugate_gradient,
+line_search,descent_minimizers,iteration_controllers}.py.  Everything here is host control flow over a
+*vector protocol* (``+ - * scalar``, ``s_vdot``, ``norm``) that both ``MultiField`` and the fused
+engine's ``LatentVec`` implement; the numerics of every vector operation happen in HIP kernels.
+``ConjugateGradient`` additionally has an in-place path with device-resident scalars (one host
+synchronisation per iteration) for vectors that provide it.
+"""
+import functools
+import logging
+from time import time
+
+import numpy as np
+
+logger = logging.getLogger("nifty_amd")
+
+CONVERGED, CONTINUE, ERROR = 0, 1, 2
+
+
+# ------------------------------------------------------------------------------------------------
+# Energy protocol
+# ------------------------------------------------------------------------------------------------
+class Energy:
+    """Value, gradient and metric of a scalar function at ``position`` (reference energy.py:45-136)."""
+
+    def __init__(self, position):
+        self._position = position
+        self._gradnorm = None
+
+    def at(self, position):
+        raise NotImplementedError
+
+    @property
+    def position(self):
+        return self._position
+
+    @property
+    def value(self):
+        raise NotImplementedError
+
+    @property
+    def gradient(self):
+        raise NotImplementedError
+
+    @property
+    def gradient_norm(self):
+        if self._gradnorm is None:
+            self._gradnorm = self.gradient.norm()
+        return self._gradnorm
+
+    @property
+    def metric(self):
+        raise NotImplementedError
+
+    def apply_metric(self, x):
+        raise NotImplementedError
+
+    def longest_step(self, direction):
+        return None
+
+
+class QuadraticEnergy(Energy):
+    """E(x) = 1/2 x^T A x - b^T x   (reference quadratic_energy.py:27-78)."""
+
+    def __init__(self, position, A, b, _grad=None):
+        super().__init__(position)
+        self._A, self._b = A, b
+        if _grad is None:
+            Ax = self._A(self._position)
+            self._grad = Ax if b is None else Ax - b
+        else:
+            self._grad = _grad
+            Ax = _grad if b is None else _grad + b
+        self._value = 0.5 * np.real(self._position.s_vdot(Ax))
+        if b is not None:
+            self._value -= np.real(b.s_vdot(self._position))
+
+    def at(self, position):
+        return QuadraticEnergy(position, self._A, self._b)
+
+    def at_with_grad(self, position, grad):
+        return QuadraticEnergy(position, self._A, self._b, grad)
+
+    @property
+    def value(self):
+        return self._value
+
+    @property
+    def gradient(self):
+        return self._grad
+
+    @property
+    def metric(self):
+        return self._A
+
+    def apply_metric(self, x):
+        return self._A(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# iteration controllers
+# ------------------------------------------------------------------------------------------------
+class EnergyHistory:
+    def __init__(self):
+        self._lst = []
+
+    def append(self, x):
+        if len(x) != 2:
+            raise ValueError
+        self._lst.append((float(x[0]), float(x[1])))
+
+    def reset(self):
+        self._lst = []
+
+    def __getitem__(self, i):
+        return self._lst[i]
+
+    def __len__(self):
+        return len(self._lst)
+
+    @property
+    def time_stamps(self):
+        return [t for t, _ in self._lst]
+
+    @property
+    def energy_values(self):
+        return [e for _, e in self._lst]
+
+    def __add__(self, other):
+        if not isinstance(other, EnergyHistory):
+            return NotImplemented
+        res = EnergyHistory()
+        res._lst = self._lst + other._lst
+        return res
+
+    def __iadd__(self, other):
+        if not isinstance(other, EnergyHistory):
+            return NotImplemented
+        self._lst += other._lst
+        return self
+
+
+def _logged(fn):
+    @functools.wraps(fn)
+    def wrapper(self, energy):
+        if isinstance(self._history, EnergyHistory):
+            self._history.append((time(), energy.value))
+        return fn(self, energy)
+
+    return wrapper
+
+
+class IterationController:
+    """start(energy) / check(energy) -> CONVERGED | CONTINUE | ERROR (iteration_controllers.py:49-95)."""
+
+    CONVERGED, CONTINUE, ERROR = CONVERGED, CONTINUE, ERROR
+
+    def __init__(self):
+        self._history = None
+
+    def start(self, energy):
+        raise NotImplementedError
+
+    def check(self, energy):
+        raise NotImplementedError
+
+    def enable_logging(self):
+        if self._history is None:
+            self._history = EnergyHistory()
+
+    def disable_logging(self):
+        self._history = None
+
+    @property
+    def history(self):
+        return self._history
+
+
+class _LevelController(IterationController):
+    """Shared bookkeeping: iteration counter, convergence level, iteration limit."""
+
+    def __init__(self, convergence_level, iteration_limit, name):
+        super().__init__()
+        self._convergence_level = convergence_level
+        self._iteration_limit = iteration_limit
+        self._name = name
+
+    def _reset(self):
+        self._itcount, self._ccount = -1, 0
+
+    def _criterion(self, energy):  # -> (bool increase_level, str log)
+        raise NotImplementedError
+
+    @_logged
+    def start(self, energy):
+        self._reset()
+        self._on_start(energy)
+        return self.check.__wrapped__(self, energy)
+
+    def _on_start(self, energy):
+        pass
+
+    @_logged
+    def check(self, energy):
+        self._itcount += 1
+        inc, msg = self._criterion(energy)
+        self._ccount = self._ccount + 1 if inc else max(0, self._ccount - 1)
+        if self._name is not None:
+            logger.info(f"{self._name}: Iteration #{self._itcount} energy={energy.value:.6E} {msg} clvl={self._ccount}")
+        if self._iteration_limit is not None and self._itcount >= self._iteration_limit:
+            logger.warning(("" if self._name is None else self._name + ": ") + "Iteration limit reached. Assuming convergence")
+            return CONVERGED
+        if self._ccount >= self._convergence_level:
+            return CONVERGED
+        return CONTINUE
+
+
+class GradientNormController(_LevelController):
+    """iteration_controllers.py:170-221"""
+
+    def __init__(self, tol_abs_gradnorm=None, tol_rel_gradnorm=None, convergence_level=1, iteration_limit=None, name=None):
+        super().__init__(convergence_level, iteration_limit, name)
+        self._tol_abs, self._tol_rel = tol_abs_gradnorm, tol_rel_gradnorm
+
+    def _on_start(self, energy):
+        if self._tol_rel is not None:
+            self._tol_rel_now = self._tol_rel * energy.gradient_norm
+
+    def _criterion(self, energy):
+        inc = False
+        if self._tol_abs is not None and energy.gradient_norm <= self._tol_abs:
+            inc = True
+        if self._tol_rel is not None and energy.gradient_norm <= self._tol_rel_now:
+            inc = True
+        return inc, ""
+
+
+class GradInfNormController(_LevelController):
+    """iteration_controllers.py:242-283"""
+
+    def __init__(self, tol, convergence_level=1, iteration_limit=None, name=None):
+        super().__init__(convergence_level, iteration_limit, name)
+        self._tol = tol
+
+    def _criterion(self, energy):
+        crit = energy.gradient.norm(np.inf) / abs(energy.value)
+        return (self._tol is not None and crit <= self._tol), f"crit={crit:.2E}"
+
+
+class DeltaEnergyController(_LevelController):
+    """iteration_controllers.py:305-355 (relative energy change)."""
+
+    def __init__(self, tol_rel_deltaE, convergence_level=1, iteration_limit=None, name=None):
+        super().__init__(convergence_level, iteration_limit, name)
+        self._tol = tol_rel_deltaE
+
+    def _on_start(self, energy):
+        self._Eold = 0.0
+
+    def _criterion(self, energy):
+        E = energy.value
+        rel = abs(self._Eold - E) / max(abs(self._Eold), abs(E))
+        inc = self._itcount > 0 and rel < self._tol
+        self._Eold = E
+        return inc, f"reldiff={rel:.6E}"
+
+
+class AbsDeltaEnergyController(_LevelController):
+    """iteration_controllers.py:375-423 (absolute energy change)."""
+
+    def __init__(self, deltaE, convergence_level=1, iteration_limit=None, name=None):
+        super().__init__(convergence_level, iteration_limit, name)
+        self._deltaE = deltaE
+
+    def _on_start(self, energy):
+        self._Eold = 0.0
+
+    def _criterion(self, energy):
+        E = energy.value
+        diff = abs(self._Eold - E)
+        inc = self._itcount > 0 and diff < self._deltaE
+        self._Eold = E
+        return inc, f"diff={diff:.6E} crit={self._deltaE:.1E}"
+
+
+# ------------------------------------------------------------------------------------------------
+# conjugate gradient
+# ------------------------------------------------------------------------------------------------
+class Minimizer:
+    def __call__(self, energy, preconditioner=None):
+        raise NotImplementedError
+
+
+class _ScalarEnergyView:
+    """What a controller needs from the in-place CG state: value and gradient norm as host floats."""
+
+    def __init__(self, value, gradnorm):
+        self.value, self.gradient_norm = value, gradnorm
+
+
+class ConjugateGradient(Minimizer):
+    """Linear CG on a QuadraticEnergy (reference conjugate_gradient.py:48-126).
+
+    If the vectors implement ``cg_workspace()`` (the fused engine's LatentVec) the iteration runs in
+    place with the fused kernels nk_cg_curv / nk_cg_update / nk_cg_direction: alpha, beta, gamma and
+    the quadratic energy value stay on the device and are fetched with ONE copy per iteration.
+    """
+
+    def __init__(self, controller, nreset=20):
+        self._controller = controller
+        self._nreset = nreset
+
+    def __call__(self, energy, preconditioner=None):
+        if preconditioner is None and hasattr(energy.position, "cg_workspace") and isinstance(energy, QuadraticEnergy):
+            return self._solve_inplace(energy)
+        return self._solve_generic(energy, preconditioner)
+
+    def _solve_generic(self, energy, preconditioner):
+        controller = self._controller
+        status = controller.start(energy)
+        if status != CONTINUE:
+            return energy, status
+        r = energy.gradient
+        d = r if preconditioner is None else preconditioner(r)
+        gamma_prev = np.real(r.s_vdot(d))
+        if np.isnan(gamma_prev):
+            logger.error("Error: ConjugateGradient: previous_gamma==NaN")
+            return energy, ERROR
+        if gamma_prev == 0:
+            return energy, CONVERGED
+        since_reset = 0
+        while True:
+            q = energy.apply_metric(d)
+            curv = np.real(d.s_vdot(q))
+            if np.isnan(curv) or curv == 0.0:
+                logger.error("Error: ConjugateGradient: curv==NaN or 0")
+                return energy, ERROR
+            alpha = gamma_prev / curv
+            if alpha < 0:
+                logger.error("Error: ConjugateGradient: alpha<0.")
+                return energy, ERROR
+            since_reset += 1
+            new_pos = energy.position - alpha * d
+            if since_reset < self._nreset:
+                r = r - q * alpha
+                energy = energy.at_with_grad(new_pos, r)
+            else:
+                energy = energy.at(new_pos)
+                r = energy.gradient
+                since_reset = 0
+            s = r if preconditioner is None else preconditioner(r)
+            gamma = np.real(r.s_vdot(s))
+            if np.isnan(gamma):
+                logger.error("Error: ConjugateGradient: gamma==NaN")
+                return energy, ERROR
+            if gamma < 0:
+                logger.error("Positive definiteness of preconditioner violated!")
+                return energy, ERROR
+            if gamma == 0:
+                return energy, CONVERGED
+            status = controller.check(energy)
+            if status != CONTINUE:
+                return energy, status
+            d = d * max(0, gamma / gamma_prev) + s
+            gamma_prev = gamma
+
+    def _solve_inplace(self, energy):
+        controller = self._controller
+        status = controller.start(energy)
+        if status != CONTINUE:
+            return energy, status
+        A, b = energy._A, energy._b
+        x = energy.position.clone()
+        r = energy.gradient.clone()
+        d = r.clone()
+        ws = x.cg_workspace()
+        gamma_prev = r.s_vdot(r)
+        if np.isnan(gamma_prev):
+            return energy, ERROR
+        if gamma_prev == 0:
+            return energy, CONVERGED
+        ws.set_gamma(gamma_prev)
+        since_reset = 0
+
+        def finish(status):
+            return energy.at_with_grad(x, r), status
+
+        while True:
+            q = A(d)
+            ws.curv(d, q)
+            ws.update(x, r, d, q, b)
+            since_reset += 1
+            if since_reset >= self._nreset:
+                # periodic residual refresh (conjugate_gradient.py:103-106): r = A x - b
+                Ax = A(x)
+                r = Ax - b if b is not None else Ax
+                ws.refresh(x, r, b)
+                since_reset = 0
+            sc = ws.fetch()  # the single host synchronisation of this iteration
+            curv, gamma, alpha = sc["curv"], sc["gamma"], sc["alpha"]
+            if np.isnan(curv) or curv == 0.0 or np.isnan(alpha) or alpha < 0:
+                logger.error("Error: ConjugateGradient: bad curvature / step")
+                return finish(ERROR)
+            if np.isnan(gamma) or gamma < 0:
+                return finish(ERROR)
+            if gamma == 0:
+                return finish(CONVERGED)
+            value = 0.5 * sc["xr"] - 0.5 * sc["xb"] if b is not None else 0.5 * sc["xr"]
+            status = controller.check(_ScalarEnergyView(value, float(np.sqrt(gamma))))
+            if status != CONTINUE:
+                return finish(status)
+            ws.direction(d, r)
+
+
+# ------------------------------------------------------------------------------------------------
+# line search (strong Wolfe conditions, Nocedal & Wright alg. 3.5 / 3.6)
+# ------------------------------------------------------------------------------------------------
+class LineEnergy:
+    """Restriction of an Energy to the line position + t * direction (line_search.py:52-100)."""
+
+    def __init__(self, line_position, energy, line_direction, offset=0.0):
+        self._t = float(line_position)
+        self._dir = line_direction
+        if self._t == float(offset):
+            self._energy = energy
+        else:
+            self._energy = energy.at(position=energy.position + (self._t - float(offset)) * self._dir)
+
+    def at(self, line_position):
+        return LineEnergy(line_position, self._energy, self._dir, offset=self._t)
+
+    @property
+    def energy(self):
+        return self._energy
+
+    @property
+    def value(self):
+        return self._energy.value
+
+    @property
+    def directional_derivative(self):
+        return np.real(self._energy.gradient.s_vdot(self._dir))
+
+
+def _interp_cubic(a, fa, fpa, b, fb, c, fc):
+    """Minimiser of the cubic through (a,fa,fpa), (b,fb), (c,fc); None if it does not exist."""
+    with np.errstate(divide="raise", over="raise", invalid="raise"):
+        try:
+            db, dc = b - a, c - a
+            denom = (db * dc) ** 2 * (db - dc)
+            m = np.array([[dc * dc, -db * db], [-dc ** 3, db ** 3]])
+            A, B = m @ np.array([fb - fa - fpa * db, fc - fa - fpa * dc])
+            A, B = A / denom, B / denom
+            xmin = a + (-B + np.sqrt(B * B - 3 * A * fpa)) / (3 * A)
+        except ArithmeticError:
+            return None
+    return xmin if np.isfinite(xmin) else None
+
+
+def _interp_quadratic(a, fa, fpa, b, fb):
+    with np.errstate(divide="raise", over="raise", invalid="raise"):
+        try:
+            db = b - a * 1.0
+            B = (fb - fa - fpa * db) / (db * db)
+            xmin = a - fpa / (2.0 * B)
+        except ArithmeticError:
+            return None
+    return xmin if np.isfinite(xmin) else None
+
+
+class LineSearch:
+    """reference line_search.py:103-416"""
+
+    def __init__(self, preferred_initial_step_size=None, c1=1e-4, c2=0.9, max_step_size=1e30, max_iterations=100,
+                 max_zoom_iterations=100):
+        self.preferred_initial_step_size = preferred_initial_step_size
+        self.c1, self.c2 = float(c1), float(c2)
+        self.max_step_size = max_step_size
+        self.max_iterations = int(max_iterations)
+        self.max_zoom_iterations = int(max_zoom_iterations)
+
+    def perform_line_search(self, energy, pk, f_k_minus_1=None):
+        le0 = LineEnergy(0.0, energy, pk, 0.0)
+        cap = energy.longest_step(pk)
+        cap = self.max_step_size if cap is None else min(cap, self.max_step_size)
+        phi0, dphi0 = le0.value, le0.directional_derivative
+        if dphi0 == 0:
+            logger.warning("Directional derivative is zero; assuming convergence")
+            return energy, False
+        if dphi0 > 0:
+            logger.error("Error: search direction is not a descent direction")
+            return energy, False
+        if self.preferred_initial_step_size is not None:
+            t1 = self.preferred_initial_step_size
+        elif f_k_minus_1 is not None:
+            t1 = min(1.0, 1.01 * 2 * (phi0 - f_k_minus_1) / dphi0)
+            if t1 < 0:
+                t1 = 1.0
+        else:
+            t1 = 1.0 / pk.norm()
+        t1 = min(t1, 0.99 * cap)
+        t0, phi_t0, dphi_t0 = 0.0, phi0, dphi0
+        le1 = None
+        for it in range(1, self.max_iterations + 1):
+            if t1 == 0:
+                return le0.energy, False
+            try:
+                le1 = le0.at(t1)
+                phi1 = le1.value
+            except FloatingPointError:
+                t1 = (t0 + t1) / 2
+                continue
+            if np.isnan(phi1) or abs(phi1) > 1e100:
+                t1 = (t0 + t1) / 2
+                continue
+            if phi1 > phi0 + self.c1 * t1 * dphi0 or (phi1 >= phi_t0 and it > 1):
+                return self._zoom(t0, t1, phi0, dphi0, phi_t0, dphi_t0, phi1, le0)
+            dphi1 = le1.directional_derivative
+            if abs(dphi1) <= -self.c2 * dphi0:
+                return le1.energy, True
+            if dphi1 >= 0:
+                return self._zoom(t1, t0, phi0, dphi0, phi1, dphi1, phi_t0, le0)
+            t0, t1 = t1, min(2 * t1, cap)
+            if t1 == cap:
+                logger.warning("max step size reached")
+                return le1.energy, False
+            phi_t0, dphi_t0 = phi1, dphi1
+        logger.warning("max iterations reached")
+        return le1.energy, False
+
+    def _zoom(self, lo, hi, phi0, dphi0, phi_lo, dphi_lo, phi_hi, le0):
+        if phi_lo > phi0 + self.c1 * lo * dphi0:
+            raise ValueError("inconsistent data")
+        if dphi_lo * (hi - lo) >= 0.0:
+            raise ValueError("inconsistent data")
+        recent = phi_recent = None
+        lej = None
+        for i in range(self.max_zoom_iterations):
+            width = hi - lo
+            left, right = min(lo, hi), max(lo, hi)
+            tj = None
+            if i > 0:
+                guard = 0.2 * width
+                tj = _interp_cubic(lo, phi_lo, dphi_lo, hi, phi_hi, recent, phi_recent)
+            if i == 0 or tj is None or tj > right - guard or tj < left + guard:
+                guard_q = 0.1 * width
+                tj = _interp_quadratic(lo, phi_lo, dphi_lo, hi, phi_hi)
+                if tj is None or tj > right - guard_q or tj < left + guard_q:
+                    tj = lo + 0.5 * width
+            lej = le0.at(tj)
+            phij = lej.value
+            if phij > phi0 + self.c1 * tj * dphi0 or phij >= phi_lo:
+                recent, phi_recent = hi, phi_hi
+                hi, phi_hi = tj, phij
+            else:
+                dphij = lej.directional_derivative
+                if abs(dphij) <= -self.c2 * dphi0:
+                    return lej.energy, True
+                if dphij * width >= 0:
+                    recent, phi_recent = hi, phi_hi
+                    hi, phi_hi = lo, phi_lo
+                else:
+                    recent, phi_recent = lo, phi_lo
+                lo, phi_lo, dphi_lo = tj, phij, dphij
+        logger.warning("The line search algorithm (zoom) did not converge.")
+        return lej.energy, False
+
+
+# ------------------------------------------------------------------------------------------------
+# descent minimizers
+# ------------------------------------------------------------------------------------------------
+class DescentMinimizer(Minimizer):
+    """reference descent_minimizers.py:52-108"""
+
+    def __init__(self, controller, line_searcher=None):
+        self._controller = controller
+        self.line_searcher = LineSearch() if line_searcher is None else line_searcher
+
+    def __call__(self, energy):
+        f_prev = None
+        controller = self._controller
+        status = controller.start(energy)
+        if status != CONTINUE:
+            return energy, status
+        while True:
+            if energy.gradient_norm == 0:
+                return energy, CONVERGED
+            direction = self.get_descent_direction(energy, f_prev)
+            new_energy, success = self.line_searcher.perform_line_search(energy=energy, pk=direction, f_k_minus_1=f_prev)
+            if not success:
+                self.reset()
+            f_prev = energy.value
+            if new_energy.value > energy.value:
+                logger.error("Error: Energy has increased")
+                return energy, ERROR
+            if new_energy.value == energy.value:
+                logger.warning("Warning: Energy has not changed. Assuming convergence...")
+                return new_energy, CONVERGED
+            energy = new_energy
+            status = controller.check(energy)
+            if status != CONTINUE:
+                return energy, status
+
+    def reset(self):
+        pass
+
+    def get_descent_direction(self, energy, old_value=None):
+        raise NotImplementedError
+
+    @property
+    def controller(self):
+        return self._controller
+
+
+class SteepestDescent(DescentMinimizer):
+    def get_descent_direction(self, energy, _=None):
+        return -energy.gradient
+
+
+class NewtonCG(DescentMinimizer):
+    """Inexact Newton: CG on metric * delta = gradient (reference descent_minimizers.py:166-210)."""
+
+    def __init__(self, controller, napprox=0, line_searcher=None, name=None, nreset=20, max_cg_iterations=200,
+                 energy_reduction_factor=0.1, enable_logging=False):
+        if line_searcher is None:
+            line_searcher = LineSearch(preferred_initial_step_size=1.0)
+        super().__init__(controller, line_searcher)
+        if napprox > 1:
+            raise NotImplementedError("napprox preconditioning is out of scope (SURVEY 8f rank 4)")
+        self._name, self._nreset = name, nreset
+        self._max_cg_iterations = max_cg_iterations
+        self._alpha = energy_reduction_factor
+        self._history = EnergyHistory() if enable_logging else None
+
+    def get_descent_direction(self, energy, old_value=None):
+        if old_value is None:
+            ic = GradientNormController(iteration_limit=5)
+        else:
+            ic = AbsDeltaEnergyController(self._alpha * (old_value - energy.value),
+                                          iteration_limit=self._max_cg_iterations, name=self._name)
+        if self._history is not None:
+            ic.enable_logging()
+        g = energy.gradient
+        # QuadraticEnergy(0*pos, metric, gradient): A(0) = 0 exactly, so the start gradient is -g and the
+        # reference's metric application to the zero vector is skipped.
+        zero = energy.position * 0.0
+        quad = QuadraticEnergy(zero, energy.metric, g, _grad=-g)
+        quad, conv = ConjugateGradient(ic, nreset=self._nreset)(quad)
+        if self._history is not None:
+            self._history += ic.history
+        if conv == ERROR:
+            raise ValueError("Cannot find descent direction")
+        return -quad.position
+
+    @property
+    def inversion_history(self):
+        return self._history

@@ -1,0 +1,130 @@
+"""GPU parity tests of the fused engine (HIP path through the C ABI) against the oracle and the golden
+vectors generated from the reference.  Tolerance: 1e-5 relative in fp64 is the north-star bar; the
+checks below are far tighter wherever the arithmetic allows (documented per assertion)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nifty_oracle as orc
+from tests import goldenlib as gl
+
+pytestmark = pytest.mark.gpu
+
+NON_GEO = ("g1d", "p2d", "g3d")
+
+
+def _model(z, dtype=torch.float64):
+    from nifty_amd.engine import FusedModel
+
+    m = gl.meta(z)
+    kw = dict(offset_mean=2.0, likelihood=m["kind"], nonlin=m["nonlin"], dtype=dtype, device="cuda:0")
+    if m["kind"] == "gaussian":
+        ic = z["icov"]
+        kw["icov"] = float(ic) if ic.shape == () else ic
+    model = FusedModel(m["shape"], m["distances"], data=z["data"], **kw)
+    return m, model
+
+
+def _lv(model, d):
+    from nifty_amd.engine import LatentVec
+
+    return LatentVec.from_dict(model, d)
+
+
+@pytest.mark.parametrize("case", gl.MODEL_CASES)
+def test_signal_and_hamiltonian_vs_reference_golden(case):
+    z = gl.load("model_" + case)
+    m, model = _model(z)
+    x, v = gl.latent(z, "x"), gl.latent(z, "v")
+    xl, vl = _lv(model, x), _lv(model, v)
+    sig = model.signal(xl).cpu().numpy()
+    g, _ = orc.NONLIN[m["nonlin"]]
+    assert gl.relerr(sig, g(z["cf"])) < 1e-11
+    lp = model.linearize(xl)
+    hv = float(lp.value.item())
+    assert abs(hv - float(z["ham_value"])) < 1e-11 * abs(float(z["ham_value"]))
+    assert gl.lat_relerr(lp.grad.to_dict(), gl.latent(z, "ham_grad")) < 1e-10
+    mv = model.metric(lp, vl).to_dict()
+    assert gl.lat_relerr(mv, gl.latent(z, "ham_metric_v")) < 1e-10
+
+
+@pytest.mark.parametrize("case", NON_GEO + ("g2d_dist",))
+def test_mgvi_samples_kl_newton_vs_reference_golden(case):
+    from nifty_amd import random
+    from nifty_amd.engine import FusedKL, draw_samples
+    from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG
+
+    z = gl.load("model_" + case)
+    m, model = _model(z)
+    x, v = gl.latent(z, "x"), gl.latent(z, "v")
+    xl, vl = _lv(model, x), _lv(model, v)
+    random.push_sseq_from_seed(m["seed"] + 1)
+    try:
+        res, negs, n_total = draw_samples(model, xl, m["n_samples"], True,
+                                          lambda: AbsDeltaEnergyController(0.05, iteration_limit=m["sampling_limit"]))
+    finally:
+        random.pop_sseq()
+    assert n_total == int(z["n_residuals"])
+    for i, (r, neg) in enumerate(zip(res, negs)):
+        rd = r.to_dict()
+        if neg:
+            rd = {k: -a for k, a in rd.items()}
+        assert gl.lat_relerr(rd, gl.latent(z, f"residual{i}")) < 1e-8, i
+    kl = FusedKL(model, xl, res, negs)
+    assert abs(kl.value - float(z["kl_value"])) < 1e-9 * abs(float(z["kl_value"]))
+    assert gl.lat_relerr(kl.gradient.to_dict(), gl.latent(z, "kl_grad")) < 1e-8
+    assert gl.lat_relerr(kl.apply_metric(vl).to_dict(), gl.latent(z, "kl_metric_v")) < 1e-8
+    mini = NewtonCG(AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=8)
+    kl2, _ = mini(kl)
+    assert abs(kl2.value - float(z["kl_min_value"])) < 1e-7 * abs(float(z["kl_min_value"]))
+    assert gl.lat_relerr(kl2.position.to_dict(), gl.latent(z, "kl_min_pos")) < 1e-6
+
+
+@pytest.mark.parametrize("shape,kind,nonlin", [((256,), "gaussian", None), ((128, 64), "poisson", "exp"),
+                                               ((32, 16, 64), "gaussian", "sigmoid"), ((64, 64, 64), "gaussian", None)])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_engine_vs_oracle_seeded(shape, kind, nonlin, dtype):
+    """Same seeded inputs through the HIP engine and the numpy oracle; fp32 fields use fp64 accumulators."""
+    from nifty_amd.engine import FusedModel, LatentVec
+
+    rng = np.random.default_rng(11)
+    cf = orc.CFModel(shape, None, orc.CFParams(offset_mean=1.5))
+    truth = cf.draw_latent(rng)
+    s = cf.forward(truth)
+    g, _ = orc.NONLIN[nonlin]
+    if kind == "gaussian":
+        data = g(s) + 0.1 * rng.normal(size=shape)
+        lh = orc.Likelihood("gaussian", data, icov=100.0, nonlin=nonlin)
+        model = FusedModel(shape, offset_mean=1.5, likelihood="gaussian", data=data, icov=100.0, nonlin=nonlin, dtype=dtype)
+    else:
+        data = rng.poisson(g(s)).astype(np.int64)
+        lh = orc.Likelihood("poisson", data, nonlin=nonlin)
+        model = FusedModel(shape, offset_mean=1.5, likelihood="poisson", data=data, nonlin=nonlin, dtype=dtype)
+    x = {k: 0.3 * a for k, a in cf.draw_latent(rng).items()}
+    v = cf.draw_latent(rng)
+    if dtype == torch.float32:  # identical inputs for both paths
+        x["xi"] = x["xi"].astype(np.float32).astype(np.float64)
+        v["xi"] = v["xi"].astype(np.float32).astype(np.float64)
+    lin = orc.Linearized(cf, lh, x)
+    val, grad = lin.value_grad()
+    mv = lin.metric(v)
+    xl, vl = LatentVec.from_dict(model, x), LatentVec.from_dict(model, v)
+    lp = model.linearize(xl)
+    tol = 1e-10 if dtype == torch.float64 else 2e-4
+    assert abs(float(lp.value.item()) - val) < tol * abs(val)
+    assert gl.lat_relerr(lp.grad.to_dict(), grad) < tol
+    assert gl.lat_relerr(model.metric(lp, vl).to_dict(), mv) < tol
+    # adjointness of the metric (reference extra.py:220-231): <u, M v> == <M u, v>
+    u = LatentVec.from_dict(model, cf.draw_latent(rng))
+    a = u.s_vdot(model.metric(lp, vl))
+    b = model.metric(lp, u).s_vdot(vl)
+    assert abs(a - b) < (1e-10 if dtype == torch.float64 else 1e-4) * max(abs(a), abs(b))
+
+
+def test_engine_rejects_cpu():
+    from nifty_amd.engine import FusedModel
+
+    with pytest.raises(RuntimeError):
+        FusedModel((16,), data=np.zeros(16), device="cpu")
