@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""bench.py -- MGVI iterations/s of the fused MI355X path on BASELINE.json's headline workload.
+
+A "step" is ONE global MGVI iteration (the body of the reference's optimize_kl loop,
+nifty/cl/minimization/optimize_kl.py:357-451, without I/O): draw 8 mirrored MGVI samples (4 CG solves
+of (J^T N^-1 J + 1) y = b) and minimise the sampled KL with NewtonCG, with the fixed recipe of
+SURVEY 8(d): ic_sampling = AbsDeltaEnergyController(0.05, iteration_limit=20), kl_minimizer =
+NewtonCG(AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=3), max_cg_iterations=20).
+Workload (C5): 1024^3 RGSpace CorrelatedField + Gaussian likelihood, fp32 fields with fp64
+accumulators, 8 samples in total; with --gpus N the samples are sharded over the ranks (strong
+scaling, one all-reduce of the latent vector per KL value/gradient and per CG iteration).  Inputs are
+synthetic, generated on the device before the timed region.
+
+Prints ONE JSON line (rank 0).  NK_BENCH_SHAPE=256,256,256 / NK_BENCH_DTYPE=f64 override the workload
+for quick checks (the line then names that workload and is not the headline number).
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from nifty_amd import _lib as L  # noqa: E402
+from nifty_amd import parallel, random  # noqa: E402
+from nifty_amd.engine import FusedModel, LatentVec, mgvi_iteration  # noqa: E402
+from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+KERNEL_NAMES = {0: "k_pass1d", 1: "k_passA", 2: "k_passB", 3: "k_passC", 4: "k_passD"}
+PRO_NAMES = {0: "plain", 1: "amp", 2: "amp_jvp", 3: "mul"}
+EPI_NAMES = {0: "affine", 1: "mul", 2: "vjp", 3: "likelihood", 4: "nonlin"}
+
+
+def algorithmic_bytes(kernel, pro, epi, N, b, const_mid):
+    """Algorithmic HBM bytes of ONE launch of a transform pass kernel (DESIGN.md 'roofline').
+
+    Every pass reads and writes the array once (2*N*b, SURVEY 8(d) per-axis-pass model); fused operands
+    are counted once where they are consumed: prologue operands in pass A, epilogue operands in pass C.
+    Optional operands (addend / accumulate in the VJP epilogue) are NOT counted (conservative).
+    """
+    if kernel == 4:  # pass D touches 2 planes only
+        return 0.0
+    total = 2.0 * N * b
+    if kernel in (0, 1):
+        total += {0: 0, 1: 4 * N, 2: N * b + 4 * N, 3: N * b}[pro]
+    if kernel in (0, 3):
+        total += {0: 0, 1: 0 if const_mid else N * b, 2: N * b + 4 * N, 3: N * b + (0 if const_mid else N * b),
+                  4: 0}[epi]
+    return total
+
+
+def collect_profile():
+    lib = L.load()
+    ms = (ctypes.c_double * 125)()
+    cnt = (ctypes.c_int64 * 125)()
+    lib.nk_profile_collect(ms, cnt)
+    out = {}
+    for key in range(125):
+        if cnt[key]:
+            out[(key // 25, (key % 25) // 5, key % 5)] = (ms[key], cnt[key])
+    return out
+
+
+def cpu_baseline(counts_per_step, shape_full, sample_shape=(128, 128, 128), budget_s=20.0):
+    """Oracle (numpy + scipy.fft restatement of the reference path) timed on the host cores on a bounded
+    sample, extrapolated with N log N to the full workload.  A reported baseline, not a target."""
+    from oracle import nifty_oracle as orc
+
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(0)
+    cf = orc.CFModel(sample_shape, None, orc.CFParams(offset_mean=2.0), workers=cores)
+    x = {k: 0.1 * v for k, v in cf.draw_latent(rng).items()}
+    v = cf.draw_latent(rng)
+    data = cf.forward(x) + 0.1 * rng.normal(size=sample_shape)
+    lh = orc.Likelihood("gaussian", data, icov=100.0)
+    lin = orc.Linearized(cf, lh, x)
+    lin.metric(v)
+    t_met, t_vg, n = 0.0, 0.0, 0
+    t_start = time.perf_counter()
+    while time.perf_counter() - t_start < budget_s or n < 2:
+        t0 = time.perf_counter()
+        lin.metric(v)
+        t1 = time.perf_counter()
+        orc.Linearized(cf, lh, x).value_grad()
+        t2 = time.perf_counter()
+        t_met += t1 - t0
+        t_vg += t2 - t1
+        n += 1
+    t_met, t_vg = t_met / n, t_vg / n
+    Ns, Nf = float(np.prod(sample_shape)), float(np.prod(shape_full))
+    scale = (Nf * math.log2(Nf)) / (Ns * math.log2(Ns))
+    sec_per_step = scale * (counts_per_step["metric"] * t_met + counts_per_step["value_grad"] * t_vg)
+    return dict(value=1.0 / sec_per_step, unit="MGVI iters/s", cores=cores, kind="port",
+                sample=(f"oracle (numpy+scipy.fft, workers={cores}) metric apply {t_met * 1e3:.1f} ms and value+gradient "
+                        f"{t_vg * 1e3:.1f} ms per sample at {'x'.join(map(str, sample_shape))} fp64 ({n} reps), "
+                        f"extrapolated x{scale:.0f} (N log N) to {'x'.join(map(str, shape_full))} and multiplied by the "
+                        f"{counts_per_step['metric']:.0f} metric applies + {counts_per_step['value_grad']:.0f} "
+                        "value/gradient evaluations one GPU step executed"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    comm, local_rank = parallel.init("nccl")
+    rank = 0 if comm is None else comm.rank
+    world = 1 if comm is None else comm.size
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    shape = tuple(int(s) for s in os.environ.get("NK_BENCH_SHAPE", "1024,1024,1024").split(","))
+    dt_name = os.environ.get("NK_BENCH_DTYPE", "f32")
+    dtype = torch.float32 if dt_name == "f32" else torch.float64
+    b = 4 if dtype == torch.float32 else 8
+    N = int(np.prod(shape))
+    n_pairs = 4  # mirrored -> 8 samples in total
+    noise_var = 0.01
+
+    L.load()
+    model = FusedModel(shape, offset_mean=2.0, offset_std=(1e-1, 3e-2), fluctuations=(1.0, 5e-1),
+                       loglogavgslope=(-3.0, 2e-1), flexibility=(1.0, 2e-1), asperity=(5e-1, 5e-2),
+                       likelihood="gaussian", icov=1.0 / noise_var, dtype=dtype, device=device)
+    # synthetic data: d = cf(truth) + noise, identical on all ranks (same device seed)
+    gen = torch.Generator(device=device).manual_seed(42)
+    truth = model.draw_prior(gen)
+    data = model.signal(truth)
+    data.add_(torch.randn(shape, dtype=dtype, device=device, generator=gen), alpha=math.sqrt(noise_var))
+    model.set_data(data, 1.0 / noise_var)
+    del truth
+    mean = 0.1 * model.draw_prior(gen)
+    rng_draws = torch.Generator(device=device).manual_seed(1234 + rank)
+    random.push_sseq_from_seed(42)
+
+    def step(mean):
+        ic = lambda: AbsDeltaEnergyController(0.05, iteration_limit=20)  # noqa: E731
+        mini = NewtonCG(AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=3), max_cg_iterations=20)
+        new_mean, kl = mgvi_iteration(model, mean, n_pairs, ic, mini, mirror_samples=True, comm=comm,
+                                      device_rng=rng_draws)
+        return new_mean, kl.value
+
+    def sync():
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        mean, _ = step(mean)
+    model.counters = {k: 0 for k in model.counters}
+    lib = L.load()
+    lib.nk_profile_enable(1)
+    collect_profile()
+    sync()
+    t0 = time.perf_counter()
+    energy = float("nan")
+    for _ in range(args.steps):
+        mean, energy = step(mean)
+    sync()
+    elapsed = time.perf_counter() - t0
+    lib.nk_profile_enable(0)
+    prof = collect_profile()
+    if comm is not None:
+        elapsed = comm.max_float(elapsed, device)
+    ms_per_step = 1e3 * elapsed / args.steps
+    counts = {k: v / args.steps for k, v in model.counters.items()}
+
+    if rank == 0:
+        # dominant transform pass kernel of this rank, live HIP-event timing over the timed region
+        by_kernel = {}
+        for (kern, pro, epi), (ms, cnt) in prof.items():
+            ent = by_kernel.setdefault(kern, dict(ms=0.0, cnt=0, bytes=0.0))
+            ent["ms"] += ms
+            ent["cnt"] += cnt
+            ent["bytes"] += cnt * algorithmic_bytes(kern, pro, epi, N, b, model.const_mid)
+        roofline = None
+        if by_kernel:
+            kern = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
+            ent = by_kernel[kern]
+            avg_ms = ent["ms"] / ent["cnt"]
+            achieved = ent["bytes"] / ent["cnt"] / (avg_ms * 1e-3) / 1e9
+            roofline = dict(bound="hbm", kernel=KERNEL_NAMES[kern], achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+                            unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                            avg_launch_ms=round(avg_ms, 4), launches=int(ent["cnt"]),
+                            algorithmic_bytes_per_launch=ent["bytes"] / ent["cnt"],
+                            all_pass_kernels={KERNEL_NAMES[k]: dict(ms_total=round(v["ms"], 2), launches=int(v["cnt"]),
+                                                                    GBps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
+                                              for k, v in sorted(by_kernel.items())})
+        # whole-step algorithmic bytes: B_met, B_vg per sample evaluation on this rank
+        D = len(shape)
+        B_met = (4 * D + 4) * N * b + 8 * N
+        B_vg = (4 * D + 3) * N * b + 8 * N
+        step_bytes = counts["metric"] * B_met + counts["value_grad"] * B_vg
+        line = {
+            "metric": "MGVI iters/sec on 1024^3 RGSpace CorrelatedField, 8 samples; achieved HBM GB/s",
+            "value": args.steps / elapsed,
+            "unit": "MGVI iters/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32" if dtype == torch.float32 else "f64",
+            "data": "synthetic",
+            "config": {"workload": f"C5: {'x'.join(map(str, shape))} RGSpace CorrelatedField + Gaussian likelihood, "
+                                   f"{2 * n_pairs} mirrored MGVI samples, {dt_name} fields / fp64 accumulators, "
+                                   "sampling CG limit 20, NewtonCG 3 steps x <=20 CG iterations",
+                       "samples_total": 2 * n_pairs, "parallelism": f"sample-sharded x{world}",
+                       "rng": "device generator for the synthetic noise draws (parity tests use the reference's numpy PCG64 streams)"},
+            "final_kl_energy": energy,
+            "per_step_counts_rank0": counts,
+            "step_algorithmic_GBps_rank0": step_bytes / (ms_per_step * 1e-3) / 1e9,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(counts, shape)
+            except Exception as exc:  # the baseline must never take the bench line down
+                line["cpu_baseline"] = {"error": repr(exc)}
+        print(json.dumps(line))
+    if comm is not None:
+        comm.barrier()
+
+
+if __name__ == "__main__":
+    main()

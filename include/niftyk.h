@@ -103,6 +103,13 @@ int nk_hartley_fused(const nk_plan* plan, const nk_fuse* fuse, int convention, v
 int nk_fftn(const nk_plan* plan, const void* in, void* out, int inverse, double scale, void* workspace,
             void* stream);
 
+/* live profiling for bench.py: when enabled every transform pass kernel launch is bracketed by HIP events on
+ * its launch stream; nk_profile_collect synchronises and returns summed milliseconds and launch counts in
+ * ms[125] / count[125], index = kernel*25 + prologue*5 + epilogue (kernel: 0 pass1d, 1 passA, 2 passB,
+ * 3 passC, 4 passD) and resets the record. */
+int nk_profile_enable(int on);
+int nk_profile_collect(double* ms, int64_t* count);
+
 /* ---- reductions: replace ducc_dispatch.vdot / AnyArray.vdot / norm / sum
  *      (nifty/cl/ducc_dispatch.py:145-150, any_array.py:544-552).  fp64 accumulation for both dtypes;
  *      result is written to a DEVICE double (no host sync).  `result` must be zeroed by the caller

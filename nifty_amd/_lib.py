@@ -41,6 +41,8 @@ SIGNATURES = {
     "nk_hartley": (_i, [_vp, _vp, _vp, _d, _i, _vp, _vp]),
     "nk_hartley_fused": (_i, [_vp, ctypes.POINTER(Fuse), _i, _vp, _vp]),
     "nk_fftn": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp]),
+    "nk_profile_enable": (_i, [_i]),
+    "nk_profile_collect": (_i, [_vp, _vp]),
     "nk_vdot": (_i, [_i64, _vp, _vp, _i, _vp, _i, _vp]),
     "nk_sum": (_i, [_i64, _vp, _i, _vp, _i, _vp]),
     "nk_binary": (_i, [_i, _i64, _vp, _d, _vp, _d, _vp, _i, _vp]),

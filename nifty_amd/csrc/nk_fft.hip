@@ -10,6 +10,85 @@
 #include "nk_util.h"
 
 // ------------------------------------------------------------------------------------------------
+// optional live profiling: HIP events around every pass-kernel launch, on the launch stream
+// ------------------------------------------------------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec {
+  hipEvent_t e0, e1;
+  int key;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+std::mutex g_prof_mu;
+constexpr size_t NK_PROF_MAX = 1 << 17;
+
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+struct ProfScope {
+  hipStream_t st;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int key;
+  bool on;
+  ProfScope(hipStream_t s, int kernel, int pro, int epi) : st(s), key(kernel * 25 + pro * 5 + epi), on(g_prof_on) {
+    if (!on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_recs.size() >= NK_PROF_MAX) {
+      on = false;
+      return;
+    }
+    e0 = prof_event();
+    e1 = prof_event();
+    if (!e0 || !e1) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(e0, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(e1, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_recs.push_back(ProfRec{e0, e1, key});
+  }
+};
+}  // namespace
+
+extern "C" int nk_profile_enable(int on) {
+  g_prof_on = on != 0;
+  return NK_OK;
+}
+
+// ms[125], count[125] indexed by kernel*25 + pro*5 + epi  (kernel: 0 pass1d, 1 passA, 2 passB, 3 passC, 4 passD)
+extern "C" int nk_profile_collect(double* ms, int64_t* count) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (int i = 0; i < 125; ++i) ms[i] = 0.0, count[i] = 0;
+  for (ProfRec& r : g_prof_recs) {
+    float t = 0.f;
+    hipError_t e = hipEventSynchronize(r.e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, r.e0, r.e1);
+    if (e == hipSuccess && r.key >= 0 && r.key < 125) {
+      ms[r.key] += t;
+      count[r.key] += 1;
+    }
+    g_prof_pool.push_back(r.e0);
+    g_prof_pool.push_back(r.e1);
+  }
+  g_prof_recs.clear();
+  return NK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -330,17 +409,22 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
   const int64_t blocks_a = (pa.nlines + pa.tl.tile - 1) / pa.tl.tile;
   if (blocks_a > 0x7fffffffLL) return nk_set_error(NK_ERR_UNSUPPORTED, "too many lines for one launch");
   if (hp.g.ndim == 1) {
+    ProfScope ps(st, 0, f.pro, f.epi);
     hipLaunchKernelGGL(k_pass1d<T>, dim3((unsigned)blocks_a), dim3(hp.threads_a), hp.lds_a, st, pa, f, tw_a, twr);
     return nk_check_launch("k_pass1d");
   }
   if (!workspace) return nk_set_error(NK_ERR_INVALID, "nk_hartley: workspace required for ndim >= 2");
   C2<T>* work = (C2<T>*)workspace;
   C2<T>* scratch = (C2<T>*)((char*)workspace + (hp.work_bytes + 255) / 256 * 256);
-  hipLaunchKernelGGL(k_passA<T>, dim3((unsigned)blocks_a), dim3(hp.threads_a), hp.lds_a, st, pa, f, tw_a, twr, work);
+  {
+    ProfScope ps(st, 1, f.pro, f.epi);
+    hipLaunchKernelGGL(k_passA<T>, dim3((unsigned)blocks_a), dim3(hp.threads_a), hp.lds_a, st, pa, f, tw_a, twr, work);
+  }
   int rc = nk_check_launch("k_passA");
   if (rc != NK_OK) return rc;
   if (hp.g.ndim == 3) {
     const int64_t blocks_b = hp.pb.outer * hp.pb.tiles_per_slab;
+    ProfScope ps(st, 2, f.pro, f.epi);
     hipLaunchKernelGGL(k_passB<T>, dim3((unsigned)blocks_b), dim3(hp.threads_b), hp.lds_b, st, hp.pb,
                        (const C2<T>*)P->d_tw_b, work);
     rc = nk_check_launch("k_passB");
@@ -349,13 +433,19 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
   NkPassS pc = hp.pc;
   pc.g.sign = pa.g.sign;
   const int64_t blocks_c = pc.outer * pc.tiles_per_slab;
-  hipLaunchKernelGGL(k_passC<T>, dim3((unsigned)blocks_c), dim3(hp.threads_c), hp.lds_c, st, pc, f,
-                     (const C2<T>*)P->d_tw_c, (const C2<T>*)work, scratch);
+  {
+    ProfScope ps(st, 3, f.pro, f.epi);
+    hipLaunchKernelGGL(k_passC<T>, dim3((unsigned)blocks_c), dim3(hp.threads_c), hp.lds_c, st, pc, f,
+                       (const C2<T>*)P->d_tw_c, (const C2<T>*)work, scratch);
+  }
   rc = nk_check_launch("k_passC");
   if (rc != NK_OK) return rc;
   const int64_t total_d = (int64_t)hp.g.batch * hp.g.nm * hp.g.na;
-  hipLaunchKernelGGL(k_passD<T>, dim3((unsigned)((total_d + 255) / 256)), dim3(256), 0, st, pc.g, f,
-                     (const C2<T>*)scratch, total_d);
+  {
+    ProfScope ps(st, 4, f.pro, f.epi);
+    hipLaunchKernelGGL(k_passD<T>, dim3((unsigned)((total_d + 255) / 256)), dim3(256), 0, st, pc.g, f,
+                       (const C2<T>*)scratch, total_d);
+  }
   return nk_check_launch("k_passD");
 }
 
