@@ -1,7 +1,35 @@
 """nifty_amd -- MI355X-native implementation of the nifty.cl MGVI/geoVI hot path.
 
-Host code is Python on PyTorch-ROCm tensors; all numerics on device Fields run in hand-written
-HIP kernels (libniftyk, C ABI in include/niftyk.h) -- there is no CPU or eager-PyTorch fallback
-for device data.
+``import nifty_amd as ift`` exposes the names of ``nifty.cl`` that the path needs (domains, Field /
+MultiField, the operator algebra, energies, minimizers, CorrelatedFieldMaker, SampledKLEnergy,
+optimize_kl).  Host code is Python on PyTorch-ROCm tensors; all numerics on device Fields run in
+hand-written HIP kernels (libniftyk, C ABI in include/niftyk.h) -- there is no CPU or eager-PyTorch
+fallback for device data.
 """
 __version__ = "0.1.0"
+
+from . import config, parallel, random  # noqa: F401
+from .correlated_fields import (CorrelatedFieldMaker, CorrelatedFieldOperator, LognormalTransform,  # noqa: F401
+                                NormalTransform, SimpleCorrelatedField)
+from .domains import (DomainTuple, MultiDomain, PowerSpace, RGSpace, StructuredDomain, UnstructuredDomain,  # noqa: F401
+                      makeDomain)
+from .energy_operators import (EnergyOperator, GaussianEnergy, LikelihoodEnergyOperator, PoissonianEnergy,  # noqa: F401
+                               QuadraticFormOperator, Squared2NormOperator, StandardHamiltonian)
+from .field import Field, MultiField, device_available, from_random, full, is_fieldlike, makeField  # noqa: F401
+from .kl import (EnergyAdapter, ResidualSampleList, SampledKLEnergy, SampledKLEnergyClass, SampleList,  # noqa: F401
+                 draw_samples)
+from .minimization import (AbsDeltaEnergyController, ConjugateGradient, DeltaEnergyController, DescentMinimizer,  # noqa: F401
+                           Energy, EnergyHistory, GradientNormController, GradInfNormController, IterationController,
+                           LineSearch, NewtonCG, QuadraticEnergy, SteepestDescent)
+from .operators import (Adder, BlockDiagonalOperator, ChainOperator, ContractionOperator, DiagonalOperator,  # noqa: F401
+                        DOFDistributor, EndomorphicOperator, FFTOperator, FieldAdapter, HarmonicTransformOperator,
+                        HartleyOperator, Linearization, LinearOperator, NullOperator, Operator, OperatorAdapter,
+                        PowerDistributor, Realizer, SamplingEnabler, SandwichOperator, ScalingOperator, SumOperator,
+                        Variable, VdotOperator, ducktape, makeOp)
+from .optimize_kl import optimize_kl  # noqa: F401
+from .parallel import shareRange  # noqa: F401
+
+
+def set_nthreads(n):
+    """Accepted for source compatibility with nifty.cl (ducc_dispatch.py:35-46); the device kernels ignore it."""
+    return None

@@ -1,0 +1,257 @@
+"""Likelihood energies and the standard Hamiltonian.
+
+Counterpart of reference nifty/cl/operators/energy_operators.py: EnergyOperator (:36-41),
+LikelihoodEnergyOperator (:44-164), _LikelihoodChain (:166-208), Squared2NormOperator (:306-327),
+QuadraticFormOperator (:330-352), GaussianEnergy (:517-595), PoissonianEnergy (:617-640) and
+StandardHamiltonian (:890-931).  Other likelihoods of the reference are out of scope.
+"""
+import numpy as np
+
+from .domains import DomainTuple, MultiDomain, makeDomain
+from .field import Field, MultiField
+from .operators import (Adder, EndomorphicOperator, LinearOperator, Linearization, Operator, SamplingEnabler,
+                        SandwichOperator, ScalingOperator, VdotOperator, _OpChain, _same_domain, is_linearization,
+                        is_operator, makeOp)
+
+
+class EnergyOperator(Operator):
+    """Operator with scalar target."""
+
+    _target = DomainTuple.scalar_domain()
+
+
+class LikelihoodEnergyOperator(EnergyOperator):
+    """Energy with a data residual and a Fisher metric in data space."""
+
+    def __init__(self, data_residual, sqrt_data_metric_at):
+        if data_residual is not None and not is_operator(data_residual):
+            raise TypeError(f"{data_residual} is not an operator")
+        self._res = data_residual
+        self._sqrt_data_metric_at = sqrt_data_metric_at
+        self._name = None
+
+    def normalized_residual(self, x):
+        return (self._sqrt_data_metric_at(x) @ self._res).force(x)
+
+    @property
+    def data_domain(self):
+        return None if self._res is None else self._res.target
+
+    def get_transformation(self):
+        raise NotImplementedError("`get_transformation` not implemented (yet) for this operator")
+
+    def __matmul__(self, other):
+        return _LikelihoodChain(self, other)
+
+    def __rmatmul__(self, other):
+        return _LikelihoodChain(other, self)
+
+    def get_metric_at(self, x):
+        dtp, f = self.get_transformation()
+        bun = f(Linearization.make_var(x)).jac
+        return SandwichOperator.make(bun, sampling_dtype=dtp)
+
+    @property
+    def name(self):
+        return self._name
+
+    @name.setter
+    def name(self, x):
+        self._name = x
+
+
+class _LikelihoodChain(LikelihoodEnergyOperator):
+    """likelihood @ model  (or scalar @ likelihood)."""
+
+    def __init__(self, op1, op2):
+        self._op = _OpChain.make((op1, op2))
+        self._domain = self._op.domain
+        if isinstance(op1, ScalingOperator):
+            res, sqrt_met = op2._res, op2._sqrt_data_metric_at
+        elif op1._res is None:
+            res = sqrt_met = None
+        else:
+            if op2.target is not op1._res.domain:
+                raise NotImplementedError("likelihood chains need model.target == data-residual domain "
+                                          "(PartialExtractor is not implemented)")
+            res = op1._res @ op2
+
+            def sqrt_met(x, a=op1, b=op2):
+                return a._sqrt_data_metric_at(b.force(x))
+        super().__init__(res, sqrt_met)
+        self.name = (op2 if isinstance(op1, ScalingOperator) else op1).name
+
+    @property
+    def likelihood(self):
+        ops = self._op._ops
+        return ops[1] if isinstance(ops[0], ScalingOperator) else ops[0]
+
+    @property
+    def model(self):
+        """The operator chain feeding the likelihood (used by the fusion pass of optimize_kl)."""
+        ops = self._op._ops
+        ii = 2 if isinstance(ops[0], ScalingOperator) else 1
+        return _OpChain.make(ops[ii:]) if len(ops) > ii else None
+
+    def get_transformation(self):
+        ops = self._op._ops
+        scaled = isinstance(ops[0], ScalingOperator)
+        ii = 1 if scaled else 0
+        tr = ops[ii].get_transformation()
+        if tr is None:
+            return tr
+        dtype, trafo = tr
+        if scaled:
+            trafo = trafo.scale(np.sqrt(ops[0]._factor))
+        return dtype, _OpChain.make((trafo,) + tuple(ops[ii + 1:]))
+
+    def apply(self, x):
+        self._check_input(x)
+        return self._op(x)
+
+    def __repr__(self):
+        return repr(self._op)
+
+
+class Squared2NormOperator(EnergyOperator):
+    def __init__(self, domain):
+        self._domain = domain
+
+    def apply(self, x):
+        self._check_input(x)
+        if not is_linearization(x):
+            return x.vdot(x).at(x.device_id)
+        res = x.val.vdot(x.val).at(x.device_id)
+        return x.new(res, VdotOperator(x.val * 2.0))
+
+
+class QuadraticFormOperator(EnergyOperator):
+    def __init__(self, endo):
+        if not isinstance(endo, EndomorphicOperator):
+            raise TypeError(f"op must be an EndomorphicOperator.\nGot: {endo}")
+        self._op = endo
+        self._domain = endo.domain
+
+    def apply(self, x):
+        self._check_input(x)
+        if not is_linearization(x):
+            return (x.vdot(self._op(x)) * 0.5).at(x.device_id)
+        tmp = self._op(x.val)
+        res = (x.val.vdot(tmp) * 0.5).at(x.device_id)
+        return x.new(res, VdotOperator(tmp))
+
+
+class GaussianEnergy(LikelihoodEnergyOperator):
+    """E(s) = 1/2 (s - d)^dagger N^-1 (s - d)."""
+
+    def __init__(self, data=None, inverse_covariance=None, domain=None, sampling_dtype=None):
+        if inverse_covariance is not None and not isinstance(inverse_covariance, LinearOperator):
+            raise TypeError(f"inverse_covariance needs to be either None or a LinearOperator, got: {inverse_covariance}")
+        if data is not None and not isinstance(data, (Field, MultiField)):
+            raise TypeError(f"data needs to be a (Multi)Field or None, got: {data}")
+        dom = None
+        for cand in (None if inverse_covariance is None else inverse_covariance.domain,
+                     None if data is None else data.domain, None if domain is None else makeDomain(domain)):
+            if cand is None:
+                continue
+            if dom is not None:
+                _same_domain(dom, makeDomain(cand))
+            dom = makeDomain(cand)
+        if dom is None:
+            raise ValueError("no domain given")
+        self._domain = dom
+        if inverse_covariance is None:
+            self._op = Squared2NormOperator(self._domain).scale(0.5)
+            dt = sampling_dtype if data is None else data.dtype
+            self._icov = ScalingOperator(self._domain, 1.0, dt)
+        else:
+            self._op = QuadraticFormOperator(inverse_covariance)
+            self._icov = inverse_covariance
+        self._data = data
+        res = Operator.identity_operator(self._domain) if data is None else Adder(data, neg=True)
+        super().__init__(res, lambda x: self.get_metric_at(x).get_sqrt())
+
+    def apply(self, x):
+        self._check_input(x)
+        if self._data is not None and self._data.device_id != x.device_id:
+            self._data = self._data.at(x.device_id)
+        residual = x if self._data is None else x - self._data
+        res = self._op(residual)
+        if is_linearization(x) and x.want_metric:
+            return res.add_metric(self._icov)
+        return res
+
+    def get_metric_at(self, x):
+        return self._icov
+
+    def get_transformation(self):
+        return self._icov.sampling_dtype, self._icov.get_sqrt()
+
+    def __repr__(self):
+        return "GaussianEnergy"
+
+
+class PoissonianEnergy(LikelihoodEnergyOperator):
+    """E(lambda) = sum(lambda) - d^T log(lambda) for integer counts d."""
+
+    def __init__(self, d):
+        if not isinstance(d, Field) or not np.issubdtype(d.dtype, np.integer):
+            raise TypeError("data is of invalid data-type; counts need to be integers")
+        if bool((d.val < 0).any()):
+            raise ValueError("count data is negative and thus can not be Poissonian")
+        self._d = d
+        self._d_float = {}
+        self._domain = DomainTuple.make(d.domain)
+        super().__init__(Adder(d, neg=True), lambda x: self.get_metric_at(x).get_sqrt())
+
+    def _counts_like(self, x):
+        key = (x.device_id, x.dtype)
+        if key not in self._d_float:
+            self._d_float[key] = self._d.at(x.device_id).astype(x.dtype)
+        return self._d_float[key]
+
+    def apply(self, x):
+        self._check_input(x)
+        val = x.val if is_linearization(x) else x
+        d = self._counts_like(val)
+        res = x.sum() - x.log().vdot(d)
+        if not (is_linearization(x) and x.want_metric):
+            return res
+        return res.add_metric(self.get_metric_at(x.val))
+
+    def get_transformation(self):
+        return np.float64, Operator.identity_operator(self._domain).sqrt().scale(2.0)
+
+
+class StandardHamiltonian(EnergyOperator):
+    """likelihood energy + 1/2 |x|^2; its metric can draw samples through CG (energy_operators.py:890-931)."""
+
+    def __init__(self, lh, ic_samp=None, prior_sampling_dtype=None):
+        self._lh = lh
+        self._prior = GaussianEnergy(data=None, domain=lh.domain, sampling_dtype=prior_sampling_dtype)
+        self._prior_sampling_dtype = prior_sampling_dtype
+        self._ic_samp = ic_samp
+        self._domain = lh.domain
+
+    def apply(self, x):
+        self._check_input(x)
+        lhx, prx = self._lh(x), self._prior(x)
+        if not (is_linearization(x) and x.want_metric) or self._ic_samp is None:
+            return lhx + prx
+        met = SamplingEnabler(lhx.metric, prx.metric, self._ic_samp)
+        return (lhx + prx).add_metric(met)
+
+    @property
+    def prior_energy(self):
+        return self._prior
+
+    @property
+    def likelihood_energy(self):
+        return self._lh
+
+    @property
+    def iteration_controller(self):
+        return self._ic_samp
+
+    def __repr__(self):
+        return "StandardHamiltonian:\n  Likelihood energy:\n    " + repr(self._lh).replace("\n", "\n    ")

@@ -209,7 +209,7 @@ class Field:
         return float(B.vdot(_cast(a, dt).contiguous(), _cast(b, dt).contiguous()).item())
 
     def vdot(self, x):
-        return Field.scalar(self.s_vdot(x))
+        return Field.scalar(self.s_vdot(x)).at(self.device_id)
 
     def norm(self, ord=2):
         if ord == 2:
@@ -226,7 +226,7 @@ class Field:
 
     def sum(self, spaces=None):
         if spaces is None:
-            return Field.scalar(self.s_sum())
+            return Field.scalar(self.s_sum()).at(self.device_id)
         raise NotImplementedError("partial contractions live in ContractionOperator")
 
     def s_mean(self):
@@ -487,7 +487,7 @@ class MultiField:
         return res
 
     def vdot(self, x):
-        return Field.scalar(self.s_vdot(x))
+        return Field.scalar(self.s_vdot(x)).at(self.device_id)
 
     def norm(self, ord=2):
         if ord == 2:

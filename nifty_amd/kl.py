@@ -1,0 +1,416 @@
+"""Sampled KL energy, MGVI / geoVI sample drawing and sample lists on the generic operator graph.
+
+Counterpart of reference nifty/cl/minimization/kl_energies.py (draw_samples :91-159, SampledKLEnergy
+:162-296, SampledKLEnergyClass :299-360), minimization/sample_list.py (SampleListBase :46-383,
+ResidualSampleList :386-498, SampleList :501-597) and minimization/energy_adapter.py.  The fused
+single-GPU engine (engine.py) implements the same mathematics for the recognised CorrelatedField +
+likelihood pattern; optimize_kl picks it automatically.
+
+Difference by design: the linearisation of the Hamiltonian at every sample is cached when the KL
+energy is built, so one metric application costs one forward + one adjoint Jacobian per sample (the
+reference re-linearises inside every apply_metric call; mathematically identical).
+"""
+import os
+import pickle
+
+import numpy as np
+
+from . import random
+from .domains import MultiDomain
+from .energy_operators import GaussianEnergy, StandardHamiltonian
+from .field import Field, MultiField, is_fieldlike
+from .minimization import DescentMinimizer, Energy
+from .operators import (EndomorphicOperator, Linearization, SamplingEnabler, SandwichOperator, ScalingOperator,
+                        is_operator, makeDomain)
+from .parallel import get_MPI_params_from_comm, shareRange
+
+
+def _scalar_value(field):
+    v = field.asnumpy()[()]
+    return float(np.real(v))
+
+
+class EnergyAdapter(Energy):
+    """Energy protocol on top of an EnergyOperator (reference energy_adapter.py:28-110)."""
+
+    def __init__(self, position, op, constants=[], want_metric=False, nanisinf=False):
+        if len(constants) > 0:
+            raise NotImplementedError("constants are not implemented yet (SURVEY 8f)")
+        super().__init__(position)
+        self._op, self._want_metric, self._nanisinf = op, want_metric, nanisinf
+        lin = op(Linearization.make_var(position, want_metric))
+        self._val = _scalar_value(lin.val)
+        if self._nanisinf and np.isnan(self._val):
+            self._val = np.inf
+        self._grad = lin.gradient
+        self._metric = lin.metric
+
+    def at(self, position):
+        return EnergyAdapter(position, self._op, want_metric=self._want_metric, nanisinf=self._nanisinf)
+
+    @property
+    def value(self):
+        return self._val
+
+    @property
+    def gradient(self):
+        return self._grad
+
+    @property
+    def metric(self):
+        return self._metric
+
+    def apply_metric(self, x):
+        return self._metric(x)
+
+
+class _SelfAdjointOperatorWrapper(EndomorphicOperator):
+    def __init__(self, domain, func):
+        self._func = func
+        self._capability = self.TIMES | self.ADJOINT_TIMES
+        self._domain = makeDomain(domain)
+
+    def apply(self, x, mode):
+        self._check_input(x, mode)
+        return self._func(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# sample lists
+# ------------------------------------------------------------------------------------------------
+class SampleListBase:
+    """A set of samples distributed over the ranks of ``comm`` (sample_list.py:46-383)."""
+
+    def __init__(self, comm, domain):
+        self._comm = comm
+        self._domain = makeDomain(domain)
+        ntask, rank, _ = get_MPI_params_from_comm(comm)
+        self._n_local = None
+        self._ntask, self._rank = ntask, rank
+
+    @property
+    def comm(self):
+        return self._comm
+
+    @property
+    def domain(self):
+        return self._domain
+
+    def n_local_samples(self):
+        raise NotImplementedError
+
+    def local_item(self, i):
+        raise NotImplementedError
+
+    @property
+    def n_samples(self):
+        n = self.n_local_samples()
+        if self._comm is None:
+            return n
+        import torch
+
+        t = torch.tensor([float(n)], dtype=torch.float64, device=self._reduce_device())
+        self._comm.allreduce_sum_([t])
+        return int(round(t.item()))
+
+    def _reduce_device(self):
+        import torch
+
+        return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() and \
+            self._comm is not None and getattr(self._comm, "backend_is_nccl", False) else torch.device("cpu")
+
+    def local_iterator(self, op=None):
+        for i in range(self.n_local_samples()):
+            s = self.local_item(i)
+            yield s if op is None else op(s)
+
+    def iterator(self, op=None):
+        if self._comm is not None and self._comm.size > 1:
+            raise NotImplementedError("global iteration over distributed samples: use average()/local_iterator()")
+        return self.local_iterator(op)
+
+    def _allreduce_fields(self, obj):
+        """Sum a Field / MultiField / python float over ranks in place."""
+        if self._comm is None or self._comm.size == 1:
+            return obj
+        import torch
+
+        if isinstance(obj, float):
+            t = torch.tensor([obj], dtype=torch.float64)
+            self._comm.allreduce_sum_([t])
+            return float(t.item())
+        tensors = [f.val for f in (obj.values() if isinstance(obj, MultiField) else [obj])]
+        self._comm.allreduce_sum_(tensors)
+        return obj
+
+    def average(self, op=None):
+        """Mean of op(sample) over ALL samples (sample_list.py:212-237)."""
+        acc = None
+        for s in self.local_iterator(op):
+            acc = s if acc is None else acc + s
+        if acc is None:
+            raise NotImplementedError("ranks without samples need a zero element; give every rank >= 1 sample")
+        acc = self._allreduce_fields(acc * 1.0)
+        return acc * (1.0 / self.n_samples)
+
+    def _average_2tuple(self, op):
+        """Mean of a (float, field) pair (sample_list.py:239-270)."""
+        v_acc, f_acc = 0.0, None
+        for v, f in self.local_iterator(op):
+            v_acc += v
+            f_acc = f if f_acc is None else f_acc + f
+        n = self.n_samples
+        v_acc = self._allreduce_fields(float(v_acc))
+        f_acc = self._allreduce_fields(f_acc * 1.0)
+        return v_acc / n, f_acc * (1.0 / n)
+
+    def sample_stat(self, op=None):
+        """(mean, variance) over the samples (sample_list.py:272-293); single rank only."""
+        n = self.n_samples
+        if n < 2:
+            raise RuntimeError("need at least two samples")
+        samples = list(self.iterator(op))
+        mean = samples[0]
+        for s in samples[1:]:
+            mean = mean + s
+        mean = mean * (1.0 / n)
+        var = None
+        for s in samples:
+            d = s - mean
+            var = d * d if var is None else var + d * d
+        return mean, var * (1.0 / (n - 1))
+
+    def save(self, file_name_base, overwrite=False):
+        raise NotImplementedError
+
+
+class ResidualSampleList(SampleListBase):
+    """mean +/- residual_i (sample_list.py:386-498)."""
+
+    def __init__(self, mean, residuals, neg, comm=None):
+        super().__init__(comm, mean.domain)
+        self._m = mean
+        self._r = tuple(residuals)
+        self._n = tuple(neg)
+        if len(self._r) != len(self._n):
+            raise ValueError("length mismatch between residuals and neg")
+        r_dom = self._r[0].domain if self._r else None
+        for r in self._r:
+            if r.domain is not r_dom:
+                raise ValueError("all residuals must live on the same domain")
+
+    def n_local_samples(self):
+        return len(self._r)
+
+    def local_item(self, i):
+        return self._m.flexible_addsub(self._r[i], self._n[i])
+
+    def at(self, mean):
+        return ResidualSampleList(mean, self._r, self._n, self._comm)
+
+    @property
+    def mean(self):
+        return self._m
+
+    def save(self, file_name_base, overwrite=False):
+        """One pickle per sample: [residual(host dict), neg] + .mean.pickle (sample_list.py:467-484)."""
+        nsample = self.n_samples
+        lo, _ = shareRange(nsample, self._ntask, self._rank)
+        for i, (r, n) in enumerate(zip(self._r, self._n)):
+            _dump(f"{file_name_base}.{lo + i}.pickle", [_to_host(r), n], overwrite)
+        if self._rank == 0:
+            _dump(f"{file_name_base}.mean.pickle", _to_host(self._m), overwrite)
+            _dump(f"{file_name_base}.nsamples", nsample, overwrite)
+
+    @staticmethod
+    def load_mean(file_name_base):
+        with open(f"{file_name_base}.mean.pickle", "rb") as f:
+            return pickle.load(f)
+
+    @staticmethod
+    def load(file_name_base, comm=None, device_id=-1):
+        with open(f"{file_name_base}.nsamples", "rb") as f:
+            nsample = pickle.load(f)
+        ntask, rank, _ = get_MPI_params_from_comm(comm)
+        lo, hi = shareRange(nsample, ntask, rank)
+        res, neg = [], []
+        for i in range(lo, hi):
+            with open(f"{file_name_base}.{i}.pickle", "rb") as f:
+                r, n = pickle.load(f)
+            res.append(r.at(device_id))
+            neg.append(n)
+        mean = ResidualSampleList.load_mean(file_name_base).at(device_id)
+        return ResidualSampleList(mean, res, neg, comm)
+
+
+class SampleList(SampleListBase):
+    """Explicit list of samples (sample_list.py:501-597)."""
+
+    def __init__(self, samples, comm=None, domain=None):
+        if domain is None:
+            if not samples:
+                raise ValueError("need a domain for an empty SampleList")
+            domain = samples[0].domain
+        super().__init__(comm, domain)
+        self._s = tuple(samples)
+
+    def n_local_samples(self):
+        return len(self._s)
+
+    def local_item(self, i):
+        return self._s[i]
+
+    def save(self, file_name_base, overwrite=False):
+        nsample = self.n_samples
+        lo, _ = shareRange(nsample, self._ntask, self._rank)
+        for i, s in enumerate(self._s):
+            _dump(f"{file_name_base}.{lo + i}.pickle", _to_host(s), overwrite)
+        if self._rank == 0:
+            _dump(f"{file_name_base}.nsamples", nsample, overwrite)
+
+    @staticmethod
+    def load(file_name_base, comm=None, device_id=-1):
+        with open(f"{file_name_base}.nsamples", "rb") as f:
+            nsample = pickle.load(f)
+        ntask, rank, _ = get_MPI_params_from_comm(comm)
+        lo, hi = shareRange(nsample, ntask, rank)
+        samples = []
+        for i in range(lo, hi):
+            with open(f"{file_name_base}.{i}.pickle", "rb") as f:
+                samples.append(pickle.load(f).at(device_id))
+        return SampleList(samples, comm)
+
+
+def _to_host(f):
+    return f.at(-1)
+
+
+def _dump(fname, obj, overwrite):
+    if os.path.isfile(fname) and not overwrite:
+        raise RuntimeError(f"{fname} already exists")
+    with open(fname, "wb") as f:
+        pickle.dump(obj, f, protocol=pickle.HIGHEST_PROTOCOL)
+
+
+# ------------------------------------------------------------------------------------------------
+# sampling
+# ------------------------------------------------------------------------------------------------
+def draw_samples(position, H, minimizer, n_samples, mirror_samples, napprox=0, want_error=False, comm=None,
+                 device_id=-1):
+    """MGVI (minimizer None) or geoVI residual samples around ``position`` (kl_energies.py:91-159)."""
+    if not isinstance(n_samples, int):
+        raise TypeError
+    if not isinstance(mirror_samples, bool):
+        raise TypeError
+    if not isinstance(H, StandardHamiltonian):
+        raise TypeError
+    if napprox >= 1:
+        raise NotImplementedError("napprox preconditioning is out of scope (SURVEY 8f rank 4)")
+    sam_position = position.extract(H.domain) if isinstance(position, MultiField) else position
+    geometric = minimizer is not None
+    if geometric:
+        tr = H.likelihood_energy.get_transformation()
+        if tr is None:
+            raise ValueError("Geometric sampling only works for likelihoods")
+        dtype, f_lh = tr
+        scale = ScalingOperator(f_lh.target, 1.0, dtype)
+        fl = f_lh(Linearization.make_var(sam_position))
+        transformation = ScalingOperator(f_lh.domain, 1.0) + fl.jac.adjoint @ f_lh
+        transformation_mean = sam_position + fl.jac.adjoint(fl.val)
+        met = SamplingEnabler(SandwichOperator.make(fl.jac, scale), ScalingOperator(fl.domain, 1.0, float),
+                              H.iteration_controller)
+    else:
+        met = H(Linearization.make_var(sam_position, want_metric=True)).metric
+    sseq = random.spawn_sseq(n_samples)
+    if mirror_samples:
+        sseq = [s for ss in sseq for s in (ss, ss)]
+    local_samples, local_neg = [], []
+    y = yi = None
+    ntask, rank, _ = get_MPI_params_from_comm(comm)
+    for i in range(*shareRange(len(sseq), ntask, rank)):
+        with random.Context(sseq[i]):
+            neg = mirror_samples and i % 2 != 0
+            if not neg or y is None:
+                y, yi = met.special_draw_sample(True, device_id=device_id)
+            if geometric:
+                m = transformation_mean - y if neg else transformation_mean + y
+                pos = sam_position - yi if neg else sam_position + yi
+                en = EnergyAdapter(pos, GaussianEnergy(m) @ transformation, nanisinf=True, want_metric=True)
+                en, _ = minimizer(en)
+                local_samples.append(en.position - sam_position)
+                local_neg.append(False)
+            else:
+                local_samples.append(yi)
+                local_neg.append(neg)
+    return ResidualSampleList(position, local_samples, local_neg, comm)
+
+
+def SampledKLEnergy(position, hamiltonian, n_samples, minimizer_sampling, mirror_samples=True, constants=[],
+                    point_estimates=[], napprox=0, comm=None, nanisinf=True, device_id=-1):
+    """Draw samples at ``position`` and return the sampled KL energy (kl_energies.py:162-296)."""
+    if not isinstance(hamiltonian, StandardHamiltonian):
+        raise TypeError
+    if hamiltonian.domain is not position.domain:
+        raise ValueError
+    if not isinstance(n_samples, int):
+        raise TypeError
+    if not isinstance(mirror_samples, bool):
+        raise TypeError
+    if not (minimizer_sampling is None or isinstance(minimizer_sampling, DescentMinimizer)):
+        raise TypeError
+    if len(constants) > 0 or len(point_estimates) > 0:
+        raise NotImplementedError("constants / point_estimates are not implemented yet (SURVEY 8f)")
+    sample_list = draw_samples(position, hamiltonian, minimizer_sampling, n_samples, mirror_samples, napprox=napprox,
+                               comm=comm, device_id=device_id)
+    return SampledKLEnergyClass(sample_list, hamiltonian, constants, None, nanisinf)
+
+
+class SampledKLEnergyClass(Energy):
+    """KL(p) = 1/S sum_s H(p +/- r_s)  (kl_energies.py:299-360)."""
+
+    def __init__(self, sample_list, hamiltonian, constants, invariants, nanisinf):
+        if not isinstance(sample_list, ResidualSampleList):
+            raise TypeError
+        if sample_list.domain is not hamiltonian.domain:
+            raise ValueError("domain mismatch")
+        super().__init__(sample_list._m)
+        self._sample_list, self._hamiltonian = sample_list, hamiltonian
+        self._constants, self._invariants, self._nanisinf = constants, invariants, bool(nanisinf)
+        self._lins = []
+
+        def _func(inp):
+            lin = hamiltonian(Linearization.make_var(inp, want_metric=True))
+            self._lins.append(lin)
+            return _scalar_value(lin.val), lin.gradient
+
+        self._val, self._grad = sample_list._average_2tuple(_func)
+        if np.isnan(self._val) and self._nanisinf:
+            self._val = np.inf
+
+    @property
+    def value(self):
+        return self._val
+
+    @property
+    def gradient(self):
+        return self._grad
+
+    def at(self, position):
+        return SampledKLEnergyClass(self._sample_list.at(position), self._hamiltonian, self._constants,
+                                    self._invariants, self._nanisinf)
+
+    def apply_metric(self, x):
+        acc = None
+        for lin in self._lins:
+            m = lin.metric(x)
+            acc = m if acc is None else acc + m
+        acc = self._sample_list._allreduce_fields(acc * 1.0)
+        return acc * (1.0 / self._sample_list.n_samples)
+
+    @property
+    def metric(self):
+        return _SelfAdjointOperatorWrapper(self.position.domain, self.apply_metric)
+
+    @property
+    def samples(self):
+        return self._sample_list

@@ -1,0 +1,290 @@
+"""optimize_kl: the MGVI / geoVI driver loop.
+
+Counterpart of reference nifty/cl/minimization/optimize_kl.py:51-453 (same keyword surface).  Per
+global iteration: push the iteration's SeedSequence, initialise missing latent keys with 0.1*N(0,1),
+draw samples, minimise the sampled KL, optionally save / call back.
+
+Fusion pass (``fuse=True``, device runs only): when the likelihood is
+``GaussianEnergy | PoissonianEnergy  @  [exp | sigmoid]  @  CorrelatedFieldOperator`` the iteration runs
+on the fused engine (engine.py: one forward + one adjoint transform per sample and metric application,
+CG with device-resident scalars) and the results are handed back as MultiFields / ResidualSampleList.
+Everything else walks the generic operator graph.  Plotting, minisanity and HDF5 export of the
+reference are diagnostics outside the hot path and not implemented.
+"""
+import os
+import pickle
+from inspect import signature
+
+import numpy as np
+
+from . import random
+from .domains import DomainTuple, MultiDomain, makeDomain
+from .energy_operators import GaussianEnergy, PoissonianEnergy, StandardHamiltonian, _LikelihoodChain
+from .field import Field, MultiField, from_random, full
+from .kl import EnergyAdapter, ResidualSampleList, SampledKLEnergy, SampleList
+from .minimization import DescentMinimizer, EnergyHistory, IterationController, Minimizer, logger
+from .operators import DiagonalOperator, Operator, ScalingOperator, _FunctionApplier, _OpChain
+from .parallel import get_MPI_params_from_comm
+
+
+def _make_callable(obj):
+    if callable(obj) and not isinstance(obj, (Minimizer, IterationController, Operator)):
+        return obj
+    return lambda x: obj
+
+
+def _nargs(func):
+    return len(signature(func).parameters)
+
+
+def _normal_initialize(mf, domain, std=0.1, device_id=-1):
+    """Draw the keys of ``domain`` missing in ``mf`` (optimize_kl.py:792-805)."""
+    if MultiDomain.union([domain, mf.domain]) != domain:
+        raise RuntimeError("Domain of MultiField and final domain are not compatible")
+    diff = makeDomain({k: domain[k] for k in domain.keys() if k not in mf.domain})
+    if len(diff) == 0:
+        return mf.extract(domain)
+    fld = from_random(diff, std=std, device_id=device_id)
+    res = mf.unite(fld) if len(mf.domain) else fld
+    return res.extract(domain) if res.domain is not domain else res
+
+
+# ------------------------------------------------------------------------------------------------
+# fusion pass
+# ------------------------------------------------------------------------------------------------
+def match_fused(lh):
+    """Return the FusedModel keyword arguments for a recognised likelihood graph, else None."""
+    from .correlated_fields import CorrelatedFieldOperator
+
+    if not isinstance(lh, _LikelihoodChain):
+        return None
+    like, model = lh.likelihood, lh.model
+    nonlin = None
+    if isinstance(model, _OpChain):
+        ops = model._ops
+        if len(ops) == 2 and isinstance(ops[0], _FunctionApplier) and ops[0]._funcname in ("exp", "sigmoid") \
+                and not ops[0]._args and isinstance(ops[1], CorrelatedFieldOperator):
+            nonlin, model = ops[0]._funcname, ops[1]
+        else:
+            return None
+    if not isinstance(model, CorrelatedFieldOperator) or model._prefix != "":
+        return None
+    kw = dict(model.fused_parameters)
+    kw.pop("prefix")
+    kw["nonlin"] = nonlin
+    if isinstance(like, PoissonianEnergy):
+        kw.update(likelihood="poisson", data=like._d.val)
+    elif isinstance(like, GaussianEnergy) and like._data is not None:
+        icov = like._icov
+        if isinstance(icov, ScalingOperator) and np.isreal(icov._factor):
+            kw.update(likelihood="gaussian", data=like._data.val, icov=float(np.real(icov._factor)))
+        elif isinstance(icov, DiagonalOperator) and icov._full() and icov._trafo == 0 and not icov._complex:
+            kw.update(likelihood="gaussian", data=like._data.val, icov=icov._ldiag)
+        else:
+            return None
+    else:
+        return None
+    return kw
+
+
+_fused_cache = {}
+
+
+def _fused_model(lh, device_id, dtype):
+    import torch
+
+    from .engine import FusedModel
+
+    key = (id(lh), device_id, dtype)
+    if key not in _fused_cache:
+        kw = match_fused(lh)
+        if kw is None:
+            _fused_cache[key] = None
+        else:
+            tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+            _fused_cache[key] = (lh, FusedModel(kw.pop("shape"), kw.pop("distances"), dtype=tdt,
+                                                device=f"cuda:{device_id}", **kw))
+    ent = _fused_cache[key]
+    return None if ent is None else ent[1]
+
+
+def _mf_to_latent(model, mf):
+    import torch
+
+    from .engine import SMALL_KEYS, LatentVec
+
+    small = torch.cat([mf[k].val.reshape(1).to(torch.float64) for k in SMALL_KEYS] +
+                      [mf["spectrum"].val.reshape(-1).to(torch.float64)]).to(model.device).contiguous()
+    return LatentVec(mf["xi"].val.to(model.device).to(model.tdtype).contiguous(), small)
+
+
+def _latent_to_mf(domain, lv, dtype):
+    import torch
+
+    from .engine import SMALL_KEYS
+    from .field import torch_dtype
+
+    tdt = torch_dtype(dtype)
+    vals = {k: Field(domain[k], lv.small[i].reshape(()).to(tdt)) for i, k in enumerate(SMALL_KEYS)}
+    vals["spectrum"] = Field(domain["spectrum"], lv.small[5:].reshape(2, -1).to(tdt))
+    vals["xi"] = Field(domain["xi"], lv.xi.to(tdt))
+    return MultiField.from_dict(vals, domain)
+
+
+def _fused_iteration(model, lh, mean, n_samples, minimizer, ic_sampling, comm):
+    from .engine import FusedKL, draw_samples
+
+    dtype = mean["xi"].dtype
+    mean_lv = _mf_to_latent(model, mean)
+    residuals, negs, n_total = draw_samples(model, mean_lv, n_samples, True, lambda: ic_sampling, comm)
+    kl = FusedKL(model, mean_lv, residuals, negs, n_total, comm)
+    kl, _ = minimizer(kl)
+    new_mean = _latent_to_mf(lh.domain, kl.position, dtype)
+    res_mf = [_latent_to_mf(lh.domain, r, dtype) for r in residuals]
+    return new_mean, ResidualSampleList(new_mean, res_mf, negs, comm), kl.value
+
+
+# ------------------------------------------------------------------------------------------------
+# driver
+# ------------------------------------------------------------------------------------------------
+def optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sampling_iteration_controller, *,
+                nonlinear_sampling_minimizer=None, constants=[], point_estimates=[], transitions=None,
+                export_operator_outputs={}, output_directory=None, initial_position=None, initial_index=0, comm=None,
+                inspect_callback=None, terminate_callback=None, plot_energy_history=True,
+                plot_minisanity_history=True, save_strategy="latest", return_final_position=False, resume=False,
+                sanity_checks=True, dry_run=False, fresh_stochasticity=True, device_id=-1, fuse=True):
+    if not isinstance(export_operator_outputs, dict):
+        raise TypeError
+    if not isinstance(initial_index, int):
+        raise TypeError
+    if save_strategy not in ("all", "latest"):
+        raise ValueError(f"Save strategy '{save_strategy}' not supported.")
+    if output_directory is None and resume:
+        raise ValueError("Can only resume minimization if output_directory is not None")
+    likelihood_energy = _make_callable(likelihood_energy)
+    kl_minimizer = _make_callable(kl_minimizer)
+    sampling_iteration_controller = _make_callable(sampling_iteration_controller)
+    nonlinear_sampling_minimizer = _make_callable(nonlinear_sampling_minimizer)
+    constants, point_estimates = _make_callable(constants), _make_callable(point_estimates)
+    transitions, n_samples, comm = _make_callable(transitions), _make_callable(n_samples), _make_callable(comm)
+    inspect_callback = _make_callable(inspect_callback)
+    terminate_callback = _make_callable(False) if terminate_callback is None else terminate_callback
+    fresh_stochasticity = _make_callable(fresh_stochasticity)
+    if initial_index >= total_iterations:
+        raise ValueError(f"Initial index is bigger than total iterations: {initial_index} >= {total_iterations}")
+    if likelihood_energy(initial_index).target is not DomainTuple.scalar_domain():
+        raise TypeError
+    if sanity_checks:
+        for ig in range(initial_index, total_iterations):
+            for obj, cls in ((likelihood_energy, Operator), (kl_minimizer, DescentMinimizer),
+                             (nonlinear_sampling_minimizer, (DescentMinimizer, type(None))),
+                             (constants, (list, tuple)), (point_estimates, (list, tuple)), (n_samples, int)):
+                if not isinstance(obj(ig), cls):
+                    raise TypeError(f"{obj(ig)} is not instance of {cls} but rather {type(obj(ig))}")
+            if sampling_iteration_controller(ig) is None:
+                if n_samples(ig) != 0:
+                    raise ValueError("sampling controller missing")
+            elif not isinstance(sampling_iteration_controller(ig), IterationController):
+                raise TypeError
+
+    mean = full(makeDomain({}), 0.0) if initial_position is None else initial_position.at(device_id)
+    sl = None
+    energy_history = EnergyHistory()
+    master = get_MPI_params_from_comm(comm(initial_index))[2]
+
+    def fname(ig):
+        return "latest" if save_strategy == "latest" else f"iteration_{ig}"
+
+    if output_directory is not None:
+        if master:
+            os.makedirs(os.path.join(output_directory, "pickle"), exist_ok=True)
+        lfile = os.path.join(output_directory, "last_finished_iteration")
+        if resume and os.path.isfile(lfile):
+            with open(lfile) as f:
+                last = int(f.read())
+            initial_index = last + 1
+            base = os.path.join(output_directory, "pickle", fname(last))
+            if os.path.isfile(base + ".mean.pickle"):
+                mean = ResidualSampleList.load_mean(base).at(device_id)
+                sl = ResidualSampleList.load(base, comm=comm(last), device_id=device_id)
+            else:
+                sl = SampleList.load(base, device_id=device_id)
+                mean = sl.local_item(0)
+            if initial_index == total_iterations:
+                return (sl, mean) if return_final_position else sl
+            with open(os.path.join(output_directory, "pickle", "nifty_random_state"), "rb") as f:
+                random.setState(f.read())
+            with open(os.path.join(output_directory, "pickle", "energy_history_" + fname(last)), "rb") as f:
+                energy_history = pickle.load(f)
+        elif master:
+            with open(os.path.join(output_directory, "pickle", "nifty_random_state"), "wb") as f:
+                f.write(random.getState())
+
+    sseqs = random.spawn_sseq(total_iterations)
+    for ig in range(total_iterations):
+        if not fresh_stochasticity(ig):
+            if ig == 0:
+                raise ValueError("fresh_stochasticity needs to be True for initial iteration")
+            prev = sseqs[ig - 1]
+            sseqs[ig] = np.random.SeedSequence(prev.entropy, spawn_key=prev.spawn_key, pool_size=prev.pool_size)
+
+    for ig in range(initial_index, total_iterations):
+        random.push_sseq(sseqs[ig])
+        lh = likelihood_energy(ig)
+        if not isinstance(lh.domain, MultiDomain):
+            raise TypeError(f"Domain of likelihood_energy needs to be a MultiDomain, got\n{lh.domain}")
+        t = transitions(ig)
+        mean = mean if t is None else t(sl)
+        mean = _normal_initialize(mean, lh.domain, device_id=device_id)
+        minimizer = kl_minimizer(ig)
+        mean_iter = mean.extract(lh.domain)
+        if len(constants(ig)) > 0 or len(point_estimates(ig)) > 0:
+            raise NotImplementedError("constants / point_estimates are not implemented yet (SURVEY 8f)")
+        if dry_run:
+            logger.info(f"Iteration {ig} checked")
+            random.pop_sseq()
+            continue
+        ns = n_samples(ig)
+        model = None
+        if fuse and device_id >= 0 and ns > 0 and nonlinear_sampling_minimizer(ig) is None:
+            model = _fused_model(lh, device_id, mean_iter["xi"].dtype if "xi" in mean_iter else np.float64)
+        if model is not None:
+            new_mean, sl, value = _fused_iteration(model, lh, mean_iter, ns, minimizer, sampling_iteration_controller(ig),
+                                                   comm(ig))
+            mean = MultiField.union([mean, new_mean])
+            sl = sl.at(mean)
+            energy_history.append((ig, value))
+        else:
+            ham = StandardHamiltonian(lh, sampling_iteration_controller(ig), prior_sampling_dtype=mean_iter.dtype)
+            if ns == 0:
+                e = EnergyAdapter(mean_iter, ham, want_metric=True)
+                e, _ = minimizer(e)
+                mean = MultiField.union([mean, e.position])
+                sl = SampleList([mean])
+            else:
+                e = SampledKLEnergy(mean_iter, ham, ns, nonlinear_sampling_minimizer(ig), comm=comm(ig),
+                                    device_id=device_id)
+                e, _ = minimizer(e)
+                mean = MultiField.union([mean, e.position])
+                sl = e.samples.at(mean)
+            energy_history.append((ig, e.value))
+        if output_directory is not None:
+            sl.save(os.path.join(output_directory, "pickle", fname(ig)), overwrite=True)
+            if get_MPI_params_from_comm(comm(ig))[2]:
+                with open(os.path.join(output_directory, "last_finished_iteration"), "w") as f:
+                    f.write(str(ig))
+                with open(os.path.join(output_directory, "pickle", "energy_history_" + fname(ig)), "wb") as f:
+                    pickle.dump(energy_history, f)
+        cb = inspect_callback
+        if cb is not None and callable(cb):
+            try:
+                na = _nargs(cb)
+            except (TypeError, ValueError):
+                na = 1
+            res = cb(sl) if na == 1 else cb(sl, ig)
+            del res
+        terminate = terminate_callback(ig)
+        random.pop_sseq()
+        if terminate:
+            break
+    return (sl, mean) if return_final_position else sl

@@ -29,6 +29,8 @@ class Comm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
+        self.backend = str(dist.get_backend(group))
+        self.backend_is_nccl = "nccl" in self.backend
 
     def allreduce_sum_(self, tensors):
         """In-place sum over ranks of every tensor in the list (one collective per tensor)."""

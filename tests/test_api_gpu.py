@@ -1,0 +1,100 @@
+"""The nifty.cl-shaped API with device Fields (device_id=0): every operation below runs in libniftyk
+kernels.  Same script as tests/test_api_host.py, checked against the reference's golden vectors."""
+import numpy as np
+import pytest
+
+import nifty_amd as ift
+from tests import goldenlib as gl
+from tests.test_api_host import build
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(mf):
+    return mf.at(0)
+
+
+@pytest.mark.parametrize("case", gl.MODEL_CASES)
+def test_cf_and_hamiltonian_on_device(case):
+    z = gl.load("model_" + case)
+    m, cfm, cf, lh = build(z, device_id=0)
+    x = dev(ift.MultiField.from_raw(cf.domain, gl.latent(z, "x")))
+    v = dev(ift.MultiField.from_raw(cf.domain, gl.latent(z, "v")))
+    assert x.device_id == 0
+    lin = cf(ift.Linearization.make_var(x))
+    assert lin.val.device_id == 0
+    assert gl.relerr(lin.val.asnumpy(), z["cf"]) < 1e-12
+    assert gl.relerr(lin.jac(v).asnumpy(), z["cf_jvp"]) < 1e-11
+    w = ift.makeField(cf.target, z["w"], 0)
+    assert gl.lat_relerr(lin.jac.adjoint(w).asnumpy(), gl.latent(z, "cf_vjp")) < 1e-11
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=m["sampling_limit"])
+    ham = ift.StandardHamiltonian(lh, ic, prior_sampling_dtype=np.float64)
+    hl = ham(ift.Linearization.make_var(x, want_metric=True))
+    assert abs(float(hl.val.asnumpy()) - float(z["ham_value"])) < 1e-11 * abs(float(z["ham_value"]))
+    assert gl.lat_relerr(hl.gradient.asnumpy(), gl.latent(z, "ham_grad")) < 1e-10
+    assert gl.lat_relerr(hl.metric(v).asnumpy(), gl.latent(z, "ham_metric_v")) < 1e-10
+
+
+@pytest.mark.parametrize("case", ["g1d", "p2d", "p2d_geo"])
+def test_sampled_kl_generic_graph_on_device(case):
+    z = gl.load("model_" + case)
+    m, cfm, cf, lh = build(z, device_id=0)
+    x = dev(ift.MultiField.from_raw(cf.domain, gl.latent(z, "x")))
+    v = dev(ift.MultiField.from_raw(cf.domain, gl.latent(z, "v")))
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=m["sampling_limit"])
+    ham = ift.StandardHamiltonian(lh, ic, prior_sampling_dtype=np.float64)
+    geo = None
+    if m["geo"]:
+        geo = ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=3, convergence_level=2), max_cg_iterations=6)
+    ift.random.push_sseq_from_seed(m["seed"] + 1)
+    try:
+        kl = ift.SampledKLEnergy(x, ham, m["n_samples"], geo, mirror_samples=True, device_id=0)
+    finally:
+        ift.random.pop_sseq()
+    tol = 1e-6 if m["geo"] else 1e-9
+    for i, s in enumerate(kl.samples.iterator()):
+        assert s.device_id == 0
+        assert gl.lat_relerr((s - x).asnumpy(), gl.latent(z, f"residual{i}")) < tol, i
+    assert abs(kl.value - float(z["kl_value"])) < tol * abs(float(z["kl_value"]))
+    assert gl.lat_relerr(kl.gradient.asnumpy(), gl.latent(z, "kl_grad")) < 10 * tol
+    assert gl.lat_relerr(kl.apply_metric(v).asnumpy(), gl.latent(z, "kl_metric_v")) < 10 * tol
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_optimize_kl_on_device_matches_reference(fuse):
+    """Drop-in check: the reference's optimize_kl result for the same seeds, once through the fused engine
+    (fusion pass) and once through the generic operator graph, both on the GPU."""
+    z = gl.load("model_g1d")
+    m, cfm, cf, lh = build(z, device_id=0)
+    ift.random.push_sseq_from_seed(m["seed"] + 2)
+    try:
+        ic_s = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=m["sampling_limit"])
+        mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2),  # noqa: E731
+                                    max_cg_iterations=8)
+        sl, mean = ift.optimize_kl(lh, 2, m["n_samples"], mk, ic_s, output_directory=None, return_final_position=True,
+                                   device_id=0, fuse=fuse)
+    finally:
+        ift.random.pop_sseq()
+    assert mean.device_id == 0
+    assert gl.lat_relerr(mean.asnumpy(), gl.latent(z, "okl_mean")) < 1e-5
+    for i, s in enumerate(sl.iterator()):
+        assert gl.lat_relerr(s.asnumpy(), gl.latent(z, f"okl_sample{i}")) < 1e-5
+
+
+def test_device_operator_identities():
+    sp = ift.RGSpace((16, 32))
+    h = ift.HartleyOperator(sp.get_default_codomain(), sp)
+    x = ift.from_random(h.domain, device_id=0)
+    y = ift.from_random(h.target, device_id=0)
+    assert abs(y.s_vdot(h(x)) - h.adjoint(y).s_vdot(x)) < 1e-11
+    assert gl.relerr(h.inverse(h(x)).asnumpy(), x.asnumpy()) < 1e-12
+    # host and device agree (reference extra.py:519-549)
+    assert gl.relerr(h(x).asnumpy(), h(x.at(-1)).asnumpy()) < 1e-12
+    pd = ift.PowerDistributor(h.domain)
+    a = ift.from_random(pd.domain, device_id=0)
+    assert abs(x.s_vdot(pd(a)) - pd.adjoint(x).s_vdot(a)) < 1e-11
+    assert gl.relerr(pd.adjoint(x).asnumpy(), pd.adjoint(x.at(-1)).asnumpy()) < 1e-12
+    f = ift.FFTOperator(sp)
+    xc = ift.from_random(sp, dtype=np.complex128, device_id=0)
+    assert gl.relerr(f.inverse(f(xc)).asnumpy(), xc.asnumpy()) < 1e-12
+    assert gl.relerr(f(xc).asnumpy(), f(xc.at(-1)).asnumpy()) < 1e-12

@@ -1,0 +1,168 @@
+"""Host (device_id = -1) tests of the nifty.cl-shaped API against the golden vectors generated from the
+reference: the same user-level script (CorrelatedFieldMaker -> GaussianEnergy/PoissonianEnergy ->
+StandardHamiltonian -> SampledKLEnergy -> NewtonCG -> optimize_kl) with ``import nifty_amd as ift``.
+This is config 1 of BASELINE.json ("plumbing, no GPU") and exercises the generic operator graph."""
+import numpy as np
+import pytest
+
+import nifty_amd as ift
+from tests import goldenlib as gl
+
+CF_ARGS = dict(fluctuations=(1.0, 5e-1), flexibility=(1.0, 2e-1), asperity=(5e-1, 5e-2), loglogavgslope=(-3.0, 2e-1))
+
+
+def build(z, device_id=-1):
+    m = gl.meta(z)
+    sp = ift.RGSpace(m["shape"], m["distances"])
+    cfm = ift.CorrelatedFieldMaker("")
+    cfm.add_fluctuations(sp, CF_ARGS["fluctuations"], CF_ARGS["flexibility"], CF_ARGS["asperity"], CF_ARGS["loglogavgslope"])
+    cfm.set_amplitude_total_offset(2.0, (1e-1, 3e-2))
+    cf = cfm.finalize()
+    sig = cf if m["nonlin"] is None else cf.ptw(m["nonlin"])
+    if m["kind"] == "gaussian":
+        d = ift.makeField(sig.target, z["data"], device_id)
+        ic = z["icov"]
+        if ic.shape == ():
+            N_inv = ift.ScalingOperator(sig.target, float(ic), np.float64)
+        else:
+            N_inv = ift.makeOp(ift.makeField(sig.target, ic, device_id), sampling_dtype=np.float64)
+        lh = ift.GaussianEnergy(d, N_inv) @ sig
+    else:
+        lh = ift.PoissonianEnergy(ift.makeField(sig.target, z["data"], device_id)) @ sig
+    return m, cfm, cf, lh
+
+
+@pytest.mark.parametrize("case", gl.MODEL_CASES)
+def test_cf_and_hamiltonian(case):
+    z = gl.load("model_" + case)
+    m, cfm, cf, lh = build(z)
+    x = ift.MultiField.from_raw(cf.domain, gl.latent(z, "x"))
+    v = ift.MultiField.from_raw(cf.domain, gl.latent(z, "v"))
+    lin = cf(ift.Linearization.make_var(x))
+    assert gl.relerr(lin.val.asnumpy(), z["cf"]) < 1e-12
+    assert gl.relerr(lin.jac(v).asnumpy(), z["cf_jvp"]) < 1e-11
+    w = ift.makeField(cf.target, z["w"])
+    assert gl.lat_relerr(lin.jac.adjoint(w).asnumpy(), gl.latent(z, "cf_vjp")) < 1e-11
+    amp = cfm.amplitude
+    assert gl.relerr(amp.force(x).asnumpy(), z["amplitude"]) < 1e-12
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=m["sampling_limit"])
+    ham = ift.StandardHamiltonian(lh, ic, prior_sampling_dtype=np.float64)
+    hl = ham(ift.Linearization.make_var(x, want_metric=True))
+    assert abs(float(hl.val.asnumpy()) - float(z["ham_value"])) < 1e-11 * abs(float(z["ham_value"]))
+    assert gl.lat_relerr(hl.gradient.asnumpy(), gl.latent(z, "ham_grad")) < 1e-10
+    assert gl.lat_relerr(hl.metric(v).asnumpy(), gl.latent(z, "ham_metric_v")) < 1e-10
+
+
+@pytest.mark.parametrize("case", ["g1d", "p2d", "g2d_dist", "p2d_geo"])
+def test_sampled_kl_and_newton(case):
+    z = gl.load("model_" + case)
+    m, cfm, cf, lh = build(z)
+    x = ift.MultiField.from_raw(cf.domain, gl.latent(z, "x"))
+    v = ift.MultiField.from_raw(cf.domain, gl.latent(z, "v"))
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=m["sampling_limit"])
+    ham = ift.StandardHamiltonian(lh, ic, prior_sampling_dtype=np.float64)
+    geo = None
+    if m["geo"]:
+        geo = ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=3, convergence_level=2), max_cg_iterations=6)
+    ift.random.push_sseq_from_seed(m["seed"] + 1)
+    try:
+        kl = ift.SampledKLEnergy(x, ham, m["n_samples"], geo, mirror_samples=True)
+    finally:
+        ift.random.pop_sseq()
+    tol = 1e-6 if m["geo"] else 1e-9
+    for i, s in enumerate(kl.samples.iterator()):
+        assert gl.lat_relerr((s - x).asnumpy(), gl.latent(z, f"residual{i}")) < tol, i
+    assert abs(kl.value - float(z["kl_value"])) < tol * abs(float(z["kl_value"]))
+    assert gl.lat_relerr(kl.gradient.asnumpy(), gl.latent(z, "kl_grad")) < 10 * tol
+    assert gl.lat_relerr(kl.apply_metric(v).asnumpy(), gl.latent(z, "kl_metric_v")) < 10 * tol
+    mini = ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=8)
+    kl2, _ = mini(kl)
+    assert abs(kl2.value - float(z["kl_min_value"])) < 100 * tol * abs(float(z["kl_min_value"]))
+
+
+def test_optimize_kl_host_matches_reference():
+    z = gl.load("model_g1d")
+    m, cfm, cf, lh = build(z)
+    ift.random.push_sseq_from_seed(m["seed"] + 2)
+    try:
+        ic_s = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=m["sampling_limit"])
+        mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2),  # noqa: E731
+                                    max_cg_iterations=8)
+        sl, mean = ift.optimize_kl(lh, 2, m["n_samples"], mk, ic_s, output_directory=None, return_final_position=True)
+    finally:
+        ift.random.pop_sseq()
+    assert gl.lat_relerr(mean.asnumpy(), gl.latent(z, "okl_mean")) < 1e-6
+    for i, s in enumerate(sl.iterator()):
+        assert gl.lat_relerr(s.asnumpy(), gl.latent(z, f"okl_sample{i}")) < 1e-5
+
+
+def test_optimize_kl_resume(tmp_path):
+    """Interrupted + resumed run equals the uninterrupted one (reference test_mpi/test_optimize_kl.py:117-146)."""
+    z = gl.load("model_g1d")
+    m, cfm, cf, lh = build(z)
+    ic_s = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=3)
+    mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=1), max_cg_iterations=4)  # noqa: E731
+
+    def run(total, outdir, resume):
+        ift.random.push_sseq_from_seed(5)
+        try:
+            return ift.optimize_kl(lh, total, 1, mk, ic_s, output_directory=str(outdir), return_final_position=True,
+                                   resume=resume)[1]
+        finally:
+            ift.random.pop_sseq()
+
+    full = run(3, tmp_path / "a", False)
+    with pytest.raises(Exception):
+        ift.random.push_sseq_from_seed(5)
+        try:
+            ift.optimize_kl(lh, 3, 1, mk, ic_s, output_directory=str(tmp_path / "b"), return_final_position=True,
+                            terminate_callback=lambda i: (_ for _ in ()).throw(RuntimeError("stop")) if i == 1 else False)
+        finally:
+            ift.random.pop_sseq()
+    resumed = run(3, tmp_path / "b", True)
+    assert gl.lat_relerr(resumed.asnumpy(), full.asnumpy()) < 1e-12
+
+
+def test_linear_operator_modes_and_errors():
+    sp = ift.RGSpace((8, 8))
+    h = ift.HartleyOperator(sp.get_default_codomain(), sp)
+    x = ift.from_random(h.domain)
+    y = ift.from_random(h.target)
+    # adjointness <y, A x> == <A^T y, x>  (reference extra.py:220-231)
+    assert abs(y.s_vdot(h(x)) - h.adjoint(y).s_vdot(x)) < 1e-12
+    # A A^-1 = 1 (extra.py:234-244)
+    assert gl.relerr(h.inverse(h(x)).asnumpy(), x.asnumpy()) < 1e-12
+    with pytest.raises(ValueError):
+        h(y)  # wrong domain -> ValueError like utilities.check_object_identity
+    with pytest.raises(NotImplementedError):
+        ift.HarmonicTransformOperator(h.domain, sp).apply(x, ift.LinearOperator.INVERSE_TIMES)
+    with pytest.raises(NotImplementedError):
+        h.apply(x, 3)
+    d = ift.makeOp(ift.from_random(h.domain).exp())
+    assert gl.relerr(d.inverse(d(x)).asnumpy(), x.asnumpy()) < 1e-12
+    ch = h @ d
+    assert abs(y.s_vdot(ch(x)) - ch.adjoint(y).s_vdot(x)) < 1e-12
+    pd = ift.PowerDistributor(h.domain)
+    a = ift.from_random(pd.domain)
+    assert abs(x.s_vdot(pd(a)) - pd.adjoint(x).s_vdot(a)) < 1e-12
+
+
+def test_fft_roundtrip_host():
+    # reference test_fft_operator.py:38-56
+    sp = ift.RGSpace((16, 8), distances=(0.3, 0.7))
+    op = ift.FFTOperator(sp)
+    x = ift.from_random(sp, dtype=np.complex128)
+    assert gl.relerr(op.inverse(op(x)).asnumpy(), x.asnumpy()) < 1e-12
+
+
+def test_fusion_pass_matches_graph():
+    from nifty_amd.optimize_kl import match_fused
+
+    z = gl.load("model_p2d")
+    m, cfm, cf, lh = build(z)
+    kw = match_fused(lh)
+    assert kw is not None and kw["likelihood"] == "poisson" and kw["nonlin"] == "exp" and kw["shape"] == (32, 32)
+    z = gl.load("model_g1d")
+    m, cfm, cf, lh = build(z)
+    kw = match_fused(lh)
+    assert kw["likelihood"] == "gaussian" and kw["icov"] == pytest.approx(100.0) and kw["nonlin"] is None

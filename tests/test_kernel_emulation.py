@@ -1,0 +1,95 @@
+"""Host emulation of the transform kernels (tests/emu): the SAME phase functions the GPU runs, executed
+thread-by-thread on the CPU, against scipy.fft.  Checks index math, digit reversal, twiddles, the packed
+half-spectrum layout and the fused prologue/epilogue without a GPU."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import scipy.fft
+
+from nifty_amd._lib import Fuse
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "emu", "libnk_emu.so")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(EMU), reason="emulation library not built (run __graft_entry__.build())")
+
+
+def lib():
+    return ctypes.CDLL(EMU)
+
+
+def run(f, shape, dtype, conv=0, batch=1):
+    shp = (ctypes.c_int64 * len(shape))(*shape)
+    rc = lib().emu_hartley_fused(len(shape), shp, 0 if dtype == np.float32 else 1, batch, ctypes.byref(f), conv)
+    assert rc == 0
+
+
+@pytest.mark.parametrize("shape", [(2,), (8,), (64,), (1024,), (2, 2), (4, 16), (32, 8), (64, 64), (2, 2, 2), (8, 4, 16),
+                                   (16, 16, 16), (2, 32, 4)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_hartley_emulation(shape, dtype):
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=shape).astype(dtype)
+    F = scipy.fft.fftn(x.astype(np.float64))
+    for conv, ref in ((0, F.real + F.imag), (1, F.real - F.imag)):
+        out = np.empty_like(x)
+        f = Fuse()
+        f.in_, f.out, f.scale = x.ctypes.data, out.ctypes.data, 1.0
+        run(f, shape, dtype, conv)
+        err = np.max(np.abs(out - ref)) / np.max(np.abs(ref))
+        assert err < (1e-12 if dtype == np.float64 else 2e-5)
+
+
+@pytest.mark.parametrize("shape", [(64,), (16, 8), (8, 4, 16)])
+def test_fused_prologue_epilogue_emulation(shape):
+    """AMP_JVP prologue and VJP epilogue against their numpy definition."""
+    rng = np.random.default_rng(1)
+    n = int(np.prod(shape))
+    nb = 7
+    pidx = rng.integers(0, nb, size=shape).astype(np.int32)
+    # mirror-symmetric bins like a real PowerSpace
+    idx = np.indices(shape)
+    mirror = tuple((-idx[d]) % shape[d] for d in range(len(shape)))
+    pidx = np.minimum(pidx, pidx[mirror]).astype(np.int32)
+    amp, damp = rng.normal(size=nb), rng.normal(size=nb)
+    xi, dxi, w, addend = (rng.normal(size=shape) for _ in range(4))
+    H = lambda a: (lambda F: F.real + F.imag)(scipy.fft.fftn(a))  # noqa: E731
+    out = np.empty(shape)
+    f = Fuse()
+    f.pro, f.in_, f.in2, f.pidx, f.amp, f.damp = 2, dxi.ctypes.data, xi.ctypes.data, pidx.ctypes.data, amp.ctypes.data, damp.ctypes.data
+    f.epi, f.out, f.scale, f.offset = 0, out.ctypes.data, 0.5, 1.25
+    run(f, shape, np.float64)
+    ref = 0.5 * H(amp[pidx] * dxi + damp[pidx] * xi) + 1.25
+    assert np.max(np.abs(out - ref)) < 1e-11 * np.max(np.abs(ref))
+    abar = np.zeros(nb)
+    out2 = np.full(shape, 3.0)
+    f = Fuse()
+    f.pro, f.in_ = 0, w.ctypes.data
+    f.epi, f.out, f.scale = 2, out2.ctypes.data, 0.25
+    f.pidx, f.amp, f.xi, f.abar = pidx.ctypes.data, amp.ctypes.data, xi.ctypes.data, abar.ctypes.data
+    f.addend, f.addend_scale, f.accumulate = addend.ctypes.data, 2.0, 1
+    run(f, shape, np.float64)
+    t = 0.25 * H(w)
+    assert np.max(np.abs(out2 - (amp[pidx] * t + 2.0 * addend + 3.0))) < 1e-11 * np.max(np.abs(t))
+    assert np.max(np.abs(abar - np.bincount(pidx.ravel(), weights=(xi * t).ravel(), minlength=nb))) < 1e-10
+
+
+def test_likelihood_epilogue_emulation():
+    shape = (8, 16)
+    rng = np.random.default_rng(2)
+    xi = rng.normal(size=shape)
+    d = rng.poisson(3.0, size=shape).astype(np.int64)
+    gs, mid = np.empty(shape), np.empty(shape)
+    val = np.zeros(1)
+    f = Fuse()
+    f.in_, f.epi, f.out, f.out2, f.scale, f.offset = xi.ctypes.data, 3, gs.ctypes.data, mid.ctypes.data, 0.1, 0.3
+    f.lh_kind, f.nonlin, f.data, f.value = 1, 1, d.ctypes.data, val.ctypes.data
+    run(f, shape, np.float64)
+    F = scipy.fft.fftn(xi)
+    s = 0.1 * (F.real + F.imag) + 0.3
+    lam = np.exp(s)
+    assert abs(val[0] - (lam.sum() - (d * s).sum())) < 1e-10 * abs(val[0])
+    assert np.max(np.abs(gs - (lam - d))) < 1e-11 * np.max(np.abs(lam))
+    assert np.max(np.abs(mid - lam)) < 1e-11 * np.max(np.abs(lam))
