@@ -114,7 +114,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    comm, local_rank = parallel.init("nccl")
+    comm, local_rank = parallel.init(os.environ.get("NK_DIST_BACKEND", "nccl"))
+    if os.environ.get("NK_SHARE_DEVICE"):  # developer check: several ranks on one GPU (with NK_DIST_BACKEND=gloo)
+        local_rank = 0
     rank = 0 if comm is None else comm.rank
     world = 1 if comm is None else comm.size
     if world != args.gpus and rank == 0:

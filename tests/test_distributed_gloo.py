@@ -1,0 +1,131 @@
+"""world_size-2 gloo tests of the sample-parallel path (reference test_mpi/test_kl.py:26-114): the KL
+energy built from samples sharded over two ranks equals the single-process one."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem():
+    import nifty_amd as ift
+    from tests import goldenlib as gl
+    from tests.test_api_host import build
+
+    z = gl.load("model_g1d")
+    m, cfm, cf, lh = build(z)
+    x = ift.MultiField.from_raw(cf.domain, gl.latent(z, "x"))
+    v = ift.MultiField.from_raw(cf.domain, gl.latent(z, "v"))
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=m["sampling_limit"])
+    ham = ift.StandardHamiltonian(lh, ic, prior_sampling_dtype=np.float64)
+    return ift, m, ham, x, v
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from nifty_amd import parallel
+
+    comm, _ = parallel.init("gloo")
+    ift, m, ham, x, v = _problem()
+    ift.random.push_sseq_from_seed(m["seed"] + 1)
+    kl = ift.SampledKLEnergy(x, ham, m["n_samples"], None, mirror_samples=True, comm=comm)
+    ift.random.pop_sseq()
+    assert kl.samples.n_local_samples() == 2 and kl.samples.n_samples == 4
+    res = dict(value=kl.value, grad=kl.gradient.asnumpy(), met=kl.apply_metric(v).asnumpy())
+    mini = ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=8)
+    kl2, _ = mini(kl)
+    res["min_value"] = kl2.value
+    res["min_pos"] = kl2.position.asnumpy()
+    if rank == 0:
+        torch.save(res, out)
+    comm.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_kl_equals_serial(tmp_path):
+    from tests import goldenlib as gl
+
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    par = torch.load(out, weights_only=False)
+    z = gl.load("model_g1d")
+    assert abs(par["value"] - float(z["kl_value"])) < 1e-9 * abs(float(z["kl_value"]))
+    assert gl.lat_relerr(par["grad"], gl.latent(z, "kl_grad")) < 1e-8
+    assert gl.lat_relerr(par["met"], gl.latent(z, "kl_metric_v")) < 1e-8
+    assert abs(par["min_value"] - float(z["kl_min_value"])) < 1e-7 * abs(float(z["kl_min_value"]))
+    assert gl.lat_relerr(par["min_pos"], gl.latent(z, "kl_min_pos")) < 1e-6
+
+
+def test_share_range_matches_reference_semantics():
+    from nifty_amd.parallel import shareRange
+
+    # reference utilities.py:282-306: contiguous blocks, remainder to the first shares
+    assert [shareRange(8, 3, r) for r in range(3)] == [(0, 3), (3, 6), (6, 8)]
+    assert [shareRange(16, 8, r) for r in range(8)] == [(2 * r, 2 * r + 2) for r in range(8)]
+    assert [shareRange(2, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    covered = sorted(i for r in range(5) for i in range(*shareRange(13, 5, r)))
+    assert covered == list(range(13))
+
+
+def _engine_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from nifty_amd import parallel, random
+    from nifty_amd.engine import FusedKL, LatentVec, draw_samples
+    from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG
+    from tests import goldenlib as gl
+    from tests.test_engine_gpu import _model
+
+    comm, _ = parallel.init("gloo")  # both ranks share cuda:0; gloo stages device tensors through the host
+    z = gl.load("model_g1d")
+    m, model = _model(z)
+    xl = LatentVec.from_dict(model, gl.latent(z, "x"))
+    vl = LatentVec.from_dict(model, gl.latent(z, "v"))
+    random.push_sseq_from_seed(m["seed"] + 1)
+    res, negs, n_total = draw_samples(model, xl, m["n_samples"], True,
+                                      lambda: AbsDeltaEnergyController(0.05, iteration_limit=m["sampling_limit"]), comm)
+    random.pop_sseq()
+    assert len(res) == 2 and n_total == 4
+    kl = FusedKL(model, xl, res, negs, n_total, comm)
+    out_d = dict(value=kl.value, grad=kl.gradient.to_dict(), met=kl.apply_metric(vl).to_dict())
+    mini = NewtonCG(AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=8)
+    kl2, _ = mini(kl)
+    out_d["min_value"] = kl2.value
+    out_d["min_pos"] = kl2.position.to_dict()
+    if rank == 0:
+        torch.save(out_d, out)
+    comm.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_rank_fused_engine_equals_reference(tmp_path):
+    """The sample-sharded fused engine (the path bench.py --gpus N runs) with 2 ranks on one GPU."""
+    from tests import goldenlib as gl
+
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_engine_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    par = torch.load(out, weights_only=False)
+    z = gl.load("model_g1d")
+    assert abs(par["value"] - float(z["kl_value"])) < 1e-9 * abs(float(z["kl_value"]))
+    assert gl.lat_relerr(par["grad"], gl.latent(z, "kl_grad")) < 1e-8
+    assert gl.lat_relerr(par["met"], gl.latent(z, "kl_metric_v")) < 1e-8
+    assert abs(par["min_value"] - float(z["kl_min_value"])) < 1e-7 * abs(float(z["kl_min_value"]))
+    assert gl.lat_relerr(par["min_pos"], gl.latent(z, "kl_min_pos")) < 1e-6
