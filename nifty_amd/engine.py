@@ -517,6 +517,10 @@ def draw_samples(model, position, n_samples, mirror_samples, controller_factory,
             if not neg or y is None:
                 if lp is None:
                     lp = model.linearize(position)
+                if device_rng is not None:
+                    # synthetic-draw mode: still one stream per sample seed, so both members of a mirrored pair
+                    # see identical draws even when they live on different ranks (kl_energies.py:132-146)
+                    device_rng.manual_seed(int(sseq[i].generate_state(1, np.uint64)[0] >> np.uint64(1)))
                 _, y = model.draw_mgvi_sample(lp, controller_factory(), device_rng)
             residuals.append(y)
             negs.append(neg)
