@@ -7,6 +7,7 @@
 #include <new>
 
 #include "nk_plan.h"
+#include "nk_fft2.h"
 #include "nk_util.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -178,6 +179,92 @@ __global__ void k_passD(NkGeom g, NkFuse f, const C2<T>* __restrict__ scratch, i
   double acc = 0.0;
   if (gid < total) nk_passD<T>(g, f, gid, scratch, acc);
   nk_flush_energy(f, acc, red);
+}
+
+// ---- fast path: register-resident passes (nk_fft2.h) ---------------------------------------------------
+template <typename T, int H, bool IS_1D>
+__global__ void __launch_bounds__((ContigTile<T, H>::THREADS))
+    k2_contig(NkPassA p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr, C2<T>* __restrict__ work) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  DeviceExec<T, Sched<T, H>::E> ex;
+  double acc = 0.0;
+  nk_contig_body<T, H, ContigTile<T, H>::TILE, IS_1D>(ex, p, f, blockIdx.x, (T*)smem, tw, twr, work, &acc);
+  if (IS_1D) nk_flush_energy(f, acc, smem);
+}
+
+template <typename T, int N, bool IS_C>
+__global__ void __launch_bounds__((StridedTile<T, N>::THREADS))
+    k2_strided(NkPassS p, NkFuse f, const C2<T>* __restrict__ tw, C2<T>* __restrict__ work, C2<T>* __restrict__ scratch) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  DeviceExec<T, Sched<T, N>::E> ex;
+  double acc = 0.0;
+  nk_strided_body<T, N, StridedTile<T, N>::TILE, IS_C>(ex, p, f, blockIdx.x, (T*)smem, tw, work, scratch, &acc);
+  if (IS_C) nk_flush_energy(f, acc, smem);
+}
+
+template <typename T, int H, bool IS_1D>
+static int nk_launch_contig(const NkPassA& pa, const NkFuse& f, const C2<T>* tw, const C2<T>* twr, C2<T>* work,
+                            hipStream_t st) {
+  using CT = ContigTile<T, H>;
+  auto kern = k2_contig<T, H, IS_1D>;
+  static bool attr_done = false;
+  if (!attr_done && CT::LDS_BYTES > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CT::LDS_BYTES);
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k2_contig)");
+  }
+  attr_done = true;
+  const int64_t blocks = (pa.nlines + CT::TILE - 1) / CT::TILE;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CT::THREADS), CT::LDS_BYTES, st, pa, f, tw, twr, work);
+  return nk_check_launch("k2_contig");
+}
+
+template <typename T, int N, bool IS_C>
+static int nk_launch_strided(NkPassS ps, const NkFuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch, hipStream_t st) {
+  using ST = StridedTile<T, N>;
+  auto kern = k2_strided<T, N, IS_C>;
+  static bool attr_done = false;
+  if (!attr_done && ST::LDS_BYTES > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ST::LDS_BYTES);
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k2_strided)");
+  }
+  attr_done = true;
+  ps.tl.tile = ST::TILE;
+  ps.tiles_per_slab = (int)(ps.inner / ST::TILE);
+  const int64_t blocks = ps.outer * ps.tiles_per_slab;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ST::THREADS), ST::LDS_BYTES, st, ps, f, tw, work, scratch);
+  return nk_check_launch("k2_strided");
+}
+
+template <typename T, bool IS_1D>
+static int nk_dispatch_contig(int h, const NkPassA& pa, const NkFuse& f, const C2<T>* tw, const C2<T>* twr, C2<T>* work,
+                              hipStream_t st) {
+  switch (h) {
+#define NK_CASE(NN) \
+  case NN:          \
+    return nk_launch_contig<T, NN, IS_1D>(pa, f, tw, twr, work, st);
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+  }
+  return nk_set_error(NK_ERR_UNSUPPORTED, "no fast contiguous pass for this length");
+}
+
+template <typename T, bool IS_C>
+static int nk_dispatch_strided(int n, const NkPassS& ps, const NkFuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch,
+                               hipStream_t st) {
+  switch (n) {
+#define NK_CASE(NN) \
+  case NN:          \
+    return nk_launch_strided<T, NN, IS_C>(ps, f, tw, work, scratch, st);
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+  }
+  return nk_set_error(NK_ERR_UNSUPPORTED, "no fast strided pass for this length");
+}
+
+static bool nk_fast_enabled() {
+  static int v = -1;
+  if (v < 0) v = nk_env_int("NK_FAST", 1) ? 1 : 0;
+  return v == 1;
 }
 
 // ---- c2c passes -----------------------------------------------------------------------------------
@@ -408,26 +495,38 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
   const C2<T>* twr = (const C2<T>*)P->d_twr_a;
   const int64_t blocks_a = (pa.nlines + pa.tl.tile - 1) / pa.tl.tile;
   if (blocks_a > 0x7fffffffLL) return nk_set_error(NK_ERR_UNSUPPORTED, "too many lines for one launch");
+  const bool fast = nk_fast_enabled();
   if (hp.g.ndim == 1) {
     ProfScope ps(st, 0, f.pro, f.epi);
+    if (fast && nk_fast_contig_ok(hp.g.h))
+      return nk_dispatch_contig<T, true>(hp.g.h, pa, f, tw_a, twr, (C2<T>*)nullptr, st);
     hipLaunchKernelGGL(k_pass1d<T>, dim3((unsigned)blocks_a), dim3(hp.threads_a), hp.lds_a, st, pa, f, tw_a, twr);
     return nk_check_launch("k_pass1d");
   }
   if (!workspace) return nk_set_error(NK_ERR_INVALID, "nk_hartley: workspace required for ndim >= 2");
   C2<T>* work = (C2<T>*)workspace;
   C2<T>* scratch = (C2<T>*)((char*)workspace + (hp.work_bytes + 255) / 256 * 256);
+  int rc;
   {
     ProfScope ps(st, 1, f.pro, f.epi);
-    hipLaunchKernelGGL(k_passA<T>, dim3((unsigned)blocks_a), dim3(hp.threads_a), hp.lds_a, st, pa, f, tw_a, twr, work);
+    if (fast && nk_fast_contig_ok(hp.g.h)) {
+      rc = nk_dispatch_contig<T, false>(hp.g.h, pa, f, tw_a, twr, work, st);
+    } else {
+      hipLaunchKernelGGL(k_passA<T>, dim3((unsigned)blocks_a), dim3(hp.threads_a), hp.lds_a, st, pa, f, tw_a, twr, work);
+      rc = nk_check_launch("k_passA");
+    }
   }
-  int rc = nk_check_launch("k_passA");
   if (rc != NK_OK) return rc;
   if (hp.g.ndim == 3) {
     const int64_t blocks_b = hp.pb.outer * hp.pb.tiles_per_slab;
     ProfScope ps(st, 2, f.pro, f.epi);
-    hipLaunchKernelGGL(k_passB<T>, dim3((unsigned)blocks_b), dim3(hp.threads_b), hp.lds_b, st, hp.pb,
-                       (const C2<T>*)P->d_tw_b, work);
-    rc = nk_check_launch("k_passB");
+    if (fast && nk_fast_strided_ok<T>(hp.g.nm, hp.pb.inner)) {
+      rc = nk_dispatch_strided<T, false>(hp.g.nm, hp.pb, f, (const C2<T>*)P->d_tw_b, work, scratch, st);
+    } else {
+      hipLaunchKernelGGL(k_passB<T>, dim3((unsigned)blocks_b), dim3(hp.threads_b), hp.lds_b, st, hp.pb,
+                         (const C2<T>*)P->d_tw_b, work);
+      rc = nk_check_launch("k_passB");
+    }
     if (rc != NK_OK) return rc;
   }
   NkPassS pc = hp.pc;
@@ -435,10 +534,14 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
   const int64_t blocks_c = pc.outer * pc.tiles_per_slab;
   {
     ProfScope ps(st, 3, f.pro, f.epi);
-    hipLaunchKernelGGL(k_passC<T>, dim3((unsigned)blocks_c), dim3(hp.threads_c), hp.lds_c, st, pc, f,
-                       (const C2<T>*)P->d_tw_c, (const C2<T>*)work, scratch);
+    if (fast && nk_fast_strided_ok<T>(hp.g.na, pc.inner)) {
+      rc = nk_dispatch_strided<T, true>(hp.g.na, pc, f, (const C2<T>*)P->d_tw_c, work, scratch, st);
+    } else {
+      hipLaunchKernelGGL(k_passC<T>, dim3((unsigned)blocks_c), dim3(hp.threads_c), hp.lds_c, st, pc, f,
+                         (const C2<T>*)P->d_tw_c, (const C2<T>*)work, scratch);
+      rc = nk_check_launch("k_passC");
+    }
   }
-  rc = nk_check_launch("k_passC");
   if (rc != NK_OK) return rc;
   const int64_t total_d = (int64_t)hp.g.batch * hp.g.nm * hp.g.na;
   {

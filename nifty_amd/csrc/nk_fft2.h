@@ -1,0 +1,521 @@
+// nk_fft2.h -- register-resident, compile-time specialised line FFT passes (the fast path).
+//
+// Each thread keeps E complex elements of one line in registers for the whole pass; a line of N points is
+// transformed by S <= 3 Stockham stages of radix R_s <= E done entirely in registers (recursive radix-2
+// decimation in time with compile-time twiddles), with ONE LDS exchange between consecutive stages.  The
+// exchange can be split into a real and an imaginary half so the LDS tile is N*TILE*sizeof(T) bytes (half of
+// the complex tile): 1024 x 16 fp32 lines fit in 64 KiB -> two workgroups per CU.
+//
+// Stage s (Ns = R_1..R_{s-1}, R = R_s), butterfly j in [0, N/R):   (Stockham autosort, natural order in and out)
+//     in   x[j + r N/R]              r = 0..R-1,   twiddled by W_{Ns R}^{(j mod Ns) r}
+//     out  y[(j - j mod Ns) R + (j mod Ns) + r' Ns]
+// Thread p of a line (P = N/E threads per line) owns butterflies j = p + q P, q = 0..E/R-1, so stage inputs
+// are always rows p, p+P, ...: consecutive lanes touch consecutive rows (coalesced global loads in the first
+// stage, conflict-free LDS reads in later ones).
+//
+// The body is written against an executor: on the GPU a phase is the code between two __syncthreads(); the
+// test-only host emulation (tests/emu) runs every phase for all thread ids in turn with the per-thread
+// registers kept in an array.
+#pragma once
+#include "nk_fft_phases.h"
+
+// ---------------------------------------------------------------------------------------------
+// in-register DFT of compile-time size R (natural order in / out), forward sign
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct TwConst {
+  // cos(2 pi k / 32), sin(2 pi k / 32), k = 0..15
+  static NK_HD T c(int k) {
+    constexpr double v[16] = {1.0,
+                              0.98078528040323044913,
+                              0.92387953251128675613,
+                              0.83146961230254523708,
+                              0.70710678118654752440,
+                              0.55557023301960222474,
+                              0.38268343236508977173,
+                              0.19509032201612826785,
+                              0.0,
+                              -0.19509032201612826785,
+                              -0.38268343236508977173,
+                              -0.55557023301960222474,
+                              -0.70710678118654752440,
+                              -0.83146961230254523708,
+                              -0.92387953251128675613,
+                              -0.98078528040323044913};
+    return (T)v[k];
+  }
+  static NK_HD T s(int k) {
+    constexpr double v[16] = {0.0,
+                              0.19509032201612826785,
+                              0.38268343236508977173,
+                              0.55557023301960222474,
+                              0.70710678118654752440,
+                              0.83146961230254523708,
+                              0.92387953251128675613,
+                              0.98078528040323044913,
+                              1.0,
+                              0.98078528040323044913,
+                              0.92387953251128675613,
+                              0.83146961230254523708,
+                              0.70710678118654752440,
+                              0.55557023301960222474,
+                              0.38268343236508977173,
+                              0.19509032201612826785};
+    return (T)v[k];
+  }
+};
+
+// v[0..R-1] at stride STR inside a register array; result replaces the inputs in natural order.
+template <typename T, int R>
+struct RegDft {
+  static NK_HD void run(C2<T>* v) {
+    C2<T> ev[R / 2], od[R / 2];
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      ev[i] = v[2 * i];
+      od[i] = v[2 * i + 1];
+    }
+    RegDft<T, R / 2>::run(ev);
+    RegDft<T, R / 2>::run(od);
+#pragma unroll
+    for (int k = 0; k < R / 2; ++k) {
+      // w = exp(-2 pi i k / R) = (cos, -sin) with angle index k*(32/R)
+      const int a = k * (32 / R);
+      C2<T> t;
+      if (a == 0) {
+        t = od[k];
+      } else if (a == 8) {
+        t = C2<T>{od[k].y, -od[k].x};
+      } else {
+        const T c = TwConst<T>::c(a), s = TwConst<T>::s(a);
+        t = C2<T>{od[k].x * c + od[k].y * s, od[k].y * c - od[k].x * s};
+      }
+      v[k] = C2<T>{ev[k].x + t.x, ev[k].y + t.y};
+      v[k + R / 2] = C2<T>{ev[k].x - t.x, ev[k].y - t.y};
+    }
+  }
+};
+template <typename T>
+struct RegDft<T, 1> {
+  static NK_HD void run(C2<T>*) {}
+};
+template <typename T>
+struct RegDft<T, 2> {
+  static NK_HD void run(C2<T>* v) {
+    const C2<T> a = v[0], b = v[1];
+    v[0] = C2<T>{a.x + b.x, a.y + b.y};
+    v[1] = C2<T>{a.x - b.x, a.y - b.y};
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// compile-time schedules
+// ---------------------------------------------------------------------------------------------
+template <int N_, int E_, int S_, int R0_, int R1_, int R2_>
+struct SchedDef {
+  static constexpr int N = N_, E = E_, S = S_, R0 = R0_, R1 = R1_, R2 = R2_;
+  static constexpr int P = N_ / E_;  // threads per line
+  static_assert(R0_ * R1_ * R2_ == N_, "radices must multiply to N");
+  static_assert(E_ % R0_ == 0 && E_ % R1_ == 0 && E_ % R2_ == 0, "radices must divide E");
+  static constexpr int radix(int s) { return s == 0 ? R0_ : s == 1 ? R1_ : R2_; }
+};
+template <typename T, int N>
+struct Sched;
+#define NK_SCHED(TT, NN, EE, SS, A, B, C) \
+  template <>                              \
+  struct Sched<TT, NN> : SchedDef<NN, EE, SS, A, B, C> {}
+NK_SCHED(float, 64, 8, 2, 8, 8, 1);
+NK_SCHED(float, 128, 16, 2, 16, 8, 1);
+NK_SCHED(float, 256, 16, 2, 16, 16, 1);
+NK_SCHED(float, 512, 32, 2, 32, 16, 1);
+NK_SCHED(float, 1024, 32, 2, 32, 32, 1);
+NK_SCHED(float, 2048, 32, 3, 32, 32, 2);
+NK_SCHED(float, 4096, 32, 3, 32, 32, 4);
+NK_SCHED(double, 64, 8, 2, 8, 8, 1);
+NK_SCHED(double, 128, 16, 2, 16, 8, 1);
+NK_SCHED(double, 256, 16, 2, 16, 16, 1);
+NK_SCHED(double, 512, 16, 3, 16, 16, 2);
+NK_SCHED(double, 1024, 16, 3, 16, 16, 4);
+NK_SCHED(double, 2048, 16, 3, 16, 16, 8);
+NK_SCHED(double, 4096, 16, 3, 16, 16, 16);
+#undef NK_SCHED
+
+// ---------------------------------------------------------------------------------------------
+// LDS exchange planes (scalar T).
+//   strided passes : plane[row][t], lanes run over the TILE columns first.  Rows written by neighbouring
+//                    butterflies are R0 apart and would hit the same half of the bank period, so bit 0 of the
+//                    row is flipped by bit log2(R0):  row' = row ^ ((row >> LOGR0) & 1)   (a bijection)
+//   contiguous pass: plane[t][idx + (idx >> 5)], lanes run over the line elements first; the pad turns the
+//                    stride-R0 write pattern into stride R0+1 and the pitch staggers the lines over the banks
+// ---------------------------------------------------------------------------------------------
+constexpr int nk_ilog2(int v) { return v <= 1 ? 0 : 1 + nk_ilog2(v / 2); }
+
+template <int TILE, int LOGR0>
+NK_HD int nk_xrow(int row, int t) {
+  return ((row ^ ((row >> LOGR0) & 1)) * TILE) + t;
+}
+
+template <int N, int P>
+struct ContigLayout {
+  static constexpr int NPAD = N + (N >> 5);
+  static constexpr int PITCH = NPAD + ((P % 32) - (NPAD % 32) + 32) % 32;
+  static NK_HD int addr(int t, int idx) { return t * PITCH + idx + (idx >> 5); }
+};
+
+// tile choices of the fast path ------------------------------------------------------------------
+// strided passes: rows of 128 B when the thread count (P*TILE <= 1024) and the LDS plane (<= 128 KiB) allow
+template <typename T, int N>
+struct StridedTile {
+  static constexpr int P = Sched<T, N>::P;
+  static constexpr int want = 128 / (2 * (int)sizeof(T));
+  static constexpr int by_threads = 1024 / P;
+  static constexpr int by_lds = (128 * 1024) / (N * (int)sizeof(T));
+  static constexpr int m1 = want < by_threads ? want : by_threads;
+  static constexpr int TILE = m1 < by_lds ? m1 : by_lds;
+  static constexpr int THREADS = P * TILE;
+  static constexpr int LDS_BYTES = N * TILE * (int)sizeof(T);
+};
+// contiguous pass: ~256 threads, both planes within 48 KiB
+template <typename T, int H>
+struct ContigTile {
+  static constexpr int P = Sched<T, H>::P;
+  static constexpr int PITCH = ContigLayout<H, P>::PITCH;
+  static constexpr int fit(int tile) {
+    return (tile > 1 && (P * tile > 256 || 2 * tile * PITCH * (int)sizeof(T) > 48 * 1024)) ? fit(tile / 2) : tile;
+  }
+  static constexpr int TILE = fit(16);
+  static constexpr int THREADS = P * TILE;
+  static constexpr int LDS_BYTES = 2 * TILE * PITCH * (int)sizeof(T);
+};
+
+// per-thread register file of one pass
+template <typename T, int E>
+struct PassRegs {
+  C2<T> v[E];
+  T tmp[E];
+};
+
+#ifndef NK_HOST_EMU
+// device executor: a phase is the code between two workgroup barriers, registers live in `regs`
+template <typename T, int E>
+struct DeviceExec {
+  PassRegs<T, E> regs;
+  template <typename F>
+  __device__ __forceinline__ void phase(F f) {
+    f((int)threadIdx.x, regs);
+    __syncthreads();
+  }
+  template <typename F>
+  __device__ __forceinline__ void last_phase(F f) {
+    f((int)threadIdx.x, regs);
+  }
+};
+#endif
+
+template <typename T, typename SC, int S>
+struct StageInfo {
+  static constexpr int R = SC::radix(S);
+  static constexpr int NS = S == 0 ? 1 : S == 1 ? SC::R0 : SC::R0 * SC::R1;  // product of previous radices
+  static constexpr int Q = SC::E / R;                                        // butterflies per thread
+};
+
+// twiddle + in-register butterflies of stage S on v (inputs ordered v[q*R + r])
+template <typename T, typename SC, int S>
+NK_HD void nk_stage_compute(C2<T>* v, int p, const C2<T>* __restrict__ tw) {
+  using SI = StageInfo<T, SC, S>;
+  constexpr int R = SI::R, NS = SI::NS, Q = SI::Q, N = SC::N, P = SC::P;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    if (NS > 1) {
+      const int k = (p + q * P) & (NS - 1);
+      constexpr int step = N / (NS * R);
+#pragma unroll
+      for (int r = 1; r < R; ++r) {
+        const C2<T> w = tw[(k * r * step) & (N - 1)];
+        v[q * R + r] = cmul(v[q * R + r], w);
+      }
+    }
+    RegDft<T, R>::run(v + q * R);
+  }
+}
+
+// row (= line element index) held in v[q*R + r'] AFTER stage S
+template <typename SC, int S>
+NK_HD int nk_out_row(int p, int q, int rp) {
+  constexpr int R = SC::radix(S);
+  constexpr int NS = S == 0 ? 1 : S == 1 ? SC::R0 : SC::R0 * SC::R1;
+  const int j = p + q * SC::P;
+  const int k = j & (NS - 1);
+  return (j - k) * R + k + rp * NS;
+}
+// row that must be in v[q*R + r] BEFORE stage S
+template <typename SC, int S>
+NK_HD int nk_in_row(int p, int q, int r) {
+  constexpr int R = SC::radix(S);
+  return p + q * SC::P + r * (SC::N / R);
+}
+
+// exchange helpers for the strided layout: COMP 0 = real parts, 1 = imaginary parts
+template <typename T, typename SC, int S, int TILE, int COMP>
+NK_HD void nk_xwrite_cols(const C2<T>* v, T* plane, int pp, int t) {
+  constexpr int R = SC::radix(S), Q = SC::E / R, L0 = nk_ilog2(SC::R0);
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+#pragma unroll
+    for (int r = 0; r < R; ++r) plane[nk_xrow<TILE, L0>(nk_out_row<SC, S>(pp, q, r), t)] = COMP ? v[q * R + r].y : v[q * R + r].x;
+}
+template <typename T, typename SC, int S, int TILE>
+NK_HD void nk_xread_cols(T* dst, const T* plane, int pp, int t) {
+  constexpr int R = SC::radix(S), Q = SC::E / R, L0 = nk_ilog2(SC::R0);
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+#pragma unroll
+    for (int r = 0; r < R; ++r) dst[q * R + r] = plane[nk_xrow<TILE, L0>(nk_in_row<SC, S>(pp, q, r), t)];
+}
+
+// ---------------------------------------------------------------------------------------------
+// strided pass body (pass B: in place c2c; pass C: c2c + Hartley combine + epilogue)
+// thread id -> column t = tid % TILE, line thread pp = tid / TILE;  blockDim = P * TILE
+// LDS: ONE scalar plane of N*TILE elements (split real / imaginary exchange)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int N, int TILE, bool IS_C, typename Exec>
+NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t blk, T* plane,
+                           const C2<T>* __restrict__ tw, C2<T>* __restrict__ work, C2<T>* __restrict__ scratch,
+                           double* acc_out) {
+  using SC = Sched<T, N>;
+  constexpr int E = SC::E, S = SC::S;
+  const int64_t o = blk / p.tiles_per_slab;
+  const int64_t c0 = (blk % p.tiles_per_slab) * (int64_t)TILE;
+  C2<T>* base = work + o * N * p.inner + c0;
+
+  ex.phase([&](int tid, PassRegs<T, E>& rg) {
+    const int t = tid % TILE, pp = tid / TILE;
+    constexpr int R = SC::radix(0), Q = E / R;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) rg.v[q * R + r] = base[(int64_t)nk_in_row<SC, 0>(pp, q, r) * p.inner + t];
+    nk_stage_compute<T, SC, 0>(rg.v, pp, tw);
+    nk_xwrite_cols<T, SC, 0, TILE, 0>(rg.v, plane, pp, t);
+  });
+  // exchange 0 -> stage 1
+  ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xread_cols<T, SC, 1, TILE>(rg.tmp, plane, tid / TILE, tid % TILE); });
+  ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xwrite_cols<T, SC, 0, TILE, 1>(rg.v, plane, tid / TILE, tid % TILE); });
+  ex.phase([&](int tid, PassRegs<T, E>& rg) {
+    const int t = tid % TILE, pp = tid / TILE;
+    T im[E];
+    nk_xread_cols<T, SC, 1, TILE>(im, plane, pp, t);
+#pragma unroll
+    for (int e = 0; e < E; ++e) rg.v[e] = C2<T>{rg.tmp[e], im[e]};
+    nk_stage_compute<T, SC, 1>(rg.v, pp, tw);
+  });
+  if constexpr (S == 3) {
+    ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xwrite_cols<T, SC, 1, TILE, 0>(rg.v, plane, tid / TILE, tid % TILE); });
+    ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xread_cols<T, SC, 2, TILE>(rg.tmp, plane, tid / TILE, tid % TILE); });
+    ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xwrite_cols<T, SC, 1, TILE, 1>(rg.v, plane, tid / TILE, tid % TILE); });
+    ex.phase([&](int tid, PassRegs<T, E>& rg) {
+      const int t = tid % TILE, pp = tid / TILE;
+      T im[E];
+      nk_xread_cols<T, SC, 2, TILE>(im, plane, pp, t);
+#pragma unroll
+      for (int e = 0; e < E; ++e) rg.v[e] = C2<T>{rg.tmp[e], im[e]};
+      nk_stage_compute<T, SC, 2>(rg.v, pp, tw);
+    });
+  }
+  ex.last_phase([&](int tid, PassRegs<T, E>& rg) {
+    const int t = tid % TILE, pp = tid / TILE;
+    constexpr int LS = S - 1;
+    constexpr int R = SC::radix(LS), Q = E / R;
+    if (!IS_C) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) base[(int64_t)nk_out_row<SC, LS>(pp, q, r) * p.inner + t] = rg.v[q * R + r];
+    } else {
+      const int h = p.g.h, nm = p.g.nm, nl = p.g.nl;
+      const T sg = (T)p.g.sign;
+      const int64_t c = c0 + t;
+      const int m = (int)(c / h), kl = (int)(c % h);
+      const int mm = m ? nm - m : 0;
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int k0 = nk_out_row<SC, LS>(pp, q, r);
+          const C2<T> F = rg.v[q * R + r];
+          if (kl == 0) {
+            scratch[(o * nm + m) * N + k0] = F;
+          } else {
+            const int k0m = k0 ? N - k0 : 0;
+            const int64_t o1 = ((o * N + k0) * nm + m) * nl + kl;
+            const int64_t o2 = ((o * N + k0m) * nm + mm) * nl + (nl - kl);
+            nk_epilogue_pair<T>(f, o1, F.x + sg * F.y, o2, F.x - sg * F.y, acc);
+          }
+        }
+      *acc_out += acc;
+    }
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
+// contiguous pass body (pass A: real lines -> packed half spectrum;  IS_1D: full 1-D Hartley)
+// thread id -> line thread pp = tid % P, line t = tid / P;  blockDim = P * TILE
+// LDS: TWO scalar planes (re, im) of TILE * PITCH elements
+// ---------------------------------------------------------------------------------------------
+template <typename T, int H, int TILE, bool IS_1D, typename Exec>
+NK_HD void nk_contig_body(Exec& ex, const NkPassA& p, const NkFuse& f, int64_t blk, T* planes,
+                          const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr, C2<T>* __restrict__ work,
+                          double* acc_out) {
+  using SC = Sched<T, H>;
+  using LY = ContigLayout<H, SC::P>;
+  constexpr int E = SC::E, S = SC::S, P = SC::P;
+  T* pre = planes;
+  T* pim = planes + TILE * LY::PITCH;
+  const int64_t line0 = blk * TILE;
+  const int nl = p.g.nl;
+
+  ex.phase([&](int tid, PassRegs<T, E>& rg) {
+    const int pp = tid % P, t = tid / P;
+    const int64_t line = line0 + t;
+    constexpr int R = SC::radix(0), Q = E / R;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        C2<T> z{(T)0, (T)0};
+        if (line < p.nlines) {
+          const int64_t i = line * nl + 2 * (int64_t)nk_in_row<SC, 0>(pp, q, r);
+          z.x = nk_prologue<T>(f, i);
+          z.y = nk_prologue<T>(f, i + 1);
+        }
+        rg.v[q * R + r] = z;
+      }
+    nk_stage_compute<T, SC, 0>(rg.v, pp, tw);
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int a = LY::addr(t, nk_out_row<SC, 0>(pp, q, r));
+        pre[a] = rg.v[q * R + r].x;
+        pim[a] = rg.v[q * R + r].y;
+      }
+  });
+  // stage 1
+  ex.phase([&](int tid, PassRegs<T, E>& rg) {
+    const int pp = tid % P, t = tid / P;
+    constexpr int R = SC::radix(1), Q = E / R;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int a = LY::addr(t, nk_in_row<SC, 1>(pp, q, r));
+        rg.v[q * R + r] = C2<T>{pre[a], pim[a]};
+      }
+    nk_stage_compute<T, SC, 1>(rg.v, pp, tw);
+  });
+  ex.phase([&](int tid, PassRegs<T, E>& rg) {
+    const int pp = tid % P, t = tid / P;
+    constexpr int R = SC::radix(1), Q = E / R;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int a = LY::addr(t, nk_out_row<SC, 1>(pp, q, r));
+        pre[a] = rg.v[q * R + r].x;
+        pim[a] = rg.v[q * R + r].y;
+      }
+  });
+  if constexpr (S == 3) {
+    ex.phase([&](int tid, PassRegs<T, E>& rg) {
+      const int pp = tid % P, t = tid / P;
+      constexpr int R = SC::radix(2), Q = E / R;
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int a = LY::addr(t, nk_in_row<SC, 2>(pp, q, r));
+          rg.v[q * R + r] = C2<T>{pre[a], pim[a]};
+        }
+      nk_stage_compute<T, SC, 2>(rg.v, pp, tw);
+    });
+    ex.phase([&](int tid, PassRegs<T, E>& rg) {
+      const int pp = tid % P, t = tid / P;
+      constexpr int R = SC::radix(2), Q = E / R;
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int a = LY::addr(t, nk_out_row<SC, 2>(pp, q, r));
+          pre[a] = rg.v[q * R + r].x;
+          pim[a] = rg.v[q * R + r].y;
+        }
+    });
+  }
+  // untangle (+ Hartley combine for 1-D) from the natural-order planes
+  ex.last_phase([&](int tid, PassRegs<T, E>& rg) {
+    (void)rg;
+    constexpr int NK = H / 2 + 1;
+    constexpr int NT = P * TILE;
+    const T sg = (T)p.g.sign;
+    double acc = 0.0;
+    for (int idx = tid; idx < TILE * NK; idx += NT) {
+      const int k = idx % NK, t = idx / NK;
+      const int64_t line = line0 + t;
+      if (line >= p.nlines) continue;
+      if (k == 0) {
+        const T zx = pre[LY::addr(t, 0)], zy = pim[LY::addr(t, 0)];
+        if (IS_1D) {
+          nk_epilogue<T>(f, line * nl, zx + zy, acc);
+          nk_epilogue<T>(f, line * nl + H, zx - zy, acc);
+        } else {
+          work[line * H] = C2<T>{zx + zy, zx - zy};
+        }
+        continue;
+      }
+      const int a1 = LY::addr(t, k), a2 = LY::addr(t, H - k);
+      const C2<T> Zk{pre[a1], pim[a1]}, Zm{pre[a2], pim[a2]};
+      const C2<T> Ev{(T)0.5 * (Zk.x + Zm.x), (T)0.5 * (Zk.y - Zm.y)};
+      const C2<T> Od{(T)0.5 * (Zk.x - Zm.x), (T)0.5 * (Zk.y + Zm.y)};
+      const C2<T> G = cmul(twr[k], Od);
+      const C2<T> Fk{Ev.x + G.y, Ev.y - G.x}, Fm{Ev.x - G.y, -Ev.y - G.x};
+      if (IS_1D) {
+        const int64_t ob = line * nl;
+        nk_epilogue_pair<T>(f, ob + k, Fk.x + sg * Fk.y, ob + nl - k, Fk.x - sg * Fk.y, acc);
+        if (k != H - k) nk_epilogue_pair<T>(f, ob + H - k, Fm.x + sg * Fm.y, ob + H + k, Fm.x - sg * Fm.y, acc);
+      } else {
+        work[line * H + k] = Fk;
+        work[line * H + H - k] = Fm;
+      }
+    }
+    *acc_out += acc;
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
+// eligibility of the fast path (shared by the HIP driver and the host emulation)
+// ---------------------------------------------------------------------------------------------
+#define NK_FAST_SIZES(X) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096)
+
+static inline bool nk_fast_size(int n) {
+  return n == 64 || n == 128 || n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096;
+}
+template <typename T>
+static inline int nk_fast_strided_tile(int n) {
+  switch (n) {
+#define NK_CASE(NN) \
+  case NN:          \
+    return StridedTile<T, NN>::TILE;
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+    default:
+      return 0;
+  }
+}
+template <typename T>
+static inline bool nk_fast_strided_ok(int n, int64_t inner) {
+  if (!nk_fast_size(n)) return false;
+  const int tile = nk_fast_strided_tile<T>(n);
+  return tile > 0 && inner % tile == 0;
+}
+static inline bool nk_fast_contig_ok(int h) { return nk_fast_size(h); }

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../nifty_amd/csrc/nk_plan.h"
+#include "../../nifty_amd/csrc/nk_fft2.h"
 
 template <typename T>
 static std::vector<C2<T>> conv_tw(const std::vector<double>& tw) {
@@ -78,6 +79,106 @@ static int emu_run(int ndim, const int64_t* shape, int dtype, int64_t batch, con
   }
   if (f->epi == NK_EPI_LIKELIHOOD && f->value) *f->value += energy;
   return NK_OK;
+}
+
+// ---- fast path (register-resident bodies of nk_fft2.h) ------------------------------------------------
+template <typename T, int E>
+struct HostExec {
+  std::vector<PassRegs<T, E>> regs;
+  explicit HostExec(int n) : regs(n) {}
+  template <typename F>
+  void phase(F f) {
+    for (int tid = 0; tid < (int)regs.size(); ++tid) f(tid, regs[tid]);
+  }
+  template <typename F>
+  void last_phase(F f) {
+    phase(f);
+  }
+};
+
+template <typename T, int N>
+static void emu2_strided(NkPassS p, bool is_c, const nk_fuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch,
+                         double* energy) {
+  using ST = StridedTile<T, N>;
+  p.tl.tile = ST::TILE;
+  p.tiles_per_slab = (int)(p.inner / ST::TILE);
+  std::vector<T> plane(N * ST::TILE);
+  const int64_t blocks = p.outer * p.tiles_per_slab;
+  for (int64_t blk = 0; blk < blocks; ++blk) {
+    HostExec<T, Sched<T, N>::E> ex(ST::THREADS);
+    if (is_c) nk_strided_body<T, N, ST::TILE, true>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+    else nk_strided_body<T, N, ST::TILE, false>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+  }
+}
+
+template <typename T, int H>
+static void emu2_contig(NkPassA p, bool is_1d, const nk_fuse& f, const C2<T>* tw, const C2<T>* twr, C2<T>* work,
+                        double* energy) {
+  using CT = ContigTile<T, H>;
+  std::vector<T> planes(CT::LDS_BYTES / sizeof(T));
+  const int64_t blocks = (p.nlines + CT::TILE - 1) / CT::TILE;
+  for (int64_t blk = 0; blk < blocks; ++blk) {
+    HostExec<T, Sched<T, H>::E> ex(CT::THREADS);
+    if (is_1d) nk_contig_body<T, H, CT::TILE, true>(ex, p, f, blk, planes.data(), tw, twr, work, energy);
+    else nk_contig_body<T, H, CT::TILE, false>(ex, p, f, blk, planes.data(), tw, twr, work, energy);
+  }
+}
+
+template <typename T>
+static int emu2_run(int ndim, const int64_t* shape, int dtype, int64_t batch, const nk_fuse* f, int convention) {
+  NkHostPlan hp;
+  const char* msg;
+  int rc = nk_host_plan_init(hp, ndim, shape, dtype, batch, &msg);
+  if (rc != NK_OK) return rc;
+  auto tw_a = conv_tw<T>(hp.tw_a), twr = conv_tw<T>(hp.twr_a), tw_b = conv_tw<T>(hp.tw_b), tw_c = conv_tw<T>(hp.tw_c);
+  const NkGeom& g = hp.g;
+  if (!nk_fast_contig_ok(g.h)) return -100;
+  if (ndim == 3 && !nk_fast_strided_ok<T>(g.nm, hp.pb.inner)) return -101;
+  if (ndim >= 2 && !nk_fast_strided_ok<T>(g.na, hp.pc.inner)) return -102;
+  NkPassA pa = hp.pa;
+  pa.g.sign = convention == NK_HARTLEY_CANONICAL ? -1 : 1;
+  double energy = 0.0;
+  std::vector<C2<T>> work(hp.work_bytes / sizeof(C2<T>) + 1), scratch(hp.scratch_bytes / sizeof(C2<T>) + 1);
+  switch (g.h) {
+#define NK_CASE(NN) \
+  case NN:          \
+    emu2_contig<T, NN>(pa, ndim == 1, *f, tw_a.data(), twr.data(), work.data(), &energy); \
+    break;
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+  }
+  if (ndim == 3) {
+    switch (g.nm) {
+#define NK_CASE(NN) \
+  case NN:          \
+    emu2_strided<T, NN>(hp.pb, false, *f, tw_b.data(), work.data(), scratch.data(), &energy); \
+    break;
+      NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+    }
+  }
+  if (ndim >= 2) {
+    NkPassS pc = hp.pc;
+    pc.g.sign = pa.g.sign;
+    switch (g.na) {
+#define NK_CASE(NN) \
+  case NN:          \
+    emu2_strided<T, NN>(pc, true, *f, tw_c.data(), work.data(), scratch.data(), &energy); \
+    break;
+      NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+    }
+    const int64_t total_d = (int64_t)pc.g.batch * pc.g.nm * pc.g.na;
+    for (int64_t gid = 0; gid < total_d; ++gid) nk_passD<T>(pc.g, *f, gid, scratch.data(), energy);
+  }
+  if (f->epi == NK_EPI_LIKELIHOOD && f->value) *f->value += energy;
+  return NK_OK;
+}
+
+extern "C" int emu2_hartley_fused(int ndim, const int64_t* shape, int dtype, int64_t batch, const nk_fuse* f,
+                                  int convention) {
+  if (dtype == NK_F32) return emu2_run<float>(ndim, shape, dtype, batch, f, convention);
+  return emu2_run<double>(ndim, shape, dtype, batch, f, convention);
 }
 
 extern "C" int emu_hartley_fused(int ndim, const int64_t* shape, int dtype, int64_t batch, const nk_fuse* f,
