@@ -283,6 +283,33 @@ NK_HD void nk_epilogue_pair(const NkFuse& f, int64_t o1, T v1, int64_t o2, T v2,
   }
 }
 
+// up to four outputs that share one power bin (the mirror images of one coefficient): one atomic for the VJP
+template <typename T>
+NK_HD void nk_epilogue_multi(const NkFuse& f, const int64_t (&o)[4], const T (&v)[4], int mask, double& acc) {
+  if (f.epi == NK_EPI_VJP) {
+    T* out = (T*)f.out;
+    const T* xi = (const T*)f.xi;
+    const int32_t p = f.pidx[o[0]];
+    const double a = f.amp[p];
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!(mask & (1 << i))) continue;
+      const double t = (double)v[i] * f.scale;
+      double r = a * t;
+      if (f.addend) r += f.addend_scale * (double)((const T*)f.addend)[o[i]];
+      if (f.accumulate) r += (double)out[o[i]];
+      out[o[i]] = (T)r;
+      s += (double)xi[o[i]] * t;
+    }
+    NK_ATOMIC_ADD(f.abar + p, s);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (mask & (1 << i)) nk_epilogue<T>(f, o[i], v[i], acc);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // transform geometry shared by the pass kernels
 // ---------------------------------------------------------------------------------------------

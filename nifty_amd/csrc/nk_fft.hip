@@ -192,14 +192,53 @@ __global__ void __launch_bounds__((ContigTile<T, H>::THREADS))
   if (IS_1D) nk_flush_energy(f, acc, smem);
 }
 
-template <typename T, int N, bool IS_C>
+template <typename T, int N, int MODE>
 __global__ void __launch_bounds__((StridedTile<T, N>::THREADS))
     k2_strided(NkPassS p, NkFuse f, const C2<T>* __restrict__ tw, C2<T>* __restrict__ work, C2<T>* __restrict__ scratch) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, Sched<T, N>::E> ex;
   double acc = 0.0;
-  nk_strided_body<T, N, StridedTile<T, N>::TILE, IS_C>(ex, p, f, blockIdx.x, (T*)smem, tw, work, scratch, &acc);
-  if (IS_C) nk_flush_energy(f, acc, smem);
+  nk_strided_body<T, N, StridedTile<T, N>::TILE, MODE>(ex, p, f, blockIdx.x, (T*)smem, tw, work, scratch, &acc);
+  (void)acc;
+}
+
+template <typename T, int NL>
+__global__ void __launch_bounds__((ContigTile<T, NL>::THREADS))
+    k2_final(NkPassF p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  DeviceExec<T, Sched<T, NL>::E> ex;
+  double acc = 0.0;
+  nk_final_body<T, NL, ContigTile<T, NL>::TILE>(ex, p, f, blockIdx.x, (T*)smem, tw, work, &acc);
+  nk_flush_energy(f, acc, smem);
+}
+
+template <typename T, int NL>
+static int nk_launch_final(NkPassF pf, const NkFuse& f, const C2<T>* tw, const C2<T>* work, hipStream_t st) {
+  using CT = ContigTile<T, NL>;
+  auto kern = k2_final<T, NL>;
+  static bool attr_done = false;
+  if (!attr_done && CT::LDS_BYTES > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CT::LDS_BYTES);
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k2_final)");
+  }
+  attr_done = true;
+  pf.tiles_per_a = (pf.M + CT::TILE - 1) / CT::TILE;
+  const int64_t blocks = (int64_t)pf.g.batch * (pf.A / 2 + 1) * pf.tiles_per_a;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CT::THREADS), CT::LDS_BYTES, st, pf, f, tw, work);
+  return nk_check_launch("k2_final");
+}
+
+template <typename T>
+static int nk_dispatch_final(int nl, const NkPassF& pf, const NkFuse& f, const C2<T>* tw, const C2<T>* work,
+                             hipStream_t st) {
+  switch (nl) {
+#define NK_CASE(NN) \
+  case NN:          \
+    return nk_launch_final<T, NN>(pf, f, tw, work, st);
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+  }
+  return nk_set_error(NK_ERR_UNSUPPORTED, "no fast final pass for this length");
 }
 
 template <typename T, int H, bool IS_1D>
@@ -218,10 +257,10 @@ static int nk_launch_contig(const NkPassA& pa, const NkFuse& f, const C2<T>* tw,
   return nk_check_launch("k2_contig");
 }
 
-template <typename T, int N, bool IS_C>
+template <typename T, int N, int MODE>
 static int nk_launch_strided(NkPassS ps, const NkFuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch, hipStream_t st) {
   using ST = StridedTile<T, N>;
-  auto kern = k2_strided<T, N, IS_C>;
+  auto kern = k2_strided<T, N, MODE>;
   static bool attr_done = false;
   if (!attr_done && ST::LDS_BYTES > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ST::LDS_BYTES);
@@ -248,13 +287,13 @@ static int nk_dispatch_contig(int h, const NkPassA& pa, const NkFuse& f, const C
   return nk_set_error(NK_ERR_UNSUPPORTED, "no fast contiguous pass for this length");
 }
 
-template <typename T, bool IS_C>
+template <typename T, int MODE>
 static int nk_dispatch_strided(int n, const NkPassS& ps, const NkFuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch,
                                hipStream_t st) {
   switch (n) {
 #define NK_CASE(NN) \
   case NN:          \
-    return nk_launch_strided<T, NN, IS_C>(ps, f, tw, work, scratch, st);
+    return nk_launch_strided<T, NN, MODE>(ps, f, tw, work, scratch, st);
     NK_FAST_SIZES(NK_CASE)
 #undef NK_CASE
   }
@@ -341,6 +380,7 @@ struct nk_plan {
   void* d_twr_a = nullptr;  // untangle twiddles
   void* d_tw_b = nullptr;
   void* d_tw_c = nullptr;
+  void* d_tw_f = nullptr;   // full-length table of the last axis (final pass of the strided-first pipeline)
   // c2c: full-length contiguous-axis plan
   NkPassCC cc{};
   int threads_cc = 256;
@@ -400,6 +440,7 @@ extern "C" int nk_plan_create(nk_plan** out, int ndim, const int64_t* shape, int
   if (rc == NK_OK) rc = nk_upload_twiddle(&P->d_twr_a, hp.twr_a, dtype);
   if (rc == NK_OK && ndim == 3) rc = nk_upload_twiddle(&P->d_tw_b, hp.tw_b, dtype);
   if (rc == NK_OK && ndim >= 2) rc = nk_upload_twiddle(&P->d_tw_c, hp.tw_c, dtype);
+  if (rc == NK_OK && ndim >= 2) rc = nk_upload_twiddle(&P->d_tw_f, hp.tw_f, dtype);
   // c2c plan pieces: contiguous last axis of full length nl, strided middle/first axes with inner = nl
   if (rc == NK_OK) {
     const NkGeom& g = hp.g;
@@ -469,7 +510,7 @@ extern "C" int nk_plan_create(nk_plan** out, int ndim, const int64_t* shape, int
 
 extern "C" int nk_plan_destroy(nk_plan* P) {
   if (!P) return NK_OK;
-  void* ptrs[] = {P->d_tw_a, P->d_twr_a, P->d_tw_b, P->d_tw_c, P->d_tw_cc};
+  void* ptrs[] = {P->d_tw_a, P->d_twr_a, P->d_tw_b, P->d_tw_c, P->d_tw_cc, P->d_tw_f};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete P;
@@ -507,6 +548,32 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
   C2<T>* work = (C2<T>*)workspace;
   C2<T>* scratch = (C2<T>*)((char*)workspace + (hp.work_bytes + 255) / 256 * 256);
   int rc;
+  // ---- strided-first pipeline (default when every axis has a specialised kernel): strided c2c passes on the
+  //      real array viewed as complex pairs, then ONE contiguous final pass per line pair (k, -k)
+  static const int pipeline = nk_env_int("NK_PIPELINE", 2);
+  if (fast && pipeline == 2 && nk_fast_size(hp.g.nl) && nk_fast_strided_ok<T>(hp.g.na, hp.pc.inner) &&
+      (hp.g.ndim == 2 || nk_fast_strided_ok<T>(hp.g.nm, hp.pb.inner))) {
+    if (hp.g.ndim == 3) {
+      {
+        ProfScope ps(st, 1, f.pro, f.epi);
+        rc = nk_dispatch_strided<T, 3>(hp.g.nm, hp.pb, f, (const C2<T>*)P->d_tw_b, work, scratch, st);
+      }
+      if (rc != NK_OK) return rc;
+      ProfScope ps(st, 2, f.pro, f.epi);
+      rc = nk_dispatch_strided<T, 0>(hp.g.na, hp.pc, f, (const C2<T>*)P->d_tw_c, work, scratch, st);
+    } else {
+      ProfScope ps(st, 1, f.pro, f.epi);
+      rc = nk_dispatch_strided<T, 3>(hp.g.na, hp.pc, f, (const C2<T>*)P->d_tw_c, work, scratch, st);
+    }
+    if (rc != NK_OK) return rc;
+    NkPassF pf{};
+    pf.g = hp.g;
+    pf.g.sign = pa.g.sign;
+    pf.A = hp.g.ndim == 3 ? hp.g.na : 1;
+    pf.M = hp.g.ndim == 3 ? hp.g.nm : hp.g.na;
+    ProfScope ps(st, 3, f.pro, f.epi);
+    return nk_dispatch_final<T>(hp.g.nl, pf, f, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
+  }
   {
     ProfScope ps(st, 1, f.pro, f.epi);
     if (fast && nk_fast_contig_ok(hp.g.h)) {
@@ -517,11 +584,13 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
     }
   }
   if (rc != NK_OK) return rc;
+  NkPassS pc = hp.pc;
+  pc.g.sign = pa.g.sign;
   if (hp.g.ndim == 3) {
     const int64_t blocks_b = hp.pb.outer * hp.pb.tiles_per_slab;
     ProfScope ps(st, 2, f.pro, f.epi);
     if (fast && nk_fast_strided_ok<T>(hp.g.nm, hp.pb.inner)) {
-      rc = nk_dispatch_strided<T, false>(hp.g.nm, hp.pb, f, (const C2<T>*)P->d_tw_b, work, scratch, st);
+      rc = nk_dispatch_strided<T, 0>(hp.g.nm, hp.pb, f, (const C2<T>*)P->d_tw_b, work, scratch, st);
     } else {
       hipLaunchKernelGGL(k_passB<T>, dim3((unsigned)blocks_b), dim3(hp.threads_b), hp.lds_b, st, hp.pb,
                          (const C2<T>*)P->d_tw_b, work);
@@ -529,18 +598,12 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
     }
     if (rc != NK_OK) return rc;
   }
-  NkPassS pc = hp.pc;
-  pc.g.sign = pa.g.sign;
   const int64_t blocks_c = pc.outer * pc.tiles_per_slab;
   {
     ProfScope ps(st, 3, f.pro, f.epi);
-    if (fast && nk_fast_strided_ok<T>(hp.g.na, pc.inner)) {
-      rc = nk_dispatch_strided<T, true>(hp.g.na, pc, f, (const C2<T>*)P->d_tw_c, work, scratch, st);
-    } else {
-      hipLaunchKernelGGL(k_passC<T>, dim3((unsigned)blocks_c), dim3(hp.threads_c), hp.lds_c, st, pc, f,
-                         (const C2<T>*)P->d_tw_c, (const C2<T>*)work, scratch);
-      rc = nk_check_launch("k_passC");
-    }
+    hipLaunchKernelGGL(k_passC<T>, dim3((unsigned)blocks_c), dim3(hp.threads_c), hp.lds_c, st, pc, f,
+                       (const C2<T>*)P->d_tw_c, (const C2<T>*)work, scratch);
+    rc = nk_check_launch("k_passC");
   }
   if (rc != NK_OK) return rc;
   const int64_t total_d = (int64_t)hp.g.batch * hp.g.nm * hp.g.na;

@@ -278,7 +278,10 @@ NK_HD void nk_xread_cols(T* dst, const T* plane, int pp, int t) {
 // thread id -> column t = tid % TILE, line thread pp = tid / TILE;  blockDim = P * TILE
 // LDS: ONE scalar plane of N*TILE elements (split real / imaginary exchange)
 // ---------------------------------------------------------------------------------------------
-template <typename T, int N, int TILE, bool IS_C, typename Exec>
+// MODE 3: FIRST pass of the strided-first pipeline: the real input (through the fused prologue) is read as
+//         complex pairs along the contiguous axis, transformed along this strided axis and written to `work`
+// MODE 0: plain in-place c2c
+template <typename T, int N, int TILE, int MODE, typename Exec>
 NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t blk, T* plane,
                            const C2<T>* __restrict__ tw, C2<T>* __restrict__ work, C2<T>* __restrict__ scratch,
                            double* acc_out) {
@@ -294,7 +297,15 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
-      for (int r = 0; r < R; ++r) rg.v[q * R + r] = base[(int64_t)nk_in_row<SC, 0>(pp, q, r) * p.inner + t];
+      for (int r = 0; r < R; ++r) {
+        const int64_t off = (int64_t)nk_in_row<SC, 0>(pp, q, r) * p.inner + t;
+        if (MODE == 3) {
+          const int64_t i = 2 * ((base - work) + off);
+          rg.v[q * R + r] = C2<T>{nk_prologue<T>(f, i), nk_prologue<T>(f, i + 1)};
+        } else {
+          rg.v[q * R + r] = base[off];
+        }
+      }
     nk_stage_compute<T, SC, 0>(rg.v, pp, tw);
     nk_xwrite_cols<T, SC, 0, TILE, 0>(rg.v, plane, pp, t);
   });
@@ -326,34 +337,13 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
     const int t = tid % TILE, pp = tid / TILE;
     constexpr int LS = S - 1;
     constexpr int R = SC::radix(LS), Q = E / R;
-    if (!IS_C) {
+    (void)scratch;
+    (void)acc_out;
+    {
 #pragma unroll
       for (int q = 0; q < Q; ++q)
 #pragma unroll
         for (int r = 0; r < R; ++r) base[(int64_t)nk_out_row<SC, LS>(pp, q, r) * p.inner + t] = rg.v[q * R + r];
-    } else {
-      const int h = p.g.h, nm = p.g.nm, nl = p.g.nl;
-      const T sg = (T)p.g.sign;
-      const int64_t c = c0 + t;
-      const int m = (int)(c / h), kl = (int)(c % h);
-      const int mm = m ? nm - m : 0;
-      double acc = 0.0;
-#pragma unroll
-      for (int q = 0; q < Q; ++q)
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int k0 = nk_out_row<SC, LS>(pp, q, r);
-          const C2<T> F = rg.v[q * R + r];
-          if (kl == 0) {
-            scratch[(o * nm + m) * N + k0] = F;
-          } else {
-            const int k0m = k0 ? N - k0 : 0;
-            const int64_t o1 = ((o * N + k0) * nm + m) * nl + kl;
-            const int64_t o2 = ((o * N + k0m) * nm + mm) * nl + (nl - kl);
-            nk_epilogue_pair<T>(f, o1, F.x + sg * F.y, o2, F.x - sg * F.y, acc);
-          }
-        }
-      *acc_out += acc;
     }
   });
 }
@@ -487,6 +477,162 @@ NK_HD void nk_contig_body(Exec& ex, const NkPassA& p, const NkFuse& f, int64_t b
         work[line * H + k] = Fk;
         work[line * H + H - k] = Fm;
       }
+    }
+    *acc_out += acc;
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
+// FINAL pass of the strided-first pipeline (contiguous axis).
+// After the strided passes  Z_j(k) = A_j(k) + i B_j(k)  with A_j = FFT_strided(x[.., 2j]), B_j = FFT_strided(x[.., 2j+1])
+// (both Hermitian in the strided wave vector k).  For the line pair (k, -k):
+//     G(k, 2j)   = A_j(k) = (Z_j(k) + conj Z_j(-k)) / 2
+//     G(k, 2j+1) = B_j(k) = (Z_j(k) - conj Z_j(-k)) / (2i)
+// ONE complex FFT of length nl over n_last gives F(k, k_last); the partner line follows from
+// F(-k, k_last) = conj F(k, -k_last), so  H(k, kl) = Re F + s Im F  and  H(-k, -kl) = Re F - s Im F  are both
+// written as whole contiguous rows (no scattered mirror segments, no packed column).
+// Lines are (a, b): a on the first axis (A values, 1 for 2-D), b on the middle axis (M values).
+// thread id -> line thread pp = tid % P, pair slot t = tid / P;  LDS: two planes of TILE * PITCH
+// ---------------------------------------------------------------------------------------------
+struct NkPassF {
+  NkGeom g;
+  int A, M;          // line index space (first, middle)
+  int tiles_per_a;   // M / TILE
+};
+
+template <typename T, int NL, int TILE, typename Exec>
+NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f, int64_t blk, T* planes,
+                         const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, double* acc_out) {
+  using SC = Sched<T, NL>;
+  using LY = ContigLayout<NL, SC::P>;
+  constexpr int E = SC::E, S = SC::S, P = SC::P, H = NL / 2;
+  T* pre = planes;
+  T* pim = planes + TILE * LY::PITCH;
+  const int A = p.A, M = p.M;
+  const int bt0 = (int)(blk % p.tiles_per_a);
+  const int64_t r0 = blk / p.tiles_per_a;
+  const int a = (int)(r0 % (A / 2 + 1));
+  const int64_t bat = r0 / (A / 2 + 1);
+  const int am = a ? A - a : 0;
+  const bool a_self = (a == am);
+
+  auto line_of = [&](int t, int& b, int& bm, bool& active, bool& self) {
+    b = bt0 * TILE + t;
+    bm = b ? M - b : 0;
+    active = b < M && !(a_self && b > bm);
+    self = a_self && b == bm;
+  };
+
+  ex.phase([&](int tid, PassRegs<T, E>& rg) {
+    const int pp = tid % P, t = tid / P;
+    int b, bm;
+    bool active, self;
+    line_of(t, b, bm, active, self);
+    const C2<T>* lk = work + ((bat * A + a) * M + b) * (int64_t)H;
+    const C2<T>* lm = work + ((bat * A + am) * M + bm) * (int64_t)H;
+    constexpr int R = SC::radix(0), Q = E / R;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        C2<T> z{(T)0, (T)0};
+        if (active) {
+          const int n2 = nk_in_row<SC, 0>(pp, q, r);
+          const C2<T> Zk = lk[n2 >> 1], Zm = lm[n2 >> 1];
+          if (n2 & 1)
+            z = C2<T>{(T)0.5 * (Zk.y + Zm.y), (T)0.5 * (Zm.x - Zk.x)};  // B = -i (Zk - conj Zm)/2
+          else
+            z = C2<T>{(T)0.5 * (Zk.x + Zm.x), (T)0.5 * (Zk.y - Zm.y)};  // A = (Zk + conj Zm)/2
+        }
+        rg.v[q * R + r] = z;
+      }
+    nk_stage_compute<T, SC, 0>(rg.v, pp, tw);
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int ad = LY::addr(t, nk_out_row<SC, 0>(pp, q, r));
+        pre[ad] = rg.v[q * R + r].x;
+        pim[ad] = rg.v[q * R + r].y;
+      }
+  });
+  ex.phase([&](int tid, PassRegs<T, E>& rg) {
+    const int pp = tid % P, t = tid / P;
+    constexpr int R = SC::radix(1), Q = E / R;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int ad = LY::addr(t, nk_in_row<SC, 1>(pp, q, r));
+        rg.v[q * R + r] = C2<T>{pre[ad], pim[ad]};
+      }
+    nk_stage_compute<T, SC, 1>(rg.v, pp, tw);
+  });
+  if constexpr (S == 3) {
+    ex.phase([&](int tid, PassRegs<T, E>& rg) {
+      const int pp = tid % P, t = tid / P;
+      constexpr int R = SC::radix(1), Q = E / R;
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int ad = LY::addr(t, nk_out_row<SC, 1>(pp, q, r));
+          pre[ad] = rg.v[q * R + r].x;
+          pim[ad] = rg.v[q * R + r].y;
+        }
+    });
+    ex.phase([&](int tid, PassRegs<T, E>& rg) {
+      const int pp = tid % P, t = tid / P;
+      constexpr int R = SC::radix(2), Q = E / R;
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int ad = LY::addr(t, nk_in_row<SC, 2>(pp, q, r));
+          rg.v[q * R + r] = C2<T>{pre[ad], pim[ad]};
+        }
+      nk_stage_compute<T, SC, 2>(rg.v, pp, tw);
+    });
+  }
+  // natural-order spectrum back to the planes, then an LDS-driven epilogue loop: each work item owns the four
+  // mirror images (k,kl), (k,-kl), (-k,-kl), (-k,kl) of one coefficient pair -- they share their power bin, so the
+  // VJP scatter needs ONE fp64 atomic per four outputs; rows are written contiguously (ascending / descending)
+  ex.phase([&](int tid, PassRegs<T, E>& rg) {
+    const int pp = tid % P, t = tid / P;
+    constexpr int LS = S - 1;
+    constexpr int R = SC::radix(LS), Q = E / R;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int ad = LY::addr(t, nk_out_row<SC, LS>(pp, q, r));
+        pre[ad] = rg.v[q * R + r].x;
+        pim[ad] = rg.v[q * R + r].y;
+      }
+  });
+  ex.last_phase([&](int tid, PassRegs<T, E>& rg) {
+    (void)rg;
+    constexpr int NK = NL / 2 + 1;
+    constexpr int NT = P * TILE;
+    const T sg = (T)p.g.sign;
+    double acc = 0.0;
+    for (int idx = tid; idx < TILE * NK; idx += NT) {
+      const int k2 = idx % NK, t = idx / NK;
+      int b, bm;
+      bool active, self;
+      line_of(t, b, bm, active, self);
+      if (!active) continue;
+      const int64_t ok = (((bat * A + a) * M + b)) * (int64_t)NL;
+      const int64_t om = (((bat * A + am) * M + bm)) * (int64_t)NL;
+      const int k2m = k2 ? NL - k2 : 0;
+      const int a1 = LY::addr(t, k2);
+      const T fx = pre[a1], fy = pim[a1];
+      const int a2 = LY::addr(t, k2m);
+      const T gx = pre[a2], gy = pim[a2];
+      const int64_t o[4] = {ok + k2, om + k2m, ok + k2m, om + k2};
+      const T v[4] = {fx + sg * fy, fx - sg * fy, gx + sg * gy, gx - sg * gy};  // H(k,kl) H(-k,-kl) H(k,-kl) H(-k,kl)
+      const int mask = 1 | (self ? 0 : 2) | (k2m != k2 ? (self ? 4 : 12) : 0);
+      nk_epilogue_multi<T>(f, o, v, mask, acc);
     }
     *acc_out += acc;
   });

@@ -97,7 +97,7 @@ struct HostExec {
 };
 
 template <typename T, int N>
-static void emu2_strided(NkPassS p, bool is_c, const nk_fuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch,
+static void emu2_strided(NkPassS p, int mode, const nk_fuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch,
                          double* energy) {
   using ST = StridedTile<T, N>;
   p.tl.tile = ST::TILE;
@@ -106,8 +106,8 @@ static void emu2_strided(NkPassS p, bool is_c, const nk_fuse& f, const C2<T>* tw
   const int64_t blocks = p.outer * p.tiles_per_slab;
   for (int64_t blk = 0; blk < blocks; ++blk) {
     HostExec<T, Sched<T, N>::E> ex(ST::THREADS);
-    if (is_c) nk_strided_body<T, N, ST::TILE, true>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
-    else nk_strided_body<T, N, ST::TILE, false>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+    if (mode == 3) nk_strided_body<T, N, ST::TILE, 3>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+    else nk_strided_body<T, N, ST::TILE, 0>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
   }
 }
 
@@ -124,6 +124,76 @@ static void emu2_contig(NkPassA p, bool is_1d, const nk_fuse& f, const C2<T>* tw
   }
 }
 
+template <typename T, int NL>
+static void emu2_final(const NkPassF& pf0, const nk_fuse& f, const C2<T>* tw, const C2<T>* work, double* energy) {
+  using CT = ContigTile<T, NL>;
+  NkPassF pf = pf0;
+  pf.tiles_per_a = (pf.M + CT::TILE - 1) / CT::TILE;
+  std::vector<T> planes(CT::LDS_BYTES / sizeof(T));
+  const int64_t blocks = (int64_t)pf.g.batch * (pf.A / 2 + 1) * pf.tiles_per_a;
+  for (int64_t blk = 0; blk < blocks; ++blk) {
+    HostExec<T, Sched<T, NL>::E> ex(CT::THREADS);
+    nk_final_body<T, NL, CT::TILE>(ex, pf, f, blk, planes.data(), tw, work, energy);
+  }
+}
+
+// strided-first pipeline (ndim >= 2)
+template <typename T>
+static int emu3_run(int ndim, const int64_t* shape, int dtype, int64_t batch, const nk_fuse* f, int convention) {
+  NkHostPlan hp;
+  const char* msg;
+  int rc = nk_host_plan_init(hp, ndim, shape, dtype, batch, &msg);
+  if (rc != NK_OK) return rc;
+  if (ndim < 2) return -99;
+  auto tw_b = conv_tw<T>(hp.tw_b), tw_c = conv_tw<T>(hp.tw_c), tw_f = conv_tw<T>(hp.tw_f);
+  const NkGeom& g = hp.g;
+  if (!nk_fast_size(g.nl)) return -100;
+  if (ndim == 3 && !nk_fast_strided_ok<T>(g.nm, hp.pb.inner)) return -101;
+  if (!nk_fast_strided_ok<T>(g.na, hp.pc.inner)) return -102;
+  double energy = 0.0;
+  std::vector<C2<T>> work(hp.work_bytes / sizeof(C2<T>) + 1);
+  NkPassS pb = hp.pb, pc = hp.pc;
+  if (ndim == 3) {
+    switch (g.nm) {
+#define NK_CASE(NN) \
+  case NN:          \
+    emu2_strided<T, NN>(pb, 3, *f, tw_b.data(), work.data(), nullptr, &energy); \
+    break;
+      NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+    }
+  }
+  switch (g.na) {
+#define NK_CASE(NN) \
+  case NN:          \
+    emu2_strided<T, NN>(pc, ndim == 3 ? 0 : 3, *f, tw_c.data(), work.data(), nullptr, &energy); \
+    break;
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+  }
+  NkPassF pf{};
+  pf.g = g;
+  pf.g.sign = convention == NK_HARTLEY_CANONICAL ? -1 : 1;
+  pf.A = ndim == 3 ? g.na : 1;
+  pf.M = ndim == 3 ? g.nm : g.na;
+  switch (g.nl) {
+#define NK_CASE(NN) \
+  case NN:          \
+    emu2_final<T, NN>(pf, *f, tw_f.data(), work.data(), &energy); \
+    break;
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+  }
+  if (f->epi == NK_EPI_LIKELIHOOD && f->value) *f->value += energy;
+  return NK_OK;
+}
+
+extern "C" int emu3_hartley_fused(int ndim, const int64_t* shape, int dtype, int64_t batch, const nk_fuse* f,
+                                  int convention) {
+  if (dtype == NK_F32) return emu3_run<float>(ndim, shape, dtype, batch, f, convention);
+  return emu3_run<double>(ndim, shape, dtype, batch, f, convention);
+}
+
 template <typename T>
 static int emu2_run(int ndim, const int64_t* shape, int dtype, int64_t batch, const nk_fuse* f, int convention) {
   NkHostPlan hp;
@@ -132,9 +202,8 @@ static int emu2_run(int ndim, const int64_t* shape, int dtype, int64_t batch, co
   if (rc != NK_OK) return rc;
   auto tw_a = conv_tw<T>(hp.tw_a), twr = conv_tw<T>(hp.twr_a), tw_b = conv_tw<T>(hp.tw_b), tw_c = conv_tw<T>(hp.tw_c);
   const NkGeom& g = hp.g;
+  if (ndim != 1) return -99;  // >= 2-D fast transforms use the strided-first pipeline (emu3)
   if (!nk_fast_contig_ok(g.h)) return -100;
-  if (ndim == 3 && !nk_fast_strided_ok<T>(g.nm, hp.pb.inner)) return -101;
-  if (ndim >= 2 && !nk_fast_strided_ok<T>(g.na, hp.pc.inner)) return -102;
   NkPassA pa = hp.pa;
   pa.g.sign = convention == NK_HARTLEY_CANONICAL ? -1 : 1;
   double energy = 0.0;
@@ -146,30 +215,6 @@ static int emu2_run(int ndim, const int64_t* shape, int dtype, int64_t batch, co
     break;
     NK_FAST_SIZES(NK_CASE)
 #undef NK_CASE
-  }
-  if (ndim == 3) {
-    switch (g.nm) {
-#define NK_CASE(NN) \
-  case NN:          \
-    emu2_strided<T, NN>(hp.pb, false, *f, tw_b.data(), work.data(), scratch.data(), &energy); \
-    break;
-      NK_FAST_SIZES(NK_CASE)
-#undef NK_CASE
-    }
-  }
-  if (ndim >= 2) {
-    NkPassS pc = hp.pc;
-    pc.g.sign = pa.g.sign;
-    switch (g.na) {
-#define NK_CASE(NN) \
-  case NN:          \
-    emu2_strided<T, NN>(pc, true, *f, tw_c.data(), work.data(), scratch.data(), &energy); \
-    break;
-      NK_FAST_SIZES(NK_CASE)
-#undef NK_CASE
-    }
-    const int64_t total_d = (int64_t)pc.g.batch * pc.g.nm * pc.g.na;
-    for (int64_t gid = 0; gid < total_d; ++gid) nk_passD<T>(pc.g, *f, gid, scratch.data(), energy);
   }
   if (f->epi == NK_EPI_LIKELIHOOD && f->value) *f->value += energy;
   return NK_OK;
