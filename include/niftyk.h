@@ -44,6 +44,7 @@ enum { NK_NL_ID = 0, NK_NL_EXP = 1, NK_NL_SIGMOID = 2 };
  *     AMP      amp[pidx[i]] * in[i]                              (PowerDistributor gather x xi,
  *                                                                  distributors.py:114-119 + diagonal multiply)
  *     AMP_JVP  amp[pidx[i]] * in[i] + damp[pidx[i]] * in2[i]     (product rule, operator.py:579-582)
+ *              (with `afield` set the amp gather becomes a stream: afield[i] * in[i]; `dampT` = da table in T)
  *     MUL      in[i] * in2[i]
  *   epilogue  for transform output v at index o, t = v * scale:
  *     AFFINE      out[o] = t + offset                            (scalar_dvol factor + Adder, adder.py:47-52)
@@ -80,6 +81,10 @@ typedef struct nk_fuse {
   double icov_scalar;
   void* out2;
   double* value;
+  const void* afield;   /* optional T* field a[pidx[i]] (materialised once per linearisation): replaces the amp gather */
+  const void* dampT;    /* optional da table in the field dtype T (AMP_JVP) instead of the double table `damp` */
+  int abar_copies;      /* VJP: 0/1 = one device-scope accumulator; 8 = one private accumulator per XCD */
+  int64_t abar_stride;  /* elements between the private accumulators (fold them with nk_fold_copies) */
 } nk_fuse;
 
 typedef struct nk_plan nk_plan;
@@ -134,6 +139,9 @@ int nk_pointwise(int fn, double param, int64_t n, const void* x, void* fx, void*
 int nk_gather(int64_t n, const void* table, const int32_t* pidx, void* out, int dtype, void* stream);
 int nk_scatter_add(int64_t n, const void* in, const int32_t* pidx, int64_t nbins, void* bins, int dtype,
                    void* stream);
+
+/* dst[0..n) = sum over c < copies of src[c*stride + (0..n)]  (folds the per-XCD VJP accumulators) */
+int nk_fold_copies(int64_t n, int copies, int64_t stride, const double* src, double* dst, void* stream);
 
 /* power-bin index of every grid point from integer k^2 (equal harmonic distances): pidx[i] = k2table[k^2(i)],
  * rho[bin] += 1 (rho may be NULL, else zeroed by the caller).  Replaces the int64 full-grid searchsorted of

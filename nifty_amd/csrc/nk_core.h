@@ -13,13 +13,34 @@
 
 #ifdef NK_HOST_EMU
 #include <cmath>
+struct int2 {
+  int x, y;
+};
 #define NK_HD inline
 #define NK_ATOMIC_ADD(p, v) (*(p) += (v))
+#define NK_ATOMIC_ADD_XCD(p, v) (*(p) += (v))
+static inline int nk_xcc_id() { return 0; }
 #else
 #include <hip/hip_runtime.h>
 #define NK_HD __host__ __device__ __forceinline__
 #define NK_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+// accumulator private to one XCD: every contributor sits behind the same L2, so workgroup scope (an L2 atomic
+// without the memory-side round trip of agent scope) is sufficient -- see nk_epilogue VJP
+#define NK_ATOMIC_ADD_XCD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+__device__ __forceinline__ int nk_xcc_id() {
+  return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7);  // HW_REG_XCC_ID
+}
 #endif
+
+// VJP scatter target: one accumulator, or one per XCD selected by the hardware XCC id at run time (placement
+// independent: whatever XCD a workgroup lands on, it only ever touches that XCD's private copy)
+#define NK_VJP_SCATTER(f, p, val)                                                   \
+  do {                                                                              \
+    if ((f).abar_copies > 1)                                                        \
+      NK_ATOMIC_ADD_XCD((f).abar + (int64_t)nk_xcc_id() * (f).abar_stride + (p), (val)); \
+    else                                                                            \
+      NK_ATOMIC_ADD((f).abar + (p), (val));                                         \
+  } while (0)
 
 #define NK_MAX_STAGES 8
 
@@ -179,15 +200,76 @@ NK_HD T nk_prologue(const NkFuse& f, int64_t i) {
   const T* in = (const T*)f.in;
   switch (f.pro) {
     case NK_PRO_AMP:
+      if (f.afield) return ((const T*)f.afield)[i] * in[i];
       return (T)(f.amp[f.pidx[i]] * (double)in[i]);
     case NK_PRO_AMP_JVP: {
       const int32_t p = f.pidx[i];
+      if (f.afield) {
+        const T da = f.dampT ? ((const T*)f.dampT)[p] : (T)f.damp[p];
+        return ((const T*)f.afield)[i] * in[i] + da * ((const T*)f.in2)[i];
+      }
       return (T)(f.amp[p] * (double)in[i] + f.damp[p] * (double)((const T*)f.in2)[i]);
     }
     case NK_PRO_MUL:
       return in[i] * ((const T*)f.in2)[i];
     default:
       return in[i];
+  }
+}
+
+// prologue of two adjacent real elements (i even): 2*sizeof(T)-byte vector loads of every operand stream
+template <typename T>
+NK_HD C2<T> nk_prologue_pair(const NkFuse& f, int64_t i) {
+  const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + i);
+  switch (f.pro) {
+    case NK_PRO_AMP: {
+      if (f.afield) {
+        const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + i);
+        return C2<T>{m.x * a.x, m.y * a.y};
+      }
+      const int32_t p0 = f.pidx[i], p1 = f.pidx[i + 1];
+      return C2<T>{(T)(f.amp[p0] * (double)a.x), (T)(f.amp[p1] * (double)a.y)};
+    }
+    case NK_PRO_AMP_JVP: {
+      const int32_t p0 = f.pidx[i], p1 = f.pidx[i + 1];
+      const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + i);
+      if (f.afield) {
+        const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + i);
+        const T d0 = f.dampT ? ((const T*)f.dampT)[p0] : (T)f.damp[p0];
+        const T d1 = f.dampT ? ((const T*)f.dampT)[p1] : (T)f.damp[p1];
+        return C2<T>{m.x * a.x + d0 * x.x, m.y * a.y + d1 * x.y};
+      }
+      return C2<T>{(T)(f.amp[p0] * (double)a.x + f.damp[p0] * (double)x.x),
+                   (T)(f.amp[p1] * (double)a.y + f.damp[p1] * (double)x.y)};
+    }
+    case NK_PRO_MUL: {
+      const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + i);
+      return C2<T>{a.x * x.x, a.y * x.y};
+    }
+    default:
+      return a;
+  }
+}
+
+// compile-time specialised pair prologues of the hot configurations (no run-time switch in the load loop):
+//   PC = 0 plain, 1 afield*in, 2 afield*in + dampT[pidx]*in2, anything else -> generic run-time version
+template <typename T, int PC>
+NK_HD C2<T> nk_prologue_ct(const NkFuse& f, int64_t i) {
+  if constexpr (PC == 0) {
+    return *reinterpret_cast<const C2<T>*>((const T*)f.in + i);
+  } else if constexpr (PC == 1) {
+    const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + i);
+    const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + i);
+    return C2<T>{m.x * a.x, m.y * a.y};
+  } else if constexpr (PC == 2) {
+    const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + i);
+    const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + i);
+    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + i);
+    const int2 p = *reinterpret_cast<const int2*>(f.pidx + i);
+    const T* dt = (const T*)f.dampT;
+    return C2<T>{m.x * a.x + dt[p.x] * x.x, m.y * a.y + dt[p.y] * x.y};
+  } else {
+    return C2<T>{nk_prologue<T>(f, i), nk_prologue<T>(f, i + 1)};
   }
 }
 
@@ -217,11 +299,11 @@ NK_HD void nk_epilogue(const NkFuse& f, int64_t o, T v, double& acc) {
     case NK_EPI_VJP: {
       const double t = (double)v * f.scale;
       const int32_t p = f.pidx[o];
-      double r = f.amp[p] * t;
+      double r = (f.afield ? (double)((const T*)f.afield)[o] : f.amp[p]) * t;
       if (f.addend) r += f.addend_scale * (double)((const T*)f.addend)[o];
       if (f.accumulate) r += (double)out[o];
       out[o] = (T)r;
-      NK_ATOMIC_ADD(f.abar + p, (double)((const T*)f.xi)[o] * t);
+      NK_VJP_SCATTER(f, p, (double)((const T*)f.xi)[o] * t);
     } break;
     case NK_EPI_LIKELIHOOD: {
       const double s = (double)v * f.scale + f.offset;
@@ -263,7 +345,7 @@ NK_HD void nk_epilogue_pair(const NkFuse& f, int64_t o1, T v1, int64_t o2, T v2,
     T* out = (T*)f.out;
     const double t1 = (double)v1 * f.scale, t2 = (double)v2 * f.scale;
     const int32_t p = f.pidx[o1];
-    const double a = f.amp[p];
+    const double a = f.afield ? (double)((const T*)f.afield)[o1] : f.amp[p];
     double r1 = a * t1, r2 = a * t2;
     if (f.addend) {
       r1 += f.addend_scale * (double)((const T*)f.addend)[o1];
@@ -276,24 +358,52 @@ NK_HD void nk_epilogue_pair(const NkFuse& f, int64_t o1, T v1, int64_t o2, T v2,
     out[o1] = (T)r1;
     out[o2] = (T)r2;
     const T* xi = (const T*)f.xi;
-    NK_ATOMIC_ADD(f.abar + p, (double)xi[o1] * t1 + (double)xi[o2] * t2);
+    NK_VJP_SCATTER(f, p, (double)xi[o1] * t1 + (double)xi[o2] * t2);
   } else {
     nk_epilogue<T>(f, o1, v1, acc);
     nk_epilogue<T>(f, o2, v2, acc);
   }
 }
 
-// up to four outputs that share one power bin (the mirror images of one coefficient): one atomic for the VJP
-template <typename T>
-NK_HD void nk_epilogue_multi(const NkFuse& f, const int64_t (&o)[4], const T (&v)[4], int mask, double& acc) {
+// compile-time specialised single-output epilogues of the hot configurations (EC = 0 affine, 1 multiply,
+// anything else -> generic run-time version)
+template <typename T, int EC>
+NK_HD void nk_emit(const NkFuse& f, int64_t o, T v, double& acc) {
+  if constexpr (EC == 0) {
+    ((T*)f.out)[o] = (T)((double)v * f.scale + f.offset);
+  } else if constexpr (EC == 1) {
+    double r = (double)v * f.scale * f.mul_scalar;
+    if (f.mul) r *= (double)((const T*)f.mul)[o];
+    ((T*)f.out)[o] = (T)r;
+  } else {
+    nk_epilogue<T>(f, o, v, acc);
+  }
+}
+
+// one output of the scatter (VJP) epilogue: writes out[o], returns the xi*t contribution to the bin sum
+template <typename T, bool AFIELD>
+NK_HD double nk_emit_vjp(const NkFuse& f, int64_t o, T v, double a_bin) {
+  T* out = (T*)f.out;
+  const double t = (double)v * f.scale;
+  double r = ((AFIELD || f.afield) ? (double)((const T*)f.afield)[o] : a_bin) * t;
+  if (f.addend) r += f.addend_scale * (double)((const T*)f.addend)[o];
+  if (f.accumulate) r += (double)out[o];
+  out[o] = (T)r;
+  return (double)((const T*)f.xi)[o] * t;
+}
+
+// up to eight outputs that share one power bin (the sign-flip images of one coefficient): one atomic for the VJP
+template <typename T, int NOUT>
+NK_HD void nk_epilogue_multi(const NkFuse& f, const int64_t (&o)[8], const T (&v)[8], int mask, double& acc) {
   if (f.epi == NK_EPI_VJP) {
     T* out = (T*)f.out;
     const T* xi = (const T*)f.xi;
-    const int32_t p = f.pidx[o[0]];
-    const double a = f.amp[p];
+    const int first = (mask & 15) ? 0 : 4;  // slot 0 of an active half is always valid
+    const int32_t p = f.pidx[o[first]];
+    const double a = f.afield ? (double)((const T*)f.afield)[o[first]] : f.amp[p];
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NOUT; ++i) {
       if (!(mask & (1 << i))) continue;
       const double t = (double)v[i] * f.scale;
       double r = a * t;
@@ -302,10 +412,10 @@ NK_HD void nk_epilogue_multi(const NkFuse& f, const int64_t (&o)[4], const T (&v
       out[o[i]] = (T)r;
       s += (double)xi[o[i]] * t;
     }
-    NK_ATOMIC_ADD(f.abar + p, s);
+    NK_VJP_SCATTER(f, p, s);
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NOUT; ++i)
       if (mask & (1 << i)) nk_epilogue<T>(f, o[i], v[i], acc);
   }
 }

@@ -192,40 +192,56 @@ __global__ void __launch_bounds__((ContigTile<T, H>::THREADS))
   if (IS_1D) nk_flush_energy(f, acc, smem);
 }
 
-template <typename T, int N, int MODE>
+template <typename T, int N, int MODE, int PC>
 __global__ void __launch_bounds__((StridedTile<T, N>::THREADS))
     k2_strided(NkPassS p, NkFuse f, const C2<T>* __restrict__ tw, C2<T>* __restrict__ work, C2<T>* __restrict__ scratch) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, Sched<T, N>::E> ex;
   double acc = 0.0;
-  nk_strided_body<T, N, StridedTile<T, N>::TILE, MODE>(ex, p, f, blockIdx.x, (T*)smem, tw, work, scratch, &acc);
+  nk_strided_body<T, N, StridedTile<T, N>::TILE, MODE, PC>(ex, p, f, blockIdx.x, (T*)smem, tw, work, scratch, &acc);
   (void)acc;
 }
 
-template <typename T, int NL>
-__global__ void __launch_bounds__((ContigTile<T, NL>::THREADS))
+template <typename T, int NL, bool COUPLES, int EC>
+__global__ void __launch_bounds__((FinalTile<T, NL>::THREADS))
     k2_final(NkPassF p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, Sched<T, NL>::E> ex;
   double acc = 0.0;
-  nk_final_body<T, NL, ContigTile<T, NL>::TILE>(ex, p, f, blockIdx.x, (T*)smem, tw, work, &acc);
+  nk_final_body<T, NL, FinalTile<T, NL>::TILE, COUPLES, EC>(ex, p, f, blockIdx.x, (T*)smem, tw, work, &acc);
   nk_flush_energy(f, acc, smem);
 }
 
-template <typename T, int NL>
-static int nk_launch_final(NkPassF pf, const NkFuse& f, const C2<T>* tw, const C2<T>* work, hipStream_t st) {
-  using CT = ContigTile<T, NL>;
-  auto kern = k2_final<T, NL>;
+template <typename T, int NL, bool COUPLES, int EC>
+static int nk_launch_final_c(NkPassF pf, const NkFuse& f, const C2<T>* tw, const C2<T>* work, hipStream_t st) {
+  using CT = FinalTile<T, NL>;
+  auto kern = k2_final<T, NL, COUPLES, EC>;
   static bool attr_done = false;
   if (!attr_done && CT::LDS_BYTES > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CT::LDS_BYTES);
     if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k2_final)");
   }
   attr_done = true;
-  pf.tiles_per_a = (pf.M + CT::TILE - 1) / CT::TILE;
+  pf.tiles_per_a = (COUPLES && pf.A > 1 && CT::TILE >= 2) ? (pf.M / 2 + 1 + CT::TILE / 2 - 1) / (CT::TILE / 2)
+                                               : (pf.M + CT::TILE - 1) / CT::TILE;
   const int64_t blocks = (int64_t)pf.g.batch * (pf.A / 2 + 1) * pf.tiles_per_a;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CT::THREADS), CT::LDS_BYTES, st, pf, f, tw, work);
   return nk_check_launch("k2_final");
+}
+
+// the scatter epilogue (VJP) runs on line couples (8 sign-flip images per atomic); everything else on plain pairs
+template <typename T, int NL>
+static int nk_launch_final(const NkPassF& pf, const NkFuse& f, const C2<T>* tw, const C2<T>* work, hipStream_t st) {
+  static const int generic = nk_env_int("NK_EC_GENERIC", 0);
+  if (generic) {
+    if (f.epi == NK_EPI_VJP) return nk_launch_final_c<T, NL, true, -1>(pf, f, tw, work, st);
+    return nk_launch_final_c<T, NL, false, -1>(pf, f, tw, work, st);
+  }
+  if (f.epi == NK_EPI_VJP && f.afield) return nk_launch_final_c<T, NL, true, 2>(pf, f, tw, work, st);
+  if (f.epi == NK_EPI_VJP) return nk_launch_final_c<T, NL, true, -1>(pf, f, tw, work, st);
+  if (f.epi == NK_EPI_AFFINE) return nk_launch_final_c<T, NL, false, 0>(pf, f, tw, work, st);
+  if (f.epi == NK_EPI_MUL) return nk_launch_final_c<T, NL, false, 1>(pf, f, tw, work, st);
+  return nk_launch_final_c<T, NL, false, -1>(pf, f, tw, work, st);
 }
 
 template <typename T>
@@ -257,10 +273,10 @@ static int nk_launch_contig(const NkPassA& pa, const NkFuse& f, const C2<T>* tw,
   return nk_check_launch("k2_contig");
 }
 
-template <typename T, int N, int MODE>
-static int nk_launch_strided(NkPassS ps, const NkFuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch, hipStream_t st) {
+template <typename T, int N, int MODE, int PC>
+static int nk_launch_strided_pc(NkPassS ps, const NkFuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch, hipStream_t st) {
   using ST = StridedTile<T, N>;
-  auto kern = k2_strided<T, N, MODE>;
+  auto kern = k2_strided<T, N, MODE, PC>;
   static bool attr_done = false;
   if (!attr_done && ST::LDS_BYTES > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ST::LDS_BYTES);
@@ -285,6 +301,18 @@ static int nk_dispatch_contig(int h, const NkPassA& pa, const NkFuse& f, const C
 #undef NK_CASE
   }
   return nk_set_error(NK_ERR_UNSUPPORTED, "no fast contiguous pass for this length");
+}
+
+// pick the compile-time prologue specialisation (first pass only)
+template <typename T, int N, int MODE>
+static int nk_launch_strided(const NkPassS& ps, const NkFuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch, hipStream_t st) {
+  if constexpr (MODE == 3) {
+    if (f.pro == NK_PRO_PLAIN) return nk_launch_strided_pc<T, N, MODE, 0>(ps, f, tw, work, scratch, st);
+    if (f.pro == NK_PRO_AMP && f.afield) return nk_launch_strided_pc<T, N, MODE, 1>(ps, f, tw, work, scratch, st);
+    if (f.pro == NK_PRO_AMP_JVP && f.afield && f.dampT)
+      return nk_launch_strided_pc<T, N, MODE, 2>(ps, f, tw, work, scratch, st);
+  }
+  return nk_launch_strided_pc<T, N, MODE, -1>(ps, f, tw, work, scratch, st);
 }
 
 template <typename T, int MODE>
@@ -572,6 +600,8 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
     pf.A = hp.g.ndim == 3 ? hp.g.na : 1;
     pf.M = hp.g.ndim == 3 ? hp.g.nm : hp.g.na;
     ProfScope ps(st, 3, f.pro, f.epi);
+    static const int skip_final = nk_env_int("NK_SKIP_FINAL", 0);  // debugging aid
+    if (skip_final) return NK_OK;
     return nk_dispatch_final<T>(hp.g.nl, pf, f, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
   }
   {

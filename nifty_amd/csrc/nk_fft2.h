@@ -188,6 +188,22 @@ struct ContigTile {
   static constexpr int LDS_BYTES = 2 * TILE * PITCH * (int)sizeof(T);
 };
 
+#ifndef NK_FINAL_LDS_KB
+#define NK_FINAL_LDS_KB 72
+#endif
+// final pass of the strided-first pipeline: up to 256 threads and ~72 KiB of planes (two workgroups per CU)
+template <typename T, int NL>
+struct FinalTile {
+  static constexpr int P = Sched<T, NL>::P;
+  static constexpr int PITCH = ContigLayout<NL, P>::PITCH;
+  static constexpr int fit(int tile) {
+    return (tile > 1 && (P * tile > 256 || 2 * tile * PITCH * (int)sizeof(T) > NK_FINAL_LDS_KB * 1024)) ? fit(tile / 2) : tile;
+  }
+  static constexpr int TILE = fit(16);
+  static constexpr int THREADS = P * TILE;
+  static constexpr int LDS_BYTES = 2 * TILE * PITCH * (int)sizeof(T);
+};
+
 // per-thread register file of one pass
 template <typename T, int E>
 struct PassRegs {
@@ -281,7 +297,7 @@ NK_HD void nk_xread_cols(T* dst, const T* plane, int pp, int t) {
 // MODE 3: FIRST pass of the strided-first pipeline: the real input (through the fused prologue) is read as
 //         complex pairs along the contiguous axis, transformed along this strided axis and written to `work`
 // MODE 0: plain in-place c2c
-template <typename T, int N, int TILE, int MODE, typename Exec>
+template <typename T, int N, int TILE, int MODE, int PC, typename Exec>
 NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t blk, T* plane,
                            const C2<T>* __restrict__ tw, C2<T>* __restrict__ work, C2<T>* __restrict__ scratch,
                            double* acc_out) {
@@ -301,7 +317,7 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
         const int64_t off = (int64_t)nk_in_row<SC, 0>(pp, q, r) * p.inner + t;
         if (MODE == 3) {
           const int64_t i = 2 * ((base - work) + off);
-          rg.v[q * R + r] = C2<T>{nk_prologue<T>(f, i), nk_prologue<T>(f, i + 1)};
+          rg.v[q * R + r] = nk_prologue_ct<T, PC>(f, i);
         } else {
           rg.v[q * R + r] = base[off];
         }
@@ -375,9 +391,7 @@ NK_HD void nk_contig_body(Exec& ex, const NkPassA& p, const NkFuse& f, int64_t b
       for (int r = 0; r < R; ++r) {
         C2<T> z{(T)0, (T)0};
         if (line < p.nlines) {
-          const int64_t i = line * nl + 2 * (int64_t)nk_in_row<SC, 0>(pp, q, r);
-          z.x = nk_prologue<T>(f, i);
-          z.y = nk_prologue<T>(f, i + 1);
+          z = nk_prologue_pair<T>(f, line * nl + 2 * (int64_t)nk_in_row<SC, 0>(pp, q, r));
         }
         rg.v[q * R + r] = z;
       }
@@ -482,6 +496,69 @@ NK_HD void nk_contig_body(Exec& ex, const NkPassA& p, const NkFuse& f, int64_t b
   });
 }
 
+// per-group constants of the final epilogue (one slot, or one couple of slots)
+template <int NH>
+struct FinalGroup {
+  int64_t okh[NH], omh[NH];
+  int base[NH], mlo[NH];
+};
+
+// emits the images of coefficient k2 (and of NL-k2 when `both`) for all slots of a group
+template <typename T, int NL, int NH, int EC>
+NK_HD void nk_final_emit(const NkFuse& f, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg, int k2, bool both,
+                         double& acc) {
+  constexpr bool VJP = (EC == 2);
+  const int k2m = k2 ? NL - k2 : 0;
+  const int d1 = k2 + (k2 >> 5), d2 = k2m + (k2m >> 5);
+  T fx[NH], fy[NH], gx[NH], gy[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    fx[h] = pre[gp.base[h] + d1], fy[h] = pim[gp.base[h] + d1];
+    gx[h] = pre[gp.base[h] + d2], gy[h] = pim[gp.base[h] + d2];
+  }
+  double ssum = 0.0, a_bin = 0.0;
+  int32_t bin = 0;
+  const bool scatter = VJP || f.epi == NK_EPI_VJP;
+  if (scatter) {
+    int hv = 0;
+#pragma unroll
+    for (int h = NH - 1; h >= 0; --h)
+      if (gp.mlo[h]) hv = h;
+    bin = f.pidx[gp.okh[hv] + k2];
+    a_bin = f.afield ? 0.0 : f.amp[bin];
+  }
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    if (!gp.mlo[h]) continue;
+    const bool self = gp.mlo[h] == 1;
+    const T v0 = fx[h] + sg * fy[h], v1 = fx[h] - sg * fy[h], v2 = gx[h] + sg * gy[h], v3 = gx[h] - sg * gy[h];
+    const int64_t ok = gp.okh[h], om = gp.omh[h];
+    if (VJP) {
+      ssum += nk_emit_vjp<T, true>(f, ok + k2, v0, a_bin);
+      if (!self) ssum += nk_emit_vjp<T, true>(f, om + k2m, v1, a_bin);
+      if (both) {
+        ssum += nk_emit_vjp<T, true>(f, ok + k2m, v2, a_bin);
+        if (!self) ssum += nk_emit_vjp<T, true>(f, om + k2, v3, a_bin);
+      }
+    } else if (scatter) {
+      ssum += nk_emit_vjp<T, false>(f, ok + k2, v0, a_bin);
+      if (!self) ssum += nk_emit_vjp<T, false>(f, om + k2m, v1, a_bin);
+      if (both) {
+        ssum += nk_emit_vjp<T, false>(f, ok + k2m, v2, a_bin);
+        if (!self) ssum += nk_emit_vjp<T, false>(f, om + k2, v3, a_bin);
+      }
+    } else {
+      nk_emit<T, EC>(f, ok + k2, v0, acc);
+      if (!self) nk_emit<T, EC>(f, om + k2m, v1, acc);
+      if (both) {
+        nk_emit<T, EC>(f, ok + k2m, v2, acc);
+        if (!self) nk_emit<T, EC>(f, om + k2, v3, acc);
+      }
+    }
+  }
+  if (scatter) NK_VJP_SCATTER(f, bin, ssum);
+}
+
 // ---------------------------------------------------------------------------------------------
 // FINAL pass of the strided-first pipeline (contiguous axis).
 // After the strided passes  Z_j(k) = A_j(k) + i B_j(k)  with A_j = FFT_strided(x[.., 2j]), B_j = FFT_strided(x[.., 2j+1])
@@ -500,7 +577,8 @@ struct NkPassF {
   int tiles_per_a;   // M / TILE
 };
 
-template <typename T, int NL, int TILE, typename Exec>
+// EC: compile-time epilogue class (0 affine, 1 multiply, 2 scatter/VJP with materialised amplitude field, -1 generic)
+template <typename T, int NL, int TILE, bool COUPLES, int EC, typename Exec>
 NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f, int64_t blk, T* planes,
                          const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, double* acc_out) {
   using SC = Sched<T, NL>;
@@ -516,11 +594,24 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f, int64_t bl
   const int am = a ? A - a : 0;
   const bool a_self = (a == am);
 
+  // slot -> line.  3-D (A > 1): slots come in couples (b0, M - b0) so that one epilogue work item owns all EIGHT
+  // sign-flip images of a coefficient (one scatter atomic per eight outputs); 2-D: consecutive lines.
+  const bool couples = COUPLES && (A > 1) && (TILE >= 2);
   auto line_of = [&](int t, int& b, int& bm, bool& active, bool& self) {
-    b = bt0 * TILE + t;
-    bm = b ? M - b : 0;
-    active = b < M && !(a_self && b > bm);
-    self = a_self && b == bm;
+    if (couples) {
+      const int b0 = bt0 * (TILE / 2) + (t >> 1);
+      const int flip = t & 1;
+      const int b0m = b0 ? M - b0 : 0;
+      b = flip ? b0m : b0;
+      bm = flip ? b0 : b0m;
+      active = b0 <= M / 2 && !(flip && (b0m == b0 || a_self));
+      self = a_self && b == bm;
+    } else {
+      b = bt0 * TILE + t;
+      bm = b ? M - b : 0;
+      active = b < M && !(a_self && b > bm);
+      self = a_self && b == bm;
+    }
   };
 
   ex.phase([&](int tid, PassRegs<T, E>& rg) {
@@ -616,24 +707,62 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f, int64_t bl
     constexpr int NT = P * TILE;
     const T sg = (T)p.g.sign;
     double acc = 0.0;
-    for (int idx = tid; idx < TILE * NK; idx += NT) {
-      const int k2 = idx % NK, t = idx / NK;
+    // a fixed group of threads serves one slot (2-D) / one couple of slots (3-D): all line bookkeeping is hoisted
+    // out of the k_last loop, which then only advances by the group width
+    const int nslot = couples ? TILE / 2 : TILE;
+    const int tps = NT / nslot;
+    const int u = tid / tps, lane = tid % tps;
+    constexpr int NH = COUPLES ? 2 : 1;
+    FinalGroup<NH> gp;  // mlo per slot: 0 inactive, 1 self-paired line, 3 regular pair
+    int any = 0;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int t = couples ? 2 * u + h : u;
       int b, bm;
       bool active, self;
       line_of(t, b, bm, active, self);
-      if (!active) continue;
-      const int64_t ok = (((bat * A + a) * M + b)) * (int64_t)NL;
-      const int64_t om = (((bat * A + am) * M + bm)) * (int64_t)NL;
-      const int k2m = k2 ? NL - k2 : 0;
-      const int a1 = LY::addr(t, k2);
-      const T fx = pre[a1], fy = pim[a1];
-      const int a2 = LY::addr(t, k2m);
-      const T gx = pre[a2], gy = pim[a2];
-      const int64_t o[4] = {ok + k2, om + k2m, ok + k2m, om + k2};
-      const T v[4] = {fx + sg * fy, fx - sg * fy, gx + sg * gy, gx - sg * gy};  // H(k,kl) H(-k,-kl) H(k,-kl) H(-k,kl)
-      const int mask = 1 | (self ? 0 : 2) | (k2m != k2 ? (self ? 4 : 12) : 0);
-      nk_epilogue_multi<T>(f, o, v, mask, acc);
+      if (h == 1 && !couples) active = false;
+      gp.okh[h] = (((bat * A + a) * M + b)) * (int64_t)NL;
+      gp.omh[h] = (((bat * A + am) * M + bm)) * (int64_t)NL;
+      gp.base[h] = LY::addr(t, 0);
+      gp.mlo[h] = active ? (self ? 1 : 3) : 0;
+      any |= gp.mlo[h];
     }
+#ifdef NK_FINAL_EMIT_V2
+    if (any) {
+      if (lane == 0) nk_final_emit<T, NL, NH, EC>(f, gp, pre, pim, sg, 0, false, acc);
+      if (lane == 1) nk_final_emit<T, NL, NH, EC>(f, gp, pre, pim, sg, NL / 2, false, acc);
+      // 1 <= k2 < NL/2: every image distinct; two coefficients per trip keep more LDS / global traffic in flight
+      int k2 = 1 + lane;
+      for (; k2 + tps < NL / 2; k2 += 2 * tps) {
+        nk_final_emit<T, NL, NH, EC>(f, gp, pre, pim, sg, k2, true, acc);
+        nk_final_emit<T, NL, NH, EC>(f, gp, pre, pim, sg, k2 + tps, true, acc);
+      }
+      if (k2 < NL / 2) nk_final_emit<T, NL, NH, EC>(f, gp, pre, pim, sg, k2, true, acc);
+    }
+#else
+    if (any) {
+      for (int k2 = lane; k2 < NK; k2 += tps) {
+        const int k2m = k2 ? NL - k2 : 0;
+        const int d1 = k2 + (k2 >> 5), d2 = k2m + (k2m >> 5);
+        int64_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        T v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int mask = 0;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          const T fx = pre[gp.base[h] + d1], fy = pim[gp.base[h] + d1];
+          const T gx = pre[gp.base[h] + d2], gy = pim[gp.base[h] + d2];
+          o[4 * h + 0] = gp.okh[h] + k2, v[4 * h + 0] = fx + sg * fy;   // H(k, kl)
+          o[4 * h + 1] = gp.omh[h] + k2m, v[4 * h + 1] = fx - sg * fy;  // H(-k, -kl)
+          o[4 * h + 2] = gp.okh[h] + k2m, v[4 * h + 2] = gx + sg * gy;  // H(k, -kl)
+          o[4 * h + 3] = gp.omh[h] + k2, v[4 * h + 3] = gx - sg * gy;   // H(-k, kl)
+          const int m4 = gp.mlo[h] == 0 ? 0 : (gp.mlo[h] == 1 ? (k2m != k2 ? 5 : 1) : (k2m != k2 ? 15 : 3));
+          mask |= m4 << (4 * h);
+        }
+        nk_epilogue_multi<T, 4 * NH>(f, o, v, mask, acc);
+      }
+    }
+#endif
     *acc_out += acc;
   });
 }

@@ -497,3 +497,20 @@ extern "C" int nk_pindex_from_k2(int ndim, const int64_t* shape, const int32_t* 
                      (unsigned long long*)rho, total);
   return nk_check_launch("k_pindex_k2");
 }
+
+// ---- fold the per-XCD private VJP accumulators ------------------------------------------------------------------
+__global__ void k_fold_copies(int64_t n, int copies, int64_t stride, const double* __restrict__ src, double* __restrict__ dst) {
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gs) {
+    double s = 0.0;
+    for (int c = 0; c < copies; ++c) s += src[c * stride + i];
+    dst[i] = s;
+  }
+}
+
+extern "C" int nk_fold_copies(int64_t n, int copies, int64_t stride, const double* src, double* dst, void* stream) {
+  if (n < 0 || copies < 1 || !src || !dst) return nk_set_error(NK_ERR_INVALID, "nk_fold_copies: bad argument");
+  if (n == 0) return NK_OK;
+  hipLaunchKernelGGL(k_fold_copies, dim3(nk_grid(n)), dim3(NK_VEC_THREADS), 0, (hipStream_t)stream, n, copies, stride, src, dst);
+  return nk_check_launch("k_fold_copies");
+}

@@ -175,10 +175,11 @@ class LatentVec:
 class LinPoint:
     """Everything cached about one latent point: amplitude tables and the s-space metric weight."""
 
-    __slots__ = ("x", "amp", "state", "mid", "mid_scalar", "value", "grad")
+    __slots__ = ("x", "amp", "afield", "state", "mid", "mid_scalar", "value", "grad")
 
     def __init__(self):
         self.mid = None
+        self.afield = None
         self.mid_scalar = 1.0
 
 
@@ -220,6 +221,10 @@ class FusedModel:
             self.geo = torch.from_numpy(geo).to(self.device)
             self.hyp = torch.from_numpy(hyp).to(self.device)
             self.plan = B.get_plan(self.shape, dtype, 1, self.device)
+            # VJP scatter accumulators: one private copy per XCD (L2-scope atomics), folded into self.abar
+            self.abar_stride = (nb + 31) // 32 * 32
+            self.abar_copies = 8
+            self.abar_priv = torch.zeros(self.abar_copies * self.abar_stride, dtype=torch.float64, device=self.device)
             self.abar = torch.zeros(nb, dtype=torch.float64, device=self.device)
             self.damp = torch.empty(nb, dtype=torch.float64, device=self.device)
             self.latbar = torch.empty(self.nsmall, dtype=torch.float64, device=self.device)
@@ -261,6 +266,12 @@ class FusedModel:
                                         state.data_ptr(), amp.data_ptr(), B._stream()), "nk_amp_forward")
         return amp, state
 
+    def _amp_field(self, amp):
+        """a[pindex] materialised in the field dtype: ONE gather per linearisation point instead of one per
+        transform (every later prologue / epilogue streams it)."""
+        table = amp if self.tdtype == torch.float64 else amp.to(self.tdtype)
+        return B.gather(table, self.pidx, self.shape)
+
     def _fuse(self):
         f = L.Fuse()
         f.scale = self.h_dvol
@@ -285,9 +296,14 @@ class FusedModel:
         f = self._fuse()
         f.pro, f.in_ = L.PRO_PLAIN, w.data_ptr()
         f.epi, f.out, f.scale = L.EPI_VJP, out_xi.data_ptr(), self.h_dvol * scale
-        f.pidx, f.amp, f.xi, f.abar = self.pidx.data_ptr(), lp.amp.data_ptr(), lp.x.xi.data_ptr(), self.abar.data_ptr()
+        f.pidx, f.amp, f.xi = self.pidx.data_ptr(), lp.amp.data_ptr(), lp.x.xi.data_ptr()
+        f.afield = B.ptr(lp.afield)
+        f.abar, f.abar_copies, f.abar_stride = self.abar_priv.data_ptr(), self.abar_copies, self.abar_stride
         f.addend, f.addend_scale, f.accumulate = B.ptr(addend), addend_scale, 1 if accumulate else 0
+        self.abar_priv.zero_()
         B.hartley_fused(self.plan, f)
+        L.check(L.load().nk_fold_copies(self.nb, self.abar_copies, self.abar_stride, self.abar_priv.data_ptr(),
+                                        self.abar.data_ptr(), B._stream()), "nk_fold_copies")
         self.counters["transforms"] += 1
 
     def _amp_vjp(self, lp):
@@ -303,11 +319,13 @@ class FusedModel:
         lp = LinPoint()
         lp.x = x
         lp.amp, lp.state = self._amp_forward(x.small)
+        lp.afield = self._amp_field(lp.amp)
         w = 1.0 / n_total
         value = torch.zeros(1, dtype=torch.float64, device=self.device) if value_acc is None else value_acc
         lhval = torch.zeros(1, dtype=torch.float64, device=self.device)
         f = self._fuse()
         f.pro, f.in_, f.pidx, f.amp = L.PRO_AMP, x.xi.data_ptr(), self.pidx.data_ptr(), lp.amp.data_ptr()
+        f.afield = lp.afield.data_ptr()
         gs = self.tmp
         if not self.const_mid:
             lp.mid = torch.empty(self.shape, dtype=self.tdtype, device=self.device)
@@ -321,7 +339,6 @@ class FusedModel:
         # gradient: J^T gs + x
         first = grad_acc is None
         grad = LatentVec(torch.empty_like(x.xi), None) if first else grad_acc
-        self.abar.zero_()
         self._vjp(lp, gs, w, x.xi, w, not first, grad.xi)
         self._amp_vjp(lp)
         # (abar, hence latbar, already carries the 1/n_total weight)
@@ -345,9 +362,12 @@ class FusedModel:
         f = self._fuse()
         f.pro, f.in_, f.in2 = L.PRO_AMP_JVP, d.xi.data_ptr(), lp.x.xi.data_ptr()
         f.pidx, f.amp, f.damp = self.pidx.data_ptr(), lp.amp.data_ptr(), self.damp.data_ptr()
+        f.afield = B.ptr(lp.afield)
+        if self.tdtype != torch.float64:
+            damp_t = self.damp.to(self.tdtype)  # table in the field dtype (dtype conversion only)
+            f.dampT = damp_t.data_ptr()
         f.epi, f.out, f.mul, f.mul_scalar = L.EPI_MUL, self.tmp.data_ptr(), B.ptr(lp.mid), lp.mid_scalar
         B.hartley_fused(self.plan, f)
-        self.abar.zero_()
         self._vjp(lp, self.tmp, scale, None, 0.0, not first, out.xi)
         self.counters["transforms"] += 1
         self._amp_vjp(lp)
@@ -399,7 +419,6 @@ class FusedModel:
         if not self.const_mid:
             eta = B.binary(L.OP_MUL, eta, B.pointwise("sqrt", lp.mid))
         out = LatentVec(torch.empty(self.shape, dtype=self.tdtype, device=self.device), None)
-        self.abar.zero_()
         self._vjp(lp, eta, 1.0, None, 0.0, False, out.xi)
         self._amp_vjp(lp)
         out.small = B.axpby(1.0, self.latbar)

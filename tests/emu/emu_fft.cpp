@@ -106,8 +106,14 @@ static void emu2_strided(NkPassS p, int mode, const nk_fuse& f, const C2<T>* tw,
   const int64_t blocks = p.outer * p.tiles_per_slab;
   for (int64_t blk = 0; blk < blocks; ++blk) {
     HostExec<T, Sched<T, N>::E> ex(ST::THREADS);
-    if (mode == 3) nk_strided_body<T, N, ST::TILE, 3>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
-    else nk_strided_body<T, N, ST::TILE, 0>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+    if (mode == 3) {
+      if (f.pro == NK_PRO_PLAIN) nk_strided_body<T, N, ST::TILE, 3, 0>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+      else if (f.pro == NK_PRO_AMP && f.afield) nk_strided_body<T, N, ST::TILE, 3, 1>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+      else if (f.pro == NK_PRO_AMP_JVP && f.afield && f.dampT) nk_strided_body<T, N, ST::TILE, 3, 2>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+      else nk_strided_body<T, N, ST::TILE, 3, -1>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+    } else {
+      nk_strided_body<T, N, ST::TILE, 0, -1>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+    }
   }
 }
 
@@ -126,14 +132,20 @@ static void emu2_contig(NkPassA p, bool is_1d, const nk_fuse& f, const C2<T>* tw
 
 template <typename T, int NL>
 static void emu2_final(const NkPassF& pf0, const nk_fuse& f, const C2<T>* tw, const C2<T>* work, double* energy) {
-  using CT = ContigTile<T, NL>;
+  using CT = FinalTile<T, NL>;
   NkPassF pf = pf0;
-  pf.tiles_per_a = (pf.M + CT::TILE - 1) / CT::TILE;
+  const bool couples = f.epi == NK_EPI_VJP;
+  pf.tiles_per_a = (couples && pf.A > 1 && CT::TILE >= 2) ? (pf.M / 2 + 1 + CT::TILE / 2 - 1) / (CT::TILE / 2)
+                                                          : (pf.M + CT::TILE - 1) / CT::TILE;
   std::vector<T> planes(CT::LDS_BYTES / sizeof(T));
   const int64_t blocks = (int64_t)pf.g.batch * (pf.A / 2 + 1) * pf.tiles_per_a;
   for (int64_t blk = 0; blk < blocks; ++blk) {
     HostExec<T, Sched<T, NL>::E> ex(CT::THREADS);
-    nk_final_body<T, NL, CT::TILE>(ex, pf, f, blk, planes.data(), tw, work, energy);
+    if (couples && f.afield) nk_final_body<T, NL, CT::TILE, true, 2>(ex, pf, f, blk, planes.data(), tw, work, energy);
+    else if (couples) nk_final_body<T, NL, CT::TILE, true, -1>(ex, pf, f, blk, planes.data(), tw, work, energy);
+    else if (f.epi == NK_EPI_AFFINE) nk_final_body<T, NL, CT::TILE, false, 0>(ex, pf, f, blk, planes.data(), tw, work, energy);
+    else if (f.epi == NK_EPI_MUL) nk_final_body<T, NL, CT::TILE, false, 1>(ex, pf, f, blk, planes.data(), tw, work, energy);
+    else nk_final_body<T, NL, CT::TILE, false, -1>(ex, pf, f, blk, planes.data(), tw, work, energy);
   }
 }
 

@@ -20,10 +20,15 @@ def lib():
     return ctypes.CDLL(EMU)
 
 
-def run(f, shape, dtype, conv=0, batch=1):
+def run(f, shape, dtype, conv=0, batch=1, fn="emu_hartley_fused"):
+    """fn: emu_hartley_fused = generic kernels; emu2_/emu3_ = register-resident fast path (1-D / strided-first)."""
     shp = (ctypes.c_int64 * len(shape))(*shape)
-    rc = lib().emu_hartley_fused(len(shape), shp, 0 if dtype == np.float32 else 1, batch, ctypes.byref(f), conv)
-    assert rc == 0
+    rc = getattr(lib(), fn)(len(shape), shp, 0 if dtype == np.float32 else 1, batch, ctypes.byref(f), conv)
+    assert rc == 0, rc
+
+
+def fast_fn(shape):
+    return "emu2_hartley_fused" if len(shape) == 1 else "emu3_hartley_fused"
 
 
 @pytest.mark.parametrize("shape", [(2,), (8,), (64,), (1024,), (2, 2), (4, 16), (32, 8), (64, 64), (2, 2, 2), (8, 4, 16),
@@ -42,17 +47,38 @@ def test_hartley_emulation(shape, dtype):
         assert err < (1e-12 if dtype == np.float64 else 2e-5)
 
 
-@pytest.mark.parametrize("shape", [(64,), (16, 8), (8, 4, 16)])
-def test_fused_prologue_epilogue_emulation(shape):
+@pytest.mark.parametrize("shape", [(128,), (64, 128), (128, 64), (64, 64, 64), (64, 128, 64)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fast_path_emulation(shape, dtype):
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(2,) + shape).astype(dtype)  # batch of 2
+    F = scipy.fft.fftn(x.astype(np.float64), axes=tuple(range(1, len(shape) + 1)))
+    for conv, ref in ((0, F.real + F.imag), (1, F.real - F.imag)):
+        out = np.empty_like(x)
+        f = Fuse()
+        f.in_, f.out, f.scale = x.ctypes.data, out.ctypes.data, 1.0
+        run(f, shape, dtype, conv, batch=2, fn=fast_fn(shape))
+        err = np.max(np.abs(out - ref)) / np.max(np.abs(ref))
+        assert err < (1e-12 if dtype == np.float64 else 2e-5)
+
+
+FUSED_SHAPES = [((64,), "emu_hartley_fused"), ((16, 8), "emu_hartley_fused"), ((8, 4, 16), "emu_hartley_fused"),
+                ((256,), "emu2_hartley_fused"), ((64, 128), "emu3_hartley_fused"), ((64, 64, 64), "emu3_hartley_fused")]
+
+
+@pytest.mark.parametrize("shape,fn", FUSED_SHAPES)
+def test_fused_prologue_epilogue_emulation(shape, fn):
     """AMP_JVP prologue and VJP epilogue against their numpy definition."""
     rng = np.random.default_rng(1)
     n = int(np.prod(shape))
     nb = 7
     pidx = rng.integers(0, nb, size=shape).astype(np.int32)
-    # mirror-symmetric bins like a real PowerSpace
+    # bins symmetric under the sign flip of every single axis, like a real PowerSpace (|k| binning)
     idx = np.indices(shape)
-    mirror = tuple((-idx[d]) % shape[d] for d in range(len(shape)))
-    pidx = np.minimum(pidx, pidx[mirror]).astype(np.int32)
+    for d in range(len(shape)):
+        flip = tuple((-idx[e]) % shape[e] if e == d else idx[e] for e in range(len(shape)))
+        pidx = np.minimum(pidx, pidx[flip])
+    pidx = pidx.astype(np.int32)
     amp, damp = rng.normal(size=nb), rng.normal(size=nb)
     xi, dxi, w, addend = (rng.normal(size=shape) for _ in range(4))
     H = lambda a: (lambda F: F.real + F.imag)(scipy.fft.fftn(a))  # noqa: E731
@@ -60,7 +86,7 @@ def test_fused_prologue_epilogue_emulation(shape):
     f = Fuse()
     f.pro, f.in_, f.in2, f.pidx, f.amp, f.damp = 2, dxi.ctypes.data, xi.ctypes.data, pidx.ctypes.data, amp.ctypes.data, damp.ctypes.data
     f.epi, f.out, f.scale, f.offset = 0, out.ctypes.data, 0.5, 1.25
-    run(f, shape, np.float64)
+    run(f, shape, np.float64, fn=fn)
     ref = 0.5 * H(amp[pidx] * dxi + damp[pidx] * xi) + 1.25
     assert np.max(np.abs(out - ref)) < 1e-11 * np.max(np.abs(ref))
     abar = np.zeros(nb)
@@ -70,14 +96,35 @@ def test_fused_prologue_epilogue_emulation(shape):
     f.epi, f.out, f.scale = 2, out2.ctypes.data, 0.25
     f.pidx, f.amp, f.xi, f.abar = pidx.ctypes.data, amp.ctypes.data, xi.ctypes.data, abar.ctypes.data
     f.addend, f.addend_scale, f.accumulate = addend.ctypes.data, 2.0, 1
-    run(f, shape, np.float64)
+    run(f, shape, np.float64, fn=fn)
     t = 0.25 * H(w)
     assert np.max(np.abs(out2 - (amp[pidx] * t + 2.0 * addend + 3.0))) < 1e-11 * np.max(np.abs(t))
-    assert np.max(np.abs(abar - np.bincount(pidx.ravel(), weights=(xi * t).ravel(), minlength=nb))) < 1e-10
+    ref_abar = np.bincount(pidx.ravel(), weights=(xi * t).ravel(), minlength=nb)
+    assert np.max(np.abs(abar - ref_abar)) < 1e-10 * max(1.0, np.max(np.abs(ref_abar)))
+    # materialised amplitude field + T-typed da table + private accumulators give the same answer
+    afield = amp[pidx].copy()
+    out3 = np.empty(shape)
+    f = Fuse()
+    f.pro, f.in_, f.in2, f.pidx, f.amp, f.damp = 2, dxi.ctypes.data, xi.ctypes.data, pidx.ctypes.data, amp.ctypes.data, damp.ctypes.data
+    f.afield, f.dampT = afield.ctypes.data, damp.ctypes.data
+    f.epi, f.out, f.scale, f.offset = 0, out3.ctypes.data, 0.5, 1.25
+    run(f, shape, np.float64, fn=fn)
+    assert np.max(np.abs(out3 - ref)) < 1e-11 * np.max(np.abs(ref))
+    priv = np.zeros(8 * 32)
+    out4 = np.empty(shape)
+    f = Fuse()
+    f.pro, f.in_ = 0, w.ctypes.data
+    f.epi, f.out, f.scale = 2, out4.ctypes.data, 0.25
+    f.pidx, f.amp, f.xi, f.abar, f.afield = pidx.ctypes.data, amp.ctypes.data, xi.ctypes.data, priv.ctypes.data, afield.ctypes.data
+    f.abar_copies, f.abar_stride = 8, 32
+    run(f, shape, np.float64, fn=fn)
+    assert np.max(np.abs(out4 - amp[pidx] * t)) < 1e-11 * np.max(np.abs(t))
+    assert np.max(np.abs(priv.reshape(8, 32).sum(0)[:nb] - ref_abar)) < 1e-10 * max(1.0, np.max(np.abs(ref_abar)))
 
 
-def test_likelihood_epilogue_emulation():
-    shape = (8, 16)
+@pytest.mark.parametrize("shape,fn", [((8, 16), "emu_hartley_fused"), ((64, 64), "emu3_hartley_fused"),
+                                      ((64, 64, 64), "emu3_hartley_fused")])
+def test_likelihood_epilogue_emulation(shape, fn):
     rng = np.random.default_rng(2)
     xi = rng.normal(size=shape)
     d = rng.poisson(3.0, size=shape).astype(np.int64)
@@ -86,7 +133,7 @@ def test_likelihood_epilogue_emulation():
     f = Fuse()
     f.in_, f.epi, f.out, f.out2, f.scale, f.offset = xi.ctypes.data, 3, gs.ctypes.data, mid.ctypes.data, 0.1, 0.3
     f.lh_kind, f.nonlin, f.data, f.value = 1, 1, d.ctypes.data, val.ctypes.data
-    run(f, shape, np.float64)
+    run(f, shape, np.float64, fn=fn)
     F = scipy.fft.fftn(xi)
     s = 0.1 * (F.real + F.imag) + 0.3
     lam = np.exp(s)
