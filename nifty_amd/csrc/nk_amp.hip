@@ -11,16 +11,15 @@
 //   a_0 = V zm;  a_b = V fluct sqrt(spec_b / S)
 // The double cumulative sum is ONE scan with the associative affine operator
 //   (c, s) -> (c + A, s + c*Dk + B),  compose(l, r) = (Al+Ar, Dl+Dr, Bl+Br+Al*Dr)
-// so each of forward / JVP / VJP is a single launch.  Round-1 implementation: one 1024-thread
-// workgroup walks the bins in coalesced tiles (nb <= ~1.2e6 -> a few hundred tiles); a multi-workgroup
-// look-back version is the planned follow-up.
+// executed as a two-launch multi-workgroup scan (per-workgroup aggregates, then carry-in + rescan), followed by
+// the element-wise / reduction stages: forward and JVP are 3 launches, VJP 5 (+ one memset) over <= 256 workgroups.
 #include <hip/hip_runtime.h>
 
 #include "nk_util.h"
 
 namespace {
 
-constexpr int AMP_THREADS = 1024;
+constexpr int AMP_THREADS = 256;
 constexpr int AMP_WAVES = AMP_THREADS / 64;
 
 struct Seg {
@@ -84,24 +83,64 @@ __device__ __forceinline__ Hyper hyper_from_lat(const double* hyp, const double*
 }
 
 constexpr int EPT = 4;  // elements per thread per tile
+constexpr int MAXG = 256;  // workgroups per launch
 
-// runs the affine scan over m = nb-2 elements; elem(j) returns the segment of element j (in scan order),
-// emit(j, c, s) receives the inclusive state after element j.  `reverse` walks j = m-1 .. 0.
-template <typename ElemF, typename EmitF>
-__device__ __forceinline__ Seg affine_scan(int m, bool reverse, ElemF elem, EmitF emit, Seg* sh) {
+// Multi-workgroup affine scan in two launches:
+//   aggregate: workgroup g reduces its chunk of the scan order to one segment  -> segs[g]
+//   apply    : workgroup g combines segs[0..g) (its carry-in) and all segs (the total), rescans its chunk
+//              and emits the inclusive state after every element.
+// elem(j) returns the segment of element j; `reverse` walks j = m-1 .. 0.
+struct ScanGeom {
+  int m;       // elements
+  int chunk;   // elements per workgroup (multiple of the tile)
+  int ngroups;
+};
+
+static inline ScanGeom make_scan_geom(int m) {
+  const int tile = AMP_THREADS * EPT;
+  int ng = (m + tile - 1) / tile;
+  if (ng > MAXG) ng = MAXG;
+  if (ng < 1) ng = 1;
+  int chunk = (m + ng - 1) / ng;
+  chunk = (chunk + tile - 1) / tile * tile;
+  ng = (m + chunk - 1) / chunk;
+  if (ng < 1) ng = 1;
+  return ScanGeom{m, chunk, ng};
+}
+
+template <typename ElemF>
+__device__ __forceinline__ Seg chunk_aggregate(const ScanGeom& sg, bool reverse, ElemF elem, Seg* sh) {
+  const int q0 = blockIdx.x * sg.chunk;
+  const int q1 = min(q0 + sg.chunk, sg.m);
   Seg carry{0.0, 0.0, 0.0};
   const int tile = AMP_THREADS * EPT;
-  for (int base = 0; base < m; base += tile) {
+  for (int base = q0; base < q1; base += tile) {
+    Seg agg{0.0, 0.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int q = base + threadIdx.x * EPT + e;
+      if (q < q1) agg = seg_combine(agg, elem(reverse ? sg.m - 1 - q : q));
+    }
+    Seg excl, total;
+    block_scan_seg(agg, excl, total, sh);
+    carry = seg_combine(carry, total);
+    __syncthreads();
+  }
+  return carry;
+}
+
+template <typename ElemF, typename EmitF>
+__device__ __forceinline__ void chunk_apply(const ScanGeom& sg, bool reverse, Seg carry, ElemF elem, EmitF emit, Seg* sh) {
+  const int q0 = blockIdx.x * sg.chunk;
+  const int q1 = min(q0 + sg.chunk, sg.m);
+  const int tile = AMP_THREADS * EPT;
+  for (int base = q0; base < q1; base += tile) {
     Seg local[EPT];
     Seg agg{0.0, 0.0, 0.0};
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-      const int q = base + threadIdx.x * EPT + e;  // position in scan order
-      if (q < m) {
-        local[e] = elem(reverse ? m - 1 - q : q);
-      } else {
-        local[e] = Seg{0.0, 0.0, 0.0};
-      }
+      const int q = base + threadIdx.x * EPT + e;
+      local[e] = q < q1 ? elem(reverse ? sg.m - 1 - q : q) : Seg{0.0, 0.0, 0.0};
       agg = seg_combine(agg, local[e]);
     }
     Seg excl, total;
@@ -111,214 +150,318 @@ __device__ __forceinline__ Seg affine_scan(int m, bool reverse, ElemF elem, Emit
     for (int e = 0; e < EPT; ++e) {
       const int q = base + threadIdx.x * EPT + e;
       run = seg_combine(run, local[e]);
-      if (q < m) emit(reverse ? m - 1 - q : q, run.A, run.B);
+      if (q < q1) emit(reverse ? sg.m - 1 - q : q, run.A, run.B);
     }
     carry = seg_combine(carry, total);
     __syncthreads();
   }
-  return carry;
 }
 
-__global__ void __launch_bounds__(AMP_THREADS) k_amp_forward(int nb, const double* __restrict__ geo,
-                                                             const double* __restrict__ hyp,
-                                                             const double* __restrict__ lat, double* __restrict__ state,
-                                                             double* __restrict__ amp) {
+// carry-in of this workgroup and the grand total from the per-workgroup aggregates
+__device__ __forceinline__ void seg_prefix_total(const double* __restrict__ segs, int ngroups, Seg& prefix, Seg& total) {
+  Seg p{0.0, 0.0, 0.0}, t{0.0, 0.0, 0.0};
+  for (int g = 0; g < ngroups; ++g) {
+    const Seg sgm{segs[3 * g], segs[3 * g + 1], segs[3 * g + 2]};
+    if (g == (int)blockIdx.x) p = t;
+    t = seg_combine(t, sgm);
+  }
+  prefix = p;
+  total = t;
+}
+
+struct AmpPtrs {
+  const double *rel, *sc, *mult, *delta;
+  double *spec, *ahat, *tmp, *segs;
+};
+__device__ __forceinline__ AmpPtrs amp_ptrs(int nb, const double* geo, double* state) {
+  AmpPtrs a;
+  a.rel = geo;
+  a.sc = geo + nb;
+  a.mult = geo + 2 * (size_t)nb;
+  a.delta = geo + 3 * (size_t)nb;
+  a.spec = state + 16;
+  a.ahat = a.spec + nb;
+  a.tmp = a.ahat + nb;
+  a.segs = state + 16 + 4 * (size_t)nb;  // 3 * MAXG doubles
+  return a;
+}
+
+// state scalars: [0] flex [1] asp [2] fluct [3] zm [4] slope [5] S [6] last [7] dS
+//                [8] fl_bar [9] Q [10] slope_bar [11] sc_dot [12] flex_bar [13] asp_bar
+__device__ __forceinline__ Seg fwd_elem(const AmpPtrs& a, const Hyper& h, const double* xs0, const double* xs1, int j) {
+  const double d = a.delta[j];
+  const double sq = sqrt(d);
+  const double x0 = h.flex * sq * sqrt(d * d / 12.0 + h.asp) * xs0[j];
+  const double x1 = h.flex * sq * xs1[j];
+  return Seg{x1, d, 0.5 * x1 * d + x0};
+}
+
+__global__ void __launch_bounds__(AMP_THREADS) k_fwd_agg(int nb, ScanGeom sg, const double* __restrict__ geo,
+                                                         const double* __restrict__ hyp, const double* __restrict__ lat,
+                                                         double* __restrict__ state) {
+  __shared__ Seg sh_seg[AMP_WAVES];
+  const AmpPtrs a = amp_ptrs(nb, geo, state);
+  const Hyper h = hyper_from_lat(hyp, lat);
+  const double *xs0 = lat + 5, *xs1 = lat + 5 + sg.m;
+  const Seg c = chunk_aggregate(sg, false, [&](int j) { return fwd_elem(a, h, xs0, xs1, j); }, sh_seg);
+  if (threadIdx.x == 0) {
+    a.segs[3 * blockIdx.x] = c.A, a.segs[3 * blockIdx.x + 1] = c.D, a.segs[3 * blockIdx.x + 2] = c.B;
+    if (blockIdx.x == 0) {
+      state[0] = h.flex, state[1] = h.asp, state[2] = h.fluct, state[3] = h.zm, state[4] = h.slope;
+      state[5] = 0.0;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(AMP_THREADS) k_fwd_apply(int nb, ScanGeom sg, const double* __restrict__ geo,
+                                                           const double* __restrict__ hyp, const double* __restrict__ lat,
+                                                           double* __restrict__ state) {
   __shared__ Seg sh_seg[AMP_WAVES];
   __shared__ double sh_d[AMP_WAVES];
-  const double* rel = geo;
-  const double* sc = geo + nb;
-  const double* mult = geo + 2 * (size_t)nb;
-  const double* delta = geo + 3 * (size_t)nb;
-  const int m = nb - 2;
+  const AmpPtrs a = amp_ptrs(nb, geo, state);
   const Hyper h = hyper_from_lat(hyp, lat);
-  const double* xs0 = lat + 5;
-  const double* xs1 = lat + 5 + m;
-  double* spec = state + 16;
-  double* ahat = spec + nb;
-  double* smooth = ahat + nb;  // tmp
-  const double V = hyp[10];
-  if (threadIdx.x == 0) {
-    state[0] = h.flex, state[1] = h.asp, state[2] = h.fluct, state[3] = h.zm, state[4] = h.slope;
-    smooth[0] = 0.0;
-    smooth[1] = 0.0;
-  }
-  Seg tot = affine_scan(
-      m, false,
-      [&](int j) {
-        const double d = delta[j];
-        const double sq = sqrt(d);
-        const double x0 = h.flex * sq * sqrt(d * d / 12.0 + h.asp) * xs0[j];
-        const double x1 = h.flex * sq * xs1[j];
-        return Seg{x1, d, 0.5 * x1 * d + x0};
-      },
-      [&](int j, double, double s) { smooth[j + 2] = s; }, sh_seg);
-  const double last = tot.B;  // smooth[nb-1]
-  __syncthreads();
+  const double *xs0 = lat + 5, *xs1 = lat + 5 + sg.m;
+  Seg prefix, total;
+  seg_prefix_total(a.segs, sg.ngroups, prefix, total);
+  const double last = total.B;
   double part = 0.0;
-  for (int b = threadIdx.x; b < nb; b += AMP_THREADS) {
-    const double p = h.slope * rel[b] + smooth[b] - last * sc[b];
-    const double s = exp(p);
-    spec[b] = s;
-    part += mult[b] * s;
-  }
+  auto bin = [&](int b, double smooth) {
+    const double s = exp(h.slope * a.rel[b] + smooth - last * a.sc[b]);
+    a.spec[b] = s;
+    part += a.mult[b] * s;
+  };
+  if (blockIdx.x == 0 && threadIdx.x < 2) bin(threadIdx.x, 0.0);
+  chunk_apply(sg, false, prefix, [&](int j) { return fwd_elem(a, h, xs0, xs1, j); },
+              [&](int j, double, double s) { bin(j + 2, s); }, sh_seg);
   const double S = block_sum(part, sh_d);
-  if (threadIdx.x == 0) state[5] = S, state[6] = last;
-  for (int b = threadIdx.x; b < nb; b += AMP_THREADS) {
+  if (threadIdx.x == 0) {
+    atomicAdd(state + 5, S);
+    if (blockIdx.x == 0) state[6] = last;
+  }
+}
+
+__global__ void k_fwd_final(int nb, const double* __restrict__ hyp, double* __restrict__ state, double* __restrict__ amp) {
+  const double S = state[5], V = hyp[10], zm = state[3], fluct = state[2];
+  const double* spec = state + 16;
+  double* ahat = state + 16 + nb;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
     const double ah = sqrt(spec[b] / S);
     ahat[b] = ah;
-    amp[b] = b == 0 ? V * h.zm : V * h.fluct * ah;
+    amp[b] = b == 0 ? V * zm : V * fluct * ah;
   }
 }
 
-__global__ void __launch_bounds__(AMP_THREADS) k_amp_jvp(int nb, const double* __restrict__ geo,
-                                                         const double* __restrict__ hyp,
-                                                         const double* __restrict__ lat, double* __restrict__ state,
-                                                         const double* __restrict__ dlat, double* __restrict__ damp) {
+// ---- JVP --------------------------------------------------------------------------------------------------------
+struct JvpScal {
+  double flex, asp, dflex, dasp;
+};
+__device__ __forceinline__ Seg jvp_elem(const AmpPtrs& a, const JvpScal& q, const double* xs0, const double* xs1,
+                                        const double* dxs0, const double* dxs1, int j) {
+  const double d = a.delta[j];
+  const double sq = sqrt(d);
+  const double w0 = sqrt(d * d / 12.0 + q.asp);
+  const double sig0 = q.flex * sq * w0, sig1 = q.flex * sq;
+  const double dsig0 = q.dflex * sq * w0 + q.flex * sq * (0.5 / w0) * q.dasp;
+  const double dsig1 = q.dflex * sq;
+  const double dx0 = dsig0 * xs0[j] + sig0 * dxs0[j];
+  const double dx1 = dsig1 * xs1[j] + sig1 * dxs1[j];
+  return Seg{dx1, d, 0.5 * dx1 * d + dx0};
+}
+
+__global__ void __launch_bounds__(AMP_THREADS) k_jvp_agg(int nb, ScanGeom sg, const double* __restrict__ geo,
+                                                         const double* __restrict__ hyp, const double* __restrict__ lat,
+                                                         double* __restrict__ state, const double* __restrict__ dlat) {
+  __shared__ Seg sh_seg[AMP_WAVES];
+  const AmpPtrs a = amp_ptrs(nb, geo, state);
+  const JvpScal q{state[0], state[1], state[0] * hyp[3] * dlat[1], state[1] * hyp[5] * dlat[0]};
+  const Seg c = chunk_aggregate(
+      sg, false, [&](int j) { return jvp_elem(a, q, lat + 5, lat + 5 + sg.m, dlat + 5, dlat + 5 + sg.m, j); }, sh_seg);
+  if (threadIdx.x == 0) {
+    a.segs[3 * blockIdx.x] = c.A, a.segs[3 * blockIdx.x + 1] = c.D, a.segs[3 * blockIdx.x + 2] = c.B;
+    if (blockIdx.x == 0) state[7] = 0.0;
+  }
+}
+
+__global__ void __launch_bounds__(AMP_THREADS) k_jvp_apply(int nb, ScanGeom sg, const double* __restrict__ geo,
+                                                           const double* __restrict__ hyp, const double* __restrict__ lat,
+                                                           double* __restrict__ state, const double* __restrict__ dlat) {
   __shared__ Seg sh_seg[AMP_WAVES];
   __shared__ double sh_d[AMP_WAVES];
-  const double* rel = geo;
-  const double* sc = geo + nb;
-  const double* mult = geo + 2 * (size_t)nb;
-  const double* delta = geo + 3 * (size_t)nb;
-  const int m = nb - 2;
-  const double flex = state[0], asp = state[1], fluct = state[2], zm = state[3], S = state[5];
-  const double* spec = state + 16;
-  const double* ahat = spec + nb;
-  double* dsm = state + 16 + 2 * (size_t)nb;  // tmp
-  const double V = hyp[10];
-  const double dasp = asp * hyp[5] * dlat[0];
-  const double dflex = flex * hyp[3] * dlat[1];
-  const double dfluct = fluct * hyp[1] * dlat[2];
+  const AmpPtrs a = amp_ptrs(nb, geo, state);
+  const JvpScal q{state[0], state[1], state[0] * hyp[3] * dlat[1], state[1] * hyp[5] * dlat[0]};
   const double dslope = hyp[9] * dlat[3];
-  const double dzm = zm * hyp[7] * dlat[4];
-  const double* xs0 = lat + 5;
-  const double* xs1 = lat + 5 + m;
-  const double* dxs0 = dlat + 5;
-  const double* dxs1 = dlat + 5 + m;
-  if (threadIdx.x == 0) dsm[0] = 0.0, dsm[1] = 0.0;
-  Seg tot = affine_scan(
-      m, false,
-      [&](int j) {
-        const double d = delta[j];
-        const double sq = sqrt(d);
-        const double w0 = sqrt(d * d / 12.0 + asp);
-        const double sig0 = flex * sq * w0, sig1 = flex * sq;
-        const double dsig0 = dflex * sq * w0 + flex * sq * (0.5 / w0) * dasp;
-        const double dsig1 = dflex * sq;
-        const double dx0 = dsig0 * xs0[j] + sig0 * dxs0[j];
-        const double dx1 = dsig1 * xs1[j] + sig1 * dxs1[j];
-        return Seg{dx1, d, 0.5 * dx1 * d + dx0};
-      },
-      [&](int j, double, double s) { dsm[j + 2] = s; }, sh_seg);
-  const double last = tot.B;
-  __syncthreads();
+  Seg prefix, total;
+  seg_prefix_total(a.segs, sg.ngroups, prefix, total);
+  const double last = total.B;
   double part = 0.0;
-  for (int b = threadIdx.x; b < nb; b += AMP_THREADS) {
-    const double dp = dslope * rel[b] + dsm[b] - last * sc[b];
-    dsm[b] = dp;
-    part += mult[b] * spec[b] * dp;
-  }
+  auto bin = [&](int b, double dsm) {
+    const double dp = dslope * a.rel[b] + dsm - last * a.sc[b];
+    a.tmp[b] = dp;
+    part += a.mult[b] * a.spec[b] * dp;
+  };
+  if (blockIdx.x == 0 && threadIdx.x < 2) bin(threadIdx.x, 0.0);
+  chunk_apply(sg, false, prefix,
+              [&](int j) { return jvp_elem(a, q, lat + 5, lat + 5 + sg.m, dlat + 5, dlat + 5 + sg.m, j); },
+              [&](int j, double, double s) { bin(j + 2, s); }, sh_seg);
   const double dS = block_sum(part, sh_d);
-  for (int b = threadIdx.x; b < nb; b += AMP_THREADS) {
-    const double dah = 0.5 * ahat[b] * (dsm[b] - dS / S);
+  if (threadIdx.x == 0) atomicAdd(state + 7, dS);
+}
+
+__global__ void k_jvp_final(int nb, const double* __restrict__ hyp, const double* __restrict__ state,
+                            const double* __restrict__ dlat, double* __restrict__ damp) {
+  const double S = state[5], dS = state[7], V = hyp[10], fluct = state[2], zm = state[3];
+  const double dfluct = fluct * hyp[1] * dlat[2], dzm = zm * hyp[7] * dlat[4];
+  const double* ahat = state + 16 + nb;
+  const double* dp = state + 16 + 2 * (size_t)nb;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
+    const double dah = 0.5 * ahat[b] * (dp[b] - dS / S);
     damp[b] = b == 0 ? V * dzm : V * (dfluct * ahat[b] + fluct * dah);
   }
 }
 
-__global__ void __launch_bounds__(AMP_THREADS) k_amp_vjp(int nb, const double* __restrict__ geo,
-                                                         const double* __restrict__ hyp,
-                                                         const double* __restrict__ lat, double* __restrict__ state,
-                                                         const double* __restrict__ abar, double* __restrict__ latbar) {
-  __shared__ Seg sh_seg[AMP_WAVES];
+// ---- VJP --------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(AMP_THREADS) k_vjp_red1(int nb, const double* __restrict__ hyp, double* __restrict__ state,
+                                                          const double* __restrict__ abar) {
   __shared__ double sh_d[AMP_WAVES];
-  const double* rel = geo;
-  const double* sc = geo + nb;
-  const double* mult = geo + 2 * (size_t)nb;
-  const double* delta = geo + 3 * (size_t)nb;
-  const int m = nb - 2;
-  const double flex = state[0], asp = state[1], fluct = state[2], zm = state[3], S = state[5];
-  const double* spec = state + 16;
-  const double* ahat = spec + nb;
-  double* pbar = state + 16 + 2 * (size_t)nb;  // tmp
-  const double V = hyp[10];
-  const double* xs0 = lat + 5;
-  const double* xs1 = lat + 5 + m;
-  // reductions: fl_bar, Q = sum q
+  const double V = hyp[10], fluct = state[2];
+  const double* ahat = state + 16 + nb;
   double p_fl = 0.0, p_q = 0.0;
-  for (int b = threadIdx.x + 1; b < nb; b += AMP_THREADS) {
+  for (int b = 1 + blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
     p_fl += abar[b] * ahat[b];
     p_q += 0.5 * ahat[b] * (V * fluct * abar[b]);
   }
-  const double fl_bar = V * block_sum(p_fl, sh_d);
-  const double Q = block_sum(p_q, sh_d);
-  double p_sl = 0.0, p_sc = 0.0;
-  for (int b = threadIdx.x; b < nb; b += AMP_THREADS) {
-    const double q = b == 0 ? 0.0 : 0.5 * ahat[b] * (V * fluct * abar[b]);
-    const double pb = q - (Q / S) * mult[b] * spec[b];
-    pbar[b] = pb;
-    p_sl += pb * rel[b];
-    p_sc += pb * sc[b];
-  }
-  const double slope_bar = block_sum(p_sl, sh_d);
-  const double sc_dot = block_sum(p_sc, sh_d);
-  __syncthreads();
-  // y = pbar with y[nb-1] -= sc_dot   (slope remover adjoint); reverse affine scan
-  double* sbar0 = latbar + 5;
-  double* sbar1 = latbar + 5 + m;
-  double p_flex = 0.0, p_asp = 0.0;
-  affine_scan(
-      m, true,
-      [&](int j) {
-        double y = pbar[j + 2];
-        if (j + 2 == nb - 1) y -= sc_dot;
-        const double dj = delta[j];
-        const double dn = j + 1 < m ? delta[j + 1] : 0.0;
-        return Seg{y, 0.5 * (dj + dn), 0.5 * y * dj};
-      },
-      [&](int j, double t, double g1) {
-        const double d = delta[j];
-        const double sq = sqrt(d);
-        const double w0 = sqrt(d * d / 12.0 + asp);
-        const double sig0 = flex * sq * w0, sig1 = flex * sq;
-        sbar0[j] = t * sig0;
-        sbar1[j] = g1 * sig1;
-        const double s0b = t * xs0[j], s1b = g1 * xs1[j];
-        p_flex += s0b * sq * w0 + s1b * sq;
-        p_asp += s0b * flex * sq * 0.5 / w0;
-      },
-      sh_seg);
-  const double flex_bar = block_sum(p_flex, sh_d);
-  const double asp_bar = block_sum(p_asp, sh_d);
+  const double s1 = block_sum(p_fl, sh_d);
+  const double s2 = block_sum(p_q, sh_d);
   if (threadIdx.x == 0) {
-    latbar[0] = asp_bar * asp * hyp[5];
-    latbar[1] = flex_bar * flex * hyp[3];
-    latbar[2] = fl_bar * fluct * hyp[1];
-    latbar[3] = slope_bar * hyp[9];
+    atomicAdd(state + 8, V * s1);
+    atomicAdd(state + 9, s2);
+  }
+}
+
+__global__ void __launch_bounds__(AMP_THREADS) k_vjp_red2(int nb, const double* __restrict__ geo, const double* __restrict__ hyp,
+                                                          double* __restrict__ state, const double* __restrict__ abar) {
+  __shared__ double sh_d[AMP_WAVES];
+  const AmpPtrs a = amp_ptrs(nb, geo, state);
+  const double V = hyp[10], fluct = state[2], S = state[5], Q = state[9];
+  double p_sl = 0.0, p_sc = 0.0;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
+    const double q = b == 0 ? 0.0 : 0.5 * a.ahat[b] * (V * fluct * abar[b]);
+    const double pb = q - (Q / S) * a.mult[b] * a.spec[b];
+    a.tmp[b] = pb;
+    p_sl += pb * a.rel[b];
+    p_sc += pb * a.sc[b];
+  }
+  const double s1 = block_sum(p_sl, sh_d);
+  const double s2 = block_sum(p_sc, sh_d);
+  if (threadIdx.x == 0) {
+    atomicAdd(state + 10, s1);
+    atomicAdd(state + 11, s2);
+  }
+}
+
+__device__ __forceinline__ Seg vjp_elem(const AmpPtrs& a, int nb, int m, double sc_dot, int j) {
+  double y = a.tmp[j + 2];
+  if (j + 2 == nb - 1) y -= sc_dot;
+  const double dj = a.delta[j];
+  const double dn = j + 1 < m ? a.delta[j + 1] : 0.0;
+  return Seg{y, 0.5 * (dj + dn), 0.5 * y * dj};
+}
+
+__global__ void __launch_bounds__(AMP_THREADS) k_vjp_agg(int nb, ScanGeom sg, const double* __restrict__ geo,
+                                                         double* __restrict__ state) {
+  __shared__ Seg sh_seg[AMP_WAVES];
+  const AmpPtrs a = amp_ptrs(nb, geo, state);
+  const double sc_dot = state[11];
+  const Seg c = chunk_aggregate(sg, true, [&](int j) { return vjp_elem(a, nb, sg.m, sc_dot, j); }, sh_seg);
+  if (threadIdx.x == 0) a.segs[3 * blockIdx.x] = c.A, a.segs[3 * blockIdx.x + 1] = c.D, a.segs[3 * blockIdx.x + 2] = c.B;
+}
+
+__global__ void __launch_bounds__(AMP_THREADS) k_vjp_apply(int nb, ScanGeom sg, const double* __restrict__ geo,
+                                                           const double* __restrict__ lat, double* __restrict__ state,
+                                                           double* __restrict__ latbar) {
+  __shared__ Seg sh_seg[AMP_WAVES];
+  __shared__ double sh_d[AMP_WAVES];
+  const AmpPtrs a = amp_ptrs(nb, geo, state);
+  const double flex = state[0], asp = state[1], sc_dot = state[11];
+  const double *xs0 = lat + 5, *xs1 = lat + 5 + sg.m;
+  double *sbar0 = latbar + 5, *sbar1 = latbar + 5 + sg.m;
+  Seg prefix, total;
+  seg_prefix_total(a.segs, sg.ngroups, prefix, total);
+  double p_flex = 0.0, p_asp = 0.0;
+  chunk_apply(sg, true, prefix, [&](int j) { return vjp_elem(a, nb, sg.m, sc_dot, j); },
+              [&](int j, double t, double g1) {
+                const double d = a.delta[j];
+                const double sq = sqrt(d);
+                const double w0 = sqrt(d * d / 12.0 + asp);
+                sbar0[j] = t * flex * sq * w0;
+                sbar1[j] = g1 * flex * sq;
+                const double s0b = t * xs0[j], s1b = g1 * xs1[j];
+                p_flex += s0b * sq * w0 + s1b * sq;
+                p_asp += s0b * flex * sq * 0.5 / w0;
+              },
+              sh_seg);
+  const double s1 = block_sum(p_flex, sh_d);
+  const double s2 = block_sum(p_asp, sh_d);
+  if (threadIdx.x == 0) {
+    atomicAdd(state + 12, s1);
+    atomicAdd(state + 13, s2);
+  }
+}
+
+__global__ void k_vjp_final(const double* __restrict__ hyp, const double* __restrict__ state, const double* __restrict__ abar,
+                            double* __restrict__ latbar) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double flex = state[0], asp = state[1], fluct = state[2], zm = state[3], V = hyp[10];
+    latbar[0] = state[13] * asp * hyp[5];
+    latbar[1] = state[12] * flex * hyp[3];
+    latbar[2] = state[8] * fluct * hyp[1];
+    latbar[3] = state[10] * hyp[9];
     latbar[4] = V * abar[0] * zm * hyp[7];
   }
 }
 
 }  // namespace
 
+static inline int amp_grid(int nb) {
+  int g = (nb + AMP_THREADS - 1) / AMP_THREADS;
+  return g < 1 ? 1 : (g > MAXG ? MAXG : g);
+}
+
 extern "C" int nk_amp_forward(int nb, const double* geo, const double* hyp, const double* lat, double* state,
                               double* amp, void* stream) {
   if (nb < 3 || !geo || !hyp || !lat || !state || !amp) return nk_set_error(NK_ERR_INVALID, "nk_amp_forward: bad argument");
-  hipLaunchKernelGGL(k_amp_forward, dim3(1), dim3(AMP_THREADS), 0, (hipStream_t)stream, nb, geo, hyp, lat, state, amp);
-  return nk_check_launch("k_amp_forward");
+  hipStream_t st = (hipStream_t)stream;
+  const ScanGeom sg = make_scan_geom(nb - 2);
+  hipLaunchKernelGGL(k_fwd_agg, dim3(sg.ngroups), dim3(AMP_THREADS), 0, st, nb, sg, geo, hyp, lat, state);
+  hipLaunchKernelGGL(k_fwd_apply, dim3(sg.ngroups), dim3(AMP_THREADS), 0, st, nb, sg, geo, hyp, lat, state);
+  hipLaunchKernelGGL(k_fwd_final, dim3(amp_grid(nb)), dim3(AMP_THREADS), 0, st, nb, hyp, state, amp);
+  return nk_check_launch("nk_amp_forward");
 }
 
 extern "C" int nk_amp_jvp(int nb, const double* geo, const double* hyp, const double* lat, double* state,
                           const double* dlat, double* damp, void* stream) {
   if (nb < 3 || !geo || !hyp || !lat || !state || !dlat || !damp)
     return nk_set_error(NK_ERR_INVALID, "nk_amp_jvp: bad argument");
-  hipLaunchKernelGGL(k_amp_jvp, dim3(1), dim3(AMP_THREADS), 0, (hipStream_t)stream, nb, geo, hyp, lat, state, dlat, damp);
-  return nk_check_launch("k_amp_jvp");
+  hipStream_t st = (hipStream_t)stream;
+  const ScanGeom sg = make_scan_geom(nb - 2);
+  hipLaunchKernelGGL(k_jvp_agg, dim3(sg.ngroups), dim3(AMP_THREADS), 0, st, nb, sg, geo, hyp, lat, state, dlat);
+  hipLaunchKernelGGL(k_jvp_apply, dim3(sg.ngroups), dim3(AMP_THREADS), 0, st, nb, sg, geo, hyp, lat, state, dlat);
+  hipLaunchKernelGGL(k_jvp_final, dim3(amp_grid(nb)), dim3(AMP_THREADS), 0, st, nb, hyp, state, dlat, damp);
+  return nk_check_launch("nk_amp_jvp");
 }
 
 extern "C" int nk_amp_vjp(int nb, const double* geo, const double* hyp, const double* lat, double* state,
                           const double* abar, double* latbar, void* stream) {
   if (nb < 3 || !geo || !hyp || !lat || !state || !abar || !latbar)
     return nk_set_error(NK_ERR_INVALID, "nk_amp_vjp: bad argument");
-  hipLaunchKernelGGL(k_amp_vjp, dim3(1), dim3(AMP_THREADS), 0, (hipStream_t)stream, nb, geo, hyp, lat, state, abar, latbar);
-  return nk_check_launch("k_amp_vjp");
+  hipStream_t st = (hipStream_t)stream;
+  const ScanGeom sg = make_scan_geom(nb - 2);
+  hipError_t e = hipMemsetAsync(state + 8, 0, 6 * sizeof(double), st);
+  if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(amp vjp scalars)");
+  hipLaunchKernelGGL(k_vjp_red1, dim3(amp_grid(nb)), dim3(AMP_THREADS), 0, st, nb, hyp, state, abar);
+  hipLaunchKernelGGL(k_vjp_red2, dim3(amp_grid(nb)), dim3(AMP_THREADS), 0, st, nb, geo, hyp, state, abar);
+  hipLaunchKernelGGL(k_vjp_agg, dim3(sg.ngroups), dim3(AMP_THREADS), 0, st, nb, sg, geo, state);
+  hipLaunchKernelGGL(k_vjp_apply, dim3(sg.ngroups), dim3(AMP_THREADS), 0, st, nb, sg, geo, lat, state, latbar);
+  hipLaunchKernelGGL(k_vjp_final, dim3(1), dim3(64), 0, st, hyp, state, abar, latbar);
+  return nk_check_launch("nk_amp_vjp");
 }
