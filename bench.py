@@ -124,8 +124,14 @@ def main():
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
 
-    shape = tuple(int(s) for s in os.environ.get("NK_BENCH_SHAPE", "1024,1024,1024").split(","))
-    dt_name = os.environ.get("NK_BENCH_DTYPE", "f32")
+    # NK_BENCH_CONFIG selects another BASELINE.json config for side measurements (never the default):
+    #   C2 = 2048^2 fp64 Poisson(exp) ;  C3 = 512^3 fp64 Gaussian ;  C5 (default) = 1024^3 fp32 Gaussian
+    cfg = os.environ.get("NK_BENCH_CONFIG", "C5")
+    preset = {"C2": ("2048,2048", "f64", "poisson"), "C3": ("512,512,512", "f64", "gaussian"),
+              "C5": ("1024,1024,1024", "f32", "gaussian")}[cfg]
+    shape = tuple(int(s) for s in os.environ.get("NK_BENCH_SHAPE", preset[0]).split(","))
+    dt_name = os.environ.get("NK_BENCH_DTYPE", preset[1])
+    lh_kind = preset[2]
     dtype = torch.float32 if dt_name == "f32" else torch.float64
     b = 4 if dtype == torch.float32 else 8
     N = int(np.prod(shape))
@@ -135,13 +141,18 @@ def main():
     L.load()
     model = FusedModel(shape, offset_mean=2.0, offset_std=(1e-1, 3e-2), fluctuations=(1.0, 5e-1),
                        loglogavgslope=(-3.0, 2e-1), flexibility=(1.0, 2e-1), asperity=(5e-1, 5e-2),
-                       likelihood="gaussian", icov=1.0 / noise_var, dtype=dtype, device=device)
-    # synthetic data: d = cf(truth) + noise, identical on all ranks (same device seed)
+                       likelihood=lh_kind, icov=1.0 / noise_var, nonlin="exp" if lh_kind == "poisson" else None,
+                       dtype=dtype, device=device)
+    # synthetic data, identical on all ranks (same device seed): d = cf(truth) + noise, or d ~ Poisson(exp(cf(truth)))
     gen = torch.Generator(device=device).manual_seed(42)
     truth = model.draw_prior(gen)
     data = model.signal(truth)
-    data.add_(torch.randn(shape, dtype=dtype, device=device, generator=gen), alpha=math.sqrt(noise_var))
-    model.set_data(data, 1.0 / noise_var)
+    if lh_kind == "poisson":
+        data = torch.poisson(data.double(), generator=gen).to(torch.int64)
+        model.set_data(data)
+    else:
+        data.add_(torch.randn(shape, dtype=dtype, device=device, generator=gen), alpha=math.sqrt(noise_var))
+        model.set_data(data, 1.0 / noise_var)
     del truth
     mean = 0.1 * model.draw_prior(gen)
     rng_draws = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -193,8 +204,14 @@ def main():
             ent = by_kernel[kern]
             avg_ms = ent["ms"] / ent["cnt"]
             achieved = ent["bytes"] / ent["cnt"] / (avg_ms * 1e-3) / 1e9
+            traffic = None  # PMC numbers come from separate rocprofv3 passes of this very command (profiles/)
+            tfile = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+            if os.path.exists(tfile) and world == 1:
+                tj = json.load(open(tfile))
+                if tj.get("workload") == f"{'x'.join(map(str, shape))}:{dt_name}":
+                    traffic = tj["kernels"].get(KERNEL_NAMES[kern], {}).get("bytes")
             roofline = dict(bound="hbm", kernel=KERNEL_NAMES[kern], achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
-                            unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                            unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                             avg_launch_ms=round(avg_ms, 4), launches=int(ent["cnt"]),
                             algorithmic_bytes_per_launch=ent["bytes"] / ent["cnt"],
                             all_pass_kernels={KERNEL_NAMES[k]: dict(ms_total=round(v["ms"], 2), launches=int(v["cnt"]),
@@ -218,7 +235,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if dtype == torch.float32 else "f64",
             "data": "synthetic",
-            "config": {"workload": f"C5: {'x'.join(map(str, shape))} RGSpace CorrelatedField + Gaussian likelihood, "
+            "config": {"workload": f"{cfg}: {'x'.join(map(str, shape))} RGSpace CorrelatedField + {lh_kind} likelihood, "
                                    f"{2 * n_pairs} mirrored MGVI samples, {dt_name} fields / fp64 accumulators, "
                                    "sampling CG limit 20, NewtonCG 3 steps x <=20 CG iterations",
                        "samples_total": 2 * n_pairs, "parallelism": f"sample-sharded x{world}",

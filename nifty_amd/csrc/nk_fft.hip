@@ -206,7 +206,7 @@ template <typename T, int NL, bool COUPLES, int EC>
 __global__ void __launch_bounds__((FinalTile<T, NL>::THREADS))
     k2_final(NkPassF p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work) {
   extern __shared__ __align__(16) unsigned char smem[];
-  DeviceExec<T, Sched<T, NL>::E> ex;
+  DeviceExec<T, SchedF<T, NL>::E> ex;
   double acc = 0.0;
   nk_final_body<T, NL, FinalTile<T, NL>::TILE, COUPLES, EC>(ex, p, f, blockIdx.x, (T*)smem, tw, work, &acc);
   nk_flush_energy(f, acc, smem);

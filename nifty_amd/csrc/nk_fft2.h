@@ -140,6 +140,19 @@ NK_SCHED(double, 2048, 16, 3, 16, 16, 8);
 NK_SCHED(double, 4096, 16, 3, 16, 16, 16);
 #undef NK_SCHED
 
+// schedule of the FINAL (contiguous) pass: E = 16 everywhere -- twice the threads per line pair, half the LDS
+// tile per workgroup -> twice the resident waves for the latency-bound epilogue
+template <typename T, int N>
+struct SchedF : Sched<T, N> {};
+template <>
+struct SchedF<float, 512> : SchedDef<512, 16, 3, 16, 16, 2> {};
+template <>
+struct SchedF<float, 1024> : SchedDef<1024, 16, 3, 16, 16, 4> {};
+template <>
+struct SchedF<float, 2048> : SchedDef<2048, 16, 3, 16, 16, 8> {};
+template <>
+struct SchedF<float, 4096> : SchedDef<4096, 16, 3, 16, 16, 16> {};
+
 // ---------------------------------------------------------------------------------------------
 // LDS exchange planes (scalar T).
 //   strided passes : plane[row][t], lanes run over the TILE columns first.  Rows written by neighbouring
@@ -189,12 +202,12 @@ struct ContigTile {
 };
 
 #ifndef NK_FINAL_LDS_KB
-#define NK_FINAL_LDS_KB 72
+#define NK_FINAL_LDS_KB 40
 #endif
 // final pass of the strided-first pipeline: up to 256 threads and ~72 KiB of planes (two workgroups per CU)
 template <typename T, int NL>
 struct FinalTile {
-  static constexpr int P = Sched<T, NL>::P;
+  static constexpr int P = SchedF<T, NL>::P;
   static constexpr int PITCH = ContigLayout<NL, P>::PITCH;
   static constexpr int fit(int tile) {
     return (tile > 1 && (P * tile > 256 || 2 * tile * PITCH * (int)sizeof(T) > NK_FINAL_LDS_KB * 1024)) ? fit(tile / 2) : tile;
@@ -581,7 +594,7 @@ struct NkPassF {
 template <typename T, int NL, int TILE, bool COUPLES, int EC, typename Exec>
 NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f, int64_t blk, T* planes,
                          const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, double* acc_out) {
-  using SC = Sched<T, NL>;
+  using SC = SchedF<T, NL>;
   using LY = ContigLayout<NL, SC::P>;
   constexpr int E = SC::E, S = SC::S, P = SC::P, H = NL / 2;
   T* pre = planes;

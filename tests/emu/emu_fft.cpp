@@ -140,7 +140,7 @@ static void emu2_final(const NkPassF& pf0, const nk_fuse& f, const C2<T>* tw, co
   std::vector<T> planes(CT::LDS_BYTES / sizeof(T));
   const int64_t blocks = (int64_t)pf.g.batch * (pf.A / 2 + 1) * pf.tiles_per_a;
   for (int64_t blk = 0; blk < blocks; ++blk) {
-    HostExec<T, Sched<T, NL>::E> ex(CT::THREADS);
+    HostExec<T, SchedF<T, NL>::E> ex(CT::THREADS);
     if (couples && f.afield) nk_final_body<T, NL, CT::TILE, true, 2>(ex, pf, f, blk, planes.data(), tw, work, energy);
     else if (couples) nk_final_body<T, NL, CT::TILE, true, -1>(ex, pf, f, blk, planes.data(), tw, work, energy);
     else if (f.epi == NK_EPI_AFFINE) nk_final_body<T, NL, CT::TILE, false, 0>(ex, pf, f, blk, planes.data(), tw, work, energy);
