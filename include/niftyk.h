@@ -85,6 +85,10 @@ typedef struct nk_fuse {
   const void* dampT;    /* optional da table in the field dtype T (AMP_JVP) instead of the double table `damp` */
   int abar_copies;      /* VJP: 0/1 = one device-scope accumulator; 8 = one private accumulator per XCD */
   int64_t abar_stride;  /* elements between the private accumulators (fold them with nk_fold_copies) */
+  const void* dafield;  /* optional T* field da[pidx[i]] (nk_octant_expand of the da table): AMP_JVP without any gather */
+  double* w8;           /* VJP, optional: instead of atomics store the per-octant-point sums xi*t (all sign-flip images
+                           merged) to w8[batch][A/2+1][M/2+1][NL/2+1]; reduce with nk_octant_scatter.  Only honoured
+                           when nk_plan_octant_vjp(plan) != 0 */
 } nk_fuse;
 
 typedef struct nk_plan nk_plan;
@@ -142,6 +146,22 @@ int nk_scatter_add(int64_t n, const void* in, const int32_t* pidx, int64_t nbins
 
 /* dst[0..n) = sum over c < copies of src[c*stride + (0..n)]  (folds the per-XCD VJP accumulators) */
 int nk_fold_copies(int64_t n, int copies, int64_t stride, const double* src, double* dst, void* stream);
+
+/* ---- octant helpers: |k| binning is invariant under the sign flip of every axis, so bin-indexed tables are
+ *      expanded / reduced on the octant k_i <= n_i/2 only (1/8 of the gathers / atomics in 3-D).
+ *      shape = the `ndim` (1..3) grid axes; fields are [shape...] C order.
+ * nk_octant_expand : field[x] = table[pidx[x]] for every grid point, one table gather per octant point
+ *                    (PowerDistributor TIMES, distributors.py:114-119)
+ * nk_octant_scatter: abar[pidx[x]] += w8[x] over the octant array w8[A/2+1][M/2+1][NL/2+1] written by the VJP
+ *                    epilogue; merge_swapped_lines != 0 (only valid when the first two axes have equal length AND
+ *                    equal harmonic distances) folds the lines (a,b) and (b,a) before the atomics
+ *                    (PowerDistributor ADJOINT_TIMES, distributors.py:106-112) */
+int nk_octant_expand(int ndim, const int64_t* shape, const void* table, const int32_t* pidx, void* field, int dtype,
+                     void* stream);
+int nk_octant_scatter(int ndim, const int64_t* shape, const double* w8, const int32_t* pidx, double* abar,
+                      int merge_swapped_lines, void* stream);
+/* 1 if nk_hartley_fused on this plan honours nk_fuse.w8 (the register-resident pipeline is active) */
+int nk_plan_octant_vjp(const nk_plan* plan);
 
 /* power-bin index of every grid point from integer k^2 (equal harmonic distances): pidx[i] = k2table[k^2(i)],
  * rho[bin] += 1 (rho may be NULL, else zeroed by the caller).  Replaces the int64 full-grid searchsorted of

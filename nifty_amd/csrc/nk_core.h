@@ -203,6 +203,8 @@ NK_HD T nk_prologue(const NkFuse& f, int64_t i) {
       if (f.afield) return ((const T*)f.afield)[i] * in[i];
       return (T)(f.amp[f.pidx[i]] * (double)in[i]);
     case NK_PRO_AMP_JVP: {
+      if (f.afield && f.dafield)
+        return ((const T*)f.afield)[i] * in[i] + ((const T*)f.dafield)[i] * ((const T*)f.in2)[i];
       const int32_t p = f.pidx[i];
       if (f.afield) {
         const T da = f.dampT ? ((const T*)f.dampT)[p] : (T)f.damp[p];
@@ -252,7 +254,7 @@ NK_HD C2<T> nk_prologue_pair(const NkFuse& f, int64_t i) {
 }
 
 // compile-time specialised pair prologues of the hot configurations (no run-time switch in the load loop):
-//   PC = 0 plain, 1 afield*in, 2 afield*in + dampT[pidx]*in2, anything else -> generic run-time version
+//   PC = 0 plain, 1 afield*in, 2 afield*in + dampT[pidx]*in2, 3 afield*in + dafield*in2, else generic run-time version
 template <typename T, int PC>
 NK_HD C2<T> nk_prologue_ct(const NkFuse& f, int64_t i) {
   if constexpr (PC == 0) {
@@ -268,6 +270,12 @@ NK_HD C2<T> nk_prologue_ct(const NkFuse& f, int64_t i) {
     const int2 p = *reinterpret_cast<const int2*>(f.pidx + i);
     const T* dt = (const T*)f.dampT;
     return C2<T>{m.x * a.x + dt[p.x] * x.x, m.y * a.y + dt[p.y] * x.y};
+  } else if constexpr (PC == 3) {
+    const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + i);
+    const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + i);
+    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + i);
+    const C2<T> dm = *reinterpret_cast<const C2<T>*>((const T*)f.dafield + i);
+    return C2<T>{m.x * a.x + dm.x * x.x, m.y * a.y + dm.y * x.y};
   } else {
     return C2<T>{nk_prologue<T>(f, i), nk_prologue<T>(f, i + 1)};
   }
@@ -393,26 +401,70 @@ NK_HD double nk_emit_vjp(const NkFuse& f, int64_t o, T v, double a_bin) {
 }
 
 // up to eight outputs that share one power bin (the sign-flip images of one coefficient): one atomic for the VJP
+// scatter (VJP) epilogue of the four images of one slot: all loads first, then the stores; returns sum xi*t
+template <typename T>
+NK_HD double nk_vjp_quad(const NkFuse& f, const int64_t (&o)[4], const T (&v)[4], int mask, double a) {
+  T* out = (T*)f.out;
+  const T* xi = (const T*)f.xi;
+  const T* addend = (const T*)f.addend;
+  T xv[4], av[4], ov[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool on = (mask >> i) & 1;
+    xv[i] = on ? xi[o[i]] : (T)0;
+    av[i] = (on && addend) ? addend[o[i]] : (T)0;
+    ov[i] = (on && f.accumulate) ? out[o[i]] : (T)0;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!((mask >> i) & 1)) continue;
+    const double t = (double)v[i] * f.scale;
+    out[o[i]] = (T)(a * t + f.addend_scale * (double)av[i] + (double)ov[i]);
+    s += (double)xv[i] * t;
+  }
+  return s;
+}
+
 template <typename T, int NOUT>
-NK_HD void nk_epilogue_multi(const NkFuse& f, const int64_t (&o)[8], const T (&v)[8], int mask, double& acc) {
+NK_HD void nk_epilogue_multi(const NkFuse& f, const int64_t (&o)[8], const T (&v)[8], int mask, double& acc,
+                             double* w8slot = nullptr) {
   if (f.epi == NK_EPI_VJP) {
     T* out = (T*)f.out;
     const T* xi = (const T*)f.xi;
+    const T* addend = (const T*)f.addend;
+    const T* afield = (const T*)f.afield;
     const int first = (mask & 15) ? 0 : 4;  // slot 0 of an active half is always valid
-    const int32_t p = f.pidx[o[first]];
-    const double a = f.afield ? (double)((const T*)f.afield)[o[first]] : f.amp[p];
+    // all loads first (nothing below may be reordered across the stores by the compiler: out may alias)
+    T xv[NOUT], av[NOUT], ov[NOUT];
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+      const bool on = (mask >> i) & 1;
+      xv[i] = on ? xi[o[i]] : (T)0;
+      av[i] = (on && addend) ? addend[o[i]] : (T)0;
+      ov[i] = (on && f.accumulate) ? out[o[i]] : (T)0;
+    }
+    int32_t p = 0;
+    double a;
+    if (afield) {
+      a = (double)afield[o[first]];
+      if (!w8slot) p = f.pidx[o[first]];
+    } else {
+      p = f.pidx[o[first]];
+      a = f.amp[p];
+    }
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
-      if (!(mask & (1 << i))) continue;
+      if (!((mask >> i) & 1)) continue;
       const double t = (double)v[i] * f.scale;
-      double r = a * t;
-      if (f.addend) r += f.addend_scale * (double)((const T*)f.addend)[o[i]];
-      if (f.accumulate) r += (double)out[o[i]];
-      out[o[i]] = (T)r;
-      s += (double)xi[o[i]] * t;
+      out[o[i]] = (T)(a * t + f.addend_scale * (double)av[i] + (double)ov[i]);
+      s += (double)xv[i] * t;
     }
-    NK_VJP_SCATTER(f, p, s);
+    if (w8slot)
+      *w8slot = s;  // octant array: every slot is written exactly once, reduced later by nk_octant_scatter
+    else
+      NK_VJP_SCATTER(f, p, s);
   } else {
 #pragma unroll
     for (int i = 0; i < NOUT; ++i)

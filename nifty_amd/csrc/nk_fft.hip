@@ -203,7 +203,7 @@ __global__ void __launch_bounds__((StridedTile<T, N>::THREADS))
 }
 
 template <typename T, int NL, bool COUPLES, int EC>
-__global__ void __launch_bounds__((FinalTile<T, NL>::THREADS))
+__global__ void __launch_bounds__((FinalTile<T, NL>::THREADS), (COUPLES ? 3 : 4))
     k2_final(NkPassF p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, SchedF<T, NL>::E> ex;
@@ -309,6 +309,8 @@ static int nk_launch_strided(const NkPassS& ps, const NkFuse& f, const C2<T>* tw
   if constexpr (MODE == 3) {
     if (f.pro == NK_PRO_PLAIN) return nk_launch_strided_pc<T, N, MODE, 0>(ps, f, tw, work, scratch, st);
     if (f.pro == NK_PRO_AMP && f.afield) return nk_launch_strided_pc<T, N, MODE, 1>(ps, f, tw, work, scratch, st);
+    if (f.pro == NK_PRO_AMP_JVP && f.afield && f.dafield)
+      return nk_launch_strided_pc<T, N, MODE, 3>(ps, f, tw, work, scratch, st);
     if (f.pro == NK_PRO_AMP_JVP && f.afield && f.dampT)
       return nk_launch_strided_pc<T, N, MODE, 2>(ps, f, tw, work, scratch, st);
   }
@@ -544,6 +546,18 @@ extern "C" int nk_plan_destroy(nk_plan* P) {
   delete P;
   return NK_OK;
 }
+
+static bool nk_plan_uses_pipeline2(const nk_plan* P) {
+  const NkHostPlan& hp = P->hp;
+  const bool f32 = hp.dtype == NK_F32;
+  if (!nk_fast_enabled() || nk_env_int("NK_PIPELINE", 2) != 2 || hp.g.ndim < 2 || !nk_fast_size(hp.g.nl)) return false;
+  const bool first_ok = f32 ? nk_fast_strided_ok<float>(hp.g.na, hp.pc.inner) : nk_fast_strided_ok<double>(hp.g.na, hp.pc.inner);
+  const bool mid_ok = hp.g.ndim == 2 || (f32 ? nk_fast_strided_ok<float>(hp.g.nm, hp.pb.inner)
+                                             : nk_fast_strided_ok<double>(hp.g.nm, hp.pb.inner));
+  return first_ok && mid_ok;
+}
+
+extern "C" int nk_plan_octant_vjp(const nk_plan* P) { return P && nk_plan_uses_pipeline2(P) ? 1 : 0; }
 
 extern "C" size_t nk_plan_workspace_bytes(const nk_plan* P) {
   if (!P) return 0;

@@ -728,6 +728,12 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f, int64_t bl
     constexpr int NH = COUPLES ? 2 : 1;
     FinalGroup<NH> gp;  // mlo per slot: 0 inactive, 1 self-paired line, 3 regular pair
     int any = 0;
+    // octant slot of this group for the optional w8 output (VJP): [batch][a][b0][k_last]
+    double* w8line = nullptr;
+    if (f.w8 && f.epi == NK_EPI_VJP) {
+      const int b0 = couples ? bt0 * (TILE / 2) + u : bt0 * TILE + u;
+      w8line = f.w8 + ((bat * (A / 2 + 1) + a) * (int64_t)(M / 2 + 1) + b0) * (NL / 2 + 1);
+    }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int t = couples ? 2 * u + h : u;
@@ -755,9 +761,42 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f, int64_t bl
     }
 #else
     if (any) {
+      const bool vjp = f.epi == NK_EPI_VJP;
       for (int k2 = lane; k2 < NK; k2 += tps) {
         const int k2m = k2 ? NL - k2 : 0;
         const int d1 = k2 + (k2 >> 5), d2 = k2m + (k2m >> 5);
+        if (vjp) {
+          // one slot (four images) at a time keeps the register footprint of the scatter epilogue small
+          int hv = 0;
+#pragma unroll
+          for (int h = NH - 1; h >= 0; --h)
+            if (gp.mlo[h]) hv = h;
+          int32_t bin = 0;
+          double a;
+          if (f.afield) {
+            a = (double)((const T*)f.afield)[gp.okh[hv] + k2];
+            if (!w8line) bin = f.pidx[gp.okh[hv] + k2];
+          } else {
+            bin = f.pidx[gp.okh[hv] + k2];
+            a = f.amp[bin];
+          }
+          double ssum = 0.0;
+#pragma unroll
+          for (int h = 0; h < NH; ++h) {
+            if (!gp.mlo[h]) continue;
+            const T fx = pre[gp.base[h] + d1], fy = pim[gp.base[h] + d1];
+            const T gx = pre[gp.base[h] + d2], gy = pim[gp.base[h] + d2];
+            const int64_t o4[4] = {gp.okh[h] + k2, gp.omh[h] + k2m, gp.okh[h] + k2m, gp.omh[h] + k2};
+            const T v4[4] = {fx + sg * fy, fx - sg * fy, gx + sg * gy, gx - sg * gy};
+            const int m4 = gp.mlo[h] == 1 ? (k2m != k2 ? 5 : 1) : (k2m != k2 ? 15 : 3);
+            ssum += nk_vjp_quad<T>(f, o4, v4, m4, a);
+          }
+          if (w8line)
+            w8line[k2] = ssum;
+          else
+            NK_VJP_SCATTER(f, bin, ssum);
+          continue;
+        }
         int64_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         T v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int mask = 0;

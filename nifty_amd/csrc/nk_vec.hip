@@ -514,3 +514,82 @@ extern "C" int nk_fold_copies(int64_t n, int copies, int64_t stride, const doubl
   hipLaunchKernelGGL(k_fold_copies, dim3(nk_grid(n)), dim3(NK_VEC_THREADS), 0, (hipStream_t)stream, n, copies, stride, src, dst);
   return nk_check_launch("k_fold_copies");
 }
+
+// ---- octant expand / scatter ---------------------------------------------------------------------------------------
+struct NkOct {
+  int A, M, NL;     // grid axes, right aligned (1 for missing axes)
+  int Ah, Mh, Ch;   // octant extents n/2 + 1
+};
+static int nk_make_oct(int ndim, const int64_t* shape, NkOct& o) {
+  if (ndim < 1 || ndim > 3 || !shape) return nk_set_error(NK_ERR_INVALID, "octant: bad shape");
+  o.A = ndim == 3 ? (int)shape[0] : 1;
+  o.M = ndim >= 2 ? (int)shape[ndim - 2] : 1;
+  o.NL = (int)shape[ndim - 1];
+  o.Ah = o.A / 2 + 1, o.Mh = o.M / 2 + 1, o.Ch = o.NL / 2 + 1;
+  return NK_OK;
+}
+
+// one workgroup per octant line (a, b); lanes run over c = k_last
+template <typename T>
+__global__ void k_octant_expand(NkOct o, const T* __restrict__ table, const int32_t* __restrict__ pidx, T* __restrict__ field) {
+  const int b = blockIdx.x % o.Mh, a = blockIdx.x / o.Mh;
+  const int am = a ? o.A - a : 0, bm = b ? o.M - b : 0;
+  const int64_t r00 = ((int64_t)a * o.M + b) * o.NL, r01 = ((int64_t)a * o.M + bm) * o.NL;
+  const int64_t r10 = ((int64_t)am * o.M + b) * o.NL, r11 = ((int64_t)am * o.M + bm) * o.NL;
+  for (int c = threadIdx.x; c < o.Ch; c += blockDim.x) {
+    const int cm = c ? o.NL - c : 0;
+    const T v = table[pidx[r00 + c]];
+    field[r00 + c] = v;
+    field[r00 + cm] = v;
+    field[r01 + c] = v;
+    field[r01 + cm] = v;
+    field[r10 + c] = v;
+    field[r10 + cm] = v;
+    field[r11 + c] = v;
+    field[r11 + cm] = v;
+  }
+}
+
+__global__ void k_octant_scatter(NkOct o, int swap_merge, const double* __restrict__ w8, const int32_t* __restrict__ pidx,
+                                 double* __restrict__ abar) {
+  const int b = blockIdx.x % o.Mh, a = blockIdx.x / o.Mh;
+  if (swap_merge && a > b) return;  // (b, a) is folded into (a, b)
+  const double* l0 = w8 + ((int64_t)a * o.Mh + b) * o.Ch;
+  const double* l1 = w8 + ((int64_t)b * o.Mh + a) * o.Ch;
+  const bool both = swap_merge && a < b;
+  const int64_t r00 = ((int64_t)a * o.M + b) * o.NL;
+  for (int c = threadIdx.x; c < o.Ch; c += blockDim.x) {
+    double s = l0[c];
+    if (both) s += l1[c];
+    atomicAdd(abar + pidx[r00 + c], s);
+  }
+}
+
+extern "C" int nk_octant_expand(int ndim, const int64_t* shape, const void* table, const int32_t* pidx, void* field,
+                                int dtype, void* stream) {
+  NkOct o;
+  int rc = nk_make_oct(ndim, shape, o);
+  if (rc != NK_OK) return rc;
+  if (!table || !pidx || !field) return nk_set_error(NK_ERR_INVALID, "nk_octant_expand: null argument");
+  const int64_t blocks = (int64_t)o.Ah * o.Mh;
+  const int threads = o.Ch >= 256 ? 256 : 64;
+  NK_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL(k_octant_expand<T>, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, o, (const T*)table,
+                       pidx, (T*)field);
+  })
+  return nk_check_launch("k_octant_expand");
+}
+
+extern "C" int nk_octant_scatter(int ndim, const int64_t* shape, const double* w8, const int32_t* pidx, double* abar,
+                                 int merge_swapped_lines, void* stream) {
+  NkOct o;
+  int rc = nk_make_oct(ndim, shape, o);
+  if (rc != NK_OK) return rc;
+  if (!w8 || !pidx || !abar) return nk_set_error(NK_ERR_INVALID, "nk_octant_scatter: null argument");
+  const int64_t blocks = (int64_t)o.Ah * o.Mh;
+  const int threads = o.Ch >= 256 ? 256 : 64;
+  const int swap_merge = (merge_swapped_lines && ndim == 3 && o.A == o.M) ? 1 : 0;
+  hipLaunchKernelGGL(k_octant_scatter, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, o, swap_merge, w8, pidx,
+                     abar);
+  return nk_check_launch("k_octant_scatter");
+}

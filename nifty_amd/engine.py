@@ -16,6 +16,7 @@ minimization/kl_energies.py:91-159, 299-360, behind the Energy protocol of minim
 Latent vectors are ``LatentVec``: ``xi`` (the harmonic-space excitations, field dtype) and ``small``
 (float64: asperity, flexibility, fluctuations, loglogavgslope, zeromode, spectrum[2, nb-2]).
 """
+import ctypes
 import math
 
 import numpy as np
@@ -229,6 +230,13 @@ class FusedModel:
             self.damp = torch.empty(nb, dtype=torch.float64, device=self.device)
             self.latbar = torch.empty(self.nsmall, dtype=torch.float64, device=self.device)
             self.tmp = torch.empty(self.shape, dtype=dtype, device=self.device)
+            self.dafield = torch.empty(self.shape, dtype=dtype, device=self.device)
+            # octant array for the VJP scatter (sign-flip images merged in the final transform pass)
+            self.octant_vjp = bool(L.load().nk_plan_octant_vjp(self.plan.handle))
+            oct_n = int(np.prod([n // 2 + 1 for n in self.shape]))
+            self.w8 = torch.empty(oct_n, dtype=torch.float64, device=self.device) if self.octant_vjp else None
+            self.merge_swapped = int(len(self.shape) == 3 and self.shape[0] == self.shape[1]
+                                     and hsp.distances[0] == hsp.distances[1])
         # likelihood
         if likelihood not in ("gaussian", "poisson"):
             raise ValueError("likelihood must be 'gaussian' or 'poisson'")
@@ -266,11 +274,15 @@ class FusedModel:
                                         state.data_ptr(), amp.data_ptr(), B._stream()), "nk_amp_forward")
         return amp, state
 
-    def _amp_field(self, amp):
-        """a[pindex] materialised in the field dtype: ONE gather per linearisation point instead of one per
-        transform (every later prologue / epilogue streams it)."""
+    def _amp_field(self, amp, out=None):
+        """table[pindex] materialised in the field dtype with one gather per OCTANT point (|k| bins are invariant
+        under the sign flip of every axis): every later prologue / epilogue streams the field instead of gathering."""
         table = amp if self.tdtype == torch.float64 else amp.to(self.tdtype)
-        return B.gather(table, self.pidx, self.shape)
+        out = torch.empty(self.shape, dtype=self.tdtype, device=self.device) if out is None else out
+        shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
+        L.check(L.load().nk_octant_expand(len(self.shape), shp, table.data_ptr(), self.pidx.data_ptr(), out.data_ptr(),
+                                          B.dtype_code(out), B._stream()), "nk_octant_expand")
+        return out
 
     def _fuse(self):
         f = L.Fuse()
@@ -298,12 +310,21 @@ class FusedModel:
         f.epi, f.out, f.scale = L.EPI_VJP, out_xi.data_ptr(), self.h_dvol * scale
         f.pidx, f.amp, f.xi = self.pidx.data_ptr(), lp.amp.data_ptr(), lp.x.xi.data_ptr()
         f.afield = B.ptr(lp.afield)
-        f.abar, f.abar_copies, f.abar_stride = self.abar_priv.data_ptr(), self.abar_copies, self.abar_stride
         f.addend, f.addend_scale, f.accumulate = B.ptr(addend), addend_scale, 1 if accumulate else 0
-        self.abar_priv.zero_()
-        B.hartley_fused(self.plan, f)
-        L.check(L.load().nk_fold_copies(self.nb, self.abar_copies, self.abar_stride, self.abar_priv.data_ptr(),
-                                        self.abar.data_ptr(), B._stream()), "nk_fold_copies")
+        if self.octant_vjp:
+            # the final pass stores one merged sum per octant point; nk_octant_scatter reduces them into the bins
+            f.abar, f.w8 = self.abar.data_ptr(), self.w8.data_ptr()
+            B.hartley_fused(self.plan, f)
+            self.abar.zero_()
+            shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
+            L.check(L.load().nk_octant_scatter(len(self.shape), shp, self.w8.data_ptr(), self.pidx.data_ptr(),
+                                               self.abar.data_ptr(), self.merge_swapped, B._stream()), "nk_octant_scatter")
+        else:
+            f.abar, f.abar_copies, f.abar_stride = self.abar_priv.data_ptr(), self.abar_copies, self.abar_stride
+            self.abar_priv.zero_()
+            B.hartley_fused(self.plan, f)
+            L.check(L.load().nk_fold_copies(self.nb, self.abar_copies, self.abar_stride, self.abar_priv.data_ptr(),
+                                            self.abar.data_ptr(), B._stream()), "nk_fold_copies")
         self.counters["transforms"] += 1
 
     def _amp_vjp(self, lp):
@@ -363,9 +384,8 @@ class FusedModel:
         f.pro, f.in_, f.in2 = L.PRO_AMP_JVP, d.xi.data_ptr(), lp.x.xi.data_ptr()
         f.pidx, f.amp, f.damp = self.pidx.data_ptr(), lp.amp.data_ptr(), self.damp.data_ptr()
         f.afield = B.ptr(lp.afield)
-        if self.tdtype != torch.float64:
-            damp_t = self.damp.to(self.tdtype)  # table in the field dtype (dtype conversion only)
-            f.dampT = damp_t.data_ptr()
+        self._amp_field(self.damp, out=self.dafield)  # da[pindex] through the octant expansion (1/8 of the gathers)
+        f.dafield = self.dafield.data_ptr()
         f.epi, f.out, f.mul, f.mul_scalar = L.EPI_MUL, self.tmp.data_ptr(), B.ptr(lp.mid), lp.mid_scalar
         B.hartley_fused(self.plan, f)
         self._vjp(lp, self.tmp, scale, None, 0.0, not first, out.xi)

@@ -109,6 +109,7 @@ static void emu2_strided(NkPassS p, int mode, const nk_fuse& f, const C2<T>* tw,
     if (mode == 3) {
       if (f.pro == NK_PRO_PLAIN) nk_strided_body<T, N, ST::TILE, 3, 0>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
       else if (f.pro == NK_PRO_AMP && f.afield) nk_strided_body<T, N, ST::TILE, 3, 1>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+      else if (f.pro == NK_PRO_AMP_JVP && f.afield && f.dafield) nk_strided_body<T, N, ST::TILE, 3, 3>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
       else if (f.pro == NK_PRO_AMP_JVP && f.afield && f.dampT) nk_strided_body<T, N, ST::TILE, 3, 2>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
       else nk_strided_body<T, N, ST::TILE, 3, -1>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
     } else {

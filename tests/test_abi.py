@@ -31,9 +31,10 @@ def test_fuse_struct_layout_matches_header():
 
     text = open(os.path.join(ROOT, "include", "niftyk.h")).read()
     body = text[text.index("typedef struct nk_fuse {"):text.index("} nk_fuse;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = []
     for line in body.splitlines()[1:]:
-        line = line.split("/*")[0].strip().rstrip(";")
+        line = line.strip().rstrip(";")
         if not line:
             continue
         decl = line.split("(")[0]
