@@ -376,8 +376,9 @@ class FusedModel:
         self.counters["value_grad"] += 1
         return lp
 
-    def lh_metric_accumulate(self, lp, d, out, scale, first):
-        """out (+)= scale * J^T M J d   (likelihood Fisher metric pulled back to latent space)."""
+    def lh_metric_accumulate(self, lp, d, out, scale, first, identity=0.0):
+        """out (+)= scale * J^T M J d  (+ identity * d): the likelihood Fisher metric pulled back to latent space;
+        the optional multiple of d (prior metric = 1) rides along in the VJP epilogue of the xi part."""
         L.check(L.load().nk_amp_jvp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(),
                                     lp.state.data_ptr(), d.small.data_ptr(), self.damp.data_ptr(), B._stream()), "nk_amp_jvp")
         f = self._fuse()
@@ -388,20 +389,22 @@ class FusedModel:
         f.dafield = self.dafield.data_ptr()
         f.epi, f.out, f.mul, f.mul_scalar = L.EPI_MUL, self.tmp.data_ptr(), B.ptr(lp.mid), lp.mid_scalar
         B.hartley_fused(self.plan, f)
-        self._vjp(lp, self.tmp, scale, None, 0.0, not first, out.xi)
+        self._vjp(lp, self.tmp, scale, d.xi if identity else None, identity, not first, out.xi)
         self.counters["transforms"] += 1
         self._amp_vjp(lp)
         if first:
-            out.small = B.axpby(1.0, self.latbar)
+            out.small = B.axpby(1.0, self.latbar, identity, d.small) if identity else B.axpby(1.0, self.latbar)
         else:
             B.axpby(1.0, self.latbar, 1.0, out.small, out=out.small)
+            if identity:
+                B.axpby(identity, d.small, 1.0, out.small, out=out.small)
         self.counters["metric"] += 1
 
     def metric(self, lp, d):
         """(J^T M J + 1) d at the linearisation point lp."""
         out = LatentVec(torch.empty_like(d.xi), None)
-        self.lh_metric_accumulate(lp, d, out, 1.0, True)
-        return out + d
+        self.lh_metric_accumulate(lp, d, out, 1.0, True, identity=1.0)
+        return out
 
     def lh_metric(self, lp, d):
         out = LatentVec(torch.empty_like(d.xi), None)
@@ -512,17 +515,16 @@ class FusedKL(Energy):
         m = self.model
         out = LatentVec(torch.empty_like(d.xi), None)
         w = 1.0 / self.n_total
-        for i, lp in enumerate(self.lins):
-            m.lh_metric_accumulate(lp, d, out, w, i == 0)
         nloc = len(self.lins)
+        for i, lp in enumerate(self.lins):
+            # prior term (identity): every rank contributes its share nloc/n_total of d with its first sample,
+            # fused into that sample's VJP epilogue; the sum over ranks is d
+            m.lh_metric_accumulate(lp, d, out, w, i == 0, identity=nloc * w if i == 0 else 0.0)
         if nloc == 0:
             out = LatentVec.zeros(m)
         if self.comm is not None:
-            # prior term: every rank adds its share nloc/n_total of d, the sum over ranks is d
-            out = out.axpy(nloc * w, d)
             self.comm.allreduce_sum_([out.xi, out.small])
-            return out
-        return out.axpy(nloc * w, d)
+        return out
 
     @property
     def metric(self):
