@@ -20,6 +20,7 @@ struct int2 {
 #define NK_ATOMIC_ADD(p, v) (*(p) += (v))
 #define NK_ATOMIC_ADD_XCD(p, v) (*(p) += (v))
 static inline int nk_xcc_id() { return 0; }
+static inline int nk_uniform(int v) { return v; }
 #else
 #include <hip/hip_runtime.h>
 #define NK_HD __host__ __device__ __forceinline__
@@ -29,6 +30,15 @@ static inline int nk_xcc_id() { return 0; }
 #define NK_ATOMIC_ADD_XCD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 __device__ __forceinline__ int nk_xcc_id() {
   return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7);  // HW_REG_XCC_ID
+}
+// value known to be identical in all lanes of a wave: move it to a scalar register (scalar address arithmetic,
+// scalar branches); identity on the host
+__host__ __device__ __forceinline__ int nk_uniform(int v) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_readfirstlane(v);
+#else
+  return v;
+#endif
 }
 #endif
 

@@ -516,60 +516,141 @@ struct FinalGroup {
   int base[NH], mlo[NH];
 };
 
-// emits the images of coefficient k2 (and of NL-k2 when `both`) for all slots of a group
-template <typename T, int NL, int NH, int EC>
-NK_HD void nk_final_emit(const NkFuse& f, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg, int k2, bool both,
-                         double& acc) {
-  constexpr bool VJP = (EC == 2);
-  const int k2m = k2 ? NL - k2 : 0;
+// compile-time specialised epilogue of the final pass (EC 0 affine, 1 multiply, 2 scatter/VJP with materialised
+// amplitude field): per-launch constants hoisted into registers, arithmetic in the field type T (the bin sums of
+// the scatter stay fp64), and -- the point of the exercise -- no per-output run-time switch
+template <typename T>
+struct FinalCt {
+  T* out;
+  const T *mul, *xi, *addend, *af;
+  T sc, off, asc;
+  bool accum;
+};
+template <typename T, int EC>
+NK_HD FinalCt<T> nk_final_ct(const NkFuse& f) {
+  FinalCt<T> c;
+  c.out = (T*)f.out;
+  c.mul = (const T*)f.mul;
+  c.xi = (const T*)f.xi;
+  c.addend = (const T*)f.addend;
+  c.af = (const T*)f.afield;
+  c.sc = (T)(f.scale * (EC == 1 ? f.mul_scalar : 1.0));
+  c.off = (T)f.offset;
+  c.asc = (T)f.addend_scale;
+  c.accum = f.accumulate != 0;
+  return c;
+}
+
+// the (up to) four images of one coefficient of ONE slot: H(k,kl) -> ok+k2, H(-k,-kl) -> om+k2m, and when BOTH
+// (k2m != k2) H(k,-kl) -> ok+k2m, H(-k,kl) -> om+k2.  `self`: the line is its own partner (images 1, 3 coincide
+// with 2, 0).  Returns the fp64 bin-sum contribution for EC 2.
+template <typename T, int EC, bool BOTH>
+NK_HD double nk_final_slot(const FinalCt<T>& c, int64_t ok, int64_t om, bool self, T sg, T fx, T fy, T gx, T gy, int k2,
+                           int k2m, T a) {
+  const T v0 = fx + sg * fy, v1 = fx - sg * fy, v2 = gx + sg * gy, v3 = gx - sg * gy;
+  T* outk = c.out + ok;
+  T* outm = c.out + om;
+  if constexpr (EC == 0) {
+    outk[k2] = v0 * c.sc + c.off;
+    if (BOTH) outk[k2m] = v2 * c.sc + c.off;
+    if (!self) {
+      outm[k2m] = v1 * c.sc + c.off;
+      if (BOTH) outm[k2] = v3 * c.sc + c.off;
+    }
+    return 0.0;
+  } else if constexpr (EC == 1) {
+    if (c.mul) {
+      const T* mk = c.mul + ok;
+      const T* mm = c.mul + om;
+      const T m0 = mk[k2], m2 = BOTH ? mk[k2m] : (T)0;
+      T m1 = (T)0, m3 = (T)0;
+      if (!self) {
+        m1 = mm[k2m];
+        if (BOTH) m3 = mm[k2];
+      }
+      outk[k2] = v0 * c.sc * m0;
+      if (BOTH) outk[k2m] = v2 * c.sc * m2;
+      if (!self) {
+        outm[k2m] = v1 * c.sc * m1;
+        if (BOTH) outm[k2] = v3 * c.sc * m3;
+      }
+    } else {
+      outk[k2] = v0 * c.sc;
+      if (BOTH) outk[k2m] = v2 * c.sc;
+      if (!self) {
+        outm[k2m] = v1 * c.sc;
+        if (BOTH) outm[k2] = v3 * c.sc;
+      }
+    }
+    return 0.0;
+  } else {
+    const T t0 = v0 * c.sc, t1 = v1 * c.sc, t2 = v2 * c.sc, t3 = v3 * c.sc;
+    const T* xk = c.xi + ok;
+    const T* xm = c.xi + om;
+    // all loads first, then the stores (out may alias the addend)
+    const T x0 = xk[k2], x2 = BOTH ? xk[k2m] : (T)0;
+    T x1 = (T)0, x3 = (T)0;
+    if (!self) {
+      x1 = xm[k2m];
+      if (BOTH) x3 = xm[k2];
+    }
+    T r0 = a * t0, r1 = a * t1, r2 = a * t2, r3 = a * t3;
+    if (c.addend) {
+      const T* ak = c.addend + ok;
+      const T* am = c.addend + om;
+      r0 += c.asc * ak[k2];
+      if (BOTH) r2 += c.asc * ak[k2m];
+      if (!self) {
+        r1 += c.asc * am[k2m];
+        if (BOTH) r3 += c.asc * am[k2];
+      }
+    }
+    if (c.accum) {
+      r0 += outk[k2];
+      if (BOTH) r2 += outk[k2m];
+      if (!self) {
+        r1 += outm[k2m];
+        if (BOTH) r3 += outm[k2];
+      }
+    }
+    outk[k2] = r0;
+    if (BOTH) outk[k2m] = r2;
+    double s = (double)x0 * (double)t0;
+    if (BOTH) s += (double)x2 * (double)t2;
+    if (!self) {
+      outm[k2m] = r1;
+      s += (double)x1 * (double)t1;
+      if (BOTH) {
+        outm[k2] = r3;
+        s += (double)x3 * (double)t3;
+      }
+    }
+    return s;
+  }
+}
+
+// all slots of a group for coefficient k2
+template <typename T, int NL, int NH, int EC, bool BOTH>
+NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg,
+                          int k2, int hv, double* w8line) {
+  const int k2m = (NL - k2) & (NL - 1);
   const int d1 = k2 + (k2 >> 5), d2 = k2m + (k2m >> 5);
-  T fx[NH], fy[NH], gx[NH], gy[NH];
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    fx[h] = pre[gp.base[h] + d1], fy[h] = pim[gp.base[h] + d1];
-    gx[h] = pre[gp.base[h] + d2], gy[h] = pim[gp.base[h] + d2];
-  }
-  double ssum = 0.0, a_bin = 0.0;
-  int32_t bin = 0;
-  const bool scatter = VJP || f.epi == NK_EPI_VJP;
-  if (scatter) {
-    int hv = 0;
-#pragma unroll
-    for (int h = NH - 1; h >= 0; --h)
-      if (gp.mlo[h]) hv = h;
-    bin = f.pidx[gp.okh[hv] + k2];
-    a_bin = f.afield ? 0.0 : f.amp[bin];
-  }
+  T a = (T)0;
+  if constexpr (EC == 2) a = c.af[gp.okh[hv] + k2];
+  double ssum = 0.0;
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     if (!gp.mlo[h]) continue;
-    const bool self = gp.mlo[h] == 1;
-    const T v0 = fx[h] + sg * fy[h], v1 = fx[h] - sg * fy[h], v2 = gx[h] + sg * gy[h], v3 = gx[h] - sg * gy[h];
-    const int64_t ok = gp.okh[h], om = gp.omh[h];
-    if (VJP) {
-      ssum += nk_emit_vjp<T, true>(f, ok + k2, v0, a_bin);
-      if (!self) ssum += nk_emit_vjp<T, true>(f, om + k2m, v1, a_bin);
-      if (both) {
-        ssum += nk_emit_vjp<T, true>(f, ok + k2m, v2, a_bin);
-        if (!self) ssum += nk_emit_vjp<T, true>(f, om + k2, v3, a_bin);
-      }
-    } else if (scatter) {
-      ssum += nk_emit_vjp<T, false>(f, ok + k2, v0, a_bin);
-      if (!self) ssum += nk_emit_vjp<T, false>(f, om + k2m, v1, a_bin);
-      if (both) {
-        ssum += nk_emit_vjp<T, false>(f, ok + k2m, v2, a_bin);
-        if (!self) ssum += nk_emit_vjp<T, false>(f, om + k2, v3, a_bin);
-      }
-    } else {
-      nk_emit<T, EC>(f, ok + k2, v0, acc);
-      if (!self) nk_emit<T, EC>(f, om + k2m, v1, acc);
-      if (both) {
-        nk_emit<T, EC>(f, ok + k2m, v2, acc);
-        if (!self) nk_emit<T, EC>(f, om + k2, v3, acc);
-      }
-    }
+    const T fx = pre[gp.base[h] + d1], fy = pim[gp.base[h] + d1];
+    const T gx = pre[gp.base[h] + d2], gy = pim[gp.base[h] + d2];
+    ssum += nk_final_slot<T, EC, BOTH>(c, gp.okh[h], gp.omh[h], gp.mlo[h] == 1, sg, fx, fy, gx, gy, k2, k2m, a);
   }
-  if (scatter) NK_VJP_SCATTER(f, bin, ssum);
+  if constexpr (EC == 2) {
+    if (w8line)
+      w8line[k2] = ssum;
+    else
+      NK_VJP_SCATTER(f, f.pidx[gp.okh[hv] + k2], ssum);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -592,8 +673,11 @@ struct NkPassF {
 
 // EC: compile-time epilogue class (0 affine, 1 multiply, 2 scatter/VJP with materialised amplitude field, -1 generic)
 template <typename T, int NL, int TILE, bool COUPLES, int EC, typename Exec>
-NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f, int64_t blk, T* planes,
+NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t blk, T* planes,
                          const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, double* acc_out) {
+  // the line FFT runs on 2A / 2B (see the load phase): fold the 1/2 into the output scale every epilogue applies first
+  NkFuse f = f_in;
+  f.scale = 0.5 * f_in.scale;
   using SC = SchedF<T, NL>;
   using LY = ContigLayout<NL, SC::P>;
   constexpr int E = SC::E, S = SC::S, P = SC::P, H = NL / 2;
@@ -628,28 +712,32 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f, int64_t bl
   };
 
   ex.phase([&](int tid, PassRegs<T, E>& rg) {
-    const int pp = tid % P, t = tid / P;
+    const int pp = tid % P;
+    int t = tid / P;
+    if constexpr (P % 64 == 0) t = nk_uniform(t);
     int b, bm;
     bool active, self;
     line_of(t, b, bm, active, self);
     const C2<T>* lk = work + ((bat * A + a) * M + b) * (int64_t)H;
     const C2<T>* lm = work + ((bat * A + am) * M + bm) * (int64_t)H;
     constexpr int R = SC::radix(0), Q = E / R;
+    // stage-0 rows of a thread are pp + multiples of P (P even): the parity of the element index is a per-thread
+    // constant.  even: 2A = Zk + conj Zm, odd: 2B = -i (Zk - conj Zm); the factor 1/2 is folded into the output scale
+    const bool odd = pp & 1;
+    if (active) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q)
+      for (int q = 0; q < Q; ++q)
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        C2<T> z{(T)0, (T)0};
-        if (active) {
+        for (int r = 0; r < R; ++r) {
           const int n2 = nk_in_row<SC, 0>(pp, q, r);
           const C2<T> Zk = lk[n2 >> 1], Zm = lm[n2 >> 1];
-          if (n2 & 1)
-            z = C2<T>{(T)0.5 * (Zk.y + Zm.y), (T)0.5 * (Zm.x - Zk.x)};  // B = -i (Zk - conj Zm)/2
-          else
-            z = C2<T>{(T)0.5 * (Zk.x + Zm.x), (T)0.5 * (Zk.y - Zm.y)};  // A = (Zk + conj Zm)/2
+          const T c0 = odd ? Zk.y : Zk.x, c1 = odd ? Zm.y : Zm.x, c2 = odd ? Zm.x : Zk.y, c3 = odd ? Zk.x : Zm.y;
+          rg.v[q * R + r] = C2<T>{c0 + c1, c2 - c3};
         }
-        rg.v[q * R + r] = z;
-      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) rg.v[e] = C2<T>{(T)0, (T)0};
+    }
     nk_stage_compute<T, SC, 0>(rg.v, pp, tw);
 #pragma unroll
     for (int q = 0; q < Q; ++q)
@@ -724,7 +812,9 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f, int64_t bl
     // out of the k_last loop, which then only advances by the group width
     const int nslot = couples ? TILE / 2 : TILE;
     const int tps = NT / nslot;
-    const int u = tid / tps, lane = tid % tps;
+    int u = tid / tps;  // tps is P or 2P: whole waves when P is a multiple of 64
+    if constexpr (P % 64 == 0) u = nk_uniform(u);
+    const int lane = tid - u * tps;
     constexpr int NH = COUPLES ? 2 : 1;
     FinalGroup<NH> gp;  // mlo per slot: 0 inactive, 1 self-paired line, 3 regular pair
     int any = 0;
@@ -747,20 +837,19 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f, int64_t bl
       gp.mlo[h] = active ? (self ? 1 : 3) : 0;
       any |= gp.mlo[h];
     }
-#ifdef NK_FINAL_EMIT_V2
-    if (any) {
-      if (lane == 0) nk_final_emit<T, NL, NH, EC>(f, gp, pre, pim, sg, 0, false, acc);
-      if (lane == 1) nk_final_emit<T, NL, NH, EC>(f, gp, pre, pim, sg, NL / 2, false, acc);
-      // 1 <= k2 < NL/2: every image distinct; two coefficients per trip keep more LDS / global traffic in flight
-      int k2 = 1 + lane;
-      for (; k2 + tps < NL / 2; k2 += 2 * tps) {
-        nk_final_emit<T, NL, NH, EC>(f, gp, pre, pim, sg, k2, true, acc);
-        nk_final_emit<T, NL, NH, EC>(f, gp, pre, pim, sg, k2 + tps, true, acc);
+    if constexpr (EC >= 0) {
+      if (any) {
+        const FinalCt<T> c = nk_final_ct<T, EC>(f);
+        int hv = 0;
+#pragma unroll
+        for (int h = NH - 1; h >= 0; --h)
+          if (gp.mlo[h]) hv = h;
+        // k_last = 0 and NL/2 are their own mirrors; everything in between has four distinct images per slot
+        if (lane < 2) nk_final_coeff<T, NL, NH, EC, false>(f, c, gp, pre, pim, sg, lane ? NL / 2 : 0, hv, w8line);
+        for (int k2 = 1 + lane; k2 < NL / 2; k2 += tps)
+          nk_final_coeff<T, NL, NH, EC, true>(f, c, gp, pre, pim, sg, k2, hv, w8line);
       }
-      if (k2 < NL / 2) nk_final_emit<T, NL, NH, EC>(f, gp, pre, pim, sg, k2, true, acc);
-    }
-#else
-    if (any) {
+    } else if (any) {
       const bool vjp = f.epi == NK_EPI_VJP;
       for (int k2 = lane; k2 < NK; k2 += tps) {
         const int k2m = k2 ? NL - k2 : 0;
@@ -814,7 +903,6 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f, int64_t bl
         nk_epilogue_multi<T, 4 * NH>(f, o, v, mask, acc);
       }
     }
-#endif
     *acc_out += acc;
   });
 }
