@@ -89,6 +89,11 @@ typedef struct nk_fuse {
   double* w8;           /* VJP, optional: instead of atomics store the per-octant-point sums xi*t (all sign-flip images
                            merged) to w8[batch][A/2+1][M/2+1][NL/2+1]; reduce with nk_octant_scatter.  Only honoured
                            when nk_plan_octant_vjp(plan) != 0 */
+  int field_octant;     /* != 0: afield / dafield are OCTANT arrays [A/2+1][M/2+1][NL/2+1] (nk_octant_expand with
+                           compact != 0), broadcast over the batch: the sign-flip images of a coefficient share the
+                           value, so the prologue of the first pass and the VJP epilogue read 1/8 of the bytes.  Only
+                           valid when nk_plan_octant_vjp(plan) != 0 and with prologue PLAIN / MUL / AMP(afield) /
+                           AMP_JVP(afield + dafield) and, for the VJP epilogue, afield set (NK_ERR_INVALID otherwise) */
 } nk_fuse;
 
 typedef struct nk_plan nk_plan;
@@ -151,13 +156,14 @@ int nk_fold_copies(int64_t n, int copies, int64_t stride, const double* src, dou
  *      expanded / reduced on the octant k_i <= n_i/2 only (1/8 of the gathers / atomics in 3-D).
  *      shape = the `ndim` (1..3) grid axes; fields are [shape...] C order.
  * nk_octant_expand : field[x] = table[pidx[x]] for every grid point, one table gather per octant point
- *                    (PowerDistributor TIMES, distributors.py:114-119)
+ *                    (PowerDistributor TIMES, distributors.py:114-119); compact != 0: only the octant array
+ *                    field8[A/2+1][M/2+1][NL/2+1] is written (see nk_fuse.field_octant)
  * nk_octant_scatter: abar[pidx[x]] += w8[x] over the octant array w8[A/2+1][M/2+1][NL/2+1] written by the VJP
  *                    epilogue; merge_swapped_lines != 0 (only valid when the first two axes have equal length AND
  *                    equal harmonic distances) folds the lines (a,b) and (b,a) before the atomics
  *                    (PowerDistributor ADJOINT_TIMES, distributors.py:106-112) */
 int nk_octant_expand(int ndim, const int64_t* shape, const void* table, const int32_t* pidx, void* field, int dtype,
-                     void* stream);
+                     int compact, void* stream);
 int nk_octant_scatter(int ndim, const int64_t* shape, const double* w8, const int32_t* pidx, double* abar,
                       int merge_swapped_lines, void* stream);
 /* 1 if nk_hartley_fused on this plan honours nk_fuse.w8 (the register-resident pipeline is active) */

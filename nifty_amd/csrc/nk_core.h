@@ -291,6 +291,38 @@ NK_HD C2<T> nk_prologue_ct(const NkFuse& f, int64_t i) {
   }
 }
 
+// octant-shaped fields (nk_fuse.field_octant): fold a grid coordinate onto k <= n/2
+NK_HD int nk_fold(int x, int n) { return 2 * x <= n ? x : n - x; }
+
+// two adjacent elements of an octant row (only element-aligned): one 2*sizeof(T) load
+template <typename T>
+struct __attribute__((packed, aligned(sizeof(T)))) NkPairU {
+  T x, y;
+};
+template <typename T>
+NK_HD C2<T> nk_load_pair_u(const T* p) {
+  const NkPairU<T> v = *reinterpret_cast<const NkPairU<T>*>(p);
+  return C2<T>{v.x, v.y};
+}
+
+// pair prologues with OCTANT amplitude fields: j = octant offset of the lower of the two folded positions of the
+// adjacent reals (i, i+1); desc: the pair is stored in descending order (mirrored half of the last axis)
+//   PC = 4: afield8 * in,  5: afield8 * in + dafield8 * in2
+template <typename T, int PC>
+NK_HD C2<T> nk_prologue_oct(const NkFuse& f, int64_t i, uint32_t j, bool desc) {
+  const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + i);
+  C2<T> m = nk_load_pair_u<T>((const T*)f.afield + j);
+  if (desc) m = C2<T>{m.y, m.x};
+  if constexpr (PC == 4) {
+    return C2<T>{m.x * a.x, m.y * a.y};
+  } else {
+    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + i);
+    C2<T> dm = nk_load_pair_u<T>((const T*)f.dafield + j);
+    if (desc) dm = C2<T>{dm.y, dm.x};
+    return C2<T>{m.x * a.x + dm.x * x.x, m.y * a.y + dm.y * x.y};
+  }
+}
+
 NK_HD void nk_nonlin(int kind, double s, double& g, double& gp) {
   if (kind == NK_NL_EXP) {
     g = gp = exp(s);

@@ -233,7 +233,7 @@ static int nk_launch_final_c(NkPassF pf, const NkFuse& f, const C2<T>* tw, const
 template <typename T, int NL>
 static int nk_launch_final(const NkPassF& pf, const NkFuse& f, const C2<T>* tw, const C2<T>* work, hipStream_t st) {
   static const int generic = nk_env_int("NK_EC_GENERIC", 0);
-  if (generic) {
+  if (generic && !f.field_octant) {
     if (f.epi == NK_EPI_VJP) return nk_launch_final_c<T, NL, true, -1>(pf, f, tw, work, st);
     return nk_launch_final_c<T, NL, false, -1>(pf, f, tw, work, st);
   }
@@ -307,6 +307,8 @@ static int nk_dispatch_contig(int h, const NkPassA& pa, const NkFuse& f, const C
 template <typename T, int N, int MODE>
 static int nk_launch_strided(const NkPassS& ps, const NkFuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch, hipStream_t st) {
   if constexpr (MODE == 3) {
+    if (f.field_octant && f.pro == NK_PRO_AMP) return nk_launch_strided_pc<T, N, MODE, 4>(ps, f, tw, work, scratch, st);
+    if (f.field_octant && f.pro == NK_PRO_AMP_JVP) return nk_launch_strided_pc<T, N, MODE, 5>(ps, f, tw, work, scratch, st);
     if (f.pro == NK_PRO_PLAIN) return nk_launch_strided_pc<T, N, MODE, 0>(ps, f, tw, work, scratch, st);
     if (f.pro == NK_PRO_AMP && f.afield) return nk_launch_strided_pc<T, N, MODE, 1>(ps, f, tw, work, scratch, st);
     if (f.pro == NK_PRO_AMP_JVP && f.afield && f.dafield)
@@ -675,6 +677,17 @@ extern "C" int nk_hartley_fused(const nk_plan* P, const nk_fuse* fuse, int conve
     return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: VJP epilogue needs pidx, amp, xi and abar");
   if (fuse->epi == NK_EPI_LIKELIHOOD && (!fuse->data || !fuse->value))
     return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: LIKELIHOOD epilogue needs data and value");
+  if (fuse->field_octant) {
+    if (!nk_plan_uses_pipeline2(P))
+      return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: field_octant needs nk_plan_octant_vjp(plan) != 0");
+    const bool amp_pro = fuse->pro == NK_PRO_AMP || fuse->pro == NK_PRO_AMP_JVP;
+    if ((amp_pro && !fuse->afield) || (fuse->pro == NK_PRO_AMP_JVP && !fuse->dafield) ||
+        (fuse->epi == NK_EPI_VJP && !fuse->afield))
+      return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: field_octant needs afield (and dafield for AMP_JVP)");
+    const NkGeom& g = P->hp.g;
+    if ((int64_t)(g.na / 2 + 1) * (g.nm / 2 + 1) * (g.nl / 2 + 1) >= ((int64_t)1 << 31))
+      return nk_set_error(NK_ERR_UNSUPPORTED, "nk_hartley_fused: octant field too large (>= 2^31 elements)");
+  }
   hipStream_t st = (hipStream_t)stream;
   if (P->hp.dtype == NK_F32) return nk_run_hartley<float>(P, *fuse, convention, workspace, st);
   return nk_run_hartley<double>(P, *fuse, convention, workspace, st);

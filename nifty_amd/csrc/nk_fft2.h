@@ -302,6 +302,26 @@ NK_HD void nk_xread_cols(T* dst, const T* plane, int pp, int t) {
     for (int r = 0; r < R; ++r) dst[q * R + r] = plane[nk_xrow<TILE, L0>(nk_in_row<SC, S>(pp, q, r), t)];
 }
 
+// XCD-aware block order of the first pass with OCTANT amplitude fields (3-D): the slabs a and A-a and, inside a
+// slab, the tiles c and NL-c read the same octant lines.  Workgroups are dealt round-robin to the 8 XCDs
+// (blockIdx % 8), each XCD keeps 2 * 32 of them in flight -- so every XCD is handed whole slab PAIRS (a, A-a),
+// all their tiles back to back: the octant lines are fetched from HBM once and re-used out of that XCD's L2.
+// A bijection of [0, nblocks); placement only matters for speed.
+NK_HD int64_t nk_oct_block_remap(int64_t v, const NkPassS& p) {
+  const int na = p.g.na, tiles = p.tiles_per_slab;
+  if (p.g.ndim != 3 || (na / 2) % 8 != 0) return v;
+  const int64_t per = (int64_t)na * tiles;
+  const int64_t bat = v / per;
+  v -= bat * per;
+  const int x = (int)(v % 8);
+  const int64_t s = v / 8;
+  const int64_t g = (s / (2 * tiles)) * 8 + x;  // slab pair handled by XCD x
+  const int within = (int)(s % (2 * tiles));
+  const int64_t idx = 2 * g + within / tiles;   // slab sequence 0, A/2, 1, A-1, 2, A-2, ...
+  const int64_t slab = idx == 0 ? 0 : idx == 1 ? na / 2 : ((idx & 1) ? na - idx / 2 : idx / 2);
+  return bat * per + slab * tiles + within % tiles;
+}
+
 // ---------------------------------------------------------------------------------------------
 // strided pass body (pass B: in place c2c; pass C: c2c + Hartley combine + epilogue)
 // thread id -> column t = tid % TILE, line thread pp = tid / TILE;  blockDim = P * TILE
@@ -316,6 +336,7 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
                            double* acc_out) {
   using SC = Sched<T, N>;
   constexpr int E = SC::E, S = SC::S;
+  if constexpr (MODE == 3 && (PC == 4 || PC == 5)) blk = nk_oct_block_remap(blk, p);
   const int64_t o = blk / p.tiles_per_slab;
   const int64_t c0 = (blk % p.tiles_per_slab) * (int64_t)TILE;
   C2<T>* base = work + o * N * p.inner + c0;
@@ -323,12 +344,29 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
   ex.phase([&](int tid, PassRegs<T, E>& rg) {
     const int t = tid % TILE, pp = tid / TILE;
     constexpr int R = SC::radix(0), Q = E / R;
+    constexpr bool OCT = MODE == 3 && (PC == 4 || PC == 5);
+    // octant amplitude fields [A/2+1][N/2+1][nl/2+1] (this axis is the middle one; A = 1 in 2-D): the two reals of
+    // a pair sit at folded last-axis offsets c8a, c8b of the folded row
+    [[maybe_unused]] uint32_t o8 = 0, ch = 0, c8 = 0;
+    [[maybe_unused]] bool desc = false;
+    if constexpr (OCT) {
+      const int nl = p.g.nl, c = 2 * (int)(c0 + t);
+      ch = nl / 2 + 1;
+      desc = 2 * c >= nl;  // (c, c+1) -> (nl-c, nl-c-1): stored descending, lower position nl-c-1
+      c8 = desc ? nl - c - 1 : c;
+      o8 = p.g.ndim == 3 ? (uint32_t)nk_fold((int)(o % p.g.na), p.g.na) * (N / 2 + 1) : 0u;
+    }
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const int64_t off = (int64_t)nk_in_row<SC, 0>(pp, q, r) * p.inner + t;
-        if (MODE == 3) {
+        const int row = nk_in_row<SC, 0>(pp, q, r);
+        const int64_t off = (int64_t)row * p.inner + t;
+        if constexpr (OCT) {
+          const int64_t i = 2 * ((base - work) + off);
+          const uint32_t j8 = (o8 + (uint32_t)nk_fold(row, N)) * ch + c8;  // octant arrays hold < 2^31 elements
+          rg.v[q * R + r] = nk_prologue_oct<T, PC>(f, i, j8, desc);
+        } else if (MODE == 3) {
           const int64_t i = 2 * ((base - work) + off);
           rg.v[q * R + r] = nk_prologue_ct<T, PC>(f, i);
         } else {
@@ -632,11 +670,11 @@ NK_HD double nk_final_slot(const FinalCt<T>& c, int64_t ok, int64_t om, bool sel
 // all slots of a group for coefficient k2
 template <typename T, int NL, int NH, int EC, bool BOTH>
 NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg,
-                          int k2, int hv, double* w8line) {
+                          int k2, int hv, const T* afline, double* w8line) {
   const int k2m = (NL - k2) & (NL - 1);
   const int d1 = k2 + (k2 >> 5), d2 = k2m + (k2m >> 5);
   T a = (T)0;
-  if constexpr (EC == 2) a = c.af[gp.okh[hv] + k2];
+  if constexpr (EC == 2) a = afline[k2];
   double ssum = 0.0;
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
@@ -820,10 +858,9 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
     int any = 0;
     // octant slot of this group for the optional w8 output (VJP): [batch][a][b0][k_last]
     double* w8line = nullptr;
-    if (f.w8 && f.epi == NK_EPI_VJP) {
-      const int b0 = couples ? bt0 * (TILE / 2) + u : bt0 * TILE + u;
-      w8line = f.w8 + ((bat * (A / 2 + 1) + a) * (int64_t)(M / 2 + 1) + b0) * (NL / 2 + 1);
-    }
+    const int b0g = couples ? bt0 * (TILE / 2) + u : bt0 * TILE + u;
+    if (f.w8 && f.epi == NK_EPI_VJP)
+      w8line = f.w8 + ((bat * (A / 2 + 1) + a) * (int64_t)(M / 2 + 1) + b0g) * (NL / 2 + 1);
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int t = couples ? 2 * u + h : u;
@@ -844,10 +881,14 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
 #pragma unroll
         for (int h = NH - 1; h >= 0; --h)
           if (gp.mlo[h]) hv = h;
+        // amplitude value of the group's coefficients: a full field line, or (field_octant) the octant line (a, b0)
+        const T* afline = nullptr;
+        if constexpr (EC == 2)
+          afline = f.field_octant ? c.af + ((int64_t)a * (M / 2 + 1) + b0g) * (NL / 2 + 1) : c.af + gp.okh[hv];
         // k_last = 0 and NL/2 are their own mirrors; everything in between has four distinct images per slot
-        if (lane < 2) nk_final_coeff<T, NL, NH, EC, false>(f, c, gp, pre, pim, sg, lane ? NL / 2 : 0, hv, w8line);
+        if (lane < 2) nk_final_coeff<T, NL, NH, EC, false>(f, c, gp, pre, pim, sg, lane ? NL / 2 : 0, hv, afline, w8line);
         for (int k2 = 1 + lane; k2 < NL / 2; k2 += tps)
-          nk_final_coeff<T, NL, NH, EC, true>(f, c, gp, pre, pim, sg, k2, hv, w8line);
+          nk_final_coeff<T, NL, NH, EC, true>(f, c, gp, pre, pim, sg, k2, hv, afline, w8line);
       }
     } else if (any) {
       const bool vjp = f.epi == NK_EPI_VJP;

@@ -531,8 +531,14 @@ static int nk_make_oct(int ndim, const int64_t* shape, NkOct& o) {
 
 // one workgroup per octant line (a, b); lanes run over c = k_last
 template <typename T>
-__global__ void k_octant_expand(NkOct o, const T* __restrict__ table, const int32_t* __restrict__ pidx, T* __restrict__ field) {
+__global__ void k_octant_expand(NkOct o, int compact, const T* __restrict__ table, const int32_t* __restrict__ pidx,
+                                T* __restrict__ field) {
   const int b = blockIdx.x % o.Mh, a = blockIdx.x / o.Mh;
+  if (compact) {  // octant array only: field8[a][b][c]
+    const int64_t src = ((int64_t)a * o.M + b) * o.NL, dst = ((int64_t)a * o.Mh + b) * o.Ch;
+    for (int c = threadIdx.x; c < o.Ch; c += blockDim.x) field[dst + c] = table[pidx[src + c]];
+    return;
+  }
   const int am = a ? o.A - a : 0, bm = b ? o.M - b : 0;
   const int64_t r00 = ((int64_t)a * o.M + b) * o.NL, r01 = ((int64_t)a * o.M + bm) * o.NL;
   const int64_t r10 = ((int64_t)am * o.M + b) * o.NL, r11 = ((int64_t)am * o.M + bm) * o.NL;
@@ -566,7 +572,7 @@ __global__ void k_octant_scatter(NkOct o, int swap_merge, const double* __restri
 }
 
 extern "C" int nk_octant_expand(int ndim, const int64_t* shape, const void* table, const int32_t* pidx, void* field,
-                                int dtype, void* stream) {
+                                int dtype, int compact, void* stream) {
   NkOct o;
   int rc = nk_make_oct(ndim, shape, o);
   if (rc != NK_OK) return rc;
@@ -574,7 +580,8 @@ extern "C" int nk_octant_expand(int ndim, const int64_t* shape, const void* tabl
   const int64_t blocks = (int64_t)o.Ah * o.Mh;
   const int threads = o.Ch >= 256 ? 256 : 64;
   NK_DISPATCH_DTYPE(dtype, {
-    hipLaunchKernelGGL(k_octant_expand<T>, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, o, (const T*)table,
+    hipLaunchKernelGGL(k_octant_expand<T>, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, o, compact,
+                       (const T*)table,
                        pidx, (T*)field);
   })
   return nk_check_launch("k_octant_expand");

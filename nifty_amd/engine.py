@@ -230,10 +230,12 @@ class FusedModel:
             self.damp = torch.empty(nb, dtype=torch.float64, device=self.device)
             self.latbar = torch.empty(self.nsmall, dtype=torch.float64, device=self.device)
             self.tmp = torch.empty(self.shape, dtype=dtype, device=self.device)
-            self.dafield = torch.empty(self.shape, dtype=dtype, device=self.device)
-            # octant array for the VJP scatter (sign-flip images merged in the final transform pass)
+            # octant arrays: the VJP scatter sums (sign-flip images merged in the final transform pass) and the
+            # amplitude fields a[pindex], da[pindex] (identical on all sign-flip images: 1/8 of the bytes)
             self.octant_vjp = bool(L.load().nk_plan_octant_vjp(self.plan.handle))
             oct_n = int(np.prod([n // 2 + 1 for n in self.shape]))
+            self.field_shape = (oct_n,) if self.octant_vjp else self.shape
+            self.dafield = torch.empty(self.field_shape, dtype=dtype, device=self.device)
             self.w8 = torch.empty(oct_n, dtype=torch.float64, device=self.device) if self.octant_vjp else None
             self.merge_swapped = int(len(self.shape) == 3 and self.shape[0] == self.shape[1]
                                      and hsp.distances[0] == hsp.distances[1])
@@ -278,10 +280,10 @@ class FusedModel:
         """table[pindex] materialised in the field dtype with one gather per OCTANT point (|k| bins are invariant
         under the sign flip of every axis): every later prologue / epilogue streams the field instead of gathering."""
         table = amp if self.tdtype == torch.float64 else amp.to(self.tdtype)
-        out = torch.empty(self.shape, dtype=self.tdtype, device=self.device) if out is None else out
+        out = torch.empty(self.field_shape, dtype=self.tdtype, device=self.device) if out is None else out
         shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
         L.check(L.load().nk_octant_expand(len(self.shape), shp, table.data_ptr(), self.pidx.data_ptr(), out.data_ptr(),
-                                          B.dtype_code(out), B._stream()), "nk_octant_expand")
+                                          B.dtype_code(out), 1 if self.octant_vjp else 0, B._stream()), "nk_octant_expand")
         return out
 
     def _fuse(self):
@@ -289,6 +291,7 @@ class FusedModel:
         f.scale = self.h_dvol
         f.mul_scalar = 1.0
         f.addend_scale = 1.0
+        f.field_octant = 1 if self.octant_vjp else 0
         return f
 
     def signal(self, x, want_derivative=False):
@@ -296,6 +299,8 @@ class FusedModel:
         amp, _ = self._amp_forward(x.small)
         f = self._fuse()
         f.pro, f.in_, f.pidx, f.amp = L.PRO_AMP, x.xi.data_ptr(), self.pidx.data_ptr(), amp.data_ptr()
+        afield = self._amp_field(amp)
+        f.afield = afield.data_ptr()
         out = torch.empty(self.shape, dtype=self.tdtype, device=self.device)
         d = torch.empty_like(out) if want_derivative else None
         f.epi, f.out, f.out2, f.offset, f.nonlin = L.EPI_NONLIN, out.data_ptr(), B.ptr(d), self.offset_mean, self.nonlin

@@ -120,6 +120,40 @@ def test_fused_prologue_epilogue_emulation(shape, fn):
     run(f, shape, np.float64, fn=fn)
     assert np.max(np.abs(out4 - amp[pidx] * t)) < 1e-11 * np.max(np.abs(t))
     assert np.max(np.abs(priv.reshape(8, 32).sum(0)[:nb] - ref_abar)) < 1e-10 * max(1.0, np.max(np.abs(ref_abar)))
+    if fn != "emu3_hartley_fused":
+        return
+    # OCTANT-shaped amplitude fields (nk_fuse.field_octant) + octant sums w8: strided-first pipeline only
+    oct_sl = tuple(slice(0, s // 2 + 1) for s in shape)
+    af8, daf8 = np.ascontiguousarray(amp[pidx][oct_sl]), np.ascontiguousarray(damp[pidx][oct_sl])
+    out5 = np.empty(shape)
+    f = Fuse()
+    f.pro, f.in_, f.in2, f.pidx, f.amp, f.damp = 2, dxi.ctypes.data, xi.ctypes.data, pidx.ctypes.data, amp.ctypes.data, damp.ctypes.data
+    f.afield, f.dafield, f.field_octant = af8.ctypes.data, daf8.ctypes.data, 1
+    f.epi, f.out, f.scale, f.offset = 0, out5.ctypes.data, 0.5, 1.25
+    run(f, shape, np.float64, fn=fn)
+    assert np.max(np.abs(out5 - ref)) < 1e-11 * np.max(np.abs(ref))
+    out6 = np.empty(shape)
+    f = Fuse()
+    f.pro, f.in_, f.pidx, f.amp = 1, xi.ctypes.data, pidx.ctypes.data, amp.ctypes.data
+    f.afield, f.field_octant = af8.ctypes.data, 1
+    f.epi, f.out, f.scale, f.offset = 0, out6.ctypes.data, 1.0, 0.0
+    run(f, shape, np.float64, fn=fn)
+    ref6 = H(amp[pidx] * xi)
+    assert np.max(np.abs(out6 - ref6)) < 1e-11 * np.max(np.abs(ref6))
+    w8 = np.full(af8.shape, np.nan)
+    out7 = np.full(shape, 3.0)
+    dummy = np.zeros(nb)
+    f = Fuse()
+    f.pro, f.in_ = 0, w.ctypes.data
+    f.epi, f.out, f.scale = 2, out7.ctypes.data, 0.25
+    f.pidx, f.amp, f.xi, f.abar = pidx.ctypes.data, amp.ctypes.data, xi.ctypes.data, dummy.ctypes.data
+    f.afield, f.field_octant, f.w8 = af8.ctypes.data, 1, w8.ctypes.data
+    f.addend, f.addend_scale, f.accumulate = addend.ctypes.data, 2.0, 1
+    run(f, shape, np.float64, fn=fn)
+    assert np.max(np.abs(out7 - (amp[pidx] * t + 2.0 * addend + 3.0))) < 1e-11 * np.max(np.abs(t))
+    got = np.bincount(pidx[oct_sl].ravel(), weights=w8.ravel(), minlength=nb)
+    assert np.max(np.abs(got - ref_abar)) < 1e-10 * max(1.0, np.max(np.abs(ref_abar)))
+    assert np.all(dummy == 0.0)
 
 
 @pytest.mark.parametrize("shape,fn", [((8, 16), "emu_hartley_fused"), ((64, 64), "emu3_hartley_fused"),

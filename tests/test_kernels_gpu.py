@@ -67,3 +67,39 @@ def test_unsupported_shapes_raise():
         B.hartley(torch.zeros(12, device="cuda", dtype=torch.float64))
     with pytest.raises(RuntimeError):
         B.hartley(torch.zeros(16, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("shape", [(64,), (32, 64), (64, 64, 64), (128, 64, 256)])
+def test_octant_expand_and_scatter(shape):
+    """nk_octant_expand (full and compact) = PowerDistributor TIMES, nk_octant_scatter = its adjoint on the octant sums
+    (distributors.py:106-127), on a real PowerSpace pindex."""
+    import ctypes
+
+    import nifty_amd as ift
+    from nifty_amd import _lib as L
+    from nifty_amd import backend as B
+
+    hsp = ift.RGSpace(shape).get_default_codomain()
+    ps = ift.PowerSpace(hsp)
+    pidx = np.array(ps.pindex).astype(np.int32)
+    nb = ps.shape[0]
+    rng = np.random.default_rng(5)
+    table = rng.normal(size=nb)
+    pd, td = torch.from_numpy(pidx).cuda(), torch.from_numpy(table).cuda()
+    shp = (ctypes.c_int64 * len(shape))(*shape)
+    lib = L.load()
+    full = torch.empty(shape, dtype=torch.float64, device="cuda")
+    L.check(lib.nk_octant_expand(len(shape), shp, td.data_ptr(), pd.data_ptr(), full.data_ptr(), L.NK_F64, 0, B._stream()), "x")
+    assert np.array_equal(full.cpu().numpy(), table[pidx])
+    osl = tuple(slice(0, n // 2 + 1) for n in shape)
+    oshape = tuple(n // 2 + 1 for n in shape)
+    comp = torch.empty(oshape, dtype=torch.float64, device="cuda")
+    L.check(lib.nk_octant_expand(len(shape), shp, td.data_ptr(), pd.data_ptr(), comp.data_ptr(), L.NK_F64, 1, B._stream()), "x")
+    assert np.array_equal(comp.cpu().numpy(), table[pidx][osl])
+    w8 = rng.normal(size=oshape)
+    abar = torch.zeros(nb, dtype=torch.float64, device="cuda")
+    merge = int(len(shape) == 3 and shape[0] == shape[1])
+    L.check(lib.nk_octant_scatter(len(shape), shp, torch.from_numpy(w8).cuda().data_ptr(), pd.data_ptr(), abar.data_ptr(),
+                                  merge, B._stream()), "x")
+    ref = np.bincount(pidx[osl].ravel(), weights=w8.ravel(), minlength=nb)
+    assert np.max(np.abs(abar.cpu().numpy() - ref)) < 1e-12 * max(1.0, np.max(np.abs(ref)))
