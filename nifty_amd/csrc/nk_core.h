@@ -265,29 +265,30 @@ NK_HD C2<T> nk_prologue_pair(const NkFuse& f, int64_t i) {
 
 // compile-time specialised pair prologues of the hot configurations (no run-time switch in the load loop):
 //   PC = 0 plain, 1 afield*in, 2 afield*in + dampT[pidx]*in2, 3 afield*in + dafield*in2, else generic run-time version
+// iu: wave-uniform part of the flat index (scalar registers), it: per-thread part (32 bit)
 template <typename T, int PC>
-NK_HD C2<T> nk_prologue_ct(const NkFuse& f, int64_t i) {
+NK_HD C2<T> nk_prologue_ct(const NkFuse& f, int64_t iu, uint32_t it) {
   if constexpr (PC == 0) {
-    return *reinterpret_cast<const C2<T>*>((const T*)f.in + i);
+    return *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
   } else if constexpr (PC == 1) {
-    const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + i);
-    const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + i);
+    const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
+    const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + iu + it);
     return C2<T>{m.x * a.x, m.y * a.y};
   } else if constexpr (PC == 2) {
-    const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + i);
-    const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + i);
-    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + i);
-    const int2 p = *reinterpret_cast<const int2*>(f.pidx + i);
+    const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
+    const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + iu + it);
+    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
+    const int2 p = *reinterpret_cast<const int2*>(f.pidx + iu + it);
     const T* dt = (const T*)f.dampT;
     return C2<T>{m.x * a.x + dt[p.x] * x.x, m.y * a.y + dt[p.y] * x.y};
   } else if constexpr (PC == 3) {
-    const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + i);
-    const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + i);
-    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + i);
-    const C2<T> dm = *reinterpret_cast<const C2<T>*>((const T*)f.dafield + i);
+    const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
+    const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + iu + it);
+    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
+    const C2<T> dm = *reinterpret_cast<const C2<T>*>((const T*)f.dafield + iu + it);
     return C2<T>{m.x * a.x + dm.x * x.x, m.y * a.y + dm.y * x.y};
   } else {
-    return C2<T>{nk_prologue<T>(f, i), nk_prologue<T>(f, i + 1)};
+    return C2<T>{nk_prologue<T>(f, iu + it), nk_prologue<T>(f, iu + it + 1)};
   }
 }
 
@@ -309,14 +310,14 @@ NK_HD C2<T> nk_load_pair_u(const T* p) {
 // adjacent reals (i, i+1); desc: the pair is stored in descending order (mirrored half of the last axis)
 //   PC = 4: afield8 * in,  5: afield8 * in + dafield8 * in2
 template <typename T, int PC>
-NK_HD C2<T> nk_prologue_oct(const NkFuse& f, int64_t i, uint32_t j, bool desc) {
-  const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + i);
+NK_HD C2<T> nk_prologue_oct(const NkFuse& f, int64_t iu, uint32_t it, uint32_t j, bool desc) {
+  const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
   C2<T> m = nk_load_pair_u<T>((const T*)f.afield + j);
   if (desc) m = C2<T>{m.y, m.x};
   if constexpr (PC == 4) {
     return C2<T>{m.x * a.x, m.y * a.y};
   } else {
-    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + i);
+    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
     C2<T> dm = nk_load_pair_u<T>((const T*)f.dafield + j);
     if (desc) dm = C2<T>{dm.y, dm.x};
     return C2<T>{m.x * a.x + dm.x * x.x, m.y * a.y + dm.y * x.y};

@@ -192,8 +192,20 @@ __global__ void __launch_bounds__((ContigTile<T, H>::THREADS))
   if (IS_1D) nk_flush_energy(f, acc, smem);
 }
 
+// first pass (MODE 3): two workgroups per CU (<= 128 VGPRs at 512 threads); the in-place pass keeps the whole
+// register file for its loads in flight
+#ifndef NK_S0_WAVES
+#define NK_S0_WAVES 1
+#endif
+#ifndef NK_S1_TWO_WG
+#define NK_S1_TWO_WG 0
+#endif
 template <typename T, int N, int MODE, int PC>
-__global__ void __launch_bounds__((StridedTile<T, N>::THREADS))
+__global__ void __launch_bounds__((StridedTile<T, N>::THREADS),
+                                  (MODE == 3 && NK_S1_TWO_WG && StridedTile<T, N>::LDS_BYTES <= 80 * 1024 &&
+                                           StridedTile<T, N>::THREADS <= 512
+                                       ? 2 * StridedTile<T, N>::THREADS / 256
+                                       : NK_S0_WAVES))
     k2_strided(NkPassS p, NkFuse f, const C2<T>* __restrict__ tw, C2<T>* __restrict__ work, C2<T>* __restrict__ scratch) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, Sched<T, N>::E> ex;
@@ -597,24 +609,32 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
   static const int pipeline = nk_env_int("NK_PIPELINE", 2);
   if (fast && pipeline == 2 && nk_fast_size(hp.g.nl) && nk_fast_strided_ok<T>(hp.g.na, hp.pc.inner) &&
       (hp.g.ndim == 2 || nk_fast_strided_ok<T>(hp.g.nm, hp.pb.inner))) {
+    // 3-D work array: natural [batch][first] slabs whose stride is padded by NK_WORK_PAD elements -- the in-place pass
+    // over the first axis otherwise walks an exact power-of-two stride (nm*nl/2 elements: HBM channel aliasing,
+    // 2.9 -> 2.05 ms at 1024^3 fp32).  NK_WORK_BLO=1 selects the transposed slab order [batch][mid][first][last/2]
+    // instead (second pass at stride nl/2, first-pass stores at the big stride): measured slower in total.
+    static const int work_blo = nk_env_int("NK_WORK_BLO", 0), work_pad = nk_env_int("NK_WORK_PAD", 2080);
+    NkPipe2 q = nk_pipe2_setup(hp, pa.g.sign, work_blo, work_pad);
+    // per-thread address parts are 32-bit: (threads per line) * (row stride) must stay below 2^31 elements
+    {
+      const int64_t smax = q.s1.ss > q.s0.inner ? q.s1.ss : q.s0.inner;
+      if (128 * (smax > q.s1.inner ? smax : q.s1.inner) >= ((int64_t)1 << 31))
+        return nk_set_error(NK_ERR_UNSUPPORTED, "transform too large for the 32-bit thread offsets of the strided passes");
+    }
     if (hp.g.ndim == 3) {
       {
         ProfScope ps(st, 1, f.pro, f.epi);
-        rc = nk_dispatch_strided<T, 3>(hp.g.nm, hp.pb, f, (const C2<T>*)P->d_tw_b, work, scratch, st);
+        rc = nk_dispatch_strided<T, 3>(hp.g.nm, q.s1, f, (const C2<T>*)P->d_tw_b, work, scratch, st);
       }
       if (rc != NK_OK) return rc;
       ProfScope ps(st, 2, f.pro, f.epi);
-      rc = nk_dispatch_strided<T, 0>(hp.g.na, hp.pc, f, (const C2<T>*)P->d_tw_c, work, scratch, st);
+      rc = nk_dispatch_strided<T, 0>(hp.g.na, q.s0, f, (const C2<T>*)P->d_tw_c, work, scratch, st);
     } else {
       ProfScope ps(st, 1, f.pro, f.epi);
-      rc = nk_dispatch_strided<T, 3>(hp.g.na, hp.pc, f, (const C2<T>*)P->d_tw_c, work, scratch, st);
+      rc = nk_dispatch_strided<T, 3>(hp.g.na, q.s1, f, (const C2<T>*)P->d_tw_c, work, scratch, st);
     }
     if (rc != NK_OK) return rc;
-    NkPassF pf{};
-    pf.g = hp.g;
-    pf.g.sign = pa.g.sign;
-    pf.A = hp.g.ndim == 3 ? hp.g.na : 1;
-    pf.M = hp.g.ndim == 3 ? hp.g.nm : hp.g.na;
+    const NkPassF& pf = q.pf;
     ProfScope ps(st, 3, f.pro, f.epi);
     static const int skip_final = nk_env_int("NK_SKIP_FINAL", 0);  // debugging aid
     if (skip_final) return NK_OK;

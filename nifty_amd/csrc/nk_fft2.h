@@ -339,7 +339,24 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
   if constexpr (MODE == 3 && (PC == 4 || PC == 5)) blk = nk_oct_block_remap(blk, p);
   const int64_t o = blk / p.tiles_per_slab;
   const int64_t c0 = (blk % p.tiles_per_slab) * (int64_t)TILE;
-  C2<T>* base = work + o * N * p.inner + c0;
+  // MODE 3 reads the user array: line element j of column c0 at (o*N + j)*inner, and writes the work array.
+  // MODE 0 runs in place on the work array.  Work layouts of the strided-first pipeline (3-D; p.ss = slab stride):
+  //   blo == 0 : [batch][first] slabs of ss >= mid*last/2 elements, natural order inside
+  //   blo == 1 : [batch][mid] slabs of ss >= first*last/2 elements, each [first][last/2]
+  // (2-D, or ss == 0: plain natural layout)
+  // Every address is split into a WAVE-UNIFORM 64-bit part (scalar registers) and a small per-thread 32-bit offset:
+  // row(pp, q, r) = row(pp, 0, 0) + row(0, q, r) for both the input and the output order of a stage.
+  const int64_t in_off = o * N * p.inner + c0;
+  int64_t rstride = p.inner;
+  C2<T>* base = work + in_off;
+  if (MODE == 0 && p.ss > 0) {
+    if (p.blo > 0) {  // lines over the first axis, o = batch*mid + b
+      base = work + o * p.ss + c0;
+    } else {          // o = batch, columns run over (mid, last/2)
+      rstride = p.ss;
+      base = work + o * N * p.ss + c0;
+    }
+  }
 
   ex.phase([&](int tid, PassRegs<T, E>& rg) {
     const int t = tid % TILE, pp = tid / TILE;
@@ -356,21 +373,19 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
       c8 = desc ? nl - c - 1 : c;
       o8 = p.g.ndim == 3 ? (uint32_t)nk_fold((int)(o % p.g.na), p.g.na) * (N / 2 + 1) : 0u;
     }
+    const uint32_t toff = (uint32_t)(pp * rstride + t);  // thread part (< 2^31: checked by the host driver)
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const int row = nk_in_row<SC, 0>(pp, q, r);
-        const int64_t off = (int64_t)row * p.inner + t;
+        const int64_t uoff = (int64_t)nk_in_row<SC, 0>(0, q, r) * rstride;  // uniform part
         if constexpr (OCT) {
-          const int64_t i = 2 * ((base - work) + off);
-          const uint32_t j8 = (o8 + (uint32_t)nk_fold(row, N)) * ch + c8;  // octant arrays hold < 2^31 elements
-          rg.v[q * R + r] = nk_prologue_oct<T, PC>(f, i, j8, desc);
+          const uint32_t j8 = (o8 + (uint32_t)nk_fold(nk_in_row<SC, 0>(pp, q, r), N)) * ch + c8;  // < 2^31 elements
+          rg.v[q * R + r] = nk_prologue_oct<T, PC>(f, 2 * (in_off + uoff), 2 * toff, j8, desc);
         } else if (MODE == 3) {
-          const int64_t i = 2 * ((base - work) + off);
-          rg.v[q * R + r] = nk_prologue_ct<T, PC>(f, i);
+          rg.v[q * R + r] = nk_prologue_ct<T, PC>(f, 2 * (in_off + uoff), 2 * toff);
         } else {
-          rg.v[q * R + r] = base[off];
+          rg.v[q * R + r] = (base + uoff)[toff];
         }
       }
     nk_stage_compute<T, SC, 0>(rg.v, pp, tw);
@@ -406,12 +421,24 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
     constexpr int R = SC::radix(LS), Q = E / R;
     (void)scratch;
     (void)acc_out;
-    {
-#pragma unroll
-      for (int q = 0; q < Q; ++q)
-#pragma unroll
-        for (int r = 0; r < R; ++r) base[(int64_t)nk_out_row<SC, LS>(pp, q, r) * p.inner + t] = rg.v[q * R + r];
+    // store: MODE 0 in place; MODE 3 into the work array -- natural slabs (o = batch*first + a, or 2-D) or, blo == 1,
+    // [batch][this axis][first][last/2]: row b -> slab b, position a
+    C2<T>* obase = base;
+    int64_t ostride = rstride;
+    if (MODE == 3 && p.ss > 0) {
+      if (p.blo > 0) {
+        const int64_t bat = o / p.g.na, a = o % p.g.na;
+        obase = work + bat * N * p.ss + a * p.inner + c0;
+        ostride = p.ss;
+      } else {
+        obase = work + o * p.ss + c0;
+      }
     }
+    const uint32_t toff = (uint32_t)(nk_out_row<SC, LS>(pp, 0, 0) * ostride + t);
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) (obase + (int64_t)nk_out_row<SC, LS>(0, q, r) * ostride)[toff] = rg.v[q * R + r];
   });
 }
 
@@ -707,6 +734,8 @@ struct NkPassF {
   NkGeom g;
   int A, M;          // line index space (first, middle)
   int tiles_per_a;   // M / TILE
+  int blo;           // work array layout, see nk_strided_body
+  int64_t ss;        // slab stride (0: plain natural layout)
 };
 
 // EC: compile-time epilogue class (0 affine, 1 multiply, 2 scatter/VJP with materialised amplitude field, -1 generic)
@@ -756,8 +785,13 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
     int b, bm;
     bool active, self;
     line_of(t, b, bm, active, self);
-    const C2<T>* lk = work + ((bat * A + a) * M + b) * (int64_t)H;
-    const C2<T>* lm = work + ((bat * A + am) * M + bm) * (int64_t)H;
+    auto line_at = [&](int aa, int bb) {
+      if (p.ss > 0 && p.blo > 0) return work + (bat * M + bb) * p.ss + (int64_t)aa * H;
+      if (p.ss > 0) return work + (bat * A + aa) * p.ss + (int64_t)bb * H;
+      return work + ((bat * A + aa) * M + bb) * (int64_t)H;
+    };
+    const C2<T>* lk = line_at(a, b);
+    const C2<T>* lm = line_at(am, bm);
     constexpr int R = SC::radix(0), Q = E / R;
     // stage-0 rows of a thread are pp + multiples of P (P even): the parity of the element index is a per-thread
     // constant.  even: 2A = Zk + conj Zm, odd: 2B = -i (Zk - conj Zm); the factor 1/2 is folded into the output scale
@@ -975,3 +1009,38 @@ static inline bool nk_fast_strided_ok(int n, int64_t inner) {
   return tile > 0 && inner % tile == 0;
 }
 static inline bool nk_fast_contig_ok(int h) { return nk_fast_size(h); }
+
+// ---------------------------------------------------------------------------------------------
+// pass parameters of the strided-first pipeline (shared by the HIP driver and the host emulation)
+// ---------------------------------------------------------------------------------------------
+#include "nk_plan.h"
+struct NkPipe2 {
+  NkPassS s1, s0;  // first pass (fused prologue); second, in-place pass (3-D only)
+  NkPassF pf;
+};
+#define NK_WORK_PAD_MAX 8192  // elements; the plan's workspace reserves this much per slab
+static inline NkPipe2 nk_pipe2_setup(const NkHostPlan& hp, int sign, int blo, int pad) {
+  NkPipe2 q{};
+  const NkGeom& g = hp.g;
+  if (pad < 0) pad = 0;
+  if (pad > NK_WORK_PAD_MAX) pad = NK_WORK_PAD_MAX;
+  if (g.ndim == 3) {
+    blo = blo > 0 ? 1 : 0;
+    q.s1 = hp.pb;
+    q.s0 = hp.pc;
+    const int64_t ss = blo ? (int64_t)g.na * g.h + pad : (int64_t)g.nm * g.h + pad;
+    q.s1.blo = q.s0.blo = q.pf.blo = blo;
+    q.s1.ss = q.s0.ss = q.pf.ss = ss;
+    if (blo) {  // second pass: one line per (batch, mid) and last-axis tile, rows `h` apart
+      q.s0.outer = (int64_t)g.batch * g.nm;
+      q.s0.inner = g.h;
+    }
+  } else {
+    q.s1 = hp.pc;
+  }
+  q.pf.g = g;
+  q.pf.g.sign = sign;
+  q.pf.A = g.ndim == 3 ? g.na : 1;
+  q.pf.M = g.ndim == 3 ? g.nm : g.na;
+  return q;
+}

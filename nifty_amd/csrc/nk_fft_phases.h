@@ -115,6 +115,8 @@ struct NkPassS {
   int64_t outer;   // number of outer slabs
   int64_t inner;   // complex elements between consecutive line elements
   int tiles_per_slab;  // inner / tile
+  int blo;             // strided-first pipeline, 3-D: work array blocked as [batch][mid/blo][first][blo][last/2] (0: natural)
+  int64_t ss;          // ... and its slab stride in elements (>= slab size: padding de-aliases the power-of-two strides)
 };
 
 template <typename T>

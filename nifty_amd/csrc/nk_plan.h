@@ -180,7 +180,8 @@ static inline int nk_host_plan_init(NkHostPlan& P, int ndim, const int64_t* shap
   if (ndim == 3) setup_strided(P.pb, g.nm, batch * g.na, g.h, "NK_TILE_B", P.threads_b, P.lds_b, P.tw_b);
   if (ndim >= 2)
     setup_strided(P.pc, g.na, batch, (int64_t)g.nm * g.h, "NK_TILE_C", P.threads_c, P.lds_c, P.tw_c);
-  P.work_bytes = (size_t)(n_total / 2) * P.csize;
+  // + room for the padded slab strides of the strided-first pipeline (nk_pipe2_setup: <= NK_WORK_PAD_MAX per slab)
+  P.work_bytes = ((size_t)(n_total / 2) + (size_t)batch * (g.na > g.nm ? g.na : g.nm) * 8192) * P.csize;
   P.scratch_bytes = ndim >= 2 ? (size_t)batch * g.nm * g.na * P.csize : 0;
   return NK_OK;
 }

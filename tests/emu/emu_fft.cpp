@@ -167,7 +167,9 @@ static int emu3_run(int ndim, const int64_t* shape, int dtype, int64_t batch, co
   if (!nk_fast_strided_ok<T>(g.na, hp.pc.inner)) return -102;
   double energy = 0.0;
   std::vector<C2<T>> work(hp.work_bytes / sizeof(C2<T>) + 1);
-  NkPassS pb = hp.pb, pc = hp.pc;
+  NkPipe2 pq = nk_pipe2_setup(hp, convention == NK_HARTLEY_CANONICAL ? -1 : 1, nk_env_int("NK_WORK_BLO", 0),
+                              nk_env_int("NK_WORK_PAD", 2080));
+  NkPassS pb = pq.s1, pc = ndim == 3 ? pq.s0 : pq.s1;
   if (ndim == 3) {
     switch (g.nm) {
 #define NK_CASE(NN) \
@@ -186,11 +188,7 @@ static int emu3_run(int ndim, const int64_t* shape, int dtype, int64_t batch, co
     NK_FAST_SIZES(NK_CASE)
 #undef NK_CASE
   }
-  NkPassF pf{};
-  pf.g = g;
-  pf.g.sign = convention == NK_HARTLEY_CANONICAL ? -1 : 1;
-  pf.A = ndim == 3 ? g.na : 1;
-  pf.M = ndim == 3 ? g.nm : g.na;
+  const NkPassF pf = pq.pf;
   switch (g.nl) {
 #define NK_CASE(NN) \
   case NN:          \
