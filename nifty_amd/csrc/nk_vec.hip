@@ -600,3 +600,70 @@ extern "C" int nk_octant_scatter(int ndim, const int64_t* shape, const double* w
                      abar);
   return nk_check_launch("k_octant_scatter");
 }
+
+// ---- shell-binned octant scatter (natural binning on equal-distance grids) -------------------------------
+// Bins are the distinct integer k^2 = a^2 + b^2 + c^2 in ascending order, so a block of NK_SHELL_BINS consecutive
+// bins is a spherical shell [klo, khi) in k^2.  One workgroup owns (shell j, split s): it walks the octant lines
+// (a, b) that cut the shell -- their c-range follows from two integer square roots -- and accumulates the run
+// w8[a][b][c_lo..c_hi) into an LDS copy of the shell's bins (LDS fp64 adds, no global atomics); every (j, s) writes
+// its whole shell to partial[s][.], folded afterwards.
+#define NK_SHELL_BINS 4096
+#define NK_SHELL_SPLITS 8
+
+__device__ __forceinline__ int nk_isqrt_ceil(int x) {  // smallest n >= 0 with n*n >= x (x < 2^24)
+  if (x <= 0) return 0;
+  int n = (int)ceilf(sqrtf((float)x));
+  while (n * n < x) ++n;
+  while (n > 0 && (n - 1) * (n - 1) >= x) --n;
+  return n;
+}
+
+__global__ void __launch_bounds__(256)
+    k_octant_scatter_k2(NkOct o, const double* __restrict__ w8, const int32_t* __restrict__ pidx,
+                        const int32_t* __restrict__ bin_k2, int nb, int64_t pstride, double* __restrict__ partial) {
+  __shared__ double acc[NK_SHELL_BINS];
+  const int j = blockIdx.x / NK_SHELL_SPLITS, s = blockIdx.x % NK_SHELL_SPLITS;
+  const int bin0 = j * NK_SHELL_BINS;
+  const int nbin = min(NK_SHELL_BINS, nb - bin0);
+  for (int i = threadIdx.x; i < NK_SHELL_BINS; i += blockDim.x) acc[i] = 0.0;
+  __syncthreads();
+  const int klo = bin_k2[bin0];
+  const int khi = bin0 + NK_SHELL_BINS < nb ? bin_k2[bin0 + NK_SHELL_BINS] : 0x7fffffff;
+  const int hc2 = (o.Ch - 1) * (o.Ch - 1);
+  const int hw = threadIdx.x >> 5, l32 = threadIdx.x & 31;  // 8 half-waves, one octant line each
+  for (int a = s; a < o.Ah; a += NK_SHELL_SPLITS) {
+    const int ra = a * a;
+    if (ra >= khi) break;
+    const int b_hi = khi == 0x7fffffff ? o.Mh : min(o.Mh, nk_isqrt_ceil(khi - ra));  // b^2 < khi - ra
+    const int b_lo = nk_isqrt_ceil(klo - hc2 - ra);                                   // b^2 + hc2 >= klo - ra
+    for (int b = b_lo + hw; b < b_hi; b += 8) {
+      const int r2 = ra + b * b;
+      const int c_lo = nk_isqrt_ceil(klo - r2);
+      const int c_hi = khi == 0x7fffffff ? o.Ch : min(o.Ch, nk_isqrt_ceil(khi - r2));
+      const double* wl = w8 + ((int64_t)a * o.Mh + b) * o.Ch;
+      const int32_t* pl = pidx + ((int64_t)a * o.M + b) * o.NL;
+      for (int c = c_lo + l32; c < c_hi; c += 32) atomicAdd(&acc[pl[c] - bin0], wl[c]);
+    }
+  }
+  __syncthreads();
+  double* dst = partial + (int64_t)s * pstride + bin0;
+  for (int i = threadIdx.x; i < nbin; i += blockDim.x) dst[i] = acc[i];
+}
+
+extern "C" int nk_octant_scatter_k2(int ndim, const int64_t* shape, const double* w8, const int32_t* pidx,
+                                    const int32_t* bin_k2, int64_t nb, double* scratch, double* abar, void* stream) {
+  NkOct o;
+  int rc = nk_make_oct(ndim, shape, o);
+  if (rc != NK_OK) return rc;
+  if (!w8 || !pidx || !bin_k2 || !scratch || !abar || nb < 1 || nb > 0x7fffffff)
+    return nk_set_error(NK_ERR_INVALID, "nk_octant_scatter_k2: bad argument");
+  if ((int64_t)(o.Ah - 1) * (o.Ah - 1) + (int64_t)(o.Mh - 1) * (o.Mh - 1) + (int64_t)(o.Ch - 1) * (o.Ch - 1) >= (1 << 24))
+    return nk_set_error(NK_ERR_UNSUPPORTED, "nk_octant_scatter_k2: k^2 range too large");
+  const int64_t shells = (nb + NK_SHELL_BINS - 1) / NK_SHELL_BINS;
+  const int64_t pstride = (nb + 31) / 32 * 32;
+  hipLaunchKernelGGL(k_octant_scatter_k2, dim3((unsigned)(shells * NK_SHELL_SPLITS)), dim3(256), 0, (hipStream_t)stream, o, w8,
+                     pidx, bin_k2, (int)nb, pstride, scratch);
+  rc = nk_check_launch("k_octant_scatter_k2");
+  if (rc != NK_OK) return rc;
+  return nk_fold_copies(nb, NK_SHELL_SPLITS, pstride, scratch, abar, stream);
+}

@@ -69,7 +69,7 @@ def test_unsupported_shapes_raise():
         B.hartley(torch.zeros(16, dtype=torch.float64))
 
 
-@pytest.mark.parametrize("shape", [(64,), (32, 64), (64, 64, 64), (128, 64, 256)])
+@pytest.mark.parametrize("shape", [(64,), (32, 64), (64, 64, 64), (128, 64, 256), (256, 256, 256)])
 def test_octant_expand_and_scatter(shape):
     """nk_octant_expand (full and compact) = PowerDistributor TIMES, nk_octant_scatter = its adjoint on the octant sums
     (distributors.py:106-127), on a real PowerSpace pindex."""
@@ -99,7 +99,17 @@ def test_octant_expand_and_scatter(shape):
     w8 = rng.normal(size=oshape)
     abar = torch.zeros(nb, dtype=torch.float64, device="cuda")
     merge = int(len(shape) == 3 and shape[0] == shape[1])
-    L.check(lib.nk_octant_scatter(len(shape), shp, torch.from_numpy(w8).cuda().data_ptr(), pd.data_ptr(), abar.data_ptr(),
-                                  merge, B._stream()), "x")
+    w8d0 = torch.from_numpy(w8).cuda()
+    L.check(lib.nk_octant_scatter(len(shape), shp, w8d0.data_ptr(), pd.data_ptr(), abar.data_ptr(), merge, B._stream()), "x")
     ref = np.bincount(pidx[osl].ravel(), weights=w8.ravel(), minlength=nb)
     assert np.max(np.abs(abar.cpu().numpy() - ref)) < 1e-12 * max(1.0, np.max(np.abs(ref)))
+    # shell-binned variant for natural binning on equal-distance grids (overwrites abar)
+    if len(set(hsp.distances)) == 1:
+        k2 = np.nonzero(hsp._k2_flags())[0].astype(np.int32)
+        assert len(k2) == nb
+        scratch = torch.full((8 * (nb + 32),), np.nan, dtype=torch.float64, device="cuda")
+        abar2 = torch.full((nb,), np.nan, dtype=torch.float64, device="cuda")
+        w8d, k2d = torch.from_numpy(w8).cuda(), torch.from_numpy(k2).cuda()
+        L.check(lib.nk_octant_scatter_k2(len(shape), shp, w8d.data_ptr(), pd.data_ptr(), k2d.data_ptr(), nb,
+                                         scratch.data_ptr(), abar2.data_ptr(), B._stream()), "x")
+        assert np.max(np.abs(abar2.cpu().numpy() - ref)) < 1e-12 * max(1.0, np.max(np.abs(ref)))
