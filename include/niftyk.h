@@ -169,7 +169,7 @@ int nk_octant_scatter(int ndim, const int64_t* shape, const double* w8, const in
 /* nk_octant_scatter for NATURAL binning on a grid with equal harmonic distances on all axes (bins = the distinct integer
  * k^2 = a^2+b^2+c^2 in ascending order; bin_k2[nb] = k^2 of every bin): abar[.] = sum over the octant array, OVERWRITING
  * abar.  Shell-binned: blocks of consecutive bins are spherical shells whose cut with every octant line is a c-range
- * known from two integer square roots, accumulated in LDS -- no global atomics.  scratch: >= 8*(nb+32) doubles. */
+ * known from two integer square roots, accumulated in LDS -- no global atomics.  scratch: >= 16*(nb+32) doubles. */
 int nk_octant_scatter_k2(int ndim, const int64_t* shape, const double* w8, const int32_t* pidx, const int32_t* bin_k2,
                          int64_t nb, double* scratch, double* abar, void* stream);
 /* 1 if nk_hartley_fused on this plan honours nk_fuse.w8 (the register-resident pipeline is active) */

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libniftyk.so")
+# NK_LIB_PATH: developer override used for A/B runs of alternative builds (tools/); the product default is in-tree
+LIB_PATH = os.environ.get("NK_LIB_PATH") or os.path.join(_HERE, "csrc", "libniftyk.so")
 
 NK_OK, NK_ERR_INVALID, NK_ERR_UNSUPPORTED, NK_ERR_RUNTIME, NK_ERR_NOMEM = 0, -1, -2, -3, -4
 NK_F32, NK_F64 = 0, 1

@@ -607,8 +607,15 @@ extern "C" int nk_octant_scatter(int ndim, const int64_t* shape, const double* w
 // (a, b) that cut the shell -- their c-range follows from two integer square roots -- and accumulates the run
 // w8[a][b][c_lo..c_hi) into an LDS copy of the shell's bins (LDS fp64 adds, no global atomics); every (j, s) writes
 // its whole shell to partial[s][.], folded afterwards.
+#ifndef NK_SHELL_BINS
 #define NK_SHELL_BINS 4096
-#define NK_SHELL_SPLITS 8
+#endif
+#ifndef NK_SHELL_SPLITS
+#define NK_SHELL_SPLITS 16
+#endif
+#ifndef NK_SHELL_NU
+#define NK_SHELL_NU 8
+#endif
 
 __device__ __forceinline__ int nk_isqrt_ceil(int x) {  // smallest n >= 0 with n*n >= x (x < 2^24)
   if (x <= 0) return 0;
@@ -630,19 +637,42 @@ __global__ void __launch_bounds__(256)
   const int klo = bin_k2[bin0];
   const int khi = bin0 + NK_SHELL_BINS < nb ? bin_k2[bin0 + NK_SHELL_BINS] : 0x7fffffff;
   const int hc2 = (o.Ch - 1) * (o.Ch - 1);
-  const int hw = threadIdx.x >> 5, l32 = threadIdx.x & 31;  // 8 half-waves, one octant line each
+  // 16 groups of 16 lanes; a group takes NU lines per trip and issues all their loads before the first LDS add:
+  // the runs are short (~10 points), so the kernel lives on memory-level parallelism, not on bandwidth per request
+  constexpr int NG = 16, NU = NK_SHELL_NU;
+  const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+  const bool last = khi == 0x7fffffff;
   for (int a = s; a < o.Ah; a += NK_SHELL_SPLITS) {
     const int ra = a * a;
     if (ra >= khi) break;
-    const int b_hi = khi == 0x7fffffff ? o.Mh : min(o.Mh, nk_isqrt_ceil(khi - ra));  // b^2 < khi - ra
-    const int b_lo = nk_isqrt_ceil(klo - hc2 - ra);                                   // b^2 + hc2 >= klo - ra
-    for (int b = b_lo + hw; b < b_hi; b += 8) {
-      const int r2 = ra + b * b;
-      const int c_lo = nk_isqrt_ceil(klo - r2);
-      const int c_hi = khi == 0x7fffffff ? o.Ch : min(o.Ch, nk_isqrt_ceil(khi - r2));
-      const double* wl = w8 + ((int64_t)a * o.Mh + b) * o.Ch;
-      const int32_t* pl = pidx + ((int64_t)a * o.M + b) * o.NL;
-      for (int c = c_lo + l32; c < c_hi; c += 32) atomicAdd(&acc[pl[c] - bin0], wl[c]);
+    const int b_hi = last ? o.Mh : min(o.Mh, nk_isqrt_ceil(khi - ra));  // b^2 < khi - ra
+    const int b_lo = nk_isqrt_ceil(klo - hc2 - ra);                      // b^2 + hc2 >= klo - ra
+    for (int b0 = b_lo + grp; b0 < b_hi; b0 += NG * NU) {
+      int cc[NU], ce[NU];
+      const double* wl[NU];
+      const int32_t* pl[NU];
+      double v[NU];
+      int32_t pb[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int b = b0 + u * NG;
+        const int r2 = ra + b * b;
+        const bool on = b < b_hi;
+        cc[u] = nk_isqrt_ceil(klo - r2) + l16;
+        ce[u] = on ? (last ? o.Ch : min(o.Ch, nk_isqrt_ceil(khi - r2))) : 0;
+        wl[u] = w8 + ((int64_t)a * o.Mh + b) * o.Ch;
+        pl[u] = pidx + ((int64_t)a * o.M + b) * o.NL;
+        const bool in = cc[u] < ce[u];
+        v[u] = in ? wl[u][cc[u]] : 0.0;
+        pb[u] = in ? pl[u][cc[u]] : bin0;
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+        if (cc[u] < ce[u]) atomicAdd(&acc[pb[u] - bin0], v[u]);
+      // rare: runs longer than 16 points
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+        for (int c = cc[u] + 16; c < ce[u]; c += 16) atomicAdd(&acc[pl[u][c] - bin0], wl[u][c]);
     }
   }
   __syncthreads();

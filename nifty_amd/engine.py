@@ -225,6 +225,7 @@ class FusedModel:
             # VJP scatter accumulators: one private copy per XCD (L2-scope atomics), folded into self.abar
             self.abar_stride = (nb + 31) // 32 * 32
             self.abar_copies = 8
+            self.scatter_scratch = torch.empty(16 * (nb + 32), dtype=torch.float64, device=self.device)
             self.abar_priv = torch.zeros(self.abar_copies * self.abar_stride, dtype=torch.float64, device=self.device)
             self.abar = torch.zeros(nb, dtype=torch.float64, device=self.device)
             self.damp = torch.empty(nb, dtype=torch.float64, device=self.device)
@@ -330,7 +331,7 @@ class FusedModel:
             shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
             if self.bin_k2 is not None:
                 L.check(L.load().nk_octant_scatter_k2(len(self.shape), shp, self.w8.data_ptr(), self.pidx.data_ptr(),
-                                                      self.bin_k2.data_ptr(), self.nb, self.abar_priv.data_ptr(),
+                                                      self.bin_k2.data_ptr(), self.nb, self.scatter_scratch.data_ptr(),
                                                       self.abar.data_ptr(), B._stream()), "nk_octant_scatter_k2")
             else:
                 self.abar.zero_()

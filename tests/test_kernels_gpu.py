@@ -107,7 +107,7 @@ def test_octant_expand_and_scatter(shape):
     if len(set(hsp.distances)) == 1:
         k2 = np.nonzero(hsp._k2_flags())[0].astype(np.int32)
         assert len(k2) == nb
-        scratch = torch.full((8 * (nb + 32),), np.nan, dtype=torch.float64, device="cuda")
+        scratch = torch.full((16 * (nb + 32),), np.nan, dtype=torch.float64, device="cuda")
         abar2 = torch.full((nb,), np.nan, dtype=torch.float64, device="cuda")
         w8d, k2d = torch.from_numpy(w8).cuda(), torch.from_numpy(k2).cuda()
         L.check(lib.nk_octant_scatter_k2(len(shape), shp, w8d.data_ptr(), pd.data_ptr(), k2d.data_ptr(), nb,

@@ -1,0 +1,24 @@
+"""Times nk_octant_scatter vs nk_octant_scatter_k2 on a 1024^3 (or given) grid and checks they agree."""
+import sys, ctypes, time, numpy as np, torch
+sys.path.insert(0, ".")
+import nifty_amd as ift
+from nifty_amd import _lib as L, backend as B
+shape = tuple(int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1024,1024,1024").split(","))
+hsp = ift.RGSpace(shape).get_default_codomain(); ps = ift.PowerSpace(hsp)
+dev = torch.device("cuda:0"); pidx = ps.device_pindex(dev); nb = ps.shape[0]
+lib = L.load(); shp = (ctypes.c_int64 * len(shape))(*shape)
+oshape = tuple(n // 2 + 1 for n in shape)
+w8 = torch.randn(oshape, dtype=torch.float64, device=dev)
+k2 = torch.from_numpy(np.nonzero(hsp._k2_flags())[0].astype(np.int32)).to(dev)
+a1 = torch.zeros(nb, dtype=torch.float64, device=dev); a2 = torch.empty_like(a1)
+scratch = torch.empty(64 * (nb + 32), dtype=torch.float64, device=dev)
+def t(fn, n=5):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+def f1():
+    a1.zero_(); L.check(lib.nk_octant_scatter(len(shape), shp, w8.data_ptr(), pidx.data_ptr(), a1.data_ptr(), 1 if len(shape) == 3 and shape[0] == shape[1] else 0, B._stream()), "x")
+def f2():
+    L.check(lib.nk_octant_scatter_k2(len(shape), shp, w8.data_ptr(), pidx.data_ptr(), k2.data_ptr(), nb, scratch.data_ptr(), a2.data_ptr(), B._stream()), "x")
+print("atomic  %.3f ms" % t(f1)); print("shell   %.3f ms" % t(f2))
+print("max rel diff", float((a1 - a2).abs().max() / a1.abs().max()))
