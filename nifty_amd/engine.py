@@ -96,6 +96,42 @@ class CgWorkspace:
                     alpha=float(s[0] / s[1]) if s[1] != 0 else float("nan"))
 
 
+class ShardedCgWorkspace(CgWorkspace):
+    """CG scalars when every rank holds 1/size of xi (and a replicated copy of the small part): the xi partial sums
+    are all-reduced (one 8..24-byte collective per reduction), then the replicated small part is added on every rank."""
+
+    def __init__(self, device, comm):
+        super().__init__(device)
+        self.comm = comm
+
+    def dot(self, u, v, slot):
+        res = self.scal[slot:slot + 1]
+        B.vdot(u.xi.reshape(-1), v.xi.reshape(-1), result=res, accumulate=False)
+        self.comm.allreduce_sum_([res])
+        B.vdot(u.small, v.small, result=res, accumulate=True)
+        return res
+
+    def curv(self, d, q):
+        lib, st = L.load(), B._stream()
+        (dx, qx), (ds, qs) = self._segments(d, q)
+        L.check(lib.nk_cg_curv(dx.numel(), dx.data_ptr(), qx.data_ptr(), B.dtype_code(dx), self.scal.data_ptr(), 0, st))
+        self.comm.allreduce_sum_([self.scal[1:2]])
+        L.check(lib.nk_cg_curv(ds.numel(), ds.data_ptr(), qs.data_ptr(), B.dtype_code(ds), self.scal.data_ptr(), 1, st))
+
+    def update(self, x, r, d, q, b):
+        lib, st = L.load(), B._stream()
+        for i, (xx, rr, dd, qq, bb) in enumerate(self._segments(x, r, d, q, b)):
+            L.check(lib.nk_cg_update(xx.numel(), xx.data_ptr(), rr.data_ptr(), dd.data_ptr(), qq.data_ptr(), B.ptr(bb),
+                                     B.dtype_code(xx), self.scal.data_ptr(), i, st))
+            if i == 0:
+                self.comm.allreduce_sum_([self.scal[2:5]])
+
+    def refresh(self, x, r, b):
+        for slot, (u, v) in ((2, (r, r)), (3, (x, r)), (4, (x, b))):
+            if v is not None:
+                self.dot(u, v, slot)
+
+
 class LatentVec:
     """A point / tangent / cotangent of the latent space (vector protocol of minimization.py)."""
 
@@ -530,7 +566,8 @@ class FusedKL(Energy):
     def at(self, position):
         return FusedKL(self.model, position, self.residuals, self.negs, self.n_total, self.comm, self.nanisinf)
 
-    def apply_metric(self, d):
+    def _apply_metric_local(self, d):
+        """This rank's share of the KL metric applied to d (no communication)."""
         m = self.model
         out = LatentVec(torch.empty_like(d.xi), None)
         w = 1.0 / self.n_total
@@ -541,17 +578,59 @@ class FusedKL(Energy):
             m.lh_metric_accumulate(lp, d, out, w, i == 0, identity=nloc * w if i == 0 else 0.0)
         if nloc == 0:
             out = LatentVec.zeros(m)
+        return out
+
+    def apply_metric(self, d):
+        out = self._apply_metric_local(d)
         if self.comm is not None:
             self.comm.allreduce_sum_([out.xi, out.small])
         return out
 
     @property
     def metric(self):
-        return _Callable(self.apply_metric)
+        A = _Callable(self.apply_metric)
+        if self.comm is not None and self.comm.can_shard(self.model.N):
+            A.sharded = ShardedMetric(self)  # picked up by ConjugateGradient: CG vectors sharded over the ranks
+        return A
 
     @property
     def samples(self):
         return [(self._position - r if neg else self._position + r) for r, neg in zip(self.residuals, self.negs)]
+
+
+class ShardedMetric:
+    """The KL metric for a CG whose vectors are sharded over the ranks: instead of all-reducing the
+    N-sized metric output and repeating every CG vector update on all ranks, the sample sum is REDUCE-SCATTERED
+    (each rank receives its 1/size slice of q), the CG updates run on that slice, and only the new search direction
+    is ALL-GATHERED for the next metric application.  Same bytes on the links as the all-reduce (which is a
+    reduce-scatter followed by an all-gather), 1/size of the vector work and memory per rank."""
+
+    def __init__(self, kl):
+        self.kl, self.comm, self.model = kl, kl.comm, kl.model
+        n = kl.model.N // self.comm.size
+        self.lo, self.hi = self.comm.rank * n, (self.comm.rank + 1) * n
+
+    def shard(self, v, copy=False):
+        xi = v.xi.reshape(-1)[self.lo:self.hi]
+        return LatentVec(xi.clone(), v.small.clone()) if copy else LatentVec(xi, v.small)
+
+    def workspace(self):
+        return ShardedCgWorkspace(self.model.device, self.comm)
+
+    def apply(self, d_full):
+        out = self.kl._apply_metric_local(d_full)
+        q_xi = torch.empty(self.hi - self.lo, dtype=out.xi.dtype, device=out.xi.device)
+        self.comm.reduce_scatter_sum(out.xi.reshape(-1), q_xi)
+        self.comm.allreduce_sum_([out.small])
+        return LatentVec(q_xi, out.small)
+
+    def gather(self, shard_vec, out_full=None):
+        if out_full is None:
+            out_full = LatentVec(torch.empty(self.model.shape, dtype=shard_vec.xi.dtype, device=shard_vec.xi.device),
+                                 torch.empty_like(shard_vec.small))
+        self.comm.all_gather(shard_vec.xi, out_full.xi.reshape(-1))
+        out_full.small.copy_(shard_vec.small)
+        return out_full
 
 
 def share_range(nwork, nshares, myshare):

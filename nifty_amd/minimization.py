@@ -371,6 +371,9 @@ class ConjugateGradient(Minimizer):
         if status != CONTINUE:
             return energy, status
         A, b = energy._A, energy._b
+        sm = getattr(A, "sharded", None)
+        if sm is not None and b is not None:
+            return self._solve_inplace_sharded(energy, sm)
         x = energy.position.clone()
         r = energy.gradient.clone()
         d = r.clone()
@@ -411,6 +414,54 @@ class ConjugateGradient(Minimizer):
             if status != CONTINUE:
                 return finish(status)
             ws.direction(d, r)
+
+
+    def _solve_inplace_sharded(self, energy, sm):
+        """Same iteration as _solve_inplace with x, r, d, q held as per-rank shards (engine.ShardedMetric): one
+        reduce-scatter + one all-gather of the latent vector and two scalar all-reduces per iteration."""
+        controller = self._controller
+        b_full = energy._b
+        b = sm.shard(b_full)
+        x = sm.shard(energy.position, copy=True)
+        r = sm.shard(energy.gradient, copy=True)
+        d = r.clone()
+        d_full = energy.gradient.clone()
+        ws = sm.workspace()
+        gamma_prev = float(ws.dot(r, r, 0).item())
+        if np.isnan(gamma_prev):
+            return energy, ERROR
+        if gamma_prev == 0:
+            return energy, CONVERGED
+        since_reset = 0
+
+        def finish(status):
+            return energy.at_with_grad(sm.gather(x), sm.gather(r)), status
+
+        while True:
+            q = sm.apply(d_full)
+            ws.curv(d, q)
+            ws.update(x, r, d, q, b)
+            since_reset += 1
+            if since_reset >= self._nreset:
+                Ax = sm.apply(sm.gather(x))
+                r = Ax - b
+                ws.refresh(x, r, b)
+                since_reset = 0
+            sc = ws.fetch()
+            curv, gamma, alpha = sc["curv"], sc["gamma"], sc["alpha"]
+            if np.isnan(curv) or curv == 0.0 or np.isnan(alpha) or alpha < 0:
+                logger.error("Error: ConjugateGradient: bad curvature / step")
+                return finish(ERROR)
+            if np.isnan(gamma) or gamma < 0:
+                return finish(ERROR)
+            if gamma == 0:
+                return finish(CONVERGED)
+            value = 0.5 * sc["xr"] - 0.5 * sc["xb"]
+            status = controller.check(_ScalarEnergyView(value, float(np.sqrt(gamma))))
+            if status != CONTINUE:
+                return finish(status)
+            ws.direction(d, r)
+            sm.gather(d, d_full)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -38,6 +38,57 @@ class Comm:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return tensors
 
+    # -- sharded vectors: the CG state of the KL minimisation lives on 1/size of the latent vector per rank -------
+    def can_shard(self, n):
+        return self.size > 1 and n % self.size == 0 and os.environ.get("NK_SHARDED_CG", "1") != "0"
+
+    def _native_reduce_scatter(self, device):
+        """RCCL reduce_scatter_tensor is used after ONE self-check against all_reduce; gloo has no reduce-scatter
+        (all_reduce + slice is used instead -- same result, the CPU tests and single-GPU multi-rank tests run this)."""
+        ok = getattr(self, "_rs_ok", None)
+        if ok is None:
+            ok = False
+            if self.backend_is_nccl:
+                try:
+                    n = 64 * self.size
+                    full = torch.arange(n, dtype=torch.float32, device=device) * (self.rank + 1)
+                    ref = full.clone()
+                    shard = torch.empty(n // self.size, dtype=torch.float32, device=device)
+                    dist.reduce_scatter_tensor(shard, full, op=dist.ReduceOp.SUM, group=self.group)
+                    dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.group)
+                    lo = self.rank * (n // self.size)
+                    ok = bool(torch.equal(shard, ref[lo:lo + n // self.size]))
+                except Exception:  # pragma: no cover - depends on the RCCL build
+                    ok = False
+                flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+                ok = bool(flag.item() > 0.5)
+            self._rs_ok = ok
+        return ok
+
+    def reduce_scatter_sum(self, full, shard):
+        """shard[:] = (sum over ranks of full)[rank*len(shard) : (rank+1)*len(shard)]; `full` is clobbered."""
+        n = shard.numel()
+        if full.numel() != n * self.size:
+            raise ValueError("reduce_scatter_sum: length not divisible by the rank count")
+        if self._native_reduce_scatter(full.device):
+            dist.reduce_scatter_tensor(shard, full, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
+            shard.copy_(full[self.rank * n:(self.rank + 1) * n])
+        return shard
+
+    def all_gather(self, shard, full):
+        """full = concatenation over ranks of shard."""
+        n = shard.numel()
+        if full.numel() != n * self.size:
+            raise ValueError("all_gather: length not divisible by the rank count")
+        try:
+            dist.all_gather_into_tensor(full, shard, group=self.group)
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather([full[i * n:(i + 1) * n] for i in range(self.size)], shard, group=self.group)
+        return full
+
     def bcast_(self, tensor, root=0):
         dist.broadcast(tensor, src=root, group=self.group)
         return tensor

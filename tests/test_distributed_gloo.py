@@ -103,6 +103,7 @@ def _engine_worker(rank, world, port, out):
     random.pop_sseq()
     assert len(res) == 2 and n_total == 4
     kl = FusedKL(model, xl, res, negs, n_total, comm)
+    assert getattr(kl.metric, "sharded", None) is not None  # the CG below runs on per-rank shards of the latent vector
     out_d = dict(value=kl.value, grad=kl.gradient.to_dict(), met=kl.apply_metric(vl).to_dict())
     mini = NewtonCG(AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=8)
     kl2, _ = mini(kl)
@@ -129,3 +130,38 @@ def test_two_rank_fused_engine_equals_reference(tmp_path):
     assert gl.lat_relerr(par["met"], gl.latent(z, "kl_metric_v")) < 1e-8
     assert abs(par["min_value"] - float(z["kl_min_value"])) < 1e-7 * abs(float(z["kl_min_value"]))
     assert gl.lat_relerr(par["min_pos"], gl.latent(z, "kl_min_pos")) < 1e-6
+
+
+def _nccl_single_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    from nifty_amd.parallel import Comm
+
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    comm = Comm()
+    dev = torch.device("cuda:0")
+    assert comm._native_reduce_scatter(dev)  # the RCCL collectives the sharded CG relies on exist and agree
+    full = torch.arange(1024, dtype=torch.float32, device=dev)
+    ref = full.clone()
+    shard = torch.empty(1024, dtype=torch.float32, device=dev)
+    comm.reduce_scatter_sum(full, shard)
+    assert torch.equal(shard, ref)
+    back = torch.empty_like(ref)
+    comm.all_gather(shard, back)
+    assert torch.equal(back, ref)
+    s8 = torch.ones(3, dtype=torch.float64, device=dev)
+    comm.allreduce_sum_([s8[1:3]])
+    assert torch.equal(s8.cpu(), torch.ones(3, dtype=torch.float64))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_rccl_collectives_of_the_sharded_cg():
+    """reduce_scatter_tensor / all_gather_into_tensor / slice all_reduce on the real RCCL backend (one rank: the box has
+    one GPU; the multi-rank arithmetic is covered by the gloo tests above)."""
+    mp.spawn(_nccl_single_worker, args=(1, _free_port()), nprocs=1, join=True)
