@@ -338,6 +338,29 @@ NK_HD void nk_nonlin(int kind, double s, double& g, double& gp) {
 }
 
 // single-output epilogue; `acc` collects the per-thread energy contribution
+// LIKELIHOOD epilogue of one output (energy_operators.py:517-640): energy term -> acc, dE/ds -> out, Fisher weight -> out2
+template <typename T>
+NK_HD void nk_epi_likelihood(const NkFuse& f, int64_t o, T v, double& acc) {
+  const double s = (double)v * f.scale + f.offset;
+  double g, gp;
+  nk_nonlin(f.nonlin, s, g, gp);
+  double gs, w;
+  if (f.lh_kind == NK_LH_GAUSS) {
+    const double ic = f.icov ? (double)((const T*)f.icov)[o] : f.icov_scalar;
+    const double r = g - (double)((const T*)f.data)[o];
+    acc += 0.5 * ic * r * r;
+    gs = gp * ic * r;
+    w = gp * gp * ic;
+  } else {
+    const double d = (double)((const int64_t*)f.data)[o];
+    acc += g - d * log(g);
+    gs = gp * (1.0 - d / g);
+    w = gp * gp / g;
+  }
+  ((T*)f.out)[o] = (T)gs;
+  if (f.out2) ((T*)f.out2)[o] = (T)w;
+}
+
 template <typename T>
 NK_HD void nk_epilogue(const NkFuse& f, int64_t o, T v, double& acc) {
   T* out = (T*)f.out;
@@ -356,26 +379,9 @@ NK_HD void nk_epilogue(const NkFuse& f, int64_t o, T v, double& acc) {
       out[o] = (T)r;
       NK_VJP_SCATTER(f, p, (double)((const T*)f.xi)[o] * t);
     } break;
-    case NK_EPI_LIKELIHOOD: {
-      const double s = (double)v * f.scale + f.offset;
-      double g, gp;
-      nk_nonlin(f.nonlin, s, g, gp);
-      double gs, w;
-      if (f.lh_kind == NK_LH_GAUSS) {
-        const double ic = f.icov ? (double)((const T*)f.icov)[o] : f.icov_scalar;
-        const double r = g - (double)((const T*)f.data)[o];
-        acc += 0.5 * ic * r * r;
-        gs = gp * ic * r;
-        w = gp * gp * ic;
-      } else {
-        const double d = (double)((const int64_t*)f.data)[o];
-        acc += g - d * log(g);
-        gs = gp * (1.0 - d / g);
-        w = gp * gp / g;
-      }
-      out[o] = (T)gs;
-      if (f.out2) ((T*)f.out2)[o] = (T)w;
-    } break;
+    case NK_EPI_LIKELIHOOD:
+      nk_epi_likelihood<T>(f, o, v, acc);
+      break;
     case NK_EPI_NONLIN: {
       const double s = (double)v * f.scale + f.offset;
       double g, gp;

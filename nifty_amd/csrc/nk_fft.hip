@@ -253,6 +253,7 @@ static int nk_launch_final(const NkPassF& pf, const NkFuse& f, const C2<T>* tw, 
   if (f.epi == NK_EPI_VJP) return nk_launch_final_c<T, NL, true, -1>(pf, f, tw, work, st);
   if (f.epi == NK_EPI_AFFINE) return nk_launch_final_c<T, NL, false, 0>(pf, f, tw, work, st);
   if (f.epi == NK_EPI_MUL) return nk_launch_final_c<T, NL, false, 1>(pf, f, tw, work, st);
+  if (f.epi == NK_EPI_LIKELIHOOD) return nk_launch_final_c<T, NL, false, 3>(pf, f, tw, work, st);
   return nk_launch_final_c<T, NL, false, -1>(pf, f, tw, work, st);
 }
 

@@ -202,9 +202,10 @@ struct ContigTile {
 };
 
 #ifndef NK_FINAL_LDS_KB
-#define NK_FINAL_LDS_KB 40
+#define NK_FINAL_LDS_KB 20
 #endif
-// final pass of the strided-first pipeline: up to 256 threads and ~72 KiB of planes (two workgroups per CU)
+// final pass of the strided-first pipeline: up to 256 threads and <= NK_FINAL_LDS_KB of planes (20 KiB: two line pairs
+// per workgroup at 1024 fp32 -- many small workgroups hide the load/epilogue latency best)
 template <typename T, int NL>
 struct FinalTile {
   static constexpr int P = SchedF<T, NL>::P;
@@ -610,12 +611,21 @@ NK_HD FinalCt<T> nk_final_ct(const NkFuse& f) {
 // (k2m != k2) H(k,-kl) -> ok+k2m, H(-k,kl) -> om+k2.  `self`: the line is its own partner (images 1, 3 coincide
 // with 2, 0).  Returns the fp64 bin-sum contribution for EC 2.
 template <typename T, int EC, bool BOTH>
-NK_HD double nk_final_slot(const FinalCt<T>& c, int64_t ok, int64_t om, bool self, T sg, T fx, T fy, T gx, T gy, int k2,
-                           int k2m, T a) {
+NK_HD double nk_final_slot(const NkFuse& f, const FinalCt<T>& c, int64_t ok, int64_t om, bool self, T sg, T fx, T fy, T gx,
+                           T gy, int k2, int k2m, T a) {
   const T v0 = fx + sg * fy, v1 = fx - sg * fy, v2 = gx + sg * gy, v3 = gx - sg * gy;
   T* outk = c.out + ok;
   T* outm = c.out + om;
-  if constexpr (EC == 0) {
+  if constexpr (EC == 3) {  // likelihood: the reference arithmetic (fp64) per output, energy terms returned
+    double e = 0.0;
+    nk_epi_likelihood<T>(f, ok + k2, v0, e);
+    if (BOTH) nk_epi_likelihood<T>(f, ok + k2m, v2, e);
+    if (!self) {
+      nk_epi_likelihood<T>(f, om + k2m, v1, e);
+      if (BOTH) nk_epi_likelihood<T>(f, om + k2, v3, e);
+    }
+    return e;
+  } else if constexpr (EC == 0) {
     outk[k2] = v0 * c.sc + c.off;
     if (BOTH) outk[k2m] = v2 * c.sc + c.off;
     if (!self) {
@@ -697,7 +707,7 @@ NK_HD double nk_final_slot(const FinalCt<T>& c, int64_t ok, int64_t om, bool sel
 // all slots of a group for coefficient k2
 template <typename T, int NL, int NH, int EC, bool BOTH>
 NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg,
-                          int k2, int hv, const T* afline, double* w8line) {
+                          int k2, int hv, const T* afline, double* w8line, double& acc) {
   const int k2m = (NL - k2) & (NL - 1);
   const int d1 = k2 + (k2 >> 5), d2 = k2m + (k2m >> 5);
   T a = (T)0;
@@ -708,7 +718,7 @@ NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup
     if (!gp.mlo[h]) continue;
     const T fx = pre[gp.base[h] + d1], fy = pim[gp.base[h] + d1];
     const T gx = pre[gp.base[h] + d2], gy = pim[gp.base[h] + d2];
-    ssum += nk_final_slot<T, EC, BOTH>(c, gp.okh[h], gp.omh[h], gp.mlo[h] == 1, sg, fx, fy, gx, gy, k2, k2m, a);
+    ssum += nk_final_slot<T, EC, BOTH>(f, c, gp.okh[h], gp.omh[h], gp.mlo[h] == 1, sg, fx, fy, gx, gy, k2, k2m, a);
   }
   if constexpr (EC == 2) {
     if (w8line)
@@ -716,6 +726,7 @@ NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup
     else
       NK_VJP_SCATTER(f, f.pidx[gp.okh[hv] + k2], ssum);
   }
+  if constexpr (EC == 3) acc += ssum;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -738,7 +749,8 @@ struct NkPassF {
   int64_t ss;        // slab stride (0: plain natural layout)
 };
 
-// EC: compile-time epilogue class (0 affine, 1 multiply, 2 scatter/VJP with materialised amplitude field, -1 generic)
+// EC: compile-time epilogue class (0 affine, 1 multiply, 2 scatter/VJP with materialised amplitude field,
+// 3 likelihood, -1 generic)
 template <typename T, int NL, int TILE, bool COUPLES, int EC, typename Exec>
 NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t blk, T* planes,
                          const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, double* acc_out) {
@@ -920,9 +932,9 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
         if constexpr (EC == 2)
           afline = f.field_octant ? c.af + ((int64_t)a * (M / 2 + 1) + b0g) * (NL / 2 + 1) : c.af + gp.okh[hv];
         // k_last = 0 and NL/2 are their own mirrors; everything in between has four distinct images per slot
-        if (lane < 2) nk_final_coeff<T, NL, NH, EC, false>(f, c, gp, pre, pim, sg, lane ? NL / 2 : 0, hv, afline, w8line);
+        if (lane < 2) nk_final_coeff<T, NL, NH, EC, false>(f, c, gp, pre, pim, sg, lane ? NL / 2 : 0, hv, afline, w8line, acc);
         for (int k2 = 1 + lane; k2 < NL / 2; k2 += tps)
-          nk_final_coeff<T, NL, NH, EC, true>(f, c, gp, pre, pim, sg, k2, hv, afline, w8line);
+          nk_final_coeff<T, NL, NH, EC, true>(f, c, gp, pre, pim, sg, k2, hv, afline, w8line, acc);
       }
     } else if (any) {
       const bool vjp = f.epi == NK_EPI_VJP;

@@ -148,6 +148,7 @@ static void emu2_final(const NkPassF& pf0, const nk_fuse& f, const C2<T>* tw, co
     else if (couples) nk_final_body<T, NL, CT::TILE, true, -1>(ex, pf, f, blk, planes.data(), tw, work, energy);
     else if (f.epi == NK_EPI_AFFINE) nk_final_body<T, NL, CT::TILE, false, 0>(ex, pf, f, blk, planes.data(), tw, work, energy);
     else if (f.epi == NK_EPI_MUL) nk_final_body<T, NL, CT::TILE, false, 1>(ex, pf, f, blk, planes.data(), tw, work, energy);
+    else if (f.epi == NK_EPI_LIKELIHOOD) nk_final_body<T, NL, CT::TILE, false, 3>(ex, pf, f, blk, planes.data(), tw, work, energy);
     else nk_final_body<T, NL, CT::TILE, false, -1>(ex, pf, f, blk, planes.data(), tw, work, energy);
   }
 }
