@@ -52,6 +52,9 @@ enum { NK_NL_ID = 0, NK_NL_EXP = 1, NK_NL_SIGMOID = 2 };
  *     VJP         out[o] = amp[pidx[o]] * t (+ addend_scale * addend[o]) (+ out[o] if accumulate);
  *                 abar[pidx[o]] += xi[o] * t                     (PowerDistributor adjoint, distributors.py:106-112;
  *                                                                 accumulate = sum over samples, sample_list.py:212-270)
+ *                 with `value` and `addend` set and nk_plan_octant_vjp(plan) != 0 (+ afield):
+ *                 *value += sum_o addend[o] * out[o]             (the CG curvature d.(A d) of conjugate_gradient.py:88
+ *                                                                 for addend = d, taken while out is written)
  *     LIKELIHOOD  s = t + offset, g = nonlin(s); Gaussian / Poisson energy -> *value (atomic),
  *                 out[o] = dE/ds, out2[o] = g'(s)^2 * M_d (Fisher metric weight in s-space)
  *                                                                (energy_operators.py:517-640)

@@ -111,7 +111,7 @@ __device__ __forceinline__ void nk_run_stages(C2<T>* lds, int tid, int nthr, con
 
 // block-wide fp64 sum of `acc`, one atomic per workgroup (only when the epilogue produces an energy)
 __device__ __forceinline__ void nk_flush_energy(const NkFuse& f, double acc, void* lds_raw) {
-  if (f.epi != NK_EPI_LIKELIHOOD || f.value == nullptr) return;
+  if ((f.epi != NK_EPI_LIKELIHOOD && f.epi != NK_EPI_VJP) || f.value == nullptr) return;
   __syncthreads();  // LDS tile is dead from here on
   double* red = (double*)lds_raw;
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);

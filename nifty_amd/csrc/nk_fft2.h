@@ -590,7 +590,7 @@ struct FinalCt {
   T* out;
   const T *mul, *xi, *addend, *af;
   T sc, off, asc;
-  bool accum;
+  bool accum, dot;  // dot: also accumulate sum addend[o] * out[o] (the CG curvature d.(A d) when addend = d)
 };
 template <typename T, int EC>
 NK_HD FinalCt<T> nk_final_ct(const NkFuse& f) {
@@ -604,6 +604,7 @@ NK_HD FinalCt<T> nk_final_ct(const NkFuse& f) {
   c.off = (T)f.offset;
   c.asc = (T)f.addend_scale;
   c.accum = f.accumulate != 0;
+  c.dot = EC == 2 && f.value != nullptr && f.addend != nullptr;
   return c;
 }
 
@@ -612,7 +613,7 @@ NK_HD FinalCt<T> nk_final_ct(const NkFuse& f) {
 // with 2, 0).  Returns the fp64 bin-sum contribution for EC 2.
 template <typename T, int EC, bool BOTH>
 NK_HD double nk_final_slot(const NkFuse& f, const FinalCt<T>& c, int64_t ok, int64_t om, bool self, T sg, T fx, T fy, T gx,
-                           T gy, int k2, int k2m, T a) {
+                           T gy, int k2, int k2m, T a, double& acc) {
   const T v0 = fx + sg * fy, v1 = fx - sg * fy, v2 = gx + sg * gy, v3 = gx - sg * gy;
   T* outk = c.out + ok;
   T* outm = c.out + om;
@@ -670,15 +671,17 @@ NK_HD double nk_final_slot(const NkFuse& f, const FinalCt<T>& c, int64_t ok, int
       if (BOTH) x3 = xm[k2];
     }
     T r0 = a * t0, r1 = a * t1, r2 = a * t2, r3 = a * t3;
+    T d0 = (T)0, d1 = (T)0, d2 = (T)0, d3 = (T)0;
     if (c.addend) {
       const T* ak = c.addend + ok;
       const T* am = c.addend + om;
-      r0 += c.asc * ak[k2];
-      if (BOTH) r2 += c.asc * ak[k2m];
+      d0 = ak[k2];
+      if (BOTH) d2 = ak[k2m];
       if (!self) {
-        r1 += c.asc * am[k2m];
-        if (BOTH) r3 += c.asc * am[k2];
+        d1 = am[k2m];
+        if (BOTH) d3 = am[k2];
       }
+      r0 += c.asc * d0, r1 += c.asc * d1, r2 += c.asc * d2, r3 += c.asc * d3;
     }
     if (c.accum) {
       r0 += outk[k2];
@@ -687,6 +690,12 @@ NK_HD double nk_final_slot(const NkFuse& f, const FinalCt<T>& c, int64_t ok, int
         r1 += outm[k2m];
         if (BOTH) r3 += outm[k2];
       }
+    }
+    if (c.dot) {  // d1/d3 (d2/d3) are zero when the image does not exist
+      double e = (double)d0 * (double)r0;
+      if (BOTH) e += (double)d2 * (double)r2;
+      if (!self) e += (double)d1 * (double)r1 + (BOTH ? (double)d3 * (double)r3 : 0.0);
+      acc += e;
     }
     outk[k2] = r0;
     if (BOTH) outk[k2m] = r2;
@@ -718,7 +727,7 @@ NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup
     if (!gp.mlo[h]) continue;
     const T fx = pre[gp.base[h] + d1], fy = pim[gp.base[h] + d1];
     const T gx = pre[gp.base[h] + d2], gy = pim[gp.base[h] + d2];
-    ssum += nk_final_slot<T, EC, BOTH>(f, c, gp.okh[h], gp.omh[h], gp.mlo[h] == 1, sg, fx, fy, gx, gy, k2, k2m, a);
+    ssum += nk_final_slot<T, EC, BOTH>(f, c, gp.okh[h], gp.omh[h], gp.mlo[h] == 1, sg, fx, fy, gx, gy, k2, k2m, a, acc);
   }
   if constexpr (EC == 2) {
     if (w8line)

@@ -66,6 +66,17 @@ class CgWorkspace:
         for i, (dd, qq) in enumerate(self._segments(d, q)):
             L.check(lib.nk_cg_curv(dd.numel(), dd.data_ptr(), qq.data_ptr(), B.dtype_code(dd), self.scal.data_ptr(), i, st))
 
+    def curv_slot(self):
+        """Zeroed device slot of d.q for an operator that deposits the xi part itself (``fused_dot``)."""
+        slot = self.scal[1:2]
+        slot.zero_()
+        return slot
+
+    def curv_small(self, d, q):
+        """Adds the small-part of d.q to the slot an operator has already filled with the xi part."""
+        L.check(L.load().nk_cg_curv(d.small.numel(), d.small.data_ptr(), q.small.data_ptr(), B.dtype_code(d.small),
+                                    self.scal.data_ptr(), 1, B._stream()))
+
     def update(self, x, r, d, q, b):
         lib, st = L.load(), B._stream()
         for i, (xx, rr, dd, qq, bb) in enumerate(self._segments(x, r, d, q, b)):
@@ -352,9 +363,14 @@ class FusedModel:
         self.counters["transforms"] += 1
         return (out, d) if want_derivative else out
 
-    def _vjp(self, lp, w, scale, addend, addend_scale, accumulate, out_xi):
-        """out_xi (+)= a t + addend_scale*addend,  self.abar += scatter(xi t),  t = scale * HT(w)."""
+    def _vjp(self, lp, w, scale, addend, addend_scale, accumulate, out_xi, dot_out=None):
+        """out_xi (+)= a t + addend_scale*addend,  self.abar += scatter(xi t),  t = scale * HT(w);
+        dot_out (device fp64 scalar, needs addend): += sum addend * out_xi, taken in the same epilogue."""
         f = self._fuse()
+        if dot_out is not None:
+            if addend is None or not self.octant_vjp:
+                raise ValueError("dot_out needs an addend and the register-resident transform pipeline")
+            f.value = dot_out.data_ptr()
         f.pro, f.in_ = L.PRO_PLAIN, w.data_ptr()
         f.epi, f.out, f.scale = L.EPI_VJP, out_xi.data_ptr(), self.h_dvol * scale
         f.pidx, f.amp, f.xi = self.pidx.data_ptr(), lp.amp.data_ptr(), lp.x.xi.data_ptr()
@@ -431,7 +447,7 @@ class FusedModel:
         self.counters["value_grad"] += 1
         return lp
 
-    def lh_metric_accumulate(self, lp, d, out, scale, first, identity=0.0):
+    def lh_metric_accumulate(self, lp, d, out, scale, first, identity=0.0, dot_out=None):
         """out (+)= scale * J^T M J d  (+ identity * d): the likelihood Fisher metric pulled back to latent space;
         the optional multiple of d (prior metric = 1) rides along in the VJP epilogue of the xi part."""
         L.check(L.load().nk_amp_jvp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(),
@@ -444,7 +460,7 @@ class FusedModel:
         f.dafield = self.dafield.data_ptr()
         f.epi, f.out, f.mul, f.mul_scalar = L.EPI_MUL, self.tmp.data_ptr(), B.ptr(lp.mid), lp.mid_scalar
         B.hartley_fused(self.plan, f)
-        self._vjp(lp, self.tmp, scale, d.xi if identity else None, identity, not first, out.xi)
+        self._vjp(lp, self.tmp, scale, d.xi if identity else None, identity, not first, out.xi, dot_out=dot_out)
         self.counters["transforms"] += 1
         self._amp_vjp(lp)
         if first:
@@ -455,10 +471,10 @@ class FusedModel:
                 B.axpby(identity, d.small, 1.0, out.small, out=out.small)
         self.counters["metric"] += 1
 
-    def metric(self, lp, d):
-        """(J^T M J + 1) d at the linearisation point lp."""
+    def metric(self, lp, d, dot_out=None):
+        """(J^T M J + 1) d at the linearisation point lp (dot_out: += d.xi . out.xi, see _vjp)."""
         out = LatentVec(torch.empty_like(d.xi), None)
-        self.lh_metric_accumulate(lp, d, out, 1.0, True, identity=1.0)
+        self.lh_metric_accumulate(lp, d, out, 1.0, True, identity=1.0, dot_out=dot_out)
         return out
 
     def lh_metric(self, lp, d):
@@ -508,18 +524,22 @@ class FusedModel:
         nj = self.draw_lh_noise(lp, device_rng)
         b = s + nj
         g0 = self.lh_metric(lp, s) - nj
-        A = _Callable(lambda v: self.metric(lp, v))
+        A = _Callable(lambda v, dot_out=None: self.metric(lp, v, dot_out=dot_out), fused_dot=self.octant_vjp)
         energy = QuadraticEnergy(s, A, b, _grad=g0)
         energy, _ = ConjugateGradient(controller)(energy)
         return b, energy.position
 
 
 class _Callable:
-    def __init__(self, fn):
-        self._fn = fn
+    """Operator handle for the minimisers.  ``fused_dot``: the operator can deposit the xi part of d.(A d) into a
+    device scalar while it writes A d (``A(d, dot_out=slot)``) -- ConjugateGradient then skips that BLAS-1 pass."""
 
-    def __call__(self, x):
-        return self._fn(x)
+    def __init__(self, fn, fused_dot=False):
+        self._fn = fn
+        self.fused_dot = fused_dot
+
+    def __call__(self, x, **kw):
+        return self._fn(x, **kw)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -566,29 +586,34 @@ class FusedKL(Energy):
     def at(self, position):
         return FusedKL(self.model, position, self.residuals, self.negs, self.n_total, self.comm, self.nanisinf)
 
-    def _apply_metric_local(self, d):
+    def _apply_metric_local(self, d, dot_out=None):
         """This rank's share of the KL metric applied to d (no communication)."""
         m = self.model
         out = LatentVec(torch.empty_like(d.xi), None)
         w = 1.0 / self.n_total
         nloc = len(self.lins)
         for i, lp in enumerate(self.lins):
-            # prior term (identity): every rank contributes its share nloc/n_total of d with its first sample,
-            # fused into that sample's VJP epilogue; the sum over ranks is d
-            m.lh_metric_accumulate(lp, d, out, w, i == 0, identity=nloc * w if i == 0 else 0.0)
+            # prior term (identity): every rank contributes its share nloc/n_total of d with its LAST sample, fused
+            # into that sample's VJP epilogue (the sum over ranks is d); the same epilogue sees the finished local
+            # q = A d and can take d.q on the way (single process only)
+            last = i == nloc - 1
+            m.lh_metric_accumulate(lp, d, out, w, i == 0, identity=nloc * w if last else 0.0,
+                                   dot_out=dot_out if last else None)
         if nloc == 0:
             out = LatentVec.zeros(m)
         return out
 
-    def apply_metric(self, d):
-        out = self._apply_metric_local(d)
+    def apply_metric(self, d, dot_out=None):
+        if dot_out is not None and self.comm is not None:
+            raise ValueError("the fused curvature dot is a single-process shortcut")
+        out = self._apply_metric_local(d, dot_out)
         if self.comm is not None:
             self.comm.allreduce_sum_([out.xi, out.small])
         return out
 
     @property
     def metric(self):
-        A = _Callable(self.apply_metric)
+        A = _Callable(self.apply_metric, fused_dot=self.comm is None and self.model.octant_vjp and len(self.lins) > 0)
         if self.comm is not None and self.comm.can_shard(self.model.N):
             A.sharded = ShardedMetric(self)  # picked up by ConjugateGradient: CG vectors sharded over the ranks
         return A

@@ -389,9 +389,15 @@ class ConjugateGradient(Minimizer):
         def finish(status):
             return energy.at_with_grad(x, r), status
 
+        fused_dot = bool(getattr(A, "fused_dot", False)) and hasattr(ws, "curv_slot")
         while True:
-            q = A(d)
-            ws.curv(d, q)
+            if fused_dot:
+                # the operator's last epilogue takes d.q (xi part) while it writes q: one BLAS-1 pass less
+                q = A(d, dot_out=ws.curv_slot())
+                ws.curv_small(d, q)
+            else:
+                q = A(d)
+                ws.curv(d, q)
             ws.update(x, r, d, q, b)
             since_reset += 1
             if since_reset >= self._nreset:

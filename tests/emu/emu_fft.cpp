@@ -77,7 +77,7 @@ static int emu_run(int ndim, const int64_t* shape, int dtype, int64_t batch, con
     const int64_t total_d = (int64_t)pc.g.batch * pc.g.nm * pc.g.na;
     for (int64_t gid = 0; gid < total_d; ++gid) nk_passD<T>(pc.g, *f, gid, scratch.data(), energy);
   }
-  if (f->epi == NK_EPI_LIKELIHOOD && f->value) *f->value += energy;
+  if ((f->epi == NK_EPI_LIKELIHOOD || f->epi == NK_EPI_VJP) && f->value) *f->value += energy;
   return NK_OK;
 }
 
@@ -198,7 +198,7 @@ static int emu3_run(int ndim, const int64_t* shape, int dtype, int64_t batch, co
     NK_FAST_SIZES(NK_CASE)
 #undef NK_CASE
   }
-  if (f->epi == NK_EPI_LIKELIHOOD && f->value) *f->value += energy;
+  if ((f->epi == NK_EPI_LIKELIHOOD || f->epi == NK_EPI_VJP) && f->value) *f->value += energy;
   return NK_OK;
 }
 
@@ -230,7 +230,7 @@ static int emu2_run(int ndim, const int64_t* shape, int dtype, int64_t batch, co
     NK_FAST_SIZES(NK_CASE)
 #undef NK_CASE
   }
-  if (f->epi == NK_EPI_LIKELIHOOD && f->value) *f->value += energy;
+  if ((f->epi == NK_EPI_LIKELIHOOD || f->epi == NK_EPI_VJP) && f->value) *f->value += energy;
   return NK_OK;
 }
 

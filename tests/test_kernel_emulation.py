@@ -149,8 +149,11 @@ def test_fused_prologue_epilogue_emulation(shape, fn):
     f.pidx, f.amp, f.xi, f.abar = pidx.ctypes.data, amp.ctypes.data, xi.ctypes.data, dummy.ctypes.data
     f.afield, f.field_octant, f.w8 = af8.ctypes.data, 1, w8.ctypes.data
     f.addend, f.addend_scale, f.accumulate = addend.ctypes.data, 2.0, 1
+    dq = np.zeros(1)
+    f.value = dq.ctypes.data  # fused CG curvature: sum addend * out, taken in the same epilogue
     run(f, shape, np.float64, fn=fn)
     assert np.max(np.abs(out7 - (amp[pidx] * t + 2.0 * addend + 3.0))) < 1e-11 * np.max(np.abs(t))
+    assert abs(dq[0] - np.sum(addend * out7)) < 1e-11 * np.sum(np.abs(addend * out7))
     got = np.bincount(pidx[oct_sl].ravel(), weights=w8.ravel(), minlength=nb)
     assert np.max(np.abs(got - ref_abar)) < 1e-10 * max(1.0, np.max(np.abs(ref_abar)))
     assert np.all(dummy == 0.0)
