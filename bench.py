@@ -69,7 +69,7 @@ def collect_profile():
     return out
 
 
-def cpu_baseline(counts_per_step, shape_full, sample_shape=(128, 128, 128), budget_s=20.0):
+def cpu_baseline(counts_per_step, shape_full, sample_shape=(128, 128, 128), budget_s=20.0, device=None):
     """Oracle (numpy + scipy.fft restatement of the reference path) timed on the host cores on a bounded
     sample, extrapolated with N log N to the full workload.  A reported baseline, not a target."""
     from oracle import nifty_oracle as orc
@@ -82,7 +82,20 @@ def cpu_baseline(counts_per_step, shape_full, sample_shape=(128, 128, 128), budg
     data = cf.forward(x) + 0.1 * rng.normal(size=sample_shape)
     lh = orc.Likelihood("gaussian", data, icov=100.0)
     lin = orc.Linearized(cf, lh, x)
-    lin.metric(v)
+    mv = lin.metric(v)
+    # parity of the HIP path against the oracle on this very sample (<= 1e-5 relative, asserted in the run)
+    parity = None
+    if device is not None:
+        from nifty_amd.engine import FusedModel, LatentVec
+
+        model = FusedModel(sample_shape, offset_mean=2.0, likelihood="gaussian", data=data, icov=100.0, device=device)
+        lp = model.linearize(LatentVec.from_dict(model, x))
+        got = model.metric(lp, LatentVec.from_dict(model, v)).to_dict()
+        val_o, _ = lin.value_grad()
+        parity = max(float(np.max(np.abs(got[k] - mv[k])) / np.max(np.abs(mv[k]))) for k in ("xi", "spectrum"))
+        parity = max(parity, abs(float(lp.value.item()) - val_o) / abs(val_o))
+        assert parity < 1e-5, f"HIP path deviates from the oracle: {parity}"
+        del model, lp
     t_met, t_vg, n = 0.0, 0.0, 0
     t_start = time.perf_counter()
     while time.perf_counter() - t_start < budget_s or n < 2:
@@ -98,7 +111,7 @@ def cpu_baseline(counts_per_step, shape_full, sample_shape=(128, 128, 128), budg
     Ns, Nf = float(np.prod(sample_shape)), float(np.prod(shape_full))
     scale = (Nf * math.log2(Nf)) / (Ns * math.log2(Ns))
     sec_per_step = scale * (counts_per_step["metric"] * t_met + counts_per_step["value_grad"] * t_vg)
-    return dict(value=1.0 / sec_per_step, unit="MGVI iters/s", cores=cores, kind="port",
+    return dict(value=1.0 / sec_per_step, unit="MGVI iters/s", cores=cores, kind="port", parity_rel_err_vs_hip=parity,
                 sample=(f"oracle (numpy+scipy.fft, workers={cores}) metric apply {t_met * 1e3:.1f} ms and value+gradient "
                         f"{t_vg * 1e3:.1f} ms per sample at {'x'.join(map(str, sample_shape))} fp64 ({n} reps), "
                         f"extrapolated x{scale:.0f} (N log N) to {'x'.join(map(str, shape_full))} and multiplied by the "
@@ -247,7 +260,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(counts, shape)
+                line["cpu_baseline"] = cpu_baseline(counts, shape, device=device)
             except Exception as exc:  # the baseline must never take the bench line down
                 line["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(line))
