@@ -82,7 +82,7 @@ NK_HD C2<T> cmul_mi(C2<T> a) {
 // digit-reversed order and un-reversed by the store phase.
 // ---------------------------------------------------------------------------------------------
 struct NkLinePlan {
-  int n;                       // complex line length (power of two, >= 1)
+  int n;                       // complex line length (product of radices 8, 4, 2, 3, 5, 7; >= 1)
   int nstage;                  // number of DIF stages
   int radix[NK_MAX_STAGES];    // radices in execution order
 };
@@ -92,7 +92,7 @@ NK_HD int nk_digit_reverse(const NkLinePlan& lp, int k) {
   for (int s = 0; s < lp.nstage; ++s) {
     const int R = lp.radix[s];
     span /= R;
-    p += (k & (R - 1)) * span;
+    p += (k % R) * span;
     k /= R;
   }
   return p;
@@ -162,6 +162,66 @@ struct Butterfly<T, 8> {
   }
 };
 
+// odd radices 3, 5, 7: plain O(R^2) DFT with compile-time roots of unity (natural order in and out)
+template <int R>
+struct NkRoot;
+template <>
+struct NkRoot<3> {
+  static constexpr double c[3] = {1.0, -0.5, -0.5};
+  static constexpr double s[3] = {0.0, 0.86602540378443864676, -0.86602540378443864676};
+};
+template <>
+struct NkRoot<5> {
+  static constexpr double c[5] = {1.0, 0.30901699437494742410, -0.80901699437494742410, -0.80901699437494742410,
+                                  0.30901699437494742410};
+  static constexpr double s[5] = {0.0, 0.95105651629515357212, 0.58778525229247312917, -0.58778525229247312917,
+                                  -0.95105651629515357212};
+};
+template <>
+struct NkRoot<7> {
+  static constexpr double c[7] = {1.0, 0.62348980185873353053, -0.22252093395631440429, -0.90096886790241912624,
+                                  -0.90096886790241912624, -0.22252093395631440429, 0.62348980185873353053};
+  static constexpr double s[7] = {0.0, 0.78183148246802980871, 0.97492791218182360702, 0.43388373911755812048,
+                                  -0.43388373911755812048, -0.97492791218182360702, -0.78183148246802980871};
+};
+template <typename T, int R>
+struct ButterflyOdd {
+  static NK_HD void run(C2<T>* v) {
+    C2<T> o[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      C2<T> acc = v[0];
+#pragma unroll
+      for (int r = 1; r < R; ++r) {
+        const int k = (q * r) % R;  // w_R^{qr} = cos(2 pi k/R) - i sin(2 pi k/R)
+        const T c = (T)NkRoot<R>::c[k], sn = (T)NkRoot<R>::s[k];
+        acc.x += v[r].x * c + v[r].y * sn;
+        acc.y += v[r].y * c - v[r].x * sn;
+      }
+      o[q] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = o[q];
+  }
+};
+template <typename T>
+struct Butterfly<T, 3> : ButterflyOdd<T, 3> {};
+template <typename T>
+struct Butterfly<T, 5> : ButterflyOdd<T, 5> {};
+template <typename T>
+struct Butterfly<T, 7> : ButterflyOdd<T, 7> {};
+
+// run-time radix -> compile-time stage
+#define NK_STAGE_DISPATCH(RADIX, ...)                       \
+  switch (RADIX) {                                          \
+    case 8: nk_dif_stage<T, 8>(__VA_ARGS__); break;         \
+    case 4: nk_dif_stage<T, 4>(__VA_ARGS__); break;         \
+    case 2: nk_dif_stage<T, 2>(__VA_ARGS__); break;         \
+    case 3: nk_dif_stage<T, 3>(__VA_ARGS__); break;         \
+    case 5: nk_dif_stage<T, 5>(__VA_ARGS__); break;         \
+    default: nk_dif_stage<T, 7>(__VA_ARGS__); break;        \
+  }
+
 // one in-place DIF stage of radix R on sub-blocks of length L for all `tile` lines in LDS
 template <typename T, int R>
 NK_HD void nk_dif_stage(C2<T>* lds, int tid, int nthr, const NkLinePlan& lp, const NkTile& tl, int L,
@@ -179,8 +239,9 @@ NK_HD void nk_dif_stage(C2<T>* lds, int tid, int nthr, const NkLinePlan& lp, con
       bf = idx % nbf;
       t = idx / nbf;
     }
-    const int j = bf & (Lr - 1);
-    const int base = (bf / Lr) * L + j;
+    const int blk = bf / Lr;
+    const int j = bf - blk * Lr;
+    const int base = blk * L + j;
     C2<T> v[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) v[r] = lds[nk_lds_addr(tl, base + r * Lr, t)];

@@ -98,12 +98,7 @@ __device__ __forceinline__ void nk_run_stages(C2<T>* lds, int tid, int nthr, con
   int L = lp.n;
   for (int s = 0; s < lp.nstage; ++s) {
     const int R = lp.radix[s];
-    if (R == 8)
-      nk_dif_stage<T, 8>(lds, tid, nthr, lp, tl, L, tw);
-    else if (R == 4)
-      nk_dif_stage<T, 4>(lds, tid, nthr, lp, tl, L, tw);
-    else
-      nk_dif_stage<T, 2>(lds, tid, nthr, lp, tl, L, tw);
+    NK_STAGE_DISPATCH(R, lds, tid, nthr, lp, tl, L, tw)
     L /= R;
     __syncthreads();
   }

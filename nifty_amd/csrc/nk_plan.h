@@ -9,20 +9,34 @@
 
 static inline bool nk_is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// radices 8/4/2 first, then the odd ones; nstage = -1 when n has a prime factor > 7 or needs too many stages
 static inline NkLinePlan nk_make_line_plan(int n) {
   NkLinePlan lp{};
   lp.n = n;
   lp.nstage = 0;
   int rem = n;
   while (rem > 1) {
-    int R = (rem % 8 == 0) ? 8 : (rem % 4 == 0) ? 4 : 2;
-    // avoid a trailing radix-2 after radix-8 stages when a 4x4 split is possible (8*2 -> 4*4)
-    if (R == 8 && rem == 16) R = 4;
+    int R;
+    if (rem % 8 == 0) R = (rem == 16) ? 4 : 8;  // 8*2 -> 4*4
+    else if (rem % 4 == 0) R = 4;
+    else if (rem % 2 == 0) R = 2;
+    else if (rem % 3 == 0) R = 3;
+    else if (rem % 5 == 0) R = 5;
+    else if (rem % 7 == 0) R = 7;
+    else {
+      lp.nstage = -1;
+      return lp;
+    }
+    if (lp.nstage == NK_MAX_STAGES) {
+      lp.nstage = -1;
+      return lp;
+    }
     lp.radix[lp.nstage++] = R;
     rem /= R;
   }
   return lp;
 }
+static inline bool nk_factorable(int64_t n) { return n >= 1 && n < ((int64_t)1 << 30) && nk_make_line_plan((int)n).nstage >= 0; }
 
 static inline int nk_env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -69,14 +83,15 @@ static inline int nk_pick_strided_tile(int n, int64_t inner, size_t csize, const
   int forced = nk_env_int(env, 0);
   size_t budget = 64 * 1024;
   int T = 1;
-  while ((int64_t)T * 2 <= inner && (size_t)n * (T * 2) * csize <= budget && (size_t)(T * 2) * csize <= 256) T *= 2;
+  auto fits = [&](int t) { return (int64_t)t <= inner && inner % t == 0; };  // tiles must divide the row count
+  while (fits(T * 2) && (size_t)n * (T * 2) * csize <= budget && (size_t)(T * 2) * csize <= 256) T *= 2;
   if ((size_t)T * csize < 64) {  // rows shorter than 64 B: allow one workgroup per CU
     budget = 128 * 1024;
-    while ((int64_t)T * 2 <= inner && (size_t)n * (T * 2) * csize <= budget && (size_t)(T * 2) * csize <= 256) T *= 2;
+    while (fits(T * 2) && (size_t)n * (T * 2) * csize <= budget && (size_t)(T * 2) * csize <= 256) T *= 2;
   }
   if (forced > 0) {
     T = 1;
-    while (T * 2 <= forced && (int64_t)T * 2 <= inner && (size_t)n * (T * 2) * csize <= 152 * 1024) T *= 2;
+    while (T * 2 <= forced && fits(T * 2) && (size_t)n * (T * 2) * csize <= 152 * 1024) T *= 2;
   }
   return T;
 }
@@ -102,13 +117,13 @@ static inline int nk_host_plan_init(NkHostPlan& P, int ndim, const int64_t* shap
       *msg = "axis lengths must be positive";
       return NK_ERR_INVALID;
     }
-    if (!nk_is_pow2(shape[d])) {
-      *msg = "axis lengths must be powers of two (mixed radix is not implemented yet)";
+    if (!nk_factorable(shape[d])) {
+      *msg = "axis lengths must factor into 2, 3, 5 and 7";
       return NK_ERR_UNSUPPORTED;
     }
   }
-  if (shape[ndim - 1] < 2) {
-    *msg = "last axis must have length >= 2";
+  if (shape[ndim - 1] < 2 || shape[ndim - 1] % 2 != 0) {
+    *msg = "the last axis must have an even length >= 2 (real-to-complex packing)";
     return NK_ERR_UNSUPPORTED;
   }
   P.dtype = dtype;

@@ -22,9 +22,7 @@ static void run_stages(C2<T>* lds, int nthr, const NkLinePlan& lp, const NkTile&
   for (int s = 0; s < lp.nstage; ++s) {
     const int R = lp.radix[s];
     for (int tid = 0; tid < nthr; ++tid) {
-      if (R == 8) nk_dif_stage<T, 8>(lds, tid, nthr, lp, tl, L, tw);
-      else if (R == 4) nk_dif_stage<T, 4>(lds, tid, nthr, lp, tl, L, tw);
-      else nk_dif_stage<T, 2>(lds, tid, nthr, lp, tl, L, tw);
+      NK_STAGE_DISPATCH(R, lds, tid, nthr, lp, tl, L, tw)
     }
     L /= R;
   }

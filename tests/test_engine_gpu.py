@@ -83,7 +83,11 @@ def test_mgvi_samples_kl_newton_vs_reference_golden(case):
 
 
 @pytest.mark.parametrize("shape,kind,nonlin", [((256,), "gaussian", None), ((128, 64), "poisson", "exp"),
-                                               ((32, 16, 64), "gaussian", "sigmoid"), ((64, 64, 64), "gaussian", None)])
+                                               ((32, 16, 64), "gaussian", "sigmoid"), ((64, 64, 64), "gaussian", None),
+                                               # non-power-of-two grids (mixed radix 2/3/5/7, generic kernels)
+                                               ((30, 50), "gaussian", None), ((12, 10, 14), "poisson", "exp"),
+                                               # strided-first pipeline with unequal axes
+                                               ((128, 64, 256), "gaussian", None)])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_engine_vs_oracle_seeded(shape, kind, nonlin, dtype):
     """Same seeded inputs through the HIP engine and the numpy oracle; fp32 fields use fp64 accumulators."""

@@ -32,7 +32,10 @@ def fast_fn(shape):
 
 
 @pytest.mark.parametrize("shape", [(2,), (8,), (64,), (1024,), (2, 2), (4, 16), (32, 8), (64, 64), (2, 2, 2), (8, 4, 16),
-                                   (16, 16, 16), (2, 32, 4)])
+                                   (16, 16, 16), (2, 32, 4),
+                                   # mixed radix 2/3/5/7 (generic kernels; reference test_fft_operator.py:58-103 sizes)
+                                   (6,), (10,), (12,), (30,), (210,), (98,), (500,), (3, 4), (6, 10), (15, 14), (50, 18),
+                                   (5, 7, 12), (10, 6, 12), (9, 25, 28)])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_hartley_emulation(shape, dtype):
     rng = np.random.default_rng(0)
@@ -63,6 +66,7 @@ def test_fast_path_emulation(shape, dtype):
 
 
 FUSED_SHAPES = [((64,), "emu_hartley_fused"), ((16, 8), "emu_hartley_fused"), ((8, 4, 16), "emu_hartley_fused"),
+                ((30,), "emu_hartley_fused"), ((10, 12), "emu_hartley_fused"), ((6, 5, 14), "emu_hartley_fused"),
                 ((256,), "emu2_hartley_fused"), ((64, 128), "emu3_hartley_fused"), ((64, 64, 64), "emu3_hartley_fused")]
 
 

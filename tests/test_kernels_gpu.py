@@ -63,10 +63,38 @@ def test_hartley_full_size_properties(shape, dtype):
 def test_unsupported_shapes_raise():
     from nifty_amd import backend as B
 
-    with pytest.raises(NotImplementedError):
-        B.hartley(torch.zeros(12, device="cuda", dtype=torch.float64))
+    with pytest.raises(NotImplementedError):  # prime factor > 7
+        B.hartley(torch.zeros(22, device="cuda", dtype=torch.float64))
+    with pytest.raises(NotImplementedError):  # odd last axis (real-to-complex packing)
+        B.hartley(torch.zeros(8, 15, device="cuda", dtype=torch.float64))
     with pytest.raises(RuntimeError):
         B.hartley(torch.zeros(16, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("shape", [(12,), (30,), (1000,), (6, 10), (15, 14), (120, 250), (100, 100), (9, 25, 28), (60, 50, 48),
+                                   (192, 320), (96, 96, 96)])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_mixed_radix_transforms(shape, dtype):
+    """Axis lengths with factors 2, 3, 5, 7 (ducc0 accepts any length; reference test_fft_operator.py:58-103 uses 10, 11, 12
+    -- 11 stays unsupported) against scipy.fft on the host."""
+    import scipy.fft
+
+    from nifty_amd import backend as B
+
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=shape)
+    xd = torch.from_numpy(x).to(dtype).cuda()
+    F = scipy.fft.fftn(xd.cpu().numpy().astype(np.float64))
+    tol = 1e-12 if dtype == torch.float64 else 3e-5
+    got = B.hartley(xd).cpu().numpy()
+    assert gl.relerr(got, F.real + F.imag) < tol
+    xc = (rng.normal(size=shape) + 1j * rng.normal(size=shape))
+    xcd = torch.from_numpy(xc).to(torch.complex128 if dtype == torch.float64 else torch.complex64).cuda()
+    ref = scipy.fft.fftn(xcd.cpu().numpy().astype(np.complex128))
+    got = B.fftn(xcd, inverse=False, scale=1.0).cpu().numpy()
+    assert gl.relerr(got, ref) < tol
+    got = B.fftn(xcd, inverse=True, scale=1.0 / xc.size).cpu().numpy()
+    assert gl.relerr(got, scipy.fft.ifftn(xcd.cpu().numpy().astype(np.complex128))) < tol
 
 
 @pytest.mark.parametrize("shape", [(64,), (32, 64), (64, 64, 64), (128, 64, 256), (256, 256, 256)])
