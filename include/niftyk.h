@@ -152,6 +152,16 @@ int nk_gather(int64_t n, const void* table, const int32_t* pidx, void* out, int 
 int nk_scatter_add(int64_t n, const void* in, const int32_t* pidx, int64_t nbins, void* bins, int dtype,
                    void* stream);
 
+/* ---- sparse line-of-sight response: replaces scipy.sparse matvec / rmatvec of LOSResponse.apply
+ *      (library/los_response.py:244-253).  CSR: rowptr[nrows+1] (int64), col (int32 pixel index), wgt (float32, as the
+ *      reference stores them, :196); x / y in the field dtype, fp64 accumulation.
+ * nk_spmv  : y[i] = sum_j wgt[j] * x[col[j]]
+ * nk_spmv_t: x64[col[j]] += wgt[j] * y[i] on a caller-zeroed fp64 array (cast to the field dtype afterwards) */
+int nk_spmv(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, const void* x, void* y, int dtype,
+            void* stream);
+int nk_spmv_t(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, const void* y, double* x64,
+              int dtype, void* stream);
+
 /* dst[0..n) = sum over c < copies of src[c*stride + (0..n)]  (folds the per-XCD VJP accumulators) */
 int nk_fold_copies(int64_t n, int copies, int64_t stride, const double* src, double* dst, void* stream);
 

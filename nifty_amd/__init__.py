@@ -23,9 +23,10 @@ from .minimization import (AbsDeltaEnergyController, ConjugateGradient, DeltaEne
                            LineSearch, NewtonCG, QuadraticEnergy, SteepestDescent)
 from .operators import (Adder, BlockDiagonalOperator, ChainOperator, ContractionOperator, DiagonalOperator,  # noqa: F401
                         DOFDistributor, EndomorphicOperator, FFTOperator, FieldAdapter, HarmonicTransformOperator,
-                        HartleyOperator, Linearization, LinearOperator, NullOperator, Operator, OperatorAdapter,
+                        HartleyOperator, Linearization, LinearOperator, MaskOperator, NullOperator, Operator, OperatorAdapter,
                         PowerDistributor, Realizer, SamplingEnabler, SandwichOperator, ScalingOperator, SumOperator,
                         Variable, VdotOperator, ducktape, makeOp)
+from .los_response import LOSResponse  # noqa: F401
 from .optimize_kl import optimize_kl  # noqa: F401
 from .parallel import shareRange  # noqa: F401
 

@@ -182,3 +182,21 @@ def scatter_add(x, pidx, nbins):
     L.check(L.load().nk_scatter_add(x.numel(), x.data_ptr(), pidx.data_ptr(), nbins, bins.data_ptr(), dtype_code(x),
                                     _stream()), "nk_scatter_add")
     return bins
+
+
+def spmv(rowptr, col, wgt, x, nrows):
+    """y = R x for a CSR response (LOSResponse TIMES)."""
+    _require_device(x, col)
+    y = torch.empty(nrows, dtype=x.dtype, device=x.device)
+    L.check(L.load().nk_spmv(nrows, rowptr.data_ptr(), col.data_ptr(), wgt.data_ptr(), x.data_ptr(), y.data_ptr(),
+                             dtype_code(x), _stream()), "nk_spmv")
+    return y
+
+
+def spmv_t(rowptr, col, wgt, y, ncols):
+    """x = R^T y (LOSResponse ADJOINT_TIMES): fp64 atomics, returned in y's dtype."""
+    _require_device(y, col)
+    x64 = torch.zeros(ncols, dtype=torch.float64, device=y.device)
+    L.check(L.load().nk_spmv_t(y.numel(), rowptr.data_ptr(), col.data_ptr(), wgt.data_ptr(), y.data_ptr(), x64.data_ptr(),
+                               dtype_code(y), _stream()), "nk_spmv_t")
+    return x64.to(y.dtype)  # dtype conversion copy only (same convention as scatter_add's callers)

@@ -697,3 +697,54 @@ extern "C" int nk_octant_scatter_k2(int ndim, const int64_t* shape, const double
   if (rc != NK_OK) return rc;
   return nk_fold_copies(nb, NK_SHELL_SPLITS, pstride, scratch, abar, stream);
 }
+
+// ---- sparse response (LOSResponse, reference library/los_response.py:144-253): CSR with int32 columns and
+//      float32 weights (the reference stores float32 weights too, :196), fp64 accumulation ------------------
+// y[i] = sum_j wgt[j] * x[col[j]]  over rowptr[i] <= j < rowptr[i+1]; one wavefront per row
+template <typename T>
+__global__ void k_spmv(int64_t nrows, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                       const float* __restrict__ wgt, const T* __restrict__ x, T* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int64_t lo = rowptr[row], hi = rowptr[row + 1];
+  double acc = 0.0;
+  for (int64_t j = lo + lane; j < hi; j += 64) acc += (double)wgt[j] * (double)x[col[j]];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) y[row] = (T)acc;
+}
+
+// x[col[j]] += wgt[j] * y[i]: adjoint of the above by atomics on a pre-zeroed x (rows overlap arbitrarily)
+template <typename T>
+__global__ void k_spmv_t(int64_t nrows, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                         const float* __restrict__ wgt, const T* __restrict__ y, double* __restrict__ x) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int64_t lo = rowptr[row], hi = rowptr[row + 1];
+  const double yv = (double)y[row];
+  for (int64_t j = lo + lane; j < hi; j += 64) atomicAdd(x + col[j], (double)wgt[j] * yv);
+}
+
+extern "C" int nk_spmv(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, const void* x, void* y,
+                       int dtype, void* stream) {
+  if (nrows < 0 || !rowptr || (nrows > 0 && (!x || !y))) return nk_set_error(NK_ERR_INVALID, "nk_spmv: bad argument");
+  if (nrows == 0) return NK_OK;
+  const unsigned blocks = (unsigned)((nrows + 3) / 4);
+  NK_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL(k_spmv<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nrows, rowptr, col, wgt, (const T*)x,
+                       (T*)y);
+  })
+  return nk_check_launch("k_spmv");
+}
+
+extern "C" int nk_spmv_t(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, const void* y,
+                         double* x, int dtype, void* stream) {
+  if (nrows < 0 || !rowptr || (nrows > 0 && (!x || !y))) return nk_set_error(NK_ERR_INVALID, "nk_spmv_t: bad argument");
+  if (nrows == 0) return NK_OK;
+  const unsigned blocks = (unsigned)((nrows + 3) / 4);
+  NK_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL(k_spmv_t<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nrows, rowptr, col, wgt, (const T*)y, x);
+  })
+  return nk_check_launch("k_spmv_t");
+}

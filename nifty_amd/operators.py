@@ -1407,6 +1407,42 @@ class PowerDistributor(DOFDistributor):
         self._init2(torch.from_numpy(np.array(power_space.pindex)), power_space.shape[0], power_space)
 
 
+class MaskOperator(LinearOperator):
+    """Keeps the un-flagged pixels of a field in an UnstructuredDomain (reference mask_operator.py:26-58): flags are
+    converted to boolean, True = flagged.  TIMES compresses, ADJOINT_TIMES expands with zeros."""
+
+    def __init__(self, flags):
+        if not isinstance(flags, Field):
+            raise TypeError
+        self._domain = DomainTuple.make(flags.domain)
+        keep = torch.logical_not(flags.val.to(torch.bool)).reshape(-1)
+        self._keep = torch.nonzero(keep.cpu()).reshape(-1)  # int64 flat indices of the kept pixels, ascending
+        self._target = DomainTuple.make(UnstructuredDomain(int(self._keep.numel())))
+        self._capability = self.TIMES | self.ADJOINT_TIMES
+        self._idx32 = {}
+
+    def _device_index(self, device):
+        key = str(device)
+        if key not in self._idx32:
+            self._idx32[key] = self._keep.to(torch.int32).to(device).contiguous()
+        return self._idx32[key]
+
+    def apply(self, x, mode):
+        self._check_input(x, mode)
+        v = x.val
+        if mode == self.TIMES:
+            if v.is_cuda:
+                return Field(self._target, B.gather(v.contiguous().reshape(-1), self._device_index(v.device),
+                                                    self._target.shape))
+            return Field(self._target, v.reshape(-1)[self._keep])
+        if v.is_cuda:  # unique indices: the scatter-add kernel is a plain scatter here
+            full = B.scatter_add(v.contiguous(), self._device_index(v.device), self._domain.size)
+            return Field(self._domain, full.to(v.dtype).reshape(self._domain.shape))
+        out = torch.zeros(self._domain.size, dtype=v.dtype)
+        out[self._keep] = v
+        return Field(self._domain, out.reshape(self._domain.shape))
+
+
 # ================================================================================================
 # sampling
 # ================================================================================================

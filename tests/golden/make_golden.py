@@ -163,7 +163,97 @@ def model_case(name, shape, distances, kind, nonlin, n_samples, geo, seed=42, sa
     print("wrote", name, {k: out[k].shape for k in ("cf", "x.spectrum")})
 
 
+def los_rays(shape, dist, nlos, seed, with_sigma):
+    """Random lines of sight incl. the special cases: axis-aligned, completely outside, leaving the box."""
+    rng = np.random.default_rng(seed)
+    nd = len(shape)
+    L = np.array(shape) * np.array(dist)
+    starts = rng.uniform(-0.1, 1.1, size=(nd, nlos)) * L[:, None]
+    ends = rng.uniform(-0.1, 1.1, size=(nd, nlos)) * L[:, None]
+    if nd > 1:
+        ends[0, 0] = starts[0, 0]
+        starts[:, 1], ends[:, 1] = -L, -0.5 * L
+    sig = None
+    if with_sigma:
+        ln = np.linalg.norm(ends - starts, axis=0)
+        sig = np.minimum(rng.uniform(0.01, 0.05, size=nlos), 0.3 / (3 * ln))
+    return starts, ends, sig
+
+
+def los_cases():
+    """LOSResponse (library/los_response.py) matrices and products, MaskOperator products, and a config-4 style
+    geoVI run: sigmoid(cf) -> LOS -> mask -> Gaussian noise."""
+    out = {}
+    for tag, shape, dist, nlos, sig in [("a", (20, 28), (0.05, 0.04), 14, False), ("b", (20, 28), (0.05, 0.04), 14, True),
+                                        ("c", (6, 8, 10), (0.5, 0.25, 0.2), 10, True), ("d", (16,), (0.1,), 6, False)]:
+        starts, ends, sigmas = los_rays(shape, dist, nlos, 3, sig)
+        sp = ift.RGSpace(shape, dist)
+        R = ift.LOSResponse(sp, starts, ends, sigmas)
+        rng = np.random.default_rng(5)
+        x, y = rng.normal(size=shape), rng.normal(size=nlos)
+        out[f"{tag}.shape"], out[f"{tag}.dist"] = np.array(shape), np.array(dist)
+        out[f"{tag}.starts"], out[f"{tag}.ends"] = starts, ends
+        out[f"{tag}.sigmas"] = np.array([np.nan]) if sigmas is None else sigmas
+        out[f"{tag}.dense"] = R._smat.toarray()
+        out[f"{tag}.x"], out[f"{tag}.y"] = x, y
+        out[f"{tag}.times"] = R(ift.makeField(R.domain, x)).asnumpy()
+        out[f"{tag}.adjoint"] = R.adjoint(ift.makeField(R.target, y)).asnumpy()
+    # MaskOperator
+    rng = np.random.default_rng(6)
+    flags = rng.uniform(size=(12, 9)) < 0.3
+    sp = ift.RGSpace((12, 9))
+    M = ift.MaskOperator(ift.makeField(sp, flags))
+    x, y = rng.normal(size=(12, 9)), rng.normal(size=M.target.shape)
+    out["mask.flags"], out["mask.x"], out["mask.y"] = flags, x, y
+    out["mask.times"] = M(ift.makeField(M.domain, x)).asnumpy()
+    out["mask.adjoint"] = M.adjoint(ift.makeField(M.target, y)).asnumpy()
+    # config-4 style model (demos/cl/getting_started_3.py:48-51, 98-127): sigmoid(cf), masked LOS response, geoVI
+    seed = 42
+    ift.random.push_sseq_from_seed(seed)
+    shape = (16, 16)
+    sp = ift.RGSpace(shape)
+    cfm, cf = make_cf(sp)
+    signal = cf.ptw("sigmoid")
+    starts, ends, _ = los_rays(shape, (1 / 16, 1 / 16), 40, 8, False)
+    R = ift.LOSResponse(sp, starts, ends)
+    flags = np.zeros(40, dtype=bool)
+    flags[[3, 17, 29]] = True
+    Mk = ift.MaskOperator(ift.makeField(R.target, flags))
+    resp = Mk @ R @ signal
+    truth = ift.from_random(cf.domain)
+    noise = 1e-3
+    d = resp(truth) + ift.from_random(resp.target) * np.sqrt(noise)
+    lh = ift.GaussianEnergy(d, ift.ScalingOperator(resp.target, 1.0 / noise, np.float64)) @ resp
+    x = ift.from_random(cf.domain) * 0.1 + truth * 0.5
+    v = ift.from_random(cf.domain)
+    out["c4.starts"], out["c4.ends"], out["c4.flags"], out["c4.data"] = starts, ends, flags, d.asnumpy()
+    out.update(mf2dict(x, "c4.x"))
+    out.update(mf2dict(v, "c4.v"))
+    out["c4.resp"] = resp(x).asnumpy()
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=6)
+    ham = ift.StandardHamiltonian(lh, ic, prior_sampling_dtype=np.float64)
+    hl = ham(ift.Linearization.make_var(x, want_metric=True))
+    out["c4.ham_value"] = np.array(hl.val.val.asnumpy())
+    out.update(mf2dict(hl.gradient, "c4.ham_grad"))
+    out.update(mf2dict(hl.metric(v), "c4.ham_metric_v"))
+    ift.random.push_sseq_from_seed(seed + 2)
+    mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=8)
+    nl = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=3, convergence_level=2), max_cg_iterations=GEO_CG)
+    sl, mean = ift.optimize_kl(lh, 2, 1, mk, ic, nonlinear_sampling_minimizer=nl, output_directory=None,
+                               return_final_position=True, initial_position=x, plot_energy_history=False,
+                               plot_minisanity_history=False)
+    ift.random.pop_sseq()
+    ift.random.pop_sseq()
+    out.update(mf2dict(mean, "c4.okl_mean"))
+    for i, s in enumerate(sl.iterator()):
+        out.update(mf2dict(s, f"c4.okl_sample{i}"))
+    np.savez_compressed(os.path.join(HERE, "los.npz"), **out)
+    print("wrote los", out["a.dense"].shape, out["c4.resp"].shape)
+
+
 def main():
+    if "--los-only" in sys.argv:
+        return los_cases()
     geo = {}
     for shape, dist in [((8,), None), ((7, 8), None), ((4, 5, 7), None), ((512,), None), ((64, 64), None),
                         ((16, 16, 16), None), ((16, 32), (0.3, 0.2)), ((12,), (0.7,))]:
@@ -187,6 +277,7 @@ def main():
     model_case("g2d_dist", (16, 32), (0.3, 0.2), "gaussian", None, 1, False, diag_icov=True)
     model_case("p2d_geo", (32, 32), None, "poisson", "exp", 1, True, run_optimize=True)
     model_case("g2d_sig_geo", (16, 16), None, "gaussian", "sigmoid", 1, True)
+    los_cases()
 
 
 if __name__ == "__main__":

@@ -50,9 +50,12 @@ def test_plan_errors_without_gpu_are_clean():
 
     lib = _lib.load()
     p = ctypes.c_void_p()
-    shp = (ctypes.c_int64 * 1)(12)
+    shp = (ctypes.c_int64 * 1)(22)  # prime factor 11: only 2, 3, 5, 7 are implemented
     rc = lib.nk_plan_create(ctypes.byref(p), 1, shp, _lib.NK_F64, 1)
-    assert rc == _lib.NK_ERR_UNSUPPORTED and b"powers of two" in lib.nk_last_error()
+    assert rc == _lib.NK_ERR_UNSUPPORTED and b"factor into 2, 3, 5 and 7" in lib.nk_last_error()
+    shp = (ctypes.c_int64 * 1)(15)  # odd last axis
+    rc = lib.nk_plan_create(ctypes.byref(p), 1, shp, _lib.NK_F64, 1)
+    assert rc == _lib.NK_ERR_UNSUPPORTED and b"even length" in lib.nk_last_error()
     rc = lib.nk_plan_create(ctypes.byref(p), 4, shp, _lib.NK_F64, 1)
     assert rc == _lib.NK_ERR_UNSUPPORTED
     rc = lib.nk_vdot(-1, None, None, _lib.NK_F64, None, 0, None)
