@@ -325,7 +325,8 @@ NK_HD C2<T> nk_prologue_pair(const NkFuse& f, int64_t i) {
 }
 
 // compile-time specialised pair prologues of the hot configurations (no run-time switch in the load loop):
-//   PC = 0 plain, 1 afield*in, 2 afield*in + dampT[pidx]*in2, 3 afield*in + dafield*in2, else generic run-time version
+//   PC = 0 plain, 1 afield*in, 2 afield*in + dampT[pidx]*in2, 3 afield*in + dafield*in2, 6 in*in2,
+//   else generic run-time version
 // iu: wave-uniform part of the flat index (scalar registers), it: per-thread part (32 bit)
 template <typename T, int PC>
 NK_HD C2<T> nk_prologue_ct(const NkFuse& f, int64_t iu, uint32_t it) {
@@ -348,6 +349,10 @@ NK_HD C2<T> nk_prologue_ct(const NkFuse& f, int64_t iu, uint32_t it) {
     const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
     const C2<T> dm = *reinterpret_cast<const C2<T>*>((const T*)f.dafield + iu + it);
     return C2<T>{m.x * a.x + dm.x * x.x, m.y * a.y + dm.y * x.y};
+  } else if constexpr (PC == 6) {  // MUL: in * in2
+    const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
+    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
+    return C2<T>{a.x * x.x, a.y * x.y};
   } else {
     return C2<T>{nk_prologue<T>(f, iu + it), nk_prologue<T>(f, iu + it + 1)};
   }

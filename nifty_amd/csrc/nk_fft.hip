@@ -318,6 +318,7 @@ static int nk_launch_strided(const NkPassS& ps, const NkFuse& f, const C2<T>* tw
     if (f.field_octant && f.pro == NK_PRO_AMP) return nk_launch_strided_pc<T, N, MODE, 4>(ps, f, tw, work, scratch, st);
     if (f.field_octant && f.pro == NK_PRO_AMP_JVP) return nk_launch_strided_pc<T, N, MODE, 5>(ps, f, tw, work, scratch, st);
     if (f.pro == NK_PRO_PLAIN) return nk_launch_strided_pc<T, N, MODE, 0>(ps, f, tw, work, scratch, st);
+    if (f.pro == NK_PRO_MUL) return nk_launch_strided_pc<T, N, MODE, 6>(ps, f, tw, work, scratch, st);
     if (f.pro == NK_PRO_AMP && f.afield) return nk_launch_strided_pc<T, N, MODE, 1>(ps, f, tw, work, scratch, st);
     if (f.pro == NK_PRO_AMP_JVP && f.afield && f.dafield)
       return nk_launch_strided_pc<T, N, MODE, 3>(ps, f, tw, work, scratch, st);

@@ -223,7 +223,7 @@ class LatentVec:
 class LinPoint:
     """Everything cached about one latent point: amplitude tables and the s-space metric weight."""
 
-    __slots__ = ("x", "amp", "afield", "state", "mid", "mid_scalar", "value", "grad")
+    __slots__ = ("x", "amp", "afield", "state", "mid", "mid_scalar", "value", "grad", "f", "tf")
 
     def __init__(self):
         self.mid = None
@@ -363,8 +363,8 @@ class FusedModel:
         self.counters["transforms"] += 1
         return (out, d) if want_derivative else out
 
-    def _vjp(self, lp, w, scale, addend, addend_scale, accumulate, out_xi, dot_out=None):
-        """out_xi (+)= a t + addend_scale*addend,  self.abar += scatter(xi t),  t = scale * HT(w);
+    def _vjp(self, lp, w, scale, addend, addend_scale, accumulate, out_xi, dot_out=None, w2=None):
+        """out_xi (+)= a t + addend_scale*addend,  self.abar += scatter(xi t),  t = scale * HT(w) (HT(w * w2) with w2);
         dot_out (device fp64 scalar, needs addend): += sum addend * out_xi, taken in the same epilogue."""
         f = self._fuse()
         if dot_out is not None:
@@ -372,6 +372,8 @@ class FusedModel:
                 raise ValueError("dot_out needs an addend and the register-resident transform pipeline")
             f.value = dot_out.data_ptr()
         f.pro, f.in_ = L.PRO_PLAIN, w.data_ptr()
+        if w2 is not None:
+            f.pro, f.in2 = L.PRO_MUL, w2.data_ptr()
         f.epi, f.out, f.scale = L.EPI_VJP, out_xi.data_ptr(), self.h_dvol * scale
         f.pidx, f.amp, f.xi = self.pidx.data_ptr(), lp.amp.data_ptr(), lp.x.xi.data_ptr()
         f.afield = B.ptr(lp.afield)
@@ -480,6 +482,59 @@ class FusedModel:
     def lh_metric(self, lp, d):
         out = LatentVec(torch.empty_like(d.xi), None)
         self.lh_metric_accumulate(lp, d, out, 1.0, True)
+        return out
+
+    # -- likelihood transformation f (geoVI; energy_operators.py:590-591, 639-640, kl_energies.py:105-124) ----
+    def trafo_point(self, x):
+        """Everything geoVI needs about x: amplitude tables/field, the transformed signal f(x) (Gaussian:
+        N^{-1/2} g(s), Poisson: 2 sqrt(g(s))) and the weight field tf = (df/dmu) g'(s) of its Jacobian
+        J_f = diag(tf) . J_cf."""
+        lp = LinPoint()
+        lp.x = x
+        lp.amp, lp.state = self._amp_forward(x.small)
+        lp.afield = self._amp_field(lp.amp)
+        f = self._fuse()
+        f.pro, f.in_, f.pidx, f.amp = L.PRO_AMP, x.xi.data_ptr(), self.pidx.data_ptr(), lp.amp.data_ptr()
+        f.afield = lp.afield.data_ptr()
+        g = torch.empty(self.shape, dtype=self.tdtype, device=self.device)
+        gp = torch.empty_like(g)
+        f.epi, f.out, f.out2, f.offset, f.nonlin = L.EPI_NONLIN, g.data_ptr(), gp.data_ptr(), self.offset_mean, self.nonlin
+        B.hartley_fused(self.plan, f)
+        self.counters["transforms"] += 1
+        if self.lh_kind == L.LH_GAUSS:
+            if self.icov_field is None:
+                tw = math.sqrt(self.icov_scalar)
+                lp.f, lp.tf = B.axpby(tw, g), B.axpby(tw, gp)
+            else:
+                tw = B.pointwise("sqrt", self.icov_field)
+                lp.f, lp.tf = B.binary(L.OP_MUL, g, tw), B.binary(L.OP_MUL, gp, tw)
+        else:
+            rt = B.pointwise("sqrt", g)
+            lp.f, lp.tf = B.axpby(2.0, rt), B.binary(L.OP_DIV, gp, rt)
+        return lp
+
+    def jvp_data(self, lp, d, out=None):
+        """J_f(lp.x) d = tf * dvol_h HT(a dxi + da xi): latent tangent -> data space."""
+        L.check(L.load().nk_amp_jvp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(),
+                                    lp.state.data_ptr(), d.small.data_ptr(), self.damp.data_ptr(), B._stream()), "nk_amp_jvp")
+        f = self._fuse()
+        f.pro, f.in_, f.in2 = L.PRO_AMP_JVP, d.xi.data_ptr(), lp.x.xi.data_ptr()
+        f.pidx, f.amp, f.damp = self.pidx.data_ptr(), lp.amp.data_ptr(), self.damp.data_ptr()
+        f.afield = B.ptr(lp.afield)
+        self._amp_field(self.damp, out=self.dafield)
+        f.dafield = self.dafield.data_ptr()
+        out = torch.empty(self.shape, dtype=self.tdtype, device=self.device) if out is None else out
+        f.epi, f.out, f.mul, f.mul_scalar = L.EPI_MUL, out.data_ptr(), lp.tf.data_ptr(), 1.0
+        B.hartley_fused(self.plan, f)
+        self.counters["transforms"] += 1
+        return out
+
+    def vjp_data(self, lp, w, addend=None):
+        """J_f(lp.x)^T w (+ addend): data space -> latent cotangent."""
+        out = LatentVec(torch.empty_like(lp.x.xi), None)
+        self._vjp(lp, w, 1.0, None if addend is None else addend.xi, 1.0, False, out.xi, w2=lp.tf)
+        self._amp_vjp(lp)
+        out.small = B.axpby(1.0, self.latbar) if addend is None else B.axpby(1.0, self.latbar, 1.0, addend.small)
         return out
 
     # -- sampling (kl_energies.py:91-159, sampling_enabler.py:64-86) -------------------------------
@@ -658,6 +713,46 @@ class ShardedMetric:
         return out_full
 
 
+class FusedGeoEnergy(Energy):
+    """0.5 |m - g(x)|^2 with g(x) = x + J_f(p)^T f(x): the geoVI sampling energy
+    (EnergyAdapter(pos, GaussianEnergy(m) @ transformation, want_metric=True), kl_energies.py:115-121, 148-155).
+    Every evaluation is four transforms: forward at x, J_f(p)^T, J_f(p), J_f(x)^T; so is a metric application."""
+
+    def __init__(self, model, tp_p, m, position, nanisinf=True):
+        super().__init__(position)
+        self.model, self.tp_p, self.m = model, tp_p, m
+        self.tp = model.trafo_point(position)
+        gx = model.vjp_data(tp_p, self.tp.f, addend=position)  # x + J_f(p)^T f(x)
+        self.res = gx - m
+        val = 0.5 * self.res.s_vdot(self.res)
+        self._value = math.inf if (math.isnan(val) and nanisinf) else val
+        self._grad = self._G_T(self.res)
+
+    def _G(self, d):    # dg(x) d = d + J_f(p)^T J_f(x) d
+        return self.model.vjp_data(self.tp_p, self.model.jvp_data(self.tp, d), addend=d)
+
+    def _G_T(self, y):  # dg(x)^T y = y + J_f(x)^T J_f(p) y
+        return self.model.vjp_data(self.tp, self.model.jvp_data(self.tp_p, y), addend=y)
+
+    @property
+    def value(self):
+        return self._value
+
+    @property
+    def gradient(self):
+        return self._grad
+
+    def at(self, position):
+        return FusedGeoEnergy(self.model, self.tp_p, self.m, position)
+
+    def apply_metric(self, d):
+        return self._G_T(self._G(d))
+
+    @property
+    def metric(self):
+        return _Callable(self.apply_metric)
+
+
 def share_range(nwork, nshares, myshare):
     """reference nifty/cl/utilities.py:282-306"""
     nbase, additional = divmod(nwork, nshares)
@@ -665,15 +760,17 @@ def share_range(nwork, nshares, myshare):
     return lo, lo + nbase + int(myshare < additional)
 
 
-def draw_samples(model, position, n_samples, mirror_samples, controller_factory, comm=None, device_rng=None):
-    """MGVI samples of this rank (kl_energies.py:126-159): returns (residuals, negs, n_total)."""
+def draw_samples(model, position, n_samples, mirror_samples, controller_factory, comm=None, device_rng=None,
+                 geo_minimizer=None):
+    """MGVI -- or with ``geo_minimizer`` (a DescentMinimizer) geoVI -- samples of this rank
+    (kl_energies.py:105-159): returns (residuals, negs, n_total)."""
     sseq = random.spawn_sseq(n_samples)
     if mirror_samples:
         sseq = [s for ss in sseq for s in (ss, ss)]
     ntask, rank = (1, 0) if comm is None else (comm.size, comm.rank)
-    lp = None
+    lp = tp_p = trafo_mean = None
     residuals, negs = [], []
-    y = None
+    y = b = None
     lo, hi = share_range(len(sseq), ntask, rank)
     for i in range(lo, hi):
         with random.Context(sseq[i]):
@@ -685,16 +782,29 @@ def draw_samples(model, position, n_samples, mirror_samples, controller_factory,
                     # synthetic-draw mode: still one stream per sample seed, so both members of a mirrored pair
                     # see identical draws even when they live on different ranks (kl_energies.py:132-146)
                     device_rng.manual_seed(int(sseq[i].generate_state(1, np.uint64)[0] >> np.uint64(1)))
-                _, y = model.draw_mgvi_sample(lp, controller_factory(), device_rng)
-            residuals.append(y)
-            negs.append(neg)
+                b, y = model.draw_mgvi_sample(lp, controller_factory(), device_rng)
+            if geo_minimizer is None:
+                residuals.append(y)
+                negs.append(neg)
+                continue
+            # geoVI (kl_energies.py:105-124, 148-155): the linear sample only starts a non-linear fit of
+            # g(x) = x + J_f(p)^T f(x) to  g(p) +- b
+            if tp_p is None:
+                tp_p = model.trafo_point(position)
+                trafo_mean = model.vjp_data(tp_p, tp_p.f, addend=position)
+            m = trafo_mean - b if neg else trafo_mean + b
+            start = position - y if neg else position + y
+            en, _ = geo_minimizer(FusedGeoEnergy(model, tp_p, m, start))
+            residuals.append(en.position - position)
+            negs.append(False)
     return residuals, negs, len(sseq)
 
 
 def mgvi_iteration(model, mean, n_samples, controller_factory, kl_minimizer, mirror_samples=True, comm=None,
-                   device_rng=None):
+                   device_rng=None, geo_minimizer=None):
     """One pass of the optimize_kl loop body (optimize_kl.py:357-451, no I/O): sample, then minimise."""
-    residuals, negs, n_total = draw_samples(model, mean, n_samples, mirror_samples, controller_factory, comm, device_rng)
+    residuals, negs, n_total = draw_samples(model, mean, n_samples, mirror_samples, controller_factory, comm, device_rng,
+                                            geo_minimizer)
     kl = FusedKL(model, mean, residuals, negs, n_total, comm)
     kl, _ = kl_minimizer(kl)
     return kl.position, kl

@@ -131,12 +131,13 @@ def _latent_to_mf(domain, lv, dtype):
     return MultiField.from_dict(vals, domain)
 
 
-def _fused_iteration(model, lh, mean, n_samples, minimizer, ic_sampling, comm):
+def _fused_iteration(model, lh, mean, n_samples, minimizer, ic_sampling, comm, geo_minimizer=None):
     from .engine import FusedKL, draw_samples
 
     dtype = mean["xi"].dtype
     mean_lv = _mf_to_latent(model, mean)
-    residuals, negs, n_total = draw_samples(model, mean_lv, n_samples, True, lambda: ic_sampling, comm)
+    residuals, negs, n_total = draw_samples(model, mean_lv, n_samples, True, lambda: ic_sampling, comm,
+                                            geo_minimizer=geo_minimizer)
     kl = FusedKL(model, mean_lv, residuals, negs, n_total, comm)
     kl, _ = minimizer(kl)
     new_mean = _latent_to_mf(lh.domain, kl.position, dtype)
@@ -246,11 +247,11 @@ def optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sa
             continue
         ns = n_samples(ig)
         model = None
-        if fuse and device_id >= 0 and ns > 0 and nonlinear_sampling_minimizer(ig) is None:
+        if fuse and device_id >= 0 and ns > 0:
             model = _fused_model(lh, device_id, mean_iter["xi"].dtype if "xi" in mean_iter else np.float64)
         if model is not None:
             new_mean, sl, value = _fused_iteration(model, lh, mean_iter, ns, minimizer, sampling_iteration_controller(ig),
-                                                   comm(ig))
+                                                   comm(ig), nonlinear_sampling_minimizer(ig))
             mean = MultiField.union([mean, new_mean])
             sl = sl.at(mean)
             energy_history.append((ig, value))

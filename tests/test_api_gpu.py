@@ -98,3 +98,24 @@ def test_device_operator_identities():
     xc = ift.from_random(sp, dtype=np.complex128, device_id=0)
     assert gl.relerr(f.inverse(f(xc)).asnumpy(), xc.asnumpy()) < 1e-12
     assert gl.relerr(f(xc).asnumpy(), f(xc.at(-1)).asnumpy()) < 1e-12
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_optimize_kl_geovi_on_device_matches_reference(fuse):
+    """geoVI (nonlinear_sampling_minimizer) through optimize_kl: fused engine (FusedGeoEnergy) and generic graph."""
+    z = gl.load("model_p2d_geo")
+    m, cfm, cf, lh = build(z, device_id=0)
+    ift.random.push_sseq_from_seed(m["seed"] + 2)
+    try:
+        ic_s = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=m["sampling_limit"])
+        mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2),  # noqa: E731
+                                    max_cg_iterations=8)
+        nl = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=3, convergence_level=2),  # noqa: E731
+                                    max_cg_iterations=6)
+        sl, mean = ift.optimize_kl(lh, 2, m["n_samples"], mk, ic_s, nonlinear_sampling_minimizer=nl, output_directory=None,
+                                   return_final_position=True, device_id=0, fuse=fuse)
+    finally:
+        ift.random.pop_sseq()
+    assert gl.lat_relerr(mean.asnumpy(), gl.latent(z, "okl_mean")) < 2e-3
+    for i, s in enumerate(sl.iterator()):
+        assert gl.lat_relerr(s.asnumpy(), gl.latent(z, f"okl_sample{i}")) < 5e-3

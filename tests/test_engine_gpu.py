@@ -82,6 +82,58 @@ def test_mgvi_samples_kl_newton_vs_reference_golden(case):
     assert gl.lat_relerr(kl2.position.to_dict(), gl.latent(z, "kl_min_pos")) < 1e-6
 
 
+@pytest.mark.parametrize("case", ["p2d_geo", "g2d_sig_geo"])
+def test_geovi_samples_vs_reference_golden(case):
+    """geoVI inside the fused engine (FusedGeoEnergy, kl_energies.py:105-124, 148-155) against the reference's samples,
+    KL value / gradient / metric and a NewtonCG step.  Tolerances as in the generic-graph geoVI tests: the golden CG
+    lengths are bounded to stay in the reproducible regime (make_golden.py GEO_CG)."""
+    from nifty_amd import random
+    from nifty_amd.engine import FusedKL, draw_samples
+    from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG
+
+    z = gl.load("model_" + case)
+    m, model = _model(z)
+    xl, vl = _lv(model, gl.latent(z, "x")), _lv(model, gl.latent(z, "v"))
+    geo = NewtonCG(AbsDeltaEnergyController(0.5, iteration_limit=3, convergence_level=2), max_cg_iterations=6)
+    random.push_sseq_from_seed(m["seed"] + 1)
+    try:
+        res, negs, n_total = draw_samples(model, xl, m["n_samples"], True,
+                                          lambda: AbsDeltaEnergyController(0.05, iteration_limit=m["sampling_limit"]),
+                                          geo_minimizer=geo)
+    finally:
+        random.pop_sseq()
+    assert n_total == int(z["n_residuals"]) and not any(negs)
+    for i, r in enumerate(res):
+        assert gl.lat_relerr(r.to_dict(), gl.latent(z, f"residual{i}")) < 1e-6, i
+    kl = FusedKL(model, xl, res, negs)
+    assert abs(kl.value - float(z["kl_value"])) < 1e-6 * abs(float(z["kl_value"]))
+    assert gl.lat_relerr(kl.gradient.to_dict(), gl.latent(z, "kl_grad")) < 1e-5
+    assert gl.lat_relerr(kl.apply_metric(vl).to_dict(), gl.latent(z, "kl_metric_v")) < 1e-5
+
+
+def test_geovi_energy_vs_oracle():
+    """FusedGeoEnergy value / gradient / metric against the oracle's restatement on seeded inputs."""
+    from nifty_amd.engine import FusedGeoEnergy, FusedModel, LatentVec
+
+    shape = (64, 128)
+    rng = np.random.default_rng(4)
+    cf = orc.CFModel(shape, None, orc.CFParams(offset_mean=1.5))
+    data = rng.poisson(np.exp(cf.forward(cf.draw_latent(rng)))).astype(np.int64)
+    lh = orc.Likelihood("poisson", data, nonlin="exp")
+    model = FusedModel(shape, offset_mean=1.5, likelihood="poisson", data=data, nonlin="exp")
+    p = {k: 0.2 * a for k, a in cf.draw_latent(rng).items()}
+    x = {k: 0.2 * a for k, a in cf.draw_latent(rng).items()}
+    mt = cf.draw_latent(rng)
+    d = cf.draw_latent(rng)
+    lin_p = orc.Linearized(cf, lh, p)
+    en_o = orc._GeoEnergy(cf, lh, lin_p, lh.trafo_weight(lin_p.s), mt, x)
+    pl, xl, ml, dl = (LatentVec.from_dict(model, a) for a in (p, x, mt, d))
+    en = FusedGeoEnergy(model, model.trafo_point(pl), ml, xl)
+    assert abs(en.value - en_o.value) < 1e-10 * abs(en_o.value)
+    assert gl.lat_relerr(en.gradient.to_dict(), en_o.gradient) < 1e-9
+    assert gl.lat_relerr(en.apply_metric(dl).to_dict(), en_o.apply_metric(d)) < 1e-9
+
+
 @pytest.mark.parametrize("shape,kind,nonlin", [((256,), "gaussian", None), ((128, 64), "poisson", "exp"),
                                                ((32, 16, 64), "gaussian", "sigmoid"), ((64, 64, 64), "gaussian", None),
                                                # non-power-of-two grids (mixed radix 2/3/5/7, generic kernels)

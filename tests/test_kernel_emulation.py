@@ -93,6 +93,14 @@ def test_fused_prologue_epilogue_emulation(shape, fn):
     run(f, shape, np.float64, fn=fn)
     ref = 0.5 * H(amp[pidx] * dxi + damp[pidx] * xi) + 1.25
     assert np.max(np.abs(out - ref)) < 1e-11 * np.max(np.abs(ref))
+    # MUL prologue (in * in2)
+    outm = np.empty(shape)
+    f = Fuse()
+    f.pro, f.in_, f.in2 = 3, dxi.ctypes.data, xi.ctypes.data
+    f.epi, f.out, f.scale, f.offset = 0, outm.ctypes.data, 0.5, 0.0
+    run(f, shape, np.float64, fn=fn)
+    refm = 0.5 * H(dxi * xi)
+    assert np.max(np.abs(outm - refm)) < 1e-11 * np.max(np.abs(refm))
     abar = np.zeros(nb)
     out2 = np.full(shape, 3.0)
     f = Fuse()
