@@ -488,33 +488,6 @@ NK_HD void nk_epilogue_pair(const NkFuse& f, int64_t o1, T v1, int64_t o2, T v2,
   }
 }
 
-// compile-time specialised single-output epilogues of the hot configurations (EC = 0 affine, 1 multiply,
-// anything else -> generic run-time version)
-template <typename T, int EC>
-NK_HD void nk_emit(const NkFuse& f, int64_t o, T v, double& acc) {
-  if constexpr (EC == 0) {
-    ((T*)f.out)[o] = (T)((double)v * f.scale + f.offset);
-  } else if constexpr (EC == 1) {
-    double r = (double)v * f.scale * f.mul_scalar;
-    if (f.mul) r *= (double)((const T*)f.mul)[o];
-    ((T*)f.out)[o] = (T)r;
-  } else {
-    nk_epilogue<T>(f, o, v, acc);
-  }
-}
-
-// one output of the scatter (VJP) epilogue: writes out[o], returns the xi*t contribution to the bin sum
-template <typename T, bool AFIELD>
-NK_HD double nk_emit_vjp(const NkFuse& f, int64_t o, T v, double a_bin) {
-  T* out = (T*)f.out;
-  const double t = (double)v * f.scale;
-  double r = ((AFIELD || f.afield) ? (double)((const T*)f.afield)[o] : a_bin) * t;
-  if (f.addend) r += f.addend_scale * (double)((const T*)f.addend)[o];
-  if (f.accumulate) r += (double)out[o];
-  out[o] = (T)r;
-  return (double)((const T*)f.xi)[o] * t;
-}
-
 // up to eight outputs that share one power bin (the sign-flip images of one coefficient): one atomic for the VJP
 // scatter (VJP) epilogue of the four images of one slot: all loads first, then the stores; returns sum xi*t
 template <typename T>

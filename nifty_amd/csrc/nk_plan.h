@@ -7,8 +7,6 @@
 
 #include "nk_fft_phases.h"
 
-static inline bool nk_is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
-
 // radices 8/4/2 first, then the odd ones; nstage = -1 when n has a prime factor > 7 or needs too many stages
 static inline NkLinePlan nk_make_line_plan(int n) {
   NkLinePlan lp{};
