@@ -318,9 +318,17 @@ NK_HD int64_t nk_oct_block_remap(int64_t v, const NkPassS& p) {
   const int64_t s = v / 8;
   const int64_t g = (s / (2 * tiles)) * 8 + x;  // slab pair handled by XCD x
   const int within = (int)(s % (2 * tiles));
-  const int64_t idx = 2 * g + within / tiles;   // slab sequence 0, A/2, 1, A-1, 2, A-2, ...
+  // inside the pair the four workgroups that read the same octant lines run back to back:
+  // (a, j), (a, tiles-1-j), (A-a, j), (A-a, tiles-1-j)   (tiles even: the last-axis mirror of tile j is tile tiles-1-j)
+  int sel = within / tiles, tile = within % tiles;
+  if (tiles % 2 == 0) {
+    const int quad = within / 4, m = within % 4;
+    sel = m / 2;
+    tile = (m % 2 == 0) ? quad : tiles - 1 - quad;
+  }
+  const int64_t idx = 2 * g + sel;   // slab sequence 0, A/2, 1, A-1, 2, A-2, ...
   const int64_t slab = idx == 0 ? 0 : idx == 1 ? na / 2 : ((idx & 1) ? na - idx / 2 : idx / 2);
-  return bat * per + slab * tiles + within % tiles;
+  return bat * per + slab * tiles + tile;
 }
 
 // ---------------------------------------------------------------------------------------------
