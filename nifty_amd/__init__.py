@@ -21,7 +21,8 @@ from .kl import (EnergyAdapter, ResidualSampleList, SampledKLEnergy, SampledKLEn
 from .minimization import (AbsDeltaEnergyController, ConjugateGradient, DeltaEnergyController, DescentMinimizer,  # noqa: F401
                            Energy, EnergyHistory, GradientNormController, GradInfNormController, IterationController,
                            LineSearch, NewtonCG, QuadraticEnergy, SteepestDescent)
-from .operators import (Adder, BlockDiagonalOperator, ChainOperator, ContractionOperator, DiagonalOperator,  # noqa: F401
+from .operators import (Adder, BlockDiagonalOperator, ChainOperator, ContractionOperator, CountingOperator,  # noqa: F401
+                        DiagonalOperator, HarmonicSmoothingOperator,
                         DOFDistributor, EndomorphicOperator, FFTOperator, FieldAdapter, HarmonicTransformOperator,
                         HartleyOperator, Linearization, LinearOperator, MaskOperator, NullOperator, Operator, OperatorAdapter,
                         PowerDistributor, Realizer, SamplingEnabler, SandwichOperator, ScalingOperator, SumOperator,

@@ -168,6 +168,12 @@ class RGSpace(StructuredDomain):
 
         return Field.from_raw(self, self._dist_array())
 
+    def get_fft_smoothing_kernel_function(self, sigma):
+        """k -> exp(-2 pi^2 sigma^2 k^2): Fourier image of a Gaussian of width sigma (reference rg_space.py:164-171)."""
+        if not self._harmonic:
+            raise NotImplementedError
+        return lambda x: (x * x * (-2.0 * np.pi * np.pi * sigma * sigma)).ptw("exp")
+
     def equal_distances(self):
         return bool(np.all(np.array(self.distances) == self.distances[0]))
 

@@ -1334,6 +1334,74 @@ class HarmonicTransformOperator(LinearOperator):
         return self._op.apply(x, mode)
 
 
+def HarmonicSmoothingOperator(domain, sigma, space=None):
+    """Smoothing with a Gaussian kernel of width `sigma` (position-space units) on a non-harmonic RGSpace:
+    Hartley^-1 . diag(exp(-2 pi^2 sigma^2 k^2)) . Hartley (reference harmonic_operators.py:340-380)."""
+    sigma = float(sigma)
+    if sigma < 0.0:
+        raise ValueError("sigma must be non-negative")
+    if sigma == 0.0:
+        return ScalingOperator(domain, 1.0)
+    domain = DomainTuple.make(domain)
+    if space is None and len(domain) == 1:
+        space = 0
+    if space is None or len(domain) != 1:
+        raise NotImplementedError("HarmonicSmoothingOperator on a sub-space is not implemented yet")
+    if domain[space].harmonic:
+        raise TypeError("domain must not be harmonic")
+    hartley = HartleyOperator(domain, space=space)
+    codomain = hartley.target[space]
+    kernel = codomain.get_fft_smoothing_kernel_function(sigma)(codomain.get_k_length_array())
+    return hartley.inverse(DiagonalOperator(kernel)(hartley))
+
+
+class _JacCountingOperator(EndomorphicOperator):
+    def __init__(self, domain):
+        self._domain = makeDomain(domain)
+        self._capability = self.TIMES | self.ADJOINT_TIMES
+        self._count_times = 0
+        self._count_adjoint_times = 0
+
+    def apply(self, x, mode):
+        self._check_input(x, mode)
+        if mode == self.TIMES:
+            self._count_times += 1
+        else:
+            self._count_adjoint_times += 1
+        return x
+
+
+class CountingOperator(Operator):
+    """Identity that counts how often it is applied to fields / Linearizations and how often its Jacobian and
+    adjoint Jacobian run (reference counting_operator.py:20-84; optimize_kl.py:370,441 reports them)."""
+
+    def __init__(self, domain):
+        self._domain = self._target = makeDomain(domain)
+        self._count_apply = 0
+        self._count_apply_lin = 0
+        self._derivative = _JacCountingOperator(self._domain)
+
+    def apply(self, x):
+        self._check_input(x)
+        if is_linearization(x):
+            self._count_apply_lin += 1
+            return x.new(x.val, self._derivative)
+        self._count_apply += 1
+        return x
+
+    count_apply = property(lambda self: self._count_apply)
+    count_apply_lin = property(lambda self: self._count_apply_lin)
+    count_jac = property(lambda self: self._derivative._count_times)
+    count_jac_adj = property(lambda self: self._derivative._count_adjoint_times)
+
+    def __repr__(self):
+        return f"CountingOperator({self._domain!r})"
+
+    def report(self):
+        return "\n".join([f"* apply: \t\t{self.count_apply:>7}", f"* apply Linearization: \t{self.count_apply_lin:>7}",
+                          f"* Jacobian: \t\t{self.count_jac:>7}", f"* Adjoint Jacobian: \t{self.count_jac_adj:>7}"])
+
+
 class DOFDistributor(LinearOperator):
     """Gather bins -> pixels (TIMES) and scatter-add pixels -> bins (ADJOINT_TIMES)
     (reference distributors.py:28-127)."""

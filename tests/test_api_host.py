@@ -166,3 +166,38 @@ def test_fusion_pass_matches_graph():
     m, cfm, cf, lh = build(z)
     kw = match_fused(lh)
     assert kw["likelihood"] == "gaussian" and kw["icov"] == pytest.approx(100.0) and kw["nonlin"] is None
+
+
+def _smooth_numpy(x, dist, sigma):
+    """Gaussian smoothing as a Fourier multiplier exp(-2 pi^2 sigma^2 |k|^2) (harmonic_operators.py:340-380,
+    rg_space.py:116-128, 164-171)."""
+    k2 = 0.0
+    for ax, (n, d) in enumerate(zip(x.shape, dist)):
+        k = np.minimum(np.arange(n), n - np.arange(n)) / (n * d)
+        k2 = k2 + (k ** 2).reshape([-1 if i == ax else 1 for i in range(x.ndim)])
+    return np.fft.ifftn(np.fft.fftn(x) * np.exp(-2.0 * np.pi ** 2 * sigma ** 2 * k2)).real
+
+
+@pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
+def test_harmonic_smoothing_and_counting_operator(device_id):
+    rng = np.random.default_rng(0)
+    for shape, dist in [((32,), (0.1,)), ((16, 24), (0.3, 0.2))]:
+        sp = ift.RGSpace(shape, dist)
+        x = rng.normal(size=shape)
+        op = ift.HarmonicSmoothingOperator(sp, 0.25)
+        got = op(ift.makeField(sp, x, device_id)).asnumpy()
+        assert gl.relerr(got, _smooth_numpy(x, dist, 0.25)) < 1e-12
+    assert isinstance(ift.HarmonicSmoothingOperator(sp, 0.0), ift.ScalingOperator)
+    with pytest.raises(ValueError):
+        ift.HarmonicSmoothingOperator(sp, -1.0)
+    with pytest.raises(TypeError):
+        ift.HarmonicSmoothingOperator(sp.get_default_codomain(), 1.0)
+    c = ift.CountingOperator(sp)
+    f = ift.makeField(sp, x, device_id)
+    assert c(f) is f
+    lin = c(ift.Linearization.make_var(f))
+    lin.jac(f)
+    lin.jac.adjoint(f)
+    lin.jac.adjoint(f)
+    assert (c.count_apply, c.count_apply_lin, c.count_jac, c.count_jac_adj) == (1, 1, 1, 2)
+    assert "Adjoint Jacobian" in c.report()
