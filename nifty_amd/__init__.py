@@ -8,7 +8,7 @@ fallback for device data.
 """
 __version__ = "0.1.0"
 
-from . import config, parallel, random  # noqa: F401
+from . import config, extra, parallel, random  # noqa: F401
 from .correlated_fields import (CorrelatedFieldMaker, CorrelatedFieldOperator, LognormalTransform,  # noqa: F401
                                 NormalTransform, SimpleCorrelatedField)
 from .domains import (DomainTuple, MultiDomain, PowerSpace, RGSpace, StructuredDomain, UnstructuredDomain,  # noqa: F401

@@ -1,0 +1,123 @@
+"""Consistency checks for operators (reference extra.py:41-131 ``check_linear_operator``, :134-183
+``check_operator``): the identities the reference's own test-suite is built on -- linearity, adjointness
+<y, A x> = <A^† y, x>, inverse round trips, Jacobian versus finite differences, and host/device agreement."""
+import numpy as np
+
+from .field import Field, MultiField, device_available, from_random
+from .operators import Linearization, LinearOperator, Operator
+
+__all__ = ["check_linear_operator", "check_operator", "assert_allclose"]
+
+
+def assert_allclose(f1, f2, atol=0, rtol=1e-7):
+    """Field / MultiField comparison (reference extra.py:186-192)."""
+    if isinstance(f1, Field):
+        return np.testing.assert_allclose(f1.asnumpy(), f2.asnumpy(), atol=atol, rtol=rtol)
+    if f1.domain is not f2.domain:
+        raise AssertionError
+    for key in f1.keys():
+        assert_allclose(f1[key], f2[key], atol=atol, rtol=rtol)
+
+
+def _device_ids(force_device_ids):
+    ids = {-1, *force_device_ids}
+    if device_available():
+        ids.add(0)
+    if not all(isinstance(i, int) and i >= -1 for i in ids):
+        raise TypeError("Device ids need to be int and >= -1")
+    return sorted(ids)
+
+
+def _flips(op):
+    """The operator and its adjoint / inverse / adjoint-inverse views with (domain dtype, target dtype) swapped
+    accordingly."""
+    return [(op, 0), (op.adjoint, 1), (op.inverse, 1), (op.adjoint.inverse, 0)]
+
+
+def _has(op, cap):
+    return (op.capability & cap) == cap
+
+
+def _check_one(op, dt_dom, dt_tgt, atol, rtol, only_r_linear, dev):
+    rnd = lambda dom, dt: from_random(dom, "normal", dtype=dt, device_id=dev)  # noqa: E731
+    if _has(op, op.TIMES):
+        x, y = rnd(op.domain, dt_dom), rnd(op.domain, dt_dom)
+        res = op(x)
+        if res.domain is not op.target or x.domain is not op.domain:
+            raise AssertionError("operator does not map its domain to its target")
+        if res.device_id != dev:
+            raise AssertionError("operator moved the field to another device")
+        assert_allclose(op(0.42 * x + y), 0.42 * op(x) + op(y), atol=atol, rtol=rtol)  # linearity (:263-272)
+    if _has(op, op.TIMES | op.ADJOINT_TIMES):  # adjointness (:220-231)
+        f1, f2 = rnd(op.domain, dt_dom), rnd(op.target, dt_tgt)
+        a, b = f1.s_vdot(op.adjoint_times(f2)), op.times(f1).s_vdot(f2)
+        if only_r_linear:
+            a, b = np.real(a), np.real(b)
+        np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
+    if _has(op, op.TIMES | op.INVERSE_TIMES):  # inverse round trips (:234-245)
+        foo = rnd(op.target, dt_tgt)
+        assert_allclose(op(op.inverse_times(foo)), foo, atol=atol, rtol=rtol)
+        foo = rnd(op.domain, dt_dom)
+        assert_allclose(op.inverse_times(op(foo)), foo, atol=atol, rtol=rtol)
+
+
+def check_linear_operator(op, domain_dtype=np.float64, target_dtype=np.float64, atol=1e-14, rtol=1e-14,
+                          only_r_linear=False, force_device_ids=[-1], _device_ids_override=None):
+    """Algebraic consistency of every capability of a LinearOperator on the host and, if present, on GPU 0
+    (same arguments as the reference, extra.py:41-131)."""
+    if not isinstance(op, LinearOperator):
+        raise TypeError("This test tests only linear operators.")
+    devs = _device_ids(force_device_ids) if _device_ids_override is None else _device_ids_override
+    dts = (domain_dtype, target_dtype)
+    # the same input on every device gives the same output (:520-560)
+    for view, swap in _flips(op):
+        if not _has(view, view.TIMES):
+            continue
+        x = from_random(view.domain, "normal", dtype=dts[swap], device_id=-1)
+        ref = view(x.at(devs[0]))
+        for dev in devs[1:]:
+            assert_allclose(view(x.at(dev)).at(-1), ref.at(-1), atol=max(atol, 1e-12), rtol=max(rtol, 1e-10))
+    for dev in devs:
+        for view, swap in _flips(op):
+            _check_one(view, dts[swap], dts[1 - swap], atol, rtol, only_r_linear, dev)
+
+
+def check_operator(op, loc, tol=1e-12, ntries=100, only_r_differentiable=True, force_device_ids=[-1]):
+    """Value consistency of ``op(Linearization)`` and Jacobian against finite differences at ``loc``, then
+    ``check_linear_operator`` on the Jacobian (reference extra.py:134-183, 411-496)."""
+    if not isinstance(op, Operator):
+        raise TypeError("This test tests only (nonlinear) operators.")
+    if not isinstance(loc, (Field, MultiField)) or loc.domain is not op.domain:
+        raise AssertionError("loc must live on the operator's domain")
+    ftol = np.sqrt(tol)
+    for dev in _device_ids(force_device_ids):
+        pos = loc.at(dev)
+        for wm in (False, True):
+            lin = op(Linearization.make_var(pos, wm))
+            assert_allclose(op(pos), lin.val, 0, 1e-7)
+            if lin.jac.domain is not op.domain or lin.jac.target is not op.target:
+                raise AssertionError("Jacobian domain/target mismatch")
+        for _ in range(ntries):
+            lin = op(Linearization.make_var(pos))
+            direction = from_random(pos.domain, dtype=np.float64, device_id=dev)
+            dirder = lin.jac(direction)
+            scale = lin.val.norm() * 1e-6 / dirder.norm() if dirder.norm() != 0 else lin.val.norm() * 1e-6
+            direction = direction * scale
+            pos2 = pos + direction
+            lin2 = op(Linearization.make_var(pos2))
+            nxt = pos2
+            for _ in range(50):
+                mid = pos + 0.5 * direction
+                linmid = op(Linearization.make_var(mid))
+                dirder = linmid.jac(direction)
+                numgrad = lin2.val - lin.val
+                xtol = ftol * dirder.norm() / np.sqrt(dirder.size)
+                if float(abs(numgrad - dirder).asnumpy().max()) <= xtol:
+                    break
+                direction = direction * 0.5
+                pos2, lin2 = mid, linmid
+            else:
+                raise ValueError("gradient and value seem inconsistent")
+            pos = nxt
+            check_linear_operator(linmid.jac, only_r_linear=only_r_differentiable, atol=tol, rtol=tol,
+                                  _device_ids_override=[dev])

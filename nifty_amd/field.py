@@ -65,6 +65,8 @@ def _binary(op, a, b):
             return torch.view_as_complex(B.binary(_BIN[op], torch.view_as_real(a), torch.view_as_real(b)))
         if op in ("mul", "div") and not torch.is_tensor(b) and np.isreal(b):
             return torch.view_as_complex(B.binary(_BIN[op], torch.view_as_real(a), float(np.real(b))))
+        if op == "mul" and not torch.is_tensor(a) and np.isreal(a):  # real scalar * complex field
+            return torch.view_as_complex(B.binary(_BIN[op], torch.view_as_real(b), float(np.real(a))))
         raise NotImplementedError("complex device arithmetic beyond +,-,*real is not implemented")
     if torch.is_tensor(a) and torch.is_tensor(b) and a.dtype != b.dtype:
         dt = torch.promote_types(a.dtype, b.dtype)
@@ -202,7 +204,16 @@ class Field:
             r = torch.vdot(a.reshape(-1), b.reshape(-1))
             return complex(r) if r.is_complex() else float(r)
         if a.is_complex() or b.is_complex():
-            raise NotImplementedError("complex vdot on device")
+            # conj(a).b from four real dots on de-interleaved copies (complex device data only occurs around FFTOperator)
+            def parts(t):
+                if not t.is_complex():
+                    return _cast(t, torch.float64).contiguous(), None
+                v = torch.view_as_real(t)
+                return v[..., 0].contiguous(), v[..., 1].contiguous()
+
+            (ar, ai), (br, bi) = parts(a), parts(b)
+            dot = lambda u, v: 0.0 if u is None or v is None else float(B.vdot(_cast(u, torch.float64), _cast(v, torch.float64)).item())  # noqa: E731
+            return complex(dot(ar, br) + dot(ai, bi), dot(ar, bi) - dot(ai, br))
         dt = torch.promote_types(a.dtype, b.dtype)
         if not dt.is_floating_point:
             dt = torch.float64
