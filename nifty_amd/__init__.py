@@ -20,7 +20,7 @@ from .kl import (EnergyAdapter, ResidualSampleList, SampledKLEnergy, SampledKLEn
                  draw_samples)
 from .minimization import (AbsDeltaEnergyController, ConjugateGradient, DeltaEnergyController, DescentMinimizer,  # noqa: F401
                            Energy, EnergyHistory, GradientNormController, GradInfNormController, IterationController,
-                           LineSearch, NewtonCG, QuadraticEnergy, SteepestDescent)
+                           L_BFGS, LineSearch, NewtonCG, QuadraticEnergy, RelaxedNewton, SteepestDescent)
 from .operators import (Adder, BlockDiagonalOperator, ChainOperator, ContractionOperator, CountingOperator,  # noqa: F401
                         DiagonalOperator, HarmonicSmoothingOperator,
                         DOFDistributor, EndomorphicOperator, FFTOperator, FieldAdapter, HarmonicTransformOperator,

@@ -675,6 +675,61 @@ class SteepestDescent(DescentMinimizer):
         return -energy.gradient
 
 
+class RelaxedNewton(DescentMinimizer):
+    """Newton direction -M^{-1} g with the energy's metric (reference descent_minimizers.py:149-163)."""
+
+    def __init__(self, controller, line_searcher=None):
+        super().__init__(controller, LineSearch(preferred_initial_step_size=1.0) if line_searcher is None else line_searcher)
+
+    def get_descent_direction(self, energy, _=None):
+        return -energy.metric.inverse_times(energy.gradient)
+
+
+class L_BFGS(DescentMinimizer):
+    """Limited-memory BFGS: two-loop recursion over the last `max_history_length` position / gradient differences
+    (reference descent_minimizers.py:213-262; pure vector algebra on the Field / LatentVec protocol)."""
+
+    def __init__(self, controller, line_searcher=None, max_history_length=5):
+        super().__init__(controller, line_searcher)
+        self.max_history_length = max_history_length
+        self.reset()
+
+    def __call__(self, energy):
+        self.reset()
+        return super().__call__(energy)
+
+    def reset(self):
+        self._k = 0
+        self._s = [None] * self.max_history_length
+        self._y = [None] * self.max_history_length
+
+    def get_descent_direction(self, energy, _=None):
+        m, k = self.max_history_length, self._k
+        x, g = energy.position, energy.gradient
+        if k > 0:
+            self._s[(k - 1) % m] = x - self._lastx
+            self._y[(k - 1) % m] = g - self._lastgrad
+        p = -g
+        used = list(range(k - 1, k - min(k, m) - 1, -1))  # newest first
+        alpha = {}
+        for i in used:
+            s, y = self._s[i % m], self._y[i % m]
+            alpha[i] = s.s_vdot(p) / s.s_vdot(y)
+            p = p - alpha[i] * y
+        if used:
+            s, y = self._s[(k - 1) % m], self._y[(k - 1) % m]
+            fact = s.s_vdot(y) / y.s_vdot(y)
+            if fact <= 0.0:
+                logger.error("L-BFGS curvature not positive definite!")
+            p = p * fact
+            for i in reversed(used):
+                s, y = self._s[i % m], self._y[i % m]
+                p = p + (alpha[i] - y.s_vdot(p) / s.s_vdot(y)) * s
+        self._lastx, self._lastgrad = x, g
+        self._k += 1
+        return p
+
+
 class NewtonCG(DescentMinimizer):
     """Inexact Newton: CG on metric * delta = gradient (reference descent_minimizers.py:166-210)."""
 

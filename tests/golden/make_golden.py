@@ -251,9 +251,33 @@ def los_cases():
     print("wrote los", out["a.dense"].shape, out["c4.resp"].shape)
 
 
+def minimizer_cases():
+    """L_BFGS / SteepestDescent (descent_minimizers.py:138-262) on the Hamiltonian of the g1d model at its
+    golden position x (data and x are read back from model_g1d.npz)."""
+    z = np.load(os.path.join(HERE, "model_g1d.npz"))
+    sp = ift.RGSpace(tuple(int(i) for i in z["meta.shape"]))
+    cfm, cf = make_cf(sp)
+    d = ift.makeField(cf.target, z["data"])
+    lh = ift.GaussianEnergy(d, ift.ScalingOperator(cf.target, float(z["icov"]), np.float64)) @ cf
+    x = ift.MultiField.from_raw(cf.domain, {k[2:]: z[k] for k in z.files if k.startswith("x.")})
+    ham = ift.StandardHamiltonian(lh, ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=10),
+                                  prior_sampling_dtype=np.float64)
+    out = {}
+    runs = {"lbfgs": ift.L_BFGS(ift.AbsDeltaEnergyController(0.1, iteration_limit=6)),
+            "steepest": ift.SteepestDescent(ift.GradientNormController(iteration_limit=3))}
+    for name, mini in runs.items():
+        e, _ = mini(ift.EnergyAdapter(x, ham, want_metric=True))
+        out[f"{name}.value"] = np.array(e.value)
+        out.update(mf2dict(e.position, f"{name}.pos"))
+    np.savez_compressed(os.path.join(HERE, "minimizers.npz"), **out)
+    print("wrote minimizers", {k: float(out[k]) for k in out if k.endswith("value")})
+
+
 def main():
     if "--los-only" in sys.argv:
         return los_cases()
+    if "--min-only" in sys.argv:
+        return minimizer_cases()
     geo = {}
     for shape, dist in [((8,), None), ((7, 8), None), ((4, 5, 7), None), ((512,), None), ((64, 64), None),
                         ((16, 16, 16), None), ((16, 32), (0.3, 0.2)), ((12,), (0.7,))]:
@@ -278,6 +302,7 @@ def main():
     model_case("p2d_geo", (32, 32), None, "poisson", "exp", 1, True, run_optimize=True)
     model_case("g2d_sig_geo", (16, 16), None, "gaussian", "sigmoid", 1, True)
     los_cases()
+    minimizer_cases()
 
 
 if __name__ == "__main__":

@@ -201,3 +201,31 @@ def test_harmonic_smoothing_and_counting_operator(device_id):
     lin.jac.adjoint(f)
     assert (c.count_apply, c.count_apply_lin, c.count_jac, c.count_jac_adj) == (1, 1, 1, 2)
     assert "Adjoint Jacobian" in c.report()
+
+
+@pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
+def test_lbfgs_and_steepest_descent_match_reference(device_id):
+    """descent_minimizers.py:138-262 on the Hamiltonian of the g1d model (tests/golden/minimizers.npz)."""
+    z, zm = gl.load("model_g1d"), gl.load("minimizers")
+    m, cfm, cf, lh = build(z, device_id)
+    x = ift.MultiField.from_raw(cf.domain, gl.latent(z, "x"), device_id)
+    ham = ift.StandardHamiltonian(lh, ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=10),
+                                  prior_sampling_dtype=np.float64)
+    runs = {"lbfgs": ift.L_BFGS(ift.AbsDeltaEnergyController(0.1, iteration_limit=6)),
+            "steepest": ift.SteepestDescent(ift.GradientNormController(iteration_limit=3))}
+    for name, mini in runs.items():
+        e, _ = mini(ift.EnergyAdapter(x, ham, want_metric=True))
+        assert abs(e.value - float(zm[f"{name}.value"])) < 1e-9 * abs(float(zm[f"{name}.value"]))
+        assert gl.lat_relerr(e.position.asnumpy(), gl.latent(zm, f"{name}.pos")) < 1e-8
+
+
+def test_relaxed_newton_on_quadratic():
+    """-M^{-1} g is exact for a quadratic with an invertible metric: one step reaches the minimum
+    (descent_minimizers.py:149-163)."""
+    sp = ift.RGSpace((16,))
+    rng = np.random.default_rng(1)
+    A = ift.DiagonalOperator(ift.makeField(sp, rng.uniform(0.5, 2.0, 16)))
+    b = ift.makeField(sp, rng.normal(size=16))
+    e = ift.QuadraticEnergy(ift.full(sp, 0.0), A, b)
+    e, status = ift.RelaxedNewton(ift.GradientNormController(iteration_limit=3, tol_abs_gradnorm=1e-10))(e)
+    assert gl.relerr(e.position.asnumpy(), (A.inverse_times(b)).asnumpy()) < 1e-12
