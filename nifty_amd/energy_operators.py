@@ -241,6 +241,15 @@ class StandardHamiltonian(EnergyOperator):
         met = SamplingEnabler(lhx.metric, prx.metric, self._ic_samp)
         return (lhx + prx).add_metric(met)
 
+    def _simplify_for_constant_input_nontrivial(self, c_inp):
+        """Hamiltonian of the variable keys: likelihood with the constants inserted + prior on what is left
+        (reference energy_operators.py:923-931)."""
+        out, lh1 = self._lh.simplify_for_constant_input(c_inp)
+        psdt = self._prior_sampling_dtype
+        if isinstance(psdt, dict):
+            psdt = {k: v for k, v in psdt.items() if k in lh1.domain.keys()}
+        return out, StandardHamiltonian(lh1, self._ic_samp, psdt)
+
     @property
     def prior_energy(self):
         return self._prior

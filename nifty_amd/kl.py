@@ -34,8 +34,9 @@ class EnergyAdapter(Energy):
     """Energy protocol on top of an EnergyOperator (reference energy_adapter.py:28-110)."""
 
     def __init__(self, position, op, constants=[], want_metric=False, nanisinf=False):
-        if len(constants) > 0:
-            raise NotImplementedError("constants are not implemented yet (SURVEY 8f)")
+        if len(constants) > 0:  # constant keys are inserted into the operator (energy_adapter.py:56-60)
+            _, op = op.simplify_for_constant_input(position.extract_by_keys(constants))
+            position = position.extract_by_keys(set(op.domain.keys()) - set(constants))
         super().__init__(position)
         self._op, self._want_metric, self._nanisinf = op, want_metric, nanisinf
         lin = op(Linearization.make_var(position, want_metric))
@@ -206,6 +207,9 @@ class ResidualSampleList(SampleListBase):
         return self._m.flexible_addsub(self._r[i], self._n[i])
 
     def at(self, mean):
+        """Only the entries present in `mean` are updated (sample_list.py:436-455)."""
+        if isinstance(self._m, MultiField) and self.domain is not mean.domain:
+            mean = MultiField.union([self._m, mean])
         return ResidualSampleList(mean, self._r, self._n, self._comm)
 
     @property
@@ -358,11 +362,40 @@ def SampledKLEnergy(position, hamiltonian, n_samples, minimizer_sampling, mirror
         raise TypeError
     if not (minimizer_sampling is None or isinstance(minimizer_sampling, DescentMinimizer)):
         raise TypeError
-    if len(constants) > 0 or len(point_estimates) > 0:
-        raise NotImplementedError("constants / point_estimates are not implemented yet (SURVEY 8f)")
-    sample_list = draw_samples(position, hamiltonian, minimizer_sampling, n_samples, mirror_samples, napprox=napprox,
+    if isinstance(position, MultiField):
+        if not set(constants).issubset(set(position.keys())):
+            raise ValueError(f"Constants are not a subset of the keys of the latent space: {constants}")
+        if not set(point_estimates).issubset(set(position.keys())):
+            raise ValueError(f"Point estimates are not a subset of the keys of the latent space: {point_estimates}")
+        if set(point_estimates) == set(position.keys()):
+            raise RuntimeError("Point estimates for whole domain. Use EnergyAdapter instead.")
+    # keys that are constant AND point estimates leave the problem entirely (kl_energies.py:281-287)
+    invariant = list(set(constants).intersection(point_estimates))
+    inv_pos = position.extract_by_keys(invariant) if isinstance(position, MultiField) and invariant else None
+    position, hamiltonian = _reduce_by_keys(position, hamiltonian, invariant)
+    # no samples along the point estimates: they are inserted into the Hamiltonian used for sampling (:289-293)
+    _, ham_sampling = _reduce_by_keys(position, hamiltonian, point_estimates)
+    sample_list = draw_samples(position, ham_sampling, minimizer_sampling, n_samples, mirror_samples, napprox=napprox,
                                comm=comm, device_id=device_id)
-    return SampledKLEnergyClass(sample_list, hamiltonian, constants, None, nanisinf)
+    return SampledKLEnergyClass(sample_list, hamiltonian, constants, inv_pos, nanisinf)
+
+
+def _reduce_field(field, keys):
+    if isinstance(field, MultiField) and len(keys) > 0:
+        return field.extract_by_keys(set(field.keys()) - set(keys))
+    return field
+
+
+def _reduce_by_keys(field, operator, keys):
+    """(variable part of the field, operator with the constant part inserted) (kl_energies.py:49-76)."""
+    if isinstance(field, MultiField):
+        cst = field.extract_by_keys(keys)
+        var = field.extract_by_keys(set(field.keys()) - set(keys))
+        _, operator = operator.simplify_for_constant_input(cst)
+        return var, operator
+    if len(keys) != 0:
+        raise ValueError("constants need a MultiField position")
+    return field, operator
 
 
 class SampledKLEnergyClass(Energy):
@@ -373,13 +406,15 @@ class SampledKLEnergyClass(Energy):
             raise TypeError
         if sample_list.domain is not hamiltonian.domain:
             raise ValueError("domain mismatch")
-        super().__init__(sample_list._m)
+        super().__init__(_reduce_field(sample_list._m, constants))
         self._sample_list, self._hamiltonian = sample_list, hamiltonian
         self._constants, self._invariants, self._nanisinf = constants, invariants, bool(nanisinf)
         self._lins = []
 
         def _func(inp):
-            lin = hamiltonian(Linearization.make_var(inp, want_metric=True))
+            # per sample: the constant keys of THIS sample are inserted, the rest is differentiated (:318-321)
+            inp, ham = _reduce_by_keys(inp, hamiltonian, constants)
+            lin = ham(Linearization.make_var(inp, want_metric=True))
             self._lins.append(lin)
             return _scalar_value(lin.val), lin.gradient
 
@@ -413,4 +448,6 @@ class SampledKLEnergyClass(Energy):
 
     @property
     def samples(self):
-        return self._sample_list
+        if self._invariants is None:
+            return self._sample_list
+        return self._sample_list.at(self._invariants)

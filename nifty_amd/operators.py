@@ -166,6 +166,20 @@ class Operator:
             raise TypeError("Only Operators with a MultiDomain as target can be subscripted.")
         return ducktape(None, self, key) @ self
 
+    def simplify_for_constant_input(self, c_inp):
+        """(constant output or None, operator on the remaining keys) for a partially constant input
+        (reference operator.py:393-441).  No algebraic simplification is attempted: the constants are inserted."""
+        if c_inp is None or (isinstance(c_inp, MultiField) and len(c_inp.keys()) == 0):
+            return None, self
+        if not isinstance(self.domain, MultiDomain) or not isinstance(c_inp, MultiField):
+            raise ValueError("partially constant input needs a MultiDomain")
+        if not set(c_inp.keys()) <= set(self.domain.keys()):
+            raise ValueError
+        return self._simplify_for_constant_input_nontrivial(c_inp)
+
+    def _simplify_for_constant_input_nontrivial(self, c_inp):
+        return None, self @ InsertionOperator(self.domain, c_inp)
+
     def ptw(self, op, *args, **kwargs):
         return _OpChain.make((_FunctionApplier(self.target, op, *args, **kwargs), self))
 
@@ -200,11 +214,6 @@ class Operator:
         if isinstance(name, str):
             return ducktape(None, self.target, name)(self)
         raise NotImplementedError
-
-    def simplify_for_constant_input(self, c_inp):
-        if c_inp is None or (isinstance(c_inp, MultiField) and len(c_inp.keys()) == 0):
-            return None, self
-        raise NotImplementedError("constants / point_estimates are not implemented yet (SURVEY 8f)")
 
     def __repr__(self):
         return self.__class__.__name__
@@ -634,6 +643,45 @@ class OperatorAdapter(LinearOperator):
 
     def __repr__(self):
         return "OperatorAdapter({}) of\n  ".format(["", "adjoint", "inverse", "adjoint inverse"][self._trafo]) + repr(self._op)
+
+
+class _KeyEmbedding(LinearOperator):
+    """MultiField on a sub-set of keys -> full MultiDomain with zeros on the other keys; adjoint extracts."""
+
+    def __init__(self, domain, target):
+        self._domain, self._target = MultiDomain.make(domain), MultiDomain.make(target)
+        self._capability = self.TIMES | self.ADJOINT_TIMES
+
+    def apply(self, x, mode):
+        self._check_input(x, mode)
+        if mode == self.TIMES:
+            zeros = {k: full(self._target[k], 0.0, x.device_id) for k in self._target.keys() if k not in self._domain.keys()}
+            return x.unite(MultiField.from_dict(zeros)) if zeros else x
+        return x.extract(self._domain)
+
+
+class InsertionOperator(Operator):
+    """x_variable -> x_variable united with a constant MultiField (reference simplify_for_const.py:115-146): how a
+    partially constant input is inserted into an operator (Operator.simplify_for_constant_input)."""
+
+    def __init__(self, target, cst_field):
+        if not isinstance(target, MultiDomain):
+            raise TypeError
+        if not isinstance(cst_field, MultiField):
+            raise TypeError
+        self._target = MultiDomain.make(target)
+        self._domain = MultiDomain.make({k: self._target[k] for k in self._target.keys() if k not in cst_field.keys()})
+        self._cst = cst_field
+        self._jac = _KeyEmbedding(self._domain, self._target)
+
+    def apply(self, x):
+        self._check_input(x)
+        val = x.val if is_linearization(x) else x
+        val = val.unite(self._cst.at(val.device_id))
+        return x.new(val, self._jac) if is_linearization(x) else val
+
+    def __repr__(self):
+        return f"InsertionOperator\n  Constant: {self._cst.keys()}\n  Variable: {self._domain.keys()}"
 
 
 class NullOperator(LinearOperator):

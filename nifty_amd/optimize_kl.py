@@ -239,15 +239,14 @@ def optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sa
         mean = _normal_initialize(mean, lh.domain, device_id=device_id)
         minimizer = kl_minimizer(ig)
         mean_iter = mean.extract(lh.domain)
-        if len(constants(ig)) > 0 or len(point_estimates(ig)) > 0:
-            raise NotImplementedError("constants / point_estimates are not implemented yet (SURVEY 8f)")
+        cst, pes = list(constants(ig)), list(point_estimates(ig))
         if dry_run:
             logger.info(f"Iteration {ig} checked")
             random.pop_sseq()
             continue
         ns = n_samples(ig)
         model = None
-        if fuse and device_id >= 0 and ns > 0:
+        if fuse and device_id >= 0 and ns > 0 and not cst and not pes:  # partial constants: generic graph
             model = _fused_model(lh, device_id, mean_iter["xi"].dtype if "xi" in mean_iter else np.float64)
         if model is not None:
             new_mean, sl, value = _fused_iteration(model, lh, mean_iter, ns, minimizer, sampling_iteration_controller(ig),
@@ -258,13 +257,13 @@ def optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sa
         else:
             ham = StandardHamiltonian(lh, sampling_iteration_controller(ig), prior_sampling_dtype=mean_iter.dtype)
             if ns == 0:
-                e = EnergyAdapter(mean_iter, ham, want_metric=True)
+                e = EnergyAdapter(mean_iter, ham, constants=cst, want_metric=True)
                 e, _ = minimizer(e)
                 mean = MultiField.union([mean, e.position])
                 sl = SampleList([mean])
             else:
-                e = SampledKLEnergy(mean_iter, ham, ns, nonlinear_sampling_minimizer(ig), comm=comm(ig),
-                                    device_id=device_id)
+                e = SampledKLEnergy(mean_iter, ham, ns, nonlinear_sampling_minimizer(ig), constants=cst,
+                                    point_estimates=pes, comm=comm(ig), device_id=device_id)
                 e, _ = minimizer(e)
                 mean = MultiField.union([mean, e.position])
                 sl = e.samples.at(mean)

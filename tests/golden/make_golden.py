@@ -273,7 +273,51 @@ def minimizer_cases():
     print("wrote minimizers", {k: float(out[k]) for k in out if k.endswith("value")})
 
 
+def constants_cases():
+    """SampledKLEnergy / optimize_kl with `constants` and `point_estimates` (kl_energies.py:162-297,
+    optimize_kl.py:408-421) on the g1d model at its golden position."""
+    z = np.load(os.path.join(HERE, "model_g1d.npz"))
+    sp = ift.RGSpace(tuple(int(i) for i in z["meta.shape"]))
+    cfm, cf = make_cf(sp)
+    d = ift.makeField(cf.target, z["data"])
+    lh = ift.GaussianEnergy(d, ift.ScalingOperator(cf.target, float(z["icov"]), np.float64)) @ cf
+    x = ift.MultiField.from_raw(cf.domain, {k[2:]: z[k] for k in z.files if k.startswith("x.")})
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=6)
+    ham = ift.StandardHamiltonian(lh, ic, prior_sampling_dtype=np.float64)
+    out = {}
+    cst, pes = ["fluctuations", "zeromode"], ["loglogavgslope", "zeromode"]
+    ift.random.push_sseq_from_seed(43)
+    kl = ift.SampledKLEnergy(x, ham, 2, None, mirror_samples=True, constants=cst, point_estimates=pes)
+    ift.random.pop_sseq()
+    out["kl.value"] = np.array(kl.value)
+    out.update(mf2dict(kl.gradient, "kl.grad"))
+    ift.random.push_sseq_from_seed(7)
+    v = ift.from_random(kl.position.domain)
+    ift.random.pop_sseq()
+    out.update(mf2dict(v, "kl.v"))
+    out.update(mf2dict(kl.apply_metric(v), "kl.metric_v"))
+    for i, s in enumerate(kl.samples.iterator()):
+        out.update(mf2dict(s, f"kl.sample{i}"))
+    mini = ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=8)
+    kl2, _ = mini(kl)
+    out["kl.min_value"] = np.array(kl2.value)
+    out.update(mf2dict(kl2.position, "kl.min_pos"))
+    ift.random.push_sseq_from_seed(44)
+    mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=8)
+    sl, mean = ift.optimize_kl(lh, 2, 1, mk, ic, constants=["fluctuations"], point_estimates=["flexibility"],
+                               output_directory=None, return_final_position=True, initial_position=x,
+                               plot_energy_history=False, plot_minisanity_history=False)
+    ift.random.pop_sseq()
+    out.update(mf2dict(mean, "okl.mean"))
+    for i, s in enumerate(sl.iterator()):
+        out.update(mf2dict(s, f"okl.sample{i}"))
+    np.savez_compressed(os.path.join(HERE, "constants.npz"), **out)
+    print("wrote constants", float(out["kl.value"]), sorted(k for k in out if k.startswith("kl.grad")))
+
+
 def main():
+    if "--const-only" in sys.argv:
+        return constants_cases()
     if "--los-only" in sys.argv:
         return los_cases()
     if "--min-only" in sys.argv:
@@ -303,6 +347,7 @@ def main():
     model_case("g2d_sig_geo", (16, 16), None, "gaussian", "sigmoid", 1, True)
     los_cases()
     minimizer_cases()
+    constants_cases()
 
 
 if __name__ == "__main__":

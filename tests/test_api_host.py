@@ -229,3 +229,51 @@ def test_relaxed_newton_on_quadratic():
     e = ift.QuadraticEnergy(ift.full(sp, 0.0), A, b)
     e, status = ift.RelaxedNewton(ift.GradientNormController(iteration_limit=3, tol_abs_gradnorm=1e-10))(e)
     assert gl.relerr(e.position.asnumpy(), (A.inverse_times(b)).asnumpy()) < 1e-12
+
+
+def _lat(z, prefix):
+    return {k[len(prefix) + 1:]: np.asarray(z[k]) for k in z.files if k.startswith(prefix + ".")}
+
+
+@pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
+def test_constants_and_point_estimates_match_reference(device_id):
+    """SampledKLEnergy / optimize_kl with `constants` and `point_estimates` (kl_energies.py:162-297,
+    optimize_kl.py:408-421): value, gradient on the variable keys, metric, samples, a NewtonCG step and a 2-iteration
+    optimize_kl run against tests/golden/constants.npz."""
+    z, zc = gl.load("model_g1d"), gl.load("constants")
+    m, cfm, cf, lh = build(z, device_id)
+    x = ift.MultiField.from_raw(cf.domain, gl.latent(z, "x"), device_id)
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=6)
+    ham = ift.StandardHamiltonian(lh, ic, prior_sampling_dtype=np.float64)
+    cst, pes = ["fluctuations", "zeromode"], ["loglogavgslope", "zeromode"]
+    ift.random.push_sseq_from_seed(43)
+    try:
+        kl = ift.SampledKLEnergy(x, ham, 2, None, mirror_samples=True, constants=cst, point_estimates=pes,
+                                 device_id=device_id)
+    finally:
+        ift.random.pop_sseq()
+    assert set(kl.position.keys()) == set(cf.domain.keys()) - set(cst)
+    assert abs(kl.value - float(zc["kl.value"])) < 1e-9 * abs(float(zc["kl.value"]))
+    assert gl.lat_relerr(kl.gradient.asnumpy(), _lat(zc, "kl.grad")) < 1e-8
+    v = ift.MultiField.from_raw(kl.position.domain, _lat(zc, "kl.v"), device_id)
+    assert gl.lat_relerr(kl.apply_metric(v).asnumpy(), _lat(zc, "kl.metric_v")) < 1e-8
+    for i, s in enumerate(kl.samples.iterator()):
+        ref = _lat(zc, f"kl.sample{i}")
+        assert set(s.keys()) == set(ref) and gl.lat_relerr(s.asnumpy(), ref) < 1e-8
+    mini = ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=8)
+    kl2, _ = mini(kl)
+    assert abs(kl2.value - float(zc["kl.min_value"])) < 1e-7 * abs(float(zc["kl.min_value"]))
+    assert gl.lat_relerr(kl2.position.asnumpy(), _lat(zc, "kl.min_pos")) < 1e-6
+    ift.random.push_sseq_from_seed(44)
+    try:
+        mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2),  # noqa: E731
+                                    max_cg_iterations=8)
+        sl, mean = ift.optimize_kl(lh, 2, 1, mk, ic, constants=["fluctuations"], point_estimates=["flexibility"],
+                                   output_directory=None, return_final_position=True, initial_position=x,
+                                   device_id=device_id)
+    finally:
+        ift.random.pop_sseq()
+    assert gl.lat_relerr(mean.asnumpy(), _lat(zc, "okl.mean")) < 1e-5
+    assert np.array_equal(mean["fluctuations"].asnumpy(), x["fluctuations"].asnumpy())
+    for i, s in enumerate(sl.iterator()):
+        assert gl.lat_relerr(s.asnumpy(), _lat(zc, f"okl.sample{i}")) < 1e-5
