@@ -1,5 +1,8 @@
 """Global configuration (counterpart of reference nifty/config.py:42-80)."""
-_config = dict(hartley_convention="non_canonical_hartley")
+# sampling_rng: "numpy" = the reference's host PCG64 streams (bit-compatible draws, ~10 s per 1e9 normals + the upload);
+#               "device" = the fused engine draws its N(0,1) fields with the device generator, seeded per sample from
+#               the same SeedSequence tree (same statistics and mirrored-pair consistency, different numbers)
+_config = dict(hartley_convention="non_canonical_hartley", sampling_rng="numpy")
 
 
 def get(key):
@@ -19,4 +22,9 @@ def update(key, value, /):
             value = "canonical_hartley"
         else:
             raise ValueError(f"invalid value to {key!r}; got {value!r}")
+    elif key == "sampling_rng":
+        if value not in ("numpy", "device"):
+            raise ValueError(f"invalid value to {key!r}; got {value!r}")
+    else:
+        raise ValueError(f"unknown configuration key {key!r}")
     _config[key] = value

@@ -17,7 +17,7 @@ from inspect import signature
 
 import numpy as np
 
-from . import random
+from . import config, random
 from .domains import DomainTuple, MultiDomain, makeDomain
 from .energy_operators import GaussianEnergy, PoissonianEnergy, StandardHamiltonian, _LikelihoodChain
 from .field import Field, MultiField, from_random, full
@@ -136,8 +136,13 @@ def _fused_iteration(model, lh, mean, n_samples, minimizer, ic_sampling, comm, g
 
     dtype = mean["xi"].dtype
     mean_lv = _mf_to_latent(model, mean)
+    device_rng = None
+    if config.get("sampling_rng") == "device":
+        import torch
+
+        device_rng = torch.Generator(device=model.device)
     residuals, negs, n_total = draw_samples(model, mean_lv, n_samples, True, lambda: ic_sampling, comm,
-                                            geo_minimizer=geo_minimizer)
+                                            device_rng=device_rng, geo_minimizer=geo_minimizer)
     kl = FusedKL(model, mean_lv, residuals, negs, n_total, comm)
     kl, _ = minimizer(kl)
     new_mean = _latent_to_mf(lh.domain, kl.position, dtype)
