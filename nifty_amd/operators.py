@@ -1472,16 +1472,30 @@ class DOFDistributor(LinearOperator):
         self._init2(idx, nbin, UnstructuredDomain(nbin))
 
     def _init2(self, idx, nbin, other_space):
-        self._idx = idx.reshape(-1).to(torch.int64)
+        """idx: tensor of bin indices, or a zero-argument callable producing it on first HOST use (large PowerSpaces
+        never materialise the 8 N byte host index: device applications fetch PowerSpace.device_pindex instead)."""
+        self._idx_src = idx
+        self._idx_host = None
         self._idx32 = {}
         self._nbin = nbin
         self._domain = DomainTuple.make(other_space)
         self._capability = self.TIMES | self.ADJOINT_TIMES
 
+    @property
+    def _idx(self):
+        if self._idx_host is None:
+            src = self._idx_src() if callable(self._idx_src) else self._idx_src
+            self._idx_host = src.reshape(-1).to(torch.int64)
+        return self._idx_host
+
     def _device_index(self, device):
         key = str(device)
         if key not in self._idx32:
-            self._idx32[key] = self._idx.to(torch.int32).to(device).contiguous()
+            pspace = getattr(self, "_pspace", None)
+            if pspace is not None:
+                self._idx32[key] = pspace.device_pindex(device)
+            else:
+                self._idx32[key] = self._idx.to(torch.int32).to(device).contiguous()
         return self._idx32[key]
 
     def apply(self, x, mode):
@@ -1520,7 +1534,7 @@ class PowerDistributor(DOFDistributor):
             if power_space.harmonic_partner != hspace:
                 raise ValueError("power_space does not match its partner")
         self._pspace = power_space
-        self._init2(torch.from_numpy(np.array(power_space.pindex)), power_space.shape[0], power_space)
+        self._init2(lambda: torch.from_numpy(np.array(power_space.pindex)), power_space.shape[0], power_space)
 
 
 class MaskOperator(LinearOperator):

@@ -5,7 +5,7 @@ import pytest
 
 import nifty_amd as ift
 from tests import goldenlib as gl
-from tests.test_api_host import build
+from tests.test_api_host import CF_ARGS, build
 
 pytestmark = pytest.mark.gpu
 
@@ -151,3 +151,38 @@ def test_device_sampling_rng_option():
     assert gl.lat_relerr(mean1.asnumpy(), gl.latent(z, "okl_mean")) > 1e-6  # different draws than the numpy stream
     with pytest.raises(ValueError):
         ift.config.update("sampling_rng", "cuda")
+
+
+def test_large_grid_path_without_host_pindex(monkeypatch):
+    """Grids beyond PowerSpace.HOST_PINDEX_LIMIT (1024^3: the 8 N byte host index is never built) must work through the
+    user-level API: CorrelatedFieldMaker.finalize + optimize_kl on the device.  The limit is lowered to exercise that
+    path on a small grid; the result must equal the ordinary path's."""
+    def run():
+        ift.PowerSpace._cache.clear()
+        ift.random.push_sseq_from_seed(3)
+        try:
+            sp = ift.RGSpace((64, 64, 128))
+            cfm = ift.CorrelatedFieldMaker("")
+            cfm.add_fluctuations(sp, CF_ARGS["fluctuations"], CF_ARGS["flexibility"], CF_ARGS["asperity"],
+                                 CF_ARGS["loglogavgslope"])
+            cfm.set_amplitude_total_offset(2.0, (1e-1, 3e-2))
+            cf = cfm.finalize()
+            rng = np.random.default_rng(0)
+            d = ift.makeField(cf.target, 2.0 + 0.1 * rng.normal(size=sp.shape), 0)
+            lh = ift.GaussianEnergy(d, ift.ScalingOperator(cf.target, 100.0, np.float64)) @ cf
+            ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=4)
+            mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=1),  # noqa: E731
+                                        max_cg_iterations=4)
+            return ift.optimize_kl(lh, 1, 1, mk, ic, output_directory=None, return_final_position=True, device_id=0)[1]
+        finally:
+            ift.random.pop_sseq()
+
+    ref = run().asnumpy()
+    monkeypatch.setattr(ift.PowerSpace, "HOST_PINDEX_LIMIT", 1000)
+    try:
+        got = run().asnumpy()
+        with pytest.raises(MemoryError):
+            ift.PowerSpace(ift.RGSpace((64, 64, 128)).get_default_codomain()).pindex
+    finally:
+        ift.PowerSpace._cache.clear()
+    assert gl.lat_relerr(got, ref) < 1e-10
