@@ -167,9 +167,9 @@ def pointwise(name, x, param=0.0, want_derivative=False):
     return (fx, dfx) if want_derivative else fx
 
 
-def gather(table, pidx, out_shape):
+def gather(table, pidx, out_shape, out=None):
     _require_device(table, pidx)
-    out = torch.empty(out_shape, dtype=table.dtype, device=table.device)
+    out = torch.empty(out_shape, dtype=table.dtype, device=table.device) if out is None else out
     L.check(L.load().nk_gather(out.numel(), table.data_ptr(), pidx.data_ptr(), out.data_ptr(), dtype_code(table),
                                _stream()), "nk_gather")
     return out

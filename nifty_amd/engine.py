@@ -283,6 +283,11 @@ class FusedModel:
             self.octant_vjp = bool(L.load().nk_plan_octant_vjp(self.plan.handle))
             oct_n = int(np.prod([n // 2 + 1 for n in self.shape]))
             self.field_shape = (oct_n,) if self.octant_vjp else self.shape
+            # bin index of the octant points as its own contiguous array: octant fields are plain gathers from it
+            self.pidx8 = None
+            if self.octant_vjp:
+                osl = tuple(slice(0, n // 2 + 1) for n in self.shape)
+                self.pidx8 = self.pidx.view(self.shape)[osl].contiguous().reshape(-1)
             self.dafield = torch.empty(self.field_shape, dtype=dtype, device=self.device)
             self.w8 = torch.empty(oct_n, dtype=torch.float64, device=self.device) if self.octant_vjp else None
             self.merge_swapped = int(len(self.shape) == 3 and self.shape[0] == self.shape[1]
@@ -336,6 +341,8 @@ class FusedModel:
         under the sign flip of every axis): every later prologue / epilogue streams the field instead of gathering."""
         table = amp if self.tdtype == torch.float64 else amp.to(self.tdtype)
         out = torch.empty(self.field_shape, dtype=self.tdtype, device=self.device) if out is None else out
+        if self.pidx8 is not None:
+            return B.gather(table, self.pidx8, self.field_shape, out=out)
         shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
         L.check(L.load().nk_octant_expand(len(self.shape), shp, table.data_ptr(), self.pidx.data_ptr(), out.data_ptr(),
                                           B.dtype_code(out), 1 if self.octant_vjp else 0, B._stream()), "nk_octant_expand")
