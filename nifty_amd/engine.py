@@ -24,7 +24,7 @@ import torch
 
 from . import _lib as L
 from . import backend as B
-from . import random
+from . import parallel, random
 from .domains import PowerSpace, RGSpace
 from .minimization import ConjugateGradient, Energy, QuadraticEnergy
 
@@ -65,6 +65,7 @@ class CgWorkspace:
         lib, st = L.load(), B._stream()
         for i, (dd, qq) in enumerate(self._segments(d, q)):
             L.check(lib.nk_cg_curv(dd.numel(), dd.data_ptr(), qq.data_ptr(), B.dtype_code(dd), self.scal.data_ptr(), i, st))
+        parallel.lockstep_sync_(self.scal[1:2])
 
     def curv_slot(self):
         """Zeroed device slot of d.q for an operator that deposits the xi part itself (``fused_dot``)."""
@@ -76,12 +77,14 @@ class CgWorkspace:
         """Adds the small-part of d.q to the slot an operator has already filled with the xi part."""
         L.check(L.load().nk_cg_curv(d.small.numel(), d.small.data_ptr(), q.small.data_ptr(), B.dtype_code(d.small),
                                     self.scal.data_ptr(), 1, B._stream()))
+        parallel.lockstep_sync_(self.scal[1:2])
 
     def update(self, x, r, d, q, b):
         lib, st = L.load(), B._stream()
         for i, (xx, rr, dd, qq, bb) in enumerate(self._segments(x, r, d, q, b)):
             L.check(lib.nk_cg_update(xx.numel(), xx.data_ptr(), rr.data_ptr(), dd.data_ptr(), qq.data_ptr(), B.ptr(bb),
                                      B.dtype_code(xx), self.scal.data_ptr(), i, st))
+        parallel.lockstep_sync_(self.scal[2:5])
 
     def refresh(self, x, r, b):
         """After a residual refresh: gamma = r.r, x.r and x.b recomputed (device side)."""
@@ -91,6 +94,7 @@ class CgWorkspace:
             res = self.scal[slot:slot + 1]
             B.vdot(u.xi.reshape(-1), v.xi.reshape(-1), result=res, accumulate=False)
             B.vdot(u.small, v.small, result=res, accumulate=True)
+            parallel.lockstep_sync_(res)
 
     def direction(self, d, r):
         lib, st = L.load(), B._stream()
@@ -120,6 +124,7 @@ class ShardedCgWorkspace(CgWorkspace):
         B.vdot(u.xi.reshape(-1), v.xi.reshape(-1), result=res, accumulate=False)
         self.comm.allreduce_sum_([res])
         B.vdot(u.small, v.small, result=res, accumulate=True)
+        self.comm.bcast_(res)  # the replicated small part is reduced per rank: rank 0's last bit for everybody
         return res
 
     def curv(self, d, q):
@@ -128,6 +133,7 @@ class ShardedCgWorkspace(CgWorkspace):
         L.check(lib.nk_cg_curv(dx.numel(), dx.data_ptr(), qx.data_ptr(), B.dtype_code(dx), self.scal.data_ptr(), 0, st))
         self.comm.allreduce_sum_([self.scal[1:2]])
         L.check(lib.nk_cg_curv(ds.numel(), ds.data_ptr(), qs.data_ptr(), B.dtype_code(ds), self.scal.data_ptr(), 1, st))
+        self.comm.bcast_(self.scal[1:2])
 
     def update(self, x, r, d, q, b):
         lib, st = L.load(), B._stream()
@@ -136,6 +142,7 @@ class ShardedCgWorkspace(CgWorkspace):
                                      B.dtype_code(xx), self.scal.data_ptr(), i, st))
             if i == 0:
                 self.comm.allreduce_sum_([self.scal[2:5]])
+        self.comm.bcast_(self.scal[2:5])
 
     def refresh(self, x, r, b):
         for slot, (u, v) in ((2, (r, r)), (3, (x, r)), (4, (x, b))):
@@ -209,7 +216,7 @@ class LatentVec:
         return B.vdot(self.small, o.small, result=res, accumulate=True)
 
     def s_vdot(self, o):
-        return float(self.dot_device(o).item())
+        return parallel.lockstep_float(float(self.dot_device(o).item()), self.xi.device)
 
     def norm(self, ord=2):
         if ord != 2:
@@ -813,5 +820,6 @@ def mgvi_iteration(model, mean, n_samples, controller_factory, kl_minimizer, mir
     residuals, negs, n_total = draw_samples(model, mean, n_samples, mirror_samples, controller_factory, comm, device_rng,
                                             geo_minimizer)
     kl = FusedKL(model, mean, residuals, negs, n_total, comm)
-    kl, _ = kl_minimizer(kl)
+    with parallel.lockstep(comm):  # replicated minimiser: identical decisions on every rank
+        kl, _ = kl_minimizer(kl)
     return kl.position, kl

@@ -11,7 +11,7 @@ import torch
 
 from . import backend as B
 from . import _lib as L
-from . import random
+from . import parallel, random
 from .domains import DomainTuple, MultiDomain, makeDomain
 
 _NP2T = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
@@ -217,7 +217,7 @@ class Field:
         dt = torch.promote_types(a.dtype, b.dtype)
         if not dt.is_floating_point:
             dt = torch.float64
-        return float(B.vdot(_cast(a, dt).contiguous(), _cast(b, dt).contiguous()).item())
+        return parallel.lockstep_float(float(B.vdot(_cast(a, dt).contiguous(), _cast(b, dt).contiguous()).item()), a.device)
 
     def vdot(self, x):
         return Field.scalar(self.s_vdot(x)).at(self.device_id)

@@ -63,18 +63,24 @@ class Energy:
 class QuadraticEnergy(Energy):
     """E(x) = 1/2 x^T A x - b^T x   (reference quadratic_energy.py:27-78)."""
 
-    def __init__(self, position, A, b, _grad=None):
+    def __init__(self, position, A, b, _grad=None, _value=None):
         super().__init__(position)
         self._A, self._b = A, b
+        self._grad = _grad
         if _grad is None:
             Ax = self._A(self._position)
             self._grad = Ax if b is None else Ax - b
-        else:
-            self._grad = _grad
-            Ax = _grad if b is None else _grad + b
-        self._value = 0.5 * np.real(self._position.s_vdot(Ax))
+        # the value costs three passes over the vectors: taken on first use (a CG result is usually only asked for its
+        # position), or handed in by a caller that knows it (x = 0 -> 0)
+        self._value = _value
+
+    def _compute_value(self):
+        b = self._b
+        Ax = self._grad if b is None else self._grad + b
+        val = 0.5 * np.real(self._position.s_vdot(Ax))
         if b is not None:
-            self._value -= np.real(b.s_vdot(self._position))
+            val -= np.real(b.s_vdot(self._position))
+        return val
 
     def at(self, position):
         return QuadraticEnergy(position, self._A, self._b)
@@ -84,6 +90,8 @@ class QuadraticEnergy(Energy):
 
     @property
     def value(self):
+        if self._value is None:
+            self._value = self._compute_value()
         return self._value
 
     @property
@@ -757,7 +765,7 @@ class NewtonCG(DescentMinimizer):
         # QuadraticEnergy(0*pos, metric, gradient): A(0) = 0 exactly, so the start gradient is -g and the
         # reference's metric application to the zero vector is skipped.
         zero = energy.position * 0.0
-        quad = QuadraticEnergy(zero, energy.metric, g, _grad=-g)
+        quad = QuadraticEnergy(zero, energy.metric, g, _grad=-g, _value=0.0)  # E(0) = 0
         quad, conv = ConjugateGradient(ic, nreset=self._nreset)(quad)
         if self._history is not None:
             self._history += ic.history

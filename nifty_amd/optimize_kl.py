@@ -17,7 +17,7 @@ from inspect import signature
 
 import numpy as np
 
-from . import config, random
+from . import config, parallel, random
 from .domains import DomainTuple, MultiDomain, makeDomain
 from .energy_operators import GaussianEnergy, PoissonianEnergy, StandardHamiltonian, _LikelihoodChain
 from .field import Field, MultiField, from_random, full
@@ -144,7 +144,8 @@ def _fused_iteration(model, lh, mean, n_samples, minimizer, ic_sampling, comm, g
     residuals, negs, n_total = draw_samples(model, mean_lv, n_samples, True, lambda: ic_sampling, comm,
                                             device_rng=device_rng, geo_minimizer=geo_minimizer)
     kl = FusedKL(model, mean_lv, residuals, negs, n_total, comm)
-    kl, _ = minimizer(kl)
+    with parallel.lockstep(comm):  # replicated minimiser: identical decisions on every rank
+        kl, _ = minimizer(kl)
     new_mean = _latent_to_mf(lh.domain, kl.position, dtype)
     res_mf = [_latent_to_mf(lh.domain, r, dtype) for r in residuals]
     return new_mean, ResidualSampleList(new_mean, res_mf, negs, comm), kl.value
@@ -263,13 +264,15 @@ def optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sa
             ham = StandardHamiltonian(lh, sampling_iteration_controller(ig), prior_sampling_dtype=mean_iter.dtype)
             if ns == 0:
                 e = EnergyAdapter(mean_iter, ham, constants=cst, want_metric=True)
-                e, _ = minimizer(e)
+                with parallel.lockstep(comm(ig)):
+                    e, _ = minimizer(e)
                 mean = MultiField.union([mean, e.position])
                 sl = SampleList([mean])
             else:
                 e = SampledKLEnergy(mean_iter, ham, ns, nonlinear_sampling_minimizer(ig), constants=cst,
                                     point_estimates=pes, comm=comm(ig), device_id=device_id)
-                e, _ = minimizer(e)
+                with parallel.lockstep(comm(ig)):
+                    e, _ = minimizer(e)
                 mean = MultiField.union([mean, e.position])
                 sl = e.samples.at(mean)
             energy_history.append((ig, e.value))

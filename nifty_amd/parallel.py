@@ -32,10 +32,21 @@ class Comm:
         self.backend = str(dist.get_backend(group))
         self.backend_is_nccl = "nccl" in self.backend
 
+    def _staged(self, t, fn):
+        """Run collective `fn` on `t`.  RCCL works on the device tensor; any other backend (gloo: tests, several ranks on
+        one GPU) gets an explicit host copy -- gloo's own device-tensor staging deadlocked intermittently here."""
+        if self.backend_is_nccl or not t.is_cuda:
+            fn(t)
+            return t
+        h = t.detach().cpu()
+        fn(h)
+        t.copy_(h)
+        return t
+
     def allreduce_sum_(self, tensors):
         """In-place sum over ranks of every tensor in the list (one collective per tensor)."""
         for t in tensors:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._staged(t, lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group))
         return tensors
 
     # -- sharded vectors: the CG state of the KL minimisation lives on 1/size of the latent vector per rank -------
@@ -74,7 +85,7 @@ class Comm:
         if self._native_reduce_scatter(full.device):
             dist.reduce_scatter_tensor(shard, full, op=dist.ReduceOp.SUM, group=self.group)
         else:
-            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
+            self.allreduce_sum_([full])
             shard.copy_(full[self.rank * n:(self.rank + 1) * n])
         return shard
 
@@ -83,27 +94,76 @@ class Comm:
         n = shard.numel()
         if full.numel() != n * self.size:
             raise ValueError("all_gather: length not divisible by the rank count")
-        try:
-            dist.all_gather_into_tensor(full, shard, group=self.group)
-        except (RuntimeError, NotImplementedError):
-            dist.all_gather([full[i * n:(i + 1) * n] for i in range(self.size)], shard, group=self.group)
+        if self.backend_is_nccl or not full.is_cuda:
+            try:
+                dist.all_gather_into_tensor(full, shard, group=self.group)
+            except (RuntimeError, NotImplementedError):
+                dist.all_gather([full[i * n:(i + 1) * n] for i in range(self.size)], shard, group=self.group)
+            return full
+        parts = [torch.empty(n, dtype=shard.dtype) for _ in range(self.size)]  # host staging, see _staged
+        dist.all_gather(parts, shard.detach().cpu(), group=self.group)
+        full.copy_(torch.cat(parts))
         return full
 
     def bcast_(self, tensor, root=0):
-        dist.broadcast(tensor, src=root, group=self.group)
-        return tensor
+        return self._staged(tensor, lambda x: dist.broadcast(x, src=root, group=self.group))
 
     def barrier(self):
         dist.barrier(group=self.group)
 
     def max_float(self, value, device):
-        t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=device if self.backend_is_nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
     @property
     def is_master(self):
         return self.rank == 0
+
+
+# ---- lockstep scope --------------------------------------------------------------------------------------
+# Device reductions end in fp64 atomics, so two ranks that reduce IDENTICAL replicated data may differ in the last
+# bit.  Inside a replicated computation (the KL minimisation: every rank runs the same minimiser on the same
+# all-reduced values) every host decision must nevertheless be identical on all ranks, or one rank leaves a loop the
+# others stay in and the next collective deadlocks.  Within `lockstep(comm)` every scalar that can steer control flow
+# -- host dot products, the CG's device scalars -- is therefore taken from rank 0.  The sampling phase (independent
+# per-rank solves) runs outside the scope.
+_lockstep_stack = []
+
+
+class lockstep:
+    def __init__(self, comm):
+        self._comm = comm if (comm is not None and comm.size > 1) else None
+
+    def __enter__(self):
+        _lockstep_stack.append(self._comm)
+        return self
+
+    def __exit__(self, *exc):
+        _lockstep_stack.pop()
+        return False
+
+
+def lockstep_comm():
+    return _lockstep_stack[-1] if _lockstep_stack else None
+
+
+def lockstep_float(value, device):
+    """`value` of rank 0 on every rank while a lockstep scope is active, else `value`."""
+    comm = lockstep_comm()
+    if comm is None:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    comm.bcast_(t)
+    return float(t.item())
+
+
+def lockstep_sync_(tensor):
+    """In-place: rank 0's content of a (small, device) tensor on every rank while a lockstep scope is active."""
+    comm = lockstep_comm()
+    if comm is not None:
+        comm.bcast_(tensor)
+    return tensor
 
 
 def init(backend=None):

@@ -112,13 +112,18 @@ def test_optimize_kl_geovi_on_device_matches_reference(fuse):
                                     max_cg_iterations=8)
         nl = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=3, convergence_level=2),  # noqa: E731
                                     max_cg_iterations=6)
-        sl, mean = ift.optimize_kl(lh, 2, m["n_samples"], mk, ic_s, nonlinear_sampling_minimizer=nl, output_directory=None,
+        sl, mean = ift.optimize_kl(lh, 1, m["n_samples"], mk, ic_s, nonlinear_sampling_minimizer=nl, output_directory=None,
                                    return_final_position=True, device_id=0, fuse=fuse)
     finally:
         ift.random.pop_sseq()
-    assert gl.lat_relerr(mean.asnumpy(), gl.latent(z, "okl_mean")) < 2e-3
+    # ONE iteration (tests/golden/okl1.npz): device sums are order-dependent at 1e-16 (fp64 atomics) and the second
+    # iteration of this configuration amplifies that to 1e-3..1e-2 through a discrete decision; the two-iteration
+    # vectors are checked on the (deterministic) host path
+    z1 = gl.load("okl1")
+    lat = lambda pre: {k[len(pre) + 1:]: np.asarray(z1[k]) for k in z1.files if k.startswith(pre + ".")}  # noqa: E731
+    assert gl.lat_relerr(mean.asnumpy(), lat("p2d_geo.mean")) < 1e-6
     for i, s in enumerate(sl.iterator()):
-        assert gl.lat_relerr(s.asnumpy(), gl.latent(z, f"okl_sample{i}")) < 5e-3
+        assert gl.lat_relerr(s.asnumpy(), lat(f"p2d_geo.sample{i}")) < 1e-6
 
 
 def test_device_sampling_rng_option():

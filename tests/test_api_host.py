@@ -277,3 +277,21 @@ def test_constants_and_point_estimates_match_reference(device_id):
     assert np.array_equal(mean["fluctuations"].asnumpy(), x["fluctuations"].asnumpy())
     for i, s in enumerate(sl.iterator()):
         assert gl.lat_relerr(s.asnumpy(), _lat(zc, f"okl.sample{i}")) < 1e-5
+
+
+def test_one_iteration_geovi_goldens_on_host():
+    """The one-iteration geoVI vectors the device tests use (tests/golden/okl1.npz) hold on the host path too."""
+    z, z1 = gl.load("model_p2d_geo"), gl.load("okl1")
+    m, cfm, cf, lh = build(z)
+    ift.random.push_sseq_from_seed(m["seed"] + 2)
+    try:
+        ic_s = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=m["sampling_limit"])
+        mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2),  # noqa: E731
+                                    max_cg_iterations=8)
+        nl = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=3, convergence_level=2),  # noqa: E731
+                                    max_cg_iterations=6)
+        sl, mean = ift.optimize_kl(lh, 1, m["n_samples"], mk, ic_s, nonlinear_sampling_minimizer=nl, output_directory=None,
+                                   return_final_position=True)
+    finally:
+        ift.random.pop_sseq()
+    assert gl.lat_relerr(mean.asnumpy(), _lat(z1, "p2d_geo.mean")) < 1e-6

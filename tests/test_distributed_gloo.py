@@ -83,6 +83,9 @@ def test_share_range_matches_reference_semantics():
 
 
 def _engine_worker(rank, world, port, out):
+    import faulthandler
+
+    faulthandler.dump_traceback_later(150, exit=True)  # a rank that waits for a lost partner must not hang the suite
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -106,7 +109,8 @@ def _engine_worker(rank, world, port, out):
     assert getattr(kl.metric, "sharded", None) is not None  # the CG below runs on per-rank shards of the latent vector
     out_d = dict(value=kl.value, grad=kl.gradient.to_dict(), met=kl.apply_metric(vl).to_dict())
     mini = NewtonCG(AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=8)
-    kl2, _ = mini(kl)
+    with parallel.lockstep(comm):  # as engine.mgvi_iteration / optimize_kl do: rank 0's scalars steer every rank
+        kl2, _ = mini(kl)
     out_d["min_value"] = kl2.value
     out_d["min_pos"] = kl2.position.to_dict()
     if rank == 0:
@@ -133,6 +137,9 @@ def test_two_rank_fused_engine_equals_reference(tmp_path):
 
 
 def _nccl_single_worker(rank, world, port):
+    import faulthandler
+
+    faulthandler.dump_traceback_later(150, exit=True)
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                       HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -133,14 +133,24 @@ def _check_c4(device_id):
                                     max_cg_iterations=8)
         nl = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=3, convergence_level=2),  # noqa: E731
                                     max_cg_iterations=6)
-        sl, mean = ift.optimize_kl(lh, 2, 1, mk, ic, nonlinear_sampling_minimizer=nl, output_directory=None,
+        nit = 2 if device_id < 0 else 1
+        sl, mean = ift.optimize_kl(lh, nit, 1, mk, ic, nonlinear_sampling_minimizer=nl, output_directory=None,
                                    return_final_position=True, initial_position=x, device_id=device_id)
     finally:
         ift.random.pop_sseq()
-    # geoVI: bounded CG lengths keep the run in the reproducible regime (see make_golden.py GEO_CG)
-    assert gl.lat_relerr(mean.asnumpy(), gl.latent(z, "c4.okl_mean")) < 2e-3
+    if device_id < 0:
+        # geoVI: bounded CG lengths keep the run in the reproducible regime (see make_golden.py GEO_CG)
+        assert gl.lat_relerr(mean.asnumpy(), gl.latent(z, "c4.okl_mean")) < 2e-3
+        for i, s in enumerate(sl.iterator()):
+            assert gl.lat_relerr(s.asnumpy(), gl.latent(z, f"c4.okl_sample{i}")) < 5e-3
+        return
+    # device: ONE iteration (okl1.npz) -- order-dependent fp64 atomics (1e-16) are amplified to 1e-3..1e-2 by a discrete
+    # decision in the second iteration of this configuration (see make_golden.py::okl1_cases)
+    z1 = gl.load("okl1")
+    lat = lambda pre: {k[len(pre) + 1:]: np.asarray(z1[k]) for k in z1.files if k.startswith(pre + ".")}  # noqa: E731
+    assert gl.lat_relerr(mean.asnumpy(), lat("c4.mean")) < 1e-6
     for i, s in enumerate(sl.iterator()):
-        assert gl.lat_relerr(s.asnumpy(), gl.latent(z, f"c4.okl_sample{i}")) < 5e-3
+        assert gl.lat_relerr(s.asnumpy(), lat(f"c4.sample{i}")) < 1e-6
 
 
 def test_config4_model_host():
