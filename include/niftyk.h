@@ -133,6 +133,9 @@ int nk_profile_collect(double* ms, int64_t* count);
  *      unless accumulate == 0 (then the kernel chain zeroes it first). */
 int nk_vdot(int64_t n, const void* a, const void* b, int dtype, double* result, int accumulate, void* stream);
 int nk_sum(int64_t n, const void* a, int dtype, double* result, int accumulate, void* stream);
+/* result3 = {sum, sum of squares, count} of a over the entries that are neither NaN nor exactly 0 (count = the ignored
+ * ones): the per-key statistics of extra.minisanity (extra.py:640-654) */
+int nk_stats(int64_t n, const void* a, int dtype, double* result3, void* stream);
 
 /* ---- element-wise vector algebra used by Field/MultiField arithmetic and CG
  *      (field.py:755-763, conjugate_gradient.py:100-124, quadratic_energy.py:31-39) */

@@ -48,6 +48,7 @@ SIGNATURES = {
     "nk_profile_collect": (_i, [_vp, _vp]),
     "nk_vdot": (_i, [_i64, _vp, _vp, _i, _vp, _i, _vp]),
     "nk_sum": (_i, [_i64, _vp, _i, _vp, _i, _vp]),
+    "nk_stats": (_i, [_i64, _vp, _i, _vp, _vp]),
     "nk_binary": (_i, [_i, _i64, _vp, _d, _vp, _d, _vp, _i, _vp]),
     "nk_axpby": (_i, [_i64, _d, _vp, _d, _vp, _vp, _i, _vp]),
     "nk_pointwise": (_i, [_i, _d, _i64, _vp, _vp, _vp, _i, _vp]),

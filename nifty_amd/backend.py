@@ -200,3 +200,13 @@ def spmv_t(rowptr, col, wgt, y, ncols):
     L.check(L.load().nk_spmv_t(y.numel(), rowptr.data_ptr(), col.data_ptr(), wgt.data_ptr(), y.data_ptr(), x64.data_ptr(),
                                dtype_code(y), _stream()), "nk_spmv_t")
     return x64.to(y.dtype)  # dtype conversion copy only (same convention as scatter_add's callers)
+
+
+def stats(x):
+    """(sum, sum of squares, number of ignored entries) over the entries of x that are neither NaN nor 0."""
+    _require_device(x)
+    res = torch.empty(3, dtype=torch.float64, device=x.device)
+    xc = x.contiguous()
+    L.check(L.load().nk_stats(xc.numel(), xc.data_ptr(), dtype_code(xc), res.data_ptr(), _stream()), "nk_stats")
+    s, s2, nign = res.cpu().tolist()
+    return s, s2, int(round(nign))

@@ -146,6 +146,29 @@ struct FSum {
   }
 };
 
+// sum, sum of squares and the number of ignored entries (NaN or exactly 0) -- the statistics of extra.minisanity
+template <typename T>
+struct FStats {
+  static constexpr int NRED = 3;
+  const T* a;
+  double* result;
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double* red) const {
+    T x[V];
+    nk_ld<T, V>(a, i, x);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const double v = (double)x[k];
+      const bool ign = (v != v) || v == 0.0;
+      if (!ign) {
+        red[0] += v;
+        red[1] += v * v;
+      }
+      red[2] += ign ? 1.0 : 0.0;
+    }
+  }
+};
+
 template <typename T>
 struct FBinary {
   static constexpr int NRED = 0;
@@ -372,6 +395,17 @@ extern "C" int nk_sum(int64_t n, const void* a, int dtype, double* result, int a
   NK_DISPATCH_DTYPE(dtype, {
     FSum<T> f{(const T*)a, result};
     return nk_launch_map<T>(n, f, nk_aligned16(a), st, "nk_sum");
+  })
+}
+
+extern "C" int nk_stats(int64_t n, const void* a, int dtype, double* result3, void* stream) {
+  if (n < 0 || !result3 || (n > 0 && !a)) return nk_set_error(NK_ERR_INVALID, "nk_stats: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = nk_zero(result3, 3, st);
+  if (rc != NK_OK) return rc;
+  NK_DISPATCH_DTYPE(dtype, {
+    FStats<T> f{(const T*)a, result3};
+    return nk_launch_map<T>(n, f, nk_aligned16(a), st, "nk_stats");
   })
 }
 

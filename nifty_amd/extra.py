@@ -6,7 +6,7 @@ import numpy as np
 from .field import Field, MultiField, device_available, from_random
 from .operators import Linearization, LinearOperator, Operator
 
-__all__ = ["check_linear_operator", "check_operator", "assert_allclose"]
+__all__ = ["check_linear_operator", "check_operator", "assert_allclose", "minisanity"]
 
 
 def assert_allclose(f1, f2, atol=0, rtol=1e-7):
@@ -121,3 +121,113 @@ def check_operator(op, loc, tol=1e-12, ntries=100, only_r_differentiable=True, f
             pos = nxt
             check_linear_operator(linmid.jac, only_r_linear=only_r_differentiable, atol=tol, rtol=tol,
                                   _device_ids_override=[dev])
+
+
+# ------------------------------------------------------------------------------------------------
+# minisanity (reference extra.py:552-758)
+# ------------------------------------------------------------------------------------------------
+class _Running:
+    """Mean and unbiased variance of a stream of numbers (reference probing.py:24-80, Welford)."""
+
+    def __init__(self):
+        self.n, self.mean, self.m2 = 0, 0.0, 0.0
+
+    def add(self, v):
+        self.n += 1
+        d = v - self.mean
+        self.mean += d / self.n
+        self.m2 += d * (v - self.mean)
+
+    def result(self):
+        return {"mean": self.mean, "std": float(np.sqrt(self.m2 / (self.n - 1))) if self.n > 1 else None}
+
+
+def _key_stats(field):
+    """(sum, sum of squares, #ignored, size) of one Field, ignoring NaN and exact zeros; device Fields are reduced by
+    libniftyk (nk_stats), host Fields by numpy."""
+    from . import backend as B
+
+    v = field.val
+    if v.is_cuda and not v.is_complex():
+        s, s2, nign = B.stats(v)
+        return s, s2, nign, v.numel()
+    a = field.asnumpy()
+    nign = int(np.sum(np.isnan(a)) + np.sum(a == 0))
+    return np.nansum(a), float(np.nansum(np.abs(a) ** 2)), nign, a.size
+
+
+def minisanity(likelihood_energy, samples, terminal_colors=True, return_values=False):
+    """Table of reduced chi^2, mean and degrees of freedom of the normalised data residuals and of the latent
+    variables, averaged over the samples (same arguments, table layout and return values as the reference,
+    extra.py:552-723).  Values far from 1 (chi^2) / 0 (mean) point at a bad fit or a mis-specified prior."""
+    from .domains import MultiDomain
+    from .energy_operators import LikelihoodEnergyOperator
+    from .kl import SampleListBase
+
+    if not isinstance(samples, SampleListBase):
+        raise TypeError("Minisanity takes only SampleLists as input. Wrap a single field via `ift.SampleList([field])`.")
+    if not isinstance(likelihood_energy, LikelihoodEnergyOperator):
+        return ""
+    name = likelihood_energy.name if likelihood_energy.name is not None else "<None>"
+
+    def as_dict(f, single_key):
+        return {k: f[k] for k in f.keys()} if isinstance(f.domain, MultiDomain) else {single_key: f}
+
+    # per local sample and key: (reduced chi^2, mean, ndof, #ignored); distributed sample lists exchange these few
+    # numbers so that every rank reports the statistics of ALL samples in global sample order
+    local = []
+    for x in samples.local_iterator():
+        parts = (as_dict(likelihood_energy.normalized_residual(x), name), as_dict(x, "<None>"))
+        row = []
+        for part in parts:
+            ent = {}
+            for k in sorted(part):
+                s, s2, nign, size = _key_stats(part[k])
+                ndof = size - nign
+                ent[k] = (s2 / ndof if ndof > 0 else s2, s / ndof if ndof > 0 else s, ndof, nign)
+            row.append(ent)
+        local.append(row)
+    comm = getattr(samples, "_comm", None)
+    if comm is not None and comm.size > 1:
+        local = [row for part in comm.allgather_object(local) for row in part]
+    groups = [{}, {}]  # data residuals, latent variables: key -> [chi^2 accumulator, mean accumulator, ndof, nign]
+    for row in local:
+        for grp, ent in zip(groups, row):
+            for k, (chi, mean, ndof, nign) in ent.items():
+                acc = grp.setdefault(k, [_Running(), _Running(), 0, 0])
+                acc[0].add(chi)
+                acc[1].add(mean)
+                acc[2], acc[3] = ndof, nign
+    keylen = min(max([18] + [len(k) for g in groups for k in g]), 42)
+    col = (lambda c: c) if terminal_colors else (lambda c: "")
+    warn, fail, bold, endc = col("\033[33m"), col("\033[31m"), col("\033[1m"), col("\033[0m")
+
+    def table(grp):
+        lines = []
+        for k, (chi, mean, ndof, nign) in grp.items():
+            chi, mean = chi.result(), mean.result()
+            out = "  " + (k[:keylen - 1] + "…" if len(k) > keylen else k.ljust(keylen))
+            foo = f"{chi['mean']:.1f}" + ("" if chi["std"] is None else f" ± {chi['std']:.1f}")
+            if chi["mean"] > 5 or chi["mean"] < 1 / 5:
+                out += fail + bold + f"{foo:>11}" + endc
+            elif chi["mean"] > 2 or chi["mean"] < 1 / 2:
+                out += warn + bold + f"{foo:>11}" + endc
+            else:
+                out += f"{foo:>11}"
+            foo = f"{mean['mean']:.1f}" + ("" if mean["std"] is None else f" ± {mean['std']:.1f}")
+            out += f"{foo:>14}" + f"{ndof:>11}" + f"{'-' if nign == 0 else nign:>11}"
+            lines.append(out)
+        return "\n".join(lines)
+
+    n = 49 + keylen
+    head = (keylen + 2) * " " + "{:>11}".format("reduced χ²") + "{:>14}".format("mean") + "{:>11}".format("# dof") \
+        + "{:>11}".format("# ign. dof")
+    res = "\n".join([n * "=", head, n * "-", "Data residuals", table(groups[0]), "Latent space", table(groups[1]), n * "="])
+    if not return_values:
+        return res
+    pick = lambda g, i: {k: (v[i].result() if i < 2 else v[i]) for k, v in g.items()}  # noqa: E731
+    values = {"redchisq": {"data_residuals": pick(groups[0], 0), "latent_variables": pick(groups[1], 0)},
+              "scmean": {"data_residuals": pick(groups[0], 1), "latent_variables": pick(groups[1], 1)},
+              "ndof": {"data_residuals": pick(groups[0], 2), "latent_variables": pick(groups[1], 2)},
+              "nigndof": {"data_residuals": pick(groups[0], 3), "latent_variables": pick(groups[1], 3)}}
+    return res, values

@@ -8,7 +8,7 @@ Fusion pass (``fuse=True``, device runs only): when the likelihood is
 ``GaussianEnergy | PoissonianEnergy  @  [exp | sigmoid]  @  CorrelatedFieldOperator`` the iteration runs
 on the fused engine (engine.py: one forward + one adjoint transform per sample and metric application,
 CG with device-resident scalars) and the results are handed back as MultiFields / ResidualSampleList.
-Everything else walks the generic operator graph.  Plotting, minisanity and HDF5 export of the
+Everything else walks the generic operator graph.  Plotting and HDF5 export of the
 reference are diagnostics outside the hot path and not implemented.
 """
 import os
@@ -283,6 +283,15 @@ def optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sa
                     f.write(str(ig))
                 with open(os.path.join(output_directory, "pickle", "energy_history_" + fname(ig)), "wb") as f:
                     pickle.dump(energy_history, f)
+        # fit-quality table of this iteration (optimize_kl.py:438, 571-578): logged, and appended to minisanity.txt
+        from .extra import minisanity
+
+        table = minisanity(lh, sl, terminal_colors=False)
+        if table and get_MPI_params_from_comm(comm(ig))[2]:
+            logger.info(f"Iteration {ig}: minisanity\n{table}")
+            if output_directory is not None:
+                with open(os.path.join(output_directory, "minisanity.txt"), "a") as f:
+                    f.write(f"Iteration {ig}\n{table}\n\n")
         cb = inspect_callback
         if cb is not None and callable(cb):
             try:

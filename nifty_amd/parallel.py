@@ -105,6 +105,12 @@ class Comm:
         full.copy_(torch.cat(parts))
         return full
 
+    def allgather_object(self, obj):
+        """List of every rank's (small, picklable) object in rank order."""
+        out = [None] * self.size
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
     def bcast_(self, tensor, root=0):
         return self._staged(tensor, lambda x: dist.broadcast(x, src=root, group=self.group))
 

@@ -295,3 +295,24 @@ def test_one_iteration_geovi_goldens_on_host():
     finally:
         ift.random.pop_sseq()
     assert gl.lat_relerr(mean.asnumpy(), _lat(z1, "p2d_geo.mean")) < 1e-6
+
+
+@pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
+def test_minisanity_table(device_id):
+    """extra.minisanity (extra.py:552-723) on the g1d model with its golden MGVI residuals: the table text below is the
+    reference's own output for these inputs; device Fields are reduced by nk_stats."""
+    z = gl.load("model_g1d")
+    m, cfm, cf, lh = build(z, device_id)
+    x = ift.MultiField.from_raw(cf.domain, gl.latent(z, "x"), device_id)
+    res = [ift.MultiField.from_raw(cf.domain, gl.latent(z, f"residual{i}"), device_id) for i in range(2)]
+    sl = ift.ResidualSampleList(x, res, [False, False])
+    table, vals = ift.extra.minisanity(lh, sl, terminal_colors=False, return_values=True)
+    expect = [("<None>", "68.6 ± 3.2", "0.0 ± 0.2", "128"), ("asperity", "0.0 ± 0.0", "0.2 ± 0.1", "1"),
+              ("flexibility", "4.1 ± 2.7", "-0.5 ± 2.8", "1"), ("spectrum", "1.2 ± 0.2", "-0.0 ± 0.1", "126"),
+              ("xi", "1.1 ± 0.1", "-0.0 ± 0.1", "128"), ("zeromode", "0.3 ± 0.1", "-0.1 ± 0.8", "1")]
+    lines = {ln.split()[0]: ln for ln in table.splitlines() if ln.startswith("  ")}
+    for key, chi, mean, ndof in expect:
+        assert chi in lines[key] and mean in lines[key] and lines[key].split()[-2] == ndof, lines[key]
+    assert vals["ndof"]["latent_variables"]["xi"] == 128 and vals["nigndof"]["data_residuals"]["<None>"] == 0
+    with pytest.raises(TypeError):
+        ift.extra.minisanity(lh, [x])
