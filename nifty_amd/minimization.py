@@ -71,8 +71,14 @@ class QuadraticEnergy(Energy):
             Ax = self._A(self._position)
             self._grad = Ax if b is None else Ax - b
         # the value costs three passes over the vectors: taken on first use (a CG result is usually only asked for its
-        # position), or handed in by a caller that knows it (x = 0 -> 0)
+        # position), or handed in by a caller that knows it (x = 0 -> 0).  Inside a multi-rank lockstep scope the dots
+        # are collectives, so there it is taken right away -- never lazily by whichever rank happens to ask
         self._value = _value
+        if _value is None:
+            from . import parallel
+
+            if parallel.lockstep_comm() is not None:
+                self._value = self._compute_value()
 
     def _compute_value(self):
         b = self._b
