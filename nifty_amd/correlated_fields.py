@@ -339,8 +339,6 @@ class CorrelatedFieldMaker:
 
     def add_fluctuations(self, target_subdomain, fluctuations, flexibility, asperity, loglogavgslope, prefix="",
                          index=None, dofdex=None, harmonic_partner=None):
-        if len(self._a) > 0:
-            raise NotImplementedError("product spectra (several add_fluctuations calls) are not implemented yet")
         if dofdex is not None or index is not None:
             raise NotImplementedError("dofdex / index are out of scope")
         if flexibility is None or asperity is None:
@@ -393,17 +391,24 @@ class CorrelatedFieldMaker:
         return tuple(self._a)
 
     def get_normalized_amplitudes(self):
-        amp = self._a[0]
-        pspace = amp.target[0]
-        mask, unmask = np.zeros(pspace.shape), np.zeros(pspace.shape)
-        mask[1:] = unmask[0] = 1.0
-        zm_mask = DiagonalOperator(makeField(amp.target, mask))
-        zm_unmask = makeField(amp.target, unmask)
-        na = ContractionOperator(amp.target, None).adjoint @ self.azm.reciprocal()
-        return (amp * (zm_mask(na) + zm_unmask),)
+        """Amplitudes corrected for the otherwise degenerate zero mode: a_i * (1/azm on k != 0, 1 on k = 0)
+        (reference correlated_fields.py:809-858)."""
+        out = []
+        for amp in self._a:
+            pspace = amp.target[0]
+            mask, unmask = np.zeros(pspace.shape), np.zeros(pspace.shape)
+            mask[1:] = unmask[0] = 1.0
+            zm_mask = DiagonalOperator(makeField(amp.target, mask))
+            zm_unmask = makeField(amp.target, unmask)
+            na = ContractionOperator(amp.target, None).adjoint @ self.azm.reciprocal()
+            out.append(amp * (zm_mask(na) + zm_unmask))
+        return tuple(out)
 
     @property
     def amplitude(self):
+        if len(self._a) > 1:  # reference correlated_fields.py:860-866
+            raise NotImplementedError("If more than one spectrum is present in the model, no unique set of amplitudes exist "
+                                      "because only the relative scale is determined.")
         na = self.get_normalized_amplitudes()[0]
         return na * (ContractionOperator(na.target, None).adjoint @ self.azm)
 
@@ -412,11 +417,20 @@ class CorrelatedFieldMaker:
         return self.amplitude ** 2
 
     def _generic_graph(self):
-        hspace = makeDomain(self._a[0].target[0].harmonic_partner)
-        ht = HarmonicTransformOperator(hspace, self._target_subdomains[0][0])
-        a = self.get_normalized_amplitudes()[0]
-        pd = PowerDistributor(hspace, a.target[0])
-        corr = pd @ a
+        """offset + HT( azm * prod_i a_i[pindex_i] * xi ) on the product of the harmonic spaces
+        (reference correlated_fields.py:713-764)."""
+        n = len(self._a)
+        hspace = makeDomain([a.target[0].harmonic_partner for a in self._a])
+        ht = HarmonicTransformOperator(hspace, self._target_subdomains[0][0], space=0)
+        for i in range(1, n):
+            ht = HarmonicTransformOperator(ht.target, self._target_subdomains[i][0], space=i) @ ht
+        amps = list(self.get_normalized_amplitudes())
+        for i in range(n):
+            co = ContractionOperator(hspace, tuple(j for j in range(n) if j != i))
+            amps[i] = co.adjoint @ PowerDistributor(co.target, amps[i].target[0]) @ amps[i]
+        corr = amps[0]
+        for a in amps[1:]:
+            corr = corr * a
         xi = Variable(hspace, self._prefix + "xi")
         expander = ContractionOperator(hspace, None).adjoint
         azm = expander @ self.azm
@@ -426,12 +440,12 @@ class CorrelatedFieldMaker:
         return op
 
     def finalize(self, prior_info=0):
-        if len(self._a) != 1 or self._azm is None:
-            raise NotImplementedError("exactly one add_fluctuations() and set_amplitude_total_offset() call required")
+        if len(self._a) < 1 or self._azm is None:
+            raise NotImplementedError("add_fluctuations() and set_amplitude_total_offset() must have been called")
         generic = self._generic_graph()
         pos = self._target_subdomains[0][0]
-        if not isinstance(pos, RGSpace) or self._amp_prefix != self._prefix:
-            return generic
+        if len(self._a) > 1 or not isinstance(pos, RGSpace) or self._amp_prefix != self._prefix:
+            return generic  # product spectra run on the generic operator graph
         return CorrelatedFieldOperator(pos, generic, self._prefix, 0.0 if self._offset_mean is None else self._offset_mean,
                                        dict(self._hyper))
 

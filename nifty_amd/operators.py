@@ -1256,23 +1256,32 @@ class ContractionOperator(LinearOperator):
         self._power = power
         self._capability = self.TIMES | self.ADJOINT_TIMES
         self._axes = tuple(a for s in self._spaces for a in self._domain.axes[s])
+        self._kept_index = {}
 
     def apply(self, x, mode):
         self._check_input(x, mode)
         full_contraction = len(self._spaces) == len(self._domain)
+        if not self._spaces:  # nothing to contract: identity (torch would read an empty `dim` as "all axes")
+            return x
         if self._power != 0:
             raise NotImplementedError("weighted contractions")
         if mode == self.ADJOINT_TIMES:
-            if x.val.is_cuda:
-                if not full_contraction:
-                    raise NotImplementedError("partial broadcast on device")
+            if x.val.is_cuda and full_contraction:
                 ones = torch.ones(self._domain.shape, dtype=x.val.dtype, device=x.val.device)
                 return Field(self._domain, B.binary(2, ones, float(x.val.item())))
             shp = [1 if i in self._axes else n for i, n in enumerate(self._domain.shape)]
+            # broadcast = replication copy (no arithmetic), also for device tensors
             return Field(self._domain, x.val.reshape(shp).expand(self._domain.shape).contiguous())
         if x.val.is_cuda:
             if not full_contraction:
-                raise NotImplementedError("partial contraction on device")
+                # sum over the contracted axes = scatter-add onto the flat index of the kept coordinates
+                key = str(x.val.device)
+                if key not in self._kept_index:
+                    kept = torch.arange(int(np.prod(self._target.shape)), dtype=torch.int32, device=x.val.device)
+                    shp = [1 if i in self._axes else n for i, n in enumerate(self._domain.shape)]
+                    self._kept_index[key] = kept.reshape(shp).expand(self._domain.shape).contiguous().reshape(-1)
+                res = B.scatter_add(x.val.contiguous().reshape(-1), self._kept_index[key], int(np.prod(self._target.shape)))
+                return Field(self._target, res.to(x.val.dtype).reshape(self._target.shape))
             return Field.scalar(x.s_sum()).at(x.device_id)
         if full_contraction:
             return Field.scalar(x.s_sum())
@@ -1301,9 +1310,19 @@ class _RGTransformBase(LinearOperator):
         adom.check_codomain(target)
         target.check_codomain(adom)
 
-    def _require_all_axes(self, x):
-        if len(self._domain) != 1:
-            raise NotImplementedError("transforms over a sub-space of a DomainTuple are not implemented yet")
+    def _over_subspace(self, val, fn_host, fn_dev):
+        """Apply a transform over the axes of self._space (reference harmonic_operators.py:59-75, `axes=`).  The kernels
+        transform TRAILING axes of a contiguous array with everything in front as a batch, so a sub-space that is not
+        last is moved there by a permutation copy (data movement only) and moved back afterwards."""
+        axes = tuple(self._domain.axes[self._space])
+        if not val.is_cuda:
+            return fn_host(val, axes)
+        nd = val.dim()
+        if axes == tuple(range(nd - len(axes), nd)):
+            return fn_dev(val.contiguous(), len(axes))
+        perm = [i for i in range(nd) if i not in axes] + list(axes)
+        inv = [perm.index(i) for i in range(nd)]
+        return fn_dev(val.permute(perm).contiguous(), len(axes)).permute(inv).contiguous()
 
     def _factor(self, mode):
         if mode & (self.TIMES | self.ADJOINT_TIMES):
@@ -1327,15 +1346,15 @@ class HartleyOperator(_RGTransformBase):
         return self._cartesian(x, mode)
 
     def _cartesian(self, x, mode):
-        self._require_all_axes(x)
         fct = self._factor(mode)
-        if x.val.is_cuda:
-            return Field(self._tgt(mode), B.hartley(x.val, scale=fct))
         from . import config
 
-        f = torch.fft.fftn(x.val)
-        h = f.real + f.imag if config.get("hartley_convention") == "non_canonical_hartley" else f.real - f.imag
-        return Field(self._tgt(mode), h if fct == 1 else h * fct)
+        def host(v, axes):
+            f = torch.fft.fftn(v, dim=axes)
+            h = f.real + f.imag if config.get("hartley_convention") == "non_canonical_hartley" else f.real - f.imag
+            return h if fct == 1 else h * fct
+
+        return Field(self._tgt(mode), self._over_subspace(x.val, host, lambda v, nd: B.hartley(v, ndim=nd, scale=fct)))
 
 
 class FFTOperator(_RGTransformBase):
@@ -1347,18 +1366,20 @@ class FFTOperator(_RGTransformBase):
 
     def apply(self, x, mode):
         self._check_input(x, mode)
-        self._require_all_axes(x)
         ncells = x.domain[self._space].size
         inverse = x.domain[self._space].harmonic
         fct = self._factor(mode) * (ncells if inverse else 1.0)
         v = x.val
         if not v.is_complex():
             v = v.to(torch.complex64 if v.dtype == torch.float32 else torch.complex128)
-        if v.is_cuda:
-            # ifftn carries 1/N: N * ifftn = unnormalised backward transform
-            return Field(self._tgt(mode), B.fftn(v, inverse=inverse, scale=fct / ncells if inverse else fct))
-        res = torch.fft.ifftn(v) if inverse else torch.fft.fftn(v)
-        return Field(self._tgt(mode), res if fct == 1 else res * fct)
+
+        def host(a, axes):
+            res = torch.fft.ifftn(a, dim=axes) if inverse else torch.fft.fftn(a, dim=axes)
+            return res if fct == 1 else res * fct
+
+        # ifftn carries 1/N: N * ifftn = unnormalised backward transform
+        dev = lambda a, nd: B.fftn(a, ndim=nd, inverse=inverse, scale=fct / ncells if inverse else fct)  # noqa: E731
+        return Field(self._tgt(mode), self._over_subspace(v, host, dev))
 
 
 class HarmonicTransformOperator(LinearOperator):

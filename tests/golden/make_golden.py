@@ -358,7 +358,51 @@ def okl1_cases():
     print("wrote okl1", sorted(out)[:3])
 
 
+def product_cf(I):
+    """Two-amplitude (product spectrum) correlated field on RGSpace(16, d=0.5) x RGSpace(8x6)
+    (correlated_fields.py:713-764 with two add_fluctuations calls); I = the nifty-like module to build it with."""
+    cfm = I.CorrelatedFieldMaker("p")
+    cfm.add_fluctuations(I.RGSpace((16,), (0.5,)), (1.0, 5e-1), (1.0, 2e-1), (5e-1, 5e-2), (-3.0, 2e-1), prefix="t")
+    cfm.add_fluctuations(I.RGSpace((8, 6)), (0.7, 3e-1), (1.2, 2e-1), (4e-1, 5e-2), (-2.5, 2e-1), prefix="s")
+    cfm.set_amplitude_total_offset(2.0, (1e-1, 3e-2))
+    return cfm.finalize()
+
+
+def product_cf_case():
+    out = {}
+    cf = product_cf(ift)
+    ift.random.push_sseq_from_seed(3)
+    x = ift.from_random(cf.domain) * 0.5
+    v = ift.from_random(cf.domain)
+    w = ift.from_random(cf.target)
+    d = cf(ift.from_random(cf.domain)) + ift.from_random(cf.target) * 0.1
+    ift.random.pop_sseq()
+    out.update(mf2dict(x, "x"))
+    out.update(mf2dict(v, "v"))
+    out["w"], out["data"] = w.asnumpy(), d.asnumpy()
+    lin = cf(ift.Linearization.make_var(x))
+    out["cf"], out["cf_jvp"] = lin.val.asnumpy(), lin.jac(v).asnumpy()
+    out.update(mf2dict(lin.jac.adjoint(w), "cf_vjp"))
+    lh = ift.GaussianEnergy(d, ift.ScalingOperator(cf.target, 100.0, np.float64)) @ cf
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=6)
+    ham = ift.StandardHamiltonian(lh, ic, prior_sampling_dtype=np.float64)
+    hl = ham(ift.Linearization.make_var(x, want_metric=True))
+    out["ham_value"] = np.array(hl.val.val.asnumpy())
+    out.update(mf2dict(hl.gradient, "ham_grad"))
+    out.update(mf2dict(hl.metric(v), "ham_metric_v"))
+    ift.random.push_sseq_from_seed(9)
+    mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=8)
+    sl, mean = ift.optimize_kl(lh, 1, 1, mk, ic, output_directory=None, return_final_position=True, initial_position=x,
+                               plot_energy_history=False, plot_minisanity_history=False)
+    ift.random.pop_sseq()
+    out.update(mf2dict(mean, "okl_mean"))
+    np.savez_compressed(os.path.join(HERE, "product_cf.npz"), **out)
+    print("wrote product_cf", out["cf"].shape, sorted(k for k in out if k.startswith("x.")))
+
+
 def main():
+    if "--product-only" in sys.argv:
+        return product_cf_case()
     if "--okl1-only" in sys.argv:
         return okl1_cases()
     if "--const-only" in sys.argv:
@@ -394,6 +438,7 @@ def main():
     minimizer_cases()
     constants_cases()
     okl1_cases()
+    product_cf_case()
 
 
 if __name__ == "__main__":

@@ -316,3 +316,48 @@ def test_minisanity_table(device_id):
     assert vals["ndof"]["latent_variables"]["xi"] == 128 and vals["nigndof"]["data_residuals"]["<None>"] == 0
     with pytest.raises(TypeError):
         ift.extra.minisanity(lh, [x])
+
+
+def _product_cf():
+    cfm = ift.CorrelatedFieldMaker("p")
+    cfm.add_fluctuations(ift.RGSpace((16,), (0.5,)), (1.0, 5e-1), (1.0, 2e-1), (5e-1, 5e-2), (-3.0, 2e-1), prefix="t")
+    cfm.add_fluctuations(ift.RGSpace((8, 6)), (0.7, 3e-1), (1.2, 2e-1), (4e-1, 5e-2), (-2.5, 2e-1), prefix="s")
+    cfm.set_amplitude_total_offset(2.0, (1e-1, 3e-2))
+    return cfm, cfm.finalize()
+
+
+def test_product_spectrum_correlated_field(device_id=-1):
+    """Two add_fluctuations calls: harmonic transforms over sub-spaces (`space=`), partial contraction / broadcast, product
+    of the distributed amplitudes (correlated_fields.py:713-764) against tests/golden/product_cf.npz, including a
+    Hamiltonian and one MGVI iteration on the generic operator graph.  Host Fields only: the generic nb-sized amplitude
+    operators have no device implementation (the fused single-amplitude operator covers the device path); the
+    sub-space transforms and partial contractions themselves are device-tested in test_extra_checks.py."""
+    z = gl.load("product_cf")
+    cfm, cf = _product_cf()
+    assert cf.target.shape == (16, 8, 6)
+    with pytest.raises(NotImplementedError):
+        cfm.amplitude
+    x = ift.MultiField.from_raw(cf.domain, _lat(z, "x"), device_id)
+    v = ift.MultiField.from_raw(cf.domain, _lat(z, "v"), device_id)
+    w = ift.makeField(cf.target, z["w"], device_id)
+    lin = cf(ift.Linearization.make_var(x))
+    assert gl.relerr(lin.val.asnumpy(), z["cf"]) < 1e-12
+    assert gl.relerr(lin.jac(v).asnumpy(), z["cf_jvp"]) < 1e-11
+    assert gl.lat_relerr(lin.jac.adjoint(w).asnumpy(), _lat(z, "cf_vjp")) < 1e-11
+    d = ift.makeField(cf.target, z["data"], device_id)
+    lh = ift.GaussianEnergy(d, ift.ScalingOperator(cf.target, 100.0, np.float64)) @ cf
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=6)
+    ham = ift.StandardHamiltonian(lh, ic, prior_sampling_dtype=np.float64)
+    hl = ham(ift.Linearization.make_var(x, want_metric=True))
+    assert abs(float(hl.val.asnumpy()) - float(z["ham_value"])) < 1e-11 * abs(float(z["ham_value"]))
+    assert gl.lat_relerr(hl.gradient.asnumpy(), _lat(z, "ham_grad")) < 1e-10
+    assert gl.lat_relerr(hl.metric(v).asnumpy(), _lat(z, "ham_metric_v")) < 1e-10
+    ift.random.push_sseq_from_seed(9)
+    try:
+        mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2),  # noqa: E731
+                                    max_cg_iterations=8)
+        sl, mean = ift.optimize_kl(lh, 1, 1, mk, ic, output_directory=None, return_final_position=True,
+                                   initial_position=x, device_id=device_id)
+    finally:
+        ift.random.pop_sseq()
+    assert gl.lat_relerr(mean.asnumpy(), _lat(z, "okl_mean")) < 1e-6

@@ -22,6 +22,14 @@ def _linear_operators():
                 (ift.ScalingOperator(sp, 2.5), np.float64, np.float64),
                 (ift.HarmonicSmoothingOperator(sp, 0.02), np.float64, np.float64),
                 (ift.ContractionOperator(sp, None), np.float64, np.float64)]
+    # operators on a sub-space of a DomainTuple (`space=`, reference harmonic_operators.py:59-75, contraction_operator.py)
+    dt = ift.DomainTuple.make((sp1, sp2))
+    for space in (0, 1):
+        ops += [(ift.HartleyOperator(dt, space=space), np.float64, np.float64),
+                (ift.FFTOperator(dt, space=space), np.complex128, np.complex128),
+                (ift.ContractionOperator(dt, space), np.float64, np.float64)]
+    ops.append((ift.HarmonicTransformOperator(ift.DomainTuple.make((sp1.get_default_codomain(), sp2)), space=0),
+                np.float64, np.float64))
     nlos = 9
     ops.append((ift.LOSResponse(sp2, rng.uniform(0, 4, (2, nlos)), rng.uniform(0, 2.4, (2, nlos))), np.float64, np.float64))
     ops.append((ift.MaskOperator(ift.makeField(sp2, rng.uniform(size=sp2.shape) < 0.4)), np.float64, np.float64))
