@@ -165,6 +165,11 @@ int nk_spmv(int64_t nrows, const int64_t* rowptr, const int32_t* col, const floa
 int nk_spmv_t(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, const void* y, double* x64,
               int dtype, void* stream);
 
+/* inclusive prefix sums out[i] = sum_{j<=i} in[j] (reverse != 0: suffix sums), fp64 accumulation: the cumulative sums of
+ * _TwoLogIntegrations in the GENERIC amplitude graph (library/correlated_fields.py:147-161); in and out may not overlap
+ * partially (in == out is fine) */
+int nk_cumsum(int64_t n, const void* in, void* out, int reverse, int dtype, void* stream);
+
 /* dst[0..n) = sum over c < copies of src[c*stride + (0..n)]  (folds the per-XCD VJP accumulators) */
 int nk_fold_copies(int64_t n, int copies, int64_t stride, const double* src, double* dst, void* stream);
 

@@ -210,3 +210,13 @@ def stats(x):
     L.check(L.load().nk_stats(xc.numel(), xc.data_ptr(), dtype_code(xc), res.data_ptr(), _stream()), "nk_stats")
     s, s2, nign = res.cpu().tolist()
     return s, s2, int(round(nign))
+
+
+def cumsum(x, reverse=False, out=None):
+    """Inclusive prefix (reverse: suffix) sums of a contiguous 1-D device tensor."""
+    _require_device(x)
+    x = x.contiguous()
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.load().nk_cumsum(x.numel(), x.data_ptr(), out.data_ptr(), 1 if reverse else 0, dtype_code(x), _stream()),
+            "nk_cumsum")
+    return out

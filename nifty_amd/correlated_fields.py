@@ -57,10 +57,10 @@ def _log_vol(pspace):
     return logkl[1:] - logkl[:-1]
 
 
-def _host_only(x, what):
-    if x.val.is_cuda:
-        raise NotImplementedError(f"{what}: the generic amplitude graph is host-only; device Fields use the fused "
-                                  "CorrelatedFieldOperator")
+def _dev(t, like):
+    """Static operator array on the device / dtype of the field it meets (migrated lazily like the reference's
+    `_device_preparation`)."""
+    return t.to(device=like.device, dtype=like.dtype)
 
 
 class _SlopeRemover(EndomorphicOperator):
@@ -74,8 +74,16 @@ class _SlopeRemover(EndomorphicOperator):
 
     def apply(self, x, mode):
         self._check_input(x, mode)
-        _host_only(x, "_SlopeRemover")
         v = x.val
+        if v.is_cuda:  # device Fields: libniftyk element-wise kernels, the two scalars cross the host
+            sc = _dev(self._sc, v)
+            v = v.contiguous()
+            if mode == self.TIMES:
+                return Field(self._tgt(mode), B.axpby(1.0, v, -float(v[-1].item()), sc))
+            res = v.clone()
+            last = res[-1:]
+            B.axpby(1.0, last, -float(B.vdot(v, sc).item()), torch.ones_like(last), out=last)
+            return Field(self._tgt(mode), res)
         if mode == self.TIMES:
             return Field(self._tgt(mode), v - v[-1] * self._sc)
         res = v.clone()
@@ -95,8 +103,9 @@ class _TwoLogIntegrations(LinearOperator):
 
     def apply(self, x, mode):
         self._check_input(x, mode)
-        _host_only(x, "_TwoLogIntegrations")
         lv = self._log_vol
+        if x.val.is_cuda:
+            return self._apply_device(x, mode)
         if mode == self.TIMES:
             v = x.val
             res = torch.zeros(self._target.shape, dtype=v.dtype)
@@ -115,6 +124,26 @@ class _TwoLogIntegrations(LinearOperator):
         return Field(self._domain, res)
 
 
+    def _apply_device(self, x, mode):
+        """Same arithmetic with nk_cumsum and the element-wise kernels; slicing / concatenation are copies."""
+        v = x.val.contiguous()
+        half_lv = B.axpby(0.5, _dev(self._log_vol, v).contiguous())
+        zero1 = torch.zeros(1, dtype=v.dtype, device=v.device)
+        if mode == self.TIMES:
+            res = torch.zeros(self._target.shape, dtype=v.dtype, device=v.device)
+            c = B.cumsum(v[1])
+            both = B.binary(L.OP_ADD, c, torch.cat([zero1, c[:-1]]).contiguous())  # c_j + c_{j-1}
+            inc = B.binary(L.OP_ADD, B.binary(L.OP_MUL, both, half_lv), v[0].contiguous())
+            B.cumsum(inc, out=res[2:])
+            return Field(self._target, res)
+        res = torch.zeros(self._domain.shape, dtype=v.dtype, device=v.device)
+        t = B.cumsum(v[2:], reverse=True, out=res[0])
+        u = B.binary(L.OP_MUL, t, half_lv)
+        gc = B.binary(L.OP_ADD, u, torch.cat([u[1:], zero1]).contiguous())
+        B.cumsum(gc, reverse=True, out=res[1])
+        return Field(self._domain, res)
+
+
 class _Normalization(Operator):
     def __init__(self, domain, space=0):
         self._domain = self._target = DomainTuple.make(domain)
@@ -125,8 +154,6 @@ class _Normalization(Operator):
 
     def apply(self, x):
         self._check_input(x)
-        lin = is_linearization(x)
-        _host_only(x.val if lin else x, "_Normalization")
         spec = x.exp()
         # sum over modes with multiplicities, broadcast back
         multop = makeOp(Field(self._domain, self._mult))

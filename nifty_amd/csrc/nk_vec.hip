@@ -782,3 +782,42 @@ extern "C" int nk_spmv_t(int64_t nrows, const int64_t* rowptr, const int32_t* co
   })
   return nk_check_launch("k_spmv_t");
 }
+
+// ---- inclusive prefix sum of a vector (the two log-integrations of the generic amplitude graph, reference
+//      library/correlated_fields.py:147-161).  nb-sized (<= ~1e6) and far off the hot path -- the fused amplitude
+//      kernels of nk_amp.hip are what the fused engine uses -- so ONE workgroup walks the vector in tiles with a
+//      running carry: deterministic, fp64 accumulation.  reverse != 0: suffix sums out[i] = sum_{j >= i} in[j].
+template <typename T>
+__global__ void __launch_bounds__(1024) k_cumsum(int64_t n, const T* __restrict__ in, T* __restrict__ out, int reverse) {
+  __shared__ double wsum[16];
+  __shared__ double carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0.0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const int64_t src = reverse ? n - 1 - i : i;
+    double v = i < n ? (double)in[src] : 0.0;
+    for (int off = 1; off < 64; off <<= 1) {  // inclusive scan inside the wavefront
+      const double t = __shfl_up(v, off, 64);
+      if (lane >= off) v += t;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    double pre = carry_s;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    if (i < n) out[src] = (T)(v + pre);
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = v + pre;
+    __syncthreads();
+  }
+}
+
+extern "C" int nk_cumsum(int64_t n, const void* in, void* out, int reverse, int dtype, void* stream) {
+  if (n < 0 || (n > 0 && (!in || !out))) return nk_set_error(NK_ERR_INVALID, "nk_cumsum: bad argument");
+  if (n == 0) return NK_OK;
+  NK_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL(k_cumsum<T>, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, (const T*)in, (T*)out, reverse);
+  })
+  return nk_check_launch("k_cumsum");
+}

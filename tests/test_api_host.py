@@ -326,12 +326,12 @@ def _product_cf():
     return cfm, cfm.finalize()
 
 
-def test_product_spectrum_correlated_field(device_id=-1):
+@pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
+def test_product_spectrum_correlated_field(device_id):
     """Two add_fluctuations calls: harmonic transforms over sub-spaces (`space=`), partial contraction / broadcast, product
     of the distributed amplitudes (correlated_fields.py:713-764) against tests/golden/product_cf.npz, including a
-    Hamiltonian and one MGVI iteration on the generic operator graph.  Host Fields only: the generic nb-sized amplitude
-    operators have no device implementation (the fused single-amplitude operator covers the device path); the
-    sub-space transforms and partial contractions themselves are device-tested in test_extra_checks.py."""
+    Hamiltonian and one MGVI iteration on the generic operator graph (on the device with nk_cumsum for the log-log
+    integrations)."""
     z = gl.load("product_cf")
     cfm, cf = _product_cf()
     assert cf.target.shape == (16, 8, 6)

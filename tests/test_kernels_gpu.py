@@ -141,3 +141,22 @@ def test_octant_expand_and_scatter(shape):
         L.check(lib.nk_octant_scatter_k2(len(shape), shp, w8d.data_ptr(), pd.data_ptr(), k2d.data_ptr(), nb,
                                          scratch.data_ptr(), abar2.data_ptr(), B._stream()), "x")
         assert np.max(np.abs(abar2.cpu().numpy() - ref)) < 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("n", [1, 7, 1024, 1025, 5000, 300001])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_cumsum(n, dtype):
+    """nk_cumsum (prefix / suffix sums of _TwoLogIntegrations, correlated_fields.py:147-161) against numpy."""
+    from nifty_amd import backend as B
+
+    x = np.random.default_rng(n).normal(size=n)
+    xd = torch.from_numpy(x).to(dtype).cuda()
+    ref = np.cumsum(xd.cpu().numpy().astype(np.float64))
+    tol = 1e-13 if dtype == torch.float64 else 2e-6
+    scale = max(1.0, float(np.max(np.abs(ref))))
+    assert np.max(np.abs(B.cumsum(xd).cpu().numpy() - ref)) < tol * scale
+    refr = np.cumsum(xd.cpu().numpy().astype(np.float64)[::-1])[::-1]
+    assert np.max(np.abs(B.cumsum(xd, reverse=True).cpu().numpy() - refr)) < tol * scale
+    y = xd.clone()
+    B.cumsum(y, out=y)  # in place
+    assert np.max(np.abs(y.cpu().numpy() - ref)) < tol * scale
