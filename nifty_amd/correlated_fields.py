@@ -21,7 +21,8 @@ from .domains import DomainTuple, MultiDomain, PowerSpace, RGSpace, Unstructured
 from .engine import SMALL_KEYS, lognormal_moments
 from .field import Field, MultiField, full, makeField
 from .operators import (ContractionOperator, DiagonalOperator, EndomorphicOperator, HarmonicTransformOperator,
-                        LinearOperator, Linearization, Operator, PowerDistributor, ScalingOperator, Variable, ducktape,
+                        LinearOperator, Linearization, Operator, PowerDistributor, ScalingOperator, Variable, VdotOperator,
+                        ducktape,
                         is_linearization, makeOp)
 
 
@@ -212,6 +213,28 @@ class _Amplitude(Operator):
         return self._fluc
 
 
+class _AmplitudeMatern(Operator):
+    """Parametric amplitude a(k) = scale * (1 + (k/cutoff)^2)^(loglogslope/4), with the position-space volume folded
+    in (zero mode ~ V, other modes ~ sqrt(V)) (reference library/correlated_fields.py:231-275)."""
+
+    def __init__(self, pow_spc, scale, cutoff, loglogslope, totvol):
+        expander = ContractionOperator(pow_spc, None).adjoint
+        k_squared = makeField(makeDomain(pow_spc), pow_spc.k_lengths ** 2)
+        ker = (VdotOperator(k_squared).adjoint @ cutoff.ptw("power", -2.0)) + 1.0
+        ker = (expander.scale(0.25) @ loglogslope) * ker.ptw("log") + (expander @ scale.ptw("log"))
+        op = ker.ptw("exp")
+        vol0, vol1 = np.zeros(pow_spc.shape), np.zeros(pow_spc.shape)
+        vol0[0] = totvol
+        vol1[1:] = totvol ** 0.5
+        op = DiagonalOperator(makeField(op.target, vol1))(op) + makeField(op.target, vol0)
+        self._op = op
+        self._domain, self._target = op.domain, op.target
+
+    def apply(self, x):
+        self._check_input(x)
+        return self._op(x)
+
+
 # ------------------------------------------------------------------------------------------------
 # fused device operator
 # ------------------------------------------------------------------------------------------------
@@ -393,6 +416,24 @@ class CorrelatedFieldMaker:
         self._hyper.update(fluctuations=tuple(fluctuations), flexibility=tuple(flexibility), asperity=tuple(asperity),
                            loglogavgslope=tuple(loglogavgslope))
         self._amp_prefix = pre
+
+    def add_fluctuations_matern(self, target_subdomain, scale, cutoff, loglogslope, prefix="", adjust_for_volume=True,
+                                harmonic_partner=None):
+        """Matern-kernel amplitude A(k) = a (1 + (|k|/b)^2)^(c/4) with log-normal scale a and cutoff b and normal
+        spectral index c (reference library/correlated_fields.py:577-657); runs on the generic operator graph."""
+        if harmonic_partner is None:
+            harmonic_partner = target_subdomain.get_default_codomain()
+        else:
+            target_subdomain.check_codomain(harmonic_partner)
+            harmonic_partner.check_codomain(target_subdomain)
+        tsd = makeDomain(target_subdomain)
+        pre = self._prefix + str(prefix)
+        amp = _AmplitudeMatern(PowerSpace(harmonic_partner), LognormalTransform(*scale, pre + "scale"),
+                               LognormalTransform(*cutoff, pre + "cutoff"), NormalTransform(*loglogslope, pre + "loglogslope"),
+                               tsd[-1].total_volume if adjust_for_volume else 1.0)
+        self._a.append(amp)
+        self._target_subdomains.append(tsd)
+        self._amp_prefix = None  # never the fused single-amplitude operator
 
     def set_amplitude_total_offset(self, offset_mean, offset_std, dofdex=None):
         if dofdex is not None:

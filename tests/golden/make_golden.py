@@ -396,6 +396,22 @@ def product_cf_case():
                                plot_energy_history=False, plot_minisanity_history=False)
     ift.random.pop_sseq()
     out.update(mf2dict(mean, "okl_mean"))
+    # Matern amplitude (add_fluctuations_matern, correlated_fields.py:231-275, 577-657)
+    cfm = ift.CorrelatedFieldMaker("m")
+    cfm.add_fluctuations_matern(ift.RGSpace((12, 10), (0.5, 0.25)), (1.0, 0.3), (2.0, 0.5), (-4.0, 0.5), prefix="a")
+    cfm.set_amplitude_total_offset(1.0, (1e-1, 3e-2))
+    mcf = cfm.finalize()
+    ift.random.push_sseq_from_seed(4)
+    x = ift.from_random(mcf.domain) * 0.5
+    v = ift.from_random(mcf.domain)
+    w = ift.from_random(mcf.target)
+    ift.random.pop_sseq()
+    out.update(mf2dict(x, "matern.x"))
+    out.update(mf2dict(v, "matern.v"))
+    out["matern.w"] = w.asnumpy()
+    lin = mcf(ift.Linearization.make_var(x))
+    out["matern.cf"], out["matern.cf_jvp"] = lin.val.asnumpy(), lin.jac(v).asnumpy()
+    out.update(mf2dict(lin.jac.adjoint(w), "matern.cf_vjp"))
     np.savez_compressed(os.path.join(HERE, "product_cf.npz"), **out)
     print("wrote product_cf", out["cf"].shape, sorted(k for k in out if k.startswith("x.")))
 

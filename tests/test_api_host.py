@@ -361,3 +361,21 @@ def test_product_spectrum_correlated_field(device_id):
     finally:
         ift.random.pop_sseq()
     assert gl.lat_relerr(mean.asnumpy(), _lat(z, "okl_mean")) < 1e-6
+
+
+@pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
+def test_matern_amplitude_correlated_field(device_id):
+    """add_fluctuations_matern (correlated_fields.py:231-275, 577-657): value, JVP and VJP against the reference."""
+    z = gl.load("product_cf")
+    cfm = ift.CorrelatedFieldMaker("m")
+    cfm.add_fluctuations_matern(ift.RGSpace((12, 10), (0.5, 0.25)), (1.0, 0.3), (2.0, 0.5), (-4.0, 0.5), prefix="a")
+    cfm.set_amplitude_total_offset(1.0, (1e-1, 3e-2))
+    cf = cfm.finalize()
+    assert set(cf.domain.keys()) == {"macutoff", "maloglogslope", "mascale", "mxi", "mzeromode"}
+    x = ift.MultiField.from_raw(cf.domain, _lat(z, "matern.x"), device_id)
+    v = ift.MultiField.from_raw(cf.domain, _lat(z, "matern.v"), device_id)
+    w = ift.makeField(cf.target, z["matern.w"], device_id)
+    lin = cf(ift.Linearization.make_var(x))
+    assert gl.relerr(lin.val.asnumpy(), z["matern.cf"]) < 1e-12
+    assert gl.relerr(lin.jac(v).asnumpy(), z["matern.cf_jvp"]) < 1e-11
+    assert gl.lat_relerr(lin.jac.adjoint(w).asnumpy(), _lat(z, "matern.cf_vjp")) < 1e-11
