@@ -147,7 +147,8 @@ int nk_binary(int op, int64_t n, const void* a, double ascalar, const void* b, d
 int nk_axpby(int64_t n, double alpha, const void* x, double beta, const void* y, void* out, int dtype,
              void* stream);
 /* pointwise nonlinearity with optional derivative output (pointwise.py:134-159):
- * fn: 0 exp, 1 log, 2 sqrt, 3 tanh, 4 sigmoid(0.5+0.5tanh), 5 reciprocal, 6 power(p), 7 abs, 8 log1p, 9 expm1 */
+ * fn: 0 exp, 1 log, 2 sqrt, 3 tanh, 4 sigmoid(0.5+0.5tanh), 5 reciprocal, 6 power(p), 7 abs, 8 log1p, 9 expm1,
+ *     10 arctan, 11 sin, 12 cos */
 int nk_pointwise(int fn, double param, int64_t n, const void* x, void* fx, void* dfx, int dtype, void* stream);
 /* gather / scatter-add by bin index (DOFDistributor, distributors.py:106-127): table/in/out are of `dtype`;
  * the scatter accumulates into DOUBLE bins (np.bincount semantics, utilities.py:222-246), caller zeroes them */

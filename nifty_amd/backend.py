@@ -155,7 +155,7 @@ def axpby(alpha, x, beta=0.0, y=None, out=None):
 
 
 POINTWISE = {"exp": 0, "log": 1, "sqrt": 2, "tanh": 3, "sigmoid": 4, "reciprocal": 5, "power": 6, "abs": 7,
-             "absolute": 7, "log1p": 8, "expm1": 9}
+             "absolute": 7, "log1p": 8, "expm1": 9, "arctan": 10, "sin": 11, "cos": 12}
 
 
 def pointwise(name, x, param=0.0, want_derivative=False):

@@ -235,7 +235,10 @@ struct FPointwise {
         case 6: fv = pow(v, param); dv = param * pow(v, param - 1.0); break;
         case 7: fv = fabs(v); dv = v == 0.0 ? (double)NAN : (v > 0.0 ? 1.0 : -1.0); break;
         case 8: fv = log1p(v); dv = 1.0 / (1.0 + v); break;
-        default: fv = expm1(v); dv = fv + 1.0; break;
+        case 9: fv = expm1(v); dv = fv + 1.0; break;
+        case 10: fv = atan(v); dv = 1.0 / (1.0 + v * v); break;
+        case 11: fv = sin(v); dv = cos(v); break;
+        default: fv = cos(v); dv = -sin(v); break;
       }
       f[k] = (T)fv;
       d[k] = (T)dv;
@@ -431,7 +434,7 @@ extern "C" int nk_axpby(int64_t n, double alpha, const void* x, double beta, con
 
 extern "C" int nk_pointwise(int fn, double param, int64_t n, const void* x, void* fx, void* dfx, int dtype,
                             void* stream) {
-  if (n < 0 || !x || (!fx && !dfx) || fn < 0 || fn > 9) return nk_set_error(NK_ERR_INVALID, "nk_pointwise: bad argument");
+  if (n < 0 || !x || (!fx && !dfx) || fn < 0 || fn > 12) return nk_set_error(NK_ERR_INVALID, "nk_pointwise: bad argument");
   NK_DISPATCH_DTYPE(dtype, {
     FPointwise<T> f{fn, param, (const T*)x, (T*)fx, (T*)dfx, nullptr};
     return nk_launch_map<T>(n, f, nk_aligned16(x) && nk_aligned16(fx) && nk_aligned16(dfx), (hipStream_t)stream,

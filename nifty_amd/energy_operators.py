@@ -8,7 +8,7 @@ StandardHamiltonian (:890-931).  Other likelihoods of the reference are out of s
 import numpy as np
 
 from .domains import DomainTuple, MultiDomain, makeDomain
-from .field import Field, MultiField
+from .field import Field, MultiField, full
 from .operators import (Adder, EndomorphicOperator, LinearOperator, Linearization, Operator, SamplingEnabler,
                         SandwichOperator, ScalingOperator, VdotOperator, _OpChain, _same_domain, is_linearization,
                         is_operator, makeOp)
@@ -221,6 +221,65 @@ class PoissonianEnergy(LikelihoodEnergyOperator):
 
     def get_transformation(self):
         return np.float64, Operator.identity_operator(self._domain).sqrt().scale(2.0)
+
+
+class StudentTEnergy(LikelihoodEnergyOperator):
+    """E(f) = (theta+1)/2 sum log(1 + f^2/theta), theta a scalar or a Field (reference energy_operators.py:704-746)."""
+
+    def __init__(self, domain, theta):
+        self._domain = DomainTuple.make(domain)
+        self._theta = theta
+        super().__init__(Operator.identity_operator(self._domain), lambda x: self.get_metric_at(x).get_sqrt())
+
+    def apply(self, x):
+        self._check_input(x)
+        th = self._theta
+        if isinstance(th, Field):
+            th = th.at((x.val if is_linearization(x) else x).device_id)
+            res = (makeOp((th + 1.0) * 0.5)(makeOp(th.reciprocal())(x ** 2).log1p())).sum()
+        else:
+            res = ((x ** 2) * (1.0 / th)).log1p().sum() * ((th + 1.0) / 2.0)
+        if not (is_linearization(x) and x.want_metric):
+            return res
+        return res.add_metric(self.get_metric_at(x.val))
+
+    def get_transformation(self):
+        th = self._theta if isinstance(self._theta, Field) else full(self._domain, float(self._theta))
+        return np.float64, makeOp(((th + 1.0) / (th + 3.0)).sqrt())
+
+
+class BernoulliEnergy(LikelihoodEnergyOperator):
+    """E(f) = -d^T log f - (1-d)^T log(1-f) for event data d in {0, 1} (reference energy_operators.py:749-792)."""
+
+    def __init__(self, d):
+        if not isinstance(d, Field) or not np.issubdtype(d.dtype, np.integer):
+            raise TypeError(f"d needs to be a Field with integer values. Got:\n{d}")
+        vals = set(np.unique(d.asnumpy()).tolist())
+        if not vals <= {0, 1}:
+            raise ValueError(f"d can only contain 0 and 1. Got: {vals}")
+        self._d = d
+        self._d_float = {}
+        self._domain = DomainTuple.make(d.domain)
+        super().__init__(Adder(d, neg=True), lambda x: self.get_metric_at(x).get_sqrt())
+
+    def _events_like(self, x):
+        key = (x.device_id, x.dtype)
+        if key not in self._d_float:
+            self._d_float[key] = self._d.at(x.device_id).astype(x.dtype)
+        return self._d_float[key]
+
+    def apply(self, x):
+        self._check_input(x)
+        d = self._events_like(x.val if is_linearization(x) else x)
+        res = -x.log().vdot(d) + (1.0 - x).log().vdot(d - 1.0)
+        if not (is_linearization(x) and x.want_metric):
+            return res
+        return res.add_metric(self.get_metric_at(x.val))
+
+    def get_transformation(self):
+        ident = Operator.identity_operator(self._domain)
+        res = (ScalingOperator(self._domain, -1.0) + 1.0) * ident.reciprocal()  # (1 - f) / f
+        return np.float64, res.sqrt().arctan().scale(-2.0)
 
 
 class StandardHamiltonian(EnergyOperator):

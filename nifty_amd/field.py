@@ -355,6 +355,8 @@ def _host_ptw(x, op, deriv, *args):
         if hi is not None:
             d = torch.where(f == hi, torch.zeros_like(d), d)
         return f, d
+    if op == "arctan":
+        return (torch.arctan(x), 1.0 / (1.0 + x * x)) if deriv else torch.arctan(x)
     if op in ("sin", "cos"):
         f = getattr(torch, op)(x)
         if not deriv:
@@ -374,7 +376,7 @@ def _ptw(x, op, deriv, *args, **kwargs):
     return B.pointwise(op, x.contiguous(), param, want_derivative=deriv)
 
 
-for _name in ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "sin", "cos", "absolute"):
+for _name in ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "sin", "cos", "absolute", "arctan"):
     def _make(name):
         def fn(self):
             return self.ptw(name)

@@ -219,7 +219,7 @@ class Operator:
         return self.__class__.__name__
 
 
-for _fn in ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "abs", "sin", "cos"):
+for _fn in ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "abs", "sin", "cos", "arctan"):
     def _mk(fn):
         def method(self):
             return self.ptw(fn)
@@ -465,7 +465,7 @@ class Linearization:
         return Linearization(field, NullOperator(field.domain, field.domain), want_metric=want_metric)
 
 
-for _fn in ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "abs"):
+for _fn in ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "abs", "arctan"):
     def _mk2(fn):
         def method(self):
             return self.ptw(fn)

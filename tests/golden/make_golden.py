@@ -416,7 +416,30 @@ def product_cf_case():
     print("wrote product_cf", out["cf"].shape, sorted(k for k in out if k.startswith("x.")))
 
 
+def likelihood_cases():
+    """StudentTEnergy (scalar and field theta) and BernoulliEnergy (energy_operators.py:704-792): value, gradient, metric
+    application and likelihood transformation at a random point."""
+    rng = np.random.default_rng(0)
+    shape = (10, 12)
+    x, v = rng.uniform(0.1, 0.9, size=shape), rng.normal(size=shape)
+    d = (rng.uniform(size=shape) < 0.4).astype(np.int64)
+    th = rng.uniform(2, 5, size=shape)
+    sp = ift.RGSpace(shape)
+    out = dict(x=x, v=v, d=d, theta=th)
+    for name, e in (("bernoulli", ift.BernoulliEnergy(ift.makeField(sp, d))), ("studentt", ift.StudentTEnergy(sp, 3.0)),
+                    ("studentt_field", ift.StudentTEnergy(sp, ift.makeField(sp, th)))):
+        lin = e(ift.Linearization.make_var(ift.makeField(sp, x), want_metric=True))
+        out[f"{name}.value"] = np.asarray(lin.val.asnumpy())
+        out[f"{name}.grad"] = lin.gradient.asnumpy()
+        out[f"{name}.metric_v"] = lin.metric(ift.makeField(sp, v)).asnumpy()
+        out[f"{name}.trafo"] = e.get_transformation()[1](ift.makeField(sp, x)).asnumpy()
+    np.savez_compressed(os.path.join(HERE, "likelihoods.npz"), **out)
+    print("wrote likelihoods", {k: float(out[k]) for k in out if k.endswith("value")})
+
+
 def main():
+    if "--lh-only" in sys.argv:
+        return likelihood_cases()
     if "--product-only" in sys.argv:
         return product_cf_case()
     if "--okl1-only" in sys.argv:
@@ -455,6 +478,7 @@ def main():
     constants_cases()
     okl1_cases()
     product_cf_case()
+    likelihood_cases()
 
 
 if __name__ == "__main__":

@@ -379,3 +379,33 @@ def test_matern_amplitude_correlated_field(device_id):
     assert gl.relerr(lin.val.asnumpy(), z["matern.cf"]) < 1e-12
     assert gl.relerr(lin.jac(v).asnumpy(), z["matern.cf_jvp"]) < 1e-11
     assert gl.lat_relerr(lin.jac.adjoint(w).asnumpy(), _lat(z, "matern.cf_vjp")) < 1e-11
+
+
+@pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
+def test_studentt_and_bernoulli_energies(device_id):
+    """StudentTEnergy / BernoulliEnergy (energy_operators.py:704-792) against tests/golden/likelihoods.npz, plus the
+    Jacobian-vs-finite-differences harness."""
+    from nifty_amd.extra import check_operator
+
+    z = gl.load("likelihoods")
+    sp = ift.RGSpace(z["x"].shape)
+    x, v = ift.makeField(sp, z["x"], device_id), ift.makeField(sp, z["v"], device_id)
+    energies = {"bernoulli": ift.BernoulliEnergy(ift.makeField(sp, z["d"])), "studentt": ift.StudentTEnergy(sp, 3.0),
+                "studentt_field": ift.StudentTEnergy(sp, ift.makeField(sp, z["theta"]))}
+    for name, e in energies.items():
+        lin = e(ift.Linearization.make_var(x, want_metric=True))
+        assert abs(float(lin.val.asnumpy()) - float(z[f"{name}.value"])) < 1e-12 * abs(float(z[f"{name}.value"]))
+        assert gl.relerr(lin.gradient.asnumpy(), z[f"{name}.grad"]) < 1e-12
+        assert gl.relerr(lin.metric(v).asnumpy(), z[f"{name}.metric_v"]) < 1e-12
+        assert gl.relerr(e.get_transformation()[1](x).asnumpy(), z[f"{name}.trafo"]) < 1e-12
+    if device_id < 0:
+        ift.random.push_sseq_from_seed(2)
+        try:
+            check_operator(energies["studentt"], ift.makeField(sp, z["x"]), tol=1e-8, ntries=2)
+            check_operator(energies["bernoulli"], ift.makeField(sp, z["x"]), tol=1e-7, ntries=2)
+        finally:
+            ift.random.pop_sseq()
+    with pytest.raises(ValueError):
+        ift.BernoulliEnergy(ift.makeField(sp, np.full(sp.shape, 2, dtype=np.int64)))
+    with pytest.raises(TypeError):
+        ift.BernoulliEnergy(ift.makeField(sp, z["x"]))
