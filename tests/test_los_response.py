@@ -160,3 +160,23 @@ def test_config4_model_host():
 @pytest.mark.gpu
 def test_config4_model_device():
     _check_c4(0)
+
+
+@pytest.mark.gpu
+def test_spmv_kernels_against_scipy_on_a_larger_response():
+    """nk_spmv / nk_spmv_t on a 2000-line response over a 256 x 192 grid (rows of a few hundred entries, many lines per
+    pixel) against scipy.sparse on the host; fp64 and fp32 fields."""
+    from scipy.sparse import csr_matrix
+
+    rng = np.random.default_rng(8)
+    sp = ift.RGSpace((256, 192), (1.0 / 256, 1.0 / 192))
+    R = ift.LOSResponse(sp, rng.uniform(size=(2, 2000)), rng.uniform(size=(2, 2000)))
+    m = csr_matrix((R._wgt, R._col, R._rowptr), shape=(2000, sp.size))
+    x, y = rng.normal(size=sp.shape), rng.normal(size=2000)
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 2e-6)):
+        got = R(ift.makeField(R.domain, x.astype(dt), 0)).asnumpy()
+        ref = m @ x.astype(dt).astype(np.float64).reshape(-1)
+        assert gl.relerr(got, ref) < tol
+        got = R.adjoint(ift.makeField(R.target, y.astype(dt), 0)).asnumpy()
+        ref = (m.T @ y.astype(dt).astype(np.float64)).reshape(sp.shape)
+        assert gl.relerr(got, ref) < tol
