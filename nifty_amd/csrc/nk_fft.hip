@@ -210,18 +210,18 @@ __global__ void __launch_bounds__((StridedTile<T, N>::THREADS),
 }
 
 template <typename T, int NL, bool COUPLES, int EC>
-__global__ void __launch_bounds__((FinalTile<T, NL>::THREADS), (COUPLES ? 3 : 4))
+__global__ void __launch_bounds__((FinalTile<T, NL, EC>::THREADS), (COUPLES ? 3 : 4))
     k2_final(NkPassF p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, SchedF<T, NL>::E> ex;
   double acc = 0.0;
-  nk_final_body<T, NL, FinalTile<T, NL>::TILE, COUPLES, EC>(ex, p, f, blockIdx.x, (T*)smem, tw, work, &acc);
+  nk_final_body<T, NL, FinalTile<T, NL, EC>::TILE, COUPLES, EC>(ex, p, f, blockIdx.x, (T*)smem, tw, work, &acc);
   nk_flush_energy(f, acc, smem);
 }
 
 template <typename T, int NL, bool COUPLES, int EC>
 static int nk_launch_final_c(NkPassF pf, const NkFuse& f, const C2<T>* tw, const C2<T>* work, hipStream_t st) {
-  using CT = FinalTile<T, NL>;
+  using CT = FinalTile<T, NL, EC>;
   auto kern = k2_final<T, NL, COUPLES, EC>;
   static bool attr_done = false;
   if (!attr_done && CT::LDS_BYTES > 64 * 1024) {

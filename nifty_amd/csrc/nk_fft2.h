@@ -206,14 +206,18 @@ struct ContigTile {
 #endif
 // final pass of the strided-first pipeline: up to 256 threads and <= NK_FINAL_LDS_KB of planes (20 KiB: two line pairs
 // per workgroup at 1024 fp32 -- many small workgroups hide the load/epilogue latency best)
-template <typename T, int NL>
+// The affine / multiply epilogues (EC 0, 1) carry no per-workgroup reduction and no couples: they run best with HALF that
+// tile (one line pair = one wavefront per workgroup at 1024 fp32: 2.44 -> 2.17 ms for the multiply epilogue).
+template <typename T, int NL, int EC = -1>
 struct FinalTile {
   static constexpr int P = SchedF<T, NL>::P;
   static constexpr int PITCH = ContigLayout<NL, P>::PITCH;
   static constexpr int fit(int tile) {
     return (tile > 1 && (P * tile > 256 || 2 * tile * PITCH * (int)sizeof(T) > NK_FINAL_LDS_KB * 1024)) ? fit(tile / 2) : tile;
   }
-  static constexpr int TILE = fit(16);
+  static constexpr int T0 = fit(16);
+  // halve only while the workgroup keeps a full wavefront
+  static constexpr int TILE = ((EC == 0 || EC == 1) && T0 >= 2 && P * (T0 / 2) >= 64) ? T0 / 2 : T0;
   static constexpr int THREADS = P * TILE;
   static constexpr int LDS_BYTES = 2 * TILE * PITCH * (int)sizeof(T);
 };

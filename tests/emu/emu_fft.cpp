@@ -132,24 +132,29 @@ static void emu2_contig(NkPassA p, bool is_1d, const nk_fuse& f, const C2<T>* tw
   }
 }
 
-template <typename T, int NL>
-static void emu2_final(const NkPassF& pf0, const nk_fuse& f, const C2<T>* tw, const C2<T>* work, double* energy) {
-  using CT = FinalTile<T, NL>;
+template <typename T, int NL, bool COUPLES, int EC>
+static void emu2_final_ec(const NkPassF& pf0, const nk_fuse& f, const C2<T>* tw, const C2<T>* work, double* energy) {
+  using CT = FinalTile<T, NL, EC>;
   NkPassF pf = pf0;
-  const bool couples = f.epi == NK_EPI_VJP;
-  pf.tiles_per_a = (couples && pf.A > 1 && CT::TILE >= 2) ? (pf.M / 2 + 1 + CT::TILE / 2 - 1) / (CT::TILE / 2)
+  pf.tiles_per_a = (COUPLES && pf.A > 1 && CT::TILE >= 2) ? (pf.M / 2 + 1 + CT::TILE / 2 - 1) / (CT::TILE / 2)
                                                           : (pf.M + CT::TILE - 1) / CT::TILE;
   std::vector<T> planes(CT::LDS_BYTES / sizeof(T));
   const int64_t blocks = (int64_t)pf.g.batch * (pf.A / 2 + 1) * pf.tiles_per_a;
   for (int64_t blk = 0; blk < blocks; ++blk) {
     HostExec<T, SchedF<T, NL>::E> ex(CT::THREADS);
-    if (couples && f.afield) nk_final_body<T, NL, CT::TILE, true, 2>(ex, pf, f, blk, planes.data(), tw, work, energy);
-    else if (couples) nk_final_body<T, NL, CT::TILE, true, -1>(ex, pf, f, blk, planes.data(), tw, work, energy);
-    else if (f.epi == NK_EPI_AFFINE) nk_final_body<T, NL, CT::TILE, false, 0>(ex, pf, f, blk, planes.data(), tw, work, energy);
-    else if (f.epi == NK_EPI_MUL) nk_final_body<T, NL, CT::TILE, false, 1>(ex, pf, f, blk, planes.data(), tw, work, energy);
-    else if (f.epi == NK_EPI_LIKELIHOOD) nk_final_body<T, NL, CT::TILE, false, 3>(ex, pf, f, blk, planes.data(), tw, work, energy);
-    else nk_final_body<T, NL, CT::TILE, false, -1>(ex, pf, f, blk, planes.data(), tw, work, energy);
+    nk_final_body<T, NL, CT::TILE, COUPLES, EC>(ex, pf, f, blk, planes.data(), tw, work, energy);
   }
+}
+
+template <typename T, int NL>
+static void emu2_final(const NkPassF& pf, const nk_fuse& f, const C2<T>* tw, const C2<T>* work, double* energy) {
+  const bool couples = f.epi == NK_EPI_VJP;  // same dispatch as nk_launch_final
+  if (couples && f.afield) emu2_final_ec<T, NL, true, 2>(pf, f, tw, work, energy);
+  else if (couples) emu2_final_ec<T, NL, true, -1>(pf, f, tw, work, energy);
+  else if (f.epi == NK_EPI_AFFINE) emu2_final_ec<T, NL, false, 0>(pf, f, tw, work, energy);
+  else if (f.epi == NK_EPI_MUL) emu2_final_ec<T, NL, false, 1>(pf, f, tw, work, energy);
+  else if (f.epi == NK_EPI_LIKELIHOOD) emu2_final_ec<T, NL, false, 3>(pf, f, tw, work, energy);
+  else emu2_final_ec<T, NL, false, -1>(pf, f, tw, work, energy);
 }
 
 // strided-first pipeline (ndim >= 2)
