@@ -97,6 +97,8 @@ typedef struct nk_fuse {
                            value, so the prologue of the first pass and the VJP epilogue read 1/8 of the bytes.  Only
                            valid when nk_plan_octant_vjp(plan) != 0 and with prologue PLAIN / MUL / AMP(afield) /
                            AMP_JVP(afield + dafield) and, for the VJP epilogue, afield set (NK_ERR_INVALID otherwise) */
+  int value_slots;      /* leave 0.  Set by the library itself when it spreads the per-workgroup atomics on *value over
+                           several accumulators in the workspace (folded into *value after the pass) */
 } nk_fuse;
 
 typedef struct nk_plan nk_plan;

@@ -117,7 +117,8 @@ __device__ __forceinline__ void nk_flush_energy(const NkFuse& f, double acc, voi
     double s = 0.0;
     const int nw = (blockDim.x + 63) >> 6;
     for (int w = 0; w < nw; ++w) s += red[w];
-    atomicAdd(f.value, s);
+    // one address would serialise ~1e5 workgroup atomics (~1 ms at 1024^3): spread over the slots the driver provides
+    atomicAdd(f.value + (f.value_slots > 1 ? (int)(blockIdx.x & (unsigned)(f.value_slots - 1)) : 0), s);
   }
 }
 
@@ -210,18 +211,20 @@ __global__ void __launch_bounds__((StridedTile<T, N>::THREADS),
 }
 
 template <typename T, int NL, bool COUPLES, int EC>
-__global__ void __launch_bounds__((FinalTile<T, NL, EC>::THREADS), (COUPLES ? 3 : 4))
+__global__ void __launch_bounds__((FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS),
+                                  (FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS > 256 ? 1 : (COUPLES ? 3 : 4)))
     k2_final(NkPassF p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, SchedF<T, NL>::E> ex;
   double acc = 0.0;
-  nk_final_body<T, NL, FinalTile<T, NL, EC>::TILE, COUPLES, EC>(ex, p, f, blockIdx.x, (T*)smem, tw, work, &acc);
+  nk_final_body<T, NL, FinalTile<T, NL, EC, COUPLES ? 2 : 1>::TILE, COUPLES, EC>(ex, p, f, blockIdx.x, (T*)smem, tw, work, &acc);
   nk_flush_energy(f, acc, smem);
 }
 
 template <typename T, int NL, bool COUPLES, int EC>
 static int nk_launch_final_c(NkPassF pf, const NkFuse& f, const C2<T>* tw, const C2<T>* work, hipStream_t st) {
-  using CT = FinalTile<T, NL, EC>;
+  using CT = FinalTile<T, NL, EC, COUPLES ? 2 : 1>;
+  static_assert(!COUPLES || CT::TILE >= 2, "the couple (b0, M - b0) must live in one workgroup");
   auto kern = k2_final<T, NL, COUPLES, EC>;
   static bool attr_done = false;
   if (!attr_done && CT::LDS_BYTES > 64 * 1024) {
@@ -568,13 +571,28 @@ static bool nk_plan_uses_pipeline2(const nk_plan* P) {
   return first_ok && mid_ok;
 }
 
+#define NK_VALUE_SLOTS 256
+__global__ void k_fold_slots(double* __restrict__ slots, double* __restrict__ value) {
+  __shared__ double red[NK_VALUE_SLOTS / 64];
+  double v = slots[threadIdx.x];
+  slots[threadIdx.x] = 0.0;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < NK_VALUE_SLOTS / 64; ++w) s += red[w];
+    atomicAdd(value, s);
+  }
+}
+
 extern "C" int nk_plan_octant_vjp(const nk_plan* P) { return P && nk_plan_uses_pipeline2(P) ? 1 : 0; }
 
 extern "C" size_t nk_plan_workspace_bytes(const nk_plan* P) {
   if (!P) return 0;
   // [work | scratch], scratch aligned to 256 B
   size_t w = (P->hp.work_bytes + 255) / 256 * 256;
-  return w + P->hp.scratch_bytes + 256;
+  return w + (P->hp.scratch_bytes + 255) / 256 * 256 + 256 + NK_VALUE_SLOTS * sizeof(double);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -635,6 +653,20 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
     ProfScope ps(st, 3, f.pro, f.epi);
     static const int skip_final = nk_env_int("NK_SKIP_FINAL", 0);  // debugging aid
     if (skip_final) return NK_OK;
+    static const int use_slots = nk_env_int("NK_VALUE_SLOTS", 1);  // 0: all workgroups add to *value directly
+    if (use_slots && f.value && (f.epi == NK_EPI_LIKELIHOOD || f.epi == NK_EPI_VJP)) {
+      // energy / curvature sums: per-workgroup atomics go to NK_VALUE_SLOTS accumulators at the end of the workspace
+      double* slots = (double*)((char*)workspace + (hp.work_bytes + 255) / 256 * 256 + (hp.scratch_bytes + 255) / 256 * 256 + 256);
+      hipError_t e = hipMemsetAsync(slots, 0, NK_VALUE_SLOTS * sizeof(double), st);
+      if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(value slots)");
+      NkFuse f2 = f;
+      f2.value = slots;
+      f2.value_slots = NK_VALUE_SLOTS;
+      rc = nk_dispatch_final<T>(hp.g.nl, pf, f2, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
+      if (rc != NK_OK) return rc;
+      hipLaunchKernelGGL(k_fold_slots, dim3(1), dim3(NK_VALUE_SLOTS), 0, st, slots, f.value);
+      return nk_check_launch("k_fold_slots");
+    }
     return nk_dispatch_final<T>(hp.g.nl, pf, f, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
   }
   {

@@ -206,18 +206,20 @@ struct ContigTile {
 #endif
 // final pass of the strided-first pipeline: up to 256 threads and <= NK_FINAL_LDS_KB of planes (20 KiB: two line pairs
 // per workgroup at 1024 fp32 -- many small workgroups hide the load/epilogue latency best)
-// The affine / multiply epilogues (EC 0, 1) carry no per-workgroup reduction and no couples: they run best with HALF that
-// tile (one line pair = one wavefront per workgroup at 1024 fp32: 2.44 -> 2.17 ms for the multiply epilogue).
-template <typename T, int NL, int EC = -1>
+// Every compile-time epilogue class runs best with HALF that tile while the workgroup keeps a full wavefront (one line
+// pair per workgroup at 1024 fp32: 2.44 -> 2.17 ms for the multiply epilogue, 3.9 -> 3.6 ms for the VJP).
+// MINT: the scatter/VJP kernels (COUPLES) need BOTH lines (b0, M - b0) of a couple in one workgroup -- the octant
+// outputs (w8, field_octant) are indexed by the couple -- so their tile never drops below 2, whatever the caps say.
+template <typename T, int NL, int EC = -1, int MINT = 1>
 struct FinalTile {
   static constexpr int P = SchedF<T, NL>::P;
   static constexpr int PITCH = ContigLayout<NL, P>::PITCH;
   static constexpr int fit(int tile) {
-    return (tile > 1 && (P * tile > 256 || 2 * tile * PITCH * (int)sizeof(T) > NK_FINAL_LDS_KB * 1024)) ? fit(tile / 2) : tile;
+    return (tile > MINT && (P * tile > 256 || 2 * tile * PITCH * (int)sizeof(T) > NK_FINAL_LDS_KB * 1024)) ? fit(tile / 2) : tile;
   }
   static constexpr int T0 = fit(16);
   // halve only while the workgroup keeps a full wavefront
-  static constexpr int TILE = ((EC == 0 || EC == 1) && T0 >= 2 && P * (T0 / 2) >= 64) ? T0 / 2 : T0;
+  static constexpr int TILE = (EC >= 0 && T0 / 2 >= MINT && P * (T0 / 2) >= 64) ? T0 / 2 : T0;
   static constexpr int THREADS = P * TILE;
   static constexpr int LDS_BYTES = 2 * TILE * PITCH * (int)sizeof(T);
 };

@@ -134,7 +134,7 @@ static void emu2_contig(NkPassA p, bool is_1d, const nk_fuse& f, const C2<T>* tw
 
 template <typename T, int NL, bool COUPLES, int EC>
 static void emu2_final_ec(const NkPassF& pf0, const nk_fuse& f, const C2<T>* tw, const C2<T>* work, double* energy) {
-  using CT = FinalTile<T, NL, EC>;
+  using CT = FinalTile<T, NL, EC, COUPLES ? 2 : 1>;
   NkPassF pf = pf0;
   pf.tiles_per_a = (COUPLES && pf.A > 1 && CT::TILE >= 2) ? (pf.M / 2 + 1 + CT::TILE / 2 - 1) / (CT::TILE / 2)
                                                           : (pf.M + CT::TILE - 1) / CT::TILE;

@@ -139,7 +139,11 @@ def test_geovi_energy_vs_oracle():
                                                # non-power-of-two grids (mixed radix 2/3/5/7, generic kernels)
                                                ((30, 50), "gaussian", None), ((12, 10, 14), "poisson", "exp"),
                                                # strided-first pipeline with unequal axes
-                                               ((128, 64, 256), "gaussian", None)])
+                                               ((128, 64, 256), "gaussian", None),
+                                               # long last axis: the final pass runs its smallest tiles (one line pair
+                                               # per workgroup; the VJP keeps the couple (b0, M - b0) together)
+                                               ((64, 64, 1024), "gaussian", None), ((64, 64, 2048), "poisson", "exp"),
+                                               ((64, 64, 4096), "gaussian", "sigmoid")])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_engine_vs_oracle_seeded(shape, kind, nonlin, dtype):
     """Same seeded inputs through the HIP engine and the numpy oracle; fp32 fields use fp64 accumulators."""

@@ -67,7 +67,8 @@ def test_fast_path_emulation(shape, dtype):
 
 FUSED_SHAPES = [((64,), "emu_hartley_fused"), ((16, 8), "emu_hartley_fused"), ((8, 4, 16), "emu_hartley_fused"),
                 ((30,), "emu_hartley_fused"), ((10, 12), "emu_hartley_fused"), ((6, 5, 14), "emu_hartley_fused"),
-                ((256,), "emu2_hartley_fused"), ((64, 128), "emu3_hartley_fused"), ((64, 64, 64), "emu3_hartley_fused")]
+                ((256,), "emu2_hartley_fused"), ((64, 128), "emu3_hartley_fused"), ((64, 64, 64), "emu3_hartley_fused"),
+                ((64, 64, 1024), "emu3_hartley_fused")]  # last axis 1024 in fp64: the smallest final-pass tile
 
 
 @pytest.mark.parametrize("shape,fn", FUSED_SHAPES)
