@@ -143,7 +143,11 @@ def test_geovi_energy_vs_oracle():
                                                # long last axis: the final pass runs its smallest tiles (one line pair
                                                # per workgroup; the VJP keeps the couple (b0, M - b0) together)
                                                ((64, 64, 1024), "gaussian", None), ((64, 64, 2048), "poisson", "exp"),
-                                               ((64, 64, 4096), "gaussian", "sigmoid")])
+                                               ((64, 64, 4096), "gaussian", "sigmoid"),
+                                               # long strided axes (largest register-resident line lengths)
+                                               ((2048, 64, 64), "gaussian", None), ((64, 4096, 64), "poisson", "exp"),
+                                               ((4096, 64, 128), "gaussian", None), ((4096, 1024), "gaussian", "sigmoid"),
+                                               ((512, 4096), "poisson", "exp")])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_engine_vs_oracle_seeded(shape, kind, nonlin, dtype):
     """Same seeded inputs through the HIP engine and the numpy oracle; fp32 fields use fp64 accumulators."""
