@@ -192,3 +192,46 @@ def test_engine_rejects_cpu():
 
     with pytest.raises(RuntimeError):
         FusedModel((16,), data=np.zeros(16), device="cpu")
+
+
+@pytest.mark.parametrize("shape,kind,nonlin,dtype", [
+    ((1024, 1024, 1024), "gaussian", None, torch.float32),   # BASELINE configs[4] (headline), one sample's worth
+    ((512, 512, 512), "gaussian", None, torch.float64),      # configs[2]
+    ((2048, 2048), "poisson", "exp", torch.float64),         # configs[1]
+    ((4096, 4096), "gaussian", "sigmoid", torch.float64)])   # configs[3] grid
+def test_engine_full_size_properties(shape, kind, nonlin, dtype):
+    """BASELINE.json's full sizes, through properties that need no CPU reference (reference extra.py:220-231 adjointness /
+    linearity checks, extra.py:354-380 Jacobian consistency): the metric is linear, self-adjoint and positive, and the
+    gradient is the derivative of the value along a random direction."""
+    from nifty_amd.engine import FusedModel
+
+    dev = torch.device("cuda:0")
+    model = FusedModel(shape, offset_mean=1.5, likelihood=kind, icov=100.0, nonlin=nonlin, dtype=dtype, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    truth = model.draw_prior(gen) * 0.3
+    s = model.signal(truth)
+    if kind == "poisson":
+        model.set_data(torch.poisson(s.to(torch.float64), generator=gen).to(torch.int64))
+    else:
+        model.set_data(s + 0.1 * torch.randn(shape, dtype=dtype, device=dev, generator=gen), 100.0)
+    del s
+    x = model.draw_prior(gen) * 0.2
+    u, v = model.draw_prior(gen), model.draw_prior(gen)
+    lp = model.linearize(x)
+    f32 = dtype == torch.float32
+    # self-adjoint, positive
+    mv = model.metric(lp, v)
+    a, b = u.s_vdot(mv), model.metric(lp, u).s_vdot(v)
+    assert abs(a - b) < (2e-4 if f32 else 1e-10) * max(abs(a), abs(b), abs(v.s_vdot(mv)))
+    assert v.s_vdot(mv) > 0.0
+    # linear: M(2u - 3v) = 2 Mu - 3 Mv
+    lhs = model.metric(lp, u * 2.0 - v * 3.0)
+    rhs = model.metric(lp, u) * 2.0 - mv * 3.0
+    assert (lhs - rhs).norm() < (2e-5 if f32 else 1e-11) * rhs.norm()
+    del lhs, rhs, mv
+    # gradient = derivative of the value (central difference along v; fp32 fields limit the step size)
+    eps = 1e-2 if f32 else 1e-5
+    hp = float(model.linearize(x + v * eps).value.item())
+    hm = float(model.linearize(x - v * eps).value.item())
+    slope = lp.grad.s_vdot(v)
+    assert abs((hp - hm) / (2 * eps) - slope) < (5e-3 if f32 else 1e-6) * max(abs(slope), abs(hp) * 1e-6 / eps)
