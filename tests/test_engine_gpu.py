@@ -111,11 +111,13 @@ def test_geovi_samples_vs_reference_golden(case):
     assert gl.lat_relerr(kl.apply_metric(vl).to_dict(), gl.latent(z, "kl_metric_v")) < 1e-5
 
 
-def test_geovi_energy_vs_oracle():
-    """FusedGeoEnergy value / gradient / metric against the oracle's restatement on seeded inputs."""
+@pytest.mark.parametrize("shape", [(64, 128), (256,), (64, 64, 64), (64, 64, 2048), (2048, 64, 64), (30, 50), (12, 10, 14)])
+def test_geovi_energy_vs_oracle(shape):
+    """FusedGeoEnergy value / gradient / metric against the oracle's restatement on seeded inputs (multiply prologue,
+    data-space JVP / VJP with weight fields) on the 1-D, strided-first (incl. the smallest final tiles) and generic
+    mixed-radix pipelines."""
     from nifty_amd.engine import FusedGeoEnergy, FusedModel, LatentVec
 
-    shape = (64, 128)
     rng = np.random.default_rng(4)
     cf = orc.CFModel(shape, None, orc.CFParams(offset_mean=1.5))
     data = rng.poisson(np.exp(cf.forward(cf.draw_latent(rng)))).astype(np.int64)
