@@ -6,6 +6,7 @@ used for device memory and streams only; every number is produced by a HIP kerne
 fallback: a CPU tensor handed to these functions raises.
 """
 import ctypes
+import math
 
 import torch
 
@@ -70,6 +71,79 @@ def get_plan(shape, dtype, batch=1, device=None):
     return p
 
 
+_unsupported = set()
+
+
+def plan_supported(shape, dtype, batch=1, device=None):
+    """True when the native planner takes this transform (prime factors <= 7, even last axis, line-length limits);
+    otherwise the array seam runs the chirp-z composition below and the fused nodes step aside for the generic graph."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (tuple(int(s) for s in shape), dtype, int(batch), device.index)
+    if key in _unsupported:
+        return False
+    try:
+        get_plan(shape, dtype, batch, device)
+    except NotImplementedError:
+        _unsupported.add(key)
+        return False
+    return True
+
+
+# ---- any-length fallback (Bluestein / chirp-z), composed from the native power-of-two c2c kernel -------------------
+# The reference's FFT (ducc0) takes every length (test_fft_operator.py:58-103 uses 10, 11, 12).  Lengths the planner
+# rejects are rare in the hot path, so they are served axis by axis:  X[j] = w[j] * sum_k (x[k] w[k]) conj(w)[j-k]
+# with w[k] = exp(-+ i pi k^2 / n) -- a cyclic convolution of power-of-two length m >= 2n-1, i.e. three native c2c
+# transforms per axis.  The chirp angles come from k^2 mod 2n in integers, so they carry no large-argument error.
+_chirps = {}
+_CHIRP_MAX = 1 << 14  # longest padded convolution (power of two) the fallback will build
+
+
+def _chirp(n, cdt, inverse, device):
+    key = (n, cdt, bool(inverse), device.index)
+    ent = _chirps.get(key)
+    if ent is None:
+        m = 1 << (2 * n - 2).bit_length()
+        if m > _CHIRP_MAX:
+            raise NotImplementedError(f"axis of length {n} is too long for the chirp-z fallback")
+        k = torch.arange(n, dtype=torch.int64)
+        ang = (k * k % (2 * n)).to(torch.float64) * (math.pi / n)
+        w = torch.polar(torch.ones(n, dtype=torch.float64), ang if inverse else -ang)
+        b = torch.zeros(m, dtype=torch.complex128)
+        b[:n] = w.conj()
+        b[m - n + 1:] = w.conj()[1:].flip(0)
+        w, b = w.to(cdt).to(device), b.to(cdt).to(device)
+        rdt = torch.float32 if cdt == torch.complex64 else torch.float64
+        get_plan((m,), rdt, 1, device)  # native power-of-two transform or NotImplementedError -- never the fallback again
+        ent = _chirps[key] = (m, w, fftn(b, ndim=1))
+    return ent
+
+
+def _fft_last_axis_any(z, inverse):
+    """Unnormalised c2c transform over the last axis of a contiguous complex tensor, any length."""
+    n = z.shape[-1]
+    rdt = torch.float32 if z.dtype == torch.complex64 else torch.float64
+    batch = z.numel() // max(1, n)
+    if n == 1 or z.numel() == 0:
+        return z.clone()
+    if plan_supported((n,), rdt, batch, z.device):
+        return fftn(z, ndim=1, inverse=inverse)
+    m = 1 << (2 * n - 2).bit_length()
+    # check BEFORE anything of length m is built: an unsupported m must end here, not re-enter this fallback
+    if m > _CHIRP_MAX or not plan_supported((m,), rdt, batch, z.device) or not plan_supported((m,), rdt, 1, z.device):
+        raise NotImplementedError(f"axis of length {n} is too long for the chirp-z fallback")
+    m, w, fb = _chirp(n, z.dtype, inverse, z.device)
+    a = torch.zeros(z.shape[:-1] + (m,), dtype=z.dtype, device=z.device)
+    a[..., :n] = z * w
+    c = fftn(fftn(a, ndim=1) * fb, ndim=1, inverse=True, scale=1.0 / m)
+    return (c[..., :n] * w).contiguous()
+
+
+def _fft_any(z, ndim, inverse):
+    for ax in range(z.dim() - ndim, z.dim()):
+        z = _fft_last_axis_any(z.movedim(ax, -1).contiguous(), inverse).movedim(-1, ax)
+    return z.contiguous()
+
+
 def _convention():
     return 0 if config.get("hartley_convention") == "non_canonical_hartley" else 1
 
@@ -81,6 +155,10 @@ def hartley(x, ndim=None, scale=1.0, out=None):
     ndim = x.dim() if ndim is None else ndim
     shape = x.shape[x.dim() - ndim:]
     batch = x.numel() // max(1, int(torch.Size(shape).numel()))
+    if not plan_supported(shape, x.dtype, batch, x.device):
+        f = _fft_any(torch.complex(x, torch.zeros_like(x)), ndim, False)
+        h = (f.real + f.imag if _convention() == 0 else f.real - f.imag) * float(scale)
+        return h if out is None else out.copy_(h)
     plan = get_plan(shape, x.dtype, batch, x.device)
     out = torch.empty_like(x) if out is None else out
     L.check(L.load().nk_hartley(plan.handle, x.data_ptr(), out.data_ptr(), float(scale), _convention(),
@@ -103,6 +181,8 @@ def fftn(x, ndim=None, inverse=False, scale=1.0):
     shape = x.shape[x.dim() - ndim:]
     batch = x.numel() // max(1, int(torch.Size(shape).numel()))
     rdt = torch.float32 if x.dtype == torch.complex64 else torch.float64
+    if not plan_supported(shape, rdt, batch, x.device):
+        return _fft_any(x, ndim, inverse) * float(scale)
     plan = get_plan(shape, rdt, batch, x.device)
     out = torch.empty_like(x)
     L.check(L.load().nk_fftn(plan.handle, torch.view_as_real(x).data_ptr(), torch.view_as_real(out).data_ptr(),

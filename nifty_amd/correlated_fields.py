@@ -345,6 +345,8 @@ class CorrelatedFieldOperator(Operator):
         if v.device_id < 0:
             return self._generic(x)
         xi = v[self._prefix + "xi"].val.contiguous()
+        if not B.plan_supported(self._pos.shape, xi.dtype, 1, xi.device):
+            return self._generic(x)  # grid the native planner rejects (e.g. a prime axis): generic graph, chirp-z seam
         dev = self._devdata(xi.device)
         small = self._pack_small(v)
         amp = torch.empty(self._nb, dtype=torch.float64, device=xi.device)

@@ -93,15 +93,18 @@ _fused_cache = {}
 def _fused_model(lh, device_id, dtype):
     import torch
 
+    from . import backend as B
     from .engine import FusedModel
 
     key = (id(lh), device_id, dtype)
     if key not in _fused_cache:
         kw = match_fused(lh)
+        tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+        if kw is not None and not B.plan_supported(kw["shape"], tdt, 1, f"cuda:{device_id}"):
+            kw = None  # grid outside the native planner's lengths: generic operator graph
         if kw is None:
             _fused_cache[key] = None
         else:
-            tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
             _fused_cache[key] = (lh, FusedModel(kw.pop("shape"), kw.pop("distances"), dtype=tdt,
                                                 device=f"cuda:{device_id}", **kw))
     ent = _fused_cache[key]

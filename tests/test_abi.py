@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -70,3 +72,49 @@ def test_backend_refuses_cpu_tensors():
 
     with pytest.raises(RuntimeError):
         B.vdot(torch.zeros(4, dtype=torch.float64), torch.zeros(4, dtype=torch.float64))
+
+
+def test_chirp_z_fallback_terminates_and_is_exact(monkeypatch):
+    """Host logic of the any-length fallback in backend.py with the native transform replaced by a stand-in: the
+    composition is exact, and a length whose padded convolution the planner rejects ends in NotImplementedError
+    instead of re-entering the fallback (that loop once doubled its buffers until the machine ran out of memory)."""
+    import numpy as np
+    import torch
+
+    from nifty_amd import backend as B
+
+    calls = []
+
+    def pow2_only(shape, dtype, batch=1, device=None):
+        n = int(shape[-1])
+        return len(shape) == 1 and n & (n - 1) == 0 and n <= 4096
+
+    def native(x, ndim=None, inverse=False, scale=1.0):
+        n = x.shape[-1]
+        assert ndim == 1 and n & (n - 1) == 0, "the fallback may only call power-of-two 1-D transforms"
+        calls.append(n)
+        return (torch.fft.ifft(x, dim=-1, norm="forward") if inverse else torch.fft.fft(x, dim=-1)) * scale
+
+    def plan(shape, dtype, batch=1, device=None):
+        if not pow2_only(shape, dtype):
+            raise NotImplementedError("stand-in planner")
+
+    monkeypatch.setattr(B, "plan_supported", pow2_only)
+    monkeypatch.setattr(B, "get_plan", plan)
+    monkeypatch.setattr(B, "fftn", native)
+    monkeypatch.setattr(B, "_chirps", {})
+    rng = np.random.default_rng(0)
+    for shape in [(11,), (10, 11), (3, 13, 6), (1,), (15,)]:
+        z = torch.from_numpy(rng.normal(size=shape) + 1j * rng.normal(size=shape))
+        got = B._fft_any(z, len(shape), False).numpy()
+        ref = np.fft.fftn(z.numpy())
+        assert np.max(np.abs(got - ref)) < 1e-12 * np.max(np.abs(ref))
+        got = B._fft_any(z, len(shape), True).numpy()
+        ref = np.fft.ifftn(z.numpy()) * z.numel()
+        assert np.max(np.abs(got - ref)) < 1e-12 * np.max(np.abs(ref))
+    n_before = len(calls)
+    with pytest.raises(NotImplementedError):  # 2n-1 > 4096: the stand-in planner rejects the padded length
+        B._fft_any(torch.zeros(3000, dtype=torch.complex128), 1, False)
+    with pytest.raises(NotImplementedError):  # beyond the fallback's own cap, nothing is built at all
+        B._fft_any(torch.zeros(20011, dtype=torch.complex128), 1, False)
+    assert len(calls) == n_before and all(k[0] not in (3000, 20011) for k in B._chirps)

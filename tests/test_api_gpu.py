@@ -191,3 +191,30 @@ def test_large_grid_path_without_host_pindex(monkeypatch):
     finally:
         ift.PowerSpace._cache.clear()
     assert gl.lat_relerr(got, ref) < 1e-10
+
+
+def test_optimize_kl_on_grid_the_planner_rejects():
+    """RGSpace((11, 26)): 11 and 13 are outside the native radices.  The fused nodes step aside, the generic operator graph
+    runs on the device with the chirp-z array seam, and the result equals the host path's (same seeds)."""
+    def run(device_id):
+        ift.random.push_sseq_from_seed(5)
+        try:
+            sp = ift.RGSpace((11, 26))
+            cfm = ift.CorrelatedFieldMaker("")
+            cfm.add_fluctuations(sp, CF_ARGS["fluctuations"], CF_ARGS["flexibility"], CF_ARGS["asperity"],
+                                 CF_ARGS["loglogavgslope"])
+            cfm.set_amplitude_total_offset(2.0, (1e-1, 3e-2))
+            cf = cfm.finalize()
+            rng = np.random.default_rng(0)
+            d = ift.makeField(cf.target, 2.0 + 0.1 * rng.normal(size=sp.shape), 0)
+            lh = ift.GaussianEnergy(d, ift.ScalingOperator(cf.target, 100.0, np.float64)) @ cf
+            ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=5)
+            mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2),  # noqa: E731
+                                        max_cg_iterations=5)
+            return ift.optimize_kl(lh, 1, 2, mk, ic, output_directory=None, return_final_position=True,
+                                   device_id=device_id)[1]
+        finally:
+            ift.random.pop_sseq()
+
+    on_host, on_dev = run(-1), run(0)
+    assert gl.lat_relerr(on_dev.asnumpy(), on_host.asnumpy()) < 1e-8

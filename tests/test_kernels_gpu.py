@@ -63,10 +63,13 @@ def test_hartley_full_size_properties(shape, dtype):
 def test_unsupported_shapes_raise():
     from nifty_amd import backend as B
 
-    with pytest.raises(NotImplementedError):  # prime factor > 7
-        B.hartley(torch.zeros(22, device="cuda", dtype=torch.float64))
-    with pytest.raises(NotImplementedError):  # odd last axis (real-to-complex packing)
-        B.hartley(torch.zeros(8, 15, device="cuda", dtype=torch.float64))
+    # lengths the planner rejects are served by the chirp-z composition (test_any_length_transforms) ...
+    assert not B.plan_supported((22,), torch.float64, 1, "cuda:0")      # prime factor > 7
+    assert not B.plan_supported((8, 15), torch.float64, 1, "cuda:0")    # odd last axis (real-to-complex packing)
+    assert B.plan_supported((8, 14), torch.float64, 1, "cuda:0")
+    # ... until the padded convolution length leaves the single-line limit
+    with pytest.raises(NotImplementedError):
+        B.hartley(torch.zeros(20011, device="cuda", dtype=torch.float64))
     with pytest.raises(RuntimeError):
         B.hartley(torch.zeros(16, dtype=torch.float64))
 
@@ -76,7 +79,7 @@ def test_unsupported_shapes_raise():
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_mixed_radix_transforms(shape, dtype):
     """Axis lengths with factors 2, 3, 5, 7 (ducc0 accepts any length; reference test_fft_operator.py:58-103 uses 10, 11, 12
-    -- 11 stays unsupported) against scipy.fft on the host."""
+    -- 11 goes through the chirp-z fallback, see test_any_length_transforms) against scipy.fft on the host."""
     import scipy.fft
 
     from nifty_amd import backend as B
@@ -95,6 +98,30 @@ def test_mixed_radix_transforms(shape, dtype):
     assert gl.relerr(got, ref) < tol
     got = B.fftn(xcd, inverse=True, scale=1.0 / xc.size).cpu().numpy()
     assert gl.relerr(got, scipy.fft.ifftn(xcd.cpu().numpy().astype(np.complex128))) < tol
+
+
+@pytest.mark.parametrize("shape", [(11,), (15,), (1,), (10, 11), (11, 12), (13, 17, 6), (6, 15), (22, 64), (211,), (64, 1009),
+                                   (3001,)])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_any_length_transforms(shape, dtype):
+    """Lengths the native planner rejects (prime factors > 7, odd last axis): the array seam serves them through the
+    chirp-z composition of native power-of-two transforms, like ducc0 takes every length (reference
+    test_fft_operator.py:58-103 uses 10, 11, 12)."""
+    import scipy.fft
+
+    from nifty_amd import backend as B
+
+    rng = np.random.default_rng(12)
+    xd = torch.from_numpy(rng.normal(size=shape)).to(dtype).cuda()
+    F = scipy.fft.fftn(xd.cpu().numpy().astype(np.float64))
+    tol = 1e-12 if dtype == torch.float64 else 3e-5
+    assert gl.relerr(B.hartley(xd).cpu().numpy(), F.real + F.imag) < tol
+    assert gl.relerr(B.hartley(xd, scale=0.5).cpu().numpy(), 0.5 * (F.real + F.imag)) < tol
+    xc = rng.normal(size=shape) + 1j * rng.normal(size=shape)
+    xcd = torch.from_numpy(xc).to(torch.complex128 if dtype == torch.float64 else torch.complex64).cuda()
+    xh = xcd.cpu().numpy().astype(np.complex128)
+    assert gl.relerr(B.fftn(xcd, inverse=False, scale=1.0).cpu().numpy(), scipy.fft.fftn(xh)) < tol
+    assert gl.relerr(B.fftn(xcd, inverse=True, scale=1.0 / xc.size).cpu().numpy(), scipy.fft.ifftn(xh)) < tol
 
 
 @pytest.mark.parametrize("shape", [(64,), (32, 64), (64, 64, 64), (128, 64, 256), (256, 256, 256)])
