@@ -218,3 +218,25 @@ def test_optimize_kl_on_grid_the_planner_rejects():
 
     on_host, on_dev = run(-1), run(0)
     assert gl.lat_relerr(on_dev.asnumpy(), on_host.asnumpy()) < 1e-8
+
+
+def test_product_spectrum_on_subspaces_the_planner_rejects():
+    """Product of two amplitude spectra over RGSpace((11,)) x RGSpace((5, 7)): every sub-space transform (`space=`) takes the
+    chirp-z seam on the device; value, Jacobian and adjoint Jacobian equal the host path's."""
+    cfm = ift.CorrelatedFieldMaker("p")
+    cfm.add_fluctuations(ift.RGSpace((11,), (0.5,)), (1.0, 5e-1), (1.0, 2e-1), (5e-1, 5e-2), (-3.0, 2e-1), prefix="t")
+    cfm.add_fluctuations(ift.RGSpace((5, 7)), (0.7, 3e-1), (1.2, 2e-1), (4e-1, 5e-2), (-2.5, 2e-1), prefix="s")
+    cfm.set_amplitude_total_offset(2.0, (1e-1, 3e-2))
+    cf = cfm.finalize()
+    ift.random.push_sseq_from_seed(21)
+    try:
+        x = ift.from_random(cf.domain) * 0.3
+        v = ift.from_random(cf.domain)
+        w = ift.from_random(cf.target)
+    finally:
+        ift.random.pop_sseq()
+    lin_h = cf(ift.Linearization.make_var(x))
+    lin_d = cf(ift.Linearization.make_var(x.at(0)))
+    assert gl.relerr(lin_d.val.asnumpy(), lin_h.val.asnumpy()) < 1e-12
+    assert gl.relerr(lin_d.jac(v.at(0)).asnumpy(), lin_h.jac(v).asnumpy()) < 1e-11
+    assert gl.lat_relerr(lin_d.jac.adjoint(w.at(0)).asnumpy(), lin_h.jac.adjoint(w).asnumpy()) < 1e-11
