@@ -17,7 +17,13 @@ _DT = {torch.float32: L.NK_F32, torch.float64: L.NK_F64}
 _plans = {}
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """Handle of torch's current stream on the current device (every kernel of the library is launched on it)."""
+    if _raw_stream is not None:  # ~0.3 us instead of ~8 us per launch: the small configs are host-bound
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
