@@ -427,6 +427,46 @@ NK_HD void nk_epi_likelihood(const NkFuse& f, int64_t o, T v, double& acc) {
   if (f.out2) ((T*)f.out2)[o] = (T)w;
 }
 
+// the same for the (up to) four images of one coefficient: every load is issued before the first store -- `out` may alias
+// nothing here, but the compiler cannot know, and four dependent load -> store chains per work item cost the final pass
+// 1 ms at 1024^3
+template <typename T>
+NK_HD void nk_epi_likelihood4(const NkFuse& f, const int64_t (&o)[4], const T (&v)[4], int mask, double& acc) {
+  double dv[4], ic[4];
+  const bool gauss = f.lh_kind == NK_LH_GAUSS;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool on = (mask >> i) & 1;
+    dv[i] = !on ? 1.0 : gauss ? (double)((const T*)f.data)[o[i]] : (double)((const int64_t*)f.data)[o[i]];
+    ic[i] = (on && gauss && f.icov) ? (double)((const T*)f.icov)[o[i]] : f.icov_scalar;
+  }
+  double gs[4], w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double s = (double)v[i] * f.scale + f.offset;
+    double g, gp;
+    nk_nonlin(f.nonlin, s, g, gp);
+    double e;
+    if (gauss) {
+      const double r = g - dv[i];
+      e = 0.5 * ic[i] * r * r;
+      gs[i] = gp * ic[i] * r;
+      w[i] = gp * gp * ic[i];
+    } else {
+      e = g - dv[i] * log(g);
+      gs[i] = gp * (1.0 - dv[i] / g);
+      w[i] = gp * gp / g;
+    }
+    if ((mask >> i) & 1) acc += e;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!((mask >> i) & 1)) continue;
+    ((T*)f.out)[o[i]] = (T)gs[i];
+    if (f.out2) ((T*)f.out2)[o[i]] = (T)w[i];
+  }
+}
+
 template <typename T>
 NK_HD void nk_epilogue(const NkFuse& f, int64_t o, T v, double& acc) {
   T* out = (T*)f.out;

@@ -633,12 +633,9 @@ NK_HD double nk_final_slot(const NkFuse& f, const FinalCt<T>& c, int64_t ok, int
   T* outm = c.out + om;
   if constexpr (EC == 3) {  // likelihood: the reference arithmetic (fp64) per output, energy terms returned
     double e = 0.0;
-    nk_epi_likelihood<T>(f, ok + k2, v0, e);
-    if (BOTH) nk_epi_likelihood<T>(f, ok + k2m, v2, e);
-    if (!self) {
-      nk_epi_likelihood<T>(f, om + k2m, v1, e);
-      if (BOTH) nk_epi_likelihood<T>(f, om + k2, v3, e);
-    }
+    const int64_t o4[4] = {ok + k2, om + k2m, ok + k2m, om + k2};
+    const T v4[4] = {v0, v1, v2, v3};
+    nk_epi_likelihood4<T>(f, o4, v4, (self ? 1 : 3) | (BOTH ? (self ? 4 : 12) : 0), e);
     return e;
   } else if constexpr (EC == 0) {
     outk[k2] = v0 * c.sc + c.off;
