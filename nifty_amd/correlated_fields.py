@@ -192,13 +192,24 @@ class _Amplitude(Operator):
         vol0 = makeField(target, vol0)
         vol1 = DiagonalOperator(makeField(target, vol1))
         slope = vslope @ ps_expander @ loglogavgslope
-        sig_flex = vflex @ expander @ flexibility
-        sig_asp = vasp @ expander @ asperity
+        sig_flex = vflex @ expander @ flexibility if flexibility is not None else None
+        sig_asp = vasp @ expander @ asperity if asperity is not None else None
         sig_fluc = vol1 @ ps_expander @ fluctuations
         xi = Variable(dom, key)
-        sigma = sig_flex * (sig_asp + shift).sqrt()
-        smooth = _SlopeRemover(target) @ twolog @ (sigma * xi)
-        op = _Normalization(target) @ (slope + smooth)
+        # flexibility / asperity may be switched off (reference correlated_fields.py:351-363): pure power law, or an
+        # integrated Wiener process without the asperity term
+        if sig_asp is None and sig_flex is None:
+            op = _Normalization(target) @ slope
+        elif sig_asp is None:
+            sigma = DiagonalOperator(shift.sqrt()) @ sig_flex
+            smooth = _SlopeRemover(target) @ twolog @ (sigma * xi)
+            op = _Normalization(target) @ (slope + smooth)
+        elif sig_flex is None:
+            raise ValueError("flexibility may not be disabled on its own")
+        else:
+            sigma = sig_flex * (sig_asp + shift).sqrt()
+            smooth = _SlopeRemover(target) @ twolog @ (sigma * xi)
+            op = _Normalization(target) @ (slope + smooth)
         op = (sig_fluc * op) + vol0
         self._op = op
         self._domain, self._target = op.domain, op.target
@@ -377,7 +388,8 @@ class CorrelatedFieldOperator(Operator):
 # maker
 # ------------------------------------------------------------------------------------------------
 class CorrelatedFieldMaker:
-    """Construction helper (reference correlated_fields.py:389-859), single amplitude only."""
+    """Construction helper (reference correlated_fields.py:389-859): one or several amplitude spectra (power-law +
+    integrated Wiener process, reduced variants, Matern); the single full amplitude is fused into one device operator."""
 
     def __init__(self, prefix, total_N=0):
         if total_N != 0:
@@ -393,28 +405,35 @@ class CorrelatedFieldMaker:
                          index=None, dofdex=None, harmonic_partner=None):
         if dofdex is not None or index is not None:
             raise NotImplementedError("dofdex / index are out of scope")
-        if flexibility is None or asperity is None:
-            raise NotImplementedError("flexibility=None / asperity=None variants are not implemented yet")
         if harmonic_partner is None:
             harmonic_partner = target_subdomain.get_default_codomain()
         else:
             target_subdomain.check_codomain(harmonic_partner)
             harmonic_partner.check_codomain(target_subdomain)
-        for arg in (fluctuations, loglogavgslope, flexibility, asperity):
+        for arg in (fluctuations, loglogavgslope):
             if len(arg) != 2:
                 raise TypeError
         for kw, arg in (("flexibility", flexibility), ("asperity", asperity)):
+            if arg is None:
+                continue
+            if len(arg) != 2:
+                raise TypeError
             if arg[0] <= 0.0 or arg[1] <= 0.0:
                 raise ValueError(f"{kw} must be strictly positive (or None)")
+        if flexibility is None and asperity is not None:
+            raise ValueError("flexibility may not be disabled on its own")
         pre = self._prefix + str(prefix)
         fluct = LognormalTransform(*fluctuations, pre + "fluctuations")
-        flex = LognormalTransform(*flexibility, pre + "flexibility")
-        asp = LognormalTransform(*asperity, pre + "asperity")
+        flex = LognormalTransform(*flexibility, pre + "flexibility") if flexibility is not None else None
+        asp = LognormalTransform(*asperity, pre + "asperity") if asperity is not None else None
         avgsl = NormalTransform(*loglogavgslope, pre + "loglogavgslope")
         tsd = makeDomain(target_subdomain)
         amp = _Amplitude(PowerSpace(harmonic_partner), fluct, flex, asp, avgsl, tsd[-1].total_volume, pre + "spectrum")
         self._a.append(amp)
         self._target_subdomains.append(tsd)
+        if flexibility is None or asperity is None:
+            self._amp_prefix = None  # reduced amplitude models run on the generic operator graph, never the fused node
+            return
         self._hyper.update(fluctuations=tuple(fluctuations), flexibility=tuple(flexibility), asperity=tuple(asperity),
                            loglogavgslope=tuple(loglogavgslope))
         self._amp_prefix = pre

@@ -416,6 +416,35 @@ def product_cf_case():
     print("wrote product_cf", out["cf"].shape, sorted(k for k in out if k.startswith("x.")))
 
 
+def reduced_amplitude_cf(I, asperity):
+    """Correlated field whose amplitude has flexibility without asperity (asperity=None) or neither (both None):
+    correlated_fields.py:351-363."""
+    cfm = I.CorrelatedFieldMaker("r")
+    cfm.add_fluctuations(I.RGSpace((12, 10), (0.5, 0.25)), (1.0, 5e-1), (1.2, 2e-1) if asperity != "both" else None, None,
+                         (-3.0, 2e-1), prefix="a")
+    cfm.set_amplitude_total_offset(1.5, (1e-1, 3e-2))
+    return cfm.finalize()
+
+
+def reduced_amplitude_cases():
+    out = {}
+    for tag in ("noasp", "both"):
+        cf = reduced_amplitude_cf(ift, tag)
+        ift.random.push_sseq_from_seed(6)
+        x = ift.from_random(cf.domain) * 0.5
+        v = ift.from_random(cf.domain)
+        w = ift.from_random(cf.target)
+        ift.random.pop_sseq()
+        out.update(mf2dict(x, f"{tag}.x"))
+        out.update(mf2dict(v, f"{tag}.v"))
+        out[f"{tag}.w"] = w.asnumpy()
+        lin = cf(ift.Linearization.make_var(x))
+        out[f"{tag}.cf"], out[f"{tag}.cf_jvp"] = lin.val.asnumpy(), lin.jac(v).asnumpy()
+        out.update(mf2dict(lin.jac.adjoint(w), f"{tag}.cf_vjp"))
+    np.savez_compressed(os.path.join(HERE, "reduced_amp.npz"), **out)
+    print("wrote reduced_amp", sorted(k for k in out if ".x." in k))
+
+
 def likelihood_cases():
     """StudentTEnergy (scalar and field theta) and BernoulliEnergy (energy_operators.py:704-792): value, gradient, metric
     application and likelihood transformation at a random point."""
@@ -440,6 +469,8 @@ def likelihood_cases():
 def main():
     if "--lh-only" in sys.argv:
         return likelihood_cases()
+    if "--reduced-only" in sys.argv:
+        return reduced_amplitude_cases()
     if "--product-only" in sys.argv:
         return product_cf_case()
     if "--okl1-only" in sys.argv:

@@ -409,3 +409,27 @@ def test_studentt_and_bernoulli_energies(device_id):
         ift.BernoulliEnergy(ift.makeField(sp, np.full(sp.shape, 2, dtype=np.int64)))
     with pytest.raises(TypeError):
         ift.BernoulliEnergy(ift.makeField(sp, z["x"]))
+
+
+@pytest.mark.parametrize("tag", ["noasp", "both"])
+@pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
+def test_reduced_amplitude_models(tag, device_id):
+    """add_fluctuations with asperity=None (integrated Wiener process without the asperity term) and with flexibility =
+    asperity = None (pure power law), correlated_fields.py:351-363, against tests/golden/reduced_amp.npz; flexibility
+    may not be disabled on its own."""
+    z = gl.load("reduced_amp")
+    cfm = ift.CorrelatedFieldMaker("r")
+    cfm.add_fluctuations(ift.RGSpace((12, 10), (0.5, 0.25)), (1.0, 5e-1), (1.2, 2e-1) if tag != "both" else None, None,
+                         (-3.0, 2e-1), prefix="a")
+    cfm.set_amplitude_total_offset(1.5, (1e-1, 3e-2))
+    cf = cfm.finalize()
+    assert sorted(cf.domain.keys()) == sorted(_lat(z, f"{tag}.x").keys())
+    x = ift.MultiField.from_raw(cf.domain, _lat(z, f"{tag}.x"), device_id)
+    v = ift.MultiField.from_raw(cf.domain, _lat(z, f"{tag}.v"), device_id)
+    w = ift.makeField(cf.target, z[f"{tag}.w"], device_id)
+    lin = cf(ift.Linearization.make_var(x))
+    assert gl.relerr(lin.val.asnumpy(), z[f"{tag}.cf"]) < 1e-12
+    assert gl.relerr(lin.jac(v).asnumpy(), z[f"{tag}.cf_jvp"]) < 1e-11
+    assert gl.lat_relerr(lin.jac.adjoint(w).asnumpy(), _lat(z, f"{tag}.cf_vjp")) < 1e-11
+    with pytest.raises(ValueError):
+        ift.CorrelatedFieldMaker("").add_fluctuations(ift.RGSpace((8,)), (1.0, 0.5), None, (0.5, 0.05), (-3.0, 0.2))
