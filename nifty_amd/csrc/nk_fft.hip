@@ -122,8 +122,19 @@ __device__ __forceinline__ void nk_flush_energy(const NkFuse& f, double acc, voi
   }
 }
 
+// generic LDS kernels: any thread count works (loops stride by blockDim.x).  fp64 is capped at 512 threads so that the
+// compiler may use 256 VGPRs -- with the default 1024-thread bound (128 VGPRs) every fp64 kernel spilled 52-68 B / lane
 template <typename T>
-__global__ void k_passA(NkPassA p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr,
+constexpr int nk_gen_max_threads() {
+  return sizeof(T) == 8 ? 512 : 1024;
+}
+template <typename T>
+static inline int nk_gen_threads(int t) {
+  return t > nk_gen_max_threads<T>() ? nk_gen_max_threads<T>() : t;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(nk_gen_max_threads<T>()) k_passA(NkPassA p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr,
                         C2<T>* __restrict__ work) {
   extern __shared__ __align__(16) unsigned char smem[];
   C2<T>* lds = (C2<T>*)smem;
@@ -134,7 +145,7 @@ __global__ void k_passA(NkPassA p, NkFuse f, const C2<T>* __restrict__ tw, const
 }
 
 template <typename T>
-__global__ void k_pass1d(NkPassA p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr) {
+__global__ void __launch_bounds__(nk_gen_max_threads<T>()) k_pass1d(NkPassA p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr) {
   extern __shared__ __align__(16) unsigned char smem[];
   C2<T>* lds = (C2<T>*)smem;
   nk_passA_load<T>(p, f, blockIdx.x, threadIdx.x, blockDim.x, lds);
@@ -146,7 +157,7 @@ __global__ void k_pass1d(NkPassA p, NkFuse f, const C2<T>* __restrict__ tw, cons
 }
 
 template <typename T>
-__global__ void k_passB(NkPassS p, const C2<T>* __restrict__ tw, C2<T>* __restrict__ work) {
+__global__ void __launch_bounds__(nk_gen_max_threads<T>()) k_passB(NkPassS p, const C2<T>* __restrict__ tw, C2<T>* __restrict__ work) {
   extern __shared__ __align__(16) unsigned char smem[];
   C2<T>* lds = (C2<T>*)smem;
   nk_passS_load<T>(p, blockIdx.x, threadIdx.x, blockDim.x, lds, work);
@@ -156,7 +167,7 @@ __global__ void k_passB(NkPassS p, const C2<T>* __restrict__ tw, C2<T>* __restri
 }
 
 template <typename T>
-__global__ void k_passC(NkPassS p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work,
+__global__ void __launch_bounds__(nk_gen_max_threads<T>()) k_passC(NkPassS p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work,
                         C2<T>* __restrict__ scratch) {
   extern __shared__ __align__(16) unsigned char smem[];
   C2<T>* lds = (C2<T>*)smem;
@@ -210,9 +221,11 @@ __global__ void __launch_bounds__((StridedTile<T, N>::THREADS),
   (void)acc;
 }
 
+// min waves / SIMD: 4 only for the light fp32 affine / multiply classes; everything else gets 168 VGPRs -- at 128 the fp64
+// and likelihood kernels spilled (fp64 512^3 affine pass 0.61 -> 0.42 ms without the spills)
 template <typename T, int NL, bool COUPLES, int EC>
 __global__ void __launch_bounds__((FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS),
-                                  (FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS > 256 ? 1 : (COUPLES ? 3 : 4)))
+                                  (FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS > 256 ? 1 : ((!COUPLES && sizeof(T) == 4 && (EC == 0 || EC == 1)) ? 4 : 3)))
     k2_final(NkPassF p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, SchedF<T, NL>::E> ex;
@@ -362,7 +375,7 @@ struct NkPassCC {
 };
 
 template <typename T>
-__global__ void k_c2c_contig(NkPassCC p, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ in,
+__global__ void __launch_bounds__(nk_gen_max_threads<T>()) k_c2c_contig(NkPassCC p, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ in,
                              C2<T>* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char smem[];
   C2<T>* lds = (C2<T>*)smem;
@@ -389,7 +402,7 @@ __global__ void k_c2c_contig(NkPassCC p, const C2<T>* __restrict__ tw, const C2<
 
 // strided c2c pass in place on `data` viewed as [outer][n][inner]
 template <typename T>
-__global__ void k_c2c_strided(NkPassS p, int swap, const C2<T>* __restrict__ tw, C2<T>* __restrict__ data) {
+__global__ void __launch_bounds__(nk_gen_max_threads<T>()) k_c2c_strided(NkPassS p, int swap, const C2<T>* __restrict__ tw, C2<T>* __restrict__ data) {
   extern __shared__ __align__(16) unsigned char smem[];
   C2<T>* lds = (C2<T>*)smem;
   const int n = p.lp.n, tile = p.tl.tile;
@@ -612,7 +625,7 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
     ProfScope ps(st, 0, f.pro, f.epi);
     if (fast && nk_fast_contig_ok(hp.g.h))
       return nk_dispatch_contig<T, true>(hp.g.h, pa, f, tw_a, twr, (C2<T>*)nullptr, st);
-    hipLaunchKernelGGL(k_pass1d<T>, dim3((unsigned)blocks_a), dim3(hp.threads_a), hp.lds_a, st, pa, f, tw_a, twr);
+    hipLaunchKernelGGL(k_pass1d<T>, dim3((unsigned)blocks_a), dim3(nk_gen_threads<T>(hp.threads_a)), hp.lds_a, st, pa, f, tw_a, twr);
     return nk_check_launch("k_pass1d");
   }
   if (!workspace) return nk_set_error(NK_ERR_INVALID, "nk_hartley: workspace required for ndim >= 2");
@@ -674,7 +687,7 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
     if (fast && nk_fast_contig_ok(hp.g.h)) {
       rc = nk_dispatch_contig<T, false>(hp.g.h, pa, f, tw_a, twr, work, st);
     } else {
-      hipLaunchKernelGGL(k_passA<T>, dim3((unsigned)blocks_a), dim3(hp.threads_a), hp.lds_a, st, pa, f, tw_a, twr, work);
+      hipLaunchKernelGGL(k_passA<T>, dim3((unsigned)blocks_a), dim3(nk_gen_threads<T>(hp.threads_a)), hp.lds_a, st, pa, f, tw_a, twr, work);
       rc = nk_check_launch("k_passA");
     }
   }
@@ -687,7 +700,7 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
     if (fast && nk_fast_strided_ok<T>(hp.g.nm, hp.pb.inner)) {
       rc = nk_dispatch_strided<T, 0>(hp.g.nm, hp.pb, f, (const C2<T>*)P->d_tw_b, work, scratch, st);
     } else {
-      hipLaunchKernelGGL(k_passB<T>, dim3((unsigned)blocks_b), dim3(hp.threads_b), hp.lds_b, st, hp.pb,
+      hipLaunchKernelGGL(k_passB<T>, dim3((unsigned)blocks_b), dim3(nk_gen_threads<T>(hp.threads_b)), hp.lds_b, st, hp.pb,
                          (const C2<T>*)P->d_tw_b, work);
       rc = nk_check_launch("k_passB");
     }
@@ -696,7 +709,7 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
   const int64_t blocks_c = pc.outer * pc.tiles_per_slab;
   {
     ProfScope ps(st, 3, f.pro, f.epi);
-    hipLaunchKernelGGL(k_passC<T>, dim3((unsigned)blocks_c), dim3(hp.threads_c), hp.lds_c, st, pc, f,
+    hipLaunchKernelGGL(k_passC<T>, dim3((unsigned)blocks_c), dim3(nk_gen_threads<T>(hp.threads_c)), hp.lds_c, st, pc, f,
                        (const C2<T>*)P->d_tw_c, (const C2<T>*)work, scratch);
     rc = nk_check_launch("k_passC");
   }
@@ -762,20 +775,20 @@ static int nk_run_c2c(const nk_plan* P, const void* in, void* out, int inverse, 
   cc.swap = inverse ? 1 : 0;
   cc.scale = scale;
   const int64_t blocks = (cc.nlines + cc.tl.tile - 1) / cc.tl.tile;
-  hipLaunchKernelGGL(k_c2c_contig<T>, dim3((unsigned)blocks), dim3(P->threads_cc), P->lds_cc, st, cc,
+  hipLaunchKernelGGL(k_c2c_contig<T>, dim3((unsigned)blocks), dim3(nk_gen_threads<T>(P->threads_cc)), P->lds_cc, st, cc,
                      (const C2<T>*)P->d_tw_cc, (const C2<T>*)in, (C2<T>*)out);
   int rc = nk_check_launch("k_c2c_contig");
   if (rc != NK_OK) return rc;
   if (P->ndim == 3) {
     const NkPassS& ps = P->c2c_mid;
-    hipLaunchKernelGGL(k_c2c_strided<T>, dim3((unsigned)(ps.outer * ps.tiles_per_slab)), dim3(P->threads_cm),
+    hipLaunchKernelGGL(k_c2c_strided<T>, dim3((unsigned)(ps.outer * ps.tiles_per_slab)), dim3(nk_gen_threads<T>(P->threads_cm)),
                        P->lds_cm, st, ps, cc.swap, (const C2<T>*)P->d_tw_b, (C2<T>*)out);
     rc = nk_check_launch("k_c2c_strided(mid)");
     if (rc != NK_OK) return rc;
   }
   if (P->ndim >= 2) {
     const NkPassS& ps = P->c2c_first;
-    hipLaunchKernelGGL(k_c2c_strided<T>, dim3((unsigned)(ps.outer * ps.tiles_per_slab)), dim3(P->threads_cf),
+    hipLaunchKernelGGL(k_c2c_strided<T>, dim3((unsigned)(ps.outer * ps.tiles_per_slab)), dim3(nk_gen_threads<T>(P->threads_cf)),
                        P->lds_cf, st, ps, cc.swap, (const C2<T>*)P->d_tw_c, (C2<T>*)out);
     rc = nk_check_launch("k_c2c_strided(first)");
   }
