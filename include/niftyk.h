@@ -173,6 +173,15 @@ int nk_spmv_t(int64_t nrows, const int64_t* rowptr, const int32_t* col, const fl
  * partially (in == out is fine) */
 int nk_cumsum(int64_t n, const void* in, void* out, int reverse, int dtype, void* stream);
 
+/* row-wise complex helper of the any-length (chirp-z) composition in nifty_amd/backend.py -- the transforms of lengths
+ * the planner rejects (ducc0 takes every length, ducc_dispatch.py:116-132) are three power-of-two nk_fftn calls per axis
+ * glued by this kernel.  a is rows x in_cols, out is rows x out_cols (both C order), w (may be NULL = 1) has at least
+ * min(in_cols, out_cols) complex entries:
+ *   out[r][c] = scale * op(a[r][c]) * w[c]   for c < min(in_cols, out_cols),   0 for the padded columns c >= in_cols
+ *   mode 0: a complex, out complex;  mode 1: a real, out complex;  mode 2: a complex, out real = Re + sgn * Im (w unused) */
+int nk_cplx_rows(int64_t rows, int64_t in_cols, int64_t out_cols, const void* a, const void* w, void* out, int mode,
+                 double scale, int sgn, int dtype, void* stream);
+
 /* dst[0..n) = sum over c < copies of src[c*stride + (0..n)]  (folds the per-XCD VJP accumulators) */
 int nk_fold_copies(int64_t n, int copies, int64_t stride, const double* src, double* dst, void* stream);
 

@@ -97,7 +97,7 @@ def plan_supported(shape, dtype, batch=1, device=None):
 
 # ---- any-length fallback (Bluestein / chirp-z), composed from the native power-of-two c2c kernel -------------------
 # The reference's FFT (ducc0) takes every length (test_fft_operator.py:58-103 uses 10, 11, 12).  Lengths the planner
-# rejects are rare in the hot path, so they are served axis by axis:  X[j] = w[j] * sum_k (x[k] w[k]) conj(w)[j-k]
+# rejects are rare in the hot path, so they are served axis by axis (element-wise glue: nk_cplx_rows):  X[j] = w[j] * sum_k (x[k] w[k]) conj(w)[j-k]
 # with w[k] = exp(-+ i pi k^2 / n) -- a cyclic convolution of power-of-two length m >= 2n-1, i.e. three native c2c
 # transforms per axis.  The chirp angles come from k^2 mod 2n in integers, so they carry no large-argument error.
 _chirps = {}
@@ -124,6 +124,23 @@ def _chirp(n, cdt, inverse, device):
     return ent
 
 
+def cplx_rows(a, w, in_cols, out_cols, mode, scale=1.0, sgn=1):
+    """nk_cplx_rows on a contiguous tensor viewed as rows x in_cols: chirp multiply with zero padding / cropping
+    (mode 0), real -> complex promotion (mode 1), Hartley combine Re + sgn Im (mode 2)."""
+    _require_device(a, w)
+    rows = a.numel() // max(1, in_cols)
+    if mode == 2:
+        rdt = torch.float32 if a.dtype == torch.complex64 else torch.float64
+        out = torch.empty(a.shape[:-1] + (out_cols,), dtype=rdt, device=a.device)
+    else:
+        cdt = a.dtype if a.is_complex() else (torch.complex64 if a.dtype == torch.float32 else torch.complex128)
+        out = torch.empty(a.shape[:-1] + (out_cols,), dtype=cdt, device=a.device)
+    code = 0 if out.dtype in (torch.float32, torch.complex64) else 1
+    L.check(L.load().nk_cplx_rows(rows, in_cols, out_cols, a.data_ptr(), ptr(w), out.data_ptr(), mode, float(scale),
+                                  int(sgn), code, _stream()), "nk_cplx_rows")
+    return out
+
+
 def _fft_last_axis_any(z, inverse):
     """Unnormalised c2c transform over the last axis of a contiguous complex tensor, any length."""
     n = z.shape[-1]
@@ -138,10 +155,10 @@ def _fft_last_axis_any(z, inverse):
     if m > _CHIRP_MAX or not plan_supported((m,), rdt, batch, z.device) or not plan_supported((m,), rdt, 1, z.device):
         raise NotImplementedError(f"axis of length {n} is too long for the chirp-z fallback")
     m, w, fb = _chirp(n, z.dtype, inverse, z.device)
-    a = torch.zeros(z.shape[:-1] + (m,), dtype=z.dtype, device=z.device)
-    a[..., :n] = z * w
-    c = fftn(fftn(a, ndim=1) * fb, ndim=1, inverse=True, scale=1.0 / m)
-    return (c[..., :n] * w).contiguous()
+    a = cplx_rows(z, w, n, m, 0)                       # x[k] w[k], zero-padded to m
+    p = cplx_rows(fftn(a, ndim=1), fb, m, m, 0)        # times the transformed chirp
+    c = fftn(p, ndim=1, inverse=True, scale=1.0 / m)   # cyclic convolution
+    return cplx_rows(c, w, m, n, 0)                    # first n entries, times w[j]
 
 
 def _fft_any(z, ndim, inverse):
@@ -162,8 +179,9 @@ def hartley(x, ndim=None, scale=1.0, out=None):
     shape = x.shape[x.dim() - ndim:]
     batch = x.numel() // max(1, int(torch.Size(shape).numel()))
     if not plan_supported(shape, x.dtype, batch, x.device):
-        f = _fft_any(torch.complex(x, torch.zeros_like(x)), ndim, False)
-        h = (f.real + f.imag if _convention() == 0 else f.real - f.imag) * float(scale)
+        nl = x.shape[-1]
+        f = _fft_any(cplx_rows(x, None, nl, nl, 1), ndim, False)
+        h = cplx_rows(f, None, nl, nl, 2, scale, 1 if _convention() == 0 else -1)
         return h if out is None else out.copy_(h)
     plan = get_plan(shape, x.dtype, batch, x.device)
     out = torch.empty_like(x) if out is None else out
@@ -188,7 +206,8 @@ def fftn(x, ndim=None, inverse=False, scale=1.0):
     batch = x.numel() // max(1, int(torch.Size(shape).numel()))
     rdt = torch.float32 if x.dtype == torch.complex64 else torch.float64
     if not plan_supported(shape, rdt, batch, x.device):
-        return _fft_any(x, ndim, inverse) * float(scale)
+        f = _fft_any(x, ndim, inverse)
+        return f if float(scale) == 1.0 else cplx_rows(f, None, f.shape[-1], f.shape[-1], 0, scale)
     plan = get_plan(shape, rdt, batch, x.device)
     out = torch.empty_like(x)
     L.check(L.load().nk_fftn(plan.handle, torch.view_as_real(x).data_ptr(), torch.view_as_real(out).data_ptr(),

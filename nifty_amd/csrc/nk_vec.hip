@@ -535,6 +535,53 @@ extern "C" int nk_pindex_from_k2(int ndim, const int64_t* shape, const int32_t* 
   return nk_check_launch("k_pindex_k2");
 }
 
+// ---- row-wise complex helper of the chirp-z composition (see niftyk.h) ------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(NK_VEC_THREADS) k_cplx_rows(int64_t total, int64_t in_cols, int64_t out_cols, const T* __restrict__ a,
+                                                              const T* __restrict__ w, T* __restrict__ out, int mode, T scale,
+                                                              T sgn) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / out_cols, c = i - r * out_cols;
+    T re = (T)0, im = (T)0;
+    if (c < in_cols) {
+      const int64_t j = r * in_cols + c;
+      if (mode == 1) {
+        re = a[j];
+      } else {
+        re = a[2 * j];
+        im = a[2 * j + 1];
+      }
+    }
+    if (mode == 2) {
+      out[i] = scale * (re + sgn * im);
+      continue;
+    }
+    if (w && c < in_cols) {
+      const T wr = w[2 * c], wi = w[2 * c + 1];
+      const T t = re * wr - im * wi;
+      im = re * wi + im * wr;
+      re = t;
+    }
+    out[2 * i] = scale * re;
+    out[2 * i + 1] = scale * im;
+  }
+}
+
+extern "C" int nk_cplx_rows(int64_t rows, int64_t in_cols, int64_t out_cols, const void* a, const void* w, void* out, int mode,
+                            double scale, int sgn, int dtype, void* stream) {
+  if (rows < 0 || in_cols < 0 || out_cols < 0 || mode < 0 || mode > 2 || !out || (!a && rows * in_cols > 0))
+    return nk_set_error(NK_ERR_INVALID, "nk_cplx_rows: bad argument");
+  if (mode == 2 && out_cols > in_cols) return nk_set_error(NK_ERR_INVALID, "nk_cplx_rows: mode 2 cannot pad");
+  const int64_t total = rows * out_cols;
+  if (total == 0) return NK_OK;
+  NK_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL(k_cplx_rows<T>, dim3(nk_grid(total)), dim3(NK_VEC_THREADS), 0, (hipStream_t)stream, total, in_cols,
+                       out_cols, (const T*)a, (const T*)w, (T*)out, mode, (T)scale, (T)(sgn < 0 ? -1 : 1));
+    return nk_check_launch("k_cplx_rows");
+  })
+}
+
 // ---- fold the per-XCD private VJP accumulators ------------------------------------------------------------------
 __global__ void k_fold_copies(int64_t n, int copies, int64_t stride, const double* __restrict__ src, double* __restrict__ dst) {
   const int64_t gs = (int64_t)gridDim.x * blockDim.x;

@@ -99,6 +99,16 @@ def test_chirp_z_fallback_terminates_and_is_exact(monkeypatch):
         if not pow2_only(shape, dtype):
             raise NotImplementedError("stand-in planner")
 
+    def glue(a, w, in_cols, out_cols, mode, scale=1.0, sgn=1):  # what nk_cplx_rows computes (include/niftyk.h)
+        k = min(in_cols, out_cols)
+        if mode == 2:
+            return scale * (a.real + sgn * a.imag)[..., :k]
+        src = a[..., :k].to(torch.complex128)
+        out = torch.zeros(a.shape[:-1] + (out_cols,), dtype=torch.complex128)
+        out[..., :k] = scale * (src if w is None else src * w[:k])
+        return out
+
+    monkeypatch.setattr(B, "cplx_rows", glue)
     monkeypatch.setattr(B, "plan_supported", pow2_only)
     monkeypatch.setattr(B, "get_plan", plan)
     monkeypatch.setattr(B, "fftn", native)
