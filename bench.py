@@ -234,7 +234,7 @@ def main():
             avg_ms = ent["ms"] / ent["cnt"]
             achieved = ent["bytes"] / ent["cnt"] / (avg_ms * 1e-3) / 1e9
             traffic = None  # PMC numbers come from separate rocprofv3 passes of this very command (profiles/)
-            tfile = os.path.join(ROOT, "profiles", "r01i_pmc_traffic.json")
+            tfile = os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")
             if os.path.exists(tfile) and world == 1:
                 tj = json.load(open(tfile))
                 if tj.get("workload") == f"{'x'.join(map(str, shape))}:{dt_name}":
