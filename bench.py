@@ -29,10 +29,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from nifty_amd import _lib as L  # noqa: E402
-from nifty_amd import parallel, random  # noqa: E402
+from nifty_amd import minimization, parallel, random  # noqa: E402
 from nifty_amd.engine import FusedModel, LatentVec, mgvi_iteration  # noqa: E402
 from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG  # noqa: E402
 
+PMC_TRAFFIC_FILE = "r01k_pmc_traffic.json"  # latest committed PMC summary of the bench command
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 KERNEL_NAMES = {0: "k_pass1d", 1: "k_passA", 2: "k_passB", 3: "k_passC", 4: "k_passD"}
 PRO_NAMES = {0: "plain", 1: "amp", 2: "amp_jvp", 3: "mul"}
@@ -69,12 +70,15 @@ def collect_profile():
     return out
 
 
-def cpu_baseline(counts_per_step, shape_full, sample_shape=(128, 128, 128), budget_s=20.0, device=None):
+def cpu_baseline(counts_per_step, shape_full, sample_shape=None, budget_s=20.0, device=None):
     """Oracle (numpy + scipy.fft restatement of the reference path) timed on the host cores on a bounded
     sample, extrapolated with N log N to the full workload.  A reported baseline, not a target."""
     from oracle import nifty_oracle as orc
 
     cores = os.cpu_count() or 1
+    if sample_shape is None:  # the largest cube that keeps this leg at ~20-30 s: 256^3 on a many-core host
+        edge = 256 if cores >= 32 else 128
+        sample_shape = tuple(min(edge, n) for n in shape_full)
     rng = np.random.default_rng(0)
     cf = orc.CFModel(sample_shape, None, orc.CFParams(offset_mean=2.0), workers=cores)
     x = {k: 0.1 * v for k, v in cf.draw_latent(rng).items()}
@@ -143,6 +147,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand without a launcher: run the ranks as a CHILD torchrun job (one process per GPU) and leave
+        # with its exit code -- this process has not touched the GPU yet
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     comm, local_rank = parallel.init(os.environ.get("NK_DIST_BACKEND", "nccl"))
     if os.environ.get("NK_SHARE_DEVICE"):  # developer check: several ranks on one GPU (with NK_DIST_BACKEND=gloo)
         local_rank = 0
@@ -202,6 +218,7 @@ def main():
     for _ in range(args.warmup):
         mean, _ = step(mean)
     model.counters = {k: 0 for k in model.counters}
+    minimization.counters["cg_iterations"] = 0
     lib = L.load()
     lib.nk_profile_enable(1)
     collect_profile()
@@ -217,6 +234,7 @@ def main():
     if comm is not None:
         elapsed = comm.max_float(elapsed, device)
     ms_per_step = 1e3 * elapsed / args.steps
+    model.counters["cg_iterations"] = minimization.counters["cg_iterations"]
     counts = {k: v / args.steps for k, v in model.counters.items()}
 
     if rank == 0:
@@ -233,14 +251,17 @@ def main():
             ent = by_kernel[kern]
             avg_ms = ent["ms"] / ent["cnt"]
             achieved = ent["bytes"] / ent["cnt"] / (avg_ms * 1e-3) / 1e9
-            traffic = None  # PMC numbers come from separate rocprofv3 passes of this very command (profiles/)
-            tfile = os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")
+            # PMC counters cannot be read from inside the run: they come from separate rocprofv3 --pmc passes of this
+            # very command (tools/pmc_bench.sh), whose summary is committed under profiles/ -- named in traffic_source
+            traffic, traffic_source = None, None
+            tfile = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
             if os.path.exists(tfile) and world == 1:
                 tj = json.load(open(tfile))
                 if tj.get("workload") == f"{'x'.join(map(str, shape))}:{dt_name}":
                     traffic = tj["kernels"].get(KERNEL_NAMES[kern], {}).get("bytes")
+                    traffic_source = f"profiles/{PMC_TRAFFIC_FILE} (separate rocprofv3 --pmc passes, not this run)"
             roofline = dict(bound="hbm", kernel=KERNEL_NAMES[kern], achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
-                            unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                            unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
                             avg_launch_ms=round(avg_ms, 4), launches=int(ent["cnt"]),
                             algorithmic_bytes_per_launch=ent["bytes"] / ent["cnt"],
                             all_pass_kernels={KERNEL_NAMES[k]: dict(ms_total=round(v["ms"], 2), launches=int(v["cnt"]),
@@ -248,11 +269,12 @@ def main():
                                               for k, v in sorted(by_kernel.items())})
         # whole-step algorithmic bytes: B_met, B_vg per sample evaluation on this rank
         D = len(shape)
+        shape_label = f"{shape[0]}^{D}" if len(set(shape)) == 1 else "x".join(map(str, shape))
         B_met = (4 * D + 4) * N * b + 8 * N
         B_vg = (4 * D + 3) * N * b + 8 * N
         step_bytes = counts["metric"] * B_met + counts["value_grad"] * B_vg
         line = {
-            "metric": "MGVI iters/sec on 1024^3 RGSpace CorrelatedField, 8 samples; achieved HBM GB/s",
+            "metric": f"MGVI iters/sec on {shape_label} RGSpace CorrelatedField, {2 * n_pairs} samples; achieved HBM GB/s",
             "value": args.steps / elapsed,
             "unit": "MGVI iters/s",
             "n_gpus": world,

@@ -20,17 +20,34 @@ _plans = {}
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+_current_device = torch.cuda.current_device
+
+
 def _stream():
-    """Handle of torch's current stream on the current device (every kernel of the library is launched on it)."""
+    """Handle of torch's current stream on the CURRENT device: every kernel of the library is launched on it, so the
+    operands must live on the current device (`_require_device`; `optimize_kl(device_id=k)` and the multi-rank
+    initialisation make cuda:k current)."""
     if _raw_stream is not None:  # ~0.3 us instead of ~8 us per launch: the small configs are host-bound
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(_current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
+def _wrong_device(index):
+    raise RuntimeError(f"nifty_amd.backend: operand on cuda:{index} but the current device is cuda:{_current_device()}; "
+                       f"run under `with torch.cuda.device({index})` (kernels launch on the current device's stream)")
+
+
 def _require_device(*ts):
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("nifty_amd.backend: device kernels need GPU tensors (no CPU fallback)")
+        if cur is None:
+            cur = _current_device()
+        if t.device.index != cur:
+            _wrong_device(t.device.index)
 
 
 def dtype_code(t):
@@ -191,6 +208,8 @@ def hartley(x, ndim=None, scale=1.0, out=None):
 
 
 def hartley_fused(plan, fuse):
+    if plan.device.index != _current_device():
+        _wrong_device(plan.device.index)
     L.check(L.load().nk_hartley_fused(plan.handle, ctypes.byref(fuse), _convention(), plan.workspace.data_ptr(),
                                       _stream()), "nk_hartley_fused")
 

@@ -239,12 +239,11 @@ static int nk_launch_final_c(NkPassF pf, const NkFuse& f, const C2<T>* tw, const
   using CT = FinalTile<T, NL, EC, COUPLES ? 2 : 1>;
   static_assert(!COUPLES || CT::TILE >= 2, "the couple (b0, M - b0) must live in one workgroup");
   auto kern = k2_final<T, NL, COUPLES, EC>;
-  static bool attr_done = false;
-  if (!attr_done && CT::LDS_BYTES > 64 * 1024) {
+  static unsigned long long attr_mask = 0;  // per-device attribute
+  if (CT::LDS_BYTES > 64 * 1024 && nk_first_on_device(attr_mask)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CT::LDS_BYTES);
     if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k2_final)");
   }
-  attr_done = true;
   pf.tiles_per_a = (COUPLES && pf.A > 1 && CT::TILE >= 2) ? (pf.M / 2 + 1 + CT::TILE / 2 - 1) / (CT::TILE / 2)
                                                : (pf.M + CT::TILE - 1) / CT::TILE;
   const int64_t blocks = (int64_t)pf.g.batch * (pf.A / 2 + 1) * pf.tiles_per_a;
@@ -286,12 +285,11 @@ static int nk_launch_contig(const NkPassA& pa, const NkFuse& f, const C2<T>* tw,
                             hipStream_t st) {
   using CT = ContigTile<T, H>;
   auto kern = k2_contig<T, H, IS_1D>;
-  static bool attr_done = false;
-  if (!attr_done && CT::LDS_BYTES > 64 * 1024) {
+  static unsigned long long attr_mask = 0;  // per-device attribute
+  if (CT::LDS_BYTES > 64 * 1024 && nk_first_on_device(attr_mask)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CT::LDS_BYTES);
     if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k2_contig)");
   }
-  attr_done = true;
   const int64_t blocks = (pa.nlines + CT::TILE - 1) / CT::TILE;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CT::THREADS), CT::LDS_BYTES, st, pa, f, tw, twr, work);
   return nk_check_launch("k2_contig");
@@ -301,12 +299,11 @@ template <typename T, int N, int MODE, int PC>
 static int nk_launch_strided_pc(NkPassS ps, const NkFuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch, hipStream_t st) {
   using ST = StridedTile<T, N>;
   auto kern = k2_strided<T, N, MODE, PC>;
-  static bool attr_done = false;
-  if (!attr_done && ST::LDS_BYTES > 64 * 1024) {
+  static unsigned long long attr_mask = 0;  // per-device attribute
+  if (ST::LDS_BYTES > 64 * 1024 && nk_first_on_device(attr_mask)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ST::LDS_BYTES);
     if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k2_strided)");
   }
-  attr_done = true;
   ps.tl.tile = ST::TILE;
   ps.tiles_per_slab = (int)(ps.inner / ST::TILE);
   const int64_t blocks = ps.outer * ps.tiles_per_slab;

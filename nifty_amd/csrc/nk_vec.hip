@@ -64,6 +64,11 @@ __device__ __forceinline__ double nk_block_sum(double v) {
   return s;
 }
 
+// scratch of the deterministic reductions (per device: __device__ globals are instantiated on every GPU)
+static constexpr int NK_MAX_RED = 4;
+__device__ double g_red_partial[NK_MAX_RED * NK_MAX_BLOCKS];
+__device__ unsigned int g_red_ticket = 0;
+
 // ---- generic "map with up to 4 inputs, 3 outputs and 3 reductions" skeleton ---------------------------
 // F::apply(const T* in[..] values, T* outs, double* red) is called per element.
 template <typename T, typename F, bool VEC>
@@ -80,11 +85,34 @@ __global__ void __launch_bounds__(NK_VEC_THREADS) k_map(int64_t n, F f) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < n - tail0) f.template run<1>(tail0 + gid, red);
   }
-  if (F::NRED > 0) {
+  if constexpr (F::NRED > 0) {
+    // DETERMINISTIC reduction: every workgroup stores its partial sums; the workgroup that takes the last ticket adds
+    // them up in block order with a fixed tree and updates result[].  Identical inputs therefore give identical
+    // bits on every launch and on every GPU of a node (the grid is a function of n only) -- the replicated CG /
+    // line-search scalars of a multi-rank KL minimisation agree without any exchange.  The scratch belongs to the
+    // device; launches on one stream are serialised, and every launch leaves the ticket at zero.
+    __shared__ bool is_last;
 #pragma unroll
     for (int r = 0; r < F::NRED; ++r) {
       const double s = nk_block_sum(red[r]);
-      if (threadIdx.x == 0) atomicAdd(f.result + r, s);
+      if (threadIdx.x == 0) g_red_partial[r * NK_MAX_BLOCKS + blockIdx.x] = s;
+    }
+    if (threadIdx.x == 0) {
+      __threadfence();
+      is_last = atomicAdd(&g_red_ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (is_last) {
+      __threadfence();
+#pragma unroll
+      for (int r = 0; r < F::NRED; ++r) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < (int)gridDim.x; b += NK_VEC_THREADS)
+          v += __builtin_nontemporal_load(&g_red_partial[r * NK_MAX_BLOCKS + b]);
+        const double s = nk_block_sum(v);
+        if (threadIdx.x == 0) f.result[r] += s;
+      }
+      if (threadIdx.x == 0) g_red_ticket = 0;
     }
   }
 }

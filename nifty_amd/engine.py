@@ -105,7 +105,7 @@ class CgWorkspace:
 
     def fetch(self):
         self._host.copy_(self.scal, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream(self.scal.device).synchronize()
         s = self._host.numpy()
         return dict(gamma_prev=float(s[0]), curv=float(s[1]), gamma=float(s[2]), xr=float(s[3]), xb=float(s[4]),
                     alpha=float(s[0] / s[1]) if s[1] != 0 else float("nan"))
@@ -216,7 +216,7 @@ class LatentVec:
         return B.vdot(self.small, o.small, result=res, accumulate=True)
 
     def s_vdot(self, o):
-        return parallel.lockstep_float(float(self.dot_device(o).item()), self.xi.device)
+        return float(self.dot_device(o).item())  # rank-local; minimisers synchronise their decisions (minimization._ls)
 
     def norm(self, ord=2):
         if ord != 2:
@@ -248,6 +248,12 @@ class FusedModel:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("FusedModel runs on a GPU only (no CPU fallback)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if self.device.index != torch.cuda.current_device():
+            # every kernel is launched on the CURRENT device's stream (backend._stream)
+            raise RuntimeError(f"FusedModel(device={self.device}): make it the current device first "
+                               f"(torch.cuda.set_device / `with torch.cuda.device({self.device.index})`)")
         self.tdtype = dtype
         self.shape = tuple(int(s) for s in np.atleast_1d(shape))
         self.N = int(np.prod(self.shape))

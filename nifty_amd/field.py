@@ -217,7 +217,9 @@ class Field:
         dt = torch.promote_types(a.dtype, b.dtype)
         if not dt.is_floating_point:
             dt = torch.float64
-        return parallel.lockstep_float(float(B.vdot(_cast(a, dt).contiguous(), _cast(b, dt).contiguous()).item()), a.device)
+        # no communication here: energies take rank-local per-sample values with this (the minimisers synchronise the
+        # scalars that steer them, minimization._ls)
+        return float(B.vdot(_cast(a, dt).contiguous(), _cast(b, dt).contiguous()).item())
 
     def vdot(self, x):
         return Field.scalar(self.s_vdot(x)).at(self.device_id)

@@ -86,7 +86,7 @@ class SampleListBase:
         self._comm = comm
         self._domain = makeDomain(domain)
         ntask, rank, _ = get_MPI_params_from_comm(comm)
-        self._n_local = None
+        self._n_total = None
         self._ntask, self._rank = ntask, rank
 
     @property
@@ -105,20 +105,11 @@ class SampleListBase:
 
     @property
     def n_samples(self):
-        n = self.n_local_samples()
-        if self._comm is None:
-            return n
-        import torch
-
-        t = torch.tensor([float(n)], dtype=torch.float64, device=self._reduce_device())
-        self._comm.allreduce_sum_([t])
-        return int(round(t.item()))
-
-    def _reduce_device(self):
-        import torch
-
-        return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() and \
-            self._comm is not None and getattr(self._comm, "backend_is_nccl", False) else torch.device("cpu")
+        """Global sample count (one scalar all-reduce, cached: the local count of a sample list never changes)."""
+        if self._n_total is None:
+            n = self.n_local_samples()
+            self._n_total = n if self._comm is None else int(round(self._comm.sum_float(n)))
+        return self._n_total
 
     def local_iterator(self, op=None):
         for i in range(self.n_local_samples()):
@@ -134,12 +125,8 @@ class SampleListBase:
         """Sum a Field / MultiField / python float over ranks in place."""
         if self._comm is None or self._comm.size == 1:
             return obj
-        import torch
-
         if isinstance(obj, float):
-            t = torch.tensor([obj], dtype=torch.float64)
-            self._comm.allreduce_sum_([t])
-            return float(t.item())
+            return self._comm.sum_float(obj)  # the scalar lives where the backend needs it (RCCL: on the GPU)
         tensors = [f.val for f in (obj.values() if isinstance(obj, MultiField) else [obj])]
         self._comm.allreduce_sum_(tensors)
         return obj
@@ -210,7 +197,9 @@ class ResidualSampleList(SampleListBase):
         """Only the entries present in `mean` are updated (sample_list.py:436-455)."""
         if isinstance(self._m, MultiField) and self.domain is not mean.domain:
             mean = MultiField.union([self._m, mean])
-        return ResidualSampleList(mean, self._r, self._n, self._comm)
+        sl = ResidualSampleList(mean, self._r, self._n, self._comm)
+        sl._n_total = self._n_total  # same residuals: no new count reduction per evaluation
+        return sl
 
     @property
     def mean(self):

@@ -16,6 +16,21 @@ import numpy as np
 logger = logging.getLogger("nifty_amd")
 
 CONVERGED, CONTINUE, ERROR = 0, 1, 2
+counters = {"cg_iterations": 0}  # work counters (bench.py): CG iterations = metric applications inside ConjugateGradient
+
+
+def _ls(value):
+    """Decision-point synchronisation: inside a multi-rank ``parallel.lockstep`` scope (the replicated KL
+    minimisation) the scalar of rank 0, otherwise ``value`` itself.  Applied to every reduction of REPLICATED vectors
+    that steers control flow here (CG / line-search / L-BFGS dot products, gradient norms); per-sample energies are
+    rank-local and must not pass through it."""
+    from . import parallel
+
+    if parallel.lockstep_comm() is None:
+        return value
+    if isinstance(value, complex):
+        return complex(parallel.lockstep_float(value.real), parallel.lockstep_float(value.imag))
+    return parallel.lockstep_float(float(value))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -46,7 +61,7 @@ class Energy:
     @property
     def gradient_norm(self):
         if self._gradnorm is None:
-            self._gradnorm = self.gradient.norm()
+            self._gradnorm = _ls(self.gradient.norm())
         return self._gradnorm
 
     @property
@@ -86,7 +101,7 @@ class QuadraticEnergy(Energy):
         val = 0.5 * np.real(self._position.s_vdot(Ax))
         if b is not None:
             val -= np.real(b.s_vdot(self._position))
-        return val
+        return _ls(val)
 
     def at(self, position):
         return QuadraticEnergy(position, self._A, self._b)
@@ -258,7 +273,7 @@ class GradInfNormController(_LevelController):
         self._tol = tol
 
     def _criterion(self, energy):
-        crit = energy.gradient.norm(np.inf) / abs(energy.value)
+        crit = _ls(energy.gradient.norm(np.inf)) / abs(energy.value)
         return (self._tol is not None and crit <= self._tol), f"crit={crit:.2E}"
 
 
@@ -337,7 +352,7 @@ class ConjugateGradient(Minimizer):
             return energy, status
         r = energy.gradient
         d = r if preconditioner is None else preconditioner(r)
-        gamma_prev = np.real(r.s_vdot(d))
+        gamma_prev = _ls(np.real(r.s_vdot(d)))
         if np.isnan(gamma_prev):
             logger.error("Error: ConjugateGradient: previous_gamma==NaN")
             return energy, ERROR
@@ -346,7 +361,8 @@ class ConjugateGradient(Minimizer):
         since_reset = 0
         while True:
             q = energy.apply_metric(d)
-            curv = np.real(d.s_vdot(q))
+            counters["cg_iterations"] += 1
+            curv = _ls(np.real(d.s_vdot(q)))
             if np.isnan(curv) or curv == 0.0:
                 logger.error("Error: ConjugateGradient: curv==NaN or 0")
                 return energy, ERROR
@@ -364,7 +380,7 @@ class ConjugateGradient(Minimizer):
                 r = energy.gradient
                 since_reset = 0
             s = r if preconditioner is None else preconditioner(r)
-            gamma = np.real(r.s_vdot(s))
+            gamma = _ls(np.real(r.s_vdot(s)))
             if np.isnan(gamma):
                 logger.error("Error: ConjugateGradient: gamma==NaN")
                 return energy, ERROR
@@ -392,7 +408,7 @@ class ConjugateGradient(Minimizer):
         r = energy.gradient.clone()
         d = r.clone()
         ws = x.cg_workspace()
-        gamma_prev = r.s_vdot(r)
+        gamma_prev = _ls(r.s_vdot(r))
         if np.isnan(gamma_prev):
             return energy, ERROR
         if gamma_prev == 0:
@@ -413,6 +429,7 @@ class ConjugateGradient(Minimizer):
                 q = A(d)
                 ws.curv(d, q)
             ws.update(x, r, d, q, b)
+            counters["cg_iterations"] += 1
             since_reset += 1
             if since_reset >= self._nreset:
                 # periodic residual refresh (conjugate_gradient.py:103-106): r = A x - b
@@ -461,6 +478,7 @@ class ConjugateGradient(Minimizer):
             q = sm.apply(d_full)
             ws.curv(d, q)
             ws.update(x, r, d, q, b)
+            counters["cg_iterations"] += 1
             since_reset += 1
             if since_reset >= self._nreset:
                 Ax = sm.apply(sm.gather(x))
@@ -511,7 +529,7 @@ class LineEnergy:
 
     @property
     def directional_derivative(self):
-        return np.real(self._energy.gradient.s_vdot(self._dir))
+        return _ls(np.real(self._energy.gradient.s_vdot(self._dir)))
 
 
 def _interp_cubic(a, fa, fpa, b, fb, c, fc):
@@ -569,7 +587,7 @@ class LineSearch:
             if t1 < 0:
                 t1 = 1.0
         else:
-            t1 = 1.0 / pk.norm()
+            t1 = 1.0 / _ls(pk.norm())
         t1 = min(t1, 0.99 * cap)
         t0, phi_t0, dphi_t0 = 0.0, phi0, dphi0
         le1 = None
@@ -728,17 +746,17 @@ class L_BFGS(DescentMinimizer):
         alpha = {}
         for i in used:
             s, y = self._s[i % m], self._y[i % m]
-            alpha[i] = s.s_vdot(p) / s.s_vdot(y)
+            alpha[i] = _ls(s.s_vdot(p)) / _ls(s.s_vdot(y))
             p = p - alpha[i] * y
         if used:
             s, y = self._s[(k - 1) % m], self._y[(k - 1) % m]
-            fact = s.s_vdot(y) / y.s_vdot(y)
+            fact = _ls(s.s_vdot(y)) / _ls(y.s_vdot(y))
             if fact <= 0.0:
                 logger.error("L-BFGS curvature not positive definite!")
             p = p * fact
             for i in reversed(used):
                 s, y = self._s[i % m], self._y[i % m]
-                p = p + (alpha[i] - y.s_vdot(p) / s.s_vdot(y)) * s
+                p = p + (alpha[i] - _ls(y.s_vdot(p)) / _ls(s.s_vdot(y))) * s
         self._lastx, self._lastgrad = x, g
         self._k += 1
         return p

@@ -87,7 +87,8 @@ def match_fused(lh):
     return kw
 
 
-_fused_cache = {}
+_fused_cache = {}  # at most _FUSED_CACHE_MAX entries: an entry pins its likelihood and the model's device buffers
+_FUSED_CACHE_MAX = 2
 
 
 def _fused_model(lh, device_id, dtype):
@@ -98,6 +99,8 @@ def _fused_model(lh, device_id, dtype):
 
     key = (id(lh), device_id, dtype)
     if key not in _fused_cache:
+        while len(_fused_cache) >= _FUSED_CACHE_MAX:  # oldest first (dicts keep insertion order)
+            _fused_cache.pop(next(iter(_fused_cache)))
         kw = match_fused(lh)
         tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
         if kw is not None and not B.plan_supported(kw["shape"], tdt, 1, f"cuda:{device_id}"):
@@ -158,11 +161,25 @@ def _fused_iteration(model, lh, mean, n_samples, minimizer, ic_sampling, comm, g
 # driver
 # ------------------------------------------------------------------------------------------------
 def optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sampling_iteration_controller, *,
-                nonlinear_sampling_minimizer=None, constants=[], point_estimates=[], transitions=None,
-                export_operator_outputs={}, output_directory=None, initial_position=None, initial_index=0, comm=None,
-                inspect_callback=None, terminate_callback=None, plot_energy_history=True,
-                plot_minisanity_history=True, save_strategy="latest", return_final_position=False, resume=False,
-                sanity_checks=True, dry_run=False, fresh_stochasticity=True, device_id=-1, fuse=True):
+                device_id=-1, **kwargs):
+    """reference optimize_kl.py:51-453.  With ``device_id >= 0`` the whole run executes with that GPU as torch's
+    current device: every libniftyk kernel is launched on the current device's current stream (backend._stream)."""
+    if device_id is not None and device_id >= 0:
+        import torch
+
+        with torch.cuda.device(device_id):
+            return _optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer,
+                                sampling_iteration_controller, device_id=device_id, **kwargs)
+    return _optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sampling_iteration_controller,
+                        device_id=device_id, **kwargs)
+
+
+def _optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sampling_iteration_controller, *,
+                 nonlinear_sampling_minimizer=None, constants=[], point_estimates=[], transitions=None,
+                 export_operator_outputs={}, output_directory=None, initial_position=None, initial_index=0, comm=None,
+                 inspect_callback=None, terminate_callback=None, plot_energy_history=True,
+                 plot_minisanity_history=True, save_strategy="latest", return_final_position=False, resume=False,
+                 sanity_checks=True, dry_run=False, fresh_stochasticity=True, device_id=-1, fuse=True):
     if not isinstance(export_operator_outputs, dict):
         raise TypeError
     if not isinstance(initial_index, int):
@@ -280,12 +297,19 @@ def optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sa
                 sl = e.samples.at(mean)
             energy_history.append((ig, e.value))
         if output_directory is not None:
+            # every rank's sample files are complete before rank 0 declares the iteration finished, and the marker is
+            # on disk before anybody moves on (optimize_kl.py:425-435: save under ensure_all_tasks_succeed + barriers)
+            c = comm(ig)
             sl.save(os.path.join(output_directory, "pickle", fname(ig)), overwrite=True)
-            if get_MPI_params_from_comm(comm(ig))[2]:
-                with open(os.path.join(output_directory, "last_finished_iteration"), "w") as f:
-                    f.write(str(ig))
+            if c is not None:
+                c.barrier()
+            if get_MPI_params_from_comm(c)[2]:
                 with open(os.path.join(output_directory, "pickle", "energy_history_" + fname(ig)), "wb") as f:
                     pickle.dump(energy_history, f)
+                with open(os.path.join(output_directory, "last_finished_iteration"), "w") as f:
+                    f.write(str(ig))
+            if c is not None:
+                c.barrier()
         # fit-quality table of this iteration (optimize_kl.py:438, 571-578): logged, and appended to minisanity.txt
         from .extra import minisanity
 

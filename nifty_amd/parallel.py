@@ -32,10 +32,26 @@ class Comm:
         self.backend = str(dist.get_backend(group))
         self.backend_is_nccl = "nccl" in self.backend
 
+    def scalar_device(self):
+        """Where small tensors that go through a collective must live: RCCL has no host path (the current GPU), every
+        other backend takes host tensors."""
+        if self.backend_is_nccl:
+            return torch.device("cuda", torch.cuda.current_device())
+        return torch.device("cpu")
+
     def _staged(self, t, fn):
-        """Run collective `fn` on `t`.  RCCL works on the device tensor; any other backend (gloo: tests, several ranks on
-        one GPU) gets an explicit host copy -- gloo's own device-tensor staging deadlocked intermittently here."""
-        if self.backend_is_nccl or not t.is_cuda:
+        """Run collective `fn` on `t`.  RCCL works on device tensors only (a host tensor is staged through the current
+        GPU); any other backend (gloo: tests, several ranks on one GPU) gets an explicit host copy -- gloo's own
+        device-tensor staging deadlocked intermittently here."""
+        if self.backend_is_nccl:
+            if t.is_cuda:
+                fn(t)
+                return t
+            d = t.to(self.scalar_device())
+            fn(d)
+            t.copy_(d)
+            return t
+        if not t.is_cuda:
             fn(t)
             return t
         h = t.detach().cpu()
@@ -117,9 +133,15 @@ class Comm:
     def barrier(self):
         dist.barrier(group=self.group)
 
-    def max_float(self, value, device):
-        t = torch.tensor([float(value)], dtype=torch.float64, device=device if self.backend_is_nccl else "cpu")
+    def max_float(self, value, device=None):
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.scalar_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def sum_float(self, value):
+        """Sum of a python float over the ranks (identical on every rank)."""
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.scalar_device())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return float(t.item())
 
     @property
@@ -128,12 +150,14 @@ class Comm:
 
 
 # ---- lockstep scope --------------------------------------------------------------------------------------
-# Device reductions end in fp64 atomics, so two ranks that reduce IDENTICAL replicated data may differ in the last
-# bit.  Inside a replicated computation (the KL minimisation: every rank runs the same minimiser on the same
-# all-reduced values) every host decision must nevertheless be identical on all ranks, or one rank leaves a loop the
-# others stay in and the next collective deadlocks.  Within `lockstep(comm)` every scalar that can steer control flow
-# -- host dot products, the CG's device scalars -- is therefore taken from rank 0.  The sampling phase (independent
-# per-rank solves) runs outside the scope.
+# Inside a replicated computation (the KL minimisation: every rank runs the same minimiser on the same all-reduced
+# values) every host decision must be identical on all ranks, or one rank leaves a loop the others stay in and the
+# next collective deadlocks.  The BLAS-1 reductions of libniftyk are deterministic (fixed-order block partials), so
+# identical replicated data gives identical scalars; as a second line of defence the MINIMISERS take every scalar that
+# steers their control flow -- CG / line-search / L-BFGS dot products, gradient norms, the CG's device scalars --
+# from rank 0 while a `lockstep(comm)` scope is active (`lockstep_float` at the decision points of minimization.py).
+# Field / LatentVec dot products themselves never communicate: energies evaluate per-sample (rank-local) values with
+# them, and ranks may hold different numbers of samples.  The sampling phase runs outside the scope.
 _lockstep_stack = []
 
 
@@ -154,12 +178,12 @@ def lockstep_comm():
     return _lockstep_stack[-1] if _lockstep_stack else None
 
 
-def lockstep_float(value, device):
+def lockstep_float(value, device=None):
     """`value` of rank 0 on every rank while a lockstep scope is active, else `value`."""
     comm = lockstep_comm()
     if comm is None:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=comm.scalar_device())
     comm.bcast_(t)
     return float(t.item())
 

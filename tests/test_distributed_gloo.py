@@ -71,6 +71,59 @@ def test_two_rank_kl_equals_serial(tmp_path):
     assert gl.lat_relerr(par["min_pos"], gl.latent(z, "kl_min_pos")) < 1e-6
 
 
+def _uneven_kl(comm):
+    """Generic-graph KL with 3 unmirrored samples (2 + 1 over two ranks), minimised inside the lockstep scope exactly
+    like optimize_kl does."""
+    from nifty_amd import parallel
+
+    ift, m, ham, x, v = _problem()
+    ift.random.push_sseq_from_seed(m["seed"] + 5)
+    kl = ift.SampledKLEnergy(x, ham, 3, None, mirror_samples=False, comm=comm)
+    ift.random.pop_sseq()
+    mini = ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=3), max_cg_iterations=6)
+    with parallel.lockstep(comm):
+        kl2, _ = mini(kl)
+    return kl, kl2
+
+
+def _uneven_worker(rank, world, port, out):
+    import faulthandler
+
+    faulthandler.dump_traceback_later(200, exit=True)  # mispaired collectives would hang: fail instead
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from nifty_amd import parallel
+
+    comm, _ = parallel.init("gloo")
+    kl, kl2 = _uneven_kl(comm)
+    assert kl.samples.n_local_samples() == (2 if rank == 0 else 1) and kl.samples.n_samples == 3
+    torch.save(dict(value=kl.value, min_value=kl2.value, min_pos=kl2.position.asnumpy()), f"{out}.{rank}")
+    comm.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(400)
+def test_two_rank_lockstep_with_unequal_sample_counts(tmp_path):
+    """the dot products inside the per-sample energies must not communicate -- ranks with different
+    local sample counts would mispair the broadcasts, and rank 0's per-sample values would overwrite the others'."""
+    from tests import goldenlib as gl
+
+    out = str(tmp_path / "rank")
+    mp.spawn(_uneven_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0", weights_only=False), torch.load(out + ".1", weights_only=False)
+    kl, kl2 = _uneven_kl(None)  # serial truth
+    for r in (r0, r1):
+        assert abs(r["value"] - kl.value) < 1e-10 * abs(kl.value)
+        assert abs(r["min_value"] - kl2.value) < 1e-8 * abs(kl2.value)
+        assert gl.lat_relerr(r["min_pos"], kl2.position.asnumpy()) < 1e-7
+    # replicated state stays identical on both ranks
+    assert r0["min_value"] == r1["min_value"]
+    for k in r0["min_pos"]:
+        assert np.array_equal(r0["min_pos"][k], r1["min_pos"][k])
+
+
 def test_share_range_matches_reference_semantics():
     from nifty_amd.parallel import shareRange
 
@@ -163,6 +216,36 @@ def _nccl_single_worker(rank, world, port):
     s8 = torch.ones(3, dtype=torch.float64, device=dev)
     comm.allreduce_sum_([s8[1:3]])
     assert torch.equal(s8.cpu(), torch.ones(3, dtype=torch.float64))
+    # host scalars / host tensors on the RCCL backend (RCCL has no host path -- they are staged on the GPU)
+    assert comm.sum_float(2.5) == 2.5 and comm.max_float(-1.25) == -1.25
+    h = torch.arange(4, dtype=torch.float64)
+    comm.allreduce_sum_([h])
+    comm.bcast_(h)
+    assert torch.equal(h, torch.arange(4, dtype=torch.float64))
+    from nifty_amd import parallel
+
+    with parallel.lockstep(None):
+        assert parallel.lockstep_float(3.0) == 3.0
+    parallel._lockstep_stack.append(comm)  # a one-rank communicator still walks the broadcast path
+    try:
+        assert parallel.lockstep_float(3.5) == 3.5
+    finally:
+        parallel._lockstep_stack.pop()
+    # the generic sampled KL builds and reduces under RCCL (value/gradient averages, sample count)
+    from tests import goldenlib as gl
+    from tests.test_api_host import build
+    import nifty_amd as ift
+
+    z = gl.load("model_g1d")
+    m, cfm, cf, lh = build(z)
+    x = ift.MultiField.from_raw(cf.domain, gl.latent(z, "x")).at(0)
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=m["sampling_limit"])
+    ham = ift.StandardHamiltonian(lh, ic, prior_sampling_dtype=np.float64)
+    ift.random.push_sseq_from_seed(m["seed"] + 1)
+    kl = ift.SampledKLEnergy(x, ham, m["n_samples"], None, mirror_samples=True, comm=comm, device_id=0)
+    ift.random.pop_sseq()
+    assert kl.samples.n_samples == 4
+    assert abs(kl.value - float(z["kl_value"])) < 1e-9 * abs(float(z["kl_value"]))
     dist.destroy_process_group()
 
 
