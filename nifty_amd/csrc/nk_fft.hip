@@ -213,11 +213,14 @@ __global__ void __launch_bounds__((StridedTile<T, N>::THREADS),
                                            StridedTile<T, N>::THREADS <= 512
                                        ? 2 * StridedTile<T, N>::THREADS / 256
                                        : NK_S0_WAVES))
-    k2_strided(NkPassS p, NkFuse f, const C2<T>* __restrict__ tw, C2<T>* __restrict__ work, C2<T>* __restrict__ scratch) {
+    k2_strided(NkPassS p, NkFuse f, const C2<T>* __restrict__ tw, C2<T>* __restrict__ work, C2<T>* __restrict__ scratch, int xmap) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, Sched<T, N>::E> ex;
   double acc = 0.0;
-  nk_strided_body<T, N, StridedTile<T, N>::TILE, MODE, PC>(ex, p, f, blockIdx.x, (T*)smem, tw, work, scratch, &acc);
+  // the octant prologues bring their own XCD-aware order (nk_oct_block_remap)
+  constexpr bool OCT = MODE == 3 && (PC == 4 || PC == 5);
+  const int64_t blk = (xmap && !OCT) ? nk_xcd_contig(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  nk_strided_body<T, N, StridedTile<T, N>::TILE, MODE, PC>(ex, p, f, blk, (T*)smem, tw, work, scratch, &acc);
   (void)acc;
 }
 
@@ -226,11 +229,12 @@ __global__ void __launch_bounds__((StridedTile<T, N>::THREADS),
 template <typename T, int NL, bool COUPLES, int EC>
 __global__ void __launch_bounds__((FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS),
                                   (FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS > 256 ? 1 : ((!COUPLES && sizeof(T) == 4 && (EC == 0 || EC == 1)) ? 4 : 3)))
-    k2_final(NkPassF p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work) {
+    k2_final(NkPassF p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, int xmap) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, SchedF<T, NL>::E> ex;
   double acc = 0.0;
-  nk_final_body<T, NL, FinalTile<T, NL, EC, COUPLES ? 2 : 1>::TILE, COUPLES, EC>(ex, p, f, blockIdx.x, (T*)smem, tw, work, &acc);
+  const int64_t blk = xmap ? nk_xcd_contig(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  nk_final_body<T, NL, FinalTile<T, NL, EC, COUPLES ? 2 : 1>::TILE, COUPLES, EC>(ex, p, f, blk, (T*)smem, tw, work, &acc);
   nk_flush_energy(f, acc, smem);
 }
 
@@ -247,7 +251,8 @@ static int nk_launch_final_c(NkPassF pf, const NkFuse& f, const C2<T>* tw, const
   pf.tiles_per_a = (COUPLES && pf.A > 1 && CT::TILE >= 2) ? (pf.M / 2 + 1 + CT::TILE / 2 - 1) / (CT::TILE / 2)
                                                : (pf.M + CT::TILE - 1) / CT::TILE;
   const int64_t blocks = (int64_t)pf.g.batch * (pf.A / 2 + 1) * pf.tiles_per_a;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CT::THREADS), CT::LDS_BYTES, st, pf, f, tw, work);
+  static const int xmap_env = nk_env_int("NK_XMAP", NK_XMAP_DEFAULT);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CT::THREADS), CT::LDS_BYTES, st, pf, f, tw, work, xmap_env & 4);
   return nk_check_launch("k2_final");
 }
 
@@ -307,7 +312,9 @@ static int nk_launch_strided_pc(NkPassS ps, const NkFuse& f, const C2<T>* tw, C2
   ps.tl.tile = ST::TILE;
   ps.tiles_per_slab = (int)(ps.inner / ST::TILE);
   const int64_t blocks = ps.outer * ps.tiles_per_slab;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ST::THREADS), ST::LDS_BYTES, st, ps, f, tw, work, scratch);
+  static const int xmap_env = nk_env_int("NK_XMAP", NK_XMAP_DEFAULT);
+  const int xmap = MODE == 3 ? (xmap_env & 1) : (xmap_env & 2);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ST::THREADS), ST::LDS_BYTES, st, ps, f, tw, work, scratch, xmap);
   return nk_check_launch("k2_strided");
 }
 

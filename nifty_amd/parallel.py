@@ -67,7 +67,8 @@ class Comm:
 
     # -- sharded vectors: the CG state of the KL minimisation lives on 1/size of the latent vector per rank -------
     def can_shard(self, n):
-        return self.size > 1 and n % self.size == 0 and os.environ.get("NK_SHARDED_CG", "1") != "0"
+        multi = self.size > 1 or os.environ.get("NK_FORCE_COMM", "0") == "1"
+        return multi and n % self.size == 0 and os.environ.get("NK_SHARDED_CG", "1") != "0"
 
     def _native_reduce_scatter(self, device):
         """RCCL reduce_scatter_tensor is used after ONE self-check against all_reduce; gloo has no reduce-scatter
@@ -163,7 +164,8 @@ _lockstep_stack = []
 
 class lockstep:
     def __init__(self, comm):
-        self._comm = comm if (comm is not None and comm.size > 1) else None
+        force = os.environ.get("NK_FORCE_COMM", "0") == "1"
+        self._comm = comm if (comm is not None and (comm.size > 1 or force)) else None
 
     def __enter__(self):
         _lockstep_stack.append(self._comm)
@@ -203,8 +205,15 @@ def init(backend=None):
     """
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world <= 1:
+    # NK_FORCE_COMM=1: build a ONE-rank communicator anyway (and let it shard), so that every collective of the
+    # multi-rank path -- RCCL reduce-scatter / all-gather / all-reduce at full problem size, lockstep broadcasts --
+    # runs on a 1-GPU box (development smoke test; the arithmetic of >1 ranks is covered by the gloo tests)
+    force = os.environ.get("NK_FORCE_COMM", "0") == "1"
+    if world <= 1 and not force:
         return None, local_rank
+    if world <= 1:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
