@@ -327,31 +327,46 @@ NK_HD C2<T> nk_prologue_pair(const NkFuse& f, int64_t i) {
 // compile-time specialised pair prologues of the hot configurations (no run-time switch in the load loop):
 //   PC = 0 plain, 1 afield*in, 2 afield*in + dampT[pidx]*in2, 3 afield*in + dafield*in2, 6 in*in2,
 //   else generic run-time version
+// Element base[iu + it] as a V, with the address split into a wave-uniform 64-bit part (scalar registers) and a
+// 32-bit per-thread BYTE offset: compiles to the scalar-base + VGPR-offset form of global_load / global_store (ONE
+// address VGPR per access instead of a 64-bit pair -- 32 accesses in flight otherwise cost 64 VGPRs).  The drivers
+// guarantee it * sizeof(T) < 2^32.
+template <typename V, typename T>
+NK_HD const V& nk_at32(const T* base, int64_t iu, uint32_t it) {
+  const char* b = reinterpret_cast<const char*>(base + iu);
+  return *reinterpret_cast<const V*>(b + (uint32_t)(it * (uint32_t)sizeof(T)));
+}
+template <typename V, typename T>
+NK_HD V* nk_ptr32(T* base, int64_t iu, uint32_t it) {
+  char* b = reinterpret_cast<char*>(base + iu);
+  return reinterpret_cast<V*>(b + (uint32_t)(it * (uint32_t)sizeof(T)));
+}
+
 // iu: wave-uniform part of the flat index (scalar registers), it: per-thread part (32 bit)
 template <typename T, int PC>
 NK_HD C2<T> nk_prologue_ct(const NkFuse& f, int64_t iu, uint32_t it) {
   if constexpr (PC == 0) {
-    return *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
+    return nk_at32<C2<T>>((const T*)f.in, iu, it);
   } else if constexpr (PC == 1) {
-    const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
-    const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + iu + it);
+    const C2<T> a = nk_at32<C2<T>>((const T*)f.in, iu, it);
+    const C2<T> m = nk_at32<C2<T>>((const T*)f.afield, iu, it);
     return C2<T>{m.x * a.x, m.y * a.y};
   } else if constexpr (PC == 2) {
-    const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
-    const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + iu + it);
-    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
-    const int2 p = *reinterpret_cast<const int2*>(f.pidx + iu + it);
+    const C2<T> a = nk_at32<C2<T>>((const T*)f.in, iu, it);
+    const C2<T> m = nk_at32<C2<T>>((const T*)f.afield, iu, it);
+    const C2<T> x = nk_at32<C2<T>>((const T*)f.in2, iu, it);
+    const int2 p = nk_at32<int2>(f.pidx, iu, it);
     const T* dt = (const T*)f.dampT;
     return C2<T>{m.x * a.x + dt[p.x] * x.x, m.y * a.y + dt[p.y] * x.y};
   } else if constexpr (PC == 3) {
-    const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
-    const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + iu + it);
-    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
-    const C2<T> dm = *reinterpret_cast<const C2<T>*>((const T*)f.dafield + iu + it);
+    const C2<T> a = nk_at32<C2<T>>((const T*)f.in, iu, it);
+    const C2<T> m = nk_at32<C2<T>>((const T*)f.afield, iu, it);
+    const C2<T> x = nk_at32<C2<T>>((const T*)f.in2, iu, it);
+    const C2<T> dm = nk_at32<C2<T>>((const T*)f.dafield, iu, it);
     return C2<T>{m.x * a.x + dm.x * x.x, m.y * a.y + dm.y * x.y};
   } else if constexpr (PC == 6) {  // MUL: in * in2
-    const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
-    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
+    const C2<T> a = nk_at32<C2<T>>((const T*)f.in, iu, it);
+    const C2<T> x = nk_at32<C2<T>>((const T*)f.in2, iu, it);
     return C2<T>{a.x * x.x, a.y * x.y};
   } else {
     return C2<T>{nk_prologue<T>(f, iu + it), nk_prologue<T>(f, iu + it + 1)};

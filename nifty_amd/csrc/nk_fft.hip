@@ -220,7 +220,9 @@ __global__ void __launch_bounds__((StridedTile<T, N>::THREADS),
   // the octant prologues bring their own XCD-aware order (nk_oct_block_remap)
   constexpr bool OCT = MODE == 3 && (PC == 4 || PC == 5);
   const int64_t blk = (xmap && !OCT) ? nk_xcd_contig(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
-  nk_strided_body<T, N, StridedTile<T, N>::TILE, MODE, PC>(ex, p, f, blk, (T*)smem, tw, work, scratch, &acc);
+  using ST = StridedTile<T, N, nk_strided_cx<MODE, PC>()>;
+  C2<T>* tw_lds = ST::TWLDS ? reinterpret_cast<C2<T>*>(smem + ST::LDS_BYTES) : nullptr;
+  nk_strided_body<T, N, ST::TILE, MODE, PC, nk_strided_cx<MODE, PC>()>(ex, p, f, blk, (T*)smem, tw, work, scratch, &acc, tw_lds);
   (void)acc;
 }
 
@@ -302,11 +304,11 @@ static int nk_launch_contig(const NkPassA& pa, const NkFuse& f, const C2<T>* tw,
 
 template <typename T, int N, int MODE, int PC>
 static int nk_launch_strided_pc(NkPassS ps, const NkFuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch, hipStream_t st) {
-  using ST = StridedTile<T, N>;
+  using ST = StridedTile<T, N, nk_strided_cx<MODE, PC>()>;
   auto kern = k2_strided<T, N, MODE, PC>;
   static unsigned long long attr_mask = 0;  // per-device attribute
-  if (ST::LDS_BYTES > 64 * 1024 && nk_first_on_device(attr_mask)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ST::LDS_BYTES);
+  if (ST::LDS_TOTAL > 64 * 1024 && nk_first_on_device(attr_mask)) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ST::LDS_TOTAL);
     if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k2_strided)");
   }
   ps.tl.tile = ST::TILE;
@@ -314,7 +316,7 @@ static int nk_launch_strided_pc(NkPassS ps, const NkFuse& f, const C2<T>* tw, C2
   const int64_t blocks = ps.outer * ps.tiles_per_slab;
   static const int xmap_env = nk_env_int("NK_XMAP", NK_XMAP_DEFAULT);
   const int xmap = MODE == 3 ? (xmap_env & 1) : (xmap_env & 2);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ST::THREADS), ST::LDS_BYTES, st, ps, f, tw, work, scratch, xmap);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ST::THREADS), ST::LDS_TOTAL, st, ps, f, tw, work, scratch, xmap);
   return nk_check_launch("k2_strided");
 }
 
@@ -650,7 +652,8 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
     // per-thread address parts are 32-bit: (threads per line) * (row stride) must stay below 2^31 elements
     {
       const int64_t smax = q.s1.ss > q.s0.inner ? q.s1.ss : q.s0.inner;
-      if (128 * (smax > q.s1.inner ? smax : q.s1.inner) >= ((int64_t)1 << 31))
+      // ... and the per-thread BYTE offsets (nk_at32) below 2^32
+      if (128 * (smax > q.s1.inner ? smax : q.s1.inner) * (int64_t)sizeof(C2<T>) >= ((int64_t)1 << 32))
         return nk_set_error(NK_ERR_UNSUPPORTED, "transform too large for the 32-bit thread offsets of the strided passes");
     }
     if (hp.g.ndim == 3) {

@@ -177,7 +177,12 @@ struct ContigLayout {
 
 // tile choices of the fast path ------------------------------------------------------------------
 // strided passes: rows of 128 B when the thread count (P*TILE <= 1024) and the LDS plane (<= 128 KiB) allow
-template <typename T, int N>
+// CX: the light first-pass classes exchange through ONE complex plane and read their twiddles from LDS (see below)
+template <int MODE, int PC>
+constexpr bool nk_strided_cx() {
+  return MODE == 3 && (PC == 0 || PC == 1 || PC == 6);
+}
+template <typename T, int N, bool CX = false>
 struct StridedTile {
   static constexpr int P = Sched<T, N>::P;
   static constexpr int want = 128 / (2 * (int)sizeof(T));
@@ -186,7 +191,22 @@ struct StridedTile {
   static constexpr int m1 = want < by_threads ? want : by_threads;
   static constexpr int TILE = m1 < by_lds ? m1 : by_lds;
   static constexpr int THREADS = P * TILE;
-  static constexpr int LDS_BYTES = N * TILE * (int)sizeof(T);
+  // CPLX: exchange through ONE complex plane -- a single write + read round per stage boundary with 8-byte LDS
+  // accesses (half the LDS instructions, one barrier instead of three, no tmp registers) -- where the workgroup is
+  // alone on its CU anyway: the fp32 radix-32 kernels at 512 threads need 130-170 VGPRs.  Otherwise two half rounds
+  // through one scalar plane (half the LDS: two workgroups per CU, the fp64 kernels).  Measured at 1024^3 fp32
+  // (gpurun_out/r02c_probe.log): plain first pass 1.84 -> 1.76 ms; the in-place pass (1.95 -> 2.00 ms) and the
+  // register-heavy JVP prologues (they spill with the complex plane: 3.3 -> 5.7 ms) keep the split exchange -> CX.
+  static constexpr bool CPLX = CX && sizeof(T) == 4 && Sched<T, N>::E == 32 && P * TILE == 512 && N * TILE * 8 <= 128 * 1024;
+  static constexpr int LDS_BYTES = N * TILE * (int)sizeof(T) * (CPLX ? 2 : 1);
+  // TWLDS: the workgroup copies the axis' twiddle table (N complex) behind the exchange plane once and the stages read
+  // it with ds_read instead of global loads.  The ~R twiddle loads per thread and stage are vector-memory instructions
+  // with four distinct addresses per wave: they queue in the same address / L1 pipeline as the tile's own loads and
+  // stores (tile copy with the pass's access pattern, tools/micro/copy_bench.hip: 5.81 TB/s, 5.33 with 31 such loads
+  // per thread, 4.93 with the LDS exchange on top -- the measured speed of the pass).
+  static constexpr int TW_BYTES = N * 2 * (int)sizeof(T);
+  static constexpr bool TWLDS = CPLX && (LDS_BYTES + TW_BYTES) < 160 * 1024 && TW_BYTES % 1024 == 0;
+  static constexpr int LDS_TOTAL = LDS_BYTES + (TWLDS ? TW_BYTES : 0);
 };
 // contiguous pass: ~256 threads, both planes within 48 KiB
 template <typename T, int H>
@@ -337,6 +357,24 @@ NK_HD void nk_xread_cols(T* dst, const T* plane, int pp, int t) {
     for (int r = 0; r < R; ++r) dst[q * R + r] = plane[nk_xrow<TILE, L0>(nk_in_row<SC, S>(pp, q, r), t)];
 }
 
+// the same exchange through a complex plane (StridedTile::CPLX): 8-byte accesses, rows of TILE * 8 bytes
+template <typename T, typename SC, int S, int TILE>
+NK_HD void nk_xwrite_c2(const C2<T>* v, C2<T>* plane, int pp, int t) {
+  constexpr int R = SC::radix(S), Q = SC::E / R, L0 = nk_ilog2(SC::R0);
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+#pragma unroll
+    for (int r = 0; r < R; ++r) plane[nk_xrow<TILE, L0>(nk_out_row<SC, S>(pp, q, r), t)] = v[q * R + r];
+}
+template <typename T, typename SC, int S, int TILE>
+NK_HD void nk_xread_c2(C2<T>* dst, const C2<T>* plane, int pp, int t) {
+  constexpr int R = SC::radix(S), Q = SC::E / R, L0 = nk_ilog2(SC::R0);
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+#pragma unroll
+    for (int r = 0; r < R; ++r) dst[q * R + r] = plane[nk_xrow<TILE, L0>(nk_in_row<SC, S>(pp, q, r), t)];
+}
+
 // XCD-aware block order of the first pass with OCTANT amplitude fields (3-D): the slabs a and A-a and, inside a
 // slab, the tiles c and NL-c read the same octant lines.  Workgroups are dealt round-robin to the 8 XCDs
 // (blockIdx % 8), each XCD keeps 2 * 32 of them in flight -- so every XCD is handed whole slab PAIRS (a, A-a),
@@ -365,6 +403,23 @@ NK_HD int64_t nk_oct_block_remap(int64_t v, const NkPassS& p) {
   return bat * per + slab * tiles + tile;
 }
 
+// Twiddle table -> LDS without touching a VGPR: global_load_lds_dwordx4 moves 16 bytes per lane straight into LDS
+// (wave w of the workgroup deposits 1 KiB per instruction at the wave-uniform LDS address base + offset); the
+// workgroup barrier that follows waits for it (vmcnt) and publishes it.  Table sizes are multiples of 1 KiB
+// (StridedTile::TWLDS).
+template <typename T>
+NK_HD void nk_tw_to_lds(const C2<T>* __restrict__ tw_global, C2<T>* tw_lds, int n, int tid, int nthreads) {
+#ifndef NK_HOST_EMU
+  const int bytes = n * (int)sizeof(C2<T>);
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int off = wave * 1024; off < bytes; off += (nthreads >> 6) * 1024)
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(tw_global) + off + lane * 16,
+                                     (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(tw_lds) + off), 16, 0, 0);
+#else
+  for (int i = tid; i < n; i += nthreads) tw_lds[i] = tw_global[i];
+#endif
+}
+
 // XCD-contiguous block order: hardware deals workgroup b to XCD b % 8 (observed, MI355X_MICROARCH.md); with this
 // remap the workgroups of one XCD take a CONTIGUOUS range of work items, so the tiles that share a 4 KiB row of the
 // array (adjacent 128 B pieces) meet in one XCD's L2 / TLB instead of being spread over all eight.  A pure copy with
@@ -387,12 +442,16 @@ NK_HD int64_t nk_xcd_contig(int64_t blk, int64_t nb) {
 // MODE 3: FIRST pass of the strided-first pipeline: the real input (through the fused prologue) is read as
 //         complex pairs along the contiguous axis, transformed along this strided axis and written to `work`
 // MODE 0: plain in-place c2c
-template <typename T, int N, int TILE, int MODE, int PC, typename Exec>
+template <typename T, int N, int TILE, int MODE, int PC, bool CX = false, typename Exec>
 NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t blk, T* plane,
-                           const C2<T>* __restrict__ tw, C2<T>* __restrict__ work, C2<T>* __restrict__ scratch,
-                           double* acc_out) {
+                           const C2<T>* __restrict__ tw_global, C2<T>* __restrict__ work, C2<T>* __restrict__ scratch,
+                           double* acc_out, C2<T>* tw_lds = nullptr) {
   using SC = Sched<T, N>;
   constexpr int E = SC::E, S = SC::S;
+  constexpr bool CPLX = StridedTile<T, N, CX>::CPLX && TILE == StridedTile<T, N, CX>::TILE;
+  // twiddles of the later stages: from the workgroup's LDS copy when the caller provides the room (StridedTile::TWLDS)
+  const C2<T>* tw = tw_lds ? tw_lds : tw_global;
+  [[maybe_unused]] C2<T>* cplane = reinterpret_cast<C2<T>*>(plane);
   if constexpr (MODE == 3 && (PC == 4 || PC == 5)) blk = nk_oct_block_remap(blk, p);
   const int64_t o = blk / p.tiles_per_slab;
   const int64_t c0 = (blk % p.tiles_per_slab) * (int64_t)TILE;
@@ -442,37 +501,17 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
         } else if (MODE == 3) {
           rg.v[q * R + r] = nk_prologue_ct<T, PC>(f, 2 * (in_off + uoff), 2 * toff);
         } else {
-          rg.v[q * R + r] = (base + uoff)[toff];
+          rg.v[q * R + r] = nk_at32<C2<T>>(base, uoff, toff);
         }
       }
+    if (tw_lds) nk_tw_to_lds<T>(tw_global, tw_lds, N, tid, SC::P * TILE);  // published by this phase's barrier
     nk_stage_compute<T, SC, 0>(rg.v, pp, tw);
-    nk_xwrite_cols<T, SC, 0, TILE, 0>(rg.v, plane, pp, t);
+    if constexpr (CPLX)
+      nk_xwrite_c2<T, SC, 0, TILE>(rg.v, cplane, pp, t);
+    else
+      nk_xwrite_cols<T, SC, 0, TILE, 0>(rg.v, plane, pp, t);
   });
-  // exchange 0 -> stage 1
-  ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xread_cols<T, SC, 1, TILE>(rg.tmp, plane, tid / TILE, tid % TILE); });
-  ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xwrite_cols<T, SC, 0, TILE, 1>(rg.v, plane, tid / TILE, tid % TILE); });
-  ex.phase([&](int tid, PassRegs<T, E>& rg) {
-    const int t = tid % TILE, pp = tid / TILE;
-    T im[E];
-    nk_xread_cols<T, SC, 1, TILE>(im, plane, pp, t);
-#pragma unroll
-    for (int e = 0; e < E; ++e) rg.v[e] = C2<T>{rg.tmp[e], im[e]};
-    nk_stage_compute<T, SC, 1>(rg.v, pp, tw);
-  });
-  if constexpr (S == 3) {
-    ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xwrite_cols<T, SC, 1, TILE, 0>(rg.v, plane, tid / TILE, tid % TILE); });
-    ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xread_cols<T, SC, 2, TILE>(rg.tmp, plane, tid / TILE, tid % TILE); });
-    ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xwrite_cols<T, SC, 1, TILE, 1>(rg.v, plane, tid / TILE, tid % TILE); });
-    ex.phase([&](int tid, PassRegs<T, E>& rg) {
-      const int t = tid % TILE, pp = tid / TILE;
-      T im[E];
-      nk_xread_cols<T, SC, 2, TILE>(im, plane, pp, t);
-#pragma unroll
-      for (int e = 0; e < E; ++e) rg.v[e] = C2<T>{rg.tmp[e], im[e]};
-      nk_stage_compute<T, SC, 2>(rg.v, pp, tw);
-    });
-  }
-  ex.last_phase([&](int tid, PassRegs<T, E>& rg) {
+  auto store_tile = [&](int tid, PassRegs<T, E>& rg) {
     const int t = tid % TILE, pp = tid / TILE;
     constexpr int LS = S - 1;
     constexpr int R = SC::radix(LS), Q = E / R;
@@ -495,8 +534,65 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
-      for (int r = 0; r < R; ++r) nk_store_stream((obase + (int64_t)nk_out_row<SC, LS>(0, q, r) * ostride) + toff, rg.v[q * R + r]);
-  });
+      for (int r = 0; r < R; ++r) {
+        const int64_t uo = (int64_t)nk_out_row<SC, LS>(0, q, r) * ostride;
+        if constexpr (S == 2)  // thread part = pp * ostride + t (small): 32-bit byte offset from a scalar base
+          nk_store_stream(nk_ptr32<C2<T>>(obase, uo, toff), rg.v[q * R + r]);
+        else
+          nk_store_stream((obase + uo) + toff, rg.v[q * R + r]);
+      }
+  };
+  if constexpr (CPLX) {
+    // one round per stage boundary; the last stage's butterflies and the stores share the final phase (no barrier)
+    if constexpr (S == 3) {
+      ex.phase([&](int tid, PassRegs<T, E>& rg) {
+        nk_xread_c2<T, SC, 1, TILE>(rg.v, cplane, tid / TILE, tid % TILE);
+        nk_stage_compute<T, SC, 1>(rg.v, tid / TILE, tw);
+      });
+      ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xwrite_c2<T, SC, 1, TILE>(rg.v, cplane, tid / TILE, tid % TILE); });
+    }
+    ex.last_phase([&](int tid, PassRegs<T, E>& rg) {
+      nk_xread_c2<T, SC, S - 1, TILE>(rg.v, cplane, tid / TILE, tid % TILE);
+      nk_stage_compute<T, SC, S - 1>(rg.v, tid / TILE, tw);
+      store_tile(tid, rg);
+    });
+    return;
+  }
+  // exchange 0 -> stage 1 (split: real parts, then imaginary parts through the same scalar plane)
+  ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xread_cols<T, SC, 1, TILE>(rg.tmp, plane, tid / TILE, tid % TILE); });
+  ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xwrite_cols<T, SC, 0, TILE, 1>(rg.v, plane, tid / TILE, tid % TILE); });
+  if constexpr (S == 2) {
+    ex.last_phase([&](int tid, PassRegs<T, E>& rg) {
+      const int t = tid % TILE, pp = tid / TILE;
+      T im[E];
+      nk_xread_cols<T, SC, 1, TILE>(im, plane, pp, t);
+#pragma unroll
+      for (int e = 0; e < E; ++e) rg.v[e] = C2<T>{rg.tmp[e], im[e]};
+      nk_stage_compute<T, SC, 1>(rg.v, pp, tw);
+      store_tile(tid, rg);
+    });
+  } else {
+    ex.phase([&](int tid, PassRegs<T, E>& rg) {
+      const int t = tid % TILE, pp = tid / TILE;
+      T im[E];
+      nk_xread_cols<T, SC, 1, TILE>(im, plane, pp, t);
+#pragma unroll
+      for (int e = 0; e < E; ++e) rg.v[e] = C2<T>{rg.tmp[e], im[e]};
+      nk_stage_compute<T, SC, 1>(rg.v, pp, tw);
+    });
+    ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xwrite_cols<T, SC, 1, TILE, 0>(rg.v, plane, tid / TILE, tid % TILE); });
+    ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xread_cols<T, SC, 2, TILE>(rg.tmp, plane, tid / TILE, tid % TILE); });
+    ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xwrite_cols<T, SC, 1, TILE, 1>(rg.v, plane, tid / TILE, tid % TILE); });
+    ex.last_phase([&](int tid, PassRegs<T, E>& rg) {
+      const int t = tid % TILE, pp = tid / TILE;
+      T im[E];
+      nk_xread_cols<T, SC, 2, TILE>(im, plane, pp, t);
+#pragma unroll
+      for (int e = 0; e < E; ++e) rg.v[e] = C2<T>{rg.tmp[e], im[e]};
+      nk_stage_compute<T, SC, 2>(rg.v, pp, tw);
+      store_tile(tid, rg);
+    });
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

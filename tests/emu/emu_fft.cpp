@@ -100,16 +100,16 @@ static void emu2_strided(NkPassS p, int mode, const nk_fuse& f, const C2<T>* tw,
   using ST = StridedTile<T, N>;
   p.tl.tile = ST::TILE;
   p.tiles_per_slab = (int)(p.inner / ST::TILE);
-  std::vector<T> plane(N * ST::TILE);
+  std::vector<T> plane(StridedTile<T, N, true>::LDS_BYTES / sizeof(T));  // room for the complex-plane classes
   const int64_t blocks = p.outer * p.tiles_per_slab;
   for (int64_t blk = 0; blk < blocks; ++blk) {
     HostExec<T, Sched<T, N>::E> ex(ST::THREADS);
     if (mode == 3) {
       if (f.field_octant && f.pro == NK_PRO_AMP) nk_strided_body<T, N, ST::TILE, 3, 4>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
       else if (f.field_octant && f.pro == NK_PRO_AMP_JVP) nk_strided_body<T, N, ST::TILE, 3, 5>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
-      else if (f.pro == NK_PRO_PLAIN) nk_strided_body<T, N, ST::TILE, 3, 0>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
-      else if (f.pro == NK_PRO_MUL) nk_strided_body<T, N, ST::TILE, 3, 6>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
-      else if (f.pro == NK_PRO_AMP && f.afield) nk_strided_body<T, N, ST::TILE, 3, 1>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+      else if (f.pro == NK_PRO_PLAIN) nk_strided_body<T, N, ST::TILE, 3, 0, true>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+      else if (f.pro == NK_PRO_MUL) nk_strided_body<T, N, ST::TILE, 3, 6, true>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+      else if (f.pro == NK_PRO_AMP && f.afield) nk_strided_body<T, N, ST::TILE, 3, 1, true>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
       else if (f.pro == NK_PRO_AMP_JVP && f.afield && f.dafield) nk_strided_body<T, N, ST::TILE, 3, 3>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
       else if (f.pro == NK_PRO_AMP_JVP && f.afield && f.dampT) nk_strided_body<T, N, ST::TILE, 3, 2>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
       else nk_strided_body<T, N, ST::TILE, 3, -1>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);

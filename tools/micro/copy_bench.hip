@@ -105,6 +105,77 @@ __global__ void __launch_bounds__(128) k_pair(const f4* __restrict__ a, f4* __re
   b[l0 + threadIdx.x] = v[0]; b[l0 + 128 + threadIdx.x] = v[1]; b[l1 + threadIdx.x] = v[2]; b[l1 + 128 + threadIdx.x] = v[3];
 }
 
+// V7: tile copy with a fake compute phase (SPIN dependent FMAs per element + 4 barriers) between load and store --
+// the shape of an FFT pass.  PERSIST: one workgroup per CU walks its tiles; PREF: the next tile is fetched into
+// registers while the current one "computes".
+template <int SPIN, int PERSIST, int PREF, int XMAP, int TW = 0, int LDSX = 0>
+__global__ void __launch_bounds__(512) k_fft_like(const f2* __restrict__ a, f2* __restrict__ b, size_t rstride, size_t slab_stride,
+                                                   int tiles_per_row, unsigned nblocks, const f2* __restrict__ table = nullptr) {
+  extern __shared__ float lds[];
+  const int t = threadIdx.x % 16, pp = threadIdx.x / 16;
+  auto off_of = [&](unsigned blk) {
+    const int ct = blk % tiles_per_row;
+    const size_t o = blk / tiles_per_row;
+    return o * slab_stride + (size_t)ct * 16 + t + (size_t)pp * rstride;
+  };
+  auto tile_of = [&](unsigned j, unsigned& blk) {  // j-th tile of this workgroup
+    if (!PERSIST) { blk = XMAP ? (blockIdx.x % 8) * (nblocks / 8) + blockIdx.x / 8 : blockIdx.x; return j == 0; }
+    if (XMAP) { const unsigned q = nblocks / 8, x = blockIdx.x % 8, i = blockIdx.x / 8 + j * (gridDim.x / 8); blk = x * q + i; return i < q; }
+    blk = blockIdx.x + j * gridDim.x; return blk < nblocks;
+  };
+  f2 v[32], nx[32];
+  unsigned blk, nblk_;
+  if (!tile_of(0, blk)) return;
+  size_t off = off_of(blk);
+#pragma unroll
+  for (int r = 0; r < 32; ++r) (PREF ? nx[r] : v[r]) = a[off + (size_t)(32 * r) * rstride];
+  for (unsigned j = 0;; ++j) {
+    if (PREF) {
+#pragma unroll
+      for (int r = 0; r < 32; ++r) v[r] = nx[r];
+    }
+    // "stage 0"
+#pragma unroll
+    for (int r = 0; r < 32; ++r)
+      for (int k = 0; k < SPIN / 2; ++k) v[r].x = v[r].x * 1.0001f + v[(r + 1) & 31].y * 1e-9f;
+    const bool more = tile_of(j + 1, nblk_);
+    if (PREF && more) {
+      const size_t no = off_of(nblk_);
+#pragma unroll
+      for (int r = 0; r < 32; ++r) nx[r] = a[no + (size_t)(32 * r) * rstride];
+    }
+    lds[threadIdx.x] = v[0].x; __syncthreads(); v[1].y += lds[(threadIdx.x + 17) & 511] * 1e-9f; __syncthreads();
+    lds[threadIdx.x] = v[2].x; __syncthreads(); v[3].y += lds[(threadIdx.x + 33) & 511] * 1e-9f; __syncthreads();
+    if (TW) {  // twiddle-like loads: per thread TW table entries, 4 distinct addresses per wave
+#pragma unroll
+      for (int r = 1; r <= TW; ++r) { const f2 w = table[((pp & 31) * r) & 1023]; v[r & 31].x = v[r & 31].x * w.x - v[r & 31].y * w.y; }
+    }
+    if (LDSX) {  // full LDS exchange like the FFT: 32 b32 writes + reads, twice
+      float* pl = lds + 512;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) pl[(32 * pp + r) * 16 + t] = h ? v[r].y : v[r].x;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 32; ++r) { const float x = pl[(pp + 32 * r) * 16 + t]; if (h) v[r].y = x; else v[r].x = x; }
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r)
+      for (int k = 0; k < SPIN / 2; ++k) v[r].y = v[r].y * 1.0001f + v[(r + 1) & 31].x * 1e-9f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) b[off + (size_t)(32 * r) * rstride] = v[r];
+    if (!more) break;
+    off = off_of(nblk_);
+    if (!PREF) {
+#pragma unroll
+      for (int r = 0; r < 32; ++r) v[r] = a[off + (size_t)(32 * r) * rstride];
+    }
+  }
+}
+
 template <typename F>
 static void timed(const char* tag, double bytes, F fn, int reps = 10) {
   fn();
@@ -163,6 +234,46 @@ int main(int argc, char** argv) {
     snprintf(tag, 96, "mid-axis tile %d x %d B rows, xmap %d", ROWS, TW * 8, XM);                              \
     timed(tag, B2, [&] { hipLaunchKernelGGL((k_tile2<TW, ROWS, XM>), dim3(nb), dim3(512), 0, 0, (const f2*)a, (f2*)b, rs, ss, tpr, rbs, nb); }); \
   }
+#define TILE4(TW, ROWS, XM)                                                                                     \
+  {                                                                                                             \
+    const int tpr = 512 * 1024 / TW, rbs = 1024 / ROWS;                                                         \
+    const unsigned nb = (unsigned)tpr * rbs;                                                                    \
+    char tag[96];                                                                                               \
+    snprintf(tag, 96, "first-axis PADDED tile %d x %d B rows, xmap %d", ROWS, TW * 8, XM);                     \
+    timed(tag, B2, [&] { hipLaunchKernelGGL((k_tile2<TW, ROWS, XM>), dim3(nb), dim3(512), 0, 0, (const f2*)a2, (f2*)b2, (size_t)512 * 1024 + 2080, (size_t)0, tpr, rbs, nb); }); \
+  }
+    float *a2, *b2;
+    CK(hipMalloc(&a2, n * 4 + 1024 * 2080 * 8)); CK(hipMalloc(&b2, n * 4 + 1024 * 2080 * 8));
+    CK(hipMemset(a2, 1, n * 4));
+    {
+      const int tpr = 32; const unsigned nb = 1024u * tpr;
+#define FFTL(SPIN, PERS, PREF, XM, LDSK, PADDED)                                                                  \
+  {                                                                                                               \
+    auto k = k_fft_like<SPIN, PERS, PREF, XM>;                                                                    \
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDSK * 1024));            \
+    char tag[128];                                                                                                \
+    snprintf(tag, 128, "fft-like %s spin %d persist %d prefetch %d xmap %d LDS %dK", PADDED ? "first-axis" : "mid-axis", SPIN, PERS, PREF, XM, LDSK); \
+    const unsigned grid = PERS ? 256 : nb;                                                                        \
+    if (PADDED) timed(tag, B2, [&] { hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDSK * 1024, 0, (const f2*)a2, (f2*)b2, (size_t)512 * 1024 + 2080, (size_t)0, 512 * 1024 / 16, nb, (const f2*)nullptr); }); \
+    else timed(tag, B2, [&] { hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDSK * 1024, 0, (const f2*)a, (f2*)b, rs, ss, tpr, nb, (const f2*)nullptr); }); \
+  }
+      {
+        f2* tab; CK(hipMalloc(&tab, 1024 * 8)); CK(hipMemset(tab, 0, 1024 * 8));
+#define FFTT(SPIN, XM, TWN, LX)                                                                                   \
+  {                                                                                                               \
+    auto k = k_fft_like<SPIN, 0, 0, XM, TWN, LX>;                                                                 \
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));             \
+    char tag[128];                                                                                                \
+    snprintf(tag, 128, "fft-like mid-axis spin %d xmap %d twiddle loads %d lds-exchange %d", SPIN, XM, TWN, LX);   \
+    timed(tag, B2, [&] { hipLaunchKernelGGL(k, dim3(nb), dim3(512), 128 * 1024, 0, (const f2*)a, (f2*)b, rs, ss, tpr, nb, (const f2*)tab); }); \
+  }
+        FFTT(20, 1, 0, 0) FFTT(20, 1, 31, 0) FFTT(20, 1, 0, 1) FFTT(20, 1, 31, 1) FFTT(20, 0, 31, 1) FFTT(40, 1, 31, 1) FFTT(0, 1, 31, 1) FFTT(0, 1, 0, 1) FFTT(0, 1, 31, 0)
+      }
+      FFTL(0, 0, 0, 0, 128, 0) FFTL(20, 0, 0, 0, 128, 0) FFTL(20, 0, 0, 1, 128, 0) FFTL(20, 0, 0, 0, 64, 0) FFTL(20, 0, 0, 1, 64, 0)
+      FFTL(20, 1, 0, 0, 128, 0) FFTL(20, 1, 1, 0, 128, 0) FFTL(20, 1, 1, 1, 128, 0) FFTL(0, 1, 1, 1, 128, 0)
+      FFTL(40, 0, 0, 0, 128, 0) FFTL(40, 1, 1, 1, 128, 0) FFTL(40, 0, 0, 1, 64, 0)
+      FFTL(20, 0, 0, 0, 128, 1) FFTL(20, 0, 0, 0, 64, 1) FFTL(20, 1, 1, 0, 128, 1) FFTL(20, 1, 1, 1, 128, 1) FFTL(40, 0, 0, 0, 128, 1) FFTL(40, 1, 1, 0, 128, 1)
+    }
     // occupancy: the same copy with a dynamic LDS allocation that admits 4 / 2 / 1 workgroups per CU
     for (int kib : {0, 40, 64, 128}) for (int xm : {0, 1}) {
       const int tpr = 512 / 16; const unsigned nb = 1024u * tpr;
@@ -174,6 +285,7 @@ int main(int argc, char** argv) {
       if (xm) timed(tag, B2, [&] { hipLaunchKernelGGL((k_tile2<16, 1024, 1>), dim3(nb), dim3(512), kib * 1024, 0, (const f2*)a, (f2*)b, rs, ss, tpr, 1, nb); });
       else timed(tag, B2, [&] { hipLaunchKernelGGL((k_tile2<16, 1024, 0>), dim3(nb), dim3(512), kib * 1024, 0, (const f2*)a, (f2*)b, rs, ss, tpr, 1, nb); });
     }
+    TILE2(8, 1024, 0) TILE2(8, 1024, 1) TILE4(8, 1024, 0) TILE4(8, 1024, 1)
     TILE2(16, 1024, 0) TILE2(16, 1024, 1) TILE2(32, 512, 0) TILE2(32, 512, 1) TILE2(64, 256, 0) TILE2(64, 256, 1)
     TILE2(128, 128, 0) TILE2(512, 32, 0) TILE2(16, 256, 0) TILE2(16, 256, 1)
     // first-axis pattern: rows are whole slabs apart (4 MiB), "slab" index = (b, c-tile)
@@ -187,17 +299,6 @@ int main(int argc, char** argv) {
   }
     TILE3(16, 1024, 0) TILE3(16, 1024, 1) TILE3(32, 512, 0) TILE3(64, 256, 0) TILE3(16, 256, 0)
     // with the padded slab stride of the real work array (2080 complex elements)
-#define TILE4(TW, ROWS, XM)                                                                                     \
-  {                                                                                                             \
-    const int tpr = 512 * 1024 / TW, rbs = 1024 / ROWS;                                                         \
-    const unsigned nb = (unsigned)tpr * rbs;                                                                    \
-    char tag[96];                                                                                               \
-    snprintf(tag, 96, "first-axis PADDED tile %d x %d B rows, xmap %d", ROWS, TW * 8, XM);                     \
-    timed(tag, B2, [&] { hipLaunchKernelGGL((k_tile2<TW, ROWS, XM>), dim3(nb), dim3(512), 0, 0, (const f2*)a2, (f2*)b2, (size_t)512 * 1024 + 2080, (size_t)0, tpr, rbs, nb); }); \
-  }
-    float *a2, *b2;
-    CK(hipMalloc(&a2, n * 4 + 1024 * 2080 * 8)); CK(hipMalloc(&b2, n * 4 + 1024 * 2080 * 8));
-    CK(hipMemset(a2, 1, n * 4));
     TILE4(16, 1024, 0) TILE4(16, 1024, 1) TILE4(32, 512, 0) TILE4(32, 512, 1) TILE4(64, 256, 0)
     {
       const unsigned nb = 512u * 512u;  // half of the (a, b) pairs: every line exactly once except self-paired ones
