@@ -35,7 +35,12 @@ from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG  # noqa: E
 
 PMC_TRAFFIC_FILE = "r01k_pmc_traffic.json"  # latest committed PMC summary of the bench command
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-KERNEL_NAMES = {0: "k_pass1d", 1: "k_passA", 2: "k_passB", 3: "k_passC", 4: "k_passD"}
+# transform pass kernels by profile id: strided-first pipeline (A first strided pass with prologue, B in-place strided
+# pass, C final contiguous pass with epilogue) and the five-pass sandwich H D H of a metric application (S1 contiguous
+# first pass with prologue, S2 in-place middle-axis passes, SM fused first-axis pass, then C)
+KERNEL_NAMES = {0: "k_pass1d", 1: "k_passA", 2: "k_passB", 3: "k_passC", 4: "k_passD", 5: "k_passS1", 6: "k_passS2",
+                7: "k_passSM"}
+NK_PROF_KEYS = 200
 PRO_NAMES = {0: "plain", 1: "amp", 2: "amp_jvp", 3: "mul"}
 EPI_NAMES = {0: "affine", 1: "mul", 2: "vjp", 3: "likelihood", 4: "nonlin"}
 
@@ -50,7 +55,9 @@ def algorithmic_bytes(kernel, pro, epi, N, b, const_mid):
     if kernel == 4:  # pass D touches 2 planes only
         return 0.0
     total = 2.0 * N * b
-    if kernel in (0, 1):
+    if kernel == 7 and not const_mid:  # the diagonal between the two transforms of a sandwich
+        total += N * b
+    if kernel in (0, 1, 5):
         total += {0: 0, 1: 4 * N, 2: N * b + 4 * N, 3: N * b}[pro]
     if kernel in (0, 3):
         total += {0: 0, 1: 0 if const_mid else N * b, 2: N * b + 4 * N, 3: N * b + (0 if const_mid else N * b),
@@ -60,11 +67,11 @@ def algorithmic_bytes(kernel, pro, epi, N, b, const_mid):
 
 def collect_profile():
     lib = L.load()
-    ms = (ctypes.c_double * 125)()
-    cnt = (ctypes.c_int64 * 125)()
+    ms = (ctypes.c_double * NK_PROF_KEYS)()
+    cnt = (ctypes.c_int64 * NK_PROF_KEYS)()
     lib.nk_profile_collect(ms, cnt)
     out = {}
-    for key in range(125):
+    for key in range(NK_PROF_KEYS):
         if cnt[key]:
             out[(key // 25, (key % 25) // 5, key % 5)] = (ms[key], cnt[key])
     return out

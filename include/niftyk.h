@@ -117,6 +117,18 @@ size_t nk_plan_workspace_bytes(const nk_plan* plan);
 int nk_hartley(const nk_plan* plan, const void* in, void* out, double scale, int convention, void* workspace,
                void* stream);
 int nk_hartley_fused(const nk_plan* plan, const nk_fuse* fuse, int convention, void* workspace, void* stream);
+/* Hartley SANDWICH  H D H  of a metric application  J^T M J  (LikelihoodEnergyOperator.get_metric_at,
+ * operators/energy_operators.py:146-152: SandwichOperator.make(J, M) with J ending / J^T starting in HartleyOperator,
+ * harmonic_operators.py:144-161), as ONE call:
+ *     t1 = scale_first * Hartley(PRO(in));   x[o] = mul_scalar * (mul ? mul[o] : 1) * t1[o];
+ *     t2 = fuse->scale * Hartley(x);         EPI(t2)
+ * with the prologues / epilogues of nk_fuse (`mul` / `mul_scalar` are the diagonal between the transforms, so the MUL
+ * epilogue is not available).  Five passes over the array instead of six and no position-space intermediate: the last
+ * pass of the first transform and the first pass of the second one are one kernel (nifty_amd/csrc/nk_fft3.h).
+ * Available when nk_plan_sandwich(plan) != 0 (>= 2 axes, every axis length a power of two in 64 .. 4096). */
+int nk_plan_sandwich(const nk_plan* plan);
+int nk_hartley_sandwich(const nk_plan* plan, const nk_fuse* fuse, double scale_first, int convention, void* workspace,
+                        void* stream);
 /* complex-to-complex: in/out interleaved (re,im) of the plan dtype; inverse != 0 uses exp(+i..);
  * result is multiplied by `scale` (pass 1/N for numpy-style ifftn).  in == out allowed. */
 int nk_fftn(const nk_plan* plan, const void* in, void* out, int inverse, double scale, void* workspace,
@@ -124,8 +136,9 @@ int nk_fftn(const nk_plan* plan, const void* in, void* out, int inverse, double 
 
 /* live profiling for bench.py: when enabled every transform pass kernel launch is bracketed by HIP events on
  * its launch stream; nk_profile_collect synchronises and returns summed milliseconds and launch counts in
- * ms[125] / count[125], index = kernel*25 + prologue*5 + epilogue (kernel: 0 pass1d, 1 passA, 2 passB,
- * 3 passC, 4 passD) and resets the record. */
+ * ms[200] / count[200], index = kernel*25 + prologue*5 + epilogue (kernel: 0 pass1d, 1 passA, 2 passB,
+ * 3 passC, 4 passD; sandwich: 5 contiguous first pass, 6 in-place middle-axis pass, 7 fused first-axis pass; its
+ * final pass counts as 3) and resets the record. */
 int nk_profile_enable(int on);
 int nk_profile_collect(double* ms, int64_t* count);
 

@@ -43,6 +43,8 @@ SIGNATURES = {
     "nk_plan_workspace_bytes": (_sz, [_vp]),
     "nk_hartley": (_i, [_vp, _vp, _vp, _d, _i, _vp, _vp]),
     "nk_hartley_fused": (_i, [_vp, ctypes.POINTER(Fuse), _i, _vp, _vp]),
+    "nk_plan_sandwich": (_i, [_vp]),
+    "nk_hartley_sandwich": (_i, [_vp, ctypes.POINTER(Fuse), _d, _i, _vp, _vp]),
     "nk_fftn": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp]),
     "nk_profile_enable": (_i, [_i]),
     "nk_profile_collect": (_i, [_vp, _vp]),

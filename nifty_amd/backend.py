@@ -214,6 +214,19 @@ def hartley_fused(plan, fuse):
                                       _stream()), "nk_hartley_fused")
 
 
+def plan_sandwich(plan):
+    """True when nk_hartley_sandwich serves this plan (>= 2 axes, power-of-two lengths 64 .. 4096)."""
+    return bool(L.load().nk_plan_sandwich(plan.handle))
+
+
+def hartley_sandwich(plan, fuse, scale_first):
+    """EPI(fuse.scale * H(mul_scalar * mul . scale_first * H(PRO(in)))) in five passes (include/niftyk.h)."""
+    if plan.device.index != _current_device():
+        _wrong_device(plan.device.index)
+    L.check(L.load().nk_hartley_sandwich(plan.handle, ctypes.byref(fuse), float(scale_first), _convention(),
+                                         plan.workspace.data_ptr(), _stream()), "nk_hartley_sandwich")
+
+
 def fftn(x, ndim=None, inverse=False, scale=1.0):
     """c2c FFT over the last ``ndim`` axes of a complex tensor (reference ducc_dispatch.fftn / ifftn)."""
     _require_device(x)

@@ -25,6 +25,7 @@ std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
 std::mutex g_prof_mu;
 constexpr size_t NK_PROF_MAX = 1 << 17;
+constexpr int NK_PROF_KEYS = 200;
 
 hipEvent_t prof_event() {
   if (!g_prof_pool.empty()) {
@@ -70,15 +71,16 @@ extern "C" int nk_profile_enable(int on) {
   return NK_OK;
 }
 
-// ms[125], count[125] indexed by kernel*25 + pro*5 + epi  (kernel: 0 pass1d, 1 passA, 2 passB, 3 passC, 4 passD)
+// ms[200], count[200] indexed by kernel*25 + pro*5 + epi  (kernel: 0 pass1d, 1 passA, 2 passB, 3 passC, 4 passD,
+// sandwich pipeline: 5 contiguous first pass, 6 in-place middle-axis pass, 7 fused first-axis pass)
 extern "C" int nk_profile_collect(double* ms, int64_t* count) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (int i = 0; i < 125; ++i) ms[i] = 0.0, count[i] = 0;
+  for (int i = 0; i < NK_PROF_KEYS; ++i) ms[i] = 0.0, count[i] = 0;
   for (ProfRec& r : g_prof_recs) {
     float t = 0.f;
     hipError_t e = hipEventSynchronize(r.e1);
     if (e == hipSuccess) e = hipEventElapsedTime(&t, r.e0, r.e1);
-    if (e == hipSuccess && r.key >= 0 && r.key < 125) {
+    if (e == hipSuccess && r.key >= 0 && r.key < NK_PROF_KEYS) {
       ms[r.key] += t;
       count[r.key] += 1;
     }
@@ -228,7 +230,7 @@ __global__ void __launch_bounds__((StridedTile<T, N>::THREADS),
 
 // min waves / SIMD: 4 only for the light fp32 affine / multiply classes; everything else gets 168 VGPRs -- at 128 the fp64
 // and likelihood kernels spilled (fp64 512^3 affine pass 0.61 -> 0.42 ms without the spills)
-template <typename T, int NL, bool COUPLES, int EC>
+template <typename T, int NL, bool COUPLES, int EC, int PAIR>
 __global__ void __launch_bounds__((FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS),
                                   (FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS > 256 ? 1 : ((!COUPLES && sizeof(T) == 4 && (EC == 0 || EC == 1)) ? 4 : 3)))
     k2_final(NkPassF p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, int xmap) {
@@ -236,15 +238,15 @@ __global__ void __launch_bounds__((FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREAD
   DeviceExec<T, SchedF<T, NL>::E> ex;
   double acc = 0.0;
   const int64_t blk = xmap ? nk_xcd_contig(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
-  nk_final_body<T, NL, FinalTile<T, NL, EC, COUPLES ? 2 : 1>::TILE, COUPLES, EC>(ex, p, f, blk, (T*)smem, tw, work, &acc);
+  nk_final_body<T, NL, FinalTile<T, NL, EC, COUPLES ? 2 : 1>::TILE, COUPLES, EC, PAIR>(ex, p, f, blk, (T*)smem, tw, work, &acc);
   nk_flush_energy(f, acc, smem);
 }
 
-template <typename T, int NL, bool COUPLES, int EC>
+template <typename T, int NL, bool COUPLES, int EC, int PAIR = 0>
 static int nk_launch_final_c(NkPassF pf, const NkFuse& f, const C2<T>* tw, const C2<T>* work, hipStream_t st) {
   using CT = FinalTile<T, NL, EC, COUPLES ? 2 : 1>;
   static_assert(!COUPLES || CT::TILE >= 2, "the couple (b0, M - b0) must live in one workgroup");
-  auto kern = k2_final<T, NL, COUPLES, EC>;
+  auto kern = k2_final<T, NL, COUPLES, EC, PAIR>;
   static unsigned long long attr_mask = 0;  // per-device attribute
   if (CT::LDS_BYTES > 64 * 1024 && nk_first_on_device(attr_mask)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CT::LDS_BYTES);
@@ -272,6 +274,28 @@ static int nk_launch_final(const NkPassF& pf, const NkFuse& f, const C2<T>* tw, 
   if (f.epi == NK_EPI_MUL) return nk_launch_final_c<T, NL, false, 1>(pf, f, tw, work, st);
   if (f.epi == NK_EPI_LIKELIHOOD) return nk_launch_final_c<T, NL, false, 3>(pf, f, tw, work, st);
   return nk_launch_final_c<T, NL, false, -1>(pf, f, tw, work, st);
+}
+
+// final pass of the sandwich pipeline (row-mirror pairing): the hot classes are compile-time, the rest run-time
+template <typename T, int NL>
+static int nk_launch_final3(const NkPassF& pf, const NkFuse& f, const C2<T>* tw, const C2<T>* work, hipStream_t st) {
+  if (f.epi == NK_EPI_VJP && f.afield) return nk_launch_final_c<T, NL, true, 2, 1>(pf, f, tw, work, st);
+  if (f.epi == NK_EPI_VJP) return nk_launch_final_c<T, NL, true, -1, 1>(pf, f, tw, work, st);
+  if (f.epi == NK_EPI_AFFINE) return nk_launch_final_c<T, NL, false, 0, 1>(pf, f, tw, work, st);
+  return nk_launch_final_c<T, NL, false, -1, 1>(pf, f, tw, work, st);
+}
+
+template <typename T>
+static int nk_dispatch_final3(int nl, const NkPassF& pf, const NkFuse& f, const C2<T>* tw, const C2<T>* work,
+                              hipStream_t st) {
+  switch (nl) {
+#define NK_CASE(NN) \
+  case NN:          \
+    return nk_launch_final3<T, NN>(pf, f, tw, work, st);
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+  }
+  return nk_set_error(NK_ERR_UNSUPPORTED, "no fast final pass for this length");
 }
 
 template <typename T>
@@ -357,6 +381,115 @@ static int nk_dispatch_strided(int n, const NkPassS& ps, const NkFuse& f, const 
 #define NK_CASE(NN) \
   case NN:          \
     return nk_launch_strided<T, NN, MODE>(ps, f, tw, work, scratch, st);
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+  }
+  return nk_set_error(NK_ERR_UNSUPPORTED, "no fast strided pass for this length");
+}
+
+// ---- sandwich pipeline (nk_fft3.h) ------------------------------------------------------------------------
+template <typename T, int H, int PC>
+__global__ void __launch_bounds__((Contig3Tile<T, H>::THREADS))
+    k3_contig(NkPass3 p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr, C2<T>* __restrict__ work) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  DeviceExec<T, Contig3Tile<T, H>::SC::E> ex;
+  nk_contig3_body<T, H, Contig3Tile<T, H>::TILE, PC>(ex, p, f, blockIdx.x, (T*)smem, tw, twr, work);
+}
+
+template <typename T, int H, int PC>
+static int nk_launch_contig3(const NkPass3& p3, const NkFuse& f, const C2<T>* tw, const C2<T>* twr, C2<T>* work, hipStream_t st) {
+  using CT = Contig3Tile<T, H>;
+  auto kern = k3_contig<T, H, PC>;
+  static unsigned long long attr_mask = 0;  // per-device attribute
+  if (CT::LDS_BYTES > 64 * 1024 && nk_first_on_device(attr_mask)) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CT::LDS_BYTES);
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k3_contig)");
+  }
+  const int64_t blocks = (p3.nlines + CT::TILE - 1) / CT::TILE;
+  if (blocks > 0x7fffffffLL) return nk_set_error(NK_ERR_UNSUPPORTED, "too many lines for one launch");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CT::THREADS), CT::LDS_BYTES, st, p3, f, tw, twr, work);
+  return nk_check_launch("k3_contig");
+}
+
+template <typename T, int H>
+static int nk_launch_contig3_pc(const NkPass3& p3, const NkFuse& f, const C2<T>* tw, const C2<T>* twr, C2<T>* work, hipStream_t st) {
+  if (f.field_octant && f.pro == NK_PRO_AMP) return nk_launch_contig3<T, H, 4>(p3, f, tw, twr, work, st);
+  if (f.field_octant && f.pro == NK_PRO_AMP_JVP) return nk_launch_contig3<T, H, 5>(p3, f, tw, twr, work, st);
+  if (f.pro == NK_PRO_PLAIN) return nk_launch_contig3<T, H, 0>(p3, f, tw, twr, work, st);
+  if (f.pro == NK_PRO_MUL) return nk_launch_contig3<T, H, 6>(p3, f, tw, twr, work, st);
+  return nk_launch_contig3<T, H, -1>(p3, f, tw, twr, work, st);
+}
+
+template <typename T>
+static int nk_dispatch_contig3(int h, const NkPass3& p3, const NkFuse& f, const C2<T>* tw, const C2<T>* twr, C2<T>* work,
+                               hipStream_t st) {
+  switch (h) {
+#define NK_CASE(NN) \
+  case NN:          \
+    return nk_launch_contig3_pc<T, NN>(p3, f, tw, twr, work, st);
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+  }
+  return nk_set_error(NK_ERR_UNSUPPORTED, "no fast contiguous pass for this length");
+}
+
+#ifndef NK_MID_CX
+#define NK_MID_CX 1
+#endif
+#ifndef NK_MID_WAVES
+#define NK_MID_WAVES 0  // > 0: min waves per SIMD the fused middle kernel must allow (register cap)
+#endif
+#ifndef NK_MID_PF
+#define NK_MID_PF 0   // persistent workgroups that prefetch the next tile into registers
+#endif
+template <typename T, int N, bool MF>
+__global__ void __launch_bounds__((StridedTile<T, N, NK_MID_CX != 0>::THREADS),
+                                  (NK_MID_WAVES > 0 ? NK_MID_WAVES : StridedTile<T, N, NK_MID_CX != 0>::THREADS <= 256 ? 2 : 1))
+    k3_mid(NkPassM pm, NkFuse f, const C2<T>* __restrict__ tw, C2<T>* __restrict__ work, int64_t nblk, int xmap) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  using ST = StridedTile<T, N, NK_MID_CX != 0>;
+  DeviceExecR<MidRegs<T, Sched<T, N>::E>> ex;
+  C2<T>* tw_lds = ST::TWLDS ? reinterpret_cast<C2<T>*>(smem + ST::LDS_BYTES) : nullptr;
+  nk_mid_body<T, N, ST::TILE, ST::CPLX, MF, NK_MID_PF != 0>(ex, pm, f, (int64_t)blockIdx.x, (int64_t)gridDim.x, nblk, xmap, (T*)smem,
+                                                            tw, work, tw_lds);
+}
+
+template <typename T, int N, bool MF>
+static int nk_launch_mid(NkPassM pm, const NkFuse& f, const C2<T>* tw, C2<T>* work, hipStream_t st) {
+  using ST = StridedTile<T, N, NK_MID_CX != 0>;
+  auto kern = k3_mid<T, N, MF>;
+  static unsigned long long attr_mask = 0;  // per-device attribute
+  if (ST::LDS_TOTAL > 64 * 1024 && nk_first_on_device(attr_mask)) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ST::LDS_TOTAL);
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k3_mid)");
+  }
+  pm.s.tl.tile = ST::TILE;
+  pm.s.tiles_per_slab = (int)(pm.s.inner / ST::TILE);
+  const int64_t blocks = pm.s.outer * pm.s.tiles_per_slab;
+  static const int xmap_env = nk_env_int("NK_XMAP", NK_XMAP_DEFAULT);
+  // persistent: as many workgroups as the device keeps resident (LDS decides: one or two per CU)
+  int64_t grid = blocks;
+  if (NK_MID_PF) {
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    static const int per_cu_env = nk_env_int("NK_MID_WG_PER_CU", 0);
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (ST::LDS_TOTAL <= 80 * 1024 && ST::THREADS <= 512 ? 2 : 1);
+    if (grid > (int64_t)cus * per_cu) grid = (int64_t)cus * per_cu;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(ST::THREADS), ST::LDS_TOTAL, st, pm, f, tw, work, blocks, xmap_env & 2);
+  return nk_check_launch("k3_mid");
+}
+
+template <typename T>
+static int nk_dispatch_mid(int n, const NkPassM& pm, const NkFuse& f, const C2<T>* tw, C2<T>* work, hipStream_t st) {
+  switch (n) {
+#define NK_CASE(NN) \
+  case NN:          \
+    return f.mul ? nk_launch_mid<T, NN, true>(pm, f, tw, work, st) : nk_launch_mid<T, NN, false>(pm, f, tw, work, st);
     NK_FAST_SIZES(NK_CASE)
 #undef NK_CASE
   }
@@ -760,6 +893,98 @@ extern "C" int nk_hartley_fused(const nk_plan* P, const nk_fuse* fuse, int conve
   hipStream_t st = (hipStream_t)stream;
   if (P->hp.dtype == NK_F32) return nk_run_hartley<float>(P, *fuse, convention, workspace, st);
   return nk_run_hartley<double>(P, *fuse, convention, workspace, st);
+}
+
+// sandwich: out = EPI( scale * H( scale_first * mul_scalar * mul . H( PRO(in) ) ) ), five passes (nk_fft3.h)
+static bool nk_strided_tile_divides(const nk_plan* P, int n, int64_t inner) {
+  return P->hp.dtype == NK_F32 ? nk_fast_strided_ok<float>(n, inner) : nk_fast_strided_ok<double>(n, inner);
+}
+extern "C" int nk_plan_sandwich(const nk_plan* P) {
+  if (!P || !nk_plan_uses_pipeline2(P) || !nk_fast_contig_ok(P->hp.g.h)) return 0;
+  const NkGeom& g = P->hp.g;
+  const int64_t rs = g.h + (P->hp.dtype == NK_F32 ? nk_pipe3_colpad<float>() : nk_pipe3_colpad<double>());
+  if (g.ndim == 3 && !nk_strided_tile_divides(P, g.nm, rs)) return 0;
+  return nk_strided_tile_divides(P, g.na, g.ndim == 3 ? (int64_t)g.nm * rs : rs) ? 1 : 0;
+}
+
+template <typename T>
+static int nk_run_sandwich(const nk_plan* P, const NkFuse& f, double scale_first, int convention, void* workspace, hipStream_t st) {
+  const NkHostPlan& hp = P->hp;
+  const int sign = convention == NK_HARTLEY_CANONICAL ? -1 : 1;
+  static const int work_pad = nk_env_int("NK_WORK_PAD", 2080);
+  const NkPipe3 q = nk_pipe3_setup<T>(hp, sign, work_pad, scale_first * (f.mul_scalar != 0.0 ? f.mul_scalar : 1.0));
+  if (nk_pipe3_work_elems(hp.g, nk_pipe3_colpad<T>(), work_pad) * sizeof(C2<T>) > hp.work_bytes)
+    return nk_set_error(NK_ERR_RUNTIME, "nk_hartley_sandwich: plan workspace too small");
+  if (128 * (q.ss > q.pm.s.inner ? q.ss : q.pm.s.inner) * (int64_t)sizeof(C2<T>) >= ((int64_t)1 << 32))
+    return nk_set_error(NK_ERR_UNSUPPORTED, "transform too large for the 32-bit thread offsets of the strided passes");
+  C2<T>* work = (C2<T>*)workspace;
+  int rc;
+  {
+    ProfScope ps(st, 5, f.pro, f.epi);
+    rc = nk_dispatch_contig3<T>(hp.g.h, q.p1, f, (const C2<T>*)P->d_tw_a, (const C2<T>*)P->d_twr_a, work, st);
+  }
+  if (rc != NK_OK) return rc;
+  if (hp.g.ndim == 3) {
+    ProfScope ps(st, 6, f.pro, f.epi);
+    rc = nk_dispatch_strided<T, 0>(hp.g.nm, q.s2, f, (const C2<T>*)P->d_tw_b, work, (C2<T>*)nullptr, st);
+    if (rc != NK_OK) return rc;
+  }
+  {
+    ProfScope ps(st, 7, f.pro, f.epi);
+    rc = nk_dispatch_mid<T>(hp.g.na, q.pm, f, (const C2<T>*)P->d_tw_c, work, st);
+  }
+  if (rc != NK_OK) return rc;
+  if (hp.g.ndim == 3) {
+    ProfScope ps(st, 6, f.pro, f.epi);
+    rc = nk_dispatch_strided<T, 0>(hp.g.nm, q.s2, f, (const C2<T>*)P->d_tw_b, work, (C2<T>*)nullptr, st);
+    if (rc != NK_OK) return rc;
+  }
+  ProfScope ps(st, 3, f.pro, f.epi);
+  static const int use_slots = nk_env_int("NK_VALUE_SLOTS", 1);
+  if (use_slots && f.value && (f.epi == NK_EPI_LIKELIHOOD || f.epi == NK_EPI_VJP)) {
+    double* slots = (double*)((char*)workspace + (hp.work_bytes + 255) / 256 * 256 + (hp.scratch_bytes + 255) / 256 * 256 + 256);
+    hipError_t e = hipMemsetAsync(slots, 0, NK_VALUE_SLOTS * sizeof(double), st);
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(value slots)");
+    NkFuse f2 = f;
+    f2.value = slots;
+    f2.value_slots = NK_VALUE_SLOTS;
+    rc = nk_dispatch_final3<T>(hp.g.nl, q.pf, f2, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
+    if (rc != NK_OK) return rc;
+    hipLaunchKernelGGL(k_fold_slots, dim3(1), dim3(NK_VALUE_SLOTS), 0, st, slots, f.value);
+    return nk_check_launch("k_fold_slots");
+  }
+  return nk_dispatch_final3<T>(hp.g.nl, q.pf, f, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
+}
+
+extern "C" int nk_hartley_sandwich(const nk_plan* P, const nk_fuse* fuse, double scale_first, int convention,
+                                   void* workspace, void* stream) {
+  if (!P || !fuse) return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: null argument");
+  if (!fuse->in || !fuse->out || !workspace) return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: in/out/workspace must be set");
+  if (convention != NK_HARTLEY_NON_CANONICAL && convention != NK_HARTLEY_CANONICAL)
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: unknown hartley convention");
+  if (!nk_plan_sandwich(P)) return nk_set_error(NK_ERR_UNSUPPORTED, "nk_hartley_sandwich: needs nk_plan_sandwich(plan) != 0");
+  if (fuse->epi == NK_EPI_MUL)
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: `mul` is the diagonal between the transforms; the MUL epilogue is not available");
+  if ((fuse->pro == NK_PRO_AMP || fuse->pro == NK_PRO_AMP_JVP) && (!fuse->pidx || !fuse->amp))
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: AMP prologue needs pidx and amp");
+  if (fuse->pro == NK_PRO_AMP_JVP && (!fuse->damp || !fuse->in2))
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: AMP_JVP prologue needs damp and in2");
+  if (fuse->pro == NK_PRO_MUL && !fuse->in2) return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: MUL prologue needs in2");
+  if (fuse->epi == NK_EPI_VJP && (!fuse->pidx || !fuse->amp || !fuse->xi || !fuse->abar))
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: VJP epilogue needs pidx, amp, xi and abar");
+  if (fuse->epi == NK_EPI_LIKELIHOOD && (!fuse->data || !fuse->value))
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: LIKELIHOOD epilogue needs data and value");
+  if (fuse->field_octant) {
+    const bool amp_pro = fuse->pro == NK_PRO_AMP || fuse->pro == NK_PRO_AMP_JVP;
+    if ((amp_pro && !fuse->afield) || (fuse->pro == NK_PRO_AMP_JVP && !fuse->dafield) || (fuse->epi == NK_EPI_VJP && !fuse->afield))
+      return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: field_octant needs afield (and dafield for AMP_JVP)");
+    const NkGeom& g = P->hp.g;
+    if ((int64_t)(g.na / 2 + 1) * (g.nm / 2 + 1) * (g.nl / 2 + 1) >= ((int64_t)1 << 31))
+      return nk_set_error(NK_ERR_UNSUPPORTED, "nk_hartley_sandwich: octant field too large (>= 2^31 elements)");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (P->hp.dtype == NK_F32) return nk_run_sandwich<float>(P, *fuse, scale_first, convention, workspace, st);
+  return nk_run_sandwich<double>(P, *fuse, scale_first, convention, workspace, st);
 }
 
 extern "C" int nk_hartley(const nk_plan* P, const void* in, void* out, double scale, int convention, void* workspace,

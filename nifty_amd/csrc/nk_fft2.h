@@ -20,47 +20,79 @@
 #include "nk_fft_phases.h"
 
 // ---------------------------------------------------------------------------------------------
-// in-register DFT of compile-time size R (natural order in / out), forward sign
+// in-register DFT of compile-time size R <= 64 (natural order in / out), forward sign
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 struct TwConst {
-  // cos(2 pi k / 32), sin(2 pi k / 32), k = 0..15
+  // cos(2 pi k / 64), sin(2 pi k / 64), k = 0..31
   static NK_HD T c(int k) {
-    constexpr double v[16] = {1.0,
+    constexpr double v[32] = {1.0,
+                              0.99518472667219688624,
                               0.98078528040323044913,
+                              0.95694033573220886494,
                               0.92387953251128675613,
+                              0.88192126434835502971,
                               0.83146961230254523708,
+                              0.77301045336273696081,
                               0.70710678118654752440,
+                              0.63439328416364549822,
                               0.55557023301960222474,
+                              0.47139673682599764856,
                               0.38268343236508977173,
+                              0.29028467725446236764,
                               0.19509032201612826785,
+                              0.09801714032956060199,
                               0.0,
+                              -0.09801714032956060199,
                               -0.19509032201612826785,
+                              -0.29028467725446236764,
                               -0.38268343236508977173,
+                              -0.47139673682599764856,
                               -0.55557023301960222474,
+                              -0.63439328416364549822,
                               -0.70710678118654752440,
+                              -0.77301045336273696081,
                               -0.83146961230254523708,
+                              -0.88192126434835502971,
                               -0.92387953251128675613,
-                              -0.98078528040323044913};
+                              -0.95694033573220886494,
+                              -0.98078528040323044913,
+                              -0.99518472667219688624};
     return (T)v[k];
   }
   static NK_HD T s(int k) {
-    constexpr double v[16] = {0.0,
+    constexpr double v[32] = {0.0,
+                              0.09801714032956060199,
                               0.19509032201612826785,
+                              0.29028467725446236764,
                               0.38268343236508977173,
+                              0.47139673682599764856,
                               0.55557023301960222474,
+                              0.63439328416364549822,
                               0.70710678118654752440,
+                              0.77301045336273696081,
                               0.83146961230254523708,
+                              0.88192126434835502971,
                               0.92387953251128675613,
+                              0.95694033573220886494,
                               0.98078528040323044913,
+                              0.99518472667219688624,
                               1.0,
+                              0.99518472667219688624,
                               0.98078528040323044913,
+                              0.95694033573220886494,
                               0.92387953251128675613,
+                              0.88192126434835502971,
                               0.83146961230254523708,
+                              0.77301045336273696081,
                               0.70710678118654752440,
+                              0.63439328416364549822,
                               0.55557023301960222474,
+                              0.47139673682599764856,
                               0.38268343236508977173,
-                              0.19509032201612826785};
+                              0.29028467725446236764,
+                              0.19509032201612826785,
+                              0.09801714032956060199};
     return (T)v[k];
   }
 };
@@ -79,12 +111,12 @@ struct RegDft {
     RegDft<T, R / 2>::run(od);
 #pragma unroll
     for (int k = 0; k < R / 2; ++k) {
-      // w = exp(-2 pi i k / R) = (cos, -sin) with angle index k*(32/R)
-      const int a = k * (32 / R);
+      // w = exp(-2 pi i k / R) = (cos, -sin) with angle index k*(64/R)
+      const int a = k * (64 / R);
       C2<T> t;
       if (a == 0) {
         t = od[k];
-      } else if (a == 8) {
+      } else if (a == 16) {
         t = C2<T>{od[k].y, -od[k].x};
       } else {
         const T c = TwConst<T>::c(a), s = TwConst<T>::s(a);
@@ -128,7 +160,11 @@ NK_SCHED(float, 64, 8, 2, 8, 8, 1);
 NK_SCHED(float, 128, 16, 2, 16, 8, 1);
 NK_SCHED(float, 256, 16, 2, 16, 16, 1);
 NK_SCHED(float, 512, 32, 2, 32, 16, 1);
+#ifdef NK_E64
+NK_SCHED(float, 1024, 64, 2, 64, 16, 1);  // 256 threads x 64 elements: two workgroups per CU
+#else
 NK_SCHED(float, 1024, 32, 2, 32, 32, 1);
+#endif
 NK_SCHED(float, 2048, 32, 3, 32, 32, 2);
 NK_SCHED(float, 4096, 32, 3, 32, 32, 4);
 NK_SCHED(double, 64, 8, 2, 8, 8, 1);
@@ -303,6 +339,9 @@ struct StageInfo {
   static constexpr int Q = SC::E / R;                                        // butterflies per thread
 };
 
+#ifndef NK_TW_GROUP
+#define NK_TW_GROUP 0
+#endif
 // twiddle + in-register butterflies of stage S on v (inputs ordered v[q*R + r])
 template <typename T, typename SC, int S>
 NK_HD void nk_stage_compute(C2<T>* v, int p, const C2<T>* __restrict__ tw) {
@@ -317,6 +356,10 @@ NK_HD void nk_stage_compute(C2<T>* v, int p, const C2<T>* __restrict__ tw) {
       for (int r = 1; r < R; ++r) {
         const C2<T> w = tw[(k * r * step) & (N - 1)];
         v[q * R + r] = cmul(v[q * R + r], w);
+#if !defined(NK_HOST_EMU) && NK_TW_GROUP > 0
+        // scheduling fence: at most NK_TW_GROUP twiddles in flight (all R - 1 hoisted loads cost 2 (R - 1) VGPRs)
+        if (r % NK_TW_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     }
     RegDft<T, R>::run(v + q * R);
@@ -905,11 +948,18 @@ struct NkPassF {
   int tiles_per_a;   // M / TILE
   int blo;           // work array layout, see nk_strided_body
   int64_t ss;        // slab stride (0: plain natural layout)
+  int64_t rs;        // row stride of the work array in complex elements (0: nl / 2)
 };
 
 // EC: compile-time epilogue class (0 affine, 1 multiply, 2 scatter/VJP with materialised amplitude field,
 // 3 likelihood, -1 generic)
-template <typename T, int NL, int TILE, bool COUPLES, int EC, typename Exec>
+// PAIR: how the two work rows (k, -k) encode the line X(k, .) of length NL that is transformed here
+//   0  even/odd columns (strided-first pipeline, above):  Z_j(k) = X(k, 2j) + i X(k, 2j+1)
+//   1  row-mirror pairing of the sandwich pipeline (nk_fft3.h): rows of NL/2 + 1 columns,
+//        G_c(k) = X(k, c) + i X(-k, NL - c),  X(-k, c) = conj X(k, c)   (x real)
+//      =>  2 X(k, c)      = G_c(k) + conj G_c(-k)                  c = 0 .. NL/2
+//          2 X(k, NL - c) = conj( (G_c(k) - conj G_c(-k)) / i )    c = 1 .. NL/2 - 1
+template <typename T, int NL, int TILE, bool COUPLES, int EC, int PAIR = 0, typename Exec>
 NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t blk, T* planes,
                          const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, double* acc_out) {
   // the line FFT runs on 2A / 2B (see the load phase): fold the 1/2 into the output scale every epilogue applies first
@@ -955,10 +1005,11 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
     int b, bm;
     bool active, self;
     line_of(t, b, bm, active, self);
+    const int64_t rs = p.rs > 0 ? p.rs : (int64_t)H;
     auto line_at = [&](int aa, int bb) {
-      if (p.ss > 0 && p.blo > 0) return work + (bat * M + bb) * p.ss + (int64_t)aa * H;
-      if (p.ss > 0) return work + (bat * A + aa) * p.ss + (int64_t)bb * H;
-      return work + ((bat * A + aa) * M + bb) * (int64_t)H;
+      if (p.ss > 0 && p.blo > 0) return work + (bat * M + bb) * p.ss + (int64_t)aa * rs;
+      if (p.ss > 0) return work + (bat * A + aa) * p.ss + (int64_t)bb * rs;
+      return work + ((bat * A + aa) * M + bb) * rs;
     };
     const C2<T>* lk = line_at(a, b);
     const C2<T>* lm = line_at(am, bm);
@@ -972,9 +1023,17 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const int n2 = nk_in_row<SC, 0>(pp, q, r);
-          const C2<T> Zk = lk[n2 >> 1], Zm = lm[n2 >> 1];
-          const T c0 = odd ? Zk.y : Zk.x, c1 = odd ? Zm.y : Zm.x, c2 = odd ? Zm.x : Zk.y, c3 = odd ? Zk.x : Zm.y;
-          rg.v[q * R + r] = C2<T>{c0 + c1, c2 - c3};
+          if constexpr (PAIR == 1) {
+            const bool up = n2 > H;
+            const int c = up ? NL - n2 : n2;
+            const C2<T> Zk = lk[c], Zm = lm[c];
+            const T c0 = up ? Zk.y : Zk.x, c1 = up ? Zm.y : Zm.x, c2 = up ? Zk.x : Zk.y, c3 = up ? Zm.x : Zm.y;
+            rg.v[q * R + r] = C2<T>{c0 + c1, c2 - c3};
+          } else {
+            const C2<T> Zk = lk[n2 >> 1], Zm = lm[n2 >> 1];
+            const T c0 = odd ? Zk.y : Zk.x, c1 = odd ? Zm.y : Zm.x, c2 = odd ? Zm.x : Zk.y, c3 = odd ? Zk.x : Zm.y;
+            rg.v[q * R + r] = C2<T>{c0 + c1, c2 - c3};
+          }
         }
     } else {
 #pragma unroll
@@ -1191,11 +1250,12 @@ static inline bool nk_fast_contig_ok(int h) { return nk_fast_size(h); }
 // pass parameters of the strided-first pipeline (shared by the HIP driver and the host emulation)
 // ---------------------------------------------------------------------------------------------
 #include "nk_plan.h"
+#define NK_WORK_PAD_MAX 8192  // elements; the plan's workspace reserves this much per slab
+#include "nk_fft3.h"
 struct NkPipe2 {
   NkPassS s1, s0;  // first pass (fused prologue); second, in-place pass (3-D only)
   NkPassF pf;
 };
-#define NK_WORK_PAD_MAX 8192  // elements; the plan's workspace reserves this much per slab
 static inline NkPipe2 nk_pipe2_setup(const NkHostPlan& hp, int sign, int blo, int pad) {
   NkPipe2 q{};
   const NkGeom& g = hp.g;

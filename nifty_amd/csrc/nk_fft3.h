@@ -1,0 +1,473 @@
+// nk_fft3.h -- the SANDWICH pipeline:  out = epilogue( H( m . H( prologue(in) ) ) )  in five passes instead of six.
+//
+// A metric application J^T M J d (energy_operators.py:146-152 through harmonic_operators.py:144-161) is two genuine
+// Hartley transforms with a diagonal in between.  Run back to back through the strided-first pipeline they cost six
+// passes over the array: the last pass of the first transform writes the position-space field, the first pass of the
+// second one reads it again.  Here the first transform runs CONTIGUOUS AXIS FIRST and the second one contiguous axis
+// last, so that the last pass of the former and the first pass of the latter meet on the same (first) axis and become
+// ONE kernel with the whole line in registers -- the position-space field never exists in memory.
+//
+//   F1  contiguous axis, real lines through the fused prologue -> half spectrum W(a, b, c), c = 0 .. nl/2, rows of
+//       RS = nl/2 + 16 (fp32) / + 8 (fp64) complex columns (unpacked: no packed Nyquist column; the pad columns are 0)
+//   F2  middle axis (3-D), in place, plain c2c                                      (k2_strided, MODE 0)
+//   FM  first axis, in place: c2c -> F(a, b, c) = p + i q, the full spectrum of the real input.  The Hartley field at
+//       the two points this coefficient feeds is  s(a, b, c) = p + sg q  and  s(-a, -b, -c) = p - sg q.  With the
+//       diagonal m and ROW-MIRROR PAIRING
+//           y_c(a) = m(a, b, c) s(a, b, c)  +  i m(-a, -b, -c) s(-a, -b, -c)
+//       is an element-wise function of F(a, b, c) alone (no partner element, no second row), and the c2c transform
+//       of y along a is  G_c(k_a; b) = X~(k_a; b, c) + i X~(-k_a; M - b, nl - c)  with x = m . s the (real) input of the
+//       second transform and X~ its spectrum along a: the first pass of the second transform, done on the spot.
+//   A2  middle axis (3-D), in place: G_c(k) = X2(k, c) + i X2(-k, nl - c), k = (k_a, k_b)
+//   A3  contiguous axis, line pairs (k, -k): X2(-k, c) = conj X2(k, c) gives the whole line X2(k, 0..nl-1) from the two
+//       rows (nk_final_body, PAIR = 1), one complex FFT of length nl, Hartley combine and the usual fused epilogues.
+//
+// Every access of F2 / FM / A2 is a 128-byte row segment of the ONE work array (all three run in place); only a
+// non-constant diagonal m is read in 64-byte pieces (its own and the mirrored row).
+#pragma once
+#include <type_traits>
+
+// contiguous first pass -------------------------------------------------------------------------------------
+struct NkPass3 {
+  NkGeom g;
+  int64_t nlines;     // batch * na * nm
+  int rows_per_slab;  // lines per work slab (3-D: nm, 2-D: na)
+  int64_t rs, ss;     // work row stride / slab stride in complex elements
+};
+
+// thread id -> line thread pp = tid % P, line t = tid / P; LDS: two scalar planes (re, im) of TILE * PITCH elements
+// PC: compile-time prologue class as in nk_strided_body (0 plain, 1 afield, 3 afield + dafield, 4 / 5 octant fields,
+// 6 multiply, -1 run-time)
+// Schedule and tile: like the final pass (SchedF, E = 16: twice the threads per line, small workgroups) -- a row pass is
+// latency-bound, many small workgroups hide the loads of the prologue operands best (JVP prologue at 1024^3 fp32:
+// 4.96 ms with 8 lines x 16 threads x 32 elements per workgroup)
+#ifndef NK_CONTIG3_LDS_KB
+#define NK_CONTIG3_LDS_KB 20
+#endif
+template <typename T, int H>
+struct Contig3Tile {
+  using SC = SchedF<T, H>;
+  static constexpr int P = SC::P;
+  static constexpr int PITCH = ContigLayout<H, P>::PITCH;
+  static constexpr int fit(int tile) {
+    return (tile > 1 && (P * tile > 256 || 2 * tile * PITCH * (int)sizeof(T) > NK_CONTIG3_LDS_KB * 1024)) ? fit(tile / 2) : tile;
+  }
+  static constexpr int T0 = fit(16);
+  static constexpr int TILE = (T0 / 2 >= 1 && P * (T0 / 2) >= 64) ? T0 / 2 : T0;  // halve while a full wavefront remains
+  static constexpr int THREADS = P * TILE;
+  static constexpr int LDS_BYTES = 2 * TILE * PITCH * (int)sizeof(T);
+};
+
+template <typename T, int H, int TILE, int PC, typename Exec>
+NK_HD void nk_contig3_body(Exec& ex, const NkPass3& p, const NkFuse& f, int64_t blk, T* planes,
+                           const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr, C2<T>* __restrict__ work) {
+  using SC = typename Contig3Tile<T, H>::SC;
+  using LY = ContigLayout<H, SC::P>;
+  constexpr int E = SC::E, S = SC::S, P = SC::P;
+  T* pre = planes;
+  T* pim = planes + TILE * LY::PITCH;
+  const int64_t line0 = blk * TILE;
+  const int nl = p.g.nl;
+
+  ex.phase([&](int tid, PassRegs<T, E>& rg) {
+    const int pp = tid % P, t = tid / P;
+    const int64_t line = line0 + t;
+    constexpr int R = SC::radix(0), Q = E / R;
+    constexpr bool OCT = PC == 4 || PC == 5;
+    [[maybe_unused]] uint32_t o8 = 0;
+    if constexpr (OCT) {
+      const uint32_t ch = nl / 2 + 1;
+      if (p.g.ndim == 3) {
+        const int b = (int)(line % p.g.nm), a = (int)((line / p.g.nm) % p.g.na);
+        o8 = ((uint32_t)nk_fold(a, p.g.na) * (p.g.nm / 2 + 1) + (uint32_t)nk_fold(b, p.g.nm)) * ch;
+      } else {
+        o8 = (uint32_t)nk_fold((int)(line % p.g.na), p.g.na) * ch;
+      }
+    }
+    const int64_t iu = line0 * nl;           // wave-uniform part of the flat real index
+    const uint32_t tl = (uint32_t)(t * nl);  // < 2^31: a tile of lines
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int row = nk_in_row<SC, 0>(pp, q, r);  // complex index j: reals 2j, 2j+1
+        C2<T> z{(T)0, (T)0};
+        if (line < p.nlines) {
+          if constexpr (OCT) {
+            const bool desc = 4 * row >= nl;  // (c, c+1) -> (nl-c, nl-c-1): stored descending, lower position nl-c-1
+            const uint32_t c8 = desc ? nl - 2 * row - 1 : 2 * row;
+            z = nk_prologue_oct<T, PC>(f, iu, tl + 2 * row, o8 + c8, desc);
+          } else if constexpr (PC >= 0) {
+            z = nk_prologue_ct<T, PC>(f, iu, tl + 2 * row);
+          } else {
+            z = nk_prologue_pair<T>(f, iu + tl + 2 * row);
+          }
+        }
+        rg.v[q * R + r] = z;
+      }
+    nk_stage_compute<T, SC, 0>(rg.v, pp, tw);
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int a = LY::addr(t, nk_out_row<SC, 0>(pp, q, r));
+        pre[a] = rg.v[q * R + r].x;
+        pim[a] = rg.v[q * R + r].y;
+      }
+  });
+  ex.phase([&](int tid, PassRegs<T, E>& rg) {
+    const int pp = tid % P, t = tid / P;
+    constexpr int R = SC::radix(1), Q = E / R;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int a = LY::addr(t, nk_in_row<SC, 1>(pp, q, r));
+        rg.v[q * R + r] = C2<T>{pre[a], pim[a]};
+      }
+    nk_stage_compute<T, SC, 1>(rg.v, pp, tw);
+  });
+  ex.phase([&](int tid, PassRegs<T, E>& rg) {
+    const int pp = tid % P, t = tid / P;
+    constexpr int R = SC::radix(1), Q = E / R;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int a = LY::addr(t, nk_out_row<SC, 1>(pp, q, r));
+        pre[a] = rg.v[q * R + r].x;
+        pim[a] = rg.v[q * R + r].y;
+      }
+  });
+  if constexpr (S == 3) {
+    ex.phase([&](int tid, PassRegs<T, E>& rg) {
+      const int pp = tid % P, t = tid / P;
+      constexpr int R = SC::radix(2), Q = E / R;
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int a = LY::addr(t, nk_in_row<SC, 2>(pp, q, r));
+          rg.v[q * R + r] = C2<T>{pre[a], pim[a]};
+        }
+      nk_stage_compute<T, SC, 2>(rg.v, pp, tw);
+    });
+    ex.phase([&](int tid, PassRegs<T, E>& rg) {
+      const int pp = tid % P, t = tid / P;
+      constexpr int R = SC::radix(2), Q = E / R;
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int a = LY::addr(t, nk_out_row<SC, 2>(pp, q, r));
+          pre[a] = rg.v[q * R + r].x;
+          pim[a] = rg.v[q * R + r].y;
+        }
+    });
+  }
+  // untangle the half-length transform of z_j = x_2j + i x_2j+1 into F[0 .. H] (natural-order planes) and write the
+  // unpacked row; the pad columns H+1 .. rs-1 are zeroed so that the in-place passes never touch uninitialised data
+  ex.last_phase([&](int tid, PassRegs<T, E>& rg) {
+    (void)rg;
+    constexpr int NK = H / 2 + 1;
+    constexpr int NT = P * TILE;
+    auto row_of = [&](int64_t line) { return work + (line / p.rows_per_slab) * p.ss + (line % p.rows_per_slab) * p.rs; };
+    for (int idx = tid; idx < TILE * NK; idx += NT) {
+      const int k = idx % NK, t = idx / NK;
+      const int64_t line = line0 + t;
+      if (line >= p.nlines) continue;
+      C2<T>* dst = row_of(line);
+      if (k == 0) {
+        const T zx = pre[LY::addr(t, 0)], zy = pim[LY::addr(t, 0)];
+        nk_store_stream(dst, C2<T>{zx + zy, (T)0});
+        nk_store_stream(dst + H, C2<T>{zx - zy, (T)0});
+        continue;
+      }
+      const int a1 = LY::addr(t, k), a2 = LY::addr(t, H - k);
+      const C2<T> Zk{pre[a1], pim[a1]}, Zm{pre[a2], pim[a2]};
+      const C2<T> Ev{(T)0.5 * (Zk.x + Zm.x), (T)0.5 * (Zk.y - Zm.y)};
+      const C2<T> Od{(T)0.5 * (Zk.x - Zm.x), (T)0.5 * (Zk.y + Zm.y)};
+      const C2<T> G = cmul(twr[k], Od);
+      nk_store_stream(dst + k, C2<T>{Ev.x + G.y, Ev.y - G.x});
+      if (k != H - k) nk_store_stream(dst + (H - k), C2<T>{Ev.x - G.y, -Ev.y - G.x});
+    }
+    const int npad = (int)(p.rs - (H + 1));
+    for (int idx = tid; idx < TILE * npad; idx += NT) {
+      const int64_t line = line0 + idx / npad;
+      if (line < p.nlines) row_of(line)[H + 1 + idx % npad] = C2<T>{(T)0, (T)0};
+    }
+  });
+}
+
+// fused middle pass -----------------------------------------------------------------------------------------
+struct NkPassM {
+  NkPassS s;         // strided geometry over the first axis (MODE 0 addressing of nk_strided_body)
+  int64_t rs;        // work row stride in complex elements
+  int M;             // rows per slab (3-D: nm, 2-D: 1)
+  double mid_scale;  // (scale of the first transform) * mul_scalar
+};
+
+// registers of the fused middle pass: the pass registers plus the prefetched first-stage inputs of the NEXT tile
+template <typename T, int E>
+struct MidRegs : PassRegs<T, E> {
+  C2<T> nxt[E];
+};
+#ifndef NK_HOST_EMU
+template <typename Regs>
+struct DeviceExecR {
+  Regs regs;
+  template <typename F>
+  __device__ __forceinline__ void phase(F f) {
+    f((int)threadIdx.x, regs);
+    __syncthreads();
+  }
+  template <typename F>
+  __device__ __forceinline__ void last_phase(F f) {
+    f((int)threadIdx.x, regs);
+  }
+};
+#endif
+
+// thread id -> column t = tid % TILE, line thread pp = tid / TILE; blockDim = P * TILE
+// The workgroup walks the tiles v = v0, v0 + vstep, ... < nblk (a persistent launch: vstep = gridDim; one tile per
+// workgroup: vstep >= nblk).  One workgroup fills a CU (registers, LDS) and the two line transforms cost about as much
+// VALU time as the tile's HBM traffic takes (1024 x 16 fp32: ~11 us each), so with PF the loads of the NEXT tile are
+// issued into spare registers before the current tile's first butterfly and land while it is computed.
+// CX: exchanges through one complex plane (N*TILE*2*sizeof(T) bytes) instead of two half rounds through a scalar plane
+// MF: the diagonal is a field (fuse.mul), else only the scalar mid_scale
+template <typename T, int N, int TILE, bool CX, bool MF, bool PF, typename Exec>
+NK_HD void nk_mid_body(Exec& ex, const NkPassM& pm, const NkFuse& f, int64_t v0, int64_t vstep, int64_t nblk, int xmap,
+                       T* plane, const C2<T>* __restrict__ tw_global, C2<T>* __restrict__ work, C2<T>* tw_lds = nullptr) {
+  using SC = Sched<T, N>;
+  using RG = MidRegs<T, SC::E>;
+  constexpr int E = SC::E, S = SC::S, LS = S - 1;
+  const NkPassS& p = pm.s;
+  const C2<T>* tw = tw_lds ? tw_lds : tw_global;
+  [[maybe_unused]] C2<T>* cplane = reinterpret_cast<C2<T>*>(plane);
+  const int64_t rstride = p.ss > 0 ? p.ss : p.inner;
+  auto tile_of = [&](int64_t v, int64_t& o, int64_t& c0) {
+    const int64_t blk = xmap ? nk_xcd_contig(v, nblk) : v;
+    o = blk / p.tiles_per_slab;
+    c0 = (blk % p.tiles_per_slab) * (int64_t)TILE;
+  };
+  auto load_tile = [&](C2<T>* dst, int64_t v, int tid) {
+    int64_t o, c0;
+    tile_of(v, o, c0);
+    const C2<T>* base = work + o * N * rstride + c0;
+    const int t = tid % TILE, pp = tid / TILE;
+    constexpr int R = SC::radix(0), Q = E / R;
+    const uint32_t toff = (uint32_t)(pp * rstride + t);
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) dst[q * R + r] = nk_at32<C2<T>>(base, (int64_t)nk_in_row<SC, 0>(0, q, r) * rstride, toff);
+  };
+
+  // exchange: the output of stage SA (rows nk_out_row<SA>) becomes the input of stage SB (rows nk_in_row<SB>)
+  auto xwrite = [&](auto sa, int half, int tid, RG& rg) {
+    constexpr int SA = decltype(sa)::value;
+    const int t = tid % TILE, pp = tid / TILE;
+    if constexpr (CX) {
+      nk_xwrite_c2<T, SC, SA, TILE>(rg.v, cplane, pp, t);
+    } else {
+      if (half == 0)
+        nk_xwrite_cols<T, SC, SA, TILE, 0>(rg.v, plane, pp, t);
+      else
+        nk_xwrite_cols<T, SC, SA, TILE, 1>(rg.v, plane, pp, t);
+    }
+  };
+  auto xread = [&](auto sb, int half, int tid, RG& rg) {
+    constexpr int SB = decltype(sb)::value;
+    const int t = tid % TILE, pp = tid / TILE;
+    if constexpr (CX) {
+      nk_xread_c2<T, SC, SB, TILE>(rg.v, cplane, pp, t);
+    } else if (half == 0) {
+      nk_xread_cols<T, SC, SB, TILE>(rg.tmp, plane, pp, t);
+    } else {
+      T im[E];
+      nk_xread_cols<T, SC, SB, TILE>(im, plane, pp, t);
+#pragma unroll
+      for (int e = 0; e < E; ++e) rg.v[e] = C2<T>{rg.tmp[e], im[e]};
+    }
+  };
+  // the barrier-separated rounds of one exchange after the producing phase has written (half 0 of) its output
+  auto exchange_rest = [&](auto sa, auto sb) {
+    ex.phase([&](int tid, RG& rg) { xread(sb, 0, tid, rg); });
+    if constexpr (!CX) {
+      ex.phase([&](int tid, RG& rg) { xwrite(sa, 1, tid, rg); });
+      ex.phase([&](int tid, RG& rg) { xread(sb, 1, tid, rg); });
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using ILS = std::integral_constant<int, LS>;
+
+  if (tw_lds || PF) {
+    ex.phase([&](int tid, RG& rg) {
+      if (tw_lds) nk_tw_to_lds<T>(tw_global, tw_lds, N, tid, SC::P * TILE);  // published by this phase's barrier
+      if constexpr (PF) {
+        if (v0 < nblk) load_tile(rg.nxt, v0, tid);
+      }
+    });
+  }
+  auto do_tile = [&](int64_t v) {
+    int64_t o, c0;
+    tile_of(v, o, c0);
+    C2<T>* base = work + o * N * rstride + c0;
+    // ---- first transform: the tile (prefetched, or loaded here), stages 0 .. LS
+    ex.phase([&](int tid, RG& rg) {
+      if constexpr (PF) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) rg.v[e] = rg.nxt[e];
+        if (v + vstep < nblk) load_tile(rg.nxt, v + vstep, tid);
+      } else {
+        load_tile(rg.v, v, tid);
+      }
+      nk_stage_compute<T, SC, 0>(rg.v, tid / TILE, tw);
+      xwrite(I0{}, 0, tid, rg);
+    });
+    exchange_rest(I0{}, I1{});
+    if constexpr (S == 3) {
+      ex.phase([&](int tid, RG& rg) {
+        nk_stage_compute<T, SC, 1>(rg.v, tid / TILE, tw);
+        xwrite(I1{}, 0, tid, rg);
+      });
+      exchange_rest(I1{}, I2{});
+    }
+    // ---- last stage of the first transform, the diagonal with row-mirror pairing, hand-over to the second transform
+    ex.phase([&](int tid, RG& rg) {
+      const int t = tid % TILE, pp = tid / TILE;
+      nk_stage_compute<T, SC, LS>(rg.v, pp, tw);
+      constexpr int R = SC::radix(LS), Q = E / R;
+      const T sg = (T)p.g.sign, ms = (T)pm.mid_scale;
+      if constexpr (MF) {
+        const T* mul = (const T*)f.mul;
+        // m(a, b, c) for the real part, m(-a, -b, -c) for the imaginary part: 64-byte pieces of the user's field
+        const int nl = p.g.nl, M = pm.M;
+        const int64_t col = c0 + t;
+        const int b = (int)(col / pm.rs), c = (int)(col % pm.rs);
+        const bool valid = c <= nl / 2;
+        const int64_t rowlen = (int64_t)M * nl;
+        const T* m1p = mul + (o * N * M + b) * (int64_t)nl + c;
+        const T* m2p = mul + (o * N * M + (b ? M - b : 0)) * (int64_t)nl + (c ? nl - c : 0);
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int a = nk_out_row<SC, LS>(pp, q, r);
+            const C2<T> F = rg.v[q * R + r];
+            T m1 = (T)0, m2 = (T)0;
+            if (valid) {
+              m1 = ms * m1p[a * rowlen];
+              m2 = ms * m2p[(a ? N - a : 0) * rowlen];
+            }
+            rg.v[q * R + r] = C2<T>{m1 * (F.x + sg * F.y), m2 * (F.x - sg * F.y)};
+          }
+      } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const C2<T> F = rg.v[e];
+          rg.v[e] = C2<T>{ms * (F.x + sg * F.y), ms * (F.x - sg * F.y)};
+        }
+      }
+      xwrite(ILS{}, 0, tid, rg);
+    });
+    exchange_rest(ILS{}, I0{});
+    // ---- second transform
+    ex.phase([&](int tid, RG& rg) {
+      nk_stage_compute<T, SC, 0>(rg.v, tid / TILE, tw);
+      xwrite(I0{}, 0, tid, rg);
+    });
+    if constexpr (S == 3) {
+      exchange_rest(I0{}, I1{});
+      ex.phase([&](int tid, RG& rg) {
+        nk_stage_compute<T, SC, 1>(rg.v, tid / TILE, tw);
+        xwrite(I1{}, 0, tid, rg);
+      });
+    }
+    // last exchange, then the last stage and the stores; the plane is free again after the exchange's last barrier
+    using IPREV = std::integral_constant<int, LS - 1>;
+    exchange_rest(IPREV{}, ILS{});
+    ex.last_phase([&](int tid, RG& rg) {
+      const int t = tid % TILE, pp = tid / TILE;
+      nk_stage_compute<T, SC, LS>(rg.v, pp, tw);
+      constexpr int R = SC::radix(LS), Q = E / R;
+      const uint32_t toff = (uint32_t)(nk_out_row<SC, LS>(pp, 0, 0) * rstride + t);
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int64_t uo = (int64_t)nk_out_row<SC, LS>(0, q, r) * rstride;
+          if constexpr (S == 2)
+            nk_store_stream(nk_ptr32<C2<T>>(base, uo, toff), rg.v[q * R + r]);
+          else
+            nk_store_stream((base + uo) + toff, rg.v[q * R + r]);
+        }
+    });
+  };
+  if constexpr (PF) {
+    for (int64_t v = v0; v < nblk; v += vstep) do_tile(v);
+  } else {
+    if (v0 < nblk) do_tile(v0);  // one tile per workgroup (vstep >= nblk): no loop around the phases
+  }
+}
+
+// pass parameters of the sandwich pipeline (shared by the HIP driver and the host emulation) --------------------
+struct NkPipe3 {
+  NkPass3 p1;   // contiguous first pass
+  NkPassS s2;   // in-place middle-axis pass (3-D), used for F2 and A2
+  NkPassM pm;   // fused first-axis pass
+  NkPassF pf;   // final pass (PAIR = 1)
+  int64_t rs, ss;
+};
+template <typename T>
+static inline int nk_pipe3_colpad() {
+  return 128 / (2 * (int)sizeof(T));  // one 128-byte row segment: every strided tile divides it
+}
+// complex elements of the work array the sandwich needs
+static inline size_t nk_pipe3_work_elems(const NkGeom& g, int colpad, int pad) {
+  const int64_t rs = g.h + colpad;
+  if (g.ndim == 3) return (size_t)g.batch * g.na * ((int64_t)g.nm * rs + pad);
+  return (size_t)g.batch * g.na * rs;
+}
+template <typename T>
+static inline NkPipe3 nk_pipe3_setup(const NkHostPlan& hp, int sign, int pad, double mid_scale) {
+  NkPipe3 q{};
+  const NkGeom& g = hp.g;
+  if (pad < 0) pad = 0;
+  if (pad > NK_WORK_PAD_MAX) pad = NK_WORK_PAD_MAX;
+  const int cp = nk_pipe3_colpad<T>();
+  pad = pad / cp * cp;
+  q.rs = g.h + cp;
+  q.ss = g.ndim == 3 ? (int64_t)g.nm * q.rs + pad : 0;
+  q.p1.g = g;
+  q.p1.g.sign = sign;
+  q.p1.nlines = (int64_t)g.batch * g.na * g.nm;
+  q.p1.rows_per_slab = g.ndim == 3 ? g.nm : g.na;
+  q.p1.rs = q.rs;
+  q.p1.ss = g.ndim == 3 ? q.ss : (int64_t)g.na * q.rs;
+  if (g.ndim == 3) {
+    q.s2 = hp.pb;  // lines over the middle axis inside slab o = batch * na + a: base = work + o * ss, rows rs apart
+    q.s2.outer = (int64_t)g.batch * g.na;
+    q.s2.inner = q.rs;
+    q.s2.blo = 1;
+    q.s2.ss = q.ss;
+  }
+  q.pm.s = hp.pc;
+  q.pm.s.g.sign = sign;
+  q.pm.s.outer = g.batch;
+  q.pm.s.inner = g.ndim == 3 ? (int64_t)g.nm * q.rs : q.rs;
+  q.pm.s.blo = 0;
+  q.pm.s.ss = q.ss;
+  q.pm.rs = q.rs;
+  q.pm.M = g.ndim == 3 ? g.nm : 1;
+  q.pm.mid_scale = mid_scale;
+  q.pf.g = g;
+  q.pf.g.sign = sign;
+  q.pf.A = g.ndim == 3 ? g.na : 1;
+  q.pf.M = g.ndim == 3 ? g.nm : g.na;
+  q.pf.blo = 0;
+  q.pf.ss = q.ss;
+  q.pf.rs = q.rs;
+  return q;
+}

@@ -194,7 +194,9 @@ static inline int nk_host_plan_init(NkHostPlan& P, int ndim, const int64_t* shap
   if (ndim >= 2)
     setup_strided(P.pc, g.na, batch, (int64_t)g.nm * g.h, "NK_TILE_C", P.threads_c, P.lds_c, P.tw_c);
   // + room for the padded slab strides of the strided-first pipeline (nk_pipe2_setup: <= NK_WORK_PAD_MAX per slab)
-  P.work_bytes = ((size_t)(n_total / 2) + (size_t)batch * (g.na > g.nm ? g.na : g.nm) * 8192) * P.csize;
+  // ... and for the rows of nl/2 + 16 columns of the sandwich pipeline (nk_fft3.h)
+  P.work_bytes = ((size_t)(n_total / 2) + (size_t)batch * g.na * g.nm * 16 +
+                  (size_t)batch * (g.na > g.nm ? g.na : g.nm) * 8192) * P.csize;
   P.scratch_bytes = ndim >= 2 ? (size_t)batch * g.nm * g.na * P.csize : 0;
   return NK_OK;
 }

@@ -18,6 +18,7 @@ Latent vectors are ``LatentVec``: ``xi`` (the harmonic-space excitations, field 
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -294,6 +295,8 @@ class FusedModel:
             # octant arrays: the VJP scatter sums (sign-flip images merged in the final transform pass) and the
             # amplitude fields a[pindex], da[pindex] (identical on all sign-flip images: 1/8 of the bytes)
             self.octant_vjp = bool(L.load().nk_plan_octant_vjp(self.plan.handle))
+            # metric applications as ONE five-pass Hartley sandwich (NK_SANDWICH=0: two three-pass transforms)
+            self.sandwich = self.octant_vjp and B.plan_sandwich(self.plan) and os.environ.get("NK_SANDWICH", "1") != "0"
             oct_n = int(np.prod([n // 2 + 1 for n in self.shape]))
             self.field_shape = (oct_n,) if self.octant_vjp else self.shape
             # bin index of the octant points as its own contiguous array: octant fields are plain gathers from it
@@ -383,17 +386,30 @@ class FusedModel:
         self.counters["transforms"] += 1
         return (out, d) if want_derivative else out
 
-    def _vjp(self, lp, w, scale, addend, addend_scale, accumulate, out_xi, dot_out=None, w2=None):
+    def _vjp(self, lp, w, scale, addend, addend_scale, accumulate, out_xi, dot_out=None, w2=None, sandwich=None):
         """out_xi (+)= a t + addend_scale*addend,  self.abar += scatter(xi t),  t = scale * HT(w) (HT(w * w2) with w2);
-        dot_out (device fp64 scalar, needs addend): += sum addend * out_xi, taken in the same epilogue."""
+        dot_out (device fp64 scalar, needs addend): += sum addend * out_xi, taken in the same epilogue.
+        sandwich = (fill_prologue, scale_first, mid, mid_scalar): t = scale * HT(mid_scalar * mid . scale_first *
+        HT(prologue)) through nk_hartley_sandwich instead (w is ignored)."""
         f = self._fuse()
+
+        def run(f):
+            if sandwich is None:
+                B.hartley_fused(self.plan, f)
+            else:
+                B.hartley_sandwich(self.plan, f, sandwich[1])
+
         if dot_out is not None:
             if addend is None or not self.octant_vjp:
                 raise ValueError("dot_out needs an addend and the register-resident transform pipeline")
             f.value = dot_out.data_ptr()
-        f.pro, f.in_ = L.PRO_PLAIN, w.data_ptr()
-        if w2 is not None:
-            f.pro, f.in2 = L.PRO_MUL, w2.data_ptr()
+        if sandwich is not None:
+            sandwich[0](f)
+            f.mul, f.mul_scalar = B.ptr(sandwich[2]), sandwich[3]
+        else:
+            f.pro, f.in_ = L.PRO_PLAIN, w.data_ptr()
+            if w2 is not None:
+                f.pro, f.in2 = L.PRO_MUL, w2.data_ptr()
         f.epi, f.out, f.scale = L.EPI_VJP, out_xi.data_ptr(), self.h_dvol * scale
         f.pidx, f.amp, f.xi = self.pidx.data_ptr(), lp.amp.data_ptr(), lp.x.xi.data_ptr()
         f.afield = B.ptr(lp.afield)
@@ -401,7 +417,7 @@ class FusedModel:
         if self.octant_vjp:
             # the final pass stores one merged sum per octant point; nk_octant_scatter reduces them into the bins
             f.abar, f.w8 = self.abar.data_ptr(), self.w8.data_ptr()
-            B.hartley_fused(self.plan, f)
+            run(f)
             shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
             if self.bin_k2 is not None:
                 L.check(L.load().nk_octant_scatter_k2(len(self.shape), shp, self.w8.data_ptr(), self.pidx.data_ptr(),
@@ -415,10 +431,10 @@ class FusedModel:
         else:
             f.abar, f.abar_copies, f.abar_stride = self.abar_priv.data_ptr(), self.abar_copies, self.abar_stride
             self.abar_priv.zero_()
-            B.hartley_fused(self.plan, f)
+            run(f)
             L.check(L.load().nk_fold_copies(self.nb, self.abar_copies, self.abar_stride, self.abar_priv.data_ptr(),
                                             self.abar.data_ptr(), B._stream()), "nk_fold_copies")
-        self.counters["transforms"] += 1
+        self.counters["transforms"] += 1 if sandwich is None else 2
 
     def _amp_vjp(self, lp):
         L.check(L.load().nk_amp_vjp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(),
@@ -474,16 +490,25 @@ class FusedModel:
         the optional multiple of d (prior metric = 1) rides along in the VJP epilogue of the xi part."""
         L.check(L.load().nk_amp_jvp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(),
                                     lp.state.data_ptr(), d.small.data_ptr(), self.damp.data_ptr(), B._stream()), "nk_amp_jvp")
-        f = self._fuse()
-        f.pro, f.in_, f.in2 = L.PRO_AMP_JVP, d.xi.data_ptr(), lp.x.xi.data_ptr()
-        f.pidx, f.amp, f.damp = self.pidx.data_ptr(), lp.amp.data_ptr(), self.damp.data_ptr()
-        f.afield = B.ptr(lp.afield)
         self._amp_field(self.damp, out=self.dafield)  # da[pindex] through the octant expansion (1/8 of the gathers)
-        f.dafield = self.dafield.data_ptr()
-        f.epi, f.out, f.mul, f.mul_scalar = L.EPI_MUL, self.tmp.data_ptr(), B.ptr(lp.mid), lp.mid_scalar
-        B.hartley_fused(self.plan, f)
-        self._vjp(lp, self.tmp, scale, d.xi if identity else None, identity, not first, out.xi, dot_out=dot_out)
-        self.counters["transforms"] += 1
+
+        def jvp_prologue(f):
+            f.pro, f.in_, f.in2 = L.PRO_AMP_JVP, d.xi.data_ptr(), lp.x.xi.data_ptr()
+            f.pidx, f.amp, f.damp = self.pidx.data_ptr(), lp.amp.data_ptr(), self.damp.data_ptr()
+            f.afield = B.ptr(lp.afield)
+            f.dafield = self.dafield.data_ptr()
+
+        if self.sandwich:
+            # H D H in five passes: the position-space field between the transforms never exists (nk_fft3.h)
+            self._vjp(lp, None, scale, d.xi if identity else None, identity, not first, out.xi, dot_out=dot_out,
+                      sandwich=(jvp_prologue, self.h_dvol, lp.mid, lp.mid_scalar))
+        else:
+            f = self._fuse()
+            jvp_prologue(f)
+            f.epi, f.out, f.mul, f.mul_scalar = L.EPI_MUL, self.tmp.data_ptr(), B.ptr(lp.mid), lp.mid_scalar
+            B.hartley_fused(self.plan, f)
+            self._vjp(lp, self.tmp, scale, d.xi if identity else None, identity, not first, out.xi, dot_out=dot_out)
+            self.counters["transforms"] += 1
         self._amp_vjp(lp)
         if first:
             out.small = B.axpby(1.0, self.latbar, identity, d.small) if identity else B.axpby(1.0, self.latbar)

@@ -132,7 +132,7 @@ static void emu2_contig(NkPassA p, bool is_1d, const nk_fuse& f, const C2<T>* tw
   }
 }
 
-template <typename T, int NL, bool COUPLES, int EC>
+template <typename T, int NL, bool COUPLES, int EC, int PAIR = 0>
 static void emu2_final_ec(const NkPassF& pf0, const nk_fuse& f, const C2<T>* tw, const C2<T>* work, double* energy) {
   using CT = FinalTile<T, NL, EC, COUPLES ? 2 : 1>;
   NkPassF pf = pf0;
@@ -142,7 +142,7 @@ static void emu2_final_ec(const NkPassF& pf0, const nk_fuse& f, const C2<T>* tw,
   const int64_t blocks = (int64_t)pf.g.batch * (pf.A / 2 + 1) * pf.tiles_per_a;
   for (int64_t blk = 0; blk < blocks; ++blk) {
     HostExec<T, SchedF<T, NL>::E> ex(CT::THREADS);
-    nk_final_body<T, NL, CT::TILE, COUPLES, EC>(ex, pf, f, blk, planes.data(), tw, work, energy);
+    nk_final_body<T, NL, CT::TILE, COUPLES, EC, PAIR>(ex, pf, f, blk, planes.data(), tw, work, energy);
   }
 }
 
@@ -155,6 +155,135 @@ static void emu2_final(const NkPassF& pf, const nk_fuse& f, const C2<T>* tw, con
   else if (f.epi == NK_EPI_MUL) emu2_final_ec<T, NL, false, 1>(pf, f, tw, work, energy);
   else if (f.epi == NK_EPI_LIKELIHOOD) emu2_final_ec<T, NL, false, 3>(pf, f, tw, work, energy);
   else emu2_final_ec<T, NL, false, -1>(pf, f, tw, work, energy);
+}
+
+// ---- sandwich pipeline (nk_fft3.h) ----------------------------------------------------------------------
+template <typename T, int NL>
+static void emu3_final(const NkPassF& pf, const nk_fuse& f, const C2<T>* tw, const C2<T>* work, double* energy) {
+  if (f.epi == NK_EPI_VJP && f.afield) emu2_final_ec<T, NL, true, 2, 1>(pf, f, tw, work, energy);  // as nk_launch_final3
+  else if (f.epi == NK_EPI_VJP) emu2_final_ec<T, NL, true, -1, 1>(pf, f, tw, work, energy);
+  else if (f.epi == NK_EPI_AFFINE) emu2_final_ec<T, NL, false, 0, 1>(pf, f, tw, work, energy);
+  else emu2_final_ec<T, NL, false, -1, 1>(pf, f, tw, work, energy);
+}
+
+template <typename T, int H>
+static void emu3_contig(const NkPass3& p, const nk_fuse& f, const C2<T>* tw, const C2<T>* twr, C2<T>* work) {
+  using CT = Contig3Tile<T, H>;
+  std::vector<T> planes(CT::LDS_BYTES / sizeof(T));
+  const int64_t blocks = (p.nlines + CT::TILE - 1) / CT::TILE;
+  for (int64_t blk = 0; blk < blocks; ++blk) {
+    HostExec<T, CT::SC::E> ex(CT::THREADS);
+    if (f.field_octant && f.pro == NK_PRO_AMP) nk_contig3_body<T, H, CT::TILE, 4>(ex, p, f, blk, planes.data(), tw, twr, work);
+    else if (f.field_octant && f.pro == NK_PRO_AMP_JVP) nk_contig3_body<T, H, CT::TILE, 5>(ex, p, f, blk, planes.data(), tw, twr, work);
+    else if (f.pro == NK_PRO_PLAIN) nk_contig3_body<T, H, CT::TILE, 0>(ex, p, f, blk, planes.data(), tw, twr, work);
+    else if (f.pro == NK_PRO_MUL) nk_contig3_body<T, H, CT::TILE, 6>(ex, p, f, blk, planes.data(), tw, twr, work);
+    else nk_contig3_body<T, H, CT::TILE, -1>(ex, p, f, blk, planes.data(), tw, twr, work);
+  }
+}
+
+template <typename Regs>
+struct HostExecR {
+  std::vector<Regs> regs;
+  explicit HostExecR(int n) : regs(n) {}
+  template <typename F>
+  void phase(F f) {
+    for (int tid = 0; tid < (int)regs.size(); ++tid) f(tid, regs[tid]);
+  }
+  template <typename F>
+  void last_phase(F f) {
+    phase(f);
+  }
+};
+
+// cx: complex-plane exchange; grid > 0: persistent launch of `grid` workgroups with register prefetch
+template <typename T, int N>
+static void emu3_mid(NkPassM pm, const nk_fuse& f, const C2<T>* tw, C2<T>* work, bool cx, int grid) {
+  using ST = StridedTile<T, N, true>;
+  pm.s.tl.tile = ST::TILE;
+  pm.s.tiles_per_slab = (int)(pm.s.inner / ST::TILE);
+  std::vector<T> plane(N * ST::TILE * 2 + 16);
+  const int64_t blocks = pm.s.outer * pm.s.tiles_per_slab;
+  const int64_t nwg = grid > 0 ? (grid < blocks ? grid : blocks) : blocks;
+  for (int64_t wg = 0; wg < nwg; ++wg) {
+    HostExecR<MidRegs<T, Sched<T, N>::E>> ex(ST::THREADS);
+#define NK_MID(CXV, MFV, PFV) nk_mid_body<T, N, ST::TILE, CXV, MFV, PFV>(ex, pm, f, wg, nwg, blocks, 1, plane.data(), tw, work)
+    if (grid > 0) {
+      if (cx && f.mul) NK_MID(true, true, true);
+      else if (cx) NK_MID(true, false, true);
+      else if (f.mul) NK_MID(false, true, true);
+      else NK_MID(false, false, true);
+    } else {
+      if (cx && f.mul) NK_MID(true, true, false);
+      else if (cx) NK_MID(true, false, false);
+      else if (f.mul) NK_MID(false, true, false);
+      else NK_MID(false, false, false);
+    }
+#undef NK_MID
+  }
+}
+
+template <typename T>
+static int emu4_run(int ndim, const int64_t* shape, int dtype, int64_t batch, const nk_fuse* f, double scale_first,
+                    int convention, int cx) {
+  NkHostPlan hp;
+  const char* msg;
+  int rc = nk_host_plan_init(hp, ndim, shape, dtype, batch, &msg);
+  if (rc != NK_OK) return rc;
+  const NkGeom& g = hp.g;
+  if (ndim < 2 || !nk_fast_size(g.nl) || !nk_fast_contig_ok(g.h)) return -100;
+  auto tw_a = conv_tw<T>(hp.tw_a), twr = conv_tw<T>(hp.twr_a), tw_b = conv_tw<T>(hp.tw_b), tw_c = conv_tw<T>(hp.tw_c),
+       tw_f = conv_tw<T>(hp.tw_f);
+  const int sign = convention == NK_HARTLEY_CANONICAL ? -1 : 1;
+  const NkPipe3 q = nk_pipe3_setup<T>(hp, sign, 2080, scale_first * (f->mul_scalar != 0.0 ? f->mul_scalar : 1.0));
+  if (!nk_fast_strided_ok<T>(g.na, q.pm.s.inner) || (ndim == 3 && !nk_fast_strided_ok<T>(g.nm, q.rs))) return -100;
+  if (nk_pipe3_work_elems(g, nk_pipe3_colpad<T>(), 2080) * sizeof(C2<T>) > hp.work_bytes) return -101;
+  // poison the work array: every element a later pass reads must have been written by an earlier one
+  std::vector<C2<T>> work(hp.work_bytes / sizeof(C2<T>) + 1, C2<T>{(T)NAN, (T)NAN});
+  double energy = 0.0;
+  switch (g.h) {
+#define NK_CASE(NN) \
+  case NN:          \
+    emu3_contig<T, NN>(q.p1, *f, tw_a.data(), twr.data(), work.data()); \
+    break;
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+  }
+  auto mid_axis = [&]() {
+    switch (g.nm) {
+#define NK_CASE(NN) \
+  case NN:          \
+    emu2_strided<T, NN>(q.s2, 0, *f, tw_b.data(), work.data(), nullptr, &energy); \
+    break;
+      NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+    }
+  };
+  if (ndim == 3) mid_axis();
+  switch (g.na) {
+#define NK_CASE(NN) \
+  case NN:          \
+    emu3_mid<T, NN>(q.pm, *f, tw_c.data(), work.data(), (cx & 1) != 0, cx >= 2 ? 5 : 0); \
+    break;
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+  }
+  if (ndim == 3) mid_axis();
+  switch (g.nl) {
+#define NK_CASE(NN) \
+  case NN:          \
+    emu3_final<T, NN>(q.pf, *f, tw_f.data(), work.data(), &energy); \
+    break;
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+  }
+  if ((f->epi == NK_EPI_LIKELIHOOD || f->epi == NK_EPI_VJP) && f->value) *f->value += energy;
+  return NK_OK;
+}
+
+extern "C" int emu4_hartley_sandwich(int ndim, const int64_t* shape, int dtype, int64_t batch, const nk_fuse* f,
+                                     double scale_first, int convention, int cx) {
+  if (dtype == NK_F32) return emu4_run<float>(ndim, shape, dtype, batch, f, scale_first, convention, cx);
+  return emu4_run<double>(ndim, shape, dtype, batch, f, scale_first, convention, cx);
 }
 
 // strided-first pipeline (ndim >= 2)

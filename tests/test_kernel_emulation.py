@@ -190,3 +190,87 @@ def test_likelihood_epilogue_emulation(shape, fn):
     assert abs(val[0] - (lam.sum() - (d * s).sum())) < 1e-10 * abs(val[0])
     assert np.max(np.abs(gs - (lam - d))) < 1e-11 * np.max(np.abs(lam))
     assert np.max(np.abs(mid - lam)) < 1e-11 * np.max(np.abs(lam))
+
+
+def run_sandwich(f, shape, dtype, scale_first, conv=0, batch=1, cx=0):
+    shp = (ctypes.c_int64 * len(shape))(*shape)
+    fn = lib().emu4_hartley_sandwich
+    fn.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
+                   ctypes.c_double, ctypes.c_int, ctypes.c_int]
+    rc = fn(len(shape), shp, 0 if dtype == np.float32 else 1, batch, ctypes.addressof(f), scale_first, conv, cx)
+    assert rc == 0, rc
+
+
+@pytest.mark.parametrize("shape", [(64, 128), (128, 128), (64, 256), (64, 64, 128), (128, 64, 128), (64, 128, 256)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("cx", [0, 1, 2, 3])
+def test_sandwich_emulation(shape, dtype, cx):
+    """nk_hartley_sandwich (five-pass H D H, nk_fft3.h) against two scipy transforms: plain, both conventions, a
+    batch of 2, constant and field diagonal.  cx bit 0: complex-plane exchange of the fused pass, cx >= 2: persistent
+    workgroups (5 of them) with register prefetch of the next tile."""
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(2,) + shape).astype(dtype)
+    m = rng.normal(size=(2,) + shape).astype(dtype)
+    axes = tuple(range(1, len(shape) + 1))
+    tol = 1e-12 if dtype == np.float64 else 5e-5
+    for conv, sg in ((0, 1.0), (1, -1.0)):
+        H = lambda a: (lambda F: F.real + sg * F.imag)(scipy.fft.fftn(a.astype(np.float64), axes=axes))  # noqa: E731
+        for mul in (None, m):
+            out = np.empty_like(x)
+            f = Fuse()
+            f.in_, f.out, f.scale, f.offset, f.mul_scalar = x.ctypes.data, out.ctypes.data, 0.5, 0.75, 1.5
+            if mul is not None:
+                f.mul = mul.ctypes.data
+            run_sandwich(f, shape, dtype, 0.25, conv, batch=2, cx=cx)
+            mid = 1.5 * 0.25 * H(x) * (1.0 if mul is None else mul.astype(np.float64))
+            ref = 0.5 * H(mid) + 0.75
+            err = np.max(np.abs(out - ref)) / np.max(np.abs(ref))
+            assert err < tol, (conv, mul is not None, err)
+
+
+@pytest.mark.parametrize("shape", [(64, 128), (64, 64, 128), (64, 64, 1024)])
+def test_sandwich_fused_emulation(shape):
+    """The metric application through the sandwich: AMP_JVP prologue with octant fields, field diagonal, VJP epilogue
+    with octant sums, addend, accumulation and the fused curvature dot."""
+    rng = np.random.default_rng(6)
+    nb = 7
+    pidx = rng.integers(0, nb, size=shape).astype(np.int32)
+    idx = np.indices(shape)
+    for d in range(len(shape)):
+        flip = tuple((-idx[e]) % shape[e] if e == d else idx[e] for e in range(len(shape)))
+        pidx = np.minimum(pidx, pidx[flip])
+    pidx = pidx.astype(np.int32)
+    amp, damp = rng.normal(size=nb), rng.normal(size=nb)
+    xi, dxi, addend, mid = (rng.normal(size=shape) for _ in range(4))
+    H = lambda a: (lambda F: F.real + F.imag)(scipy.fft.fftn(a))  # noqa: E731
+    oct_sl = tuple(slice(0, s // 2 + 1) for s in shape)
+    af8, daf8 = np.ascontiguousarray(amp[pidx][oct_sl]), np.ascontiguousarray(damp[pidx][oct_sl])
+    for use_mid in (False, True):
+        for octant in (True, False):
+            w8 = np.full(af8.shape, np.nan)
+            out = np.full(shape, 3.0)
+            abar = np.zeros(nb)
+            dq = np.zeros(1)
+            f = Fuse()
+            f.pro, f.in_, f.in2, f.pidx, f.amp, f.damp = 2, dxi.ctypes.data, xi.ctypes.data, pidx.ctypes.data, amp.ctypes.data, damp.ctypes.data
+            f.mul_scalar = 0.7
+            if use_mid:
+                f.mul = mid.ctypes.data
+            f.epi, f.out, f.scale = 2, out.ctypes.data, 0.25
+            f.xi, f.abar = xi.ctypes.data, abar.ctypes.data
+            f.addend, f.addend_scale, f.accumulate = addend.ctypes.data, 2.0, 1
+            if octant:
+                f.afield, f.dafield, f.field_octant, f.w8 = af8.ctypes.data, daf8.ctypes.data, 1, w8.ctypes.data
+                f.value = dq.ctypes.data
+            run_sandwich(f, shape, np.float64, 0.5)
+            s = 0.5 * H(amp[pidx] * dxi + damp[pidx] * xi)
+            t = 0.25 * H(0.7 * (mid if use_mid else 1.0) * s)
+            ref = amp[pidx] * t + 2.0 * addend + 3.0
+            assert np.max(np.abs(out - ref)) < 1e-11 * np.max(np.abs(t)), (use_mid, octant)
+            ref_abar = np.bincount(pidx.ravel(), weights=(xi * t).ravel(), minlength=nb)
+            if octant:
+                got = np.bincount(pidx[oct_sl].ravel(), weights=w8.ravel(), minlength=nb)
+                assert abs(dq[0] - np.sum(addend * out)) < 1e-11 * np.sum(np.abs(addend * out))
+            else:
+                got = abar
+            assert np.max(np.abs(got - ref_abar)) < 1e-10 * max(1.0, np.max(np.abs(ref_abar)))

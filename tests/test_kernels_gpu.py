@@ -187,3 +187,43 @@ def test_cumsum(n, dtype):
     y = xd.clone()
     B.cumsum(y, out=y)  # in place
     assert np.max(np.abs(y.cpu().numpy() - ref)) < tol * scale
+
+
+@pytest.mark.parametrize("shape,dtype", [((64, 128), torch.float64), ((2048, 2048), torch.float64), ((256, 128), torch.float32),
+                                         ((64, 64, 128), torch.float64), ((128, 256, 256), torch.float32),
+                                         ((256, 256, 256), torch.float64), ((64, 128, 4096), torch.float32),
+                                         ((512, 512, 512), torch.float32)])
+@pytest.mark.parametrize("field_mid", [False, True])
+def test_sandwich_equals_two_transforms(shape, dtype, field_mid):
+    """nk_hartley_sandwich (five passes, no position-space intermediate; nk_fft3.h) against the same H D H computed
+    with two nk_hartley_fused calls, plain prologue / affine epilogue, both conventions."""
+    from nifty_amd import _lib as L
+    from nifty_amd import backend as B
+    from nifty_amd import config
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(shape, dtype=dtype, device="cuda", generator=g)
+    m = torch.randn(shape, dtype=dtype, device="cuda", generator=g) if field_mid else None
+    plan = B.get_plan(shape, dtype, 1, x.device)
+    assert B.plan_sandwich(plan)
+    tol = 1e-11 if dtype == torch.float64 else 3e-4
+    n = x.numel()
+    try:
+        for conv in ("non_canonical_hartley", "canonical_hartley"):
+            config.update("hartley_convention", conv)
+            tmp, ref, out = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+            f = L.Fuse()
+            f.pro, f.in_, f.epi, f.out, f.scale = L.PRO_PLAIN, x.data_ptr(), L.EPI_MUL, tmp.data_ptr(), 0.25
+            f.mul, f.mul_scalar = B.ptr(m), 1.5
+            B.hartley_fused(plan, f)
+            f = L.Fuse()
+            f.pro, f.in_, f.epi, f.out, f.scale, f.offset = L.PRO_PLAIN, tmp.data_ptr(), L.EPI_AFFINE, ref.data_ptr(), 2.0 / n, 0.5
+            B.hartley_fused(plan, f)
+            f = L.Fuse()
+            f.pro, f.in_, f.epi, f.out, f.scale, f.offset = L.PRO_PLAIN, x.data_ptr(), L.EPI_AFFINE, out.data_ptr(), 2.0 / n, 0.5
+            f.mul, f.mul_scalar = B.ptr(m), 1.5
+            B.hartley_sandwich(plan, f, 0.25)
+            err = ((out - ref).abs().max() / ref.abs().max()).item()
+            assert err < tol, (conv, err)
+    finally:
+        config.update("hartley_convention", "non_canonical_hartley")

@@ -37,3 +37,17 @@ report("metric")
 for _ in range(3):
     s = model.signal(x)
 report("signal")
+if B.plan_sandwich(model.plan):
+    out = torch.empty_like(d.xi)
+    for _ in range(3):
+        f = L.Fuse()
+        f.pro, f.in_, f.epi, f.out, f.scale, f.mul_scalar = L.PRO_PLAIN, d.xi.data_ptr(), L.EPI_AFFINE, out.data_ptr(), 1.0 / N, 1.0
+        B.hartley_sandwich(model.plan, f, 1.0)
+    report("sandwich")
+    mid = torch.rand_like(d.xi)
+    for _ in range(3):
+        f = L.Fuse()
+        f.pro, f.in_, f.epi, f.out, f.scale, f.mul_scalar = L.PRO_PLAIN, d.xi.data_ptr(), L.EPI_AFFINE, out.data_ptr(), 1.0 / N, 1.0
+        f.mul = mid.data_ptr()
+        B.hartley_sandwich(model.plan, f, 1.0)
+    report("sandwich+mid")
