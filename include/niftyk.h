@@ -99,6 +99,9 @@ typedef struct nk_fuse {
                            AMP_JVP(afield + dafield) and, for the VJP epilogue, afield set (NK_ERR_INVALID otherwise) */
   int value_slots;      /* leave 0.  Set by the library itself when it spreads the per-workgroup atomics on *value over
                            several accumulators in the workspace (folded into *value after the pass) */
+  const int32_t* pidx_octant; /* optional, nk_hartley_sandwich with field_octant and the AMP_JVP prologue: the bin index of
+                           the OCTANT points [A/2+1][M/2+1][NL/2+1]; with it (and dampT) the prologue gathers da from the
+                           table itself and `dafield` is not needed -- no per-application expansion of da[pidx] */
 } nk_fuse;
 
 typedef struct nk_plan nk_plan;

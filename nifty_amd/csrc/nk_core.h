@@ -390,6 +390,7 @@ NK_HD C2<T> nk_load_pair_u(const T* p) {
 // pair prologues with OCTANT amplitude fields: j = octant offset of the lower of the two folded positions of the
 // adjacent reals (i, i+1); desc: the pair is stored in descending order (mirrored half of the last axis)
 //   PC = 4: afield8 * in,  5: afield8 * in + dafield8 * in2
+//   PC = 7: afield8 * in + dampT[pidx_octant] * in2   (da gathered from its table: no expanded da field)
 template <typename T, int PC>
 NK_HD C2<T> nk_prologue_oct(const NkFuse& f, int64_t iu, uint32_t it, uint32_t j, bool desc) {
   const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
@@ -397,6 +398,13 @@ NK_HD C2<T> nk_prologue_oct(const NkFuse& f, int64_t iu, uint32_t it, uint32_t j
   if (desc) m = C2<T>{m.y, m.x};
   if constexpr (PC == 4) {
     return C2<T>{m.x * a.x, m.y * a.y};
+  } else if constexpr (PC == 7) {
+    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
+    const NkPairU<int32_t> p = *reinterpret_cast<const NkPairU<int32_t>*>(f.pidx_octant + j);
+    const T* dt = (const T*)f.dampT;
+    C2<T> dm{dt[p.x], dt[p.y]};
+    if (desc) dm = C2<T>{dm.y, dm.x};
+    return C2<T>{m.x * a.x + dm.x * x.x, m.y * a.y + dm.y * x.y};
   } else {
     const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
     C2<T> dm = nk_load_pair_u<T>((const T*)f.dafield + j);

@@ -210,19 +210,21 @@ __global__ void __launch_bounds__((ContigTile<T, H>::THREADS))
 #define NK_S1_TWO_WG 0
 #endif
 template <typename T, int N, int MODE, int PC>
-__global__ void __launch_bounds__((StridedTile<T, N>::THREADS),
-                                  (MODE == 3 && NK_S1_TWO_WG && StridedTile<T, N>::LDS_BYTES <= 80 * 1024 &&
-                                           StridedTile<T, N>::THREADS <= 512
-                                       ? 2 * StridedTile<T, N>::THREADS / 256
-                                       : NK_S0_WAVES))
+__global__ void __launch_bounds__((StridedTile<T, N, nk_strided_cx<MODE, PC>(), MODE>::THREADS),
+                                  (StridedTile<T, N, nk_strided_cx<MODE, PC>(), MODE>::SC::E == 64
+                                       ? 2  // 256 threads x 64 elements: two workgroups per CU
+                                       : (MODE == 3 && NK_S1_TWO_WG && StridedTile<T, N>::LDS_BYTES <= 80 * 1024 &&
+                                                  StridedTile<T, N>::THREADS <= 512
+                                              ? 2 * StridedTile<T, N>::THREADS / 256
+                                              : NK_S0_WAVES)))
     k2_strided(NkPassS p, NkFuse f, const C2<T>* __restrict__ tw, C2<T>* __restrict__ work, C2<T>* __restrict__ scratch, int xmap) {
   extern __shared__ __align__(16) unsigned char smem[];
-  DeviceExec<T, Sched<T, N>::E> ex;
+  using ST = StridedTile<T, N, nk_strided_cx<MODE, PC>(), MODE>;
+  DeviceExec<T, ST::SC::E> ex;
   double acc = 0.0;
   // the octant prologues bring their own XCD-aware order (nk_oct_block_remap)
   constexpr bool OCT = MODE == 3 && (PC == 4 || PC == 5);
   const int64_t blk = (xmap && !OCT) ? nk_xcd_contig(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
-  using ST = StridedTile<T, N, nk_strided_cx<MODE, PC>()>;
   C2<T>* tw_lds = ST::TWLDS ? reinterpret_cast<C2<T>*>(smem + ST::LDS_BYTES) : nullptr;
   nk_strided_body<T, N, ST::TILE, MODE, PC, nk_strided_cx<MODE, PC>()>(ex, p, f, blk, (T*)smem, tw, work, scratch, &acc, tw_lds);
   (void)acc;
@@ -328,7 +330,7 @@ static int nk_launch_contig(const NkPassA& pa, const NkFuse& f, const C2<T>* tw,
 
 template <typename T, int N, int MODE, int PC>
 static int nk_launch_strided_pc(NkPassS ps, const NkFuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch, hipStream_t st) {
-  using ST = StridedTile<T, N, nk_strided_cx<MODE, PC>()>;
+  using ST = StridedTile<T, N, nk_strided_cx<MODE, PC>(), MODE>;
   auto kern = k2_strided<T, N, MODE, PC>;
   static unsigned long long attr_mask = 0;  // per-device attribute
   if (ST::LDS_TOTAL > 64 * 1024 && nk_first_on_device(attr_mask)) {
@@ -414,6 +416,7 @@ static int nk_launch_contig3(const NkPass3& p3, const NkFuse& f, const C2<T>* tw
 template <typename T, int H>
 static int nk_launch_contig3_pc(const NkPass3& p3, const NkFuse& f, const C2<T>* tw, const C2<T>* twr, C2<T>* work, hipStream_t st) {
   if (f.field_octant && f.pro == NK_PRO_AMP) return nk_launch_contig3<T, H, 4>(p3, f, tw, twr, work, st);
+  if (f.field_octant && f.pro == NK_PRO_AMP_JVP && f.pidx_octant && f.dampT) return nk_launch_contig3<T, H, 7>(p3, f, tw, twr, work, st);
   if (f.field_octant && f.pro == NK_PRO_AMP_JVP) return nk_launch_contig3<T, H, 5>(p3, f, tw, twr, work, st);
   if (f.pro == NK_PRO_PLAIN) return nk_launch_contig3<T, H, 0>(p3, f, tw, twr, work, st);
   if (f.pro == NK_PRO_MUL) return nk_launch_contig3<T, H, 6>(p3, f, tw, twr, work, st);
@@ -976,8 +979,9 @@ extern "C" int nk_hartley_sandwich(const nk_plan* P, const nk_fuse* fuse, double
     return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: LIKELIHOOD epilogue needs data and value");
   if (fuse->field_octant) {
     const bool amp_pro = fuse->pro == NK_PRO_AMP || fuse->pro == NK_PRO_AMP_JVP;
-    if ((amp_pro && !fuse->afield) || (fuse->pro == NK_PRO_AMP_JVP && !fuse->dafield) || (fuse->epi == NK_EPI_VJP && !fuse->afield))
-      return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: field_octant needs afield (and dafield for AMP_JVP)");
+    if ((amp_pro && !fuse->afield) || (fuse->pro == NK_PRO_AMP_JVP && !fuse->dafield && !(fuse->pidx_octant && fuse->dampT)) ||
+        (fuse->epi == NK_EPI_VJP && !fuse->afield))
+      return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: field_octant needs afield (and dafield, or pidx_octant + dampT, for AMP_JVP)");
     const NkGeom& g = P->hp.g;
     if ((int64_t)(g.na / 2 + 1) * (g.nm / 2 + 1) * (g.nl / 2 + 1) >= ((int64_t)1 << 31))
       return nk_set_error(NK_ERR_UNSUPPORTED, "nk_hartley_sandwich: octant field too large (>= 2^31 elements)");

@@ -17,6 +17,8 @@
 // test-only host emulation (tests/emu) runs every phase for all thread ids in turn with the per-thread
 // registers kept in an array.
 #pragma once
+#include <type_traits>
+
 #include "nk_fft_phases.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -160,11 +162,7 @@ NK_SCHED(float, 64, 8, 2, 8, 8, 1);
 NK_SCHED(float, 128, 16, 2, 16, 8, 1);
 NK_SCHED(float, 256, 16, 2, 16, 16, 1);
 NK_SCHED(float, 512, 32, 2, 32, 16, 1);
-#ifdef NK_E64
-NK_SCHED(float, 1024, 64, 2, 64, 16, 1);  // 256 threads x 64 elements: two workgroups per CU
-#else
 NK_SCHED(float, 1024, 32, 2, 32, 32, 1);
-#endif
 NK_SCHED(float, 2048, 32, 3, 32, 32, 2);
 NK_SCHED(float, 4096, 32, 3, 32, 32, 4);
 NK_SCHED(double, 64, 8, 2, 8, 8, 1);
@@ -175,6 +173,19 @@ NK_SCHED(double, 1024, 16, 3, 16, 16, 4);
 NK_SCHED(double, 2048, 16, 3, 16, 16, 8);
 NK_SCHED(double, 4096, 16, 3, 16, 16, 16);
 #undef NK_SCHED
+
+// schedule of the plain IN-PLACE strided pass (MODE 0): 1024 fp32 lines as 256 threads x 64 elements (radix 64 x 16) --
+// 250 VGPRs, 64 KiB of LDS, so TWO independent workgroups share a CU and one computes while the other waits for its
+// rows (1024^3 fp32: middle-axis pass 1.80 -> 1.68 ms, first-axis pass 1.95 -> 1.89 ms).  The first pass with its
+// prologue operands and the fused middle pass of the sandwich spill with 64 elements per thread and keep Sched.
+template <typename T, int N>
+struct SchedW : Sched<T, N> {};
+#ifndef NK_NO_WIDE
+template <>
+struct SchedW<float, 1024> : SchedDef<1024, 64, 2, 64, 16, 1> {};
+#endif
+template <typename T, int N, int MODE>
+using StridedSched = std::conditional_t<MODE == 0, SchedW<T, N>, Sched<T, N>>;
 
 // schedule of the FINAL (contiguous) pass: E = 16 everywhere -- twice the threads per line pair, half the LDS
 // tile per workgroup -> twice the resident waves for the latency-bound epilogue
@@ -218,9 +229,10 @@ template <int MODE, int PC>
 constexpr bool nk_strided_cx() {
   return MODE == 3 && (PC == 0 || PC == 1 || PC == 6);
 }
-template <typename T, int N, bool CX = false>
+template <typename T, int N, bool CX = false, int MODE = 3>
 struct StridedTile {
-  static constexpr int P = Sched<T, N>::P;
+  using SC = StridedSched<T, N, MODE>;
+  static constexpr int P = SC::P;
   static constexpr int want = 128 / (2 * (int)sizeof(T));
   static constexpr int by_threads = 1024 / P;
   static constexpr int by_lds = (128 * 1024) / (N * (int)sizeof(T));
@@ -233,7 +245,7 @@ struct StridedTile {
   // through one scalar plane (half the LDS: two workgroups per CU, the fp64 kernels).  Measured at 1024^3 fp32
   // (gpurun_out/r02c_probe.log): plain first pass 1.84 -> 1.76 ms; the in-place pass (1.95 -> 2.00 ms) and the
   // register-heavy JVP prologues (they spill with the complex plane: 3.3 -> 5.7 ms) keep the split exchange -> CX.
-  static constexpr bool CPLX = CX && sizeof(T) == 4 && Sched<T, N>::E == 32 && P * TILE == 512 && N * TILE * 8 <= 128 * 1024;
+  static constexpr bool CPLX = CX && sizeof(T) == 4 && SC::E == 32 && P * TILE == 512 && N * TILE * 8 <= 128 * 1024;
   static constexpr int LDS_BYTES = N * TILE * (int)sizeof(T) * (CPLX ? 2 : 1);
   // TWLDS: the workgroup copies the axis' twiddle table (N complex) behind the exchange plane once and the stages read
   // it with ds_read instead of global loads.  The ~R twiddle loads per thread and stage are vector-memory instructions
@@ -489,9 +501,9 @@ template <typename T, int N, int TILE, int MODE, int PC, bool CX = false, typena
 NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t blk, T* plane,
                            const C2<T>* __restrict__ tw_global, C2<T>* __restrict__ work, C2<T>* __restrict__ scratch,
                            double* acc_out, C2<T>* tw_lds = nullptr) {
-  using SC = Sched<T, N>;
+  using SC = StridedSched<T, N, MODE>;
   constexpr int E = SC::E, S = SC::S;
-  constexpr bool CPLX = StridedTile<T, N, CX>::CPLX && TILE == StridedTile<T, N, CX>::TILE;
+  constexpr bool CPLX = StridedTile<T, N, CX, MODE>::CPLX && TILE == StridedTile<T, N, CX, MODE>::TILE;
   // twiddles of the later stages: from the workgroup's LDS copy when the caller provides the room (StridedTile::TWLDS)
   const C2<T>* tw = tw_lds ? tw_lds : tw_global;
   [[maybe_unused]] C2<T>* cplane = reinterpret_cast<C2<T>*>(plane);
@@ -1231,7 +1243,7 @@ static inline int nk_fast_strided_tile(int n) {
   switch (n) {
 #define NK_CASE(NN) \
   case NN:          \
-    return StridedTile<T, NN>::TILE;
+    return StridedTile<T, NN>::TILE > StridedTile<T, NN, false, 0>::TILE ? StridedTile<T, NN>::TILE : StridedTile<T, NN, false, 0>::TILE;
     NK_FAST_SIZES(NK_CASE)
 #undef NK_CASE
     default:

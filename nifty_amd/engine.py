@@ -490,13 +490,23 @@ class FusedModel:
         the optional multiple of d (prior metric = 1) rides along in the VJP epilogue of the xi part."""
         L.check(L.load().nk_amp_jvp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(),
                                     lp.state.data_ptr(), d.small.data_ptr(), self.damp.data_ptr(), B._stream()), "nk_amp_jvp")
-        self._amp_field(self.damp, out=self.dafield)  # da[pindex] through the octant expansion (1/8 of the gathers)
+        # da[pindex] is expanded to an octant field once per application (1/8 of the gathers, 0.72 ms at 1024^3 fp32).
+        # NK_DA_GATHER=1 lets the sandwich's first pass gather it from the table through the octant bin index instead:
+        # measured 3.3 -> 8.9 ms for that pass (dependent gathers in a latency-bound row kernel) -- not the default
+        gather_da = self.sandwich and self.pidx8 is not None and os.environ.get("NK_DA_GATHER", "0") == "1"
+        if gather_da:
+            damp_t = self.damp if self.tdtype == torch.float64 else self.damp.to(self.tdtype)
+        else:
+            self._amp_field(self.damp, out=self.dafield)
 
         def jvp_prologue(f):
             f.pro, f.in_, f.in2 = L.PRO_AMP_JVP, d.xi.data_ptr(), lp.x.xi.data_ptr()
             f.pidx, f.amp, f.damp = self.pidx.data_ptr(), lp.amp.data_ptr(), self.damp.data_ptr()
             f.afield = B.ptr(lp.afield)
-            f.dafield = self.dafield.data_ptr()
+            if gather_da:
+                f.pidx_octant, f.dampT = self.pidx8.data_ptr(), damp_t.data_ptr()
+            else:
+                f.dafield = self.dafield.data_ptr()
 
         if self.sandwich:
             # H D H in five passes: the position-space field between the transforms never exists (nk_fft3.h)

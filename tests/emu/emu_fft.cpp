@@ -94,17 +94,16 @@ struct HostExec {
   }
 };
 
-template <typename T, int N>
-static void emu2_strided(NkPassS p, int mode, const nk_fuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch,
-                         double* energy) {
-  using ST = StridedTile<T, N>;
+template <typename T, int N, int MODE>
+static void emu2_strided_m(NkPassS p, const nk_fuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch, double* energy) {
+  using ST = StridedTile<T, N, false, MODE>;
   p.tl.tile = ST::TILE;
   p.tiles_per_slab = (int)(p.inner / ST::TILE);
   std::vector<T> plane(StridedTile<T, N, true>::LDS_BYTES / sizeof(T));  // room for the complex-plane classes
   const int64_t blocks = p.outer * p.tiles_per_slab;
   for (int64_t blk = 0; blk < blocks; ++blk) {
-    HostExec<T, Sched<T, N>::E> ex(ST::THREADS);
-    if (mode == 3) {
+    HostExec<T, ST::SC::E> ex(ST::THREADS);
+    if constexpr (MODE == 3) {
       if (f.field_octant && f.pro == NK_PRO_AMP) nk_strided_body<T, N, ST::TILE, 3, 4>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
       else if (f.field_octant && f.pro == NK_PRO_AMP_JVP) nk_strided_body<T, N, ST::TILE, 3, 5>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
       else if (f.pro == NK_PRO_PLAIN) nk_strided_body<T, N, ST::TILE, 3, 0, true>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
@@ -117,6 +116,12 @@ static void emu2_strided(NkPassS p, int mode, const nk_fuse& f, const C2<T>* tw,
       nk_strided_body<T, N, ST::TILE, 0, -1>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
     }
   }
+}
+template <typename T, int N>
+static void emu2_strided(NkPassS p, int mode, const nk_fuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch,
+                         double* energy) {
+  if (mode == 3) emu2_strided_m<T, N, 3>(p, f, tw, work, scratch, energy);
+  else emu2_strided_m<T, N, 0>(p, f, tw, work, scratch, energy);
 }
 
 template <typename T, int H>
@@ -174,6 +179,7 @@ static void emu3_contig(const NkPass3& p, const nk_fuse& f, const C2<T>* tw, con
   for (int64_t blk = 0; blk < blocks; ++blk) {
     HostExec<T, CT::SC::E> ex(CT::THREADS);
     if (f.field_octant && f.pro == NK_PRO_AMP) nk_contig3_body<T, H, CT::TILE, 4>(ex, p, f, blk, planes.data(), tw, twr, work);
+    else if (f.field_octant && f.pro == NK_PRO_AMP_JVP && f.pidx_octant && f.dampT) nk_contig3_body<T, H, CT::TILE, 7>(ex, p, f, blk, planes.data(), tw, twr, work);
     else if (f.field_octant && f.pro == NK_PRO_AMP_JVP) nk_contig3_body<T, H, CT::TILE, 5>(ex, p, f, blk, planes.data(), tw, twr, work);
     else if (f.pro == NK_PRO_PLAIN) nk_contig3_body<T, H, CT::TILE, 0>(ex, p, f, blk, planes.data(), tw, twr, work);
     else if (f.pro == NK_PRO_MUL) nk_contig3_body<T, H, CT::TILE, 6>(ex, p, f, blk, planes.data(), tw, twr, work);

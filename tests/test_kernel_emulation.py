@@ -245,6 +245,7 @@ def test_sandwich_fused_emulation(shape):
     H = lambda a: (lambda F: F.real + F.imag)(scipy.fft.fftn(a))  # noqa: E731
     oct_sl = tuple(slice(0, s // 2 + 1) for s in shape)
     af8, daf8 = np.ascontiguousarray(amp[pidx][oct_sl]), np.ascontiguousarray(damp[pidx][oct_sl])
+    pidx8 = np.ascontiguousarray(pidx[oct_sl])
     for use_mid in (False, True):
         for octant in (True, False):
             w8 = np.full(af8.shape, np.nan)
@@ -260,7 +261,11 @@ def test_sandwich_fused_emulation(shape):
             f.xi, f.abar = xi.ctypes.data, abar.ctypes.data
             f.addend, f.addend_scale, f.accumulate = addend.ctypes.data, 2.0, 1
             if octant:
-                f.afield, f.dafield, f.field_octant, f.w8 = af8.ctypes.data, daf8.ctypes.data, 1, w8.ctypes.data
+                f.afield, f.field_octant, f.w8 = af8.ctypes.data, 1, w8.ctypes.data
+                if use_mid:  # da gathered from its table through the octant bin index instead of an expanded field
+                    f.pidx_octant, f.dampT = pidx8.ctypes.data, damp.ctypes.data
+                else:
+                    f.dafield = daf8.ctypes.data
                 f.value = dq.ctypes.data
             run_sandwich(f, shape, np.float64, 0.5)
             s = 0.5 * H(amp[pidx] * dxi + damp[pidx] * xi)
@@ -274,3 +279,27 @@ def test_sandwich_fused_emulation(shape):
             else:
                 got = abar
             assert np.max(np.abs(got - ref_abar)) < 1e-10 * max(1.0, np.max(np.abs(ref_abar)))
+
+
+def test_wide_schedule_emulation():
+    """The in-place strided pass of 1024-point fp32 lines runs 256 threads x 64 elements (radix 64 x 16, SchedW): first
+    axis of a 3-D strided-first transform and the middle-axis passes of a sandwich."""
+    rng = np.random.default_rng(8)
+    shape = (1024, 64, 128)
+    x = rng.normal(size=shape).astype(np.float32)
+    F = scipy.fft.fftn(x.astype(np.float64))
+    ref = F.real + F.imag
+    out = np.empty_like(x)
+    f = Fuse()
+    f.in_, f.out, f.scale = x.ctypes.data, out.ctypes.data, 1.0
+    run(f, shape, np.float32, fn="emu3_hartley_fused")
+    assert np.max(np.abs(out - ref)) / np.max(np.abs(ref)) < 2e-5
+    shape = (64, 1024, 128)
+    x = rng.normal(size=shape).astype(np.float32)
+    H = lambda a: (lambda F: F.real + F.imag)(scipy.fft.fftn(a.astype(np.float64)))  # noqa: E731
+    out = np.empty_like(x)
+    f = Fuse()
+    f.in_, f.out, f.scale, f.mul_scalar = x.ctypes.data, out.ctypes.data, 1.0 / x.size, 1.0
+    run_sandwich(f, shape, np.float32, 1.0)
+    ref = H(H(x)) / x.size
+    assert np.max(np.abs(out - ref)) / np.max(np.abs(ref)) < 5e-5
