@@ -445,21 +445,36 @@ static int nk_dispatch_contig3(int h, const NkPass3& p3, const NkFuse& f, const 
 #ifndef NK_MID_PF
 #define NK_MID_PF 0   // persistent workgroups that prefetch the next tile into registers
 #endif
+#ifndef NK_MID_WIDE_XM
+#define NK_MID_WIDE_XM 2
+#endif
+#ifndef NK_MID_WIDE
+#define NK_MID_WIDE 0  // 1: wide schedule (SchedW, two workgroups per CU) for the fused middle kernel -- spills 116..464 B per lane, 3.1 -> 5.0 ms
+#endif
+// tile / schedule / exchange mode of the fused middle kernel
+template <typename T, int N>
+struct MidCfg {
+  static constexpr bool WIDE = NK_MID_WIDE && SchedW<T, N>::E == 64;
+  using ST = StridedTile<T, N, !WIDE && NK_MID_CX != 0, WIDE ? 0 : 3>;
+  using SC = typename ST::SC;
+  static constexpr int XM = WIDE ? NK_MID_WIDE_XM : (ST::CPLX ? 1 : 0);
+};
 template <typename T, int N, bool MF>
-__global__ void __launch_bounds__((StridedTile<T, N, NK_MID_CX != 0>::THREADS),
-                                  (NK_MID_WAVES > 0 ? NK_MID_WAVES : StridedTile<T, N, NK_MID_CX != 0>::THREADS <= 256 ? 2 : 1))
+__global__ void __launch_bounds__((MidCfg<T, N>::ST::THREADS),
+                                  (NK_MID_WAVES > 0 ? NK_MID_WAVES : MidCfg<T, N>::ST::THREADS <= 256 ? 2 : 1))
     k3_mid(NkPassM pm, NkFuse f, const C2<T>* __restrict__ tw, C2<T>* __restrict__ work, int64_t nblk, int xmap) {
   extern __shared__ __align__(16) unsigned char smem[];
-  using ST = StridedTile<T, N, NK_MID_CX != 0>;
-  DeviceExecR<MidRegs<T, Sched<T, N>::E>> ex;
+  using CF = MidCfg<T, N>;
+  using ST = typename CF::ST;
+  DeviceExecR<MidRegs<T, CF::SC::E, NK_MID_PF != 0>> ex;
   C2<T>* tw_lds = ST::TWLDS ? reinterpret_cast<C2<T>*>(smem + ST::LDS_BYTES) : nullptr;
-  nk_mid_body<T, N, ST::TILE, ST::CPLX, MF, NK_MID_PF != 0>(ex, pm, f, (int64_t)blockIdx.x, (int64_t)gridDim.x, nblk, xmap, (T*)smem,
-                                                            tw, work, tw_lds);
+  nk_mid_body<T, N, ST::TILE, CF::XM, MF, NK_MID_PF != 0, typename CF::SC>(ex, pm, f, (int64_t)blockIdx.x, (int64_t)gridDim.x, nblk,
+                                                                           xmap, (T*)smem, tw, work, tw_lds);
 }
 
 template <typename T, int N, bool MF>
 static int nk_launch_mid(NkPassM pm, const NkFuse& f, const C2<T>* tw, C2<T>* work, hipStream_t st) {
-  using ST = StridedTile<T, N, NK_MID_CX != 0>;
+  using ST = typename MidCfg<T, N>::ST;
   auto kern = k3_mid<T, N, MF>;
   static unsigned long long attr_mask = 0;  // per-device attribute
   if (ST::LDS_TOTAL > 64 * 1024 && nk_first_on_device(attr_mask)) {

@@ -207,9 +207,9 @@ struct NkPassM {
 };
 
 // registers of the fused middle pass: the pass registers plus the prefetched first-stage inputs of the NEXT tile
-template <typename T, int E>
+template <typename T, int E, bool PF = true>
 struct MidRegs : PassRegs<T, E> {
-  C2<T> nxt[E];
+  C2<T> nxt[PF ? E : 1];
 };
 #ifndef NK_HOST_EMU
 template <typename Regs>
@@ -232,13 +232,16 @@ struct DeviceExecR {
 // workgroup: vstep >= nblk).  One workgroup fills a CU (registers, LDS) and the two line transforms cost about as much
 // VALU time as the tile's HBM traffic takes (1024 x 16 fp32: ~11 us each), so with PF the loads of the NEXT tile are
 // issued into spare registers before the current tile's first butterfly and land while it is computed.
-// CX: exchanges through one complex plane (N*TILE*2*sizeof(T) bytes) instead of two half rounds through a scalar plane
+// XM: exchange mode.  0: two half rounds (real, imaginary parts) through a scalar plane of N*TILE*sizeof(T) bytes;
+//     1: one round through a complex plane (twice the LDS);  2: a complex plane of HALF the columns, used twice (columns
+//     t < TILE/2, then the rest) -- the LDS of mode 0 without its E temporaries per thread, which is what lets the
+//     wide schedule (64 elements per thread, two workgroups per CU) run without spills
 // MF: the diagonal is a field (fuse.mul), else only the scalar mid_scale
-template <typename T, int N, int TILE, bool CX, bool MF, bool PF, typename Exec>
+template <typename T, int N, int TILE, int XM, bool MF, bool PF, typename SC, typename Exec>
 NK_HD void nk_mid_body(Exec& ex, const NkPassM& pm, const NkFuse& f, int64_t v0, int64_t vstep, int64_t nblk, int xmap,
                        T* plane, const C2<T>* __restrict__ tw_global, C2<T>* __restrict__ work, C2<T>* tw_lds = nullptr) {
-  using SC = Sched<T, N>;
-  using RG = MidRegs<T, SC::E>;
+  using RG = MidRegs<T, SC::E, PF>;
+  constexpr bool CX = XM == 1;
   constexpr int E = SC::E, S = SC::S, LS = S - 1;
   const NkPassS& p = pm.s;
   const C2<T>* tw = tw_lds ? tw_lds : tw_global;
@@ -266,8 +269,10 @@ NK_HD void nk_mid_body(Exec& ex, const NkPassM& pm, const NkFuse& f, int64_t v0,
   auto xwrite = [&](auto sa, int half, int tid, RG& rg) {
     constexpr int SA = decltype(sa)::value;
     const int t = tid % TILE, pp = tid / TILE;
-    if constexpr (CX) {
+    if constexpr (XM == 1) {
       nk_xwrite_c2<T, SC, SA, TILE>(rg.v, cplane, pp, t);
+    } else if constexpr (XM == 2) {
+      if ((t >= TILE / 2) == (half != 0)) nk_xwrite_c2<T, SC, SA, TILE / 2>(rg.v, cplane, pp, t % (TILE / 2));
     } else {
       if (half == 0)
         nk_xwrite_cols<T, SC, SA, TILE, 0>(rg.v, plane, pp, t);
@@ -278,8 +283,10 @@ NK_HD void nk_mid_body(Exec& ex, const NkPassM& pm, const NkFuse& f, int64_t v0,
   auto xread = [&](auto sb, int half, int tid, RG& rg) {
     constexpr int SB = decltype(sb)::value;
     const int t = tid % TILE, pp = tid / TILE;
-    if constexpr (CX) {
+    if constexpr (XM == 1) {
       nk_xread_c2<T, SC, SB, TILE>(rg.v, cplane, pp, t);
+    } else if constexpr (XM == 2) {
+      if ((t >= TILE / 2) == (half != 0)) nk_xread_c2<T, SC, SB, TILE / 2>(rg.v, cplane, pp, t % (TILE / 2));
     } else if (half == 0) {
       nk_xread_cols<T, SC, SB, TILE>(rg.tmp, plane, pp, t);
     } else {

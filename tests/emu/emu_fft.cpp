@@ -201,29 +201,37 @@ struct HostExecR {
   }
 };
 
-// cx: complex-plane exchange; grid > 0: persistent launch of `grid` workgroups with register prefetch
+// mode bit 0: complex-plane exchange, bit 1: persistent launch with register prefetch (5 workgroups), bit 2: wide
+// schedule (SchedW) with the half-column complex exchange
 template <typename T, int N>
-static void emu3_mid(NkPassM pm, const nk_fuse& f, const C2<T>* tw, C2<T>* work, bool cx, int grid) {
-  using ST = StridedTile<T, N, true>;
-  pm.s.tl.tile = ST::TILE;
-  pm.s.tiles_per_slab = (int)(pm.s.inner / ST::TILE);
-  std::vector<T> plane(N * ST::TILE * 2 + 16);
+static void emu3_mid(NkPassM pm, const nk_fuse& f, const C2<T>* tw, C2<T>* work, int mode) {
+  const bool cx = mode & 1, pf = mode & 2, wide = (mode & 4) && SchedW<T, N>::E != Sched<T, N>::E;
+  using STN = StridedTile<T, N, true>;
+  using STW = StridedTile<T, N, false, 0>;
+  const int tile = wide ? STW::TILE : STN::TILE, threads = wide ? STW::THREADS : STN::THREADS;
+  pm.s.tl.tile = tile;
+  pm.s.tiles_per_slab = (int)(pm.s.inner / tile);
+  std::vector<T> plane(N * STN::TILE * 2 + 16);
   const int64_t blocks = pm.s.outer * pm.s.tiles_per_slab;
-  const int64_t nwg = grid > 0 ? (grid < blocks ? grid : blocks) : blocks;
+  const int64_t nwg = pf ? (5 < blocks ? 5 : blocks) : blocks;
   for (int64_t wg = 0; wg < nwg; ++wg) {
-    HostExecR<MidRegs<T, Sched<T, N>::E>> ex(ST::THREADS);
-#define NK_MID(CXV, MFV, PFV) nk_mid_body<T, N, ST::TILE, CXV, MFV, PFV>(ex, pm, f, wg, nwg, blocks, 1, plane.data(), tw, work)
-    if (grid > 0) {
-      if (cx && f.mul) NK_MID(true, true, true);
-      else if (cx) NK_MID(true, false, true);
-      else if (f.mul) NK_MID(false, true, true);
-      else NK_MID(false, false, true);
+#define NK_MID(XMV, MFV, PFV, SCV, TILEV)                                                                      \
+  {                                                                                                            \
+    HostExecR<MidRegs<T, SCV::E, PFV>> ex(threads);                                                                 \
+    nk_mid_body<T, N, TILEV, XMV, MFV, PFV, SCV>(ex, pm, f, wg, nwg, blocks, 1, plane.data(), tw, work);      \
+  }
+#define NK_MID_MF(XMV, PFV, SCV, TILEV)                   \
+  if (f.mul) NK_MID(XMV, true, PFV, SCV, TILEV) else NK_MID(XMV, false, PFV, SCV, TILEV)
+    using SN = Sched<T, N>;
+    using SW = SchedW<T, N>;
+    if (wide) {
+      if (pf) NK_MID_MF(2, true, SW, STW::TILE) else NK_MID_MF(2, false, SW, STW::TILE)
+    } else if (cx) {
+      if (pf) NK_MID_MF(1, true, SN, STN::TILE) else NK_MID_MF(1, false, SN, STN::TILE)
     } else {
-      if (cx && f.mul) NK_MID(true, true, false);
-      else if (cx) NK_MID(true, false, false);
-      else if (f.mul) NK_MID(false, true, false);
-      else NK_MID(false, false, false);
+      if (pf) NK_MID_MF(0, true, SN, STN::TILE) else NK_MID_MF(0, false, SN, STN::TILE)
     }
+#undef NK_MID_MF
 #undef NK_MID
   }
 }
@@ -268,7 +276,7 @@ static int emu4_run(int ndim, const int64_t* shape, int dtype, int64_t batch, co
   switch (g.na) {
 #define NK_CASE(NN) \
   case NN:          \
-    emu3_mid<T, NN>(q.pm, *f, tw_c.data(), work.data(), (cx & 1) != 0, cx >= 2 ? 5 : 0); \
+    emu3_mid<T, NN>(q.pm, *f, tw_c.data(), work.data(), cx); \
     break;
     NK_FAST_SIZES(NK_CASE)
 #undef NK_CASE

@@ -303,3 +303,14 @@ def test_wide_schedule_emulation():
     run_sandwich(f, shape, np.float32, 1.0)
     ref = H(H(x)) / x.size
     assert np.max(np.abs(out - ref)) / np.max(np.abs(ref)) < 5e-5
+    # ... and the fused first-axis pass itself on the wide schedule (half-column complex exchange), field diagonal
+    shape = (1024, 128)
+    x = rng.normal(size=shape).astype(np.float32)
+    m = rng.normal(size=shape).astype(np.float32)
+    for mode in (4, 6):
+        out = np.empty_like(x)
+        f = Fuse()
+        f.in_, f.out, f.scale, f.mul_scalar, f.mul = x.ctypes.data, out.ctypes.data, 1.0 / x.size, 1.0, m.ctypes.data
+        run_sandwich(f, shape, np.float32, 1.0, cx=mode)
+        ref = H(m.astype(np.float64) * H(x)) / x.size
+        assert np.max(np.abs(out - ref)) / np.max(np.abs(ref)) < 5e-5

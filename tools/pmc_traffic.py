@@ -1,4 +1,4 @@
-"""HBM bytes per launch of the three transform pass kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
+"""HBM bytes per launch of the transform pass kernels (k_passB includes the in-place middle-axis passes of the sandwich) from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
 of the SAME bench.py command.  FETCH_SIZE is doubled (gfx950 correction of MI355X_MICROARCH.md); both counters are KiB.
 Usage: pmc_traffic.py <fetch_dir> <write_dir> <workload> > profiles/<name>_pmc_traffic.json"""
 import csv, glob, json, sys, collections
@@ -6,6 +6,10 @@ import csv, glob, json, sys, collections
 def family(name):
     if "k2_final" in name or "k_passC" in name:
         return "k_passC"
+    if "k3_contig" in name:
+        return "k_passS1"
+    if "k3_mid" in name:
+        return "k_passSM"
     if "k2_strided" in name:
         args = name.split("<", 1)[1].split(">")[0].split(",")
         return "k_passA" if args[2].strip() == "3" else "k_passB"
