@@ -102,6 +102,12 @@ typedef struct nk_fuse {
   const int32_t* pidx_octant; /* optional, nk_hartley_sandwich with field_octant and the AMP_JVP prologue: the bin index of
                            the OCTANT points [A/2+1][M/2+1][NL/2+1]; with it (and dampT) the prologue gathers da from the
                            table itself and `dafield` is not needed -- no per-application expansion of da[pidx] */
+  const void* cg_r;     /* optional, nk_hartley_sandwich with field_octant and the AMP_JVP prologue (+ dafield, cg_scal):
+                           the pending search-direction update of a conjugate-gradient iteration
+                           (conjugate_gradient.py:124), done on the way: in[i] <- max(0, cg_scal[2] / cg_scal[0]) * in[i]
+                           + cg_r[i] is WRITTEN BACK to `in` (not const here) and the new value enters the transform */
+  const double* cg_scal; /* the device scalars of nk_cg_update; roll them afterwards with
+                           nk_cg_direction(0, NULL, NULL, dtype, scal, 1, stream) */
 } nk_fuse;
 
 typedef struct nk_plan nk_plan;
@@ -241,7 +247,7 @@ int nk_cg_curv(int64_t n, const void* d, const void* q, int dtype, double* scal,
 int nk_cg_update(int64_t n, void* x, void* r, const void* d, const void* q, const void* b, int dtype,
                  double* scal, int accumulate, void* stream);
 /* roll != 0: after the update also do scal[5]=alpha, scal[6]=beta, scal[0]=scal[2] (call once per iteration,
- * on the last segment of a multi-segment vector) */
+ * on the last segment of a multi-segment vector; n == 0 with d = r = NULL only rolls) */
 int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, double* scal, int roll, void* stream);
 
 /* ---- amplitude model on the nb power bins (library/correlated_fields.py:89-208,277-386).

@@ -391,9 +391,18 @@ NK_HD C2<T> nk_load_pair_u(const T* p) {
 // adjacent reals (i, i+1); desc: the pair is stored in descending order (mirrored half of the last axis)
 //   PC = 4: afield8 * in,  5: afield8 * in + dafield8 * in2
 //   PC = 7: afield8 * in + dampT[pidx_octant] * in2   (da gathered from its table: no expanded da field)
+//   PC = 8: as 5, after the pending CG direction update  in <- beta * in + cg_r  (written back; same fp64 arithmetic as
+//           nk_cg_direction, so the fused and the separate update agree bit for bit)
 template <typename T, int PC>
 NK_HD C2<T> nk_prologue_oct(const NkFuse& f, int64_t iu, uint32_t it, uint32_t j, bool desc) {
-  const C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
+  C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
+  if constexpr (PC == 8) {
+    double beta = f.cg_scal[2] / f.cg_scal[0];
+    beta = beta > 0.0 ? beta : 0.0;
+    const C2<T> r = *reinterpret_cast<const C2<T>*>((const T*)f.cg_r + iu + it);
+    a = C2<T>{(T)(beta * (double)a.x + (double)r.x), (T)(beta * (double)a.y + (double)r.y)};
+    *reinterpret_cast<C2<T>*>(const_cast<T*>((const T*)f.in) + iu + it) = a;
+  }
   C2<T> m = nk_load_pair_u<T>((const T*)f.afield + j);
   if (desc) m = C2<T>{m.y, m.x};
   if constexpr (PC == 4) {

@@ -416,6 +416,7 @@ static int nk_launch_contig3(const NkPass3& p3, const NkFuse& f, const C2<T>* tw
 template <typename T, int H>
 static int nk_launch_contig3_pc(const NkPass3& p3, const NkFuse& f, const C2<T>* tw, const C2<T>* twr, C2<T>* work, hipStream_t st) {
   if (f.field_octant && f.pro == NK_PRO_AMP) return nk_launch_contig3<T, H, 4>(p3, f, tw, twr, work, st);
+  if (f.field_octant && f.pro == NK_PRO_AMP_JVP && f.cg_r && f.dafield) return nk_launch_contig3<T, H, 8>(p3, f, tw, twr, work, st);
   if (f.field_octant && f.pro == NK_PRO_AMP_JVP && f.pidx_octant && f.dampT) return nk_launch_contig3<T, H, 7>(p3, f, tw, twr, work, st);
   if (f.field_octant && f.pro == NK_PRO_AMP_JVP) return nk_launch_contig3<T, H, 5>(p3, f, tw, twr, work, st);
   if (f.pro == NK_PRO_PLAIN) return nk_launch_contig3<T, H, 0>(p3, f, tw, twr, work, st);
@@ -897,6 +898,7 @@ extern "C" int nk_hartley_fused(const nk_plan* P, const nk_fuse* fuse, int conve
     return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: VJP epilogue needs pidx, amp, xi and abar");
   if (fuse->epi == NK_EPI_LIKELIHOOD && (!fuse->data || !fuse->value))
     return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: LIKELIHOOD epilogue needs data and value");
+  if (fuse->cg_r) return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: cg_r is a prologue of nk_hartley_sandwich only");
   if (fuse->field_octant) {
     if (!nk_plan_uses_pipeline2(P))
       return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: field_octant needs nk_plan_octant_vjp(plan) != 0");
@@ -983,6 +985,8 @@ extern "C" int nk_hartley_sandwich(const nk_plan* P, const nk_fuse* fuse, double
   if (!nk_plan_sandwich(P)) return nk_set_error(NK_ERR_UNSUPPORTED, "nk_hartley_sandwich: needs nk_plan_sandwich(plan) != 0");
   if (fuse->epi == NK_EPI_MUL)
     return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: `mul` is the diagonal between the transforms; the MUL epilogue is not available");
+  if (fuse->cg_r && !(fuse->field_octant && fuse->pro == NK_PRO_AMP_JVP && fuse->dafield && fuse->cg_scal))
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: cg_r needs field_octant, the AMP_JVP prologue with dafield, and cg_scal");
   if ((fuse->pro == NK_PRO_AMP || fuse->pro == NK_PRO_AMP_JVP) && (!fuse->pidx || !fuse->amp))
     return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: AMP prologue needs pidx and amp");
   if (fuse->pro == NK_PRO_AMP_JVP && (!fuse->damp || !fuse->in2))

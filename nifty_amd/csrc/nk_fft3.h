@@ -36,7 +36,7 @@ struct NkPass3 {
 
 // thread id -> line thread pp = tid % P, line t = tid / P; LDS: two scalar planes (re, im) of TILE * PITCH elements
 // PC: compile-time prologue class as in nk_strided_body (0 plain, 1 afield, 3 afield + dafield, 4 / 5 octant fields,
-// 6 multiply, 7 octant a field + da gathered from its table, -1 run-time)
+// 6 multiply, 7 octant a field + da gathered from its table, 8 = 5 with the pending CG direction update, -1 run-time)
 // Schedule and tile: like the final pass (SchedF, E = 16: twice the threads per line, small workgroups) -- a row pass is
 // latency-bound, many small workgroups hide the loads of the prologue operands best (JVP prologue at 1024^3 fp32:
 // 4.96 ms with 8 lines x 16 threads x 32 elements per workgroup)
@@ -72,7 +72,7 @@ NK_HD void nk_contig3_body(Exec& ex, const NkPass3& p, const NkFuse& f, int64_t 
     const int pp = tid % P, t = tid / P;
     const int64_t line = line0 + t;
     constexpr int R = SC::radix(0), Q = E / R;
-    constexpr bool OCT = PC == 4 || PC == 5 || PC == 7;
+    constexpr bool OCT = PC == 4 || PC == 5 || PC == 7 || PC == 8;
     [[maybe_unused]] uint32_t o8 = 0;
     if constexpr (OCT) {
       const uint32_t ch = nl / 2 + 1;

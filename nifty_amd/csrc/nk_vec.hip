@@ -553,7 +553,7 @@ extern "C" int nk_cg_update(int64_t n, void* x, void* r, const void* d, const vo
 }
 
 extern "C" int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, double* scal, int roll, void* stream) {
-  if (n < 0 || !d || !r || !scal) return nk_set_error(NK_ERR_INVALID, "nk_cg_direction: bad argument");
+  if (n < 0 || (n > 0 && (!d || !r)) || !scal) return nk_set_error(NK_ERR_INVALID, "nk_cg_direction: bad argument");
   hipStream_t st = (hipStream_t)stream;
   int rc;
   NK_DISPATCH_DTYPE(dtype, {

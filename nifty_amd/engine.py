@@ -97,6 +97,15 @@ class CgWorkspace:
             B.vdot(u.small, v.small, result=res, accumulate=True)
             parallel.lockstep_sync_(res)
 
+    def direction_small(self, d, r):
+        """d.small <- beta d.small + r.small WITHOUT rolling the scalars: the xi part follows inside the next metric
+        application (nk_fuse.cg_r), which then calls ``roll``."""
+        L.check(L.load().nk_cg_direction(d.small.numel(), d.small.data_ptr(), r.small.data_ptr(), B.dtype_code(d.small),
+                                         self.scal.data_ptr(), 0, B._stream()))
+
+    def roll(self):
+        L.check(L.load().nk_cg_direction(0, 0, 0, L.NK_F64, self.scal.data_ptr(), 1, B._stream()))
+
     def direction(self, d, r):
         lib, st = L.load(), B._stream()
         segs = self._segments(d, r)
@@ -297,6 +306,8 @@ class FusedModel:
             self.octant_vjp = bool(L.load().nk_plan_octant_vjp(self.plan.handle))
             # metric applications as ONE five-pass Hartley sandwich (NK_SANDWICH=0: two three-pass transforms)
             self.sandwich = self.octant_vjp and B.plan_sandwich(self.plan) and os.environ.get("NK_SANDWICH", "1") != "0"
+            # the CG search-direction update d <- beta d + r rides in the first pass of the next metric application
+            self.fused_direction = self.sandwich and os.environ.get("NK_CG_FUSED_DIRECTION", "1") != "0"
             oct_n = int(np.prod([n // 2 + 1 for n in self.shape]))
             self.field_shape = (oct_n,) if self.octant_vjp else self.shape
             # bin index of the octant points as its own contiguous array: octant fields are plain gathers from it
@@ -485,9 +496,13 @@ class FusedModel:
         self.counters["value_grad"] += 1
         return lp
 
-    def lh_metric_accumulate(self, lp, d, out, scale, first, identity=0.0, dot_out=None):
+    def lh_metric_accumulate(self, lp, d, out, scale, first, identity=0.0, dot_out=None, cg_direction=None):
         """out (+)= scale * J^T M J d  (+ identity * d): the likelihood Fisher metric pulled back to latent space;
-        the optional multiple of d (prior metric = 1) rides along in the VJP epilogue of the xi part."""
+        the optional multiple of d (prior metric = 1) rides along in the VJP epilogue of the xi part.
+        cg_direction = (r, workspace): d.xi <- beta d.xi + r.xi first, inside the sandwich's first pass (d.small was
+        updated by the caller: CgWorkspace.direction_small); the workspace scalars are rolled afterwards."""
+        if cg_direction is not None and not self.fused_direction:
+            raise ValueError("cg_direction needs the sandwich pipeline (FusedModel.fused_direction)")
         L.check(L.load().nk_amp_jvp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(),
                                     lp.state.data_ptr(), d.small.data_ptr(), self.damp.data_ptr(), B._stream()), "nk_amp_jvp")
         # da[pindex] is expanded to an octant field once per application (1/8 of the gathers, 0.72 ms at 1024^3 fp32).
@@ -507,11 +522,15 @@ class FusedModel:
                 f.pidx_octant, f.dampT = self.pidx8.data_ptr(), damp_t.data_ptr()
             else:
                 f.dafield = self.dafield.data_ptr()
+            if cg_direction is not None:
+                f.cg_r, f.cg_scal = cg_direction[0].xi.data_ptr(), cg_direction[1].scal.data_ptr()
 
         if self.sandwich:
             # H D H in five passes: the position-space field between the transforms never exists (nk_fft3.h)
             self._vjp(lp, None, scale, d.xi if identity else None, identity, not first, out.xi, dot_out=dot_out,
                       sandwich=(jvp_prologue, self.h_dvol, lp.mid, lp.mid_scalar))
+            if cg_direction is not None:
+                cg_direction[1].roll()
         else:
             f = self._fuse()
             jvp_prologue(f)
@@ -528,10 +547,10 @@ class FusedModel:
                 B.axpby(identity, d.small, 1.0, out.small, out=out.small)
         self.counters["metric"] += 1
 
-    def metric(self, lp, d, dot_out=None):
+    def metric(self, lp, d, dot_out=None, cg_direction=None):
         """(J^T M J + 1) d at the linearisation point lp (dot_out: += d.xi . out.xi, see _vjp)."""
         out = LatentVec(torch.empty_like(d.xi), None)
-        self.lh_metric_accumulate(lp, d, out, 1.0, True, identity=1.0, dot_out=dot_out)
+        self.lh_metric_accumulate(lp, d, out, 1.0, True, identity=1.0, dot_out=dot_out, cg_direction=cg_direction)
         return out
 
     def lh_metric(self, lp, d):
@@ -634,7 +653,8 @@ class FusedModel:
         nj = self.draw_lh_noise(lp, device_rng)
         b = s + nj
         g0 = self.lh_metric(lp, s) - nj
-        A = _Callable(lambda v, dot_out=None: self.metric(lp, v, dot_out=dot_out), fused_dot=self.octant_vjp)
+        A = _Callable(lambda v, dot_out=None, cg_direction=None: self.metric(lp, v, dot_out=dot_out, cg_direction=cg_direction),
+                      fused_dot=self.octant_vjp, fused_direction=self.fused_direction)
         energy = QuadraticEnergy(s, A, b, _grad=g0)
         energy, _ = ConjugateGradient(controller)(energy)
         return b, energy.position
@@ -644,9 +664,12 @@ class _Callable:
     """Operator handle for the minimisers.  ``fused_dot``: the operator can deposit the xi part of d.(A d) into a
     device scalar while it writes A d (``A(d, dot_out=slot)``) -- ConjugateGradient then skips that BLAS-1 pass."""
 
-    def __init__(self, fn, fused_dot=False):
+    def __init__(self, fn, fused_dot=False, fused_direction=False):
         self._fn = fn
         self.fused_dot = fused_dot
+        # the operator can also take over the pending CG direction update: A(d, cg_direction=(r, workspace)) updates
+        # d.xi in place (d <- beta d + r) before applying itself and rolls the workspace scalars
+        self.fused_direction = fused_direction
 
     def __call__(self, x, **kw):
         return self._fn(x, **kw)
@@ -696,7 +719,7 @@ class FusedKL(Energy):
     def at(self, position):
         return FusedKL(self.model, position, self.residuals, self.negs, self.n_total, self.comm, self.nanisinf)
 
-    def _apply_metric_local(self, d, dot_out=None):
+    def _apply_metric_local(self, d, dot_out=None, cg_direction=None):
         """This rank's share of the KL metric applied to d (no communication)."""
         m = self.model
         out = LatentVec(torch.empty_like(d.xi), None)
@@ -708,22 +731,24 @@ class FusedKL(Energy):
             # q = A d and can take d.q on the way (single process only)
             last = i == nloc - 1
             m.lh_metric_accumulate(lp, d, out, w, i == 0, identity=nloc * w if last else 0.0,
-                                   dot_out=dot_out if last else None)
+                                   dot_out=dot_out if last else None, cg_direction=cg_direction if i == 0 else None)
         if nloc == 0:
             out = LatentVec.zeros(m)
         return out
 
-    def apply_metric(self, d, dot_out=None):
-        if dot_out is not None and self.comm is not None:
-            raise ValueError("the fused curvature dot is a single-process shortcut")
-        out = self._apply_metric_local(d, dot_out)
+    def apply_metric(self, d, dot_out=None, cg_direction=None):
+        if (dot_out is not None or cg_direction is not None) and self.comm is not None:
+            raise ValueError("the fused curvature dot / direction update are single-process shortcuts")
+        out = self._apply_metric_local(d, dot_out, cg_direction)
         if self.comm is not None:
             self.comm.allreduce_sum_([out.xi, out.small])
         return out
 
     @property
     def metric(self):
-        A = _Callable(self.apply_metric, fused_dot=self.comm is None and self.model.octant_vjp and len(self.lins) > 0)
+        single = self.comm is None and len(self.lins) > 0
+        A = _Callable(self.apply_metric, fused_dot=single and self.model.octant_vjp,
+                      fused_direction=single and self.model.fused_direction)
         if self.comm is not None and self.comm.can_shard(self.model.N):
             A.sharded = ShardedMetric(self)  # picked up by ConjugateGradient: CG vectors sharded over the ranks
         return A

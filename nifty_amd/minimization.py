@@ -420,10 +420,18 @@ class ConjugateGradient(Minimizer):
             return energy.at_with_grad(x, r), status
 
         fused_dot = bool(getattr(A, "fused_dot", False)) and hasattr(ws, "curv_slot")
+        # ... and the first pass of its transform can take over the previous iteration's direction update
+        fused_dir = fused_dot and bool(getattr(A, "fused_direction", False)) and hasattr(ws, "direction_small")
+        pending_direction = False
         while True:
             if fused_dot:
                 # the operator's last epilogue takes d.q (xi part) while it writes q: one BLAS-1 pass less
-                q = A(d, dot_out=ws.curv_slot())
+                if pending_direction:
+                    ws.direction_small(d, r)
+                    q = A(d, dot_out=ws.curv_slot(), cg_direction=(r, ws))
+                    pending_direction = False
+                else:
+                    q = A(d, dot_out=ws.curv_slot())
                 ws.curv_small(d, q)
             else:
                 q = A(d)
@@ -450,7 +458,10 @@ class ConjugateGradient(Minimizer):
             status = controller.check(_ScalarEnergyView(value, float(np.sqrt(gamma))))
             if status != CONTINUE:
                 return finish(status)
-            ws.direction(d, r)
+            if fused_dir:
+                pending_direction = True  # d <- beta d + r happens inside the next A(d)
+            else:
+                ws.direction(d, r)
 
 
     def _solve_inplace_sharded(self, energy, sm):

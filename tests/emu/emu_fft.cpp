@@ -179,6 +179,7 @@ static void emu3_contig(const NkPass3& p, const nk_fuse& f, const C2<T>* tw, con
   for (int64_t blk = 0; blk < blocks; ++blk) {
     HostExec<T, CT::SC::E> ex(CT::THREADS);
     if (f.field_octant && f.pro == NK_PRO_AMP) nk_contig3_body<T, H, CT::TILE, 4>(ex, p, f, blk, planes.data(), tw, twr, work);
+    else if (f.field_octant && f.pro == NK_PRO_AMP_JVP && f.cg_r && f.dafield) nk_contig3_body<T, H, CT::TILE, 8>(ex, p, f, blk, planes.data(), tw, twr, work);
     else if (f.field_octant && f.pro == NK_PRO_AMP_JVP && f.pidx_octant && f.dampT) nk_contig3_body<T, H, CT::TILE, 7>(ex, p, f, blk, planes.data(), tw, twr, work);
     else if (f.field_octant && f.pro == NK_PRO_AMP_JVP) nk_contig3_body<T, H, CT::TILE, 5>(ex, p, f, blk, planes.data(), tw, twr, work);
     else if (f.pro == NK_PRO_PLAIN) nk_contig3_body<T, H, CT::TILE, 0>(ex, p, f, blk, planes.data(), tw, twr, work);

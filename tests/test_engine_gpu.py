@@ -239,3 +239,58 @@ def test_engine_full_size_properties(shape, kind, nonlin, dtype):
     hm = float(model.linearize(x - v * eps).value.item())
     slope = lp.grad.s_vdot(v)
     assert abs((hp - hm) / (2 * eps) - slope) < (5e-3 if f32 else 1e-6) * max(abs(slope), abs(hp) * 1e-6 / eps)
+
+
+@pytest.mark.parametrize("shape,dtype,lh", [((64, 128), torch.float64, "gaussian"), ((64, 64, 128), torch.float64, "gaussian"),
+                                            ((128, 256), torch.float64, "poisson"), ((64, 64, 128), torch.float32, "gaussian")])
+def test_sandwich_engine_vs_oracle(shape, dtype, lh, monkeypatch):
+    """Grids large enough for the five-pass sandwich (every axis >= 64, last >= 128): metric application, MGVI sample
+    (CG with the fused curvature dot AND the direction update riding in the first transform pass) and KL against the
+    numpy oracle; and the same run with the fusions switched off."""
+    from nifty_amd import random
+    from nifty_amd.engine import FusedKL, FusedModel, LatentVec, draw_samples
+    from nifty_amd.minimization import AbsDeltaEnergyController
+
+    rng = np.random.default_rng(3)
+    cf = orc.CFModel(shape, None, orc.CFParams(offset_mean=1.0))
+    x = {k: 0.2 * v for k, v in cf.draw_latent(rng).items()}
+    v = cf.draw_latent(rng)
+    if lh == "poisson":
+        data = rng.poisson(np.exp(cf.forward(cf.draw_latent(rng)) * 0.3)).astype(np.int64)
+        lho = orc.Likelihood("poisson", data, nonlin="exp")
+        kw = dict(likelihood="poisson", data=data, nonlin="exp")
+    else:
+        data = cf.forward(cf.draw_latent(rng)) + 0.1 * rng.normal(size=shape)
+        lho = orc.Likelihood("gaussian", data, icov=100.0)
+        kw = dict(likelihood="gaussian", data=data, icov=100.0)
+    lin = orc.Linearized(cf, lho, x)
+    mv = lin.metric(v)
+    tol = 1e-9 if dtype == torch.float64 else 2e-4
+
+    def rel(a, b):
+        return max(float(np.max(np.abs(a[k] - b[k])) / max(np.max(np.abs(b[k])), 1e-30)) for k in ("xi", "spectrum"))
+
+    results = []
+    for sandwich, fused_dir in (("1", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("NK_SANDWICH", sandwich)
+        monkeypatch.setenv("NK_CG_FUSED_DIRECTION", fused_dir)
+        model = FusedModel(shape, offset_mean=1.0, dtype=dtype, device="cuda:0", **kw)
+        assert model.sandwich == (sandwich == "1") and model.fused_direction == (fused_dir == "1")
+        xl, vl = LatentVec.from_dict(model, x), LatentVec.from_dict(model, v)
+        lp = model.linearize(xl)
+        assert rel(model.metric(lp, vl).to_dict(), mv) < tol
+        random.push_sseq_from_seed(7)
+        res, negs, _ = draw_samples(model, xl, 1, True, lambda: AbsDeltaEnergyController(0.05, iteration_limit=6))
+        random.pop_sseq()
+        kl = FusedKL(model, xl, res, negs)
+        results.append((res[0].to_dict(), kl.value, kl.apply_metric(vl).to_dict()))
+    res_o, negs_o = orc.draw_samples(cf, lho, x, 1, True, np.random.SeedSequence(7),
+                                     lambda: orc.AbsDeltaEnergyController(0.05, iteration_limit=6))
+    kl_o = orc.SampledKL(cf, lho, x, res_o, negs_o)
+    ctol = 1e-7 if dtype == torch.float64 else 5e-3  # six CG iterations amplify rounding differences
+    for r0, val, mv_kl in results:
+        assert rel(r0, res_o[0]) < ctol
+        assert abs(val - kl_o.value) < (1e-8 if dtype == torch.float64 else 1e-4) * abs(kl_o.value)
+        assert rel(mv_kl, kl_o.apply_metric(v)) < ctol
+    # the fused and the separate direction update are the same arithmetic
+    assert rel(results[0][0], results[1][0]) < (1e-12 if dtype == torch.float64 else 1e-5)

@@ -314,3 +314,37 @@ def test_wide_schedule_emulation():
         run_sandwich(f, shape, np.float32, 1.0, cx=mode)
         ref = H(m.astype(np.float64) * H(x)) / x.size
         assert np.max(np.abs(out - ref)) / np.max(np.abs(ref)) < 5e-5
+
+
+def test_sandwich_cg_direction_emulation():
+    """The pending CG direction update d <- beta d + r rides in the sandwich's first pass (written back to d)."""
+    rng = np.random.default_rng(9)
+    shape = (64, 64, 128)
+    nb = 7
+    pidx = rng.integers(0, nb, size=shape).astype(np.int32)
+    idx = np.indices(shape)
+    for d_ in range(3):
+        flip = tuple((-idx[e]) % shape[e] if e == d_ else idx[e] for e in range(3))
+        pidx = np.minimum(pidx, pidx[flip])
+    pidx = pidx.astype(np.int32)
+    amp, damp = rng.normal(size=nb), rng.normal(size=nb)
+    xi, d, r = (rng.normal(size=shape) for _ in range(3))
+    scal = np.array([2.0, 0.0, 0.5, 0, 0, 0, 0, 0])
+    beta = 0.25
+    H = lambda a: (lambda F: F.real + F.imag)(scipy.fft.fftn(a))  # noqa: E731
+    oct_sl = tuple(slice(0, s_ // 2 + 1) for s_ in shape)
+    af8, daf8 = np.ascontiguousarray(amp[pidx][oct_sl]), np.ascontiguousarray(damp[pidx][oct_sl])
+    d_new = beta * d + r
+    d_work = d.copy()
+    out = np.empty(shape)
+    abar, w8 = np.zeros(nb), np.full(af8.shape, np.nan)
+    f = Fuse()
+    f.pro, f.in_, f.in2, f.pidx, f.amp, f.damp = 2, d_work.ctypes.data, xi.ctypes.data, pidx.ctypes.data, amp.ctypes.data, damp.ctypes.data
+    f.afield, f.dafield, f.field_octant, f.w8 = af8.ctypes.data, daf8.ctypes.data, 1, w8.ctypes.data
+    f.cg_r, f.cg_scal = r.ctypes.data, scal.ctypes.data
+    f.mul_scalar, f.epi, f.out, f.scale = 1.0, 2, out.ctypes.data, 0.25
+    f.xi, f.abar, f.addend, f.addend_scale = xi.ctypes.data, abar.ctypes.data, d_work.ctypes.data, 1.0
+    run_sandwich(f, shape, np.float64, 0.5)
+    assert np.array_equal(d_work, d_new)
+    t = 0.25 * H(0.5 * H(amp[pidx] * d_new + damp[pidx] * xi))
+    assert np.max(np.abs(out - (amp[pidx] * t + d_new))) < 1e-11 * np.max(np.abs(t))
