@@ -304,8 +304,13 @@ class FusedModel:
             # octant arrays: the VJP scatter sums (sign-flip images merged in the final transform pass) and the
             # amplitude fields a[pindex], da[pindex] (identical on all sign-flip images: 1/8 of the bytes)
             self.octant_vjp = bool(L.load().nk_plan_octant_vjp(self.plan.handle))
-            # metric applications as ONE five-pass Hartley sandwich (NK_SANDWICH=0: two three-pass transforms)
-            self.sandwich = self.octant_vjp and B.plan_sandwich(self.plan) and os.environ.get("NK_SANDWICH", "1") != "0"
+            # metric applications as ONE five-pass Hartley sandwich (NK_SANDWICH=0: two three-pass transforms).  Default
+            # for 3-D grids only: in 2-D it replaces four passes by three, but the fused pass with its two line transforms
+            # costs more than the pass it saves (2048^2 fp64 Poisson: 0.197 vs 0.162 ms per metric application;
+            # NK_SANDWICH=2 forces it for every eligible grid)
+            sw = os.environ.get("NK_SANDWICH", "1")
+            self.sandwich = (self.octant_vjp and B.plan_sandwich(self.plan) and sw != "0"
+                             and (len(self.shape) == 3 or sw == "2"))
             # the CG search-direction update d <- beta d + r rides in the first pass of the next metric application
             self.fused_direction = self.sandwich and os.environ.get("NK_CG_FUSED_DIRECTION", "1") != "0"
             oct_n = int(np.prod([n // 2 + 1 for n in self.shape]))

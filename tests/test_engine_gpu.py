@@ -271,11 +271,11 @@ def test_sandwich_engine_vs_oracle(shape, dtype, lh, monkeypatch):
         return max(float(np.max(np.abs(a[k] - b[k])) / max(np.max(np.abs(b[k])), 1e-30)) for k in ("xi", "spectrum"))
 
     results = []
-    for sandwich, fused_dir in (("1", "1"), ("1", "0"), ("0", "0")):
+    for sandwich, fused_dir in (("2", "1"), ("2", "0"), ("0", "0")):
         monkeypatch.setenv("NK_SANDWICH", sandwich)
         monkeypatch.setenv("NK_CG_FUSED_DIRECTION", fused_dir)
         model = FusedModel(shape, offset_mean=1.0, dtype=dtype, device="cuda:0", **kw)
-        assert model.sandwich == (sandwich == "1") and model.fused_direction == (fused_dir == "1")
+        assert model.sandwich == (sandwich == "2") and model.fused_direction == (fused_dir == "1")
         xl, vl = LatentVec.from_dict(model, x), LatentVec.from_dict(model, v)
         lp = model.linearize(xl)
         assert rel(model.metric(lp, vl).to_dict(), mv) < tol
