@@ -246,6 +246,11 @@ int nk_pindex_from_k2(int ndim, const int64_t* shape, const int32_t* k2table, in
 int nk_cg_curv(int64_t n, const void* d, const void* q, int dtype, double* scal, int accumulate, void* stream);
 int nk_cg_update(int64_t n, void* x, void* r, const void* d, const void* q, const void* b, int dtype,
                  double* scal, int accumulate, void* stream);
+/* nk_cg_update without the linear term: alpha = scal[0]/scal[1]; scal[3] = d.r (OLD residual); x -= alpha d; r -= alpha q;
+ * scal[2] = r.r.  The quadratic energy of the iterate (quadratic_energy.py:31-39, which the reference re-evaluates from
+ * x, r, b every iteration: conjugate_gradient.py:100-101) advances by dE = -alpha d.r + alpha^2/2 d.q */
+int nk_cg_update_dr(int64_t n, void* x, void* r, const void* d, const void* q, int dtype, double* scal, int accumulate,
+                    void* stream);
 /* roll != 0: after the update also do scal[5]=alpha, scal[6]=beta, scal[0]=scal[2] (call once per iteration,
  * on the last segment of a multi-segment vector; n == 0 with d = r = NULL only rolls) */
 int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, double* scal, int roll, void* stream);

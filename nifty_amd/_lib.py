@@ -68,6 +68,7 @@ SIGNATURES = {
     "nk_pindex_from_k2": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp]),
     "nk_cg_curv": (_i, [_i64, _vp, _vp, _i, _vp, _i, _vp]),
     "nk_cg_update": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "nk_cg_update_dr": (_i, [_i64, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "nk_cg_direction": (_i, [_i64, _vp, _vp, _i, _vp, _i, _vp]),
     "nk_amp_forward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nk_amp_jvp": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -391,6 +391,38 @@ struct FCgUpdate {
   }
 };
 
+// the same update without the linear term b: instead of x.r and x.b (from which the quadratic energy was recomputed) it
+// returns d.r of the OLD residual, and the caller advances the energy by  dE = -alpha d.r + alpha^2/2 d.q  -- one
+// input stream less (6 instead of 7), and the energy DIFFERENCE the stopping rule looks at is formed directly
+template <typename T>
+struct FCgUpdateDr {
+  static constexpr int NRED = 2;
+  T *x, *r;
+  const T *d, *q;
+  const double* scal;
+  double* result;  // = scal + 2: gamma, d.r_old
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double* red) const {
+    const double alpha = scal[0] / scal[1];
+    T xv[V], rv[V], dv[V], qv[V];
+    nk_ld<T, V>(x, i, xv);
+    nk_ld<T, V>(r, i, rv);
+    nk_ld<T, V>(d, i, dv);
+    nk_ld<T, V>(q, i, qv);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      red[1] += (double)dv[k] * (double)rv[k];
+      const T xn = (T)((double)xv[k] - alpha * (double)dv[k]);
+      const T rn = (T)((double)rv[k] - alpha * (double)qv[k]);
+      xv[k] = xn;
+      rv[k] = rn;
+      red[0] += (double)rn * (double)rn;
+    }
+    nk_st<T, V>(x, i, xv);
+    nk_st<T, V>(r, i, rv);
+  }
+};
+
 // CG: d = max(0, gamma/gamma_prev) d + r
 template <typename T>
 struct FCgDir {
@@ -549,6 +581,21 @@ extern "C" int nk_cg_update(int64_t n, void* x, void* r, const void* d, const vo
     return nk_launch_map<T>(
         n, f, nk_aligned16(x) && nk_aligned16(r) && nk_aligned16(d) && nk_aligned16(q) && nk_aligned16(b), st,
         "nk_cg_update");
+  })
+}
+
+extern "C" int nk_cg_update_dr(int64_t n, void* x, void* r, const void* d, const void* q, int dtype, double* scal,
+                               int accumulate, void* stream) {
+  if (n < 0 || !x || !r || !d || !q || !scal) return nk_set_error(NK_ERR_INVALID, "nk_cg_update_dr: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    int rc = nk_zero(scal + 2, 2, st);
+    if (rc != NK_OK) return rc;
+  }
+  NK_DISPATCH_DTYPE(dtype, {
+    FCgUpdateDr<T> f{(T*)x, (T*)r, (const T*)d, (const T*)q, scal, scal + 2};
+    return nk_launch_map<T>(n, f, nk_aligned16(x) && nk_aligned16(r) && nk_aligned16(d) && nk_aligned16(q), st,
+                            "nk_cg_update_dr");
   })
 }
 

@@ -87,6 +87,14 @@ class CgWorkspace:
                                      B.dtype_code(xx), self.scal.data_ptr(), i, st))
         parallel.lockstep_sync_(self.scal[2:5])
 
+    def update_dr(self, x, r, d, q):
+        """x -= alpha d, r -= alpha q; gamma = r.r and d.r (old residual) land in scal[2], scal[3] (nk_cg_update_dr)."""
+        lib, st = L.load(), B._stream()
+        for i, (xx, rr, dd, qq) in enumerate(self._segments(x, r, d, q)):
+            L.check(lib.nk_cg_update_dr(xx.numel(), xx.data_ptr(), rr.data_ptr(), dd.data_ptr(), qq.data_ptr(),
+                                        B.dtype_code(xx), self.scal.data_ptr(), i, st))
+        parallel.lockstep_sync_(self.scal[2:4])
+
     def refresh(self, x, r, b):
         """After a residual refresh: gamma = r.r, x.r and x.b recomputed (device side)."""
         for slot, (u, v) in ((2, (r, r)), (3, (x, r)), (4, (x, b))):
@@ -117,7 +125,7 @@ class CgWorkspace:
         self._host.copy_(self.scal, non_blocking=True)
         torch.cuda.current_stream(self.scal.device).synchronize()
         s = self._host.numpy()
-        return dict(gamma_prev=float(s[0]), curv=float(s[1]), gamma=float(s[2]), xr=float(s[3]), xb=float(s[4]),
+        return dict(gamma_prev=float(s[0]), curv=float(s[1]), gamma=float(s[2]), xr=float(s[3]), xb=float(s[4]), dr=float(s[3]),
                     alpha=float(s[0] / s[1]) if s[1] != 0 else float("nan"))
 
 
@@ -153,6 +161,15 @@ class ShardedCgWorkspace(CgWorkspace):
             if i == 0:
                 self.comm.allreduce_sum_([self.scal[2:5]])
         self.comm.bcast_(self.scal[2:5])
+
+    def update_dr(self, x, r, d, q):
+        lib, st = L.load(), B._stream()
+        for i, (xx, rr, dd, qq) in enumerate(self._segments(x, r, d, q)):
+            L.check(lib.nk_cg_update_dr(xx.numel(), xx.data_ptr(), rr.data_ptr(), dd.data_ptr(), qq.data_ptr(),
+                                        B.dtype_code(xx), self.scal.data_ptr(), i, st))
+            if i == 0:
+                self.comm.allreduce_sum_([self.scal[2:4]])
+        self.comm.bcast_(self.scal[2:4])
 
     def refresh(self, x, r, b):
         for slot, (u, v) in ((2, (r, r)), (3, (x, r)), (4, (x, b))):

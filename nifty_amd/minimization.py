@@ -321,6 +321,17 @@ class Minimizer:
         raise NotImplementedError
 
 
+def _config_track_energy():
+    """Default: the quadratic energy of the iterate is re-evaluated from x.r and x.b every iteration, as the reference
+    does (conjugate_gradient.py:100-101, quadratic_energy.py:31-39) -- the stopping rules then see the energy of the
+    STORED (for fp32 fields: rounded) iterate.  NK_CG_ENERGY_RECURRENCE=1 advances it by dE = -alpha d.r + alpha^2/2 d.q
+    instead (nk_cg_update_dr: one input stream less, -0.8 ms per iteration at 1024^3 fp32); the controllers then make
+    different decisions (measured: 25 -> 28 Newton-CG iterations per step of the benchmark), so it is not the default."""
+    import os
+
+    return os.environ.get("NK_CG_ENERGY_RECURRENCE", "0") == "1"
+
+
 class _ScalarEnergyView:
     """What a controller needs from the in-place CG state: value and gradient norm as host floats."""
 
@@ -419,6 +430,9 @@ class ConjugateGradient(Minimizer):
         def finish(status):
             return energy.at_with_grad(x, r), status
 
+        # the energy of the iterate advances by a two-dot recurrence instead of being recomputed from x.r and x.b
+        track_energy = hasattr(ws, "update_dr") and _config_track_energy()
+        value = float(energy.value) if track_energy else None
         fused_dot = bool(getattr(A, "fused_dot", False)) and hasattr(ws, "curv_slot")
         # ... and the first pass of its transform can take over the previous iteration's direction update
         fused_dir = fused_dot and bool(getattr(A, "fused_direction", False)) and hasattr(ws, "direction_small")
@@ -436,15 +450,20 @@ class ConjugateGradient(Minimizer):
             else:
                 q = A(d)
                 ws.curv(d, q)
-            ws.update(x, r, d, q, b)
+            if track_energy:
+                ws.update_dr(x, r, d, q)
+            else:
+                ws.update(x, r, d, q, b)
             counters["cg_iterations"] += 1
             since_reset += 1
+            refreshed = False
             if since_reset >= self._nreset:
                 # periodic residual refresh (conjugate_gradient.py:103-106): r = A x - b
                 Ax = A(x)
                 r = Ax - b if b is not None else Ax
                 ws.refresh(x, r, b)
                 since_reset = 0
+                refreshed = True
             sc = ws.fetch()  # the single host synchronisation of this iteration
             curv, gamma, alpha = sc["curv"], sc["gamma"], sc["alpha"]
             if np.isnan(curv) or curv == 0.0 or np.isnan(alpha) or alpha < 0:
@@ -454,7 +473,11 @@ class ConjugateGradient(Minimizer):
                 return finish(ERROR)
             if gamma == 0:
                 return finish(CONVERGED)
-            value = 0.5 * sc["xr"] - 0.5 * sc["xb"] if b is not None else 0.5 * sc["xr"]
+            if track_energy and not refreshed:
+                # E(x - alpha d) = E(x) - alpha d.r + alpha^2/2 d.q, both dots taken on the way (nk_cg_update_dr)
+                value = value - alpha * sc["dr"] + 0.5 * alpha * alpha * curv
+            else:
+                value = 0.5 * sc["xr"] - 0.5 * sc["xb"] if b is not None else 0.5 * sc["xr"]
             status = controller.check(_ScalarEnergyView(value, float(np.sqrt(gamma))))
             if status != CONTINUE:
                 return finish(status)
@@ -475,6 +498,8 @@ class ConjugateGradient(Minimizer):
         d = r.clone()
         d_full = energy.gradient.clone()
         ws = sm.workspace()
+        track_energy = hasattr(ws, "update_dr") and _config_track_energy()
+        value = float(energy.value) if track_energy else None
         gamma_prev = float(ws.dot(r, r, 0).item())
         if np.isnan(gamma_prev):
             return energy, ERROR
@@ -488,14 +513,19 @@ class ConjugateGradient(Minimizer):
         while True:
             q = sm.apply(d_full)
             ws.curv(d, q)
-            ws.update(x, r, d, q, b)
+            if track_energy:
+                ws.update_dr(x, r, d, q)
+            else:
+                ws.update(x, r, d, q, b)
             counters["cg_iterations"] += 1
             since_reset += 1
+            refreshed = False
             if since_reset >= self._nreset:
                 Ax = sm.apply(sm.gather(x))
                 r = Ax - b
                 ws.refresh(x, r, b)
                 since_reset = 0
+                refreshed = True
             sc = ws.fetch()
             curv, gamma, alpha = sc["curv"], sc["gamma"], sc["alpha"]
             if np.isnan(curv) or curv == 0.0 or np.isnan(alpha) or alpha < 0:
@@ -505,7 +535,10 @@ class ConjugateGradient(Minimizer):
                 return finish(ERROR)
             if gamma == 0:
                 return finish(CONVERGED)
-            value = 0.5 * sc["xr"] - 0.5 * sc["xb"]
+            if track_energy and not refreshed:
+                value = value - alpha * sc["dr"] + 0.5 * alpha * alpha * curv
+            else:
+                value = 0.5 * sc["xr"] - 0.5 * sc["xb"]
             status = controller.check(_ScalarEnergyView(value, float(np.sqrt(gamma))))
             if status != CONTINUE:
                 return finish(status)

@@ -271,9 +271,10 @@ def test_sandwich_engine_vs_oracle(shape, dtype, lh, monkeypatch):
         return max(float(np.max(np.abs(a[k] - b[k])) / max(np.max(np.abs(b[k])), 1e-30)) for k in ("xi", "spectrum"))
 
     results = []
-    for sandwich, fused_dir in (("2", "1"), ("2", "0"), ("0", "0")):
+    for sandwich, fused_dir, recur in (("2", "1", "0"), ("2", "0", "0"), ("0", "0", "0"), ("2", "1", "1")):
         monkeypatch.setenv("NK_SANDWICH", sandwich)
         monkeypatch.setenv("NK_CG_FUSED_DIRECTION", fused_dir)
+        monkeypatch.setenv("NK_CG_ENERGY_RECURRENCE", recur)  # 1: energy of the CG iterate by recurrence (nk_cg_update_dr)
         model = FusedModel(shape, offset_mean=1.0, dtype=dtype, device="cuda:0", **kw)
         assert model.sandwich == (sandwich == "2") and model.fused_direction == (fused_dir == "1")
         xl, vl = LatentVec.from_dict(model, x), LatentVec.from_dict(model, v)

@@ -227,3 +227,24 @@ def test_sandwich_equals_two_transforms(shape, dtype, field_mid):
             assert err < tol, (conv, err)
     finally:
         config.update("hartley_convention", "non_canonical_hartley")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_cg_update_dr(dtype):
+    """nk_cg_update_dr: the fused CG update that returns d.r (old residual) instead of x.r / x.b."""
+    from nifty_amd import _lib as L
+    from nifty_amd import backend as B
+
+    n = 1 << 20
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x, r, d, q = (torch.randn(n + 3, dtype=dtype, device="cuda", generator=g) for _ in range(4))
+    scal = torch.tensor([3.0, 2.0, 0, 0, 0, 0, 0, 0], dtype=torch.float64, device="cuda")
+    alpha = 1.5
+    xr, rr = (x.double() - alpha * d.double()).to(dtype), (r.double() - alpha * q.double()).to(dtype)
+    dr = float((d.double() * r.double()).sum())
+    L.check(L.load().nk_cg_update_dr(n + 3, x.data_ptr(), r.data_ptr(), d.data_ptr(), q.data_ptr(), B.dtype_code(x),
+                                     scal.data_ptr(), 0, B._stream()))
+    assert torch.equal(x, xr) and torch.equal(r, rr)
+    s = scal.cpu().numpy()
+    assert abs(s[2] - float((rr.double() ** 2).sum())) < 1e-12 * s[2]
+    assert abs(s[3] - dr) < 1e-10 * abs((d.double() * r.double()).abs().sum().item())
