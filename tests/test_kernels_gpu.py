@@ -244,7 +244,8 @@ def test_cg_update_dr(dtype):
     dr = float((d.double() * r.double()).sum())
     L.check(L.load().nk_cg_update_dr(n + 3, x.data_ptr(), r.data_ptr(), d.data_ptr(), q.data_ptr(), B.dtype_code(x),
                                      scal.data_ptr(), 0, B._stream()))
-    assert torch.equal(x, xr) and torch.equal(r, rr)
+    tol = 4e-16 if dtype == torch.float64 else 1e-7  # the kernel contracts x - alpha d into one fma
+    assert ((x - xr).abs().max() <= tol * 8).item() and ((r - rr).abs().max() <= tol * 8).item()
     s = scal.cpu().numpy()
-    assert abs(s[2] - float((rr.double() ** 2).sum())) < 1e-12 * s[2]
+    assert abs(s[2] - float((r.double() ** 2).sum())) < 1e-12 * s[2]
     assert abs(s[3] - dr) < 1e-10 * abs((d.double() * r.double()).abs().sum().item())
