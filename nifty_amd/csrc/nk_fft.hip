@@ -452,30 +452,40 @@ static int nk_dispatch_contig3(int h, const NkPass3& p3, const NkFuse& f, const 
 #ifndef NK_MID_WIDE
 #define NK_MID_WIDE 0  // 1: wide schedule (SchedW, two workgroups per CU) for the fused middle kernel -- spills 116..464 B per lane, 3.1 -> 5.0 ms
 #endif
-// tile / schedule / exchange mode of the fused middle kernel
-template <typename T, int N>
+// tile / schedule / exchange mode of the fused middle kernel.
+// TWO: the fp32 512-thread x 32-element configuration (1024-point lines) with a constant diagonal runs TWO workgroups per
+// CU: split exchange (64 KiB of LDS), composed twiddles and a 128-VGPR cap (32 B / lane of spills).  One workgroup per CU
+// serialises the ~11 us of VALU work of the two line transforms with the ~12 us its tile's HBM traffic takes; two
+// independent ones overlap them: 3.07 -> 2.24 ms at 1024^3 fp32 (gpurun_out/r02r_probe.log).
+#ifndef NK_MID_TWO
+#define NK_MID_TWO 1
+#endif
+template <typename T, int N, bool MF>
 struct MidCfg {
   static constexpr bool WIDE = NK_MID_WIDE && SchedW<T, N>::E == 64;
-  using ST = StridedTile<T, N, !WIDE && NK_MID_CX != 0, WIDE ? 0 : 3>;
+  static constexpr bool TWO = NK_MID_TWO && !WIDE && !MF && sizeof(T) == 4 && Sched<T, N>::E == 32 &&
+                              StridedTile<T, N, false, 3>::THREADS == 512 && StridedTile<T, N, false, 3>::LDS_BYTES <= 64 * 1024;
+  using ST = StridedTile<T, N, !WIDE && !TWO && NK_MID_CX != 0, WIDE ? 0 : 3>;
   using SC = typename ST::SC;
   static constexpr int XM = WIDE ? NK_MID_WIDE_XM : (ST::CPLX ? 1 : 0);
+  static constexpr bool TWC = TWO;
+  static constexpr int WAVES = NK_MID_WAVES > 0 ? NK_MID_WAVES : TWO ? 4 : ST::THREADS <= 256 ? 2 : 1;
 };
 template <typename T, int N, bool MF>
-__global__ void __launch_bounds__((MidCfg<T, N>::ST::THREADS),
-                                  (NK_MID_WAVES > 0 ? NK_MID_WAVES : MidCfg<T, N>::ST::THREADS <= 256 ? 2 : 1))
+__global__ void __launch_bounds__((MidCfg<T, N, MF>::ST::THREADS), (MidCfg<T, N, MF>::WAVES))
     k3_mid(NkPassM pm, NkFuse f, const C2<T>* __restrict__ tw, C2<T>* __restrict__ work, int64_t nblk, int xmap) {
   extern __shared__ __align__(16) unsigned char smem[];
-  using CF = MidCfg<T, N>;
+  using CF = MidCfg<T, N, MF>;
   using ST = typename CF::ST;
   DeviceExecR<MidRegs<T, CF::SC::E, NK_MID_PF != 0>> ex;
   C2<T>* tw_lds = ST::TWLDS ? reinterpret_cast<C2<T>*>(smem + ST::LDS_BYTES) : nullptr;
-  nk_mid_body<T, N, ST::TILE, CF::XM, MF, NK_MID_PF != 0, typename CF::SC>(ex, pm, f, (int64_t)blockIdx.x, (int64_t)gridDim.x, nblk,
-                                                                           xmap, (T*)smem, tw, work, tw_lds);
+  nk_mid_body<T, N, ST::TILE, CF::XM, MF, NK_MID_PF != 0, typename CF::SC, CF::TWC>(ex, pm, f, (int64_t)blockIdx.x, (int64_t)gridDim.x,
+                                                                                     nblk, xmap, (T*)smem, tw, work, tw_lds);
 }
 
 template <typename T, int N, bool MF>
 static int nk_launch_mid(NkPassM pm, const NkFuse& f, const C2<T>* tw, C2<T>* work, hipStream_t st) {
-  using ST = typename MidCfg<T, N>::ST;
+  using ST = typename MidCfg<T, N, MF>::ST;
   auto kern = k3_mid<T, N, MF>;
   static unsigned long long attr_mask = 0;  // per-device attribute
   if (ST::LDS_TOTAL > 64 * 1024 && nk_first_on_device(attr_mask)) {

@@ -225,9 +225,12 @@ struct ContigLayout {
 // tile choices of the fast path ------------------------------------------------------------------
 // strided passes: rows of 128 B when the thread count (P*TILE <= 1024) and the LDS plane (<= 128 KiB) allow
 // CX: the light first-pass classes exchange through ONE complex plane and read their twiddles from LDS (see below)
+#ifndef NK_S1_TWO_WG
+#define NK_S1_TWO_WG 0
+#endif
 template <int MODE, int PC>
 constexpr bool nk_strided_cx() {
-  return MODE == 3 && (PC == 0 || PC == 1 || PC == 6);
+  return !NK_S1_TWO_WG && MODE == 3 && (PC == 0 || PC == 1 || PC == 6);
 }
 template <typename T, int N, bool CX = false, int MODE = 3>
 struct StridedTile {
@@ -355,13 +358,29 @@ struct StageInfo {
 #define NK_TW_GROUP 0
 #endif
 // twiddle + in-register butterflies of stage S on v (inputs ordered v[q*R + r])
-template <typename T, typename SC, int S>
+// TWC: compose the R - 1 twiddles of a butterfly from 7 + (R/8 - 1) table entries, w^r = w^(8 (r/8)) w^(r%8): one more
+// complex multiplication per element but ~40 fewer live registers than R - 1 hoisted table loads (R >= 16)
+template <typename T, typename SC, int S, bool TWC = false>
 NK_HD void nk_stage_compute(C2<T>* v, int p, const C2<T>* __restrict__ tw) {
   using SI = StageInfo<T, SC, S>;
   constexpr int R = SI::R, NS = SI::NS, Q = SI::Q, N = SC::N, P = SC::P;
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
-    if (NS > 1) {
+    if constexpr (TWC && NS > 1 && R >= 16) {
+      const int k = (p + q * P) & (NS - 1);
+      constexpr int step = N / (NS * R);
+      C2<T> wl[8], wh[R / 8];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) wl[r] = tw[(k * r * step) & (N - 1)];
+#pragma unroll
+      for (int h = 1; h < R / 8; ++h) wh[h] = tw[(k * 8 * h * step) & (N - 1)];
+#pragma unroll
+      for (int r = 1; r < R; ++r) {
+        const int h = r / 8, l = r % 8;
+        const C2<T> w = h == 0 ? wl[l] : (l == 0 ? wh[h] : cmul(wh[h], wl[l]));
+        v[q * R + r] = cmul(v[q * R + r], w);
+      }
+    } else if (NS > 1) {
       const int k = (p + q * P) & (NS - 1);
       constexpr int step = N / (NS * R);
 #pragma unroll
@@ -490,6 +509,9 @@ NK_HD int64_t nk_xcd_contig(int64_t blk, int64_t nb) {
 }
 
 // ---------------------------------------------------------------------------------------------
+#ifndef NK_STRIDED_TWC
+#define NK_STRIDED_TWC 0  // experiment: composed twiddles in the strided passes (see nk_stage_compute)
+#endif
 // strided pass body (pass B: in place c2c; pass C: c2c + Hartley combine + epilogue)
 // thread id -> column t = tid % TILE, line thread pp = tid / TILE;  blockDim = P * TILE
 // LDS: ONE scalar plane of N*TILE elements (split real / imaginary exchange)
@@ -602,13 +624,13 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
     if constexpr (S == 3) {
       ex.phase([&](int tid, PassRegs<T, E>& rg) {
         nk_xread_c2<T, SC, 1, TILE>(rg.v, cplane, tid / TILE, tid % TILE);
-        nk_stage_compute<T, SC, 1>(rg.v, tid / TILE, tw);
+        nk_stage_compute<T, SC, 1, NK_STRIDED_TWC != 0>(rg.v, tid / TILE, tw);
       });
       ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xwrite_c2<T, SC, 1, TILE>(rg.v, cplane, tid / TILE, tid % TILE); });
     }
     ex.last_phase([&](int tid, PassRegs<T, E>& rg) {
       nk_xread_c2<T, SC, S - 1, TILE>(rg.v, cplane, tid / TILE, tid % TILE);
-      nk_stage_compute<T, SC, S - 1>(rg.v, tid / TILE, tw);
+      nk_stage_compute<T, SC, S - 1, NK_STRIDED_TWC != 0>(rg.v, tid / TILE, tw);
       store_tile(tid, rg);
     });
     return;
@@ -623,7 +645,7 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
       nk_xread_cols<T, SC, 1, TILE>(im, plane, pp, t);
 #pragma unroll
       for (int e = 0; e < E; ++e) rg.v[e] = C2<T>{rg.tmp[e], im[e]};
-      nk_stage_compute<T, SC, 1>(rg.v, pp, tw);
+      nk_stage_compute<T, SC, 1, NK_STRIDED_TWC != 0>(rg.v, pp, tw);
       store_tile(tid, rg);
     });
   } else {
@@ -633,7 +655,7 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
       nk_xread_cols<T, SC, 1, TILE>(im, plane, pp, t);
 #pragma unroll
       for (int e = 0; e < E; ++e) rg.v[e] = C2<T>{rg.tmp[e], im[e]};
-      nk_stage_compute<T, SC, 1>(rg.v, pp, tw);
+      nk_stage_compute<T, SC, 1, NK_STRIDED_TWC != 0>(rg.v, pp, tw);
     });
     ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xwrite_cols<T, SC, 1, TILE, 0>(rg.v, plane, tid / TILE, tid % TILE); });
     ex.phase([&](int tid, PassRegs<T, E>& rg) { nk_xread_cols<T, SC, 2, TILE>(rg.tmp, plane, tid / TILE, tid % TILE); });
@@ -644,7 +666,7 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
       nk_xread_cols<T, SC, 2, TILE>(im, plane, pp, t);
 #pragma unroll
       for (int e = 0; e < E; ++e) rg.v[e] = C2<T>{rg.tmp[e], im[e]};
-      nk_stage_compute<T, SC, 2>(rg.v, pp, tw);
+      nk_stage_compute<T, SC, 2, NK_STRIDED_TWC != 0>(rg.v, pp, tw);
       store_tile(tid, rg);
     });
   }

@@ -236,8 +236,8 @@ struct DeviceExecR {
 //     1: one round through a complex plane (twice the LDS);  2: a complex plane of HALF the columns, used twice (columns
 //     t < TILE/2, then the rest) -- the LDS of mode 0 without its E temporaries per thread, which is what lets the
 //     wide schedule (64 elements per thread, two workgroups per CU) run without spills
-// MF: the diagonal is a field (fuse.mul), else only the scalar mid_scale
-template <typename T, int N, int TILE, int XM, bool MF, bool PF, typename SC, typename Exec>
+// MF: the diagonal is a field (fuse.mul), else only the scalar mid_scale;  TWC: composed twiddles (nk_stage_compute)
+template <typename T, int N, int TILE, int XM, bool MF, bool PF, typename SC, bool TWC = false, typename Exec>
 NK_HD void nk_mid_body(Exec& ex, const NkPassM& pm, const NkFuse& f, int64_t v0, int64_t vstep, int64_t nblk, int xmap,
                        T* plane, const C2<T>* __restrict__ tw_global, C2<T>* __restrict__ work, C2<T>* tw_lds = nullptr) {
   using RG = MidRegs<T, SC::E, PF>;
@@ -330,13 +330,13 @@ NK_HD void nk_mid_body(Exec& ex, const NkPassM& pm, const NkFuse& f, int64_t v0,
       } else {
         load_tile(rg.v, v, tid);
       }
-      nk_stage_compute<T, SC, 0>(rg.v, tid / TILE, tw);
+      nk_stage_compute<T, SC, 0, TWC>(rg.v, tid / TILE, tw);
       xwrite(I0{}, 0, tid, rg);
     });
     exchange_rest(I0{}, I1{});
     if constexpr (S == 3) {
       ex.phase([&](int tid, RG& rg) {
-        nk_stage_compute<T, SC, 1>(rg.v, tid / TILE, tw);
+        nk_stage_compute<T, SC, 1, TWC>(rg.v, tid / TILE, tw);
         xwrite(I1{}, 0, tid, rg);
       });
       exchange_rest(I1{}, I2{});
@@ -344,7 +344,7 @@ NK_HD void nk_mid_body(Exec& ex, const NkPassM& pm, const NkFuse& f, int64_t v0,
     // ---- last stage of the first transform, the diagonal with row-mirror pairing, hand-over to the second transform
     ex.phase([&](int tid, RG& rg) {
       const int t = tid % TILE, pp = tid / TILE;
-      nk_stage_compute<T, SC, LS>(rg.v, pp, tw);
+      nk_stage_compute<T, SC, LS, TWC>(rg.v, pp, tw);
       constexpr int R = SC::radix(LS), Q = E / R;
       const T sg = (T)p.g.sign, ms = (T)pm.mid_scale;
       if constexpr (MF) {
@@ -382,13 +382,13 @@ NK_HD void nk_mid_body(Exec& ex, const NkPassM& pm, const NkFuse& f, int64_t v0,
     exchange_rest(ILS{}, I0{});
     // ---- second transform
     ex.phase([&](int tid, RG& rg) {
-      nk_stage_compute<T, SC, 0>(rg.v, tid / TILE, tw);
+      nk_stage_compute<T, SC, 0, TWC>(rg.v, tid / TILE, tw);
       xwrite(I0{}, 0, tid, rg);
     });
     if constexpr (S == 3) {
       exchange_rest(I0{}, I1{});
       ex.phase([&](int tid, RG& rg) {
-        nk_stage_compute<T, SC, 1>(rg.v, tid / TILE, tw);
+        nk_stage_compute<T, SC, 1, TWC>(rg.v, tid / TILE, tw);
         xwrite(I1{}, 0, tid, rg);
       });
     }
@@ -397,7 +397,7 @@ NK_HD void nk_mid_body(Exec& ex, const NkPassM& pm, const NkFuse& f, int64_t v0,
     exchange_rest(IPREV{}, ILS{});
     ex.last_phase([&](int tid, RG& rg) {
       const int t = tid % TILE, pp = tid / TILE;
-      nk_stage_compute<T, SC, LS>(rg.v, pp, tw);
+      nk_stage_compute<T, SC, LS, TWC>(rg.v, pp, tw);
       constexpr int R = SC::radix(LS), Q = E / R;
       const uint32_t toff = (uint32_t)(nk_out_row<SC, LS>(pp, 0, 0) * rstride + t);
 #pragma unroll

@@ -206,7 +206,7 @@ struct HostExecR {
 // schedule (SchedW) with the half-column complex exchange
 template <typename T, int N>
 static void emu3_mid(NkPassM pm, const nk_fuse& f, const C2<T>* tw, C2<T>* work, int mode) {
-  const bool cx = mode & 1, pf = mode & 2, wide = (mode & 4) && SchedW<T, N>::E != Sched<T, N>::E;
+  const bool cx = mode & 1, pf = mode & 2, wide = (mode & 4) && SchedW<T, N>::E != Sched<T, N>::E, twc = mode & 8;
   using STN = StridedTile<T, N, true>;
   using STW = StridedTile<T, N, false, 0>;
   const int tile = wide ? STW::TILE : STN::TILE, threads = wide ? STW::THREADS : STN::THREADS;
@@ -229,6 +229,10 @@ static void emu3_mid(NkPassM pm, const nk_fuse& f, const C2<T>* tw, C2<T>* work,
       if (pf) NK_MID_MF(2, true, SW, STW::TILE) else NK_MID_MF(2, false, SW, STW::TILE)
     } else if (cx) {
       if (pf) NK_MID_MF(1, true, SN, STN::TILE) else NK_MID_MF(1, false, SN, STN::TILE)
+    } else if (twc) {  // composed twiddles (the two-workgroups-per-CU configuration of k3_mid)
+      HostExecR<MidRegs<T, SN::E, false>> ex(threads);
+      if (f.mul) nk_mid_body<T, N, STN::TILE, 0, true, false, SN, true>(ex, pm, f, wg, nwg, blocks, 1, plane.data(), tw, work);
+      else nk_mid_body<T, N, STN::TILE, 0, false, false, SN, true>(ex, pm, f, wg, nwg, blocks, 1, plane.data(), tw, work);
     } else {
       if (pf) NK_MID_MF(0, true, SN, STN::TILE) else NK_MID_MF(0, false, SN, STN::TILE)
     }

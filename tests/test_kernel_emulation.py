@@ -203,11 +203,11 @@ def run_sandwich(f, shape, dtype, scale_first, conv=0, batch=1, cx=0):
 
 @pytest.mark.parametrize("shape", [(64, 128), (128, 128), (64, 256), (64, 64, 128), (128, 64, 128), (64, 128, 256)])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("cx", [0, 1, 2, 3])
+@pytest.mark.parametrize("cx", [0, 1, 2, 3, 8])
 def test_sandwich_emulation(shape, dtype, cx):
     """nk_hartley_sandwich (five-pass H D H, nk_fft3.h) against two scipy transforms: plain, both conventions, a
-    batch of 2, constant and field diagonal.  cx bit 0: complex-plane exchange of the fused pass, cx >= 2: persistent
-    workgroups (5 of them) with register prefetch of the next tile."""
+    batch of 2, constant and field diagonal.  cx bit 0: complex-plane exchange of the fused pass, bit 1: persistent
+    workgroups (5 of them) with register prefetch of the next tile, 8: composed twiddles."""
     rng = np.random.default_rng(5)
     x = rng.normal(size=(2,) + shape).astype(dtype)
     m = rng.normal(size=(2,) + shape).astype(dtype)
@@ -307,7 +307,7 @@ def test_wide_schedule_emulation():
     shape = (1024, 128)
     x = rng.normal(size=shape).astype(np.float32)
     m = rng.normal(size=shape).astype(np.float32)
-    for mode in (4, 6):
+    for mode in (4, 6, 8):
         out = np.empty_like(x)
         f = Fuse()
         f.in_, f.out, f.scale, f.mul_scalar, f.mul = x.ctypes.data, out.ctypes.data, 1.0 / x.size, 1.0, m.ctypes.data
