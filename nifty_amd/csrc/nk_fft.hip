@@ -460,10 +460,13 @@ static int nk_dispatch_contig3(int h, const NkPass3& p3, const NkFuse& f, const 
 #ifndef NK_MID_TWO
 #define NK_MID_TWO 1
 #endif
+#ifndef NK_MID_TWO_MF
+#define NK_MID_TWO_MF 0  // the two-workgroup configuration also for a field diagonal
+#endif
 template <typename T, int N, bool MF>
 struct MidCfg {
   static constexpr bool WIDE = NK_MID_WIDE && SchedW<T, N>::E == 64;
-  static constexpr bool TWO = NK_MID_TWO && !WIDE && !MF && sizeof(T) == 4 && Sched<T, N>::E == 32 &&
+  static constexpr bool TWO = NK_MID_TWO && !WIDE && (!MF || NK_MID_TWO_MF) && sizeof(T) == 4 && Sched<T, N>::E == 32 &&
                               StridedTile<T, N, false, 3>::THREADS == 512 && StridedTile<T, N, false, 3>::LDS_BYTES <= 64 * 1024;
   using ST = StridedTile<T, N, !WIDE && !TWO && NK_MID_CX != 0, WIDE ? 0 : 3>;
   using SC = typename ST::SC;

@@ -348,25 +348,34 @@ NK_HD void nk_mid_body(Exec& ex, const NkPassM& pm, const NkFuse& f, int64_t v0,
       constexpr int R = SC::radix(LS), Q = E / R;
       const T sg = (T)p.g.sign, ms = (T)pm.mid_scale;
       if constexpr (MF) {
-        const T* mul = (const T*)f.mul;
-        // m(a, b, c) for the real part, m(-a, -b, -c) for the imaginary part: 64-byte pieces of the user's field
+        // m(a, b, c) for the real part, m(-a, -b, -c) for the imaginary part: 64-byte pieces of the user's field.
+        // Addresses as a wave-uniform 64-bit part (the register slot's row) + a 32-bit per-thread byte offset (nk_at32):
+        // 2 E loads with 64-bit per-lane addresses would cost 4 E VGPRs
         const int nl = p.g.nl, M = pm.M;
         const int64_t col = c0 + t;
         const int b = (int)(col / pm.rs), c = (int)(col % pm.rs);
         const bool valid = c <= nl / 2;
         const int64_t rowlen = (int64_t)M * nl;
-        const T* m1p = mul + (o * N * M + b) * (int64_t)nl + c;
-        const T* m2p = mul + (o * N * M + (b ? M - b : 0)) * (int64_t)nl + (c ? nl - c : 0);
+        const T* mb = (const T*)f.mul + o * N * rowlen;  // this batch entry
+        const int rp = nk_out_row<SC, LS>(pp, 0, 0);
+        const int RPMAX = nk_out_row<SC, LS>(SC::P - 1, 0, 0);  // rp <= RPMAX (rows of a thread grow with pp)
+        const uint32_t off1 = (uint32_t)((int64_t)b * nl + c), off2 = (uint32_t)((int64_t)(b ? M - b : 0) * nl + (c ? nl - c : 0));
+        const uint32_t t1 = (uint32_t)(rp * rowlen) + off1;
+        const uint32_t t2 = (uint32_t)((RPMAX - rp) * rowlen) + off2;
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const int a = nk_out_row<SC, LS>(pp, q, r);
+            const int ru = nk_out_row<SC, LS>(0, q, r);  // a = rp + ru
             const C2<T> F = rg.v[q * R + r];
             T m1 = (T)0, m2 = (T)0;
             if (valid) {
-              m1 = ms * m1p[a * rowlen];
-              m2 = ms * m2p[(a ? N - a : 0) * rowlen];
+              m1 = ms * nk_at32<T>(mb, (int64_t)ru * rowlen, t1);
+              // mirror row (N - a) % N: (N - ru - RPMAX) + (RPMAX - rp), except a = 0 (its own mirror)
+              if (ru == 0 && rp == 0)
+                m2 = ms * mb[off2];
+              else
+                m2 = ms * nk_at32<T>(mb, (int64_t)(N - ru - RPMAX) * rowlen, t2);
             }
             rg.v[q * R + r] = C2<T>{m1 * (F.x + sg * F.y), m2 * (F.x - sg * F.y)};
           }
