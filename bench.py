@@ -227,7 +227,9 @@ def main():
     model.counters = {k: 0 for k in model.counters}
     minimization.counters["cg_iterations"] = 0
     lib = L.load()
-    lib.nk_profile_enable(1)
+    # live per-kernel HIP events (the roofline object); NK_BENCH_PROFILE=0 switches them off for side measurements
+    if os.environ.get("NK_BENCH_PROFILE", "1") != "0":
+        lib.nk_profile_enable(1)
     collect_profile()
     sync()
     t0 = time.perf_counter()
