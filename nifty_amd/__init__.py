@@ -13,14 +13,16 @@ from .correlated_fields import (CorrelatedFieldMaker, CorrelatedFieldOperator, L
                                 NormalTransform, SimpleCorrelatedField)
 from .domains import (DomainTuple, MultiDomain, PowerSpace, RGSpace, StructuredDomain, UnstructuredDomain,  # noqa: F401
                       makeDomain)
-from .energy_operators import (BernoulliEnergy, EnergyOperator, GaussianEnergy, LikelihoodEnergyOperator, PoissonianEnergy,  # noqa: F401
+from .energy_operators import (BernoulliEnergy, EnergyOperator, GaussianEnergy, InverseGammaEnergy, LikelihoodEnergyOperator, PoissonianEnergy,  # noqa: F401
                                QuadraticFormOperator, Squared2NormOperator, StandardHamiltonian, StudentTEnergy)
 from .field import Field, MultiField, device_available, from_random, full, is_fieldlike, makeField  # noqa: F401
 from .kl import (EnergyAdapter, ResidualSampleList, SampledKLEnergy, SampledKLEnergyClass, SampleList,  # noqa: F401
                  draw_samples)
 from .minimization import (AbsDeltaEnergyController, ConjugateGradient, DeltaEnergyController, DescentMinimizer,  # noqa: F401
                            Energy, EnergyHistory, GradientNormController, GradInfNormController, IterationController,
-                           L_BFGS, LineSearch, NewtonCG, QuadraticEnergy, RelaxedNewton, SteepestDescent)
+                           L_BFGS, LineSearch, NewtonCG, QuadraticEnergy, RelaxedNewton, SteepestDescent,
+                           StochasticAbsDeltaEnergyController, VL_BFGS)
+from .probing import StatCalculator, approximation2endo  # noqa: F401
 from .operators import (Adder, BlockDiagonalOperator, ChainOperator, ContractionOperator, CountingOperator,  # noqa: F401
                         DiagonalOperator, HarmonicSmoothingOperator,
                         DOFDistributor, EndomorphicOperator, FFTOperator, FieldAdapter, HarmonicTransformOperator,

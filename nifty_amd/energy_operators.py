@@ -282,6 +282,54 @@ class BernoulliEnergy(LikelihoodEnergyOperator):
         return np.float64, res.sqrt().arctan().scale(-2.0)
 
 
+class InverseGammaEnergy(LikelihoodEnergyOperator):
+    """E(x) = sum (alpha+1) ln x + beta / x: the likelihood of a variance x given beta = |s|^2 / 2 of a field s with that
+    variance (reference energy_operators.py:643-701).  alpha: a scalar or a Field."""
+
+    def __init__(self, beta, alpha=-0.5):
+        if not isinstance(beta, Field):
+            raise TypeError(f"beta needs to be a `Field`. Got:\n{beta}")
+        if beta.dtype != np.float64:
+            raise TypeError(f"beta.dtype needs to be float64. Got: {beta.dtype}")
+        self._domain = DomainTuple.make(beta.domain)
+        self._beta = beta
+        if np.isscalar(alpha):
+            alpha = full(beta.domain, float(alpha))
+        elif not isinstance(alpha, Field):
+            raise TypeError(f"alpha needs to be a `Field`. Got:\n{alpha}")
+        self._alphap1 = alpha + 1.0
+        # residual 2 beta (a constant, as in the reference) with the metric x^-1 in data space
+        super().__init__(_ConstantFieldOperator(self._domain, beta * 2.0), lambda x: makeOp(x.reciprocal().sqrt()))
+
+    def apply(self, x):
+        self._check_input(x)
+        dev = (x.val if is_linearization(x) else x).device_id
+        res = x.log().vdot(self._alphap1.at(dev)) + x.reciprocal().vdot(self._beta.at(dev))
+        if not (is_linearization(x) and x.want_metric):
+            return res
+        return res.add_metric(self.get_metric_at(x.val))
+
+    def get_transformation(self):
+        return np.float64, makeOp(self._alphap1.sqrt()) @ Operator.identity_operator(self._domain).log()
+
+
+class _ConstantFieldOperator(Operator):
+    """x -> a fixed Field (the data residual of InverseGammaEnergy; zero Jacobian)."""
+
+    def __init__(self, domain, value):
+        self._domain = DomainTuple.make(domain)
+        self._target = value.domain
+        self._value = value
+
+    def apply(self, x):
+        self._check_input(x)
+        if is_linearization(x):
+            from .operators import NullOperator
+
+            return x.new(self._value.at(x.val.device_id), NullOperator(self._domain, self._target))
+        return self._value.at(x.device_id)
+
+
 class StandardHamiltonian(EnergyOperator):
     """likelihood energy + 1/2 |x|^2; its metric can draw samples through CG (energy_operators.py:890-931)."""
 

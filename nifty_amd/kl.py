@@ -297,8 +297,6 @@ def draw_samples(position, H, minimizer, n_samples, mirror_samples, napprox=0, w
         raise TypeError
     if not isinstance(H, StandardHamiltonian):
         raise TypeError
-    if napprox >= 1:
-        raise NotImplementedError("napprox preconditioning is out of scope (SURVEY 8f rank 4)")
     sam_position = position.extract(H.domain) if isinstance(position, MultiField) else position
     geometric = minimizer is not None
     if geometric:
@@ -314,6 +312,13 @@ def draw_samples(position, H, minimizer, n_samples, mirror_samples, napprox=0, w
                               H.iteration_controller)
     else:
         met = H(Linearization.make_var(sam_position, want_metric=True)).metric
+    if napprox >= 1:
+        # sampled diagonal of the metric as the preconditioner of the sampling solves (kl_energies.py:127-128); its draws
+        # come from the CURRENT stream, before the per-sample seeds are spawned -- same RNG order as the reference
+        from .operators import makeOp
+        from .probing import approximation2endo
+
+        met._approximation = makeOp(approximation2endo(met, napprox, device_id))
     sseq = random.spawn_sseq(n_samples)
     if mirror_samples:
         sseq = [s for ss in sseq for s in (ss, ss)]

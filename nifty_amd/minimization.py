@@ -313,6 +313,24 @@ class AbsDeltaEnergyController(_LevelController):
         return inc, f"diff={diff:.6E} crit={self._deltaE:.1E}"
 
 
+class StochasticAbsDeltaEnergyController(_LevelController):
+    """Convergence from the standard deviation of the last ``memory_length`` energies (for stochastic minimisers;
+    reference iteration_controllers.py:426-497)."""
+
+    def __init__(self, deltaE, convergence_level=1, iteration_limit=None, name=None, memory_length=10):
+        super().__init__(convergence_level, iteration_limit, name)
+        self._deltaE = deltaE
+        self.memory_length = memory_length
+
+    def _on_start(self, energy):
+        self._memory = []
+
+    def _criterion(self, energy):
+        self._memory = (self._memory + [energy.value])[-self.memory_length:]
+        diff = float(np.std(self._memory))
+        return self._itcount > 0 and diff < self._deltaE, f"diff={diff:.6E} crit={self._deltaE:.1E}"
+
+
 # ------------------------------------------------------------------------------------------------
 # conjugate gradient
 # ------------------------------------------------------------------------------------------------
@@ -814,6 +832,79 @@ class L_BFGS(DescentMinimizer):
         return p
 
 
+class VL_BFGS(DescentMinimizer):
+    """Vector-free L-BFGS (Chen, Wang, Zhou 2014; reference descent_minimizers.py:264-468): the two-loop recursion runs
+    on the (2m+1) x (2m+1) Gram matrix of the basis b = (s_1..s_m, y_1..y_m, g) instead of on vectors, so one descent
+    direction costs 3m+... dot products (cached across iterations) and ONE linear combination of the basis -- on the GPU
+    2m+1 axpy passes instead of the 4m of L_BFGS."""
+
+    def __init__(self, controller, line_searcher=None, max_history_length=5):
+        super().__init__(controller, line_searcher)
+        self.max_history_length = max_history_length
+        self.reset()
+
+    def __call__(self, energy):
+        self.reset()
+        return super().__call__(energy)
+
+    def reset(self):
+        m = self.max_history_length
+        self._k = 0  # number of stored updates so far
+        self._s, self._y = [None] * m, [None] * m
+        self._ss, self._sy, self._yy = (np.zeros((m, m)) for _ in range(3))
+        self._lastx = self._lastgrad = None
+
+    def _dot(self, a, b):
+        return _ls(np.real(a.s_vdot(b)))
+
+    def get_descent_direction(self, energy, _=None):
+        mmax = self.max_history_length
+        x, g = energy.position, energy.gradient
+        if self._lastx is not None:
+            self._s[self._k % mmax] = x - self._lastx
+            self._y[self._k % mmax] = g - self._lastgrad
+            self._k += 1
+        self._lastx, self._lastgrad = x, g
+        k, m = self._k, min(self._k, mmax)
+        slot = [(k - m + i) % mmax for i in range(m)]  # oldest ... newest
+        # scalar products involving the newest pair (everything older is cached)
+        if m:
+            new = slot[-1]
+            for i in slot:
+                self._ss[i, new] = self._ss[new, i] = self._dot(self._s[i], self._s[new])
+                self._yy[i, new] = self._yy[new, i] = self._dot(self._y[i], self._y[new])
+                self._sy[i, new] = self._dot(self._s[i], self._y[new])
+            for j in slot[:-1]:
+                self._sy[new, j] = self._dot(self._s[new], self._y[j])
+        n = 2 * m + 1
+        B = np.empty((n, n))
+        for i, si in enumerate(slot):
+            for j, sj in enumerate(slot):
+                B[i, j] = self._ss[si, sj]
+                B[i, m + j] = B[m + j, i] = self._sy[si, sj]
+                B[m + i, m + j] = self._yy[si, sj]
+            B[2 * m, i] = B[i, 2 * m] = self._dot(self._s[si], g)
+            B[2 * m, m + i] = B[m + i, 2 * m] = self._dot(self._y[si], g)
+        B[2 * m, 2 * m] = g.norm()  # (never read below; the reference stores the norm here, not its square)
+        # two-loop recursion in coefficient space
+        delta = np.zeros(n)
+        delta[2 * m] = -1.0
+        alpha = np.empty(m)
+        for j in range(m - 1, -1, -1):
+            alpha[j] = float(np.dot(delta, B[:, j])) / B[j, m + j]
+            delta[m + j] -= alpha[j]
+        if m:
+            delta *= B[m - 1, 2 * m - 1] / B[2 * m - 1, 2 * m - 1]
+        for j in range(m):
+            beta = float(np.dot(delta, B[m + j, :])) / B[j, m + j]
+            delta[j] += alpha[j] - beta
+        basis = [self._s[i] for i in slot] + [self._y[i] for i in slot] + [g]
+        direction = basis[0] * delta[0]
+        for coeff, vec in zip(delta[1:], basis[1:]):
+            direction = direction + vec * coeff
+        return direction
+
+
 class NewtonCG(DescentMinimizer):
     """Inexact Newton: CG on metric * delta = gradient (reference descent_minimizers.py:166-210)."""
 
@@ -822,8 +913,7 @@ class NewtonCG(DescentMinimizer):
         if line_searcher is None:
             line_searcher = LineSearch(preferred_initial_step_size=1.0)
         super().__init__(controller, line_searcher)
-        if napprox > 1:
-            raise NotImplementedError("napprox preconditioning is out of scope (SURVEY 8f rank 4)")
+        self._napprox = napprox
         self._name, self._nreset = name, nreset
         self._max_cg_iterations = max_cg_iterations
         self._alpha = energy_reduction_factor
@@ -842,7 +932,14 @@ class NewtonCG(DescentMinimizer):
         # reference's metric application to the zero vector is skipped.
         zero = energy.position * 0.0
         quad = QuadraticEnergy(zero, energy.metric, g, _grad=-g, _value=0.0)  # E(0) = 0
-        quad, conv = ConjugateGradient(ic, nreset=self._nreset)(quad)
+        precond = None
+        if self._napprox > 1:
+            # sampled diagonal of the metric as CG preconditioner (descent_minimizers.py:201-203)
+            from .operators import makeOp
+            from .probing import approximation2endo
+
+            precond = makeOp(approximation2endo(energy.metric, self._napprox, getattr(energy.position, "device_id", -1))).inverse
+        quad, conv = ConjugateGradient(ic, nreset=self._nreset)(quad, precond)
         if self._history is not None:
             self._history += ic.history
         if conv == ERROR:

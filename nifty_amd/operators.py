@@ -1060,8 +1060,9 @@ class SumOperator(LinearOperator):
                 rest.append(op)
                 rneg.append(n)
         if scal is not None:
-            rest.insert(0, ScalingOperator(scal[0], scal[1], sdt))
-            rneg.insert(0, False)
+            # at the END like the reference (sum_operator.py:104-107): the order fixes the RNG sequence of draw_sample
+            rest.append(ScalingOperator(scal[0], scal[1], sdt))
+            rneg.append(False)
         if len(rest) == 1:
             return rest[0] if not rneg[0] else rest[0].scale(-1)
         return SumOperator(tuple(rest), tuple(rneg), _callingfrommake=True)

@@ -272,7 +272,8 @@ def _optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, s
             continue
         ns = n_samples(ig)
         model = None
-        if fuse and device_id >= 0 and ns > 0 and not cst and not pes:  # partial constants: generic graph
+        # partial constants and a preconditioned NewtonCG (napprox) run on the generic graph
+        if fuse and device_id >= 0 and ns > 0 and not cst and not pes and getattr(minimizer, "_napprox", 0) <= 1:
             model = _fused_model(lh, device_id, mean_iter["xi"].dtype if "xi" in mean_iter else np.float64)
         if model is not None:
             new_mean, sl, value = _fused_iteration(model, lh, mean_iter, ns, minimizer, sampling_iteration_controller(ig),

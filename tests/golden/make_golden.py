@@ -264,13 +264,45 @@ def minimizer_cases():
                                   prior_sampling_dtype=np.float64)
     out = {}
     runs = {"lbfgs": ift.L_BFGS(ift.AbsDeltaEnergyController(0.1, iteration_limit=6)),
-            "steepest": ift.SteepestDescent(ift.GradientNormController(iteration_limit=3))}
+            "steepest": ift.SteepestDescent(ift.GradientNormController(iteration_limit=3)),
+            "vlbfgs": ift.VL_BFGS(ift.AbsDeltaEnergyController(0.1, iteration_limit=6), max_history_length=3),
+            "lbfgs_stoch": ift.L_BFGS(ift.StochasticAbsDeltaEnergyController(5.0, iteration_limit=8, memory_length=3))}
     for name, mini in runs.items():
         e, _ = mini(ift.EnergyAdapter(x, ham, want_metric=True))
         out[f"{name}.value"] = np.array(e.value)
         out.update(mf2dict(e.position, f"{name}.pos"))
     np.savez_compressed(os.path.join(HERE, "minimizers.npz"), **out)
     print("wrote minimizers", {k: float(out[k]) for k in out if k.endswith("value")})
+
+
+def napprox_cases():
+    """The sampled diagonal preconditioner (`napprox`, kl_energies.py:127-128, descent_minimizers.py:201-203,
+    probing.py:142-152) on the g1d model: MGVI samples with napprox=3 and a NewtonCG(napprox=3) minimisation of the Hamiltonian."""
+    z = np.load(os.path.join(HERE, "model_g1d.npz"))
+    sp = ift.RGSpace(tuple(int(i) for i in z["meta.shape"]))
+    cfm, cf = make_cf(sp)
+    d = ift.makeField(cf.target, z["data"])
+    # (short CG runs: the badly scaled three-sample diagonal makes the preconditioned solve amplify rounding differences
+    # by 1e8 within eight iterations)
+    lh = ift.GaussianEnergy(d, ift.ScalingOperator(cf.target, float(z["icov"]), np.float64)) @ cf
+    x = ift.MultiField.from_raw(cf.domain, {k[2:]: z[k] for k in z.files if k.startswith("x.")})
+    ham = ift.StandardHamiltonian(lh, ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=4),
+                                  prior_sampling_dtype=np.float64)
+    out = {}
+    ift.random.push_sseq_from_seed(44)
+    kl = ift.SampledKLEnergy(x, ham, 2, None, mirror_samples=True, napprox=3)
+    ift.random.pop_sseq()
+    out["kl.value"] = np.array(kl.value)
+    for i, s in enumerate(kl.samples.iterator()):
+        out.update(mf2dict(s, f"kl.sample{i}"))
+    ift.random.push_sseq_from_seed(45)
+    mini = ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=2), napprox=3, max_cg_iterations=4)
+    e, _ = mini(ift.EnergyAdapter(x, ham, want_metric=True))  # (the KL metric wrapper cannot draw samples)
+    ift.random.pop_sseq()
+    out["newton.value"] = np.array(e.value)
+    out.update(mf2dict(e.position, "newton.pos"))
+    np.savez_compressed(os.path.join(HERE, "napprox.npz"), **out)
+    print("wrote napprox", float(out["kl.value"]), float(out["newton.value"]))
 
 
 def constants_cases():
@@ -455,8 +487,12 @@ def likelihood_cases():
     th = rng.uniform(2, 5, size=shape)
     sp = ift.RGSpace(shape)
     out = dict(x=x, v=v, d=d, theta=th)
+    beta = rng.uniform(0.5, 2.0, size=shape)
+    out["beta"] = beta
     for name, e in (("bernoulli", ift.BernoulliEnergy(ift.makeField(sp, d))), ("studentt", ift.StudentTEnergy(sp, 3.0)),
-                    ("studentt_field", ift.StudentTEnergy(sp, ift.makeField(sp, th)))):
+                    ("studentt_field", ift.StudentTEnergy(sp, ift.makeField(sp, th))),
+                    ("invgamma", ift.InverseGammaEnergy(ift.makeField(sp, beta))),
+                    ("invgamma_field", ift.InverseGammaEnergy(ift.makeField(sp, beta), ift.makeField(sp, th)))):
         lin = e(ift.Linearization.make_var(ift.makeField(sp, x), want_metric=True))
         out[f"{name}.value"] = np.asarray(lin.val.asnumpy())
         out[f"{name}.grad"] = lin.gradient.asnumpy()
@@ -481,6 +517,8 @@ def main():
         return los_cases()
     if "--min-only" in sys.argv:
         return minimizer_cases()
+    if "--napprox-only" in sys.argv:
+        return napprox_cases()
     geo = {}
     for shape, dist in [((8,), None), ((7, 8), None), ((4, 5, 7), None), ((512,), None), ((64, 64), None),
                         ((16, 16, 16), None), ((16, 32), (0.3, 0.2)), ((12,), (0.7,))]:

@@ -205,14 +205,17 @@ def test_harmonic_smoothing_and_counting_operator(device_id):
 
 @pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
 def test_lbfgs_and_steepest_descent_match_reference(device_id):
-    """descent_minimizers.py:138-262 on the Hamiltonian of the g1d model (tests/golden/minimizers.npz)."""
+    """descent_minimizers.py:138-468 on the Hamiltonian of the g1d model (tests/golden/minimizers.npz)."""
     z, zm = gl.load("model_g1d"), gl.load("minimizers")
     m, cfm, cf, lh = build(z, device_id)
     x = ift.MultiField.from_raw(cf.domain, gl.latent(z, "x"), device_id)
     ham = ift.StandardHamiltonian(lh, ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=10),
                                   prior_sampling_dtype=np.float64)
     runs = {"lbfgs": ift.L_BFGS(ift.AbsDeltaEnergyController(0.1, iteration_limit=6)),
-            "steepest": ift.SteepestDescent(ift.GradientNormController(iteration_limit=3))}
+            "steepest": ift.SteepestDescent(ift.GradientNormController(iteration_limit=3)),
+            # vector-free L-BFGS (:264-468) and the stochastic controller (iteration_controllers.py:426-497)
+            "vlbfgs": ift.VL_BFGS(ift.AbsDeltaEnergyController(0.1, iteration_limit=6), max_history_length=3),
+            "lbfgs_stoch": ift.L_BFGS(ift.StochasticAbsDeltaEnergyController(5.0, iteration_limit=8, memory_length=3))}
     for name, mini in runs.items():
         e, _ = mini(ift.EnergyAdapter(x, ham, want_metric=True))
         assert abs(e.value - float(zm[f"{name}.value"])) < 1e-9 * abs(float(zm[f"{name}.value"]))
@@ -391,7 +394,10 @@ def test_studentt_and_bernoulli_energies(device_id):
     sp = ift.RGSpace(z["x"].shape)
     x, v = ift.makeField(sp, z["x"], device_id), ift.makeField(sp, z["v"], device_id)
     energies = {"bernoulli": ift.BernoulliEnergy(ift.makeField(sp, z["d"])), "studentt": ift.StudentTEnergy(sp, 3.0),
-                "studentt_field": ift.StudentTEnergy(sp, ift.makeField(sp, z["theta"]))}
+                "studentt_field": ift.StudentTEnergy(sp, ift.makeField(sp, z["theta"])),
+                # InverseGammaEnergy (energy_operators.py:643-701), scalar and field alpha
+                "invgamma": ift.InverseGammaEnergy(ift.makeField(sp, z["beta"])),
+                "invgamma_field": ift.InverseGammaEnergy(ift.makeField(sp, z["beta"]), ift.makeField(sp, z["theta"]))}
     for name, e in energies.items():
         lin = e(ift.Linearization.make_var(x, want_metric=True))
         assert abs(float(lin.val.asnumpy()) - float(z[f"{name}.value"])) < 1e-12 * abs(float(z[f"{name}.value"]))
@@ -403,12 +409,17 @@ def test_studentt_and_bernoulli_energies(device_id):
         try:
             check_operator(energies["studentt"], ift.makeField(sp, z["x"]), tol=1e-8, ntries=2)
             check_operator(energies["bernoulli"], ift.makeField(sp, z["x"]), tol=1e-7, ntries=2)
+            check_operator(energies["invgamma_field"], ift.makeField(sp, z["x"]), tol=1e-7, ntries=2)
         finally:
             ift.random.pop_sseq()
     with pytest.raises(ValueError):
         ift.BernoulliEnergy(ift.makeField(sp, np.full(sp.shape, 2, dtype=np.int64)))
     with pytest.raises(TypeError):
         ift.BernoulliEnergy(ift.makeField(sp, z["x"]))
+    with pytest.raises(TypeError):
+        ift.InverseGammaEnergy(z["beta"])
+    with pytest.raises(TypeError):
+        ift.InverseGammaEnergy(ift.makeField(sp, z["beta"].astype(np.float32)))
 
 
 @pytest.mark.parametrize("tag", ["noasp", "both"])
@@ -433,3 +444,38 @@ def test_reduced_amplitude_models(tag, device_id):
     assert gl.lat_relerr(lin.jac.adjoint(w).asnumpy(), _lat(z, f"{tag}.cf_vjp")) < 1e-11
     with pytest.raises(ValueError):
         ift.CorrelatedFieldMaker("").add_fluctuations(ift.RGSpace((8,)), (1.0, 0.5), None, (0.5, 0.05), (-3.0, 0.2))
+
+
+@pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
+def test_napprox_preconditioner_matches_reference(device_id):
+    """The sampled diagonal preconditioner `napprox` (kl_energies.py:127-128, descent_minimizers.py:201-203,
+    probing.py:24-75, 142-152): MGVI samples and a NewtonCG run against tests/golden/napprox.npz (RNG order included:
+    the probing draws come from the current stream before the sample seeds are spawned)."""
+    z, zn = gl.load("model_g1d"), gl.load("napprox")
+    m, cfm, cf, lh = build(z, device_id)
+    x = ift.MultiField.from_raw(cf.domain, gl.latent(z, "x"), device_id)
+    ham = ift.StandardHamiltonian(lh, ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=4),
+                                  prior_sampling_dtype=np.float64)
+    ift.random.push_sseq_from_seed(44)
+    try:
+        kl = ift.SampledKLEnergy(x, ham, 2, None, mirror_samples=True, napprox=3, device_id=device_id)
+    finally:
+        ift.random.pop_sseq()
+    assert abs(kl.value - float(zn["kl.value"])) < 1e-8 * abs(float(zn["kl.value"]))
+    for i, s in enumerate(kl.samples.iterator()):
+        assert gl.lat_relerr(s.asnumpy(), _lat(zn, f"kl.sample{i}")) < 1e-7
+    ift.random.push_sseq_from_seed(45)
+    try:
+        mini = ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=2), napprox=3, max_cg_iterations=4)
+        e, _ = mini(ift.EnergyAdapter(x, ham, want_metric=True))
+    finally:
+        ift.random.pop_sseq()
+    assert abs(e.value - float(zn["newton.value"])) < 1e-8 * abs(float(zn["newton.value"]))
+    assert gl.lat_relerr(e.position.asnumpy(), _lat(zn, "newton.pos")) < 1e-7
+    # StatCalculator: running mean / unbiased variance
+    sc = ift.StatCalculator()
+    vals = [ift.full(cf.target, float(v)) for v in (1.0, 2.0, 4.0)]
+    for v in vals:
+        sc.add(v)
+    assert abs(float(sc.mean.asnumpy().ravel()[0]) - 7.0 / 3.0) < 1e-14
+    assert abs(float(sc.var.asnumpy().ravel()[0]) - np.var([1.0, 2.0, 4.0], ddof=1)) < 1e-14
