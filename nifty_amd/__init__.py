@@ -13,8 +13,9 @@ from .correlated_fields import (CorrelatedFieldMaker, CorrelatedFieldOperator, L
                                 NormalTransform, SimpleCorrelatedField)
 from .domains import (DomainTuple, MultiDomain, PowerSpace, RGSpace, StructuredDomain, UnstructuredDomain,  # noqa: F401
                       makeDomain)
-from .energy_operators import (BernoulliEnergy, EnergyOperator, GaussianEnergy, InverseGammaEnergy, LikelihoodEnergyOperator, PoissonianEnergy,  # noqa: F401
-                               QuadraticFormOperator, Squared2NormOperator, StandardHamiltonian, StudentTEnergy)
+from .energy_operators import (AveragedEnergy, BernoulliEnergy, CategoricalEnergy, EnergyOperator, GaussianEnergy, InverseGammaEnergy, LikelihoodEnergyOperator, PoissonianEnergy,  # noqa: F401
+                               QuadraticFormOperator, Squared2NormOperator, StandardHamiltonian, StudentTEnergy,
+                               VariableCovarianceGaussianEnergy)
 from .field import Field, MultiField, device_available, from_random, full, is_fieldlike, makeField  # noqa: F401
 from .kl import (EnergyAdapter, ResidualSampleList, SampledKLEnergy, SampledKLEnergyClass, SampleList,  # noqa: F401
                  draw_samples)

@@ -282,6 +282,103 @@ class BernoulliEnergy(LikelihoodEnergyOperator):
         return np.float64, res.sqrt().arctan().scale(-2.0)
 
 
+class VariableCovarianceGaussianEnergy(LikelihoodEnergyOperator):
+    """-log of a Gaussian in the residual s with an UNKNOWN diagonal inverse covariance C, both inferred:
+    E(s, C) = 1/2 s^T C s - 1/2 tr log C on the MultiDomain {residual_key, inverse_covariance_key}
+    (reference energy_operators.py:355-450; real sampling dtypes).  ``use_full_fisher``: the exact Fisher metric
+    diag(C, 1/2 C^-2); otherwise the metric of the local transformation used by geoVI."""
+
+    def __init__(self, domain, residual_key, inverse_covariance_key, sampling_dtype, use_full_fisher=True):
+        self._kr, self._ki = str(residual_key), str(inverse_covariance_key)
+        dom = DomainTuple.make(domain)
+        self._domain = MultiDomain.make({self._kr: dom, self._ki: dom})
+        if np.issubdtype(np.dtype(sampling_dtype), np.complexfloating):
+            raise NotImplementedError("complex residuals are not supported")
+        self._dt = {self._kr: np.dtype(sampling_dtype).type, self._ki: np.float64}
+        self._use_full_fisher = bool(use_full_fisher)
+        super().__init__(Operator.identity_operator(dom).ducktape(self._kr), lambda x: makeOp(x[self._ki].sqrt()))
+
+    def apply(self, x):
+        self._check_input(x)
+        r, i = x[self._kr], x[self._ki]
+        res = (r.vdot(r * i) - i.log().sum()) * 0.5
+        if not (is_linearization(x) and x.want_metric):
+            return res
+        if not self._use_full_fisher:
+            return res.add_metric(self.get_metric_at(x.val))
+        ival = i.val
+        met = MultiField.from_dict({self._kr: ival, self._ki: (ival ** (-2)) * 0.5}, self._domain)
+        return res.add_metric(makeOp(met, sampling_dtype=self._dt))
+
+    def get_transformation(self):
+        """No global transformation to a Euclidean space exists for this energy; a local one invoking the residual is
+        used (reference :436-450)."""
+        from .operators import FieldAdapter
+
+        r = FieldAdapter(self._domain[self._kr], self._kr)
+        ivar = FieldAdapter(self._domain[self._kr], self._ki)
+        f = r.adjoint @ (ivar.sqrt() * r) + ivar.adjoint @ (ivar.log().scale(0.5))
+        return self._dt, f
+
+
+class CategoricalEnergy(LikelihoodEnergyOperator):
+    """E(x) = -sum d log x for one-hot data d and probabilities x normalised along `axis` by the caller (reference
+    energy_operators.py:795-850)."""
+
+    def __init__(self, d, axis=0):
+        if not isinstance(d, Field) or not np.issubdtype(d.dtype, np.integer):
+            raise TypeError(f"d needs to be a Field with integer values. Got:\n{d}")
+        d_np = d.asnumpy()
+        vals = set(np.unique(d_np).tolist())
+        if not vals <= {0, 1}:
+            raise ValueError(f"d can only contain 0 and 1. Got: {vals}")
+        if not np.all(np.sum(d_np, axis=axis) == 1):
+            raise ValueError("d must sum to 1 along the category axis (one-hot encoded)")
+        self._d, self._axis = d, axis
+        self._d_float = {}
+        self._domain = DomainTuple.make(d.domain)
+        super().__init__(Adder(d, neg=True), lambda x: self.get_metric_at(x).get_sqrt())
+
+    def apply(self, x):
+        self._check_input(x)
+        xv = x.val if is_linearization(x) else x
+        key = (xv.device_id, xv.dtype)
+        if key not in self._d_float:
+            self._d_float[key] = self._d.at(xv.device_id).astype(xv.dtype)
+        res = -x.log().vdot(self._d_float[key])
+        if not (is_linearization(x) and x.want_metric):
+            return res
+        return res.add_metric(self.get_metric_at(x.val))
+
+    def get_transformation(self):
+        return np.float64, Operator.identity_operator(self._domain).sqrt().scale(2.0)
+
+
+class AveragedEnergy(EnergyOperator):
+    """Mean of an energy over residual samples, E(x) = 1/n sum_s h(x + v_s) (reference energy_operators.py:934-971)."""
+
+    def __init__(self, h, res_samples):
+        self._h, self._domain = h, h.domain
+        self._res_samples = tuple(res_samples)
+
+    def apply(self, x):
+        self._check_input(x)
+        dev = (x.val if is_linearization(x) else x).device_id
+        res = None
+        for v in self._res_samples:
+            term = self._h(x + v.at(dev))
+            res = term if res is None else res + term
+        return res * (1.0 / len(self._res_samples))
+
+    def get_transformation(self):
+        dtp, trafo = self._h.get_transformation()
+        tot = None
+        for v in self._res_samples:
+            term = trafo @ Adder(v)
+            tot = term if tot is None else tot + term
+        return dtp, tot.scale(1.0 / np.sqrt(len(self._res_samples)))
+
+
 class InverseGammaEnergy(LikelihoodEnergyOperator):
     """E(x) = sum (alpha+1) ln x + beta / x: the likelihood of a variance x given beta = |s|^2 / 2 of a field s with that
     variance (reference energy_operators.py:643-701).  alpha: a scalar or a Field."""

@@ -498,6 +498,42 @@ def likelihood_cases():
         out[f"{name}.grad"] = lin.gradient.asnumpy()
         out[f"{name}.metric_v"] = lin.metric(ift.makeField(sp, v)).asnumpy()
         out[f"{name}.trafo"] = e.get_transformation()[1](ift.makeField(sp, x)).asnumpy()
+    # CategoricalEnergy (:795-850): 5 categories along axis 0, probabilities normalised along it
+    ncat = 5
+    csp = ift.RGSpace((ncat, 12))
+    hot = np.zeros((ncat, 12), dtype=np.int64)
+    hot[rng.integers(0, ncat, size=12), np.arange(12)] = 1
+    prob = rng.uniform(0.1, 1.0, size=(ncat, 12))
+    prob /= prob.sum(axis=0, keepdims=True)
+    cv = rng.normal(size=(ncat, 12))
+    out.update(cat_d=hot, cat_x=prob, cat_v=cv)
+    e = ift.CategoricalEnergy(ift.makeField(csp, hot))
+    lin = e(ift.Linearization.make_var(ift.makeField(csp, prob), want_metric=True))
+    out["categorical.value"] = np.asarray(lin.val.asnumpy())
+    out["categorical.grad"] = lin.gradient.asnumpy()
+    out["categorical.metric_v"] = lin.metric(ift.makeField(csp, cv)).asnumpy()
+    out["categorical.trafo"] = e.get_transformation()[1](ift.makeField(csp, prob)).asnumpy()
+    # AveragedEnergy (:934-971) of a StudentT energy over three residual samples
+    res_samples = [rng.normal(size=shape) * 0.1 for _ in range(3)]
+    out["avg_samples"] = np.array(res_samples)
+    e = ift.AveragedEnergy(ift.StudentTEnergy(sp, 3.0), [ift.makeField(sp, r_) for r_ in res_samples])
+    lin = e(ift.Linearization.make_var(ift.makeField(sp, x), want_metric=True))
+    out["averaged.value"] = np.asarray(lin.val.asnumpy())
+    out["averaged.grad"] = lin.gradient.asnumpy()
+    out["averaged.metric_v"] = lin.metric(ift.makeField(sp, v)).asnumpy()
+    # VariableCovarianceGaussianEnergy (energy_operators.py:355-450): residual and inverse covariance both latent
+    rr, ii, vr, vi = rng.normal(size=shape), rng.uniform(0.5, 2.0, size=shape), rng.normal(size=shape), rng.normal(size=shape)
+    out.update(vcg_r=rr, vcg_i=ii, vcg_vr=vr, vcg_vi=vi)
+    for full in (True, False):
+        e = ift.VariableCovarianceGaussianEnergy(sp, "res", "icov", np.float64, use_full_fisher=full)
+        pos = ift.MultiField.from_raw(e.domain, {"res": rr, "icov": ii})
+        vv = ift.MultiField.from_raw(e.domain, {"res": vr, "icov": vi})
+        lin = e(ift.Linearization.make_var(pos, want_metric=True))
+        tag = "vcg_full" if full else "vcg_local"
+        out[f"{tag}.value"] = np.asarray(lin.val.asnumpy())
+        out.update(mf2dict(lin.gradient, f"{tag}.grad"))
+        out.update(mf2dict(lin.metric(vv), f"{tag}.metric_v"))
+        out.update(mf2dict(e.get_transformation()[1](pos), f"{tag}.trafo"))
     np.savez_compressed(os.path.join(HERE, "likelihoods.npz"), **out)
     print("wrote likelihoods", {k: float(out[k]) for k in out if k.endswith("value")})
 

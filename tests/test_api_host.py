@@ -479,3 +479,46 @@ def test_napprox_preconditioner_matches_reference(device_id):
         sc.add(v)
     assert abs(float(sc.mean.asnumpy().ravel()[0]) - 7.0 / 3.0) < 1e-14
     assert abs(float(sc.var.asnumpy().ravel()[0]) - np.var([1.0, 2.0, 4.0], ddof=1)) < 1e-14
+
+
+@pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("full", [True, False])
+def test_variable_covariance_gaussian_energy(device_id, full):
+    """VariableCovarianceGaussianEnergy (energy_operators.py:355-450) on a MultiDomain {residual, inverse covariance}:
+    value, gradient, metric (exact Fisher / local transformation) and get_transformation against
+    tests/golden/likelihoods.npz."""
+    z = gl.load("likelihoods")
+    sp = ift.RGSpace(z["vcg_r"].shape)
+    e = ift.VariableCovarianceGaussianEnergy(sp, "res", "icov", np.float64, use_full_fisher=full)
+    pos = ift.MultiField.from_raw(e.domain, {"res": z["vcg_r"], "icov": z["vcg_i"]}, device_id)
+    vv = ift.MultiField.from_raw(e.domain, {"res": z["vcg_vr"], "icov": z["vcg_vi"]}, device_id)
+    lin = e(ift.Linearization.make_var(pos, want_metric=True))
+    tag = "vcg_full" if full else "vcg_local"
+    assert abs(float(lin.val.asnumpy()) - float(z[f"{tag}.value"])) < 1e-12 * abs(float(z[f"{tag}.value"]))
+    assert gl.lat_relerr(lin.gradient.asnumpy(), _lat(z, f"{tag}.grad")) < 1e-12
+    assert gl.lat_relerr(lin.metric(vv).asnumpy(), _lat(z, f"{tag}.metric_v")) < 1e-12
+    assert gl.lat_relerr(e.get_transformation()[1](pos).asnumpy(), _lat(z, f"{tag}.trafo")) < 1e-12
+    with pytest.raises(NotImplementedError):
+        ift.VariableCovarianceGaussianEnergy(sp, "res", "icov", np.complex128)
+
+
+@pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
+def test_categorical_and_averaged_energies(device_id):
+    """CategoricalEnergy (energy_operators.py:795-850) and AveragedEnergy (:934-971) against tests/golden/likelihoods.npz."""
+    z = gl.load("likelihoods")
+    csp = ift.RGSpace(z["cat_d"].shape)
+    e = ift.CategoricalEnergy(ift.makeField(csp, z["cat_d"]))
+    x, v = ift.makeField(csp, z["cat_x"], device_id), ift.makeField(csp, z["cat_v"], device_id)
+    lin = e(ift.Linearization.make_var(x, want_metric=True))
+    assert abs(float(lin.val.asnumpy()) - float(z["categorical.value"])) < 1e-12 * abs(float(z["categorical.value"]))
+    assert gl.relerr(lin.gradient.asnumpy(), z["categorical.grad"]) < 1e-12
+    assert gl.relerr(lin.metric(v).asnumpy(), z["categorical.metric_v"]) < 1e-12
+    assert gl.relerr(e.get_transformation()[1](x).asnumpy(), z["categorical.trafo"]) < 1e-12
+    with pytest.raises(ValueError):
+        ift.CategoricalEnergy(ift.makeField(csp, np.ones(csp.shape, dtype=np.int64)))
+    sp = ift.RGSpace(z["x"].shape)
+    e = ift.AveragedEnergy(ift.StudentTEnergy(sp, 3.0), [ift.makeField(sp, r) for r in z["avg_samples"]])
+    lin = e(ift.Linearization.make_var(ift.makeField(sp, z["x"], device_id), want_metric=True))
+    assert abs(float(lin.val.asnumpy()) - float(z["averaged.value"])) < 1e-12 * abs(float(z["averaged.value"]))
+    assert gl.relerr(lin.gradient.asnumpy(), z["averaged.grad"]) < 1e-12
+    assert gl.relerr(lin.metric(ift.makeField(sp, z["v"], device_id)).asnumpy(), z["averaged.metric_v"]) < 1e-12
