@@ -24,6 +24,7 @@ from .minimization import (AbsDeltaEnergyController, ConjugateGradient, DeltaEne
                            L_BFGS, LineSearch, NewtonCG, QuadraticEnergy, RelaxedNewton, SteepestDescent,
                            StochasticAbsDeltaEnergyController, VL_BFGS)
 from .probing import StatCalculator, approximation2endo  # noqa: F401
+from .operators import PrependKey  # noqa: F401
 from .operators import (Adder, BlockDiagonalOperator, ChainOperator, ContractionOperator, CountingOperator,  # noqa: F401
                         DiagonalOperator, HarmonicSmoothingOperator,
                         DOFDistributor, EndomorphicOperator, FFTOperator, FieldAdapter, HarmonicTransformOperator,

@@ -46,6 +46,12 @@ class LikelihoodEnergyOperator(EnergyOperator):
     def __rmatmul__(self, other):
         return _LikelihoodChain(other, self)
 
+    def __add__(self, other):
+        return _LikelihoodSum.make([self, other])
+
+    def __radd__(self, other):
+        return _LikelihoodSum.make([other, self])
+
     def get_metric_at(self, x):
         dtp, f = self.get_transformation()
         bun = f(Linearization.make_var(x)).jac
@@ -57,6 +63,9 @@ class LikelihoodEnergyOperator(EnergyOperator):
 
     @name.setter
     def name(self, x):
+        if isinstance(self, _LikelihoodSum):
+            raise RuntimeError("The name of a LikelihoodSum cannot be set. Set the name of each individual "
+                               "LikelihoodEnergy separately.")
         self._name = x
 
 
@@ -111,6 +120,102 @@ class _LikelihoodChain(LikelihoodEnergyOperator):
 
     def __repr__(self):
         return repr(self._op)
+
+
+class _LikelihoodSum(LikelihoodEnergyOperator):
+    """Sum of likelihoods (several data sets / instruments; reference energy_operators.py:211-303).  The data spaces
+    of the summands form a disjoint union: residuals, data metrics and transformations carry the summand's name
+    ("Likelihood i" by default) as key (DomainTuple data) or key prefix (MultiDomain data)."""
+
+    def __init__(self, ops, _callingfrommake=False):
+        from .operators import PrependKey
+
+        if not _callingfrommake:
+            raise NotImplementedError
+        if len({isinstance(oo.domain, DomainTuple) for oo in ops}) > 1:
+            raise RuntimeError("Some operators have DomainTuple and others have MultiDomain as domain. "
+                               "This should not happen.")
+        self._ops = list(ops)
+        self._name = None
+        names = self._all_names()
+        if len(names) != len(set(names)):
+            raise ValueError(f"Name collision in likelihoods detected: {names}")
+        res, prep, data_ops = [], [], []
+        for ii, oo in enumerate(self._ops):
+            if oo._res is None:
+                continue
+            lprep = Operator.identity_operator(oo.data_domain)
+            key = self._get_name(ii)
+            if isinstance(lprep.target, DomainTuple):
+                lprep = lprep.ducktape_left("")
+            else:
+                key = key + ": "
+            lprep = PrependKey(lprep.target, key) @ lprep
+            prep.append(lprep)
+            res.append(lprep @ oo._res)
+            data_ops.append(oo)
+
+        def sqrt_data_metric_at(x):
+            tot = None
+            for pp, oo in zip(prep, data_ops):
+                term = pp @ oo._sqrt_data_metric_at(x) @ pp.adjoint
+                tot = term if tot is None else tot + term
+            return tot
+
+        data_residuals = None
+        for rr in res:
+            data_residuals = rr if data_residuals is None else data_residuals + rr
+        self._res, self._sqrt_data_metric_at = data_residuals, sqrt_data_metric_at
+        self._domain = data_residuals.domain if data_residuals is not None else self._ops[0].domain
+
+    @classmethod
+    def _unpack(cls, ops, res):
+        for op in ops:
+            res = cls._unpack(op._ops, res) if isinstance(op, cls) else res + [op]
+        return res
+
+    @classmethod
+    def make(cls, ops):
+        for op in ops:
+            if not isinstance(op, LikelihoodEnergyOperator):
+                raise TypeError(f"a likelihood can only be added to another likelihood, got {type(op).__name__}")
+        res = cls._unpack(ops, [])
+        return res[0] if len(res) == 1 else cls(res, _callingfrommake=True)
+
+    def apply(self, x):
+        from .operators import _OpSum
+
+        self._check_input(x)
+        return _OpSum._apply_operator_sum(x, self._ops)
+
+    def get_transformation(self):
+        from .operators import PrependKey
+
+        trs = [oo.get_transformation() for oo in self._ops]
+        if any(tr is None for tr in trs):
+            return None
+        dtype, total = {}, None
+        for ii, (dtp, tr) in enumerate(trs):
+            key = self._get_name(ii)
+            if isinstance(tr.target, MultiDomain):
+                key = key + ": "
+                dtype.update({key + d: dtp[d] for d in dtp.keys()})
+                tr = PrependKey(tr.target, key) @ tr
+            else:
+                dtype[key] = dtp
+                tr = tr.ducktape_left(key)
+            total = tr if total is None else total + tr
+        return dtype, total
+
+    def _all_names(self):
+        return [self._get_name(ii) for ii in range(len(self._ops))]
+
+    def _get_name(self, i):
+        res = self._ops[i].name
+        return f"Likelihood {i}" if res is None else res
+
+    def __repr__(self):
+        return "_LikelihoodSum:\n" + "\n".join(f"  *{self._get_name(ii)}*\n  {oo!r}" for ii, oo in enumerate(self._ops))
 
 
 class Squared2NormOperator(EnergyOperator):

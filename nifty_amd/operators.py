@@ -645,6 +645,23 @@ class OperatorAdapter(LinearOperator):
         return "OperatorAdapter({}) of\n  ".format(["", "adjoint", "inverse", "adjoint inverse"][self._trafo]) + repr(self._op)
 
 
+class PrependKey(LinearOperator):
+    """Prepends a string to every key of a MultiDomain (reference simple_linear_operators.py:447-471)."""
+
+    def __init__(self, domain, pre):
+        if not isinstance(domain, MultiDomain):
+            raise ValueError("PrependKey needs a MultiDomain")
+        self._domain, self._pre = domain, str(pre)
+        self._target = MultiDomain.make({self._pre + k: domain[k] for k in domain.keys()})
+        self._capability = self.TIMES | self.ADJOINT_TIMES
+
+    def apply(self, x, mode):
+        self._check_input(x, mode)
+        if mode == self.TIMES:
+            return MultiField.from_dict({self._pre + k: x[k] for k in self._domain.keys()}, self._target)
+        return MultiField.from_dict({k: x[self._pre + k] for k in self._domain.keys()}, self._domain)
+
+
 class _KeyEmbedding(LinearOperator):
     """MultiField on a sub-set of keys -> full MultiDomain with zeros on the other keys; adjoint extracts."""
 

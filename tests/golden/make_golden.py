@@ -275,6 +275,44 @@ def minimizer_cases():
     print("wrote minimizers", {k: float(out[k]) for k in out if k.endswith("value")})
 
 
+def lhsum_cases():
+    """Sum of two likelihoods on one correlated field (energy_operators.py:211-303): Gaussian data of the field and
+    Poisson counts of its exponential (one named, one not).  Hamiltonian value / gradient / metric, normalised residual,
+    MGVI and geoVI samples and a KL value."""
+    z = np.load(os.path.join(HERE, "model_g1d.npz"))
+    sp = ift.RGSpace(tuple(int(i) for i in z["meta.shape"]))
+    cfm, cf = make_cf(sp)
+    rng = np.random.default_rng(11)
+    counts = rng.poisson(2.0, size=sp.shape).astype(np.int64)
+    d = ift.makeField(cf.target, z["data"])
+    lh1 = ift.GaussianEnergy(d, ift.ScalingOperator(cf.target, float(z["icov"]), np.float64)) @ cf
+    lh2 = ift.PoissonianEnergy(ift.makeField(cf.target, counts)) @ cf.exp()
+    lh2.name = "counts"
+    lh = lh1 + lh2
+    x = ift.MultiField.from_raw(cf.domain, {k[2:]: z[k] for k in z.files if k.startswith("x.")})
+    out = dict(counts=counts)
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=6)
+    ham = ift.StandardHamiltonian(lh, ic, prior_sampling_dtype=np.float64)
+    lin = ham(ift.Linearization.make_var(x, want_metric=True))
+    out["ham.value"] = np.asarray(lin.val.asnumpy())
+    out.update(mf2dict(lin.gradient, "ham.grad"))
+    ift.random.push_sseq_from_seed(8)
+    v = ift.from_random(x.domain)
+    ift.random.pop_sseq()
+    out.update(mf2dict(v, "v"))
+    out.update(mf2dict(lin.metric(v), "ham.metric_v"))
+    out.update(mf2dict(lh.normalized_residual(x), "nres"))
+    for name, geo in (("mgvi", None), ("geovi", ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=2), max_cg_iterations=4))):
+        ift.random.push_sseq_from_seed(21)
+        kl = ift.SampledKLEnergy(x, ham, 1, geo, mirror_samples=True)
+        ift.random.pop_sseq()
+        out[f"{name}.kl_value"] = np.array(kl.value)
+        for i, smp in enumerate(kl.samples.iterator()):
+            out.update(mf2dict(smp, f"{name}.sample{i}"))
+    np.savez_compressed(os.path.join(HERE, "lhsum.npz"), **out)
+    print("wrote lhsum", float(out["ham.value"]), float(out["mgvi.kl_value"]), float(out["geovi.kl_value"]))
+
+
 def napprox_cases():
     """The sampled diagonal preconditioner (`napprox`, kl_energies.py:127-128, descent_minimizers.py:201-203,
     probing.py:142-152) on the g1d model: MGVI samples with napprox=3 and a NewtonCG(napprox=3) minimisation of the Hamiltonian."""
@@ -555,6 +593,8 @@ def main():
         return minimizer_cases()
     if "--napprox-only" in sys.argv:
         return napprox_cases()
+    if "--lhsum-only" in sys.argv:
+        return lhsum_cases()
     geo = {}
     for shape, dist in [((8,), None), ((7, 8), None), ((4, 5, 7), None), ((512,), None), ((64, 64), None),
                         ((16, 16, 16), None), ((16, 32), (0.3, 0.2)), ((12,), (0.7,))]:

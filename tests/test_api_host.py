@@ -522,3 +522,38 @@ def test_categorical_and_averaged_energies(device_id):
     assert abs(float(lin.val.asnumpy()) - float(z["averaged.value"])) < 1e-12 * abs(float(z["averaged.value"]))
     assert gl.relerr(lin.gradient.asnumpy(), z["averaged.grad"]) < 1e-12
     assert gl.relerr(lin.metric(ift.makeField(sp, z["v"], device_id)).asnumpy(), z["averaged.metric_v"]) < 1e-12
+
+
+@pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
+def test_likelihood_sum_matches_reference(device_id):
+    """lh1 + lh2 (energy_operators.py:211-303: several data sets on one model; disjoint union of the data spaces keyed by
+    the likelihood names): Hamiltonian value / gradient / metric, normalised residual, MGVI and geoVI samples against
+    tests/golden/lhsum.npz."""
+    z, zs = gl.load("model_g1d"), gl.load("lhsum")
+    m, cfm, cf, lh1 = build(z, device_id)
+    lh2 = ift.PoissonianEnergy(ift.makeField(cf.target, zs["counts"], device_id)) @ cf.exp()
+    lh2.name = "counts"
+    lh = lh1 + lh2
+    assert type(lh).__name__ == "_LikelihoodSum" and lh._all_names() == ["Likelihood 0", "counts"]
+    with pytest.raises(RuntimeError):
+        lh.name = "x"
+    x = ift.MultiField.from_raw(cf.domain, gl.latent(z, "x"), device_id)
+    v = ift.MultiField.from_raw(cf.domain, _lat(zs, "v"), device_id)
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=6)
+    ham = ift.StandardHamiltonian(lh, ic, prior_sampling_dtype=np.float64)
+    lin = ham(ift.Linearization.make_var(x, want_metric=True))
+    assert abs(float(lin.val.asnumpy()) - float(zs["ham.value"])) < 1e-11 * abs(float(zs["ham.value"]))
+    assert gl.lat_relerr(lin.gradient.asnumpy(), _lat(zs, "ham.grad")) < 1e-10
+    assert gl.lat_relerr(lin.metric(v).asnumpy(), _lat(zs, "ham.metric_v")) < 1e-10
+    nres = lh.normalized_residual(x)
+    assert set(nres.keys()) == {"Likelihood 0", "counts"}
+    assert gl.lat_relerr(nres.asnumpy(), _lat(zs, "nres")) < 1e-10
+    for name, geo in (("mgvi", None), ("geovi", ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=2), max_cg_iterations=4))):
+        ift.random.push_sseq_from_seed(21)
+        try:
+            kl = ift.SampledKLEnergy(x, ham, 1, geo, mirror_samples=True, device_id=device_id)
+        finally:
+            ift.random.pop_sseq()
+        assert abs(kl.value - float(zs[f"{name}.kl_value"])) < 1e-7 * abs(float(zs[f"{name}.kl_value"]))
+        for i, smp in enumerate(kl.samples.iterator()):
+            assert gl.lat_relerr(smp.asnumpy(), _lat(zs, f"{name}.sample{i}")) < 1e-6
