@@ -29,16 +29,55 @@ from .operators import (ContractionOperator, DiagonalOperator, EndomorphicOperat
 # ------------------------------------------------------------------------------------------------
 # hyper-parameter transforms (normal_operators.py:28-72)
 # ------------------------------------------------------------------------------------------------
+def _per_copy(param, n):
+    """A scalar hyper-parameter, or one value per copy (normal_operators.py / utilities.value_reshaper)."""
+    arr = np.asarray(param, dtype=np.float64)
+    if arr.shape in ((), (1,)):
+        return np.full(n, float(arr.reshape(-1)[0]))
+    if arr.shape != (n,):
+        raise TypeError(f"hyper-parameter of shape {arr.shape} does not match the {n} copies")
+    return arr
+
+
 def NormalTransform(mean, sigma, key, N_copies=0):
-    if N_copies != 0:
-        raise NotImplementedError("N_copies > 0 (total_N > 0) is out of scope")
-    domain = DomainTuple.scalar_domain()
-    return float(sigma) * ducktape(domain, None, key) + float(mean)
+    """mean + sigma * xi_key; N_copies >= 1: one value per copy on an UnstructuredDomain(N_copies)."""
+    if N_copies == 0:
+        domain = DomainTuple.scalar_domain()
+        return float(sigma) * ducktape(domain, None, key) + float(mean)
+    domain = DomainTuple.make(UnstructuredDomain(N_copies))
+    mean_f, sigma_f = (makeField(domain, _per_copy(p, N_copies)) for p in (mean, sigma))
+    return (makeOp(sigma_f) @ ducktape(domain, None, key)) + mean_f
 
 
 def LognormalTransform(mean, sigma, key, N_copies=0):
-    logmean, logsigma = lognormal_moments(mean, sigma)
+    if N_copies == 0:
+        logmean, logsigma = lognormal_moments(mean, sigma)
+    else:
+        pairs = [lognormal_moments(m, sg) for m, sg in zip(_per_copy(mean, N_copies), _per_copy(sigma, N_copies))]
+        logmean, logsigma = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
     return NormalTransform(logmean, logsigma, key, N_copies).ptw("exp")
+
+
+class _Distributor(LinearOperator):
+    """Copies of a few amplitude / zero-mode models onto the total_N fields: out[i] = in[dofdex[i]] along the leading
+    axis (reference correlated_fields.py:211-231)."""
+
+    def __init__(self, dofdex, domain, target):
+        self._dofdex = torch.as_tensor(np.asarray(dofdex), dtype=torch.int64)
+        self._domain, self._target = DomainTuple.make(domain), DomainTuple.make(target)
+        self._capability = self.TIMES | self.ADJOINT_TIMES
+
+    def apply(self, x, mode):
+        self._check_input(x, mode)
+        v = x.val
+        idx = self._dofdex.tolist()
+        if mode == self.TIMES:
+            return Field(self._target, torch.stack([v[i] for i in idx]).contiguous())
+        rows = [None] * self._domain.shape[0]
+        for j, i in enumerate(idx):
+            rows[i] = v[j] if rows[i] is None else rows[i] + v[j] if not v.is_cuda else B.axpby(1.0, rows[i], 1.0, v[j].contiguous())
+        zero = torch.zeros_like(v[0])
+        return Field(self._domain, torch.stack([zero if r is None else r for r in rows]).contiguous())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -64,65 +103,90 @@ def _dev(t, like):
     return t.to(device=like.device, dtype=like.dtype)
 
 
+def _batched(domain, space, cls_name):
+    """(leading copies, PowerSpace) domains: `space` must be the last space; returns the number of leading rows (0: none)."""
+    domain = makeDomain(domain)
+    if space != len(domain) - 1 or len(domain) > 2 or not isinstance(domain[space], PowerSpace):
+        raise NotImplementedError(f"{cls_name}: a PowerSpace as the last of at most two spaces is supported")
+    return domain, (domain.shape[0] if len(domain) == 2 else 0)
+
+
+def _rowwise(v, nrows, fn):
+    """fn on every leading row of v (nrows == 0: on v itself); slices and stacking are copies."""
+    if nrows == 0:
+        return fn(v)
+    return torch.stack([fn(v[i].contiguous()) for i in range(nrows)]).contiguous()
+
+
 class _SlopeRemover(EndomorphicOperator):
     def __init__(self, domain, space=0):
-        self._domain = makeDomain(domain)
-        if len(self._domain) != 1 or not isinstance(self._domain[0], PowerSpace):
-            raise NotImplementedError("only a single PowerSpace is supported")
-        logkl = _relative_log_k_lengths(self._domain[0])
+        self._domain, self._nrows = _batched(domain, space, "_SlopeRemover")
+        logkl = _relative_log_k_lengths(self._domain[space])
         self._sc = torch.from_numpy(logkl / float(logkl[-1]))
         self._capability = self.TIMES | self.ADJOINT_TIMES
 
     def apply(self, x, mode):
         self._check_input(x, mode)
+        return Field(self._tgt(mode), _rowwise(x.val, self._nrows, lambda v: self._apply1(v, mode)))
+
+    def _apply1(self, v, mode):
+        return self._apply_row(Field(DomainTuple.make(self._domain[-1]), v), mode).val
+
+    def _apply_row(self, x, mode):
         v = x.val
         if v.is_cuda:  # device Fields: libniftyk element-wise kernels, the two scalars cross the host
             sc = _dev(self._sc, v)
             v = v.contiguous()
             if mode == self.TIMES:
-                return Field(self._tgt(mode), B.axpby(1.0, v, -float(v[-1].item()), sc))
+                return Field(x.domain, B.axpby(1.0, v, -float(v[-1].item()), sc))
             res = v.clone()
             last = res[-1:]
             B.axpby(1.0, last, -float(B.vdot(v, sc).item()), torch.ones_like(last), out=last)
-            return Field(self._tgt(mode), res)
+            return Field(x.domain, res)
         if mode == self.TIMES:
-            return Field(self._tgt(mode), v - v[-1] * self._sc)
+            return Field(x.domain, v - v[-1] * self._sc)
         res = v.clone()
         res[-1] = res[-1] - (v * self._sc).sum()
-        return Field(self._tgt(mode), res)
+        return Field(x.domain, res)
 
 
 class _TwoLogIntegrations(LinearOperator):
     def __init__(self, target, space=0):
-        self._target = makeDomain(target)
-        if len(self._target) != 1 or not isinstance(self._target[0], PowerSpace):
-            raise NotImplementedError("only a single PowerSpace is supported")
-        nb = self._target[0].shape[0]
-        self._domain = makeDomain(UnstructuredDomain((2, nb - 2)))
-        self._log_vol = torch.from_numpy(_log_vol(self._target[0]))
+        self._target, self._nrows = _batched(target, space, "_TwoLogIntegrations")
+        nb = self._target[space].shape[0]
+        dom = list(self._target)
+        dom[space] = UnstructuredDomain((2, nb - 2))
+        self._domain = makeDomain(dom)
+        self._row_target = DomainTuple.make(self._target[space])
+        self._row_domain = DomainTuple.make(dom[space])
+        self._log_vol = torch.from_numpy(_log_vol(self._target[space]))
         self._capability = self.TIMES | self.ADJOINT_TIMES
 
     def apply(self, x, mode):
         self._check_input(x, mode)
+        rdom = self._row_domain if mode == self.TIMES else self._row_target
+        return Field(self._tgt(mode), _rowwise(x.val, self._nrows, lambda v: self._apply_row(Field(rdom, v), mode).val))
+
+    def _apply_row(self, x, mode):
         lv = self._log_vol
         if x.val.is_cuda:
             return self._apply_device(x, mode)
         if mode == self.TIMES:
             v = x.val
-            res = torch.zeros(self._target.shape, dtype=v.dtype)
+            res = torch.zeros(self._row_target.shape, dtype=v.dtype)
             c = torch.cumsum(v[1], 0)
             cprev = torch.cat([torch.zeros(1, dtype=v.dtype), c[:-1]])
             res[2:] = torch.cumsum((c + cprev) / 2 * lv + v[0], 0)
-            return Field(self._target, res)
+            return Field(self._row_target, res)
         y = x.val
-        res = torch.zeros(self._domain.shape, dtype=y.dtype)
+        res = torch.zeros(self._row_domain.shape, dtype=y.dtype)
         t = torch.flip(torch.cumsum(torch.flip(y[2:], [0]), 0), [0])
         res[0] = t
         u = t * (lv / 2.0)
         gc = u.clone()
         gc[:-1] += u[1:]
         res[1] = torch.flip(torch.cumsum(torch.flip(gc, [0]), 0), [0])
-        return Field(self._domain, res)
+        return Field(self._row_domain, res)
 
 
     def _apply_device(self, x, mode):
@@ -131,66 +195,80 @@ class _TwoLogIntegrations(LinearOperator):
         half_lv = B.axpby(0.5, _dev(self._log_vol, v).contiguous())
         zero1 = torch.zeros(1, dtype=v.dtype, device=v.device)
         if mode == self.TIMES:
-            res = torch.zeros(self._target.shape, dtype=v.dtype, device=v.device)
+            res = torch.zeros(self._row_target.shape, dtype=v.dtype, device=v.device)
             c = B.cumsum(v[1])
             both = B.binary(L.OP_ADD, c, torch.cat([zero1, c[:-1]]).contiguous())  # c_j + c_{j-1}
             inc = B.binary(L.OP_ADD, B.binary(L.OP_MUL, both, half_lv), v[0].contiguous())
             B.cumsum(inc, out=res[2:])
-            return Field(self._target, res)
-        res = torch.zeros(self._domain.shape, dtype=v.dtype, device=v.device)
+            return Field(self._row_target, res)
+        res = torch.zeros(self._row_domain.shape, dtype=v.dtype, device=v.device)
         t = B.cumsum(v[2:], reverse=True, out=res[0])
         u = B.binary(L.OP_MUL, t, half_lv)
         gc = B.binary(L.OP_ADD, u, torch.cat([u[1:], zero1]).contiguous())
         B.cumsum(gc, reverse=True, out=res[1])
-        return Field(self._domain, res)
+        return Field(self._row_domain, res)
 
 
 class _Normalization(Operator):
     def __init__(self, domain, space=0):
         self._domain = self._target = DomainTuple.make(domain)
-        pspace = self._domain[0]
+        _batched(self._domain, space, "_Normalization")
+        self._space = space
+        pspace = self._domain[space]
         mult = pspace.rho.astype(np.float64).copy()
         mult[0] = 0.0
-        self._mult = torch.from_numpy(mult)
+        self._mult = makeField(DomainTuple.make(pspace), mult)
 
     def apply(self, x):
         self._check_input(x)
         spec = x.exp()
-        # sum over modes with multiplicities, broadcast back
-        multop = makeOp(Field(self._domain, self._mult))
-        co = ContractionOperator(self._domain, None)
+        # sum over modes with multiplicities (per copy), broadcast back
+        multop = DiagonalOperator(self._mult, self._domain, self._space)
+        co = ContractionOperator(self._domain, self._space)
         specsum = co.adjoint(co(multop(spec)))
         return (specsum.reciprocal() * spec).sqrt()
 
 
 class _Amplitude(Operator):
-    """a(k) = vol0 + vol1 fluct * normalised( slope rel_logk + SlopeRemover(TwoLogIntegrations(sigma xi_s)) )."""
+    """a(k) = vol0 + vol1 fluct * normalised( slope rel_logk + SlopeRemover(TwoLogIntegrations(sigma xi_s)) ).
+    dofdex (total_N > 0): max(dofdex)+1 independent spectra on a leading UnstructuredDomain, distributed to the
+    len(dofdex) fields (reference correlated_fields.py:277-386)."""
 
-    def __init__(self, target, fluctuations, flexibility, asperity, loglogavgslope, totvol, key):
-        target = makeDomain(target)
-        pspace = target[0]
+    def __init__(self, target, fluctuations, flexibility, asperity, loglogavgslope, totvol, key, dofdex=()):
+        dofdex = [int(i) for i in dofdex]
+        distributor = None
+        if len(dofdex) > 0:
+            n_copies, space = max(dofdex) + 1, 1
+            target = makeDomain((UnstructuredDomain(n_copies), target))
+            if n_copies != len(dofdex):
+                distributed_tgt = makeDomain((UnstructuredDomain(len(dofdex)), target[1]))
+                distributor = _Distributor(dofdex, target, distributed_tgt)
+        else:
+            space = 0
+            target = makeDomain(target)
+        pspace = target[space]
         if not isinstance(pspace, PowerSpace):
             raise TypeError("PowerSpace required")
-        twolog = _TwoLogIntegrations(target)
+        twolog = _TwoLogIntegrations(target, space)
         dom = twolog.domain
-        shp = dom.shape
-        expander = ContractionOperator(dom, None).adjoint
-        ps_expander = ContractionOperator(target, None).adjoint
+        shp = dom[space].shape
+        expander = ContractionOperator(dom, space).adjoint
+        ps_expander = ContractionOperator(target, space).adjoint
         lv = _log_vol(pspace)
         vflex = np.zeros(shp)
         vflex[0] = vflex[1] = np.sqrt(lv)
-        vflex = DiagonalOperator(makeField(dom, vflex))
+        vflex = DiagonalOperator(makeField(dom[space], vflex), dom, space)
         vasp = np.zeros(shp)
         vasp[0] += 1
-        vasp = DiagonalOperator(makeField(dom, vasp))
+        vasp = DiagonalOperator(makeField(dom[space], vasp), dom, space)
         shift = np.ones(shp)
         shift[0] = lv ** 2 / 12.0
-        shift = makeField(dom, shift)
-        vslope = DiagonalOperator(makeField(target, _relative_log_k_lengths(pspace)))
+        shift = DiagonalOperator(makeField(dom[space], shift), dom, space)(full(dom, 1.0))
+        vslope = DiagonalOperator(makeField(pspace, _relative_log_k_lengths(pspace)), target, space)
         vol0, vol1 = np.zeros(pspace.shape), np.zeros(pspace.shape)
         vol1[1:] = vol0[0] = totvol
-        vol0 = makeField(target, vol0)
-        vol1 = DiagonalOperator(makeField(target, vol1))
+        vol0 = DiagonalOperator(makeField(pspace, vol0), target, space)(full(target, 1.0))
+        vol1 = DiagonalOperator(makeField(pspace, vol1), target, space)
         slope = vslope @ ps_expander @ loglogavgslope
         sig_flex = vflex @ expander @ flexibility if flexibility is not None else None
         sig_asp = vasp @ expander @ asperity if asperity is not None else None
@@ -199,21 +277,26 @@ class _Amplitude(Operator):
         # flexibility / asperity may be switched off (reference correlated_fields.py:351-363): pure power law, or an
         # integrated Wiener process without the asperity term
         if sig_asp is None and sig_flex is None:
-            op = _Normalization(target) @ slope
+            op = _Normalization(target, space) @ slope
         elif sig_asp is None:
             sigma = DiagonalOperator(shift.sqrt()) @ sig_flex
-            smooth = _SlopeRemover(target) @ twolog @ (sigma * xi)
-            op = _Normalization(target) @ (slope + smooth)
+            smooth = _SlopeRemover(target, space) @ twolog @ (sigma * xi)
+            op = _Normalization(target, space) @ (slope + smooth)
         elif sig_flex is None:
             raise ValueError("flexibility may not be disabled on its own")
         else:
             sigma = sig_flex * (sig_asp + shift).sqrt()
-            smooth = _SlopeRemover(target) @ twolog @ (sigma * xi)
-            op = _Normalization(target) @ (slope + smooth)
-        op = (sig_fluc * op) + vol0
+            smooth = _SlopeRemover(target, space) @ twolog @ (sigma * xi)
+            op = _Normalization(target, space) @ (slope + smooth)
+        if distributor is not None:
+            op = ((distributor @ sig_fluc) * (distributor @ op)) + distributor(vol0)
+            self._fluc = _Distributor(dofdex, fluctuations.target, distributed_tgt[0]) @ fluctuations
+        else:
+            op = (sig_fluc * op) + vol0
+            self._fluc = fluctuations
         self._op = op
         self._domain, self._target = op.domain, op.target
-        self._fluc = fluctuations
+        self._space = space
 
     def apply(self, x):
         self._check_input(x)
@@ -392,8 +475,9 @@ class CorrelatedFieldMaker:
     integrated Wiener process, reduced variants, Matern); the single full amplitude is fused into one device operator."""
 
     def __init__(self, prefix, total_N=0):
-        if total_N != 0:
-            raise NotImplementedError("total_N > 0 is out of scope (SURVEY 2 #15)")
+        if int(total_N) < 0:
+            raise ValueError("total_N must be >= 0")
+        self._total_N = int(total_N)  # > 0: total_N fields at once on a leading UnstructuredDomain(total_N)
         self._prefix = prefix
         self._a = []
         self._target_subdomains = []
@@ -403,8 +487,8 @@ class CorrelatedFieldMaker:
 
     def add_fluctuations(self, target_subdomain, fluctuations, flexibility, asperity, loglogavgslope, prefix="",
                          index=None, dofdex=None, harmonic_partner=None):
-        if dofdex is not None or index is not None:
-            raise NotImplementedError("dofdex / index are out of scope")
+        dofdex = self._check_dofdex(dofdex)
+        N = max(dofdex) + 1 if self._total_N > 0 else 0
         if harmonic_partner is None:
             harmonic_partner = target_subdomain.get_default_codomain()
         else:
@@ -423,15 +507,20 @@ class CorrelatedFieldMaker:
         if flexibility is None and asperity is not None:
             raise ValueError("flexibility may not be disabled on its own")
         pre = self._prefix + str(prefix)
-        fluct = LognormalTransform(*fluctuations, pre + "fluctuations")
-        flex = LognormalTransform(*flexibility, pre + "flexibility") if flexibility is not None else None
-        asp = LognormalTransform(*asperity, pre + "asperity") if asperity is not None else None
-        avgsl = NormalTransform(*loglogavgslope, pre + "loglogavgslope")
-        tsd = makeDomain(target_subdomain)
-        amp = _Amplitude(PowerSpace(harmonic_partner), fluct, flex, asp, avgsl, tsd[-1].total_volume, pre + "spectrum")
-        self._a.append(amp)
-        self._target_subdomains.append(tsd)
-        if flexibility is None or asperity is None:
+        fluct = LognormalTransform(*fluctuations, pre + "fluctuations", N)
+        flex = LognormalTransform(*flexibility, pre + "flexibility", N) if flexibility is not None else None
+        asp = LognormalTransform(*asperity, pre + "asperity", N) if asperity is not None else None
+        avgsl = NormalTransform(*loglogavgslope, pre + "loglogavgslope", N)
+        tsd = makeDomain((UnstructuredDomain(N), target_subdomain)) if self._total_N > 0 else makeDomain(target_subdomain)
+        amp = _Amplitude(PowerSpace(harmonic_partner), fluct, flex, asp, avgsl, tsd[-1].total_volume, pre + "spectrum",
+                         dofdex if self._total_N > 0 else ())
+        if index is not None:
+            self._a.insert(index, amp)
+            self._target_subdomains.insert(index, tsd)
+        else:
+            self._a.append(amp)
+            self._target_subdomains.append(tsd)
+        if flexibility is None or asperity is None or self._total_N > 0:
             self._amp_prefix = None  # reduced amplitude models run on the generic operator graph, never the fused node
             return
         self._hyper.update(fluctuations=tuple(fluctuations), flexibility=tuple(flexibility), asperity=tuple(asperity),
@@ -442,6 +531,8 @@ class CorrelatedFieldMaker:
                                 harmonic_partner=None):
         """Matern-kernel amplitude A(k) = a (1 + (|k|/b)^2)^(c/4) with log-normal scale a and cutoff b and normal
         spectral index c (reference library/correlated_fields.py:577-657); runs on the generic operator graph."""
+        if self._total_N > 0:
+            raise NotImplementedError("the Matern amplitude only works for total_N == 0 (as in the reference)")
         if harmonic_partner is None:
             harmonic_partner = target_subdomain.get_default_codomain()
         else:
@@ -456,15 +547,26 @@ class CorrelatedFieldMaker:
         self._target_subdomains.append(tsd)
         self._amp_prefix = None  # never the fused single-amplitude operator
 
+    def _check_dofdex(self, dofdex):
+        if dofdex is None:
+            return [0] * self._total_N
+        dofdex = [int(i) for i in dofdex]
+        if len(dofdex) != self._total_N:
+            raise ValueError("length of dofdex needs to match total_N")
+        return dofdex
+
     def set_amplitude_total_offset(self, offset_mean, offset_std, dofdex=None):
-        if dofdex is not None:
-            raise NotImplementedError
         self._offset_mean = offset_mean
         if offset_std is None or np.isscalar(offset_std) or isinstance(offset_std, Operator):
             raise NotImplementedError("only a (mean, std) tuple is supported for offset_std")
         if len(offset_std) != 2:
             raise TypeError("`offset_std` of invalid type and/or shape; expected a 2D tuple of floats")
-        self._azm = LognormalTransform(*offset_std, self._prefix + "zeromode")
+        dofdex = self._check_dofdex(dofdex)
+        N = max(dofdex) + 1 if self._total_N > 0 else 0
+        zm = LognormalTransform(*offset_std, self._prefix + "zeromode", N)
+        if self._total_N > 0:
+            zm = _Distributor(dofdex, zm.target, UnstructuredDomain(self._total_N)) @ zm
+        self._azm = zm
         self._hyper["offset_std"] = tuple(offset_std)
 
     @property
@@ -482,14 +584,15 @@ class CorrelatedFieldMaker:
     def get_normalized_amplitudes(self):
         """Amplitudes corrected for the otherwise degenerate zero mode: a_i * (1/azm on k != 0, 1 on k = 0)
         (reference correlated_fields.py:809-858)."""
+        space = 1 if self._total_N > 0 else 0
         out = []
         for amp in self._a:
-            pspace = amp.target[0]
+            pspace = amp.target[space]
             mask, unmask = np.zeros(pspace.shape), np.zeros(pspace.shape)
             mask[1:] = unmask[0] = 1.0
-            zm_mask = DiagonalOperator(makeField(amp.target, mask))
-            zm_unmask = makeField(amp.target, unmask)
-            na = ContractionOperator(amp.target, None).adjoint @ self.azm.reciprocal()
+            zm_mask = DiagonalOperator(makeField(pspace, mask), amp.target, space)
+            zm_unmask = DiagonalOperator(makeField(pspace, unmask), amp.target, space)(full(amp.target, 1.0))
+            na = ContractionOperator(amp.target, space).adjoint @ self.azm.reciprocal()
             out.append(amp * (zm_mask(na) + zm_unmask))
         return tuple(out)
 
@@ -498,30 +601,36 @@ class CorrelatedFieldMaker:
         if len(self._a) > 1:  # reference correlated_fields.py:860-866
             raise NotImplementedError("If more than one spectrum is present in the model, no unique set of amplitudes exist "
                                       "because only the relative scale is determined.")
+        space = 1 if self._total_N > 0 else 0
         na = self.get_normalized_amplitudes()[0]
-        return na * (ContractionOperator(na.target, None).adjoint @ self.azm)
+        return na * (ContractionOperator(na.target, space).adjoint @ self.azm)
 
     @property
     def power_spectrum(self):
         return self.amplitude ** 2
 
     def _generic_graph(self):
-        """offset + HT( azm * prod_i a_i[pindex_i] * xi ) on the product of the harmonic spaces
-        (reference correlated_fields.py:713-764)."""
+        """offset + HT( azm * prod_i a_i[pindex_i] * xi ) on the product of the harmonic spaces, with a leading
+        UnstructuredDomain(total_N) when several fields are modelled at once (reference correlated_fields.py:713-764)."""
         n = len(self._a)
-        hspace = makeDomain([a.target[0].harmonic_partner for a in self._a])
-        ht = HarmonicTransformOperator(hspace, self._target_subdomains[0][0], space=0)
+        if self._total_N > 0:
+            hspace = makeDomain([UnstructuredDomain(self._total_N)] + [a.target[-1].harmonic_partner for a in self._a])
+            spaces, amp_space = tuple(range(1, n + 1)), 1
+        else:
+            hspace = makeDomain([a.target[0].harmonic_partner for a in self._a])
+            spaces, amp_space = tuple(range(n)), 0
+        ht = HarmonicTransformOperator(hspace, self._target_subdomains[0][amp_space], space=spaces[0])
         for i in range(1, n):
-            ht = HarmonicTransformOperator(ht.target, self._target_subdomains[i][0], space=i) @ ht
+            ht = HarmonicTransformOperator(ht.target, self._target_subdomains[i][amp_space], space=spaces[i]) @ ht
         amps = list(self.get_normalized_amplitudes())
         for i in range(n):
-            co = ContractionOperator(hspace, tuple(j for j in range(n) if j != i))
-            amps[i] = co.adjoint @ PowerDistributor(co.target, amps[i].target[0]) @ amps[i]
+            co = ContractionOperator(hspace, spaces[:i] + spaces[i + 1:])
+            amps[i] = co.adjoint @ PowerDistributor(co.target, amps[i].target[amp_space], amp_space) @ amps[i]
         corr = amps[0]
         for a in amps[1:]:
             corr = corr * a
         xi = Variable(hspace, self._prefix + "xi")
-        expander = ContractionOperator(hspace, None).adjoint
+        expander = ContractionOperator(hspace, spaces).adjoint
         azm = expander @ self.azm
         op = ht((azm * corr).real * xi)
         if self._offset_mean is not None:
@@ -533,8 +642,8 @@ class CorrelatedFieldMaker:
             raise NotImplementedError("add_fluctuations() and set_amplitude_total_offset() must have been called")
         generic = self._generic_graph()
         pos = self._target_subdomains[0][0]
-        if len(self._a) > 1 or not isinstance(pos, RGSpace) or self._amp_prefix != self._prefix:
-            return generic  # product spectra run on the generic operator graph
+        if len(self._a) > 1 or self._total_N > 0 or not isinstance(pos, RGSpace) or self._amp_prefix != self._prefix:
+            return generic  # product spectra and total_N > 0 run on the generic operator graph
         return CorrelatedFieldOperator(pos, generic, self._prefix, 0.0 if self._offset_mean is None else self._offset_mean,
                                        dict(self._hyper))
 

@@ -840,10 +840,18 @@ class DiagonalOperator(EndomorphicOperator):
             d = torch.conj_physical(d)
         if not xval.is_cuda:
             return xval / d if divide else xval * d
-        if not self._full() or self._complex or xval.is_complex():
-            raise NotImplementedError("broadcast / complex DiagonalOperator on device")
+        if self._complex or xval.is_complex():
+            raise NotImplementedError("complex DiagonalOperator on device")
         if d.dtype != xval.dtype:
             d = d.to(xval.dtype)
+        if not self._full():
+            # a diagonal on a sub-set of the spaces: its broadcast over the other axes is materialised once (a copy),
+            # the product itself is the element-wise kernel
+            key = (str(xval.device), xval.dtype)
+            cache = self.__dict__.setdefault("_expanded", {})
+            if key not in cache:
+                cache[key] = d.expand(self._domain.shape).contiguous()
+            d = cache[key]
         from . import _lib as L
 
         return B.binary(L.OP_DIV if divide else L.OP_MUL, xval.contiguous(), d.contiguous())
@@ -1500,8 +1508,9 @@ class DOFDistributor(LinearOperator):
         if space is None and len(self._target) == 1:
             space = 0
         self._space = int(space)
-        if len(self._target) != 1:
-            raise NotImplementedError("DOFDistributor on a sub-space is not implemented yet")
+        if self._space != len(self._target) - 1:
+            raise NotImplementedError("DOFDistributor: only the LAST space of the target can be distributed "
+                                      "(leading spaces are carried along)")
         idx = dofdex.val if isinstance(dofdex, Field) else torch.as_tensor(dofdex)
         if idx.dtype not in (torch.int32, torch.int64):
             raise TypeError("dofdex must contain integers")
@@ -1517,7 +1526,10 @@ class DOFDistributor(LinearOperator):
         self._idx_host = None
         self._idx32 = {}
         self._nbin = nbin
-        self._domain = DomainTuple.make(other_space)
+        # leading spaces of the target (e.g. the UnstructuredDomain(total_N) of several correlated fields) are batch axes
+        lead = tuple(self._target[i] for i in range(len(self._target) - 1)) if hasattr(self, "_target") else ()
+        self._domain = DomainTuple.make(lead + (other_space,))
+        self._nlead = int(np.prod([d.size for d in lead])) if lead else 0
         self._capability = self.TIMES | self.ADJOINT_TIMES
 
     @property
@@ -1539,17 +1551,25 @@ class DOFDistributor(LinearOperator):
 
     def apply(self, x, mode):
         self._check_input(x, mode)
-        v = x.val
+        if self._nlead:  # one gather / scatter per leading index (slices and stacking are copies)
+            tshape = tuple(self._target.shape[len(self._target.shape) - len(self._target[self._space].shape):])
+            rows = x.val.reshape((self._nlead, -1))
+            outs = [self._apply1(rows[i], mode, tshape) for i in range(self._nlead)]
+            return Field(self._tgt(mode), torch.stack(outs).reshape(self._tgt(mode).shape))
+        tshape = self._target.shape
+        return Field(self._tgt(mode), self._apply1(x.val, mode, tshape).reshape(self._tgt(mode).shape))
+
+    def _apply1(self, v, mode, tshape):
         if mode == self.TIMES:
             if v.is_cuda:
-                return Field(self._target, B.gather(v.contiguous(), self._device_index(v.device), self._target.shape))
-            return Field(self._target, v[self._idx.to(v.device)].reshape(self._target.shape))
+                return B.gather(v.contiguous(), self._device_index(v.device), tshape)
+            return v[self._idx.to(v.device)].reshape(tshape)
         if v.is_cuda:
             bins = B.scatter_add(v.contiguous().reshape(-1), self._device_index(v.device), self._nbin)
-            return Field(self._domain, bins.to(v.dtype))
+            return bins.to(v.dtype)
         out = torch.zeros(self._nbin, dtype=torch.float64)
         out.index_add_(0, self._idx, v.reshape(-1).to(torch.float64))
-        return Field(self._domain, out.to(v.dtype))
+        return out.to(v.dtype)
 
 
 class PowerDistributor(DOFDistributor):
@@ -1560,8 +1580,8 @@ class PowerDistributor(DOFDistributor):
         if space is None and len(self._target) == 1:
             space = 0
         self._space = int(space)
-        if len(self._target) != 1:
-            raise NotImplementedError("PowerDistributor on a sub-space is not implemented yet")
+        if self._space != len(self._target) - 1:
+            raise NotImplementedError("PowerDistributor: only the LAST space of the target can be distributed")
         hspace = self._target[self._space]
         if not hspace.harmonic:
             raise ValueError("Operator requires harmonic target space")

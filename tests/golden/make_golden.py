@@ -275,6 +275,46 @@ def minimizer_cases():
     print("wrote minimizers", {k: float(out[k]) for k in out if k.endswith("value")})
 
 
+def totaln_cf(lib):
+    """Three correlated fields at once (total_N = 3): a 2-D spectrum shared by fields 0, 1 and separate for field 2
+    (dofdex = [0, 0, 1]) times a 1-D spectrum with one model per field; two zero-mode models."""
+    cfm = lib.CorrelatedFieldMaker("t", total_N=3)
+    cfm.add_fluctuations(lib.RGSpace((8, 6), (0.5, 0.25)), (1.0, 0.5), (1.2, 0.4), (0.4, 0.2), (-3.0, 0.5), prefix="sp",
+                         dofdex=[0, 0, 1])
+    cfm.add_fluctuations(lib.RGSpace((10,)), (0.8, 0.3), (1.0, 0.3), None, (-2.0, 0.4), prefix="en", dofdex=[0, 1, 2])
+    cfm.set_amplitude_total_offset(0.5, (1e-1, 3e-2), dofdex=[0, 1, 1])
+    return cfm, cfm.finalize()
+
+
+def totaln_case():
+    """CorrelatedFieldMaker(total_N > 0) with dofdex (correlated_fields.py:211-231, 277-386, 435-764): forward, Jacobian,
+    adjoint Jacobian, normalised amplitudes and a Hamiltonian value / gradient / metric."""
+    cfm, cf = totaln_cf(ift)
+    out = {}
+    ift.random.push_sseq_from_seed(13)
+    x = ift.from_random(cf.domain) * 0.5
+    v = ift.from_random(cf.domain)
+    w = ift.from_random(cf.target)
+    d = cf(ift.from_random(cf.domain)) + ift.from_random(cf.target) * 0.1
+    ift.random.pop_sseq()
+    out.update(mf2dict(x, "x"))
+    out.update(mf2dict(v, "v"))
+    out["w"], out["data"] = w.asnumpy(), d.asnumpy()
+    lin = cf(ift.Linearization.make_var(x))
+    out["cf"], out["cf_jvp"] = lin.val.asnumpy(), lin.jac(v).asnumpy()
+    out.update(mf2dict(lin.jac.adjoint(w), "cf_vjp"))
+    for i, na in enumerate(cfm.get_normalized_amplitudes()):
+        out[f"namp{i}"] = na.force(x).asnumpy()
+    lh = ift.GaussianEnergy(d, ift.ScalingOperator(cf.target, 100.0, np.float64)) @ cf
+    ham = ift.StandardHamiltonian(lh, ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=6), prior_sampling_dtype=np.float64)
+    hl = ham(ift.Linearization.make_var(x, want_metric=True))
+    out["ham_value"] = np.array(hl.val.val.asnumpy())
+    out.update(mf2dict(hl.gradient, "ham_grad"))
+    out.update(mf2dict(hl.metric(v), "ham_metric_v"))
+    np.savez_compressed(os.path.join(HERE, "totaln_cf.npz"), **out)
+    print("wrote totaln_cf", cf.target.shape, float(out["ham_value"]), sorted(k for k in out if k.startswith("x.")))
+
+
 def lhsum_cases():
     """Sum of two likelihoods on one correlated field (energy_operators.py:211-303): Gaussian data of the field and
     Poisson counts of its exponential (one named, one not).  Hamiltonian value / gradient / metric, normalised residual,
@@ -595,6 +635,8 @@ def main():
         return napprox_cases()
     if "--lhsum-only" in sys.argv:
         return lhsum_cases()
+    if "--totaln-only" in sys.argv:
+        return totaln_case()
     geo = {}
     for shape, dist in [((8,), None), ((7, 8), None), ((4, 5, 7), None), ((512,), None), ((64, 64), None),
                         ((16, 16, 16), None), ((16, 32), (0.3, 0.2)), ((12,), (0.7,))]:

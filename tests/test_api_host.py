@@ -557,3 +557,41 @@ def test_likelihood_sum_matches_reference(device_id):
         assert abs(kl.value - float(zs[f"{name}.kl_value"])) < 1e-7 * abs(float(zs[f"{name}.kl_value"]))
         for i, smp in enumerate(kl.samples.iterator()):
             assert gl.lat_relerr(smp.asnumpy(), _lat(zs, f"{name}.sample{i}")) < 1e-6
+
+
+@pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
+def test_total_N_correlated_fields_with_dofdex(device_id):
+    """CorrelatedFieldMaker(total_N=3): three fields on a leading UnstructuredDomain, a 2-D spectrum shared by two of them
+    (dofdex [0, 0, 1]) times a 1-D spectrum with one model per field, two zero-mode models
+    (correlated_fields.py:211-231, 277-386, 435-764) against tests/golden/totaln_cf.npz."""
+    z = gl.load("totaln_cf")
+    cfm = ift.CorrelatedFieldMaker("t", total_N=3)
+    cfm.add_fluctuations(ift.RGSpace((8, 6), (0.5, 0.25)), (1.0, 0.5), (1.2, 0.4), (0.4, 0.2), (-3.0, 0.5), prefix="sp",
+                         dofdex=[0, 0, 1])
+    cfm.add_fluctuations(ift.RGSpace((10,)), (0.8, 0.3), (1.0, 0.3), None, (-2.0, 0.4), prefix="en", dofdex=[0, 1, 2])
+    cfm.set_amplitude_total_offset(0.5, (1e-1, 3e-2), dofdex=[0, 1, 1])
+    cf = cfm.finalize()
+    assert cf.target.shape == (3, 8, 6, 10)
+    assert cf.domain["tspspectrum"].shape[0] == 2 and cf.domain["tenspectrum"].shape[0] == 3
+    assert cf.domain["tzeromode"].shape == (2,)
+    x = ift.MultiField.from_raw(cf.domain, _lat(z, "x"), device_id)
+    v = ift.MultiField.from_raw(cf.domain, _lat(z, "v"), device_id)
+    w = ift.makeField(cf.target, z["w"], device_id)
+    lin = cf(ift.Linearization.make_var(x))
+    assert gl.relerr(lin.val.asnumpy(), z["cf"]) < 1e-12
+    assert gl.relerr(lin.jac(v).asnumpy(), z["cf_jvp"]) < 1e-11
+    assert gl.lat_relerr(lin.jac.adjoint(w).asnumpy(), _lat(z, "cf_vjp")) < 1e-11
+    for i, na in enumerate(cfm.get_normalized_amplitudes()):
+        assert gl.relerr(na.force(x).asnumpy(), z[f"namp{i}"]) < 1e-12
+    d = ift.makeField(cf.target, z["data"], device_id)
+    lh = ift.GaussianEnergy(d, ift.ScalingOperator(cf.target, 100.0, np.float64)) @ cf
+    ham = ift.StandardHamiltonian(lh, ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=6),
+                                  prior_sampling_dtype=np.float64)
+    hl = ham(ift.Linearization.make_var(x, want_metric=True))
+    assert abs(float(hl.val.asnumpy()) - float(z["ham_value"])) < 1e-11 * abs(float(z["ham_value"]))
+    assert gl.lat_relerr(hl.gradient.asnumpy(), _lat(z, "ham_grad")) < 1e-10
+    assert gl.lat_relerr(hl.metric(v).asnumpy(), _lat(z, "ham_metric_v")) < 1e-10
+    with pytest.raises(ValueError):
+        cfm.add_fluctuations(ift.RGSpace((4,)), (1.0, 0.5), (1.2, 0.4), (0.4, 0.2), (-3.0, 0.5), dofdex=[0, 1])
+    with pytest.raises(NotImplementedError):
+        cfm.add_fluctuations_matern(ift.RGSpace((4,)), (1.0, 0.3), (2.0, 0.5), (-4.0, 0.5))
