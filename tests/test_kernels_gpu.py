@@ -249,3 +249,37 @@ def test_cg_update_dr(dtype):
     s = scal.cpu().numpy()
     assert abs(s[2] - float((r.double() ** 2).sum())) < 1e-12 * s[2]
     assert abs(s[3] - dr) < 1e-10 * abs((d.double() * r.double()).abs().sum().item())
+
+
+@pytest.mark.parametrize("shape,dtype", [((1024, 1024, 1024), torch.float32), ((512, 512, 512), torch.float64)])
+def test_sandwich_full_size_properties(shape, dtype):
+    """Size-independent properties of the five-pass H D H at BASELINE's full sizes: with D = 1/N it is the identity
+    (H o H = N), and with a positive diagonal it is symmetric, <y, S x> = <x, S y>."""
+    from nifty_amd import _lib as L
+    from nifty_amd import backend as B
+
+    g = torch.Generator(device="cuda").manual_seed(17)
+    x = torch.randn(shape, dtype=dtype, device="cuda", generator=g)
+    plan = B.get_plan(shape, dtype, 1, x.device)
+    assert B.plan_sandwich(plan)
+    n = x.numel()
+    tol = 1e-11 if dtype == torch.float64 else 3e-4
+
+    def sandwich(inp, mid):
+        out = torch.empty_like(inp)
+        f = L.Fuse()
+        f.pro, f.in_, f.epi, f.out, f.scale, f.mul_scalar, f.mul = L.PRO_PLAIN, inp.data_ptr(), L.EPI_AFFINE, out.data_ptr(), 1.0 / n, 1.0, B.ptr(mid)
+        B.hartley_sandwich(plan, f, 1.0)
+        return out
+
+    back = sandwich(x, None)
+    assert ((back - x).abs().max() / x.abs().max()).item() < tol
+    del back
+    y = torch.randn(shape, dtype=dtype, device="cuda", generator=g)
+    mid = torch.rand(shape, dtype=dtype, device="cuda", generator=g) + 0.5
+    sx = sandwich(x, mid)
+    a = B.vdot(y.reshape(-1), sx.reshape(-1)).item()
+    del sx
+    sy = sandwich(y, mid)
+    b = B.vdot(x.reshape(-1), sy.reshape(-1)).item()
+    assert abs(a - b) < tol * (abs(a) + abs(b) + n ** 0.5)
