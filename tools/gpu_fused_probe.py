@@ -34,6 +34,17 @@ report("linearize")
 for _ in range(3):
     q = model.metric(lp, d)
 report("metric")
+acc_out = LatentVec(torch.zeros_like(d.xi), None)
+dot = torch.zeros(1, dtype=torch.float64, device=dev)
+for _ in range(3):
+    model.lh_metric_accumulate(lp, d, acc_out, 0.125, True)
+report("metric 1st")
+for _ in range(3):
+    model.lh_metric_accumulate(lp, d, acc_out, 0.125, False)
+report("metric acc")
+for _ in range(3):
+    model.lh_metric_accumulate(lp, d, acc_out, 0.125, False, identity=1.0, dot_out=dot)
+report("metric acc+d")
 for _ in range(3):
     s = model.signal(x)
 report("signal")
