@@ -146,6 +146,11 @@ def cpu_baseline(counts_per_step, shape_full, sample_shape=None, budget_s=20.0, 
                         "value/gradient evaluations one GPU step executed"))
 
 
+RNG_LABEL = {"numpy": "the reference's numpy PCG64 + ziggurat streams (seed 42, one SeedSequence per sample), computed on the "
+                      "device from the host generators' states (nk_pcg64_normal)",
+             "device": "torch device generator (NK_BENCH_RNG=device)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,20 +200,31 @@ def main():
                        loglogavgslope=(-3.0, 2e-1), flexibility=(1.0, 2e-1), asperity=(5e-1, 5e-2),
                        likelihood=lh_kind, icov=1.0 / noise_var, nonlin="exp" if lh_kind == "poisson" else None,
                        dtype=dtype, device=device)
-    # synthetic data, identical on all ranks (same device seed): d = cf(truth) + noise, or d ~ Poisson(exp(cf(truth)))
-    gen = torch.Generator(device=device).manual_seed(42)
+    # synthetic inputs with the reference's seed discipline: push_sseq_from_seed(42); truth = from_random;
+    # d = cf(truth) + N(0, noise_var) (or d ~ Poisson(exp(cf(truth)))); start = 0.1 * from_random.  Every normal field is
+    # numpy's PCG64 + ziggurat stream computed ON THE DEVICE from the host generator's state (nk_pcg64_normal: the very
+    # numbers `rng.normal` returns, 12 ms instead of 9 s per 1024^3 field), identical on all ranks.
+    # NK_BENCH_RNG=device: torch's device generator instead (different numbers, for A/B timing).
+    rng_mode = os.environ.get("NK_BENCH_RNG", "numpy")
+    random.push_sseq_from_seed(42)
+    gen = torch.Generator(device=device).manual_seed(42) if rng_mode == "device" else None
     truth = model.draw_prior(gen)
     data = model.signal(truth)
     if lh_kind == "poisson":
-        data = torch.poisson(data.double(), generator=gen).to(torch.int64)
+        pgen = torch.Generator(device=device).manual_seed(42)
+        data = torch.poisson(data.double(), generator=pgen).to(torch.int64)
         model.set_data(data)
     else:
-        data.add_(torch.randn(shape, dtype=dtype, device=device, generator=gen), alpha=math.sqrt(noise_var))
+        if gen is None:
+            noise = random.Random.normal_on_device(model.npdtype, shape, 0.0, math.sqrt(noise_var), device)
+        else:
+            noise = torch.randn(shape, dtype=dtype, device=device, generator=gen) * math.sqrt(noise_var)
+        data.add_(noise)
+        del noise
         model.set_data(data, 1.0 / noise_var)
     del truth
     mean = 0.1 * model.draw_prior(gen)
-    rng_draws = torch.Generator(device=device).manual_seed(1234 + rank)
-    random.push_sseq_from_seed(42)
+    rng_draws = torch.Generator(device=device).manual_seed(1234 + rank) if rng_mode == "device" else None
 
     def step(mean):
         ic = lambda: AbsDeltaEnergyController(0.05, iteration_limit=20)  # noqa: E731
@@ -299,7 +315,7 @@ def main():
                                    f"{2 * n_pairs} mirrored MGVI samples, {dt_name} fields / fp64 accumulators, "
                                    "sampling CG limit 20, NewtonCG 3 steps x <=20 CG iterations",
                        "samples_total": 2 * n_pairs, "parallelism": f"sample-sharded x{world}",
-                       "rng": "device generator for the synthetic noise draws (parity tests use the reference's numpy PCG64 streams)"},
+                       "rng": RNG_LABEL[rng_mode]},
             "final_kl_energy": energy,
             "per_step_counts_rank0": counts,
             "step_algorithmic_GBps_rank0": step_bytes / (ms_per_step * 1e-3) / 1e9,

@@ -269,6 +269,23 @@ int nk_amp_jvp(int nb, const double* geo, const double* hyp, const double* lat, 
 int nk_amp_vjp(int nb, const double* geo, const double* hyp, const double* lat, double* state, const double* abar,
                double* latbar, void* stream);
 
+/* ---- random fields: numpy's `Generator(PCG64).normal(mean, std, n)` stream reproduced on the device, draw for draw
+ *      (replaces the host draws of nifty/cl/random.py:219-237 `Random.normal`, reached from field.py:128-156
+ *      `Field.from_random`, multi_field.py:109-153 and kl_energies.py:91-159; numpy is the reference's third-party RNG:
+ *      PCG XSL-RR 128/64 + 256-strip ziggurat, restated in nifty_amd/csrc/nk_rng.h).
+ *      state, inc: HOST pointers, the 128-bit generator state and increment as {high, low} 64-bit words
+ *                  (`bit_generator.state["state"]`); inc is odd
+ *      out       : device, n values of dtype (fp32 = the fp64 draw rounded once, like `.astype(float32)`)
+ *      scratch   : device, nk_pcg64_normal_scratch_bytes(n, attempt) bytes
+ *      status    : device uint64[2]: [0] <- number of raw 64-bit draws the n normals consumed (advance the host generator
+ *                  by it to stay in lockstep), [1] <- error bits: 2 = the scratch sizing was too tight, call again with
+ *                  attempt + 1 (never seen for attempt 0 beyond n ~ 10^3); 1 = chain merge failed (probability < 1e-60)
+ *      Asynchronous on `stream`; values are bit-identical to numpy's except in the |x| > 3.654 tail (2.7e-4 of the
+ *      draws), where log1p of the device math library may differ from the host libm in the last bit. */
+int64_t nk_pcg64_normal_scratch_bytes(int64_t n, int attempt);
+int nk_pcg64_normal(const uint64_t* state, const uint64_t* inc, int64_t n, double mean, double std, void* out, int dtype,
+                    void* scratch, int64_t scratch_bytes, int attempt, uint64_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

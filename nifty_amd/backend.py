@@ -357,3 +357,61 @@ def cumsum(x, reverse=False, out=None):
     L.check(L.load().nk_cumsum(x.numel(), x.data_ptr(), out.data_ptr(), 1 if reverse else 0, dtype_code(x), _stream()),
             "nk_cumsum")
     return out
+
+
+_PCG_MULT = 0x2360ED051FC65DA44385DF649FCCF645
+_M128 = (1 << 128) - 1
+
+
+def _pcg64_advanced(state, inc, delta):
+    """State of a PCG64 stream `delta` steps later (LCG jump-ahead in O(log delta) steps)."""
+    am, ap, m, p = 1, 0, _PCG_MULT, inc
+    while delta:
+        if delta & 1:
+            am = (am * m) & _M128
+            ap = (ap * m + p) & _M128
+        p = ((m + 1) * p) & _M128
+        m = (m * m) & _M128
+        delta >>= 1
+    return (am * state + ap) & _M128
+
+
+def pcg64_normal(rng, mean, std, shape, dtype, device):
+    """`rng.normal(mean, std, shape)` of a numpy Generator over PCG64 (the reference's generator: nifty/cl/random.py:146-206
+    push_sseq -> np.random.default_rng), computed on `device` from the generator's current state: the same values draw for
+    draw (cast to dtype like `.astype`), and `rng` is left in the state the host call would leave it in.  nk_pcg64_normal;
+    one host sync (the number of raw draws consumed comes back from the device)."""
+    import ctypes
+
+    import numpy as np
+
+    bg = rng.bit_generator
+    st = bg.state
+    if st.get("bit_generator") != "PCG64":
+        raise TypeError("pcg64_normal needs a numpy Generator over PCG64 (np.random.default_rng)")
+    n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
+    out = torch.empty(tuple(shape), dtype=dtype, device=device)
+    _require_device(out)
+    if n == 0:
+        return out
+    state, inc = int(st["state"]["state"]), int(st["state"]["inc"])
+    words = (ctypes.c_uint64 * 4)(state >> 64, state & (2**64 - 1), inc >> 64, inc & (2**64 - 1))
+    status = torch.empty(2, dtype=torch.int64, device=device)
+    lib = L.load()
+    for attempt in range(9):
+        nbytes = lib.nk_pcg64_normal_scratch_bytes(n, attempt)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        L.check(lib.nk_pcg64_normal(ctypes.addressof(words), ctypes.addressof(words) + 16, n, float(mean), float(std),
+                                    out.data_ptr(), dtype_code(out), scratch.data_ptr(), nbytes, attempt,
+                                    status.data_ptr(), _stream()), "nk_pcg64_normal")
+        consumed, err = status.cpu().tolist()
+        del scratch
+        if err == 0:
+            break
+        if err & 1:
+            raise RuntimeError("nk_pcg64_normal: chain merge failed")
+    else:
+        raise RuntimeError("nk_pcg64_normal: scratch sizing failed")
+    st["state"]["state"] = _pcg64_advanced(state, inc, int(consumed))
+    bg.state = st  # keeps has_uint32 / uinteger, exactly like the host draw of doubles does
+    return out

@@ -1,7 +1,10 @@
 """Global configuration (counterpart of reference nifty/config.py:42-80)."""
-# sampling_rng: "numpy" = the reference's host PCG64 streams (bit-compatible draws, ~10 s per 1e9 normals + the upload);
-#               "device" = the fused engine draws its N(0,1) fields with the device generator, seeded per sample from
-#               the same SeedSequence tree (same statistics and mirrored-pair consistency, different numbers)
+# sampling_rng: "numpy" = the reference's PCG64 + ziggurat streams, draw for draw.  Fields that live on a GPU are drawn
+#               THERE from the host generator's state (nk_pcg64_normal: same numbers, generator left in the same state;
+#               ~25 ms per 1e9 normals instead of ~10 s + the upload);
+#               "numpy_host" = the same streams drawn by numpy on the host and uploaded (cross-check of the above);
+#               "device" = the fused engine draws its N(0,1) fields with torch's device generator, seeded per sample
+#               from the same SeedSequence tree (same statistics and mirrored-pair consistency, different numbers)
 _config = dict(hartley_convention="non_canonical_hartley", sampling_rng="numpy")
 
 
@@ -23,7 +26,7 @@ def update(key, value, /):
         else:
             raise ValueError(f"invalid value to {key!r}; got {value!r}")
     elif key == "sampling_rng":
-        if value not in ("numpy", "device"):
+        if value not in ("numpy", "numpy_host", "device"):
             raise ValueError(f"invalid value to {key!r}; got {value!r}")
     else:
         raise ValueError(f"unknown configuration key {key!r}")

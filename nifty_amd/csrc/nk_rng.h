@@ -1,0 +1,216 @@
+// nk_rng.h -- numpy's `Generator(PCG64).normal` stream, reproduced draw for draw on the device.
+//
+// The reference draws every random field on the host with `np.random.default_rng(SeedSequence).normal(mean, std, shape)`
+// (nifty/cl/random.py:219-237, called from field.py:128-156 / multi_field.py:109-153 / kl_energies.py:91-159); at 1024^3
+// that is 10-15 s per field, more than a whole MGVI iteration takes on the GPU.  numpy (third party; reference pin
+// numpy>=1.23, this image 2.2.6) implements it as
+//   * bit generator PCG64 = PCG XSL-RR 128/64 (O'Neill 2014): state <- state * M + inc (mod 2^128), output
+//     rotr64(hi ^ lo, hi >> 58) of the NEW state; M = 0x2360ED051FC65DA44385DF649FCCF645
+//     (numpy/random/src/pcg64/pcg64.h: pcg_setseq_128_step_r, pcg_output_xsl_rr_128_64)
+//   * next_double = (next_uint64 >> 11) * 2^-53
+//   * standard normal: 256-strip ziggurat on ONE raw 64-bit draw (bits 0-7 strip, bit 8 sign, bits 9-60 magnitude), wedge
+//     test with one more double, tail (strip 0) by Marsaglia's exponential rejection with two doubles per try
+//     (numpy/random/src/distributions/distributions.c: random_standard_normal); normal = mean + std * standard normal.
+// A normal consumes 1 raw draw 97.9 % of the time and 2+ otherwise, so the position of the i-th normal in the raw stream
+// depends on all earlier rejections.  The device algorithm (nk_rng.hip) makes that parallel without changing the stream:
+//   A   the raw stream is cut into CHUNKS of NK_RNG_CHUNK draws (PCG64 jumps ahead in O(log) steps); every chunk walks
+//       the ziggurat from its first draw: number of normals started in the chunk, overrun into the next chunk, bit mask of
+//       the positions where a normal starts
+//   A2  the true entry of a chunk is the overrun of its predecessor; whenever it is not 0 the chunk walks from there
+//       until it lands on a position of the mask (the two chains have merged: every later draw is shared), which corrects
+//       the count -- and shows that the overrun of a chunk does NOT depend on its entry, so no serial pass over chunks is
+//       needed.  (No merge inside one chunk has probability < 1e-60; it raises NK_RNG_ERR_NOMERGE, never a wrong stream.)
+//   S   exclusive prefix sum of the counts = output offset of every chunk
+//   B   every chunk walks again from its true entry and writes its normals; the chunk that writes normal n-1 reports
+//       the number of raw draws consumed, so that the host generator can be advanced (`bit_generator.advance`) and
+//       stays in lockstep with the reference for the draws that follow.
+// The functions below are the per-chunk bodies; the test-only host emulation (tests/emu) runs the same ones.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "nk_core.h"
+#include "nk_ziggurat_tables.h"
+
+#define NK_RNG_CHUNK 64            // raw draws per chunk (= bits of the start mask)
+#define NK_RNG_ERR_NOMERGE 1u      // status bits (device word)
+#define NK_RNG_ERR_SHORT 2u        // the chunks did not hold n normals (the caller retries with more)
+#define NK_ZIG_R 3.6541528853610087963519472518
+#define NK_ZIG_INV_R 0.27366123732975827203338247596
+
+struct NkU128 {
+  uint64_t hi, lo;
+};
+NK_HD uint64_t nk_mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+NK_HD NkU128 nk_mul128(NkU128 a, NkU128 b) {
+  NkU128 r;
+  r.lo = a.lo * b.lo;
+  r.hi = nk_mulhi64(a.lo, b.lo) + a.hi * b.lo + a.lo * b.hi;
+  return r;
+}
+NK_HD NkU128 nk_add128(NkU128 a, NkU128 b) {
+  NkU128 r;
+  r.lo = a.lo + b.lo;
+  r.hi = a.hi + b.hi + (r.lo < a.lo ? 1u : 0u);
+  return r;
+}
+
+// jump table: (m[i], p[i]) advance the generator by 2^i steps, state <- m[i] * state + p[i]
+struct NkPcgJump {
+  NkU128 m[64], p[64];
+};
+NK_HD void nk_pcg_jump_table(NkU128 inc, NkPcgJump& t) {
+  NkU128 m{0x2360ED051FC65DA4ull, 0x4385DF649FCCF645ull}, p = inc;
+  for (int i = 0; i < 64; ++i) {
+    t.m[i] = m;
+    t.p[i] = p;
+    p = nk_mul128(nk_add128(m, NkU128{0, 1}), p);
+    m = nk_mul128(m, m);
+  }
+}
+NK_HD NkU128 nk_pcg_advance(NkU128 s, uint64_t delta, const NkPcgJump& t) {
+  NkU128 am{0, 1}, ap{0, 0};
+  for (int i = 0; delta; ++i, delta >>= 1)
+    if (delta & 1) {
+      am = nk_mul128(am, t.m[i]);
+      ap = nk_add128(nk_mul128(ap, t.m[i]), t.p[i]);
+    }
+  return nk_add128(nk_mul128(am, s), ap);
+}
+
+// the raw stream from a given position on; pos counts the draws taken
+struct NkRaw {
+  NkU128 s, inc;
+  int pos;
+  NK_HD uint64_t next() {
+    s = nk_add128(nk_mul128(s, NkU128{0x2360ED051FC65DA4ull, 0x4385DF649FCCF645ull}), inc);
+    ++pos;
+    const uint64_t x = s.hi ^ s.lo;
+    const unsigned rot = (unsigned)(s.hi >> 58);
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+  }
+  NK_HD double next_double() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+struct NkZig {
+  const uint64_t* ki;
+  const double *wi, *fi;
+};
+
+// products and sums below must round separately like numpy's (built without FMA contraction): the accept / reject
+// decisions and mean + std * x have to come out the same.  hipcc contracts by default (and its __dmul_rn / __dadd_rn are
+// plain operators that fuse after inlining), so contraction is switched off per function
+#if defined(__clang__)
+#define NK_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define NK_NO_CONTRACT
+#endif
+#define NK_DMUL(a, b) ((a) * (b))
+#define NK_DADD(a, b) ((a) + (b))
+
+// one standard normal starting at the current position of the raw stream (random_standard_normal)
+NK_HD double nk_zig_normal(NkRaw& g, const NkZig& z) {
+  NK_NO_CONTRACT
+  for (;;) {
+    uint64_t r = g.next();
+    const int idx = (int)(r & 0xff);
+    r >>= 8;
+    const int sign = (int)(r & 1);
+    const uint64_t rabs = (r >> 1) & 0x000fffffffffffffull;
+    double x = NK_DMUL((double)rabs, z.wi[idx]);
+    if (sign) x = -x;
+    if (rabs < z.ki[idx]) return x;
+    if (idx == 0) {
+      for (;;) {
+        const double xx = NK_DMUL(-NK_ZIG_INV_R, log1p(-g.next_double()));
+        const double yy = -log1p(-g.next_double());
+        if (NK_DADD(yy, yy) > NK_DMUL(xx, xx)) return ((rabs >> 8) & 1) ? -NK_DADD(NK_ZIG_R, xx) : NK_DADD(NK_ZIG_R, xx);
+      }
+    } else {
+      const double lhs = NK_DADD(NK_DMUL(z.fi[idx - 1] - z.fi[idx], g.next_double()), z.fi[idx]);
+      if (lhs < exp(NK_DMUL(NK_DMUL(-0.5, x), x))) return x;
+    }
+  }
+}
+
+struct NkRngArgs {
+  NkU128 state, inc;   // generator state BEFORE the first draw
+  int64_t n;           // normals wanted
+  int64_t nchunks;
+  double mean, std;
+};
+
+NK_HD NkRaw nk_rng_chunk_start(const NkRngArgs& a, const NkPcgJump& jt, int64_t k, int entry) {
+  NkRaw g;
+  g.inc = a.inc;
+  g.s = nk_pcg_advance(a.state, (uint64_t)k * NK_RNG_CHUNK + (uint64_t)entry, jt);
+  g.pos = entry;
+  return g;
+}
+
+// pass A: chain from the first draw of chunk k -> c0 normals started, overrun ov, start mask m
+NK_HD void nk_rng_pass_a(const NkRngArgs& a, const NkPcgJump& jt, const NkZig& z, int64_t k, int& c0, int& ov, uint64_t& m) {
+  NkRaw g = nk_rng_chunk_start(a, jt, k, 0);
+  m = 0;
+  c0 = 0;
+  while (g.pos < NK_RNG_CHUNK) {
+    m |= 1ull << g.pos;
+    (void)nk_zig_normal(g, z);
+    ++c0;
+  }
+  ov = g.pos - NK_RNG_CHUNK;
+  if (ov > 255) ov = 255;
+}
+
+// pass A2: the count of chunk k for its true entry e (= overrun of chunk k - 1); sets status bits on failure
+NK_HD int nk_rng_pass_a2(const NkRngArgs& a, const NkPcgJump& jt, const NkZig& z, int64_t k, int e, int c0, uint64_t m,
+                         unsigned* err) {
+  if (e == 0) return c0;
+  if (e >= NK_RNG_CHUNK) {
+    *err |= NK_RNG_ERR_NOMERGE;
+    return 0;
+  }
+  NkRaw g = nk_rng_chunk_start(a, jt, k, e);
+  int c = 0;
+  while (g.pos < NK_RNG_CHUNK && !((m >> g.pos) & 1)) {
+    (void)nk_zig_normal(g, z);
+    ++c;
+  }
+  if (g.pos >= NK_RNG_CHUNK) {  // the chains never met inside this chunk: its overrun is not the recorded one
+    *err |= NK_RNG_ERR_NOMERGE;
+    return 0;
+  }
+  // merged at g.pos: from there on the chunk's own chain is followed
+  int before = 0;
+  for (int b = 0; b < g.pos; ++b) before += (int)((m >> b) & 1);
+  return c + c0 - before;
+}
+
+// pass B: write the normals of chunk k (true entry, output offset off); the chunk holding normal n-1 reports the raw
+// draws consumed up to and including it
+template <typename T>
+NK_HD void nk_rng_pass_b(const NkRngArgs& a, const NkPcgJump& jt, const NkZig& z, int64_t k, int entry, int64_t off, T* out,
+                         uint64_t* consumed) {
+  NK_NO_CONTRACT
+  if (off >= a.n || entry >= NK_RNG_CHUNK) return;
+  NkRaw g = nk_rng_chunk_start(a, jt, k, entry);
+  while (g.pos < NK_RNG_CHUNK && off < a.n) {
+    const double x = nk_zig_normal(g, z);
+    out[off] = (T)NK_DADD(a.mean, NK_DMUL(a.std, x));
+    if (off == a.n - 1) *consumed = (uint64_t)k * NK_RNG_CHUNK + (uint64_t)g.pos;
+    ++off;
+  }
+}
+
+static inline int64_t nk_rng_chunks_for(int64_t n, int attempt) {
+  // a normal takes 1.0220 raw draws on average (2.1 % need a second one); margin 0.5 % (+ 32 chunks for small n),
+  // doubled on every retry
+  const double need = (double)n * (1.0225 + 0.005 * (double)(1 << attempt)) / NK_RNG_CHUNK;
+  return (int64_t)need + 32 * (int64_t)(1 + attempt);
+}

@@ -282,6 +282,7 @@ class FusedModel:
             raise RuntimeError(f"FusedModel(device={self.device}): make it the current device first "
                                f"(torch.cuda.set_device / `with torch.cuda.device({self.device.index})`)")
         self.tdtype = dtype
+        self.npdtype = np.float32 if dtype == torch.float32 else np.float64
         self.shape = tuple(int(s) for s in np.atleast_1d(shape))
         self.N = int(np.prod(self.shape))
         pos = RGSpace(self.shape, distances)
@@ -648,10 +649,13 @@ class FusedModel:
         nb = self.nb
         parts = {}
         for k in LATENT_KEYS:  # alphabetical = the reference's draw order
-            shp = (2, nb - 2) if k == "spectrum" else self.shape if k == "xi" else ()
+            if k == "xi":  # the numpy stream, computed on the device from the host generator's state
+                xi = random.Random.normal_on_device(self.npdtype, self.shape, 0.0, 1.0, self.device)
+                continue
+            shp = (2, nb - 2) if k == "spectrum" else ()
             parts[k] = random.current_rng().normal(0.0, 1.0, shp)
         small = np.concatenate([[parts[k] for k in SMALL_KEYS], parts["spectrum"].ravel()])
-        return LatentVec(self._upload(parts["xi"], self.tdtype), self._upload(small, torch.float64))
+        return LatentVec(xi, self._upload(small, torch.float64))
 
     def draw_lh_noise(self, lp, device_rng=None):
         """J^T M_d^{1/2} eta with eta ~ N(0,1) in data space."""
@@ -660,9 +664,9 @@ class FusedModel:
             if self.const_mid:
                 eta = B.axpby(math.sqrt(self.icov_scalar), eta)
         elif self.const_mid:
-            eta = self._upload(random.current_rng().normal(0.0, math.sqrt(self.icov_scalar), self.shape), self.tdtype)
+            eta = random.Random.normal_on_device(self.npdtype, self.shape, 0.0, math.sqrt(self.icov_scalar), self.device)
         else:
-            eta = self._upload(random.current_rng().normal(0.0, 1.0, self.shape), self.tdtype)
+            eta = random.Random.normal_on_device(self.npdtype, self.shape, 0.0, 1.0, self.device)
         if not self.const_mid:
             eta = B.binary(L.OP_MUL, eta, B.pointwise("sqrt", lp.mid))
         out = LatentVec(torch.empty(self.shape, dtype=self.tdtype, device=self.device), None)

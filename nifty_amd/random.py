@@ -1,11 +1,15 @@
 """Seed-sequence / generator STACK with the reference's discipline (nifty/cl/random.py:83-290).
 
 Parity with the nifty.cl numpy path on identical seeds requires the very same numpy PCG64 streams,
-spawned the same way, so the draws happen on the host with numpy and are uploaded to the device.
+spawned the same way: the generators live on the host (numpy); large normal draws of device fields are computed on the
+GPU from the generator's state (`Random.normal_on_device` -> nk_pcg64_normal, the same numbers draw for draw).
 """
 import pickle
 
 import numpy as np
+
+# draws smaller than this stay on the host even for device fields (launch + sync cost more than numpy takes)
+DEVICE_DRAW_MIN = 1 << 15
 
 _sseq = [np.random.SeedSequence(42)]
 _rng = [np.random.default_rng(_sseq[-1])]
@@ -62,6 +66,37 @@ class Random:
         if np.issubdtype(type(mean), np.complexfloating):
             raise TypeError("mean must not be complex for a real result field")
         return _rng[-1].normal(mean, std, shape).astype(dtype, copy=False)
+
+    @staticmethod
+    def normal_on_device(dtype, shape, mean, std, device):
+        """`normal` for a field that lives on a GPU: the same numpy stream, drawn on the device (backend.pcg64_normal)
+        unless the draw is small or config sampling_rng = "numpy_host"; returns a torch tensor on `device`."""
+        import torch
+
+        from . import backend, config
+        from .field import _as_tensor
+
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
+        if config.get("sampling_rng") == "numpy_host" or n < DEVICE_DRAW_MIN:
+            return _as_tensor(Random.normal(dtype, shape, mean, std), device)
+        if not (np.issubdtype(dtype, np.floating) or np.issubdtype(dtype, np.complexfloating)):
+            raise TypeError("dtype must be float or complex")
+        if not np.isscalar(mean) or not np.isscalar(std):
+            raise TypeError("mean and std must be scalars")
+        if np.issubdtype(type(std), np.complexfloating):
+            raise TypeError("std must not be complex")
+        if np.issubdtype(dtype, np.complexfloating):
+            rdt = torch.float32 if dtype == np.complex64 else torch.float64
+            re = backend.pcg64_normal(_rng[-1], np.real(mean), std, shape, rdt, device)
+            im = backend.pcg64_normal(_rng[-1], np.imag(mean), std, shape, rdt, device)
+            return torch.complex(re, im)
+        if np.issubdtype(type(mean), np.complexfloating):
+            raise TypeError("mean must not be complex for a real result field")
+        tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}.get(dtype)
+        if tdt is None:  # float16 and friends: host path
+            return _as_tensor(Random.normal(dtype, shape, mean, std), device)
+        return backend.pcg64_normal(_rng[-1], mean, std, shape, tdt, device)
 
     @staticmethod
     def pm1(dtype, shape):

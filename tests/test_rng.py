@@ -1,0 +1,268 @@
+"""numpy's Generator(PCG64).normal stream on the device (nifty_amd/csrc/nk_rng.h, nk_rng.hip).
+
+The checker is numpy itself -- the reference's third-party RNG (nifty/cl/random.py:146-237), present on every box.
+CPU tests run the host emulation of the per-chunk kernel bodies (tests/emu/emu_rng.cpp: the same functions the kernels
+call) and the Python side of the state hand-over; GPU tests run nk_pcg64_normal through the C ABI.
+Bar: bit-identical values and generator state.  On the device the |x| > 3.654 tail (2.7e-4 of the draws) goes through the
+device math library's log1p and may differ from the host libm in the last bits (tolerance 4 ulp, written below)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "emu", "libnk_emu.so")
+U64P = ctypes.POINTER(ctypes.c_uint64)
+TAIL = 3.6541528853610087
+
+
+def _words(rng):
+    s = rng.bit_generator.state["state"]
+    m = 2**64 - 1
+    return (np.array([s["state"] >> 64, s["state"] & m], dtype=np.uint64), np.array([s["inc"] >> 64, s["inc"] & m], dtype=np.uint64))
+
+
+def _emu():
+    if not os.path.exists(EMU):
+        pytest.skip("emulation library not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(EMU)
+    lib.emu_rng_chunks_for.restype = ctypes.c_int64
+    lib.emu_pcg64_normal_chunked.restype = ctypes.c_uint
+    return lib
+
+
+CASES = [(42, 2_000_000, 0.0, 1.0), (7, 1, 0.0, 1.0), (8, 63, 1.5, 0.1), (9, 100_003, -2.0, 3.0), (31, 64, 0.0, 1.0),
+         (10, 3_000_000, 0.0, 10.0)]
+
+
+@pytest.mark.parametrize("seed,n,mean,std", CASES)
+def test_serial_restatement_equals_numpy(seed, n, mean, std):
+    lib = _emu()
+    rng = np.random.default_rng(np.random.SeedSequence(seed))
+    state, inc = _words(rng)
+    ref = rng.normal(mean, std, n)
+    after, _ = _words(rng)
+    out = np.empty(n)
+    used = ctypes.c_uint64(0)
+    lib.emu_pcg64_normal_serial(state.ctypes.data_as(U64P), inc.ctypes.data_as(U64P), ctypes.c_int64(n), ctypes.c_double(mean),
+                                ctypes.c_double(std), out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.byref(used))
+    assert np.array_equal(out.view(np.uint64), ref.view(np.uint64))
+    adv = np.zeros(2, dtype=np.uint64)
+    lib.emu_pcg64_advance(state.ctypes.data_as(U64P), inc.ctypes.data_as(U64P), ctypes.c_uint64(used.value), adv.ctypes.data_as(U64P))
+    assert np.array_equal(adv, after)
+    if n >= 2_000_000:  # the sample exercises the wedge and the tail branch
+        assert (np.abs((ref - mean) / std) > TAIL).sum() > 100
+        assert used.value > n
+
+
+@pytest.mark.parametrize("seed,n,mean,std", CASES)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_chunked_kernel_bodies_equal_numpy(seed, n, mean, std, dtype):
+    lib = _emu()
+    rng = np.random.default_rng(np.random.SeedSequence(seed))
+    state, inc = _words(rng)
+    ref = rng.normal(mean, std, n).astype(dtype)
+    after, _ = _words(rng)
+    nch = lib.emu_rng_chunks_for(ctypes.c_int64(n), 0)
+    out = np.empty(n, dtype=dtype)
+    used = ctypes.c_uint64(0)
+    err = lib.emu_pcg64_normal_chunked(state.ctypes.data_as(U64P), inc.ctypes.data_as(U64P), ctypes.c_int64(n), ctypes.c_double(mean),
+                                       ctypes.c_double(std), 1 if dtype == np.float64 else 0, out.ctypes.data_as(ctypes.c_void_p),
+                                       ctypes.byref(used), ctypes.c_int64(nch))
+    assert err == 0
+    assert np.array_equal(out.view(np.uint64 if dtype == np.float64 else np.uint32), ref.view(np.uint64 if dtype == np.float64 else np.uint32))
+    adv = np.zeros(2, dtype=np.uint64)
+    lib.emu_pcg64_advance(state.ctypes.data_as(U64P), inc.ctypes.data_as(U64P), ctypes.c_uint64(used.value), adv.ctypes.data_as(U64P))
+    assert np.array_equal(adv, after)
+
+
+def test_too_few_chunks_is_reported_not_wrong():
+    lib = _emu()
+    rng = np.random.default_rng(5)
+    state, inc = _words(rng)
+    n = 10_000
+    out = np.empty(n)
+    used = ctypes.c_uint64(0)
+    err = lib.emu_pcg64_normal_chunked(state.ctypes.data_as(U64P), inc.ctypes.data_as(U64P), ctypes.c_int64(n), ctypes.c_double(0.0),
+                                       ctypes.c_double(1.0), 1, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(used),
+                                       ctypes.c_int64(n // 64))  # 64 draws per chunk hold < 64 normals
+    assert err == 2
+
+
+@pytest.mark.parametrize("delta", [0, 1, 63, 64, 12345678901, 2**63 + 17])
+def test_python_jump_ahead_equals_numpy_advance(delta):
+    from nifty_amd.backend import _pcg64_advanced
+
+    rng = np.random.default_rng(123)
+    st = rng.bit_generator.state["state"]
+    got = _pcg64_advanced(int(st["state"]), int(st["inc"]), delta)
+    rng.bit_generator.advance(delta)
+    assert got == int(rng.bit_generator.state["state"]["state"])
+    lib = _emu()
+    rng2 = np.random.default_rng(123)
+    state, inc = _words(rng2)
+    adv = np.zeros(2, dtype=np.uint64)
+    lib.emu_pcg64_advance(state.ctypes.data_as(U64P), inc.ctypes.data_as(U64P), ctypes.c_uint64(delta), adv.ctypes.data_as(U64P))
+    assert (int(adv[0]) << 64) | int(adv[1]) == got
+
+
+def test_tables_header_matches_installed_numpy():
+    """The committed bit patterns are numpy's: a single-draw generator built from them reproduces numpy for every strip."""
+    lib = _emu()
+    rng = np.random.default_rng(99)
+    n = 400_000  # every one of the 256 strips is hit > 1000 times
+    state, inc = _words(rng)
+    raw = np.random.default_rng(99).bit_generator.random_raw(n)
+    assert len(np.unique(raw & 0xFF)) == 256
+    ref = rng.normal(size=n)
+    out = np.empty(n)
+    used = ctypes.c_uint64(0)
+    lib.emu_pcg64_normal_serial(state.ctypes.data_as(U64P), inc.ctypes.data_as(U64P), ctypes.c_int64(n), ctypes.c_double(0.0),
+                                ctypes.c_double(1.0), out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.byref(used))
+    assert np.array_equal(out, ref)
+
+
+def test_small_and_host_forced_draws_take_the_host_path():
+    from nifty_amd import config, random
+
+    with random.Context(11):
+        a = random.Random.normal_on_device(np.float64, (100,), 0.0, 1.0, torch.device("cpu"))
+    with random.Context(11):
+        b = random.Random.normal(np.float64, (100,))
+    assert np.array_equal(a.numpy(), b)
+    config.update("sampling_rng", "numpy_host")
+    try:
+        with random.Context(12):
+            a = random.Random.normal_on_device(np.float32, (1 << 16,), 1.0, 2.0, torch.device("cpu"))
+        with random.Context(12):
+            b = random.Random.normal(np.float32, (1 << 16,), 1.0, 2.0)
+        assert np.array_equal(a.numpy(), b)
+    finally:
+        config.update("sampling_rng", "numpy")
+    with pytest.raises(ValueError):
+        config.update("sampling_rng", "nonsense")
+
+
+# ---- device ---------------------------------------------------------------------------------------------------------
+def _ulps(a, b):
+    ia = a.view(np.int64 if a.dtype == np.float64 else np.int32).astype(np.int64)
+    ib = b.view(np.int64 if b.dtype == np.float64 else np.int32).astype(np.int64)
+    return np.abs(ia - ib)
+
+
+def _check_device_draw(got, ref64, mean, std, dtype):
+    ref = ref64.astype(dtype)
+    tail = np.abs((ref64 - mean) / std) > TAIL
+    assert np.array_equal(got[~tail], ref[~tail])  # bit-identical outside the tail
+    if tail.any():
+        assert _ulps(got[tail], ref[tail]).max() <= 4  # log1p: device math library vs host libm
+    return int(tail.sum()), int((got != ref).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,mean,std", CASES + [(77, (1 << 24) + 12345, 0.0, 1.0)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_device_normal_equals_numpy(seed, n, mean, std, dtype):
+    from nifty_amd import backend as B
+
+    rng = np.random.default_rng(np.random.SeedSequence(seed))
+    ref_rng = np.random.default_rng(np.random.SeedSequence(seed))
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    got = B.pcg64_normal(rng, mean, std, (n,), tdt, torch.device("cuda:0")).cpu().numpy()
+    ref = ref_rng.normal(mean, std, n)
+    _check_device_draw(got, ref, mean, std, dtype)
+    # the host generator continues exactly where numpy's own draw would have left it
+    assert rng.bit_generator.state == ref_rng.bit_generator.state
+    assert np.array_equal(rng.normal(size=5), ref_rng.normal(size=5))
+    assert np.array_equal(rng.integers(0, 2, size=9), ref_rng.integers(0, 2, size=9))
+
+
+@pytest.mark.gpu
+def test_device_normal_keeps_the_cached_uint32():
+    """A pending 32-bit half draw (Generator.integers) survives the device draw like it survives numpy's own normal."""
+    from nifty_amd import backend as B
+
+    rng, ref_rng = np.random.default_rng(3), np.random.default_rng(3)
+    for g in (rng, ref_rng):
+        g.integers(0, 2, size=3, dtype=np.uint32)
+    assert rng.bit_generator.state["has_uint32"] == ref_rng.bit_generator.state["has_uint32"]
+    got = B.pcg64_normal(rng, 0.0, 1.0, (70000,), torch.float64, torch.device("cuda:0")).cpu().numpy()
+    ref = ref_rng.normal(size=70000)
+    _check_device_draw(got, ref, 0.0, 1.0, np.float64)
+    assert rng.bit_generator.state == ref_rng.bit_generator.state
+    assert np.array_equal(rng.integers(0, 1 << 20, size=7, dtype=np.uint32), ref_rng.integers(0, 1 << 20, size=7, dtype=np.uint32))
+
+
+@pytest.mark.gpu
+def test_device_fields_draw_the_reference_stream():
+    """Field.from_random / MultiField.from_random on a device: same values and same generator hand-over as on the host."""
+    import nifty_amd as ift
+    from nifty_amd import random
+
+    dom = ift.RGSpace((96, 1024))
+    md = ift.MultiDomain.make({"a": ift.RGSpace(7), "b": dom, "c": ift.RGSpace(3)})
+    for dtype in (np.float64, np.float32, np.complex128):
+        with random.Context(21):
+            host = ift.from_random(md, "normal", dtype=dtype, std=2.0, mean=0.5)
+            host_next = random.current_rng().normal(size=3)
+        with random.Context(21):
+            dev = ift.from_random(md, "normal", dtype=dtype, device_id=0, std=2.0, mean=0.5)
+            dev_next = random.current_rng().normal(size=3)
+        for k in md.keys():
+            h, d = host[k].asnumpy(), dev[k].asnumpy()
+            assert d.dtype == h.dtype and dev[k].device_id == 0
+            if np.iscomplexobj(h):
+                same = (h == d)
+            else:
+                same = (h == d)
+            assert same.mean() > 0.999 and np.allclose(h, d, rtol=1e-14 if dtype != np.float32 else 1e-6, atol=0)
+        assert np.array_equal(host_next, dev_next)
+
+
+@pytest.mark.gpu
+def test_engine_draws_equal_host_draws():
+    """FusedModel.draw_prior / draw_lh_noise with the stream computed on the device vs numpy_host."""
+    from nifty_amd import config, random
+    from nifty_amd.engine import FusedModel
+
+    model = FusedModel((64, 64, 128), offset_mean=2.0, likelihood="gaussian", icov=100.0, dtype=torch.float32, device="cuda:0")
+    res = {}
+    for mode in ("numpy", "numpy_host"):
+        config.update("sampling_rng", mode)
+        try:
+            with random.Context(5):
+                x = model.draw_prior()
+                model.set_data(model.signal(x), 100.0)
+                lp = model.linearize(x)
+                nj = model.draw_lh_noise(lp)
+                res[mode] = (x.xi.cpu().numpy(), x.small.cpu().numpy(), nj.xi.cpu().numpy(), random.current_rng().normal(size=2))
+        finally:
+            config.update("sampling_rng", "numpy")
+    a, b = res["numpy"], res["numpy_host"]
+    assert (a[0] != b[0]).mean() < 1e-3 and np.allclose(a[0], b[0], rtol=1e-6, atol=0)
+    assert np.array_equal(a[1], b[1])
+    assert np.allclose(a[2], b[2], rtol=1e-4, atol=1e-4 * np.abs(b[2]).max())
+    assert np.array_equal(a[3], b[3])
+
+
+@pytest.mark.gpu
+def test_device_normal_full_size_stream():
+    """BASELINE size: 1024^3 fp32 normals, compared with numpy slice by slice (the stream does not depend on how it is cut)."""
+    from nifty_amd import backend as B
+
+    n = 1 << 30
+    rng = np.random.default_rng(np.random.SeedSequence(42))
+    ref_rng = np.random.default_rng(np.random.SeedSequence(42))
+    got = B.pcg64_normal(rng, 0.0, 1.0, (n,), torch.float32, torch.device("cuda:0"))
+    step = 1 << 26
+    ntail = ndiff = 0
+    for lo in range(0, n, step):
+        ref = ref_rng.normal(0.0, 1.0, step)
+        t, d = _check_device_draw(got[lo:lo + step].cpu().numpy(), ref, 0.0, 1.0, np.float32)
+        ntail += t
+        ndiff += d
+    assert rng.bit_generator.state == ref_rng.bit_generator.state
+    assert 2.0e-4 * n < ntail < 3.5e-4 * n
+    assert ndiff <= ntail
