@@ -29,11 +29,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from nifty_amd import _lib as L  # noqa: E402
+from nifty_amd import backend as B  # noqa: E402
 from nifty_amd import minimization, parallel, random  # noqa: E402
 from nifty_amd.engine import FusedModel, LatentVec, mgvi_iteration  # noqa: E402
 from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG  # noqa: E402
 
-PMC_TRAFFIC_FILE = "r02d_pmc_traffic.json"  # latest committed PMC summary of the bench command
+PMC_TRAFFIC_FILE = "r02e_pmc_traffic.json"  # latest committed PMC summary of the bench command
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # transform pass kernels by profile id: strided-first pipeline (A first strided pass with prologue, B in-place strided
 # pass, C final contiguous pass with epilogue) and the five-pass sandwich H D H of a metric application (S1 contiguous
@@ -292,6 +293,26 @@ def main():
                             all_pass_kernels={KERNEL_NAMES[k]: dict(ms_total=round(v["ms"], 2), launches=int(v["cnt"]),
                                                                     GBps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
                                               for k, v in sorted(by_kernel.items())})
+        if roofline is not None:
+            # "confirm on the box with a device-copy ceiling and report both" -- a 1 read + 1 write stream copy
+            # of one field-sized array through the library's own chunked element-wise kernel (after the timed region)
+            try:
+                src = torch.empty(max(N, 1 << 28), dtype=dtype, device=device).normal_()
+                dst = torch.empty_like(src)
+                B.axpby(1.0, src, out=dst)
+                torch.cuda.synchronize(device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    B.axpby(1.0, src, out=dst)
+                e1.record()
+                torch.cuda.synchronize(device)
+                ceil = 10 * 2 * src.numel() * b / (e0.elapsed_time(e1) * 1e-3) / 1e9
+                roofline["copy_ceiling"] = {"GBps": round(ceil, 1), "frac_of_ceiling": round(achieved / ceil, 4),
+                                            "what": "measured here: 1 read + 1 write stream device copy of one field"}
+                del src, dst
+            except Exception as exc:
+                roofline["copy_ceiling"] = {"error": repr(exc)}
         # whole-step algorithmic bytes: B_met, B_vg per sample evaluation on this rank
         D = len(shape)
         shape_label = f"{shape[0]}^{D}" if len(set(shape)) == 1 else "x".join(map(str, shape))
