@@ -157,16 +157,20 @@ __device__ __forceinline__ void chunk_apply(const ScanGeom& sg, bool reverse, Se
   }
 }
 
-// carry-in of this workgroup and the grand total from the per-workgroup aggregates
-__device__ __forceinline__ void seg_prefix_total(const double* __restrict__ segs, int ngroups, Seg& prefix, Seg& total) {
-  Seg p{0.0, 0.0, 0.0}, t{0.0, 0.0, 0.0};
-  for (int g = 0; g < ngroups; ++g) {
-    const Seg sgm{segs[3 * g], segs[3 * g + 1], segs[3 * g + 2]};
-    if (g == (int)blockIdx.x) p = t;
-    t = seg_combine(t, sgm);
-  }
-  prefix = p;
-  total = t;
+// carry-in of this workgroup and the grand total from the per-workgroup aggregates: thread t takes aggregate t and
+// the workgroup scans them (ngroups <= MAXG = AMP_THREADS) -- the serial walk over up to 256 aggregates that every
+// thread did before was half of the 33 us these launches took at nb = 3e5
+static_assert(MAXG <= AMP_THREADS, "one aggregate per thread");
+__device__ __forceinline__ void seg_prefix_total(const double* __restrict__ segs, int ngroups, Seg& prefix, Seg& total,
+                                                 Seg* sh /*[AMP_WAVES + 1]*/) {
+  const int g = threadIdx.x;
+  const Seg mine = g < ngroups ? Seg{segs[3 * g], segs[3 * g + 1], segs[3 * g + 2]} : Seg{0.0, 0.0, 0.0};
+  Seg excl;
+  block_scan_seg(mine, excl, total, sh);
+  if (g == (int)blockIdx.x) sh[AMP_WAVES] = excl;
+  __syncthreads();
+  prefix = sh[AMP_WAVES];
+  __syncthreads();
 }
 
 struct AmpPtrs {
@@ -199,7 +203,7 @@ __device__ __forceinline__ Seg fwd_elem(const AmpPtrs& a, const Hyper& h, const 
 __global__ void __launch_bounds__(AMP_THREADS) k_fwd_agg(int nb, ScanGeom sg, const double* __restrict__ geo,
                                                          const double* __restrict__ hyp, const double* __restrict__ lat,
                                                          double* __restrict__ state) {
-  __shared__ Seg sh_seg[AMP_WAVES];
+  __shared__ Seg sh_seg[AMP_WAVES + 1];
   const AmpPtrs a = amp_ptrs(nb, geo, state);
   const Hyper h = hyper_from_lat(hyp, lat);
   const double *xs0 = lat + 5, *xs1 = lat + 5 + sg.m;
@@ -216,13 +220,13 @@ __global__ void __launch_bounds__(AMP_THREADS) k_fwd_agg(int nb, ScanGeom sg, co
 __global__ void __launch_bounds__(AMP_THREADS) k_fwd_apply(int nb, ScanGeom sg, const double* __restrict__ geo,
                                                            const double* __restrict__ hyp, const double* __restrict__ lat,
                                                            double* __restrict__ state) {
-  __shared__ Seg sh_seg[AMP_WAVES];
+  __shared__ Seg sh_seg[AMP_WAVES + 1];
   __shared__ double sh_d[AMP_WAVES];
   const AmpPtrs a = amp_ptrs(nb, geo, state);
   const Hyper h = hyper_from_lat(hyp, lat);
   const double *xs0 = lat + 5, *xs1 = lat + 5 + sg.m;
   Seg prefix, total;
-  seg_prefix_total(a.segs, sg.ngroups, prefix, total);
+  seg_prefix_total(a.segs, sg.ngroups, prefix, total, sh_seg);
   const double last = total.B;
   double part = 0.0;
   auto bin = [&](int b, double smooth) {
@@ -271,7 +275,7 @@ __device__ __forceinline__ Seg jvp_elem(const AmpPtrs& a, const JvpScal& q, cons
 __global__ void __launch_bounds__(AMP_THREADS) k_jvp_agg(int nb, ScanGeom sg, const double* __restrict__ geo,
                                                          const double* __restrict__ hyp, const double* __restrict__ lat,
                                                          double* __restrict__ state, const double* __restrict__ dlat) {
-  __shared__ Seg sh_seg[AMP_WAVES];
+  __shared__ Seg sh_seg[AMP_WAVES + 1];
   const AmpPtrs a = amp_ptrs(nb, geo, state);
   const JvpScal q{state[0], state[1], state[0] * hyp[3] * dlat[1], state[1] * hyp[5] * dlat[0]};
   const Seg c = chunk_aggregate(
@@ -285,13 +289,13 @@ __global__ void __launch_bounds__(AMP_THREADS) k_jvp_agg(int nb, ScanGeom sg, co
 __global__ void __launch_bounds__(AMP_THREADS) k_jvp_apply(int nb, ScanGeom sg, const double* __restrict__ geo,
                                                            const double* __restrict__ hyp, const double* __restrict__ lat,
                                                            double* __restrict__ state, const double* __restrict__ dlat) {
-  __shared__ Seg sh_seg[AMP_WAVES];
+  __shared__ Seg sh_seg[AMP_WAVES + 1];
   __shared__ double sh_d[AMP_WAVES];
   const AmpPtrs a = amp_ptrs(nb, geo, state);
   const JvpScal q{state[0], state[1], state[0] * hyp[3] * dlat[1], state[1] * hyp[5] * dlat[0]};
   const double dslope = hyp[9] * dlat[3];
   Seg prefix, total;
-  seg_prefix_total(a.segs, sg.ngroups, prefix, total);
+  seg_prefix_total(a.segs, sg.ngroups, prefix, total, sh_seg);
   const double last = total.B;
   double part = 0.0;
   auto bin = [&](int b, double dsm) {
@@ -369,7 +373,7 @@ __device__ __forceinline__ Seg vjp_elem(const AmpPtrs& a, int nb, int m, double 
 
 __global__ void __launch_bounds__(AMP_THREADS) k_vjp_agg(int nb, ScanGeom sg, const double* __restrict__ geo,
                                                          double* __restrict__ state) {
-  __shared__ Seg sh_seg[AMP_WAVES];
+  __shared__ Seg sh_seg[AMP_WAVES + 1];
   const AmpPtrs a = amp_ptrs(nb, geo, state);
   const double sc_dot = state[11];
   const Seg c = chunk_aggregate(sg, true, [&](int j) { return vjp_elem(a, nb, sg.m, sc_dot, j); }, sh_seg);
@@ -379,14 +383,14 @@ __global__ void __launch_bounds__(AMP_THREADS) k_vjp_agg(int nb, ScanGeom sg, co
 __global__ void __launch_bounds__(AMP_THREADS) k_vjp_apply(int nb, ScanGeom sg, const double* __restrict__ geo,
                                                            const double* __restrict__ lat, double* __restrict__ state,
                                                            double* __restrict__ latbar) {
-  __shared__ Seg sh_seg[AMP_WAVES];
+  __shared__ Seg sh_seg[AMP_WAVES + 1];
   __shared__ double sh_d[AMP_WAVES];
   const AmpPtrs a = amp_ptrs(nb, geo, state);
   const double flex = state[0], asp = state[1], sc_dot = state[11];
   const double *xs0 = lat + 5, *xs1 = lat + 5 + sg.m;
   double *sbar0 = latbar + 5, *sbar1 = latbar + 5 + sg.m;
   Seg prefix, total;
-  seg_prefix_total(a.segs, sg.ngroups, prefix, total);
+  seg_prefix_total(a.segs, sg.ngroups, prefix, total, sh_seg);
   double p_flex = 0.0, p_asp = 0.0;
   chunk_apply(sg, true, prefix, [&](int j) { return vjp_elem(a, nb, sg.m, sc_dot, j); },
               [&](int j, double t, double g1) {
