@@ -5,6 +5,8 @@
 // at most 256 CUs x 8 workgroups.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -31,6 +33,14 @@ static inline int nk_vec_env_int(const char* name, int dflt) {
 
 static inline int nk_grid(int64_t nvec) {
   int64_t b = (nvec + NK_VEC_THREADS - 1) / NK_VEC_THREADS;
+  if (b < 1) b = 1;
+  if (b > NK_MAX_BLOCKS) b = NK_MAX_BLOCKS;
+  return (int)b;
+}
+
+static inline int nk_grid_red(int64_t nvec) {
+  int64_t b = (nvec + 32 * NK_VEC_THREADS - 1) / (32 * NK_VEC_THREADS);
+  if (b > 512) b = std::max<int64_t>(512, (nvec + 64 * NK_VEC_THREADS - 1) / (64 * NK_VEC_THREADS));
   if (b < 1) b = 1;
   if (b > NK_MAX_BLOCKS) b = NK_MAX_BLOCKS;
   return (int)b;
@@ -170,11 +180,18 @@ static int nk_launch_map(int64_t n, const F& f, bool aligned, hipStream_t st, co
   if (n <= 0) return NK_OK;
   static const int cu_env = nk_vec_env_int("NK_VEC_CU", 0);  // developer sweep: chunk length in units of 256 vectors
   const int cu_max = cu_env > 0 ? cu_env : NkChunkUnits<F>::value;
+  // kernels with reductions pay a fixed tail per workgroup (block sums, fence, ticket, ~2 us each, a few rounds of them
+  // per CU): below ~10^8 elements that tail, not the streaming part, sets the time.  Their grid therefore gives every
+  // thread >= 32 vectors (>= 64 from 512 workgroups on) before it grows to the full 2048 -- 2^22 fp64: nk_cg_update
+  // 121 -> 51 us, nk_vdot 77 -> 22 us; 2^24: 295 -> 208 us, 109 -> 60 us; 2^30 fp32 unchanged (tools/gpu_vec_probe.py).
+  // The grid stays a function of n only, so the sums stay bit-reproducible.
   if (aligned) {
     const int64_t nvec = n / VecOf<T>::N;
-    hipLaunchKernelGGL((k_map<T, F, true>), dim3(nk_grid(nvec > 0 ? nvec : 1)), dim3(NK_VEC_THREADS), 0, st, n, f, cu_max);
+    const int grid = F::NRED > 0 ? nk_grid_red(nvec) : nk_grid(nvec > 0 ? nvec : 1);
+    hipLaunchKernelGGL((k_map<T, F, true>), dim3(grid), dim3(NK_VEC_THREADS), 0, st, n, f, cu_max);
   } else {
-    hipLaunchKernelGGL((k_map<T, F, false>), dim3(nk_grid(n)), dim3(NK_VEC_THREADS), 0, st, n, f, cu_max);
+    const int grid = F::NRED > 0 ? nk_grid_red(n) : nk_grid(n);
+    hipLaunchKernelGGL((k_map<T, F, false>), dim3(grid), dim3(NK_VEC_THREADS), 0, st, n, f, cu_max);
   }
   return nk_check_launch(what);
 }
