@@ -227,6 +227,11 @@ int nk_octant_scatter(int ndim, const int64_t* shape, const double* w8, const in
  * known from two integer square roots, accumulated in LDS -- no global atomics.  scratch: >= 16*(nb+32) doubles. */
 int nk_octant_scatter_k2(int ndim, const int64_t* shape, const double* w8, const int32_t* pidx, const int32_t* bin_k2,
                          int64_t nb, double* scratch, double* abar, void* stream);
+/* nk_segment_sum: dst[s] (+)= sum_{rowptr[s] <= i < rowptr[s+1]} src[perm[i]] -- the same scatter-add for a static index map
+ * given as a bin-sorted permutation of the source points (rowptr: int32[nseg+1], perm: int32[rowptr[nseg]]): one thread per
+ * bin, fixed summation order, no atomics.  The engine uses it for the quadrant sums of 2-D grids. */
+int nk_segment_sum(int64_t nseg, const int32_t* rowptr, const int32_t* perm, const double* src, double* dst, int accumulate,
+                   void* stream);
 /* 1 if nk_hartley_fused on this plan honours nk_fuse.w8 (the register-resident pipeline is active) */
 int nk_plan_octant_vjp(const nk_plan* plan);
 

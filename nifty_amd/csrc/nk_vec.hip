@@ -782,6 +782,33 @@ __global__ void k_octant_scatter(NkOct o, int swap_merge, const double* __restri
   }
 }
 
+// ---- segmented gather-sum: dst[s] (+)= sum of src[perm[i]] over rowptr[s] <= i < rowptr[s+1] ---------------
+// The scatter-add N -> nb of the power distributor's adjoint (distributors.py:106-127, utilities.py:222-246) turned
+// inside out for a STATIC index map: perm lists the source points bin by bin (a stable sort of the bin index, made once),
+// so every bin is summed by one thread in a fixed order -- no atomics, bit-reproducible.  Used for the quadrant sums of
+// 2-D grids (a few points per bin: 2048^2: 47 us of global fp64 atomics -> see DESIGN 3.2); on 3-D grids a bin holds
+// hundreds of points scattered over the octant and the shell-binned scatter above wins.
+__global__ void __launch_bounds__(256) k_segment_sum(int64_t nseg, const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ perm, const double* __restrict__ src,
+                                                     double* __restrict__ dst, int accumulate) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseg) return;
+  const int lo = rowptr[s], hi = rowptr[s + 1];
+  double v = 0.0;
+  for (int i = lo; i < hi; ++i) v += src[perm[i]];
+  dst[s] = accumulate ? dst[s] + v : v;
+}
+
+extern "C" int nk_segment_sum(int64_t nseg, const int32_t* rowptr, const int32_t* perm, const double* src, double* dst,
+                              int accumulate, void* stream) {
+  if (nseg < 0 || (nseg > 0 && (!rowptr || !perm || !src || !dst)))
+    return nk_set_error(NK_ERR_INVALID, "nk_segment_sum: bad argument");
+  if (nseg == 0) return NK_OK;
+  hipLaunchKernelGGL(k_segment_sum, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nseg, rowptr,
+                     perm, src, dst, accumulate);
+  return nk_check_launch("k_segment_sum");
+}
+
 extern "C" int nk_octant_expand(int ndim, const int64_t* shape, const void* table, const int32_t* pidx, void* field,
                                 int dtype, int compact, void* stream) {
   NkOct o;

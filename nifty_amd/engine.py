@@ -345,6 +345,14 @@ class FusedModel:
             # natural binning on an equal-distance grid: bins are the ascending distinct integer k^2, which lets the
             # octant sums be reduced shell by shell in LDS (nk_octant_scatter_k2) instead of with global atomics
             self.bin_k2 = None
+            # 2-D (and 1-D): the quadrant points sorted by bin, once -- every bin is then summed by one thread in a fixed
+            # order (nk_segment_sum) instead of with global fp64 atomics (NK_SEGMENT_SUM=0: atomics)
+            self.seg_perm = self.seg_rowptr = None
+            if self.octant_vjp and len(self.shape) < 3 and os.environ.get("NK_SEGMENT_SUM", "1") != "0":
+                self.seg_perm = torch.argsort(self.pidx8, stable=True).to(torch.int32)
+                counts = torch.bincount(self.pidx8.long(), minlength=self.nb)
+                self.seg_rowptr = torch.zeros(self.nb + 1, dtype=torch.int32, device=self.device)
+                self.seg_rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
             # (3-D only: on a 2-D quadrant plain atomics win, 2048^2: 49 vs 78 us, 4096^2: 184 vs 318 us --
             # tools/gpu_scatter2d_probe.py)
             if self.octant_vjp and len(self.shape) == 3 and ps._data.get("k2table") is not None and max(self.shape) >= 64:
@@ -459,6 +467,9 @@ class FusedModel:
                 L.check(L.load().nk_octant_scatter_k2(len(self.shape), shp, self.w8.data_ptr(), self.pidx.data_ptr(),
                                                       self.bin_k2.data_ptr(), self.nb, self.scatter_scratch.data_ptr(),
                                                       self.abar.data_ptr(), B._stream()), "nk_octant_scatter_k2")
+            elif self.seg_perm is not None:
+                L.check(L.load().nk_segment_sum(self.nb, self.seg_rowptr.data_ptr(), self.seg_perm.data_ptr(),
+                                                self.w8.data_ptr(), self.abar.data_ptr(), 0, B._stream()), "nk_segment_sum")
             else:
                 self.abar.zero_()
                 L.check(L.load().nk_octant_scatter(len(self.shape), shp, self.w8.data_ptr(), self.pidx.data_ptr(),

@@ -283,3 +283,32 @@ def test_sandwich_full_size_properties(shape, dtype):
     sy = sandwich(y, mid)
     b = B.vdot(x.reshape(-1), sy.reshape(-1)).item()
     assert abs(a - b) < tol * (abs(a) + abs(b) + n ** 0.5)
+
+
+@pytest.mark.parametrize("n,nb", [(1, 1), (1000, 37), (1025 * 1025, 313847), (300000, 5)])
+def test_segment_sum_equals_bincount(n, nb):
+    """nk_segment_sum over the bin-sorted permutation == np.bincount(pindex, weights) (distributors.py:106-127 adjoint)."""
+    from nifty_amd import _lib as L
+    from nifty_amd import backend as B
+
+    rng = np.random.default_rng(n + nb)
+    pidx = rng.integers(0, nb, size=n).astype(np.int32)
+    if nb > 2:
+        pidx[pidx == 1] = 0  # an empty bin
+    w = rng.normal(size=n)
+    ref = np.bincount(pidx, weights=w, minlength=nb)
+    perm = np.argsort(pidx, kind="stable").astype(np.int32)
+    rowptr = np.zeros(nb + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(np.bincount(pidx, minlength=nb))
+    dev = torch.device("cuda:0")
+    wd, pd, rd = torch.from_numpy(w).to(dev), torch.from_numpy(perm).to(dev), torch.from_numpy(rowptr).to(dev)
+    out = torch.full((nb,), 7.0, dtype=torch.float64, device=dev)
+    L.check(L.load().nk_segment_sum(nb, rd.data_ptr(), pd.data_ptr(), wd.data_ptr(), out.data_ptr(), 0, B._stream()))
+    got = out.cpu().numpy()
+    assert np.allclose(got, ref, rtol=1e-13, atol=1e-13 * np.abs(w).sum() / max(nb, 1))
+    L.check(L.load().nk_segment_sum(nb, rd.data_ptr(), pd.data_ptr(), wd.data_ptr(), out.data_ptr(), 1, B._stream()))
+    assert np.allclose(out.cpu().numpy(), 2 * got, rtol=1e-15, atol=0)
+    # same bits on a second launch (fixed summation order)
+    out2 = torch.empty_like(out)
+    L.check(L.load().nk_segment_sum(nb, rd.data_ptr(), pd.data_ptr(), wd.data_ptr(), out2.data_ptr(), 0, B._stream()))
+    assert np.array_equal(out2.cpu().numpy(), got)
