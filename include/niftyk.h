@@ -97,8 +97,8 @@ typedef struct nk_fuse {
                            value, so the prologue of the first pass and the VJP epilogue read 1/8 of the bytes.  Only
                            valid when nk_plan_octant_vjp(plan) != 0 and with prologue PLAIN / MUL / AMP(afield) /
                            AMP_JVP(afield + dafield) and, for the VJP epilogue, afield set (NK_ERR_INVALID otherwise) */
-  int value_slots;      /* leave 0.  Set by the library itself when it spreads the per-workgroup atomics on *value over
-                           several accumulators in the workspace (folded into *value after the pass) */
+  int value_slots;      /* leave 0.  Set by the library itself when it gives every workgroup of the final pass its own
+                           accumulator in the workspace (folded into *value in a fixed order after the pass) */
   const int32_t* pidx_octant; /* optional, nk_hartley_sandwich with field_octant and the AMP_JVP prologue: the bin index of
                            the OCTANT points [A/2+1][M/2+1][NL/2+1]; with it (and dampT) the prologue gathers da from the
                            table itself and `dafield` is not needed -- no per-application expansion of da[pidx] */
@@ -224,7 +224,9 @@ int nk_octant_scatter(int ndim, const int64_t* shape, const double* w8, const in
 /* nk_octant_scatter for NATURAL binning on a grid with equal harmonic distances on all axes (bins = the distinct integer
  * k^2 = a^2+b^2+c^2 in ascending order; bin_k2[nb] = k^2 of every bin): abar[.] = sum over the octant array, OVERWRITING
  * abar.  Shell-binned: blocks of consecutive bins are spherical shells whose cut with every octant line is a c-range
- * known from two integer square roots, accumulated in LDS -- no global atomics.  scratch: >= 16*(nb+32) doubles. */
+ * known from two integer square roots, accumulated in LDS -- no global atomics.  scratch: >= 64*(nb+32) doubles.
+ * NK_DETERMINISTIC=1 (environment, read once): a variant whose bin sums are built in a fixed order -- bit-reproducible, 2.9 ms
+ * instead of 0.85 ms at 1024^3 (the default's LDS atomics differ in the last bit from run to run). */
 int nk_octant_scatter_k2(int ndim, const int64_t* shape, const double* w8, const int32_t* pidx, const int32_t* bin_k2,
                          int64_t nb, double* scratch, double* abar, void* stream);
 /* nk_segment_sum: dst[s] (+)= sum_{rowptr[s] <= i < rowptr[s+1]} src[perm[i]] -- the same scatter-add for a static index map

@@ -65,6 +65,35 @@ __device__ __forceinline__ double block_sum(double v, double* sh /*[AMP_WAVES]*/
   return s;
 }
 
+// DETERMINISTIC cross-workgroup sums of the amplitude scalars (S, dS, the VJP reductions): every workgroup stores its
+// partial(s); the workgroup that takes the last ticket adds them in block order with the fixed tree of block_sum and
+// STORES the result -- the same bits on every run (until round 2: one fp64 atomic per workgroup, order-dependent in the
+// last bit, and every later kernel of the step inherits S).  One launch at a time per device (one stream), like the
+// reductions of nk_vec.hip; the ticket is left at zero.
+__device__ unsigned int g_amp_ticket = 0;
+template <int NV>
+__device__ __forceinline__ void amp_store_sums(const double (&v)[NV] /* valid in thread 0 */, double* part,
+                                               double* const (&dst)[NV], double* sh /*[AMP_WAVES]*/) {
+  __shared__ bool is_last;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) part[k * gridDim.x + blockIdx.x] = v[k];
+    __threadfence();
+    is_last = atomicAdd(&g_amp_ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double x = 0.0;
+    for (int g = threadIdx.x; g < (int)gridDim.x; g += AMP_THREADS) x += __builtin_nontemporal_load(&part[k * gridDim.x + g]);
+    const double t = block_sum(x, sh);
+    if (threadIdx.x == 0) *dst[k] = t;
+  }
+  if (threadIdx.x == 0) g_amp_ticket = 0;
+}
+
 // geo layout: rel[nb] | sc[nb] | mult[nb] | delta[nb]
 // hyp layout: lm_fluct, ls_fluct, lm_flex, ls_flex, lm_asp, ls_asp, lm_zm, ls_zm, slope_mean, slope_sigma, V
 // lat layout: xi_asp, xi_flex, xi_fluct, xi_slope, xi_zm, spectrum[2][nb-2]
@@ -175,7 +204,7 @@ __device__ __forceinline__ void seg_prefix_total(const double* __restrict__ segs
 
 struct AmpPtrs {
   const double *rel, *sc, *mult, *delta;
-  double *spec, *ahat, *tmp, *segs;
+  double *spec, *ahat, *tmp, *segs, *part;
 };
 __device__ __forceinline__ AmpPtrs amp_ptrs(int nb, const double* geo, double* state) {
   AmpPtrs a;
@@ -186,7 +215,9 @@ __device__ __forceinline__ AmpPtrs amp_ptrs(int nb, const double* geo, double* s
   a.spec = state + 16;
   a.ahat = a.spec + nb;
   a.tmp = a.ahat + nb;
-  a.segs = state + 16 + 4 * (size_t)nb;  // 3 * MAXG doubles
+  a.segs = state + 16 + 4 * (size_t)nb;  // 3 doubles per scan workgroup (<= (nb - 2) / 1024 + 1, <= MAXG)
+  int ng = (nb + 1023) / 1024 + 1;
+  a.part = a.segs + 3 * (ng > MAXG ? MAXG : ng);  // 2 doubles per workgroup of the reducing launch (<= nb / 256 + 1, <= MAXG)
   return a;
 }
 
@@ -238,10 +269,11 @@ __global__ void __launch_bounds__(AMP_THREADS) k_fwd_apply(int nb, ScanGeom sg, 
   chunk_apply(sg, false, prefix, [&](int j) { return fwd_elem(a, h, xs0, xs1, j); },
               [&](int j, double, double s) { bin(j + 2, s); }, sh_seg);
   const double S = block_sum(part, sh_d);
-  if (threadIdx.x == 0) {
-    atomicAdd(state + 5, S);
-    if (blockIdx.x == 0) state[6] = last;
-  }
+  if (threadIdx.x == 0 && blockIdx.x == 0) state[6] = last;
+  __syncthreads();
+  const double v[1] = {S};
+  double* const dst[1] = {state + 5};
+  amp_store_sums<1>(v, a.part, dst, sh_d);
 }
 
 __global__ void k_fwd_final(int nb, const double* __restrict__ hyp, double* __restrict__ state, double* __restrict__ amp) {
@@ -308,7 +340,10 @@ __global__ void __launch_bounds__(AMP_THREADS) k_jvp_apply(int nb, ScanGeom sg, 
               [&](int j) { return jvp_elem(a, q, lat + 5, lat + 5 + sg.m, dlat + 5, dlat + 5 + sg.m, j); },
               [&](int j, double, double s) { bin(j + 2, s); }, sh_seg);
   const double dS = block_sum(part, sh_d);
-  if (threadIdx.x == 0) atomicAdd(state + 7, dS);
+  __syncthreads();
+  const double v[1] = {dS};
+  double* const dst[1] = {state + 7};
+  amp_store_sums<1>(v, a.part, dst, sh_d);
 }
 
 __global__ void k_jvp_final(int nb, const double* __restrict__ hyp, const double* __restrict__ state,
@@ -336,10 +371,10 @@ __global__ void __launch_bounds__(AMP_THREADS) k_vjp_red1(int nb, const double* 
   }
   const double s1 = block_sum(p_fl, sh_d);
   const double s2 = block_sum(p_q, sh_d);
-  if (threadIdx.x == 0) {
-    atomicAdd(state + 8, V * s1);
-    atomicAdd(state + 9, s2);
-  }
+  __syncthreads();
+  const double v[2] = {V * s1, s2};
+  double* const dst[2] = {state + 8, state + 9};
+  amp_store_sums<2>(v, amp_ptrs(nb, nullptr, state).part, dst, sh_d);
 }
 
 __global__ void __launch_bounds__(AMP_THREADS) k_vjp_red2(int nb, const double* __restrict__ geo, const double* __restrict__ hyp,
@@ -357,10 +392,10 @@ __global__ void __launch_bounds__(AMP_THREADS) k_vjp_red2(int nb, const double* 
   }
   const double s1 = block_sum(p_sl, sh_d);
   const double s2 = block_sum(p_sc, sh_d);
-  if (threadIdx.x == 0) {
-    atomicAdd(state + 10, s1);
-    atomicAdd(state + 11, s2);
-  }
+  __syncthreads();
+  const double v[2] = {s1, s2};
+  double* const dst[2] = {state + 10, state + 11};
+  amp_store_sums<2>(v, a.part, dst, sh_d);
 }
 
 __device__ __forceinline__ Seg vjp_elem(const AmpPtrs& a, int nb, int m, double sc_dot, int j) {
@@ -406,10 +441,10 @@ __global__ void __launch_bounds__(AMP_THREADS) k_vjp_apply(int nb, ScanGeom sg, 
               sh_seg);
   const double s1 = block_sum(p_flex, sh_d);
   const double s2 = block_sum(p_asp, sh_d);
-  if (threadIdx.x == 0) {
-    atomicAdd(state + 12, s1);
-    atomicAdd(state + 13, s2);
-  }
+  __syncthreads();
+  const double v[2] = {s1, s2};
+  double* const dst[2] = {state + 12, state + 13};
+  amp_store_sums<2>(v, a.part, dst, sh_d);
 }
 
 __global__ void k_vjp_final(const double* __restrict__ hyp, const double* __restrict__ state, const double* __restrict__ abar,

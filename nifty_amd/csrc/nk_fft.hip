@@ -2,6 +2,8 @@
 // See nk_fft_phases.h for the algorithm; nk_core.h for the LDS line FFT and fused prologue/epilogue.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -119,8 +121,12 @@ __device__ __forceinline__ void nk_flush_energy(const NkFuse& f, double acc, voi
     double s = 0.0;
     const int nw = (blockDim.x + 63) >> 6;
     for (int w = 0; w < nw; ++w) s += red[w];
-    // one address would serialise ~1e5 workgroup atomics (~1 ms at 1024^3): spread over the slots the driver provides
-    atomicAdd(f.value + (f.value_slots > 1 ? (int)(blockIdx.x & (unsigned)(f.value_slots - 1)) : 0), s);
+    // one slot per workgroup (set up by the library, folded in a fixed order afterwards: bit-reproducible sums, no
+    // atomics); without slots -- the generic kernels -- one atomic per workgroup on *value
+    if (f.value_slots > 0 && blockIdx.x < (unsigned)f.value_slots)
+      f.value[blockIdx.x] = s;
+    else
+      atomicAdd(f.value, s);
   }
 }
 
@@ -755,19 +761,49 @@ static bool nk_plan_uses_pipeline2(const nk_plan* P) {
   return first_ok && mid_ok;
 }
 
-#define NK_VALUE_SLOTS 256
-__global__ void k_fold_slots(double* __restrict__ slots, double* __restrict__ value) {
-  __shared__ double red[NK_VALUE_SLOTS / 64];
-  double v = slots[threadIdx.x];
-  slots[threadIdx.x] = 0.0;
+// energy / curvature sums of the final pass: ONE slot per workgroup at the end of the workspace, zeroed before the
+// launch, then folded in a fixed order (k_fold_slots_a: 256 workgroups over contiguous ranges; k_fold_slots_b: their
+// partials, fixed tree) -- the same bits on every run.  (Until round 2: atomics on 256 slots, order-dependent in the last
+// bit, which the energy-based stopping rules turned into different iteration counts from run to run.)
+#define NK_FOLD_BLOCKS 256
+static inline int64_t nk_value_slot_count(const NkHostPlan& hp) {
+  const int64_t lines = (int64_t)hp.g.batch * hp.g.na * hp.g.nm;  // every final-pass workgroup owns >= 1 line
+  const int64_t n = lines > NK_FOLD_BLOCKS ? lines : NK_FOLD_BLOCKS;
+  return (n + 255) / 256 * 256;
+}
+__device__ __forceinline__ double nk_fold_block_sum(double v, double* red) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int w = 0; w < NK_VALUE_SLOTS / 64; ++w) s += red[w];
-    atomicAdd(value, s);
-  }
+  double s = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+  return s;
+}
+__global__ void __launch_bounds__(256) k_fold_slots_a(const double* __restrict__ slots, int64_t n, double* __restrict__ part) {
+  __shared__ double red[4];
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double v = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) v += slots[i];
+  const double s = nk_fold_block_sum(v, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(NK_FOLD_BLOCKS) k_fold_slots_b(const double* __restrict__ part, double* __restrict__ value) {
+  __shared__ double red[NK_FOLD_BLOCKS / 64];
+  const double s = nk_fold_block_sum(part[threadIdx.x], red);
+  if (threadIdx.x == 0) *value += s;
+}
+// the slot area of a workspace: [slots: nk_value_slot_count][partials: NK_FOLD_BLOCKS]
+static inline double* nk_value_slots(const NkHostPlan& hp, void* workspace) {
+  return (double*)((char*)workspace + (hp.work_bytes + 255) / 256 * 256 + (hp.scratch_bytes + 255) / 256 * 256 + 256);
+}
+static int nk_fold_value_slots(const NkHostPlan& hp, double* slots, double* value, hipStream_t st) {
+  const int64_t n = nk_value_slot_count(hp);
+  double* part = slots + n;
+  hipLaunchKernelGGL(k_fold_slots_a, dim3(NK_FOLD_BLOCKS), dim3(256), 0, st, slots, n, part);
+  hipLaunchKernelGGL(k_fold_slots_b, dim3(1), dim3(NK_FOLD_BLOCKS), 0, st, part, value);
+  return nk_check_launch("k_fold_slots");
 }
 
 extern "C" int nk_plan_octant_vjp(const nk_plan* P) { return P && nk_plan_uses_pipeline2(P) ? 1 : 0; }
@@ -776,7 +812,7 @@ extern "C" size_t nk_plan_workspace_bytes(const nk_plan* P) {
   if (!P) return 0;
   // [work | scratch], scratch aligned to 256 B
   size_t w = (P->hp.work_bytes + 255) / 256 * 256;
-  return w + (P->hp.scratch_bytes + 255) / 256 * 256 + 256 + NK_VALUE_SLOTS * sizeof(double);
+  return w + (P->hp.scratch_bytes + 255) / 256 * 256 + 256 + (nk_value_slot_count(P->hp) + NK_FOLD_BLOCKS) * sizeof(double);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -838,19 +874,18 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
     ProfScope ps(st, 3, f.pro, f.epi);
     static const int skip_final = nk_env_int("NK_SKIP_FINAL", 0);  // debugging aid
     if (skip_final) return NK_OK;
-    static const int use_slots = nk_env_int("NK_VALUE_SLOTS", 1);  // 0: all workgroups add to *value directly
+    static const int use_slots = nk_env_int("NK_VALUE_SLOTS", 1);  // 0: one atomic per workgroup on *value
     if (use_slots && f.value && (f.epi == NK_EPI_LIKELIHOOD || f.epi == NK_EPI_VJP)) {
-      // energy / curvature sums: per-workgroup atomics go to NK_VALUE_SLOTS accumulators at the end of the workspace
-      double* slots = (double*)((char*)workspace + (hp.work_bytes + 255) / 256 * 256 + (hp.scratch_bytes + 255) / 256 * 256 + 256);
-      hipError_t e = hipMemsetAsync(slots, 0, NK_VALUE_SLOTS * sizeof(double), st);
+      // energy / curvature sums: one slot per workgroup at the end of the workspace, folded in a fixed order
+      double* slots = nk_value_slots(hp, workspace);
+      hipError_t e = hipMemsetAsync(slots, 0, nk_value_slot_count(hp) * sizeof(double), st);
       if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(value slots)");
       NkFuse f2 = f;
       f2.value = slots;
-      f2.value_slots = NK_VALUE_SLOTS;
+      f2.value_slots = (int)std::min<int64_t>(nk_value_slot_count(hp), 0x7fffffff);
       rc = nk_dispatch_final<T>(hp.g.nl, pf, f2, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
       if (rc != NK_OK) return rc;
-      hipLaunchKernelGGL(k_fold_slots, dim3(1), dim3(NK_VALUE_SLOTS), 0, st, slots, f.value);
-      return nk_check_launch("k_fold_slots");
+      return nk_fold_value_slots(hp, slots, f.value, st);
     }
     return nk_dispatch_final<T>(hp.g.nl, pf, f, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
   }
@@ -975,16 +1010,15 @@ static int nk_run_sandwich(const nk_plan* P, const NkFuse& f, double scale_first
   ProfScope ps(st, 3, f.pro, f.epi);
   static const int use_slots = nk_env_int("NK_VALUE_SLOTS", 1);
   if (use_slots && f.value && (f.epi == NK_EPI_LIKELIHOOD || f.epi == NK_EPI_VJP)) {
-    double* slots = (double*)((char*)workspace + (hp.work_bytes + 255) / 256 * 256 + (hp.scratch_bytes + 255) / 256 * 256 + 256);
-    hipError_t e = hipMemsetAsync(slots, 0, NK_VALUE_SLOTS * sizeof(double), st);
+    double* slots = nk_value_slots(hp, workspace);
+    hipError_t e = hipMemsetAsync(slots, 0, nk_value_slot_count(hp) * sizeof(double), st);
     if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(value slots)");
     NkFuse f2 = f;
     f2.value = slots;
-    f2.value_slots = NK_VALUE_SLOTS;
+    f2.value_slots = (int)std::min<int64_t>(nk_value_slot_count(hp), 0x7fffffff);
     rc = nk_dispatch_final3<T>(hp.g.nl, q.pf, f2, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
     if (rc != NK_OK) return rc;
-    hipLaunchKernelGGL(k_fold_slots, dim3(1), dim3(NK_VALUE_SLOTS), 0, st, slots, f.value);
-    return nk_check_launch("k_fold_slots");
+    return nk_fold_value_slots(hp, slots, f.value, st);
   }
   return nk_dispatch_final3<T>(hp.g.nl, q.pf, f, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
 }

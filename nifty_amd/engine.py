@@ -313,7 +313,7 @@ class FusedModel:
             # VJP scatter accumulators: one private copy per XCD (L2-scope atomics), folded into self.abar
             self.abar_stride = (nb + 31) // 32 * 32
             self.abar_copies = 8
-            self.scatter_scratch = torch.empty(16 * (nb + 32), dtype=torch.float64, device=self.device)
+            self.scatter_scratch = torch.empty(64 * (nb + 32), dtype=torch.float64, device=self.device)
             self.abar_priv = torch.zeros(self.abar_copies * self.abar_stride, dtype=torch.float64, device=self.device)
             self.abar = torch.zeros(nb, dtype=torch.float64, device=self.device)
             self.damp = torch.empty(nb, dtype=torch.float64, device=self.device)
