@@ -225,7 +225,7 @@ int nk_octant_scatter(int ndim, const int64_t* shape, const double* w8, const in
  * k^2 = a^2+b^2+c^2 in ascending order; bin_k2[nb] = k^2 of every bin): abar[.] = sum over the octant array, OVERWRITING
  * abar.  Shell-binned: blocks of consecutive bins are spherical shells whose cut with every octant line is a c-range
  * known from two integer square roots, accumulated in LDS -- no global atomics.  scratch: >= 64*(nb+32) doubles.
- * NK_DETERMINISTIC=1 (environment, read once): a variant whose bin sums are built in a fixed order -- bit-reproducible, 2.9 ms
+ * NK_DETERMINISTIC=1 (environment, read once): a variant whose bin sums are built in a fixed order -- bit-reproducible, 2.5 ms
  * instead of 0.85 ms at 1024^3 (the default's LDS atomics differ in the last bit from run to run). */
 int nk_octant_scatter_k2(int ndim, const int64_t* shape, const double* w8, const int32_t* pidx, const int32_t* bin_k2,
                          int64_t nb, double* scratch, double* abar, void* stream);

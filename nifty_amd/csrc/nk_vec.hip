@@ -920,7 +920,7 @@ __global__ void __launch_bounds__(256)
 
 
 // DETERMINISTIC variant (NK_DETERMINISTIC=1): ONE wavefront per workgroup with its own LDS copy of the shell's bins; its
-// four 16-lane groups add in turn (program order; the 16 lanes of a group sit on one line at distinct c, i.e. distinct
+// groups of NK_DET_GW lanes add in turn (program order; the lanes of a group sit on one line at distinct c, i.e. distinct
 // k^2 = distinct bins; LDS operations of one wavefront execute in order), so every partial[split][bin] is built in a
 // fixed order and the fold over the splits is fixed too: the same bits on every run.  (The default kernel above lets
 // the 16 groups of four wavefronts add concurrently with LDS atomics: last-bit differences from run to run, which the
@@ -930,6 +930,9 @@ __global__ void __launch_bounds__(256)
 #endif
 #ifndef NK_DET_NU
 #define NK_DET_NU 8
+#endif
+#ifndef NK_DET_GW
+#define NK_DET_GW 8
 #endif
 #ifndef NK_DET_SPLITS
 #define NK_DET_SPLITS 32
@@ -946,8 +949,8 @@ __global__ void __launch_bounds__(64)
   const int klo = bin_k2[bin0];
   const int khi = bin0 + NK_DET_BINS < nb ? bin_k2[bin0 + NK_DET_BINS] : 0x7fffffff;
   const int hc2 = (o.Ch - 1) * (o.Ch - 1);
-  constexpr int NG = 4, NU = NK_DET_NU;
-  const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+  constexpr int GW = NK_DET_GW, NG = 64 / GW, NU = NK_DET_NU;  // GW lanes per line, NG lines per instruction
+  const int grp = threadIdx.x / GW, l16 = threadIdx.x % GW;
   const bool last = khi == 0x7fffffff;
   for (int a = s; a < o.Ah; a += NK_DET_SPLITS) {
     const int ra = a * a;
@@ -975,11 +978,11 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
           for (int u = 0; u < NU; ++u)
             if (cc[u] < ce[u]) atomicAdd(&acc[pb[u] - bin0], v[u]);  // in order per wavefront; nobody else adds here
-          // rare: runs longer than 16 points
+          // runs longer than the group width
 #pragma unroll
           for (int u = 0; u < NU; ++u) {
             const int b = b0 + u * NG;
-            for (int c = cc[u] + 16; c < ce[u]; c += 16)
+            for (int c = cc[u] + GW; c < ce[u]; c += GW)
               atomicAdd(&acc[pidx[((int64_t)a * o.M + b) * o.NL + c] - bin0], w8[((int64_t)a * o.Mh + b) * o.Ch + c]);
           }
         }
