@@ -338,9 +338,24 @@ struct FGather {
   template <int V>
   __device__ __forceinline__ void run(int64_t i, double*) const {
     T r[V];
+    int32_t p[V];
+    if constexpr (V == 4) {  // the streamed operands as one 16-byte access each, past the cache the table lives in
+      typedef int32_t i4 __attribute__((ext_vector_type(4)));
+      const i4 pv = __builtin_nontemporal_load(reinterpret_cast<const i4*>(pidx + i));
+      p[0] = pv.x, p[1] = pv.y, p[2] = pv.z, p[3] = pv.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < V; ++k) r[k] = table[pidx[i + k]];
-    nk_st<T, V>(out, i, r);
+      for (int k = 0; k < V; ++k) p[k] = pidx[i + k];
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) r[k] = table[p[k]];
+    if constexpr (V == 4 && sizeof(T) == 4) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4 o = {(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+      __builtin_nontemporal_store(o, reinterpret_cast<f4*>(out + i));
+    } else {
+      nk_st<T, V>(out, i, r);
+    }
   }
 };
 
@@ -558,7 +573,7 @@ extern "C" int nk_gather(int64_t n, const void* table, const int32_t* pidx, void
   if (n < 0 || !table || !pidx || !out) return nk_set_error(NK_ERR_INVALID, "nk_gather: bad argument");
   NK_DISPATCH_DTYPE(dtype, {
     FGather<T> f{(const T*)table, pidx, (T*)out, nullptr};
-    return nk_launch_map<T>(n, f, nk_aligned16(out), (hipStream_t)stream, "nk_gather");
+    return nk_launch_map<T>(n, f, nk_aligned16(out) && nk_aligned16(pidx), (hipStream_t)stream, "nk_gather");
   })
 }
 
