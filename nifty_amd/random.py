@@ -78,7 +78,7 @@ class Random:
 
         dtype = np.dtype(dtype)
         n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
-        if config.get("sampling_rng") == "numpy_host" or n < DEVICE_DRAW_MIN:
+        if config.get("sampling_rng") == "numpy_host" or n < DEVICE_DRAW_MIN or torch.device(device).type != "cuda":
             return _as_tensor(Random.normal(dtype, shape, mean, std), device)
         if not (np.issubdtype(dtype, np.floating) or np.issubdtype(dtype, np.complexfloating)):
             raise TypeError("dtype must be float or complex")

@@ -132,6 +132,11 @@ def test_small_and_host_forced_draws_take_the_host_path():
     with random.Context(11):
         b = random.Random.normal(np.float64, (100,))
     assert np.array_equal(a.numpy(), b)
+    with random.Context(13):  # a host target never reaches the device kernel, whatever the size
+        a = random.Random.normal_on_device(np.float64, (1 << 16,), 0.0, 1.0, torch.device("cpu"))
+    with random.Context(13):
+        b = random.Random.normal(np.float64, (1 << 16,))
+    assert np.array_equal(a.numpy(), b)
     config.update("sampling_rng", "numpy_host")
     try:
         with random.Context(12):
