@@ -347,7 +347,20 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(counts, shape, device=device)
             except Exception as exc:  # the baseline must never take the bench line down
                 line["cpu_baseline"] = {"error": repr(exc)}
-        print(json.dumps(line))
+    else:
+        line = None
+    # RCCL writes a version banner to the C-level stdout of a rank when its first communicator is created; through a pipe
+    # that text sits in the C buffer until the process exits -- AFTER the JSON line.  Every rank empties its C buffers
+    # first, then rank 0 prints the one line, so the line is the last thing on stdout.
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if comm is not None:
+        comm.barrier()
+    if line is not None:
+        print(json.dumps(line), flush=True)
     if comm is not None:
         comm.barrier()
 
