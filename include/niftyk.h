@@ -108,6 +108,9 @@ typedef struct nk_fuse {
                            + cg_r[i] is WRITTEN BACK to `in` (not const here) and the new value enters the transform */
   const double* cg_scal; /* the device scalars of nk_cg_update; roll them afterwards with
                            nk_cg_direction(0, NULL, NULL, dtype, scal, 1, stream) */
+  double* w8max;        /* optional, with w8: device scalar <- max |w8[x]| of this launch (fixed-order maximum over the
+                           workgroups).  nk_octant_scatter_k2 takes it as the scale of its fixed-point accumulation, which
+                           makes the bin sums independent of the order of the additions (bit-reproducible) */
 } nk_fuse;
 
 typedef struct nk_plan nk_plan;
@@ -225,10 +228,12 @@ int nk_octant_scatter(int ndim, const int64_t* shape, const double* w8, const in
  * k^2 = a^2+b^2+c^2 in ascending order; bin_k2[nb] = k^2 of every bin): abar[.] = sum over the octant array, OVERWRITING
  * abar.  Shell-binned: blocks of consecutive bins are spherical shells whose cut with every octant line is a c-range
  * known from two integer square roots, accumulated in LDS -- no global atomics.  scratch: >= 64*(nb+32) doubles.
- * NK_DETERMINISTIC=1 (environment, read once): a variant whose bin sums are built in a fixed order -- bit-reproducible, 2.5 ms
- * instead of 0.85 ms at 1024^3 (the default's LDS atomics differ in the last bit from run to run). */
+ * w8max (device scalar, optional): max |w8| as produced by nk_fuse.w8max.  With it the contributions are accumulated in
+ * 64-bit FIXED POINT (quantum 2^(e-44), 2^e >= *w8max): integer additions commute, so the bin sums are the same bits on
+ * every run at the speed of the atomics; rounding <= 2.8e-14 * max |w8| per point.  NULL: floating-point LDS atomics (sums
+ * differ in the last bit from run to run).  NK_SCATTER_FP_ATOMICS=1 (environment) forces the latter. */
 int nk_octant_scatter_k2(int ndim, const int64_t* shape, const double* w8, const int32_t* pidx, const int32_t* bin_k2,
-                         int64_t nb, double* scratch, double* abar, void* stream);
+                         int64_t nb, double* scratch, double* abar, const double* w8max, void* stream);
 /* nk_segment_sum: dst[s] (+)= sum_{rowptr[s] <= i < rowptr[s+1]} src[perm[i]] -- the same scatter-add for a static index map
  * given as a bin-sorted permutation of the source points (rowptr: int32[nseg+1], perm: int32[rowptr[nseg]]): one thread per
  * bin, fixed summation order, no atomics.  The engine uses it for the quadrant sums of 2-D grids. */

@@ -30,7 +30,7 @@ class Fuse(ctypes.Structure):
         ("xi", _vp), ("addend", _vp), ("addend_scale", _d), ("accumulate", _i), ("abar", _vp), ("lh_kind", _i), ("nonlin", _i), ("data", _vp),
         ("icov", _vp), ("icov_scalar", _d), ("out2", _vp), ("value", _vp),
         ("afield", _vp), ("dampT", _vp), ("abar_copies", _i), ("abar_stride", _i64), ("dafield", _vp), ("w8", _vp),
-        ("field_octant", _i), ("value_slots", _i), ("pidx_octant", _vp), ("cg_r", _vp), ("cg_scal", _vp),
+        ("field_octant", _i), ("value_slots", _i), ("pidx_octant", _vp), ("cg_r", _vp), ("cg_scal", _vp), ("w8max", _vp),
     ]
 
 
@@ -59,7 +59,7 @@ SIGNATURES = {
     "nk_octant_expand": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _vp, _i, _i, _vp]),
     "nk_octant_scatter": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _vp, _i, _vp]),
     "nk_segment_sum": (_i, [_i64, _vp, _vp, _vp, _vp, _i, _vp]),
-    "nk_octant_scatter_k2": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "nk_octant_scatter_k2": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "nk_plan_octant_vjp": (_i, [_vp]),
     "nk_fold_copies": (_i, [_i64, _i, _i64, _vp, _vp, _vp]),
     "nk_cumsum": (_i, [_i64, _vp, _vp, _i, _i, _vp]),

@@ -130,6 +130,23 @@ __device__ __forceinline__ void nk_flush_energy(const NkFuse& f, double acc, voi
   }
 }
 
+// workgroup maximum of |w8| (octant sums of the VJP epilogue) -> this workgroup's slot; folded by the library afterwards
+__device__ __forceinline__ void nk_flush_wmax(const NkFuse& f, double wmax, void* lds_raw) {
+  if (f.w8max == nullptr || f.w8 == nullptr || f.epi != NK_EPI_VJP) return;
+  __syncthreads();
+  double* red = (double*)lds_raw;
+  for (int off = 32; off > 0; off >>= 1) wmax = fmax(wmax, __shfl_down(wmax, off, 64));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = wmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = 0.0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) m = fmax(m, red[w]);
+    if (f.value_slots > 0 && blockIdx.x < (unsigned)f.value_slots) f.w8max[blockIdx.x] = m;
+  }
+}
+
 // generic LDS kernels: any thread count works (loops stride by blockDim.x).  fp64 is capped at 512 threads so that the
 // compiler may use 256 VGPRs -- with the default 1024-thread bound (128 VGPRs) every fp64 kernel spilled 52-68 B / lane
 template <typename T>
@@ -244,10 +261,12 @@ __global__ void __launch_bounds__((FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREAD
     k2_final(NkPassF p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, int xmap) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, SchedF<T, NL>::E> ex;
-  double acc = 0.0;
+  double acc = 0.0, wmax = 0.0;
   const int64_t blk = xmap ? nk_xcd_contig(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
-  nk_final_body<T, NL, FinalTile<T, NL, EC, COUPLES ? 2 : 1>::TILE, COUPLES, EC, PAIR>(ex, p, f, blk, (T*)smem, tw, work, &acc);
+  nk_final_body<T, NL, FinalTile<T, NL, EC, COUPLES ? 2 : 1>::TILE, COUPLES, EC, PAIR>(ex, p, f, blk, (T*)smem, tw, work, &acc,
+                                                                                      (EC == 2 || EC == -1) ? &wmax : nullptr);
   nk_flush_energy(f, acc, smem);
+  if constexpr (EC == 2 || EC == -1) nk_flush_wmax(f, wmax, smem);
 }
 
 template <typename T, int NL, bool COUPLES, int EC, int PAIR = 0>
@@ -780,6 +799,29 @@ __device__ __forceinline__ double nk_fold_block_sum(double v, double* red) {
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
   return s;
 }
+__device__ __forceinline__ double nk_fold_block_max(double v, double* red) {
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s = fmax(s, red[w]);
+  return s;
+}
+__global__ void __launch_bounds__(256) k_fold_max_a(const double* __restrict__ slots, int64_t n, double* __restrict__ part) {
+  __shared__ double red[4];
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double v = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) v = fmax(v, slots[i]);
+  const double s = nk_fold_block_max(v, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(NK_FOLD_BLOCKS) k_fold_max_b(const double* __restrict__ part, double* __restrict__ value) {
+  __shared__ double red[NK_FOLD_BLOCKS / 64];
+  const double s = nk_fold_block_max(part[threadIdx.x], red);
+  if (threadIdx.x == 0) *value = s;
+}
 __global__ void __launch_bounds__(256) k_fold_slots_a(const double* __restrict__ slots, int64_t n, double* __restrict__ part) {
   __shared__ double red[4];
   const int64_t per = (n + gridDim.x - 1) / gridDim.x;
@@ -794,9 +836,12 @@ __global__ void __launch_bounds__(NK_FOLD_BLOCKS) k_fold_slots_b(const double* _
   const double s = nk_fold_block_sum(part[threadIdx.x], red);
   if (threadIdx.x == 0) *value += s;
 }
-// the slot area of a workspace: [slots: nk_value_slot_count][partials: NK_FOLD_BLOCKS]
+// the slot area of a workspace: [value slots: nk_value_slot_count][partials: NK_FOLD_BLOCKS][|w8| slots][partials]
 static inline double* nk_value_slots(const NkHostPlan& hp, void* workspace) {
   return (double*)((char*)workspace + (hp.work_bytes + 255) / 256 * 256 + (hp.scratch_bytes + 255) / 256 * 256 + 256);
+}
+static inline double* nk_wmax_slots(const NkHostPlan& hp, void* workspace) {
+  return nk_value_slots(hp, workspace) + nk_value_slot_count(hp) + NK_FOLD_BLOCKS;
 }
 static int nk_fold_value_slots(const NkHostPlan& hp, double* slots, double* value, hipStream_t st) {
   const int64_t n = nk_value_slot_count(hp);
@@ -805,6 +850,50 @@ static int nk_fold_value_slots(const NkHostPlan& hp, double* slots, double* valu
   hipLaunchKernelGGL(k_fold_slots_b, dim3(1), dim3(NK_FOLD_BLOCKS), 0, st, part, value);
   return nk_check_launch("k_fold_slots");
 }
+// final-pass launch with the per-workgroup slots the fuse record asks for (energy / curvature sum, max |w8|): zero them,
+// run `launch(f2)`, fold them in a fixed order
+template <typename Launch>
+static int nk_final_with_slots(const NkHostPlan& hp, void* workspace, const NkFuse& f, hipStream_t st, Launch&& launch) {
+  const bool want_value = f.value && (f.epi == NK_EPI_LIKELIHOOD || f.epi == NK_EPI_VJP);
+  const bool want_wmax = f.w8max && f.w8 && f.epi == NK_EPI_VJP;
+  if (!want_value && !want_wmax) {
+    NkFuse f0 = f;
+    f0.w8max = nullptr;
+    return launch(f0);
+  }
+  const int64_t n = nk_value_slot_count(hp);
+  NkFuse f2 = f;
+  f2.value_slots = (int)std::min<int64_t>(n, 0x7fffffff);
+  double* vslots = nk_value_slots(hp, workspace);
+  double* wslots = nk_wmax_slots(hp, workspace);
+  if (want_value) {
+    hipError_t e = hipMemsetAsync(vslots, 0, n * sizeof(double), st);
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(value slots)");
+    f2.value = vslots;
+  } else {
+    f2.value = nullptr;
+  }
+  const bool wmax_on = want_wmax;
+  if (wmax_on) {
+    hipError_t e = hipMemsetAsync(wslots, 0, n * sizeof(double), st);
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(|w8| slots)");
+    f2.w8max = wslots;
+  } else {
+    f2.w8max = nullptr;
+  }
+  int rc = launch(f2);
+  if (rc != NK_OK) return rc;
+  if (want_value) {
+    rc = nk_fold_value_slots(hp, vslots, f.value, st);
+    if (rc != NK_OK) return rc;
+  }
+  if (wmax_on) {
+    hipLaunchKernelGGL(k_fold_max_a, dim3(NK_FOLD_BLOCKS), dim3(256), 0, st, wslots, n, wslots + n);
+    hipLaunchKernelGGL(k_fold_max_b, dim3(1), dim3(NK_FOLD_BLOCKS), 0, st, wslots + n, f.w8max);
+    return nk_check_launch("k_fold_max");
+  }
+  return NK_OK;
+}
 
 extern "C" int nk_plan_octant_vjp(const nk_plan* P) { return P && nk_plan_uses_pipeline2(P) ? 1 : 0; }
 
@@ -812,7 +901,7 @@ extern "C" size_t nk_plan_workspace_bytes(const nk_plan* P) {
   if (!P) return 0;
   // [work | scratch], scratch aligned to 256 B
   size_t w = (P->hp.work_bytes + 255) / 256 * 256;
-  return w + (P->hp.scratch_bytes + 255) / 256 * 256 + 256 + (nk_value_slot_count(P->hp) + NK_FOLD_BLOCKS) * sizeof(double);
+  return w + (P->hp.scratch_bytes + 255) / 256 * 256 + 256 + 2 * (nk_value_slot_count(P->hp) + NK_FOLD_BLOCKS) * sizeof(double);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -874,20 +963,9 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
     ProfScope ps(st, 3, f.pro, f.epi);
     static const int skip_final = nk_env_int("NK_SKIP_FINAL", 0);  // debugging aid
     if (skip_final) return NK_OK;
-    static const int use_slots = nk_env_int("NK_VALUE_SLOTS", 1);  // 0: one atomic per workgroup on *value
-    if (use_slots && f.value && (f.epi == NK_EPI_LIKELIHOOD || f.epi == NK_EPI_VJP)) {
-      // energy / curvature sums: one slot per workgroup at the end of the workspace, folded in a fixed order
-      double* slots = nk_value_slots(hp, workspace);
-      hipError_t e = hipMemsetAsync(slots, 0, nk_value_slot_count(hp) * sizeof(double), st);
-      if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(value slots)");
-      NkFuse f2 = f;
-      f2.value = slots;
-      f2.value_slots = (int)std::min<int64_t>(nk_value_slot_count(hp), 0x7fffffff);
-      rc = nk_dispatch_final<T>(hp.g.nl, pf, f2, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
-      if (rc != NK_OK) return rc;
-      return nk_fold_value_slots(hp, slots, f.value, st);
-    }
-    return nk_dispatch_final<T>(hp.g.nl, pf, f, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
+    return nk_final_with_slots(hp, workspace, f, st, [&](const NkFuse& f2) {
+      return nk_dispatch_final<T>(hp.g.nl, pf, f2, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
+    });
   }
   {
     ProfScope ps(st, 1, f.pro, f.epi);
@@ -1008,19 +1086,9 @@ static int nk_run_sandwich(const nk_plan* P, const NkFuse& f, double scale_first
     if (rc != NK_OK) return rc;
   }
   ProfScope ps(st, 3, f.pro, f.epi);
-  static const int use_slots = nk_env_int("NK_VALUE_SLOTS", 1);
-  if (use_slots && f.value && (f.epi == NK_EPI_LIKELIHOOD || f.epi == NK_EPI_VJP)) {
-    double* slots = nk_value_slots(hp, workspace);
-    hipError_t e = hipMemsetAsync(slots, 0, nk_value_slot_count(hp) * sizeof(double), st);
-    if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(value slots)");
-    NkFuse f2 = f;
-    f2.value = slots;
-    f2.value_slots = (int)std::min<int64_t>(nk_value_slot_count(hp), 0x7fffffff);
-    rc = nk_dispatch_final3<T>(hp.g.nl, q.pf, f2, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
-    if (rc != NK_OK) return rc;
-    return nk_fold_value_slots(hp, slots, f.value, st);
-  }
-  return nk_dispatch_final3<T>(hp.g.nl, q.pf, f, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
+  return nk_final_with_slots(hp, workspace, f, st, [&](const NkFuse& f2) {
+    return nk_dispatch_final3<T>(hp.g.nl, q.pf, f2, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
+  });
 }
 
 extern "C" int nk_hartley_sandwich(const nk_plan* P, const nk_fuse* fuse, double scale_first, int convention,

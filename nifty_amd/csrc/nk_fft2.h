@@ -942,7 +942,7 @@ NK_HD double nk_final_slot(const NkFuse& f, const FinalCt<T>& c, int64_t ok, int
 // all slots of a group for coefficient k2
 template <typename T, int NL, int NH, int EC, bool BOTH>
 NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg,
-                          int k2, int hv, const T* afline, double* w8line, double& acc) {
+                          int k2, int hv, const T* afline, double* w8line, double& acc, double& wmax) {
   const int k2m = (NL - k2) & (NL - 1);
   const int d1 = k2 + (k2 >> 5), d2 = k2m + (k2m >> 5);
   T a = (T)0;
@@ -956,10 +956,12 @@ NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup
     ssum += nk_final_slot<T, EC, BOTH>(f, c, gp.okh[h], gp.omh[h], gp.mlo[h] == 1, sg, fx, fy, gx, gy, k2, k2m, a, acc);
   }
   if constexpr (EC == 2) {
-    if (w8line)
+    if (w8line) {
       w8line[k2] = ssum;
-    else
+      wmax = fmax(wmax, fabs(ssum));
+    } else {
       NK_VJP_SCATTER(f, f.pidx[gp.okh[hv] + k2], ssum);
+    }
   }
   if constexpr (EC == 3) acc += ssum;
 }
@@ -995,7 +997,8 @@ struct NkPassF {
 //          2 X(k, NL - c) = conj( (G_c(k) - conj G_c(-k)) / i )    c = 1 .. NL/2 - 1
 template <typename T, int NL, int TILE, bool COUPLES, int EC, int PAIR = 0, typename Exec>
 NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t blk, T* planes,
-                         const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, double* acc_out) {
+                         const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, double* acc_out,
+                         double* wmax_out = nullptr) {
   // the line FFT runs on 2A / 2B (see the load phase): fold the 1/2 into the output scale every epilogue applies first
   NkFuse f = f_in;
   f.scale = 0.5 * f_in.scale;
@@ -1142,7 +1145,7 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
     constexpr int NK = NL / 2 + 1;
     constexpr int NT = P * TILE;
     const T sg = (T)p.g.sign;
-    double acc = 0.0;
+    double acc = 0.0, wmax = 0.0;
     // a fixed group of threads serves one slot (2-D) / one couple of slots (3-D): all line bookkeeping is hoisted
     // out of the k_last loop, which then only advances by the group width
     const int nslot = couples ? TILE / 2 : TILE;
@@ -1183,9 +1186,9 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
         if constexpr (EC == 2)
           afline = f.field_octant ? c.af + ((int64_t)a * (M / 2 + 1) + b0g) * (NL / 2 + 1) : c.af + gp.okh[hv];
         // k_last = 0 and NL/2 are their own mirrors; everything in between has four distinct images per slot
-        if (lane < 2) nk_final_coeff<T, NL, NH, EC, false>(f, c, gp, pre, pim, sg, lane ? NL / 2 : 0, hv, afline, w8line, acc);
+        if (lane < 2) nk_final_coeff<T, NL, NH, EC, false>(f, c, gp, pre, pim, sg, lane ? NL / 2 : 0, hv, afline, w8line, acc, wmax);
         for (int k2 = 1 + lane; k2 < NL / 2; k2 += tps)
-          nk_final_coeff<T, NL, NH, EC, true>(f, c, gp, pre, pim, sg, k2, hv, afline, w8line, acc);
+          nk_final_coeff<T, NL, NH, EC, true>(f, c, gp, pre, pim, sg, k2, hv, afline, w8line, acc, wmax);
       }
     } else if (any) {
       const bool vjp = f.epi == NK_EPI_VJP;
@@ -1218,10 +1221,12 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
             const int m4 = gp.mlo[h] == 1 ? (k2m != k2 ? 5 : 1) : (k2m != k2 ? 15 : 3);
             ssum += nk_vjp_quad<T>(f, o4, v4, m4, a);
           }
-          if (w8line)
+          if (w8line) {
             w8line[k2] = ssum;
-          else
+            wmax = fmax(wmax, fabs(ssum));
+          } else {
             NK_VJP_SCATTER(f, bin, ssum);
+          }
           continue;
         }
         int64_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1242,6 +1247,7 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
       }
     }
     *acc_out += acc;
+    if (wmax_out) *wmax_out = fmax(*wmax_out, wmax);
   });
 }
 

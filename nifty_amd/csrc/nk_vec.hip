@@ -934,46 +934,44 @@ __global__ void __launch_bounds__(256)
 }
 
 
-// DETERMINISTIC variant (NK_DETERMINISTIC=1): ONE wavefront per workgroup with its own LDS copy of the shell's bins; its
-// groups of NK_DET_GW lanes add in turn (program order; the lanes of a group sit on one line at distinct c, i.e. distinct
-// k^2 = distinct bins; LDS operations of one wavefront execute in order), so every partial[split][bin] is built in a
-// fixed order and the fold over the splits is fixed too: the same bits on every run.  (The default kernel above lets
-// the 16 groups of four wavefronts add concurrently with LDS atomics: last-bit differences from run to run, which the
-// energy-based stopping rules of the minimisers can turn into a different number of iterations.)
-#ifndef NK_DET_BINS
-#define NK_DET_BINS 2048
-#endif
-#ifndef NK_DET_NU
-#define NK_DET_NU 8
-#endif
-#ifndef NK_DET_GW
-#define NK_DET_GW 8
-#endif
-#ifndef NK_DET_SPLITS
-#define NK_DET_SPLITS 32
-#endif
-__global__ void __launch_bounds__(64)
-    k_octant_scatter_k2_det(NkOct o, const double* __restrict__ w8, const int32_t* __restrict__ pidx,
-                            const int32_t* __restrict__ bin_k2, int nb, int64_t pstride, double* __restrict__ partial) {
-  __shared__ double acc[NK_DET_BINS];
-  const int j = blockIdx.x / NK_DET_SPLITS, s = blockIdx.x % NK_DET_SPLITS;
-  const int bin0 = j * NK_DET_BINS;
-  const int nbin = min(NK_DET_BINS, nb - bin0);
-  for (int i = threadIdx.x; i < NK_DET_BINS; i += 64) acc[i] = 0.0;
+// FIXED-POINT variant (the default when the caller passes the scale): the same walk, but every contribution is rounded to a
+// multiple of q = 2^(e - 44), 2^e >= max |w8| (the maximum comes from the launch that wrote w8: nk_fuse.w8max), and added
+// as a 64-bit INTEGER -- integer addition is associative, so the LDS atomics of the 16 groups give the same bits in any
+// order: bit-reproducible bin sums at the speed of the floating-point atomics.  A workgroup adds < 2^18 points of
+// magnitude <= 2^e: |sum| < 2^(e + 18) = 2^62 q, no overflow.  Rounding: <= q / 2 = max |w8| * 2.8e-14 per point, i.e.
+// the relative error of a bin sum is ~1e-14 * (max |w8| / typical |w8| of the bin) -- the price: bins whose contributions
+// are many orders of magnitude below the largest one of the whole grid lose relative (not absolute) accuracy.
+// The floating-point-atomic kernel above stays for callers without a scale (w8max == NULL).
+__global__ void __launch_bounds__(256)
+    k_octant_scatter_k2_fx(NkOct o, const double* __restrict__ w8, const int32_t* __restrict__ pidx,
+                           const int32_t* __restrict__ bin_k2, int nb, int64_t pstride, double* __restrict__ partial,
+                           const double* __restrict__ w8max) {
+  __shared__ unsigned long long acc[NK_SHELL_BINS];
+  const int j = blockIdx.x / NK_SHELL_SPLITS, s = blockIdx.x % NK_SHELL_SPLITS;
+  const int bin0 = j * NK_SHELL_BINS;
+  const int nbin = min(NK_SHELL_BINS, nb - bin0);
+  for (int i = threadIdx.x; i < NK_SHELL_BINS; i += blockDim.x) acc[i] = 0ull;
   __syncthreads();
+  // scale 2^(44 - e) with 2^e >= max |w8| > 0 (frexp: max = m * 2^e, 0.5 <= m < 1); all-zero input: scale irrelevant
+  const double gmax = *w8max;
+  int e = 0;
+  if (gmax > 0.0) (void)frexp(gmax, &e);
+  const double scale = ldexp(1.0, 44 - e), inv = ldexp(1.0, e - 44);
   const int klo = bin_k2[bin0];
-  const int khi = bin0 + NK_DET_BINS < nb ? bin_k2[bin0 + NK_DET_BINS] : 0x7fffffff;
+  const int khi = bin0 + NK_SHELL_BINS < nb ? bin_k2[bin0 + NK_SHELL_BINS] : 0x7fffffff;
   const int hc2 = (o.Ch - 1) * (o.Ch - 1);
-  constexpr int GW = NK_DET_GW, NG = 64 / GW, NU = NK_DET_NU;  // GW lanes per line, NG lines per instruction
-  const int grp = threadIdx.x / GW, l16 = threadIdx.x % GW;
+  constexpr int NG = 16, NU = NK_SHELL_NU;
+  const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
   const bool last = khi == 0x7fffffff;
-  for (int a = s; a < o.Ah; a += NK_DET_SPLITS) {
+  for (int a = s; a < o.Ah; a += NK_SHELL_SPLITS) {
     const int ra = a * a;
     if (ra >= khi) break;
     const int b_hi = last ? o.Mh : min(o.Mh, nk_isqrt_ceil(khi - ra));  // b^2 < khi - ra
     const int b_lo = nk_isqrt_ceil(klo - hc2 - ra);                      // b^2 + hc2 >= klo - ra
     for (int b0 = b_lo + grp; b0 < b_hi; b0 += NG * NU) {
       int cc[NU], ce[NU];
+      const double* wl[NU];
+      const int32_t* pl[NU];
       double v[NU];
       int32_t pb[NU];
 #pragma unroll
@@ -983,34 +981,30 @@ __global__ void __launch_bounds__(64)
         const bool on = b < b_hi;
         cc[u] = nk_isqrt_ceil(klo - r2) + l16;
         ce[u] = on ? (last ? o.Ch : min(o.Ch, nk_isqrt_ceil(khi - r2))) : 0;
+        wl[u] = w8 + ((int64_t)a * o.Mh + b) * o.Ch;
+        pl[u] = pidx + ((int64_t)a * o.M + b) * o.NL;
         const bool in = cc[u] < ce[u];
-        v[u] = in ? w8[((int64_t)a * o.Mh + b) * o.Ch + cc[u]] : 0.0;
-        pb[u] = in ? pidx[((int64_t)a * o.M + b) * o.NL + cc[u]] : bin0;
+        v[u] = in ? wl[u][cc[u]] : 0.0;
+        pb[u] = in ? pl[u][cc[u]] : bin0;
       }
 #pragma unroll
-      for (int q = 0; q < NG; ++q) {
-        if (grp == q) {
+      for (int u = 0; u < NU; ++u)
+        if (cc[u] < ce[u]) atomicAdd(&acc[pb[u] - bin0], (unsigned long long)__double2ll_rn(v[u] * scale));
+      // rare: runs longer than 16 points
 #pragma unroll
-          for (int u = 0; u < NU; ++u)
-            if (cc[u] < ce[u]) atomicAdd(&acc[pb[u] - bin0], v[u]);  // in order per wavefront; nobody else adds here
-          // runs longer than the group width
-#pragma unroll
-          for (int u = 0; u < NU; ++u) {
-            const int b = b0 + u * NG;
-            for (int c = cc[u] + GW; c < ce[u]; c += GW)
-              atomicAdd(&acc[pidx[((int64_t)a * o.M + b) * o.NL + c] - bin0], w8[((int64_t)a * o.Mh + b) * o.Ch + c]);
-          }
-        }
-      }
+      for (int u = 0; u < NU; ++u)
+        for (int c = cc[u] + 16; c < ce[u]; c += 16)
+          atomicAdd(&acc[pl[u][c] - bin0], (unsigned long long)__double2ll_rn(wl[u][c] * scale));
     }
   }
   __syncthreads();
   double* dst = partial + (int64_t)s * pstride + bin0;
-  for (int i = threadIdx.x; i < nbin; i += 64) dst[i] = acc[i];
+  for (int i = threadIdx.x; i < nbin; i += blockDim.x) dst[i] = (double)(long long)acc[i] * inv;
 }
 
 extern "C" int nk_octant_scatter_k2(int ndim, const int64_t* shape, const double* w8, const int32_t* pidx,
-                                    const int32_t* bin_k2, int64_t nb, double* scratch, double* abar, void* stream) {
+                                    const int32_t* bin_k2, int64_t nb, double* scratch, double* abar, const double* w8max,
+                                    void* stream) {
   NkOct o;
   int rc = nk_make_oct(ndim, shape, o);
   if (rc != NK_OK) return rc;
@@ -1018,20 +1012,18 @@ extern "C" int nk_octant_scatter_k2(int ndim, const int64_t* shape, const double
     return nk_set_error(NK_ERR_INVALID, "nk_octant_scatter_k2: bad argument");
   if ((int64_t)(o.Ah - 1) * (o.Ah - 1) + (int64_t)(o.Mh - 1) * (o.Mh - 1) + (int64_t)(o.Ch - 1) * (o.Ch - 1) >= (1 << 24))
     return nk_set_error(NK_ERR_UNSUPPORTED, "nk_octant_scatter_k2: k^2 range too large");
-  static const int deterministic = nk_vec_env_int("NK_DETERMINISTIC", 0);
+  // a workgroup of the fixed-point kernel must add < 2^17 points (overflow bound): its share of the octant
+  const int64_t shells = (nb + NK_SHELL_BINS - 1) / NK_SHELL_BINS;
   const int64_t pstride = (nb + 31) / 32 * 32;
-  if (deterministic) {
-    const int64_t shells = (nb + NK_DET_BINS - 1) / NK_DET_BINS;
-    hipLaunchKernelGGL(k_octant_scatter_k2_det, dim3((unsigned)(shells * NK_DET_SPLITS)), dim3(64), 0, (hipStream_t)stream, o,
-                       w8, pidx, bin_k2, (int)nb, pstride, scratch);
-    rc = nk_check_launch("k_octant_scatter_k2_det");
-    if (rc != NK_OK) return rc;
-    return nk_fold_copies(nb, NK_DET_SPLITS, pstride, scratch, abar, stream);
-  } else {
-    const int64_t shells = (nb + NK_SHELL_BINS - 1) / NK_SHELL_BINS;
+  static const int fp_atomics = nk_vec_env_int("NK_SCATTER_FP_ATOMICS", 0);  // 1: floating-point LDS atomics even with a scale
+  const bool fixed = w8max != nullptr && !fp_atomics &&
+                     (int64_t)o.Ah * o.Mh * o.Ch / NK_SHELL_SPLITS < ((int64_t)1 << 17) * shells;  // average per workgroup < 2^17, bound 2^18
+  if (fixed)
+    hipLaunchKernelGGL(k_octant_scatter_k2_fx, dim3((unsigned)(shells * NK_SHELL_SPLITS)), dim3(256), 0, (hipStream_t)stream, o,
+                       w8, pidx, bin_k2, (int)nb, pstride, scratch, w8max);
+  else
     hipLaunchKernelGGL(k_octant_scatter_k2, dim3((unsigned)(shells * NK_SHELL_SPLITS)), dim3(256), 0, (hipStream_t)stream, o, w8,
                        pidx, bin_k2, (int)nb, pstride, scratch);
-  }
   rc = nk_check_launch("k_octant_scatter_k2");
   if (rc != NK_OK) return rc;
   return nk_fold_copies(nb, NK_SHELL_SPLITS, pstride, scratch, abar, stream);

@@ -340,6 +340,7 @@ class FusedModel:
                 self.pidx8 = self.pidx.view(self.shape)[osl].contiguous().reshape(-1)
             self.dafield = torch.empty(self.field_shape, dtype=dtype, device=self.device)
             self.w8 = torch.empty(oct_n, dtype=torch.float64, device=self.device) if self.octant_vjp else None
+            self.w8max = torch.zeros(1, dtype=torch.float64, device=self.device)
             self.merge_swapped = int(len(self.shape) == 3 and self.shape[0] == self.shape[1]
                                      and hsp.distances[0] == hsp.distances[1])
             # natural binning on an equal-distance grid: bins are the ascending distinct integer k^2, which lets the
@@ -461,12 +462,15 @@ class FusedModel:
         if self.octant_vjp:
             # the final pass stores one merged sum per octant point; nk_octant_scatter reduces them into the bins
             f.abar, f.w8 = self.abar.data_ptr(), self.w8.data_ptr()
+            if self.bin_k2 is not None:  # max |w8| of this launch: the scale of the fixed-point shell scatter
+                f.w8max = self.w8max.data_ptr()
             run(f)
             shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
             if self.bin_k2 is not None:
                 L.check(L.load().nk_octant_scatter_k2(len(self.shape), shp, self.w8.data_ptr(), self.pidx.data_ptr(),
                                                       self.bin_k2.data_ptr(), self.nb, self.scatter_scratch.data_ptr(),
-                                                      self.abar.data_ptr(), B._stream()), "nk_octant_scatter_k2")
+                                                      self.abar.data_ptr(), self.w8max.data_ptr(), B._stream()),
+                        "nk_octant_scatter_k2")
             elif self.seg_perm is not None:
                 L.check(L.load().nk_segment_sum(self.nb, self.seg_rowptr.data_ptr(), self.seg_perm.data_ptr(),
                                                 self.w8.data_ptr(), self.abar.data_ptr(), 0, B._stream()), "nk_segment_sum")

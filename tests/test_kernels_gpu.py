@@ -166,8 +166,32 @@ def test_octant_expand_and_scatter(shape):
         abar2 = torch.full((nb,), np.nan, dtype=torch.float64, device="cuda")
         w8d, k2d = torch.from_numpy(w8).cuda(), torch.from_numpy(k2).cuda()
         L.check(lib.nk_octant_scatter_k2(len(shape), shp, w8d.data_ptr(), pd.data_ptr(), k2d.data_ptr(), nb,
-                                         scratch.data_ptr(), abar2.data_ptr(), B._stream()), "x")
+                                         scratch.data_ptr(), abar2.data_ptr(), None, B._stream()), "x")
         assert np.max(np.abs(abar2.cpu().numpy() - ref)) < 1e-12 * max(1.0, np.max(np.abs(ref)))
+        # fixed-point accumulation (scale = max |w8|): same sums to 1e-13 of the largest contribution, and the same BITS on
+        # every launch
+        wmax = w8d.abs().max().reshape(1).clone()
+        abar3 = torch.full((nb,), np.nan, dtype=torch.float64, device="cuda")
+        L.check(lib.nk_octant_scatter_k2(len(shape), shp, w8d.data_ptr(), pd.data_ptr(), k2d.data_ptr(), nb,
+                                         scratch.data_ptr(), abar3.data_ptr(), wmax.data_ptr(), B._stream()), "x")
+        got3 = abar3.cpu().numpy()
+        assert np.max(np.abs(got3 - ref)) < 1e-12 * max(1.0, float(wmax) * np.sqrt(w8.size / nb))
+        for _ in range(3):
+            abar3.fill_(np.nan)
+            L.check(lib.nk_octant_scatter_k2(len(shape), shp, w8d.data_ptr(), pd.data_ptr(), k2d.data_ptr(), nb,
+                                             scratch.data_ptr(), abar3.data_ptr(), wmax.data_ptr(), B._stream()), "x")
+            assert np.array_equal(abar3.cpu().numpy(), got3)
+        # all-zero input and a tiny scale
+        w0 = torch.zeros_like(w8d)
+        z = torch.zeros(1, dtype=torch.float64, device="cuda")
+        L.check(lib.nk_octant_scatter_k2(len(shape), shp, w0.data_ptr(), pd.data_ptr(), k2d.data_ptr(), nb,
+                                         scratch.data_ptr(), abar3.data_ptr(), z.data_ptr(), B._stream()), "x")
+        assert not abar3.cpu().numpy().any()
+        ws = w8d * 1e-200
+        wm = ws.abs().max().reshape(1).clone()
+        L.check(lib.nk_octant_scatter_k2(len(shape), shp, ws.data_ptr(), pd.data_ptr(), k2d.data_ptr(), nb,
+                                         scratch.data_ptr(), abar3.data_ptr(), wm.data_ptr(), B._stream()), "x")
+        assert np.max(np.abs(abar3.cpu().numpy() - 1e-200 * ref)) < 1e-12 * 1e-200 * max(1.0, float(wmax) * np.sqrt(w8.size / nb))
 
 
 @pytest.mark.parametrize("n", [1, 7, 1024, 1025, 5000, 300001])
@@ -315,8 +339,9 @@ def test_segment_sum_equals_bincount(n, nb):
 
 
 def test_deterministic_mode_is_bit_reproducible():
-    """NK_DETERMINISTIC=1 (read once per process, hence the child processes): two runs of a sampled-KL metric application and
-    an MGVI step on a 3-D grid give identical bits, and agree with the default mode to rounding."""
+    """Two runs (child processes) of an MGVI step on a 3-D grid give identical bits -- every sum of the hot path is built in a
+    fixed order or in fixed point -- and agree with the floating-point-atomic shell scatter (NK_SCATTER_FP_ATOMICS=1) to
+    rounding."""
     import os
     import subprocess
     import sys
@@ -339,7 +364,7 @@ print("RESULT", repr(float(kl.value)), repr(float(mean.xi.double().sum())), repr
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
     def run(det):
-        env = dict(os.environ, NK_DETERMINISTIC="1" if det else "0")
+        env = dict(os.environ, NK_SCATTER_FP_ATOMICS="0" if det else "1")
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1]

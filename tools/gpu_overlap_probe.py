@@ -24,7 +24,7 @@ def gather():
 
 def scatter():
     L.check(lib.nk_octant_scatter_k2(3, shp, w8.data_ptr(), model.pidx.data_ptr(), model.bin_k2.data_ptr(), model.nb,
-                                     model.scatter_scratch.data_ptr(), abar.data_ptr(), B._stream()))
+                                     model.scatter_scratch.data_ptr(), abar.data_ptr(), None, B._stream()))
 
 
 def timed(tag, fn, reps=10):

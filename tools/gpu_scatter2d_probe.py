@@ -28,7 +28,7 @@ def timed(tag, fn, reps=50):
 abar1, abar2 = torch.zeros(model.nb, dtype=torch.float64, device="cuda"), torch.zeros(model.nb, dtype=torch.float64, device="cuda")
 if model.bin_k2 is not None:
     timed("octant_scatter_k2", lambda: L.check(lib.nk_octant_scatter_k2(2, shp, w8.data_ptr(), model.pidx.data_ptr(), model.bin_k2.data_ptr(),
-                                                                     model.nb, model.scatter_scratch.data_ptr(), abar1.data_ptr(), B._stream())))
+                                                                     model.nb, model.scatter_scratch.data_ptr(), abar1.data_ptr(), None, B._stream())))
 
 
 def plain():

@@ -18,9 +18,18 @@ def t(fn, n=5):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 def f1():
     a1.zero_(); L.check(lib.nk_octant_scatter(len(shape), shp, w8.data_ptr(), pidx.data_ptr(), a1.data_ptr(), 1 if len(shape) == 3 and shape[0] == shape[1] else 0, B._stream()), "x")
+wmax = w8.abs().max().reshape(1).clone()
+a3 = torch.empty_like(a1)
 def f2():
-    L.check(lib.nk_octant_scatter_k2(len(shape), shp, w8.data_ptr(), pidx.data_ptr(), k2.data_ptr(), nb, scratch.data_ptr(), a2.data_ptr(), B._stream()), "x")
-print("atomic  %.3f ms" % t(f1)); print("shell   %.3f ms" % t(f2))
+    L.check(lib.nk_octant_scatter_k2(len(shape), shp, w8.data_ptr(), pidx.data_ptr(), k2.data_ptr(), nb, scratch.data_ptr(), a2.data_ptr(), None, B._stream()), "x")
+def f3():
+    L.check(lib.nk_octant_scatter_k2(len(shape), shp, w8.data_ptr(), pidx.data_ptr(), k2.data_ptr(), nb, scratch.data_ptr(), a3.data_ptr(), wmax.data_ptr(), B._stream()), "x")
+print("atomic  %.3f ms" % t(f1)); print("shell   %.3f ms" % t(f2)); print("shell, fixed point %.3f ms" % t(f3))
+print("fixed point vs atomics: max abs diff / max |bin sum|", float((a1 - a3).abs().max() / a1.abs().max()), " max rel diff per bin", float(((a1 - a3).abs() / a1.abs().clamp_min(1e-300)).max()))
+ref3 = a3.clone(); same3 = True
+for _ in range(5):
+    a3.zero_(); f3(); same3 = same3 and bool(torch.equal(a3, ref3))
+print("fixed-point shell scatter bit-identical over 5 more launches:", same3)
 print("max rel diff", float((a1 - a2).abs().max() / a1.abs().max()))
 ref = a2.clone(); same = True
 for _ in range(5):
