@@ -190,9 +190,8 @@ def test_large_grid_path_without_host_pindex(monkeypatch):
             ift.PowerSpace(ift.RGSpace((64, 64, 128)).get_default_codomain()).pindex
     finally:
         ift.PowerSpace._cache.clear()
-    # the two runs execute the same kernels; the 3-D shell scatter's LDS atomics make them differ in the last bit, which
-    # the CG iterations amplify (NK_DETERMINISTIC=1 removes that; the default is the faster kernel)
-    assert gl.lat_relerr(got, ref) < 1e-7
+    # the two paths build the bin index differently but run the same kernels on the same numbers
+    assert gl.lat_relerr(got, ref) < 1e-9
 
 
 def test_optimize_kl_on_grid_the_planner_rejects():
