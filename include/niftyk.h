@@ -108,8 +108,8 @@ typedef struct nk_fuse {
                            + cg_r[i] is WRITTEN BACK to `in` (not const here) and the new value enters the transform */
   const double* cg_scal; /* the device scalars of nk_cg_update; roll them afterwards with
                            nk_cg_direction(0, NULL, NULL, dtype, scal, 1, stream) */
-  double* w8max;        /* optional, with w8: device scalar <- max |w8[x]| of this launch (fixed-order maximum over the
-                           workgroups).  nk_octant_scatter_k2 takes it as the scale of its fixed-point accumulation, which
+  double* w8max;        /* optional, with w8 on a 3-D plan: device scalar <- an upper bound of max |w8[x]| of this launch, tight to
+                           fp32 rounding (fixed-order maximum over the wavefronts; NK_ERR_UNSUPPORTED on 1-D / 2-D plans).  nk_octant_scatter_k2 takes it as the scale of its fixed-point accumulation, which
                            makes the bin sums independent of the order of the additions (bit-reproducible) */
 } nk_fuse;
 

@@ -108,43 +108,42 @@ __device__ __forceinline__ void nk_run_stages(C2<T>* lds, int tid, int nthr, con
   }
 }
 
-// block-wide fp64 sum of `acc`, one atomic per workgroup (only when the epilogue produces an energy)
+// fp64 sum of `acc` over the workgroup (only when the epilogue produces an energy).  With slots (set up by the library for
+// the final pass of the pipelines): every WAVEFRONT stores its partial sum to its own slot -- no LDS hop, no barrier at
+// the end of the kernel (a barrier there kept the workgroup's LDS and wave slots busy until its last wave arrived: 4 % of
+// the scatter pass) -- and the slots are folded in a fixed order afterwards: bit-reproducible, no atomics.  Without slots
+// (the generic kernels): one atomic per workgroup on *value.
 __device__ __forceinline__ void nk_flush_energy(const NkFuse& f, double acc, void* lds_raw) {
   if ((f.epi != NK_EPI_LIKELIHOOD && f.epi != NK_EPI_VJP) || f.value == nullptr) return;
-  __syncthreads();  // LDS tile is dead from here on
-  double* red = (double*)lds_raw;
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  if (f.value_slots > 0) {
+    const int64_t slot = (int64_t)blockIdx.x * nw + wave;
+    if (lane == 0 && slot < f.value_slots) f.value[slot] = acc;
+    return;
+  }
+  __syncthreads();  // LDS tile is dead from here on
+  double* red = (double*)lds_raw;
   if (lane == 0) red[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
     double s = 0.0;
-    const int nw = (blockDim.x + 63) >> 6;
     for (int w = 0; w < nw; ++w) s += red[w];
-    // one slot per workgroup (set up by the library, folded in a fixed order afterwards: bit-reproducible sums, no
-    // atomics); without slots -- the generic kernels -- one atomic per workgroup on *value
-    if (f.value_slots > 0 && blockIdx.x < (unsigned)f.value_slots)
-      f.value[blockIdx.x] = s;
-    else
-      atomicAdd(f.value, s);
+    atomicAdd(f.value, s);
   }
 }
 
-// workgroup maximum of |w8| (octant sums of the VJP epilogue) -> this workgroup's slot; folded by the library afterwards
-__device__ __forceinline__ void nk_flush_wmax(const NkFuse& f, double wmax, void* lds_raw) {
-  if (f.w8max == nullptr || f.w8 == nullptr || f.epi != NK_EPI_VJP) return;
-  __syncthreads();
-  double* red = (double*)lds_raw;
-  for (int off = 32; off > 0; off >>= 1) wmax = fmax(wmax, __shfl_down(wmax, off, 64));
+// maximum of |w8| (octant sums of the VJP epilogue) of this wavefront -> its slot; folded by the library afterwards
+__device__ __forceinline__ void nk_flush_wmax(const NkFuse& f, float wmax) {
+#ifdef NK_WMAX_OFF
+  return;
+#endif
+  if (f.w8max == nullptr || f.w8 == nullptr || f.epi != NK_EPI_VJP || f.value_slots <= 0) return;
+  for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_down(wmax, off, 64));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) red[wave] = wmax;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double m = 0.0;
-    const int nw = (blockDim.x + 63) >> 6;
-    for (int w = 0; w < nw; ++w) m = fmax(m, red[w]);
-    if (f.value_slots > 0 && blockIdx.x < (unsigned)f.value_slots) f.w8max[blockIdx.x] = m;
-  }
+  const int64_t slot = (int64_t)blockIdx.x * ((blockDim.x + 63) >> 6) + wave;
+  if (lane == 0 && slot < f.value_slots) f.w8max[slot] = (double)wmax;
 }
 
 // generic LDS kernels: any thread count works (loops stride by blockDim.x).  fp64 is capped at 512 threads so that the
@@ -261,12 +260,13 @@ __global__ void __launch_bounds__((FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREAD
     k2_final(NkPassF p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, int xmap) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, SchedF<T, NL>::E> ex;
-  double acc = 0.0, wmax = 0.0;
+  double acc = 0.0;
+  float wmax = 0.0f;
   const int64_t blk = xmap ? nk_xcd_contig(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
   nk_final_body<T, NL, FinalTile<T, NL, EC, COUPLES ? 2 : 1>::TILE, COUPLES, EC, PAIR>(ex, p, f, blk, (T*)smem, tw, work, &acc,
-                                                                                      (EC == 2 || EC == -1) ? &wmax : nullptr);
+                                                                                      (COUPLES && (EC == 2 || EC == -1)) ? &wmax : nullptr);
   nk_flush_energy(f, acc, smem);
-  if constexpr (EC == 2 || EC == -1) nk_flush_wmax(f, wmax, smem);
+  if constexpr (COUPLES && (EC == 2 || EC == -1)) nk_flush_wmax(f, wmax);  // 3-D launches only (nk_final_with_slots)
 }
 
 template <typename T, int NL, bool COUPLES, int EC, int PAIR = 0>
@@ -780,14 +780,17 @@ static bool nk_plan_uses_pipeline2(const nk_plan* P) {
   return first_ok && mid_ok;
 }
 
-// energy / curvature sums of the final pass: ONE slot per workgroup at the end of the workspace, zeroed before the
+// energy / curvature sums of the final pass: ONE slot per wavefront at the end of the workspace, zeroed before the
 // launch, then folded in a fixed order (k_fold_slots_a: 256 workgroups over contiguous ranges; k_fold_slots_b: their
 // partials, fixed tree) -- the same bits on every run.  (Until round 2: atomics on 256 slots, order-dependent in the last
 // bit, which the energy-based stopping rules turned into different iteration counts from run to run.)
 #define NK_FOLD_BLOCKS 256
 static inline int64_t nk_value_slot_count(const NkHostPlan& hp) {
-  const int64_t lines = (int64_t)hp.g.batch * hp.g.na * hp.g.nm;  // every final-pass workgroup owns >= 1 line
-  const int64_t n = lines > NK_FOLD_BLOCKS ? lines : NK_FOLD_BLOCKS;
+  // one slot per WAVEFRONT of the final pass: P = nl / 16 threads per line (SchedF), whole wavefronts per workgroup, a
+  // workgroup owns >= 1 line; x 2 for the couples' rounding ((A/2 + 1) x tiles instead of A/2 x tiles) and odd tiles
+  const int64_t lines = (int64_t)hp.g.batch * hp.g.na * hp.g.nm;
+  const int64_t per_line = hp.g.nl > 1024 ? hp.g.nl / 1024 : 1;
+  const int64_t n = std::max<int64_t>(2 * lines * per_line, NK_FOLD_BLOCKS);
   return (n + 255) / 256 * 256;
 }
 __device__ __forceinline__ double nk_fold_block_sum(double v, double* red) {
@@ -856,6 +859,8 @@ template <typename Launch>
 static int nk_final_with_slots(const NkHostPlan& hp, void* workspace, const NkFuse& f, hipStream_t st, Launch&& launch) {
   const bool want_value = f.value && (f.epi == NK_EPI_LIKELIHOOD || f.epi == NK_EPI_VJP);
   const bool want_wmax = f.w8max && f.w8 && f.epi == NK_EPI_VJP;
+  if (want_wmax && hp.g.ndim != 3)
+    return nk_set_error(NK_ERR_UNSUPPORTED, "nk_fuse.w8max: only the 3-D final pass reports max |w8| (it feeds nk_octant_scatter_k2)");
   if (!want_value && !want_wmax) {
     NkFuse f0 = f;
     f0.w8max = nullptr;

@@ -804,6 +804,15 @@ NK_HD void nk_contig_body(Exec& ex, const NkPassA& p, const NkFuse& f, int64_t b
   });
 }
 
+// |x| rounded UP to fp32: the running maximum of the octant sums is kept in one 32-bit register (an upper bound is all the
+// fixed-point scatter needs; an fp64 maximum cost 6 % of the scatter pass and pushed the generic kernels over 128 VGPRs)
+NK_HD float nk_abs_up(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __double2float_ru(fabs(x));
+#else
+  return nextafterf((float)fabs(x), INFINITY);
+#endif
+}
 // per-group constants of the final epilogue (one slot, or one couple of slots)
 template <int NH>
 struct FinalGroup {
@@ -942,7 +951,7 @@ NK_HD double nk_final_slot(const NkFuse& f, const FinalCt<T>& c, int64_t ok, int
 // all slots of a group for coefficient k2
 template <typename T, int NL, int NH, int EC, bool BOTH>
 NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg,
-                          int k2, int hv, const T* afline, double* w8line, double& acc, double& wmax) {
+                          int k2, int hv, const T* afline, double* w8line, double& acc, float& wmax) {
   const int k2m = (NL - k2) & (NL - 1);
   const int d1 = k2 + (k2 >> 5), d2 = k2m + (k2m >> 5);
   T a = (T)0;
@@ -958,7 +967,7 @@ NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup
   if constexpr (EC == 2) {
     if (w8line) {
       w8line[k2] = ssum;
-      wmax = fmax(wmax, fabs(ssum));
+      wmax = fmaxf(wmax, nk_abs_up(ssum));
     } else {
       NK_VJP_SCATTER(f, f.pidx[gp.okh[hv] + k2], ssum);
     }
@@ -998,7 +1007,7 @@ struct NkPassF {
 template <typename T, int NL, int TILE, bool COUPLES, int EC, int PAIR = 0, typename Exec>
 NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t blk, T* planes,
                          const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, double* acc_out,
-                         double* wmax_out = nullptr) {
+                         float* wmax_out = nullptr) {
   // the line FFT runs on 2A / 2B (see the load phase): fold the 1/2 into the output scale every epilogue applies first
   NkFuse f = f_in;
   f.scale = 0.5 * f_in.scale;
@@ -1145,7 +1154,8 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
     constexpr int NK = NL / 2 + 1;
     constexpr int NT = P * TILE;
     const T sg = (T)p.g.sign;
-    double acc = 0.0, wmax = 0.0;
+    double acc = 0.0;
+    float wmax = 0.0f;
     // a fixed group of threads serves one slot (2-D) / one couple of slots (3-D): all line bookkeeping is hoisted
     // out of the k_last loop, which then only advances by the group width
     const int nslot = couples ? TILE / 2 : TILE;
@@ -1223,7 +1233,7 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
           }
           if (w8line) {
             w8line[k2] = ssum;
-            wmax = fmax(wmax, fabs(ssum));
+            wmax = fmaxf(wmax, nk_abs_up(ssum));
           } else {
             NK_VJP_SCATTER(f, bin, ssum);
           }
@@ -1247,7 +1257,7 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
       }
     }
     *acc_out += acc;
-    if (wmax_out) *wmax_out = fmax(*wmax_out, wmax);
+    if (wmax_out) *wmax_out = fmaxf(*wmax_out, wmax);
   });
 }
 
