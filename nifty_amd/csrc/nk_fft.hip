@@ -282,6 +282,9 @@ static int nk_launch_final_c(NkPassF pf, const NkFuse& f, const C2<T>* tw, const
   pf.tiles_per_a = (COUPLES && pf.A > 1 && CT::TILE >= 2) ? (pf.M / 2 + 1 + CT::TILE / 2 - 1) / (CT::TILE / 2)
                                                : (pf.M + CT::TILE - 1) / CT::TILE;
   const int64_t blocks = (int64_t)pf.g.batch * (pf.A / 2 + 1) * pf.tiles_per_a;
+  // every wavefront owns one slot of the energy / |w8| areas (nk_final_with_slots sized them): never drop a partial silently
+  if (f.value_slots > 0 && blocks * ((CT::THREADS + 63) / 64) > f.value_slots)
+    return nk_set_error(NK_ERR_RUNTIME, "final pass: more wavefronts than reduction slots (nk_value_slot_count)");
   static const int xmap_env = nk_env_int("NK_XMAP", NK_XMAP_DEFAULT);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CT::THREADS), CT::LDS_BYTES, st, pf, f, tw, work, xmap_env & 4);
   return nk_check_launch("k2_final");
@@ -787,10 +790,12 @@ static bool nk_plan_uses_pipeline2(const nk_plan* P) {
 #define NK_FOLD_BLOCKS 256
 static inline int64_t nk_value_slot_count(const NkHostPlan& hp) {
   // one slot per WAVEFRONT of the final pass: P = nl / 16 threads per line (SchedF), whole wavefronts per workgroup, a
-  // workgroup owns >= 1 line; x 2 for the couples' rounding ((A/2 + 1) x tiles instead of A/2 x tiles) and odd tiles
+  // workgroup owns >= 1 line: <= lines * max(1, nl / 1024) wavefronts on a full tiling.  The couples of the 3-D pass tile
+  // (A/2 + 1) x (M/2 + 1) line pairs instead of A x M / 4 (x (1 + 2/A)(1 + 2/M) <= 1.07 from 64^2 on, at one pair per
+  // workgroup that is 0.53 lines), odd tile counts round up: 9/8 of the lines + 512 covers every launcher
   const int64_t lines = (int64_t)hp.g.batch * hp.g.na * hp.g.nm;
   const int64_t per_line = hp.g.nl > 1024 ? hp.g.nl / 1024 : 1;
-  const int64_t n = std::max<int64_t>(2 * lines * per_line, NK_FOLD_BLOCKS);
+  const int64_t n = std::max<int64_t>(lines * per_line * 9 / 8 + 512, NK_FOLD_BLOCKS);
   return (n + 255) / 256 * 256;
 }
 __device__ __forceinline__ double nk_fold_block_sum(double v, double* red) {
