@@ -844,6 +844,38 @@ __global__ void __launch_bounds__(NK_FOLD_BLOCKS) k_fold_slots_b(const double* _
   const double s = nk_fold_block_sum(part[threadIdx.x], red);
   if (threadIdx.x == 0) *value += s;
 }
+// both folds in one pair of launches (the scatter epilogue of a CG iteration's last sample wants the curvature sum AND
+// max |w8|): workgroups [0, NK_FOLD_BLOCKS) sum the value slots, the rest take the maximum of the |w8| slots
+__global__ void __launch_bounds__(256) k_fold_both_a(const double* __restrict__ vslots, const double* __restrict__ wslots, int64_t n,
+                                                     double* __restrict__ vpart, double* __restrict__ wpart) {
+  __shared__ double red[4];
+  const bool is_max = blockIdx.x >= NK_FOLD_BLOCKS;
+  const int b = is_max ? blockIdx.x - NK_FOLD_BLOCKS : blockIdx.x;
+  const double* slots = is_max ? wslots : vslots;
+  const int64_t per = (n + NK_FOLD_BLOCKS - 1) / NK_FOLD_BLOCKS;
+  const int64_t lo = (int64_t)b * per, hi = lo + per < n ? lo + per : n;
+  double v = 0.0;
+  if (is_max) {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) v = fmax(v, slots[i]);
+    const double s = nk_fold_block_max(v, red);
+    if (threadIdx.x == 0) wpart[b] = s;
+  } else {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) v += slots[i];
+    const double s = nk_fold_block_sum(v, red);
+    if (threadIdx.x == 0) vpart[b] = s;
+  }
+}
+__global__ void __launch_bounds__(NK_FOLD_BLOCKS) k_fold_both_b(const double* __restrict__ vpart, const double* __restrict__ wpart,
+                                                                double* __restrict__ value, double* __restrict__ wmax) {
+  __shared__ double red[NK_FOLD_BLOCKS / 64];
+  if (blockIdx.x == 0) {
+    const double s = nk_fold_block_sum(vpart[threadIdx.x], red);
+    if (threadIdx.x == 0) *value += s;
+  } else {
+    const double s = nk_fold_block_max(wpart[threadIdx.x], red);
+    if (threadIdx.x == 0) *wmax = s;
+  }
+}
 // the slot area of a workspace: [value slots: nk_value_slot_count][partials: NK_FOLD_BLOCKS][|w8| slots][partials]
 static inline double* nk_value_slots(const NkHostPlan& hp, void* workspace) {
   return (double*)((char*)workspace + (hp.work_bytes + 255) / 256 * 256 + (hp.scratch_bytes + 255) / 256 * 256 + 256);
@@ -876,33 +908,26 @@ static int nk_final_with_slots(const NkHostPlan& hp, void* workspace, const NkFu
   f2.value_slots = (int)std::min<int64_t>(n, 0x7fffffff);
   double* vslots = nk_value_slots(hp, workspace);
   double* wslots = nk_wmax_slots(hp, workspace);
-  if (want_value) {
-    hipError_t e = hipMemsetAsync(vslots, 0, n * sizeof(double), st);
-    if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(value slots)");
-    f2.value = vslots;
-  } else {
-    f2.value = nullptr;
-  }
   const bool wmax_on = want_wmax;
-  if (wmax_on) {
-    hipError_t e = hipMemsetAsync(wslots, 0, n * sizeof(double), st);
-    if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(|w8| slots)");
-    f2.w8max = wslots;
-  } else {
-    f2.w8max = nullptr;
+  {  // the two areas are adjacent: one memset covers whatever is wanted
+    double* lo = want_value ? vslots : wslots;
+    double* hi = wmax_on ? wslots + n : vslots + n;
+    hipError_t e = hipMemsetAsync(lo, 0, (size_t)(hi - lo) * sizeof(double), st);
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(reduction slots)");
   }
+  f2.value = want_value ? vslots : nullptr;
+  f2.w8max = wmax_on ? wslots : nullptr;
   int rc = launch(f2);
   if (rc != NK_OK) return rc;
-  if (want_value) {
-    rc = nk_fold_value_slots(hp, vslots, f.value, st);
-    if (rc != NK_OK) return rc;
+  if (want_value && wmax_on) {
+    hipLaunchKernelGGL(k_fold_both_a, dim3(2 * NK_FOLD_BLOCKS), dim3(256), 0, st, vslots, wslots, n, vslots + n, wslots + n);
+    hipLaunchKernelGGL(k_fold_both_b, dim3(2), dim3(NK_FOLD_BLOCKS), 0, st, vslots + n, wslots + n, f.value, f.w8max);
+    return nk_check_launch("k_fold_both");
   }
-  if (wmax_on) {
-    hipLaunchKernelGGL(k_fold_max_a, dim3(NK_FOLD_BLOCKS), dim3(256), 0, st, wslots, n, wslots + n);
-    hipLaunchKernelGGL(k_fold_max_b, dim3(1), dim3(NK_FOLD_BLOCKS), 0, st, wslots + n, f.w8max);
-    return nk_check_launch("k_fold_max");
-  }
-  return NK_OK;
+  if (want_value) return nk_fold_value_slots(hp, vslots, f.value, st);
+  hipLaunchKernelGGL(k_fold_max_a, dim3(NK_FOLD_BLOCKS), dim3(256), 0, st, wslots, n, wslots + n);
+  hipLaunchKernelGGL(k_fold_max_b, dim3(1), dim3(NK_FOLD_BLOCKS), 0, st, wslots + n, f.w8max);
+  return nk_check_launch("k_fold_max");
 }
 
 extern "C" int nk_plan_octant_vjp(const nk_plan* P) { return P && nk_plan_uses_pipeline2(P) ? 1 : 0; }
