@@ -230,7 +230,8 @@ int nk_octant_scatter(int ndim, const int64_t* shape, const double* w8, const in
  * known from two integer square roots, accumulated in LDS -- no global atomics.  scratch: >= 64*(nb+32) doubles.
  * w8max (device scalar, optional): max |w8| as produced by nk_fuse.w8max.  With it the contributions are accumulated in
  * 64-bit FIXED POINT (quantum 2^(e-44), 2^e >= *w8max): integer additions commute, so the bin sums are the same bits on
- * every run at the speed of the atomics; rounding <= 2.8e-14 * max |w8| per point.  NULL: floating-point LDS atomics (sums
+ * every run at the speed of the atomics; rounding <= 2.8e-14 * max |w8| per point (used while a workgroup's share of the
+ * octant stays far below the 2^18-point overflow bound: up to ~1100^3; larger grids fall back to the next case).  NULL: floating-point LDS atomics (sums
  * differ in the last bit from run to run).  NK_SCATTER_FP_ATOMICS=1 (environment) forces the latter. */
 int nk_octant_scatter_k2(int ndim, const int64_t* shape, const double* w8, const int32_t* pidx, const int32_t* bin_k2,
                          int64_t nb, double* scratch, double* abar, const double* w8max, void* stream);

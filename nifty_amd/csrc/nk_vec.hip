@@ -1012,12 +1012,15 @@ extern "C" int nk_octant_scatter_k2(int ndim, const int64_t* shape, const double
     return nk_set_error(NK_ERR_INVALID, "nk_octant_scatter_k2: bad argument");
   if ((int64_t)(o.Ah - 1) * (o.Ah - 1) + (int64_t)(o.Mh - 1) * (o.Mh - 1) + (int64_t)(o.Ch - 1) * (o.Ch - 1) >= (1 << 24))
     return nk_set_error(NK_ERR_UNSUPPORTED, "nk_octant_scatter_k2: k^2 range too large");
-  // a workgroup of the fixed-point kernel must add < 2^17 points (overflow bound): its share of the octant
+  // a workgroup of the fixed-point kernel must add < 2^18 points (overflow bound).  The busiest (shell, split) holds 2.13x
+  // the average at 1024^3 (125 694 points against 59 006, counted exactly; the multiplicity of k^2 peaks near the cube
+  // face): the average is held below 2^16, a margin of 4 on that ratio.  Larger octants (beyond ~1100^3) take the
+  // floating-point atomics (not reproducible in the last bit, never wrong).
   const int64_t shells = (nb + NK_SHELL_BINS - 1) / NK_SHELL_BINS;
   const int64_t pstride = (nb + 31) / 32 * 32;
   static const int fp_atomics = nk_vec_env_int("NK_SCATTER_FP_ATOMICS", 0);  // 1: floating-point LDS atomics even with a scale
   const bool fixed = w8max != nullptr && !fp_atomics &&
-                     (int64_t)o.Ah * o.Mh * o.Ch / NK_SHELL_SPLITS < ((int64_t)1 << 17) * shells;  // average per workgroup < 2^17, bound 2^18
+                     (int64_t)o.Ah * o.Mh * o.Ch / NK_SHELL_SPLITS < ((int64_t)1 << 16) * shells;
   if (fixed)
     hipLaunchKernelGGL(k_octant_scatter_k2_fx, dim3((unsigned)(shells * NK_SHELL_SPLITS)), dim3(256), 0, (hipStream_t)stream, o,
                        w8, pidx, bin_k2, (int)nb, pstride, scratch, w8max);
