@@ -369,5 +369,5 @@ print("RESULT", repr(float(kl.value)), repr(float(mean.xi.double().sum())), repr
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1]
         return [float(v) for v in line.split()[1:]]
 
-    a, b = run(True), run(True)  # (the floating-point-atomic kernel is covered by test_octant_expand_scatter above)
+    a, b = run(True), run(True)  # (the floating-point-atomic kernel is covered by test_octant_expand_and_scatter above)
     assert a == b
