@@ -369,7 +369,9 @@ static int nk_launch_strided_pc(NkPassS ps, const NkFuse& f, const C2<T>* tw, C2
   ps.tiles_per_slab = (int)(ps.inner / ST::TILE);
   const int64_t blocks = ps.outer * ps.tiles_per_slab;
   static const int xmap_env = nk_env_int("NK_XMAP", NK_XMAP_DEFAULT);
-  const int xmap = MODE == 3 ? (xmap_env & 1) : (xmap_env & 2);
+  // in-place pass: bit 1 for every layout, bit 3 for the middle-axis pass of the sandwich only (blo > 0: 1.66 -> 1.62 ms at
+  // 1024^3 fp32, while the in-place pass of the six-pass pipeline loses 8 % with it)
+  const int xmap = MODE == 3 ? (xmap_env & 1) : ((xmap_env & 2) | ((xmap_env & 8) && ps.blo > 0 ? 2 : 0));
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ST::THREADS), ST::LDS_TOTAL, st, ps, f, tw, work, scratch, xmap);
   return nk_check_launch("k2_strided");
 }

@@ -500,7 +500,8 @@ NK_HD void nk_tw_to_lds(const C2<T>* __restrict__ tw_global, C2<T>* tw_lds, int 
 // the first pass's access pattern (1024 rows x 128 B at 4 KiB stride, 1024^3 fp32) runs at 4.77 TB/s in natural
 // order and at 5.51 TB/s with this order (tools/micro/copy_bench.hip).  A bijection of [0, nb); speed only.
 #ifndef NK_XMAP_DEFAULT
-#define NK_XMAP_DEFAULT 1  // bit 0: first strided pass, bit 1: in-place strided pass, bit 2: final pass
+#define NK_XMAP_DEFAULT 9  // bit 0: first strided pass, bit 1: every in-place strided pass, bit 2: final pass, bit 3: the
+                           // in-place middle-axis pass of the sandwich
 #endif
 NK_HD int64_t nk_xcd_contig(int64_t blk, int64_t nb) {
   const int64_t q = nb / 8, r = nb % 8;
