@@ -121,7 +121,9 @@ int nk_version(void);
 /* ---- transforms: replace ducc_dispatch.hartley / fftn / ifftn (nifty/cl/ducc_dispatch.py:116-142),
  *      called from HartleyOperator._apply_cartesian and FFTOperator.apply
  *      (nifty/cl/operators/harmonic_operators.py:77-94,144-161).  All `ndim` trailing axes of a
- *      [batch, shape...] array are transformed; axis lengths must be powers of two (>=2 on the last axis). */
+ *      [batch, shape...] array are transformed; every axis length must factor into {2, 3, 5, 7} (the real transforms
+ *      need an even last axis), at most 3 transformed axes, a line must fit one LDS tile -- NK_ERR_UNSUPPORTED otherwise
+ *      (the Python array seam serves such shapes through the chirp-z composition of nifty_amd/backend.py). */
 int nk_plan_create(nk_plan** plan, int ndim, const int64_t* shape, int dtype, int64_t batch);
 int nk_plan_destroy(nk_plan* plan);
 size_t nk_plan_workspace_bytes(const nk_plan* plan);
