@@ -13,6 +13,10 @@ synthetic, generated on the device before the timed region.
 
 Prints ONE JSON line (rank 0).  NK_BENCH_SHAPE=256,256,256 / NK_BENCH_DTYPE=f64 override the workload
 for quick checks (the line then names that workload and is not the headline number).
+NK_BENCH_CONFIG=C2 | C3 | C4 selects another BASELINE.json config as a side measurement (C4: 4096^2
+sigmoid(cf) -> masked LOSResponse(10^4 lines) -> Gaussian, geoVI, on the fused response engine).
+NK_BENCH_SAMPLES=16 runs BASELINE configs[4]'s sample count; with --gpus >= 2 a short 16-sample leg is
+appended to the line as "samples16" automatically (NK_BENCH_ALSO16=0 switches it off).
 """
 import argparse
 import ctypes
@@ -34,16 +38,22 @@ from nifty_amd import minimization, parallel, random  # noqa: E402
 from nifty_amd.engine import FusedModel, LatentVec, mgvi_iteration  # noqa: E402
 from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG  # noqa: E402
 
-PMC_TRAFFIC_FILE = "r02g_pmc_traffic.json"  # latest committed PMC summary of the bench command
+PMC_TRAFFIC_FILE = os.environ.get("NK_PMC_FILE", "r02g_pmc_traffic.json")  # latest committed PMC summary of the bench command
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # transform pass kernels by profile id: strided-first pipeline (A first strided pass with prologue, B in-place strided
 # pass, C final contiguous pass with epilogue) and the five-pass sandwich H D H of a metric application (S1 contiguous
 # first pass with prologue, S2 in-place middle-axis passes, SM fused first-axis pass, then C)
 KERNEL_NAMES = {0: "k_pass1d", 1: "k_passA", 2: "k_passB", 3: "k_passC", 4: "k_passD", 5: "k_passS1", 6: "k_passS2",
-                7: "k_passSM"}
-NK_PROF_KEYS = 200
+                7: "k_passSM", 8: "k_csr_rowsum"}
+NK_PROF_KEYS = 250
 PRO_NAMES = {0: "plain", 1: "amp", 2: "amp_jvp", 3: "mul"}
 EPI_NAMES = {0: "affine", 1: "mul", 2: "vjp", 3: "likelihood", 4: "nonlin"}
+
+
+def rowsum_bytes(nnz, nrows, b, weighted=True):
+    """Algorithmic bytes of one nk_csr_rowsum launch (gather-bound SpMV): per entry the int32 column, the float32 weight
+    and ONE gathered operand value; per row the int64 row pointer and the stored sum."""
+    return nnz * (4 + (4 if weighted else 0) + b) + nrows * (8 + b)
 
 
 def algorithmic_bytes(kernel, pro, epi, N, b, const_mid):
@@ -78,73 +88,134 @@ def collect_profile():
     return out
 
 
-def cpu_baseline(counts_per_step, shape_full, sample_shape=None, budget_s=20.0, device=None):
+def _cg_vector_ops_seconds(n, reps=3):
+    """One CG iteration's vector work as the reference does it on the host (conjugate_gradient.py:85-126 with
+    QuadraticEnergy.at_with_grad, quadratic_energy.py:44-78): d.q, r - alpha q, x - alpha d, r.r, beta d + r, A x = r + b,
+    x.(Ax), b.x -- immutable Fields, i.e. every result a fresh array; np.vdot for the dots (ducc_dispatch.py:103-108)."""
+    rng = np.random.default_rng(1)
+    x, r, d, q, bb = (rng.standard_normal(n) for _ in range(5))
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        alpha = np.vdot(r, r) / np.vdot(d, q)
+        r2 = r - q * alpha
+        x2 = x - d * alpha
+        gamma = np.vdot(r2, r2)
+        d2 = d * max(0.0, gamma) + r2
+        ax = r2 + bb
+        val = 0.5 * np.vdot(x2, ax) - np.vdot(bb, x2)
+        best = min(best, time.perf_counter() - t0)
+        del r2, x2, d2, ax, val
+    return best
+
+
+def cpu_baseline(counts_per_step, shape_full, cfg="C5", bench_dtype=None, budget_s=20.0, device=None, c4=None):
     """Oracle (numpy + scipy.fft restatement of the reference path) timed on the host cores on a bounded
-    sample, extrapolated with N log N to the full workload.  A reported baseline, not a target."""
+    sample of the workload, scaled to the full workload.  A reported baseline, not a target.
+
+    Sample: the full grid when it is small (2-D configs), else a cube of edge NK_BENCH_CPU_EDGE (default 256 on a
+    many-core host, 128 otherwise; 512 is affordable in RAM but its single-threaded set-up -- k-length table, draws --
+    takes about a minute).  Seconds per step = metric applications x t_metric + value/gradient evaluations x t_vg
+    + CG iterations x t_vector-ops, the first two scaled with N log N, the last with N.  C4 (geoVI with a response): every
+    transform pair the step executed is priced as one oracle metric application (two transforms + both sparse products)."""
     from oracle import nifty_oracle as orc
 
     cores = os.cpu_count() or 1
-    if sample_shape is None:  # the largest cube that keeps this leg at ~20-30 s: 256^3 on a many-core host
-        edge = 256 if cores >= 32 else 128
+    Nf = float(np.prod(shape_full))
+    if Nf <= (1 << 25):
+        sample_shape = tuple(shape_full)
+    else:
+        edge = int(os.environ.get("NK_BENCH_CPU_EDGE", "256" if cores >= 32 else "128"))
         sample_shape = tuple(min(edge, n) for n in shape_full)
     rng = np.random.default_rng(0)
     cf = orc.CFModel(sample_shape, None, orc.CFParams(offset_mean=2.0), workers=cores)
     x = {k: 0.1 * v for k, v in cf.draw_latent(rng).items()}
     v = cf.draw_latent(rng)
-    data = cf.forward(x) + 0.1 * rng.normal(size=sample_shape)
-    lh = orc.Likelihood("gaussian", data, icov=100.0)
+    response = None
+    if cfg == "C4":
+        # the sparse matrix is INPUT DATA of the oracle here: built by the host set-up the product shares with the
+        # reference's own host set-up (a numpy walk of the lines); the oracle's pure-Python walk of 2.7e7 segments would
+        # take minutes.  Matrix parity against the oracle's own walk: tests/test_config4_gpu.py.
+        from scipy.sparse import csr_matrix
+
+        response = csr_matrix((c4["wgt"], c4["col"], c4["rowptr"]), shape=(len(c4["rowptr"]) - 1, int(Nf)))
+        sig = orc.NONLIN["sigmoid"][0](cf.forward(x))
+        data = response @ sig.ravel() + np.sqrt(1e-3) * rng.normal(size=response.shape[0])
+        lh = orc.Likelihood("gaussian", data, icov=1e3, nonlin="sigmoid", response=response)
+        lh_kw = dict(likelihood="gaussian", icov=1e3, nonlin="sigmoid", response=c4["response"])
+    elif cfg == "C2":
+        data = rng.poisson(np.exp(cf.forward(x))).astype(np.int64)
+        lh = orc.Likelihood("poisson", data, nonlin="exp")
+        lh_kw = dict(likelihood="poisson", nonlin="exp")
+    else:
+        data = cf.forward(x) + 0.1 * rng.normal(size=sample_shape)
+        lh = orc.Likelihood("gaussian", data, icov=100.0)
+        lh_kw = dict(likelihood="gaussian", icov=100.0)
     lin = orc.Linearized(cf, lh, x)
     mv = lin.metric(v)
-    # parity of the HIP path against the oracle on this very sample (SURVEY 8(d): <= 1e-5 relative, asserted in the run)
-    parity = None
+    # parity of the HIP path against the oracle on this very sample (SURVEY 8(d): <= 1e-5 relative in fp64, asserted in the
+    # run), in fp64 AND in the dtype the bench computes in (fp32 fields against the fp64 oracle: reported, loosely asserted)
+    parity = {}
     if device is not None:
         from nifty_amd.engine import FusedModel, LatentVec
 
-        model = FusedModel(sample_shape, offset_mean=2.0, likelihood="gaussian", data=data, icov=100.0, device=device)
-        lp = model.linearize(LatentVec.from_dict(model, x))
-        got = model.metric(lp, LatentVec.from_dict(model, v)).to_dict()
         val_o, _ = lin.value_grad()
-        parity = max(float(np.max(np.abs(got[k] - mv[k])) / np.max(np.abs(mv[k]))) for k in ("xi", "spectrum"))
-        parity = max(parity, abs(float(lp.value.item()) - val_o) / abs(val_o))
-        assert parity < 1e-5, f"HIP path deviates from the oracle: {parity}"
-        del model, lp
-    t_met, t_vg, n = 0.0, 0.0, 0
-    t_start = time.perf_counter()
-    while time.perf_counter() - t_start < budget_s or n < 2:
-        t0 = time.perf_counter()
-        lin.metric(v)
-        t1 = time.perf_counter()
-        orc.Linearized(cf, lh, x).value_grad()
-        t2 = time.perf_counter()
-        t_met += t1 - t0
-        t_vg += t2 - t1
-        n += 1
-    t_met, t_vg = t_met / n, t_vg / n
-    Ns, Nf = float(np.prod(sample_shape)), float(np.prod(shape_full))
+        dts = [torch.float64] + ([bench_dtype] if bench_dtype not in (None, torch.float64) else [])
+        for dt in dts:
+            model = FusedModel(sample_shape, offset_mean=2.0, data=data, dtype=dt, device=device, **lh_kw)
+            lp = model.linearize(LatentVec.from_dict(model, x))
+            got = model.metric(lp, LatentVec.from_dict(model, v)).to_dict()
+            err = max(float(np.max(np.abs(got[k] - mv[k])) / np.max(np.abs(mv[k]))) for k in ("xi", "spectrum"))
+            err = max(err, abs(float(lp.value.item()) - val_o) / abs(val_o))
+            parity["f64" if dt == torch.float64 else "f32"] = err
+            del model, lp
+        assert parity["f64"] < 1e-5, f"HIP path deviates from the oracle: {parity}"
+        assert parity.get("f32", 0.0) < 1e-3, f"fp32 HIP path deviates from the fp64 oracle: {parity}"
+
+    def time_pair(lin_, cf_, budget):
+        t_met, t_vg, n = 0.0, 0.0, 0
+        t_start = time.perf_counter()
+        while time.perf_counter() - t_start < budget or n < 2:
+            t0 = time.perf_counter()
+            lin_.metric(v)
+            t1 = time.perf_counter()
+            orc.Linearized(cf_, lh, x).value_grad()
+            t2 = time.perf_counter()
+            t_met += t1 - t0
+            t_vg += t2 - t1
+            n += 1
+        return t_met / n, t_vg / n, n
+
+    t_met, t_vg, n = time_pair(lin, cf, budget_s)
+    Ns = float(np.prod(sample_shape))
     scale = (Nf * math.log2(Nf)) / (Ns * math.log2(Ns))
-    sec_per_step = scale * (counts_per_step["metric"] * t_met + counts_per_step["value_grad"] * t_vg)
+    t_cg = _cg_vector_ops_seconds(int(Ns))
+    n_cg = counts_per_step.get("cg_iterations", 0.0)
+
+    def per_step(tm, tv):
+        if cfg == "C4":
+            return scale * 0.5 * counts_per_step["transforms"] * tm + (Nf / Ns) * n_cg * t_cg
+        return (scale * (counts_per_step["metric"] * tm + counts_per_step["value_grad"] * tv) + (Nf / Ns) * n_cg * t_cg)
+
+    sec_per_step = per_step(t_met, t_vg)
     # the reference's default is ONE FFT thread (ducc_dispatch.py:46): same sample, workers=1, a few seconds
     cf1 = orc.CFModel(sample_shape, None, orc.CFParams(offset_mean=2.0), workers=1)
     lin1 = orc.Linearized(cf1, lh, x)
     lin1.metric(v)
-    t1_met, t1_vg, n1 = 0.0, 0.0, 0
-    t_start = time.perf_counter()
-    while time.perf_counter() - t_start < budget_s / 3 or n1 < 2:
-        t0 = time.perf_counter()
-        lin1.metric(v)
-        t1 = time.perf_counter()
-        orc.Linearized(cf1, lh, x).value_grad()
-        t1_met += t1 - t0
-        t1_vg += time.perf_counter() - t1
-        n1 += 1
-    sec1 = scale * (counts_per_step["metric"] * t1_met / n1 + counts_per_step["value_grad"] * t1_vg / n1)
-    return dict(value=1.0 / sec_per_step, unit="MGVI iters/s", cores=cores, kind="port", parity_rel_err_vs_hip=parity,
+    t1_met, t1_vg, n1 = time_pair(lin1, cf1, budget_s / 3)
+    sec1 = per_step(t1_met, t1_vg)
+    priced = (f"{0.5 * counts_per_step['transforms']:.0f} transform pairs (geoVI: metric applications, energy evaluations)"
+              if cfg == "C4" else
+              f"{counts_per_step['metric']:.0f} metric applies + {counts_per_step['value_grad']:.0f} value/gradient "
+              "evaluations")
+    return dict(value=1.0 / sec_per_step, unit="MGVI iters/s", cores=cores, kind="port",
+                parity_rel_err_vs_hip=parity.get("f64"), parity_rel_err_vs_hip_f32=parity.get("f32"),
                 value_one_thread=1.0 / sec1,
                 sample=(f"oracle (numpy+scipy.fft, workers={cores}) metric apply {t_met * 1e3:.1f} ms and value+gradient "
                         f"{t_vg * 1e3:.1f} ms per sample at {'x'.join(map(str, sample_shape))} fp64 ({n} reps), "
-                        f"extrapolated x{scale:.0f} (N log N) to {'x'.join(map(str, shape_full))} and multiplied by the "
-                        f"{counts_per_step['metric']:.0f} metric applies + {counts_per_step['value_grad']:.0f} "
-                        "value/gradient evaluations one GPU step executed"))
+                        f"scaled x{scale:.1f} (N log N) to {'x'.join(map(str, shape_full))} and multiplied by the {priced} "
+                        f"one GPU step executed; plus {n_cg:.0f} CG iterations x {t_cg * 1e3:.1f} ms of host vector "
+                        f"operations (x{Nf / Ns:.0f}, linear in N)"))
 
 
 RNG_LABEL = {"numpy": "the reference's numpy PCG64 + ziggurat streams (seed 42, one SeedSequence per sample), computed on the "
@@ -184,23 +255,42 @@ def main():
 
     # NK_BENCH_CONFIG selects another BASELINE.json config for side measurements (never the default):
     #   C2 = 2048^2 fp64 Poisson(exp) ;  C3 = 512^3 fp64 Gaussian ;  C5 (default) = 1024^3 fp32 Gaussian
+    #   C4 = 4096^2 fp64 sigmoid(cf) -> MaskOperator(LOSResponse(10^4 random lines)) -> Gaussian noise 1e-3, geoVI
+    #        (reference demos/cl/getting_started_3.py:48-51, 98-100, 119-127)
     cfg = os.environ.get("NK_BENCH_CONFIG", "C5")
     preset = {"C2": ("2048,2048", "f64", "poisson"), "C3": ("512,512,512", "f64", "gaussian"),
-              "C5": ("1024,1024,1024", "f32", "gaussian")}[cfg]
+              "C4": ("4096,4096", "f64", "gaussian"), "C5": ("1024,1024,1024", "f32", "gaussian")}[cfg]
     shape = tuple(int(s) for s in os.environ.get("NK_BENCH_SHAPE", preset[0]).split(","))
     dt_name = os.environ.get("NK_BENCH_DTYPE", preset[1])
     lh_kind = preset[2]
     dtype = torch.float32 if dt_name == "f32" else torch.float64
     b = 4 if dtype == torch.float32 else 8
     N = int(np.prod(shape))
-    n_pairs = 4  # mirrored -> 8 samples in total
-    noise_var = 0.01
+    n_pairs = int(os.environ.get("NK_BENCH_SAMPLES", "8")) // 2  # mirrored pairs -> 8 samples in total by default
+    noise_var = 1e-3 if cfg == "C4" else 0.01
 
     L.load()
+    response, c4 = None, None
+    if cfg == "C4":
+        from nifty_amd.los_response import SparseResponse, los_matrix
+
+        n_los = int(os.environ.get("NK_BENCH_NLOS", "10000"))
+        lrng = np.random.default_rng(1)
+        starts, ends = lrng.uniform(size=(2, n_los)), lrng.uniform(size=(2, n_los))
+        flagged = np.zeros(n_los, dtype=bool)
+        flagged[lrng.integers(0, n_los, n_los // 20)] = True
+        rowptr, col, wgt = los_matrix(shape, tuple(1.0 / n for n in shape), starts, ends)
+        from scipy.sparse import csr_matrix
+
+        kept = csr_matrix((wgt, col, rowptr), shape=(n_los, N))[np.logical_not(flagged)].tocsr()
+        response = SparseResponse(kept.indptr, kept.indices, kept.data, N)
+        c4 = dict(rowptr=kept.indptr, col=kept.indices, wgt=kept.data, response=response, nnz=int(kept.nnz),
+                  n_data=int(kept.shape[0]), n_los=n_los)
     model = FusedModel(shape, offset_mean=2.0, offset_std=(1e-1, 3e-2), fluctuations=(1.0, 5e-1),
                        loglogavgslope=(-3.0, 2e-1), flexibility=(1.0, 2e-1), asperity=(5e-1, 5e-2),
-                       likelihood=lh_kind, icov=1.0 / noise_var, nonlin="exp" if lh_kind == "poisson" else None,
-                       dtype=dtype, device=device)
+                       likelihood=lh_kind, icov=1.0 / noise_var,
+                       nonlin="exp" if lh_kind == "poisson" else "sigmoid" if cfg == "C4" else None,
+                       response=response, dtype=dtype, device=device)
     # synthetic inputs with the reference's seed discipline: push_sseq_from_seed(42); truth = from_random;
     # d = cf(truth) + N(0, noise_var) (or d ~ Poisson(exp(cf(truth)))); start = 0.1 * from_random.  Every normal field is
     # numpy's PCG64 + ziggurat stream computed ON THE DEVICE from the host generator's state (nk_pcg64_normal: the very
@@ -211,7 +301,11 @@ def main():
     gen = torch.Generator(device=device).manual_seed(42) if rng_mode == "device" else None
     truth = model.draw_prior(gen)
     data = model.signal(truth)
-    if lh_kind == "poisson":
+    if response is not None:
+        data = response.times(data)
+        data.add_(random.Random.normal_on_device(model.npdtype, (c4["n_data"],), 0.0, math.sqrt(noise_var), device))
+        model.set_data(data, 1.0 / noise_var)
+    elif lh_kind == "poisson":
         pgen = torch.Generator(device=device).manual_seed(42)
         data = torch.poisson(data.double(), generator=pgen).to(torch.int64)
         model.set_data(data)
@@ -227,11 +321,13 @@ def main():
     mean = 0.1 * model.draw_prior(gen)
     rng_draws = torch.Generator(device=device).manual_seed(1234 + rank) if rng_mode == "device" else None
 
-    def step(mean):
+    def step(mean, pairs=n_pairs):
         ic = lambda: AbsDeltaEnergyController(0.05, iteration_limit=20)  # noqa: E731
         mini = NewtonCG(AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=3), max_cg_iterations=20)
-        new_mean, kl = mgvi_iteration(model, mean, n_pairs, ic, mini, mirror_samples=True, comm=comm,
-                                      device_rng=rng_draws)
+        # C4: geoVI, the non-linear sample fit of demos/cl/getting_started_3.py:125-127
+        geo = NewtonCG(AbsDeltaEnergyController(0.5, iteration_limit=5, convergence_level=2)) if cfg == "C4" else None
+        new_mean, kl = mgvi_iteration(model, mean, pairs, ic, mini, mirror_samples=True, comm=comm,
+                                      device_rng=rng_draws, geo_minimizer=geo)
         return new_mean, kl.value
 
     def sync():
@@ -259,14 +355,46 @@ def main():
     prof = collect_profile()
     if comm is not None:
         elapsed = comm.max_float(elapsed, device)
+    # BASELINE configs[4]: the same model with 16 samples (two per GPU on the 8-GPU node).  With >= 2 ranks a short leg of it
+    # rides along (1 warm-up + up to 3 timed steps, same barriers), so that the 8-sample strong-scaling series and the
+    # 16-sample case come out of one command; on one GPU 16 samples of 1024^3 do not fit next to the CG vectors.
+    leg16 = None
+    cg_iterations = minimization.counters["cg_iterations"]
+    if world >= 2 and 2 * n_pairs == 8 and cfg == "C5" and os.environ.get("NK_BENCH_ALSO16", "1") != "0":
+        saved = dict(model.counters)
+        k16 = max(1, min(3, args.steps))
+        m16, _ = step(mean, 8)
+        sync()
+        t16 = time.perf_counter()
+        for _ in range(k16):
+            m16, e16 = step(m16, 8)
+        sync()
+        t16 = comm.max_float(time.perf_counter() - t16, device)
+        leg16 = {"samples_total": 16, "steps": k16, "warmup": 1, "ms_per_step": 1e3 * t16 / k16, "value": k16 / t16,
+                 "unit": "MGVI iters/s", "final_kl_energy": e16}
+        del m16
+        model.counters = saved
     ms_per_step = 1e3 * elapsed / args.steps
-    model.counters["cg_iterations"] = minimization.counters["cg_iterations"]
+    model.counters["cg_iterations"] = cg_iterations
     counts = {k: v / args.steps for k, v in model.counters.items()}
 
     if rank == 0:
         # dominant transform pass kernel of this rank, live HIP-event timing over the timed region
         by_kernel = {}
+        spmv = {}
         for (kern, pro, epi), (ms, cnt) in prof.items():
+            if kern == 8:
+                # nk_csr_rowsum: the matrix (>= 16 lanes per row: thousands of pixels per line) and its transpose (<= 4 lanes
+                # per row: a few lines per pixel) of the response; the unweighted launches are bin sums of static index maps
+                if c4 is None or epi != 0:
+                    continue
+                name = "k_csr_rowsum<R>" if pro >= 2 else "k_csr_rowsum<R^T>"
+                nrows = c4["n_data"] if pro >= 2 else N
+                ent = spmv.setdefault(name, dict(ms=0.0, cnt=0, bytes=0.0))
+                ent["ms"] += ms
+                ent["cnt"] += cnt
+                ent["bytes"] += cnt * rowsum_bytes(c4["nnz"], nrows, b)
+                continue
             ent = by_kernel.setdefault(kern, dict(ms=0.0, cnt=0, bytes=0.0))
             ent["ms"] += ms
             ent["cnt"] += cnt
@@ -293,6 +421,15 @@ def main():
                             all_pass_kernels={KERNEL_NAMES[k]: dict(ms_total=round(v["ms"], 2), launches=int(v["cnt"]),
                                                                     GBps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
                                               for k, v in sorted(by_kernel.items())})
+            if spmv:
+                # gather-bound sparse products of the response (C4): algorithmic bytes = per entry column + weight + one
+                # gathered operand, per row pointer + result (rowsum_bytes); against the same 8 TB/s peak
+                roofline["spmv"] = {k: dict(bound="hbm (gather)", ms_total=round(v["ms"], 2), launches=int(v["cnt"]),
+                                            avg_launch_ms=round(v["ms"] / v["cnt"], 4),
+                                            algorithmic_bytes_per_launch=v["bytes"] / v["cnt"],
+                                            achieved=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1), peak=HBM_PEAK_GBS,
+                                            unit="GB/s", frac=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4))
+                                   for k, v in sorted(spmv.items())}
         if roofline is not None:
             # "confirm on the box with a device-copy ceiling and report both" -- a 1 read + 1 write stream copy
             # of one field-sized array through the library's own chunked element-wise kernel (after the timed region)
@@ -319,6 +456,12 @@ def main():
         B_met = (4 * D + 4) * N * b + 8 * N
         B_vg = (4 * D + 3) * N * b + 8 * N
         step_bytes = counts["metric"] * B_met + counts["value_grad"] * B_vg
+        if cfg == "C4":
+            # geoVI with a response: energy evaluations and metric applications of the sample fits are transform pairs that
+            # are neither `metric` nor `value_grad` of the KL -- price every transform pair like a metric application
+            # (2 x 2DNb + 4Nb + 8N) plus its two sparse products
+            step_bytes = 0.5 * counts["transforms"] * (B_met + rowsum_bytes(c4["nnz"], c4["n_data"], b)
+                                                       + rowsum_bytes(c4["nnz"], N, b))
         line = {
             "metric": f"MGVI iters/sec on {shape_label} RGSpace CorrelatedField, {2 * n_pairs} samples; achieved HBM GB/s",
             "value": args.steps / elapsed,
@@ -332,19 +475,23 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if dtype == torch.float32 else "f64",
             "data": "synthetic",
-            "config": {"workload": f"{cfg}: {'x'.join(map(str, shape))} RGSpace CorrelatedField + {lh_kind} likelihood, "
-                                   f"{2 * n_pairs} mirrored MGVI samples, {dt_name} fields / fp64 accumulators, "
-                                   "sampling CG limit 20, NewtonCG 3 steps x <=20 CG iterations",
+            "config": {"workload": f"{cfg}: {'x'.join(map(str, shape))} RGSpace CorrelatedField + "
+                                   + (f"sigmoid -> MaskOperator(LOSResponse({c4['n_los']} lines, {c4['nnz']} entries)) -> "
+                                      if c4 else "")
+                                   + f"{lh_kind} likelihood, {2 * n_pairs} mirrored {'geoVI' if c4 else 'MGVI'} samples, "
+                                   f"{dt_name} fields / fp64 accumulators, sampling CG limit 20, NewtonCG 3 steps x <=20 CG "
+                                   "iterations" + (", sample fit NewtonCG <=5 steps" if c4 else ""),
                        "samples_total": 2 * n_pairs, "parallelism": f"sample-sharded x{world}",
                        "rng": RNG_LABEL[rng_mode]},
             "final_kl_energy": energy,
+            "samples16": leg16,
             "per_step_counts_rank0": counts,
             "step_algorithmic_GBps_rank0": step_bytes / (ms_per_step * 1e-3) / 1e9,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(counts, shape, device=device)
+                line["cpu_baseline"] = cpu_baseline(counts, shape, cfg=cfg, bench_dtype=dtype, device=device, c4=c4)
             except Exception as exc:  # the baseline must never take the bench line down
                 line["cpu_baseline"] = {"error": repr(exc)}
     else:

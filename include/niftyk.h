@@ -150,9 +150,10 @@ int nk_fftn(const nk_plan* plan, const void* in, void* out, int inverse, double 
 
 /* live profiling for bench.py: when enabled every transform pass kernel launch is bracketed by HIP events on
  * its launch stream; nk_profile_collect synchronises and returns summed milliseconds and launch counts in
- * ms[200] / count[200], index = kernel*25 + prologue*5 + epilogue (kernel: 0 pass1d, 1 passA, 2 passB,
+ * ms[250] / count[250], index = kernel*25 + prologue*5 + epilogue (kernel: 0 pass1d, 1 passA, 2 passB,
  * 3 passC, 4 passD; sandwich: 5 contiguous first pass, 6 in-place middle-axis pass, 7 fused first-axis pass; its
- * final pass counts as 3) and resets the record. */
+ * final pass counts as 3; kernel 8 = nk_csr_rowsum with "prologue" = lanes class 0..3 (1 / 4 / 16 / 64 lanes per row) and
+ * "epilogue" = 0 weighted / 1 unweighted) and resets the record. */
 int nk_profile_enable(int on);
 int nk_profile_collect(double* ms, int64_t* count);
 
@@ -180,7 +181,10 @@ int nk_axpby(int64_t n, double alpha, const void* x, double beta, const void* y,
  *     10 arctan, 11 sin, 12 cos */
 int nk_pointwise(int fn, double param, int64_t n, const void* x, void* fx, void* dfx, int dtype, void* stream);
 /* gather / scatter-add by bin index (DOFDistributor, distributors.py:106-127): table/in/out are of `dtype`;
- * the scatter accumulates into DOUBLE bins (np.bincount semantics, utilities.py:222-246), caller zeroes them */
+ * the scatter accumulates into DOUBLE bins (np.bincount semantics, utilities.py:222-246), caller zeroes them.
+ * nk_scatter_add uses fp64 atomics: with colliding indices the sums depend on the order of the atomics in the last bit.
+ * For a STATIC index map use nk_csr_rowsum over the bin-sorted permutation instead (fixed order, no atomics): that is
+ * what nifty_amd's DOFDistributor / PowerDistributor / ContractionOperator do. */
 int nk_gather(int64_t n, const void* table, const int32_t* pidx, void* out, int dtype, void* stream);
 int nk_scatter_add(int64_t n, const void* in, const int32_t* pidx, int64_t nbins, void* bins, int dtype,
                    void* stream);
@@ -188,8 +192,17 @@ int nk_scatter_add(int64_t n, const void* in, const int32_t* pidx, int64_t nbins
 /* ---- sparse line-of-sight response: replaces scipy.sparse matvec / rmatvec of LOSResponse.apply
  *      (library/los_response.py:244-253).  CSR: rowptr[nrows+1] (int64), col (int32 pixel index), wgt (float32, as the
  *      reference stores them, :196); x / y in the field dtype, fp64 accumulation.
- * nk_spmv  : y[i] = sum_j wgt[j] * x[col[j]]
- * nk_spmv_t: x64[col[j]] += wgt[j] * y[i] on a caller-zeroed fp64 array (cast to the field dtype afterwards) */
+ * nk_csr_rowsum: y[i] = sum_j (wgt ? wgt[j] : 1) * x[col[j]] over rowptr[i] <= j < rowptr[i+1], `lanes` (1, 4, 16 or 64)
+ *            lanes per row: lane l adds the entries l, l + lanes, ... in ascending order, a fixed shuffle tree joins the
+ *            lanes -- the summation order depends on the matrix only (bit-reproducible, no atomics).  Serves TIMES
+ *            (lanes 64: thousands of pixels per line), ADJOINT_TIMES through the TRANSPOSED matrix the caller builds once
+ *            (lanes 1: a few lines per pixel), and every scatter-add of a static index map (rows = bins, col = the
+ *            bin-sorted permutation of the source points, wgt = NULL; np.bincount / _special_add_at, utilities.py:222-246).
+ * nk_spmv  : nk_csr_rowsum with lanes = 64
+ * nk_spmv_t: x64[col[j]] += wgt[j] * y[i] on a caller-zeroed fp64 array (cast to the field dtype afterwards) by fp64
+ *            atomics -- for callers that do not hold the transpose; order-dependent in the last bit */
+int nk_csr_rowsum(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, const void* x, void* y,
+                  int dtype, int lanes, void* stream);
 int nk_spmv(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, const void* x, void* y, int dtype,
             void* stream);
 int nk_spmv_t(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, const void* y, double* x64,

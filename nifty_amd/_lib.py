@@ -64,6 +64,7 @@ SIGNATURES = {
     "nk_fold_copies": (_i, [_i64, _i, _i64, _vp, _vp, _vp]),
     "nk_cumsum": (_i, [_i64, _vp, _vp, _i, _i, _vp]),
     "nk_cplx_rows": (_i, [_i64, _i64, _i64, _vp, _vp, _vp, _i, _d, _i, _i, _vp]),
+    "nk_csr_rowsum": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "nk_spmv": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "nk_spmv_t": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "nk_pindex_from_k2": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp]),

@@ -313,7 +313,9 @@ def gather(table, pidx, out_shape, out=None):
 
 
 def scatter_add(x, pidx, nbins):
-    """np.bincount(pidx, weights=x, minlength=nbins): fp64 bins."""
+    """np.bincount(pidx, weights=x, minlength=nbins): fp64 bins, by fp64 atomics.  Exact and reproducible when the indices
+    are unique (MaskOperator); with collisions the last bit depends on the order -- static index maps go through
+    ``bin_plan`` / ``bin_sum`` instead."""
     _require_device(x, pidx)
     bins = torch.zeros(nbins, dtype=torch.float64, device=x.device)
     L.check(L.load().nk_scatter_add(x.numel(), x.data_ptr(), pidx.data_ptr(), nbins, bins.data_ptr(), dtype_code(x),
@@ -321,17 +323,50 @@ def scatter_add(x, pidx, nbins):
     return bins
 
 
-def spmv(rowptr, col, wgt, x, nrows):
-    """y = R x for a CSR response (LOSResponse TIMES)."""
+def lanes_for(nnz, nrows):
+    """Lanes per row of nk_csr_rowsum from the average row length."""
+    avg = nnz / max(1, nrows)
+    return 1 if avg <= 4 else 4 if avg <= 32 else 16 if avg <= 256 else 64
+
+
+BIN_PLAN_MAX = 1 << 28  # largest static index map that is sorted once (the sort holds ~20 bytes per point transiently)
+
+
+def bin_plan(pidx, nbins):
+    """(rowptr int64[nbins+1], perm int32[n], lanes) of a STATIC device index map: the source points listed bin by bin
+    (stable sort, made once), so that ``bin_sum`` adds every bin in a fixed order without atomics (the scatter-add of
+    np.bincount / _special_add_at, reference utilities.py:222-246, turned inside out).  Index bookkeeping only (set-up)."""
+    _require_device(pidx)
+    flat = pidx.reshape(-1)
+    perm = torch.argsort(flat, stable=True).to(torch.int32)
+    rowptr = torch.zeros(nbins + 1, dtype=torch.int64, device=pidx.device)
+    rowptr[1:] = torch.cumsum(torch.bincount(flat, minlength=nbins), 0)
+    return rowptr, perm, lanes_for(flat.numel(), nbins)
+
+
+def bin_sum(x, plan, out_dtype=None):
+    """bins[b] = sum of x over the points of bin b (plan from ``bin_plan``), fp64 accumulation in a fixed order; returned in
+    x's dtype (the reference casts its fp64 bincount back to the field dtype as well, distributors.py:112)."""
+    rowptr, perm, lanes = plan
+    _require_device(x, perm)
+    y = torch.empty(rowptr.numel() - 1, dtype=x.dtype, device=x.device)
+    L.check(L.load().nk_csr_rowsum(y.numel(), rowptr.data_ptr(), perm.data_ptr(), 0, x.data_ptr(), y.data_ptr(),
+                                   dtype_code(x), lanes, _stream()), "nk_csr_rowsum")
+    return y
+
+
+def spmv(rowptr, col, wgt, x, nrows, lanes=64):
+    """y = R x for a CSR response (LOSResponse TIMES; ADJOINT_TIMES with the transposed arrays): fixed summation order."""
     _require_device(x, col)
     y = torch.empty(nrows, dtype=x.dtype, device=x.device)
-    L.check(L.load().nk_spmv(nrows, rowptr.data_ptr(), col.data_ptr(), wgt.data_ptr(), x.data_ptr(), y.data_ptr(),
-                             dtype_code(x), _stream()), "nk_spmv")
+    L.check(L.load().nk_csr_rowsum(nrows, rowptr.data_ptr(), col.data_ptr(), wgt.data_ptr(), x.data_ptr(), y.data_ptr(),
+                                   dtype_code(x), lanes, _stream()), "nk_csr_rowsum")
     return y
 
 
 def spmv_t(rowptr, col, wgt, y, ncols):
-    """x = R^T y (LOSResponse ADJOINT_TIMES): fp64 atomics, returned in y's dtype."""
+    """x = R^T y by fp64 atomics, returned in y's dtype -- for callers without the transposed arrays (LOSResponse holds
+    them and uses ``spmv``); order-dependent in the last bit."""
     _require_device(y, col)
     x64 = torch.zeros(ncols, dtype=torch.float64, device=y.device)
     L.check(L.load().nk_spmv_t(y.numel(), rowptr.data_ptr(), col.data_ptr(), wgt.data_ptr(), y.data_ptr(), x64.data_ptr(),

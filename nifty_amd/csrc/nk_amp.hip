@@ -68,18 +68,19 @@ __device__ __forceinline__ double block_sum(double v, double* sh /*[AMP_WAVES]*/
 // DETERMINISTIC cross-workgroup sums of the amplitude scalars (S, dS, the VJP reductions): every workgroup stores its
 // partial(s); the workgroup that takes the last ticket adds them in block order with the fixed tree of block_sum and
 // STORES the result -- the same bits on every run (until round 2: one fp64 atomic per workgroup, order-dependent in the
-// last bit, and every later kernel of the step inherits S).  One launch at a time per device (one stream), like the
-// reductions of nk_vec.hip; the ticket is left at zero.
-__device__ unsigned int g_amp_ticket = 0;
+// last bit, and every later kernel of the step inherits S).  The ticket lives in the caller's STATE buffer (state[14],
+// zeroed by the first kernel of nk_amp_forward, left at zero by every user), next to the partials: launches that work
+// on different states -- other streams, other host threads -- never share scratch.
+__device__ __forceinline__ unsigned int* amp_ticket(double* state) { return reinterpret_cast<unsigned int*>(state + 14); }
 template <int NV>
 __device__ __forceinline__ void amp_store_sums(const double (&v)[NV] /* valid in thread 0 */, double* part,
-                                               double* const (&dst)[NV], double* sh /*[AMP_WAVES]*/) {
+                                               double* const (&dst)[NV], double* sh /*[AMP_WAVES]*/, unsigned int* ticket) {
   __shared__ bool is_last;
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) part[k * gridDim.x + blockIdx.x] = v[k];
     __threadfence();
-    is_last = atomicAdd(&g_amp_ticket, 1u) == gridDim.x - 1;
+    is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
   }
   __syncthreads();
   if (!is_last) return;
@@ -91,7 +92,7 @@ __device__ __forceinline__ void amp_store_sums(const double (&v)[NV] /* valid in
     const double t = block_sum(x, sh);
     if (threadIdx.x == 0) *dst[k] = t;
   }
-  if (threadIdx.x == 0) g_amp_ticket = 0;
+  if (threadIdx.x == 0) *ticket = 0;
 }
 
 // geo layout: rel[nb] | sc[nb] | mult[nb] | delta[nb]
@@ -244,6 +245,7 @@ __global__ void __launch_bounds__(AMP_THREADS) k_fwd_agg(int nb, ScanGeom sg, co
     if (blockIdx.x == 0) {
       state[0] = h.flex, state[1] = h.asp, state[2] = h.fluct, state[3] = h.zm, state[4] = h.slope;
       state[5] = 0.0;
+      state[14] = 0.0;  // the reduction ticket (amp_ticket)
     }
   }
 }
@@ -273,7 +275,7 @@ __global__ void __launch_bounds__(AMP_THREADS) k_fwd_apply(int nb, ScanGeom sg, 
   __syncthreads();
   const double v[1] = {S};
   double* const dst[1] = {state + 5};
-  amp_store_sums<1>(v, a.part, dst, sh_d);
+  amp_store_sums<1>(v, a.part, dst, sh_d, amp_ticket(state));
 }
 
 __global__ void k_fwd_final(int nb, const double* __restrict__ hyp, double* __restrict__ state, double* __restrict__ amp) {
@@ -343,7 +345,7 @@ __global__ void __launch_bounds__(AMP_THREADS) k_jvp_apply(int nb, ScanGeom sg, 
   __syncthreads();
   const double v[1] = {dS};
   double* const dst[1] = {state + 7};
-  amp_store_sums<1>(v, a.part, dst, sh_d);
+  amp_store_sums<1>(v, a.part, dst, sh_d, amp_ticket(state));
 }
 
 __global__ void k_jvp_final(int nb, const double* __restrict__ hyp, const double* __restrict__ state,
@@ -374,7 +376,7 @@ __global__ void __launch_bounds__(AMP_THREADS) k_vjp_red1(int nb, const double* 
   __syncthreads();
   const double v[2] = {V * s1, s2};
   double* const dst[2] = {state + 8, state + 9};
-  amp_store_sums<2>(v, amp_ptrs(nb, nullptr, state).part, dst, sh_d);
+  amp_store_sums<2>(v, amp_ptrs(nb, nullptr, state).part, dst, sh_d, amp_ticket(state));
 }
 
 __global__ void __launch_bounds__(AMP_THREADS) k_vjp_red2(int nb, const double* __restrict__ geo, const double* __restrict__ hyp,
@@ -395,7 +397,7 @@ __global__ void __launch_bounds__(AMP_THREADS) k_vjp_red2(int nb, const double* 
   __syncthreads();
   const double v[2] = {s1, s2};
   double* const dst[2] = {state + 10, state + 11};
-  amp_store_sums<2>(v, a.part, dst, sh_d);
+  amp_store_sums<2>(v, a.part, dst, sh_d, amp_ticket(state));
 }
 
 __device__ __forceinline__ Seg vjp_elem(const AmpPtrs& a, int nb, int m, double sc_dot, int j) {
@@ -444,7 +446,7 @@ __global__ void __launch_bounds__(AMP_THREADS) k_vjp_apply(int nb, ScanGeom sg, 
   __syncthreads();
   const double v[2] = {s1, s2};
   double* const dst[2] = {state + 12, state + 13};
-  amp_store_sums<2>(v, a.part, dst, sh_d);
+  amp_store_sums<2>(v, a.part, dst, sh_d, amp_ticket(state));
 }
 
 __global__ void k_vjp_final(const double* __restrict__ hyp, const double* __restrict__ state, const double* __restrict__ abar,

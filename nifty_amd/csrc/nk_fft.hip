@@ -17,81 +17,7 @@
 // ------------------------------------------------------------------------------------------------
 #include <mutex>
 #include <vector>
-namespace {
-struct ProfRec {
-  hipEvent_t e0, e1;
-  int key;
-};
-bool g_prof_on = false;
-std::vector<ProfRec> g_prof_recs;
-std::vector<hipEvent_t> g_prof_pool;
-std::mutex g_prof_mu;
-constexpr size_t NK_PROF_MAX = 1 << 17;
-constexpr int NK_PROF_KEYS = 200;
-
-hipEvent_t prof_event() {
-  if (!g_prof_pool.empty()) {
-    hipEvent_t e = g_prof_pool.back();
-    g_prof_pool.pop_back();
-    return e;
-  }
-  hipEvent_t e;
-  if (hipEventCreate(&e) != hipSuccess) return nullptr;
-  return e;
-}
-struct ProfScope {
-  hipStream_t st;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  int key;
-  bool on;
-  ProfScope(hipStream_t s, int kernel, int pro, int epi) : st(s), key(kernel * 25 + pro * 5 + epi), on(g_prof_on) {
-    if (!on) return;
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (g_prof_recs.size() >= NK_PROF_MAX) {
-      on = false;
-      return;
-    }
-    e0 = prof_event();
-    e1 = prof_event();
-    if (!e0 || !e1) {
-      on = false;
-      return;
-    }
-    (void)hipEventRecord(e0, st);
-  }
-  ~ProfScope() {
-    if (!on) return;
-    (void)hipEventRecord(e1, st);
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_recs.push_back(ProfRec{e0, e1, key});
-  }
-};
-}  // namespace
-
-extern "C" int nk_profile_enable(int on) {
-  g_prof_on = on != 0;
-  return NK_OK;
-}
-
-// ms[200], count[200] indexed by kernel*25 + pro*5 + epi  (kernel: 0 pass1d, 1 passA, 2 passB, 3 passC, 4 passD,
-// sandwich pipeline: 5 contiguous first pass, 6 in-place middle-axis pass, 7 fused first-axis pass)
-extern "C" int nk_profile_collect(double* ms, int64_t* count) {
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (int i = 0; i < NK_PROF_KEYS; ++i) ms[i] = 0.0, count[i] = 0;
-  for (ProfRec& r : g_prof_recs) {
-    float t = 0.f;
-    hipError_t e = hipEventSynchronize(r.e1);
-    if (e == hipSuccess) e = hipEventElapsedTime(&t, r.e0, r.e1);
-    if (e == hipSuccess && r.key >= 0 && r.key < NK_PROF_KEYS) {
-      ms[r.key] += t;
-      count[r.key] += 1;
-    }
-    g_prof_pool.push_back(r.e0);
-    g_prof_pool.push_back(r.e1);
-  }
-  g_prof_recs.clear();
-  return NK_OK;
-}
+using ProfScope = NkProfScope;  // live per-kernel HIP events (nk_util.h)
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
@@ -140,7 +66,7 @@ __device__ __forceinline__ void nk_flush_wmax(const NkFuse& f, float wmax) {
   return;
 #endif
   if (f.w8max == nullptr || f.w8 == nullptr || f.epi != NK_EPI_VJP || f.value_slots <= 0) return;
-  for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_down(wmax, off, 64));
+  for (int off = 32; off > 0; off >>= 1) wmax = nk_wmax_join(wmax, __shfl_down(wmax, off, 64));  // NaN / inf survive
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t slot = (int64_t)blockIdx.x * ((blockDim.x + 63) >> 6) + wave;
   if (lane == 0 && slot < f.value_slots) f.w8max[slot] = (double)wmax;
@@ -809,13 +735,15 @@ __device__ __forceinline__ double nk_fold_block_sum(double v, double* red) {
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
   return s;
 }
+// maximum of non-negative values that propagates NaN (fmax would drop it)
+__device__ __forceinline__ double nk_max_nan(double a, double b) { return (a != a || b != b) ? (a != a ? a : b) : fmax(a, b); }
 __device__ __forceinline__ double nk_fold_block_max(double v, double* red) {
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  for (int off = 32; off > 0; off >>= 1) v = nk_max_nan(v, __shfl_down(v, off, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   double s = 0.0;
   if (threadIdx.x == 0)
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s = fmax(s, red[w]);
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s = nk_max_nan(s, red[w]);
   return s;
 }
 __global__ void __launch_bounds__(256) k_fold_max_a(const double* __restrict__ slots, int64_t n, double* __restrict__ part) {
@@ -823,7 +751,7 @@ __global__ void __launch_bounds__(256) k_fold_max_a(const double* __restrict__ s
   const int64_t per = (n + gridDim.x - 1) / gridDim.x;
   const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
   double v = 0.0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) v = fmax(v, slots[i]);
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) v = nk_max_nan(v, slots[i]);
   const double s = nk_fold_block_max(v, red);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
@@ -858,7 +786,7 @@ __global__ void __launch_bounds__(256) k_fold_both_a(const double* __restrict__ 
   const int64_t lo = (int64_t)b * per, hi = lo + per < n ? lo + per : n;
   double v = 0.0;
   if (is_max) {
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) v = fmax(v, slots[i]);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) v = nk_max_nan(v, slots[i]);
     const double s = nk_fold_block_max(v, red);
     if (threadIdx.x == 0) wpart[b] = s;
   } else {

@@ -814,6 +814,18 @@ NK_HD float nk_abs_up(double x) {
   return nextafterf((float)fabs(x), INFINITY);
 #endif
 }
+// running maximum of |x| that PROPAGATES NaN: for non-negative floats the order of the bit patterns is the order of the
+// values, and every NaN pattern lies above +inf -- an unsigned integer maximum of the bits (one VALU instruction, like
+// fmaxf) therefore carries a NaN or an infinity of the octant sums through to the scale of the fixed-point scatter,
+// which then answers with NaN instead of rounding them to finite garbage
+NK_HD float nk_wmax_join(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned int ua = __float_as_uint(a), ub = __float_as_uint(b);
+  return __uint_as_float(ua > ub ? ua : ub);
+#else
+  return (a != a || b != b) ? NAN : (a > b ? a : b);
+#endif
+}
 // per-group constants of the final epilogue (one slot, or one couple of slots)
 template <int NH>
 struct FinalGroup {
@@ -968,7 +980,7 @@ NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup
   if constexpr (EC == 2) {
     if (w8line) {
       w8line[k2] = ssum;
-      wmax = fmaxf(wmax, nk_abs_up(ssum));
+      wmax = nk_wmax_join(wmax, nk_abs_up(ssum));
     } else {
       NK_VJP_SCATTER(f, f.pidx[gp.okh[hv] + k2], ssum);
     }
@@ -1234,7 +1246,7 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
           }
           if (w8line) {
             w8line[k2] = ssum;
-            wmax = fmaxf(wmax, nk_abs_up(ssum));
+            wmax = nk_wmax_join(wmax, nk_abs_up(ssum));
           } else {
             NK_VJP_SCATTER(f, bin, ssum);
           }
@@ -1258,7 +1270,7 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
       }
     }
     *acc_out += acc;
-    if (wmax_out) *wmax_out = fmaxf(*wmax_out, wmax);
+    if (wmax_out) *wmax_out = nk_wmax_join(*wmax_out, wmax);
   });
 }
 

@@ -23,3 +23,30 @@ static inline bool nk_first_on_device(unsigned long long& mask) {
   mask |= bit;
   return true;
 }
+
+// Scratch of the deterministic (ticket-ordered) reductions of nk_vec.hip: block partials + ticket, one set per
+// (device, stream), allocated on first use and kept for the life of the process.  Launches on ONE stream are serialised
+// and leave the ticket at zero; launches on different streams / from different host threads use different scratch, so
+// the C ABI may be driven from several streams at once.
+constexpr int NK_RED_MAX = 4;          // reductions per launch
+constexpr int NK_RED_MAX_BLOCKS = 2048;  // workgroups per launch
+struct NkRedScratch {
+  double* partial;       // [NK_RED_MAX][NK_RED_MAX_BLOCKS]
+  unsigned int* ticket;  // zero between launches
+};
+int nk_red_scratch(hipStream_t st, NkRedScratch* out);
+
+// Live profiling for bench.py (nk_profile_enable / nk_profile_collect): a scope brackets ONE kernel launch with HIP events
+// on its launch stream.  key = kernel * 25 + pro * 5 + epi:
+//   kernel 0 pass1d, 1 passA, 2 passB, 3 passC, 4 passD; sandwich: 5 contiguous first pass, 6 in-place middle-axis pass,
+//   7 fused first-axis pass (pro / epi = prologue / epilogue class of the launch);
+//   kernel 8 = nk_csr_rowsum (pro = lanes class 0..3 for 1 / 4 / 16 / 64 lanes per row, epi = 0 weighted, 1 unweighted).
+constexpr int NK_PROF_KEYS = 250;
+struct NkProfScope {
+  hipStream_t st;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int key;
+  bool on;
+  NkProfScope(hipStream_t s, int kernel, int pro, int epi);
+  ~NkProfScope();
+};

@@ -91,15 +91,14 @@ __device__ __forceinline__ double nk_block_sum(double v) {
   return s;
 }
 
-// scratch of the deterministic reductions (per device: __device__ globals are instantiated on every GPU)
-static constexpr int NK_MAX_RED = 4;
-__device__ double g_red_partial[NK_MAX_RED * NK_MAX_BLOCKS];
-__device__ unsigned int g_red_ticket = 0;
+// scratch of the deterministic reductions: per (device, stream), see nk_red_scratch (nk_util.h)
+static_assert(NK_RED_MAX_BLOCKS >= NK_MAX_BLOCKS, "reduction scratch must cover the largest grid");
 
 // ---- generic "map with up to 4 inputs, 3 outputs and 3 reductions" skeleton ---------------------------
 // F::apply(const T* in[..] values, T* outs, double* red) is called per element.
 template <typename T, typename F, bool VEC>
-__global__ void __launch_bounds__(NK_VEC_THREADS) k_map(int64_t n, F f, int cu_max) {
+__global__ void __launch_bounds__(NK_VEC_THREADS) k_map(int64_t n, F f, int cu_max, NkRedScratch rs) {
+  static_assert(F::NRED <= NK_RED_MAX, "too many reductions for the scratch of nk_red_scratch");
   constexpr int V = VEC ? VecOf<T>::N : 1;
   double red[F::NRED > 0 ? F::NRED : 1];
 #pragma unroll
@@ -133,16 +132,16 @@ __global__ void __launch_bounds__(NK_VEC_THREADS) k_map(int64_t n, F f, int cu_m
     // them up in block order with a fixed tree and updates result[].  Identical inputs therefore give identical
     // bits on every launch and on every GPU of a node (the grid is a function of n only) -- the replicated CG /
     // line-search scalars of a multi-rank KL minimisation agree without any exchange.  The scratch belongs to the
-    // device; launches on one stream are serialised, and every launch leaves the ticket at zero.
+    // (device, stream) pair of the launch; launches on one stream are serialised, and every launch leaves the ticket at zero.
     __shared__ bool is_last;
 #pragma unroll
     for (int r = 0; r < F::NRED; ++r) {
       const double s = nk_block_sum(red[r]);
-      if (threadIdx.x == 0) g_red_partial[r * NK_MAX_BLOCKS + blockIdx.x] = s;
+      if (threadIdx.x == 0) rs.partial[r * NK_RED_MAX_BLOCKS + blockIdx.x] = s;
     }
     if (threadIdx.x == 0) {
       __threadfence();
-      is_last = atomicAdd(&g_red_ticket, 1u) == gridDim.x - 1;
+      is_last = atomicAdd(rs.ticket, 1u) == gridDim.x - 1;
     }
     __syncthreads();
     if (is_last) {
@@ -151,11 +150,11 @@ __global__ void __launch_bounds__(NK_VEC_THREADS) k_map(int64_t n, F f, int cu_m
       for (int r = 0; r < F::NRED; ++r) {
         double v = 0.0;
         for (int b = threadIdx.x; b < (int)gridDim.x; b += NK_VEC_THREADS)
-          v += __builtin_nontemporal_load(&g_red_partial[r * NK_MAX_BLOCKS + b]);
+          v += __builtin_nontemporal_load(&rs.partial[r * NK_RED_MAX_BLOCKS + b]);
         const double s = nk_block_sum(v);
         if (threadIdx.x == 0) f.result[r] += s;
       }
-      if (threadIdx.x == 0) g_red_ticket = 0;
+      if (threadIdx.x == 0) *rs.ticket = 0;
     }
   }
 }
@@ -180,6 +179,11 @@ static int nk_launch_map(int64_t n, const F& f, bool aligned, hipStream_t st, co
   if (n <= 0) return NK_OK;
   static const int cu_env = nk_vec_env_int("NK_VEC_CU", 0);  // developer sweep: chunk length in units of 256 vectors
   const int cu_max = cu_env > 0 ? cu_env : NkChunkUnits<F>::value;
+  NkRedScratch rs{nullptr, nullptr};
+  if (F::NRED > 0) {
+    const int rc = nk_red_scratch(st, &rs);
+    if (rc != NK_OK) return rc;
+  }
   // kernels with reductions pay a fixed tail per workgroup (block sums, fence, ticket, ~2 us each, a few rounds of them
   // per CU): below ~10^8 elements that tail, not the streaming part, sets the time.  Their grid therefore gives every
   // thread >= 32 vectors (>= 64 from 512 workgroups on) before it grows to the full 2048 -- 2^22 fp64: nk_cg_update
@@ -188,10 +192,10 @@ static int nk_launch_map(int64_t n, const F& f, bool aligned, hipStream_t st, co
   if (aligned) {
     const int64_t nvec = n / VecOf<T>::N;
     const int grid = F::NRED > 0 ? nk_grid_red(nvec) : nk_grid(nvec > 0 ? nvec : 1);
-    hipLaunchKernelGGL((k_map<T, F, true>), dim3(grid), dim3(NK_VEC_THREADS), 0, st, n, f, cu_max);
+    hipLaunchKernelGGL((k_map<T, F, true>), dim3(grid), dim3(NK_VEC_THREADS), 0, st, n, f, cu_max, rs);
   } else {
     const int grid = F::NRED > 0 ? nk_grid_red(n) : nk_grid(n);
-    hipLaunchKernelGGL((k_map<T, F, false>), dim3(grid), dim3(NK_VEC_THREADS), 0, st, n, f, cu_max);
+    hipLaunchKernelGGL((k_map<T, F, false>), dim3(grid), dim3(NK_VEC_THREADS), 0, st, n, f, cu_max, rs);
   }
   return nk_check_launch(what);
 }
@@ -947,16 +951,22 @@ __global__ void __launch_bounds__(256)
                            const int32_t* __restrict__ bin_k2, int nb, int64_t pstride, double* __restrict__ partial,
                            const double* __restrict__ w8max) {
   __shared__ unsigned long long acc[NK_SHELL_BINS];
+  __shared__ unsigned int npoints;
   const int j = blockIdx.x / NK_SHELL_SPLITS, s = blockIdx.x % NK_SHELL_SPLITS;
   const int bin0 = j * NK_SHELL_BINS;
   const int nbin = min(NK_SHELL_BINS, nb - bin0);
   for (int i = threadIdx.x; i < NK_SHELL_BINS; i += blockDim.x) acc[i] = 0ull;
+  if (threadIdx.x == 0) npoints = 0u;
   __syncthreads();
-  // scale 2^(44 - e) with 2^e >= max |w8| > 0 (frexp: max = m * 2^e, 0.5 <= m < 1); all-zero input: scale irrelevant
+  // scale 2^(44 - e) with 2^e >= max |w8| > 0 (frexp: max = m * 2^e, 0.5 <= m < 1); all-zero input: scale irrelevant.
+  // A NaN or an infinity among the octant sums arrives here as a non-finite maximum (the final pass joins the maxima
+  // with a NaN-propagating rule): the bins are then NaN -- loud -- instead of rounded garbage.
   const double gmax = *w8max;
+  const bool finite = gmax <= 1.79769313486231570815e308;  // false for NaN and +inf
   int e = 0;
-  if (gmax > 0.0) (void)frexp(gmax, &e);
+  if (finite && gmax > 0.0) (void)frexp(gmax, &e);
   const double scale = ldexp(1.0, 44 - e), inv = ldexp(1.0, e - 44);
+  unsigned int mine = 0u;
   const int klo = bin_k2[bin0];
   const int khi = bin0 + NK_SHELL_BINS < nb ? bin_k2[bin0 + NK_SHELL_BINS] : 0x7fffffff;
   const int hc2 = (o.Ch - 1) * (o.Ch - 1);
@@ -989,17 +999,28 @@ __global__ void __launch_bounds__(256)
       }
 #pragma unroll
       for (int u = 0; u < NU; ++u)
-        if (cc[u] < ce[u]) atomicAdd(&acc[pb[u] - bin0], (unsigned long long)__double2ll_rn(v[u] * scale));
+        if (cc[u] < ce[u]) {
+          atomicAdd(&acc[pb[u] - bin0], (unsigned long long)__double2ll_rn(v[u] * scale));
+          ++mine;
+        }
       // rare: runs longer than 16 points
 #pragma unroll
       for (int u = 0; u < NU; ++u)
-        for (int c = cc[u] + 16; c < ce[u]; c += 16)
+        for (int c = cc[u] + 16; c < ce[u]; c += 16) {
           atomicAdd(&acc[pl[u][c] - bin0], (unsigned long long)__double2ll_rn(wl[u][c] * scale));
+          ++mine;
+        }
     }
   }
+  atomicAdd(&npoints, mine);
   __syncthreads();
+  // overflow guard: < 2^18 points of magnitude <= 2^e per workgroup keep |sum| < 2^62 quanta.  Callers pick this kernel
+  // only for grids whose busiest (shell, split) is below that (nifty_amd counts it exactly at model set-up); a grid that
+  // breaks the bound anyway gets NaN, never a wrapped sum.
+  const bool ok = finite && npoints < (1u << 18);
   double* dst = partial + (int64_t)s * pstride + bin0;
-  for (int i = threadIdx.x; i < nbin; i += blockDim.x) dst[i] = (double)(long long)acc[i] * inv;
+  for (int i = threadIdx.x; i < nbin; i += blockDim.x)
+    dst[i] = ok ? (double)(long long)acc[i] * inv : __longlong_as_double(0x7ff8000000000000LL);
 }
 
 extern "C" int nk_octant_scatter_k2(int ndim, const int64_t* shape, const double* w8, const int32_t* pidx,
@@ -1034,21 +1055,36 @@ extern "C" int nk_octant_scatter_k2(int ndim, const int64_t* shape, const double
 
 // ---- sparse response (LOSResponse, reference library/los_response.py:144-253): CSR with int32 columns and
 //      float32 weights (the reference stores float32 weights too, :196), fp64 accumulation ------------------
-// y[i] = sum_j wgt[j] * x[col[j]]  over rowptr[i] <= j < rowptr[i+1]; one wavefront per row
-template <typename T>
-__global__ void k_spmv(int64_t nrows, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                       const float* __restrict__ wgt, const T* __restrict__ x, T* __restrict__ y) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= nrows) return;
-  const int64_t lo = rowptr[row], hi = rowptr[row + 1];
+// y[i] = sum_j (wgt ? wgt[j] : 1) * x[col[j]]  over rowptr[i] <= j < rowptr[i+1].  LANES lanes share a row (1, 4, 16 or 64):
+// lane l adds the entries l, l + LANES, ... in ascending order, then a fixed shuffle tree joins the lanes -- the
+// summation order is a function of the matrix only: bit-reproducible, no atomics.  This one kernel serves
+//   * LOSResponse TIMES (one wavefront per line of sight, thousands of pixels per row),
+//   * LOSResponse ADJOINT_TIMES through the TRANSPOSED matrix built once at set-up (one thread per pixel, a few lines
+//     each) instead of fp64 atomics into a zeroed image,
+//   * every scatter-add of a STATIC index map (DOFDistributor / PowerDistributor ADJOINT_TIMES, partial contractions,
+//     the octant sums of grids without the shell structure): rows = bins, col = the bin-sorted permutation, wgt = NULL.
+template <typename T, int LANES>
+__global__ void __launch_bounds__(256) k_csr_rowsum(int64_t nrows, const int64_t* __restrict__ rowptr,
+                                                    const int32_t* __restrict__ col, const float* __restrict__ wgt,
+                                                    const T* __restrict__ x, T* __restrict__ y) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = gid / LANES;
+  const int lane = (int)(gid % LANES);
+  int64_t lo = 0, hi = 0;
+  if (row < nrows) lo = rowptr[row], hi = rowptr[row + 1];
   double acc = 0.0;
-  for (int64_t j = lo + lane; j < hi; j += 64) acc += (double)wgt[j] * (double)x[col[j]];
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if (lane == 0) y[row] = (T)acc;
+  if (wgt) {
+    for (int64_t j = lo + lane; j < hi; j += LANES) acc += (double)wgt[j] * (double)x[col[j]];
+  } else {
+    for (int64_t j = lo + lane; j < hi; j += LANES) acc += (double)x[col[j]];
+  }
+#pragma unroll
+  for (int off = LANES / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, LANES);
+  if (lane == 0 && row < nrows) y[row] = (T)acc;
 }
 
-// x[col[j]] += wgt[j] * y[i]: adjoint of the above by atomics on a pre-zeroed x (rows overlap arbitrarily)
+// x[col[j]] += wgt[j] * y[i]: adjoint by atomics on a pre-zeroed x (rows overlap arbitrarily).  Kept for matrices whose
+// transpose the caller does not hold; the sums then depend on the order of the atomics in the last bit.
 template <typename T>
 __global__ void k_spmv_t(int64_t nrows, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                          const float* __restrict__ wgt, const T* __restrict__ y, double* __restrict__ x) {
@@ -1060,16 +1096,39 @@ __global__ void k_spmv_t(int64_t nrows, const int64_t* __restrict__ rowptr, cons
   for (int64_t j = lo + lane; j < hi; j += 64) atomicAdd(x + col[j], (double)wgt[j] * yv);
 }
 
+template <typename T, int LANES>
+static int nk_launch_rowsum(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, const void* x, void* y,
+                            hipStream_t st) {
+  const int64_t blocks = (nrows * LANES + 255) / 256;
+  if (blocks > 0x7fffffffLL) return nk_set_error(NK_ERR_UNSUPPORTED, "nk_csr_rowsum: too many rows for one launch");
+  hipLaunchKernelGGL((k_csr_rowsum<T, LANES>), dim3((unsigned)blocks), dim3(256), 0, st, nrows, rowptr, col, wgt, (const T*)x,
+                     (T*)y);
+  return nk_check_launch("k_csr_rowsum");
+}
+
+extern "C" int nk_csr_rowsum(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, const void* x, void* y,
+                             int dtype, int lanes, void* stream) {
+  if (nrows < 0 || !rowptr || (nrows > 0 && (!x || !y || !col)))
+    return nk_set_error(NK_ERR_INVALID, "nk_csr_rowsum: bad argument");
+  if (lanes != 1 && lanes != 4 && lanes != 16 && lanes != 64)
+    return nk_set_error(NK_ERR_INVALID, "nk_csr_rowsum: lanes must be 1, 4, 16 or 64");
+  if (nrows == 0) return NK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  NkProfScope ps(st, 8, lanes == 1 ? 0 : lanes == 4 ? 1 : lanes == 16 ? 2 : 3, wgt ? 0 : 1);
+  NK_DISPATCH_DTYPE(dtype, {
+    switch (lanes) {
+      case 1: return nk_launch_rowsum<T, 1>(nrows, rowptr, col, wgt, x, y, st);
+      case 4: return nk_launch_rowsum<T, 4>(nrows, rowptr, col, wgt, x, y, st);
+      case 16: return nk_launch_rowsum<T, 16>(nrows, rowptr, col, wgt, x, y, st);
+      default: return nk_launch_rowsum<T, 64>(nrows, rowptr, col, wgt, x, y, st);
+    }
+  })
+}
+
 extern "C" int nk_spmv(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, const void* x, void* y,
                        int dtype, void* stream) {
-  if (nrows < 0 || !rowptr || (nrows > 0 && (!x || !y))) return nk_set_error(NK_ERR_INVALID, "nk_spmv: bad argument");
-  if (nrows == 0) return NK_OK;
-  const unsigned blocks = (unsigned)((nrows + 3) / 4);
-  NK_DISPATCH_DTYPE(dtype, {
-    hipLaunchKernelGGL(k_spmv<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nrows, rowptr, col, wgt, (const T*)x,
-                       (T*)y);
-  })
-  return nk_check_launch("k_spmv");
+  if (!wgt && nrows > 0) return nk_set_error(NK_ERR_INVALID, "nk_spmv: bad argument");
+  return nk_csr_rowsum(nrows, rowptr, col, wgt, x, y, dtype, 64, stream);
 }
 
 extern "C" int nk_spmv_t(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, const void* y,

@@ -257,20 +257,26 @@ class LatentVec:
 class LinPoint:
     """Everything cached about one latent point: amplitude tables and the s-space metric weight."""
 
-    __slots__ = ("x", "amp", "afield", "state", "mid", "mid_scalar", "value", "grad", "f", "tf")
+    __slots__ = ("x", "amp", "afield", "state", "mid", "mid_scalar", "value", "grad", "f", "tf", "gp", "wd", "tfd")
 
     def __init__(self):
         self.mid = None
         self.afield = None
         self.mid_scalar = 1.0
+        self.gp = self.wd = self.tfd = None  # response models: g'(s) [grid], data-space metric weight, df/dmu [data]
 
 
 class FusedModel:
-    """offset + HT(a[pindex] xi) -> nonlinearity -> Gaussian / Poisson likelihood, plus the standard prior."""
+    """offset + HT(a[pindex] xi) -> nonlinearity [-> linear response] -> Gaussian / Poisson likelihood, plus the standard
+    prior.  ``response`` (optional): a sparse linear map signal space -> data space with ``times`` / ``adjoint`` /
+    ``n_data`` (los_response.SparseResponse: masked LOSResponse, BASELINE config 4); the likelihood then lives on the
+    n_data-sized data space, and a metric application is JVP transform (x g'), R, data-space weight, R^T, (x g') VJP
+    transform -- two three-pass transforms and two nk_csr_rowsum launches."""
 
     def __init__(self, shape, distances=None, *, offset_mean=0.0, offset_std=(1e-1, 3e-2), fluctuations=(1.0, 5e-1),
                  loglogavgslope=(-3.0, 2e-1), flexibility=(1.0, 2e-1), asperity=(5e-1, 5e-2),
-                 likelihood="gaussian", data=None, icov=1.0, nonlin=None, dtype=torch.float64, device="cuda:0"):
+                 likelihood="gaussian", data=None, icov=1.0, nonlin=None, response=None, dtype=torch.float64,
+                 device="cuda:0"):
         L.load()  # fail loudly without the HIP extension
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -346,26 +352,40 @@ class FusedModel:
             # natural binning on an equal-distance grid: bins are the ascending distinct integer k^2, which lets the
             # octant sums be reduced shell by shell in LDS (nk_octant_scatter_k2) instead of with global atomics
             self.bin_k2 = None
-            # 2-D (and 1-D): the quadrant points sorted by bin, once -- every bin is then summed by one thread in a fixed
-            # order (nk_segment_sum) instead of with global fp64 atomics (NK_SEGMENT_SUM=0: atomics)
-            self.seg_perm = self.seg_rowptr = None
-            if self.octant_vjp and len(self.shape) < 3 and os.environ.get("NK_SEGMENT_SUM", "1") != "0":
-                self.seg_perm = torch.argsort(self.pidx8, stable=True).to(torch.int32)
-                counts = torch.bincount(self.pidx8.long(), minlength=self.nb)
-                self.seg_rowptr = torch.zeros(self.nb + 1, dtype=torch.int32, device=self.device)
-                self.seg_rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
-            # (3-D only: on a 2-D quadrant plain atomics win, 2048^2: 49 vs 78 us, 4096^2: 184 vs 318 us --
+            # grids without the shell structure below (2-D, 1-D, non-natural binning, unequal distances): the octant points
+            # sorted by bin, once -- every bin is then summed in a fixed order by nk_csr_rowsum instead of with global fp64
+            # atomics (NK_SEGMENT_SUM=0: atomics, for A/B)
+            self.seg_plan = None
+            # (3-D only: on a 2-D quadrant plain atomics win over the shell walk, 2048^2: 49 vs 78 us, 4096^2: 184 vs 318 us --
             # tools/gpu_scatter2d_probe.py)
             if self.octant_vjp and len(self.shape) == 3 and ps._data.get("k2table") is not None and max(self.shape) >= 64:
                 k2 = np.nonzero(hsp._k2_flags())[0].astype(np.int32)
                 if len(k2) == nb and int(k2[-1]) < (1 << 24):
                     self.bin_k2 = torch.from_numpy(k2).to(self.device)
+            # fixed-point accumulation of the shell scatter: a workgroup = (shell of 4096 bins, first-axis index mod 16) must
+            # add < 2^18 points (overflow bound of the 64-bit sums) -- counted exactly here, once (a cube heuristic missed
+            # anisotropic grids); beyond the bound the floating-point LDS atomics take over
+            self.scatter_fixed_point = False
+            if self.bin_k2 is not None:
+                a_idx = torch.arange(self.shape[0] // 2 + 1, device=self.device, dtype=torch.int64)
+                key = (self.pidx8.view(self.shape[0] // 2 + 1, -1) // 4096).to(torch.int64) * 16 + (a_idx % 16)[:, None]
+                self.scatter_busiest = int(torch.bincount(key.reshape(-1)).max().item())
+                self.scatter_fixed_point = self.scatter_busiest < (1 << 18)
+                del key, a_idx
+            if self.octant_vjp and self.bin_k2 is None and os.environ.get("NK_SEGMENT_SUM", "1") != "0":
+                self.seg_plan = B.bin_plan(self.pidx8, self.nb)
         # likelihood
         if likelihood not in ("gaussian", "poisson"):
             raise ValueError("likelihood must be 'gaussian' or 'poisson'")
         self.lh_kind = L.LH_GAUSS if likelihood == "gaussian" else L.LH_POISSON
         self.nonlin = _NONLIN[nonlin]
         self.icov_field, self.icov_scalar = None, 1.0
+        self.response = response
+        self.data_shape = self.shape if response is None else (int(response.n_data),)
+        if response is not None:
+            if int(response.n_pix) != self.N:
+                raise ValueError("response does not act on this grid")
+            self.sandwich = self.fused_direction = False  # the middle of J^T M J is not diagonal in position space
         if data is not None:
             self.set_data(data, icov)
         self.counters = dict(value_grad=0, metric=0, transforms=0, cg_iterations=0)
@@ -373,7 +393,7 @@ class FusedModel:
     # -- data ---------------------------------------------------------------------------------
     def set_data(self, data, icov=1.0):
         data = torch.as_tensor(data)
-        if tuple(data.shape) != self.shape:
+        if tuple(data.shape) != self.data_shape:
             raise ValueError("data shape mismatch")
         if self.lh_kind == L.LH_POISSON:
             if data.dtype.is_floating_point:
@@ -387,7 +407,10 @@ class FusedModel:
                 self.icov_scalar, self.icov_field = float(icov), None
             else:
                 self.icov_field = torch.as_tensor(icov).to(self.tdtype).to(self.device).contiguous()
-        self.const_mid = self.lh_kind == L.LH_GAUSS and self.nonlin == L.NL_ID and self.icov_field is None
+        self.const_mid = (self.lh_kind == L.LH_GAUSS and self.nonlin == L.NL_ID and self.icov_field is None
+                          and self.response is None)
+        # data-space metric weight of a Gaussian with scalar N^-1: a number, not a field (response models)
+        self.const_wd = self.lh_kind == L.LH_GAUSS and self.icov_field is None
 
     # -- kernels --------------------------------------------------------------------------------
     def _amp_forward(self, small):
@@ -462,18 +485,20 @@ class FusedModel:
         if self.octant_vjp:
             # the final pass stores one merged sum per octant point; nk_octant_scatter reduces them into the bins
             f.abar, f.w8 = self.abar.data_ptr(), self.w8.data_ptr()
-            if self.bin_k2 is not None:  # max |w8| of this launch: the scale of the fixed-point shell scatter
+            if self.scatter_fixed_point:  # max |w8| of this launch: the scale of the fixed-point shell scatter
                 f.w8max = self.w8max.data_ptr()
             run(f)
             shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
             if self.bin_k2 is not None:
                 L.check(L.load().nk_octant_scatter_k2(len(self.shape), shp, self.w8.data_ptr(), self.pidx.data_ptr(),
                                                       self.bin_k2.data_ptr(), self.nb, self.scatter_scratch.data_ptr(),
-                                                      self.abar.data_ptr(), self.w8max.data_ptr(), B._stream()),
+                                                      self.abar.data_ptr(),
+                                                      self.w8max.data_ptr() if self.scatter_fixed_point else 0, B._stream()),
                         "nk_octant_scatter_k2")
-            elif self.seg_perm is not None:
-                L.check(L.load().nk_segment_sum(self.nb, self.seg_rowptr.data_ptr(), self.seg_perm.data_ptr(),
-                                                self.w8.data_ptr(), self.abar.data_ptr(), 0, B._stream()), "nk_segment_sum")
+            elif self.seg_plan is not None:
+                rowptr, perm, lanes = self.seg_plan
+                L.check(L.load().nk_csr_rowsum(self.nb, rowptr.data_ptr(), perm.data_ptr(), 0, self.w8.data_ptr(),
+                                               self.abar.data_ptr(), L.NK_F64, lanes, B._stream()), "nk_csr_rowsum")
             else:
                 self.abar.zero_()
                 L.check(L.load().nk_octant_scatter(len(self.shape), shp, self.w8.data_ptr(), self.pidx.data_ptr(),
@@ -504,6 +529,8 @@ class FusedModel:
         w = 1.0 / n_total
         value = torch.zeros(1, dtype=torch.float64, device=self.device) if value_acc is None else value_acc
         lhval = torch.zeros(1, dtype=torch.float64, device=self.device)
+        if self.response is not None:
+            return self._linearize_response(lp, x, grad_acc, w, value, lhval)
         f = self._fuse()
         f.pro, f.in_, f.pidx, f.amp = L.PRO_AMP, x.xi.data_ptr(), self.pidx.data_ptr(), lp.amp.data_ptr()
         f.afield = lp.afield.data_ptr()
@@ -517,10 +544,14 @@ class FusedModel:
         f.data, f.icov, f.icov_scalar, f.value = self.data.data_ptr(), B.ptr(self.icov_field), self.icov_scalar, lhval.data_ptr()
         B.hartley_fused(self.plan, f)
         self.counters["transforms"] += 1
+        return self._finish_linearize(lp, x, gs, None, grad_acc, w, value, lhval)
+
+    def _finish_linearize(self, lp, x, gs, gs2, grad_acc, w, value, lhval):
+        """Gradient J^T (gs * gs2) + x and the value lh + 1/2 x.x, accumulated with weight w."""
         # gradient: J^T gs + x
         first = grad_acc is None
         grad = LatentVec(torch.empty_like(x.xi), None) if first else grad_acc
-        self._vjp(lp, gs, w, x.xi, w, not first, grad.xi)
+        self._vjp(lp, gs, w, x.xi, w, not first, grad.xi, w2=gs2)
         self._amp_vjp(lp)
         # (abar, hence latbar, already carries the 1/n_total weight)
         if first:
@@ -536,6 +567,56 @@ class FusedModel:
         self.counters["value_grad"] += 1
         return lp
 
+    # -- models with a linear response between the signal and the data (BASELINE config 4) -------------------------
+    def _forward_nonlin(self, lp, x, g_out):
+        """g(s) -> g_out and g'(s) -> lp.gp for s = offset + HT(a xi): one transform with the pointwise epilogue."""
+        f = self._fuse()
+        f.pro, f.in_, f.pidx, f.amp = L.PRO_AMP, x.xi.data_ptr(), self.pidx.data_ptr(), lp.amp.data_ptr()
+        f.afield = lp.afield.data_ptr()
+        lp.gp = torch.empty(self.shape, dtype=self.tdtype, device=self.device)
+        f.epi, f.out, f.out2, f.offset, f.nonlin = L.EPI_NONLIN, g_out.data_ptr(), lp.gp.data_ptr(), self.offset_mean, self.nonlin
+        B.hartley_fused(self.plan, f)
+        self.counters["transforms"] += 1
+
+    def _weigh_data(self, u, lp):
+        """u * M_d (data-space Fisher metric: N^-1, or 1/mu for counts)."""
+        if self.const_wd:
+            return B.axpby(self.icov_scalar, u)
+        return B.binary(L.OP_MUL, u, self.icov_field if self.lh_kind == L.LH_GAUSS else lp.wd)
+
+    def _linearize_response(self, lp, x, grad_acc, w, value, lhval):
+        """energy_operators.py:517-595 / :617-640 composed with R o g o cf: mu = R g(s) lives on the data space."""
+        self._forward_nonlin(lp, x, self.tmp)
+        mu = self.response.times(self.tmp)
+        if self.lh_kind == L.LH_GAUSS:
+            r = B.axpby(1.0, mu, -1.0, self.data)
+            ir = self._weigh_data(r, lp)
+            B.vdot(r, ir, result=lhval, accumulate=False)
+            B.axpby(0.5, lhval, out=lhval)
+        else:
+            dat = self.data.to(self.tdtype)
+            B.vsum(mu, result=lhval, accumulate=False)
+            ld = B.vdot(B.pointwise("log", mu), dat)
+            B.axpby(1.0, lhval, -1.0, ld, out=lhval)
+            lp.wd = B.pointwise("reciprocal", mu)
+            ir = B.binary(L.OP_SUB, 1.0, B.binary(L.OP_MUL, dat, lp.wd))  # 1 - d / mu
+        gs = self.response.adjoint(ir, self.shape)
+        return self._finish_linearize(lp, x, gs, lp.gp, grad_acc, w, value, lhval)
+
+    def _jvp_response(self, lp, d, cg_direction=None):
+        """R (g'(s) . J_cf d): latent tangent -> data space (one transform, one row-sum launch)."""
+        L.check(L.load().nk_amp_jvp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(),
+                                    lp.state.data_ptr(), d.small.data_ptr(), self.damp.data_ptr(), B._stream()), "nk_amp_jvp")
+        self._amp_field(self.damp, out=self.dafield)
+        f = self._fuse()
+        f.pro, f.in_, f.in2 = L.PRO_AMP_JVP, d.xi.data_ptr(), lp.x.xi.data_ptr()
+        f.pidx, f.amp, f.damp = self.pidx.data_ptr(), lp.amp.data_ptr(), self.damp.data_ptr()
+        f.afield, f.dafield = B.ptr(lp.afield), self.dafield.data_ptr()
+        f.epi, f.out, f.mul, f.mul_scalar = L.EPI_MUL, self.tmp.data_ptr(), lp.gp.data_ptr(), 1.0
+        B.hartley_fused(self.plan, f)
+        self.counters["transforms"] += 1
+        return self.response.times(self.tmp)
+
     def lh_metric_accumulate(self, lp, d, out, scale, first, identity=0.0, dot_out=None, cg_direction=None):
         """out (+)= scale * J^T M J d  (+ identity * d): the likelihood Fisher metric pulled back to latent space;
         the optional multiple of d (prior metric = 1) rides along in the VJP epilogue of the xi part.
@@ -543,6 +624,11 @@ class FusedModel:
         updated by the caller: CgWorkspace.direction_small); the workspace scalars are rolled afterwards."""
         if cg_direction is not None and not self.fused_direction:
             raise ValueError("cg_direction needs the sandwich pipeline (FusedModel.fused_direction)")
+        if self.response is not None:
+            wsig = self.response.adjoint(self._weigh_data(self._jvp_response(lp, d), lp), self.shape)
+            self._vjp(lp, wsig, scale, d.xi if identity else None, identity, not first, out.xi, dot_out=dot_out, w2=lp.gp)
+            self._finish_metric(lp, d, out, first, identity)
+            return
         L.check(L.load().nk_amp_jvp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(),
                                     lp.state.data_ptr(), d.small.data_ptr(), self.damp.data_ptr(), B._stream()), "nk_amp_jvp")
         # da[pindex] is expanded to an octant field once per application (1/8 of the gathers, 0.72 ms at 1024^3 fp32).
@@ -578,6 +664,9 @@ class FusedModel:
             B.hartley_fused(self.plan, f)
             self._vjp(lp, self.tmp, scale, d.xi if identity else None, identity, not first, out.xi, dot_out=dot_out)
             self.counters["transforms"] += 1
+        self._finish_metric(lp, d, out, first, identity)
+
+    def _finish_metric(self, lp, d, out, first, identity):
         self._amp_vjp(lp)
         if first:
             out.small = B.axpby(1.0, self.latbar, identity, d.small) if identity else B.axpby(1.0, self.latbar)
@@ -607,6 +696,17 @@ class FusedModel:
         lp.x = x
         lp.amp, lp.state = self._amp_forward(x.small)
         lp.afield = self._amp_field(lp.amp)
+        if self.response is not None:
+            # f = N^{-1/2} mu or 2 sqrt(mu) on the data space; J_f = diag(tfd) R diag(g') J_cf
+            self._forward_nonlin(lp, x, self.tmp)
+            mu = self.response.times(self.tmp)
+            if self.lh_kind == L.LH_GAUSS:
+                lp.tfd = math.sqrt(self.icov_scalar) if self.icov_field is None else B.pointwise("sqrt", self.icov_field)
+                lp.f = B.axpby(lp.tfd, mu) if self.icov_field is None else B.binary(L.OP_MUL, mu, lp.tfd)
+            else:
+                rt = B.pointwise("sqrt", mu)
+                lp.f, lp.tfd = B.axpby(2.0, rt), B.pointwise("reciprocal", rt)
+            return lp
         f = self._fuse()
         f.pro, f.in_, f.pidx, f.amp = L.PRO_AMP, x.xi.data_ptr(), self.pidx.data_ptr(), lp.amp.data_ptr()
         f.afield = lp.afield.data_ptr()
@@ -629,6 +729,9 @@ class FusedModel:
 
     def jvp_data(self, lp, d, out=None):
         """J_f(lp.x) d = tf * dvol_h HT(a dxi + da xi): latent tangent -> data space."""
+        if self.response is not None:
+            u = self._jvp_response(lp, d)
+            return B.axpby(lp.tfd, u, out=out) if np.isscalar(lp.tfd) else B.binary(L.OP_MUL, u, lp.tfd, out=out)
         L.check(L.load().nk_amp_jvp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(),
                                     lp.state.data_ptr(), d.small.data_ptr(), self.damp.data_ptr(), B._stream()), "nk_amp_jvp")
         f = self._fuse()
@@ -646,7 +749,11 @@ class FusedModel:
     def vjp_data(self, lp, w, addend=None):
         """J_f(lp.x)^T w (+ addend): data space -> latent cotangent."""
         out = LatentVec(torch.empty_like(lp.x.xi), None)
-        self._vjp(lp, w, 1.0, None if addend is None else addend.xi, 1.0, False, out.xi, w2=lp.tf)
+        w2 = lp.tf
+        if self.response is not None:
+            u = B.axpby(lp.tfd, w) if np.isscalar(lp.tfd) else B.binary(L.OP_MUL, w, lp.tfd)
+            w, w2 = self.response.adjoint(u, self.shape), lp.gp
+        self._vjp(lp, w, 1.0, None if addend is None else addend.xi, 1.0, False, out.xi, w2=w2)
         self._amp_vjp(lp)
         out.small = B.axpby(1.0, self.latbar) if addend is None else B.axpby(1.0, self.latbar, 1.0, addend.small)
         return out
@@ -674,6 +781,22 @@ class FusedModel:
 
     def draw_lh_noise(self, lp, device_rng=None):
         """J^T M_d^{1/2} eta with eta ~ N(0,1) in data space."""
+        if self.response is not None:
+            dshape = self.data_shape
+            if device_rng is not None:
+                eta = torch.randn(dshape, dtype=self.tdtype, device=self.device, generator=device_rng)
+                if self.const_wd:
+                    eta = B.axpby(math.sqrt(self.icov_scalar), eta)
+            else:
+                eta = random.Random.normal_on_device(self.npdtype, dshape, 0.0,
+                                                     math.sqrt(self.icov_scalar) if self.const_wd else 1.0, self.device)
+            if not self.const_wd:
+                eta = B.binary(L.OP_MUL, eta, B.pointwise("sqrt", self.icov_field if self.lh_kind == L.LH_GAUSS else lp.wd))
+            out = LatentVec(torch.empty(self.shape, dtype=self.tdtype, device=self.device), None)
+            self._vjp(lp, self.response.adjoint(eta, self.shape), 1.0, None, 0.0, False, out.xi, w2=lp.gp)
+            self._amp_vjp(lp)
+            out.small = B.axpby(1.0, self.latbar)
+            return out
         if device_rng is not None:
             eta = torch.randn(self.shape, dtype=self.tdtype, device=self.device, generator=device_rng)
             if self.const_mid:

@@ -4,8 +4,9 @@
 grid; the path length inside each pixel -- optionally weighted by the survival function of a Gaussian
 uncertainty of the inverse distance -- becomes one entry of a sparse ``n_los x n_pix`` matrix (float32
 weights, int32 indices as in the reference, :194-197).  TIMES = SpMV, ADJOINT_TIMES = SpMV^T.  The set-up runs
-on the host in numpy (as in the reference); on a GPU the products run in libniftyk (``nk_spmv``/``nk_spmv_t``),
-on the host through scipy.sparse.
+on the host in numpy (as in the reference); on a GPU both products run in libniftyk as row sums of a CSR matrix
+(``nk_csr_rowsum``: the matrix for TIMES, its transpose -- built once on the host -- for ADJOINT_TIMES, so every
+output is summed in a fixed order without atomics), on the host through scipy.sparse.
 """
 import numpy as np
 import torch
@@ -116,6 +117,7 @@ class LOSResponse(LinearOperator):
         self._nlos = len(self._rowptr) - 1
         self._target = DomainTuple.make(UnstructuredDomain(self._nlos))
         self._host = None
+        self._host_t = None
         self._dev = {}
 
     def _host_matrix(self):
@@ -125,23 +127,85 @@ class LOSResponse(LinearOperator):
             self._host = csr_matrix((self._wgt, self._col, self._rowptr), shape=(self._nlos, self._domain.size))
         return self._host
 
-    def _device_arrays(self, device):
-        key = str(device)
+    def _transposed(self):
+        """CSR arrays of R^T (rows = pixels; the entries of a pixel in ascending line order: scipy's csr -> csc pass walks
+        the lines in order), made once."""
+        if self._host_t is None:
+            mt = self._host_matrix().tocsc()
+            self._host_t = (mt.indptr.astype(np.int64), mt.indices.astype(np.int32), mt.data.astype(np.float32))
+        return self._host_t
+
+    def _device_arrays(self, device, transposed=False):
+        key = (str(device), transposed)
         if key not in self._dev:
-            self._dev[key] = tuple(torch.from_numpy(a).to(device) for a in (self._rowptr, self._col, self._wgt))
+            arrs = self._transposed() if transposed else (self._rowptr, self._col, self._wgt)
+            self._dev[key] = tuple(torch.from_numpy(a).to(device) for a in arrs)
         return self._dev[key]
 
     def apply(self, x, mode):
         self._check_input(x, mode)
         v = x.val
         if v.is_cuda:
-            rowptr, col, wgt = self._device_arrays(v.device)
+            nnz = len(self._col)
             if mode == self.TIMES:
-                return Field(self._target, B.spmv(rowptr, col, wgt, v.contiguous().reshape(-1), self._nlos))
-            res = B.spmv_t(rowptr, col, wgt, v.contiguous(), self._domain.size)
+                rowptr, col, wgt = self._device_arrays(v.device)
+                return Field(self._target, B.spmv(rowptr, col, wgt, v.contiguous().reshape(-1), self._nlos,
+                                                  B.lanes_for(nnz, self._nlos)))
+            rowptr, col, wgt = self._device_arrays(v.device, transposed=True)
+            res = B.spmv(rowptr, col, wgt, v.contiguous(), self._domain.size, B.lanes_for(nnz, self._domain.size))
             return Field(self._domain, res.reshape(self._domain.shape))
         m = self._host_matrix()
         a = v.numpy()
         if mode == self.TIMES:
             return Field(self._target, torch.from_numpy(np.asarray(m @ a.reshape(-1))))
         return Field(self._domain, torch.from_numpy(np.asarray(m.T @ a).reshape(self._domain.shape)))
+
+
+class SparseResponse:
+    """A linear response signal space -> data space as ONE sparse matrix for the fused engine (FusedModel(response=...)):
+    the rows of a LOSResponse that a following MaskOperator keeps (reference demos/cl/getting_started_3.py:98-100:
+    ``Mask @ LOSResponse``), held on the device as CSR arrays of the matrix and of its transpose.  Both products are
+    nk_csr_rowsum launches (fixed summation order); float32 weights, fp64 accumulation, like LOSResponse itself."""
+
+    def __init__(self, rowptr, col, wgt, n_pix):
+        from scipy.sparse import csr_matrix
+
+        self.n_data, self.n_pix = len(rowptr) - 1, int(n_pix)
+        self._m = csr_matrix((np.asarray(wgt, dtype=np.float32), np.asarray(col, dtype=np.int32),
+                              np.asarray(rowptr, dtype=np.int64)), shape=(self.n_data, self.n_pix))
+        self._dev = {}
+
+    @staticmethod
+    def from_operators(los, mask=None):
+        """LOSResponse, optionally followed by a MaskOperator on its target."""
+        m = los._host_matrix()
+        if mask is not None:
+            if mask.domain is not los.target and mask.domain != los.target:
+                raise ValueError("mask does not act on the response's target")
+            m = m[mask._keep.numpy()]
+        m = m.tocsr()
+        return SparseResponse(m.indptr, m.indices, m.data, los.domain.size)
+
+    @property
+    def host_matrix(self):
+        return self._m
+
+    def _arrays(self, device):
+        key = str(device)
+        if key not in self._dev:
+            mt = self._m.tocsc()
+            host = (self._m.indptr.astype(np.int64), self._m.indices.astype(np.int32), self._m.data.astype(np.float32),
+                    mt.indptr.astype(np.int64), mt.indices.astype(np.int32), mt.data.astype(np.float32))
+            self._dev[key] = tuple(torch.from_numpy(a).to(device) for a in host)
+        return self._dev[key]
+
+    def times(self, x):
+        """R x: x any tensor with n_pix entries -> [n_data]."""
+        a = self._arrays(x.device)
+        return B.spmv(a[0], a[1], a[2], x.contiguous().reshape(-1), self.n_data, B.lanes_for(self._m.nnz, self.n_data))
+
+    def adjoint(self, y, shape=None):
+        """R^T y: [n_data] -> n_pix entries (reshaped to `shape`)."""
+        a = self._arrays(y.device)
+        out = B.spmv(a[3], a[4], a[5], y.contiguous(), self.n_pix, B.lanes_for(self._m.nnz, self.n_pix))
+        return out if shape is None else out.reshape(shape)

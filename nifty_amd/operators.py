@@ -1301,13 +1301,20 @@ class ContractionOperator(LinearOperator):
         if x.val.is_cuda:
             if not full_contraction:
                 # sum over the contracted axes = scatter-add onto the flat index of the kept coordinates
+                # (static map: bins summed in a fixed order through the bin-sorted permutation, no atomics)
                 key = str(x.val.device)
+                nkept = int(np.prod(self._target.shape))
                 if key not in self._kept_index:
-                    kept = torch.arange(int(np.prod(self._target.shape)), dtype=torch.int32, device=x.val.device)
+                    kept = torch.arange(nkept, dtype=torch.int32, device=x.val.device)
                     shp = [1 if i in self._axes else n for i, n in enumerate(self._domain.shape)]
-                    self._kept_index[key] = kept.reshape(shp).expand(self._domain.shape).contiguous().reshape(-1)
-                res = B.scatter_add(x.val.contiguous().reshape(-1), self._kept_index[key], int(np.prod(self._target.shape)))
-                return Field(self._target, res.to(x.val.dtype).reshape(self._target.shape))
+                    kept = kept.reshape(shp).expand(self._domain.shape).contiguous().reshape(-1)
+                    self._kept_index[key] = B.bin_plan(kept, nkept) if kept.numel() <= B.BIN_PLAN_MAX else kept
+                plan = self._kept_index[key]
+                if isinstance(plan, tuple):
+                    res = B.bin_sum(x.val.contiguous().reshape(-1), plan)
+                else:
+                    res = B.scatter_add(x.val.contiguous().reshape(-1), plan, nkept).to(x.val.dtype)
+                return Field(self._target, res.reshape(self._target.shape))
             return Field.scalar(x.s_sum()).at(x.device_id)
         if full_contraction:
             return Field.scalar(x.s_sum())
@@ -1525,6 +1532,7 @@ class DOFDistributor(LinearOperator):
         self._idx_src = idx
         self._idx_host = None
         self._idx32 = {}
+        self._bin_plans = {}
         self._nbin = nbin
         # leading spaces of the target (e.g. the UnstructuredDomain(total_N) of several correlated fields) are batch axes
         lead = tuple(self._target[i] for i in range(len(self._target) - 1)) if hasattr(self, "_target") else ()
@@ -1565,6 +1573,15 @@ class DOFDistributor(LinearOperator):
                 return B.gather(v.contiguous(), self._device_index(v.device), tshape)
             return v[self._idx.to(v.device)].reshape(tshape)
         if v.is_cuda:
+            # static index map: every bin is summed in a fixed order over the bin-sorted permutation of the pixels (made
+            # once per device); only maps beyond BIN_PLAN_MAX points keep the fp64 atomics
+            key = str(v.device)
+            if key not in self._bin_plans:
+                idx = self._device_index(v.device)
+                self._bin_plans[key] = B.bin_plan(idx, self._nbin) if idx.numel() <= B.BIN_PLAN_MAX else None
+            plan = self._bin_plans[key]
+            if plan is not None:
+                return B.bin_sum(v.contiguous().reshape(-1), plan)
             bins = B.scatter_add(v.contiguous().reshape(-1), self._device_index(v.device), self._nbin)
             return bins.to(v.dtype)
         out = torch.zeros(self._nbin, dtype=torch.float64)

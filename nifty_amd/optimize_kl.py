@@ -5,8 +5,8 @@ global iteration: push the iteration's SeedSequence, initialise missing latent k
 draw samples, minimise the sampled KL, optionally save / call back.
 
 Fusion pass (``fuse=True``, device runs only): when the likelihood is
-``GaussianEnergy | PoissonianEnergy  @  [exp | sigmoid]  @  CorrelatedFieldOperator`` the iteration runs
-on the fused engine (engine.py: one forward + one adjoint transform per sample and metric application,
+``GaussianEnergy | PoissonianEnergy  @  [[MaskOperator @] LOSResponse @]  [exp | sigmoid]  @  CorrelatedFieldOperator``
+the iteration runs on the fused engine (engine.py: one forward + one adjoint transform per sample and metric application,
 CG with device-resident scalars) and the results are handed back as MultiFields / ResidualSampleList.
 Everything else walks the generic operator graph.  Plotting and HDF5 export of the
 reference are diagnostics outside the hot path and not implemented.
@@ -23,7 +23,9 @@ from .energy_operators import GaussianEnergy, PoissonianEnergy, StandardHamilton
 from .field import Field, MultiField, from_random, full
 from .kl import EnergyAdapter, ResidualSampleList, SampledKLEnergy, SampleList
 from .minimization import DescentMinimizer, EnergyHistory, IterationController, Minimizer, logger
-from .operators import DiagonalOperator, Operator, ScalingOperator, _FunctionApplier, _OpChain
+from .los_response import LOSResponse, SparseResponse
+from .operators import (ChainOperator, DiagonalOperator, MaskOperator, Operator, ScalingOperator, _FunctionApplier,
+                        _OpChain)
 from .parallel import get_MPI_params_from_comm
 
 
@@ -60,11 +62,27 @@ def match_fused(lh):
         return None
     like, model = lh.likelihood, lh.model
     nonlin = None
+    response = None
     if isinstance(model, _OpChain):
-        ops = model._ops
+        ops = list(model._ops)
+        # leading linear part: [MaskOperator @] LOSResponse (BASELINE config 4, reference demos/cl/getting_started_3.py:98-100),
+        # possibly merged into one ChainOperator -- it becomes ONE sparse matrix of the fused engine
+        lin = []
+        while ops and isinstance(ops[0], (MaskOperator, LOSResponse, ChainOperator)):
+            op = ops.pop(0)
+            lin.extend(op._ops if isinstance(op, ChainOperator) else [op])
+        if lin:
+            if len(lin) == 1 and isinstance(lin[0], LOSResponse):
+                response = (lin[0], None)
+            elif len(lin) == 2 and isinstance(lin[0], MaskOperator) and isinstance(lin[1], LOSResponse):
+                response = (lin[1], lin[0])
+            else:
+                return None
         if len(ops) == 2 and isinstance(ops[0], _FunctionApplier) and ops[0]._funcname in ("exp", "sigmoid") \
                 and not ops[0]._args and isinstance(ops[1], CorrelatedFieldOperator):
             nonlin, model = ops[0]._funcname, ops[1]
+        elif len(ops) == 1 and isinstance(ops[0], CorrelatedFieldOperator) and response is not None:
+            model = ops[0]
         else:
             return None
     if not isinstance(model, CorrelatedFieldOperator) or model._prefix != "":
@@ -72,6 +90,10 @@ def match_fused(lh):
     kw = dict(model.fused_parameters)
     kw.pop("prefix")
     kw["nonlin"] = nonlin
+    if response is not None:
+        if response[0].domain[0] is not model.target[0] and response[0].domain != model.target:
+            return None
+        kw["response"] = SparseResponse.from_operators(*response)
     if isinstance(like, PoissonianEnergy):
         kw.update(likelihood="poisson", data=like._d.val)
     elif isinstance(like, GaussianEnergy) and like._data is not None:

@@ -371,3 +371,147 @@ print("RESULT", repr(float(kl.value)), repr(float(mean.xi.double().sum())), repr
 
     a, b = run(True), run(True)  # (the floating-point-atomic kernel is covered by test_octant_expand_and_scatter above)
     assert a == b
+
+
+@pytest.mark.parametrize("lanes", [1, 4, 16, 64])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_csr_rowsum_against_scipy_and_bitwise_repeatable(lanes, dtype):
+    """nk_csr_rowsum (weighted = LOSResponse products, unweighted = bin sums of a static index map) against scipy.sparse /
+    np.bincount, every lanes-per-row variant on rows of 0 .. 300 entries; the same bits on every launch."""
+    from scipy.sparse import random as sprandom
+
+    from nifty_amd import _lib as L
+    from nifty_amd import backend as B
+
+    rng = np.random.default_rng(lanes)
+    m = sprandom(3000, 5000, density=0.01, format="csr", random_state=7, dtype=np.float32)
+    m = m[np.r_[0:1500, 1500:3000:2]]  # plus a run of rows in a different order
+    x = rng.normal(size=5000).astype(np.float32 if dtype == torch.float32 else np.float64)
+    dev = torch.device("cuda:0")
+    rp, col, wg = (torch.from_numpy(a).to(dev) for a in (m.indptr.astype(np.int64), m.indices.astype(np.int32), m.data))
+    xd = torch.from_numpy(x).to(dev)
+    y = torch.empty(m.shape[0], dtype=dtype, device=dev)
+    lib = L.load()
+    L.check(lib.nk_csr_rowsum(m.shape[0], rp.data_ptr(), col.data_ptr(), wg.data_ptr(), xd.data_ptr(), y.data_ptr(),
+                              B.dtype_code(xd), lanes, B._stream()))
+    ref = m.astype(np.float64) @ x.astype(np.float64)
+    tol = 1e-13 if dtype == torch.float64 else 2e-6
+    assert np.max(np.abs(y.cpu().numpy() - ref)) < tol * max(1.0, np.max(np.abs(ref)))
+    y2 = torch.empty_like(y)
+    L.check(lib.nk_csr_rowsum(m.shape[0], rp.data_ptr(), col.data_ptr(), wg.data_ptr(), xd.data_ptr(), y2.data_ptr(),
+                              B.dtype_code(xd), lanes, B._stream()))
+    assert torch.equal(y, y2)
+    # unweighted: bin sums through bin_plan / bin_sum == np.bincount
+    nb = 777
+    pidx = rng.integers(0, nb, size=200000).astype(np.int32)
+    pidx[pidx == 5] = 6  # an empty bin
+    w = rng.normal(size=pidx.size).astype(x.dtype)
+    plan = B.bin_plan(torch.from_numpy(pidx).to(dev), nb)
+    plan = (plan[0], plan[1], lanes)
+    got = B.bin_sum(torch.from_numpy(w).to(dev), plan)
+    refb = np.bincount(pidx, weights=w.astype(np.float64), minlength=nb)
+    assert np.max(np.abs(got.cpu().numpy() - refb)) < (1e-12 if dtype == torch.float64 else 1e-5) * np.max(np.abs(refb))
+    assert torch.equal(got, B.bin_sum(torch.from_numpy(w).to(dev), plan))
+    with pytest.raises(ValueError):
+        L.check(lib.nk_csr_rowsum(1, rp.data_ptr(), col.data_ptr(), 0, xd.data_ptr(), y.data_ptr(), B.dtype_code(xd), 3,
+                                  B._stream()))
+
+
+def test_fixed_point_scatter_answers_non_finite_input_with_nan():
+    """a NaN / Inf among the octant sums must not come out of the fixed-point shell scatter as a finite number.
+    The final pass joins max |w8| with a NaN-propagating rule; the scatter then writes NaN.  Through the engine: a NaN
+    in the data gives a NaN (-> inf) energy and a NaN spectrum gradient, like the floating-point path."""
+    import ctypes
+
+    import nifty_amd as ift
+    from nifty_amd import _lib as L
+    from nifty_amd import backend as B
+    from nifty_amd import random
+    from nifty_amd.engine import FusedModel
+
+    shape = (64, 64, 64)
+    hsp = ift.RGSpace(shape).get_default_codomain()
+    ps = ift.PowerSpace(hsp)
+    pidx = torch.from_numpy(np.array(ps.pindex).astype(np.int32)).cuda()
+    nb = ps.shape[0]
+    k2d = torch.from_numpy(np.nonzero(hsp._k2_flags())[0].astype(np.int32)).cuda()
+    oshape = tuple(n // 2 + 1 for n in shape)
+    shp = (ctypes.c_int64 * 3)(*shape)
+    scratch = torch.empty(64 * (nb + 32), dtype=torch.float64, device="cuda")
+    w8 = torch.randn(oshape, dtype=torch.float64, device="cuda")
+    for bad in (float("nan"), float("inf")):
+        wmax = torch.tensor([bad], dtype=torch.float64, device="cuda")
+        abar = torch.zeros(nb, dtype=torch.float64, device="cuda")
+        L.check(L.load().nk_octant_scatter_k2(3, shp, w8.data_ptr(), pidx.data_ptr(), k2d.data_ptr(), nb, scratch.data_ptr(),
+                                              abar.data_ptr(), wmax.data_ptr(), B._stream()))
+        assert bool(torch.isnan(abar).all())
+    # end to end: a NaN in the data reaches the spectrum gradient
+    model = FusedModel(shape, offset_mean=2.0, likelihood="gaussian", icov=100.0, dtype=torch.float64, device="cuda:0")
+    assert model.scatter_fixed_point
+    random.push_sseq_from_seed(9)
+    try:
+        x = model.draw_prior() * 0.1
+        data = model.signal(x)
+    finally:
+        random.pop_sseq()
+    data[3, 4, 5] = float("nan")
+    model.set_data(data, 100.0)
+    lp = model.linearize(x)
+    assert not np.isfinite(float(lp.value.item()))
+    assert bool(torch.isnan(lp.grad.small[5:]).any())
+
+
+@pytest.mark.parametrize("shape", [(64, 128, 256), (256, 64, 64)])
+def test_anisotropic_grid_scatter_eligibility_is_counted_exactly(shape):
+    """the overflow bound of the fixed-point scatter (< 2^18 points per (shell, split) workgroup) is counted
+    from the bin index of the grid at hand, not from a cube heuristic; the VJP bin sums of a non-cubic grid with equal
+    physical box lengths agree with the host bincount."""
+    from nifty_amd import random
+    from nifty_amd.engine import FusedModel
+
+    model = FusedModel(shape, offset_mean=1.0, likelihood="gaussian", icov=10.0, dtype=torch.float64, device="cuda:0")
+    if model.bin_k2 is not None:
+        a = np.arange(shape[0] // 2 + 1)
+        p8 = model.pidx8.cpu().numpy().reshape(shape[0] // 2 + 1, -1)
+        key = (p8 // 4096) * 16 + (a % 16)[:, None]
+        assert model.scatter_busiest == int(np.bincount(key.ravel()).max())
+        assert model.scatter_fixed_point == (model.scatter_busiest < (1 << 18))
+    random.push_sseq_from_seed(2)
+    try:
+        x = model.draw_prior() * 0.1
+        model.set_data(model.signal(model.draw_prior()), 10.0)
+    finally:
+        random.pop_sseq()
+    lp = model.linearize(x)
+    assert np.isfinite(float(lp.value.item()))
+    # abar of the last VJP against the host scatter of the octant sums it was reduced from
+    osl = tuple(slice(0, n // 2 + 1) for n in shape)
+    pid8 = model.pidx.view(shape)[osl].cpu().numpy().ravel()
+    ref = np.bincount(pid8, weights=model.w8.cpu().numpy().ravel(), minlength=model.nb)
+    got = model.abar.cpu().numpy()
+    assert np.max(np.abs(got - ref)) < 1e-11 * max(1.0, np.max(np.abs(ref)))
+
+
+def test_reductions_on_concurrent_streams_do_not_share_scratch():
+    """the ticket-ordered reductions keep their block partials per (device, stream).  Dots launched alternately
+    on two streams (so that launches of one overlap launches of the other) equal the serial results bit for bit."""
+    from nifty_amd import _lib as L
+
+    n = 1 << 24
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = [torch.randn(n, dtype=torch.float32, device="cuda", generator=g) for _ in range(4)]
+    lib = L.load()
+    serial = torch.zeros(4, dtype=torch.float64, device="cuda")
+    st0 = torch.cuda.current_stream().cuda_stream
+    for i in range(4):
+        L.check(lib.nk_vdot(n, a[i].data_ptr(), a[(i + 1) % 4].data_ptr(), L.NK_F32, serial[i:i + 1].data_ptr(), 0, st0))
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(20):
+        out = torch.zeros(4, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        for i in range(4):
+            st = (s1 if i % 2 == 0 else s2).cuda_stream
+            L.check(lib.nk_vdot(n, a[i].data_ptr(), a[(i + 1) % 4].data_ptr(), L.NK_F32, out[i:i + 1].data_ptr(), 0, st))
+        torch.cuda.synchronize()
+        assert torch.equal(out, serial), rep
