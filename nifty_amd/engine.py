@@ -263,6 +263,7 @@ class LinPoint:
         self.mid = None
         self.afield = None
         self.mid_scalar = 1.0
+        self.f = self.tf = None
         self.gp = self.wd = self.tfd = None  # response models: g'(s) [grid], data-space metric weight, df/dmu [data]
 
 

@@ -182,31 +182,45 @@ def test_same_lines_on_512_squared_against_the_oracle():
         assert gl.lat_relerr(r.to_dict(), o) < 1e-6
 
 
+def _run_okl(lh, fuse, ic, mk, nl):
+    ift.random.push_sseq_from_seed(42)
+    try:
+        return ift.optimize_kl(lh, 1, 4, mk, ic, nonlinear_sampling_minimizer=nl, output_directory=None,
+                               return_final_position=True, device_id=0, fuse=fuse)
+    finally:
+        ift.random.pop_sseq()
+
+
 def test_one_geovi_iteration_at_full_size(full):
     cf, resp, lh, d, R, Mk = full
+    # (a) bounded CG / Newton lengths: the fused response engine and the generic operator graph walk the same algorithm
+    # with the same seeds and must agree to rounding (long ill-conditioned runs amplify 1e-16 differences chaotically
+    # through their discrete decisions, DESIGN 6 -- the full recipe below differs at O(1) between ANY two arithmetics)
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=4)
+    mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2),  # noqa: E731
+                                max_cg_iterations=4)
+    nl = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=2, convergence_level=2),  # noqa: E731
+                                max_cg_iterations=4)
+    (sl_f, mean_f), (sl_g, mean_g) = _run_okl(lh, True, ic, mk, nl), _run_okl(lh, False, ic, mk, nl)
+    assert sl_f.n_samples == sl_g.n_samples == 8  # geoVI keeps both members of a mirrored pair as independent residuals
+    err = gl.lat_relerr(mean_f.asnumpy(), mean_g.asnumpy())
+    print(f"4096^2 geoVI iteration, bounded recipe: fused vs generic graph mean {err:.2e}")
+    # (measured 4.6e-6: two Newton steps of four CG iterations each amplify the 1e-13 differences of the two arithmetics)
+    assert err < 1e-4
+    for a, b in zip(sl_f.iterator(), sl_g.iterator()):
+        assert gl.lat_relerr(a.asnumpy(), b.asnumpy()) < 1e-4
+    # (b) the recipe of the config (demos/cl/getting_started_3.py:119-127) on the fused engine: finite, and the posterior
+    # mean explains the data better than the start
     ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=20)
     mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=3),  # noqa: E731
                                 max_cg_iterations=20)
     nl = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=5, convergence_level=2))  # noqa: E731
-    out = {}
-    for fuse in (True, False):
-        ift.random.push_sseq_from_seed(42)
-        try:
-            sl, mean = ift.optimize_kl(lh, 1, 4, mk, ic, nonlinear_sampling_minimizer=nl, output_directory=None,
-                                       return_final_position=True, device_id=0, fuse=fuse)
-        finally:
-            ift.random.pop_sseq()
-        assert sl.n_samples == 8  # geoVI keeps both members of a mirrored pair as independent residuals
-        out[fuse] = (mean, [s for s in sl.iterator()])
-        for k in mean.keys():
-            assert bool(torch.isfinite(mean[k].val).all())
-    # fused engine and generic graph walk the same algorithm (same seeds, same control flow): they agree to the
-    # amplification of their different rounding through the CG / line-search decisions of one iteration
-    mean_f, mean_g = out[True][0].asnumpy(), out[False][0].asnumpy()
-    assert gl.lat_relerr(mean_f, mean_g) < 1e-3
-    # the posterior mean reproduces the data within the noise: reduced chi^2 of the kept lines of O(1)
-    r = (resp(out[True][0]) - d).asnumpy()
-    chi2 = float(np.mean(r * r) / NOISE_VAR)
-    start = ift.full(lh.domain, 0.0)
-    r0 = (resp(start.at(0) if hasattr(start, "at") else start) - d).asnumpy()
-    assert chi2 < float(np.mean(r0 * r0) / NOISE_VAR)
+    sl, mean = _run_okl(lh, True, ic, mk, nl)
+    assert sl.n_samples == 8
+    for k in mean.keys():
+        assert bool(torch.isfinite(mean[k].val).all())
+    r = (resp(mean) - d).asnumpy()
+    r0 = (resp(ift.full(lh.domain, 0.0).at(0)) - d).asnumpy()
+    chi2, chi2_0 = float(np.mean(r * r) / NOISE_VAR), float(np.mean(r0 * r0) / NOISE_VAR)
+    print(f"4096^2 geoVI iteration, full recipe: reduced chi^2 {chi2_0:.1f} -> {chi2:.1f}")
+    assert chi2 < chi2_0
