@@ -1002,49 +1002,47 @@ class FusedGeoEnergy(Energy):
 
 def share_range(nwork, nshares, myshare):
     """reference nifty/cl/utilities.py:282-306"""
-    nbase, additional = divmod(nwork, nshares)
-    lo = myshare * nbase + min(myshare, additional)
-    return lo, lo + nbase + int(myshare < additional)
+    return parallel.shareRange(nwork, nshares, myshare)
 
 
 def draw_samples(model, position, n_samples, mirror_samples, controller_factory, comm=None, device_rng=None,
                  geo_minimizer=None):
     """MGVI -- or with ``geo_minimizer`` (a DescentMinimizer) geoVI -- samples of this rank
-    (kl_energies.py:105-159): returns (residuals, negs, n_total)."""
-    sseq = random.spawn_sseq(n_samples)
-    if mirror_samples:
-        sseq = [s for ss in sseq for s in (ss, ss)]
-    ntask, rank = (1, 0) if comm is None else (comm.size, comm.rank)
-    lp = tp_p = trafo_mean = None
-    residuals, negs = [], []
-    y = b = None
-    lo, hi = share_range(len(sseq), ntask, rank)
-    for i in range(lo, hi):
-        with random.Context(sseq[i]):
-            neg = mirror_samples and i % 2 != 0
-            if not neg or y is None:
-                if lp is None:
-                    lp = model.linearize(position)
-                if device_rng is not None:
-                    # synthetic-draw mode: still one stream per sample seed, so both members of a mirrored pair
-                    # see identical draws even when they live on different ranks (kl_energies.py:132-146)
-                    device_rng.manual_seed(int(sseq[i].generate_state(1, np.uint64)[0] >> np.uint64(1)))
-                b, y = model.draw_mgvi_sample(lp, controller_factory(), device_rng)
-            if geo_minimizer is None:
-                residuals.append(y)
-                negs.append(neg)
-                continue
-            # geoVI (kl_energies.py:105-124, 148-155): the linear sample only starts a non-linear fit of
-            # g(x) = x + J_f(p)^T f(x) to  g(p) +- b
-            if tp_p is None:
-                tp_p = model.trafo_point(position)
-                trafo_mean = model.vjp_data(tp_p, tp_p.f, addend=position)
-            m = trafo_mean - b if neg else trafo_mean + b
-            start = position - y if neg else position + y
-            en, _ = geo_minimizer(FusedGeoEnergy(model, tp_p, m, start))
-            residuals.append(en.position - position)
-            negs.append(False)
-    return residuals, negs, len(sseq)
+    (kl_energies.py:105-159): returns (residuals, negs, n_total).  Which rank draws which sample from which seed is
+    the parallel.SamplePlan shared with the generic operator graph (kl.draw_samples); a rank may get no sample."""
+    plan = parallel.SamplePlan(n_samples, mirror_samples, comm)
+    plan.check_synchronised()
+    cache = {}
+
+    def linearisation():
+        if "lp" not in cache:
+            cache["lp"] = model.linearize(position)
+        return cache["lp"]
+
+    def draw(seed):
+        if device_rng is not None:
+            # synthetic-draw mode: still one stream per sample seed, so both members of a mirrored pair
+            # see identical draws even when they live on different ranks (kl_energies.py:132-146)
+            device_rng.manual_seed(int(seed.generate_state(1, np.uint64)[0] >> np.uint64(1)))
+        return model.draw_mgvi_sample(linearisation(), controller_factory(), device_rng)
+
+    def linear_residual(pair, mirrored):
+        return pair[1], mirrored
+
+    def fitted_residual(pair, mirrored):
+        # geoVI (kl_energies.py:105-124, 148-155): the linear sample only starts a non-linear fit of
+        # g(x) = x + J_f(p)^T f(x) to  g(p) +- b
+        if "tp" not in cache:
+            cache["tp"] = model.trafo_point(position)
+            cache["g_p"] = model.vjp_data(cache["tp"], cache["tp"].f, addend=position)
+        b, y = pair
+        target = cache["g_p"] - b if mirrored else cache["g_p"] + b
+        start = position - y if mirrored else position + y
+        fit, _ = geo_minimizer(FusedGeoEnergy(model, cache["tp"], target, start))
+        return fit.position - position, False
+
+    drawn = plan.run(draw, linear_residual if geo_minimizer is None else fitted_residual)
+    return [r for r, _ in drawn], [n for _, n in drawn], plan.n_total
 
 
 def mgvi_iteration(model, mean, n_samples, controller_factory, kl_minimizer, mirror_samples=True, comm=None,

@@ -22,7 +22,7 @@ from .field import Field, MultiField, is_fieldlike
 from .minimization import DescentMinimizer, Energy
 from .operators import (EndomorphicOperator, Linearization, SamplingEnabler, SandwichOperator, ScalingOperator,
                         is_operator, makeDomain)
-from .parallel import get_MPI_params_from_comm, shareRange
+from .parallel import SamplePlan, get_MPI_params_from_comm, shareRange
 
 
 def _scalar_value(field):
@@ -117,43 +117,70 @@ class SampleListBase:
             yield s if op is None else op(s)
 
     def iterator(self, op=None):
-        if self._comm is not None and self._comm.size > 1:
-            raise NotImplementedError("global iteration over distributed samples: use average()/local_iterator()")
-        return self.local_iterator(op)
+        """All samples in global order on EVERY rank (sample_list.py:186-210): each sample is handed over by the rank that
+        holds it -- one object broadcast per sample (through the host: pickled Fields), so this is for diagnostics and
+        small statistics, not for the hot path (average() / local_iterator() never move samples)."""
+        comm = self._comm
+        if comm is None or comm.size == 1:
+            yield from self.local_iterator(op)
+            return
+        counts = comm.allgather_object(self.n_local_samples())
+        device_id = self._device_id()
+        for owner, count in enumerate(counts):
+            for i in range(count):
+                mine = _to_host(self.local_item(i)) if owner == comm.rank else None
+                s = comm.bcast_object(mine, root=owner).at(device_id)
+                yield s if op is None else op(s)
+
+    def _device_id(self):
+        return -1
+
+    def _sum_over_ranks(self, local_terms):
+        """Sum of Fields / MultiFields / floats (or tuples of those) over the local terms and over all ranks.  Ranks
+        WITHOUT samples (shareRange leaves ranks empty when there are fewer samples than ranks, utilities.py:349-414 copes
+        with any split) contribute a zero element whose shape they learn from the first rank that holds a term."""
+        acc = None
+        for t in local_terms:
+            acc = t if acc is None else _add(acc, t)
+        comm = self._comm
+        if comm is None or comm.size == 1:
+            if acc is None:
+                raise ValueError("sum over an empty sample list")
+            return acc
+        have = comm.allgather_object(acc is not None)
+        if not any(have):
+            raise ValueError("sum over an empty sample list")
+        if not all(have):
+            root = have.index(True)
+            template = comm.bcast_object(_zero_like_host(acc) if comm.rank == root else None, root=root)
+            if acc is None:
+                acc = _place_like(template, self._device_id())
+        return _map(acc, self._allreduce_fields)
 
     def _allreduce_fields(self, obj):
-        """Sum a Field / MultiField / python float over ranks in place."""
+        """Sum a Field / MultiField / python float over ranks (fields: in place on a private copy)."""
         if self._comm is None or self._comm.size == 1:
             return obj
         if isinstance(obj, float):
             return self._comm.sum_float(obj)  # the scalar lives where the backend needs it (RCCL: on the GPU)
+        obj = obj * 1.0
         tensors = [f.val for f in (obj.values() if isinstance(obj, MultiField) else [obj])]
         self._comm.allreduce_sum_(tensors)
         return obj
 
     def average(self, op=None):
         """Mean of op(sample) over ALL samples (sample_list.py:212-237)."""
-        acc = None
-        for s in self.local_iterator(op):
-            acc = s if acc is None else acc + s
-        if acc is None:
-            raise NotImplementedError("ranks without samples need a zero element; give every rank >= 1 sample")
-        acc = self._allreduce_fields(acc * 1.0)
-        return acc * (1.0 / self.n_samples)
+        total = self._sum_over_ranks(self.local_iterator(op))
+        return total * (1.0 / self.n_samples)
 
     def _average_2tuple(self, op):
         """Mean of a (float, field) pair (sample_list.py:239-270)."""
-        v_acc, f_acc = 0.0, None
-        for v, f in self.local_iterator(op):
-            v_acc += v
-            f_acc = f if f_acc is None else f_acc + f
+        v, f = self._sum_over_ranks((float(a), b) for a, b in self.local_iterator(op))
         n = self.n_samples
-        v_acc = self._allreduce_fields(float(v_acc))
-        f_acc = self._allreduce_fields(f_acc * 1.0)
-        return v_acc / n, f_acc * (1.0 / n)
+        return v / n, f * (1.0 / n)
 
     def sample_stat(self, op=None):
-        """(mean, variance) over the samples (sample_list.py:272-293); single rank only."""
+        """(mean, variance) over the samples (sample_list.py:272-293); distributed lists go through iterator()."""
         n = self.n_samples
         if n < 2:
             raise RuntimeError("need at least two samples")
@@ -192,6 +219,9 @@ class ResidualSampleList(SampleListBase):
 
     def local_item(self, i):
         return self._m.flexible_addsub(self._r[i], self._n[i])
+
+    def _device_id(self):
+        return self._m.device_id
 
     def at(self, mean):
         """Only the entries present in `mean` are updated (sample_list.py:436-455)."""
@@ -253,6 +283,9 @@ class SampleList(SampleListBase):
     def local_item(self, i):
         return self._s[i]
 
+    def _device_id(self):
+        return self._s[0].device_id if self._s else -1
+
     def save(self, file_name_base, overwrite=False):
         nsample = self.n_samples
         lo, _ = shareRange(nsample, self._ntask, self._rank)
@@ -278,6 +311,22 @@ def _to_host(f):
     return f.at(-1)
 
 
+def _map(obj, fn):
+    return tuple(fn(o) for o in obj) if isinstance(obj, tuple) else fn(obj)
+
+
+def _add(a, b):
+    return tuple(x + y for x, y in zip(a, b)) if isinstance(a, tuple) else a + b
+
+
+def _zero_like_host(obj):
+    return _map(obj, lambda o: 0.0 if isinstance(o, float) else _to_host(o) * 0.0)
+
+
+def _place_like(template, device_id):
+    return _map(template, lambda o: o if isinstance(o, float) else o.at(device_id))
+
+
 def _dump(fname, obj, overwrite):
     if os.path.isfile(fname) and not overwrite:
         raise RuntimeError(f"{fname} already exists")
@@ -288,90 +337,94 @@ def _dump(fname, obj, overwrite):
 # ------------------------------------------------------------------------------------------------
 # sampling
 # ------------------------------------------------------------------------------------------------
+class _LinearSampler:
+    """Draws (b, y) with y = M^-1 b for the metric M of the sampling problem at `position`: the Hamiltonian's own
+    metric (MGVI), or 1 + J_f^T J_f of the likelihood's Gaussianising transformation f (geoVI), which also provides
+    the coordinate transformation g(x) = x + J_f(p)^T f(x) and g(p) for the non-linear fit (kl_energies.py:105-128)."""
+
+    def __init__(self, ham, position, geometric, napprox, device_id):
+        self.position, self.device_id = position, device_id
+        self.g = self.g_of_position = None
+        if geometric:
+            tr = ham.likelihood_energy.get_transformation()
+            if tr is None:
+                raise ValueError("Geometric sampling only works for likelihoods")
+            dtype, f = tr
+            f_lin = f(Linearization.make_var(position))
+            jac = f_lin.jac
+            self.g = ScalingOperator(f.domain, 1.0) + jac.adjoint @ f
+            self.g_of_position = position + jac.adjoint(f_lin.val)
+            self.metric = SamplingEnabler(SandwichOperator.make(jac, ScalingOperator(f.target, 1.0, dtype)),
+                                          ScalingOperator(f_lin.domain, 1.0, float), ham.iteration_controller)
+        else:
+            self.metric = ham(Linearization.make_var(position, want_metric=True)).metric
+        if napprox >= 1:
+            # sampled diagonal of the metric as the preconditioner of the sampling solves (kl_energies.py:127-128); its
+            # draws come from the CURRENT stream, before the per-sample seeds are spawned -- the reference's RNG order
+            from .operators import makeOp
+            from .probing import approximation2endo
+
+            self.metric._approximation = makeOp(approximation2endo(self.metric, napprox, device_id))
+
+    def draw(self, _seed=None):
+        return self.metric.special_draw_sample(True, device_id=self.device_id)
+
+
 def draw_samples(position, H, minimizer, n_samples, mirror_samples, napprox=0, want_error=False, comm=None,
                  device_id=-1):
-    """MGVI (minimizer None) or geoVI residual samples around ``position`` (kl_energies.py:91-159)."""
-    if not isinstance(n_samples, int):
-        raise TypeError
-    if not isinstance(mirror_samples, bool):
-        raise TypeError
-    if not isinstance(H, StandardHamiltonian):
-        raise TypeError
-    sam_position = position.extract(H.domain) if isinstance(position, MultiField) else position
-    geometric = minimizer is not None
-    if geometric:
-        tr = H.likelihood_energy.get_transformation()
-        if tr is None:
-            raise ValueError("Geometric sampling only works for likelihoods")
-        dtype, f_lh = tr
-        scale = ScalingOperator(f_lh.target, 1.0, dtype)
-        fl = f_lh(Linearization.make_var(sam_position))
-        transformation = ScalingOperator(f_lh.domain, 1.0) + fl.jac.adjoint @ f_lh
-        transformation_mean = sam_position + fl.jac.adjoint(fl.val)
-        met = SamplingEnabler(SandwichOperator.make(fl.jac, scale), ScalingOperator(fl.domain, 1.0, float),
-                              H.iteration_controller)
-    else:
-        met = H(Linearization.make_var(sam_position, want_metric=True)).metric
-    if napprox >= 1:
-        # sampled diagonal of the metric as the preconditioner of the sampling solves (kl_energies.py:127-128); its draws
-        # come from the CURRENT stream, before the per-sample seeds are spawned -- same RNG order as the reference
-        from .operators import makeOp
-        from .probing import approximation2endo
+    """MGVI (minimizer None) or geoVI residual samples around ``position`` (kl_energies.py:91-159), as a
+    ResidualSampleList distributed over ``comm`` by a parallel.SamplePlan (ranks may end up without samples)."""
+    for arg, kind in ((n_samples, int), (mirror_samples, bool), (H, StandardHamiltonian)):
+        if not isinstance(arg, kind):
+            raise TypeError
+    at = position.extract(H.domain) if isinstance(position, MultiField) else position
+    sampler = _LinearSampler(H, at, minimizer is not None, napprox, device_id)
+    plan = SamplePlan(n_samples, mirror_samples, comm)
+    plan.check_synchronised()
 
-        met._approximation = makeOp(approximation2endo(met, napprox, device_id))
-    sseq = random.spawn_sseq(n_samples)
-    if mirror_samples:
-        sseq = [s for ss in sseq for s in (ss, ss)]
-    local_samples, local_neg = [], []
-    y = yi = None
-    ntask, rank, _ = get_MPI_params_from_comm(comm)
-    for i in range(*shareRange(len(sseq), ntask, rank)):
-        with random.Context(sseq[i]):
-            neg = mirror_samples and i % 2 != 0
-            if not neg or y is None:
-                y, yi = met.special_draw_sample(True, device_id=device_id)
-            if geometric:
-                m = transformation_mean - y if neg else transformation_mean + y
-                pos = sam_position - yi if neg else sam_position + yi
-                en = EnergyAdapter(pos, GaussianEnergy(m) @ transformation, nanisinf=True, want_metric=True)
-                en, _ = minimizer(en)
-                local_samples.append(en.position - sam_position)
-                local_neg.append(False)
-            else:
-                local_samples.append(yi)
-                local_neg.append(neg)
-    return ResidualSampleList(position, local_samples, local_neg, comm)
+    def linear_residual(pair, mirrored):
+        return pair[1], mirrored
+
+    def fitted_residual(pair, mirrored):
+        # geoVI: fit x to  g(x) = g(p) +- b  starting at  p +- y; the fit's displacement is stored unmirrored
+        b, y = pair
+        target = sampler.g_of_position - b if mirrored else sampler.g_of_position + b
+        start = at - y if mirrored else at + y
+        fit, _ = minimizer(EnergyAdapter(start, GaussianEnergy(target) @ sampler.g, nanisinf=True, want_metric=True))
+        return fit.position - at, False
+
+    drawn = plan.run(sampler.draw, linear_residual if minimizer is None else fitted_residual)
+    return ResidualSampleList(position, [r for r, _ in drawn], [n for _, n in drawn], comm)
 
 
 def SampledKLEnergy(position, hamiltonian, n_samples, minimizer_sampling, mirror_samples=True, constants=[],
                     point_estimates=[], napprox=0, comm=None, nanisinf=True, device_id=-1):
     """Draw samples at ``position`` and return the sampled KL energy (kl_energies.py:162-296)."""
-    if not isinstance(hamiltonian, StandardHamiltonian):
-        raise TypeError
+    checks = ((hamiltonian, StandardHamiltonian), (n_samples, int), (mirror_samples, bool),
+              (minimizer_sampling, (DescentMinimizer, type(None))))
+    for arg, kind in checks:
+        if not isinstance(arg, kind):
+            raise TypeError
     if hamiltonian.domain is not position.domain:
         raise ValueError
-    if not isinstance(n_samples, int):
-        raise TypeError
-    if not isinstance(mirror_samples, bool):
-        raise TypeError
-    if not (minimizer_sampling is None or isinstance(minimizer_sampling, DescentMinimizer)):
-        raise TypeError
+    frozen, estimated = set(constants), set(point_estimates)
     if isinstance(position, MultiField):
-        if not set(constants).issubset(set(position.keys())):
+        keys = set(position.keys())
+        if not frozen <= keys:
             raise ValueError(f"Constants are not a subset of the keys of the latent space: {constants}")
-        if not set(point_estimates).issubset(set(position.keys())):
+        if not estimated <= keys:
             raise ValueError(f"Point estimates are not a subset of the keys of the latent space: {point_estimates}")
-        if set(point_estimates) == set(position.keys()):
+        if estimated == keys:
             raise RuntimeError("Point estimates for whole domain. Use EnergyAdapter instead.")
-    # keys that are constant AND point estimates leave the problem entirely (kl_energies.py:281-287)
-    invariant = list(set(constants).intersection(point_estimates))
-    inv_pos = position.extract_by_keys(invariant) if isinstance(position, MultiField) and invariant else None
-    position, hamiltonian = _reduce_by_keys(position, hamiltonian, invariant)
-    # no samples along the point estimates: they are inserted into the Hamiltonian used for sampling (:289-293)
-    _, ham_sampling = _reduce_by_keys(position, hamiltonian, point_estimates)
-    sample_list = draw_samples(position, ham_sampling, minimizer_sampling, n_samples, mirror_samples, napprox=napprox,
-                               comm=comm, device_id=device_id)
-    return SampledKLEnergyClass(sample_list, hamiltonian, constants, inv_pos, nanisinf)
+    # keys that are constant AND point estimates leave the problem entirely (kl_energies.py:281-287) ...
+    gone = sorted(frozen & estimated)
+    left_out = position.extract_by_keys(gone) if isinstance(position, MultiField) and gone else None
+    position, hamiltonian = _reduce_by_keys(position, hamiltonian, gone)
+    # ... and nothing is sampled along the point estimates: they are inserted into the sampling Hamiltonian (:289-293)
+    _, sampling_hamiltonian = _reduce_by_keys(position, hamiltonian, point_estimates)
+    samples = draw_samples(position, sampling_hamiltonian, minimizer_sampling, n_samples, mirror_samples, napprox=napprox,
+                           comm=comm, device_id=device_id)
+    return SampledKLEnergyClass(samples, hamiltonian, constants, left_out, nanisinf)
 
 
 def _reduce_field(field, keys):
@@ -393,7 +446,9 @@ def _reduce_by_keys(field, operator, keys):
 
 
 class SampledKLEnergyClass(Energy):
-    """KL(p) = 1/S sum_s H(p +/- r_s)  (kl_energies.py:299-360)."""
+    """KL(p) = 1/S sum_s H(p +/- r_s)  (kl_energies.py:299-360).  The Hamiltonian is linearised ONCE per local sample
+    when the energy is built; value, gradient and every later metric application reuse those linearisations, and the
+    sums over samples go through SampleListBase._sum_over_ranks (ranks without samples contribute zeros)."""
 
     def __init__(self, sample_list, hamiltonian, constants, invariants, nanisinf):
         if not isinstance(sample_list, ResidualSampleList):
@@ -403,16 +458,14 @@ class SampledKLEnergyClass(Energy):
         super().__init__(_reduce_field(sample_list._m, constants))
         self._sample_list, self._hamiltonian = sample_list, hamiltonian
         self._constants, self._invariants, self._nanisinf = constants, invariants, bool(nanisinf)
+        # per sample: the constant keys of THIS sample are inserted, the rest is differentiated (:318-321)
         self._lins = []
-
-        def _func(inp):
-            # per sample: the constant keys of THIS sample are inserted, the rest is differentiated (:318-321)
-            inp, ham = _reduce_by_keys(inp, hamiltonian, constants)
-            lin = ham(Linearization.make_var(inp, want_metric=True))
-            self._lins.append(lin)
-            return _scalar_value(lin.val), lin.gradient
-
-        self._val, self._grad = sample_list._average_2tuple(_func)
+        for sample in sample_list.local_iterator():
+            variable, ham = _reduce_by_keys(sample, hamiltonian, constants)
+            self._lins.append(ham(Linearization.make_var(variable, want_metric=True)))
+        n = sample_list.n_samples
+        value, gradient = sample_list._sum_over_ranks((_scalar_value(lin.val), lin.gradient) for lin in self._lins)
+        self._val, self._grad = value / n, gradient * (1.0 / n)
         if np.isnan(self._val) and self._nanisinf:
             self._val = np.inf
 
@@ -429,12 +482,8 @@ class SampledKLEnergyClass(Energy):
                                     self._invariants, self._nanisinf)
 
     def apply_metric(self, x):
-        acc = None
-        for lin in self._lins:
-            m = lin.metric(x)
-            acc = m if acc is None else acc + m
-        acc = self._sample_list._allreduce_fields(acc * 1.0)
-        return acc * (1.0 / self._sample_list.n_samples)
+        total = self._sample_list._sum_over_ranks(lin.metric(x) for lin in self._lins)
+        return total * (1.0 / self._sample_list.n_samples)
 
     @property
     def metric(self):

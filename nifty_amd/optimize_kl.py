@@ -294,6 +294,14 @@ def _optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, s
             continue
         ns = n_samples(ig)
         model = None
+        # the ranks of this iteration's communicator must agree on seeds, domains and the mean before anything is drawn
+        # (reference optimize_kl.py:382-385); the mean is compared through a device-side fingerprint (parallel._fingerprint)
+        c = comm(ig)
+        if c is not None:
+            parallel.check_MPI_synced_random_state(c)
+            parallel.check_MPI_equality(repr(lh.domain), c)
+            parallel.check_MPI_equality(repr(mean.domain), c)
+            parallel.check_MPI_equality(mean, c, hash=True)
         # partial constants and a preconditioned NewtonCG (napprox) run on the generic graph
         if fuse and device_id >= 0 and ns > 0 and not cst and not pes and getattr(minimizer, "_napprox", 0) <= 1:
             model = _fused_model(lh, device_id, mean_iter["xi"].dtype if "xi" in mean_iter else np.float64)

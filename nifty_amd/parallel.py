@@ -128,6 +128,14 @@ class Comm:
         dist.all_gather_object(out, obj, group=self.group)
         return out
 
+    def bcast_object(self, obj, root=0):
+        """`obj` of rank `root` on every rank (pickled through the host; device Fields are handed over as host copies by
+        their callers).  `root` is a rank of THIS communicator."""
+        box = [obj if self.rank == root else None]
+        src = root if self.group is None else dist.get_global_rank(self.group, root)
+        dist.broadcast_object_list(box, src=src, group=self.group)
+        return box[0]
+
     def bcast_(self, tensor, root=0):
         return self._staged(tensor, lambda x: dist.broadcast(x, src=root, group=self.group))
 
@@ -230,3 +238,118 @@ def get_MPI_params_from_comm(comm):
     if comm is None:
         return 1, 0, True
     return comm.size, comm.rank, comm.rank == 0
+
+
+# ---- rank-synchronisation guards (reference utilities.py:529-585) ----------------------------------------------------
+def _fingerprint(obj):
+    """Bytes that are equal on two ranks iff `obj` is (for every practical purpose) equal.  Host objects: their pickle.
+    Fields / MultiFields on a GPU: per key the fp64 sum and sum of squares from the library's fixed-order reduction
+    (nk_stats) -- equal data gives equal bits, and a 1024^3 mean is fingerprinted in a few milliseconds on the device
+    instead of being copied to the host and hashed (4 GiB, seconds) as the reference's `hash=True` does."""
+    import pickle
+
+    from .field import Field, MultiField
+
+    if isinstance(obj, (Field, MultiField)):
+        from hashlib import blake2b
+
+        items = list(obj.items()) if isinstance(obj, MultiField) else [("", obj)]
+        parts = []
+        for key, f in items:
+            v = f.val
+            if v.is_cuda and not v.is_complex() and v.dtype in (torch.float32, torch.float64):
+                from . import backend as B
+
+                s1, s2, nign = B.stats(v)
+                parts.append((key, tuple(v.shape), str(v.dtype), float(s1).hex(), float(s2).hex(), nign))
+            else:  # host (or exotic dtype): digest of the raw bytes -- a pickle of a tensor is not canonical
+                raw = v.detach().cpu().contiguous().numpy().tobytes()
+                parts.append((key, tuple(v.shape), str(v.dtype), blake2b(raw).hexdigest()))
+        return pickle.dumps(parts)
+    return pickle.dumps(obj)
+
+
+def check_MPI_equality(obj, comm, hash=False):
+    """RuntimeError unless `obj` is the same on all ranks of `comm` (no-op without a communicator).  hash=True compares a
+    digest instead of the pickled object (utilities.py:529-553)."""
+    if comm is None:
+        return
+    blob = _fingerprint(obj)
+    if hash:
+        from hashlib import blake2b
+
+        blob = blake2b(blob).hexdigest()
+    if len(set(comm.allgather_object(blob))) != 1:
+        raise RuntimeError("MPI tasks are not in sync")
+
+
+def check_MPI_synced_random_state(comm):
+    """RuntimeError unless the seed-sequence / generator stacks agree on all ranks (utilities.py:556-571): a rank with
+    a desynchronised stack would silently draw different samples."""
+    if comm is None:
+        return
+    from .random import getState
+
+    check_MPI_equality(getState(), comm)
+
+
+class ensure_all_tasks_succeed:
+    """``with ensure_all_tasks_succeed(comm):`` -- an exception on ANY rank inside the block surfaces as a RuntimeError on
+    EVERY rank (utilities.py:574-585), so that no rank walks on into a collective its failed partner never reaches."""
+
+    def __init__(self, comm):
+        self._comm = comm
+
+    def __enter__(self):
+        if self._comm is not None:
+            self._comm.barrier()
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        ok, message = exc_type is None, "" if exc is None else str(exc)
+        flags = [(ok, message)] if self._comm is None else self._comm.allgather_object((ok, message))
+        if all(f for f, _ in flags):
+            return False
+        raise RuntimeError(message or next(m for f, m in flags if not f)) from exc
+
+
+# ---- which rank draws which sample ---------------------------------------------------------------------------------
+class SamplePlan:
+    """The sample bookkeeping of one KL evaluation, shared by the fused engine (engine.draw_samples) and the generic
+    operator graph (kl.draw_samples): `n_samples` seeds are spawned from the current seed sequence, a mirrored run lists
+    every seed twice (members 2i, 2i+1 of a pair share seed i), and rank r owns the contiguous block
+    shareRange(total, size, r) of that list -- possibly an empty one (reference kl_energies.py:130-146,
+    utilities.py:282-306).  Every rank spawns ALL seeds, so the streams do not depend on the number of ranks."""
+
+    def __init__(self, n_samples, mirror_samples, comm=None):
+        from . import random
+
+        self.mirror = bool(mirror_samples)
+        self.comm = comm
+        self.seeds = [s for s in random.spawn_sseq(n_samples) for _ in range(2 if self.mirror else 1)]
+        ntask, rank, _ = get_MPI_params_from_comm(comm)
+        self.lo, self.hi = shareRange(len(self.seeds), ntask, rank)
+
+    @property
+    def n_total(self):
+        return len(self.seeds)
+
+    def check_synchronised(self):
+        """The reference's guards at this point (kl_energies.py:137-138)."""
+        check_MPI_synced_random_state(self.comm)
+        check_MPI_equality(self.seeds, self.comm)
+
+    def run(self, draw, finish):
+        """For every sample of this rank, inside the sample's own random context: `draw()` makes the linear sample of the
+        pair unless this rank has just drawn it for the pair's first member; `finish(pair, mirrored)` turns it into the
+        stored residual.  Returns the list of finish() results in sample order."""
+        from . import random
+
+        out, pair = [], None
+        for i in range(self.lo, self.hi):
+            mirrored = self.mirror and i % 2 == 1
+            with random.Context(self.seeds[i]):
+                if pair is None or not mirrored:
+                    pair = draw(self.seeds[i])
+                out.append(finish(pair, mirrored))
+        return out

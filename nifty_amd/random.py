@@ -1,143 +1,167 @@
-"""Seed-sequence / generator STACK with the reference's discipline (nifty/cl/random.py:83-290).
+"""Random numbers with the reference's seed discipline (nifty/cl/random.py:83-290): a STACK of numpy
+SeedSequences, each with its own ``default_rng`` (PCG64) generator; draws always come from the top frame.
 
-Parity with the nifty.cl numpy path on identical seeds requires the very same numpy PCG64 streams,
-spawned the same way: the generators live on the host (numpy); large normal draws of device fields are computed on the
-GPU from the generator's state (`Random.normal_on_device` -> nk_pcg64_normal, the same numbers draw for draw).
+Parity with the nifty.cl numpy path on identical seeds requires the very same numpy streams, spawned the same way, so
+the generators live on the host.  Large normal draws of device fields are computed on the GPU from the top generator's
+state (``Random.normal_on_device`` -> nk_pcg64_normal): the values numpy would return -- bit-identical except in the
+ziggurat tail |x| > 3.654 (2.7e-4 of the draws), where the device's log1p may differ from the host libm by <= 4 ulp
+(tests/test_rng.py) -- and the host generator is advanced by exactly the raw draws consumed, so host and device draws
+interleave like in the reference.
 """
 import pickle
+from collections import namedtuple
 
 import numpy as np
 
 # draws smaller than this stay on the host even for device fields (launch + sync cost more than numpy takes)
 DEVICE_DRAW_MIN = 1 << 15
 
-_sseq = [np.random.SeedSequence(42)]
-_rng = [np.random.default_rng(_sseq[-1])]
+_Frame = namedtuple("_Frame", "sseq rng")
 
 
+def _frame(sseq):
+    return _Frame(sseq, np.random.default_rng(sseq))
+
+
+_frames = [_frame(np.random.SeedSequence(42))]  # the reference starts every process on SeedSequence(42) too (:83-85)
+
+
+# ---- the stack -----------------------------------------------------------------------------------------------------
 def getState():
-    return pickle.dumps((_sseq, _rng))
+    """The whole stack as bytes (for setState, the resume file of optimize_kl and the rank-synchronisation guard)."""
+    return pickle.dumps([tuple(f) for f in _frames])
 
 
 def setState(state):
-    global _sseq, _rng
-    _sseq, _rng = pickle.loads(state)
-
-
-def spawn_sseq(n, parent=None):
-    if parent is None:
-        parent = _sseq[-1]
-    return parent.spawn(n)
+    _frames[:] = [_Frame(*f) for f in pickle.loads(state)]
 
 
 def current_rng():
-    return _rng[-1]
+    return _frames[-1].rng
+
+
+def spawn_sseq(n, parent=None):
+    """`n` child SeedSequences of `parent` (default: the top of the stack); advances the parent's spawn counter."""
+    return (_frames[-1].sseq if parent is None else parent).spawn(n)
 
 
 def push_sseq(sseq):
-    _sseq.append(sseq)
-    _rng.append(np.random.default_rng(_sseq[-1]))
+    _frames.append(_frame(sseq))
 
 
 def push_sseq_from_seed(seed):
-    push_sseq(np.random.SeedSequence(seed))
+    _frames.append(_frame(np.random.SeedSequence(seed)))
 
 
 def pop_sseq():
-    _sseq.pop()
-    _rng.pop()
+    _frames.pop()
+
+
+class Context:
+    """``with Context(seed_or_sseq):`` -- draws inside the block come from a fresh generator on that seed; leaving the
+    block restores the previous one and checks that the block left the stack balanced."""
+
+    def __init__(self, inp):
+        self._sseq = inp if isinstance(inp, np.random.SeedSequence) else np.random.SeedSequence(inp)
+        self._height = None
+
+    def __enter__(self):
+        self._height = len(_frames)
+        push_sseq(self._sseq)
+
+    def __exit__(self, exc_type, exc_value, tb):
+        pop_sseq()
+        if len(_frames) != self._height:
+            raise RuntimeError("inconsistent RNG usage detected")
+        return exc_type is None
+
+
+# ---- draws ---------------------------------------------------------------------------------------------------------
+def _kind(dtype):
+    dtype = np.dtype(dtype)
+    for name, abstract in (("complex", np.complexfloating), ("float", np.floating), ("int", np.integer)):
+        if np.issubdtype(dtype, abstract):
+            return dtype, name
+    return dtype, "other"
+
+
+def _check_normal_args(kind, mean, std):
+    if kind not in ("float", "complex"):
+        raise TypeError("dtype must be float or complex")
+    if not (np.isscalar(mean) and np.isscalar(std)):
+        raise TypeError("mean and std must be scalars")
+    if np.issubdtype(type(std), np.complexfloating):
+        raise TypeError("std must not be complex")
+    if kind == "float" and np.issubdtype(type(mean), np.complexfloating):
+        raise TypeError("mean must not be complex for a real result field")
+    if std < 0:
+        raise ValueError("scale < 0")  # numpy's own message for rng.normal; the device path would accept it silently
+
+
+def _two_parts(dtype, shape, draw):
+    """complex result whose real and imaginary parts are drawn one after the other (real first: reference :226-230)."""
+    out = np.empty(shape, dtype=dtype)
+    out.real = draw(0)
+    out.imag = draw(1)
+    return out
 
 
 class Random:
+    """Static draw functions on the top generator (reference random.py:209-258)."""
+
     @staticmethod
     def normal(dtype, shape, mean=0.0, std=1.0):
-        dtype = np.dtype(dtype)
-        if not (np.issubdtype(dtype, np.floating) or np.issubdtype(dtype, np.complexfloating)):
-            raise TypeError("dtype must be float or complex")
-        if not np.isscalar(mean) or not np.isscalar(std):
-            raise TypeError("mean and std must be scalars")
-        if np.issubdtype(type(std), np.complexfloating):
-            raise TypeError("std must not be complex")
-        if np.issubdtype(dtype, np.complexfloating):
-            x = np.empty(shape, dtype=dtype)
-            x.real = _rng[-1].normal(np.real(mean), std, shape)
-            x.imag = _rng[-1].normal(np.imag(mean), std, shape)
-            return x
-        if np.issubdtype(type(mean), np.complexfloating):
-            raise TypeError("mean must not be complex for a real result field")
-        return _rng[-1].normal(mean, std, shape).astype(dtype, copy=False)
+        dtype, kind = _kind(dtype)
+        _check_normal_args(kind, mean, std)
+        rng = current_rng()
+        if kind == "complex":
+            centre = (np.real(mean), np.imag(mean))
+            return _two_parts(dtype, shape, lambda part: rng.normal(centre[part], std, shape))
+        return rng.normal(mean, std, shape).astype(dtype, copy=False)
 
     @staticmethod
     def normal_on_device(dtype, shape, mean, std, device):
         """`normal` for a field that lives on a GPU: the same numpy stream, drawn on the device (backend.pcg64_normal)
-        unless the draw is small or config sampling_rng = "numpy_host"; returns a torch tensor on `device`."""
+        unless the draw is small, of an exotic dtype, or config sampling_rng = "numpy_host"; a torch tensor on `device`."""
         import torch
 
         from . import backend, config
         from .field import _as_tensor
 
-        dtype = np.dtype(dtype)
+        dtype, kind = _kind(dtype)
         n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
-        if config.get("sampling_rng") == "numpy_host" or n < DEVICE_DRAW_MIN or torch.device(device).type != "cuda":
+        real_dt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+                   np.dtype(np.complex64): torch.float32, np.dtype(np.complex128): torch.float64}.get(dtype)
+        on_host = (config.get("sampling_rng") == "numpy_host" or n < DEVICE_DRAW_MIN or real_dt is None
+                   or torch.device(device).type != "cuda")
+        if on_host:
             return _as_tensor(Random.normal(dtype, shape, mean, std), device)
-        if not (np.issubdtype(dtype, np.floating) or np.issubdtype(dtype, np.complexfloating)):
-            raise TypeError("dtype must be float or complex")
-        if not np.isscalar(mean) or not np.isscalar(std):
-            raise TypeError("mean and std must be scalars")
-        if np.issubdtype(type(std), np.complexfloating):
-            raise TypeError("std must not be complex")
-        if np.issubdtype(dtype, np.complexfloating):
-            rdt = torch.float32 if dtype == np.complex64 else torch.float64
-            re = backend.pcg64_normal(_rng[-1], np.real(mean), std, shape, rdt, device)
-            im = backend.pcg64_normal(_rng[-1], np.imag(mean), std, shape, rdt, device)
-            return torch.complex(re, im)
-        if np.issubdtype(type(mean), np.complexfloating):
-            raise TypeError("mean must not be complex for a real result field")
-        tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}.get(dtype)
-        if tdt is None:  # float16 and friends: host path
-            return _as_tensor(Random.normal(dtype, shape, mean, std), device)
-        return backend.pcg64_normal(_rng[-1], mean, std, shape, tdt, device)
+        _check_normal_args(kind, mean, std)
+        rng = current_rng()
+        if kind == "complex":
+            re = backend.pcg64_normal(rng, np.real(mean), std, shape, real_dt, device)
+            return torch.complex(re, backend.pcg64_normal(rng, np.imag(mean), std, shape, real_dt, device))
+        return backend.pcg64_normal(rng, mean, std, shape, real_dt, device)
 
     @staticmethod
     def pm1(dtype, shape):
-        dtype = np.dtype(dtype)
-        if np.issubdtype(dtype, np.complexfloating):
-            x = np.array([1 + 0j, 0 + 1j, -1 + 0j, 0 - 1j], dtype=dtype)
-            x = x[_rng[-1].integers(0, 4, size=shape)]
-        else:
-            x = 2 * _rng[-1].integers(0, 2, size=shape) - 1
-        return x.astype(dtype, copy=False)
+        """+-1 (real) or one of 1, i, -1, -i (complex) with equal probability."""
+        dtype, kind = _kind(dtype)
+        rng = current_rng()
+        if kind == "complex":
+            units = np.array([1, 1j, -1, -1j], dtype=dtype)
+            return units[rng.integers(0, 4, size=shape)]
+        return (2 * rng.integers(0, 2, size=shape) - 1).astype(dtype, copy=False)
 
     @staticmethod
     def uniform(dtype, shape, low=0.0, high=1.0):
-        dtype = np.dtype(dtype)
-        if not np.isscalar(low) or not np.isscalar(high):
+        """Uniform on [low, high): floats; integers: low..high inclusive; complex: both parts."""
+        dtype, kind = _kind(dtype)
+        if not (np.isscalar(low) and np.isscalar(high)):
             raise TypeError("low and high must be scalars")
-        if np.issubdtype(dtype, np.complexfloating):
-            x = np.empty(shape, dtype=dtype)
-            x.real = _rng[-1].uniform(low, high, shape)
-            x.imag = _rng[-1].uniform(low, high, shape)
-        elif np.issubdtype(dtype, np.integer):
-            x = _rng[-1].integers(low, high + 1, shape)
-        else:
-            x = _rng[-1].uniform(low, high, shape)
-        return x.astype(dtype, copy=False)
-
-
-class Context:
-    """``with Context(seed_or_sseq):`` pushes a fresh generator and pops it on exit."""
-
-    def __init__(self, inp):
-        if not isinstance(inp, np.random.SeedSequence):
-            inp = np.random.SeedSequence(inp)
-        self._sseq = inp
-
-    def __enter__(self):
-        self._depth = len(_sseq)
-        push_sseq(self._sseq)
-
-    def __exit__(self, exc_type, exc_value, tb):
-        pop_sseq()
-        if self._depth != len(_sseq):
-            raise RuntimeError("inconsistent RNG usage detected")
-        return exc_type is None
+        rng = current_rng()
+        if kind == "complex":
+            return _two_parts(dtype, shape, lambda part: rng.uniform(low, high, shape))
+        if kind == "int":
+            return rng.integers(low, high + 1, shape).astype(dtype, copy=False)
+        return rng.uniform(low, high, shape).astype(dtype, copy=False)

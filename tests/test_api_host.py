@@ -96,31 +96,44 @@ def test_optimize_kl_host_matches_reference():
         assert gl.lat_relerr(s.asnumpy(), gl.latent(z, f"okl_sample{i}")) < 1e-5
 
 
-def test_optimize_kl_resume(tmp_path):
-    """Interrupted + resumed run equals the uninterrupted one (reference test_mpi/test_optimize_kl.py:117-146)."""
+def _resume_case(tmp_path, device_id, fuse=True, comm=None, rank=0):
+    """Interrupted + resumed run equals the uninterrupted one (reference test_mpi/test_optimize_kl.py:117-146): the
+    sample files, the mean, last_finished_iteration and the RNG state file on disk carry the whole state."""
     z = gl.load("model_g1d")
-    m, cfm, cf, lh = build(z)
+    m, cfm, cf, lh = build(z, device_id)
     ic_s = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=3)
     mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=1), max_cg_iterations=4)  # noqa: E731
+    kw = dict(return_final_position=True, device_id=device_id, fuse=fuse, comm=comm)
 
-    def run(total, outdir, resume):
+    def run(total, outdir, resume, **extra):
         ift.random.push_sseq_from_seed(5)
         try:
-            return ift.optimize_kl(lh, total, 1, mk, ic_s, output_directory=str(outdir), return_final_position=True,
-                                   resume=resume)[1]
+            return ift.optimize_kl(lh, total, 1, mk, ic_s, output_directory=str(outdir), resume=resume, **kw, **extra)
         finally:
             ift.random.pop_sseq()
 
-    full = run(3, tmp_path / "a", False)
+    sl_full, full = run(3, tmp_path / "a", False)
     with pytest.raises(Exception):
-        ift.random.push_sseq_from_seed(5)
-        try:
-            ift.optimize_kl(lh, 3, 1, mk, ic_s, output_directory=str(tmp_path / "b"), return_final_position=True,
-                            terminate_callback=lambda i: (_ for _ in ()).throw(RuntimeError("stop")) if i == 1 else False)
-        finally:
-            ift.random.pop_sseq()
-    resumed = run(3, tmp_path / "b", True)
+        run(3, tmp_path / "b", False,
+            terminate_callback=lambda i: (_ for _ in ()).throw(RuntimeError("stop")) if i == 1 else False)
+    sl_res, resumed = run(3, tmp_path / "b", True)
+    assert resumed.device_id == device_id
     assert gl.lat_relerr(resumed.asnumpy(), full.asnumpy()) < 1e-12
+    for a, b in zip(sl_res.local_iterator(), sl_full.local_iterator()):
+        assert gl.lat_relerr(a.asnumpy(), b.asnumpy()) < 1e-12
+    return full
+
+
+def test_optimize_kl_resume(tmp_path):
+    _resume_case(tmp_path, -1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fuse", [True, False])
+def test_optimize_kl_resume_on_device(tmp_path, fuse):
+    """The same with device fields (samples are written as host pickles and come back to the device), on the fused engine
+    and on the generic graph."""
+    _resume_case(tmp_path, 0, fuse=fuse)
 
 
 def test_linear_operator_modes_and_errors():

@@ -255,3 +255,125 @@ def test_rccl_collectives_of_the_sharded_cg():
     """reduce_scatter_tensor / all_gather_into_tensor / slice all_reduce on the real RCCL backend (one rank: the box has
     one GPU; the multi-rank arithmetic is covered by the gloo tests above)."""
     mp.spawn(_nccl_single_worker, args=(1, _free_port()), nprocs=1, join=True)
+
+
+def _sparse_worker(rank, world, port, out):
+    """Fewer samples than ranks, the distributed iterator and the rank-synchronisation guards (one process group)."""
+    import faulthandler
+
+    faulthandler.dump_traceback_later(200, exit=True)
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from nifty_amd import parallel
+
+    comm, _ = parallel.init("gloo")
+    ift, m, ham, x, v = _problem()
+    res = {}
+    # (1) ONE unmirrored sample on two ranks: rank 1 holds nothing (shareRange(1, 2, 1) is empty; reference
+    # utilities.py:349-414 sums over any split, config 2's 4 samples on an 8-GPU node leave ranks empty as well)
+    ift.random.push_sseq_from_seed(m["seed"] + 9)
+    kl = ift.SampledKLEnergy(x, ham, 1, None, mirror_samples=False, comm=comm)
+    ift.random.pop_sseq()
+    assert kl.samples.n_local_samples() == (1 if rank == 0 else 0) and kl.samples.n_samples == 1
+    mini = ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=5)
+    with parallel.lockstep(comm):
+        kl2, _ = mini(kl)
+    res["one"] = dict(value=kl.value, grad=kl.gradient.asnumpy(), met=kl.apply_metric(v).asnumpy(), min_value=kl2.value,
+                      mean=kl.samples.average().asnumpy())
+    # (2) three samples (2 + 1): every rank iterates over ALL of them in global order (sample_list.py:186-210)
+    ift.random.push_sseq_from_seed(m["seed"] + 5)
+    kl3 = ift.SampledKLEnergy(x, ham, 3, None, mirror_samples=False, comm=comm)
+    ift.random.pop_sseq()
+    everything = [s.asnumpy() for s in kl3.samples.iterator()]
+    assert len(everything) == 3
+    mean, var = kl3.samples.sample_stat()
+    res["three"] = dict(samples=everything, mean=mean.asnumpy(), var=var.asnumpy())
+    # (3) guards (utilities.py:529-585)
+    parallel.check_MPI_equality({"a": 1, "b": [1, 2]}, comm)
+    parallel.check_MPI_equality(x, comm, hash=True)
+    parallel.check_MPI_synced_random_state(comm)
+    with pytest.raises(RuntimeError, match="not in sync"):
+        parallel.check_MPI_equality(rank, comm)
+    ift.random.push_sseq_from_seed(100 + rank)  # a desynchronised seed stack: the reference raises, so do we
+    try:
+        with pytest.raises(RuntimeError, match="not in sync"):
+            ift.SampledKLEnergy(x, ham, 2, None, mirror_samples=True, comm=comm)
+    finally:
+        ift.random.pop_sseq()
+    with pytest.raises(RuntimeError, match="boom on rank 1"):
+        with parallel.ensure_all_tasks_succeed(comm):
+            if rank == 1:
+                raise ValueError("boom on rank 1")
+    with parallel.ensure_all_tasks_succeed(comm):
+        pass
+    torch.save(res, f"{out}.{rank}")
+    comm.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(400)
+def test_ranks_without_samples_distributed_iterator_and_sync_guards(tmp_path):
+    from tests import goldenlib as gl
+
+    out = str(tmp_path / "rank")
+    mp.spawn(_sparse_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0", weights_only=False), torch.load(out + ".1", weights_only=False)
+    ift, m, ham, x, v = _problem()
+    ift.random.push_sseq_from_seed(m["seed"] + 9)
+    kl = ift.SampledKLEnergy(x, ham, 1, None, mirror_samples=False)
+    ift.random.pop_sseq()
+    mini = ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=5)
+    kl2, _ = mini(kl)
+    for r in (r0["one"], r1["one"]):
+        assert abs(r["value"] - kl.value) < 1e-12 * abs(kl.value)
+        assert gl.lat_relerr(r["grad"], kl.gradient.asnumpy()) < 1e-12
+        assert gl.lat_relerr(r["met"], kl.apply_metric(v).asnumpy()) < 1e-12
+        assert abs(r["min_value"] - kl2.value) < 1e-9 * abs(kl2.value)
+        assert gl.lat_relerr(r["mean"], kl.samples.average().asnumpy()) < 1e-12
+    ift.random.push_sseq_from_seed(m["seed"] + 5)
+    kl3 = ift.SampledKLEnergy(x, ham, 3, None, mirror_samples=False)
+    ift.random.pop_sseq()
+    serial = [s.asnumpy() for s in kl3.samples.iterator()]
+    mean, var = kl3.samples.sample_stat()
+    for r in (r0["three"], r1["three"]):
+        for a, b in zip(r["samples"], serial):
+            assert gl.lat_relerr(a, b) < 1e-12
+        assert gl.lat_relerr(r["mean"], mean.asnumpy()) < 1e-12 and gl.lat_relerr(r["var"], var.asnumpy()) < 1e-10
+
+
+def _resume_worker(rank, world, port, base):
+    import faulthandler
+    import pathlib
+
+    faulthandler.dump_traceback_later(250, exit=True)
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from nifty_amd import parallel
+    from tests.test_api_host import _resume_case
+
+    comm, _ = parallel.init("gloo")
+    full = _resume_case(pathlib.Path(base), -1, comm=comm, rank=rank)
+    torch.save(full.asnumpy(), f"{base}/mean.{rank}")
+    comm.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(400)
+def test_two_rank_resume_equals_uninterrupted(tmp_path):
+    """reference test/test_cl/test_mpi/test_optimize_kl.py:117-146 with two ranks: every rank writes its own sample files,
+    rank 0 the mean and the markers; an interrupted and resumed run ends where the uninterrupted one does, and where the
+    single-process run does."""
+    import pathlib
+
+    from tests import goldenlib as gl
+    from tests.test_api_host import _resume_case
+
+    mp.spawn(_resume_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(f"{tmp_path}/mean.{r}", weights_only=False) for r in (0, 1))
+    serial = _resume_case(pathlib.Path(tmp_path) / "serial", -1).asnumpy()
+    for r in (r0, r1):
+        assert gl.lat_relerr(r, serial) < 1e-9
