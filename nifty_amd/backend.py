@@ -450,3 +450,34 @@ def pcg64_normal(rng, mean, std, shape, dtype, device):
     st["state"]["state"] = _pcg64_advanced(state, inc, int(consumed))
     bg.state = st  # keeps has_uint32 / uinteger, exactly like the host draw of doubles does
     return out
+
+
+# ---- operands on another GPU than torch's current one ---------------------------------------------------------------
+# The reference lets Fields live on any device_id; kernels here launch on the CURRENT device's stream.  Instead of refusing
+# such operands every public entry point makes the device of its first tensor argument current for the
+# duration of the call -- a no-op (one attribute read per call) in the common case that it already is.
+def _runs_on_operand_device(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        for a in args:
+            if torch.is_tensor(a):
+                if a.is_cuda and a.device.index != _current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kw)
+                break
+            if isinstance(a, Plan):
+                if a.device.index != _current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kw)
+                break
+        return fn(*args, **kw)
+
+    return wrapper
+
+
+for _name in ("cplx_rows", "hartley", "hartley_fused", "hartley_sandwich", "fftn", "vdot", "vsum", "binary", "axpby",
+              "pointwise", "gather", "scatter_add", "bin_plan", "bin_sum", "spmv", "spmv_t", "stats", "cumsum"):
+    globals()[_name] = _runs_on_operand_device(globals()[_name])
+del _name
