@@ -354,9 +354,34 @@ __global__ void __launch_bounds__((Contig3Tile<T, H>::THREADS))
   nk_contig3_body<T, H, Contig3Tile<T, H>::TILE, PC>(ex, p, f, blockIdx.x, (T*)smem, tw, twr, work);
 }
 
+// QUAD variant: one workgroup per octant row pair of pairs (nk_fft3.h)
+template <typename T, int H, int PC>
+__global__ void __launch_bounds__((Contig3Tile<T, H>::QTHREADS))
+    k3_contig_quad(NkPass3 p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr, C2<T>* __restrict__ work) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  DeviceExec<T, Contig3Tile<T, H>::SC::E> ex;
+  nk_contig3_body<T, H, 4, PC, true>(ex, p, f, blockIdx.x, (T*)smem, tw, twr, work);
+}
+
 template <typename T, int H, int PC>
 static int nk_launch_contig3(const NkPass3& p3, const NkFuse& f, const C2<T>* tw, const C2<T>* twr, C2<T>* work, hipStream_t st) {
   using CT = Contig3Tile<T, H>;
+  if constexpr ((PC == 4 || PC == 5 || PC == 7 || PC == 8) && CT::QUAD_OK) {
+    static const int quad = nk_env_int("NK_CONTIG_QUAD", 1);
+    if (quad && p3.g.ndim == 3) {
+      auto qkern = k3_contig_quad<T, H, PC>;
+      static unsigned long long qattr_mask = 0;
+      if (CT::QLDS_BYTES > 64 * 1024 && nk_first_on_device(qattr_mask)) {
+        hipError_t e = hipFuncSetAttribute((const void*)qkern, hipFuncAttributeMaxDynamicSharedMemorySize, CT::QLDS_BYTES);
+        if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k3_contig_quad)");
+      }
+      const int64_t batch = p3.nlines / ((int64_t)p3.g.na * p3.g.nm);
+      const int64_t qblocks = batch * (p3.g.na / 2 + 1) * (p3.g.nm / 2 + 1);
+      if (qblocks > 0x7fffffffLL) return nk_set_error(NK_ERR_UNSUPPORTED, "too many lines for one launch");
+      hipLaunchKernelGGL(qkern, dim3((unsigned)qblocks), dim3(CT::QTHREADS), CT::QLDS_BYTES, st, p3, f, tw, twr, work);
+      return nk_check_launch("k3_contig_quad");
+    }
+  }
   auto kern = k3_contig<T, H, PC>;
   static unsigned long long attr_mask = 0;  // per-device attribute
   if (CT::LDS_BYTES > 64 * 1024 && nk_first_on_device(attr_mask)) {

@@ -55,24 +55,52 @@ struct Contig3Tile {
   static constexpr int TILE = (T0 / 2 >= 1 && P * (T0 / 2) >= 64) ? T0 / 2 : T0;  // halve while a full wavefront remains
   static constexpr int THREADS = P * TILE;
   static constexpr int LDS_BYTES = 2 * TILE * PITCH * (int)sizeof(T);
+  // QUAD launches (3-D, octant prologue classes): one workgroup = the four rows (a, b), (a, M-b), (A-a, b), (A-a, M-b)
+  static constexpr bool QUAD_OK = P * 4 <= 256;
+  static constexpr int QTHREADS = P * 4;
+  static constexpr int QLDS_BYTES = 2 * 4 * PITCH * (int)sizeof(T);
 };
 
-template <typename T, int H, int TILE, int PC, typename Exec>
+// QUAD (3-D grids, octant prologue classes; TILE == 4): workgroup blk = (batch, a8, b8) over the OCTANT of the first two
+// axes takes the rows (a8, b8), (a8, M - b8), (A - a8, b8), (A - a8, M - b8) -- the four rows of the grid that read the
+// SAME lines of the octant amplitude fields a[pidx], da[pidx].  In natural row order these four rows run at unrelated
+// times on different XCDs and every octant line was fetched about four times (rocprofv3 FETCH_SIZE of the JVP class:
+// 15.2 GB against 9.7 GB of operands, profiles/r02g_pmc_traffic.json); here the first wavefront's request brings the line
+// in and the other rows hit the CU's vector cache.  Rows that coincide with their mirror (a8 or b8 equal to 0 or n/2) stay
+// idle in their duplicate slots (0.4 % of the slots at 1024^2 rows).
+template <typename T, int H, int TILE, int PC, bool QUAD = false, typename Exec>
 NK_HD void nk_contig3_body(Exec& ex, const NkPass3& p, const NkFuse& f, int64_t blk, T* planes,
                            const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr, C2<T>* __restrict__ work) {
   using SC = typename Contig3Tile<T, H>::SC;
   using LY = ContigLayout<H, SC::P>;
   constexpr int E = SC::E, S = SC::S, P = SC::P;
+  static_assert(!QUAD || TILE == 4, "a QUAD workgroup holds exactly four rows");
   T* pre = planes;
   T* pim = planes + TILE * LY::PITCH;
   const int64_t line0 = blk * TILE;
   const int nl = p.g.nl;
+  // row of tile slot t, or -1 for an idle slot
+  auto line_of = [&](int t) -> int64_t {
+    if constexpr (!QUAD) {
+      const int64_t l = line0 + t;
+      return l < p.nlines ? l : -1;
+    } else {
+      const int Mh = p.g.nm / 2 + 1, Ah = p.g.na / 2 + 1;
+      const int64_t bat = blk / ((int64_t)Ah * Mh);
+      const int r = (int)(blk % ((int64_t)Ah * Mh));
+      const int a8 = r / Mh, b8 = r % Mh;
+      const bool ma = (t & 2) != 0, mb = (t & 1) != 0;
+      if ((ma && (a8 == 0 || 2 * a8 == p.g.na)) || (mb && (b8 == 0 || 2 * b8 == p.g.nm))) return -1;
+      return (bat * p.g.na + (ma ? p.g.na - a8 : a8)) * p.g.nm + (mb ? p.g.nm - b8 : b8);
+    }
+  };
 
   ex.phase([&](int tid, PassRegs<T, E>& rg) {
     const int pp = tid % P, t = tid / P;
-    const int64_t line = line0 + t;
+    const int64_t line = line_of(t);
     constexpr int R = SC::radix(0), Q = E / R;
     constexpr bool OCT = PC == 4 || PC == 5 || PC == 7 || PC == 8;
+    static_assert(!QUAD || OCT, "QUAD launches exist for the octant prologue classes only");
     [[maybe_unused]] uint32_t o8 = 0;
     if constexpr (OCT) {
       const uint32_t ch = nl / 2 + 1;
@@ -83,15 +111,16 @@ NK_HD void nk_contig3_body(Exec& ex, const NkPass3& p, const NkFuse& f, int64_t 
         o8 = (uint32_t)nk_fold((int)(line % p.g.na), p.g.na) * ch;
       }
     }
-    const int64_t iu = line0 * nl;           // wave-uniform part of the flat real index
-    const uint32_t tl = (uint32_t)(t * nl);  // < 2^31: a tile of lines
+    // flat real index of the row = iu (wave-uniform where the rows of a tile are consecutive) + tl (per thread)
+    const int64_t iu = QUAD ? (line < 0 ? 0 : line * nl) : line0 * nl;
+    const uint32_t tl = QUAD ? 0u : (uint32_t)(t * nl);  // < 2^31: a tile of lines
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int row = nk_in_row<SC, 0>(pp, q, r);  // complex index j: reals 2j, 2j+1
         C2<T> z{(T)0, (T)0};
-        if (line < p.nlines) {
+        if (line >= 0) {
           if constexpr (OCT) {
             const bool desc = 4 * row >= nl;  // (c, c+1) -> (nl-c, nl-c-1): stored descending, lower position nl-c-1
             const uint32_t c8 = desc ? nl - 2 * row - 1 : 2 * row;
@@ -173,8 +202,8 @@ NK_HD void nk_contig3_body(Exec& ex, const NkPass3& p, const NkFuse& f, int64_t 
     auto row_of = [&](int64_t line) { return work + (line / p.rows_per_slab) * p.ss + (line % p.rows_per_slab) * p.rs; };
     for (int idx = tid; idx < TILE * NK; idx += NT) {
       const int k = idx % NK, t = idx / NK;
-      const int64_t line = line0 + t;
-      if (line >= p.nlines) continue;
+      const int64_t line = line_of(t);
+      if (line < 0) continue;
       C2<T>* dst = row_of(line);
       if (k == 0) {
         const T zx = pre[LY::addr(t, 0)], zy = pim[LY::addr(t, 0)];
@@ -192,8 +221,8 @@ NK_HD void nk_contig3_body(Exec& ex, const NkPass3& p, const NkFuse& f, int64_t 
     }
     const int npad = (int)(p.rs - (H + 1));
     for (int idx = tid; idx < TILE * npad; idx += NT) {
-      const int64_t line = line0 + idx / npad;
-      if (line < p.nlines) row_of(line)[H + 1 + idx % npad] = C2<T>{(T)0, (T)0};
+      const int64_t line = line_of(idx / npad);
+      if (line >= 0) row_of(line)[H + 1 + idx % npad] = C2<T>{(T)0, (T)0};
     }
   });
 }

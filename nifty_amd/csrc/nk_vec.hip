@@ -844,6 +844,48 @@ extern "C" int nk_octant_expand(int ndim, const int64_t* shape, const void* tabl
   return nk_check_launch("k_octant_expand");
 }
 
+// ---- octant expansion for NATURAL binning without an index stream ----------------------------------------------------
+// On a grid with equal harmonic distances the bin of a point is a function of the integer k^2 = a^2 + b^2 + c^2 alone
+// (bins = the ascending distinct k^2, bin_k2[bin] = its k^2).  Step 1 spreads the nb table entries (fp64, as the
+// amplitude kernels produce them) over a DENSE table indexed by k^2 in the field dtype (3 MiB fp32 at 1024^3: L2
+// resident); step 2 writes field8[a][b][c] = dense[a^2 + b^2 + c^2] with the index computed from the coordinates: the only
+// HBM stream left is the store (the plain gather also read one int32 bin index per octant point).
+template <typename T>
+__global__ void __launch_bounds__(256) k_k2_dense(int64_t nb, const int32_t* __restrict__ bin_k2, const double* __restrict__ table,
+                                                  T* __restrict__ dense) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nb) dense[bin_k2[i]] = (T)table[i];
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_octant_expand_k2(NkOct o, const T* __restrict__ dense, T* __restrict__ field8) {
+  // one wavefront per octant line (a, b), four lines per workgroup; lanes run over c
+  const int lane = threadIdx.x & 63;
+  const int64_t line = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (line >= (int64_t)o.Ah * o.Mh) return;
+  const int b = (int)(line % o.Mh), a = (int)(line / o.Mh);
+  const int r2 = a * a + b * b;
+  T* dst = field8 + line * o.Ch;
+  for (int c = lane; c < o.Ch; c += 64) __builtin_nontemporal_store(dense[r2 + c * c], dst + c);
+}
+
+extern "C" int nk_octant_expand_k2(int ndim, const int64_t* shape, const double* table, const int32_t* bin_k2, int64_t nb,
+                                   void* dense, void* field8, int dtype, void* stream) {
+  NkOct o;
+  int rc = nk_make_oct(ndim, shape, o);
+  if (rc != NK_OK) return rc;
+  if (!table || !bin_k2 || !dense || !field8 || nb < 1) return nk_set_error(NK_ERR_INVALID, "nk_octant_expand_k2: bad argument");
+  if ((int64_t)(o.Ah - 1) * (o.Ah - 1) + (int64_t)(o.Mh - 1) * (o.Mh - 1) + (int64_t)(o.Ch - 1) * (o.Ch - 1) >= (1 << 24))
+    return nk_set_error(NK_ERR_UNSUPPORTED, "nk_octant_expand_k2: k^2 range too large");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t lines = (int64_t)o.Ah * o.Mh;
+  NK_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL(k_k2_dense<T>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, nb, bin_k2, table, (T*)dense);
+    hipLaunchKernelGGL(k_octant_expand_k2<T>, dim3((unsigned)((lines + 3) / 4)), dim3(256), 0, st, o, (const T*)dense,
+                       (T*)field8);
+  })
+  return nk_check_launch("k_octant_expand_k2");
+}
+
 extern "C" int nk_octant_scatter(int ndim, const int64_t* shape, const double* w8, const int32_t* pidx, double* abar,
                                  int merge_swapped_lines, void* stream) {
   NkOct o;

@@ -373,6 +373,9 @@ class FusedModel:
                 self.scatter_busiest = int(torch.bincount(key.reshape(-1)).max().item())
                 self.scatter_fixed_point = self.scatter_busiest < (1 << 18)
                 del key, a_idx
+            self.k2_dense = None
+            if self.bin_k2 is not None and os.environ.get("NK_EXPAND_K2", "1") != "0":
+                self.k2_dense = torch.zeros(int(self.bin_k2[-1].item()) + 1, dtype=dtype, device=self.device)
             if self.octant_vjp and self.bin_k2 is None and os.environ.get("NK_SEGMENT_SUM", "1") != "0":
                 self.seg_plan = B.bin_plan(self.pidx8, self.nb)
         # likelihood
@@ -424,8 +427,15 @@ class FusedModel:
     def _amp_field(self, amp, out=None):
         """table[pindex] materialised in the field dtype with one gather per OCTANT point (|k| bins are invariant
         under the sign flip of every axis): every later prologue / epilogue streams the field instead of gathering."""
-        table = amp if self.tdtype == torch.float64 else amp.to(self.tdtype)
         out = torch.empty(self.field_shape, dtype=self.tdtype, device=self.device) if out is None else out
+        if self.k2_dense is not None:
+            # natural binning: the bin is a function of k^2 -- no index stream (nk_octant_expand_k2; NK_EXPAND_K2=0: gather)
+            shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
+            L.check(L.load().nk_octant_expand_k2(len(self.shape), shp, amp.data_ptr(), self.bin_k2.data_ptr(), self.nb,
+                                                 self.k2_dense.data_ptr(), out.data_ptr(), B.dtype_code(out), B._stream()),
+                    "nk_octant_expand_k2")
+            return out
+        table = amp if self.tdtype == torch.float64 else amp.to(self.tdtype)
         if self.pidx8 is not None:
             return B.gather(table, self.pidx8, self.field_shape, out=out)
         shp = (ctypes.c_int64 * len(self.shape))(*self.shape)

@@ -4,6 +4,7 @@
 // Never linked into the product library and never used as a fallback.
 #define NK_HOST_EMU 1
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 #include "../../nifty_amd/csrc/nk_plan.h"
@@ -174,6 +175,23 @@ static void emu3_final(const NkPassF& pf, const nk_fuse& f, const C2<T>* tw, con
 template <typename T, int H>
 static void emu3_contig(const NkPass3& p, const nk_fuse& f, const C2<T>* tw, const C2<T>* twr, C2<T>* work) {
   using CT = Contig3Tile<T, H>;
+  // QUAD launches of the octant classes on 3-D grids: as nk_launch_contig3 (NK_CONTIG_QUAD=0 switches them off there too)
+  const char* qenv = getenv("NK_CONTIG_QUAD");
+  if constexpr (CT::QUAD_OK) {
+    if (f.field_octant && p.g.ndim == 3 && (f.pro == NK_PRO_AMP || f.pro == NK_PRO_AMP_JVP) && !(qenv && atoi(qenv) == 0)) {
+      std::vector<T> qplanes(CT::QLDS_BYTES / sizeof(T));
+      const int64_t batch = p.nlines / ((int64_t)p.g.na * p.g.nm);
+      const int64_t qblocks = batch * (p.g.na / 2 + 1) * (p.g.nm / 2 + 1);
+      for (int64_t blk = 0; blk < qblocks; ++blk) {
+        HostExec<T, CT::SC::E> ex(CT::QTHREADS);
+        if (f.pro == NK_PRO_AMP) nk_contig3_body<T, H, 4, 4, true>(ex, p, f, blk, qplanes.data(), tw, twr, work);
+        else if (f.cg_r && f.dafield) nk_contig3_body<T, H, 4, 8, true>(ex, p, f, blk, qplanes.data(), tw, twr, work);
+        else if (f.pidx_octant && f.dampT) nk_contig3_body<T, H, 4, 7, true>(ex, p, f, blk, qplanes.data(), tw, twr, work);
+        else nk_contig3_body<T, H, 4, 5, true>(ex, p, f, blk, qplanes.data(), tw, twr, work);
+      }
+      return;
+    }
+  }
   std::vector<T> planes(CT::LDS_BYTES / sizeof(T));
   const int64_t blocks = (p.nlines + CT::TILE - 1) / CT::TILE;
   for (int64_t blk = 0; blk < blocks; ++blk) {
