@@ -1445,16 +1445,20 @@ def HarmonicSmoothingOperator(domain, sigma, space=None):
     if sigma == 0.0:
         return ScalingOperator(domain, 1.0)
     domain = DomainTuple.make(domain)
-    if space is None and len(domain) == 1:
+    if space is None:
+        if len(domain) != 1:
+            raise ValueError("need to specify space")
         space = 0
-    if space is None or len(domain) != 1:
-        raise NotImplementedError("HarmonicSmoothingOperator on a sub-space is not implemented yet")
+    space = int(space)
+    if space < 0 or space >= len(domain):
+        raise ValueError("invalid space index")
     if domain[space].harmonic:
         raise TypeError("domain must not be harmonic")
     hartley = HartleyOperator(domain, space=space)
     codomain = hartley.target[space]
     kernel = codomain.get_fft_smoothing_kernel_function(sigma)(codomain.get_k_length_array())
-    return hartley.inverse(DiagonalOperator(kernel)(hartley))
+    # the kernel lives on the transformed sub-space only and is broadcast over the others (diagonal_operator.py:51-120)
+    return hartley.inverse(DiagonalOperator(kernel, hartley.target, space)(hartley))
 
 
 class _JacCountingOperator(EndomorphicOperator):

@@ -200,6 +200,17 @@ def test_harmonic_smoothing_and_counting_operator(device_id):
         op = ift.HarmonicSmoothingOperator(sp, 0.25)
         got = op(ift.makeField(sp, x, device_id)).asnumpy()
         assert gl.relerr(got, _smooth_numpy(x, dist, 0.25)) < 1e-12
+    # on ONE space of a DomainTuple (harmonic_operators.py:340-380 with `space`): the other spaces are carried along
+    un = ift.UnstructuredDomain(3)
+    for doms, space, lead in (((un, sp), 1, True), ((sp, un), 0, False)):
+        op = ift.HarmonicSmoothingOperator(doms, 0.25, space=space)
+        xs = rng.normal(size=op.domain.shape)
+        got = op(ift.makeField(op.domain, xs, device_id)).asnumpy()
+        for i in range(3):
+            ref = _smooth_numpy(xs[i] if lead else xs[..., i], dist, 0.25)
+            assert gl.relerr(got[i] if lead else got[..., i], ref) < 1e-12
+    with pytest.raises(ValueError):
+        ift.HarmonicSmoothingOperator((un, sp), 0.25)  # space must be given for several sub-domains
     assert isinstance(ift.HarmonicSmoothingOperator(sp, 0.0), ift.ScalingOperator)
     with pytest.raises(ValueError):
         ift.HarmonicSmoothingOperator(sp, -1.0)
