@@ -111,6 +111,18 @@ typedef struct nk_fuse {
   double* w8max;        /* optional, with w8 on a 3-D plan: device scalar <- an upper bound of max |w8[x]| of this launch, tight to
                            fp32 rounding (fixed-order maximum over the wavefronts; NK_ERR_UNSUPPORTED on 1-D / 2-D plans).  nk_octant_scatter_k2 takes it as the scale of its fixed-point accumulation, which
                            makes the bin sums independent of the order of the additions (bit-reproducible) */
+  /* ---- nk_hartley_sandwich only: slab pipelining against an exchange on another stream ("chunked to overlap
+   *      with the last adjoint-FFT pass").  pipe_chunks = C (even, divides the first axis; 0 / 1 = off) cuts the first
+   *      axis of `in` / `out` into C equal slab chunks.  The contiguous FIRST pass runs in C/2 stages: stage j touches the
+   *      rows of `in` in the chunks <= j and >= C-1-j only and first waits for pipe_wait[j] (a hipEvent_t recorded by the
+   *      caller once those chunks of `in` have landed -- an all-gather in chunk order j, C-1-j).  The FINAL pass runs in C/2
+   *      stages as well: after stage j the chunks j and C-1-j of `out` are final and pipe_record[j] (an existing
+   *      hipEvent_t) is recorded on `stream`, so that a reduce-scatter of those chunks can start while the later stages
+   *      still compute.  Either array may be NULL.  Results are bit-identical to the unstaged call.  3-D plans with the
+   *      octant prologue classes and batch 1 only (NK_ERR_UNSUPPORTED otherwise). */
+  int pipe_chunks;
+  void* const* pipe_wait;
+  void* const* pipe_record;
 } nk_fuse;
 
 typedef struct nk_plan nk_plan;
@@ -131,6 +143,8 @@ size_t nk_plan_workspace_bytes(const nk_plan* plan);
 int nk_hartley(const nk_plan* plan, const void* in, void* out, double scale, int convention, void* workspace,
                void* stream);
 int nk_hartley_fused(const nk_plan* plan, const nk_fuse* fuse, int convention, void* workspace, void* stream);
+/* 1 if nk_hartley_sandwich on this plan accepts nk_fuse.pipe_chunks == chunks (slab pipelining, see nk_fuse) */
+int nk_plan_pipe_ok(const nk_plan* plan, int chunks);
 /* Hartley SANDWICH  H D H  of a metric application  J^T M J  (LikelihoodEnergyOperator.get_metric_at,
  * operators/energy_operators.py:146-152: SandwichOperator.make(J, M) with J ending / J^T starting in HartleyOperator,
  * harmonic_operators.py:144-161), as ONE call:

@@ -31,6 +31,7 @@ class Fuse(ctypes.Structure):
         ("icov", _vp), ("icov_scalar", _d), ("out2", _vp), ("value", _vp),
         ("afield", _vp), ("dampT", _vp), ("abar_copies", _i), ("abar_stride", _i64), ("dafield", _vp), ("w8", _vp),
         ("field_octant", _i), ("value_slots", _i), ("pidx_octant", _vp), ("cg_r", _vp), ("cg_scal", _vp), ("w8max", _vp),
+        ("pipe_chunks", _i), ("pipe_wait", _vp), ("pipe_record", _vp),
     ]
 
 
@@ -44,6 +45,7 @@ SIGNATURES = {
     "nk_hartley": (_i, [_vp, _vp, _vp, _d, _i, _vp, _vp]),
     "nk_hartley_fused": (_i, [_vp, ctypes.POINTER(Fuse), _i, _vp, _vp]),
     "nk_plan_sandwich": (_i, [_vp]),
+    "nk_plan_pipe_ok": (_i, [_vp, _i]),
     "nk_hartley_sandwich": (_i, [_vp, ctypes.POINTER(Fuse), _d, _i, _vp, _vp]),
     "nk_fftn": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp]),
     "nk_profile_enable": (_i, [_i]),

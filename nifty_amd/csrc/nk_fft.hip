@@ -188,7 +188,7 @@ __global__ void __launch_bounds__((FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREAD
   DeviceExec<T, SchedF<T, NL>::E> ex;
   double acc = 0.0;
   float wmax = 0.0f;
-  const int64_t blk = xmap ? nk_xcd_contig(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t blk = xmap ? nk_xcd_contig(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x + p.blk0;
   nk_final_body<T, NL, FinalTile<T, NL, EC, COUPLES ? 2 : 1>::TILE, COUPLES, EC, PAIR>(ex, p, f, blk, (T*)smem, tw, work, &acc,
                                                                                       (COUPLES && (EC == 2 || EC == -1)) ? &wmax : nullptr);
   nk_flush_energy(f, acc, smem);
@@ -207,12 +207,28 @@ static int nk_launch_final_c(NkPassF pf, const NkFuse& f, const C2<T>* tw, const
   }
   pf.tiles_per_a = (COUPLES && pf.A > 1 && CT::TILE >= 2) ? (pf.M / 2 + 1 + CT::TILE / 2 - 1) / (CT::TILE / 2)
                                                : (pf.M + CT::TILE - 1) / CT::TILE;
-  const int64_t blocks = (int64_t)pf.g.batch * (pf.A / 2 + 1) * pf.tiles_per_a;
-  // every wavefront owns one slot of the energy / |w8| areas (nk_final_with_slots sized them): never drop a partial silently
-  if (f.value_slots > 0 && blocks * ((CT::THREADS + 63) / 64) > f.value_slots)
-    return nk_set_error(NK_ERR_RUNTIME, "final pass: more wavefronts than reduction slots (nk_value_slot_count)");
+  int64_t blocks = (int64_t)pf.g.batch * (pf.A / 2 + 1) * pf.tiles_per_a;
   static const int xmap_env = nk_env_int("NK_XMAP", NK_XMAP_DEFAULT);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CT::THREADS), CT::LDS_BYTES, st, pf, f, tw, work, xmap_env & 4);
+  NkFuse fs = f;
+  pf.blk0 = 0;
+  if (pf.a_cnt > 0) {
+    // one stage of a pipelined sandwich: the workgroups of the pair indices a0 .. a0 + a_cnt - 1, their reduction slots
+    // where the whole launch would have them (slot = workgroup * waves + wave)
+    if (pf.g.batch != 1 || (xmap_env & 4)) return nk_set_error(NK_ERR_UNSUPPORTED, "staged final pass: batch 1, natural block order");
+    pf.blk0 = (int64_t)pf.a0 * pf.tiles_per_a;
+    blocks = (int64_t)pf.a_cnt * pf.tiles_per_a;
+    const int64_t off = pf.blk0 * ((CT::THREADS + 63) / 64);
+    if (fs.value_slots > 0) {
+      if (fs.value) fs.value += off;
+      if (fs.w8max) fs.w8max += off;
+      fs.value_slots = fs.value_slots > off ? (int)(fs.value_slots - off) : 0;
+      if (fs.value_slots == 0) return nk_set_error(NK_ERR_RUNTIME, "final pass: more wavefronts than reduction slots (nk_value_slot_count)");
+    }
+  }
+  // every wavefront owns one slot of the energy / |w8| areas (nk_final_with_slots sized them): never drop a partial silently
+  if (fs.value_slots > 0 && blocks * ((CT::THREADS + 63) / 64) > fs.value_slots)
+    return nk_set_error(NK_ERR_RUNTIME, "final pass: more wavefronts than reduction slots (nk_value_slot_count)");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CT::THREADS), CT::LDS_BYTES, st, pf, fs, tw, work, xmap_env & 4);
   return nk_check_launch("k2_final");
 }
 
@@ -360,7 +376,7 @@ __global__ void __launch_bounds__((Contig3Tile<T, H>::QTHREADS))
     k3_contig_quad(NkPass3 p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr, C2<T>* __restrict__ work) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, Contig3Tile<T, H>::SC::E> ex;
-  nk_contig3_body<T, H, 4, PC, true>(ex, p, f, blockIdx.x, (T*)smem, tw, twr, work);
+  nk_contig3_body<T, H, 4, PC, true>(ex, p, f, (int64_t)blockIdx.x + p.blk0, (T*)smem, tw, twr, work);
 }
 
 template <typename T, int H, int PC>
@@ -376,12 +392,19 @@ static int nk_launch_contig3(const NkPass3& p3, const NkFuse& f, const C2<T>* tw
         if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k3_contig_quad)");
       }
       const int64_t batch = p3.nlines / ((int64_t)p3.g.na * p3.g.nm);
-      const int64_t qblocks = batch * (p3.g.na / 2 + 1) * (p3.g.nm / 2 + 1);
+      int64_t qblocks = batch * (p3.g.na / 2 + 1) * (p3.g.nm / 2 + 1);
+      if (p3.nblk > 0) {  // one stage of a pipelined sandwich
+        if (batch != 1 || p3.blk0 < 0 || p3.blk0 + p3.nblk > qblocks) return nk_set_error(NK_ERR_INVALID, "k3_contig_quad: bad stage range");
+        qblocks = p3.nblk;
+      }
       if (qblocks > 0x7fffffffLL) return nk_set_error(NK_ERR_UNSUPPORTED, "too many lines for one launch");
       hipLaunchKernelGGL(qkern, dim3((unsigned)qblocks), dim3(CT::QTHREADS), CT::QLDS_BYTES, st, p3, f, tw, twr, work);
       return nk_check_launch("k3_contig_quad");
     }
   }
+  if (p3.nblk > 0)
+    return nk_set_error(NK_ERR_UNSUPPORTED, "nk_fuse.pipe_chunks: the staged first pass exists for the QUAD launches only (3-D plan, "
+                                             "octant prologue classes, last axis <= 2048 fp32, NK_CONTIG_QUAD != 0)");
   auto kern = k3_contig<T, H, PC>;
   static unsigned long long attr_mask = 0;  // per-device attribute
   if (CT::LDS_BYTES > 64 * 1024 && nk_first_on_device(attr_mask)) {
@@ -1044,6 +1067,26 @@ extern "C" int nk_plan_sandwich(const nk_plan* P) {
 }
 
 template <typename T>
+static bool nk_contig3_quad_ok(int h) {
+  switch (h) {
+#define NK_CASE(NN) \
+  case NN:          \
+    return Contig3Tile<T, NN>::QUAD_OK;
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+  }
+  return false;
+}
+// 1 if nk_hartley_sandwich on this plan accepts nk_fuse.pipe_chunks == chunks (with an octant amplitude prologue)
+extern "C" int nk_plan_pipe_ok(const nk_plan* P, int chunks) {
+  if (!nk_plan_sandwich(P) || chunks < 2 || (chunks & 1)) return 0;
+  const NkGeom& g = P->hp.g;
+  if (g.ndim != 3 || g.batch != 1 || g.na % chunks != 0) return 0;
+  if (!nk_env_int("NK_CONTIG_QUAD", 1) || (nk_env_int("NK_XMAP", NK_XMAP_DEFAULT) & 4)) return 0;
+  return (P->hp.dtype == NK_F32 ? nk_contig3_quad_ok<float>(g.h) : nk_contig3_quad_ok<double>(g.h)) ? 1 : 0;
+}
+
+template <typename T>
 static int nk_run_sandwich(const nk_plan* P, const NkFuse& f, double scale_first, int convention, void* workspace, hipStream_t st) {
   const NkHostPlan& hp = P->hp;
   const int sign = convention == NK_HARTLEY_CANONICAL ? -1 : 1;
@@ -1055,11 +1098,36 @@ static int nk_run_sandwich(const nk_plan* P, const NkFuse& f, double scale_first
     return nk_set_error(NK_ERR_UNSUPPORTED, "transform too large for the 32-bit thread offsets of the strided passes");
   C2<T>* work = (C2<T>*)workspace;
   int rc;
-  {
+  // slab pipelining (nk_fuse.pipe_chunks): C/2 stages of the first and of the final pass, see include/niftyk.h
+  const int C = f.pipe_chunks >= 2 ? f.pipe_chunks : 0;
+  if (C) {
+    if (hp.g.ndim != 3 || hp.g.batch != 1 || (C & 1) || hp.g.na % C != 0 || !f.field_octant ||
+        (f.pro != NK_PRO_AMP && f.pro != NK_PRO_AMP_JVP))
+      return nk_set_error(NK_ERR_UNSUPPORTED, "nk_fuse.pipe_chunks: needs a 3-D plan with batch 1, an even chunk count that divides "
+                                               "the first axis, and an octant amplitude prologue");
+  }
+  const int wc = C ? hp.g.na / C : 0;  // slabs per chunk
+  if (C) {
+    const int Mh = hp.g.nm / 2 + 1;
+    for (int j = 0; j < C / 2; ++j) {
+      // rows a8 = j wc .. (j+1) wc - 1 (the last stage also a8 = na / 2) and their mirrors: chunks <= j and >= C-1-j of `in`
+      if (f.pipe_wait) {
+        hipError_t e = hipStreamWaitEvent(st, (hipEvent_t)f.pipe_wait[j], 0);
+        if (e != hipSuccess) return nk_set_hip_error(e, "hipStreamWaitEvent(pipe_wait)");
+      }
+      NkPass3 p1 = q.p1;
+      const int a_lo = j * wc, a_hi = (j == C / 2 - 1) ? hp.g.na / 2 + 1 : (j + 1) * wc;
+      p1.blk0 = (int64_t)a_lo * Mh;
+      p1.nblk = (int64_t)(a_hi - a_lo) * Mh;
+      ProfScope ps(st, 5, f.pro, f.epi);
+      rc = nk_dispatch_contig3<T>(hp.g.h, p1, f, (const C2<T>*)P->d_tw_a, (const C2<T>*)P->d_twr_a, work, st);
+      if (rc != NK_OK) return rc;
+    }
+  } else {
     ProfScope ps(st, 5, f.pro, f.epi);
     rc = nk_dispatch_contig3<T>(hp.g.h, q.p1, f, (const C2<T>*)P->d_tw_a, (const C2<T>*)P->d_twr_a, work, st);
+    if (rc != NK_OK) return rc;
   }
-  if (rc != NK_OK) return rc;
   if (hp.g.ndim == 3) {
     ProfScope ps(st, 6, f.pro, f.epi);
     rc = nk_dispatch_strided<T, 0>(hp.g.nm, q.s2, f, (const C2<T>*)P->d_tw_b, work, (C2<T>*)nullptr, st);
@@ -1077,7 +1145,20 @@ static int nk_run_sandwich(const nk_plan* P, const NkFuse& f, double scale_first
   }
   ProfScope ps(st, 3, f.pro, f.epi);
   return nk_final_with_slots(hp, workspace, f, st, [&](const NkFuse& f2) {
-    return nk_dispatch_final3<T>(hp.g.nl, q.pf, f2, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
+    if (!C) return nk_dispatch_final3<T>(hp.g.nl, q.pf, f2, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
+    for (int j = 0; j < C / 2; ++j) {
+      // pair indices a = j wc + 1 .. (j+1) wc (stage 0 also a = 0): afterwards the chunks j and C-1-j of `out` are final
+      NkPassF pf = q.pf;
+      pf.a0 = j == 0 ? 0 : j * wc + 1;
+      pf.a_cnt = (j + 1) * wc + 1 - pf.a0;
+      int rcj = nk_dispatch_final3<T>(hp.g.nl, pf, f2, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
+      if (rcj != NK_OK) return rcj;
+      if (f.pipe_record) {
+        hipError_t e = hipEventRecord((hipEvent_t)f.pipe_record[j], st);
+        if (e != hipSuccess) return nk_set_hip_error(e, "hipEventRecord(pipe_record)");
+      }
+    }
+    return (int)NK_OK;
   });
 }
 

@@ -1007,6 +1007,8 @@ struct NkPassF {
   int blo;           // work array layout, see nk_strided_body
   int64_t ss;        // slab stride (0: plain natural layout)
   int64_t rs;        // row stride of the work array in complex elements (0: nl / 2)
+  int a0, a_cnt;     // one pipeline stage of the sandwich: first-axis pair indices a0 .. a0 + a_cnt - 1 (a_cnt == 0: all)
+  int64_t blk0;      // first workgroup of the stage (= a0 * tiles_per_a, set by the launcher)
 };
 
 // EC: compile-time epilogue class (0 affine, 1 multiply, 2 scatter/VJP with materialised amplitude field,

@@ -32,6 +32,7 @@ struct NkPass3 {
   int64_t nlines;     // batch * na * nm
   int rows_per_slab;  // lines per work slab (3-D: nm, 2-D: na)
   int64_t rs, ss;     // work row stride / slab stride in complex elements
+  int64_t blk0, nblk; // QUAD launches of one pipeline stage: workgroups blk0 .. blk0 + nblk - 1 (nblk == 0: all)
 };
 
 // thread id -> line thread pp = tid % P, line t = tid / P; LDS: two scalar planes (re, im) of TILE * PITCH elements

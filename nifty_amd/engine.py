@@ -628,9 +628,11 @@ class FusedModel:
         self.counters["transforms"] += 1
         return self.response.times(self.tmp)
 
-    def lh_metric_accumulate(self, lp, d, out, scale, first, identity=0.0, dot_out=None, cg_direction=None):
+    def lh_metric_accumulate(self, lp, d, out, scale, first, identity=0.0, dot_out=None, cg_direction=None, pipe=None):
         """out (+)= scale * J^T M J d  (+ identity * d): the likelihood Fisher metric pulled back to latent space;
         the optional multiple of d (prior metric = 1) rides along in the VJP epilogue of the xi part.
+        pipe = (chunks, wait_events or None, record_events or None): slab pipelining of the sandwich against an exchange
+        on another stream (nk_fuse.pipe_chunks; the arrays are ctypes arrays of hipEvent_t handles).
         cg_direction = (r, workspace): d.xi <- beta d.xi + r.xi first, inside the sandwich's first pass (d.small was
         updated by the caller: CgWorkspace.direction_small); the workspace scalars are rolled afterwards."""
         if cg_direction is not None and not self.fused_direction:
@@ -661,7 +663,13 @@ class FusedModel:
                 f.dafield = self.dafield.data_ptr()
             if cg_direction is not None:
                 f.cg_r, f.cg_scal = cg_direction[0].xi.data_ptr(), cg_direction[1].scal.data_ptr()
+            if pipe is not None:
+                f.pipe_chunks = pipe[0]
+                f.pipe_wait = None if pipe[1] is None else ctypes.cast(pipe[1], ctypes.c_void_p)
+                f.pipe_record = None if pipe[2] is None else ctypes.cast(pipe[2], ctypes.c_void_p)
 
+        if pipe is not None and not self.sandwich:
+            raise ValueError("slab pipelining needs the sandwich pipeline")
         if self.sandwich:
             # H D H in five passes: the position-space field between the transforms never exists (nk_fft3.h)
             self._vjp(lp, None, scale, d.xi if identity else None, identity, not first, out.xi, dot_out=dot_out,
@@ -896,19 +904,24 @@ class FusedKL(Energy):
     def at(self, position):
         return FusedKL(self.model, position, self.residuals, self.negs, self.n_total, self.comm, self.nanisinf)
 
-    def _apply_metric_local(self, d, dot_out=None, cg_direction=None):
-        """This rank's share of the KL metric applied to d (no communication)."""
+    def _apply_metric_local(self, d, dot_out=None, cg_direction=None, pipe=None):
+        """This rank's share of the KL metric applied to d (no communication).  pipe = (chunks, wait, record): the FIRST
+        local sample's transform waits chunk by chunk for d, the LAST one records chunk by chunk that `out` is final."""
         m = self.model
         out = LatentVec(torch.empty_like(d.xi), None)
         w = 1.0 / self.n_total
         nloc = len(self.lins)
         for i, lp in enumerate(self.lins):
+            stage = None
+            if pipe is not None:
+                stage = (pipe[0], pipe[1] if i == 0 else None, pipe[2] if i == nloc - 1 else None)
             # prior term (identity): every rank contributes its share nloc/n_total of d with its LAST sample, fused
             # into that sample's VJP epilogue (the sum over ranks is d); the same epilogue sees the finished local
             # q = A d and can take d.q on the way (single process only)
             last = i == nloc - 1
             m.lh_metric_accumulate(lp, d, out, w, i == 0, identity=nloc * w if last else 0.0,
-                                   dot_out=dot_out if last else None, cg_direction=cg_direction if i == 0 else None)
+                                   dot_out=dot_out if last else None, cg_direction=cg_direction if i == 0 else None,
+                                   pipe=stage)
         if nloc == 0:
             out = LatentVec.zeros(m)
         return out
@@ -938,36 +951,129 @@ class FusedKL(Energy):
 class ShardedMetric:
     """The KL metric for a CG whose vectors are sharded over the ranks: instead of all-reducing the
     N-sized metric output and repeating every CG vector update on all ranks, the sample sum is REDUCE-SCATTERED
-    (each rank receives its 1/size slice of q), the CG updates run on that slice, and only the new search direction
+    (each rank receives its 1/size share of q), the CG updates run on that share, and only the new search direction
     is ALL-GATHERED for the next metric application.  Same bytes on the links as the all-reduce (which is a
-    reduce-scatter followed by an all-gather), 1/size of the vector work and memory per rank."""
+    reduce-scatter followed by an all-gather), 1/size of the vector work and memory per rank.
+
+    Chunked, overlapped exchange (round 3).  The xi part is cut along the first axis into C slab chunks
+    (NK_PIPE_CHUNKS, default 8; 1 = the unchunked exchange) and a rank's share is the rank-th 1/size of EVERY chunk,
+    i.e. the flat vector viewed as [C][size][m] is owned as [:, rank, :] (the CG updates are element-wise, any fixed
+    subset will do).  Every chunk of the full vector is then contiguous, so chunk-wise all_gather_into_tensor /
+    reduce_scatter_tensor work in place on the natural layout.  The collectives run on a side stream:
+      * the all-gather of d is issued chunk by chunk in the order 0, C-1, 1, C-2, ... and the contiguous first pass of the
+        first local sample's transform starts on the rows whose chunks have landed (nk_fuse.pipe_wait);
+      * the final pass of the last local sample's transform finishes `out` chunk pair by chunk pair (nk_fuse.pipe_record)
+        and the reduce-scatter of a pair starts while the later pairs are still computed.
+    The three passes in between need the whole array, so at most the first (3.3 ms at 1024^3 fp32) and the final pass
+    (4.0 ms) hide communication.  The staged passes and the overlap change no arithmetic: for a given C the results are
+    bit-identical with and without them (NK_PIPE_OVERLAP=0), and on one rank for every C.  With several ranks C decides
+    which elements a rank owns, i.e. how the CG's dot products are grouped into per-rank partial sums: results for
+    different C agree to rounding, exactly like results for different rank counts (tests/test_distributed_gloo.py)."""
 
     def __init__(self, kl):
         self.kl, self.comm, self.model = kl, kl.comm, kl.model
-        n = kl.model.N // self.comm.size
-        self.lo, self.hi = self.comm.rank * n, (self.comm.rank + 1) * n
+        model, P = self.model, self.comm.size
+        C = int(os.environ.get("NK_PIPE_CHUNKS", "8"))
+        ok = (C >= 2 and model.sandwich and len(model.shape) == 3 and len(kl.lins) > 0
+              and bool(L.load().nk_plan_pipe_ok(model.plan.handle, C)) and (model.N // C) % P == 0)
+        # every rank must take the same decision (a rank without samples cannot stage its transform: it has none)
+        if P > 1:
+            ok = all(self.comm.allgather_object(bool(ok)))
+        self.chunks = C if ok else 1
+        self.m = model.N // (self.chunks * P)  # elements of this rank per chunk
+        self.native = self.comm.backend_is_nccl
+        self._side = self._ev_in = self._ev_out = None
+        # NK_PIPE_OVERLAP=0: the same chunked ownership and collectives, but one-launch passes and a blocking exchange on
+        # the compute stream (A/B for the overlap; bit-identical results)
+        self.overlap = os.environ.get("NK_PIPE_OVERLAP", "1") != "0"
+        if self.chunks > 1 and self.native and self.overlap:
+            cache = model.__dict__.setdefault("_pipe_cache", {})  # side stream and events live as long as the model
+            if self.chunks not in cache:
+                ns = self.chunks // 2
+                side = torch.cuda.Stream(device=model.device)
+                ev_in, ev_out = [torch.cuda.Event() for _ in range(ns)], [torch.cuda.Event() for _ in range(ns)]
+                for ev in ev_in + ev_out:
+                    ev.record()  # creates the underlying hipEvent_t; every later record replaces this one
+                cache[self.chunks] = (side, ev_in, ev_out, (ctypes.c_void_p * ns)(*[ev.cuda_event for ev in ev_in]),
+                                      (ctypes.c_void_p * ns)(*[ev.cuda_event for ev in ev_out]))
+            self._side, self._ev_in, self._ev_out, self._h_in, self._h_out = cache[self.chunks]
+
+    # -- layout ---------------------------------------------------------------------------------------------------------
+    def _mine(self, flat):
+        """This rank's share of a full flat vector as a [C, m] view."""
+        return flat.view(self.chunks, self.comm.size, self.m)[:, self.comm.rank, :]
 
     def shard(self, v, copy=False):
-        xi = v.xi.reshape(-1)[self.lo:self.hi]
-        return LatentVec(xi.clone(), v.small.clone()) if copy else LatentVec(xi, v.small)
+        xi = self._mine(v.xi.reshape(-1))
+        if self.chunks == 1:
+            xi = xi.reshape(-1)
+            return LatentVec(xi.clone(), v.small.clone()) if copy else LatentVec(xi, v.small)
+        return LatentVec(xi.reshape(-1) if xi.is_contiguous() else xi.contiguous().view(-1),
+                         v.small.clone() if copy else v.small)
 
     def workspace(self):
         return ShardedCgWorkspace(self.model.device, self.comm)
 
-    def apply(self, d_full):
-        out = self.kl._apply_metric_local(d_full)
-        q_xi = torch.empty(self.hi - self.lo, dtype=out.xi.dtype, device=out.xi.device)
-        self.comm.reduce_scatter_sum(out.xi.reshape(-1), q_xi)
-        self.comm.allreduce_sum_([out.small])
-        return LatentVec(q_xi, out.small)
+    def _stage_chunks(self):
+        """Chunk pairs in the order the kernels' stages need them: (0, C-1), (1, C-2), ..."""
+        C = self.chunks
+        return [(j, C - 1 - j) for j in range(C // 2)] if C > 1 else [(0,)]
 
+    # -- exchange -------------------------------------------------------------------------------------------------------
     def gather(self, shard_vec, out_full=None):
+        """Full vector from the shares (blocking on the current stream)."""
         if out_full is None:
             out_full = LatentVec(torch.empty(self.model.shape, dtype=shard_vec.xi.dtype, device=shard_vec.xi.device),
                                  torch.empty_like(shard_vec.small))
-        self.comm.all_gather(shard_vec.xi, out_full.xi.reshape(-1))
+        full = out_full.xi.reshape(-1).view(self.chunks, -1)
+        mine = shard_vec.xi.view(self.chunks, self.m)
+        for c in range(self.chunks):
+            self.comm.all_gather(mine[c], full[c])
         out_full.small.copy_(shard_vec.small)
         return out_full
+
+    def apply(self, d_full):
+        """q share = this rank's part of (sum over ranks of the local metric applied to the FULL d): unpipelined entry
+        (residual refresh; callers that hold the full vector already)."""
+        staged = self.chunks > 1 and self.overlap
+        return self._reduce(self.kl._apply_metric_local(d_full, pipe=(self.chunks, None, None) if staged else None))
+
+    def _reduce(self, out):
+        q_xi = torch.empty(self.chunks * self.m, dtype=out.xi.dtype, device=out.xi.device)
+        full = out.xi.reshape(-1).view(self.chunks, -1)
+        for c in range(self.chunks):
+            self.comm.reduce_scatter_sum(full[c], q_xi[c * self.m:(c + 1) * self.m])
+        self.comm.allreduce_sum_([out.small])
+        return LatentVec(q_xi, out.small)
+
+    def apply_shard(self, d_shard, d_full):
+        """q share for the search direction held as a share: all-gather d into `d_full`, apply the local metric, reduce-
+        scatter -- with the exchange overlapped chunk by chunk when RCCL runs it on the side stream."""
+        if self._side is None:  # one chunk, or a backend that stages through the host (gloo: tests)
+            self.gather(d_shard, d_full)
+            return self.apply(d_full)
+        cur = torch.cuda.current_stream(self.model.device)
+        side, pairs = self._side, self._stage_chunks()
+        full = d_full.xi.reshape(-1).view(self.chunks, -1)
+        mine = d_shard.xi.view(self.chunks, self.m)
+        d_full.small.copy_(d_shard.small)
+        side.wait_stream(cur)  # the share of d is final
+        with torch.cuda.stream(side):
+            for j, pair in enumerate(pairs):
+                for c in pair:
+                    self.comm.all_gather(mine[c], full[c])
+                self._ev_in[j].record(side)
+        out = self.kl._apply_metric_local(d_full, pipe=(self.chunks, self._h_in, self._h_out))
+        q_xi = torch.empty(self.chunks * self.m, dtype=out.xi.dtype, device=out.xi.device)
+        ofull = out.xi.reshape(-1).view(self.chunks, -1)
+        with torch.cuda.stream(side):
+            for j, pair in enumerate(pairs):
+                side.wait_event(self._ev_out[j])
+                for c in pair:
+                    self.comm.reduce_scatter_sum(ofull[c], q_xi[c * self.m:(c + 1) * self.m])
+        cur.wait_stream(side)
+        self.comm.allreduce_sum_([out.small])
+        return LatentVec(q_xi, out.small)
 
 
 class FusedGeoEnergy(Energy):

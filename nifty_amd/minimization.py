@@ -537,7 +537,7 @@ class ConjugateGradient(Minimizer):
             return energy.at_with_grad(sm.gather(x), sm.gather(r)), status
 
         while True:
-            q = sm.apply(d_full)
+            q = sm.apply_shard(d, d_full)  # all-gather of d, local metric, reduce-scatter (overlapped chunk by chunk)
             ws.curv(d, q)
             if track_energy:
                 ws.update_dr(x, r, d, q)
@@ -569,7 +569,6 @@ class ConjugateGradient(Minimizer):
             if status != CONTINUE:
                 return finish(status)
             ws.direction(d, r)
-            sm.gather(d, d_full)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -515,3 +515,59 @@ def test_reductions_on_concurrent_streams_do_not_share_scratch():
             L.check(lib.nk_vdot(n, a[i].data_ptr(), a[(i + 1) % 4].data_ptr(), L.NK_F32, out[i:i + 1].data_ptr(), 0, st))
         torch.cuda.synchronize()
         assert torch.equal(out, serial), rep
+
+
+@pytest.mark.parametrize("shape,dtype", [((64, 64, 128), torch.float64), ((128, 64, 256), torch.float32)])
+def test_staged_sandwich_is_bit_identical(shape, dtype):
+    """nk_fuse.pipe_chunks: the first and the final pass of the sandwich in C/2 stages (slab pipelining against the
+    exchange of the sharded CG) write the same bits as the one-launch passes -- with and without the event hand-over."""
+    import ctypes
+
+    from nifty_amd import _lib as L
+    from nifty_amd import random
+    from nifty_amd.engine import FusedModel, LatentVec
+
+    model = FusedModel(shape, offset_mean=2.0, likelihood="gaussian", icov=100.0, dtype=dtype, device="cuda:0")
+    assert model.sandwich
+    random.push_sseq_from_seed(4)
+    try:
+        x = model.draw_prior() * 0.1
+        model.set_data(model.signal(model.draw_prior()), 100.0)
+        d = model.draw_prior()
+    finally:
+        random.pop_sseq()
+    lp = model.linearize(x)
+
+    def run(pipe, accumulate_into=None):
+        out = LatentVec(torch.zeros_like(d.xi), None) if accumulate_into is None else accumulate_into
+        dot = torch.zeros(1, dtype=torch.float64, device="cuda")
+        model.lh_metric_accumulate(lp, d, out, 0.5, accumulate_into is None, identity=1.0, dot_out=dot, pipe=pipe)
+        return out.xi.clone(), out.small.clone(), dot.clone(), model.abar.clone()
+
+    ref = run(None)
+    for C in (2, 4, 8, 16):
+        assert L.load().nk_plan_pipe_ok(model.plan.handle, C) == 1
+        got = run((C, None, None))
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), C
+        # events: `wait` recorded on a side stream before the call, `record` consumed by a side stream after it
+        ns = C // 2
+        side = torch.cuda.Stream()
+        ev_in, ev_out = [torch.cuda.Event() for _ in range(ns)], [torch.cuda.Event() for _ in range(ns)]
+        for ev in ev_in + ev_out:
+            ev.record()
+        with torch.cuda.stream(side):
+            for ev in ev_in:
+                torch.cuda._sleep(200000)
+                ev.record(side)
+        h_in = (ctypes.c_void_p * ns)(*[ev.cuda_event for ev in ev_in])
+        h_out = (ctypes.c_void_p * ns)(*[ev.cuda_event for ev in ev_out])
+        got = run((C, h_in, h_out))
+        for ev in ev_out:
+            side.wait_event(ev)
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), C
+    assert L.load().nk_plan_pipe_ok(model.plan.handle, 3) == 0 and L.load().nk_plan_pipe_ok(model.plan.handle, 6) == 0
+    with pytest.raises(NotImplementedError):
+        run((6, None, None))  # 6 does not divide the first axis
