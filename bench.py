@@ -510,6 +510,7 @@ def main():
         print(json.dumps(line), flush=True)
     if comm is not None:
         comm.barrier()
+        torch.distributed.destroy_process_group()  # or ProcessGroupNCCL complains on stderr after the line
 
 
 if __name__ == "__main__":
