@@ -38,7 +38,7 @@ from nifty_amd import minimization, parallel, random  # noqa: E402
 from nifty_amd.engine import FusedModel, LatentVec, mgvi_iteration  # noqa: E402
 from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG  # noqa: E402
 
-PMC_TRAFFIC_FILE = os.environ.get("NK_PMC_FILE", "r02g_pmc_traffic.json")  # latest committed PMC summary of the bench command
+PMC_TRAFFIC_FILE = os.environ.get("NK_PMC_FILE", "r03c_pmc_traffic.json")  # latest committed PMC summary of the bench command
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # transform pass kernels by profile id: strided-first pipeline (A first strided pass with prologue, B in-place strided
 # pass, C final contiguous pass with epilogue) and the five-pass sandwich H D H of a metric application (S1 contiguous
@@ -413,7 +413,8 @@ def main():
                 tj = json.load(open(tfile))
                 if tj.get("workload") == f"{'x'.join(map(str, shape))}:{dt_name}":
                     traffic = tj["kernels"].get(KERNEL_NAMES[kern], {}).get("bytes")
-                    traffic_source = f"profiles/{PMC_TRAFFIC_FILE} (separate rocprofv3 --pmc passes, not this run)"
+                    traffic_source = (f"profiles/{PMC_TRAFFIC_FILE} (separate rocprofv3 --pmc passes of this command at "
+                                      f"commit {tj.get('commit', '?')}, not this run)")
             roofline = dict(bound="hbm", kernel=KERNEL_NAMES[kern], achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                             unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
                             avg_launch_ms=round(avg_ms, 4), launches=int(ent["cnt"]),
