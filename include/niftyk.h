@@ -333,6 +333,20 @@ int nk_amp_vjp(int nb, const double* geo, const double* hyp, const double* lat, 
 int64_t nk_pcg64_normal_scratch_bytes(int64_t n, int attempt);
 int nk_pcg64_normal(const uint64_t* state, const uint64_t* inc, int64_t n, double mean, double std, void* out, int dtype,
                     void* scratch, int64_t scratch_bytes, int attempt, uint64_t* status, void* stream);
+/* Draws that consume a FIXED number of raw PCG64 values per output (plain jump-ahead parallelism), for fields on a GPU:
+ * nk_pcg64_uniform: out[i] = low + (high - low) * next_double -- `Generator.uniform(low, high, n)` behind Random.uniform
+ *                   (nifty/cl/random.py:249-258); consumes n raw draws.
+ * nk_pcg64_pm1    : the reference's Random.pm1 (random.py:239-247): +-1 from `integers(0, 2, n)` (complex_units == 0) or
+ *                   one of 1, i, -1, -i from `integers(0, 4, n)` (complex_units != 0; out = interleaved re, im of `dtype`).
+ *                   numpy's buffered 32-bit bounded path yields two outputs per raw draw (low half first) and never rejects
+ *                   for these ranges; consumes ceil(n / 2) raw draws, the caller keeps numpy's has_uint32 / uinteger
+ *                   buffer consistent (nifty_amd.backend.pcg64_pm1).
+ * state / inc: the generator BEFORE the first draw, two uint64 (hi, lo) each; scratch: nk_pcg64_fixed_scratch_bytes(). */
+int64_t nk_pcg64_fixed_scratch_bytes(void);
+int nk_pcg64_uniform(const uint64_t* state, const uint64_t* inc, int64_t n, double low, double high, void* out, int dtype,
+                     void* scratch, void* stream);
+int nk_pcg64_pm1(const uint64_t* state, const uint64_t* inc, int64_t n, void* out, int dtype, int complex_units, void* scratch,
+                 void* stream);
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,9 @@ SIGNATURES = {
     "nk_cg_update_dr": (_i, [_i64, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "nk_pcg64_normal_scratch_bytes": (_i64, [_i64, _i]),
     "nk_pcg64_normal": (_i, [_vp, _vp, _i64, _d, _d, _vp, _i, _vp, _i64, _i, _vp, _vp]),
+    "nk_pcg64_fixed_scratch_bytes": (_i64, []),
+    "nk_pcg64_uniform": (_i, [_vp, _vp, _i64, _d, _d, _vp, _i, _vp, _vp]),
+    "nk_pcg64_pm1": (_i, [_vp, _vp, _i64, _vp, _i, _i, _vp, _vp]),
     "nk_cg_direction": (_i, [_i64, _vp, _vp, _i, _vp, _i, _vp]),
     "nk_amp_forward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nk_amp_jvp": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -414,7 +414,9 @@ def _pcg64_advanced(state, inc, delta):
 def pcg64_normal(rng, mean, std, shape, dtype, device):
     """`rng.normal(mean, std, shape)` of a numpy Generator over PCG64 (the reference's generator: nifty/cl/random.py:146-206
     push_sseq -> np.random.default_rng), computed on `device` from the generator's current state: the same values draw for
-    draw (cast to dtype like `.astype`), and `rng` is left in the state the host call would leave it in.  nk_pcg64_normal;
+    draw (cast to dtype like `.astype`; bit-identical except in the ziggurat tail |x| > 3.654, 2.7e-4 of the draws, where
+    the device log1p may differ from the host libm by <= 4 ulp), and `rng` is left in the state the host call would leave it
+    in.  std < 0 raises ValueError like numpy does.  nk_pcg64_normal;
     one host sync (the number of raw draws consumed comes back from the device)."""
     import ctypes
 
@@ -424,6 +426,8 @@ def pcg64_normal(rng, mean, std, shape, dtype, device):
     st = bg.state
     if st.get("bit_generator") != "PCG64":
         raise TypeError("pcg64_normal needs a numpy Generator over PCG64 (np.random.default_rng)")
+    if float(std) < 0:
+        raise ValueError("scale < 0")
     n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
     out = torch.empty(tuple(shape), dtype=dtype, device=device)
     _require_device(out)
@@ -449,6 +453,89 @@ def pcg64_normal(rng, mean, std, shape, dtype, device):
         raise RuntimeError("nk_pcg64_normal: scratch sizing failed")
     st["state"]["state"] = _pcg64_advanced(state, inc, int(consumed))
     bg.state = st  # keeps has_uint32 / uinteger, exactly like the host draw of doubles does
+    return out
+
+
+def _pcg64_words(rng):
+    bg = rng.bit_generator
+    st = bg.state
+    if st.get("bit_generator") != "PCG64":
+        raise TypeError("needs a numpy Generator over PCG64 (np.random.default_rng)")
+    import ctypes
+
+    state, inc = int(st["state"]["state"]), int(st["state"]["inc"])
+    words = (ctypes.c_uint64 * 4)(state >> 64, state & (2**64 - 1), inc >> 64, inc & (2**64 - 1))
+    return bg, st, state, inc, words
+
+
+def pcg64_uniform(rng, low, high, shape, dtype, device):
+    """`rng.uniform(low, high, shape)` of a numpy Generator over PCG64 (the reference's Random.uniform for real fields,
+    nifty/cl/random.py:249-258) computed on `device`: bit-identical values (one raw draw each, low + (high - low) * u without
+    contraction, cast like `.astype`), generator advanced by exactly n draws.  nk_pcg64_uniform; no host sync."""
+    import ctypes
+
+    import numpy as np
+
+    bg, st, state, inc, words = _pcg64_words(rng)
+    n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
+    out = torch.empty(tuple(shape), dtype=dtype, device=device)
+    _require_device(out)
+    if n == 0:
+        return out
+    lib = L.load()
+    scratch = torch.empty(lib.nk_pcg64_fixed_scratch_bytes(), dtype=torch.uint8, device=device)
+    L.check(lib.nk_pcg64_uniform(ctypes.addressof(words), ctypes.addressof(words) + 16, n, float(low), float(high),
+                                 out.data_ptr(), dtype_code(out), scratch.data_ptr(), _stream()), "nk_pcg64_uniform")
+    st["state"]["state"] = _pcg64_advanced(state, inc, n)
+    bg.state = st
+    return out
+
+
+def pcg64_pm1(rng, shape, dtype, device, complex_units=False):
+    """The reference's Random.pm1 (nifty/cl/random.py:239-247) on `device`: `2 * rng.integers(0, 2, shape) - 1`, or for
+    complex fields one of 1, i, -1, -i from `rng.integers(0, 4, shape)` -- numpy's buffered 32-bit bounded draws (two outputs
+    per raw 64-bit value, low half first), bit-identical, with the generator's raw position AND its buffered half word
+    (`has_uint32` / `uinteger`) left as the host call would leave them.  `dtype`: the real torch dtype (float32 / float64);
+    complex_units returns a complex tensor."""
+    import ctypes
+
+    import numpy as np
+
+    n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
+    cdt = {torch.float32: torch.complex64, torch.float64: torch.complex128}[dtype]
+    out = torch.empty(tuple(shape), dtype=cdt if complex_units else dtype, device=device)
+    _require_device(out)
+    if n == 0:
+        return out
+    flat = (torch.view_as_real(out) if complex_units else out).reshape(-1)
+    width = 2 if complex_units else 1
+    done = 0
+    if rng.bit_generator.state["has_uint32"]:
+        # the first output comes from the half word numpy has buffered: let numpy draw it (one value, on the host)
+        v = int(rng.integers(0, 4 if complex_units else 2))
+        first = ([1, 0], [0, 1], [-1, 0], [0, -1])[v] if complex_units else [2 * v - 1]
+        flat[:width] = torch.tensor(first, dtype=dtype, device=device)
+        done = 1
+    m = n - done
+    if m > 0:
+        bg, st, state, inc, words = _pcg64_words(rng)
+        lib = L.load()
+        scratch = torch.empty(lib.nk_pcg64_fixed_scratch_bytes(), dtype=torch.uint8, device=device)
+        L.check(lib.nk_pcg64_pm1(ctypes.addressof(words), ctypes.addressof(words) + 16, m, flat[done * width:].data_ptr(),
+                                 _DT[dtype], 1 if complex_units else 0, scratch.data_ptr(), _stream()), "nk_pcg64_pm1")
+        nraw = (m + 1) // 2
+        if m % 2:
+            # the high half of the last raw value stays buffered for the next 32-bit draw
+            st["state"]["state"] = _pcg64_advanced(state, inc, nraw - 1)
+            bg.state = st
+            last = int(bg.random_raw(1)[0])  # advances to nraw
+            st = bg.state
+            st["has_uint32"], st["uinteger"] = 1, last >> 32
+            bg.state = st
+        else:
+            st["state"]["state"] = _pcg64_advanced(state, inc, nraw)
+            st["has_uint32"], st["uinteger"] = 0, 0
+            bg.state = st
     return out
 
 

@@ -1,6 +1,8 @@
 """Global configuration (counterpart of reference nifty/config.py:42-80)."""
 # sampling_rng: "numpy" = the reference's PCG64 + ziggurat streams, draw for draw.  Fields that live on a GPU are drawn
-#               THERE from the host generator's state (nk_pcg64_normal: same numbers, generator left in the same state;
+#               THERE from the host generator's state (nk_pcg64_normal: the same numbers -- bit-identical except in the ziggurat
+#               tail |x| > 3.654, 2.7e-4 of the draws, where the device log1p may differ from the host libm by <= 4 ulp --,
+#               generator left in the same state;
 #               ~25 ms per 1e9 normals instead of ~10 s + the upload);
 #               "numpy_host" = the same streams drawn by numpy on the host and uploaded (cross-check of the above);
 #               "device" = the fused engine draws its N(0,1) fields with torch's device generator, seeded per sample

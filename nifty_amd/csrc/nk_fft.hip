@@ -362,8 +362,19 @@ static int nk_dispatch_strided(int n, const NkPassS& ps, const NkFuse& f, const 
 }
 
 // ---- sandwich pipeline (nk_fft3.h) ------------------------------------------------------------------------
+// NK_CONTIG3_WAVES (experiment): upper bound of the waves per SIMD the compiler should plan for -- the LDS tile limits the
+// row kernels to ~5 waves per SIMD anyway, so a register budget of 512 / 5 VGPRs costs no occupancy and lets the scheduler
+// keep more of the 64 prologue loads of a thread in flight
+#ifndef NK_CONTIG3_WAVES
+#define NK_CONTIG3_WAVES 0
+#endif
+#if NK_CONTIG3_WAVES > 0
+#define NK_CONTIG3_ATTR __attribute__((amdgpu_waves_per_eu(1, NK_CONTIG3_WAVES)))
+#else
+#define NK_CONTIG3_ATTR
+#endif
 template <typename T, int H, int PC>
-__global__ void __launch_bounds__((Contig3Tile<T, H>::THREADS))
+__global__ void __launch_bounds__((Contig3Tile<T, H>::THREADS)) NK_CONTIG3_ATTR
     k3_contig(NkPass3 p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr, C2<T>* __restrict__ work) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, Contig3Tile<T, H>::SC::E> ex;

@@ -214,3 +214,47 @@ static inline int64_t nk_rng_chunks_for(int64_t n, int attempt) {
   const double need = (double)n * (1.0225 + 0.005 * (double)(1 << attempt)) / NK_RNG_CHUNK;
   return (int64_t)need + 32 * (int64_t)(1 + attempt);
 }
+
+// ---- draws that consume a FIXED number of raw values per output: plain jump-ahead parallelism ------------------------
+// numpy's `Generator.uniform(low, high, n)` (random_uniform: low + (high - low) * next_double, one raw draw each) and the
+// power-of-two bounded integers behind the reference's `Random.pm1` (random.py:239-247: `integers(0, 2, n)` for real,
+// `integers(0, 4, n)` for complex fields).  For a range 2^k numpy's buffered 32-bit Lemire path never rejects: every raw
+// 64-bit draw yields TWO outputs, the top k bits of its low 32-bit half first, then those of its high half
+// (numpy/random/src/distributions/distributions.c: buffered_bounded_lemire_uint32; checked against numpy in
+// tests/test_rng.py).  A thread takes NK_RNG_FIX raw draws: one O(log) jump, then the plain recurrence.
+#define NK_RNG_FIX 32
+// MODE 0: uniform -> T;  1: +-1 -> T;  2: one of 1, i, -1, -i -> C2<T> (interleaved re, im)
+template <typename T, int MODE>
+NK_HD void nk_rng_fixed_body(NkU128 state, NkU128 inc, const NkPcgJump& jt, int64_t n, double low, double scale, int64_t k,
+                             T* out) {
+  NK_NO_CONTRACT
+  const int64_t per = MODE == 0 ? NK_RNG_FIX : 2 * NK_RNG_FIX;  // outputs of this thread
+  const int64_t e0 = k * per;
+  if (e0 >= n) return;
+  NkRaw g;
+  g.s = nk_pcg_advance(state, (uint64_t)k * NK_RNG_FIX, jt);
+  g.inc = inc;
+  g.pos = 0;
+  for (int i = 0; i < NK_RNG_FIX; ++i) {
+    const uint64_t raw = g.next();
+    if (MODE == 0) {
+      const int64_t e = e0 + i;
+      if (e >= n) return;
+      const double u = (double)(raw >> 11) * (1.0 / 9007199254740992.0);
+      out[e] = (T)NK_DADD(low, NK_DMUL(scale, u));
+    } else {
+      for (int h = 0; h < 2; ++h) {
+        const int64_t e = e0 + 2 * i + h;
+        if (e >= n) return;
+        const uint32_t half = h ? (uint32_t)(raw >> 32) : (uint32_t)raw;
+        if (MODE == 1) {
+          out[e] = (half >> 31) ? (T)1 : (T)-1;
+        } else {
+          const uint32_t code = half >> 30;  // 0: 1, 1: i, 2: -1, 3: -i
+          out[2 * e] = code == 0 ? (T)1 : code == 2 ? (T)-1 : (T)0;
+          out[2 * e + 1] = code == 1 ? (T)1 : code == 3 ? (T)-1 : (T)0;
+        }
+      }
+    }
+  }
+}

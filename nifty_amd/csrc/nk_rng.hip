@@ -139,7 +139,51 @@ RngLayout rng_layout(int64_t n, int attempt) {
   return L;
 }
 
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) k_rng_fixed(NkU128 state, NkU128 inc, const NkPcgJump* jt, int64_t n, double low,
+                                                   double scale, T* out) {
+  __shared__ NkPcgJump l_jt;
+  for (int i = threadIdx.x; i < (int)(sizeof(NkPcgJump) / sizeof(uint64_t)); i += blockDim.x)
+    reinterpret_cast<uint64_t*>(&l_jt)[i] = reinterpret_cast<const uint64_t*>(jt)[i];
+  __syncthreads();
+  nk_rng_fixed_body<T, MODE>(state, inc, l_jt, n, low, scale, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, out);
+}
+
+template <int MODE>
+int rng_fixed_launch(const uint64_t* state, const uint64_t* inc, int64_t n, double low, double scale, void* out, int dtype,
+                     void* scratch, hipStream_t stream, const char* what) {
+  if (!state || !inc || n < 0 || (n > 0 && (!out || !scratch)) || (dtype != NK_F32 && dtype != NK_F64))
+    return nk_set_error(NK_ERR_INVALID, "nk_pcg64 fixed-rate draw: bad argument");
+  if (!(inc[1] & 1)) return nk_set_error(NK_ERR_INVALID, "nk_pcg64 fixed-rate draw: the increment of a PCG64 stream is odd");
+  if (n == 0) return NK_OK;
+  const NkU128 s{state[0], state[1]}, c{inc[0], inc[1]};
+  NkPcgJump* jt = (NkPcgJump*)scratch;
+  hipLaunchKernelGGL(k_rng_table, dim3(1), dim3(1), 0, stream, c, jt);
+  const int64_t per = MODE == 0 ? NK_RNG_FIX : 2 * NK_RNG_FIX;
+  const int64_t threads = (n + per - 1) / per;
+  const unsigned blocks = (unsigned)((threads + 255) / 256);
+  if (dtype == NK_F32)
+    hipLaunchKernelGGL((k_rng_fixed<float, MODE>), dim3(blocks), dim3(256), 0, stream, s, c, jt, n, low, scale, (float*)out);
+  else
+    hipLaunchKernelGGL((k_rng_fixed<double, MODE>), dim3(blocks), dim3(256), 0, stream, s, c, jt, n, low, scale, (double*)out);
+  return nk_check_launch(what);
+}
+
 }  // namespace
+
+extern "C" int64_t nk_pcg64_fixed_scratch_bytes(void) { return (int64_t)sizeof(NkPcgJump); }
+
+extern "C" int nk_pcg64_uniform(const uint64_t* state, const uint64_t* inc, int64_t n, double low, double high, void* out,
+                                int dtype, void* scratch, void* stream) {
+  return rng_fixed_launch<0>(state, inc, n, low, high - low, out, dtype, scratch, (hipStream_t)stream, "nk_pcg64_uniform");
+}
+
+extern "C" int nk_pcg64_pm1(const uint64_t* state, const uint64_t* inc, int64_t n, void* out, int dtype, int complex_units,
+                            void* scratch, void* stream) {
+  if (complex_units)
+    return rng_fixed_launch<2>(state, inc, n, 0.0, 0.0, out, dtype, scratch, (hipStream_t)stream, "nk_pcg64_pm1");
+  return rng_fixed_launch<1>(state, inc, n, 0.0, 0.0, out, dtype, scratch, (hipStream_t)stream, "nk_pcg64_pm1");
+}
 
 extern "C" int64_t nk_pcg64_normal_scratch_bytes(int64_t n, int attempt) {
   if (n < 0 || attempt < 0 || attempt > 8) return 0;

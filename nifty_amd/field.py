@@ -121,13 +121,11 @@ class Field:
 
     @staticmethod
     def from_random(domain, random_type="normal", dtype=np.float64, device_id=-1, **kwargs):
-        """numpy PCG64 draw (parity with the reference's seeds): on the host, then uploaded -- or, for a normal draw of a
-        device field, the same stream computed on the GPU.  field.py:128-156"""
+        """numpy PCG64 draw (parity with the reference's seeds): on the host -- or, for a normal / uniform / pm1 draw of a
+        device field, the same stream computed on the GPU (random.Random.on_device).  field.py:128-156"""
         domain = DomainTuple.make(domain)
-        if random_type == "normal" and device_id >= 0:
-            val = random.Random.normal_on_device(dtype, domain.shape, kwargs.pop("mean", 0.0), kwargs.pop("std", 1.0),
-                                                 device_of(device_id), **kwargs)
-            return Field(domain, val)
+        if device_id >= 0:
+            return Field(domain, random.Random.on_device(random_type, dtype, domain.shape, device_of(device_id), **kwargs))
         gen = getattr(random.Random, random_type)
         arr = gen(dtype=dtype, shape=domain.shape, **kwargs)
         return Field(domain, _as_tensor(arr, device_of(device_id)))

@@ -144,6 +144,37 @@ class Random:
         return backend.pcg64_normal(rng, mean, std, shape, real_dt, device)
 
     @staticmethod
+    def on_device(random_type, dtype, shape, device, **kwargs):
+        """A draw of `random_type` for a field that lives on a GPU: the same numpy stream computed there where a device
+        kernel exists (normal; uniform and pm1 of float / complex fields), else drawn on the host and uploaded.  Small draws
+        stay on the host (a launch and its bookkeeping cost more than numpy takes)."""
+        import torch
+
+        from . import backend, config
+        from .field import _as_tensor
+
+        dt, kind = _kind(dtype)
+        n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
+        real_dt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+                   np.dtype(np.complex64): torch.float32, np.dtype(np.complex128): torch.float64}.get(dt)
+        host = (config.get("sampling_rng") == "numpy_host" or n < DEVICE_DRAW_MIN or real_dt is None
+                or torch.device(device).type != "cuda")
+        if random_type == "normal":
+            return Random.normal_on_device(dtype, shape, kwargs.pop("mean", 0.0), kwargs.pop("std", 1.0), device, **kwargs)
+        rng = current_rng()
+        if random_type == "pm1" and not host and not kwargs:
+            return backend.pcg64_pm1(rng, shape, real_dt, device, complex_units=kind == "complex")
+        if random_type == "uniform" and not host and set(kwargs) <= {"low", "high"}:
+            low, high = kwargs.get("low", 0.0), kwargs.get("high", 1.0)
+            if not (np.isscalar(low) and np.isscalar(high)):
+                raise TypeError("low and high must be scalars")
+            if kind == "complex":  # real part first, then the imaginary part, like the host draw
+                re = backend.pcg64_uniform(rng, low, high, shape, real_dt, device)
+                return torch.complex(re, backend.pcg64_uniform(rng, low, high, shape, real_dt, device))
+            return backend.pcg64_uniform(rng, low, high, shape, real_dt, device)
+        return _as_tensor(getattr(Random, random_type)(dtype=dtype, shape=shape, **kwargs), device)
+
+    @staticmethod
     def pm1(dtype, shape):
         """+-1 (real) or one of 1, i, -1, -i (complex) with equal probability."""
         dtype, kind = _kind(dtype)

@@ -75,3 +75,25 @@ extern "C" unsigned emu_pcg64_normal_chunked(const uint64_t* state, const uint64
 }
 
 extern "C" int64_t emu_rng_chunks_for(int64_t n, int attempt) { return nk_rng_chunks_for(n, attempt); }
+
+// fixed-rate draws (uniform / pm1): the per-thread body of k_rng_fixed, thread after thread.  mode as nk_rng_fixed_body.
+extern "C" int emu_pcg64_fixed(const uint64_t* state, const uint64_t* inc, int64_t n, double low, double high, int mode,
+                               int dtype, void* out) {
+  const NkU128 s{state[0], state[1]}, c{inc[0], inc[1]};
+  NkPcgJump jt;
+  nk_pcg_jump_table(c, jt);
+  const int64_t per = mode == 0 ? NK_RNG_FIX : 2 * NK_RNG_FIX;
+  const int64_t threads = (n + per - 1) / per;
+  for (int64_t k = 0; k < threads; ++k) {
+    if (dtype == 0) {
+      if (mode == 0) nk_rng_fixed_body<float, 0>(s, c, jt, n, low, high - low, k, (float*)out);
+      else if (mode == 1) nk_rng_fixed_body<float, 1>(s, c, jt, n, 0, 0, k, (float*)out);
+      else nk_rng_fixed_body<float, 2>(s, c, jt, n, 0, 0, k, (float*)out);
+    } else {
+      if (mode == 0) nk_rng_fixed_body<double, 0>(s, c, jt, n, low, high - low, k, (double*)out);
+      else if (mode == 1) nk_rng_fixed_body<double, 1>(s, c, jt, n, 0, 0, k, (double*)out);
+      else nk_rng_fixed_body<double, 2>(s, c, jt, n, 0, 0, k, (double*)out);
+    }
+  }
+  return 0;
+}

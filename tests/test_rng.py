@@ -271,3 +271,64 @@ def test_device_normal_full_size_stream():
     assert rng.bit_generator.state == ref_rng.bit_generator.state
     assert 2.0e-4 * n < ntail < 3.5e-4 * n
     assert ndiff <= ntail
+
+
+# ---- fixed-rate draws: uniform and pm1 (nk_pcg64_uniform / nk_pcg64_pm1) ------------------------------------------------------
+def _fixed_emu(rng, n, mode, dt, low=0.0, high=1.0):
+    lib = _emu()
+    s, i = _words(rng)
+    out = np.empty(2 * n if mode == 2 else n, dtype=dt)
+    lib.emu_pcg64_fixed(s.ctypes.data_as(U64P), i.ctypes.data_as(U64P), ctypes.c_int64(n), ctypes.c_double(low), ctypes.c_double(high), mode,
+                        0 if dt == np.float32 else 1, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 1000, 4097])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_fixed_rate_bodies_equal_numpy(n, dt):
+    """The per-thread body of k_rng_fixed (host emulation) against numpy itself, bit for bit: `uniform`, the +-1 draws of
+    `2 * integers(0, 2) - 1` and the complex units of `integers(0, 4)` (reference random.py:239-258)."""
+    r = np.random.default_rng(n)
+    got = _fixed_emu(r, n, 0, dt, 1.5, 4.0)
+    assert np.array_equal(got, r.uniform(1.5, 4.0, n).astype(dt))
+    r = np.random.default_rng(n + 7)
+    got = _fixed_emu(r, n, 1, dt)
+    assert np.array_equal(got, (2 * r.integers(0, 2, size=n) - 1).astype(dt))
+    r = np.random.default_rng(n + 9)
+    got = _fixed_emu(r, n, 2, dt)
+    units = np.array([1, 1j, -1, -1j])
+    assert np.array_equal(got[0::2] + 1j * got[1::2], units[r.integers(0, 4, size=n)])
+
+
+@pytest.mark.gpu
+def test_uniform_and_pm1_on_the_device_equal_numpy_including_generator_state():
+    """Field.from_random(random_type="uniform" | "pm1", device_id=0) draws the reference's numpy stream on the device: the
+    values, AND the generator afterwards (raw position, buffered 32-bit half word) -- checked by the draws that follow."""
+    import nifty_amd as ift
+
+    n = 70001  # odd: a pm1 draw leaves half a raw value buffered
+    dom = ift.UnstructuredDomain(n)
+    units = np.array([1, 1j, -1, -1j])
+    for dt in (np.float64, np.float32):
+        cdt = np.complex128 if dt == np.float64 else np.complex64
+        ift.random.push_sseq_from_seed(11)
+        ref_rng = np.random.default_rng(np.random.SeedSequence(11))
+        try:
+            u = ift.from_random(dom, "uniform", dtype=dt, device_id=0, low=-2.0, high=3.0)
+            assert u.device_id == 0 and np.array_equal(u.asnumpy(), ref_rng.uniform(-2.0, 3.0, n).astype(dt))
+            p = ift.from_random(dom, "pm1", dtype=dt, device_id=0)
+            assert np.array_equal(p.asnumpy(), (2 * ref_rng.integers(0, 2, size=n) - 1).astype(dt))
+            # the buffered half word is consumed first by the next 32-bit draw -- here on the device again ...
+            p2 = ift.from_random(dom, "pm1", dtype=cdt, device_id=0)
+            assert np.array_equal(p2.asnumpy(), units[ref_rng.integers(0, 4, size=n)].astype(cdt))
+            # ... the complex uniform draws real part first, and a host draw continues exactly where numpy would be
+            cu = ift.from_random(dom, "uniform", dtype=cdt, device_id=0)
+            ref = ref_rng.uniform(0.0, 1.0, n) + 1j * ref_rng.uniform(0.0, 1.0, n)
+            assert np.array_equal(cu.asnumpy(), ref.astype(cdt))
+            p3 = ift.from_random(ift.UnstructuredDomain(9), "pm1", dtype=dt, device_id=0)  # small: host draw + upload
+            assert np.array_equal(p3.asnumpy(), (2 * ref_rng.integers(0, 2, size=9) - 1).astype(dt))
+            assert ift.random.current_rng().bit_generator.state == ref_rng.bit_generator.state
+            nrm = ift.from_random(dom, "normal", dtype=dt, device_id=0)
+            assert np.allclose(nrm.asnumpy(), ref_rng.normal(0.0, 1.0, n).astype(dt), rtol=1e-6, atol=0)
+        finally:
+            ift.random.pop_sseq()
