@@ -32,4 +32,6 @@ dense, model.k2_dense = model.k2_dense, None
 old = model._amp_field(table).clone()
 t_old = timed(lambda: model._amp_field(table, out=model.dafield))
 model.k2_dense = dense
-print(f"{n}^3 {dt}: gather through pidx8 {t_old:.3f} ms, dense k^2 table {t_new:.3f} ms, identical: {torch.equal(old, new)}")
+import os
+print(f"{n}^3 {dt}: gather through pidx8 {t_old:.3f} ms, dense k^2 table (NK_EXPAND_SHELL={os.environ.get('NK_EXPAND_SHELL', '1')}) "
+      f"{t_new:.3f} ms, identical: {torch.equal(old, new)}")
