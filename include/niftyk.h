@@ -190,6 +190,11 @@ int nk_binary(int op, int64_t n, const void* a, double ascalar, const void* b, d
 /* out = alpha * x + beta * y   (y may be NULL) */
 int nk_axpby(int64_t n, double alpha, const void* x, double beta, const void* y, void* out, int dtype,
              void* stream);
+/* out = alpha * x + beta * y and, in the same pass, *result (+)= sum(out[i]^2) of the stored values (fp64 accumulation,
+ * fixed order): a KL sample position p +- r together with its prior term 1/2 |x|^2 (kl_energies.py:318-321,
+ * energy_operators.py:890-931) */
+int nk_axpby_sqnorm(int64_t n, double alpha, const void* x, double beta, const void* y, void* out, int dtype, double* result,
+                    int accumulate, void* stream);
 /* pointwise nonlinearity with optional derivative output (pointwise.py:134-159):
  * fn: 0 exp, 1 log, 2 sqrt, 3 tanh, 4 sigmoid(0.5+0.5tanh), 5 reciprocal, 6 power(p), 7 abs, 8 log1p, 9 expm1,
  *     10 arctan, 11 sin, 12 cos */

@@ -55,6 +55,7 @@ SIGNATURES = {
     "nk_stats": (_i, [_i64, _vp, _i, _vp, _vp]),
     "nk_binary": (_i, [_i, _i64, _vp, _d, _vp, _d, _vp, _i, _vp]),
     "nk_axpby": (_i, [_i64, _d, _vp, _d, _vp, _vp, _i, _vp]),
+    "nk_axpby_sqnorm": (_i, [_i64, _d, _vp, _d, _vp, _vp, _i, _vp, _i, _vp]),
     "nk_pointwise": (_i, [_i, _d, _i64, _vp, _vp, _vp, _i, _vp]),
     "nk_gather": (_i, [_i64, _vp, _vp, _vp, _i, _vp]),
     "nk_scatter_add": (_i, [_i64, _vp, _vp, _i64, _vp, _i, _vp]),

@@ -291,6 +291,15 @@ def axpby(alpha, x, beta=0.0, y=None, out=None):
     return out
 
 
+def axpby_sqnorm(alpha, x, beta, y, result, accumulate=False):
+    """alpha x + beta y (a new tensor) and result (+)= |that|^2 in the same pass (device double)."""
+    _require_device(x, y, result)
+    out = torch.empty_like(x)
+    L.check(L.load().nk_axpby_sqnorm(x.numel(), float(alpha), x.data_ptr(), float(beta), y.data_ptr(), out.data_ptr(),
+                                     dtype_code(x), result.data_ptr(), 1 if accumulate else 0, _stream()), "nk_axpby_sqnorm")
+    return out
+
+
 POINTWISE = {"exp": 0, "log": 1, "sqrt": 2, "tanh": 3, "sigmoid": 4, "reciprocal": 5, "power": 6, "abs": 7,
              "absolute": 7, "log1p": 8, "expm1": 9, "arctan": 10, "sin": 11, "cos": 12}
 
@@ -565,6 +574,7 @@ def _runs_on_operand_device(fn):
 
 
 for _name in ("cplx_rows", "hartley", "hartley_fused", "hartley_sandwich", "fftn", "vdot", "vsum", "binary", "axpby",
+              "axpby_sqnorm",
               "pointwise", "gather", "scatter_add", "bin_plan", "bin_sum", "spmv", "spmv_t", "stats", "cumsum"):
     globals()[_name] = _runs_on_operand_device(globals()[_name])
 del _name

@@ -293,6 +293,29 @@ struct FAxpby {
   }
 };
 
+// out = alpha x + beta y  AND  result += sum(out^2) of the values as STORED (rounded to T): the sample position p +- r of a
+// KL evaluation together with its prior term 1/2 |x|^2 -- one pass instead of an axpby and a dot
+template <typename T>
+struct FAxpbySq {
+  static constexpr int NRED = 1;
+  double alpha, beta;
+  const T *x, *y;
+  T* out;
+  double* result;
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double* red) const {
+    T a[V], b[V], r[V];
+    nk_ld<T, V>(x, i, a);
+    nk_ld<T, V>(y, i, b);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      r[k] = (T)(alpha * (double)a[k] + beta * (double)b[k]);
+      red[0] += (double)r[k] * (double)r[k];
+    }
+    nk_st<T, V>(out, i, r);
+  }
+};
+
 template <typename T>
 struct FPointwise {
   static constexpr int NRED = 0;
@@ -560,6 +583,20 @@ extern "C" int nk_axpby(int64_t n, double alpha, const void* x, double beta, con
     FAxpby<T> f{alpha, beta, (const T*)x, (const T*)y, (T*)out, nullptr};
     return nk_launch_map<T>(n, f, nk_aligned16(x) && nk_aligned16(y) && nk_aligned16(out), (hipStream_t)stream,
                             "nk_axpby");
+  })
+}
+
+extern "C" int nk_axpby_sqnorm(int64_t n, double alpha, const void* x, double beta, const void* y, void* out, int dtype,
+                               double* result, int accumulate, void* stream) {
+  if (n < 0 || !out || !x || !y || !result) return nk_set_error(NK_ERR_INVALID, "nk_axpby_sqnorm: bad argument");
+  if (!accumulate) {
+    int rc = nk_zero(result, 1, (hipStream_t)stream);
+    if (rc != NK_OK) return rc;
+  }
+  NK_DISPATCH_DTYPE(dtype, {
+    FAxpbySq<T> f{alpha, beta, (const T*)x, (const T*)y, (T*)out, result};
+    return nk_launch_map<T>(n, f, nk_aligned16(x) && nk_aligned16(y) && nk_aligned16(out), (hipStream_t)stream,
+                            "nk_axpby_sqnorm");
   })
 }
 

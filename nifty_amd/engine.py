@@ -180,10 +180,11 @@ class ShardedCgWorkspace(CgWorkspace):
 class LatentVec:
     """A point / tangent / cotangent of the latent space (vector protocol of minimization.py)."""
 
-    __slots__ = ("xi", "small")
+    __slots__ = ("xi", "small", "sqnorm")
 
-    def __init__(self, xi, small):
+    def __init__(self, xi, small, sqnorm=None):
         self.xi, self.small = xi, small
+        self.sqnorm = sqnorm  # optional device double: |self|^2, taken while the vector was written (shifted())
 
     # -- construction -------------------------------------------------------------------------
     @staticmethod
@@ -214,6 +215,14 @@ class LatentVec:
         return CgWorkspace(self.xi.device)
 
     # -- vector protocol -----------------------------------------------------------------------
+    def shifted(self, sign, other):
+        """self + sign * other together with its squared norm (one pass over xi): a KL sample position p +- r and the prior
+        term of its Hamiltonian."""
+        sq = torch.zeros(1, dtype=torch.float64, device=self.xi.device)
+        xi = B.axpby_sqnorm(1.0, self.xi, float(sign), other.xi, sq)
+        small = B.axpby_sqnorm(1.0, self.small, float(sign), other.small, sq, accumulate=True)
+        return LatentVec(xi, small, sq)
+
     def _lin(self, alpha, other, beta):
         """alpha*self + beta*other"""
         return LatentVec(B.axpby(alpha, self.xi, beta, other.xi), B.axpby(alpha, self.small, beta, other.small))
@@ -571,7 +580,7 @@ class FusedModel:
             B.axpby(1.0, self.latbar, 1.0, grad.small, out=grad.small)
             B.axpby(w, x.small, 1.0, grad.small, out=grad.small)
         # value: lh + 1/2 x.x
-        prior = x.dot_device(x)
+        prior = x.sqnorm if x.sqnorm is not None else x.dot_device(x)
         B.axpby(w, lhval, 1.0, value, out=value)
         B.axpby(0.5 * w, prior, 1.0, value, out=value)
         lp.value, lp.grad = value, grad
@@ -628,19 +637,24 @@ class FusedModel:
         self.counters["transforms"] += 1
         return self.response.times(self.tmp)
 
-    def lh_metric_accumulate(self, lp, d, out, scale, first, identity=0.0, dot_out=None, cg_direction=None, pipe=None):
+    def lh_metric_accumulate(self, lp, d, out, scale, first, identity=0.0, dot_out=None, cg_direction=None, pipe=None,
+                             addend=None):
         """out (+)= scale * J^T M J d  (+ identity * d): the likelihood Fisher metric pulled back to latent space;
         the optional multiple of d (prior metric = 1) rides along in the VJP epilogue of the xi part.
         pipe = (chunks, wait_events or None, record_events or None): slab pipelining of the sandwich against an exchange
         on another stream (nk_fuse.pipe_chunks; the arrays are ctypes arrays of hipEvent_t handles).
+        addend = (vector, factor): out += factor * vector instead of the identity term (rides in the same epilogue).
         cg_direction = (r, workspace): d.xi <- beta d.xi + r.xi first, inside the sandwich's first pass (d.small was
         updated by the caller: CgWorkspace.direction_small); the workspace scalars are rolled afterwards."""
         if cg_direction is not None and not self.fused_direction:
             raise ValueError("cg_direction needs the sandwich pipeline (FusedModel.fused_direction)")
+        if addend is not None and identity:
+            raise ValueError("either the identity term or an explicit addend")
+        avec, afac = (d, identity) if addend is None else addend  # the vector the epilogue adds, and its factor
         if self.response is not None:
             wsig = self.response.adjoint(self._weigh_data(self._jvp_response(lp, d), lp), self.shape)
-            self._vjp(lp, wsig, scale, d.xi if identity else None, identity, not first, out.xi, dot_out=dot_out, w2=lp.gp)
-            self._finish_metric(lp, d, out, first, identity)
+            self._vjp(lp, wsig, scale, avec.xi if afac else None, afac, not first, out.xi, dot_out=dot_out, w2=lp.gp)
+            self._finish_metric(lp, avec, out, first, afac)
             return
         L.check(L.load().nk_amp_jvp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(),
                                     lp.state.data_ptr(), d.small.data_ptr(), self.damp.data_ptr(), B._stream()), "nk_amp_jvp")
@@ -672,7 +686,7 @@ class FusedModel:
             raise ValueError("slab pipelining needs the sandwich pipeline")
         if self.sandwich:
             # H D H in five passes: the position-space field between the transforms never exists (nk_fft3.h)
-            self._vjp(lp, None, scale, d.xi if identity else None, identity, not first, out.xi, dot_out=dot_out,
+            self._vjp(lp, None, scale, avec.xi if afac else None, afac, not first, out.xi, dot_out=dot_out,
                       sandwich=(jvp_prologue, self.h_dvol, lp.mid, lp.mid_scalar))
             if cg_direction is not None:
                 cg_direction[1].roll()
@@ -681,9 +695,9 @@ class FusedModel:
             jvp_prologue(f)
             f.epi, f.out, f.mul, f.mul_scalar = L.EPI_MUL, self.tmp.data_ptr(), B.ptr(lp.mid), lp.mid_scalar
             B.hartley_fused(self.plan, f)
-            self._vjp(lp, self.tmp, scale, d.xi if identity else None, identity, not first, out.xi, dot_out=dot_out)
+            self._vjp(lp, self.tmp, scale, avec.xi if afac else None, afac, not first, out.xi, dot_out=dot_out)
             self.counters["transforms"] += 1
-        self._finish_metric(lp, d, out, first, identity)
+        self._finish_metric(lp, avec, out, first, afac)
 
     def _finish_metric(self, lp, d, out, first, identity):
         self._amp_vjp(lp)
@@ -701,9 +715,10 @@ class FusedModel:
         self.lh_metric_accumulate(lp, d, out, 1.0, True, identity=1.0, dot_out=dot_out, cg_direction=cg_direction)
         return out
 
-    def lh_metric(self, lp, d):
+    def lh_metric(self, lp, d, minus=None):
+        """J^T M J d, optionally minus another latent vector (subtracted in the VJP epilogue: no extra pass)."""
         out = LatentVec(torch.empty_like(d.xi), None)
-        self.lh_metric_accumulate(lp, d, out, 1.0, True)
+        self.lh_metric_accumulate(lp, d, out, 1.0, True, addend=None if minus is None else (minus, -1.0))
         return out
 
     # -- likelihood transformation f (geoVI; energy_operators.py:590-591, 639-640, kl_energies.py:105-124) ----
@@ -837,10 +852,11 @@ class FusedModel:
         s = self.draw_prior(device_rng)
         nj = self.draw_lh_noise(lp, device_rng)
         b = s + nj
-        g0 = self.lh_metric(lp, s) - nj
+        g0 = self.lh_metric(lp, s, minus=nj)  # J^T M J s - nj: the subtraction rides in the transform's epilogue
         A = _Callable(lambda v, dot_out=None, cg_direction=None: self.metric(lp, v, dot_out=dot_out, cg_direction=cg_direction),
                       fused_dot=self.octant_vjp, fused_direction=self.fused_direction)
         energy = QuadraticEnergy(s, A, b, _grad=g0)
+        energy.consumable = True  # s and g0 belong to this solve: the CG may update them in place
         energy, _ = ConjugateGradient(controller)(energy)
         return b, energy.position
 
@@ -879,7 +895,7 @@ class FusedKL(Energy):
         value = torch.zeros(1, dtype=torch.float64, device=model.device)
         grad = None
         for r, neg in zip(residuals, negs):
-            x = position - r if neg else position + r
+            x = position.shifted(-1.0 if neg else 1.0, r)  # p +- r and |p +- r|^2 in one pass
             lp = model.linearize(x, grad_acc=grad, n_total=self.n_total, value_acc=value)
             grad = lp.grad
             lp.grad = None

@@ -433,8 +433,12 @@ class ConjugateGradient(Minimizer):
         sm = getattr(A, "sharded", None)
         if sm is not None and b is not None:
             return self._solve_inplace_sharded(energy, sm)
-        x = energy.position.clone()
-        r = energy.gradient.clone()
+        # the iterate and the residual are updated in place: on private copies -- unless the caller has handed the vectors
+        # over (QuadraticEnergy.consumable: nobody else holds the start position / gradient, two N-sized copies less)
+        if getattr(energy, "consumable", False):
+            x, r = energy.position, energy.gradient
+        else:
+            x, r = energy.position.clone(), energy.gradient.clone()
         d = r.clone()
         ws = x.cg_workspace()
         gamma_prev = _ls(r.s_vdot(r))
@@ -931,6 +935,7 @@ class NewtonCG(DescentMinimizer):
         # reference's metric application to the zero vector is skipped.
         zero = energy.position * 0.0
         quad = QuadraticEnergy(zero, energy.metric, g, _grad=-g, _value=0.0)  # E(0) = 0
+        quad.consumable = True  # `zero` and `-g` are temporaries of this call: the CG may iterate on them in place
         precond = None
         if self._napprox > 1:
             # sampled diagonal of the metric as CG preconditioner (descent_minimizers.py:201-203)
