@@ -179,6 +179,25 @@ def test_fusion_pass_matches_graph():
     m, cfm, cf, lh = build(z)
     kw = match_fused(lh)
     assert kw["likelihood"] == "gaussian" and kw["icov"] == pytest.approx(100.0) and kw["nonlin"] is None
+    # BASELINE config 4: Mask @ LOSResponse @ sigmoid(cf) becomes ONE sparse matrix of the fused engine (the kept rows)
+    zl = gl.load("los")
+    sp = ift.RGSpace((16, 16))
+    cfm = ift.CorrelatedFieldMaker("")
+    cfm.add_fluctuations(sp, CF_ARGS["fluctuations"], CF_ARGS["flexibility"], CF_ARGS["asperity"], CF_ARGS["loglogavgslope"])
+    cfm.set_amplitude_total_offset(2.0, (1e-1, 3e-2))
+    cf = cfm.finalize()
+    R = ift.LOSResponse(sp, zl["c4.starts"], zl["c4.ends"])
+    Mk = ift.MaskOperator(ift.makeField(R.target, zl["c4.flags"]))
+    for resp, n_data in ((Mk @ R @ cf.ptw("sigmoid"), Mk.target.size), (R @ cf.ptw("sigmoid"), R.target.size), (R @ cf, R.target.size)):
+        d = ift.from_random(resp.target)
+        kw = match_fused(ift.GaussianEnergy(d, ift.ScalingOperator(resp.target, 1e3, np.float64)) @ resp)
+        assert kw is not None and kw["response"].n_data == n_data and kw["response"].n_pix == 256
+        x = np.random.default_rng(0).normal(size=256)
+        want = (Mk(R(ift.makeField(sp, x.reshape(16, 16)))) if n_data == Mk.target.size else R(ift.makeField(sp, x.reshape(16, 16)))).asnumpy()
+        assert gl.relerr(kw["response"].host_matrix @ x, want) < 1e-12
+    # a response the fusion pass does not know stays on the generic graph
+    other = ift.ScalingOperator(R.target, 2.0) @ R @ cf
+    assert match_fused(ift.GaussianEnergy(ift.from_random(other.target), ift.ScalingOperator(other.target, 1e3, np.float64)) @ other) is None
 
 
 def _smooth_numpy(x, dist, sigma):
