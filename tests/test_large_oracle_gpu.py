@@ -121,3 +121,38 @@ def test_fp32_fields_against_the_fp64_oracle_at_256_cubed():
     # application to a few 1e-6 of their largest entry
     e_val, e_grad, e_met = errs[torch.float32]
     assert e_val < 1e-8 and e_grad < 3e-4 and e_met < 1e-6
+
+
+@pytest.mark.timeout(600)
+def test_config2_full_size_against_the_oracle():
+    """BASELINE config 2 at its real size: 2048^2 RGSpace, Poissonian likelihood on exp(correlated field), fp64 -- value,
+    gradient, metric application and one mirrored MGVI sample pair against the oracle."""
+    from nifty_amd import random
+    from nifty_amd.engine import FusedModel, LatentVec, draw_samples
+    from nifty_amd.minimization import AbsDeltaEnergyController
+
+    shape = (2048, 2048)
+    cores = os.cpu_count() or 1
+    cf = orc.CFModel(shape, None, orc.CFParams(offset_mean=2.0), workers=cores)
+    rng = np.random.default_rng(23)
+    x = {k: 0.1 * a for k, a in cf.draw_latent(rng).items()}
+    v = cf.draw_latent(rng)
+    data = rng.poisson(np.exp(cf.forward(cf.draw_latent(rng)))).astype(np.int64)
+    lh = orc.Likelihood("poisson", data, nonlin="exp")
+    model = FusedModel(shape, offset_mean=2.0, likelihood="poisson", nonlin="exp", data=data, dtype=torch.float64, device="cuda:0")
+    lin = orc.Linearized(cf, lh, x)
+    e_val, e_grad, e_met = _errors(model, lin, x, v, "2048^2 fp64 Poisson")
+    print(f"2048^2 fp64 Poisson vs oracle: value {e_val:.2e} gradient {e_grad:.2e} metric {e_met:.2e}")
+    assert e_val < 1e-11 and e_grad < 1e-9 and e_met < 1e-9
+    random.push_sseq_from_seed(6)
+    try:
+        res, negs, n_total = draw_samples(model, LatentVec.from_dict(model, x), 1, True,
+                                          lambda: AbsDeltaEnergyController(0.05, iteration_limit=4))
+    finally:
+        random.pop_sseq()
+    ores, onegs = orc.draw_samples(cf, lh, x, 1, True, np.random.SeedSequence(6),
+                                   lambda: orc.AbsDeltaEnergyController(0.05, iteration_limit=4))
+    assert n_total == 2 and negs == onegs == [False, True]
+    e_s = gl.lat_relerr(res[0].to_dict(), ores[0])
+    print(f"2048^2 fp64 Poisson MGVI sample vs oracle: {e_s:.2e}")
+    assert e_s < 1e-7
