@@ -123,6 +123,11 @@ typedef struct nk_fuse {
   int pipe_chunks;
   void* const* pipe_wait;
   void* const* pipe_record;
+  double* wfull;        /* optional, VJP epilogue on plans WITHOUT the octant pipeline (nk_plan_octant_vjp == 0: mixed-radix
+                           grids, short axes): full-grid fp64 array [batch][shape...] that receives xi[o] * t[o] per point
+                           (mirror partners of one kernel work item: their sum at the first, 0 at the others) INSTEAD of
+                           the atomics into abar -- the caller reduces it in a fixed order (nk_csr_rowsum over the
+                           bin-sorted permutation): bit-reproducible spectrum gradients on every grid */
 } nk_fuse;
 
 typedef struct nk_plan nk_plan;

@@ -52,6 +52,16 @@ __host__ __device__ __forceinline__ int nk_uniform(int v) {
       NK_ATOMIC_ADD((f).abar + (p), (val));                                         \
   } while (0)
 
+// ... or, with nk_fuse.wfull, no accumulation at all: the contribution lands at its own grid point (the partners of a
+// work item write 0) and the caller sums the bins in a fixed order
+#define NK_VJP_SCATTER_AT(f, o, p, val)     \
+  do {                                      \
+    if ((f).wfull)                          \
+      (f).wfull[(o)] = (val);               \
+    else                                    \
+      NK_VJP_SCATTER(f, p, val);            \
+  } while (0)
+
 #define NK_MAX_STAGES 8
 
 template <typename T>
@@ -515,7 +525,7 @@ NK_HD void nk_epilogue(const NkFuse& f, int64_t o, T v, double& acc) {
       if (f.addend) r += f.addend_scale * (double)((const T*)f.addend)[o];
       if (f.accumulate) r += (double)out[o];
       out[o] = (T)r;
-      NK_VJP_SCATTER(f, p, (double)((const T*)f.xi)[o] * t);
+      NK_VJP_SCATTER_AT(f, o, p, (double)((const T*)f.xi)[o] * t);
     } break;
     case NK_EPI_LIKELIHOOD:
       nk_epi_likelihood<T>(f, o, v, acc);
@@ -553,7 +563,8 @@ NK_HD void nk_epilogue_pair(const NkFuse& f, int64_t o1, T v1, int64_t o2, T v2,
     out[o1] = (T)r1;
     out[o2] = (T)r2;
     const T* xi = (const T*)f.xi;
-    NK_VJP_SCATTER(f, p, (double)xi[o1] * t1 + (double)xi[o2] * t2);
+    NK_VJP_SCATTER_AT(f, o1, p, (double)xi[o1] * t1 + (double)xi[o2] * t2);
+    if (f.wfull && o2 != o1) f.wfull[o2] = 0.0;
   } else {
     nk_epilogue<T>(f, o1, v1, acc);
     nk_epilogue<T>(f, o2, v2, acc);
@@ -621,10 +632,15 @@ NK_HD void nk_epilogue_multi(const NkFuse& f, const int64_t (&o)[8], const T (&v
       out[o[i]] = (T)(a * t + f.addend_scale * (double)av[i] + (double)ov[i]);
       s += (double)xv[i] * t;
     }
-    if (w8slot)
+    if (w8slot) {
       *w8slot = s;  // octant array: every slot is written exactly once, reduced later by nk_octant_scatter
-    else
+    } else if (f.wfull) {
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i)
+        if ((mask >> i) & 1) f.wfull[o[i]] = i == first ? s : 0.0;
+    } else {
       NK_VJP_SCATTER(f, p, s);
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < NOUT; ++i)

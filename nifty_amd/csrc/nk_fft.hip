@@ -786,7 +786,12 @@ static inline int64_t nk_value_slot_count(const NkHostPlan& hp) {
   // workgroup that is 0.53 lines), odd tile counts round up: 9/8 of the lines + 512 covers every launcher
   const int64_t lines = (int64_t)hp.g.batch * hp.g.na * hp.g.nm;
   const int64_t per_line = hp.g.nl > 1024 ? hp.g.nl / 1024 : 1;
-  const int64_t n = std::max<int64_t>(lines * per_line * 9 / 8 + 512, NK_FOLD_BLOCKS);
+  int64_t n = std::max<int64_t>(lines * per_line * 9 / 8 + 512, NK_FOLD_BLOCKS);
+  // the generic LDS kernels (mixed-radix grids) own one slot per wavefront as well: pass C / pass 1-D with up to 16
+  // wavefronts per workgroup, pass D with 4
+  const int64_t tile_a = hp.pa.tl.tile > 0 ? hp.pa.tl.tile : 1;
+  const int64_t gen = hp.pc.outer * hp.pc.tiles_per_slab * 16 + (lines + 255) / 256 * 4 + (hp.pa.nlines + tile_a - 1) / tile_a * 16;
+  n = std::max(n, gen + 512);
   return (n + 255) / 256 * 256;
 }
 __device__ __forceinline__ double nk_fold_block_sum(double v, double* red) {
@@ -945,12 +950,45 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
   const int64_t blocks_a = (pa.nlines + pa.tl.tile - 1) / pa.tl.tile;
   if (blocks_a > 0x7fffffffLL) return nk_set_error(NK_ERR_UNSUPPORTED, "too many lines for one launch");
   const bool fast = nk_fast_enabled();
+  // Energy / curvature sums of the kernels below (everything but the strided-first pipeline, which brings its own slot
+  // handling): one slot per WAVEFRONT in the workspace's slot area, folded in a fixed order afterwards -- bit-reproducible
+  // like the fast path (round 3; until then one fp64 atomic per workgroup).  Without a workspace (1-D calls may omit it) or
+  // if the area were too small the atomics remain.
+  const bool want_value = f.value && (f.epi == NK_EPI_LIKELIHOOD || f.epi == NK_EPI_VJP);
+  const int64_t slot_cap = nk_value_slot_count(hp);
+  double* vslots = workspace ? nk_value_slots(hp, workspace) : nullptr;
+  int64_t slot_used = 0;
+  bool slots_on = want_value && vslots != nullptr;
+  auto with_slots = [&](int64_t blocks, int threads) {
+    NkFuse g = f;
+    if (!slots_on) return g;
+    const int64_t need = blocks * ((threads + 63) / 64);
+    if (slot_used + need > slot_cap) {
+      slots_on = false;
+      return g;
+    }
+    g.value = vslots + slot_used;
+    g.value_slots = (int)need;
+    slot_used += need;
+    return g;
+  };
+  auto fold_slots = [&]() -> int {
+    if (slot_used == 0) return NK_OK;
+    return nk_fold_value_slots(hp, vslots, f.value, st);
+  };
   if (hp.g.ndim == 1) {
     ProfScope ps(st, 0, f.pro, f.epi);
     if (fast && nk_fast_contig_ok(hp.g.h))
       return nk_dispatch_contig<T, true>(hp.g.h, pa, f, tw_a, twr, (C2<T>*)nullptr, st);
-    hipLaunchKernelGGL(k_pass1d<T>, dim3((unsigned)blocks_a), dim3(nk_gen_threads<T>(hp.threads_a)), hp.lds_a, st, pa, f, tw_a, twr);
-    return nk_check_launch("k_pass1d");
+    if (slots_on) {
+      hipError_t e = hipMemsetAsync(vslots, 0, (size_t)slot_cap * sizeof(double), st);
+      if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(reduction slots)");
+    }
+    const int thr = nk_gen_threads<T>(hp.threads_a);
+    const NkFuse f1 = with_slots(blocks_a, thr);
+    hipLaunchKernelGGL(k_pass1d<T>, dim3((unsigned)blocks_a), dim3(thr), hp.lds_a, st, pa, f1, tw_a, twr);
+    const int rc1 = nk_check_launch("k_pass1d");
+    return rc1 != NK_OK ? rc1 : fold_slots();
   }
   if (!workspace) return nk_set_error(NK_ERR_INVALID, "nk_hartley: workspace required for ndim >= 2");
   C2<T>* work = (C2<T>*)workspace;
@@ -1020,20 +1058,28 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
     if (rc != NK_OK) return rc;
   }
   const int64_t blocks_c = pc.outer * pc.tiles_per_slab;
+  if (slots_on) {
+    hipError_t e = hipMemsetAsync(vslots, 0, (size_t)slot_cap * sizeof(double), st);
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(reduction slots)");
+  }
   {
     ProfScope ps(st, 3, f.pro, f.epi);
-    hipLaunchKernelGGL(k_passC<T>, dim3((unsigned)blocks_c), dim3(nk_gen_threads<T>(hp.threads_c)), hp.lds_c, st, pc, f,
-                       (const C2<T>*)P->d_tw_c, (const C2<T>*)work, scratch);
+    const int thr = nk_gen_threads<T>(hp.threads_c);
+    const NkFuse fc = with_slots(blocks_c, thr);
+    hipLaunchKernelGGL(k_passC<T>, dim3((unsigned)blocks_c), dim3(thr), hp.lds_c, st, pc, fc, (const C2<T>*)P->d_tw_c,
+                       (const C2<T>*)work, scratch);
     rc = nk_check_launch("k_passC");
   }
   if (rc != NK_OK) return rc;
   const int64_t total_d = (int64_t)hp.g.batch * hp.g.nm * hp.g.na;
   {
     ProfScope ps(st, 4, f.pro, f.epi);
-    hipLaunchKernelGGL(k_passD<T>, dim3((unsigned)((total_d + 255) / 256)), dim3(256), 0, st, pc.g, f,
-                       (const C2<T>*)scratch, total_d);
+    const int64_t blocks_d = (total_d + 255) / 256;
+    const NkFuse fd = with_slots(blocks_d, 256);
+    hipLaunchKernelGGL(k_passD<T>, dim3((unsigned)blocks_d), dim3(256), 0, st, pc.g, fd, (const C2<T>*)scratch, total_d);
   }
-  return nk_check_launch("k_passD");
+  rc = nk_check_launch("k_passD");
+  return rc != NK_OK ? rc : fold_slots();
 }
 
 extern "C" int nk_hartley_fused(const nk_plan* P, const nk_fuse* fuse, int convention, void* workspace,

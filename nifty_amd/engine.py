@@ -330,6 +330,7 @@ class FusedModel:
             self.abar_stride = (nb + 31) // 32 * 32
             self.abar_copies = 8
             self.scatter_scratch = torch.empty(64 * (nb + 32), dtype=torch.float64, device=self.device)
+            self.wfull = self.full_plan = None  # plans without the octant pipeline: see below
             self.abar_priv = torch.zeros(self.abar_copies * self.abar_stride, dtype=torch.float64, device=self.device)
             self.abar = torch.zeros(nb, dtype=torch.float64, device=self.device)
             self.damp = torch.empty(nb, dtype=torch.float64, device=self.device)
@@ -387,6 +388,12 @@ class FusedModel:
                 self.k2_dense = torch.zeros(int(self.bin_k2[-1].item()) + 1, dtype=dtype, device=self.device)
             if self.octant_vjp and self.bin_k2 is None and os.environ.get("NK_SEGMENT_SUM", "1") != "0":
                 self.seg_plan = B.bin_plan(self.pidx8, self.nb)
+            # plans WITHOUT the octant pipeline (mixed-radix grids, short axes): the generic kernels deposit xi . t per grid
+            # point in a full-grid fp64 array (nk_fuse.wfull) that is summed bin by bin in a fixed order -- instead of fp64
+            # atomics into per-XCD copies of abar (NK_SEGMENT_SUM=0: the atomics, for A/B)
+            if (not self.octant_vjp and self.N <= B.BIN_PLAN_MAX and os.environ.get("NK_SEGMENT_SUM", "1") != "0"):
+                self.full_plan = B.bin_plan(self.pidx, self.nb)
+                self.wfull = torch.empty(self.N, dtype=torch.float64, device=self.device)
         # likelihood
         if likelihood not in ("gaussian", "poisson"):
             raise ValueError("likelihood must be 'gaussian' or 'poisson'")
@@ -524,6 +531,12 @@ class FusedModel:
                 L.check(L.load().nk_octant_scatter(len(self.shape), shp, self.w8.data_ptr(), self.pidx.data_ptr(),
                                                    self.abar.data_ptr(), self.merge_swapped, B._stream()),
                         "nk_octant_scatter")
+        elif self.full_plan is not None:
+            f.abar, f.wfull = self.abar.data_ptr(), self.wfull.data_ptr()
+            run(f)
+            rowptr, perm, lanes = self.full_plan
+            L.check(L.load().nk_csr_rowsum(self.nb, rowptr.data_ptr(), perm.data_ptr(), 0, self.wfull.data_ptr(),
+                                           self.abar.data_ptr(), L.NK_F64, lanes, B._stream()), "nk_csr_rowsum")
         else:
             f.abar, f.abar_copies, f.abar_stride = self.abar_priv.data_ptr(), self.abar_copies, self.abar_stride
             self.abar_priv.zero_()
