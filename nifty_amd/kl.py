@@ -15,13 +15,10 @@ import pickle
 
 import numpy as np
 
-from . import random
-from .domains import MultiDomain
 from .energy_operators import GaussianEnergy, StandardHamiltonian
-from .field import Field, MultiField, is_fieldlike
+from .field import MultiField
 from .minimization import DescentMinimizer, Energy
-from .operators import (EndomorphicOperator, Linearization, SamplingEnabler, SandwichOperator, ScalingOperator,
-                        is_operator, makeDomain)
+from .operators import EndomorphicOperator, Linearization, SamplingEnabler, SandwichOperator, ScalingOperator, makeDomain
 from .parallel import SamplePlan, get_MPI_params_from_comm, shareRange
 
 
