@@ -246,6 +246,20 @@ def _nccl_single_worker(rank, world, port):
     ift.random.pop_sseq()
     assert kl.samples.n_samples == 4
     assert abs(kl.value - float(z["kl_value"])) < 1e-9 * abs(float(z["kl_value"]))
+    # the rank-synchronisation guards with DEVICE fields (fingerprint from the fixed-order device reduction) and the whole
+    # driver with a communicator: same result as without one
+    parallel.check_MPI_equality(x, comm, hash=True)
+    parallel.check_MPI_synced_random_state(comm)
+    mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=1), max_cg_iterations=4)  # noqa: E731
+    means = []
+    for c in (comm, None):
+        ift.random.push_sseq_from_seed(5)
+        try:
+            _, mean = ift.optimize_kl(lh, 2, 1, mk, ic, output_directory=None, return_final_position=True, device_id=0, comm=c)
+        finally:
+            ift.random.pop_sseq()
+        means.append(mean.asnumpy())
+    assert gl.lat_relerr(means[0], means[1]) < 1e-9
     dist.destroy_process_group()
 
 
