@@ -7,6 +7,6 @@ for d in sys.argv[1:]:
             name = row["Kernel_Name"].split("(")[0][-40:]
             acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for name, cs in acc.items():
-            if not ("k2_" in name or "k_pass" in name):
+            if not ("k2_" in name or "k3_" in name or "k_pass" in name or "k_octant" in name or "k_map" in name):
                 continue
             print(name, {c: f"{sum(v)/len(v):.4g}" for c, v in cs.items()})
