@@ -403,33 +403,55 @@ NK_HD C2<T> nk_load_pair_u(const T* p) {
 //   PC = 7: afield8 * in + dampT[pidx_octant] * in2   (da gathered from its table: no expanded da field)
 //   PC = 8: as 5, after the pending CG direction update  in <- beta * in + cg_r  (written back; same fp64 arithmetic as
 //           nk_cg_direction, so the fused and the separate update agree bit for bit)
+// The prologue comes in two halves, LOAD (every operand of the pair, no arithmetic, no store) and APPLY (arithmetic and
+// the write-back of class 8), so that a pass can issue the loads of all its elements before the first use: class 8's
+// store to `in` may alias every later load as far as the compiler knows, and a per-element load -> use chain leaves four
+// loads in flight per thread (ISA of the contiguous first pass before the split: 16 x "4 loads, s_waitcnt vmcnt(0)").
+template <typename T>
+struct NkOctOps {
+  C2<T> a, r, m, x, dm;
+};
 template <typename T, int PC>
-NK_HD C2<T> nk_prologue_oct(const NkFuse& f, int64_t iu, uint32_t it, uint32_t j, bool desc) {
-  C2<T> a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
-  if constexpr (PC == 8) {
-    double beta = f.cg_scal[2] / f.cg_scal[0];
-    beta = beta > 0.0 ? beta : 0.0;
-    const C2<T> r = *reinterpret_cast<const C2<T>*>((const T*)f.cg_r + iu + it);
-    a = C2<T>{(T)(beta * (double)a.x + (double)r.x), (T)(beta * (double)a.y + (double)r.y)};
-    *reinterpret_cast<C2<T>*>(const_cast<T*>((const T*)f.in) + iu + it) = a;
-  }
-  C2<T> m = nk_load_pair_u<T>((const T*)f.afield + j);
-  if (desc) m = C2<T>{m.y, m.x};
-  if constexpr (PC == 4) {
-    return C2<T>{m.x * a.x, m.y * a.y};
-  } else if constexpr (PC == 7) {
-    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
+NK_HD NkOctOps<T> nk_oct_load(const NkFuse& f, int64_t iu, uint32_t it, uint32_t j) {
+  NkOctOps<T> o;
+  o.a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
+  if constexpr (PC == 8) o.r = *reinterpret_cast<const C2<T>*>((const T*)f.cg_r + iu + it);
+  o.m = nk_load_pair_u<T>((const T*)f.afield + j);
+  if constexpr (PC != 4) o.x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
+  if constexpr (PC == 7) {
     const NkPairU<int32_t> p = *reinterpret_cast<const NkPairU<int32_t>*>(f.pidx_octant + j);
     const T* dt = (const T*)f.dampT;
-    C2<T> dm{dt[p.x], dt[p.y]};
-    if (desc) dm = C2<T>{dm.y, dm.x};
-    return C2<T>{m.x * a.x + dm.x * x.x, m.y * a.y + dm.y * x.y};
-  } else {
-    const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
-    C2<T> dm = nk_load_pair_u<T>((const T*)f.dafield + j);
-    if (desc) dm = C2<T>{dm.y, dm.x};
-    return C2<T>{m.x * a.x + dm.x * x.x, m.y * a.y + dm.y * x.y};
+    o.dm = C2<T>{dt[p.x], dt[p.y]};
+  } else if constexpr (PC != 4) {
+    o.dm = nk_load_pair_u<T>((const T*)f.dafield + j);
   }
+  return o;
+}
+// beta of class 8: the pending direction update's coefficient (same fp64 arithmetic as nk_cg_direction)
+NK_HD double nk_oct_beta(const NkFuse& f) {
+  const double beta = f.cg_scal[2] / f.cg_scal[0];
+  return beta > 0.0 ? beta : 0.0;
+}
+template <typename T, int PC>
+NK_HD C2<T> nk_oct_apply(const NkFuse& f, const NkOctOps<T>& o, int64_t iu, uint32_t it, bool desc, double beta) {
+  C2<T> a = o.a;
+  if constexpr (PC == 8) {
+    a = C2<T>{(T)(beta * (double)a.x + (double)o.r.x), (T)(beta * (double)a.y + (double)o.r.y)};
+    *reinterpret_cast<C2<T>*>(const_cast<T*>((const T*)f.in) + iu + it) = a;
+  }
+  const C2<T> m = desc ? C2<T>{o.m.y, o.m.x} : o.m;
+  if constexpr (PC == 4) {
+    return C2<T>{m.x * a.x, m.y * a.y};
+  } else {
+    const C2<T> dm = desc ? C2<T>{o.dm.y, o.dm.x} : o.dm;
+    return C2<T>{m.x * a.x + dm.x * o.x.x, m.y * a.y + dm.y * o.x.y};
+  }
+}
+template <typename T, int PC>
+NK_HD C2<T> nk_prologue_oct(const NkFuse& f, int64_t iu, uint32_t it, uint32_t j, bool desc) {
+  double beta = 0.0;
+  if constexpr (PC == 8) beta = nk_oct_beta(f);
+  return nk_oct_apply<T, PC>(f, nk_oct_load<T, PC>(f, iu, it, j), iu, it, desc, beta);
 }
 
 NK_HD void nk_nonlin(int kind, double s, double& g, double& gp) {

@@ -859,6 +859,72 @@ NK_HD FinalCt<T> nk_final_ct(const NkFuse& f) {
   return c;
 }
 
+#ifndef NK_FINAL_UNROLL
+#define NK_FINAL_UNROLL 1
+#endif
+// EC 2 (scatter / VJP) comes as LOAD (every operand of the four images: xi, the addend, the running sum in `out`) and
+// APPLY (arithmetic, stores): nk_final_coeff issues the loads of both slots of a couple before the first store -- `out`
+// may alias the addend, so no load could move above a store -- and nothing is consumed inside a conditional block (the ISA
+// before the split: one or two loads, s_waitcnt vmcnt(0), branch, per image).  Loads of images that do not exist (self-
+// paired line: om == ok, the addresses are valid) are issued regardless and their values dropped.
+// MODE >= 0: bit 0 = there is an addend, bit 1 = `out` holds a running sum -- compile-time, and every slot of the group
+// active, so the load block has no branch at all (a load under a run-time condition merges with a constant zero, and the
+// compiler moves the first use of the merged value up into the load's block: s_waitcnt per slot again).
+// MODE < 0: the flags are read at run time and inactive slots skipped (edge groups, 2-D launches of the couple kernels).
+template <typename T>
+struct NkVjpOps {
+  T x[4], d[4], o[4];
+};
+template <typename T, bool BOTH, int MODE>
+NK_HD NkVjpOps<T> nk_final_vjp_load(const FinalCt<T>& c, int64_t ok, int64_t om, int k2, int k2m) {
+  NkVjpOps<T> v;
+  const bool add = MODE < 0 ? c.addend != nullptr : (MODE & 1) != 0;
+  const bool run = MODE < 0 ? c.accum : (MODE & 2) != 0;
+  const int64_t at[4] = {ok + k2, om + k2m, ok + k2m, om + k2};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool on = BOTH || i < 2;
+    v.x[i] = on ? c.xi[at[i]] : (T)0;
+    v.d[i] = (on && add) ? c.addend[at[i]] : (T)0;
+    v.o[i] = (on && run) ? c.out[at[i]] : (T)0;
+  }
+  return v;
+}
+// returns the fp64 bin-sum contribution sum_images xi * t
+template <typename T, bool BOTH>
+NK_HD double nk_final_vjp_apply(const FinalCt<T>& c, const NkVjpOps<T>& v, int64_t ok, int64_t om, bool self, T v0, T v1,
+                                T v2, T v3, int k2, int k2m, T a, double& acc) {
+  const T t[4] = {v0 * c.sc, v1 * c.sc, v2 * c.sc, v3 * c.sc};
+  T r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r[i] = a * t[i];
+    r[i] += c.asc * v.d[i];  // d, o are zero without an addend / a running sum: exact no-ops
+    r[i] += v.o[i];
+  }
+  if (c.dot) {
+    double e = (double)v.d[0] * (double)r[0];
+    if (BOTH) e += (double)v.d[2] * (double)r[2];
+    if (!self) e += (double)v.d[1] * (double)r[1] + (BOTH ? (double)v.d[3] * (double)r[3] : 0.0);
+    acc += e;
+  }
+  T* outk = c.out + ok;
+  T* outm = c.out + om;
+  nk_store_stream_s(outk + k2, r[0]);
+  if (BOTH) nk_store_stream_s(outk + k2m, r[2]);
+  double s = (double)v.x[0] * (double)t[0];
+  if (BOTH) s += (double)v.x[2] * (double)t[2];
+  if (!self) {
+    nk_store_stream_s(outm + k2m, r[1]);
+    s += (double)v.x[1] * (double)t[1];
+    if (BOTH) {
+      nk_store_stream_s(outm + k2, r[3]);
+      s += (double)v.x[3] * (double)t[3];
+    }
+  }
+  return s;
+}
+
 // the (up to) four images of one coefficient of ONE slot: H(k,kl) -> ok+k2, H(-k,-kl) -> om+k2m, and when BOTH
 // (k2m != k2) H(k,-kl) -> ok+k2m, H(-k,kl) -> om+k2.  `self`: the line is its own partner (images 1, 3 coincide
 // with 2, 0).  Returns the fp64 bin-sum contribution for EC 2.
@@ -908,76 +974,41 @@ NK_HD double nk_final_slot(const NkFuse& f, const FinalCt<T>& c, int64_t ok, int
     }
     return 0.0;
   } else {
-    const T t0 = v0 * c.sc, t1 = v1 * c.sc, t2 = v2 * c.sc, t3 = v3 * c.sc;
-    const T* xk = c.xi + ok;
-    const T* xm = c.xi + om;
-    // all loads first, then the stores (out may alias the addend)
-    const T x0 = xk[k2], x2 = BOTH ? xk[k2m] : (T)0;
-    T x1 = (T)0, x3 = (T)0;
-    if (!self) {
-      x1 = xm[k2m];
-      if (BOTH) x3 = xm[k2];
-    }
-    T r0 = a * t0, r1 = a * t1, r2 = a * t2, r3 = a * t3;
-    T d0 = (T)0, d1 = (T)0, d2 = (T)0, d3 = (T)0;
-    if (c.addend) {
-      const T* ak = c.addend + ok;
-      const T* am = c.addend + om;
-      d0 = ak[k2];
-      if (BOTH) d2 = ak[k2m];
-      if (!self) {
-        d1 = am[k2m];
-        if (BOTH) d3 = am[k2];
-      }
-      r0 += c.asc * d0, r1 += c.asc * d1, r2 += c.asc * d2, r3 += c.asc * d3;
-    }
-    if (c.accum) {
-      r0 += outk[k2];
-      if (BOTH) r2 += outk[k2m];
-      if (!self) {
-        r1 += outm[k2m];
-        if (BOTH) r3 += outm[k2];
-      }
-    }
-    if (c.dot) {  // d1/d3 (d2/d3) are zero when the image does not exist
-      double e = (double)d0 * (double)r0;
-      if (BOTH) e += (double)d2 * (double)r2;
-      if (!self) e += (double)d1 * (double)r1 + (BOTH ? (double)d3 * (double)r3 : 0.0);
-      acc += e;
-    }
-    nk_store_stream_s(outk + k2, (T)(r0));
-    if (BOTH) nk_store_stream_s(outk + k2m, (T)(r2));
-    double s = (double)x0 * (double)t0;
-    if (BOTH) s += (double)x2 * (double)t2;
-    if (!self) {
-      nk_store_stream_s(outm + k2m, (T)(r1));
-      s += (double)x1 * (double)t1;
-      if (BOTH) {
-        nk_store_stream_s(outm + k2, (T)(r3));
-        s += (double)x3 * (double)t3;
-      }
-    }
-    return s;
+    static_assert(EC != 2, "the scatter epilogue runs through nk_final_vjp_load / nk_final_vjp_apply");
+    return 0.0;
   }
 }
 
-// all slots of a group for coefficient k2
-template <typename T, int NL, int NH, int EC, bool BOTH>
-NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg,
-                          int k2, int hv, const T* afline, double* w8line, double& acc, float& wmax) {
-  const int k2m = (NL - k2) & (NL - 1);
-  const int d1 = k2 + (k2 >> 5), d2 = k2m + (k2m >> 5);
-  T a = (T)0;
-  if constexpr (EC == 2) a = afline[k2];
-  double ssum = 0.0;
+// EC 2: all slots of a group for the coefficients k2[0 .. n_on-1] (k2[u >= n_on] repeat a valid one: loaded, not applied) --
+// the loads of all U coefficients ahead of the first store
+template <typename T, int NL, int NH, bool BOTH, int MODE, int U>
+NK_HD void nk_final_vjp_coeffs(const NkFuse& f, const FinalCt<T>& c, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg,
+                               const int (&k2s)[U], int n_on, int hv, const T* afline, double* w8line, double& acc,
+                               float& wmax) {
+  NkVjpOps<T> ops[U][NH];
+  T a[U];
 #pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    if (!gp.mlo[h]) continue;
-    const T fx = pre[gp.base[h] + d1], fy = pim[gp.base[h] + d1];
-    const T gx = pre[gp.base[h] + d2], gy = pim[gp.base[h] + d2];
-    ssum += nk_final_slot<T, EC, BOTH>(f, c, gp.okh[h], gp.omh[h], gp.mlo[h] == 1, sg, fx, fy, gx, gy, k2, k2m, a, acc);
+  for (int u = 0; u < U; ++u) {
+    const int k2 = k2s[u], k2m = (NL - k2) & (NL - 1);
+    a[u] = afline[k2];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+      if (MODE >= 0 || gp.mlo[h]) ops[u][h] = nk_final_vjp_load<T, BOTH, MODE>(c, gp.okh[h], gp.omh[h], k2, k2m);
   }
-  if constexpr (EC == 2) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (u >= n_on) break;
+    const int k2 = k2s[u], k2m = (NL - k2) & (NL - 1);
+    const int d1 = k2 + (k2 >> 5), d2 = k2m + (k2m >> 5);
+    double ssum = 0.0;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      if (MODE < 0 && !gp.mlo[h]) continue;
+      const T fx = pre[gp.base[h] + d1], fy = pim[gp.base[h] + d1];
+      const T gx = pre[gp.base[h] + d2], gy = pim[gp.base[h] + d2];
+      ssum += nk_final_vjp_apply<T, BOTH>(c, ops[u][h], gp.okh[h], gp.omh[h], gp.mlo[h] == 1, fx + sg * fy, fx - sg * fy,
+                                          gx + sg * gy, gx - sg * gy, k2, k2m, a[u], acc);
+    }
     if (w8line) {
       w8line[k2] = ssum;
       wmax = nk_wmax_join(wmax, nk_abs_up(ssum));
@@ -985,7 +1016,28 @@ NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup
       NK_VJP_SCATTER(f, f.pidx[gp.okh[hv] + k2], ssum);
     }
   }
-  if constexpr (EC == 3) acc += ssum;
+}
+
+// all slots of a group for coefficient k2
+template <typename T, int NL, int NH, int EC, bool BOTH, int MODE = -1>
+NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg,
+                          int k2, int hv, const T* afline, double* w8line, double& acc, float& wmax) {
+  if constexpr (EC == 2) {
+    const int one[1] = {k2};
+    nk_final_vjp_coeffs<T, NL, NH, BOTH, MODE, 1>(f, c, gp, pre, pim, sg, one, 1, hv, afline, w8line, acc, wmax);
+  } else {
+    const int k2m = (NL - k2) & (NL - 1);
+    const int d1 = k2 + (k2 >> 5), d2 = k2m + (k2m >> 5);
+    double ssum = 0.0;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      if (!gp.mlo[h]) continue;
+      const T fx = pre[gp.base[h] + d1], fy = pim[gp.base[h] + d1];
+      const T gx = pre[gp.base[h] + d2], gy = pim[gp.base[h] + d2];
+      ssum += nk_final_slot<T, EC, BOTH>(f, c, gp.okh[h], gp.omh[h], gp.mlo[h] == 1, sg, fx, fy, gx, gy, k2, k2m, (T)0, acc);
+    }
+    if constexpr (EC == 3) acc += ssum;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1211,9 +1263,42 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
         if constexpr (EC == 2)
           afline = f.field_octant ? c.af + ((int64_t)a * (M / 2 + 1) + b0g) * (NL / 2 + 1) : c.af + gp.okh[hv];
         // k_last = 0 and NL/2 are their own mirrors; everything in between has four distinct images per slot
-        if (lane < 2) nk_final_coeff<T, NL, NH, EC, false>(f, c, gp, pre, pim, sg, lane ? NL / 2 : 0, hv, afline, w8line, acc, wmax);
-        for (int k2 = 1 + lane; k2 < NL / 2; k2 += tps)
-          nk_final_coeff<T, NL, NH, EC, true>(f, c, gp, pre, pim, sg, k2, hv, afline, w8line, acc, wmax);
+        auto coefficients = [&](auto mode_c) {
+          constexpr int MODE = decltype(mode_c)::value;
+          if (lane < 2)
+            nk_final_coeff<T, NL, NH, EC, false, MODE>(f, c, gp, pre, pim, sg, lane ? NL / 2 : 0, hv, afline, w8line, acc, wmax);
+          if constexpr (EC == 2 && MODE >= 0 && NK_FINAL_UNROLL > 1) {
+            constexpr int U = NK_FINAL_UNROLL;
+            for (int k2 = 1 + lane; k2 < NL / 2; k2 += U * tps) {
+              int ks[U], n_on = 0;
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                const int k = k2 + u * tps;
+                const bool on = k < NL / 2;
+                ks[u] = on ? k : k2;
+                n_on += on;
+              }
+              nk_final_vjp_coeffs<T, NL, NH, true, MODE, U>(f, c, gp, pre, pim, sg, ks, n_on, hv, afline, w8line, acc, wmax);
+            }
+          } else {
+            for (int k2 = 1 + lane; k2 < NL / 2; k2 += tps)
+              nk_final_coeff<T, NL, NH, EC, true, MODE>(f, c, gp, pre, pim, sg, k2, hv, afline, w8line, acc, wmax);
+          }
+        };
+        if constexpr (EC == 2) {  // see nk_final_vjp_load
+          bool full = true;
+#pragma unroll
+          for (int h = 0; h < NH; ++h) full = full && gp.mlo[h] != 0;
+          switch (full ? (c.addend ? 1 : 0) | (c.accum ? 2 : 0) : -1) {
+            case 0: coefficients(std::integral_constant<int, 0>{}); break;
+            case 1: coefficients(std::integral_constant<int, 1>{}); break;
+            case 2: coefficients(std::integral_constant<int, 2>{}); break;
+            case 3: coefficients(std::integral_constant<int, 3>{}); break;
+            default: coefficients(std::integral_constant<int, -1>{}); break;
+          }
+        } else {
+          coefficients(std::integral_constant<int, -1>{});
+        }
       }
     } else if (any) {
       const bool vjp = f.epi == NK_EPI_VJP;

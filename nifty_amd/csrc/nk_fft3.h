@@ -62,6 +62,11 @@ struct Contig3Tile {
   static constexpr int QLDS_BYTES = 2 * 4 * PITCH * (int)sizeof(T);
 };
 
+// load batches of prologue class 8 in the first phase (see there)
+#ifndef NK_OCT8_BATCHES
+#define NK_OCT8_BATCHES 2
+#endif
+
 // QUAD (3-D grids, octant prologue classes; TILE == 4): workgroup blk = (batch, a8, b8) over the OCTANT of the first two
 // axes takes the rows (a8, b8), (a8, M - b8), (A - a8, b8), (A - a8, M - b8) -- the four rows of the grid that read the
 // SAME lines of the octant amplitude fields a[pidx], da[pidx].  In natural row order these four rows run at unrelated
@@ -115,25 +120,49 @@ NK_HD void nk_contig3_body(Exec& ex, const NkPass3& p, const NkFuse& f, int64_t 
     // flat real index of the row = iu (wave-uniform where the rows of a tile are consecutive) + tl (per thread)
     const int64_t iu = QUAD ? (line < 0 ? 0 : line * nl) : line0 * nl;
     const uint32_t tl = QUAD ? 0u : (uint32_t)(t * nl);  // < 2^31: a tile of lines
+    if constexpr (OCT) {
+      // ONE branch around the whole row, and all E elements' operand loads ahead of the first use (nk_oct_load / _apply)
+      if (line >= 0) {
+        // class 8 carries five operand pairs and fp64 temporaries per element: two half batches keep it at 4 waves/SIMD
+        constexpr int NB = PC == 8 ? NK_OCT8_BATCHES : 1, EB = E / NB;
+        double beta = 0.0;
+        if constexpr (PC == 8) beta = nk_oct_beta(f);
 #pragma unroll
-    for (int q = 0; q < Q; ++q)
+        for (int e0 = 0; e0 < E; e0 += EB) {
+          NkOctOps<T> ops[EB];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int row = nk_in_row<SC, 0>(pp, q, r);  // complex index j: reals 2j, 2j+1
-        C2<T> z{(T)0, (T)0};
-        if (line >= 0) {
-          if constexpr (OCT) {
+          for (int e = e0; e < e0 + EB; ++e) {
+            const int row = nk_in_row<SC, 0>(pp, e / R, e % R);  // complex index j: reals 2j, 2j+1
             const bool desc = 4 * row >= nl;  // (c, c+1) -> (nl-c, nl-c-1): stored descending, lower position nl-c-1
-            const uint32_t c8 = desc ? nl - 2 * row - 1 : 2 * row;
-            z = nk_prologue_oct<T, PC>(f, iu, tl + 2 * row, o8 + c8, desc);
-          } else if constexpr (PC >= 0) {
-            z = nk_prologue_ct<T, PC>(f, iu, tl + 2 * row);
-          } else {
-            z = nk_prologue_pair<T>(f, iu + tl + 2 * row);
+            ops[e - e0] = nk_oct_load<T, PC>(f, iu, tl + 2 * row, o8 + (desc ? nl - 2 * row - 1 : 2 * row));
+          }
+#pragma unroll
+          for (int e = e0; e < e0 + EB; ++e) {
+            const int row = nk_in_row<SC, 0>(pp, e / R, e % R);
+            rg.v[e] = nk_oct_apply<T, PC>(f, ops[e - e0], iu, tl + 2 * row, 4 * row >= nl, beta);
           }
         }
-        rg.v[q * R + r] = z;
+      } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) rg.v[e] = C2<T>{(T)0, (T)0};
       }
+    } else {
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int row = nk_in_row<SC, 0>(pp, q, r);
+          C2<T> z{(T)0, (T)0};
+          if (line >= 0) {
+            if constexpr (PC >= 0) {
+              z = nk_prologue_ct<T, PC>(f, iu, tl + 2 * row);
+            } else {
+              z = nk_prologue_pair<T>(f, iu + tl + 2 * row);
+            }
+          }
+          rg.v[q * R + r] = z;
+        }
+    }
     nk_stage_compute<T, SC, 0>(rg.v, pp, tw);
 #pragma unroll
     for (int q = 0; q < Q; ++q)
