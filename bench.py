@@ -345,6 +345,8 @@ def main():
         lib.nk_profile_enable(1)
     collect_profile()
     sync()
+    ms = torch.cuda.memory_stats(device)
+    mem_before = (int(ms.get("num_device_alloc", 0)), int(ms.get("num_device_free", 0)))
     t0 = time.perf_counter()
     energy = float("nan")
     for _ in range(args.steps):
@@ -352,6 +354,14 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     lib.nk_profile_enable(0)
+    # allocator behaviour of the timed region (peak footprint; hipMalloc calls after the warm-up: the peak still grows now
+    # and then -- an A/B against one up-front segment showed no time difference, gpurun_out/r3q)
+    ms = torch.cuda.memory_stats(device)
+    device_memory = {"peak_allocated_GB": round(ms.get("allocated_bytes.all.peak", 0) / 1e9, 2),
+                     "peak_reserved_GB": round(ms.get("reserved_bytes.all.peak", 0) / 1e9, 2),
+                     "hipMalloc_calls_timed": int(ms.get("num_device_alloc", 0)) - mem_before[0],
+                     "hipFree_calls_timed": int(ms.get("num_device_free", 0)) - mem_before[1],
+                     "alloc_retries": int(ms.get("num_alloc_retries", 0))}
     prof = collect_profile()
     if comm is not None:
         elapsed = comm.max_float(elapsed, device)
@@ -489,6 +499,7 @@ def main():
             "per_step_counts_rank0": counts,
             "step_algorithmic_GBps_rank0": step_bytes / (ms_per_step * 1e-3) / 1e9,
             "roofline": roofline,
+            "device_memory_rank0": device_memory,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
