@@ -9,6 +9,7 @@
 // emulation is never linked into the product library.
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/niftyk.h"
 
 #ifdef NK_HOST_EMU
@@ -491,9 +492,55 @@ NK_HD void nk_epi_likelihood(const NkFuse& f, int64_t o, T v, double& acc) {
   if (f.out2) ((T*)f.out2)[o] = (T)w;
 }
 
-// the same for the (up to) four images of one coefficient: every load is issued before the first store -- `out` may alias
-// nothing here, but the compiler cannot know, and four dependent load -> store chains per work item cost the final pass
-// 1 ms at 1024^3
+// FAST (compile-time, chosen per group of lines by the final pass): every image in `MASK` exists and the likelihood is
+// 1 = Gaussian with a scalar inverse covariance, 2 = Poissonian.  The data loads (nk_lh4_load: raw values, no arithmetic)
+// then stand in straight-line code and the caller issues them for several coefficients ahead of the first store; under
+// run-time conditions each load sat in its own block with an s_waitcnt behind it.
+template <typename T, int FAST>
+struct NkLhData {
+  typedef typename std::conditional<FAST == 2, int64_t, T>::type type;
+};
+template <typename T, int FAST, int MASK>
+NK_HD void nk_lh4_load(const NkFuse& f, const int64_t (&o)[4], typename NkLhData<T, FAST>::type (&d)[4]) {
+  typedef typename NkLhData<T, FAST>::type D;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) d[i] = ((MASK >> i) & 1) ? ((const D*)f.data)[o[i]] : (D)1;
+}
+// one output of the likelihood epilogue: energy term returned, dE/ds and the Fisher weight through gs, w
+NK_HD double nk_lh_term(const NkFuse& f, bool gauss, double v, double d, double ic, double& gs, double& w) {
+  const double s = v * f.scale + f.offset;
+  double g, gp;
+  nk_nonlin(f.nonlin, s, g, gp);
+  if (gauss) {
+    const double r = g - d;
+    gs = gp * ic * r;
+    w = gp * gp * ic;
+    return 0.5 * ic * r * r;
+  }
+  gs = gp * (1.0 - d / g);
+  w = gp * gp / g;
+  return g - d * log(g);
+}
+template <typename T, int FAST, int MASK>
+NK_HD void nk_lh4_apply(const NkFuse& f, const int64_t (&o)[4], const T (&v)[4],
+                        const typename NkLhData<T, FAST>::type (&d)[4], double& acc) {
+  double gs[4], w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double e = nk_lh_term(f, FAST == 1, (double)v[i], (double)d[i], f.icov_scalar, gs[i], w[i]);
+    if ((MASK >> i) & 1) acc += e;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!((MASK >> i) & 1)) continue;
+    ((T*)f.out)[o[i]] = (T)gs[i];
+    if (f.out2) ((T*)f.out2)[o[i]] = (T)w[i];
+  }
+}
+
+// the (up to) four images of one coefficient, everything decided at run time: every load is issued before the first store
+// -- `out` may alias nothing here, but the compiler cannot know, and four dependent load -> store chains per work item cost
+// the final pass 1 ms at 1024^3
 template <typename T>
 NK_HD void nk_epi_likelihood4(const NkFuse& f, const int64_t (&o)[4], const T (&v)[4], int mask, double& acc) {
   double dv[4], ic[4];
@@ -507,20 +554,7 @@ NK_HD void nk_epi_likelihood4(const NkFuse& f, const int64_t (&o)[4], const T (&
   double gs[4], w[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const double s = (double)v[i] * f.scale + f.offset;
-    double g, gp;
-    nk_nonlin(f.nonlin, s, g, gp);
-    double e;
-    if (gauss) {
-      const double r = g - dv[i];
-      e = 0.5 * ic[i] * r * r;
-      gs[i] = gp * ic[i] * r;
-      w[i] = gp * gp * ic[i];
-    } else {
-      e = g - dv[i] * log(g);
-      gs[i] = gp * (1.0 - dv[i] / g);
-      w[i] = gp * gp / g;
-    }
+    const double e = nk_lh_term(f, gauss, (double)v[i], dv[i], ic[i], gs[i], w[i]);
     if ((mask >> i) & 1) acc += e;
   }
 #pragma unroll

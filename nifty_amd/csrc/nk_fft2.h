@@ -862,6 +862,9 @@ NK_HD FinalCt<T> nk_final_ct(const NkFuse& f) {
 #ifndef NK_FINAL_UNROLL
 #define NK_FINAL_UNROLL 1
 #endif
+#ifndef NK_LH_UNROLL
+#define NK_LH_UNROLL 4  // coefficients per trip of the likelihood epilogue's fast paths
+#endif
 // EC 2 (scatter / VJP) comes as LOAD (every operand of the four images: xi, the addend, the running sum in `out`) and
 // APPLY (arithmetic, stores): nk_final_coeff issues the loads of both slots of a couple before the first store -- `out`
 // may alias the addend, so no load could move above a store -- and nothing is consumed inside a conditional block (the ISA
@@ -928,7 +931,7 @@ NK_HD double nk_final_vjp_apply(const FinalCt<T>& c, const NkVjpOps<T>& v, int64
 // the (up to) four images of one coefficient of ONE slot: H(k,kl) -> ok+k2, H(-k,-kl) -> om+k2m, and when BOTH
 // (k2m != k2) H(k,-kl) -> ok+k2m, H(-k,kl) -> om+k2.  `self`: the line is its own partner (images 1, 3 coincide
 // with 2, 0).  Returns the fp64 bin-sum contribution for EC 2.
-template <typename T, int EC, bool BOTH>
+template <typename T, int EC, bool BOTH, int MODE = -1>
 NK_HD double nk_final_slot(const NkFuse& f, const FinalCt<T>& c, int64_t ok, int64_t om, bool self, T sg, T fx, T fy, T gx,
                            T gy, int k2, int k2m, T a, double& acc) {
   const T v0 = fx + sg * fy, v1 = fx - sg * fy, v2 = gx + sg * gy, v3 = gx - sg * gy;
@@ -1018,6 +1021,42 @@ NK_HD void nk_final_vjp_coeffs(const NkFuse& f, const FinalCt<T>& c, const Final
   }
 }
 
+// EC 3 with MODE = 1 (Gaussian, scalar N^-1) / 2 (Poissonian) and every slot a regular line pair: all slots of a group for
+// the coefficients k2[0 .. n_on-1] -- the data loads of all U coefficients ahead of the first store (nk_lh4_load / _apply)
+template <typename T, int NL, int NH, bool BOTH, int MODE, int U>
+NK_HD void nk_final_lh_coeffs(const NkFuse& f, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg, const int (&k2s)[U],
+                              int n_on, double& acc) {
+  constexpr int MASK = BOTH ? 15 : 3;
+  typename NkLhData<T, MODE>::type d[U][NH][4];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int k2 = k2s[u], k2m = (NL - k2) & (NL - 1);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int64_t o4[4] = {gp.okh[h] + k2, gp.omh[h] + k2m, gp.okh[h] + k2m, gp.omh[h] + k2};
+      nk_lh4_load<T, MODE, MASK>(f, o4, d[u][h]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (u >= n_on) break;
+    const int k2 = k2s[u], k2m = (NL - k2) & (NL - 1);
+    const int d1 = k2 + (k2 >> 5), d2 = k2m + (k2m >> 5);
+    double ssum = 0.0;  // summed like the run-time path: images of a slot, slots of the group, then the thread's total
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const T fx = pre[gp.base[h] + d1], fy = pim[gp.base[h] + d1];
+      const T gx = pre[gp.base[h] + d2], gy = pim[gp.base[h] + d2];
+      const int64_t o4[4] = {gp.okh[h] + k2, gp.omh[h] + k2m, gp.okh[h] + k2m, gp.omh[h] + k2};
+      const T v4[4] = {fx + sg * fy, fx - sg * fy, gx + sg * gy, gx - sg * gy};
+      double e = 0.0;
+      nk_lh4_apply<T, MODE, MASK>(f, o4, v4, d[u][h], e);
+      ssum += e;
+    }
+    acc += ssum;
+  }
+}
+
 // all slots of a group for coefficient k2
 template <typename T, int NL, int NH, int EC, bool BOTH, int MODE = -1>
 NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg,
@@ -1031,10 +1070,11 @@ NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup
     double ssum = 0.0;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-      if (!gp.mlo[h]) continue;
+      if (MODE <= 0 && !gp.mlo[h]) continue;
       const T fx = pre[gp.base[h] + d1], fy = pim[gp.base[h] + d1];
       const T gx = pre[gp.base[h] + d2], gy = pim[gp.base[h] + d2];
-      ssum += nk_final_slot<T, EC, BOTH>(f, c, gp.okh[h], gp.omh[h], gp.mlo[h] == 1, sg, fx, fy, gx, gy, k2, k2m, (T)0, acc);
+      ssum += nk_final_slot<T, EC, BOTH, MODE>(f, c, gp.okh[h], gp.omh[h], gp.mlo[h] == 1, sg, fx, fy, gx, gy, k2, k2m, (T)0,
+                                               acc);
     }
     if constexpr (EC == 3) acc += ssum;
   }
@@ -1267,7 +1307,20 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
           constexpr int MODE = decltype(mode_c)::value;
           if (lane < 2)
             nk_final_coeff<T, NL, NH, EC, false, MODE>(f, c, gp, pre, pim, sg, lane ? NL / 2 : 0, hv, afline, w8line, acc, wmax);
-          if constexpr (EC == 2 && MODE >= 0 && NK_FINAL_UNROLL > 1) {
+          if constexpr (EC == 3 && MODE > 0) {
+            constexpr int U = NK_LH_UNROLL;
+            for (int k2 = 1 + lane; k2 < NL / 2; k2 += U * tps) {
+              int ks[U], n_on = 0;
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                const int k = k2 + u * tps;
+                const bool on = k < NL / 2;
+                ks[u] = on ? k : k2;
+                n_on += on;
+              }
+              nk_final_lh_coeffs<T, NL, NH, true, MODE, U>(f, gp, pre, pim, sg, ks, n_on, acc);
+            }
+          } else if constexpr (EC == 2 && MODE >= 0 && NK_FINAL_UNROLL > 1) {
             constexpr int U = NK_FINAL_UNROLL;
             for (int k2 = 1 + lane; k2 < NL / 2; k2 += U * tps) {
               int ks[U], n_on = 0;
@@ -1294,6 +1347,16 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
             case 1: coefficients(std::integral_constant<int, 1>{}); break;
             case 2: coefficients(std::integral_constant<int, 2>{}); break;
             case 3: coefficients(std::integral_constant<int, 3>{}); break;
+            default: coefficients(std::integral_constant<int, -1>{}); break;
+          }
+        } else if constexpr (EC == 3) {  // see nk_epi_likelihood4
+          bool regular = true;
+#pragma unroll
+          for (int h = 0; h < NH; ++h) regular = regular && gp.mlo[h] == 3;
+          const bool gauss = f.lh_kind == NK_LH_GAUSS;
+          switch (regular && !(gauss && f.icov) ? (gauss ? 1 : 2) : -1) {
+            case 1: coefficients(std::integral_constant<int, 1>{}); break;
+            case 2: coefficients(std::integral_constant<int, 2>{}); break;
             default: coefficients(std::integral_constant<int, -1>{}); break;
           }
         } else {
