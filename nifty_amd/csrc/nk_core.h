@@ -18,6 +18,7 @@ struct int2 {
   int x, y;
 };
 #define NK_HD inline
+#define NK_PIN(x) (void)(x)
 #define NK_ATOMIC_ADD(p, v) (*(p) += (v))
 #define NK_ATOMIC_ADD_XCD(p, v) (*(p) += (v))
 static inline int nk_xcc_id() { return 0; }
@@ -25,6 +26,13 @@ static inline int nk_uniform(int v) { return v; }
 #else
 #include <hip/hip_runtime.h>
 #define NK_HD __host__ __device__ __forceinline__
+// the value exists in a register HERE, and no memory access moves across this point (orders register-only arithmetic
+// against the loads of a following batch; the optimiser is otherwise free to sink it below them)
+#ifdef __HIP_DEVICE_COMPILE__
+#define NK_PIN(x) asm volatile("" : "+v"(x)::"memory")
+#else
+#define NK_PIN(x) (void)(x)
+#endif
 #define NK_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 // accumulator private to one XCD: every contributor sits behind the same L2, so workgroup scope (an L2 atomic
 // without the memory-side round trip of agent scope) is sufficient -- see nk_epilogue VJP

@@ -62,6 +62,9 @@ struct Contig3Tile {
   static constexpr int QLDS_BYTES = 2 * 4 * PITCH * (int)sizeof(T);
 };
 
+#ifndef NK_MID_EB
+#define NK_MID_EB 8  // elements per load batch of a field diagonal in the fused middle pass
+#endif
 // load batches of prologue class 8 in the first phase (see there)
 #ifndef NK_OCT8_BATCHES
 #define NK_OCT8_BATCHES 2
@@ -421,23 +424,39 @@ NK_HD void nk_mid_body(Exec& ex, const NkPassM& pm, const NkFuse& f, int64_t v0,
         const uint32_t off1 = (uint32_t)((int64_t)b * nl + c), off2 = (uint32_t)((int64_t)(b ? M - b : 0) * nl + (c ? nl - c : 0));
         const uint32_t t1 = (uint32_t)(rp * rowlen) + off1;
         const uint32_t t2 = (uint32_t)((RPMAX - rp) * rowlen) + off2;
+        // the two diagonal values of EB elements at a time, all their loads ahead of the first use, ONE test of `valid`
+        // around the batch (per element -- test, two loads, s_waitcnt, multiply -- the 2 E loads ran one pair at a time)
+        constexpr int EB = E < NK_MID_EB ? E : NK_MID_EB;
 #pragma unroll
-        for (int q = 0; q < Q; ++q)
+        for (int e0 = 0; e0 < E; e0 += EB) {
+          T m1[EB], m2[EB];
+          if (valid) {
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int ru = nk_out_row<SC, LS>(0, q, r);  // a = rp + ru
-            const C2<T> F = rg.v[q * R + r];
-            T m1 = (T)0, m2 = (T)0;
-            if (valid) {
-              m1 = ms * nk_at32<T>(mb, (int64_t)ru * rowlen, t1);
+            for (int e = e0; e < e0 + EB; ++e) {
+              const int ru = nk_out_row<SC, LS>(0, e / R, e % R);  // a = rp + ru
+              m1[e - e0] = nk_at32<T>(mb, (int64_t)ru * rowlen, t1);
               // mirror row (N - a) % N: (N - ru - RPMAX) + (RPMAX - rp), except a = 0 (its own mirror)
-              if (ru == 0 && rp == 0)
-                m2 = ms * mb[off2];
-              else
-                m2 = ms * nk_at32<T>(mb, (int64_t)(N - ru - RPMAX) * rowlen, t2);
+              const T* own = mb + off2;
+              const T* mir = &nk_at32<T>(mb, (int64_t)(N - ru - RPMAX) * rowlen, t2);
+              m2[e - e0] = *((ru == 0 && rp == 0) ? own : mir);
             }
-            rg.v[q * R + r] = C2<T>{m1 * (F.x + sg * F.y), m2 * (F.x - sg * F.y)};
+          } else {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) m1[e] = m2[e] = (T)0;
           }
+#pragma unroll
+          for (int e = e0; e < e0 + EB; ++e) {
+            const C2<T> F = rg.v[e];
+            rg.v[e] = C2<T>{ms * m1[e - e0] * (F.x + sg * F.y), ms * m2[e - e0] * (F.x - sg * F.y)};
+          }
+          // keep the batches apart: left alone hipcc issues all 2 E loads first and sinks the multiplications below them
+          // (212 B / lane of spills, 4.9 -> 6.4 ms); pinning the batch's results in front of a compiler fence orders them
+#pragma unroll
+          for (int e = e0; e < e0 + EB; ++e) {
+            NK_PIN(rg.v[e].x);
+            NK_PIN(rg.v[e].y);
+          }
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
