@@ -394,11 +394,13 @@ template <typename T, int H, int PC>
 static int nk_launch_contig3(const NkPass3& p3, const NkFuse& f, const C2<T>* tw, const C2<T>* twr, C2<T>* work, hipStream_t st) {
   using CT = Contig3Tile<T, H>;
   if constexpr ((PC == 4 || PC == 5 || PC == 7 || PC == 8) && CT::QUAD_OK) {
-    // NK_CONTIG_QUAD: 2 (default) = QUAD workgroups for the staged launches of a pipelined sandwich only, 1 = always,
-    // 0 = never.  QUAD cuts the FETCH of the JVP class from 15.2 to 10.1 GB per launch at 1024^3 fp32 but does not make
-    // the pass faster on an otherwise idle GPU (3.31 vs 3.26 ms; with the CG direction update 5.35 vs 5.21 ms,
-    // profiles/r03b_*): the pass is bound by its own load -> transform -> store chain, not by the fabric.
-    static const int quad = nk_env_int("NK_CONTIG_QUAD", 2);
+    // NK_CONTIG_QUAD: 1 (default) = QUAD workgroups for every launch on a 3-D grid, 2 = for the staged launches of a
+    // pipelined sandwich only, 0 = never.  QUAD cuts the FETCH of the JVP class from 15.2 to 10.1 GB per launch at 1024^3
+    // fp32 (the octant lines of a[pidx] / da[pidx] are read once per workgroup instead of once per row); on an otherwise idle
+    // GPU the pass takes the same time either way (3.59-3.63 vs 3.60-3.61 ms per launch over a bench step, identical bits:
+    // the extra fetches were served by L2 / Infinity Cache) -- the smaller footprint on the fabric is what a rank wants
+    // while its RCCL exchange runs beside the pass.
+    static const int quad = nk_env_int("NK_CONTIG_QUAD", 1);
     if ((quad == 1 || (quad == 2 && p3.nblk > 0)) && p3.g.ndim == 3) {
       auto qkern = k3_contig_quad<T, H, PC>;
       static unsigned long long qattr_mask = 0;
@@ -1143,7 +1145,7 @@ extern "C" int nk_plan_pipe_ok(const nk_plan* P, int chunks) {
   if (!nk_plan_sandwich(P) || chunks < 2 || (chunks & 1)) return 0;
   const NkGeom& g = P->hp.g;
   if (g.ndim != 3 || g.batch != 1 || g.na % chunks != 0) return 0;
-  if (!nk_env_int("NK_CONTIG_QUAD", 2) || (nk_env_int("NK_XMAP", NK_XMAP_DEFAULT) & 4)) return 0;
+  if (!nk_env_int("NK_CONTIG_QUAD", 1) || (nk_env_int("NK_XMAP", NK_XMAP_DEFAULT) & 4)) return 0;
   return (P->hp.dtype == NK_F32 ? nk_contig3_quad_ok<float>(g.h) : nk_contig3_quad_ok<double>(g.h)) ? 1 : 0;
 }
 

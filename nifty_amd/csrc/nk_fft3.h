@@ -407,7 +407,8 @@ NK_HD void nk_mid_body(Exec& ex, const NkPassM& pm, const NkFuse& f, int64_t v0,
     ex.phase([&](int tid, RG& rg) {
       const int t = tid % TILE, pp = tid / TILE;
       nk_stage_compute<T, SC, LS, TWC>(rg.v, pp, tw);
-      constexpr int R = SC::radix(LS), Q = E / R;
+      constexpr int R = SC::radix(LS);
+      [[maybe_unused]] constexpr int Q = E / R;
       const T sg = (T)p.g.sign, ms = (T)pm.mid_scale;
       if constexpr (MF) {
         // m(a, b, c) for the real part, m(-a, -b, -c) for the imaginary part: 64-byte pieces of the user's field.
