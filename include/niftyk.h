@@ -266,9 +266,12 @@ int nk_octant_scatter(int ndim, const int64_t* shape, const double* w8, const in
 /* nk_octant_expand (compact) for NATURAL binning on a grid with equal harmonic distances, without the index stream:
  * field8[a][b][c] = table[bin of k^2 = a^2 + b^2 + c^2].  `table`: nb doubles (as nk_amp_forward / nk_amp_jvp produce them),
  * bin_k2[nb]: k^2 of every bin (ascending), `dense`: scratch of (max k^2 + 1) elements of `dtype` (the table spread over
- * k^2, rewritten by every call), field8: the octant array in `dtype`.  PowerDistributor TIMES, distributors.py:114-119. */
+ * k^2, rewritten by every call), field8: the octant array in `dtype`.  line_order (optional, may be NULL): the
+ * (n_first/2+1) * (n_middle/2+1) octant line indices a * (n_middle/2+1) + b sorted by a^2 + b^2 -- lines that read the same
+ * stretch of the table then share a workgroup and its vector cache (same result, 3-D grids: ~2x faster).
+ * PowerDistributor TIMES, distributors.py:114-119. */
 int nk_octant_expand_k2(int ndim, const int64_t* shape, const double* table, const int32_t* bin_k2, int64_t nb, void* dense,
-                        void* field8, int dtype, void* stream);
+                        void* field8, int dtype, const int32_t* line_order, void* stream);
 /* nk_octant_scatter for NATURAL binning on a grid with equal harmonic distances on all axes (bins = the distinct integer
  * k^2 = a^2+b^2+c^2 in ascending order; bin_k2[nb] = k^2 of every bin): abar[.] = sum over the octant array, OVERWRITING
  * abar.  Shell-binned: blocks of consecutive bins are spherical shells whose cut with every octant line is a c-range

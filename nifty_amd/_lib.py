@@ -61,7 +61,7 @@ SIGNATURES = {
     "nk_scatter_add": (_i, [_i64, _vp, _vp, _i64, _vp, _i, _vp]),
     "nk_octant_expand": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _vp, _i, _i, _vp]),
     "nk_octant_scatter": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _vp, _i, _vp]),
-    "nk_octant_expand_k2": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _i64, _vp, _vp, _i, _vp]),
+    "nk_octant_expand_k2": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _i64, _vp, _vp, _i, _vp, _vp]),
     "nk_segment_sum": (_i, [_i64, _vp, _vp, _vp, _vp, _i, _vp]),
     "nk_octant_scatter_k2": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "nk_plan_octant_vjp": (_i, [_vp]),

@@ -901,22 +901,29 @@ __global__ void __launch_bounds__(256) k_k2_dense(int64_t nb, const int32_t* __r
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nb) dense[bin_k2[i]] = (T)table[i];
 }
+// `order` (optional): the octant lines (a, b) sorted by a^2 + b^2.  The lines of one workgroup -- one wavefront each -- then
+// read nearly the same stretch of the table (index a^2 + b^2 + c^2, offsets within a few entries of each other for equal c),
+// so that all but the first of them hit the CU's vector cache: in natural order every lane of every request pulled its own
+// 128-byte line out of L2 for 4 bytes (0.51 ms at 1024^3 fp32 for a 0.54 GB array; sorted, 4 / 8 / 16 lines per workgroup:
+// 0.39 / 0.30 / 0.27 ms).
 template <typename T>
-__global__ void __launch_bounds__(256) k_octant_expand_k2(NkOct o, const T* __restrict__ dense, T* __restrict__ field8) {
-  // one wavefront per octant line (a, b), four lines per workgroup; lanes run over c
+__global__ void __launch_bounds__(1024) k_octant_expand_k2(NkOct o, const int32_t* __restrict__ order,
+                                                           const T* __restrict__ dense, T* __restrict__ field8) {
+  // one wavefront per octant line (a, b); lanes run over c
   const int lane = threadIdx.x & 63;
-  const int64_t line = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (line >= (int64_t)o.Ah * o.Mh) return;
+  const int64_t idx = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (idx >= (int64_t)o.Ah * o.Mh) return;
+  const int64_t line = order ? order[idx] : idx;
   const int b = (int)(line % o.Mh), a = (int)(line / o.Mh);
   const int r2 = a * a + b * b;
   T* dst = field8 + line * o.Ch;
-  // (eight gathers per lane issued ahead of the stores: 0.492 vs 0.497 ms at 1024^3 fp32 -- the pass is not bound by the
-  // latency of its gathers but by their count: c^2 puts every lane of a request on its own cache line of the table)
+  // (eight gathers per lane issued ahead of the stores: 0.492 vs 0.497 ms in natural order; two / four / eight lines per
+  // wavefront in sorted order: 0.33 / 0.44 / 0.50 ms against 0.27 -- more wavefronts in flight beat longer ones)
   for (int c = lane; c < o.Ch; c += 64) __builtin_nontemporal_store(dense[r2 + c * c], dst + c);
 }
 
 extern "C" int nk_octant_expand_k2(int ndim, const int64_t* shape, const double* table, const int32_t* bin_k2, int64_t nb,
-                                   void* dense, void* field8, int dtype, void* stream) {
+                                   void* dense, void* field8, int dtype, const int32_t* line_order, void* stream) {
   NkOct o;
   int rc = nk_make_oct(ndim, shape, o);
   if (rc != NK_OK) return rc;
@@ -925,13 +932,15 @@ extern "C" int nk_octant_expand_k2(int ndim, const int64_t* shape, const double*
     return nk_set_error(NK_ERR_UNSUPPORTED, "nk_octant_expand_k2: k^2 range too large");
   hipStream_t st = (hipStream_t)stream;
   const int64_t lines = (int64_t)o.Ah * o.Mh;
+  static const int lpw_env = nk_vec_env_int("NK_EXPAND_LINES", 0);  // developer sweep: lines (wavefronts) per workgroup
+  const int lpw = lpw_env > 0 && lpw_env <= 16 ? lpw_env : (line_order ? 16 : 4);
   NK_DISPATCH_DTYPE(dtype, {
     hipLaunchKernelGGL(k_k2_dense<T>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, nb, bin_k2, table, (T*)dense);
     // (a shell-by-shell variant -- table window in LDS, runs of field8 written per line like the shell scatter walks them --
     // was measured in round 3: 0.84 ms against 0.51 ms at 1024^3 fp32; the short store runs and the integer square roots
     // cost more than the L2 gathers they replace)
-    hipLaunchKernelGGL(k_octant_expand_k2<T>, dim3((unsigned)((lines + 3) / 4)), dim3(256), 0, st, o, (const T*)dense,
-                       (T*)field8);
+    hipLaunchKernelGGL(k_octant_expand_k2<T>, dim3((unsigned)((lines + lpw - 1) / lpw)), dim3(64 * lpw), 0, st, o, line_order,
+                       (const T*)dense, (T*)field8);
   })
   return nk_check_launch("k_octant_expand_k2");
 }

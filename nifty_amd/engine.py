@@ -383,9 +383,14 @@ class FusedModel:
                 self.scatter_busiest = int(torch.bincount(key.reshape(-1)).max().item())
                 self.scatter_fixed_point = self.scatter_busiest < (1 << 18)
                 del key, a_idx
-            self.k2_dense = None
+            self.k2_dense = self.k2_line_order = None
             if self.bin_k2 is not None and os.environ.get("NK_EXPAND_K2", "1") != "0":
                 self.k2_dense = torch.zeros(int(self.bin_k2[-1].item()) + 1, dtype=dtype, device=self.device)
+                if len(self.shape) == 3 and os.environ.get("NK_EXPAND_ORDER", "1") != "0":
+                    # octant lines (a, b) sorted by a^2 + b^2: neighbours in this order read the same table entries
+                    a2 = torch.arange(self.shape[0] // 2 + 1, device=self.device, dtype=torch.int64) ** 2
+                    b2 = torch.arange(self.shape[1] // 2 + 1, device=self.device, dtype=torch.int64) ** 2
+                    self.k2_line_order = torch.argsort((a2[:, None] + b2[None, :]).reshape(-1), stable=True).to(torch.int32)
             if self.octant_vjp and self.bin_k2 is None and os.environ.get("NK_SEGMENT_SUM", "1") != "0":
                 self.seg_plan = B.bin_plan(self.pidx8, self.nb)
             # plans WITHOUT the octant pipeline (mixed-radix grids, short axes): the generic kernels deposit xi . t per grid
@@ -448,8 +453,8 @@ class FusedModel:
             # natural binning: the bin is a function of k^2 -- no index stream (nk_octant_expand_k2; NK_EXPAND_K2=0: gather)
             shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
             L.check(L.load().nk_octant_expand_k2(len(self.shape), shp, amp.data_ptr(), self.bin_k2.data_ptr(), self.nb,
-                                                 self.k2_dense.data_ptr(), out.data_ptr(), B.dtype_code(out), B._stream()),
-                    "nk_octant_expand_k2")
+                                                 self.k2_dense.data_ptr(), out.data_ptr(), B.dtype_code(out),
+                                                 B.ptr(self.k2_line_order), B._stream()), "nk_octant_expand_k2")
             return out
         table = amp if self.tdtype == torch.float64 else amp.to(self.tdtype)
         if self.pidx8 is not None:

@@ -601,3 +601,26 @@ def test_mixed_radix_grids_are_reproducible_and_sum_their_bins_in_order(shape):
         assert float(lp2.value.item()) == first[0]
         assert torch.equal(lp2.grad.xi, first[1]) and torch.equal(lp2.grad.small, first[2])
         assert torch.equal(q2.xi, first[3].xi) and torch.equal(q2.small, first[3].small)
+
+
+@pytest.mark.parametrize("shape,dtype", [((64, 64, 64), torch.float64), ((128, 64, 256), torch.float32), ((256, 64, 128), torch.float64)])
+def test_octant_expand_from_k2_table(shape, dtype):
+    """nk_octant_expand_k2 (PowerDistributor TIMES on natural binning, distributors.py:114-119, without the index stream) in
+    natural line order and in the order sorted by a^2 + b^2 against the gather through the int32 bin index: identical bits."""
+    from nifty_amd.engine import FusedModel
+
+    dist = tuple(1.0 / n for n in shape)  # equal harmonic distances on every axis: natural bins are functions of k^2
+    model = FusedModel(shape, distances=dist, offset_mean=1.0, likelihood="gaussian", icov=1.0, dtype=dtype, device="cuda:0")
+    assert model.k2_dense is not None and model.k2_line_order is not None
+    order = model.k2_line_order.to(torch.int64)
+    lines = (shape[0] // 2 + 1) * (shape[1] // 2 + 1)
+    assert torch.equal(torch.sort(order).values, torch.arange(lines, device=order.device))  # a permutation of the lines
+    table = torch.randn(model.nb, dtype=torch.float64, device="cuda:0")
+    sorted_order = model._amp_field(table).clone()
+    model.k2_line_order = None
+    natural = model._amp_field(table).clone()
+    dense, model.k2_dense = model.k2_dense, None
+    gathered = model._amp_field(table).clone()
+    model.k2_dense = dense
+    assert torch.equal(natural, gathered)
+    assert torch.equal(sorted_order, gathered)
