@@ -883,9 +883,11 @@ extern "C" int nk_octant_expand(int ndim, const int64_t* shape, const void* tabl
 
 __device__ __forceinline__ int nk_isqrt_ceil(int x) {  // smallest n >= 0 with n*n >= x (x < 2^24)
   if (x <= 0) return 0;
+  // sqrtf of an integer below 2^24 is off by less than one ulp: the candidate is right or off by one, one step each way
+  // settles it (no loops: the shell kernels call this twice per octant line)
   int n = (int)ceilf(sqrtf((float)x));
-  while (n * n < x) ++n;
-  while (n > 0 && (n - 1) * (n - 1) >= x) --n;
+  n += (n * n < x) ? 1 : 0;
+  n -= (n > 0 && (n - 1) * (n - 1) >= x) ? 1 : 0;
   return n;
 }
 
@@ -1040,6 +1042,14 @@ __global__ void __launch_bounds__(256)
 // the relative error of a bin sum is ~1e-14 * (max |w8| / typical |w8| of the bin) -- the price: bins whose contributions
 // are many orders of magnitude below the largest one of the whole grid lose relative (not absolute) accuracy.
 // The floating-point-atomic kernel above stays for callers without a scale (w8max == NULL).
+// x rounded to the nearest integer (ties to even, like __double2ll_rn) for |x| < 2^51, as two's complement: adding
+// 1.5 * 2^52 leaves the integer in the low mantissa bits -- one fp64 add and one 64-bit subtract instead of the eight
+// fp64-rate instructions of the library conversion (the scaled octant sums are below 2^45 by construction)
+__device__ __forceinline__ unsigned long long nk_fixed_rn(double x) {
+  const double magic = 6755399441055744.0;
+  return (unsigned long long)(__double_as_longlong(x + magic) - __double_as_longlong(magic));
+}
+
 __global__ void __launch_bounds__(256)
     k_octant_scatter_k2_fx(NkOct o, const double* __restrict__ w8, const int32_t* __restrict__ pidx,
                            const int32_t* __restrict__ bin_k2, int nb, int64_t pstride, double* __restrict__ partial,
@@ -1078,30 +1088,37 @@ __global__ void __launch_bounds__(256)
       const int32_t* pl[NU];
       double v[NU];
       int32_t pb[NU];
+      // rows of line b0 once, the NU - 1 others of the trip by adding the row steps (wave-uniform) -- a 64-bit product per
+      // line and array otherwise; likewise b^2 -> (b + NG)^2
+      const double* wl0 = w8 + ((int64_t)a * o.Mh + b0) * o.Ch;
+      const int32_t* pl0 = pidx + ((int64_t)a * o.M + b0) * o.NL;
+      const int64_t wstep = (int64_t)NG * o.Ch, pstep = (int64_t)NG * o.NL;
+      int r2 = ra + b0 * b0, dr2 = 2 * NG * b0 + NG * NG;  // r2(b + NG) = r2(b) + 2 NG b + NG^2
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         const int b = b0 + u * NG;
-        const int r2 = ra + b * b;
         const bool on = b < b_hi;
         cc[u] = nk_isqrt_ceil(klo - r2) + l16;
         ce[u] = on ? (last ? o.Ch : min(o.Ch, nk_isqrt_ceil(khi - r2))) : 0;
-        wl[u] = w8 + ((int64_t)a * o.Mh + b) * o.Ch;
-        pl[u] = pidx + ((int64_t)a * o.M + b) * o.NL;
+        wl[u] = wl0 + u * wstep;
+        pl[u] = pl0 + u * pstep;
         const bool in = cc[u] < ce[u];
         v[u] = in ? wl[u][cc[u]] : 0.0;
         pb[u] = in ? pl[u][cc[u]] : bin0;
+        r2 += dr2;
+        dr2 += 2 * NG * NG;
       }
 #pragma unroll
       for (int u = 0; u < NU; ++u)
         if (cc[u] < ce[u]) {
-          atomicAdd(&acc[pb[u] - bin0], (unsigned long long)__double2ll_rn(v[u] * scale));
+          atomicAdd(&acc[pb[u] - bin0], nk_fixed_rn(v[u] * scale));
           ++mine;
         }
       // rare: runs longer than 16 points
 #pragma unroll
       for (int u = 0; u < NU; ++u)
         for (int c = cc[u] + 16; c < ce[u]; c += 16) {
-          atomicAdd(&acc[pl[u][c] - bin0], (unsigned long long)__double2ll_rn(wl[u][c] * scale));
+          atomicAdd(&acc[pl[u][c] - bin0], nk_fixed_rn(wl[u][c] * scale));
           ++mine;
         }
     }
