@@ -16,9 +16,10 @@ import pickle
 import numpy as np
 
 from .energy_operators import GaussianEnergy, StandardHamiltonian
-from .field import MultiField
+from .field import Field, MultiField
 from .minimization import DescentMinimizer, Energy
-from .operators import EndomorphicOperator, Linearization, SamplingEnabler, SandwichOperator, ScalingOperator, makeDomain
+from .operators import (EndomorphicOperator, Linearization, Operator, SamplingEnabler, SandwichOperator, ScalingOperator,
+                        makeDomain)
 from .parallel import SamplePlan, get_MPI_params_from_comm, shareRange
 
 
@@ -194,6 +195,77 @@ class SampleListBase:
 
     def save(self, file_name_base, overwrite=False):
         raise NotImplementedError
+
+    def save_to_hdf5(self, file_name, op=None, samples=False, mean=False, std=False, overwrite=False):
+        """Export to one HDF5 file (sample_list.py:104-184): group ``samples`` with one entry ``"0"``, ``"1"``, ... per sample
+        of op(sample) in global order, group ``stats`` with ``mean`` and / or ``standard deviation``; a MultiField entry is
+        a sub-group with one data set per key.  File attributes: ``nifty domain`` (and for an Operator `op` its string
+        representation, domain and target).  Rank 0 writes; every rank takes part in the sample hand-over.  `h5py` is an
+        optional dependency imported here, as in the reference: without it this raises ImportError."""
+        import h5py
+
+        writer = self._rank == 0
+        if os.path.isfile(file_name):
+            if not overwrite:
+                raise RuntimeError(f"File {file_name} already exists. Delete it or use `overwrite=True`")
+            if writer:
+                os.remove(file_name)
+        if not (samples or mean or std):
+            raise ValueError("Neither samples nor mean nor standard deviation shall be written.")
+        out = h5py.File(file_name, "w") if writer else _NullGroup()
+        if isinstance(op, Operator):
+            out.attrs["nifty operator string representation"] = str(op)
+            out.attrs["nifty operator domain"] = repr(op.domain)
+            out.attrs["nifty operator target"] = repr(op.target)
+            out.attrs["nifty domain"] = repr(op.target)
+        else:
+            out.attrs["nifty domain"] = repr(self.domain)
+        if samples:
+            group = out.create_group("samples")
+            for number, sample in enumerate(self.iterator(op)):
+                _write_hdf5_entry(group, str(number), sample)
+        if mean or std:
+            group = out.create_group("stats")
+            if std:
+                mu, variance = self.sample_stat(op)
+                if mean:
+                    _write_hdf5_entry(group, "mean", mu)
+                _write_hdf5_entry(group, "standard deviation", variance.sqrt())
+            else:
+                _write_hdf5_entry(group, "mean", self.average(op))
+        out.close()
+        if self._comm is not None:
+            self._comm.barrier()
+
+
+class _NullGroup:
+    """What a rank that does not write holds instead of the h5py file: accepts everything, stores nothing."""
+
+    def __init__(self):
+        self.attrs = {}
+
+    def create_group(self, name):
+        return self
+
+    def create_dataset(self, name, data=None):
+        return None
+
+    def close(self):
+        pass
+
+
+def _write_hdf5_entry(group, name, obj):
+    """A Field as a data set, a MultiField as a sub-group of data sets (reference sample_list.py:632-642)."""
+    if not isinstance(name, str):
+        raise TypeError("HDF5 entry names are strings")
+    if isinstance(obj, MultiField):
+        sub = group.create_group(name)
+        for key, fld in obj.items():
+            _write_hdf5_entry(sub, key, fld)
+    elif isinstance(obj, Field):
+        group.create_dataset(name, data=obj.asnumpy())
+    else:
+        raise TypeError("only Fields and MultiFields can be written")
 
 
 class ResidualSampleList(SampleListBase):

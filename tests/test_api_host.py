@@ -364,6 +364,75 @@ def test_minisanity_table(device_id):
         ift.extra.minisanity(lh, [x])
 
 
+class _MemoryH5Group(dict):
+    """In-memory stand-in for an h5py group / file (the image has no h5py): records what save_to_hdf5 writes."""
+
+    def __init__(self):
+        super().__init__()
+        self.attrs, self.closed = {}, False
+
+    def create_group(self, name):
+        assert name not in self
+        self[name] = _MemoryH5Group()
+        return self[name]
+
+    def create_dataset(self, name, data=None):
+        assert name not in self
+        self[name] = np.array(data)
+
+    def close(self):
+        self.closed = True
+
+
+def test_sample_list_hdf5_export(tmp_path, monkeypatch):
+    """SampleListBase.save_to_hdf5 (sample_list.py:104-184): file layout (samples/0.., stats/mean, stats/standard deviation,
+    MultiFields as sub-groups, domain attribute), the reference's argument checks, and ImportError without h5py."""
+    import sys
+    import types
+
+    z = gl.load("model_g1d")
+    m, cfm, cf, lh = build(z, -1)
+    x = ift.MultiField.from_raw(cf.domain, gl.latent(z, "x"), -1)
+    res = [ift.MultiField.from_raw(cf.domain, gl.latent(z, f"residual{i}"), -1) for i in range(2)]
+    sl = ift.ResidualSampleList(x, res, [False, False])
+    name = str(tmp_path / "samples.h5")
+    if "h5py" not in sys.modules:
+        try:
+            import h5py  # noqa: F401
+        except ImportError:
+            with pytest.raises(ImportError):
+                sl.save_to_hdf5(name, samples=True)
+    files = {}
+    fake = types.ModuleType("h5py")
+    fake.File = lambda fn, mode: files.setdefault(fn, _MemoryH5Group())
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    with pytest.raises(ValueError):
+        sl.save_to_hdf5(name)
+    sl.save_to_hdf5(name, samples=True, mean=True, std=True)
+    f = files[name]
+    assert f.closed and f.attrs["nifty domain"] == repr(sl.domain)
+    assert sorted(f) == ["samples", "stats"] and sorted(f["samples"]) == ["0", "1"]
+    assert sorted(f["stats"]) == ["mean", "standard deviation"]
+    samples = list(sl.iterator())
+    mean, var = sl.sample_stat()
+    for key in cf.domain.keys():
+        np.testing.assert_array_equal(f["samples"]["1"][key], samples[1][key].asnumpy())
+        np.testing.assert_allclose(f["stats"]["mean"][key], mean[key].asnumpy(), rtol=1e-15)
+        np.testing.assert_allclose(f["stats"]["standard deviation"][key], np.sqrt(var[key].asnumpy()), rtol=1e-15)
+    # through an operator: Field entries are data sets, the operator is described in the attributes
+    files.clear()
+    sl.save_to_hdf5(name, op=cf, mean=True)
+    f = files[name]
+    assert sorted(f) == ["stats"] and list(f["stats"]) == ["mean"]
+    np.testing.assert_allclose(f["stats"]["mean"], sl.average(cf).asnumpy(), rtol=1e-15)
+    assert f.attrs["nifty domain"] == repr(cf.target) and f.attrs["nifty operator domain"] == repr(cf.domain)
+    # an existing file is only replaced on request
+    open(name, "w").close()
+    with pytest.raises(RuntimeError):
+        sl.save_to_hdf5(name, samples=True)
+    sl.save_to_hdf5(name, samples=True, overwrite=True)
+
+
 def _product_cf():
     cfm = ift.CorrelatedFieldMaker("p")
     cfm.add_fluctuations(ift.RGSpace((16,), (0.5,)), (1.0, 5e-1), (1.0, 2e-1), (5e-1, 5e-2), (-3.0, 2e-1), prefix="t")
