@@ -373,6 +373,45 @@ print("RESULT", repr(float(kl.value)), repr(float(mean.xi.double().sum())), repr
     assert a == b
 
 
+def test_launch_variants_of_the_metric_agree():
+    """One metric application of a 3-D model through every selectable variant of its kernels -- QUAD / row-tile launches of the
+    contiguous first pass (NK_CONTIG_QUAD 1 / 0 / 2: library statics, hence child processes), `da` expanded in sorted or
+    natural line order or gathered in the prologue (class 7) -- gives the same bits for the launch shapes and the line
+    orders, and agrees to rounding where the arithmetic differs (the gather multiplies by the fp32-rounded table entry like
+    the expansion does: same bits too)."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from nifty_amd import random
+from nifty_amd.engine import FusedModel, LatentVec
+model = FusedModel((64, 128, 128), offset_mean=2.0, likelihood="gaussian", icov=100.0, dtype=torch.float32, device="cuda:0")
+random.push_sseq_from_seed(5)
+truth = model.draw_prior()
+model.set_data(model.signal(truth), 100.0)
+x, d = 0.1 * model.draw_prior(), model.draw_prior()
+lp = model.linearize(x)
+q = model.metric(lp, d)
+print("RESULT", repr(float(lp.value.item())), repr(float(q.xi.double().sum())), repr(float((q.xi.double() ** 2).sum())),
+      repr(float(q.small.sum())))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(**env):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
+                             timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1]
+        return [float(v) for v in line.split()[1:]]
+
+    base = run()
+    for env in (dict(NK_CONTIG_QUAD="0"), dict(NK_CONTIG_QUAD="2"), dict(NK_EXPAND_ORDER="0"), dict(NK_EXPAND_K2="0"),
+                dict(NK_DA_GATHER="1")):
+        assert run(**env) == base, env
+
+
 @pytest.mark.parametrize("lanes", [1, 4, 16, 64])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_csr_rowsum_against_scipy_and_bitwise_repeatable(lanes, dtype):
