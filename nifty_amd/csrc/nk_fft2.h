@@ -1308,7 +1308,7 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
           if (lane < 2)
             nk_final_coeff<T, NL, NH, EC, false, MODE>(f, c, gp, pre, pim, sg, lane ? NL / 2 : 0, hv, afline, w8line, acc, wmax);
           if constexpr (EC == 3 && MODE > 0) {
-            constexpr int U = NK_LH_UNROLL;
+            constexpr int U = sizeof(T) == 8 ? (NK_LH_UNROLL + 1) / 2 : NK_LH_UNROLL;  // fp64: 168 VGPRs + 116 B / lane of spills with four
             for (int k2 = 1 + lane; k2 < NL / 2; k2 += U * tps) {
               int ks[U], n_on = 0;
 #pragma unroll

@@ -127,7 +127,7 @@ NK_HD void nk_contig3_body(Exec& ex, const NkPass3& p, const NkFuse& f, int64_t 
       // ONE branch around the whole row, and all E elements' operand loads ahead of the first use (nk_oct_load / _apply)
       if (line >= 0) {
         // class 8 carries five operand pairs and fp64 temporaries per element: two half batches keep it at 4 waves/SIMD
-        constexpr int NB = PC == 8 ? NK_OCT8_BATCHES : 1, EB = E / NB;
+        constexpr int NB = PC == 8 ? NK_OCT8_BATCHES * (sizeof(T) == 8 ? 2 : 1) : 1, EB = E / NB;  // fp64: 214 VGPRs with two
         double beta = 0.0;
         if constexpr (PC == 8) beta = nk_oct_beta(f);
 #pragma unroll
