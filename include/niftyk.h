@@ -162,6 +162,15 @@ int nk_plan_pipe_ok(const nk_plan* plan, int chunks);
 int nk_plan_sandwich(const nk_plan* plan);
 int nk_hartley_sandwich(const nk_plan* plan, const nk_fuse* fuse, double scale_first, int convention, void* workspace,
                         void* stream);
+/* Two sandwiches that ACCUMULATE INTO THE SAME `out` (two samples of a KL metric, SampledKLEnergyClass.apply_metric sums
+ * them, kl_energies.py:346-360) in one call: the first four passes of A and of B run one after the other on their own
+ * workspaces, the two final passes share ONE launch in which every workgroup finishes its lines for A and then for B --
+ * B's read-modify-write of `out` meets A's lines in L2 instead of HBM.  Same arithmetic, same bits as
+ * nk_hartley_sandwich(A) followed by nk_hartley_sandwich(B).  Requirements: 3-D plan, both epilogues VJP with octant
+ * amplitude fields (field_octant, afield), fuse_b->accumulate != 0, fuse_a->out == fuse_b->out, separate w8 (and w8max, value)
+ * areas, the same mul_scalar, no slab pipelining, workspace_a != workspace_b (each nk_plan_workspace_bytes). */
+int nk_hartley_sandwich_pair(const nk_plan* plan, const nk_fuse* fuse_a, const nk_fuse* fuse_b, double scale_first,
+                             int convention, void* workspace_a, void* workspace_b, void* stream);
 /* complex-to-complex: in/out interleaved (re,im) of the plan dtype; inverse != 0 uses exp(+i..);
  * result is multiplied by `scale` (pass 1/N for numpy-style ifftn).  in == out allowed. */
 int nk_fftn(const nk_plan* plan, const void* in, void* out, int inverse, double scale, void* workspace,

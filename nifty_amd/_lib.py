@@ -47,6 +47,7 @@ SIGNATURES = {
     "nk_plan_sandwich": (_i, [_vp]),
     "nk_plan_pipe_ok": (_i, [_vp, _i]),
     "nk_hartley_sandwich": (_i, [_vp, ctypes.POINTER(Fuse), _d, _i, _vp, _vp]),
+    "nk_hartley_sandwich_pair": (_i, [_vp, ctypes.POINTER(Fuse), ctypes.POINTER(Fuse), _d, _i, _vp, _vp, _vp]),
     "nk_fftn": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp]),
     "nk_profile_enable": (_i, [_i]),
     "nk_profile_collect": (_i, [_vp, _vp]),

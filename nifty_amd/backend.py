@@ -227,6 +227,16 @@ def hartley_sandwich(plan, fuse, scale_first):
                                          plan.workspace.data_ptr(), _stream()), "nk_hartley_sandwich")
 
 
+def hartley_sandwich_pair(plan, fuse_a, fuse_b, scale_first, workspace_b):
+    """Two sandwiches accumulating into one output with their final passes in ONE launch (nk_hartley_sandwich_pair): same
+    bits as two hartley_sandwich calls; `workspace_b` is a second workspace of the plan's size for sample B."""
+    if plan.device.index != _current_device():
+        _wrong_device(plan.device.index)
+    L.check(L.load().nk_hartley_sandwich_pair(plan.handle, ctypes.byref(fuse_a), ctypes.byref(fuse_b), float(scale_first),
+                                              _convention(), plan.workspace.data_ptr(), workspace_b.data_ptr(), _stream()),
+            "nk_hartley_sandwich_pair")
+
+
 def fftn(x, ndim=None, inverse=False, scale=1.0):
     """c2c FFT over the last ``ndim`` axes of a complex tensor (reference ducc_dispatch.fftn / ifftn)."""
     _require_device(x)

@@ -270,6 +270,68 @@ static int nk_dispatch_final3(int nl, const NkPassF& pf, const NkFuse& f, const 
   return nk_set_error(NK_ERR_UNSUPPORTED, "no fast final pass for this length");
 }
 
+// TWO sandwich final passes (scatter class, row-mirror pairing) in ONE launch: every workgroup runs the final pass of its
+// line pairs for sample A and then for sample B, whose epilogue accumulates onto the output lines the same workgroup has
+// just written -- B's read of `out` and A's write of it stay in L2 instead of costing an HBM read and write of the whole
+// array per extra sample (nk_hartley_sandwich_pair).  Two inlined bodies, no loop around the phases.
+template <typename T, int NL>
+__global__ void __launch_bounds__((FinalTile<T, NL, 2, 2>::THREADS), (FinalTile<T, NL, 2, 2>::THREADS > 256 ? 1 : 3))
+    k2_final2(NkPassF p, NkFuse fa, NkFuse fb, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ worka,
+              const C2<T>* __restrict__ workb) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  DeviceExec<T, SchedF<T, NL>::E> ex;
+  const int64_t blk = (int64_t)blockIdx.x;
+  fa.pipe_chunks = -1;  // A's output lines are read again by B below: keep them in the cache hierarchy (FinalCt::keep)
+  {
+    double acc = 0.0;
+    float wmax = 0.0f;
+    nk_final_body<T, NL, FinalTile<T, NL, 2, 2>::TILE, true, 2, 1>(ex, p, fa, blk, (T*)smem, tw, worka, &acc, &wmax);
+    nk_flush_energy(fa, acc, smem);
+    nk_flush_wmax(fa, wmax);
+  }
+  __syncthreads();  // A's output lines are written (and visible to this workgroup) before B's epilogue reads them
+  {
+    double acc = 0.0;
+    float wmax = 0.0f;
+    nk_final_body<T, NL, FinalTile<T, NL, 2, 2>::TILE, true, 2, 1>(ex, p, fb, blk, (T*)smem, tw, workb, &acc, &wmax);
+    nk_flush_energy(fb, acc, smem);
+    nk_flush_wmax(fb, wmax);
+  }
+}
+
+template <typename T, int NL>
+static int nk_launch_final_pair(NkPassF pf, const NkFuse& fa, const NkFuse& fb, const C2<T>* tw, const C2<T>* worka,
+                                const C2<T>* workb, hipStream_t st) {
+  using CT = FinalTile<T, NL, 2, 2>;
+  auto kern = k2_final2<T, NL>;
+  static unsigned long long attr_mask = 0;  // per-device attribute
+  if (CT::LDS_BYTES > 64 * 1024 && nk_first_on_device(attr_mask)) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CT::LDS_BYTES);
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k2_final2)");
+  }
+  pf.tiles_per_a = (pf.A > 1 && CT::TILE >= 2) ? (pf.M / 2 + 1 + CT::TILE / 2 - 1) / (CT::TILE / 2) : (pf.M + CT::TILE - 1) / CT::TILE;
+  pf.blk0 = 0;
+  const int64_t blocks = (int64_t)pf.g.batch * (pf.A / 2 + 1) * pf.tiles_per_a;
+  const int64_t waves = blocks * ((CT::THREADS + 63) / 64);
+  if ((fa.value_slots > 0 && waves > fa.value_slots) || (fb.value_slots > 0 && waves > fb.value_slots))
+    return nk_set_error(NK_ERR_RUNTIME, "final pass: more wavefronts than reduction slots (nk_value_slot_count)");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CT::THREADS), CT::LDS_BYTES, st, pf, fa, fb, tw, worka, workb);
+  return nk_check_launch("k2_final2");
+}
+
+template <typename T>
+static int nk_dispatch_final_pair(int nl, const NkPassF& pf, const NkFuse& fa, const NkFuse& fb, const C2<T>* tw,
+                                  const C2<T>* worka, const C2<T>* workb, hipStream_t st) {
+  switch (nl) {
+#define NK_CASE(NN) \
+  case NN:          \
+    return nk_launch_final_pair<T, NN>(pf, fa, fb, tw, worka, workb, st);
+    NK_FAST_SIZES(NK_CASE)
+#undef NK_CASE
+  }
+  return nk_set_error(NK_ERR_UNSUPPORTED, "no fast final pass for this length");
+}
+
 template <typename T>
 static int nk_dispatch_final(int nl, const NkPassF& pf, const NkFuse& f, const C2<T>* tw, const C2<T>* work,
                              hipStream_t st) {
@@ -1150,11 +1212,13 @@ extern "C" int nk_plan_pipe_ok(const nk_plan* P, int chunks) {
 }
 
 template <typename T>
-static int nk_run_sandwich(const nk_plan* P, const NkFuse& f, double scale_first, int convention, void* workspace, hipStream_t st) {
+static int nk_run_sandwich(const nk_plan* P, const NkFuse& f, double scale_first, int convention, void* workspace, hipStream_t st,
+                           bool with_final = true, NkPipe3* q_out = nullptr) {
   const NkHostPlan& hp = P->hp;
   const int sign = convention == NK_HARTLEY_CANONICAL ? -1 : 1;
   static const int work_pad = nk_env_int("NK_WORK_PAD", 2080);
   const NkPipe3 q = nk_pipe3_setup<T>(hp, sign, work_pad, scale_first * (f.mul_scalar != 0.0 ? f.mul_scalar : 1.0));
+  if (q_out) *q_out = q;
   if (nk_pipe3_work_elems(hp.g, nk_pipe3_colpad<T>(), work_pad) * sizeof(C2<T>) > hp.work_bytes)
     return nk_set_error(NK_ERR_RUNTIME, "nk_hartley_sandwich: plan workspace too small");
   if (128 * (q.ss > q.pm.s.inner ? q.ss : q.pm.s.inner) * (int64_t)sizeof(C2<T>) >= ((int64_t)1 << 32))
@@ -1206,6 +1270,7 @@ static int nk_run_sandwich(const nk_plan* P, const NkFuse& f, double scale_first
     rc = nk_dispatch_strided<T, 0>(hp.g.nm, q.s2, f, (const C2<T>*)P->d_tw_b, work, (C2<T>*)nullptr, st);
     if (rc != NK_OK) return rc;
   }
+  if (!with_final) return NK_OK;  // nk_hartley_sandwich_pair launches the final passes of two samples together
   ProfScope ps(st, 3, f.pro, f.epi);
   return nk_final_with_slots(hp, workspace, f, st, [&](const NkFuse& f2) {
     if (!C) return nk_dispatch_final3<T>(hp.g.nl, q.pf, f2, (const C2<T>*)P->d_tw_f, (const C2<T>*)work, st);
@@ -1225,8 +1290,7 @@ static int nk_run_sandwich(const nk_plan* P, const NkFuse& f, double scale_first
   });
 }
 
-extern "C" int nk_hartley_sandwich(const nk_plan* P, const nk_fuse* fuse, double scale_first, int convention,
-                                   void* workspace, void* stream) {
+static int nk_sandwich_check(const nk_plan* P, const nk_fuse* fuse, int convention, void* workspace) {
   if (!P || !fuse) return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: null argument");
   if (!fuse->in || !fuse->out || !workspace) return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich: in/out/workspace must be set");
   if (convention != NK_HARTLEY_NON_CANONICAL && convention != NK_HARTLEY_CANONICAL)
@@ -1254,9 +1318,51 @@ extern "C" int nk_hartley_sandwich(const nk_plan* P, const nk_fuse* fuse, double
     if ((int64_t)(g.na / 2 + 1) * (g.nm / 2 + 1) * (g.nl / 2 + 1) >= ((int64_t)1 << 31))
       return nk_set_error(NK_ERR_UNSUPPORTED, "nk_hartley_sandwich: octant field too large (>= 2^31 elements)");
   }
+  return NK_OK;
+}
+
+extern "C" int nk_hartley_sandwich(const nk_plan* P, const nk_fuse* fuse, double scale_first, int convention,
+                                   void* workspace, void* stream) {
+  const int rc = nk_sandwich_check(P, fuse, convention, workspace);
+  if (rc != NK_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (P->hp.dtype == NK_F32) return nk_run_sandwich<float>(P, *fuse, scale_first, convention, workspace, st);
   return nk_run_sandwich<double>(P, *fuse, scale_first, convention, workspace, st);
+}
+
+template <typename T>
+static int nk_run_sandwich_pair(const nk_plan* P, const NkFuse& fa, const NkFuse& fb, double scale_first, int convention,
+                                void* wsa, void* wsb, hipStream_t st) {
+  NkPipe3 q;
+  int rc = nk_run_sandwich<T>(P, fa, scale_first, convention, wsa, st, false, &q);
+  if (rc != NK_OK) return rc;
+  rc = nk_run_sandwich<T>(P, fb, scale_first, convention, wsb, st, false, nullptr);
+  if (rc != NK_OK) return rc;
+  const NkHostPlan& hp = P->hp;
+  ProfScope ps(st, 3, fa.pro, fa.epi);
+  return nk_final_with_slots(hp, wsa, fa, st, [&](const NkFuse& fa2) {
+    return nk_final_with_slots(hp, wsb, fb, st, [&](const NkFuse& fb2) {
+      return nk_dispatch_final_pair<T>(hp.g.nl, q.pf, fa2, fb2, (const C2<T>*)P->d_tw_f, (const C2<T>*)wsa, (const C2<T>*)wsb, st);
+    });
+  });
+}
+
+extern "C" int nk_hartley_sandwich_pair(const nk_plan* P, const nk_fuse* fa, const nk_fuse* fb, double scale_first,
+                                        int convention, void* workspace_a, void* workspace_b, void* stream) {
+  int rc = nk_sandwich_check(P, fa, convention, workspace_a);
+  if (rc != NK_OK) return rc;
+  rc = nk_sandwich_check(P, fb, convention, workspace_b);
+  if (rc != NK_OK) return rc;
+  const bool vjp = fa->epi == NK_EPI_VJP && fb->epi == NK_EPI_VJP && fa->afield && fb->afield && fa->field_octant && fb->field_octant;
+  if (!vjp || P->hp.g.ndim != 3 || fa->pipe_chunks || fb->pipe_chunks || workspace_a == workspace_b)
+    return nk_set_error(NK_ERR_UNSUPPORTED, "nk_hartley_sandwich_pair: two VJP epilogues with octant amplitude fields on a 3-D plan, "
+                                             "two workspaces, no slab pipelining");
+  if (fa->out != fb->out || !fb->accumulate || fa->w8 == fb->w8 || (fa->mul_scalar != fb->mul_scalar))
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich_pair: one shared `out` (B accumulates), separate w8 areas, the same "
+                                         "scalar diagonal");
+  hipStream_t st = (hipStream_t)stream;
+  if (P->hp.dtype == NK_F32) return nk_run_sandwich_pair<float>(P, *fa, *fb, scale_first, convention, workspace_a, workspace_b, st);
+  return nk_run_sandwich_pair<double>(P, *fa, *fb, scale_first, convention, workspace_a, workspace_b, st);
 }
 
 extern "C" int nk_hartley(const nk_plan* P, const void* in, void* out, double scale, int convention, void* workspace,

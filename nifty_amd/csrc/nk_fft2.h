@@ -842,6 +842,7 @@ struct FinalCt {
   const T *mul, *xi, *addend, *af;
   T sc, off, asc;
   bool accum, dot;  // dot: also accumulate sum addend[o] * out[o] (the CG curvature d.(A d) when addend = d)
+  bool keep;        // `out` is read again right away (first sample of a pair launch, k2_final2): plain stores, not streaming ones
 };
 template <typename T, int EC>
 NK_HD FinalCt<T> nk_final_ct(const NkFuse& f) {
@@ -856,6 +857,7 @@ NK_HD FinalCt<T> nk_final_ct(const NkFuse& f) {
   c.asc = (T)f.addend_scale;
   c.accum = f.accumulate != 0;
   c.dot = EC == 2 && f.value != nullptr && f.addend != nullptr;
+  c.keep = f.pipe_chunks < 0;  // host-side field otherwise; k2_final2 marks its first sample with -1
   return c;
 }
 
@@ -913,15 +915,21 @@ NK_HD double nk_final_vjp_apply(const FinalCt<T>& c, const NkVjpOps<T>& v, int64
   }
   T* outk = c.out + ok;
   T* outm = c.out + om;
-  nk_store_stream_s(outk + k2, r[0]);
-  if (BOTH) nk_store_stream_s(outk + k2m, r[2]);
+  auto put = [&](T* p, T val) {
+    if (c.keep)
+      *p = val;
+    else
+      nk_store_stream_s(p, val);
+  };
+  put(outk + k2, r[0]);
+  if (BOTH) put(outk + k2m, r[2]);
   double s = (double)v.x[0] * (double)t[0];
   if (BOTH) s += (double)v.x[2] * (double)t[2];
   if (!self) {
-    nk_store_stream_s(outm + k2m, r[1]);
+    put(outm + k2m, r[1]);
     s += (double)v.x[1] * (double)t[1];
     if (BOTH) {
-      nk_store_stream_s(outm + k2, r[3]);
+      put(outm + k2, r[3]);
       s += (double)v.x[3] * (double)t[3];
     }
   }

@@ -717,6 +717,53 @@ class FusedModel:
             self.counters["transforms"] += 1
         self._finish_metric(lp, avec, out, first, afac)
 
+    def pair_ready(self):
+        """True when two samples' metric applications can share a final-pass launch (lh_metric_accumulate_pair)."""
+        return bool(self.sandwich and self.octant_vjp and self.response is None and self.bin_k2 is not None
+                    and len(self.shape) == 3 and self.const_mid and os.environ.get("NK_PAIR_FINAL", "1") != "0")
+
+    def _pair_buffers(self):
+        """Second set of the per-application scratch arrays (sample B of a pair), allocated on first use."""
+        if getattr(self, "_pair", None) is None:
+            self._pair = dict(damp=torch.empty_like(self.damp), dafield=torch.empty_like(self.dafield),
+                              w8=torch.empty_like(self.w8), w8max=torch.zeros_like(self.w8max),
+                              workspace=torch.empty_like(self.plan.workspace))
+        return self._pair
+
+    def lh_metric_accumulate_pair(self, lpa, lpb, d, out, scale, first):
+        """lh_metric_accumulate(lpa, d, out, scale, first) followed by lh_metric_accumulate(lpb, d, out, scale, False) -- the
+        same bits -- with the two final passes in one launch: sample B's accumulation onto `out` meets sample A's freshly
+        written lines in L2 (nk_hartley_sandwich_pair; one read and one write of `out` less per pair)."""
+        pb = self._pair_buffers()
+        lib = L.load()
+        fuses = []
+        for lp, damp, dafield, w8, w8max, accumulate in ((lpa, self.damp, self.dafield, self.w8, self.w8max, not first),
+                                                        (lpb, pb["damp"], pb["dafield"], pb["w8"], pb["w8max"], True)):
+            L.check(lib.nk_amp_jvp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(), lp.state.data_ptr(),
+                                   d.small.data_ptr(), damp.data_ptr(), B._stream()), "nk_amp_jvp")
+            self._amp_field(damp, out=dafield)
+            f = self._fuse()
+            f.pro, f.in_, f.in2 = L.PRO_AMP_JVP, d.xi.data_ptr(), lp.x.xi.data_ptr()
+            f.pidx, f.amp, f.damp = self.pidx.data_ptr(), lp.amp.data_ptr(), damp.data_ptr()
+            f.afield, f.dafield = B.ptr(lp.afield), dafield.data_ptr()
+            f.mul, f.mul_scalar = B.ptr(lp.mid), lp.mid_scalar
+            f.epi, f.out, f.scale = L.EPI_VJP, out.xi.data_ptr(), self.h_dvol * scale
+            f.xi = lp.x.xi.data_ptr()
+            f.addend, f.addend_scale, f.accumulate = None, 0.0, 1 if accumulate else 0
+            f.abar, f.w8 = self.abar.data_ptr(), w8.data_ptr()
+            if self.scatter_fixed_point:
+                f.w8max = w8max.data_ptr()
+            fuses.append(f)
+        B.hartley_sandwich_pair(self.plan, fuses[0], fuses[1], self.h_dvol, pb["workspace"])
+        self.counters["transforms"] += 4
+        shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
+        for lp, w8, w8max, is_first in ((lpa, self.w8, self.w8max, first), (lpb, pb["w8"], pb["w8max"], False)):
+            L.check(lib.nk_octant_scatter_k2(len(self.shape), shp, w8.data_ptr(), self.pidx.data_ptr(), self.bin_k2.data_ptr(),
+                                             self.nb, self.scatter_scratch.data_ptr(), self.abar.data_ptr(),
+                                             w8max.data_ptr() if self.scatter_fixed_point else 0, B._stream()),
+                    "nk_octant_scatter_k2")
+            self._finish_metric(lp, d, out, is_first, 0.0)
+
     def _finish_metric(self, lp, d, out, first, identity):
         self._amp_vjp(lp)
         if first:
@@ -945,7 +992,17 @@ class FusedKL(Energy):
         out = LatentVec(torch.empty_like(d.xi), None)
         w = 1.0 / self.n_total
         nloc = len(self.lins)
-        for i, lp in enumerate(self.lins):
+        # the MIDDLE samples go two at a time with their final passes in one launch (lh_metric_accumulate_pair: the second
+        # one's accumulation onto `out` stays in L2); the first sample (pending direction update, staged first pass) and the
+        # last one (identity term, curvature dot, staged final pass) keep their own launches
+        paired = m.pair_ready()
+        i = 0
+        while i < nloc:
+            lp = self.lins[i]
+            if paired and 0 < i and i + 1 < nloc - 1:
+                m.lh_metric_accumulate_pair(lp, self.lins[i + 1], d, out, w, False)
+                i += 2
+                continue
             stage = None
             if pipe is not None:
                 stage = (pipe[0], pipe[1] if i == 0 else None, pipe[2] if i == nloc - 1 else None)
@@ -956,6 +1013,7 @@ class FusedKL(Energy):
             m.lh_metric_accumulate(lp, d, out, w, i == 0, identity=nloc * w if last else 0.0,
                                    dot_out=dot_out if last else None, cg_direction=cg_direction if i == 0 else None,
                                    pipe=stage)
+            i += 1
         if nloc == 0:
             out = LatentVec.zeros(m)
         return out

@@ -2,6 +2,7 @@
 vectors generated from the reference.  Tolerance: 1e-5 relative in fp64 is the north-star bar; the
 checks below are far tighter wherever the arithmetic allows (documented per assertion)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -295,3 +296,44 @@ def test_sandwich_engine_vs_oracle(shape, dtype, lh, monkeypatch):
         assert rel(mv_kl, kl_o.apply_metric(v)) < ctol
     # the fused and the separate direction update are the same arithmetic
     assert rel(results[0][0], results[1][0]) < (1e-12 if dtype == torch.float64 else 1e-5)
+
+
+@pytest.mark.parametrize("shape,dtype", [((64, 64, 128), torch.float64), ((64, 128, 128), torch.float32)])
+def test_pair_final_pass_is_bit_identical(shape, dtype):
+    """Two samples' metric applications with their final passes in one launch (nk_hartley_sandwich_pair,
+    FusedModel.lh_metric_accumulate_pair) against the two single applications: the same bits in the xi part, the spectrum
+    part and the octant sums -- as the first two terms of a sum and accumulated onto an existing one; and the KL metric of
+    a sample list (pairs for the middle samples) against the unpaired loop."""
+    from nifty_amd import random
+    from nifty_amd.engine import FusedKL, FusedModel, LatentVec
+
+    model = FusedModel(shape, offset_mean=2.0, likelihood="gaussian", icov=100.0, dtype=dtype, device="cuda:0")
+    random.push_sseq_from_seed(9)
+    try:
+        truth = model.draw_prior()
+        model.set_data(model.signal(truth), 100.0)
+        assert model.pair_ready()
+        xs = [0.1 * model.draw_prior() for _ in range(5)]
+        d = model.draw_prior()
+    finally:
+        random.pop_sseq()
+    lps = [model.linearize(x) for x in xs]
+    for first in (True, False):
+        seq = LatentVec(torch.full_like(d.xi, 0.25), torch.full_like(d.small, 0.5))
+        par = LatentVec(seq.xi.clone(), seq.small.clone())
+        model.lh_metric_accumulate(lps[0], d, seq, 0.125, first)
+        model.lh_metric_accumulate(lps[1], d, seq, 0.125, False)
+        w8_b = model.w8.clone()
+        model.lh_metric_accumulate_pair(lps[0], lps[1], d, par, 0.125, first)
+        assert torch.equal(seq.xi, par.xi) and torch.equal(seq.small, par.small)
+        assert torch.equal(w8_b, model._pair["w8"])
+    # the KL metric over five samples: first and last single (direction update / identity + curvature), the middle ones paired
+    res = [x - xs[0] for x in xs]
+    kl = FusedKL(model, xs[0], res, [False] * 5)
+    paired = kl.apply_metric(d)
+    os.environ["NK_PAIR_FINAL"] = "0"
+    try:
+        single = kl.apply_metric(d)
+    finally:
+        del os.environ["NK_PAIR_FINAL"]
+    assert torch.equal(paired.xi, single.xi) and torch.equal(paired.small, single.small)
