@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 # pass, C final contiguous pass with epilogue) and the five-pass sandwich H D H of a metric application (S1 contiguous
 # first pass with prologue, S2 in-place middle-axis passes, SM fused first-axis pass, then C)
 KERNEL_NAMES = {0: "k_pass1d", 1: "k_passA", 2: "k_passB", 3: "k_passC", 4: "k_passD", 5: "k_passS1", 6: "k_passS2",
-                7: "k_passSM", 8: "k_csr_rowsum"}
+                7: "k_passSM", 8: "k_csr_rowsum", 9: "k_passC2"}  # C2: the final passes of two samples in one launch
 NK_PROF_KEYS = 250
 PRO_NAMES = {0: "plain", 1: "amp", 2: "amp_jvp", 3: "mul"}
 EPI_NAMES = {0: "affine", 1: "mul", 2: "vjp", 3: "likelihood", 4: "nonlin"}
@@ -65,6 +65,8 @@ def algorithmic_bytes(kernel, pro, epi, N, b, const_mid):
     """
     if kernel == 4:  # pass D touches 2 planes only
         return 0.0
+    if kernel == 9:  # nk_hartley_sandwich_pair: two final passes in one launch
+        return 2.0 * algorithmic_bytes(3, pro, epi, N, b, const_mid)
     total = 2.0 * N * b
     if kernel == 7 and not const_mid:  # the diagonal between the two transforms of a sandwich
         total += N * b

@@ -1339,7 +1339,7 @@ static int nk_run_sandwich_pair(const nk_plan* P, const NkFuse& fa, const NkFuse
   rc = nk_run_sandwich<T>(P, fb, scale_first, convention, wsb, st, false, nullptr);
   if (rc != NK_OK) return rc;
   const NkHostPlan& hp = P->hp;
-  ProfScope ps(st, 3, fa.pro, fa.epi);
+  ProfScope ps(st, 9, fa.pro, fa.epi);  // its own profile key: one launch, two final passes
   return nk_final_with_slots(hp, wsa, fa, st, [&](const NkFuse& fa2) {
     return nk_final_with_slots(hp, wsb, fb, st, [&](const NkFuse& fb2) {
       return nk_dispatch_final_pair<T>(hp.g.nl, q.pf, fa2, fb2, (const C2<T>*)P->d_tw_f, (const C2<T>*)wsa, (const C2<T>*)wsb, st);

@@ -4,6 +4,8 @@ Usage: pmc_traffic.py <fetch_dir> <write_dir> <workload> > profiles/<name>_pmc_t
 import csv, glob, json, sys, collections
 
 def family(name):
+    if "k2_final2" in name or "k_passC2" in name:
+        return "k_passC2"
     if "k2_final" in name or "k_passC" in name:
         return "k_passC"
     if "k3_contig" in name:
