@@ -730,10 +730,13 @@ class FusedModel:
                               workspace=torch.empty_like(self.plan.workspace))
         return self._pair
 
-    def lh_metric_accumulate_pair(self, lpa, lpb, d, out, scale, first):
-        """lh_metric_accumulate(lpa, d, out, scale, first) followed by lh_metric_accumulate(lpb, d, out, scale, False) -- the
-        same bits -- with the two final passes in one launch: sample B's accumulation onto `out` meets sample A's freshly
-        written lines in L2 (nk_hartley_sandwich_pair; one read and one write of `out` less per pair)."""
+    def lh_metric_accumulate_pair(self, lpa, lpb, d, out, scale, first, identity=0.0, dot_out=None, cg_direction=None):
+        """lh_metric_accumulate(lpa, d, out, scale, first, cg_direction=...) followed by lh_metric_accumulate(lpb, d, out,
+        scale, False, identity=..., dot_out=...) -- the same bits -- with the two final passes in one launch: sample B's
+        accumulation onto `out` meets sample A's freshly written lines in the cache hierarchy (nk_hartley_sandwich_pair).
+        The pending CG direction update rides in A's first pass, the identity term and the curvature dot in B's epilogue."""
+        if cg_direction is not None and not self.fused_direction:
+            raise ValueError("cg_direction needs the sandwich pipeline (FusedModel.fused_direction)")
         pb = self._pair_buffers()
         lib = L.load()
         fuses = []
@@ -754,7 +757,17 @@ class FusedModel:
             if self.scatter_fixed_point:
                 f.w8max = w8max.data_ptr()
             fuses.append(f)
+        if cg_direction is not None:
+            fuses[0].cg_r, fuses[0].cg_scal = cg_direction[0].xi.data_ptr(), cg_direction[1].scal.data_ptr()
+        if identity:
+            fuses[1].addend, fuses[1].addend_scale = d.xi.data_ptr(), identity
+            if dot_out is not None:
+                fuses[1].value = dot_out.data_ptr()
+        elif dot_out is not None:
+            raise ValueError("dot_out needs the identity term (the addend of the epilogue)")
         B.hartley_sandwich_pair(self.plan, fuses[0], fuses[1], self.h_dvol, pb["workspace"])
+        if cg_direction is not None:
+            cg_direction[1].roll()
         self.counters["transforms"] += 4
         shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
         for lp, w8, w8max, is_first in ((lpa, self.w8, self.w8max, first), (lpb, pb["w8"], pb["w8max"], False)):
@@ -762,7 +775,7 @@ class FusedModel:
                                              self.nb, self.scatter_scratch.data_ptr(), self.abar.data_ptr(),
                                              w8max.data_ptr() if self.scatter_fixed_point else 0, B._stream()),
                     "nk_octant_scatter_k2")
-            self._finish_metric(lp, d, out, is_first, 0.0)
+            self._finish_metric(lp, d, out, is_first, 0.0 if lp is lpa else identity)
 
     def _finish_metric(self, lp, d, out, first, identity):
         self._amp_vjp(lp)
@@ -992,15 +1005,17 @@ class FusedKL(Energy):
         out = LatentVec(torch.empty_like(d.xi), None)
         w = 1.0 / self.n_total
         nloc = len(self.lins)
-        # the MIDDLE samples go two at a time with their final passes in one launch (lh_metric_accumulate_pair: the second
-        # one's accumulation onto `out` stays in L2); the first sample (pending direction update, staged first pass) and the
-        # last one (identity term, curvature dot, staged final pass) keep their own launches
+        # the samples go two at a time with their final passes in one launch (lh_metric_accumulate_pair: the second one's
+        # accumulation onto `out` meets the first one's lines in cache); an odd one out and the staged passes stay single
         paired = m.pair_ready()
         i = 0
         while i < nloc:
             lp = self.lins[i]
-            if paired and 0 < i and i + 1 < nloc - 1:
-                m.lh_metric_accumulate_pair(lp, self.lins[i + 1], d, out, w, False)
+            # (a staged first / final pass of the pipelined exchange keeps its own launch)
+            if paired and i + 1 < nloc and (pipe is None or (i > 0 and i + 1 < nloc - 1)):
+                tail = i + 1 == nloc - 1
+                m.lh_metric_accumulate_pair(lp, self.lins[i + 1], d, out, w, i == 0, identity=nloc * w if tail else 0.0,
+                                            dot_out=dot_out if tail else None, cg_direction=cg_direction if i == 0 else None)
                 i += 2
                 continue
             stage = None

@@ -337,3 +337,20 @@ def test_pair_final_pass_is_bit_identical(shape, dtype):
     finally:
         del os.environ["NK_PAIR_FINAL"]
     assert torch.equal(paired.xi, single.xi) and torch.equal(paired.small, single.small)
+    # a Newton-CG step on the KL (the CG rides its direction update in the first sample's first pass, the identity term and
+    # the curvature dot in the last sample's epilogue): pairs (0,1), (2,3) and a single, or two pairs, against single launches
+    from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG
+
+    for n in (5, 4):
+        results = []
+        for flag in ("1", "0"):
+            os.environ["NK_PAIR_FINAL"] = flag
+            try:
+                kln = FusedKL(model, xs[0], res[:n], [False] * n)
+                mini = NewtonCG(AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=6)
+                e, _ = mini(kln)
+                results.append((e.position.xi.clone(), e.position.small.clone(), e.value))
+            finally:
+                del os.environ["NK_PAIR_FINAL"]
+        assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+        assert results[0][2] == results[1][2]
