@@ -38,7 +38,7 @@ from nifty_amd import minimization, parallel, random  # noqa: E402
 from nifty_amd.engine import FusedModel, LatentVec, mgvi_iteration  # noqa: E402
 from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG  # noqa: E402
 
-PMC_TRAFFIC_FILE = os.environ.get("NK_PMC_FILE", "r03i_pmc_traffic.json")  # latest committed PMC summary of the bench command
+PMC_TRAFFIC_FILE = os.environ.get("NK_PMC_FILE", "r03j_pmc_traffic.json")  # latest committed PMC summary of the bench command
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # transform pass kernels by profile id: strided-first pipeline (A first strided pass with prologue, B in-place strided
 # pass, C final contiguous pass with epilogue) and the five-pass sandwich H D H of a metric application (S1 contiguous
