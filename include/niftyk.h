@@ -163,7 +163,7 @@ int nk_plan_sandwich(const nk_plan* plan);
 int nk_hartley_sandwich(const nk_plan* plan, const nk_fuse* fuse, double scale_first, int convention, void* workspace,
                         void* stream);
 /* Two sandwiches that ACCUMULATE INTO THE SAME `out` (two samples of a KL metric, SampledKLEnergyClass.apply_metric sums
- * them, kl_energies.py:346-360) in one call: the first four passes of A and of B run one after the other on their own
+ * them, kl_energies.py:344-350) in one call: the first four passes of A and of B run one after the other on their own
  * workspaces, the two final passes share ONE launch in which every workgroup finishes its lines for A and then for B --
  * B's read-modify-write of `out` meets A's lines in L2 instead of HBM.  Same arithmetic, same bits as
  * nk_hartley_sandwich(A) followed by nk_hartley_sandwich(B).  Requirements: 3-D plan, both epilogues VJP with octant
