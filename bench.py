@@ -38,7 +38,7 @@ from nifty_amd import minimization, parallel, random  # noqa: E402
 from nifty_amd.engine import FusedModel, LatentVec, mgvi_iteration  # noqa: E402
 from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG  # noqa: E402
 
-PMC_TRAFFIC_FILE = os.environ.get("NK_PMC_FILE", "r03j_pmc_traffic.json")  # latest committed PMC summary of the bench command
+PMC_TRAFFIC_FILE = os.environ.get("NK_PMC_FILE", "r04_pmc_traffic.json")  # latest committed PMC summary of the bench command
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # transform pass kernels by profile id: strided-first pipeline (A first strided pass with prologue, B in-place strided
 # pass, C final contiguous pass with epilogue) and the five-pass sandwich H D H of a metric application (S1 contiguous
@@ -48,6 +48,40 @@ KERNEL_NAMES = {0: "k_pass1d", 1: "k_passA", 2: "k_passB", 3: "k_passC", 4: "k_p
 NK_PROF_KEYS = 250
 PRO_NAMES = {0: "plain", 1: "amp", 2: "amp_jvp", 3: "mul"}
 EPI_NAMES = {0: "affine", 1: "mul", 2: "vjp", 3: "likelihood", 4: "nonlin"}
+
+
+class ParityFailure(AssertionError):
+    """The HIP path disagrees with the oracle on the in-run sample: the bench line is printed, the exit code is 3."""
+
+
+def kernel_symbol(kern, pro, epi, shape, dt_name, octant=True, wide=False, const_mid=True):
+    """Device symbol behind a profile key (kernel id, prologue, epilogue) of the register-resident pipelines
+    (nifty_amd/csrc/nk_fft.hip; what rocprofv3 --kernel-trace lists), for 2-D / 3-D power-of-two grids."""
+    T = "float" if dt_name == "f32" else "double"
+    A, M, NL = (shape[0], shape[1], shape[2]) if len(shape) == 3 else (1, shape[0], shape[-1])
+    pc_first = {0: "0", 1: "4" if octant else "1", 2: "5" if octant else "3", 3: "6"}[pro]   # prologue class of a first pass
+    ec = {0: "0", 1: "1", 2: "2", 3: "3", 4: "-1"}[epi]                                    # epilogue class of a final pass
+    couples = "true" if epi == 2 else "false"
+    if kern == 1:
+        if wide and pro == 1 and epi == 3:  # value / gradient forward of an fp32 model: fp64 kernels, float arrays at the ends
+            return f"k2_strided<double,{M},3,9>"
+        return f"k2_strided<{T},{M},3,{pc_first}>"
+    if kern == 2:
+        return f"k2_strided<{'double' if wide and pro == 1 and epi == 3 else T},{A if len(shape) == 3 else M},0,-1>"
+    if kern == 3:
+        if wide and pro == 1 and epi == 3:
+            return f"k2_final<double,{NL},false,5,0>"
+        pair = "1" if (pro == 2 and epi == 2 and len(shape) == 3) else "0"   # a sandwich's final pass: row-mirror pairing
+        return f"k2_final<{T},{NL},{couples},{ec},{pair}>"
+    if kern == 5:
+        return f"k3_contig_quad<{T},{NL // 2},{'5|8' if pro == 2 else pc_first}>"  # 8 = 5 with the CG direction update
+    if kern == 6:
+        return f"k2_strided<{T},{M},0,-1>"
+    if kern == 7:
+        return f"k3_mid<{T},{A},{'false' if const_mid else 'true'}>"
+    if kern == 9:
+        return f"k2_final2<{T},{NL}>"
+    return KERNEL_NAMES.get(kern, str(kern))
 
 
 def rowsum_bytes(nnz, nrows, b, weighted=True):
@@ -127,12 +161,18 @@ def cpu_baseline(counts_per_step, shape_full, cfg="C5", bench_dtype=None, budget
     if Nf <= (1 << 25):
         sample_shape = tuple(shape_full)
     else:
-        edge = int(os.environ.get("NK_BENCH_CPU_EDGE", "256" if cores >= 32 else "128"))
+        edge = int(os.environ.get("NK_BENCH_CPU_EDGE", "512" if cores >= 64 else "256" if cores >= 32 else "128"))
         sample_shape = tuple(min(edge, n) for n in shape_full)
     rng = np.random.default_rng(0)
-    cf = orc.CFModel(sample_shape, None, orc.CFParams(offset_mean=2.0), workers=cores)
+    natural = len(sample_shape) >= 2  # the default RGSpace: bins from integer k^2, slab-parallel (same arrays)
+    cf = orc.CFModel(sample_shape, None, orc.CFParams(offset_mean=2.0), workers=cores,
+                     geometry=orc.power_geometry_natural(sample_shape, workers=cores) if natural else None)
     x = {k: 0.1 * v for k, v in cf.draw_latent(rng).items()}
     v = cf.draw_latent(rng)
+    # fp32-representable excitations and data: the fp64 oracle, the fp64 engine and the fp32 engine see IDENTICAL inputs
+    # (Field.from_random(dtype=float32) rounds its fp64 draw the same way, random.py:219-237)
+    x["xi"] = x["xi"].astype(np.float32).astype(np.float64)
+    v["xi"] = v["xi"].astype(np.float32).astype(np.float64)
     response = None
     if cfg == "C4":
         # the sparse matrix is INPUT DATA of the oracle here: built by the host set-up the product shares with the
@@ -150,7 +190,7 @@ def cpu_baseline(counts_per_step, shape_full, cfg="C5", bench_dtype=None, budget
         lh = orc.Likelihood("poisson", data, nonlin="exp")
         lh_kw = dict(likelihood="poisson", nonlin="exp")
     else:
-        data = cf.forward(x) + 0.1 * rng.normal(size=sample_shape)
+        data = (cf.forward(x) + 0.1 * rng.normal(size=sample_shape)).astype(np.float32).astype(np.float64)
         lh = orc.Likelihood("gaussian", data, icov=100.0)
         lh_kw = dict(likelihood="gaussian", icov=100.0)
     lin = orc.Linearized(cf, lh, x)
@@ -161,18 +201,26 @@ def cpu_baseline(counts_per_step, shape_full, cfg="C5", bench_dtype=None, budget
     if device is not None:
         from nifty_amd.engine import FusedModel, LatentVec
 
-        val_o, _ = lin.value_grad()
+        val_o, grad_o = lin.value_grad()
+
+        def worst(got, ref):  # max |difference| over all keys, relative to the largest entry of the whole latent vector
+            top = max(float(np.max(np.abs(ref[k]))) for k in ref)
+            return max(float(np.max(np.abs(np.asarray(got[k], dtype=np.float64) - ref[k]))) for k in ref) / top
+
         dts = [torch.float64] + ([bench_dtype] if bench_dtype not in (None, torch.float64) else [])
         for dt in dts:
             model = FusedModel(sample_shape, offset_mean=2.0, data=data, dtype=dt, device=device, **lh_kw)
             lp = model.linearize(LatentVec.from_dict(model, x))
             got = model.metric(lp, LatentVec.from_dict(model, v)).to_dict()
-            err = max(float(np.max(np.abs(got[k] - mv[k])) / np.max(np.abs(mv[k]))) for k in ("xi", "spectrum"))
-            err = max(err, abs(float(lp.value.item()) - val_o) / abs(val_o))
-            parity["f64" if dt == torch.float64 else "f32"] = err
+            parity["f64" if dt == torch.float64 else "f32"] = dict(
+                value=abs(float(lp.value.item()) - val_o) / abs(val_o), gradient=worst(lp.grad.to_dict(), grad_o),
+                metric=worst(got, mv))
             del model, lp
-        assert parity["f64"] < 1e-5, f"HIP path deviates from the oracle: {parity}"
-        assert parity.get("f32", 0.0) < 1e-3, f"fp32 HIP path deviates from the fp64 oracle: {parity}"
+        # SURVEY 8(d) / north_star: <= 1e-5 relative, value, GRADIENT and metric application, in fp64 and in the dtype the
+        # bench computes in (fp32 fields against the fp64 oracle on identical inputs)
+        bad = {k: e for k, e in parity.items() if max(e.values()) >= 1e-5}
+        if bad:
+            raise ParityFailure(f"HIP path deviates from the oracle by more than 1e-5: {parity}")
 
     def time_pair(lin_, cf_, budget):
         t_met, t_vg, n = 0.0, 0.0, 0
@@ -211,7 +259,9 @@ def cpu_baseline(counts_per_step, shape_full, cfg="C5", bench_dtype=None, budget
               f"{counts_per_step['metric']:.0f} metric applies + {counts_per_step['value_grad']:.0f} value/gradient "
               "evaluations")
     return dict(value=1.0 / sec_per_step, unit="MGVI iters/s", cores=cores, kind="port",
-                parity_rel_err_vs_hip=parity.get("f64"), parity_rel_err_vs_hip_f32=parity.get("f32"),
+                parity_rel_err_vs_hip=max(parity["f64"].values()) if "f64" in parity else None,
+                parity_rel_err_vs_hip_f32=max(parity["f32"].values()) if "f32" in parity else None,
+                parity_detail=parity or None,
                 value_one_thread=1.0 / sec1,
                 sample=(f"oracle (numpy+scipy.fft, workers={cores}) metric apply {t_met * 1e3:.1f} ms and value+gradient "
                         f"{t_vg * 1e3:.1f} ms per sample at {'x'.join(map(str, sample_shape))} fp64 ({n} reps), "
@@ -398,9 +448,11 @@ def main():
     model.counters["cg_iterations"] = cg_iterations
     counts = {k: v / args.steps for k, v in model.counters.items()}
 
+    parity_failed = False
     if rank == 0:
         # dominant transform pass kernel of this rank, live HIP-event timing over the timed region
         by_kernel = {}
+        by_symbol = {}
         spmv = {}
         for (kern, pro, epi), (ms, cnt) in prof.items():
             if kern == 8:
@@ -418,7 +470,20 @@ def main():
             ent = by_kernel.setdefault(kern, dict(ms=0.0, cnt=0, bytes=0.0))
             ent["ms"] += ms
             ent["cnt"] += cnt
-            ent["bytes"] += cnt * algorithmic_bytes(kern, pro, epi, N, b, model.const_mid)
+            # (the wide forward of an fp32 model, FusedModel.wide: float arrays at the ends, fp64 work array in between)
+            wide_fwd = model.wide and pro == 1 and epi == 3
+            nbytes = cnt * algorithmic_bytes(kern, pro, epi, N, b, model.const_mid)
+            if wide_fwd:
+                nbytes += cnt * {2: 2 * N * b, 3: N * b}.get(kern, 0)  # fp64 work array: written by pass 1 (instead of the
+                # index stream the model prices), read + written by pass 2, read by the final pass
+            ent["bytes"] += nbytes
+            sym = kernel_symbol(kern, pro, epi, shape, dt_name, octant=model.octant_vjp, wide=model.wide,
+                                const_mid=model.const_mid)
+            se = by_symbol.setdefault(sym, dict(ms=0.0, cnt=0, bytes=0.0, families=set()))
+            se["ms"] += ms
+            se["cnt"] += cnt
+            se["bytes"] += nbytes
+            se["families"].add(KERNEL_NAMES[kern])
         roofline = None
         if by_kernel:
             kern = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
@@ -435,13 +500,27 @@ def main():
                     traffic = tj["kernels"].get(KERNEL_NAMES[kern], {}).get("bytes")
                     traffic_source = (f"profiles/{PMC_TRAFFIC_FILE} (separate rocprofv3 --pmc passes of this command at "
                                       f"commit {tj.get('commit', '?')}, not this run)")
-            roofline = dict(bound="hbm", kernel=KERNEL_NAMES[kern], achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+            # the same launches by DEVICE SYMBOL (what rocprofv3 --kernel-trace lists): a symbol can serve several families
+            # (the in-place strided pass is one symbol for the sandwich's middle-axis passes and the second pass of a
+            # value / gradient transform)
+            top_sym = max(by_symbol, key=lambda k: by_symbol[k]["ms"])
+            tse = by_symbol[top_sym]
+            roofline = dict(bound="hbm", kernel=KERNEL_NAMES[kern], family=KERNEL_NAMES[kern],
+                            kernel_symbols=sorted(sy for sy, v in by_symbol.items() if KERNEL_NAMES[kern] in v["families"]),
+                            largest_symbol=dict(symbol=top_sym, families=sorted(tse["families"]), ms_total=round(tse["ms"], 2),
+                                                launches=int(tse["cnt"]), avg_launch_ms=round(tse["ms"] / tse["cnt"], 4),
+                                                achieved=round(tse["bytes"] / max(tse["ms"], 1e-9) / 1e6, 1),
+                                                frac=round(tse["bytes"] / max(tse["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4)),
+                            achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                             unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
                             avg_launch_ms=round(avg_ms, 4), launches=int(ent["cnt"]),
                             algorithmic_bytes_per_launch=ent["bytes"] / ent["cnt"],
                             all_pass_kernels={KERNEL_NAMES[k]: dict(ms_total=round(v["ms"], 2), launches=int(v["cnt"]),
                                                                     GBps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
-                                              for k, v in sorted(by_kernel.items())})
+                                              for k, v in sorted(by_kernel.items())},
+                            all_pass_symbols={k: dict(ms_total=round(v["ms"], 2), launches=int(v["cnt"]),
+                                                      GBps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
+                                              for k, v in sorted(by_symbol.items(), key=lambda kv: -kv[1]["ms"])})
             if spmv:
                 # gather-bound sparse products of the response (C4): algorithmic bytes = per entry column + weight + one
                 # gathered operand, per row pointer + result (rowsum_bytes); against the same 8 TB/s peak
@@ -508,12 +587,21 @@ def main():
             "samples16": leg16,
             "per_step_counts_rank0": counts,
             "step_algorithmic_GBps_rank0": step_bytes / (ms_per_step * 1e-3) / 1e9,
+            # step_algorithmic is SURVEY 8(d)'s model: SIX passes per metric application (two three-pass transforms).  What
+            # the kernels of a step really move: the operand bytes of every executed transform pass (a metric application is
+            # a FIVE-pass sandwich) plus the CG vector update's seven streams per iteration, over the same step time
+            "step_hbm_GBps_rank0": ((sum(v["bytes"] for v in by_kernel.values()) / args.steps
+                                     + counts.get("cg_iterations", 0.0) * 7.0 * N * b / world)
+                                    / (ms_per_step * 1e-3) / 1e9) if by_kernel else None,
             "roofline": roofline,
             "device_memory_rank0": device_memory,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(counts, shape, cfg=cfg, bench_dtype=dtype, device=device, c4=c4)
+            except ParityFailure as exc:  # the line is still printed -- and the run exits with code 3
+                line["cpu_baseline"] = {"error": repr(exc)}
+                parity_failed = True
             except Exception as exc:  # the baseline must never take the bench line down
                 line["cpu_baseline"] = {"error": repr(exc)}
     else:
@@ -533,6 +621,8 @@ def main():
     if comm is not None:
         comm.barrier()
         torch.distributed.destroy_process_group()  # or ProcessGroupNCCL complains on stderr after the line
+    if parity_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -128,6 +128,14 @@ typedef struct nk_fuse {
                            (mirror partners of one kernel work item: their sum at the first, 0 at the others) INSTEAD of
                            the atomics into abar -- the caller reduces it in a fixed order (nk_csr_rowsum over the
                            bin-sorted permutation): bit-reproducible spectrum gradients on every grid */
+  int io32;             /* != 0, fp64 plans with nk_plan_octant_vjp(plan) != 0 only, nk_hartley_fused with the AMP prologue
+                           (field_octant, afield = fp64 octant field) and the LIKELIHOOD epilogue: `in`, `data` (Gaussian),
+                           `icov`, `out` and `out2` are FLOAT arrays while the transform -- amplitude product, all passes, the
+                           work array, residual and energy -- runs in fp64.  This is the value / gradient forward transform of
+                           a model with fp32 fields: the reference promotes fp32 excitations to fp64 at their product with the
+                           fp64 amplitude and transforms in fp64 (library/correlated_fields.py:755-764), and an fp32 forward
+                           transform leaves a coherent 6e-8 gain error on the signal that the residual N^-1 (s - d) amplifies
+                           (DESIGN 6).  NK_ERR_INVALID with any other prologue / epilogue or on an fp32 plan */
 } nk_fuse;
 
 typedef struct nk_plan nk_plan;

@@ -31,7 +31,7 @@ class Fuse(ctypes.Structure):
         ("icov", _vp), ("icov_scalar", _d), ("out2", _vp), ("value", _vp),
         ("afield", _vp), ("dampT", _vp), ("abar_copies", _i), ("abar_stride", _i64), ("dafield", _vp), ("w8", _vp),
         ("field_octant", _i), ("value_slots", _i), ("pidx_octant", _vp), ("cg_r", _vp), ("cg_scal", _vp), ("w8max", _vp),
-        ("pipe_chunks", _i), ("pipe_wait", _vp), ("pipe_record", _vp), ("wfull", _vp),
+        ("pipe_chunks", _i), ("pipe_wait", _vp), ("pipe_record", _vp), ("wfull", _vp), ("io32", _i),
     ]
 
 

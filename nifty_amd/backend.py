@@ -583,7 +583,7 @@ def _runs_on_operand_device(fn):
     return wrapper
 
 
-for _name in ("cplx_rows", "hartley", "hartley_fused", "hartley_sandwich", "fftn", "vdot", "vsum", "binary", "axpby",
+for _name in ("cplx_rows", "hartley", "hartley_fused", "hartley_sandwich", "hartley_sandwich_pair", "fftn", "vdot", "vsum", "binary", "axpby",
               "axpby_sqnorm",
               "pointwise", "gather", "scatter_add", "bin_plan", "bin_sum", "spmv", "spmv_t", "stats", "cumsum"):
     globals()[_name] = _runs_on_operand_device(globals()[_name])

@@ -412,6 +412,8 @@ NK_HD C2<T> nk_load_pair_u(const T* p) {
 //   PC = 7: afield8 * in + dampT[pidx_octant] * in2   (da gathered from its table: no expanded da field)
 //   PC = 8: as 5, after the pending CG direction update  in <- beta * in + cg_r  (written back; same fp64 arithmetic as
 //           nk_cg_direction, so the fused and the separate update agree bit for bit)
+//   PC = 9: as 4 with `in` a FLOAT array under a wider T (nk_fuse.io32: fp32 excitations promoted at their product with the
+//           fp64 amplitude, library/correlated_fields.py:755-764)
 // The prologue comes in two halves, LOAD (every operand of the pair, no arithmetic, no store) and APPLY (arithmetic and
 // the write-back of class 8), so that a pass can issue the loads of all its elements before the first use: class 8's
 // store to `in` may alias every later load as far as the compiler knows, and a per-element load -> use chain leaves four
@@ -423,15 +425,20 @@ struct NkOctOps {
 template <typename T, int PC>
 NK_HD NkOctOps<T> nk_oct_load(const NkFuse& f, int64_t iu, uint32_t it, uint32_t j) {
   NkOctOps<T> o;
-  o.a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
+  if constexpr (PC == 9) {
+    const C2<float> a32 = *reinterpret_cast<const C2<float>*>((const float*)f.in + iu + it);
+    o.a = C2<T>{(T)a32.x, (T)a32.y};
+  } else {
+    o.a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
+  }
   if constexpr (PC == 8) o.r = *reinterpret_cast<const C2<T>*>((const T*)f.cg_r + iu + it);
   o.m = nk_load_pair_u<T>((const T*)f.afield + j);
-  if constexpr (PC != 4) o.x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
+  if constexpr (PC != 4 && PC != 9) o.x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
   if constexpr (PC == 7) {
     const NkPairU<int32_t> p = *reinterpret_cast<const NkPairU<int32_t>*>(f.pidx_octant + j);
     const T* dt = (const T*)f.dampT;
     o.dm = C2<T>{dt[p.x], dt[p.y]};
-  } else if constexpr (PC != 4) {
+  } else if constexpr (PC != 4 && PC != 9) {
     o.dm = nk_load_pair_u<T>((const T*)f.dafield + j);
   }
   return o;
@@ -449,7 +456,7 @@ NK_HD C2<T> nk_oct_apply(const NkFuse& f, const NkOctOps<T>& o, int64_t iu, uint
     *reinterpret_cast<C2<T>*>(const_cast<T*>((const T*)f.in) + iu + it) = a;
   }
   const C2<T> m = desc ? C2<T>{o.m.y, o.m.x} : o.m;
-  if constexpr (PC == 4) {
+  if constexpr (PC == 4 || PC == 9) {
     return C2<T>{m.x * a.x, m.y * a.y};
   } else {
     const C2<T> dm = desc ? C2<T>{o.dm.y, o.dm.x} : o.dm;
@@ -504,13 +511,14 @@ NK_HD void nk_epi_likelihood(const NkFuse& f, int64_t o, T v, double& acc) {
 // 1 = Gaussian with a scalar inverse covariance, 2 = Poissonian.  The data loads (nk_lh4_load: raw values, no arithmetic)
 // then stand in straight-line code and the caller issues them for several coefficients ahead of the first store; under
 // run-time conditions each load sat in its own block with an s_waitcnt behind it.
-template <typename T, int FAST>
+// TD: the type of the data, inverse-covariance and output ARRAYS -- T, or float under a double pipeline (nk_fuse.io32)
+template <typename TD, int FAST>
 struct NkLhData {
-  typedef typename std::conditional<FAST == 2, int64_t, T>::type type;
+  typedef typename std::conditional<FAST == 2, int64_t, TD>::type type;
 };
-template <typename T, int FAST, int MASK>
-NK_HD void nk_lh4_load(const NkFuse& f, const int64_t (&o)[4], typename NkLhData<T, FAST>::type (&d)[4]) {
-  typedef typename NkLhData<T, FAST>::type D;
+template <typename TD, int FAST, int MASK>
+NK_HD void nk_lh4_load(const NkFuse& f, const int64_t (&o)[4], typename NkLhData<TD, FAST>::type (&d)[4]) {
+  typedef typename NkLhData<TD, FAST>::type D;
 #pragma unroll
   for (int i = 0; i < 4; ++i) d[i] = ((MASK >> i) & 1) ? ((const D*)f.data)[o[i]] : (D)1;
 }
@@ -529,9 +537,9 @@ NK_HD double nk_lh_term(const NkFuse& f, bool gauss, double v, double d, double 
   w = gp * gp / g;
   return g - d * log(g);
 }
-template <typename T, int FAST, int MASK>
+template <typename T, int FAST, int MASK, typename TD = T>
 NK_HD void nk_lh4_apply(const NkFuse& f, const int64_t (&o)[4], const T (&v)[4],
-                        const typename NkLhData<T, FAST>::type (&d)[4], double& acc) {
+                        const typename NkLhData<TD, FAST>::type (&d)[4], double& acc) {
   double gs[4], w[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -541,23 +549,23 @@ NK_HD void nk_lh4_apply(const NkFuse& f, const int64_t (&o)[4], const T (&v)[4],
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (!((MASK >> i) & 1)) continue;
-    ((T*)f.out)[o[i]] = (T)gs[i];
-    if (f.out2) ((T*)f.out2)[o[i]] = (T)w[i];
+    ((TD*)f.out)[o[i]] = (TD)gs[i];
+    if (f.out2) ((TD*)f.out2)[o[i]] = (TD)w[i];
   }
 }
 
 // the (up to) four images of one coefficient, everything decided at run time: every load is issued before the first store
 // -- `out` may alias nothing here, but the compiler cannot know, and four dependent load -> store chains per work item cost
 // the final pass 1 ms at 1024^3
-template <typename T>
+template <typename T, typename TD = T>
 NK_HD void nk_epi_likelihood4(const NkFuse& f, const int64_t (&o)[4], const T (&v)[4], int mask, double& acc) {
   double dv[4], ic[4];
   const bool gauss = f.lh_kind == NK_LH_GAUSS;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const bool on = (mask >> i) & 1;
-    dv[i] = !on ? 1.0 : gauss ? (double)((const T*)f.data)[o[i]] : (double)((const int64_t*)f.data)[o[i]];
-    ic[i] = (on && gauss && f.icov) ? (double)((const T*)f.icov)[o[i]] : f.icov_scalar;
+    dv[i] = !on ? 1.0 : gauss ? (double)((const TD*)f.data)[o[i]] : (double)((const int64_t*)f.data)[o[i]];
+    ic[i] = (on && gauss && f.icov) ? (double)((const TD*)f.icov)[o[i]] : f.icov_scalar;
   }
   double gs[4], w[4];
 #pragma unroll
@@ -568,8 +576,8 @@ NK_HD void nk_epi_likelihood4(const NkFuse& f, const int64_t (&o)[4], const T (&
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (!((mask >> i) & 1)) continue;
-    ((T*)f.out)[o[i]] = (T)gs[i];
-    if (f.out2) ((T*)f.out2)[o[i]] = (T)w[i];
+    ((TD*)f.out)[o[i]] = (TD)gs[i];
+    if (f.out2) ((TD*)f.out2)[o[i]] = (TD)w[i];
   }
 }
 

@@ -171,7 +171,7 @@ __global__ void __launch_bounds__((StridedTile<T, N, nk_strided_cx<MODE, PC>(), 
   DeviceExec<T, ST::SC::E> ex;
   double acc = 0.0;
   // the octant prologues bring their own XCD-aware order (nk_oct_block_remap)
-  constexpr bool OCT = MODE == 3 && (PC == 4 || PC == 5);
+  constexpr bool OCT = MODE == 3 && (PC == 4 || PC == 5 || PC == 9);
   const int64_t blk = (xmap && !OCT) ? nk_xcd_contig(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
   C2<T>* tw_lds = ST::TWLDS ? reinterpret_cast<C2<T>*>(smem + ST::LDS_BYTES) : nullptr;
   nk_strided_body<T, N, ST::TILE, MODE, PC, nk_strided_cx<MODE, PC>()>(ex, p, f, blk, (T*)smem, tw, work, scratch, &acc, tw_lds);
@@ -244,7 +244,11 @@ static int nk_launch_final(const NkPassF& pf, const NkFuse& f, const C2<T>* tw, 
   if (f.epi == NK_EPI_VJP) return nk_launch_final_c<T, NL, true, -1>(pf, f, tw, work, st);
   if (f.epi == NK_EPI_AFFINE) return nk_launch_final_c<T, NL, false, 0>(pf, f, tw, work, st);
   if (f.epi == NK_EPI_MUL) return nk_launch_final_c<T, NL, false, 1>(pf, f, tw, work, st);
-  if (f.epi == NK_EPI_LIKELIHOOD) return nk_launch_final_c<T, NL, false, 3>(pf, f, tw, work, st);
+  if (f.epi == NK_EPI_LIKELIHOOD) {
+    if constexpr (sizeof(T) == 8)  // float arrays at both ends of a double pipeline (nk_fuse.io32)
+      if (f.io32) return nk_launch_final_c<T, NL, false, 5>(pf, f, tw, work, st);
+    return nk_launch_final_c<T, NL, false, 3>(pf, f, tw, work, st);
+  }
   return nk_launch_final_c<T, NL, false, -1>(pf, f, tw, work, st);
 }
 
@@ -397,6 +401,8 @@ static int nk_dispatch_contig(int h, const NkPassA& pa, const NkFuse& f, const C
 template <typename T, int N, int MODE>
 static int nk_launch_strided(const NkPassS& ps, const NkFuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch, hipStream_t st) {
   if constexpr (MODE == 3) {
+    if constexpr (sizeof(T) == 8)  // float excitations under a double pipeline (nk_fuse.io32)
+      if (f.field_octant && f.pro == NK_PRO_AMP && f.io32) return nk_launch_strided_pc<T, N, MODE, 9>(ps, f, tw, work, scratch, st);
     if (f.field_octant && f.pro == NK_PRO_AMP) return nk_launch_strided_pc<T, N, MODE, 4>(ps, f, tw, work, scratch, st);
     if (f.field_octant && f.pro == NK_PRO_AMP_JVP) return nk_launch_strided_pc<T, N, MODE, 5>(ps, f, tw, work, scratch, st);
     if (f.pro == NK_PRO_PLAIN) return nk_launch_strided_pc<T, N, MODE, 0>(ps, f, tw, work, scratch, st);
@@ -1163,6 +1169,10 @@ extern "C" int nk_hartley_fused(const nk_plan* P, const nk_fuse* fuse, int conve
   if (fuse->epi == NK_EPI_LIKELIHOOD && (!fuse->data || !fuse->value))
     return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: LIKELIHOOD epilogue needs data and value");
   if (fuse->cg_r) return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: cg_r is a prologue of nk_hartley_sandwich only");
+  if (fuse->io32 && !(P->hp.dtype == NK_F64 && nk_plan_uses_pipeline2(P) && fuse->field_octant && fuse->pro == NK_PRO_AMP &&
+                      fuse->epi == NK_EPI_LIKELIHOOD))
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: io32 needs an fp64 plan with the octant pipeline, the AMP prologue "
+                                        "with an octant amplitude field and the LIKELIHOOD epilogue");
   if (fuse->field_octant) {
     if (!nk_plan_uses_pipeline2(P))
       return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: field_octant needs nk_plan_octant_vjp(plan) != 0");

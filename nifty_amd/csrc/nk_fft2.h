@@ -530,7 +530,7 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
   // twiddles of the later stages: from the workgroup's LDS copy when the caller provides the room (StridedTile::TWLDS)
   const C2<T>* tw = tw_lds ? tw_lds : tw_global;
   [[maybe_unused]] C2<T>* cplane = reinterpret_cast<C2<T>*>(plane);
-  if constexpr (MODE == 3 && (PC == 4 || PC == 5)) blk = nk_oct_block_remap(blk, p);
+  if constexpr (MODE == 3 && (PC == 4 || PC == 5 || PC == 9)) blk = nk_oct_block_remap(blk, p);
   const int64_t o = blk / p.tiles_per_slab;
   const int64_t c0 = (blk % p.tiles_per_slab) * (int64_t)TILE;
   // MODE 3 reads the user array: line element j of column c0 at (o*N + j)*inner, and writes the work array.
@@ -555,7 +555,7 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
   ex.phase([&](int tid, PassRegs<T, E>& rg) {
     const int t = tid % TILE, pp = tid / TILE;
     constexpr int R = SC::radix(0), Q = E / R;
-    constexpr bool OCT = MODE == 3 && (PC == 4 || PC == 5);
+    constexpr bool OCT = MODE == 3 && (PC == 4 || PC == 5 || PC == 9);
     // octant amplitude fields [A/2+1][N/2+1][nl/2+1] (this axis is the middle one; A = 1 in 2-D): the two reals of
     // a pair sit at folded last-axis offsets c8a, c8b of the folded row
     [[maybe_unused]] uint32_t o8 = 0, ch = 0, c8 = 0;
@@ -826,6 +826,15 @@ NK_HD float nk_wmax_join(float a, float b) {
   return (a != a || b != b) ? NAN : (a > b ? a : b);
 #endif
 }
+// EC 5 = EC 3 (likelihood) with FLOAT data / inverse-covariance / output arrays under a wider T (nk_fuse.io32)
+template <int EC>
+constexpr bool nk_ec_lh() {
+  return EC == 3 || EC == 5;
+}
+template <typename T, int EC>
+struct NkLhIo {
+  typedef typename std::conditional<EC == 5, float, T>::type type;
+};
 // per-group constants of the final epilogue (one slot, or one couple of slots)
 template <int NH>
 struct FinalGroup {
@@ -945,11 +954,11 @@ NK_HD double nk_final_slot(const NkFuse& f, const FinalCt<T>& c, int64_t ok, int
   const T v0 = fx + sg * fy, v1 = fx - sg * fy, v2 = gx + sg * gy, v3 = gx - sg * gy;
   T* outk = c.out + ok;
   T* outm = c.out + om;
-  if constexpr (EC == 3) {  // likelihood: the reference arithmetic (fp64) per output, energy terms returned
+  if constexpr (nk_ec_lh<EC>()) {  // likelihood: the reference arithmetic (fp64) per output, energy terms returned
     double e = 0.0;
     const int64_t o4[4] = {ok + k2, om + k2m, ok + k2m, om + k2};
     const T v4[4] = {v0, v1, v2, v3};
-    nk_epi_likelihood4<T>(f, o4, v4, (self ? 1 : 3) | (BOTH ? (self ? 4 : 12) : 0), e);
+    nk_epi_likelihood4<T, typename NkLhIo<T, EC>::type>(f, o4, v4, (self ? 1 : 3) | (BOTH ? (self ? 4 : 12) : 0), e);
     return e;
   } else if constexpr (EC == 0) {
     nk_store_stream_s(outk + k2, (T)(v0 * c.sc + c.off));
@@ -1031,18 +1040,18 @@ NK_HD void nk_final_vjp_coeffs(const NkFuse& f, const FinalCt<T>& c, const Final
 
 // EC 3 with MODE = 1 (Gaussian, scalar N^-1) / 2 (Poissonian) and every slot a regular line pair: all slots of a group for
 // the coefficients k2[0 .. n_on-1] -- the data loads of all U coefficients ahead of the first store (nk_lh4_load / _apply)
-template <typename T, int NL, int NH, bool BOTH, int MODE, int U>
+template <typename T, int NL, int NH, bool BOTH, int MODE, int U, typename TD = T>
 NK_HD void nk_final_lh_coeffs(const NkFuse& f, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg, const int (&k2s)[U],
                               int n_on, double& acc) {
   constexpr int MASK = BOTH ? 15 : 3;
-  typename NkLhData<T, MODE>::type d[U][NH][4];
+  typename NkLhData<TD, MODE>::type d[U][NH][4];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int k2 = k2s[u], k2m = (NL - k2) & (NL - 1);
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int64_t o4[4] = {gp.okh[h] + k2, gp.omh[h] + k2m, gp.okh[h] + k2m, gp.omh[h] + k2};
-      nk_lh4_load<T, MODE, MASK>(f, o4, d[u][h]);
+      nk_lh4_load<TD, MODE, MASK>(f, o4, d[u][h]);
     }
   }
 #pragma unroll
@@ -1058,7 +1067,7 @@ NK_HD void nk_final_lh_coeffs(const NkFuse& f, const FinalGroup<NH>& gp, const T
       const int64_t o4[4] = {gp.okh[h] + k2, gp.omh[h] + k2m, gp.okh[h] + k2m, gp.omh[h] + k2};
       const T v4[4] = {fx + sg * fy, fx - sg * fy, gx + sg * gy, gx - sg * gy};
       double e = 0.0;
-      nk_lh4_apply<T, MODE, MASK>(f, o4, v4, d[u][h], e);
+      nk_lh4_apply<T, MODE, MASK, TD>(f, o4, v4, d[u][h], e);
       ssum += e;
     }
     acc += ssum;
@@ -1084,7 +1093,7 @@ NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup
       ssum += nk_final_slot<T, EC, BOTH, MODE>(f, c, gp.okh[h], gp.omh[h], gp.mlo[h] == 1, sg, fx, fy, gx, gy, k2, k2m, (T)0,
                                                acc);
     }
-    if constexpr (EC == 3) acc += ssum;
+    if constexpr (nk_ec_lh<EC>()) acc += ssum;
   }
 }
 
@@ -1112,7 +1121,7 @@ struct NkPassF {
 };
 
 // EC: compile-time epilogue class (0 affine, 1 multiply, 2 scatter/VJP with materialised amplitude field,
-// 3 likelihood, -1 generic)
+// 3 likelihood, 5 likelihood with float arrays under T = double (nk_fuse.io32), -1 generic)
 // PAIR: how the two work rows (k, -k) encode the line X(k, .) of length NL that is transformed here
 //   0  even/odd columns (strided-first pipeline, above):  Z_j(k) = X(k, 2j) + i X(k, 2j+1)
 //   1  row-mirror pairing of the sandwich pipeline (nk_fft3.h): rows of NL/2 + 1 columns,
@@ -1315,7 +1324,7 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
           constexpr int MODE = decltype(mode_c)::value;
           if (lane < 2)
             nk_final_coeff<T, NL, NH, EC, false, MODE>(f, c, gp, pre, pim, sg, lane ? NL / 2 : 0, hv, afline, w8line, acc, wmax);
-          if constexpr (EC == 3 && MODE > 0) {
+          if constexpr (nk_ec_lh<EC>() && MODE > 0) {
             constexpr int U = sizeof(T) == 8 ? (NK_LH_UNROLL + 1) / 2 : NK_LH_UNROLL;  // fp64: 168 VGPRs + 116 B / lane of spills with four
             for (int k2 = 1 + lane; k2 < NL / 2; k2 += U * tps) {
               int ks[U], n_on = 0;
@@ -1326,7 +1335,7 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
                 ks[u] = on ? k : k2;
                 n_on += on;
               }
-              nk_final_lh_coeffs<T, NL, NH, true, MODE, U>(f, gp, pre, pim, sg, ks, n_on, acc);
+              nk_final_lh_coeffs<T, NL, NH, true, MODE, U, typename NkLhIo<T, EC>::type>(f, gp, pre, pim, sg, ks, n_on, acc);
             }
           } else if constexpr (EC == 2 && MODE >= 0 && NK_FINAL_UNROLL > 1) {
             constexpr int U = NK_FINAL_UNROLL;
@@ -1357,7 +1366,7 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
             case 3: coefficients(std::integral_constant<int, 3>{}); break;
             default: coefficients(std::integral_constant<int, -1>{}); break;
           }
-        } else if constexpr (EC == 3) {  // see nk_epi_likelihood4
+        } else if constexpr (nk_ec_lh<EC>()) {  // see nk_epi_likelihood4
           bool regular = true;
 #pragma unroll
           for (int h = 0; h < NH; ++h) regular = regular && gp.mlo[h] == 3;

@@ -393,6 +393,16 @@ class FusedModel:
                     self.k2_line_order = torch.argsort((a2[:, None] + b2[None, :]).reshape(-1), stable=True).to(torch.int32)
             if self.octant_vjp and self.bin_k2 is None and os.environ.get("NK_SEGMENT_SUM", "1") != "0":
                 self.seg_plan = B.bin_plan(self.pidx8, self.nb)
+            # WIDE forward transform of value + gradient for fp32 fields (nk_fuse.io32): the reference promotes fp32
+            # excitations to fp64 at their product with the fp64 amplitude and transforms in fp64
+            # (library/correlated_fields.py:755-764).  An fp32 forward transform leaves a coherent gain error of ~6e-8 on the
+            # signal; the residual N^-1 (s - d) amplifies it by sqrt(N) x signal-to-noise (1e-5 .. 1e-3 of the gradient at
+            # 256^3 .. 1024^3).  So this one transform per evaluation runs on the fp64 plan -- fp64 amplitude field,
+            # fp64 work array, residual and energy from the fp64 signal -- with the fp32 arrays at both ends; the adjoint and
+            # every transform of a metric application stay fp32 (their error is not amplified: 1e-7).  NK_WIDE_FORWARD=0: the
+            # all-fp32 evaluation, for A/B.
+            self.wide = (dtype == torch.float32 and self.octant_vjp and os.environ.get("NK_WIDE_FORWARD", "1") != "0")
+            self._wide_state = None
             # plans WITHOUT the octant pipeline (mixed-radix grids, short axes): the generic kernels deposit xi . t per grid
             # point in a full-grid fp64 array (nk_fuse.wfull) that is summed bin by bin in a fixed order -- instead of fp64
             # atomics into per-XCD copies of abar (NK_SEGMENT_SUM=0: the atomics, for A/B)
@@ -411,6 +421,7 @@ class FusedModel:
             if int(response.n_pix) != self.N:
                 raise ValueError("response does not act on this grid")
             self.sandwich = self.fused_direction = False  # the middle of J^T M J is not diagonal in position space
+            self.wide = False  # (the likelihood lives behind the response: no likelihood epilogue to widen)
         if data is not None:
             self.set_data(data, icov)
         self.counters = dict(value_grad=0, metric=0, transforms=0, cg_iterations=0)
@@ -445,18 +456,20 @@ class FusedModel:
                                         state.data_ptr(), amp.data_ptr(), B._stream()), "nk_amp_forward")
         return amp, state
 
-    def _amp_field(self, amp, out=None):
-        """table[pindex] materialised in the field dtype with one gather per OCTANT point (|k| bins are invariant
-        under the sign flip of every axis): every later prologue / epilogue streams the field instead of gathering."""
+    def _amp_field(self, amp, out=None, dense=None):
+        """table[pindex] materialised in the field dtype (or the dtype of `out`) with one gather per OCTANT point (|k| bins
+        are invariant under the sign flip of every axis): every later prologue / epilogue streams the field instead of
+        gathering.  dense: the k^2 scratch table matching out's dtype when it is not the field dtype."""
         out = torch.empty(self.field_shape, dtype=self.tdtype, device=self.device) if out is None else out
         if self.k2_dense is not None:
             # natural binning: the bin is a function of k^2 -- no index stream (nk_octant_expand_k2; NK_EXPAND_K2=0: gather)
+            dense = self.k2_dense if dense is None else dense
             shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
             L.check(L.load().nk_octant_expand_k2(len(self.shape), shp, amp.data_ptr(), self.bin_k2.data_ptr(), self.nb,
-                                                 self.k2_dense.data_ptr(), out.data_ptr(), B.dtype_code(out),
+                                                 dense.data_ptr(), out.data_ptr(), B.dtype_code(out),
                                                  B.ptr(self.k2_line_order), B._stream()), "nk_octant_expand_k2")
             return out
-        table = amp if self.tdtype == torch.float64 else amp.to(self.tdtype)
+        table = amp if out.dtype == torch.float64 else amp.to(out.dtype)
         if self.pidx8 is not None:
             return B.gather(table, self.pidx8, self.field_shape, out=out)
         shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
@@ -580,9 +593,27 @@ class FusedModel:
         f.epi, f.out, f.out2 = L.EPI_LIKELIHOOD, gs.data_ptr(), B.ptr(lp.mid)
         f.offset, f.lh_kind, f.nonlin = self.offset_mean, self.lh_kind, self.nonlin
         f.data, f.icov, f.icov_scalar, f.value = self.data.data_ptr(), B.ptr(self.icov_field), self.icov_scalar, lhval.data_ptr()
-        B.hartley_fused(self.plan, f)
+        if self.wide:
+            # fp32 arrays at both ends of an fp64 transform (see __init__): a(k) xi(k) with the fp64 amplitude
+            plan64, afield64, dense64 = self._wide_buffers()
+            f.afield, f.io32 = self._amp_field(lp.amp, out=afield64, dense=dense64).data_ptr(), 1
+            B.hartley_fused(plan64, f)
+        else:
+            B.hartley_fused(self.plan, f)
         self.counters["transforms"] += 1
         return self._finish_linearize(lp, x, gs, None, grad_acc, w, value, lhval)
+
+    def _wide_buffers(self):
+        """fp64 plan (its work array: 2 N x 4 bytes more), fp64 octant amplitude field and k^2 table of the wide forward
+        transform, created at the first value / gradient evaluation of an fp32 model."""
+        if self._wide_state is None:
+            plan64 = B.get_plan(self.shape, torch.float64, 1, self.device)
+            if not L.load().nk_plan_octant_vjp(plan64.handle):
+                raise RuntimeError("the fp64 plan of this grid has no register-resident pipeline")
+            afield64 = torch.empty(self.field_shape, dtype=torch.float64, device=self.device)
+            dense64 = None if self.k2_dense is None else torch.zeros_like(self.k2_dense, dtype=torch.float64)
+            self._wide_state = (plan64, afield64, dense64)
+        return self._wide_state
 
     def _finish_linearize(self, lp, x, gs, gs2, grad_acc, w, value, lhval):
         """Gradient J^T (gs * gs2) + x and the value lh + 1/2 x.x, accumulated with weight w."""

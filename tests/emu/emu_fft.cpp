@@ -105,7 +105,8 @@ static void emu2_strided_m(NkPassS p, const nk_fuse& f, const C2<T>* tw, C2<T>* 
   for (int64_t blk = 0; blk < blocks; ++blk) {
     HostExec<T, ST::SC::E> ex(ST::THREADS);
     if constexpr (MODE == 3) {
-      if (f.field_octant && f.pro == NK_PRO_AMP) nk_strided_body<T, N, ST::TILE, 3, 4>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+      if (sizeof(T) == 8 && f.field_octant && f.pro == NK_PRO_AMP && f.io32) nk_strided_body<T, N, ST::TILE, 3, 9>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
+      else if (f.field_octant && f.pro == NK_PRO_AMP) nk_strided_body<T, N, ST::TILE, 3, 4>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
       else if (f.field_octant && f.pro == NK_PRO_AMP_JVP) nk_strided_body<T, N, ST::TILE, 3, 5>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
       else if (f.pro == NK_PRO_PLAIN) nk_strided_body<T, N, ST::TILE, 3, 0, true>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
       else if (f.pro == NK_PRO_MUL) nk_strided_body<T, N, ST::TILE, 3, 6, true>(ex, p, f, blk, plane.data(), tw, work, scratch, energy);
@@ -159,6 +160,7 @@ static void emu2_final(const NkPassF& pf, const nk_fuse& f, const C2<T>* tw, con
   else if (couples) emu2_final_ec<T, NL, true, -1>(pf, f, tw, work, energy);
   else if (f.epi == NK_EPI_AFFINE) emu2_final_ec<T, NL, false, 0>(pf, f, tw, work, energy);
   else if (f.epi == NK_EPI_MUL) emu2_final_ec<T, NL, false, 1>(pf, f, tw, work, energy);
+  else if (f.epi == NK_EPI_LIKELIHOOD && sizeof(T) == 8 && f.io32) emu2_final_ec<T, NL, false, 5>(pf, f, tw, work, energy);
   else if (f.epi == NK_EPI_LIKELIHOOD) emu2_final_ec<T, NL, false, 3>(pf, f, tw, work, energy);
   else emu2_final_ec<T, NL, false, -1>(pf, f, tw, work, energy);
 }

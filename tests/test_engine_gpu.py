@@ -174,15 +174,21 @@ def test_engine_vs_oracle_seeded(shape, kind, nonlin, dtype):
     if dtype == torch.float32:  # identical inputs for both paths
         x["xi"] = x["xi"].astype(np.float32).astype(np.float64)
         v["xi"] = v["xi"].astype(np.float32).astype(np.float64)
+        if kind == "gaussian":
+            lh.data = lh.data.astype(np.float32).astype(np.float64)
     lin = orc.Linearized(cf, lh, x)
     val, grad = lin.value_grad()
     mv = lin.metric(v)
     xl, vl = LatentVec.from_dict(model, x), LatentVec.from_dict(model, v)
     lp = model.linearize(xl)
-    tol = 1e-10 if dtype == torch.float64 else 2e-4
-    assert abs(float(lp.value.item()) - val) < tol * abs(val)
-    assert gl.lat_relerr(lp.grad.to_dict(), grad) < tol
-    assert gl.lat_relerr(model.metric(lp, vl).to_dict(), mv) < tol
+    # fp32 fields: value + gradient within the 1e-5 of north_star (their forward transform runs in fp64, FusedModel.wide);
+    # a metric application is two fp32 transforms with a pointwise weight in between
+    # (grids without the register-resident pipeline -- mixed radix, short axes -- keep the all-fp32 evaluation)
+    tol, mtol = (1e-10, 1e-10) if dtype == torch.float64 else ((1e-5 if model.wide else 2e-4), 2e-4)
+    e_val = abs(float(lp.value.item()) - val) / abs(val)
+    e_grad, e_met = gl.lat_relerr(lp.grad.to_dict(), grad), gl.lat_relerr(model.metric(lp, vl).to_dict(), mv)
+    print(f"{shape} {kind} {nonlin} {dtype}: value {e_val:.1e} gradient {e_grad:.1e} metric {e_met:.1e}")
+    assert e_val < tol and e_grad < tol and e_met < mtol
     # adjointness of the metric (reference extra.py:220-231): <u, M v> == <M u, v>
     u = LatentVec.from_dict(model, cf.draw_latent(rng))
     mvl = model.metric(lp, vl)

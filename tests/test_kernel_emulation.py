@@ -348,3 +348,113 @@ def test_sandwich_cg_direction_emulation():
     assert np.array_equal(d_work, d_new)
     t = 0.25 * H(0.5 * H(amp[pidx] * d_new + damp[pidx] * xi))
     assert np.max(np.abs(out - (amp[pidx] * t + d_new))) < 1e-11 * np.max(np.abs(t))
+
+
+@pytest.mark.parametrize("shape", [(64, 128), (64, 64, 64), (64, 64, 128)])
+@pytest.mark.parametrize("kind", ["gauss", "gauss_icov", "poisson"])
+def test_io32_wide_forward_emulation(shape, kind):
+    """nk_fuse.io32: float excitations / data / outputs at both ends of an fp64 transform (prologue class 9, epilogue
+    class 5) -- the value / gradient forward transform of a model with fp32 fields, against its numpy definition in fp64
+    (the reference promotes fp32 xi at the product with the fp64 amplitude, library/correlated_fields.py:755-764)."""
+    rng = np.random.default_rng(11)
+    nb = 7
+    pidx = rng.integers(0, nb, size=shape).astype(np.int32)
+    idx = np.indices(shape)
+    for d in range(len(shape)):
+        flip = tuple((-idx[e]) % shape[e] if e == d else idx[e] for e in range(len(shape)))
+        pidx = np.minimum(pidx, pidx[flip])
+    pidx = pidx.astype(np.int32)
+    amp = 0.3 * rng.normal(size=nb) / np.sqrt(np.prod(shape))
+    xi = rng.normal(size=shape).astype(np.float32)
+    H = lambda a: (lambda F: F.real + F.imag)(scipy.fft.fftn(a))  # noqa: E731
+    oct_sl = tuple(slice(0, s // 2 + 1) for s in shape)
+    af8 = np.ascontiguousarray(amp[pidx][oct_sl])  # fp64 octant field
+    s = 0.5 * H(amp[pidx] * xi.astype(np.float64)) + 1.25
+    value = np.zeros(1)
+    out, out2 = np.full(shape, np.nan, dtype=np.float32), np.full(shape, np.nan, dtype=np.float32)
+    f = Fuse()
+    f.pro, f.in_, f.pidx, f.amp = 1, xi.ctypes.data, pidx.ctypes.data, amp.ctypes.data
+    f.afield, f.field_octant, f.io32 = af8.ctypes.data, 1, 1
+    f.epi, f.out, f.out2, f.scale, f.offset, f.value = 3, out.ctypes.data, out2.ctypes.data, 0.5, 1.25, value.ctypes.data
+    if kind == "poisson":
+        data = rng.poisson(np.exp(s)).astype(np.int64)
+        f.lh_kind, f.nonlin, f.data = 1, 1, data.ctypes.data
+        lam = np.exp(s)
+        ref_e, ref_gs, ref_w = np.sum(lam - data * s), lam - data, lam
+    else:
+        data = (s + 0.1 * rng.normal(size=shape)).astype(np.float32)
+        f.lh_kind, f.nonlin, f.data, f.icov_scalar = 0, 0, data.ctypes.data, 100.0
+        ic = 100.0
+        if kind == "gauss_icov":
+            icf = rng.uniform(50.0, 150.0, size=shape).astype(np.float32)
+            f.icov = icf.ctypes.data
+            ic = icf.astype(np.float64)
+        r = s - data.astype(np.float64)
+        ref_e, ref_gs, ref_w = 0.5 * np.sum(ic * r * r), ic * r, ic * np.ones(shape)
+    run(f, shape, np.float64, fn="emu3_hartley_fused")
+    assert abs(value[0] - ref_e) < 1e-12 * abs(ref_e)
+    # the outputs are the fp64 results rounded ONCE to float
+    assert np.array_equal(out, ref_gs.astype(np.float32)) or np.max(np.abs(out - ref_gs)) < 1.3e-7 * np.max(np.abs(ref_gs))
+    assert np.max(np.abs(out2 - ref_w)) < 1.3e-7 * np.max(np.abs(ref_w))
+
+
+def test_wide_forward_brings_the_fp32_gradient_to_the_fp64_oracle():
+    """Value + gradient of the correlated-field model with fp32 fields through the emulated kernels: fp64 forward
+    transform with float arrays at both ends (io32), fp32 adjoint transform -- against the fp64 oracle on IDENTICAL
+    (fp32-rounded) inputs.  The all-fp32 forward leaves a coherent gain error of ~6e-8 on the signal, which the residual
+    N^-1 (s - d) amplifies (1e-5 .. 1e-3 of the gradient); with the wide forward every key is at the 1e-7 level."""
+    from oracle import nifty_oracle as orc
+
+    shape = (64, 64, 128)
+    cf = orc.CFModel(shape, None, orc.CFParams(offset_mean=2.0))
+    rng = np.random.default_rng(22)
+    x = {k: np.asarray(a) for k, a in cf.draw_latent(rng).items()}
+    data = cf.forward(x) + 0.1 * rng.normal(size=shape)
+    x["xi"] = x["xi"].astype(np.float32).astype(np.float64)
+    data32 = data.astype(np.float32)
+    lh = orc.Likelihood("gaussian", data32.astype(np.float64), icov=100.0)
+    val, grad = orc.Linearized(cf, lh, x).value_grad()
+    st = cf.amplitude_state(x)
+    pin = cf.geo.pindex.astype(np.int32)
+    oct_sl = tuple(slice(0, s // 2 + 1) for s in shape)
+    a64 = st["a"][pin]
+    xi32 = x["xi"].astype(np.float32)
+
+    def gradient(wide):
+        gs, value = np.empty(shape, dtype=np.float32), np.zeros(1)
+        f = Fuse()
+        f.pro, f.pidx, f.amp, f.field_octant = 1, pin.ctypes.data, st["a"].ctypes.data, 1
+        f.epi, f.out, f.scale, f.offset, f.value = 3, gs.ctypes.data, 1.0, 2.0, value.ctypes.data
+        f.lh_kind, f.nonlin, f.data, f.icov_scalar = 0, 0, data32.ctypes.data, 100.0
+        af = np.ascontiguousarray(a64[oct_sl] if wide else a64[oct_sl].astype(np.float32))
+        f.in_, f.afield, f.io32 = xi32.ctypes.data, af.ctypes.data, int(wide)
+        run(f, shape, np.float64 if wide else np.float32, fn="emu3_hartley_fused")
+        # adjoint: fp32 transform with the VJP epilogue (octant sums)
+        af32 = np.ascontiguousarray(a64[oct_sl].astype(np.float32))
+        gxi, w8, dummy = np.empty(shape, dtype=np.float32), np.zeros(af32.shape), np.zeros(cf.geo.nb)
+        f = Fuse()
+        f.pro, f.in_ = 0, gs.ctypes.data
+        f.epi, f.out, f.scale = 2, gxi.ctypes.data, 1.0
+        f.pidx, f.amp, f.xi, f.abar = pin.ctypes.data, st["a"].ctypes.data, xi32.ctypes.data, dummy.ctypes.data
+        f.afield, f.field_octant, f.w8 = af32.ctypes.data, 1, w8.ctypes.data
+        f.addend, f.addend_scale = xi32.ctypes.data, 1.0
+        run(f, shape, np.float32, fn="emu3_hartley_fused")
+        abar = np.bincount(pin[oct_sl].ravel(), weights=w8.ravel(), minlength=cf.geo.nb)
+        out = cf.amplitude_vjp(st, abar)
+        out = {k: out[k] + x[k] for k in out}
+        out["xi"] = gxi.astype(np.float64)
+        prior = 0.5 * sum(float(np.sum(np.asarray(x[k]) ** 2)) for k in x)
+        return value[0] + prior, out
+
+    scale = max(float(np.max(np.abs(grad[k]))) for k in grad)
+
+    def worst(g):
+        return max(float(np.max(np.abs(g[k] - grad[k]))) / scale for k in grad)
+
+    v32, g32 = gradient(False)
+    v64, g64 = gradient(True)
+    assert abs(v64 - val) < 1e-12 * abs(val)
+    assert worst(g64) < 1e-6, worst(g64)
+    assert worst(g32) > 3 * worst(g64)  # what the wide forward removes
+    per_key = max(float(np.max(np.abs(g64[k] - grad[k]))) / float(np.max(np.abs(grad[k]))) for k in grad)
+    assert per_key < 1e-5, per_key

@@ -128,3 +128,13 @@ def test_optimize_kl(case):
     mean, kl = orc.optimize_kl(cf, lh, 2, m["n_samples"], icf, mk, seed=m["seed"] + 2, geo_minimizer_factory=geo)
     # two full geoVI iterations amplify rounding differences (see make_golden.py GEO_CG note)
     assert gl.lat_relerr(mean, gl.latent(z, "okl_mean")) < (2e-3 if m["geo"] else 1e-6)
+
+
+def test_natural_geometry_shortcut_equals_the_direct_restatement():
+    """oracle.power_geometry_natural (bins from integer k^2, slab-parallel, int32 -- what lets the oracle run at 1024^3)
+    against oracle.power_geometry, which is pinned to the reference by tests/golden/geometry.npz."""
+    for shape in ((64, 64), (32, 48), (32, 32, 32), (16, 24, 40)):
+        a, b = orc.power_geometry(shape), orc.power_geometry_natural(shape, workers=3)
+        assert np.array_equal(a.pindex, b.pindex) and np.array_equal(a.rho, b.rho)
+        assert np.max(np.abs(a.k_lengths - b.k_lengths)) < 1e-13 * a.k_lengths.max()
+        assert np.allclose(a.dvol, b.dvol, rtol=0, atol=0) and a.h_dvol == b.h_dvol and a.total_volume == b.total_volume
