@@ -159,6 +159,23 @@ __global__ void __launch_bounds__(NK_VEC_THREADS) k_map(int64_t n, F f, int cu_m
   }
 }
 
+// Element-wise maps WITHOUT reductions, 16-byte vectors: one vector per thread, one 4 KiB piece per workgroup, as many
+// workgroups as pieces (no persistent loop).  The dispatcher hands the workgroups out in order, so at any moment the chip works
+// on ONE narrow window of each stream (~10 MiB) instead of 2048 chunks spread over the whole array: a 4 GiB copy runs at
+// 6.2 TB/s in this shape -- the float4 copy figure of MI355X_MICROARCH.md -- against 5.1-5.3 TB/s for the block-cyclic 64 KiB
+// chunks of k_map, 4.5-5.4 TB/s grid-stride, 5.7 / 5.2 TB/s for pieces of 8 / 64 KiB (tools/micro/copy_ceiling.hip,
+// launch_shape.hip; profiles/r04_copy_ceiling.log).  Kernels with reductions keep k_map: one partial per piece would be 2^18
+// partials per sum, and the seven-stream CG update gains nothing from the shape (5.57 vs 5.53 TB/s).
+template <typename T, typename F>
+__global__ void __launch_bounds__(NK_VEC_THREADS) k_map_flat(int64_t n, F f) {
+  static_assert(F::NRED == 0, "k_map_flat: maps without reductions only");
+  constexpr int V = VecOf<T>::N;
+  const int64_t nvec = n / V;
+  const int64_t i = (int64_t)blockIdx.x * NK_VEC_THREADS + threadIdx.x;
+  if (i < nvec) f.template run<V>(i * V, nullptr);
+  if (i < n - nvec * V) f.template run<1>(nvec * V + i, nullptr);  // scalar tail (< V elements)
+}
+
 template <typename T, int V>
 __device__ __forceinline__ void nk_ld(const T* p, int64_t i, T (&v)[V]) {
   if constexpr (V == 1)
@@ -191,6 +208,14 @@ static int nk_launch_map(int64_t n, const F& f, bool aligned, hipStream_t st, co
   // The grid stays a function of n only, so the sums stay bit-reproducible.
   if (aligned) {
     const int64_t nvec = n / VecOf<T>::N;
+    if constexpr (F::NRED == 0) {
+      static const int flat_env = nk_vec_env_int("NK_VEC_FLAT", 1);  // 0: the block-cyclic chunks for every map (A/B)
+      const int64_t pieces = (nvec + NK_VEC_THREADS - 1) / NK_VEC_THREADS;
+      if (flat_env && pieces > NK_MAX_BLOCKS && pieces < ((int64_t)1 << 31)) {
+        hipLaunchKernelGGL((k_map_flat<T, F>), dim3((unsigned)pieces), dim3(NK_VEC_THREADS), 0, st, n, f);
+        return nk_check_launch(what);
+      }
+    }
     const int grid = F::NRED > 0 ? nk_grid_red(nvec) : nk_grid(nvec > 0 ? nvec : 1);
     hipLaunchKernelGGL((k_map<T, F, true>), dim3(grid), dim3(NK_VEC_THREADS), 0, st, n, f, cu_max, rs);
   } else {
