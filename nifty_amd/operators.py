@@ -30,11 +30,55 @@ def is_operator(x):
     return isinstance(x, Operator)
 
 
+def _operand_kind(x):
+    """What an operator is being applied to / combined with: 'lin', 'field', 'op', 'number' or None."""
+    if isinstance(x, Linearization):
+        return "lin"
+    if is_fieldlike(x):
+        return "field"
+    if isinstance(x, Operator):
+        return "op"
+    if isinstance(x, Number):
+        return "number"
+    return None
+
+
+def _identity_on(dom):
+    """Identity as a linear operator: one scaling by 1 per DomainTuple (a block per key of a MultiDomain)."""
+    dom = makeDomain(dom)
+    if isinstance(dom, MultiDomain):
+        return BlockDiagonalOperator(dom, {key: ScalingOperator(sub, 1.0) for key, sub in dom.items()})
+    return ScalingOperator(dom, 1.0)
+
+
+def _compose(outer, inner):
+    """`outer` after `inner`.  When the seam does not match (MultiDomains with different key sets) every key only one
+    side knows is routed around the other side by an identity block, so that the composition acts on / returns the union
+    (reference semantics of Operator.__matmul__ / partial_insert, operators/operator.py:177-212)."""
+    if inner.target is outer.domain:
+        for trivial, other in ((inner, outer), (outer, inner)):
+            if trivial.isIdentity():
+                return other
+        return _OpChain.make((outer, inner))
+    seam = (outer.domain, inner.target)
+    if not all(isinstance(d, MultiDomain) for d in seam):
+        raise TypeError("operators with different DomainTuples at the seam cannot be composed")
+    union = MultiDomain.union(list(seam))
+
+    def routed(op, own, other):
+        missing = [k for k in other.keys() if k not in own.keys()]
+        return op if not missing else op + _identity_on(MultiDomain.make({k: union[k] for k in missing}))
+
+    return routed(outer, outer.domain, inner.target) @ routed(inner, inner.target, outer.domain)
+
+
 # ================================================================================================
 # Operator
 # ================================================================================================
 class Operator:
-    """Possibly nonlinear map between (Multi)Domains (reference operators/operator.py:30-430)."""
+    """Possibly nonlinear map between (Multi)Domains (reference operators/operator.py:30-430).  The arithmetic of
+    operators is table-driven (`_ARITHMETIC`): an operand is classified once (_operand_kind) and the table says how
+    `self (+|-|*) operand` is built."""
 
     @property
     def domain(self):
@@ -55,111 +99,69 @@ class Operator:
         return self.apply(x.extract(self.domain))
 
     def _check_input(self, x):
-        if not (is_fieldlike(x) or is_linearization(x)):
+        kind = _operand_kind(x)
+        if kind not in ("lin", "field"):
             raise TypeError("operators act on Fields, MultiFields or Linearizations")
-        if is_linearization(x):
-            if not isinstance(x.jac, ScalingOperator) or x.jac._factor != 1:
-                raise ValueError("apply() expects a Linearization with trivial Jacobian")
+        if kind == "lin" and not x.jac.isIdentity():
+            raise ValueError("apply() expects a Linearization with trivial Jacobian")
         _same_domain(self._domain, x.domain)
 
     def __call__(self, x):
-        if is_linearization(x):
-            return self.apply(x.trivial_jac()).prepend_jac(x.jac)
-        if is_fieldlike(x):
-            return self.apply(x)
-        if is_operator(x):
-            return self @ x
-        raise TypeError(f"cannot apply operator to {type(x)}")
+        try:
+            return _CALL[_operand_kind(x)](self, x)
+        except KeyError:
+            raise TypeError(f"cannot apply operator to {type(x)}") from None
 
     # -- algebra ---------------------------------------------------------------------------------
     def __matmul__(self, x):
         from .energy_operators import LikelihoodEnergyOperator
 
-        if is_operator(x) and not isinstance(x, LikelihoodEnergyOperator):
-            if x.target is self.domain:
-                if x.isIdentity():
-                    return self
-                if self.isIdentity():
-                    return x
-                return _OpChain.make((self, x))
-            return self.partial_insert(x)
-        return NotImplemented
+        if not is_operator(x) or isinstance(x, LikelihoodEnergyOperator):
+            return NotImplemented
+        return _compose(self, x)
 
     def partial_insert(self, x):
-        if not (isinstance(self.domain, MultiDomain) and isinstance(x.target, MultiDomain)):
-            raise TypeError("partial_insert needs MultiDomains")
-        bigdom = MultiDomain.union([self.domain, x.target])
-        k1, k2 = set(self.domain.keys()), set(x.target.keys())
-        le, ri = k2 - k1, k1 - k2
-        leop, riop = self, x
-        if ri:
-            riop = riop + Operator.identity_operator(MultiDomain.make({k: bigdom[k] for k in ri}))
-        if le:
-            leop = leop + Operator.identity_operator(MultiDomain.make({k: bigdom[k] for k in le}))
-        return leop @ riop
+        if not is_operator(x) or not isinstance(self.domain, MultiDomain) or not isinstance(x.target, MultiDomain):
+            raise TypeError("partial_insert needs operators on MultiDomains")
+        return _compose(self, x)
 
-    @staticmethod
-    def identity_operator(dom):
-        dom = makeDomain(dom)
-        if isinstance(dom, DomainTuple):
-            return ScalingOperator(dom, 1.0)
-        return BlockDiagonalOperator(dom, {k: ScalingOperator(d, 1.0) for k, d in dom.items()})
+    identity_operator = staticmethod(_identity_on)
 
     def scale(self, factor):
         if not isinstance(factor, Number):
             raise TypeError(".scale() takes a number as input")
-        if factor == 1:
-            return self
-        return ScalingOperator(self.target, factor)(self)
+        return self if factor == 1 else ScalingOperator(self.target, factor)(self)
 
     def __neg__(self):
         return self.scale(-1)
 
-    def __mul__(self, x):
-        if is_operator(x):
-            return _OpProd(self, x)
-        if isinstance(x, Number):
-            return self.scale(x)
-        if is_fieldlike(x):
-            return makeOp(x) @ self
-        return NotImplemented
+    def _arithmetic(self, other, sym):
+        rule = _ARITHMETIC.get((sym, _operand_kind(other)))
+        return NotImplemented if rule is None else rule(self, other)
 
-    __rmul__ = __mul__
+    def __mul__(self, x):
+        return self._arithmetic(x, "*")
 
     def __add__(self, x):
-        if is_operator(x):
-            return _OpSum(self, x)
-        if isinstance(x, Number):
-            return Adder(full(self.target, float(x))) @ self
-        if is_fieldlike(x):
-            return Adder(x) @ self
-        return NotImplemented
-
-    __radd__ = __add__
+        return self._arithmetic(x, "+")
 
     def __sub__(self, x):
-        if is_operator(x):
-            return _OpSum(self, -x)
-        if isinstance(x, Number):
-            return Adder(full(self.target, float(x)), neg=True) @ self
-        if is_fieldlike(x):
-            return Adder(x, neg=True) @ self
-        return NotImplemented
+        return self._arithmetic(x, "-")
+
+    __rmul__ = __mul__
+    __radd__ = __add__
 
     def __rsub__(self, x):
         return x + (-self)
 
     def __truediv__(self, x):
-        if isinstance(x, Number):
+        kind = _operand_kind(x)
+        if kind == "number":
             return self.scale(1.0 / x)
-        if is_operator(x):
-            return self * x.reciprocal()
-        return NotImplemented
+        return self * x.reciprocal() if kind == "op" else NotImplemented
 
     def __pow__(self, power):
-        if isinstance(power, Number):
-            return self.ptw("power", power)
-        return NotImplemented
+        return self.ptw("power", power) if isinstance(power, Number) else NotImplemented
 
     def __getitem__(self, key):
         if not isinstance(self.target, MultiDomain):
@@ -219,13 +221,47 @@ class Operator:
         return self.__class__.__name__
 
 
-for _fn in ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "abs", "sin", "cos", "arctan"):
-    def _mk(fn):
-        def method(self):
-            return self.ptw(fn)
-        method.__name__ = fn
-        return method
-    setattr(Operator, _fn, _mk(_fn))
+def _shifted(op, constant, negate):
+    """x -> op(x) +/- constant (a number fills the target)."""
+    if isinstance(constant, Number):
+        constant = full(op.target, float(constant))
+    return Adder(constant, neg=negate) @ op
+
+
+# operand kind -> what `op(operand)` means
+_CALL = {
+    "field": lambda op, x: op.apply(x),
+    # differentiate at the value, then chain the incoming Jacobian behind the result
+    "lin": lambda op, x: op.apply(x.trivial_jac()).prepend_jac(x.jac),
+    "op": lambda op, x: op @ x,
+}
+
+# (symbol, operand kind) -> builder of `op (symbol) operand`
+_ARITHMETIC = {
+    ("*", "op"): lambda op, o: _OpProd(op, o),
+    ("*", "number"): lambda op, o: op.scale(o),
+    ("*", "field"): lambda op, o: makeOp(o) @ op,
+    ("+", "op"): lambda op, o: _OpSum(op, o),
+    ("+", "number"): lambda op, o: _shifted(op, o, False),
+    ("+", "field"): lambda op, o: _shifted(op, o, False),
+    ("-", "op"): lambda op, o: _OpSum(op, -o),
+    ("-", "number"): lambda op, o: _shifted(op, o, True),
+    ("-", "field"): lambda op, o: _shifted(op, o, True),
+}
+
+_POINTWISE_METHODS = ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "abs", "sin", "cos", "arctan")
+
+
+def _install_pointwise(cls, names):
+    """cls.exp(), cls.log(), ... = cls.ptw("exp"), ..."""
+    for name in names:
+        def method(self, _name=name):
+            return self.ptw(_name)
+        method.__name__ = name
+        setattr(cls, name, method)
+
+
+_install_pointwise(Operator, _POINTWISE_METHODS)
 
 
 class _FunctionApplier(Operator):
@@ -243,127 +279,110 @@ class _FunctionApplier(Operator):
         return f"_FunctionApplier ('{self._funcname}')"
 
 
+def _indented(title, parts):
+    return title + ":\n" + "\n".join("  " + repr(p).replace("\n", "\n  ") for p in parts)
+
+
 class _OpChain(Operator):
+    """op_0 o op_1 o ... o op_n (the LAST one acts first); nested chains are spliced by make()."""
+
     def __init__(self, ops, _callingfrommake=False):
         if not _callingfrommake:
             raise NotImplementedError
         self._ops = tuple(ops)
+        for later, earlier in zip(self._ops, self._ops[1:]):
+            _same_domain(later.domain, earlier.target)
         self._domain, self._target = self._ops[-1].domain, self._ops[0].target
-        for a, b in zip(self._ops[:-1], self._ops[1:]):
-            _same_domain(a.domain, b.target)
 
     @classmethod
     def make(cls, ops):
-        flat = []
-        for op in ops:
-            flat.extend(op._ops if isinstance(op, _OpChain) else [op])
-        return flat[0] if len(flat) == 1 else cls(flat, _callingfrommake=True)
+        links = tuple(link for op in ops for link in (op._ops if isinstance(op, _OpChain) else (op,)))
+        return links[0] if len(links) == 1 else cls(links, _callingfrommake=True)
 
     def apply(self, x):
         self._check_input(x)
-        for op in reversed(self._ops):
+        for op in self._ops[::-1]:
             x = op(x)
         return x
 
     def __repr__(self):
-        return "_OpChain:\n" + "\n".join("  " + repr(o).replace("\n", "\n  ") for o in self._ops)
+        return _indented("_OpChain", self._ops)
 
 
 def domain_union(domains):
-    if all(isinstance(d, DomainTuple) for d in domains):
-        for d in domains[1:]:
-            _same_domain(domains[0], d)
-        return domains[0]
-    return MultiDomain.union(domains)
+    domains = list(domains)
+    if any(isinstance(d, MultiDomain) for d in domains):
+        return MultiDomain.union(domains)
+    for d in domains[1:]:
+        _same_domain(domains[0], d)
+    return domains[0]
+
+
+def _evaluate_terms(x, ops):
+    """[op(restriction of x to op.domain) for op in ops]: plain values for a field, Linearizations (each w.r.t. its own
+    restriction, carrying x's want_metric) for a Linearization."""
+    if not is_linearization(x):
+        return [op.force(x) for op in ops]
+    return [op(Linearization.make_var(x.val.extract(op.domain), x.want_metric)) for op in ops]
+
+
+def sum_of_operators(x, ops):
+    """sum_i ops[i](x) where every operator sees the part of x it is defined on (reference operator.py:619-641).  The
+    sum rule of values, Jacobians and metrics is the one of Linearization.__add__; a metric survives only if every term
+    brings one."""
+    terms = _evaluate_terms(x, ops)
+    total = terms[0]
+    for term in terms[1:]:
+        total = total + term if is_linearization(x) else total.flexible_addsub(term, False)
+    return x.new(total.val, total.jac, total.metric) if is_linearization(x) else total
 
 
 class _OpProd(Operator):
-    """Pointwise product of two operators with the product rule (operator.py:555-600)."""
+    """Pointwise product of two operators (reference operator.py:555-600); the product rule is Linearization.__mul__."""
 
     def __init__(self, op1, op2):
-        self._domain = domain_union((op1.domain, op2.domain))
         if op1.target != op2.target:
             raise ValueError("target mismatch")
-        self._target = op1.target
         self._op1, self._op2 = op1, op2
+        self._domain, self._target = domain_union((op1.domain, op2.domain)), op1.target
 
     def apply(self, x):
         self._check_input(x)
-        lin = is_linearization(x)
-        wm = x.want_metric if lin else False
-        v = x.val if lin else x
-        v1, v2 = v.extract(self._op1.domain), v.extract(self._op2.domain)
-        if not lin:
-            return self._op1(v1) * self._op2(v2)
-        l1 = self._op1(Linearization.make_var(v1, wm))
-        l2 = self._op2(Linearization.make_var(v2, wm))
-        jac = makeOp(l1.val)(l2.jac)._myadd(makeOp(l2.val)(l1.jac), False)
-        return l1.new(l1.val * l2.val, jac)
+        left, right = _evaluate_terms(x, (self._op1, self._op2))
+        prod = left * right
+        return x.new(prod.val, prod.jac) if is_linearization(x) else prod
 
     def __repr__(self):
-        return "_OpProd:\n  " + repr(self._op1) + "\n  " + repr(self._op2)
+        return _indented("_OpProd", (self._op1, self._op2))
 
 
 class _OpSum(Operator):
     def __init__(self, op1, op2):
-        self._domain = domain_union((op1.domain, op2.domain))
-        self._target = domain_union((op1.target, op2.target))
         self._op1, self._op2 = op1, op2
+        self._domain, self._target = (domain_union((op1.domain, op2.domain)), domain_union((op1.target, op2.target)))
 
     def apply(self, x):
         self._check_input(x)
-        return self._apply_operator_sum(x, [self._op1, self._op2])
+        return sum_of_operators(x, (self._op1, self._op2))
 
-    @staticmethod
-    def _apply_operator_sum(x, ops):
-        """operator.py:619-641"""
-        if not is_linearization(x):
-            res = None
-            for op in ops:
-                tmp = op.force(x)
-                res = tmp if res is None else res.flexible_addsub(tmp, False)
-            return res
-        wm = x.want_metric
-        lins = [op(Linearization.make_var(x.val.extract(op.domain), wm)) for op in ops]
-        val, jac = lins[0].val, lins[0].jac
-        for ll in lins[1:]:
-            val = val.flexible_addsub(ll.val, False)
-            jac = jac._myadd(ll.jac, False)
-        res = x.new(val, jac)
-        if all(ll.metric is not None for ll in lins):
-            met = lins[0].metric
-            for ll in lins[1:]:
-                met = met._myadd(ll.metric, False)
-            res = res.add_metric(met)
-        return res
+    _apply_operator_sum = staticmethod(sum_of_operators)
 
     def __repr__(self):
-        return "_OpSum:\n  " + repr(self._op1) + "\n  " + repr(self._op2)
+        return _indented("_OpSum", (self._op1, self._op2))
 
 
 # ================================================================================================
 # Linearization (forward-mode AD object)
 # ================================================================================================
 class Linearization:
-    """Value + Jacobian (+ metric) of an operator at a point (reference linearization.py:26-435)."""
+    """Value + Jacobian (+ metric) of an operator at a point (reference linearization.py:26-435).
+
+    All arithmetic funnels into two rules: `_plus` (sum rule; metrics add, and only if both sides have one) and `_times`
+    (product rule; no metric survives a product)."""
 
     def __init__(self, val, jac, metric=None, want_metric=False):
         _same_domain(val.domain, jac.target)
         self._val, self._jac, self._metric, self._want_metric = val, jac, metric, want_metric
-
-    def new(self, val, jac, metric=None):
-        return Linearization(val, jac, metric, self._want_metric)
-
-    def trivial_jac(self):
-        return Linearization.make_var(self._val, self._want_metric)
-
-    def prepend_jac(self, jac):
-        if jac.isIdentity():
-            return self
-        new_jac = jac if self._jac.isIdentity() else self._jac @ jac
-        if self._metric is None:
-            return self.new(self._val, new_jac)
-        return self.new(self._val, new_jac, SandwichOperator.make(jac, self._metric))
 
     domain = property(lambda self: self._jac.domain)
     target = property(lambda self: self._jac.target)
@@ -373,88 +392,9 @@ class Linearization:
     metric = property(lambda self: self._metric)
     device_id = property(lambda self: self._val.device_id)
 
-    @property
-    def gradient(self):
-        return self._jac.adjoint_times(Field.scalar(1.0).at(self._val.device_id))
-
-    def __getitem__(self, name):
-        if not isinstance(self.target, MultiDomain):
-            raise TypeError("not subscriptable")
-        return self.new(self._val[name], ducktape(None, self._jac.target, name)(self._jac))
-
-    def __neg__(self):
-        if self._metric is not None:
-            raise RuntimeError("Cannot negate operators with metric")
-        return self.new(-self._val, -self._jac)
-
-    @property
-    def real(self):
-        return self.new(self._val.real, Realizer(self._jac.target)(self._jac))
-
-    def _myadd(self, other, neg):
-        if np.isscalar(other) or is_fieldlike(other):
-            return self.new(self._val - other if neg else self._val + other, self._jac, self._metric)
-        if not is_linearization(other):
-            return NotImplemented
-        met = None
-        if self._metric is not None and other._metric is not None:
-            met = self._metric._myadd(other._metric, neg)
-        return self.new(self._val.flexible_addsub(other._val, neg), self._jac._myadd(other._jac, neg), met)
-
-    def __add__(self, o): return self._myadd(o, False)
-    __radd__ = __add__
-    def __sub__(self, o): return self._myadd(o, True)
-    def __rsub__(self, o): return (-self).__add__(o)
-
-    def __mul__(self, other):
-        if np.isscalar(other):
-            if other == 1:
-                return self
-            met = None if self._metric is None else self._metric.scale(other)
-            return self.new(self._val * other, self._jac.scale(other), met)
-        if is_fieldlike(other):
-            _same_domain(self.target, other.domain)
-            return self.new(self._val * other, makeOp(other)(self._jac))
-        if is_linearization(other):
-            _same_domain(self.target, other.target)
-            return self.new(self._val * other._val,
-                            makeOp(other._val)(self._jac)._myadd(makeOp(self._val)(other._jac), False))
-        return NotImplemented
-
-    __rmul__ = __mul__
-
-    def __truediv__(self, other):
-        if np.isscalar(other):
-            return self.__mul__(1.0 / other)
-        return self.__mul__(other.ptw("reciprocal"))
-
-    def __rtruediv__(self, other):
-        return self.ptw("reciprocal").__mul__(other)
-
-    def __pow__(self, power):
-        if np.isscalar(power):
-            return self.ptw("power", power)
-        return NotImplemented
-
-    def vdot(self, other):
-        if is_fieldlike(other):
-            return self.new(self._val.vdot(other.at(self._val.device_id)), VdotOperator(other)(self._jac))
-        return self.new(self._val.vdot(other._val),
-                        VdotOperator(self._val)(other._jac) + VdotOperator(other._val)(self._jac))
-
-    def sum(self, spaces=None):
-        return self.new(self._val.sum(spaces) if spaces is not None else Field.scalar(self._val.s_sum()).at(self.device_id),
-                        ContractionOperator(self._jac.target, spaces)(self._jac))
-
-    def ptw(self, op, *args, **kwargs):
-        f, df = self._val.ptw_with_deriv(op, *args, **kwargs)
-        return self.new(f, makeOp(df)(self._jac))
-
-    def add_metric(self, metric):
-        return self.new(self._val, self._jac, metric)
-
-    def with_want_metric(self):
-        return Linearization(self._val, self._jac, self._metric, True)
+    # -- constructors ------------------------------------------------------------------------------
+    def new(self, val, jac, metric=None):
+        return Linearization(val, jac, metric, self._want_metric)
 
     @staticmethod
     def make_var(field, want_metric=False):
@@ -464,19 +404,114 @@ class Linearization:
     def make_const(field, want_metric=False):
         return Linearization(field, NullOperator(field.domain, field.domain), want_metric=want_metric)
 
+    def trivial_jac(self):
+        return Linearization.make_var(self._val, self._want_metric)
 
-for _fn in ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "abs", "arctan"):
-    def _mk2(fn):
-        def method(self):
-            return self.ptw(fn)
-        method.__name__ = fn
-        return method
-    setattr(Linearization, _fn, _mk2(_fn))
+    def add_metric(self, metric):
+        return self.new(self._val, self._jac, metric)
+
+    def with_want_metric(self):
+        return Linearization(self._val, self._jac, self._metric, True)
+
+    def prepend_jac(self, jac):
+        """Chain rule: this linearisation was taken w.r.t. a quantity whose own Jacobian is `jac`."""
+        if jac.isIdentity():
+            return self
+        pulled_back = None if self._metric is None else SandwichOperator.make(jac, self._metric)
+        return self.new(self._val, jac if self._jac.isIdentity() else self._jac @ jac, pulled_back)
+
+    @property
+    def gradient(self):
+        return self._jac.adjoint_times(Field.scalar(1.0).at(self._val.device_id))
+
+    # -- the two rules -------------------------------------------------------------------------------
+    def _plus(self, other, minus):
+        kind = _operand_kind(other)
+        if kind in ("field", "number") or np.isscalar(other):  # a constant shifts the value only
+            return self.new(self._val - other if minus else self._val + other, self._jac, self._metric)
+        if kind != "lin":
+            return NotImplemented
+        both = self._metric is not None and other._metric is not None
+        return self.new(self._val.flexible_addsub(other._val, minus), self._jac._myadd(other._jac, minus),
+                        self._metric._myadd(other._metric, minus) if both else None)
+
+    _myadd = _plus
+
+    def _times(self, other):
+        kind = _operand_kind(other)
+        if kind == "number" or np.isscalar(other):
+            if other == 1:
+                return self
+            return self.new(self._val * other, self._jac.scale(other), None if self._metric is None else self._metric.scale(other))
+        if kind not in ("field", "lin"):
+            return NotImplemented
+        _same_domain(self.target, other.domain if kind == "field" else other.target)
+        if kind == "field":
+            return self.new(self._val * other, makeOp(other)(self._jac))
+        cross = makeOp(other._val)(self._jac)._myadd(makeOp(self._val)(other._jac), False)  # v dJ_u + u dJ_v
+        return self.new(self._val * other._val, cross)
+
+    def __add__(self, o): return self._plus(o, False)
+    def __sub__(self, o): return self._plus(o, True)
+    def __rsub__(self, o): return (-self)._plus(o, False)
+    __radd__ = __add__
+    __mul__ = __rmul__ = _times
+
+    def __neg__(self):
+        if self._metric is not None:
+            raise RuntimeError("Cannot negate operators with metric")
+        return self.new(-self._val, -self._jac)
+
+    def __truediv__(self, other):
+        return self._times(1.0 / other if np.isscalar(other) else other.ptw("reciprocal"))
+
+    def __rtruediv__(self, other):
+        return self.ptw("reciprocal")._times(other)
+
+    def __pow__(self, power):
+        return self.ptw("power", power) if np.isscalar(power) else NotImplemented
+
+    # -- structure -----------------------------------------------------------------------------------
+    def __getitem__(self, name):
+        if not isinstance(self.target, MultiDomain):
+            raise TypeError("not subscriptable")
+        return self.new(self._val[name], ducktape(None, self._jac.target, name)(self._jac))
+
+    @property
+    def real(self):
+        return self.new(self._val.real, Realizer(self._jac.target)(self._jac))
+
+    def vdot(self, other):
+        if is_fieldlike(other):
+            return self.new(self._val.vdot(other.at(self._val.device_id)), VdotOperator(other)(self._jac))
+        return self.new(self._val.vdot(other._val),
+                        VdotOperator(self._val)(other._jac) + VdotOperator(other._val)(self._jac))
+
+    def sum(self, spaces=None):
+        total = self._val.sum(spaces) if spaces is not None else Field.scalar(self._val.s_sum()).at(self.device_id)
+        return self.new(total, ContractionOperator(self._jac.target, spaces)(self._jac))
+
+    def ptw(self, op, *args, **kwargs):
+        f, df = self._val.ptw_with_deriv(op, *args, **kwargs)
+        return self.new(f, makeOp(df)(self._jac))
+
+
+_install_pointwise(Linearization, ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "abs", "arctan"))
 
 
 # ================================================================================================
 # LinearOperator
 # ================================================================================================
+def _mode_index(mode):
+    """0 TIMES, 1 ADJOINT_TIMES, 2 INVERSE_TIMES, 3 ADJOINT_INVERSE_TIMES for the one-hot mode, else -1.  The index is a
+    two-bit number (bit 0: adjoint, bit 1: inverse), so viewing an operator through a transformation is an XOR."""
+    return mode.bit_length() - 1 if mode in (1, 2, 4, 8) else -1
+
+
+def _mode_seen_through(mode, trafo):
+    return 1 << (_mode_index(mode) ^ trafo)
+
+
 class LinearOperator(Operator):
     """Linear map with TIMES / ADJOINT_TIMES / INVERSE_TIMES / ADJOINT_INVERSE_TIMES modes
     (reference operators/linear_operator.py:24-262)."""
@@ -484,45 +519,32 @@ class LinearOperator(Operator):
     TIMES, ADJOINT_TIMES, INVERSE_TIMES, ADJOINT_INVERSE_TIMES = 1, 2, 4, 8
     INVERSE_ADJOINT_TIMES = 8
     ADJOINT_BIT, INVERSE_BIT = 1, 2
-    _ilog = (-1, 0, 1, -1, 2, -1, -1, -1, 3)
-    _validMode = (False, True, True, False, True, False, False, False, True)
-    _modeTable = ((1, 2, 4, 8), (2, 1, 8, 4), (4, 8, 1, 2), (8, 4, 2, 1))
-    _backwards = 6
+    _backwards = 6   # modes in which a chain runs front to back (ADJOINT_TIMES, INVERSE_TIMES)
     _all_ops = 15
 
     @staticmethod
     def _flip_capability(cap, trafo):
-        res = 0
-        for bit in (1, 2, 4, 8):
-            if cap & bit:
-                res |= LinearOperator._modeTable[trafo][LinearOperator._ilog[bit]]
-        return res
+        return sum(_mode_seen_through(bit, trafo) for bit in (1, 2, 4, 8) if cap & bit)
 
     @staticmethod
     def _add_inverse_capability(cap):
         return cap | LinearOperator._flip_capability(cap, LinearOperator.INVERSE_BIT)
 
     def _dom(self, mode):
-        return self.domain if (mode & 9) else self.target
+        """where the input of `mode` lives: TIMES and ADJOINT_INVERSE_TIMES read the domain"""
+        return self.domain if _mode_index(mode) in (0, 3) else self.target
 
     def _tgt(self, mode):
-        return self.domain if (mode & 6) else self.target
+        return self.target if _mode_index(mode) in (0, 3) else self.domain
 
     def _flip_modes(self, trafo):
-        return self if trafo == 0 else OperatorAdapter(self, trafo)
+        return OperatorAdapter(self, trafo) if trafo else self
 
-    @property
-    def inverse(self):
-        return self._flip_modes(self.INVERSE_BIT)
+    inverse = property(lambda self: self._flip_modes(LinearOperator.INVERSE_BIT))
+    adjoint = property(lambda self: self._flip_modes(LinearOperator.ADJOINT_BIT))
+    capability = property(lambda self: self._capability)
 
-    @property
-    def adjoint(self):
-        return self._flip_modes(self.ADJOINT_BIT)
-
-    @property
-    def capability(self):
-        return self._capability
-
+    # -- algebra: linear operators stay linear operators ------------------------------------------------
     def __matmul__(self, other):
         if is_operator(other) and other.isIdentity():
             return self
@@ -531,50 +553,42 @@ class LinearOperator(Operator):
         return Operator.__matmul__(self, other)
 
     def __rmatmul__(self, other):
-        if isinstance(other, LinearOperator):
-            return ChainOperator.make([other, self])
-        return NotImplemented
+        return ChainOperator.make([other, self]) if isinstance(other, LinearOperator) else NotImplemented
 
     def _myadd(self, other, oneg):
         return SumOperator.make((self, other), (False, oneg))
 
     def __add__(self, other):
-        if isinstance(other, LinearOperator):
-            return self._myadd(other, False)
-        return Operator.__add__(self, other)
-
-    __radd__ = __add__
+        return self._myadd(other, False) if isinstance(other, LinearOperator) else Operator.__add__(self, other)
 
     def __sub__(self, other):
-        if isinstance(other, LinearOperator):
-            return self._myadd(other, True)
-        return Operator.__sub__(self, other)
+        return self._myadd(other, True) if isinstance(other, LinearOperator) else Operator.__sub__(self, other)
 
-    def __neg__(self):
-        return self.scale(-1)
+    __radd__ = __add__
 
     def scale(self, factor):
         if not isinstance(factor, Number):
             raise TypeError(".scale() takes a number as input")
-        if factor == 1:
-            return self
-        return ChainOperator.make([ScalingOperator(self.target, factor), self])
+        return self if factor == 1 else ChainOperator.make([ScalingOperator(self.target, factor), self])
+
+    def __neg__(self):
+        return self.scale(-1)
+
+    # -- application ---------------------------------------------------------------------------------------
+    def apply(self, x, mode):
+        raise NotImplementedError
 
     def force(self, x):
         return self.apply(x.extract(self.domain), self.TIMES)
 
-    def apply(self, x, mode):
-        raise NotImplementedError
-
     def __call__(self, x):
-        if self.isIdentity():
-            return x
-        if is_linearization(x):
-            return x.new(self(x.val), self).prepend_jac(x.jac)
-        if is_fieldlike(x):
+        kind = _operand_kind(x)
+        if self.isIdentity() or kind == "op":
+            return x if self.isIdentity() else self @ x
+        if kind == "field":
             return self.apply(x, self.TIMES)
-        if is_operator(x):
-            return self @ x
+        if kind == "lin":  # a linear map is its own Jacobian
+            return x.new(self.apply(x.val, self.TIMES), self).prepend_jac(x.jac)
         raise TypeError(f"cannot apply linear operator to {type(x)}")
 
     def times(self, x):
@@ -592,9 +606,9 @@ class LinearOperator(Operator):
     inverse_adjoint_times = adjoint_inverse_times
 
     def _check_mode(self, mode):
-        if not (0 <= mode < 9 and self._validMode[mode]):
+        if _mode_index(mode) < 0:
             raise NotImplementedError("invalid operator mode specified")
-        if mode & self.capability == 0:
+        if not mode & self.capability:
             raise NotImplementedError("requested operator mode is not supported")
 
     def _check_input(self, x, mode):
@@ -621,28 +635,30 @@ class EndomorphicOperator(LinearOperator):
 class OperatorAdapter(LinearOperator):
     """adjoint / inverse view of another operator (reference operator_adapter.py:22-68)."""
 
+    _VIEW = ("", "adjoint", "inverse", "adjoint inverse")
+
     def __init__(self, op, trafo):
-        self._op, self._trafo = op, int(trafo)
-        if self._trafo < 1 or self._trafo > 3:
+        trafo = int(trafo)
+        if trafo not in (1, 2, 3):
             raise ValueError("invalid operator transformation")
-        self._domain = op._dom(1 << self._trafo)
-        self._target = op._tgt(1 << self._trafo)
-        self._capability = self._flip_capability(op.capability, self._trafo)
+        self._op, self._trafo = op, trafo
+        seen_times = 1 << trafo   # what the wrapped operator executes for this view's TIMES
+        self._domain, self._target = op._dom(seen_times), op._tgt(seen_times)
+        self._capability = self._flip_capability(op.capability, trafo)
 
     def _flip_modes(self, trafo):
-        newtrafo = trafo ^ self._trafo
-        return self._op if newtrafo == 0 else OperatorAdapter(self._op, newtrafo)
+        combined = trafo ^ self._trafo
+        return OperatorAdapter(self._op, combined) if combined else self._op
 
     def apply(self, x, mode):
-        return self._op.apply(x, self._modeTable[self._trafo][self._ilog[mode]])
+        return self._op.apply(x, _mode_seen_through(mode, self._trafo))
 
     def draw_sample(self, from_inverse=False, device_id=-1):
-        if self._trafo & self.INVERSE_BIT:
-            return self._op.draw_sample(not from_inverse, device_id)
-        return self._op.draw_sample(from_inverse, device_id)
+        inverted = bool(self._trafo & self.INVERSE_BIT)
+        return self._op.draw_sample(from_inverse != inverted, device_id)
 
     def __repr__(self):
-        return "OperatorAdapter({}) of\n  ".format(["", "adjoint", "inverse", "adjoint inverse"][self._trafo]) + repr(self._op)
+        return f"OperatorAdapter({self._VIEW[self._trafo]}) of\n  {self._op!r}"
 
 
 class PrependKey(LinearOperator):
@@ -682,13 +698,12 @@ class InsertionOperator(Operator):
     partially constant input is inserted into an operator (Operator.simplify_for_constant_input)."""
 
     def __init__(self, target, cst_field):
-        if not isinstance(target, MultiDomain):
-            raise TypeError
-        if not isinstance(cst_field, MultiField):
-            raise TypeError
-        self._target = MultiDomain.make(target)
-        self._domain = MultiDomain.make({k: self._target[k] for k in self._target.keys() if k not in cst_field.keys()})
-        self._cst = cst_field
+        for arg, kind in ((target, MultiDomain), (cst_field, MultiField)):
+            if not isinstance(arg, kind):
+                raise TypeError(f"{kind.__name__} expected")
+        frozen = set(cst_field.keys())
+        self._cst, self._target = cst_field, MultiDomain.make(target)
+        self._domain = MultiDomain.make({k: sub for k, sub in self._target.items() if k not in frozen})
         self._jac = _KeyEmbedding(self._domain, self._target)
 
     def apply(self, x):
@@ -712,45 +727,39 @@ class NullOperator(LinearOperator):
 
 
 class ScalingOperator(EndomorphicOperator):
-    """Multiplication by a scalar (reference scaling_operator.py:25-139)."""
+    """Multiplication by a scalar (reference scaling_operator.py:25-139).  Every mode and every adjoint / inverse view is
+    the same operation with a transformed factor (`_factor_seen_through`)."""
 
     def __init__(self, domain, factor, sampling_dtype=None):
         if isinstance(factor, Field) and factor.shape == ():
             factor = factor.asnumpy()[()]
         if not np.isscalar(factor):
             raise TypeError("Scalar required")
-        self._domain = makeDomain(domain)
-        self._factor = factor
+        self._domain, self._factor, self._dtype = makeDomain(domain), factor, sampling_dtype
         self._capability = self._all_ops
-        self._dtype = sampling_dtype
 
     def isIdentity(self):
         return self._factor == 1
 
+    def _factor_seen_through(self, trafo):
+        fct = np.conj(self._factor) if trafo & self.ADJOINT_BIT else self._factor
+        return 1.0 / fct if trafo & self.INVERSE_BIT else fct
+
     def apply(self, x, mode):
         self._check_input(x, mode)
-        fct = self._factor
-        if fct == 1.0:
+        if self._factor == 1.0:
             return x
-        if fct == 0.0:
+        if self._factor == 0.0:  # (also the "inverse" modes: the reference returns zeros, scaling_operator.py:80-81)
             return full(x.domain, 0.0, x.device_id)
-        if mode & (self.ADJOINT_TIMES | self.ADJOINT_INVERSE_TIMES):
-            fct = np.conj(fct)
-        if mode & (self.INVERSE_TIMES | self.ADJOINT_INVERSE_TIMES):
-            fct = 1.0 / fct
-        return x * fct
+        return x * self._factor_seen_through(_mode_index(mode))
 
     def _flip_modes(self, trafo):
-        fct = self._factor
-        if trafo & self.ADJOINT_BIT:
-            fct = np.conj(fct)
-        if trafo & self.INVERSE_BIT:
-            fct = 1.0 / fct
-        return ScalingOperator(self._domain, fct, self._dtype)
+        return ScalingOperator(self._domain, self._factor_seen_through(trafo), self._dtype)
 
     def _get_fct(self, from_inverse):
         fct = self._factor
-        if np.imag(fct) != 0.0 or np.real(fct) < 0.0 or (np.real(fct) == 0.0 and from_inverse):
+        positive = np.imag(fct) == 0.0 and np.real(fct) >= 0.0 and not (np.real(fct) == 0.0 and from_inverse)
+        if not positive:
             raise ValueError("operator not positive definite")
         return 1.0 / np.sqrt(fct) if from_inverse else np.sqrt(fct)
 
@@ -763,21 +772,19 @@ class ScalingOperator(EndomorphicOperator):
                            std=float(self._get_fct(from_inverse)))
 
     def get_sqrt(self):
-        fct = self._get_fct(False)
-        return ScalingOperator(self._domain, fct)
+        return ScalingOperator(self._domain, self._get_fct(False))
 
     def __call__(self, other):
         res = EndomorphicOperator.__call__(self, other)
-        if is_linearization(other) and np.isreal(self._factor) and self._factor >= 0 and other.metric is not None:
-            sq = ScalingOperator(other.metric.domain, np.sqrt(self._factor), self._dtype)
-            res = res.add_metric(SandwichOperator.make(sq, other.metric))
+        if is_linearization(other) and other.metric is not None and np.isreal(self._factor) and self._factor >= 0:
+            # the metric of the scaled quantity: sqrt(factor) on both sides of the incoming one
+            root = ScalingOperator(other.metric.domain, np.sqrt(self._factor), self._dtype)
+            res = res.add_metric(SandwichOperator.make(root, other.metric))
         return res
 
     def __repr__(self):
-        s = f"ScalingOperator ({self._factor}"
-        if self._dtype is not None:
-            s += f", sampling dtype {self._dtype}"
-        return s + ")"
+        extra = "" if self._dtype is None else f", sampling dtype {self._dtype}"
+        return f"ScalingOperator ({self._factor}{extra})"
 
 
 class DiagonalOperator(EndomorphicOperator):
@@ -787,38 +794,38 @@ class DiagonalOperator(EndomorphicOperator):
     def __init__(self, diagonal, domain=None, spaces=None, sampling_dtype=None, _trafo=0):
         if not isinstance(diagonal, Field):
             raise TypeError("Field object required")
-        self._dtype, self._trafo = sampling_dtype, _trafo
-        self._domain = diagonal.domain if domain is None else DomainTuple.make(domain)
+        dom = diagonal.domain if domain is None else DomainTuple.make(domain)
         if spaces is None:
-            self._spaces = None
-            _same_domain(diagonal.domain, self._domain)
-            self._ldiag = diagonal.val
+            _same_domain(diagonal.domain, dom)
+            active, ldiag = None, diagonal.val
         else:
-            spaces = (spaces,) if np.isscalar(spaces) else tuple(spaces)
-            if len(spaces) != len(diagonal.domain):
-                raise ValueError("spaces and domain must have the same length")
-            for i, j in enumerate(spaces):
-                if diagonal.domain[i] != self._domain[j]:
-                    raise ValueError("Mismatch between:\n{}\nand:\n{}".format(diagonal.domain[i], self._domain[j]))
-            self._spaces = None if spaces == tuple(range(len(self._domain))) else spaces
-            if self._spaces is None:
-                self._ldiag = diagonal.val
-            else:
-                active = [a for s in spaces for a in self._domain.axes[s]]
-                shp = [n if i in active else 1 for i, n in enumerate(self._domain.shape)]
-                self._ldiag = diagonal.val.reshape(shp)
-        self._complex = self._ldiag.is_complex()
+            active, ldiag = self._placed(diagonal, dom, (spaces,) if np.isscalar(spaces) else tuple(spaces))
+        self._setup(dom, ldiag, sampling_dtype, _trafo, active)
+
+    @staticmethod
+    def _placed(diagonal, dom, spaces):
+        """A diagonal that lives on the sub-spaces `spaces` of `dom`: (spaces or None when they are all of dom, the values
+        reshaped so that they broadcast against fields on dom)."""
+        if len(spaces) != len(diagonal.domain):
+            raise ValueError("spaces and domain must have the same length")
+        for own, there in enumerate(spaces):
+            if diagonal.domain[own] != dom[there]:
+                raise ValueError("Mismatch between:\n{}\nand:\n{}".format(diagonal.domain[own], dom[there]))
+        if spaces == tuple(range(len(dom))):
+            return None, diagonal.val
+        covered = {axis for sp in spaces for axis in dom.axes[sp]}
+        return spaces, diagonal.val.reshape([n if axis in covered else 1 for axis, n in enumerate(dom.shape)])
+
+    def _setup(self, dom, ldiag, sampling_dtype, trafo, spaces):
+        self._domain, self._ldiag, self._dtype, self._trafo, self._spaces = dom, ldiag, sampling_dtype, trafo, spaces
+        self._complex = ldiag.is_complex()
         self._capability = self._all_ops
         self._diagmin_cache = None
 
     @staticmethod
     def _from_ldiag(proto, ldiag, sampling_dtype, trafo, spaces):
         res = DiagonalOperator.__new__(DiagonalOperator)
-        res._dtype, res._trafo, res._domain, res._spaces = sampling_dtype, trafo, proto._domain, spaces
-        res._ldiag = ldiag
-        res._complex = ldiag.is_complex()
-        res._capability = proto._all_ops
-        res._diagmin_cache = None
+        res._setup(proto._domain, ldiag, sampling_dtype, trafo, spaces)
         return res
 
     @property
@@ -858,7 +865,7 @@ class DiagonalOperator(EndomorphicOperator):
 
     def apply(self, x, mode):
         self._check_input(x, mode)
-        trafo = self._ilog[mode] ^ self._trafo
+        trafo = _mode_index(mode) ^ self._trafo
         return Field(x.domain, self._mul(x.val, divide=bool(trafo & 2), conj=bool(trafo & 1)))
 
     def _actual_diag(self):
@@ -919,12 +926,8 @@ class BlockDiagonalOperator(EndomorphicOperator):
     def __init__(self, domain, operators):
         if not isinstance(domain, MultiDomain):
             raise TypeError("MultiDomain expected")
-        self._domain = domain
-        self._ops = tuple(operators[k] for k in domain.keys())
-        self._capability = self._all_ops
-        for op in self._ops:
-            if op is not None:
-                self._capability &= op.capability
+        self._domain, self._ops = domain, tuple(operators[k] for k in domain.keys())
+        self._capability = _common_capability([op for op in self._ops if op is not None], self._all_ops)
 
     def apply(self, x, mode):
         self._check_input(x, mode)
@@ -947,24 +950,34 @@ class BlockDiagonalOperator(EndomorphicOperator):
         return {k: getattr(op, "sampling_dtype", None) for k, op in zip(self._domain.keys(), self._ops)}
 
 
+def _common_capability(ops, start):
+    """modes every operator of `ops` supports (within `start`)"""
+    for op in ops:
+        start &= op.capability
+    return start
+
+
 def makeOp(inp, dom=None, sampling_dtype=None):
     """Diagonal operator from a scalar / Field / MultiField (reference sugar.py:410-458)."""
     if inp is None:
         return None
+    if isinstance(inp, MultiField):
+        if dom is not None:
+            raise TypeError("dom only allowed for Fields")
+        per_key = sampling_dtype if isinstance(sampling_dtype, dict) else dict.fromkeys(inp.keys(), sampling_dtype)
+        return BlockDiagonalOperator(inp.domain, {k: makeOp(v, sampling_dtype=per_key[k]) for k, v in inp.items()})
+    if isinstance(inp, Field):
+        if dom is not None:  # the field lives on the leading spaces of `dom`
+            return DiagonalOperator(inp, domain=dom, spaces=tuple(range(len(inp.domain))), sampling_dtype=sampling_dtype)
+        if inp.domain is DomainTuple.scalar_domain():
+            return ScalingOperator(inp.domain, inp.asnumpy()[()], sampling_dtype)
+        return DiagonalOperator(inp, sampling_dtype=sampling_dtype)
     if np.isscalar(inp):
         if not isinstance(dom, (DomainTuple, MultiDomain)):
             raise TypeError("need proper `dom` argument")
         return ScalingOperator(dom, inp, sampling_dtype)
-    if dom is not None and not isinstance(inp, Field):
+    if dom is not None:
         raise TypeError("dom only allowed for Fields")
-    if isinstance(inp, Field):
-        if inp.domain is DomainTuple.scalar_domain() and dom is None:
-            return ScalingOperator(inp.domain, inp.asnumpy()[()], sampling_dtype)
-        return DiagonalOperator(inp, sampling_dtype=sampling_dtype) if dom is None else \
-            DiagonalOperator(inp, domain=dom, spaces=tuple(range(len(inp.domain))), sampling_dtype=sampling_dtype)
-    if isinstance(inp, MultiField):
-        dts = sampling_dtype if isinstance(sampling_dtype, dict) else {k: sampling_dtype for k in inp.keys()}
-        return BlockDiagonalOperator(inp.domain, {k: makeOp(v, sampling_dtype=dts[k]) for k, v in inp.items()})
     raise NotImplementedError
 
 
@@ -978,64 +991,53 @@ class ChainOperator(LinearOperator):
         if not _callingfrommake:
             raise NotImplementedError
         self._ops = ops
-        self._capability = self._all_ops
-        for op in ops:
-            self._capability &= op.capability
+        self._capability = _common_capability(ops, self._all_ops)
         self._domain, self._target = ops[-1].domain, ops[0].target
 
     @staticmethod
     def simplify(ops):
-        # flatten
-        flat = []
-        for op in ops:
-            flat.extend(op._ops if isinstance(op, ChainOperator) else [op])
-        # pull scalars to the front and merge them
-        fct, rest, sdt = 1.0, [], None
-        for op in flat:
-            if isinstance(op, ScalingOperator) and np.isscalar(op._factor) and op.domain is op.target:
-                fct = fct * op._factor
-                sdt = op._dtype if op._dtype is not None else sdt
+        """One left-to-right sweep over the spliced factor list: scalars are collected into ONE number (scalings on an
+        endomorphic domain commute with everything), neighbouring full-domain diagonals are multiplied, and at the end
+        the number goes into the leading diagonal if there is one, else in front as a ScalingOperator."""
+        links = [link for op in ops for link in (op._ops if isinstance(op, ChainOperator) else (op,))]
+        number, number_dtype, kept = 1.0, None, []
+        for link in links:
+            if isinstance(link, ScalingOperator) and np.isscalar(link._factor) and link.domain is link.target:
+                number = number * link._factor
+                number_dtype = number_dtype if link._dtype is None else link._dtype
+                continue
+            mergeable = bool(kept) and all(isinstance(o, DiagonalOperator) and o._full() for o in (kept[-1], link))
+            if mergeable:
+                kept[-1] = kept[-1]._combine_prod(link)
             else:
-                rest.append(op)
-        # merge neighbouring full-domain diagonals
-        merged = []
-        for op in rest:
-            if merged and isinstance(op, DiagonalOperator) and isinstance(merged[-1], DiagonalOperator) \
-                    and op._full() and merged[-1]._full():
-                merged[-1] = merged[-1]._combine_prod(op)
-            else:
-                merged.append(op)
-        if fct != 1 or not merged:
-            if merged and isinstance(merged[0], DiagonalOperator) and merged[0]._full():
-                merged[0] = merged[0]._scale(fct)
-            else:
-                dom = merged[0].target if merged else flat[0].target
-                merged.insert(0, ScalingOperator(dom, fct, sdt))
-        return merged
+                kept.append(link)
+        if number == 1 and kept:
+            return kept
+        if kept and isinstance(kept[0], DiagonalOperator) and kept[0]._full():
+            return [kept[0]._scale(number)] + kept[1:]
+        return [ScalingOperator((kept[0] if kept else links[0]).target, number, number_dtype)] + kept
 
     @staticmethod
     def make(ops):
         ops = tuple(ops)
-        if len(ops) == 0:
+        if not ops:
             raise ValueError("ops is empty")
-        for a, b in zip(ops[:-1], ops[1:]):
-            _same_domain(a.domain, b.target)
-        ops = ChainOperator.simplify(ops)
-        if len(ops) == 1:
-            return ops[0]
-        return ChainOperator(ops, _callingfrommake=True)
+        seams = [(later.domain, earlier.target) for later, earlier in zip(ops, ops[1:])]
+        for pair in seams:
+            _same_domain(*pair)
+        *rest, first = ChainOperator.simplify(ops)[::-1]
+        return ChainOperator([first] + rest[::-1], _callingfrommake=True) if rest else first
 
     def _flip_modes(self, trafo):
-        if trafo == 0:
+        if not trafo:
             return self
-        if trafo == self.ADJOINT_BIT or trafo == self.INVERSE_BIT:
-            return ChainOperator.make([op._flip_modes(trafo) for op in reversed(self._ops)])
-        return ChainOperator.make([op._flip_modes(trafo) for op in self._ops])
+        # the adjoint and the inverse of a product reverse it; doing both restores the order
+        order = self._ops if trafo == (self.ADJOINT_BIT | self.INVERSE_BIT) else self._ops[::-1]
+        return ChainOperator.make([op._flip_modes(trafo) for op in order])
 
     def apply(self, x, mode):
         self._check_mode(mode)
-        seq = self._ops if (mode & self._backwards) else reversed(self._ops)
-        for op in seq:
+        for op in (self._ops if mode & self._backwards else self._ops[::-1]):
             x = op.apply(x, mode)
         return x
 
@@ -1043,81 +1045,74 @@ class ChainOperator(LinearOperator):
         raise NotImplementedError
 
     def __repr__(self):
-        return "ChainOperator:\n" + "\n".join("  " + repr(o).replace("\n", "\n  ") for o in self._ops)
+        return _indented("ChainOperator", self._ops)
 
 
 class SumOperator(LinearOperator):
-    """Sum / difference of linear operators (reference sum_operator.py:26-225)."""
+    """Sum / difference of linear operators (reference sum_operator.py:26-225), held as signed terms."""
 
     def __init__(self, ops, neg, _callingfrommake=False):
         if not _callingfrommake:
             raise NotImplementedError
         self._ops, self._neg = ops, neg
-        self._capability = self.TIMES | self.ADJOINT_TIMES
-        for op in ops:
-            self._capability &= op.capability
-        self._domain = domain_union([op.domain for op in ops])
-        self._target = domain_union([op.target for op in ops])
+        self._capability = _common_capability(ops, self.TIMES | self.ADJOINT_TIMES)
+        self._domain, self._target = domain_union(op.domain for op in ops), domain_union(op.target for op in ops)
+
+    @staticmethod
+    def _signed_terms(ops, neg):
+        """(operator, minus) pairs with nested sums opened up"""
+        for op, minus in zip(ops, neg):
+            if isinstance(op, SumOperator):
+                yield from ((inner, inner_minus != minus) for inner, inner_minus in zip(op._ops, op._neg))
+            else:
+                yield op, minus
 
     @staticmethod
     def make(ops, neg=None):
         ops = tuple(ops)
         neg = (False,) * len(ops) if neg is None else tuple(bool(n) for n in neg)
-        if len(ops) == 0 or len(ops) != len(neg):
+        if not ops or len(ops) != len(neg):
             raise ValueError("length mismatch")
-        flat, fneg = [], []
-        for op, n in zip(ops, neg):
-            if isinstance(op, SumOperator):
-                flat.extend(op._ops)
-                fneg.extend(nn != n for nn in op._neg)
+        # multiples of the identity on ONE domain add up to a single scaling, which goes LAST like in the reference
+        # (sum_operator.py:104-107): the order of the terms is the order of the random draws of draw_sample
+        terms, identity = [], None
+        for op, minus in SumOperator._signed_terms(ops, neg):
+            if isinstance(op, ScalingOperator) and (identity is None or identity["domain"] is op.domain):
+                identity = identity or dict(domain=op.domain, factor=0.0, dtype=None)
+                identity["factor"] = identity["factor"] + (-op._factor if minus else op._factor)
+                identity["dtype"] = identity["dtype"] if op._dtype is None else op._dtype
             else:
-                flat.append(op)
-                fneg.append(n)
-        # merge scalar multiples of the identity on identical domains
-        scal, rest, rneg, sdt = None, [], [], None
-        for op, n in zip(flat, fneg):
-            if isinstance(op, ScalingOperator) and isinstance(op.domain, (DomainTuple, MultiDomain)) and \
-                    (scal is None or scal[0] is op.domain):
-                val = -op._factor if n else op._factor
-                scal = (op.domain, val if scal is None else scal[1] + val)
-                sdt = op._dtype if op._dtype is not None else sdt
-            else:
-                rest.append(op)
-                rneg.append(n)
-        if scal is not None:
-            # at the END like the reference (sum_operator.py:104-107): the order fixes the RNG sequence of draw_sample
-            rest.append(ScalingOperator(scal[0], scal[1], sdt))
-            rneg.append(False)
-        if len(rest) == 1:
-            return rest[0] if not rneg[0] else rest[0].scale(-1)
-        return SumOperator(tuple(rest), tuple(rneg), _callingfrommake=True)
+                terms.append((op, minus))
+        if identity is not None:
+            terms.append((ScalingOperator(identity["domain"], identity["factor"], identity["dtype"]), False))
+        if len(terms) == 1:
+            op, minus = terms[0]
+            return op.scale(-1) if minus else op
+        return SumOperator(tuple(t[0] for t in terms), tuple(t[1] for t in terms), _callingfrommake=True)
 
     def _flip_modes(self, trafo):
-        if trafo & self.INVERSE_BIT:
+        if trafo & self.INVERSE_BIT:  # the inverse of a sum is not the sum of the inverses
             return OperatorAdapter(self, trafo)
         return SumOperator.make([op._flip_modes(trafo) for op in self._ops], self._neg)
 
     def apply(self, x, mode):
         self._check_mode(mode)
-        res = None
-        for op, n in zip(self._ops, self._neg):
-            tmp = op.apply(x.extract(op._dom(mode)), mode)
-            if res is None:
-                res = -tmp if n else tmp
-            else:
-                res = res.flexible_addsub(tmp, n)
-        return res
+        total = None
+        for op, minus in zip(self._ops, self._neg):
+            part = op.apply(x.extract(op._dom(mode)), mode)
+            total = (-part if minus else part) if total is None else total.flexible_addsub(part, minus)
+        return total
 
     def draw_sample(self, from_inverse=False, device_id=-1):
+        from functools import reduce
+
         if from_inverse:
             raise NotImplementedError("cannot draw from inverse of this operator")
-        res = self._ops[0].draw_sample(from_inverse, device_id)
-        for op in self._ops[1:]:
-            res = res.flexible_addsub(op.draw_sample(from_inverse, device_id), False)
-        return res
+        # the draws happen in term order (the RNG sequence); the signs do not matter for the distribution
+        return reduce(lambda acc, d: acc.flexible_addsub(d, False), [op.draw_sample(False, device_id) for op in self._ops])
 
     def __repr__(self):
-        return "SumOperator:\n" + "\n".join("  " + repr(o).replace("\n", "\n  ") for o in self._ops)
+        return _indented("SumOperator", self._ops)
 
 
 class SandwichOperator(EndomorphicOperator):
@@ -1131,36 +1126,34 @@ class SandwichOperator(EndomorphicOperator):
 
     @staticmethod
     def make(bun, cheese=None, sampling_dtype=None):
-        if isinstance(cheese, SandwichOperator):
-            bun = cheese._bun @ bun
-            cheese = cheese._cheese
-        if not isinstance(bun, LinearOperator):
-            raise TypeError("bun must be a linear operator")
-        if cheese is not None and not isinstance(cheese, LinearOperator):
-            raise TypeError("cheese must be a linear operator or None")
-        if cheese is None:
-            cheese = ScalingOperator(bun.target, 1.0, sampling_dtype)
-        if isinstance(bun, ScalingOperator):
-            fct = abs(bun._factor) ** 2
-            if fct == 1.0:
-                return cheese
-            op = cheese.scale(fct)
-        else:
-            op = bun.adjoint @ cheese @ bun
-        return SandwichOperator(bun, cheese, op, _callingfrommake=True)
+        while isinstance(cheese, SandwichOperator):  # a sandwich in a sandwich is one sandwich with a longer bun
+            bun, cheese = cheese._bun @ bun, cheese._cheese
+        for what, op, optional in (("bun", bun, False), ("cheese", cheese, True)):
+            if not (isinstance(op, LinearOperator) or (optional and op is None)):
+                raise TypeError(f"{what} must be a linear operator" + (" or None" if optional else ""))
+        cheese = ScalingOperator(bun.target, 1.0, sampling_dtype) if cheese is None else cheese
+        if not isinstance(bun, ScalingOperator):
+            return SandwichOperator(bun, cheese, bun.adjoint @ cheese @ bun, _callingfrommake=True)
+        weight = abs(bun._factor) ** 2  # a scalar bun commutes with the cheese
+        return cheese if weight == 1.0 else SandwichOperator(bun, cheese, cheese.scale(weight), _callingfrommake=True)
 
     def apply(self, x, mode):
         return self._op.apply(x, mode)
 
     def draw_sample(self, from_inverse=False, device_id=-1):
-        if from_inverse:
-            if self._bun.capability & self._bun.INVERSE_TIMES:
-                try:
-                    return self._bun.inverse_times(self._cheese.draw_sample(from_inverse, device_id))
-                except NotImplementedError:
-                    pass
+        # xi ~ cheese       =>  cov(bun^T xi)  = bun^T cheese bun
+        # xi ~ cheese^-1    =>  cov(bun^-1 xi) = (bun^T cheese bun)^-1   (needs an invertible bun)
+        if not from_inverse:
+            return self._bun.adjoint_times(self._cheese.draw_sample(False, device_id))
+        out = None
+        if self._bun.capability & self._bun.INVERSE_TIMES:
+            try:
+                out = self._bun.inverse_times(self._cheese.draw_sample(True, device_id))
+            except NotImplementedError:
+                pass
+        if out is None:
             raise NotImplementedError("cannot draw from inverse of this operator")
-        return self._bun.adjoint_times(self._cheese.draw_sample(from_inverse, device_id))
+        return out
 
     def get_sqrt(self):
         return self._cheese.get_sqrt() @ self._bun
@@ -1324,24 +1317,29 @@ class ContractionOperator(LinearOperator):
 # ================================================================================================
 # harmonic transforms and power distributors
 # ================================================================================================
+def _space_index(domain, space, what="space"):
+    """Index of the sub-space an operator acts on: `space`, or the only one of a one-space domain."""
+    if space is None:
+        if len(domain) != 1:
+            raise ValueError(f"need a {what} index for DomainTuples with more than one entry")
+        return 0
+    space = int(space)
+    if not 0 <= space < len(domain):
+        raise ValueError(f"invalid {what} index")
+    return space
+
+
 class _RGTransformBase(LinearOperator):
     def __init__(self, domain, target=None, space=None):
         self._domain = DomainTuple.make(domain)
-        if space is None:
-            if len(self._domain) != 1:
-                raise ValueError("need a space index for DomainTuples with more than one entry")
-            space = 0
-        self._space = int(space)
-        adom = self._domain[self._space]
-        if not isinstance(adom, RGSpace):
+        self._space = _space_index(self._domain, space)
+        here = self._domain[self._space]
+        if not isinstance(here, RGSpace):
             raise TypeError(f"{type(self).__name__} only works on RGSpaces")
-        if target is None:
-            target = adom.get_default_codomain()
-        tgt = list(self._domain)
-        tgt[self._space] = target
-        self._target = DomainTuple.make(tgt)
-        adom.check_codomain(target)
-        target.check_codomain(adom)
+        there = here.get_default_codomain() if target is None else target
+        for a, b in ((here, there), (there, here)):  # each must accept the other as its codomain
+            a.check_codomain(b)
+        self._target = DomainTuple.make([there if i == self._space else sub for i, sub in enumerate(self._domain)])
 
     def _over_subspace(self, val, fn_host, fn_dev):
         """Apply a transform over the axes of self._space (reference harmonic_operators.py:59-75, `axes=`).  The kernels
@@ -1419,17 +1417,19 @@ class HarmonicTransformOperator(LinearOperator):
     """Harmonic space -> position space, real to real (reference harmonic_operators.py:283-337)."""
 
     def __init__(self, domain, target=None, space=None):
-        domain = DomainTuple.make(domain)
-        if space is None and len(domain) == 1:
-            space = 0
-        hspc = domain[space]
-        if not hspc.harmonic:
-            raise TypeError("HarmonicTransformOperator only works on a harmonic space")
-        if not isinstance(hspc, RGSpace):
-            raise NotImplementedError("spherical harmonic transforms are out of scope")
-        self._op = HartleyOperator(domain, target, space)
-        self._domain, self._target = self._op.domain, self._op.target
         self._capability = self.TIMES | self.ADJOINT_TIMES
+        self._op = self._real_transform(DomainTuple.make(domain), target, space)
+        self._domain, self._target = self._op.domain, self._op.target
+
+    @staticmethod
+    def _real_transform(domain, target, space):
+        """On an RGSpace the real-to-real harmonic transform IS the Hartley transform (restricted to two modes)."""
+        source = domain[_space_index(domain, space)]
+        if not source.harmonic:
+            raise TypeError("HarmonicTransformOperator only works on a harmonic space")
+        if not isinstance(source, RGSpace):
+            raise NotImplementedError("spherical harmonic transforms are out of scope")
+        return HartleyOperator(domain, target, space)
 
     def apply(self, x, mode):
         self._check_input(x, mode)
@@ -1439,26 +1439,24 @@ class HarmonicTransformOperator(LinearOperator):
 def HarmonicSmoothingOperator(domain, sigma, space=None):
     """Smoothing with a Gaussian kernel of width `sigma` (position-space units) on a non-harmonic RGSpace:
     Hartley^-1 . diag(exp(-2 pi^2 sigma^2 k^2)) . Hartley (reference harmonic_operators.py:340-380)."""
-    sigma = float(sigma)
-    if sigma < 0.0:
-        raise ValueError("sigma must be non-negative")
-    if sigma == 0.0:
+    width = float(sigma)
+    if width == 0.0:
         return ScalingOperator(domain, 1.0)
-    domain = DomainTuple.make(domain)
-    if space is None:
-        if len(domain) != 1:
-            raise ValueError("need to specify space")
-        space = 0
-    space = int(space)
-    if space < 0 or space >= len(domain):
-        raise ValueError("invalid space index")
+    if width < 0.0:
+        raise ValueError("sigma must be non-negative")
+    return _gaussian_convolution(DomainTuple.make(domain), width, space)
+
+
+def _gaussian_convolution(domain, width, space):
+    """transform, damp every mode by the Fourier image of the Gaussian, transform back"""
+    space = _space_index(domain, space)
     if domain[space].harmonic:
         raise TypeError("domain must not be harmonic")
-    hartley = HartleyOperator(domain, space=space)
-    codomain = hartley.target[space]
-    kernel = codomain.get_fft_smoothing_kernel_function(sigma)(codomain.get_k_length_array())
+    to_harmonic = HartleyOperator(domain, space=space)
+    kspace = to_harmonic.target[space]
+    damping = kspace.get_fft_smoothing_kernel_function(width)(kspace.get_k_length_array())
     # the kernel lives on the transformed sub-space only and is broadcast over the others (diagonal_operator.py:51-120)
-    return hartley.inverse(DiagonalOperator(kernel, hartley.target, space)(hartley))
+    return ChainOperator.make([to_harmonic.inverse, DiagonalOperator(damping, to_harmonic.target, space), to_harmonic])
 
 
 class _JacCountingOperator(EndomorphicOperator):
@@ -1598,23 +1596,25 @@ class PowerDistributor(DOFDistributor):
 
     def __init__(self, target, power_space=None, space=None):
         self._target = DomainTuple.make(target)
-        if space is None and len(self._target) == 1:
-            space = 0
-        self._space = int(space)
+        self._space = _space_index(self._target, space)
         if self._space != len(self._target) - 1:
             raise NotImplementedError("PowerDistributor: only the LAST space of the target can be distributed")
-        hspace = self._target[self._space]
-        if not hspace.harmonic:
+        self._pspace = bins = self._bins_of(self._target[self._space], power_space)
+        # the host copy of the bin index is only built if a HOST field is ever distributed
+        self._init2(lambda: torch.from_numpy(np.array(bins.pindex)), bins.shape[0], bins)
+
+    @staticmethod
+    def _bins_of(grid, power_space):
+        """The PowerSpace whose bins are distributed over `grid` (the default binning when none is given)."""
+        if not grid.harmonic:
             raise ValueError("Operator requires harmonic target space")
         if power_space is None:
-            power_space = PowerSpace(hspace)
-        else:
-            if not isinstance(power_space, PowerSpace):
-                raise TypeError("power_space argument must be a PowerSpace")
-            if power_space.harmonic_partner != hspace:
-                raise ValueError("power_space does not match its partner")
-        self._pspace = power_space
-        self._init2(lambda: torch.from_numpy(np.array(power_space.pindex)), power_space.shape[0], power_space)
+            return PowerSpace(grid)
+        if not isinstance(power_space, PowerSpace):
+            raise TypeError("power_space argument must be a PowerSpace")
+        if power_space.harmonic_partner != grid:
+            raise ValueError("power_space does not match its partner")
+        return power_space
 
 
 class MaskOperator(LinearOperator):
@@ -1623,13 +1623,13 @@ class MaskOperator(LinearOperator):
 
     def __init__(self, flags):
         if not isinstance(flags, Field):
-            raise TypeError
-        self._domain = DomainTuple.make(flags.domain)
-        keep = torch.logical_not(flags.val.to(torch.bool)).reshape(-1)
-        self._keep = torch.nonzero(keep.cpu()).reshape(-1)  # int64 flat indices of the kept pixels, ascending
-        self._target = DomainTuple.make(UnstructuredDomain(int(self._keep.numel())))
-        self._capability = self.TIMES | self.ADJOINT_TIMES
+            raise TypeError("flags must be a Field")
+        flagged = flags.val.reshape(-1).to(torch.bool).cpu()
+        self._keep = torch.nonzero(~flagged).reshape(-1)  # int64 flat indices of the kept pixels, ascending
         self._idx32 = {}
+        self._capability = self.TIMES | self.ADJOINT_TIMES
+        self._domain = DomainTuple.make(flags.domain)
+        self._target = DomainTuple.make(UnstructuredDomain(int(self._keep.numel())))
 
     def _device_index(self, device):
         key = str(device)
@@ -1657,43 +1657,55 @@ class MaskOperator(LinearOperator):
 # sampling
 # ================================================================================================
 class SamplingEnabler(EndomorphicOperator):
-    """(likelihood + prior) with sampling from its inverse via CG (reference sampling_enabler.py:27-97)."""
+    """(likelihood + prior) with sampling from its inverse via CG (reference sampling_enabler.py:27-97).
+
+    A draw from the inverse of  A = likelihood + prior  is the solution y of  A y = b  for a right-hand side with
+    covariance A: b = prior(s) + nj with s ~ prior^-1 and nj ~ likelihood (or, `start_from_zero`, one draw b ~ A solved
+    from y = 0).  The CG starts at the prior draw s, where the residual A s - b = likelihood(s) - nj is known without
+    another application of the prior."""
 
     def __init__(self, likelihood, prior, iteration_controller, approximation=None, start_from_zero=False):
-        if not is_operator(likelihood) or not is_operator(prior):
-            raise TypeError
-        self._likelihood, self._prior, self._ic = likelihood, prior, iteration_controller
-        self._approximation = approximation
-        self._start_from_zero = bool(start_from_zero)
+        for op in (likelihood, prior):
+            if not is_operator(op):
+                raise TypeError("likelihood and prior must be operators")
         self._op = likelihood + prior
         self._domain, self._capability = self._op.domain, self._op.capability
+        self._likelihood, self._prior = likelihood, prior
+        self._ic, self._approximation, self._start_from_zero = iteration_controller, approximation, bool(start_from_zero)
 
     def apply(self, x, mode):
         return self._op.apply(x, mode)
 
-    def special_draw_sample(self, from_inverse=False, device_id=-1):
-        from .minimization import ConjugateGradient, QuadraticEnergy
+    def _linear_problem(self, device_id):
+        """(b, quadratic energy of A y = b at the CG's starting point)"""
+        from .minimization import QuadraticEnergy
 
+        if self._start_from_zero:
+            b = self._op.draw_sample(device_id=device_id)
+            return b, QuadraticEnergy(b * 0.0, self._op, b)
+        start = self._prior.draw_sample(from_inverse=True, device_id=device_id)
+        noise = self._likelihood.draw_sample(device_id=device_id)
+        b = self._prior(start) + noise
+        return b, QuadraticEnergy(start, self._op, b, _grad=self._likelihood(start) - noise)
+
+    def special_draw_sample(self, from_inverse=False, device_id=-1):
+        from .minimization import ConjugateGradient
+
+        y = self._direct_draw(from_inverse, device_id)
+        if y is None:
+            b, problem = self._linear_problem(device_id)
+            extra = {} if self._approximation is None else dict(preconditioner=self._approximation.inverse)
+            return b, ConjugateGradient(self._ic)(problem, **extra)[0].position
+        return self._op(y), y
+
+    def _direct_draw(self, from_inverse, device_id):
+        """A sample straight from the operator, or None when only the CG route is open (which needs from_inverse)."""
         try:
-            res = self._op.draw_sample(from_inverse, device_id)
-            return self._op(res), res
+            return self._op.draw_sample(from_inverse, device_id)
         except NotImplementedError:
             if not from_inverse:
-                raise ValueError("from_inverse must be True here")
-            if self._start_from_zero:
-                b = self._op.draw_sample(device_id=device_id)
-                energy = QuadraticEnergy(b * 0.0, self._op, b)
-            else:
-                s = self._prior.draw_sample(from_inverse=True, device_id=device_id)
-                nj = self._likelihood.draw_sample(device_id=device_id)
-                b = self._prior(s) + nj
-                energy = QuadraticEnergy(s, self._op, b, _grad=self._likelihood(s) - nj)
-            inverter = ConjugateGradient(self._ic)
-            if self._approximation is not None:
-                energy, _ = inverter(energy, preconditioner=self._approximation.inverse)
-            else:
-                energy, _ = inverter(energy)
-            return b, energy.position
+                raise ValueError("from_inverse must be True here") from None
+            return None
 
     def draw_sample(self, from_inverse=False, device_id=-1):
         return self.special_draw_sample(from_inverse, device_id)[1]
