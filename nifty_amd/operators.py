@@ -1097,10 +1097,11 @@ class SumOperator(LinearOperator):
 
     def apply(self, x, mode):
         self._check_mode(mode)
-        total = None
-        for op, minus in zip(self._ops, self._neg):
-            part = op.apply(x.extract(op._dom(mode)), mode)
-            total = (-part if minus else part) if total is None else total.flexible_addsub(part, minus)
+        parts = [(op.apply(x.extract(op._dom(mode)), mode), minus) for op, minus in zip(self._ops, self._neg)]
+        (first, first_minus), rest = parts[0], parts[1:]
+        total = -first if first_minus else first
+        for part, minus in rest:
+            total = total.flexible_addsub(part, minus)
         return total
 
     def draw_sample(self, from_inverse=False, device_id=-1):
@@ -1143,17 +1144,10 @@ class SandwichOperator(EndomorphicOperator):
     def draw_sample(self, from_inverse=False, device_id=-1):
         # xi ~ cheese       =>  cov(bun^T xi)  = bun^T cheese bun
         # xi ~ cheese^-1    =>  cov(bun^-1 xi) = (bun^T cheese bun)^-1   (needs an invertible bun)
-        if not from_inverse:
-            return self._bun.adjoint_times(self._cheese.draw_sample(False, device_id))
-        out = None
-        if self._bun.capability & self._bun.INVERSE_TIMES:
-            try:
-                out = self._bun.inverse_times(self._cheese.draw_sample(True, device_id))
-            except NotImplementedError:
-                pass
-        if out is None:
+        if from_inverse and not self._bun.capability & self._bun.INVERSE_TIMES:
             raise NotImplementedError("cannot draw from inverse of this operator")
-        return out
+        push = self._bun.inverse_times if from_inverse else self._bun.adjoint_times
+        return push(self._cheese.draw_sample(from_inverse, device_id))
 
     def get_sqrt(self):
         return self._cheese.get_sqrt() @ self._bun
@@ -1460,50 +1454,47 @@ def _gaussian_convolution(domain, width, space):
 
 
 class _JacCountingOperator(EndomorphicOperator):
-    def __init__(self, domain):
-        self._domain = makeDomain(domain)
+    """Identity whose applications are tallied per mode in the owner's counter table."""
+
+    def __init__(self, domain, tally):
+        self._domain, self._tally = makeDomain(domain), tally
         self._capability = self.TIMES | self.ADJOINT_TIMES
-        self._count_times = 0
-        self._count_adjoint_times = 0
 
     def apply(self, x, mode):
         self._check_input(x, mode)
-        if mode == self.TIMES:
-            self._count_times += 1
-        else:
-            self._count_adjoint_times += 1
+        self._tally["jac" if mode == self.TIMES else "jac_adj"] += 1
         return x
 
 
 class CountingOperator(Operator):
     """Identity that counts how often it is applied to fields / Linearizations and how often its Jacobian and
-    adjoint Jacobian run (reference counting_operator.py:20-84; optimize_kl.py:370,441 reports them)."""
+    adjoint Jacobian run (reference counting_operator.py:20-84; optimize_kl.py:370,441 reports them).  All four counters
+    live in one table; the Jacobian handed to Linearizations writes into the same table."""
+
+    _ROWS = (("apply", "apply: \t\t"), ("apply_lin", "apply Linearization: \t"), ("jac", "Jacobian: \t\t"),
+             ("jac_adj", "Adjoint Jacobian: \t"))
 
     def __init__(self, domain):
         self._domain = self._target = makeDomain(domain)
-        self._count_apply = 0
-        self._count_apply_lin = 0
-        self._derivative = _JacCountingOperator(self._domain)
+        self._tally = dict.fromkeys((key for key, _ in self._ROWS), 0)
+        self._derivative = _JacCountingOperator(self._domain, self._tally)
 
     def apply(self, x):
         self._check_input(x)
-        if is_linearization(x):
-            self._count_apply_lin += 1
-            return x.new(x.val, self._derivative)
-        self._count_apply += 1
-        return x
+        differentiated = is_linearization(x)
+        self._tally["apply_lin" if differentiated else "apply"] += 1
+        return x.new(x.val, self._derivative) if differentiated else x
 
-    count_apply = property(lambda self: self._count_apply)
-    count_apply_lin = property(lambda self: self._count_apply_lin)
-    count_jac = property(lambda self: self._derivative._count_times)
-    count_jac_adj = property(lambda self: self._derivative._count_adjoint_times)
+    count_apply = property(lambda self: self._tally["apply"])
+    count_apply_lin = property(lambda self: self._tally["apply_lin"])
+    count_jac = property(lambda self: self._tally["jac"])
+    count_jac_adj = property(lambda self: self._tally["jac_adj"])
 
     def __repr__(self):
         return f"CountingOperator({self._domain!r})"
 
     def report(self):
-        return "\n".join([f"* apply: \t\t{self.count_apply:>7}", f"* apply Linearization: \t{self.count_apply_lin:>7}",
-                          f"* Jacobian: \t\t{self.count_jac:>7}", f"* Adjoint Jacobian: \t{self.count_jac_adj:>7}"])
+        return "\n".join(f"* {label}{self._tally[key]:>7}" for key, label in self._ROWS)
 
 
 class DOFDistributor(LinearOperator):
