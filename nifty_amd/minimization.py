@@ -80,20 +80,25 @@ class QuadraticEnergy(Energy):
 
     def __init__(self, position, A, b, _grad=None, _value=None):
         super().__init__(position)
-        self._A, self._b = A, b
-        self._grad = _grad
+        self._A, self._b, self._grad, self._value = A, b, _grad, _value
         if _grad is None:
-            Ax = self._A(self._position)
-            self._grad = Ax if b is None else Ax - b
+            self._grad = self._residual()
         # the value costs three passes over the vectors: taken on first use (a CG result is usually only asked for its
         # position), or handed in by a caller that knows it (x = 0 -> 0).  Inside a multi-rank lockstep scope the dots
         # are collectives, so there it is taken right away -- never lazily by whichever rank happens to ask
-        self._value = _value
-        if _value is None:
-            from . import parallel
+        if _value is None and self._in_lockstep():
+            self._value = self._compute_value()
 
-            if parallel.lockstep_comm() is not None:
-                self._value = self._compute_value()
+    def _residual(self):
+        """gradient A x - b at the position"""
+        image = self._A(self._position)
+        return image if self._b is None else image - self._b
+
+    @staticmethod
+    def _in_lockstep():
+        from . import parallel
+
+        return parallel.lockstep_comm() is not None
 
     def _compute_value(self):
         b = self._b
@@ -631,8 +636,25 @@ def _interp_quadratic(a, fa, fpa, b, fb):
     return xmin if np.isfinite(xmin) else None
 
 
+class _Wolfe:
+    """The two strong-Wolfe tests for a search line with value phi0 and slope dphi0 < 0 at t = 0."""
+
+    def __init__(self, phi0, dphi0, c1, c2):
+        self.phi0, self.dphi0, self._c1, self._c2 = phi0, dphi0, c1, c2
+
+    def too_high(self, t, phi):
+        """sufficient-decrease (Armijo) condition violated at step t"""
+        return phi > self.phi0 + self._c1 * t * self.dphi0
+
+    def flat_enough(self, dphi):
+        """curvature condition: |phi'(t)| <= c2 |phi'(0)|"""
+        return abs(dphi) <= -self._c2 * self.dphi0
+
+
 class LineSearch:
-    """reference line_search.py:103-416"""
+    """Step length satisfying the strong Wolfe conditions (reference line_search.py:103-416; Nocedal & Wright,
+    algorithms 3.5 and 3.6): `perform_line_search` walks outwards from t = 0 until it either meets both conditions or
+    holds a bracket, which `_zoom` then shrinks by safeguarded cubic / quadratic interpolation."""
 
     def __init__(self, preferred_initial_step_size=None, c1=1e-4, c2=0.9, max_step_size=1e30, max_iterations=100,
                  max_zoom_iterations=100):
@@ -642,127 +664,148 @@ class LineSearch:
         self.max_iterations = int(max_iterations)
         self.max_zoom_iterations = int(max_zoom_iterations)
 
-    def perform_line_search(self, energy, pk, f_k_minus_1=None):
-        le0 = LineEnergy(0.0, energy, pk, 0.0)
-        cap = energy.longest_step(pk)
-        cap = self.max_step_size if cap is None else min(cap, self.max_step_size)
-        phi0, dphi0 = le0.value, le0.directional_derivative
-        if dphi0 == 0:
-            logger.warning("Directional derivative is zero; assuming convergence")
-            return energy, False
-        if dphi0 > 0:
-            logger.error("Error: search direction is not a descent direction")
-            return energy, False
+    def _opening_step(self, wolfe, direction, previous_value):
+        """First trial step: the caller's preference, else the step a quadratic model through the previous energy
+        would take, else a unit displacement."""
         if self.preferred_initial_step_size is not None:
-            t1 = self.preferred_initial_step_size
-        elif f_k_minus_1 is not None:
-            t1 = min(1.0, 1.01 * 2 * (phi0 - f_k_minus_1) / dphi0)
-            if t1 < 0:
-                t1 = 1.0
-        else:
-            t1 = 1.0 / _ls(pk.norm())
-        t1 = min(t1, 0.99 * cap)
-        t0, phi_t0, dphi_t0 = 0.0, phi0, dphi0
-        le1 = None
-        for it in range(1, self.max_iterations + 1):
-            if t1 == 0:
-                return le0.energy, False
-            try:
-                le1 = le0.at(t1)
-                phi1 = le1.value
-            except FloatingPointError:
-                t1 = (t0 + t1) / 2
-                continue
-            if np.isnan(phi1) or abs(phi1) > 1e100:
-                t1 = (t0 + t1) / 2
-                continue
-            if phi1 > phi0 + self.c1 * t1 * dphi0 or (phi1 >= phi_t0 and it > 1):
-                return self._zoom(t0, t1, phi0, dphi0, phi_t0, dphi_t0, phi1, le0)
-            dphi1 = le1.directional_derivative
-            if abs(dphi1) <= -self.c2 * dphi0:
-                return le1.energy, True
-            if dphi1 >= 0:
-                return self._zoom(t1, t0, phi0, dphi0, phi1, dphi1, phi_t0, le0)
-            t0, t1 = t1, min(2 * t1, cap)
-            if t1 == cap:
-                logger.warning("max step size reached")
-                return le1.energy, False
-            phi_t0, dphi_t0 = phi1, dphi1
-        logger.warning("max iterations reached")
-        return le1.energy, False
+            return self.preferred_initial_step_size
+        if previous_value is None:
+            return 1.0 / _ls(direction.norm())
+        guess = min(1.0, 1.01 * 2 * (wolfe.phi0 - previous_value) / wolfe.dphi0)
+        return guess if guess >= 0 else 1.0
 
-    def _zoom(self, lo, hi, phi0, dphi0, phi_lo, dphi_lo, phi_hi, le0):
-        if phi_lo > phi0 + self.c1 * lo * dphi0:
+    @staticmethod
+    def _probe(origin, t):
+        """(line energy, value) at step t, or None where the energy cannot be evaluated (overflow, NaN)"""
+        try:
+            there = origin.at(t)
+            phi = there.value
+        except FloatingPointError:
+            return None
+        return None if (np.isnan(phi) or abs(phi) > 1e100) else (there, phi)
+
+    def _descending(self, origin):
+        """the Wolfe tests of the line, or None (with a log entry) when it does not start downhill"""
+        wolfe = _Wolfe(origin.value, origin.directional_derivative, self.c1, self.c2)
+        if wolfe.dphi0 < 0:
+            return wolfe
+        if wolfe.dphi0 == 0:
+            logger.warning("Directional derivative is zero; assuming convergence")
+        else:
+            logger.error("Error: search direction is not a descent direction")
+        return None
+
+    def perform_line_search(self, energy, pk, f_k_minus_1=None):
+        origin = LineEnergy(0.0, energy, pk, 0.0)
+        wolfe = self._descending(origin)
+        if wolfe is None:
+            return energy, False
+        limit = min(cap for cap in (energy.longest_step(pk), self.max_step_size) if cap is not None)
+        t = min(self._opening_step(wolfe, pk, f_k_minus_1), 0.99 * limit)
+        behind, there = (0.0, wolfe.phi0, wolfe.dphi0), None  # behind: last accepted point on the way out (t, phi, phi')
+        for attempt in range(self.max_iterations):
+            if t == 0:
+                return origin.energy, False
+            probed = self._probe(origin, t)
+            if probed is None:  # not evaluable: come half way back
+                t = 0.5 * (behind[0] + t)
+                continue
+            there, phi = probed
+            if wolfe.too_high(t, phi) or (attempt > 0 and phi >= behind[1]):
+                return self._zoom(origin, wolfe, behind, (t, phi))
+            dphi = there.directional_derivative
+            if wolfe.flat_enough(dphi):
+                return there.energy, True
+            if dphi >= 0:  # walked past a minimum: it lies between here and the previous point
+                return self._zoom(origin, wolfe, (t, phi, dphi), behind[:2])
+            behind, t = (t, phi, dphi), min(2 * t, limit)
+            if t == limit:
+                logger.warning("max step size reached")
+                return there.energy, False
+        logger.warning("max iterations reached")
+        return there.energy, False
+
+    def _zoom(self, origin, wolfe, low, high):
+        """Shrinks the bracket between `low` = (t, phi, phi') -- the end with the smaller value, its slope pointing into
+        the bracket -- and `high` = (t, phi) until a point meets both Wolfe conditions."""
+        lo, phi_lo, dphi_lo = low
+        hi, phi_hi = high
+        if wolfe.too_high(lo, phi_lo) or dphi_lo * (hi - lo) >= 0.0:
             raise ValueError("inconsistent data")
-        if dphi_lo * (hi - lo) >= 0.0:
-            raise ValueError("inconsistent data")
-        recent = phi_recent = None
-        lej = None
-        for i in range(self.max_zoom_iterations):
-            width = hi - lo
-            left, right = min(lo, hi), max(lo, hi)
-            tj = None
-            if i > 0:
-                guard = 0.2 * width
-                tj = _interp_cubic(lo, phi_lo, dphi_lo, hi, phi_hi, recent, phi_recent)
-            if i == 0 or tj is None or tj > right - guard or tj < left + guard:
-                guard_q = 0.1 * width
-                tj = _interp_quadratic(lo, phi_lo, dphi_lo, hi, phi_hi)
-                if tj is None or tj > right - guard_q or tj < left + guard_q:
-                    tj = lo + 0.5 * width
-            lej = le0.at(tj)
-            phij = lej.value
-            if phij > phi0 + self.c1 * tj * dphi0 or phij >= phi_lo:
-                recent, phi_recent = hi, phi_hi
-                hi, phi_hi = tj, phij
+        dropped = None  # the end point given up last: third support point of the cubic
+        there = None
+        for shrink in range(self.max_zoom_iterations):
+            t = self._interpolate(lo, phi_lo, dphi_lo, hi, phi_hi, dropped)
+            there = origin.at(t)
+            phi = there.value
+            if wolfe.too_high(t, phi) or phi >= phi_lo:
+                dropped, (hi, phi_hi) = (hi, phi_hi), (t, phi)
+                continue
+            dphi = there.directional_derivative
+            if wolfe.flat_enough(dphi):
+                return there.energy, True
+            if dphi * (hi - lo) >= 0:  # the minimum is on the other side of t: the old low end becomes the high end
+                dropped, (hi, phi_hi) = (hi, phi_hi), (lo, phi_lo)
             else:
-                dphij = lej.directional_derivative
-                if abs(dphij) <= -self.c2 * dphi0:
-                    return lej.energy, True
-                if dphij * width >= 0:
-                    recent, phi_recent = hi, phi_hi
-                    hi, phi_hi = lo, phi_lo
-                else:
-                    recent, phi_recent = lo, phi_lo
-                lo, phi_lo, dphi_lo = tj, phij, dphij
+                dropped = (lo, phi_lo)
+            lo, phi_lo, dphi_lo = t, phi, dphi
         logger.warning("The line search algorithm (zoom) did not converge.")
-        return lej.energy, False
+        return there.energy, False
+
+    @staticmethod
+    def _interpolate(lo, phi_lo, dphi_lo, hi, phi_hi, third):
+        """Trial point inside the bracket: minimiser of the cubic through both ends and `third` if it keeps 20 % of the
+        (signed) bracket width away from the ends, else of the quadratic with a 10 % margin, else the midpoint."""
+        width = hi - lo
+        left, right = (lo, hi) if width >= 0 else (hi, lo)
+
+        def inside(t, margin):
+            return t is not None and left + margin * width <= t <= right - margin * width
+
+        if third is not None:
+            t = _interp_cubic(lo, phi_lo, dphi_lo, hi, phi_hi, *third)
+            if inside(t, 0.2):
+                return t
+        t = _interp_quadratic(lo, phi_lo, dphi_lo, hi, phi_hi)
+        return t if inside(t, 0.1) else lo + 0.5 * width
 
 
 # ------------------------------------------------------------------------------------------------
 # descent minimizers
 # ------------------------------------------------------------------------------------------------
 class DescentMinimizer(Minimizer):
-    """reference descent_minimizers.py:52-108"""
+    """Descent along directions a subclass proposes, each followed by a line search (reference
+    descent_minimizers.py:52-108)."""
 
     def __init__(self, controller, line_searcher=None):
         self._controller = controller
         self.line_searcher = LineSearch() if line_searcher is None else line_searcher
 
+    def _step(self, energy, previous_value):
+        """One direction + line search from `energy`: (energy to continue with, verdict), verdict None = go on."""
+        direction = self.get_descent_direction(energy, previous_value)
+        found, success = self.line_searcher.perform_line_search(energy=energy, pk=direction, f_k_minus_1=previous_value)
+        if not success:
+            self.reset()
+        if found.value > energy.value:
+            logger.error("Error: Energy has increased")
+            return energy, ERROR
+        if found.value == energy.value:
+            logger.warning("Warning: Energy has not changed. Assuming convergence...")
+            return found, CONVERGED
+        return found, None
+
     def __call__(self, energy):
-        f_prev = None
-        controller = self._controller
-        status = controller.start(energy)
-        if status != CONTINUE:
-            return energy, status
-        while True:
+        previous_value = None
+        verdict = self._controller.start(energy)
+        while verdict == CONTINUE:
             if energy.gradient_norm == 0:
                 return energy, CONVERGED
-            direction = self.get_descent_direction(energy, f_prev)
-            new_energy, success = self.line_searcher.perform_line_search(energy=energy, pk=direction, f_k_minus_1=f_prev)
-            if not success:
-                self.reset()
-            f_prev = energy.value
-            if new_energy.value > energy.value:
-                logger.error("Error: Energy has increased")
-                return energy, ERROR
-            if new_energy.value == energy.value:
-                logger.warning("Warning: Energy has not changed. Assuming convergence...")
-                return new_energy, CONVERGED
-            energy = new_energy
-            status = controller.check(energy)
-            if status != CONTINUE:
-                return energy, status
+            value_here = energy.value
+            energy, early = self._step(energy, previous_value)
+            previous_value = value_here
+            verdict = self._controller.check(energy) if early is None else early
+        return energy, verdict
 
     def reset(self):
         pass
@@ -804,34 +847,34 @@ class L_BFGS(DescentMinimizer):
         return super().__call__(energy)
 
     def reset(self):
-        self._k = 0
-        self._s = [None] * self.max_history_length
-        self._y = [None] * self.max_history_length
+        from collections import deque
+
+        self._pairs = deque(maxlen=self.max_history_length)  # (s, y) = (position, gradient) differences, oldest first
+        self._last = None
 
     def get_descent_direction(self, energy, _=None):
-        m, k = self.max_history_length, self._k
-        x, g = energy.position, energy.gradient
-        if k > 0:
-            self._s[(k - 1) % m] = x - self._lastx
-            self._y[(k - 1) % m] = g - self._lastgrad
-        p = -g
-        used = list(range(k - 1, k - min(k, m) - 1, -1))  # newest first
-        alpha = {}
-        for i in used:
-            s, y = self._s[i % m], self._y[i % m]
-            alpha[i] = _ls(s.s_vdot(p)) / _ls(s.s_vdot(y))
-            p = p - alpha[i] * y
-        if used:
-            s, y = self._s[(k - 1) % m], self._y[(k - 1) % m]
-            fact = _ls(s.s_vdot(y)) / _ls(y.s_vdot(y))
-            if fact <= 0.0:
-                logger.error("L-BFGS curvature not positive definite!")
-            p = p * fact
-            for i in reversed(used):
-                s, y = self._s[i % m], self._y[i % m]
-                p = p + (alpha[i] - _ls(y.s_vdot(p)) / _ls(s.s_vdot(y))) * s
-        self._lastx, self._lastgrad = x, g
-        self._k += 1
+        point = (energy.position, energy.gradient)
+        if self._last is not None:
+            self._pairs.append((point[0] - self._last[0], point[1] - self._last[1]))
+        self._last = point
+        p = -point[1]
+        if not self._pairs:
+            return p
+        # first loop, newest pair first: peel the curvature pairs off the gradient
+        peeled = []
+        for s, y in reversed(self._pairs):
+            sy = _ls(s.s_vdot(y))
+            weight = _ls(s.s_vdot(p)) / sy
+            p = p - weight * y
+            peeled.append((s, y, sy, weight))
+        s, y = self._pairs[-1]
+        scale = _ls(s.s_vdot(y)) / _ls(y.s_vdot(y))  # initial Hessian guess: gamma * identity
+        if scale <= 0.0:
+            logger.error("L-BFGS curvature not positive definite!")
+        p = p * scale
+        # second loop, oldest first
+        for s, y, sy, weight in reversed(peeled):
+            p = p + (weight - _ls(y.s_vdot(p)) / sy) * s
         return p
 
 
@@ -909,46 +952,56 @@ class VL_BFGS(DescentMinimizer):
 
 
 class NewtonCG(DescentMinimizer):
-    """Inexact Newton: CG on metric * delta = gradient (reference descent_minimizers.py:166-210)."""
+    """Inexact Newton: CG on metric * delta = gradient (reference descent_minimizers.py:166-210).  The CG is stopped
+    early -- after 5 iterations on the first step, afterwards once it gains less than `energy_reduction_factor` times the
+    outer iteration's last energy decrease per iteration."""
 
     def __init__(self, controller, napprox=0, line_searcher=None, name=None, nreset=20, max_cg_iterations=200,
                  energy_reduction_factor=0.1, enable_logging=False):
-        if line_searcher is None:
-            line_searcher = LineSearch(preferred_initial_step_size=1.0)
-        super().__init__(controller, line_searcher)
-        self._napprox = napprox
-        self._name, self._nreset = name, nreset
-        self._max_cg_iterations = max_cg_iterations
-        self._alpha = energy_reduction_factor
+        unit_step = LineSearch(preferred_initial_step_size=1.0)  # a Newton step has its natural length
+        super().__init__(controller, unit_step if line_searcher is None else line_searcher)
+        self._cg = dict(nreset=nreset, limit=max_cg_iterations, reduction=energy_reduction_factor, name=name)
+        self._napprox, self._name, self._nreset = napprox, name, nreset
         self._history = EnergyHistory() if enable_logging else None
 
-    def get_descent_direction(self, energy, old_value=None):
+    def _inner_controller(self, energy, old_value):
         if old_value is None:
-            ic = GradientNormController(iteration_limit=5)
+            inner = GradientNormController(iteration_limit=5)
         else:
-            ic = AbsDeltaEnergyController(self._alpha * (old_value - energy.value),
-                                          iteration_limit=self._max_cg_iterations, name=self._name)
-        if self._history is not None:
-            ic.enable_logging()
-        g = energy.gradient
-        # QuadraticEnergy(0*pos, metric, gradient): A(0) = 0 exactly, so the start gradient is -g and the
-        # reference's metric application to the zero vector is skipped.
-        zero = energy.position * 0.0
-        quad = QuadraticEnergy(zero, energy.metric, g, _grad=-g, _value=0.0)  # E(0) = 0
-        quad.consumable = True  # `zero` and `-g` are temporaries of this call: the CG may iterate on them in place
-        precond = None
-        if self._napprox > 1:
-            # sampled diagonal of the metric as CG preconditioner (descent_minimizers.py:201-203)
-            from .operators import makeOp
-            from .probing import approximation2endo
+            inner = AbsDeltaEnergyController(self._cg["reduction"] * (old_value - energy.value),
+                                             iteration_limit=self._cg["limit"], name=self._cg["name"])
+        if self._history is not None:  # the CG's energy trace is appended to `inversion_history` afterwards
+            inner.enable_logging()
+        return inner
 
-            precond = makeOp(approximation2endo(energy.metric, self._napprox, getattr(energy.position, "device_id", -1))).inverse
-        quad, conv = ConjugateGradient(ic, nreset=self._nreset)(quad, precond)
-        if self._history is not None:
-            self._history += ic.history
-        if conv == ERROR:
+    def _preconditioner(self, energy):
+        """inverse of the sampled diagonal of the metric (descent_minimizers.py:201-203), or None"""
+        if self._napprox <= 1:
+            return None
+        from .operators import makeOp
+        from .probing import approximation2endo
+
+        where = getattr(energy.position, "device_id", -1)
+        return makeOp(approximation2endo(energy.metric, self._napprox, where)).inverse
+
+    def get_descent_direction(self, energy, old_value=None):
+        inner = self._inner_controller(energy, old_value)
+        solver = ConjugateGradient(inner, nreset=self._cg["nreset"])
+        solved, outcome = solver(self._newton_model(energy), self._preconditioner(energy))
+        if inner.history is not None:
+            self._history += inner.history
+        if outcome == ERROR:
             raise ValueError("Cannot find descent direction")
-        return -quad.position
+        return -solved.position
+
+    @staticmethod
+    def _newton_model(energy):
+        """1/2 d.M d - g.d at d = 0.  M 0 = 0 exactly, so gradient (-g) and value (0) at the start are known and the
+        reference's metric application to the zero vector is skipped."""
+        g = energy.gradient
+        model = QuadraticEnergy(energy.position * 0.0, energy.metric, g, _grad=-g, _value=0.0)
+        model.consumable = True  # the start vectors are temporaries of this call: the CG may iterate on them in place
+        return model
 
     @property
     def inversion_history(self):
