@@ -153,14 +153,12 @@ class _SlopeRemover(EndomorphicOperator):
 class _TwoLogIntegrations(LinearOperator):
     def __init__(self, target, space=0):
         self._target, self._nrows = _batched(target, space, "_TwoLogIntegrations")
-        nb = self._target[space].shape[0]
-        dom = list(self._target)
-        dom[space] = UnstructuredDomain((2, nb - 2))
-        self._domain = makeDomain(dom)
-        self._row_target = DomainTuple.make(self._target[space])
-        self._row_domain = DomainTuple.make(dom[space])
-        self._log_vol = torch.from_numpy(_log_vol(self._target[space]))
+        bins = self._target[space]
+        excitations = UnstructuredDomain((2, bins.shape[0] - 2))  # two rows of white noise per log-k interval
         self._capability = self.TIMES | self.ADJOINT_TIMES
+        self._log_vol = torch.from_numpy(_log_vol(bins))
+        self._row_target, self._row_domain = DomainTuple.make(bins), DomainTuple.make(excitations)
+        self._domain = makeDomain([excitations if i == space else sub for i, sub in enumerate(self._target)])
 
     def apply(self, x, mode):
         self._check_input(x, mode)
@@ -209,94 +207,106 @@ class _TwoLogIntegrations(LinearOperator):
         return Field(self._row_domain, res)
 
 
+def _volume_slots(nbins, zero_mode, other_modes):
+    """(factor per bin with 0 in the zero-mode slot, the zero-mode slot alone): how the volume enters an amplitude"""
+    factors, slot = np.full(nbins, float(other_modes)), np.zeros(nbins)
+    factors[0], slot[0] = 0.0, zero_mode
+    return factors, slot
+
+
+def _on_space(values, domain, space):
+    """Diagonal operator on `domain` whose diagonal `values` lives on the sub-space `space` only."""
+    return DiagonalOperator(makeField(domain[space], values), domain, space)
+
+
 class _Normalization(Operator):
+    """log-spectrum p -> sqrt( e^p / sum_{k != 0} mult(k) e^p ): unit total power outside the zero mode, per copy
+    (reference correlated_fields.py:165-208)."""
+
     def __init__(self, domain, space=0):
         self._domain = self._target = DomainTuple.make(domain)
         _batched(self._domain, space, "_Normalization")
-        self._space = space
-        pspace = self._domain[space]
-        mult = pspace.rho.astype(np.float64).copy()
-        mult[0] = 0.0
-        self._mult = makeField(DomainTuple.make(pspace), mult)
+        multiplicity = self._domain[space].rho.astype(np.float64)
+        multiplicity[0] = 0.0  # the zero mode does not count
+        self._weigh = _on_space(multiplicity, self._domain, space)
+        self._total = ContractionOperator(self._domain, space)
 
     def apply(self, x):
         self._check_input(x)
-        spec = x.exp()
-        # sum over modes with multiplicities (per copy), broadcast back
-        multop = DiagonalOperator(self._mult, self._domain, self._space)
-        co = ContractionOperator(self._domain, self._space)
-        specsum = co.adjoint(co(multop(spec)))
-        return (specsum.reciprocal() * spec).sqrt()
+        power = x.exp()
+        norm = self._total.adjoint(self._total(self._weigh(power)))  # weighted sum over the bins, broadcast back
+        return (power * norm.reciprocal()).sqrt()
+
+
+class _SpectrumLayout:
+    """Where the spectra of an amplitude model live: `target` = ([copies,] PowerSpace) with the bins at `space`; when
+    several fields share fewer spectra (dofdex) `distribute` copies the spectra onto the fields."""
+
+    def __init__(self, power_space, dofdex):
+        self.dofdex = [int(i) for i in dofdex]
+        self.distribute = self.field_copies = None
+        if not self.dofdex:
+            self.target, self.space = makeDomain(power_space), 0
+        else:
+            spectra = max(self.dofdex) + 1
+            self.target, self.space = makeDomain((UnstructuredDomain(spectra), power_space)), 1
+            if spectra != len(self.dofdex):
+                self.field_copies = UnstructuredDomain(len(self.dofdex))
+                self.distribute = _Distributor(self.dofdex, self.target, makeDomain((self.field_copies, power_space)))
+        self.bins = self.target[self.space]
+        if not isinstance(self.bins, PowerSpace):
+            raise TypeError("PowerSpace required")
+
+    def onto_bins(self, per_copy_operator):
+        """a per-copy (or scalar) hyper-parameter broadcast over the bins"""
+        return ContractionOperator(self.target, self.space).adjoint @ per_copy_operator
 
 
 class _Amplitude(Operator):
-    """a(k) = vol0 + vol1 fluct * normalised( slope rel_logk + SlopeRemover(TwoLogIntegrations(sigma xi_s)) ).
-    dofdex (total_N > 0): max(dofdex)+1 independent spectra on a leading UnstructuredDomain, distributed to the
-    len(dofdex) fields (reference correlated_fields.py:277-386)."""
+    """a(k) = V zeromode-slot + V fluct * normalised( slope * rel_logk + SlopeRemover(TwoLogIntegrations(sigma xi_s)) )
+    (reference correlated_fields.py:277-386).  The log-spectrum is assembled from its two parts -- the power law and
+    the integrated-Wiener-process deviation, which may be switched off -- then normalised, scaled by the fluctuation
+    amplitude and the volume, and copied onto the fields when spectra are shared (dofdex, total_N > 0)."""
 
     def __init__(self, target, fluctuations, flexibility, asperity, loglogavgslope, totvol, key, dofdex=()):
-        dofdex = [int(i) for i in dofdex]
-        distributor = None
-        if len(dofdex) > 0:
-            n_copies, space = max(dofdex) + 1, 1
-            target = makeDomain((UnstructuredDomain(n_copies), target))
-            if n_copies != len(dofdex):
-                distributed_tgt = makeDomain((UnstructuredDomain(len(dofdex)), target[1]))
-                distributor = _Distributor(dofdex, target, distributed_tgt)
-        else:
-            space = 0
-            target = makeDomain(target)
-        pspace = target[space]
-        if not isinstance(pspace, PowerSpace):
-            raise TypeError("PowerSpace required")
-        twolog = _TwoLogIntegrations(target, space)
-        dom = twolog.domain
-        shp = dom[space].shape
-        expander = ContractionOperator(dom, space).adjoint
-        ps_expander = ContractionOperator(target, space).adjoint
-        lv = _log_vol(pspace)
-        vflex = np.zeros(shp)
-        vflex[0] = vflex[1] = np.sqrt(lv)
-        vflex = DiagonalOperator(makeField(dom[space], vflex), dom, space)
-        vasp = np.zeros(shp)
-        vasp[0] += 1
-        vasp = DiagonalOperator(makeField(dom[space], vasp), dom, space)
-        shift = np.ones(shp)
-        shift[0] = lv ** 2 / 12.0
-        shift = DiagonalOperator(makeField(dom[space], shift), dom, space)(full(dom, 1.0))
-        vslope = DiagonalOperator(makeField(pspace, _relative_log_k_lengths(pspace)), target, space)
-        vol0, vol1 = np.zeros(pspace.shape), np.zeros(pspace.shape)
-        vol1[1:] = vol0[0] = totvol
-        vol0 = DiagonalOperator(makeField(pspace, vol0), target, space)(full(target, 1.0))
-        vol1 = DiagonalOperator(makeField(pspace, vol1), target, space)
-        slope = vslope @ ps_expander @ loglogavgslope
-        sig_flex = vflex @ expander @ flexibility if flexibility is not None else None
-        sig_asp = vasp @ expander @ asperity if asperity is not None else None
-        sig_fluc = vol1 @ ps_expander @ fluctuations
-        xi = Variable(dom, key)
-        # flexibility / asperity may be switched off (reference correlated_fields.py:351-363): pure power law, or an
-        # integrated Wiener process without the asperity term
-        if sig_asp is None and sig_flex is None:
-            op = _Normalization(target, space) @ slope
-        elif sig_asp is None:
-            sigma = DiagonalOperator(shift.sqrt()) @ sig_flex
-            smooth = _SlopeRemover(target, space) @ twolog @ (sigma * xi)
-            op = _Normalization(target, space) @ (slope + smooth)
-        elif sig_flex is None:
+        if flexibility is None and asperity is not None:
             raise ValueError("flexibility may not be disabled on its own")
+        lay = _SpectrumLayout(target, dofdex)
+        log_spectrum = _on_space(_relative_log_k_lengths(lay.bins), lay.target, lay.space) @ lay.onto_bins(loglogavgslope)
+        if flexibility is not None:
+            log_spectrum = log_spectrum + self._wiener_deviation(lay, flexibility, asperity, key)
+        shape = _Normalization(lay.target, lay.space) @ log_spectrum
+        # volume factors: the zero-mode slot carries V, every other mode V * fluctuations
+        nonzero, zero = _volume_slots(lay.bins.shape, totvol, totvol)
+        strength = _on_space(nonzero, lay.target, lay.space) @ lay.onto_bins(fluctuations)
+        offset = _on_space(zero, lay.target, lay.space)(full(lay.target, 1.0))
+        if lay.distribute is None:
+            self._op, self._fluc = strength * shape + offset, fluctuations
         else:
-            sigma = sig_flex * (sig_asp + shift).sqrt()
-            smooth = _SlopeRemover(target, space) @ twolog @ (sigma * xi)
-            op = _Normalization(target, space) @ (slope + smooth)
-        if distributor is not None:
-            op = ((distributor @ sig_fluc) * (distributor @ op)) + distributor(vol0)
-            self._fluc = _Distributor(dofdex, fluctuations.target, distributed_tgt[0]) @ fluctuations
+            self._op = (lay.distribute @ strength) * (lay.distribute @ shape) + lay.distribute(offset)
+            self._fluc = _Distributor(lay.dofdex, fluctuations.target, lay.field_copies) @ fluctuations
+        self._domain, self._target, self._space = self._op.domain, self._op.target, lay.space
+
+    @staticmethod
+    def _wiener_deviation(lay, flexibility, asperity, key):
+        """SlopeRemover(TwoLogIntegrations(sigma * xi_s)): the deviation of the log-spectrum from the power law.  Per
+        log-k interval of length l the two excitation rows get sigma = flex sqrt(l) (sqrt(asp + l^2/12), 1); without
+        asperity the first factor is sqrt(l^2/12) (reference correlated_fields.py:315-326, 351-363)."""
+        integrate = _TwoLogIntegrations(lay.target, lay.space)
+        dom = integrate.domain
+        rows = dom[lay.space].shape
+        interval = _log_vol(lay.bins)
+        spread = ContractionOperator(dom, lay.space).adjoint  # hyper-parameter -> both excitation rows
+        root_l, first_row, drift = np.zeros(rows), np.zeros(rows), np.ones(rows)
+        root_l[:] = np.sqrt(interval)
+        first_row[0], drift[0] = 1.0, interval ** 2 / 12.0
+        sigma = _on_space(root_l, dom, lay.space) @ spread @ flexibility
+        drift = _on_space(drift, dom, lay.space)(full(dom, 1.0))
+        if asperity is None:
+            sigma = DiagonalOperator(drift.sqrt()) @ sigma
         else:
-            op = (sig_fluc * op) + vol0
-            self._fluc = fluctuations
-        self._op = op
-        self._domain, self._target = op.domain, op.target
-        self._space = space
+            sigma = sigma * ((_on_space(first_row, dom, lay.space) @ spread @ asperity) + drift).sqrt()
+        return _SlopeRemover(lay.target, lay.space) @ integrate @ (sigma * Variable(dom, key))
 
     def apply(self, x):
         self._check_input(x)
@@ -312,17 +322,14 @@ class _AmplitudeMatern(Operator):
     in (zero mode ~ V, other modes ~ sqrt(V)) (reference library/correlated_fields.py:231-275)."""
 
     def __init__(self, pow_spc, scale, cutoff, loglogslope, totvol):
-        expander = ContractionOperator(pow_spc, None).adjoint
-        k_squared = makeField(makeDomain(pow_spc), pow_spc.k_lengths ** 2)
-        ker = (VdotOperator(k_squared).adjoint @ cutoff.ptw("power", -2.0)) + 1.0
-        ker = (expander.scale(0.25) @ loglogslope) * ker.ptw("log") + (expander @ scale.ptw("log"))
-        op = ker.ptw("exp")
-        vol0, vol1 = np.zeros(pow_spc.shape), np.zeros(pow_spc.shape)
-        vol0[0] = totvol
-        vol1[1:] = totvol ** 0.5
-        op = DiagonalOperator(makeField(op.target, vol1))(op) + makeField(op.target, vol0)
-        self._op = op
-        self._domain, self._target = op.domain, op.target
+        onto_bins = ContractionOperator(pow_spc, None).adjoint
+        k2 = makeField(makeDomain(pow_spc), pow_spc.k_lengths ** 2)
+        # log a = log scale + slope/4 * log(1 + k^2 / cutoff^2), evaluated in log space and exponentiated
+        ratio = (VdotOperator(k2).adjoint @ cutoff.ptw("power", -2.0)) + 1.0
+        log_a = (onto_bins.scale(0.25) @ loglogslope) * ratio.ptw("log") + (onto_bins @ scale.ptw("log"))
+        volume, zero_slot = (makeField(log_a.target, v) for v in _volume_slots(pow_spc.shape, totvol, totvol ** 0.5))
+        self._op = DiagonalOperator(volume)(log_a.ptw("exp")) + zero_slot
+        self._domain, self._target = self._op.domain, self._op.target
 
     def apply(self, x):
         self._check_input(x)
@@ -475,77 +482,31 @@ class CorrelatedFieldMaker:
     integrated Wiener process, reduced variants, Matern); the single full amplitude is fused into one device operator."""
 
     def __init__(self, prefix, total_N=0):
-        if int(total_N) < 0:
-            raise ValueError("total_N must be >= 0")
         self._total_N = int(total_N)  # > 0: total_N fields at once on a leading UnstructuredDomain(total_N)
-        self._prefix = prefix
-        self._a = []
-        self._target_subdomains = []
-        self._azm = None
-        self._offset_mean = None
-        self._hyper = {}
+        if self._total_N < 0:
+            raise ValueError("total_N must be >= 0")
+        self._prefix, self._hyper = prefix, {}
+        self._a, self._target_subdomains = [], []
+        self._azm = self._offset_mean = None
 
-    def add_fluctuations(self, target_subdomain, fluctuations, flexibility, asperity, loglogavgslope, prefix="",
-                         index=None, dofdex=None, harmonic_partner=None):
-        dofdex = self._check_dofdex(dofdex)
-        N = max(dofdex) + 1 if self._total_N > 0 else 0
+    # -- argument plumbing shared by the add_* methods --------------------------------------------------
+    @staticmethod
+    def _partner_of(subdomain, harmonic_partner):
+        """the harmonic space the spectrum lives on: the default codomain unless a compatible one is given"""
         if harmonic_partner is None:
-            harmonic_partner = target_subdomain.get_default_codomain()
-        else:
-            target_subdomain.check_codomain(harmonic_partner)
-            harmonic_partner.check_codomain(target_subdomain)
-        for arg in (fluctuations, loglogavgslope):
-            if len(arg) != 2:
-                raise TypeError
-        for kw, arg in (("flexibility", flexibility), ("asperity", asperity)):
-            if arg is None:
-                continue
-            if len(arg) != 2:
-                raise TypeError
-            if arg[0] <= 0.0 or arg[1] <= 0.0:
-                raise ValueError(f"{kw} must be strictly positive (or None)")
-        if flexibility is None and asperity is not None:
-            raise ValueError("flexibility may not be disabled on its own")
-        pre = self._prefix + str(prefix)
-        fluct = LognormalTransform(*fluctuations, pre + "fluctuations", N)
-        flex = LognormalTransform(*flexibility, pre + "flexibility", N) if flexibility is not None else None
-        asp = LognormalTransform(*asperity, pre + "asperity", N) if asperity is not None else None
-        avgsl = NormalTransform(*loglogavgslope, pre + "loglogavgslope", N)
-        tsd = makeDomain((UnstructuredDomain(N), target_subdomain)) if self._total_N > 0 else makeDomain(target_subdomain)
-        amp = _Amplitude(PowerSpace(harmonic_partner), fluct, flex, asp, avgsl, tsd[-1].total_volume, pre + "spectrum",
-                         dofdex if self._total_N > 0 else ())
-        if index is not None:
-            self._a.insert(index, amp)
-            self._target_subdomains.insert(index, tsd)
-        else:
-            self._a.append(amp)
-            self._target_subdomains.append(tsd)
-        if flexibility is None or asperity is None or self._total_N > 0:
-            self._amp_prefix = None  # reduced amplitude models run on the generic operator graph, never the fused node
-            return
-        self._hyper.update(fluctuations=tuple(fluctuations), flexibility=tuple(flexibility), asperity=tuple(asperity),
-                           loglogavgslope=tuple(loglogavgslope))
-        self._amp_prefix = pre
+            return subdomain.get_default_codomain()
+        for a, b in ((subdomain, harmonic_partner), (harmonic_partner, subdomain)):
+            a.check_codomain(b)
+        return harmonic_partner
 
-    def add_fluctuations_matern(self, target_subdomain, scale, cutoff, loglogslope, prefix="", adjust_for_volume=True,
-                                harmonic_partner=None):
-        """Matern-kernel amplitude A(k) = a (1 + (|k|/b)^2)^(c/4) with log-normal scale a and cutoff b and normal
-        spectral index c (reference library/correlated_fields.py:577-657); runs on the generic operator graph."""
-        if self._total_N > 0:
-            raise NotImplementedError("the Matern amplitude only works for total_N == 0 (as in the reference)")
-        if harmonic_partner is None:
-            harmonic_partner = target_subdomain.get_default_codomain()
-        else:
-            target_subdomain.check_codomain(harmonic_partner)
-            harmonic_partner.check_codomain(target_subdomain)
-        tsd = makeDomain(target_subdomain)
-        pre = self._prefix + str(prefix)
-        amp = _AmplitudeMatern(PowerSpace(harmonic_partner), LognormalTransform(*scale, pre + "scale"),
-                               LognormalTransform(*cutoff, pre + "cutoff"), NormalTransform(*loglogslope, pre + "loglogslope"),
-                               tsd[-1].total_volume if adjust_for_volume else 1.0)
-        self._a.append(amp)
-        self._target_subdomains.append(tsd)
-        self._amp_prefix = None  # never the fused single-amplitude operator
+    @staticmethod
+    def _mean_std(name, value, positive=False):
+        """a (mean, std) hyper-prior; `positive`: both strictly positive (log-normal parameters)"""
+        if len(value) != 2:
+            raise TypeError(f"{name}: expected a (mean, std) pair")
+        if positive and not (value[0] > 0.0 and value[1] > 0.0):
+            raise ValueError(f"{name} must be strictly positive (or None)")
+        return tuple(value)
 
     def _check_dofdex(self, dofdex):
         if dofdex is None:
@@ -555,18 +516,67 @@ class CorrelatedFieldMaker:
             raise ValueError("length of dofdex needs to match total_N")
         return dofdex
 
+    def _copies(self, dofdex):
+        """(checked dofdex, number of independent models it addresses; 0 without total_N)"""
+        dofdex = self._check_dofdex(dofdex)
+        return dofdex, (max(dofdex) + 1 if self._total_N > 0 else 0)
+
+    def _register(self, amplitude, subdomain, index=None, fused_prefix=None):
+        where = len(self._a) if index is None else index
+        self._a.insert(where, amplitude)
+        self._target_subdomains.insert(where, subdomain)
+        self._amp_prefix = fused_prefix  # None: the model runs on the generic operator graph, never the fused node
+
+    def add_fluctuations(self, target_subdomain, fluctuations, flexibility, asperity, loglogavgslope, prefix="",
+                         index=None, dofdex=None, harmonic_partner=None):
+        dofdex, copies = self._copies(dofdex)
+        partner = self._partner_of(target_subdomain, harmonic_partner)
+        priors = dict(fluctuations=self._mean_std("fluctuations", fluctuations),
+                      loglogavgslope=self._mean_std("loglogavgslope", loglogavgslope),
+                      flexibility=None if flexibility is None else self._mean_std("flexibility", flexibility, positive=True),
+                      asperity=None if asperity is None else self._mean_std("asperity", asperity, positive=True))
+        if priors["flexibility"] is None and priors["asperity"] is not None:
+            raise ValueError("flexibility may not be disabled on its own")
+        pre = self._prefix + str(prefix)
+
+        def hyper(name, transform):
+            return None if priors[name] is None else transform(*priors[name], pre + name, copies)
+
+        many = self._total_N > 0
+        subdomain = makeDomain((UnstructuredDomain(copies), target_subdomain) if many else target_subdomain)
+        amplitude = _Amplitude(PowerSpace(partner), hyper("fluctuations", LognormalTransform),
+                               hyper("flexibility", LognormalTransform), hyper("asperity", LognormalTransform),
+                               hyper("loglogavgslope", NormalTransform), subdomain[-1].total_volume, pre + "spectrum",
+                               dofdex if many else ())
+        # only the full single-field model has a fused device operator
+        fusable = not many and None not in (priors["flexibility"], priors["asperity"])
+        self._register(amplitude, subdomain, index, pre if fusable else None)
+        if fusable:
+            self._hyper.update(priors)
+
+    def add_fluctuations_matern(self, target_subdomain, scale, cutoff, loglogslope, prefix="", adjust_for_volume=True,
+                                harmonic_partner=None):
+        """Matern-kernel amplitude A(k) = a (1 + (|k|/b)^2)^(c/4) with log-normal scale a and cutoff b and normal
+        spectral index c (reference library/correlated_fields.py:577-657); runs on the generic operator graph."""
+        if self._total_N > 0:
+            raise NotImplementedError("the Matern amplitude only works for total_N == 0 (as in the reference)")
+        bins = PowerSpace(self._partner_of(target_subdomain, harmonic_partner))
+        subdomain = makeDomain(target_subdomain)
+        recipe = (("scale", scale, LognormalTransform), ("cutoff", cutoff, LognormalTransform),
+                  ("loglogslope", loglogslope, NormalTransform))
+        latent = [transform(*prior, self._prefix + str(prefix) + name) for name, prior, transform in recipe]
+        self._register(_AmplitudeMatern(bins, *latent, subdomain[-1].total_volume if adjust_for_volume else 1.0), subdomain)
+
     def set_amplitude_total_offset(self, offset_mean, offset_std, dofdex=None):
-        self._offset_mean = offset_mean
         if offset_std is None or np.isscalar(offset_std) or isinstance(offset_std, Operator):
             raise NotImplementedError("only a (mean, std) tuple is supported for offset_std")
         if len(offset_std) != 2:
             raise TypeError("`offset_std` of invalid type and/or shape; expected a 2D tuple of floats")
-        dofdex = self._check_dofdex(dofdex)
-        N = max(dofdex) + 1 if self._total_N > 0 else 0
-        zm = LognormalTransform(*offset_std, self._prefix + "zeromode", N)
-        if self._total_N > 0:
-            zm = _Distributor(dofdex, zm.target, UnstructuredDomain(self._total_N)) @ zm
-        self._azm = zm
+        dofdex, copies = self._copies(dofdex)
+        zero_mode = LognormalTransform(*offset_std, self._prefix + "zeromode", copies)
+        if self._total_N > 0:  # one zero-mode model per entry of dofdex, copied onto the fields
+            zero_mode = _Distributor(dofdex, zero_mode.target, UnstructuredDomain(self._total_N)) @ zero_mode
+        self._azm, self._offset_mean = zero_mode, offset_mean
         self._hyper["offset_std"] = tuple(offset_std)
 
     @property

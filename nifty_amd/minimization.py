@@ -136,43 +136,39 @@ class QuadraticEnergy(Energy):
 # iteration controllers
 # ------------------------------------------------------------------------------------------------
 class EnergyHistory:
-    def __init__(self):
-        self._lst = []
+    """Time-stamped energy values of a minimisation, kept as two parallel columns."""
+
+    def __init__(self, stamps=(), values=()):
+        self._stamps, self._values = list(stamps), list(values)
 
     def append(self, x):
-        if len(x) != 2:
-            raise ValueError
-        self._lst.append((float(x[0]), float(x[1])))
+        stamp, value = x  # (anything but a pair: ValueError, like the reference)
+        self._stamps.append(float(stamp))
+        self._values.append(float(value))
 
     def reset(self):
-        self._lst = []
+        del self._stamps[:], self._values[:]
 
     def __getitem__(self, i):
-        return self._lst[i]
+        return self._stamps[i], self._values[i]
 
     def __len__(self):
-        return len(self._lst)
+        return len(self._values)
 
-    @property
-    def time_stamps(self):
-        return [t for t, _ in self._lst]
+    time_stamps = property(lambda self: list(self._stamps))
+    energy_values = property(lambda self: list(self._values))
 
-    @property
-    def energy_values(self):
-        return [e for _, e in self._lst]
+    def _joined(self, other, into):
+        if not isinstance(other, EnergyHistory):
+            return NotImplemented
+        into._stamps, into._values = self._stamps + other._stamps, self._values + other._values
+        return into
 
     def __add__(self, other):
-        if not isinstance(other, EnergyHistory):
-            return NotImplemented
-        res = EnergyHistory()
-        res._lst = self._lst + other._lst
-        return res
+        return self._joined(other, EnergyHistory())
 
     def __iadd__(self, other):
-        if not isinstance(other, EnergyHistory):
-            return NotImplemented
-        self._lst += other._lst
-        return self
+        return self._joined(other, self)
 
 
 def _logged(fn):
