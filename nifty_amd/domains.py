@@ -86,26 +86,21 @@ class RGSpace(StructuredDomain):
 
     def __init__(self, shape, distances=None, harmonic=False, _realdistances=None):
         self._harmonic = bool(harmonic)
-        if np.isscalar(shape):
-            shape = (shape,)
-        self._shape = tuple(int(i) for i in shape)
-        if min(self._shape) < 0:
+        self._shape = tuple(int(n) for n in np.atleast_1d(shape))
+        if any(n < 0 for n in self._shape):
             raise ValueError("Negative number of pixels encountered")
-        nshape = np.array(self._shape)
-        if _realdistances is not None:
-            rd = tuple(_realdistances)
-        elif distances is None:
-            rd = tuple(1.0 / nshape)
-        elif np.isscalar(distances):
-            rd = tuple(1.0 / (nshape * float(distances))) if self._harmonic else (float(distances),) * len(self._shape)
-        else:
-            tmp = np.empty(len(self._shape), dtype=np.float64)
-            tmp[:] = distances
-            rd = tuple(1.0 / (nshape * tmp)) if self._harmonic else tuple(tmp)
-        self._rdistances = tuple(float(d) for d in rd)
-        self._hdistances = tuple(float(d) for d in 1.0 / (nshape * np.array(self._rdistances)))
-        if min(self._rdistances) <= 0:
+        cells = np.array(self._shape, dtype=np.float64)
+        if _realdistances is not None:       # handed over by the partner space: bit-identical round trips
+            position = np.array(_realdistances, dtype=np.float64)
+        elif distances is None:              # unit total volume in position space
+            position = 1.0 / cells
+        else:                                # given for THIS space: a harmonic space stores its partner's distances
+            own = np.broadcast_to(np.asarray(distances, dtype=np.float64), cells.shape)
+            position = 1.0 / (cells * own) if self._harmonic else own
+        if position.shape != cells.shape or (position <= 0).any():
             raise ValueError("Non-positive distances encountered")
+        self._rdistances = tuple(float(d) for d in position)
+        self._hdistances = tuple(float(d) for d in 1.0 / (cells * position))
         self._dvol = float(reduce(lambda a, b: a * b, self.distances))
 
     def _key(self):
@@ -140,13 +135,14 @@ class RGSpace(StructuredDomain):
     def check_codomain(self, codomain):
         if not isinstance(codomain, RGSpace):
             raise TypeError("domain is not a RGSpace")
-        if self._shape != codomain.shape:
-            raise AttributeError("The shapes of domain and codomain must be identical.")
-        if self._harmonic == codomain.harmonic:
-            raise AttributeError("domain.harmonic and codomain.harmonic must not be the same.")
-        prod = np.array(self._shape) * np.array(self.distances) * np.array(codomain.distances)
-        if not np.all(np.abs(prod - 1) < 1e-7):
-            raise AttributeError("The grid-distances of domain and codomain do not match.")
+        # a grid and its Fourier partner: same cells, opposite character, n_i * d_i * d'_i = 1 on every axis
+        unit = [n * d * dk for n, d, dk in zip(self._shape, self.distances, codomain.distances)]
+        problems = (("The shapes of domain and codomain must be identical.", self._shape != codomain.shape),
+                    ("domain.harmonic and codomain.harmonic must not be the same.", self._harmonic == codomain.harmonic),
+                    ("The grid-distances of domain and codomain do not match.", any(abs(u - 1.0) >= 1e-7 for u in unit)))
+        for message, wrong in problems:
+            if wrong:
+                raise AttributeError(message)
 
     # --- harmonic-space geometry ---------------------------------------------------------------
     def _dist_array(self):
@@ -366,6 +362,13 @@ class PowerSpace(StructuredDomain):
         return np.logspace(np.log(float(first_bound)), np.log(float(last_bound)), nbin - 1, base=np.e)
 
 
+def _interned(cache, key, build):
+    """cache[key], built on first request: one object per distinct domain, so identity compares domains"""
+    if key not in cache:
+        cache[key] = build()
+    return cache[key]
+
+
 class DomainTuple:
     """Ordered product of Domains, interned (reference domain_tuple.py)."""
 
@@ -376,15 +379,11 @@ class DomainTuple:
         if not _callingfrommake:
             raise NotImplementedError("To create a DomainTuple call `DomainTuple.make()`.")
         self._dom = self._parse(domain)
-        self._axes = []
-        i = 0
-        for d in self._dom:
-            n = len(d.shape)
-            self._axes.append(tuple(range(i, i + n)))
-            i += n
-        self._axes = tuple(self._axes)
+        ranks = [len(d.shape) for d in self._dom]
+        firsts = [sum(ranks[:i]) for i in range(len(ranks))]  # first array axis of every sub-domain
+        self._axes = tuple(tuple(range(lo, lo + n)) for lo, n in zip(firsts, ranks))
         self._shape = tuple(s for d in self._dom for s in d.shape)
-        self._size = int(reduce(lambda a, b: a * b, self._shape, 1))
+        self._size = int(np.prod(self._shape, dtype=np.int64)) if self._shape else 1
 
     @staticmethod
     def _parse(domain):
@@ -403,15 +402,11 @@ class DomainTuple:
 
     @staticmethod
     def make(domain):
-        if isinstance(domain, DomainTuple):
-            return domain
-        if isinstance(domain, dict):
-            return MultiDomain.make(domain)
-        dom = DomainTuple._parse(domain)
-        obj = DomainTuple._cache.get(dom)
-        if obj is None:
-            obj = DomainTuple._cache[dom] = DomainTuple(dom, _callingfrommake=True)
-        return obj
+        """The ONE DomainTuple object of these sub-domains (interning makes `is` the domain comparison)."""
+        if isinstance(domain, (DomainTuple, dict)):
+            return domain if isinstance(domain, DomainTuple) else MultiDomain.make(domain)
+        parts = DomainTuple._parse(domain)
+        return _interned(DomainTuple._cache, parts, lambda: DomainTuple(parts, _callingfrommake=True))
 
     @staticmethod
     def scalar_domain():
@@ -473,20 +468,13 @@ class MultiDomain:
 
     @staticmethod
     def make(inp):
+        """The ONE MultiDomain object with these keys and sub-domains (interned like DomainTuple)."""
         if isinstance(inp, MultiDomain):
             return inp
-        if not isinstance(inp, dict):
-            raise TypeError("dict expected")
-        tmp = {}
-        for k, v in inp.items():
-            if not isinstance(k, str):
-                raise TypeError("keys must be strings")
-            tmp[k] = DomainTuple.make(v)
-        key = tuple(sorted(tmp.items(), key=lambda kv: kv[0]))
-        obj = MultiDomain._cache.get(key)
-        if obj is None:
-            obj = MultiDomain._cache[key] = MultiDomain(tmp, _callingfrommake=True)
-        return obj
+        if not (isinstance(inp, dict) and all(isinstance(key, str) for key in inp)):
+            raise TypeError("dict expected" if not isinstance(inp, dict) else "keys must be strings")
+        entries = tuple((key, DomainTuple.make(inp[key])) for key in sorted(inp))
+        return _interned(MultiDomain._cache, entries, lambda: MultiDomain(dict(entries), _callingfrommake=True))
 
     def keys(self):
         return self._keys
@@ -530,15 +518,11 @@ class MultiDomain:
 
     @staticmethod
     def union(inp):
-        res = {}
-        for dom in inp:
-            for k, v in dom.items():
-                if k in res:
-                    if res[k] != v:
-                        raise ValueError(f"domain mismatch for key {k!r}")
-                else:
-                    res[k] = v
-        return MultiDomain.make(res)
+        merged = {}
+        for key, sub in (item for dom in inp for item in dom.items()):
+            if merged.setdefault(key, sub) != sub:
+                raise ValueError(f"domain mismatch for key {key!r}")
+        return MultiDomain.make(merged)
 
     def __reduce__(self):
         return (MultiDomain.make, (dict(self.items()),))

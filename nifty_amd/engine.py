@@ -36,13 +36,14 @@ _NONLIN = {None: L.NL_ID, "": L.NL_ID, "exp": L.NL_EXP, "sigmoid": L.NL_SIGMOID}
 
 def lognormal_moments(mean, sigma):
     """reference nifty/cl/utilities.py:500-513"""
-    mean, sigma = float(mean), float(sigma)
-    if not mean > 0:
-        raise ValueError(f"mean must be greater 0; got {mean!r}")
-    if not sigma > 0:
-        raise ValueError(f"sig must be greater 0; got {sigma!r}")
-    logsigma = math.sqrt(math.log1p((sigma / mean) ** 2))
-    return math.log(mean) - logsigma ** 2 / 2, logsigma
+    checked = {}
+    for name, value in (("mean", mean), ("sig", sigma)):
+        checked[name] = float(value)
+        if not checked[name] > 0:
+            raise ValueError(f"{name} must be greater 0; got {checked[name]!r}")
+    # a log-normal with these moments: variance of the log = log(1 + (sigma/mean)^2), mean of the log below the log-mean
+    logsigma = math.sqrt(math.log1p((checked["sig"] / checked["mean"]) ** 2))
+    return math.log(checked["mean"]) - logsigma ** 2 / 2, logsigma  # (the reference's rounding: the square of the root)
 
 
 # ------------------------------------------------------------------------------------------------

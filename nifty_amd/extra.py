@@ -11,12 +11,14 @@ __all__ = ["check_linear_operator", "check_operator", "assert_allclose", "minisa
 
 def assert_allclose(f1, f2, atol=0, rtol=1e-7):
     """Field / MultiField comparison (reference extra.py:186-192)."""
-    if isinstance(f1, Field):
-        return np.testing.assert_allclose(f1.asnumpy(), f2.asnumpy(), atol=atol, rtol=rtol)
-    if f1.domain is not f2.domain:
-        raise AssertionError
-    for key in f1.keys():
-        assert_allclose(f1[key], f2[key], atol=atol, rtol=rtol)
+    if not isinstance(f1, Field):  # MultiFields: same domain object, then key by key
+        if f1.domain is not f2.domain:
+            raise AssertionError
+        pairs = [(f1[key], f2[key]) for key in f1.keys()]
+    else:
+        pairs = [(f1, f2)]
+    for a, b in pairs:
+        np.testing.assert_allclose(a.asnumpy(), b.asnumpy(), atol=atol, rtol=rtol)
 
 
 def _device_ids(force_device_ids):

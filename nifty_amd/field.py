@@ -90,12 +90,10 @@ class Field:
     def __init__(self, domain, val):
         if not isinstance(domain, DomainTuple):
             raise TypeError("domain must be of type DomainTuple")
-        if not isinstance(val, torch.Tensor):
-            val = _as_tensor(val)
-        if tuple(val.shape) != domain.shape:
-            raise ValueError(f"shape mismatch: {tuple(val.shape)} vs {domain.shape}")
-        self._domain = domain
-        self._val = val
+        tensor = val if isinstance(val, torch.Tensor) else _as_tensor(val)
+        if domain.shape != tuple(tensor.shape):
+            raise ValueError(f"shape mismatch: {tuple(tensor.shape)} vs {domain.shape}")
+        self._domain, self._val = domain, tensor
 
     # ---- constructors ---------------------------------------------------------------------
     @staticmethod
@@ -398,25 +396,22 @@ class MultiField:
     def __init__(self, domain, val):
         if not isinstance(domain, MultiDomain):
             raise TypeError("domain must be of type MultiDomain")
-        if not isinstance(val, tuple) or len(val) != len(domain):
+        if not (isinstance(val, tuple) and len(val) == len(domain)):
             raise ValueError("length mismatch")
-        for d, v in zip(domain.domains(), val):
-            if not isinstance(v, Field) or v.domain is not d:
-                raise ValueError("domain mismatch")
-        self._domain = domain
-        self._val = val
+        if not all(isinstance(f, Field) and f.domain is sub for f, sub in zip(val, domain.domains())):
+            raise ValueError("domain mismatch")  # one Field per key, each on that key's (interned) DomainTuple
+        self._domain, self._val = domain, val
 
     @staticmethod
     def from_dict(dct, domain=None):
         if domain is None:
-            for dd in dct.values():
-                if not isinstance(dd.domain, DomainTuple):
-                    raise TypeError("Values of dictionary need to be Fields defined on DomainTuples.")
-            domain = MultiDomain.make({k: v.domain for k, v in dct.items()})
-        missing = [k for k in domain.keys() if k not in dct]
-        if missing:
-            raise ValueError(f"missing keys: {missing}")
-        return MultiField(domain, tuple(dct[k] for k in domain.keys()))
+            if not all(isinstance(f.domain, DomainTuple) for f in dct.values()):
+                raise TypeError("Values of dictionary need to be Fields defined on DomainTuples.")
+            domain = MultiDomain.make({k: f.domain for k, f in dct.items()})
+        try:
+            return MultiField(domain, tuple(dct[k] for k in domain.keys()))
+        except KeyError:
+            raise ValueError(f"missing keys: {[k for k in domain.keys() if k not in dct]}") from None
 
     @staticmethod
     def from_raw(domain, arr, device_id=None):
@@ -432,12 +427,9 @@ class MultiField:
     def from_random(domain, random_type="normal", dtype=np.float64, device_id=-1, **kwargs):
         """One draw per key in ALPHABETICAL order (the parity-relevant RNG order, multi_field.py:109-153)."""
         domain = MultiDomain.make(domain)
-        if isinstance(dtype, dict):
-            dts = [dtype[k] for k in domain.keys()]
-        else:
-            dts = [dtype] * len(domain)
-        return MultiField(domain, tuple(Field.from_random(d, random_type, dt, device_id, **kwargs)
-                                        for d, dt in zip(domain.domains(), dts)))
+        per_key = dtype if isinstance(dtype, dict) else dict.fromkeys(domain.keys(), dtype)
+        draws = [Field.from_random(sub, random_type, per_key[key], device_id, **kwargs) for key, sub in domain.items()]
+        return MultiField(domain, tuple(draws))
 
     def to_dict(self):
         return {k: v for k, v in zip(self._domain.keys(), self._val)}
@@ -580,13 +572,12 @@ class MultiField:
     def flexible_addsub(self, other, neg):
         if self._domain is other._domain:
             return self - other if neg else self + other
-        res = self.to_dict()
-        for k, v in other.items():
-            if k in res:
-                res[k] = res[k] - v if neg else res[k] + v
-            else:
-                res[k] = -v if neg else v
-        return MultiField.from_dict(res)
+        # different key sets: keys both know are combined, the others pass through (with the sign for `other`'s)
+        mine = self.to_dict()
+        theirs = {k: -f if neg else f for k, f in other.items()}
+        merged = {k: mine[k] + theirs[k] if (k in mine and k in theirs) else mine.get(k, theirs.get(k))
+                  for k in {**mine, **theirs}}
+        return MultiField.from_dict(merged)
 
     def __repr__(self):
         return "<nifty_amd.MultiField keys=" + ", ".join(self.keys()) + ">"

@@ -28,21 +28,22 @@ def _scalar_value(field):
     return float(np.real(v))
 
 
+def _nan_to_inf(value, nanisinf):
+    """an energy that cannot be evaluated counts as infinitely bad when the caller asks for that"""
+    return np.inf if (nanisinf and np.isnan(value)) else value
+
+
 class EnergyAdapter(Energy):
     """Energy protocol on top of an EnergyOperator (reference energy_adapter.py:28-110)."""
 
     def __init__(self, position, op, constants=[], want_metric=False, nanisinf=False):
-        if len(constants) > 0:  # constant keys are inserted into the operator (energy_adapter.py:56-60)
-            _, op = op.simplify_for_constant_input(position.extract_by_keys(constants))
-            position = position.extract_by_keys(set(op.domain.keys()) - set(constants))
+        if constants:  # constant keys are frozen into the operator; the energy lives on the remaining keys
+            position, op = _reduce_by_keys(position, op, constants)
         super().__init__(position)
         self._op, self._want_metric, self._nanisinf = op, want_metric, nanisinf
-        lin = op(Linearization.make_var(position, want_metric))
-        self._val = _scalar_value(lin.val)
-        if self._nanisinf and np.isnan(self._val):
-            self._val = np.inf
-        self._grad = lin.gradient
-        self._metric = lin.metric
+        here = op(Linearization.make_var(position, want_metric))
+        self._grad, self._metric = here.gradient, here.metric
+        self._val = _nan_to_inf(_scalar_value(here.val), nanisinf)
 
     def at(self, position):
         return EnergyAdapter(position, self._op, want_metric=self._want_metric, nanisinf=self._nanisinf)
@@ -133,10 +134,12 @@ class SampleListBase:
     def _device_id(self):
         return -1
 
-    def _sum_over_ranks(self, local_terms):
+    def _sum_over_ranks(self, local_terms, like=None):
         """Sum of Fields / MultiFields / floats (or tuples of those) over the local terms and over all ranks.  Ranks
         WITHOUT samples (shareRange leaves ranks empty when there are fewer samples than ranks, utilities.py:349-414 copes
-        with any split) contribute a zero element whose shape they learn from the first rank that holds a term."""
+        with any split) contribute a zero element.  `like`: an object shaped like one term (floats, fields on this rank's
+        device) -- the caller usually knows it, and the zero is then built locally, once.  Without it the first rank that
+        holds a term broadcasts a host template (a pickled collective per call: diagnostics only)."""
         acc = None
         for t in local_terms:
             acc = t if acc is None else _add(acc, t)
@@ -145,11 +148,20 @@ class SampleListBase:
             if acc is None:
                 raise ValueError("sum over an empty sample list")
             return acc
-        have = comm.allgather_object(acc is not None)
-        if not any(have):
+        # which ranks hold samples never changes for a list: asked once (one pickled all-gather), not per call
+        if getattr(self, "_holders", None) is None:
+            self._holders = comm.allgather_object(acc is not None)
+        if not any(self._holders):
             raise ValueError("sum over an empty sample list")
-        if not all(have):
-            root = have.index(True)
+        if like is not None:
+            if acc is None:
+                zeros = self.__dict__.setdefault("_zeros", {})
+                key = _map(like, lambda o: float if isinstance(o, float) else id(o.domain))
+                if key not in zeros:
+                    zeros[key] = _map(like, lambda o: 0.0 if isinstance(o, float) else o * 0.0)
+                acc = zeros[key]
+        elif not all(self._holders):
+            root = self._holders.index(True)
             template = comm.bcast_object(_zero_like_host(acc) if comm.rank == root else None, root=root)
             if acc is None:
                 acc = _place_like(template, self._device_id())
@@ -180,8 +192,9 @@ class SampleListBase:
     def sample_stat(self, op=None):
         """(mean, variance) over the samples (sample_list.py:272-293); distributed lists go through iterator()."""
         n = self.n_samples
-        if n < 2:
-            raise RuntimeError("need at least two samples")
+        if n == 1:  # (sample_list.py:287-289: the mean and a zero variance)
+            only = self.average(op)
+            return only, only * 0.0
         samples = list(self.iterator(op))
         mean = samples[0]
         for s in samples[1:]:
@@ -204,35 +217,33 @@ class SampleListBase:
         optional dependency imported here, as in the reference: without it this raises ImportError."""
         import h5py
 
+        if not (samples or mean or std):
+            raise ValueError("Neither samples nor mean nor standard deviation shall be written.")
         writer = self._rank == 0
         if os.path.isfile(file_name):
             if not overwrite:
                 raise RuntimeError(f"File {file_name} already exists. Delete it or use `overwrite=True`")
             if writer:
                 os.remove(file_name)
-        if not (samples or mean or std):
-            raise ValueError("Neither samples nor mean nor standard deviation shall be written.")
         out = h5py.File(file_name, "w") if writer else _NullGroup()
-        if isinstance(op, Operator):
-            out.attrs["nifty operator string representation"] = str(op)
-            out.attrs["nifty operator domain"] = repr(op.domain)
-            out.attrs["nifty operator target"] = repr(op.target)
-            out.attrs["nifty domain"] = repr(op.target)
-        else:
-            out.attrs["nifty domain"] = repr(self.domain)
+        described = op if isinstance(op, Operator) else None
+        out.attrs["nifty domain"] = repr(self.domain if described is None else described.target)
+        if described is not None:
+            out.attrs.update({"nifty operator string representation": str(op), "nifty operator domain": repr(op.domain),
+                              "nifty operator target": repr(op.target)})
+        entries = []  # (group, name, field) in the order they are written; every rank walks the same collectives
         if samples:
-            group = out.create_group("samples")
-            for number, sample in enumerate(self.iterator(op)):
-                _write_hdf5_entry(group, str(number), sample)
-        if mean or std:
-            group = out.create_group("stats")
-            if std:
-                mu, variance = self.sample_stat(op)
-                if mean:
-                    _write_hdf5_entry(group, "mean", mu)
-                _write_hdf5_entry(group, "standard deviation", variance.sqrt())
-            else:
-                _write_hdf5_entry(group, "mean", self.average(op))
+            entries += [("samples", str(number), sample) for number, sample in enumerate(self.iterator(op))]
+        if std:
+            mu, variance = self.sample_stat(op)
+            entries += ([("stats", "mean", mu)] if mean else []) + [("stats", "standard deviation", variance.sqrt())]
+        elif mean:
+            entries.append(("stats", "mean", self.average(op)))
+        groups = {}
+        for group, name, field in entries:
+            if group not in groups:
+                groups[group] = out.create_group(group)
+            _write_hdf5_entry(groups[group], name, field)
         out.close()
         if self._comm is not None:
             self._comm.barrier()
@@ -306,13 +317,13 @@ class ResidualSampleList(SampleListBase):
 
     def save(self, file_name_base, overwrite=False):
         """One pickle per sample: [residual(host dict), neg] + .mean.pickle (sample_list.py:467-484)."""
-        nsample = self.n_samples
-        lo, _ = shareRange(nsample, self._ntask, self._rank)
-        for i, (r, n) in enumerate(zip(self._r, self._n)):
-            _dump(f"{file_name_base}.{lo + i}.pickle", [_to_host(r), n], overwrite)
+        total = self.n_samples
+        first = shareRange(total, self._ntask, self._rank)[0]  # global number of this rank's first sample
+        files = {f"{file_name_base}.{first + i}.pickle": [_to_host(res), neg] for i, (res, neg) in enumerate(zip(self._r, self._n))}
         if self._rank == 0:
-            _dump(f"{file_name_base}.mean.pickle", _to_host(self._m), overwrite)
-            _dump(f"{file_name_base}.nsamples", nsample, overwrite)
+            files.update({f"{file_name_base}.mean.pickle": _to_host(self._m), f"{file_name_base}.nsamples": total})
+        for name, content in files.items():
+            _dump(name, content, overwrite)
 
     @staticmethod
     def load_mean(file_name_base):
@@ -466,34 +477,39 @@ def draw_samples(position, H, minimizer, n_samples, mirror_samples, napprox=0, w
     return ResidualSampleList(position, [r for r, _ in drawn], [n for _, n in drawn], comm)
 
 
-def SampledKLEnergy(position, hamiltonian, n_samples, minimizer_sampling, mirror_samples=True, constants=[],
-                    point_estimates=[], napprox=0, comm=None, nanisinf=True, device_id=-1):
-    """Draw samples at ``position`` and return the sampled KL energy (kl_energies.py:162-296)."""
-    checks = ((hamiltonian, StandardHamiltonian), (n_samples, int), (mirror_samples, bool),
-              (minimizer_sampling, (DescentMinimizer, type(None))))
-    for arg, kind in checks:
-        if not isinstance(arg, kind):
-            raise TypeError
-    if hamiltonian.domain is not position.domain:
-        raise ValueError
+def _checked_key_sets(position, constants, point_estimates):
+    """(constants, point estimates) as sets, checked against the keys of the latent space"""
     frozen, estimated = set(constants), set(point_estimates)
     if isinstance(position, MultiField):
         keys = set(position.keys())
-        if not frozen <= keys:
-            raise ValueError(f"Constants are not a subset of the keys of the latent space: {constants}")
-        if not estimated <= keys:
-            raise ValueError(f"Point estimates are not a subset of the keys of the latent space: {point_estimates}")
+        for what, subset, given in (("Constants", frozen, constants), ("Point estimates", estimated, point_estimates)):
+            if not subset <= keys:
+                raise ValueError(f"{what} are not a subset of the keys of the latent space: {given}")
         if estimated == keys:
             raise RuntimeError("Point estimates for whole domain. Use EnergyAdapter instead.")
+    return frozen, estimated
+
+
+def SampledKLEnergy(position, hamiltonian, n_samples, minimizer_sampling, mirror_samples=True, constants=[],
+                    point_estimates=[], napprox=0, comm=None, nanisinf=True, device_id=-1):
+    """Draw samples at ``position`` and return the sampled KL energy (kl_energies.py:162-296)."""
+    expected = {"hamiltonian": (hamiltonian, StandardHamiltonian), "n_samples": (n_samples, int),
+                "mirror_samples": (mirror_samples, bool), "minimizer_sampling": (minimizer_sampling, (DescentMinimizer, type(None)))}
+    wrong = [name for name, (arg, kind) in expected.items() if not isinstance(arg, kind)]
+    if wrong:
+        raise TypeError(f"invalid type of: {', '.join(wrong)}")
+    if hamiltonian.domain is not position.domain:
+        raise ValueError
+    frozen, estimated = _checked_key_sets(position, constants, point_estimates)
     # keys that are constant AND point estimates leave the problem entirely (kl_energies.py:281-287) ...
     gone = sorted(frozen & estimated)
-    left_out = position.extract_by_keys(gone) if isinstance(position, MultiField) and gone else None
+    left_out = position.extract_by_keys(gone) if (gone and isinstance(position, MultiField)) else None
     position, hamiltonian = _reduce_by_keys(position, hamiltonian, gone)
     # ... and nothing is sampled along the point estimates: they are inserted into the sampling Hamiltonian (:289-293)
-    _, sampling_hamiltonian = _reduce_by_keys(position, hamiltonian, point_estimates)
-    samples = draw_samples(position, sampling_hamiltonian, minimizer_sampling, n_samples, mirror_samples, napprox=napprox,
-                           comm=comm, device_id=device_id)
-    return SampledKLEnergyClass(samples, hamiltonian, constants, left_out, nanisinf)
+    sampling_hamiltonian = _reduce_by_keys(position, hamiltonian, point_estimates)[1]
+    drawn = draw_samples(position, sampling_hamiltonian, minimizer_sampling, n_samples, mirror_samples, napprox=napprox,
+                         comm=comm, device_id=device_id)
+    return SampledKLEnergyClass(drawn, hamiltonian, constants, left_out, nanisinf)
 
 
 def _reduce_field(field, keys):
@@ -504,14 +520,13 @@ def _reduce_field(field, keys):
 
 def _reduce_by_keys(field, operator, keys):
     """(variable part of the field, operator with the constant part inserted) (kl_energies.py:49-76)."""
-    if isinstance(field, MultiField):
-        cst = field.extract_by_keys(keys)
-        var = field.extract_by_keys(set(field.keys()) - set(keys))
-        _, operator = operator.simplify_for_constant_input(cst)
-        return var, operator
-    if len(keys) != 0:
-        raise ValueError("constants need a MultiField position")
-    return field, operator
+    keys = set(keys)
+    if not isinstance(field, MultiField):
+        if keys:
+            raise ValueError("constants need a MultiField position")
+        return field, operator
+    frozen = operator.simplify_for_constant_input(field.extract_by_keys(keys))[1]
+    return field.extract_by_keys(set(field.keys()) - keys), frozen
 
 
 class SampledKLEnergyClass(Energy):
@@ -527,16 +542,16 @@ class SampledKLEnergyClass(Energy):
         super().__init__(_reduce_field(sample_list._m, constants))
         self._sample_list, self._hamiltonian = sample_list, hamiltonian
         self._constants, self._invariants, self._nanisinf = constants, invariants, bool(nanisinf)
-        # per sample: the constant keys of THIS sample are inserted, the rest is differentiated (:318-321)
-        self._lins = []
-        for sample in sample_list.local_iterator():
+
+        def linearised(sample):  # the constant keys of THIS sample are inserted, the rest is differentiated (:318-321)
             variable, ham = _reduce_by_keys(sample, hamiltonian, constants)
-            self._lins.append(ham(Linearization.make_var(variable, want_metric=True)))
-        n = sample_list.n_samples
-        value, gradient = sample_list._sum_over_ranks((_scalar_value(lin.val), lin.gradient) for lin in self._lins)
-        self._val, self._grad = value / n, gradient * (1.0 / n)
-        if np.isnan(self._val) and self._nanisinf:
-            self._val = np.inf
+            return ham(Linearization.make_var(variable, want_metric=True))
+
+        self._lins = [linearised(sample) for sample in sample_list.local_iterator()]
+        weight = 1.0 / sample_list.n_samples
+        value, gradient = sample_list._sum_over_ranks(((_scalar_value(lin.val), lin.gradient) for lin in self._lins),
+                                                      like=(0.0, self._position))
+        self._val, self._grad = _nan_to_inf(value * weight, self._nanisinf), gradient * weight
 
     @property
     def value(self):
@@ -551,7 +566,7 @@ class SampledKLEnergyClass(Energy):
                                     self._invariants, self._nanisinf)
 
     def apply_metric(self, x):
-        total = self._sample_list._sum_over_ranks(lin.metric(x) for lin in self._lins)
+        total = self._sample_list._sum_over_ranks((lin.metric(x) for lin in self._lins), like=x)
         return total * (1.0 / self._sample_list.n_samples)
 
     @property

@@ -284,13 +284,10 @@ def check_MPI_equality(obj, comm, hash=False):
 
 
 def check_MPI_synced_random_state(comm):
-    """RuntimeError unless the seed-sequence / generator stacks agree on all ranks (utilities.py:556-571): a rank with
-    a desynchronised stack would silently draw different samples."""
-    if comm is None:
-        return
+    """RuntimeError unless the seed-sequence / generator stacks agree on all ranks (utilities.py:556-571)."""
     from .random import getState
 
-    check_MPI_equality(getState(), comm)
+    return None if comm is None else check_MPI_equality(getState(), comm)  # (a stray stack = silently different samples)
 
 
 class ensure_all_tasks_succeed:

@@ -13,13 +13,15 @@ class StatCalculator:
         self._count = 0
 
     def add(self, value):
+        """Welford update: mean and the sum of squared deviations M2 advance together, in one pass over `value`."""
+        first = self._count == 0
         self._count += 1
-        if self._count == 1:
+        if first:
             self._mean, self._m2 = value * 1.0, value * 0.0
-            return
-        delta = value - self._mean
-        self._mean = self._mean + delta * (1.0 / self._count)
-        self._m2 = self._m2 + delta * (value - self._mean)
+        else:
+            before = value - self._mean                      # deviation from the old mean ...
+            self._mean = self._mean + before * (1.0 / self._count)
+            self._m2 = self._m2 + before * (value - self._mean)  # ... times the deviation from the new one
 
     @property
     def mean(self):

@@ -178,11 +178,10 @@ class Random:
     def pm1(dtype, shape):
         """+-1 (real) or one of 1, i, -1, -i (complex) with equal probability."""
         dtype, kind = _kind(dtype)
-        rng = current_rng()
-        if kind == "complex":
-            units = np.array([1, 1j, -1, -1j], dtype=dtype)
-            return units[rng.integers(0, 4, size=shape)]
-        return (2 * rng.integers(0, 2, size=shape) - 1).astype(dtype, copy=False)
+        # the n-th roots of unity for n = 4 (complex) or 2 (real), picked by ONE bounded integer draw per element -- the
+        # reference's `integers(0, n)` call, so the generator advances identically
+        roots = np.array([1, 1j, -1, -1j] if kind == "complex" else [-1, 1], dtype=dtype)
+        return roots[current_rng().integers(0, len(roots), size=shape)]
 
     @staticmethod
     def uniform(dtype, shape, low=0.0, high=1.0):
