@@ -209,6 +209,16 @@ enum { NK_OP_ADD = 0, NK_OP_SUB = 1, NK_OP_MUL = 2, NK_OP_DIV = 3 };
 /* out = a (op) b ;  b == NULL -> out = a (op) bscalar ; a == NULL -> out = ascalar (op) b */
 int nk_binary(int op, int64_t n, const void* a, double ascalar, const void* b, double bscalar, void* out,
               int dtype, void* stream);
+/* complex element-wise products / quotients on interleaved (re, im) arrays of `dtype` (n COMPLEX elements):
+ *   out = a * op(b)  or  a / op(b),  op = conj when conj_b != 0;  operand kind 0 = complex array, 1 = REAL array of n
+ *   elements, 2 = the complex scalar (sr, si) (its pointer is ignored).  DiagonalOperator with a complex diagonal in all
+ *   four modes (diagonal_operator.py:194-214: TIMES d, ADJOINT conj d, INVERSE 1/d, ADJOINT_INVERSE 1/conj d), complex
+ *   weights of Gaussian residuals (energy_operators.py:517-595).
+ * nk_cplx_pointwise: fn 0 exp, 1 log, 2 sqrt (principal branch), 3 reciprocal, 4 conjugate -- out complex; 5 |z| -- out a
+ *   REAL array of n elements (pointwise.py:134-159 on complex fields). */
+int nk_cplx_muldiv(int64_t n, const void* a, int akind, double asr, double asi, const void* b, int bkind, double bsr,
+                   double bsi, int conj_b, int divide, void* out, int dtype, void* stream);
+int nk_cplx_pointwise(int fn, int64_t n, const void* x, void* out, int dtype, void* stream);
 /* out = alpha * x + beta * y   (y may be NULL) */
 int nk_axpby(int64_t n, double alpha, const void* x, double beta, const void* y, void* out, int dtype,
              void* stream);

@@ -26,7 +26,7 @@ from .minimization import (AbsDeltaEnergyController, ConjugateGradient, DeltaEne
 from .probing import StatCalculator, approximation2endo  # noqa: F401
 from .operators import PrependKey  # noqa: F401
 from .operators import (Adder, BlockDiagonalOperator, ChainOperator, ContractionOperator, CountingOperator,  # noqa: F401
-                        DiagonalOperator, HarmonicSmoothingOperator,
+                        DiagonalOperator, HarmonicSmoothingOperator, IntegrationOperator,
                         DOFDistributor, EndomorphicOperator, FFTOperator, FieldAdapter, HarmonicTransformOperator,
                         HartleyOperator, Linearization, LinearOperator, MaskOperator, NullOperator, Operator, OperatorAdapter,
                         PowerDistributor, Realizer, SamplingEnabler, SandwichOperator, ScalingOperator, SumOperator,

@@ -55,6 +55,8 @@ SIGNATURES = {
     "nk_sum": (_i, [_i64, _vp, _i, _vp, _i, _vp]),
     "nk_stats": (_i, [_i64, _vp, _i, _vp, _vp]),
     "nk_binary": (_i, [_i, _i64, _vp, _d, _vp, _d, _vp, _i, _vp]),
+    "nk_cplx_muldiv": (_i, [_i64, _vp, _i, _d, _d, _vp, _i, _d, _d, _i, _i, _vp, _i, _vp]),
+    "nk_cplx_pointwise": (_i, [_i, _i64, _vp, _vp, _i, _vp]),
     "nk_axpby": (_i, [_i64, _d, _vp, _d, _vp, _vp, _i, _vp]),
     "nk_axpby_sqnorm": (_i, [_i64, _d, _vp, _d, _vp, _vp, _i, _vp, _i, _vp]),
     "nk_pointwise": (_i, [_i, _d, _i64, _vp, _vp, _vp, _i, _vp]),

@@ -293,6 +293,50 @@ def binary(op, a, b, out=None):
     return out
 
 
+def _cplx_operand(x, cdt):
+    """(pointer, kind, re, im) of an operand of cplx_muldiv: complex tensor, real tensor or python scalar"""
+    if torch.is_tensor(x):
+        if x.is_complex():
+            return x.to(cdt).contiguous(), 0, 0.0, 0.0
+        rdt = torch.float32 if cdt == torch.complex64 else torch.float64
+        return x.to(rdt).contiguous(), 1, 0.0, 0.0
+    z = complex(x)
+    return None, 2, z.real, z.imag
+
+
+def cplx_muldiv(a, b, divide=False, conj_b=False):
+    """a * b or a / b (b optionally conjugated) as a complex tensor; a, b: complex tensors, real tensors of the same shape or
+    python scalars, at least one of them complex (nk_cplx_muldiv)."""
+    tensors = [t for t in (a, b) if torch.is_tensor(t)]
+    _require_device(*tensors)
+    wide = any(t.dtype in (torch.complex128, torch.float64) for t in tensors)
+    cdt = torch.complex128 if wide else torch.complex64
+    ta, ka, ar, ai = _cplx_operand(a, cdt)
+    tb, kb, br, bi = _cplx_operand(b, cdt)
+    shape = tensors[0].shape
+    if any(t.shape != shape for t in tensors):
+        raise ValueError("cplx_muldiv: shape mismatch")
+    out = torch.empty(shape, dtype=cdt, device=tensors[0].device)
+    L.check(L.load().nk_cplx_muldiv(out.numel(), ptr(ta), ka, ar, ai, ptr(tb), kb, br, bi, int(bool(conj_b)), int(bool(divide)),
+                                    out.data_ptr(), 0 if cdt == torch.complex64 else 1, _stream()), "nk_cplx_muldiv")
+    return out
+
+
+CPLX_POINTWISE = {"exp": 0, "log": 1, "sqrt": 2, "reciprocal": 3, "conjugate": 4, "abs": 5, "absolute": 5}
+
+
+def cplx_pointwise(op, x):
+    """exp / log / sqrt / reciprocal / conjugate of a complex tensor, or its modulus as a REAL tensor (nk_cplx_pointwise)."""
+    _require_device(x)
+    x = x.contiguous()
+    fn = CPLX_POINTWISE[op]
+    rdt = torch.float32 if x.dtype == torch.complex64 else torch.float64
+    out = torch.empty(x.shape, dtype=rdt if fn == 5 else x.dtype, device=x.device)
+    L.check(L.load().nk_cplx_pointwise(fn, x.numel(), x.data_ptr(), out.data_ptr(), 0 if x.dtype == torch.complex64 else 1,
+                                       _stream()), "nk_cplx_pointwise")
+    return out
+
+
 def axpby(alpha, x, beta=0.0, y=None, out=None):
     _require_device(x, y)
     out = torch.empty_like(x) if out is None else out
@@ -583,7 +627,7 @@ def _runs_on_operand_device(fn):
     return wrapper
 
 
-for _name in ("cplx_rows", "hartley", "hartley_fused", "hartley_sandwich", "hartley_sandwich_pair", "fftn", "vdot", "vsum", "binary", "axpby",
+for _name in ("cplx_rows", "cplx_pointwise", "hartley", "hartley_fused", "hartley_sandwich", "hartley_sandwich_pair", "fftn", "vdot", "vsum", "binary", "axpby",
               "axpby_sqnorm",
               "pointwise", "gather", "scatter_add", "bin_plan", "bin_sum", "spmv", "spmv_t", "stats", "cumsum"):
     globals()[_name] = _runs_on_operand_device(globals()[_name])

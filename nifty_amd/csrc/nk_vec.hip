@@ -601,6 +601,104 @@ extern "C" int nk_binary(int op, int64_t n, const void* a, double ascalar, const
   })
 }
 
+// ---- complex element-wise algebra on interleaved (re, im) arrays --------------------------------------------------
+// out = a (*|/) b with b optionally conjugated; an operand is a complex array of n elements, a REAL array of n elements
+// (kind 1) or a complex scalar (kind 2).  DiagonalOperator with a complex diagonal and its adjoint / inverse modes
+// (diagonal_operator.py:194-214), complex residual weights of GaussianEnergy (energy_operators.py:517-595).
+template <typename T>
+struct FCplxMulDiv {
+  static constexpr int NRED = 0;
+  const T *a, *b;
+  int akind, bkind;   // 0 complex array, 1 real array, 2 scalar
+  double asr, asi, bsr, bsi;
+  int conj_b, divide;
+  T* out;
+  double* result;
+  __device__ __forceinline__ void one(int64_t c) const {  // complex element c
+    double ar, ai, br, bi;
+    if (akind == 0) ar = (double)a[2 * c], ai = (double)a[2 * c + 1];
+    else if (akind == 1) ar = (double)a[c], ai = 0.0;
+    else ar = asr, ai = asi;
+    if (bkind == 0) br = (double)b[2 * c], bi = (double)b[2 * c + 1];
+    else if (bkind == 1) br = (double)b[c], bi = 0.0;
+    else br = bsr, bi = bsi;
+    if (conj_b) bi = -bi;
+    double re, im;
+    if (divide) {
+      const double den = br * br + bi * bi;
+      re = (ar * br + ai * bi) / den, im = (ai * br - ar * bi) / den;
+    } else {
+      re = ar * br - ai * bi, im = ar * bi + ai * br;
+    }
+    out[2 * c] = (T)re, out[2 * c + 1] = (T)im;
+  }
+  // the map runs over the 2n reals of `out`: a work item of V reals covers V/2 complex elements (V = 1: the even index)
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double*) const {
+    if constexpr (V == 1) {
+      if ((i & 1) == 0) one(i >> 1);
+    } else {
+#pragma unroll
+      for (int k = 0; k < V / 2; ++k) one((i >> 1) + k);
+    }
+  }
+};
+
+// complex pointwise functions: fn 0 exp, 1 log, 2 sqrt (principal branch), 3 reciprocal, 4 conjugate, 5 |z| (real output array)
+template <typename T>
+struct FCplxPointwise {
+  static constexpr int NRED = 0;
+  int fn;
+  const T* x;
+  T* out;
+  double* result;
+  __device__ __forceinline__ void one(int64_t c) const {
+    const double re = (double)x[2 * c], im = (double)x[2 * c + 1];
+    double fr = re, fi = -im;
+    switch (fn) {
+      case 0: { const double e = exp(re); fr = e * cos(im), fi = e * sin(im); } break;
+      case 1: fr = 0.5 * log(re * re + im * im), fi = atan2(im, re); break;
+      case 2: {
+        const double r = hypot(re, im);
+        fr = sqrt(0.5 * (r + re));
+        fi = copysign(sqrt(0.5 * (r - re)), im);
+      } break;
+      case 3: { const double den = re * re + im * im; fr = re / den, fi = -im / den; } break;
+      case 5: out[c] = (T)hypot(re, im); return;
+      default: break;
+    }
+    out[2 * c] = (T)fr, out[2 * c + 1] = (T)fi;
+  }
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double*) const {
+    if constexpr (V == 1) {
+      if ((i & 1) == 0) one(i >> 1);
+    } else {
+#pragma unroll
+      for (int k = 0; k < V / 2; ++k) one((i >> 1) + k);
+    }
+  }
+};
+
+extern "C" int nk_cplx_muldiv(int64_t n, const void* a, int akind, double asr, double asi, const void* b, int bkind, double bsr,
+                              double bsi, int conj_b, int divide, void* out, int dtype, void* stream) {
+  if (n < 0 || !out || akind < 0 || akind > 2 || bkind < 0 || bkind > 2 || (akind != 2 && !a) || (bkind != 2 && !b))
+    return nk_set_error(NK_ERR_INVALID, "nk_cplx_muldiv: bad argument");
+  NK_DISPATCH_DTYPE(dtype, {
+    FCplxMulDiv<T> f{(const T*)a, (const T*)b, akind, bkind, asr, asi, bsr, bsi, conj_b, divide, (T*)out, nullptr};
+    // (real-array operands are read with scalar loads inside `one`; the vector width only paces the index space)
+    return nk_launch_map<T>(2 * n, f, nk_aligned16(out), (hipStream_t)stream, "nk_cplx_muldiv");
+  })
+}
+
+extern "C" int nk_cplx_pointwise(int fn, int64_t n, const void* x, void* out, int dtype, void* stream) {
+  if (n < 0 || !x || !out || fn < 0 || fn > 5) return nk_set_error(NK_ERR_INVALID, "nk_cplx_pointwise: bad argument");
+  NK_DISPATCH_DTYPE(dtype, {
+    FCplxPointwise<T> f{fn, (const T*)x, (T*)out, nullptr};
+    return nk_launch_map<T>(2 * n, f, nk_aligned16(out), (hipStream_t)stream, "nk_cplx_pointwise");
+  })
+}
+
 extern "C" int nk_axpby(int64_t n, double alpha, const void* x, double beta, const void* y, void* out, int dtype,
                         void* stream) {
   if (n < 0 || !out || !x) return nk_set_error(NK_ERR_INVALID, "nk_axpby: bad argument");

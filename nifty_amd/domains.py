@@ -54,6 +54,11 @@ class UnstructuredDomain(Domain):
     def shape(self):
         return self._shape
 
+    # an index set has no geometry: unit weights, so that Field.weight / IntegrationOperator may run over mixed domains
+    # (the reference defines no volume here and raises AttributeError when such a space is weighted)
+    scalar_dvol = dvol = property(lambda self: 1.0)
+    total_volume = property(lambda self: float(self.size))
+
 
 class StructuredDomain(Domain):
     """A domain with volume information (reference domains/structured_domain.py)."""

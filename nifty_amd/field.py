@@ -59,21 +59,30 @@ def _binary(op, a, b):
     ref = a if torch.is_tensor(a) else b
     if not ref.is_cuda:
         return _HOST_BIN[op](a, b)
-    if ref.is_complex():
-        # complex device data only occurs around FFTOperator: linear combinations via the real view
-        if op in ("add", "sub") and torch.is_tensor(a) and torch.is_tensor(b):
-            return torch.view_as_complex(B.binary(_BIN[op], torch.view_as_real(a), torch.view_as_real(b)))
-        if op in ("mul", "div") and not torch.is_tensor(b) and np.isreal(b):
-            return torch.view_as_complex(B.binary(_BIN[op], torch.view_as_real(a), float(np.real(b))))
-        if op == "mul" and not torch.is_tensor(a) and np.isreal(a):  # real scalar * complex field
-            return torch.view_as_complex(B.binary(_BIN[op], torch.view_as_real(b), float(np.real(a))))
-        raise NotImplementedError("complex device arithmetic beyond +,-,*real is not implemented")
+    involved = [t for t in (a, b) if torch.is_tensor(t)]
+    if any(t.is_complex() for t in involved) or any(isinstance(x, complex) for x in (a, b) if not torch.is_tensor(x)):
+        return _complex_binary(op, a, b, involved)
     if torch.is_tensor(a) and torch.is_tensor(b) and a.dtype != b.dtype:
         dt = torch.promote_types(a.dtype, b.dtype)
         a, b = _cast(a, dt), _cast(b, dt)
-    if not torch.is_tensor(a) and isinstance(a, complex) or not torch.is_tensor(b) and isinstance(b, complex):
-        raise NotImplementedError("complex scalars on real device fields")
     return B.binary(_BIN[op], a, b)
+
+
+def _complex_binary(op, a, b, involved):
+    """Device arithmetic with a complex operand: sums and real multiples run on the interleaved real view (nk_binary),
+    products and quotients in the complex kernel (nk_cplx_muldiv)."""
+    both = len(involved) == 2
+    if op in ("add", "sub"):
+        cdt = torch.complex128 if any(t.dtype in (torch.float64, torch.complex128) for t in involved) else torch.complex64
+        if both:
+            ca, cb = (t.to(cdt) for t in (a, b))  # (a real operand is promoted: a copy, no arithmetic)
+            return torch.view_as_complex(B.binary(_BIN[op], torch.view_as_real(ca.contiguous()), torch.view_as_real(cb.contiguous())))
+        field, scalar = (a, b) if torch.is_tensor(a) else (b, a)
+        shift = torch.full(field.shape, complex(scalar), dtype=cdt, device=field.device)  # a constant field
+        return _complex_binary(op, a if torch.is_tensor(a) else shift, b if torch.is_tensor(b) else shift, [field, shift])
+    if not both and torch.is_tensor(a) and a.is_complex() and not isinstance(b, complex):  # complex field (*|/) real number
+        return torch.view_as_complex(B.binary(_BIN[op], torch.view_as_real(a.contiguous()), float(b)))
+    return B.cplx_muldiv(a, b, divide=(op == "div"))
 
 
 def _cast(t, dt):
@@ -185,7 +194,7 @@ class Field:
         if not self._val.is_complex():
             return self
         return Field(self._domain, torch.conj_physical(self._val) if not self._val.is_cuda else
-                     torch.view_as_complex(torch.stack([self.real.val, (-self.imag).val], dim=-1).contiguous()))
+                     B.cplx_pointwise("conjugate", self._val))
 
     def astype(self, dtype):
         return Field(self._domain, _cast(self._val, torch_dtype(dtype)))
@@ -241,7 +250,29 @@ class Field:
     def sum(self, spaces=None):
         if spaces is None:
             return Field.scalar(self.s_sum()).at(self.device_id)
-        raise NotImplementedError("partial contractions live in ContractionOperator")
+        from .operators import ContractionOperator
+
+        return ContractionOperator(self._domain, spaces)(self)
+
+    def weight(self, power=1, spaces=None):
+        """Every pixel times (its volume)**power along the sub-domains `spaces` (all by default; reference field.py:285-322):
+        uniform volumes collapse into one factor, a sub-domain with individual volumes (PowerSpace: rho * pdvol per bin)
+        contributes a broadcast factor field."""
+        ndom = len(self._domain)
+        chosen = range(ndom) if spaces is None else ((int(spaces),) if np.isscalar(spaces) else tuple(int(s) for s in spaces))
+        out, uniform = self, 1.0
+        for ind in chosen:
+            vol = self._domain[ind].dvol
+            if np.isscalar(vol):
+                uniform *= vol
+                continue
+            axes = self._domain.axes[ind]
+            shape = [n if ax in axes else 1 for ax, n in enumerate(self._domain.shape)]
+            factor = np.broadcast_to((np.asarray(vol, dtype=np.float64) ** power).reshape(shape), self._domain.shape)
+            out = out * Field(self._domain, _as_tensor(np.ascontiguousarray(factor))).at(self.device_id).astype(
+                np.float64 if not self._val.is_complex() else self.dtype)
+        uniform = uniform ** power
+        return out * uniform if uniform != 1.0 else (out if out is not self else Field(self._domain, self._val.clone()))
 
     def s_mean(self):
         return self.s_sum() / self.size
@@ -372,7 +403,9 @@ def _ptw(x, op, deriv, *args, **kwargs):
     if not x.is_cuda:
         return _host_ptw(x, op, deriv, *args)
     if x.is_complex():
-        raise NotImplementedError("complex pointwise functions on device")
+        if deriv or op not in B.CPLX_POINTWISE:
+            raise NotImplementedError(f"complex pointwise operation {op!r} (with derivative: {deriv}) has no device kernel")
+        return B.cplx_pointwise(op, x)
     if op not in B.POINTWISE:
         raise NotImplementedError(f"pointwise operation {op!r} has no device kernel yet")
     param = float(args[0]) if op == "power" else 0.0

@@ -843,12 +843,15 @@ class DiagonalOperator(EndomorphicOperator):
         d = self._ldiag
         if d.device != xval.device:
             d = self._ldiag = d.to(xval.device)
-        if conj and self._complex:
-            d = torch.conj_physical(d)
+        conj = bool(conj and self._complex)
         if not xval.is_cuda:
+            d = torch.conj_physical(d) if conj else d
             return xval / d if divide else xval * d
         if self._complex or xval.is_complex():
-            raise NotImplementedError("complex DiagonalOperator on device")
+            # d, conj d, 1/d, 1/conj d (diagonal_operator.py:194-214): one launch of the complex kernel; a diagonal on a
+            # sub-set of the spaces is broadcast first (a replication copy)
+            full = d if self._full() else d.expand(self._domain.shape).contiguous()
+            return B.cplx_muldiv(xval, full, divide=divide, conj_b=conj)
         if d.dtype != xval.dtype:
             d = d.to(xval.dtype)
         if not self._full():
@@ -869,19 +872,28 @@ class DiagonalOperator(EndomorphicOperator):
         return Field(x.domain, self._mul(x.val, divide=bool(trafo & 2), conj=bool(trafo & 1)))
 
     def _actual_diag(self):
+        """the diagonal this operator multiplies by in TIMES mode (the stored one seen through the pending transformation)"""
         d = self._ldiag
-        if self._trafo & 2:
-            d = 1.0 / d if not d.is_cuda else B.binary(3, 1.0, d)
-        if self._trafo & 1 and self._complex:
-            d = torch.conj_physical(d)
-        return d
+        inverted, conjugated = bool(self._trafo & 2), bool(self._trafo & 1 and self._complex)
+        if not d.is_cuda:
+            d = 1.0 / d if inverted else d
+            return torch.conj_physical(d) if conjugated else d
+        if self._complex:
+            return B.cplx_muldiv(1.0, d, divide=True, conj_b=conjugated) if inverted else \
+                (B.cplx_pointwise("conjugate", d) if conjugated else d)
+        return B.binary(3, 1.0, d) if inverted else d
 
     def _flip_modes(self, trafo):
         return DiagonalOperator._from_ldiag(self, self._ldiag, self._dtype, self._trafo ^ trafo, self._spaces)
 
     def _scale(self, fct):
         d = self._actual_diag()
-        d = d * fct if not d.is_cuda else B.binary(2, d, float(fct))
+        if not d.is_cuda:
+            d = d * fct
+        elif d.is_complex() or isinstance(fct, complex):
+            d = B.cplx_muldiv(d, complex(fct))
+        else:
+            d = B.binary(2, d, float(fct))
         return DiagonalOperator._from_ldiag(self, d, self._dtype, 0, self._spaces)
 
     def _combine_prod(self, op):
@@ -892,7 +904,10 @@ class DiagonalOperator(EndomorphicOperator):
             return DiagonalOperator._from_ldiag(self, a * b, self._dtype if self._dtype == op._dtype else None, 0, None
                                                 if (self._full() or op._full()) else tuple(set(self._spaces) | set(op._spaces)))
         a, b = self._actual_diag(), op._actual_diag()
-        prod = a * b if not a.is_cuda else B.binary(2, a, b)
+        if not a.is_cuda:
+            prod = a * b
+        else:
+            prod = B.cplx_muldiv(a, b) if (a.is_complex() or b.is_complex()) else B.binary(2, a, b)
         return DiagonalOperator._from_ldiag(self, prod, self._dtype if self._dtype == op._dtype else None, 0, self._spaces)
 
     def process_sample(self, samp, from_inverse):
@@ -1248,6 +1263,12 @@ def ducktape(left, right, name):
     return FieldAdapter(right[name], name)
 
 
+def IntegrationOperator(domain, spaces):
+    """Contraction weighted with the pixel volumes: the integral over the sub-domains `spaces` (reference
+    contraction_operator.py:80-95)."""
+    return ContractionOperator(domain, spaces, 1)
+
+
 def Variable(domain, key):
     return ducktape(makeDomain(domain), None, key)
 
@@ -1277,7 +1298,12 @@ class ContractionOperator(LinearOperator):
         if not self._spaces:  # nothing to contract: identity (torch would read an empty `dim` as "all axes")
             return x
         if self._power != 0:
-            raise NotImplementedError("weighted contractions")
+            # pixel volumes**power along the contracted sub-domains (contraction_operator.py:54-77): on the way in for
+            # TIMES, on the way out for the broadcast
+            plain = ContractionOperator(self._domain, self._spaces)
+            if mode == self.TIMES:
+                return plain.apply(x.weight(self._power, spaces=self._spaces), mode)
+            return plain.apply(x, mode).weight(self._power, spaces=self._spaces)
         if mode == self.ADJOINT_TIMES:
             if x.val.is_cuda and full_contraction:
                 ones = torch.ones(self._domain.shape, dtype=x.val.dtype, device=x.val.device)
@@ -1505,12 +1531,7 @@ class DOFDistributor(LinearOperator):
         if target is None:
             target = dofdex.domain
         self._target = DomainTuple.make(target)
-        if space is None and len(self._target) == 1:
-            space = 0
-        self._space = int(space)
-        if self._space != len(self._target) - 1:
-            raise NotImplementedError("DOFDistributor: only the LAST space of the target can be distributed "
-                                      "(leading spaces are carried along)")
+        self._space = _space_index(self._target, space)
         idx = dofdex.val if isinstance(dofdex, Field) else torch.as_tensor(dofdex)
         if idx.dtype not in (torch.int32, torch.int64):
             raise TypeError("dofdex must contain integers")
@@ -1527,10 +1548,11 @@ class DOFDistributor(LinearOperator):
         self._idx32 = {}
         self._bin_plans = {}
         self._nbin = nbin
-        # leading spaces of the target (e.g. the UnstructuredDomain(total_N) of several correlated fields) are batch axes
-        lead = tuple(self._target[i] for i in range(len(self._target) - 1)) if hasattr(self, "_target") else ()
-        self._domain = DomainTuple.make(lead + (other_space,))
-        self._nlead = int(np.prod([d.size for d in lead])) if lead else 0
+        # the other spaces of the target (e.g. the UnstructuredDomain(total_N) of several correlated fields, or spaces
+        # BEHIND the distributed one, distributors.py:60-104) are carried along: batch rows of the gather / scatter
+        self._domain = DomainTuple.make([other_space if i == self._space else sub for i, sub in enumerate(self._target)])
+        self._nlead = int(np.prod([sub.size for i, sub in enumerate(self._target) if i != self._space])) \
+            if len(self._target) > 1 else 0
         self._capability = self.TIMES | self.ADJOINT_TIMES
 
     @property
@@ -1552,13 +1574,26 @@ class DOFDistributor(LinearOperator):
 
     def apply(self, x, mode):
         self._check_input(x, mode)
-        if self._nlead:  # one gather / scatter per leading index (slices and stacking are copies)
-            tshape = tuple(self._target.shape[len(self._target.shape) - len(self._target[self._space].shape):])
-            rows = x.val.reshape((self._nlead, -1))
-            outs = [self._apply1(rows[i], mode, tshape) for i in range(self._nlead)]
-            return Field(self._tgt(mode), torch.stack(outs).reshape(self._tgt(mode).shape))
+        if self._nlead:
+            return Field(self._tgt(mode), self._apply_rows(x.val, mode))
         tshape = self._target.shape
         return Field(self._tgt(mode), self._apply1(x.val, mode, tshape).reshape(self._tgt(mode).shape))
+
+    def _apply_rows(self, v, mode):
+        """One gather / scatter per combination of the carried-along indices.  The distributed space is moved to the back
+        first when other spaces follow it (a permutation copy), and back afterwards; slices and stacking are copies too."""
+        src, dst = self._dom(mode), self._tgt(mode)
+        grid_shape = tuple(self._target[self._space].shape)
+        mine = list(src.axes[self._space])
+        others = [ax for ax in range(len(src.shape)) if ax not in mine]
+        rows = v.permute(others + mine).contiguous().reshape((self._nlead, -1))
+        outs = torch.stack([self._apply1(rows[i], mode, grid_shape).reshape(-1) for i in range(self._nlead)])
+        # back to the natural axis order of the output domain
+        dst_mine = list(dst.axes[self._space])
+        dst_others = [ax for ax in range(len(dst.shape)) if ax not in dst_mine]
+        moved = outs.reshape([dst.shape[ax] for ax in dst_others] + [dst.shape[ax] for ax in dst_mine])
+        order = dst_others + dst_mine
+        return moved.permute([order.index(ax) for ax in range(len(dst.shape))]).contiguous()
 
     def _apply1(self, v, mode, tshape):
         if mode == self.TIMES:
@@ -1588,8 +1623,6 @@ class PowerDistributor(DOFDistributor):
     def __init__(self, target, power_space=None, space=None):
         self._target = DomainTuple.make(target)
         self._space = _space_index(self._target, space)
-        if self._space != len(self._target) - 1:
-            raise NotImplementedError("PowerDistributor: only the LAST space of the target can be distributed")
         self._pspace = bins = self._bins_of(self._target[self._space], power_space)
         # the host copy of the bin index is only built if a HOST field is ever distributed
         self._init2(lambda: torch.from_numpy(np.array(bins.pindex)), bins.shape[0], bins)

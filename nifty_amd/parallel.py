@@ -242,10 +242,13 @@ def get_MPI_params_from_comm(comm):
 
 # ---- rank-synchronisation guards (reference utilities.py:529-585) ----------------------------------------------------
 def _fingerprint(obj):
-    """Bytes that are equal on two ranks iff `obj` is (for every practical purpose) equal.  Host objects: their pickle.
-    Fields / MultiFields on a GPU: per key the fp64 sum and sum of squares from the library's fixed-order reduction
-    (nk_stats) -- equal data gives equal bits, and a 1024^3 mean is fingerprinted in a few milliseconds on the device
-    instead of being copied to the host and hashed (4 GiB, seconds) as the reference's `hash=True` does."""
+    """Bytes that are equal on two ranks when `obj` is equal, and differ for every desynchronisation seen in practice.  Host
+    objects: their pickle (Fields: a digest of the raw bytes, like the reference's `hash=True`).  Fields / MultiFields on
+    a GPU: per key the fp64 sum and sum of squares from the library's fixed-order reduction (nk_stats) plus two
+    ORDER-SENSITIVE numbers, the lag-1 and lag-7919 products sum_i v_i v_(i+lag) -- a permuted, shifted or partly
+    sign-flipped field changes them (sum and sum of squares alone are blind to that).  Equal data gives equal
+    bits (fixed-order reductions), and a 1024^3 mean is fingerprinted in a few milliseconds on the device instead of being
+    copied to the host and hashed (4 GiB, seconds).  It is a checksum, not a proof of equality."""
     import pickle
 
     from .field import Field, MultiField
@@ -261,7 +264,9 @@ def _fingerprint(obj):
                 from . import backend as B
 
                 s1, s2, nign = B.stats(v)
-                parts.append((key, tuple(v.shape), str(v.dtype), float(s1).hex(), float(s2).hex(), nign))
+                flat = v.contiguous().reshape(-1)
+                lags = [float(B.vdot(flat[:-lag], flat[lag:]).item()).hex() for lag in (1, 7919) if flat.numel() > lag]
+                parts.append((key, tuple(v.shape), str(v.dtype), float(s1).hex(), float(s2).hex(), nign, lags))
             else:  # host (or exotic dtype): digest of the raw bytes -- a pickle of a tensor is not canonical
                 raw = v.detach().cpu().contiguous().numpy().tobytes()
                 parts.append((key, tuple(v.shape), str(v.dtype), blake2b(raw).hexdigest()))

@@ -33,7 +33,17 @@ def getState():
 
 
 def setState(state):
-    _frames[:] = [_Frame(*f) for f in pickle.loads(state)]
+    """Restores what getState returned.  Also reads the layout of earlier versions (and of the reference's own
+    `getState`, random.py:98-110): a pair (list of SeedSequences, list of Generators)."""
+    loaded = pickle.loads(state)
+    if isinstance(loaded, tuple) and len(loaded) == 2 and all(isinstance(part, list) for part in loaded) \
+            and all(isinstance(q, np.random.SeedSequence) for q in loaded[0]):
+        loaded = list(zip(*loaded))
+    frames = [_Frame(*f) for f in loaded]
+    for f in frames:
+        if not (isinstance(f.sseq, np.random.SeedSequence) and isinstance(f.rng, np.random.Generator)):
+            raise TypeError("setState: not a random state of this module (expected (SeedSequence, Generator) frames)")
+    _frames[:] = frames
 
 
 def current_rng():
