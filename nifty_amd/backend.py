@@ -85,6 +85,18 @@ class Plan:
             pass
 
 
+class PlanView:
+    """The same nk_plan (twiddle tables, geometry: immutable, shareable) with a workspace of its own, so that transforms of
+    the same shape can run on several streams at once (engine.FusedModel lanes)."""
+
+    def __init__(self, plan):
+        self._plan = plan
+        self.shape, self.dtype, self.batch, self.device = plan.shape, plan.dtype, plan.batch, plan.device
+        self.workspace = torch.empty_like(plan.workspace)
+
+    handle = property(lambda self: self._plan.handle)
+
+
 def get_plan(shape, dtype, batch=1, device=None):
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     key = (tuple(int(s) for s in shape), dtype, int(batch), device.index)
@@ -617,7 +629,7 @@ def _runs_on_operand_device(fn):
                     with torch.cuda.device(a.device):
                         return fn(*args, **kw)
                 break
-            if isinstance(a, Plan):
+            if isinstance(a, (Plan, PlanView)):
                 if a.device.index != _current_device():
                     with torch.cuda.device(a.device):
                         return fn(*args, **kw)

@@ -604,6 +604,33 @@ class FusedModel:
         self.counters["transforms"] += 1
         return self._finish_linearize(lp, x, gs, None, grad_acc, w, value, lhval)
 
+    # -- lanes: independent scratch sets, so that the chains of several samples run on several streams at once ----------
+    _SCRATCH = ("scatter_scratch", "abar_priv", "abar", "damp", "latbar", "tmp", "dafield", "w8", "w8max", "wfull", "k2_dense")
+
+    def lanes(self, count):
+        """[self, clone, clone, ...]: `count` views of this model that share every static array (bin index, geometry, data,
+        plan tables, counters) and own what a transform chain scribbles on (workspace, octant sums, amplitude tangents ...),
+        each with its own stream (None for the model itself = the caller's stream).  On small grids one sample's chain of
+        ~15 short kernels leaves most of the chip idle (2048^2 fp64: 128 workgroups per pass on 256 CUs, 80 % of a step
+        spent in kernels of 5-50 us); the samples of a KL evaluation are independent, so their chains run side by side."""
+        import copy
+
+        made = self.__dict__.setdefault("_lanes", [self])
+        with torch.cuda.device(self.device):
+            while len(made) < count:
+                lane = copy.copy(self)
+                lane.plan = B.PlanView(self.plan)
+                for name in self._SCRATCH:
+                    t = getattr(self, name)
+                    setattr(lane, name, None if t is None else torch.zeros_like(t))
+                lane._wide_state = lane._pair = None
+                lane._lanes = [lane]
+                lane.stream = torch.cuda.Stream(device=self.device)
+                made.append(lane)
+        return made[:count]
+
+    stream = None
+
     def _wide_buffers(self):
         """fp64 plan (its work array: 2 N x 4 bytes more), fp64 octant amplitude field and k^2 table of the wide forward
         transform, created at the first value / gradient evaluation of an fp32 model."""
@@ -1002,14 +1029,18 @@ class FusedKL(Energy):
         self.n_total = len(residuals) if n_total is None else n_total
         self.comm, self.nanisinf = comm, nanisinf
         self.lins = []
+        self._lanes = self._pick_lanes(len(residuals))
         value = torch.zeros(1, dtype=torch.float64, device=model.device)
         grad = None
-        for r, neg in zip(residuals, negs):
-            x = position.shifted(-1.0 if neg else 1.0, r)  # p +- r and |p +- r|^2 in one pass
-            lp = model.linearize(x, grad_acc=grad, n_total=self.n_total, value_acc=value)
-            grad = lp.grad
-            lp.grad = None
-            self.lins.append(lp)
+        if len(self._lanes) > 1:
+            value, grad = self._linearize_on_lanes(position, value)
+        else:
+            for r, neg in zip(residuals, negs):
+                x = position.shifted(-1.0 if neg else 1.0, r)  # p +- r and |p +- r|^2 in one pass
+                lp = model.linearize(x, grad_acc=grad, n_total=self.n_total, value_acc=value)
+                grad = lp.grad
+                lp.grad = None
+                self.lins.append(lp)
         if grad is None:  # a rank without samples
             grad = LatentVec.zeros(model)
         if comm is not None:
@@ -1018,6 +1049,78 @@ class FusedKL(Energy):
         if math.isnan(self._value) and nanisinf:
             self._value = math.inf
         self._grad = grad
+
+    # -- small grids: the samples' kernel chains side by side on several streams (FusedModel.lanes) -------------------------
+    def _pick_lanes(self, nloc):
+        """[model] or K lanes: single process, at least two local samples, a grid small enough that one chain leaves the
+        chip mostly idle (NK_LANE_MAX_POINTS, default 2^25 points; NK_LANES = number of lanes, default 4, 0 / 1 = off)."""
+        want = int(os.environ.get("NK_LANES", "4"))
+        small = self.model.N <= int(os.environ.get("NK_LANE_MAX_POINTS", str(1 << 25)))
+        if self.comm is not None or want < 2 or nloc < 2 or not small or self.model.response is not None:
+            return [self.model]
+        return self.model.lanes(min(want, nloc))
+
+    def _on_lanes(self, job):
+        """job(lane index, lane model, sample index) for every local sample, sample i on lane i mod K, each lane on its own
+        stream; the caller's stream waits for all of them afterwards.  Tensors the jobs allocate belong to their lane's stream:
+        whatever the caller's stream reads later must be handed to `_adopt`."""
+        lanes = self._lanes
+        main = torch.cuda.current_stream(self.model.device)
+        for lane in lanes[1:]:
+            lane.stream.wait_stream(main)
+        for i in range(len(self.residuals)):
+            k = i % len(lanes)
+            if lanes[k].stream is None:
+                job(k, lanes[k], i)
+            else:
+                with torch.cuda.stream(lanes[k].stream):
+                    job(k, lanes[k], i)
+        for lane in lanes[1:]:
+            main.wait_stream(lane.stream)
+        return main
+
+    @staticmethod
+    def _adopt(main, *tensors):
+        for t in tensors:
+            if t is not None:
+                t.record_stream(main)
+
+    def _linearize_on_lanes(self, position, value):
+        K = len(self._lanes)
+        xs = [position.shifted(-1.0 if neg else 1.0, r) for r, neg in zip(self.residuals, self.negs)]
+        values = [value] + [torch.zeros_like(value) for _ in range(K - 1)]
+        grads, lins = [None] * K, [None] * len(xs)
+
+        def job(k, lane, i):
+            lp = lane.linearize(xs[i], grad_acc=grads[k], n_total=self.n_total, value_acc=values[k])
+            grads[k], lp.grad, lins[i] = lp.grad, None, lp
+
+        main = self._on_lanes(job)
+        self.lins = lins
+        grad = grads[0]
+        for k in range(1, K):
+            self._adopt(main, grads[k].xi, grads[k].small)
+            B.axpby(1.0, grad.xi, 1.0, grads[k].xi, out=grad.xi)
+            B.axpby(1.0, grad.small, 1.0, grads[k].small, out=grad.small)
+            B.axpby(1.0, value, 1.0, values[k], out=value)
+        return value, grad
+
+    def _apply_metric_on_lanes(self, d):
+        K, nloc, w = len(self._lanes), len(self.lins), 1.0 / self.n_total
+        # the partial sums of the lanes are allocated HERE (the caller's stream owns them); lane 0 also adds the prior term
+        outs = [LatentVec(torch.empty_like(d.xi), None) for _ in range(K)]
+        last_of_lane0 = ((nloc - 1) // K) * K
+
+        def job(k, lane, i):
+            lane.lh_metric_accumulate(self.lins[i], d, outs[k], w, i < K, identity=nloc * w if i == last_of_lane0 else 0.0)
+
+        main = self._on_lanes(job)
+        out = outs[0]
+        for k in range(1, K):
+            self._adopt(main, outs[k].small)
+            B.axpby(1.0, out.xi, 1.0, outs[k].xi, out=out.xi)
+            B.axpby(1.0, out.small, 1.0, outs[k].small, out=out.small)
+        return out
 
     @property
     def value(self):
@@ -1034,6 +1137,8 @@ class FusedKL(Energy):
         """This rank's share of the KL metric applied to d (no communication).  pipe = (chunks, wait, record): the FIRST
         local sample's transform waits chunk by chunk for d, the LAST one records chunk by chunk that `out` is final."""
         m = self.model
+        if len(self._lanes) > 1 and pipe is None and dot_out is None and cg_direction is None:
+            return self._apply_metric_on_lanes(d)
         out = LatentVec(torch.empty_like(d.xi), None)
         w = 1.0 / self.n_total
         nloc = len(self.lins)
@@ -1075,7 +1180,7 @@ class FusedKL(Energy):
 
     @property
     def metric(self):
-        single = self.comm is None and len(self.lins) > 0
+        single = self.comm is None and len(self.lins) > 0 and len(self._lanes) == 1  # (lanes: no fused dot / direction)
         A = _Callable(self.apply_metric, fused_dot=single and self.model.octant_vjp,
                       fused_direction=single and self.model.fused_direction)
         if self.comm is not None and self.comm.can_shard(self.model.N):

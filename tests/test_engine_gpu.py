@@ -360,3 +360,49 @@ def test_pair_final_pass_is_bit_identical(shape, dtype):
                 del os.environ["NK_PAIR_FINAL"]
         assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
         assert results[0][2] == results[1][2]
+
+
+@pytest.mark.parametrize("shape,lh", [((128, 256), "poisson"), ((64, 64, 128), "gaussian")])
+def test_sample_lanes_agree_with_the_single_stream_path(shape, lh, monkeypatch):
+    """Small grids: the chains of the local samples of a KL run side by side on several streams (FusedModel.lanes).  Same
+    linearisations, the sample sum grouped per lane: value, gradient and metric application agree with the one-stream
+    evaluation to rounding -- for every lane count, with more samples than lanes and an odd count."""
+    from nifty_amd import random
+    from nifty_amd.engine import FusedKL, FusedModel, LatentVec, draw_samples
+    from nifty_amd.minimization import AbsDeltaEnergyController
+
+    rng = np.random.default_rng(5)
+    cf = orc.CFModel(shape, None, orc.CFParams(offset_mean=1.0))
+    x = {k: 0.2 * v for k, v in cf.draw_latent(rng).items()}
+    v = cf.draw_latent(rng)
+    if lh == "poisson":
+        data = rng.poisson(np.exp(cf.forward(cf.draw_latent(rng)) * 0.3)).astype(np.int64)
+        kw = dict(likelihood="poisson", data=data, nonlin="exp")
+    else:
+        data = cf.forward(cf.draw_latent(rng)) + 0.1 * rng.normal(size=shape)
+        kw = dict(likelihood="gaussian", data=data, icov=100.0)
+    monkeypatch.setenv("NK_LANES", "0")
+    model = FusedModel(shape, offset_mean=1.0, dtype=torch.float64, device="cuda:0", **kw)
+    xl, vl = LatentVec.from_dict(model, x), LatentVec.from_dict(model, v)
+    random.push_sseq_from_seed(11)
+    res, negs, _ = draw_samples(model, xl, 3, True, lambda: AbsDeltaEnergyController(0.05, iteration_limit=3))
+    random.pop_sseq()
+    res, negs = res[:5], negs[:5]  # an odd number of samples
+    ref = FusedKL(model, xl, res, negs)
+    assert len(ref._lanes) == 1
+    ref_m = ref.apply_metric(vl).to_dict()
+    ref_g = ref.gradient.to_dict()
+    for lanes in ("2", "4", "8"):
+        monkeypatch.setenv("NK_LANES", lanes)
+        kl = FusedKL(model, xl, res, negs)
+        assert len(kl._lanes) == min(int(lanes), 5)
+        assert abs(kl.value - ref.value) < 1e-13 * abs(ref.value)
+        got_g, got_m = kl.gradient.to_dict(), kl.apply_metric(vl).to_dict()
+        for k in ref_g:
+            assert np.max(np.abs(got_g[k] - ref_g[k])) <= 1e-12 * max(np.max(np.abs(ref_g[k])), 1e-30)
+            assert np.max(np.abs(got_m[k] - ref_m[k])) <= 1e-12 * max(np.max(np.abs(ref_m[k])), 1e-30)
+        # twice the same: the lanes leave no state behind
+        again = kl.apply_metric(vl).to_dict()
+        assert all(np.array_equal(again[k], got_m[k]) for k in again)
+        # through the minimiser's protocol (CG with separate curvature dot)
+        assert not kl.metric.fused_dot
