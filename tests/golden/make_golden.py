@@ -617,6 +617,8 @@ def likelihood_cases():
 
 
 def main():
+    if "--c1-only" in sys.argv:  # BASELINE configs[0] at its stated size: RGSpace(512), Gaussian, 2 MGVI samples (mirrored)
+        return model_case("c1_512", (512,), None, "gaussian", None, 2, False, run_optimize=True)
     if "--lh-only" in sys.argv:
         return likelihood_cases()
     if "--reduced-only" in sys.argv:
@@ -655,6 +657,7 @@ def main():
             tr[f"{tag}.{k}"] = v
     np.savez_compressed(os.path.join(HERE, "transforms.npz"), **tr)
     model_case("g1d", (128,), None, "gaussian", None, 2, False, run_optimize=True)
+    model_case("c1_512", (512,), None, "gaussian", None, 2, False, run_optimize=True)  # BASELINE configs[0] at its size
     model_case("p2d", (32, 32), None, "poisson", "exp", 2, False)
     model_case("g3d", (16, 16, 16), None, "gaussian", None, 1, False)
     model_case("g2d_dist", (16, 32), (0.3, 0.2), "gaussian", None, 1, False, diag_icov=True)

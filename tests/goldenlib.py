@@ -5,7 +5,7 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 KEYS = ("asperity", "flexibility", "fluctuations", "loglogavgslope", "spectrum", "xi", "zeromode")
-MODEL_CASES = ("g1d", "p2d", "g3d", "g2d_dist", "p2d_geo", "g2d_sig_geo")
+MODEL_CASES = ("g1d", "c1_512", "p2d", "g3d", "g2d_dist", "p2d_geo", "g2d_sig_geo")  # c1_512 = BASELINE configs[0]
 
 
 def load(name):
