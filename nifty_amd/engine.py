@@ -126,6 +126,9 @@ class CgWorkspace:
         self._host.copy_(self.scal, non_blocking=True)
         torch.cuda.current_stream(self.scal.device).synchronize()
         s = self._host.numpy()
+        # inside a lockstep scope: these five scalars steer the CG -- ONE agreement check per iteration (parallel.lockstep_flush)
+        parallel.lockstep_note(s[:5])
+        parallel.lockstep_flush()
         return dict(gamma_prev=float(s[0]), curv=float(s[1]), gamma=float(s[2]), xr=float(s[3]), xb=float(s[4]), dr=float(s[3]),
                     alpha=float(s[0] / s[1]) if s[1] != 0 else float("nan"))
 
@@ -137,13 +140,21 @@ class ShardedCgWorkspace(CgWorkspace):
     def __init__(self, device, comm):
         super().__init__(device)
         self.comm = comm
+        self._broadcast = parallel._lockstep_mode() == "broadcast"
+
+    def _agree(self, t):
+        """The replicated part of a reduction is computed per rank by fixed-order kernels on identical data: identical bits.
+        NK_LOCKSTEP=broadcast forces rank 0's copy anyway (one tiny collective each, as in rounds 1-3); by default the
+        scalars are compared once per iteration after their fetch (CgWorkspace.fetch)."""
+        if self._broadcast:
+            self.comm.bcast_(t)
 
     def dot(self, u, v, slot):
         res = self.scal[slot:slot + 1]
         B.vdot(u.xi.reshape(-1), v.xi.reshape(-1), result=res, accumulate=False)
         self.comm.allreduce_sum_([res])
         B.vdot(u.small, v.small, result=res, accumulate=True)
-        self.comm.bcast_(res)  # the replicated small part is reduced per rank: rank 0's last bit for everybody
+        self._agree(res)  # the replicated small part is reduced per rank
         return res
 
     def curv(self, d, q):
@@ -152,7 +163,7 @@ class ShardedCgWorkspace(CgWorkspace):
         L.check(lib.nk_cg_curv(dx.numel(), dx.data_ptr(), qx.data_ptr(), B.dtype_code(dx), self.scal.data_ptr(), 0, st))
         self.comm.allreduce_sum_([self.scal[1:2]])
         L.check(lib.nk_cg_curv(ds.numel(), ds.data_ptr(), qs.data_ptr(), B.dtype_code(ds), self.scal.data_ptr(), 1, st))
-        self.comm.bcast_(self.scal[1:2])
+        self._agree(self.scal[1:2])
 
     def update(self, x, r, d, q, b):
         lib, st = L.load(), B._stream()
@@ -161,7 +172,7 @@ class ShardedCgWorkspace(CgWorkspace):
                                      B.dtype_code(xx), self.scal.data_ptr(), i, st))
             if i == 0:
                 self.comm.allreduce_sum_([self.scal[2:5]])
-        self.comm.bcast_(self.scal[2:5])
+        self._agree(self.scal[2:5])
 
     def update_dr(self, x, r, d, q):
         lib, st = L.load(), B._stream()
@@ -170,7 +181,7 @@ class ShardedCgWorkspace(CgWorkspace):
                                         B.dtype_code(xx), self.scal.data_ptr(), i, st))
             if i == 0:
                 self.comm.allreduce_sum_([self.scal[2:4]])
-        self.comm.bcast_(self.scal[2:4])
+        self._agree(self.scal[2:4])
 
     def refresh(self, x, r, b):
         for slot, (u, v) in ((2, (r, r)), (3, (x, r)), (4, (x, b))):

@@ -19,6 +19,12 @@ CONVERGED, CONTINUE, ERROR = 0, 1, 2
 counters = {"cg_iterations": 0}  # work counters (bench.py): CG iterations = metric applications inside ConjugateGradient
 
 
+def _lockstep_flush():
+    from . import parallel
+
+    parallel.lockstep_flush()
+
+
 def _ls(value):
     """Decision-point synchronisation: inside a multi-rank ``parallel.lockstep`` scope (the replicated KL
     minimisation) the scalar of rank 0, otherwise ``value`` itself.  Applied to every reduction of REPLICATED vectors
@@ -419,6 +425,7 @@ class ConjugateGradient(Minimizer):
                 return energy, ERROR
             if gamma == 0:
                 return energy, CONVERGED
+            _lockstep_flush()
             status = controller.check(energy)
             if status != CONTINUE:
                 return energy, status
@@ -795,6 +802,7 @@ class DescentMinimizer(Minimizer):
         previous_value = None
         verdict = self._controller.start(energy)
         while verdict == CONTINUE:
+            _lockstep_flush()  # multi-rank: one agreement check per outer step (no-op otherwise)
             if energy.gradient_norm == 0:
                 return energy, CONVERGED
             value_here = energy.value

@@ -168,6 +168,16 @@ class Comm:
 # Field / LatentVec dot products themselves never communicate: energies evaluate per-sample (rank-local) values with
 # them, and ranks may hold different numbers of samples.  The sampling phase runs outside the scope.
 _lockstep_stack = []
+_pending = []  # scalars that steered control flow since the last flush (verify mode)
+
+
+def _lockstep_mode():
+    """NK_LOCKSTEP=verify (default): the steering scalars are NOT exchanged one by one -- every device reduction is built in
+    a fixed order, so replicated data gives identical bits on every rank -- they are collected and compared ONCE per CG
+    iteration / minimiser step with one small MAX all-reduce (lockstep_flush): a disagreement raises on every rank instead
+    of dead-locking the next collective.  NK_LOCKSTEP=broadcast: rank 0's value is broadcast at every decision (rounds 1-3:
+    one tiny collective per decision)."""
+    return os.environ.get("NK_LOCKSTEP", "verify")
 
 
 class lockstep:
@@ -180,7 +190,12 @@ class lockstep:
         return self
 
     def __exit__(self, *exc):
-        _lockstep_stack.pop()
+        try:
+            if exc[0] is None:
+                lockstep_flush()
+        finally:
+            del _pending[:]
+            _lockstep_stack.pop()
         return False
 
 
@@ -189,19 +204,51 @@ def lockstep_comm():
 
 
 def lockstep_float(value, device=None):
-    """`value` of rank 0 on every rank while a lockstep scope is active, else `value`."""
+    """A scalar that steers control flow inside a lockstep scope: rank 0's value on every rank (broadcast mode), or the
+    value itself, noted for the next agreement check (verify mode).  Outside a scope: `value`."""
     comm = lockstep_comm()
     if comm is None:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=comm.scalar_device())
-    comm.bcast_(t)
-    return float(t.item())
+    if _lockstep_mode() == "broadcast":
+        t = torch.tensor([value], dtype=torch.float64, device=comm.scalar_device())
+        comm.bcast_(t)
+        return float(t.item())
+    _pending.append(float(value))
+    if len(_pending) >= 256:
+        lockstep_flush()
+    return value
+
+
+def lockstep_note(values):
+    """More steering scalars for the next agreement check (the CG's device scalars after their one fetch per iteration)."""
+    if lockstep_comm() is not None and _lockstep_mode() != "broadcast":
+        _pending.extend(float(v) for v in values)
+
+
+def lockstep_flush():
+    """ONE collective: do all ranks hold the same steering scalars since the last flush?  max(v) and max(-v) over the ranks
+    agree with the local values iff they do.  Every rank reaches the same verdict (RuntimeError everywhere or nowhere)."""
+    comm = lockstep_comm()
+    if comm is None or not _pending:
+        del _pending[:]
+        return
+    mine = torch.tensor(_pending, dtype=torch.float64)
+    del _pending[:]
+    mine = torch.nan_to_num(mine, nan=1.23456789e300, posinf=1.7e308, neginf=-1.7e308)  # comparable stand-ins
+    both = torch.cat([mine, -mine]).to(comm.scalar_device())
+    comm._staged(both, lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX, group=comm.group))
+    both = both.cpu()
+    n = mine.numel()
+    if not (torch.equal(both[:n], mine) and torch.equal(both[n:], -mine)):
+        raise RuntimeError("ranks left lockstep: replicated steering scalars differ between ranks (NK_LOCKSTEP=broadcast "
+                           "forces rank 0's values instead)")
 
 
 def lockstep_sync_(tensor):
-    """In-place: rank 0's content of a (small, device) tensor on every rank while a lockstep scope is active."""
+    """In-place: rank 0's content of a (small, device) tensor on every rank -- broadcast mode only; in verify mode the
+    tensor is left alone (its content is checked after the next fetch, lockstep_note)."""
     comm = lockstep_comm()
-    if comm is not None:
+    if comm is not None and _lockstep_mode() == "broadcast":
         comm.bcast_(tensor)
     return tensor
 

@@ -465,3 +465,45 @@ def test_chunked_overlapped_exchange_of_the_sharded_cg(tmp_path):
     assert same_bits(run(2, 4, overlap=0), two[4])
     for c in (1, 4, 16):
         assert close(two[c], serial, 1e-9), c
+
+
+def _lockstep_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from nifty_amd import parallel
+
+    comm, _ = parallel.init("gloo")
+    res = {}
+    # verify mode (default): values pass through unchanged, ONE collective per flush, agreement -> no error
+    with parallel.lockstep(comm):
+        a = [parallel.lockstep_float(v) for v in (1.5, float("nan"), -2.0, float("inf"))]
+        parallel.lockstep_note([3.0, 4.0])
+        parallel.lockstep_flush()
+        res["agree"] = a[0] == 1.5 and a[2] == -2.0
+    # a scalar that differs between the ranks is caught on EVERY rank at the flush (here: at scope exit)
+    try:
+        with parallel.lockstep(comm):
+            parallel.lockstep_float(1.0 + 1e-16 * 0 + (2.0 ** -52) * rank)
+        res["caught"] = False
+    except RuntimeError as exc:
+        res["caught"] = "left lockstep" in str(exc)
+    # broadcast mode (rounds 1-3): rank 0's value everywhere
+    os.environ["NK_LOCKSTEP"] = "broadcast"
+    with parallel.lockstep(comm):
+        res["forced"] = parallel.lockstep_float(10.0 + rank) == 10.0
+    torch.save(res, out + str(rank))
+    comm.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_lockstep_verifies_with_one_collective_per_flush(tmp_path):
+    """parallel.lockstep in its default verify mode: steering scalars are compared in ONE packed MAX all-reduce per flush
+    instead of one broadcast per decision; a disagreement raises on both ranks, NaN / inf included in the comparison."""
+    out = str(tmp_path / "ls")
+    mp.spawn(_lockstep_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for rank in (0, 1):
+        res = torch.load(out + str(rank), weights_only=False)
+        assert res == dict(agree=True, caught=True, forced=True), (rank, res)
