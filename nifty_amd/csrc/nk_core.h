@@ -361,6 +361,44 @@ NK_HD V* nk_ptr32(T* base, int64_t iu, uint32_t it) {
   return reinterpret_cast<V*>(b + (uint32_t)(it * (uint32_t)sizeof(T)));
 }
 
+// NK_NT_LOAD (bit mask): non-temporal LOADS of streams that are read exactly once per launch -- 1: work array of the
+// in-place strided passes, 2: operand streams of the octant prologues (in, in2, cg_r), 4: work array in the final pass,
+// 8: xi / addend / running sum in the scatter epilogue, 16: work array in the fused first-axis pass.  A plain streaming
+// copy gains 6 % from them (6.2 -> 6.6 TB/s, tools/micro/launch_shape.hip); in the passes (1024^3 fp32, tools/nt_load_sweep.sh,
+// profiles/r04_nt_load_sweep.log): bit 1 in-place pass 1.90 -> 3.00 ms (the line is written right back), bit 8 scatter
+// epilogue 4.29 -> 4.94 ms, bit 4 final pass 2.94 -> 3.06 ms, bit 2 first pass 3.06 -> 3.03-3.05 ms (noise), bit 16 fused
+// first-axis pass 2.22 -> 2.14-2.17 ms.  Default: bit 16 only.
+#ifndef NK_NT_LOAD
+#define NK_NT_LOAD 16
+#endif
+template <typename V>
+NK_HD V nk_ld_stream(const V* p) {
+#if !defined(NK_HOST_EMU)
+  if constexpr (sizeof(V) == 8) {
+    typedef float __attribute__((ext_vector_type(2))) W;
+    const W w = __builtin_nontemporal_load(reinterpret_cast<const W*>(p));
+    V v;
+    __builtin_memcpy(&v, &w, 8);
+    return v;
+  } else if constexpr (sizeof(V) == 16) {
+    typedef float __attribute__((ext_vector_type(4))) W;
+    const W w = __builtin_nontemporal_load(reinterpret_cast<const W*>(p));
+    V v;
+    __builtin_memcpy(&v, &w, 16);
+    return v;
+  } else if constexpr (sizeof(V) == 4) {
+    const float w = __builtin_nontemporal_load(reinterpret_cast<const float*>(p));
+    V v;
+    __builtin_memcpy(&v, &w, 4);
+    return v;
+  } else {
+    return *p;
+  }
+#else
+  return *p;
+#endif
+}
+
 // iu: wave-uniform part of the flat index (scalar registers), it: per-thread part (32 bit)
 template <typename T, int PC>
 NK_HD C2<T> nk_prologue_ct(const NkFuse& f, int64_t iu, uint32_t it) {
@@ -429,11 +467,16 @@ NK_HD NkOctOps<T> nk_oct_load(const NkFuse& f, int64_t iu, uint32_t it, uint32_t
     const C2<float> a32 = *reinterpret_cast<const C2<float>*>((const float*)f.in + iu + it);
     o.a = C2<T>{(T)a32.x, (T)a32.y};
   } else {
-    o.a = *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
+    o.a = (NK_NT_LOAD & 2) && PC != 8 ? nk_ld_stream(reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it))
+                                      : *reinterpret_cast<const C2<T>*>((const T*)f.in + iu + it);
   }
-  if constexpr (PC == 8) o.r = *reinterpret_cast<const C2<T>*>((const T*)f.cg_r + iu + it);
+  if constexpr (PC == 8)
+    o.r = (NK_NT_LOAD & 2) ? nk_ld_stream(reinterpret_cast<const C2<T>*>((const T*)f.cg_r + iu + it))
+                           : *reinterpret_cast<const C2<T>*>((const T*)f.cg_r + iu + it);
   o.m = nk_load_pair_u<T>((const T*)f.afield + j);
-  if constexpr (PC != 4 && PC != 9) o.x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
+  if constexpr (PC != 4 && PC != 9)
+    o.x = (NK_NT_LOAD & 2) ? nk_ld_stream(reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it))
+                           : *reinterpret_cast<const C2<T>*>((const T*)f.in2 + iu + it);
   if constexpr (PC == 7) {
     const NkPairU<int32_t> p = *reinterpret_cast<const NkPairU<int32_t>*>(f.pidx_octant + j);
     const T* dt = (const T*)f.dampT;

@@ -579,7 +579,7 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
         } else if (MODE == 3) {
           rg.v[q * R + r] = nk_prologue_ct<T, PC>(f, 2 * (in_off + uoff), 2 * toff);
         } else {
-          rg.v[q * R + r] = nk_at32<C2<T>>(base, uoff, toff);
+          rg.v[q * R + r] = (NK_NT_LOAD & 1) ? nk_ld_stream(&nk_at32<C2<T>>(base, uoff, toff)) : nk_at32<C2<T>>(base, uoff, toff);
         }
       }
     if (tw_lds) nk_tw_to_lds<T>(tw_global, tw_lds, N, tid, SC::P * TILE);  // published by this phase's barrier
@@ -898,9 +898,15 @@ NK_HD NkVjpOps<T> nk_final_vjp_load(const FinalCt<T>& c, int64_t ok, int64_t om,
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const bool on = BOTH || i < 2;
-    v.x[i] = on ? c.xi[at[i]] : (T)0;
-    v.d[i] = (on && add) ? c.addend[at[i]] : (T)0;
-    v.o[i] = (on && run) ? c.out[at[i]] : (T)0;
+    if constexpr ((NK_NT_LOAD & 8) != 0) {
+      v.x[i] = on ? nk_ld_stream(c.xi + at[i]) : (T)0;
+      v.d[i] = (on && add) ? nk_ld_stream(c.addend + at[i]) : (T)0;
+      v.o[i] = (on && run) ? nk_ld_stream(c.out + at[i]) : (T)0;
+    } else {
+      v.x[i] = on ? c.xi[at[i]] : (T)0;
+      v.d[i] = (on && add) ? c.addend[at[i]] : (T)0;
+      v.o[i] = (on && run) ? c.out[at[i]] : (T)0;
+    }
   }
   return v;
 }
@@ -1196,11 +1202,12 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
           if constexpr (PAIR == 1) {
             const bool up = n2 > H;
             const int c = up ? NL - n2 : n2;
-            const C2<T> Zk = lk[c], Zm = lm[c];
+            const C2<T> Zk = (NK_NT_LOAD & 4) ? nk_ld_stream(lk + c) : lk[c], Zm = (NK_NT_LOAD & 4) ? nk_ld_stream(lm + c) : lm[c];
             const T c0 = up ? Zk.y : Zk.x, c1 = up ? Zm.y : Zm.x, c2 = up ? Zk.x : Zk.y, c3 = up ? Zm.x : Zm.y;
             rg.v[q * R + r] = C2<T>{c0 + c1, c2 - c3};
           } else {
-            const C2<T> Zk = lk[n2 >> 1], Zm = lm[n2 >> 1];
+            const C2<T> Zk = (NK_NT_LOAD & 4) ? nk_ld_stream(lk + (n2 >> 1)) : lk[n2 >> 1],
+                        Zm = (NK_NT_LOAD & 4) ? nk_ld_stream(lm + (n2 >> 1)) : lm[n2 >> 1];
             const T c0 = odd ? Zk.y : Zk.x, c1 = odd ? Zm.y : Zm.x, c2 = odd ? Zm.x : Zk.y, c3 = odd ? Zk.x : Zm.y;
             rg.v[q * R + r] = C2<T>{c0 + c1, c2 - c3};
           }

@@ -324,7 +324,9 @@ NK_HD void nk_mid_body(Exec& ex, const NkPassM& pm, const NkFuse& f, int64_t v0,
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
-      for (int r = 0; r < R; ++r) dst[q * R + r] = nk_at32<C2<T>>(base, (int64_t)nk_in_row<SC, 0>(0, q, r) * rstride, toff);
+      for (int r = 0; r < R; ++r)
+        dst[q * R + r] = (NK_NT_LOAD & 16) ? nk_ld_stream(&nk_at32<C2<T>>(base, (int64_t)nk_in_row<SC, 0>(0, q, r) * rstride, toff))
+                                           : nk_at32<C2<T>>(base, (int64_t)nk_in_row<SC, 0>(0, q, r) * rstride, toff);
   };
 
   // exchange: the output of stage SA (rows nk_out_row<SA>) becomes the input of stage SB (rows nk_in_row<SB>)
