@@ -10,16 +10,19 @@ Difference by design: the linearisation of the Hamiltonian at every sample is ca
 energy is built, so one metric application costs one forward + one adjoint Jacobian per sample (the
 reference re-linearises inside every apply_metric call; mathematically identical).
 """
+import functools
 import os
 import pickle
 
 import numpy as np
+import torch
 
 from .energy_operators import GaussianEnergy, StandardHamiltonian
 from .field import Field, MultiField
 from .minimization import DescentMinimizer, Energy
 from .operators import (EndomorphicOperator, Linearization, Operator, SamplingEnabler, SandwichOperator, ScalingOperator,
                         makeDomain)
+from . import parallel
 from .parallel import SamplePlan, get_MPI_params_from_comm, shareRange
 
 
@@ -135,48 +138,47 @@ class SampleListBase:
         return -1
 
     def _sum_over_ranks(self, local_terms, like=None):
-        """Sum of Fields / MultiFields / floats (or tuples of those) over the local terms and over all ranks.  Ranks
-        WITHOUT samples (shareRange leaves ranks empty when there are fewer samples than ranks, utilities.py:349-414 copes
-        with any split) contribute a zero element.  `like`: an object shaped like one term (floats, fields on this rank's
-        device) -- the caller usually knows it, and the zero is then built locally, once.  Without it the first rank that
-        holds a term broadcasts a host template (a pickled collective per call: diagnostics only)."""
-        acc = None
-        for t in local_terms:
-            acc = t if acc is None else _add(acc, t)
-        comm = self._comm
-        if comm is None or comm.size == 1:
-            if acc is None:
-                raise ValueError("sum over an empty sample list")
-            return acc
-        # which ranks hold samples never changes for a list: asked once (one pickled all-gather), not per call
-        if getattr(self, "_holders", None) is None:
-            self._holders = comm.allgather_object(acc is not None)
-        if not any(self._holders):
+        """Sum of Fields / MultiFields / floats (or tuples of those) over the local terms and over all ranks, added in the
+        rank-count-independent order of the reference (utilities.py:349-414 -> parallel.pair_tree): the same bits for every
+        split of the samples over ranks, ranks WITHOUT samples included (shareRange leaves ranks empty when there are fewer
+        samples than ranks).  `like`: an object shaped like one term (floats, fields on this rank's device) for such a rank
+        to receive the total into -- the caller usually knows it; without it the first rank that holds a term broadcasts a
+        host template (a pickled collective per call: diagnostics only).  NK_TREE_SUM=0: local running sum + one
+        all-reduce (rounds 1-3)."""
+        terms, comm = list(local_terms), self._comm
+        tree = parallel.tree_sum_enabled()
+        alone = comm is None or comm.size == 1
+        if alone and not terms:
             raise ValueError("sum over an empty sample list")
-        if like is not None:
-            if acc is None:
-                zeros = self.__dict__.setdefault("_zeros", {})
-                key = _map(like, lambda o: float if isinstance(o, float) else id(o.domain))
-                if key not in zeros:
-                    zeros[key] = _map(like, lambda o: 0.0 if isinstance(o, float) else o * 0.0)
-                acc = zeros[key]
-        elif not all(self._holders):
-            root = self._holders.index(True)
-            template = comm.bcast_object(_zero_like_host(acc) if comm.rank == root else None, root=root)
-            if acc is None:
-                acc = _place_like(template, self._device_id())
-        return _map(acc, self._allreduce_fields)
-
-    def _allreduce_fields(self, obj):
-        """Sum a Field / MultiField / python float over ranks (fields: in place on a private copy)."""
-        if self._comm is None or self._comm.size == 1:
-            return obj
-        if isinstance(obj, float):
-            return self._comm.sum_float(obj)  # the scalar lives where the backend needs it (RCCL: on the GPU)
-        obj = obj * 1.0
-        tensors = [f.val for f in (obj.values() if isinstance(obj, MultiField) else [obj])]
-        self._comm.allreduce_sum_(tensors)
-        return obj
+        if alone:
+            return parallel.tree_fold(terms, _add) if tree else functools.reduce(_add, terms)
+        # how the terms are spread over the ranks never changes for a list: asked once (one pickled all-gather), not per call
+        if getattr(self, "_counts", None) is None:
+            self._counts = comm.term_counts(len(terms))
+        if not any(self._counts):
+            raise ValueError("sum over an empty sample list")
+        if not terms:
+            if like is None:
+                root = next(r for r, c in enumerate(self._counts) if c)
+                like = _place_like(comm.bcast_object(None, root=root), self._device_id())
+            cache = self.__dict__.setdefault("_zeros", {})
+            key = _map(like, lambda o: float if isinstance(o, float) else id(o.domain))
+            if key not in cache:
+                cache[key] = _map(like, lambda o: 0.0 if isinstance(o, float) else o * 0.0)
+            like = cache[key]
+        elif like is None and not all(self._counts):
+            root = next(r for r, c in enumerate(self._counts) if c)
+            if comm.rank == root:
+                comm.bcast_object(_zero_like_host(terms[0]), root=root)
+            else:
+                comm.bcast_object(None, root=root)
+        if not tree:
+            local = functools.reduce(_add, terms) if terms else like
+            return _map(local, self._allreduce_fields)
+        boxes = [_Flat(t, comm) for t in terms]
+        spare = _Flat(like, comm) if not terms else None
+        total = comm.tree_allreduce([b.tensors for b in boxes], self._counts, like=None if spare is None else spare.tensors)
+        return (boxes[0] if boxes else spare).rebuilt(total)
 
     def average(self, op=None):
         """Mean of op(sample) over ALL samples (sample_list.py:212-237)."""
@@ -389,6 +391,43 @@ class SampleList(SampleListBase):
 
 def _to_host(f):
     return f.at(-1)
+
+
+class _Flat:
+    """One term of a distributed sum -- a float, Field, MultiField or a tuple of those -- as a list of tensors that a
+    collective may overwrite: private copies of the field values, python floats as one-element fp64 tensors where the
+    backend wants them."""
+
+    def __init__(self, term, comm):
+        self._parts = []  # ("number", None) or ("field", private copy)
+        self._tuple = isinstance(term, tuple)
+        self.tensors = []
+        for o in (term if self._tuple else (term,)):
+            if isinstance(o, float):
+                self._parts.append(None)
+                self.tensors.append(torch.tensor([o], dtype=torch.float64, device=comm.scalar_device()))
+            else:
+                mine = o * 1.0
+                self._parts.append(mine)
+                self.tensors += [f.val for f in (mine.values() if isinstance(mine, MultiField) else [mine])]
+
+    def rebuilt(self, tensors):
+        """The term again once `tensors` (this object's own, in order) hold the result."""
+        if any(a is not b for a, b in zip(tensors, self.tensors)):
+            raise RuntimeError("_Flat.rebuilt: foreign tensors")
+        numbers = iter(float(t.item()) for t, p in zip(self._number_slots(), [p for p in self._parts if p is None]))
+        out = tuple(next(numbers) if p is None else p for p in self._parts)
+        return out if self._tuple else out[0]
+
+    def _number_slots(self):
+        slots, at = [], 0
+        for p in self._parts:
+            if p is None:
+                slots.append(self.tensors[at])
+                at += 1
+            else:
+                at += len(p.values()) if isinstance(p, MultiField) else 1
+        return slots
 
 
 def _map(obj, fn):

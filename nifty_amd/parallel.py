@@ -2,10 +2,14 @@
 
 Counterpart of the reference's only parallel strategy: samples are partitioned by
 ``shareRange`` (nifty/cl/utilities.py:282-306) and per-sample contributions are summed over ranks by
-``allreduce_sum`` (utilities.py:349-414, called from sample_list.py:237,265).  Here the sum is ONE
-in-place all-reduce per evaluation over the device-resident latent vector (backend "nccl" = RCCL on
-ROCm; "gloo" for the CPU tests).  Unlike the reference's pairwise host tree the RCCL reduction order
-depends on the rank count, i.e. results agree between rank counts to rounding (not bitwise).
+``allreduce_sum`` (utilities.py:349-414, called from sample_list.py:237,265), whose result does not depend on the number of
+tasks: the terms are added pairwise over the GLOBAL term index with doubling distance.  Here the same order is kept
+(`pair_tree`, `Comm.tree_allreduce`, `Comm.tree_reduce_slices`): a rank adds what it holds locally; where the two
+summands of a merge live on different ranks either the second one travels to the holder of the first (any split of the
+terms: point-to-point, the order of the reference) or -- every rank holding one complete subtree, the case of the fused
+engine -- the rank partials are exchanged slice-wise (one all-to-all: the bytes of a reduce-scatter) and every rank
+finishes the tree on its slice.  Backend "nccl" = RCCL on ROCm; "gloo" for the CPU tests.  NK_TREE_SUM=0 restores the
+plain all-reduce of rounds 1-3 (RCCL's order: results agree between rank counts to rounding only).
 """
 import os
 
@@ -64,6 +68,79 @@ class Comm:
         for t in tensors:
             self._staged(t, lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group))
         return tensors
+
+    # -- sums whose bits do not depend on the rank count (utilities.py:349-414) -----------------------------------------
+    def _p2p(self, t, peer, fn):
+        """dist.send / dist.recv of one tensor with this communicator's rank numbering (gloo: through a host copy)."""
+        peer = peer if self.group is None else dist.get_global_rank(self.group, peer)
+        return self._staged(t, lambda x: fn(x, peer, group=self.group))
+
+    def term_counts(self, n_local):
+        """How many terms of a distributed sum every rank holds (one small collective; callers cache it per sample list)."""
+        return [int(c) for c in self.allgather_object(int(n_local))]
+
+    def tree_allreduce(self, terms, counts, like=None):
+        """Sum over ALL ranks' terms in the order of `pair_tree`, on every rank.  `terms`: this rank's terms in global order,
+        each a list of tensors (same shapes everywhere); they are used as accumulators.  `counts[r]` terms live on rank r,
+        rank r holding the global indices sum(counts[:r]) ...  A merge whose summands sit on different ranks moves the second
+        one to the holder of the first; the total is broadcast from the holder of term 0 and returned in the tensors of this
+        rank's first term (`like`: tensors shaped like one term, for a rank without terms to receive the total into)."""
+        first = [sum(counts[:r]) for r in range(self.size)]
+        owner = [r for r, c in enumerate(counts) for _ in range(c)]
+        mine = dict(zip(range(first[self.rank], first[self.rank] + counts[self.rank]), terms))
+        for into, other in pair_tree(len(owner)):
+            a, b = owner[into], owner[other]
+            if a == b == self.rank:
+                for x, y in zip(mine[into], mine.pop(other)):
+                    x.add_(y)
+            elif a == self.rank:
+                for x in mine[into]:
+                    box = torch.empty_like(x)
+                    self._p2p(box, b, dist.recv)
+                    x.add_(box)
+            elif b == self.rank:
+                for y in mine.pop(other):
+                    self._p2p(y.contiguous(), a, dist.send)
+        if not owner:
+            raise ValueError("sum over an empty list of terms")
+        total = mine[0] if owner[0] == self.rank else (terms[0] if terms else like)  # (sent terms are free to receive into)
+        for t in total:
+            self.bcast_(t, root=owner[0])
+        return total
+
+    def subtree_per_rank(self, counts):
+        """True when every rank holds the same power-of-two number of terms: its local sum is then one node of `pair_tree`
+        and the remaining merges are the tree over the RANK partials."""
+        c = counts[0]
+        return c > 0 and c & (c - 1) == 0 and all(k == c for k in counts)
+
+    def tree_reduce_slices(self, full, shard=None):
+        """The tree over the rank partials `full` (one flat tensor per rank, the same length everywhere, divisible by the rank
+        count), slice-wise: rank j receives slice j of every partial (all-to-all), adds them in `pair_tree` order and keeps
+        the result in `shard` (returned).  The cross-rank half of a rank-count-independent reduce-scatter."""
+        m = full.numel() // self.size
+        if m * self.size != full.numel():
+            raise ValueError("tree_reduce_slices: length not divisible by the rank count")
+        box = torch.empty_like(full)
+        if self.backend_is_nccl or not full.is_cuda:
+            dist.all_to_all_single(box, full, group=self.group)
+        else:  # (several ranks on one GPU with gloo: host staging, see _staged)
+            h_in, h_out = full.detach().cpu(), torch.empty(full.shape, dtype=full.dtype)
+            dist.all_to_all_single(h_out, h_in, group=self.group)
+            box.copy_(h_out)
+        parts = list(box.view(self.size, m).unbind(0))
+        for into, other in pair_tree(self.size):
+            parts[into].add_(parts[other])
+        if shard is None:
+            return parts[0]
+        shard.copy_(parts[0])
+        return shard
+
+    def tree_allreduce_slices_(self, full):
+        """In place: the tree over the rank partials on every rank (tree_reduce_slices + all-gather)."""
+        flat = full.view(-1)
+        self.all_gather(self.tree_reduce_slices(flat).clone(), flat)
+        return full
 
     # -- sharded vectors: the CG state of the KL minimisation lives on 1/size of the latent vector per rank -------
     def can_shard(self, n):
@@ -156,6 +233,33 @@ class Comm:
     @property
     def is_master(self):
         return self.rank == 0
+
+
+def tree_sum_enabled():
+    """NK_TREE_SUM (default 1): sums over samples follow `pair_tree` -- locally and across ranks."""
+    return os.environ.get("NK_TREE_SUM", "1") != "0"
+
+
+def pair_tree(n):
+    """The merges (into, other) -- term[into] += term[other] -- that add n terms like utilities.py:349-414 does: neighbours at
+    distance 1 first ((0,1), (2,3), ...), then the survivors at distance 2, 4, ...; a term without partner waits for a later
+    round.  term[0] ends up holding the total.  The list is the same whatever the number of ranks: that is the point."""
+    merges, gap = [], 1
+    while gap < n:
+        merges += [(left, left + gap) for left in range(0, n - gap, 2 * gap)]
+        gap *= 2
+    return merges
+
+
+def tree_fold(terms, add=None):
+    """Local `pair_tree` sum of a sequence (a fresh list is folded; `add(a, b)` defaults to a + b)."""
+    vals = list(terms)
+    if not vals:
+        raise ValueError("sum over an empty list of terms")
+    for into, other in pair_tree(len(vals)):
+        vals[into] = vals[into] + vals[other] if add is None else add(vals[into], vals[other])
+        vals[other] = None
+    return vals[0]
 
 
 # ---- lockstep scope --------------------------------------------------------------------------------------
