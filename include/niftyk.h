@@ -136,6 +136,14 @@ typedef struct nk_fuse {
                            fp64 amplitude and transforms in fp64 (library/correlated_fields.py:755-764), and an fp32 forward
                            transform leaves a coherent 6e-8 gain error on the signal that the residual N^-1 (s - d) amplifies
                            (DESIGN 6).  NK_ERR_INVALID with any other prologue / epilogue or on an fp32 plan */
+  const void* carry1;
+  const void* carry2;   /* VJP epilogue, optional: T* partial sums of OTHER samples that join this one's output.  The sample's
+                           own contribution g[o] = amp * t (+ addend_scale * addend[o]) is rounded to T and then added innermost
+                           first: out[o] = [out[o] +] ([carry2[o] +] ([carry1[o] +] g[o])) (the bracketed terms when
+                           accumulate / the pointers are set) -- plain additions of stored values, so a sum over samples built
+                           in the order of the reference's allreduce_sum (nifty/cl/utilities.py:349-414: neighbours first,
+                           then pairs of pairs, ...) has the same bits whether its partial sums were formed in these epilogues
+                           on one GPU or added across ranks.  nk_hartley_sandwich_pair: B may take A's `out` as carry1 */
 } nk_fuse;
 
 typedef struct nk_plan nk_plan;
@@ -198,6 +206,25 @@ int nk_profile_collect(double* ms, int64_t* count);
  *      result is written to a DEVICE double (no host sync).  `result` must be zeroed by the caller
  *      unless accumulate == 0 (then the kernel chain zeroes it first). */
 int nk_vdot(int64_t n, const void* a, const void* b, int dtype, double* result, int accumulate, void* stream);
+
+/* ---- rank-count-independent reductions of SHARDED vectors (no reference counterpart as a function: the reference keeps
+ *      every vector whole on every task; its sums over samples are task-count independent, nifty/cl/utilities.py:349-414,
+ *      and a drop-in that shards the CG vectors has to keep that property for their dot products).
+ *      Every reduction of this library (nk_vdot, nk_sum, nk_stats, nk_axpby_sqnorm, nk_cg_curv, nk_cg_update, ...) cuts an
+ *      array whose length qualifies -- nk_red_unit(n, dtype) != 0: 64 units of whole 256-vector rows -- into 64 contiguous
+ *      UNITS, reduces each unit with a sub-grid that depends on the unit length only and adds the 64 unit sums in order.
+ *      A rank that holds a shard made of whole units announces it with nk_red_layout: unit length, the number of units it
+ *      holds, the number of units of the full array (64) and where its units sit -- the shard is a sequence of segments
+ *      of seg_units units, segment j starting at unit j * seg_stride + seg_off of the full array (the [chunk][rank][m]
+ *      ownership of the sharded CG) -- and a device array units_out[nred][k_global].  Reduction launches of THIS host
+ *      thread over exactly k_local * unit_elems elements then write the unit sums (zeros for foreign units) to units_out
+ *      INSTEAD of accumulating into their result; after a sum all-reduce of units_out over the ranks (exact: one non-zero
+ *      term per unit) nk_red_finish adds the units in order into result[0..nred) -- bit-identical to the single-process
+ *      reduction of the whole array.  nk_red_layout(0, ...) clears the announcement. */
+int64_t nk_red_unit(int64_t n, int dtype);
+int nk_red_layout(int64_t unit_elems, int k_local, int k_global, int seg_units, int seg_stride, int seg_off,
+                  double* units_out);
+int nk_red_finish(const double* units, int k_global, int nred, double* result, int accumulate, void* stream);
 int nk_sum(int64_t n, const void* a, int dtype, double* result, int accumulate, void* stream);
 /* result3 = {sum, sum of squares, count} of a over the entries that are neither NaN nor exactly 0 (count = the ignored
  * ones): the per-key statistics of extra.minisanity (extra.py:640-654) */
@@ -342,6 +369,34 @@ int nk_cg_update_dr(int64_t n, void* x, void* r, const void* d, const void* q, i
 /* roll != 0: after the update also do scal[5]=alpha, scal[6]=beta, scal[0]=scal[2] (call once per iteration,
  * on the last segment of a multi-segment vector; n == 0 with d = r = NULL only rolls) */
 int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, double* scal, int roll, void* stream);
+
+/* ---- amplitude fields of PRODUCT spectra (library/correlated_fields.py:713-764: CorrelatedFieldMaker.finalize multiplies
+ *      the amplitudes of the sub-spaces, each distributed over the full harmonic domain by ContractionOperator.adjoint @
+ *      PowerDistributor, and the zero-mode amplitude; :809-858 get_normalized_amplitudes).  The grid is [S0][S1][S2] in C
+ *      order -- up to three sub-spaces, S_i = number of points of sub-space i (a sub-space may be multi-dimensional:
+ *      its points flattened), the full grid or the OCTANT arrays of nk_fuse.field_octant / w8 alike.
+ *        pidx[i]  device int32[S_i]   power bin of every point of sub-space i
+ *        tab[i]   device double[nb_i] the sub-space's amplitude table;  dtab[i]: a tangent of it, or NULL
+ *        scale    device double       overall factor (the zero-mode amplitude);  dscale: its tangent, or NULL
+ *      nk_product_field     out[k] = scale * prod_i tab_i[pidx_i(k_i)]                     (tangent == 0)
+ *                           out[k] = dscale * prod_i tab_i + scale * sum_i dtab_i prod_(j != i) tab_j   (tangent != 0)
+ *                           -- the field `afield` / `dafield` of the AMP / AMP_JVP prologues and the VJP epilogue
+ *      nk_product_marginal  marg[b] = sum over the points k with k_which = b of w[k] * scale * prod_(j != which) tab_j:
+ *                           the adjoint of the distribution for sub-space `which` (reduce it over the bins with
+ *                           nk_csr_rowsum); w = the per-point sums xi * t of the VJP epilogue (nk_fuse.wfull / w8).  Every
+ *                           sum runs in a fixed order (bit-reproducible).  scratch: nk_product_marginal_scratch bytes */
+typedef struct nk_product {
+  int nsub;
+  int64_t size[3];
+  const int32_t* pidx[3];
+  const double* tab[3];
+  const double* dtab[3];
+  const double* scale;
+  const double* dscale;
+} nk_product;
+int nk_product_field(const nk_product* p, int tangent, void* out, int dtype, void* stream);
+size_t nk_product_marginal_scratch(const nk_product* p, int which);
+int nk_product_marginal(const nk_product* p, int which, const double* w, double* scratch, double* marg, void* stream);
 
 /* ---- amplitude model on the nb power bins (library/correlated_fields.py:89-208,277-386).
  *      geo  = double[4*nb]: rel[nb], sc[nb], mult[nb], delta[nb] (delta uses the first nb-2 slots)

@@ -31,8 +31,15 @@ class Fuse(ctypes.Structure):
         ("icov", _vp), ("icov_scalar", _d), ("out2", _vp), ("value", _vp),
         ("afield", _vp), ("dampT", _vp), ("abar_copies", _i), ("abar_stride", _i64), ("dafield", _vp), ("w8", _vp),
         ("field_octant", _i), ("value_slots", _i), ("pidx_octant", _vp), ("cg_r", _vp), ("cg_scal", _vp), ("w8max", _vp),
-        ("pipe_chunks", _i), ("pipe_wait", _vp), ("pipe_record", _vp), ("wfull", _vp), ("io32", _i),
+        ("pipe_chunks", _i), ("pipe_wait", _vp), ("pipe_record", _vp), ("wfull", _vp), ("io32", _i), ("carry1", _vp), ("carry2", _vp),
     ]
+
+
+class Product(ctypes.Structure):
+    """Mirror of ``struct nk_product`` (include/niftyk.h)."""
+
+    _fields_ = [("nsub", _i), ("size", _i64 * 3), ("pidx", _vp * 3), ("tab", _vp * 3), ("dtab", _vp * 3), ("scale", _vp),
+                ("dscale", _vp)]
 
 
 # name -> (restype, argtypes); the list is checked against include/niftyk.h by tests/test_abi.py
@@ -52,6 +59,12 @@ SIGNATURES = {
     "nk_profile_enable": (_i, [_i]),
     "nk_profile_collect": (_i, [_vp, _vp]),
     "nk_vdot": (_i, [_i64, _vp, _vp, _i, _vp, _i, _vp]),
+    "nk_product_field": (_i, [ctypes.POINTER(Product), _i, _vp, _i, _vp]),
+    "nk_product_marginal_scratch": (_sz, [ctypes.POINTER(Product), _i]),
+    "nk_product_marginal": (_i, [ctypes.POINTER(Product), _i, _vp, _vp, _vp, _vp]),
+    "nk_red_unit": (_i64, [_i64, _i]),
+    "nk_red_layout": (_i, [_i64, _i, _i, _i, _i, _i, _vp]),
+    "nk_red_finish": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "nk_sum": (_i, [_i64, _vp, _i, _vp, _i, _vp]),
     "nk_stats": (_i, [_i64, _vp, _i, _vp, _vp]),
     "nk_binary": (_i, [_i, _i64, _vp, _d, _vp, _d, _vp, _i, _vp]),

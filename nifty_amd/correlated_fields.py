@@ -12,6 +12,8 @@ Two realisations share one interface:
   Jacobian run in the HIP kernels of libniftyk (amplitude kernels + fused Hartley transform) for
   device Fields.  ``finalize()`` returns this node; on host Fields it evaluates the generic graph.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -474,6 +476,211 @@ class CorrelatedFieldOperator(Operator):
         return f"CorrelatedFieldOperator(shape={self._pos.shape}, nb={self._nb})"
 
 
+class _ProductFieldNode(Operator):
+    """{xi, the normalised amplitude tables of the sub-spaces, the zero-mode amplitude} -> offset + HT(azm prod_i
+    a_i[pindex_i] xi): the big-field half of CorrelatedFieldMaker.finalize for SEVERAL spectra and / or total_N > 0
+    (reference correlated_fields.py:713-764) as one fused node.  The amplitude models themselves -- a few numbers per power
+    bin, standard or Matern, shared between fields by dofdex -- stay operator graphs on their small domains and feed this
+    node their tables; everything that touches the grid happens here, per field copy:
+      value     nk_product_field builds azm prod_i a_i[pindex_i] straight from the tables, the transform multiplies it in
+                its prologue (AMP with `afield`) and adds the offset in its epilogue;
+      TIMES     the first-order variation of the amplitude field (nk_product_field, tangent) enters the AMP_JVP prologue;
+      ADJOINT   the VJP epilogue returns a . t and the per-point sums xi . t (nk_fuse.wfull, or the octant sums w8 on plans
+                with the register-resident pipeline); nk_product_marginal contracts them with the other sub-spaces'
+                amplitudes and nk_csr_rowsum adds them bin by bin, all in a fixed order.
+    The reference distributes every amplitude over the full grid and multiplies fields (one PowerDistributor +
+    ContractionOperator.adjoint per sub-space, six N-sized products per evaluation for two spectra)."""
+
+    KEYS = ("xi", "azm")
+
+    def __init__(self, hspace, target, amp_targets, azm_target, total_N, offset):
+        self._hspace, self._target = makeDomain(hspace), makeDomain(target)
+        self._copies = int(total_N)
+        self._lead = 1 if self._copies > 0 else 0
+        dom = {"xi": self._hspace, "azm": makeDomain(azm_target)}
+        dom.update({f"a{i}": makeDomain(t) for i, t in enumerate(amp_targets)})
+        self._domain = MultiDomain.make(dom)
+        self._nsub = len(amp_targets)
+        self._subspaces = [self._hspace[self._lead + i] for i in range(self._nsub)]
+        self._bins = [makeDomain(t)[self._lead] for t in amp_targets]
+        self._grid = tuple(n for sp in self._subspaces for n in sp.shape)
+        self._offset = float(offset)
+        self._scale = float(np.prod([sp.scalar_dvol for sp in self._subspaces]))
+        self._dev = {}
+        self.calls = {"value": 0, "times": 0, "adjoint": 0}  # (tests check that this node, not the generic graph, ran)
+
+    # -- what the kernels need, per device and dtype ------------------------------------------------------------------------
+    def supported(self, dtype, device):
+        return 1 <= self._nsub <= 3 and len(self._grid) <= 3 and B.plan_supported(self._grid, dtype, 1, device)
+
+    def _setup(self, dtype, device):
+        key = (str(device), dtype)
+        if key in self._dev:
+            return self._dev[key]
+        plan = B.get_plan(self._grid, dtype, 1, device)
+        octant = bool(L.load().nk_plan_octant_vjp(plan.handle))
+        pidx, sizes, plans = [], [], []
+        for sp, bins in zip(self._subspaces, self._bins):
+            full = bins.device_pindex(device).reshape(sp.shape)
+            part = full[tuple(slice(0, n // 2 + 1) for n in sp.shape)].contiguous() if octant else full
+            pidx.append(part.reshape(-1))
+            sizes.append(part.numel())
+            plans.append(B.bin_plan(pidx[-1], bins.shape[0]))
+        npts = int(np.prod(sizes))
+        st = dict(plan=plan, octant=octant, pidx=pidx, sizes=sizes, bin_plans=plans, npts=npts,
+                  # operands the C ABI insists on although the amplitude arrives as a field
+                  no_pidx=torch.zeros(int(np.prod(self._grid)), dtype=torch.int32, device=device),
+                  one=torch.ones(1, dtype=torch.float64, device=device), sink=torch.zeros(1, dtype=torch.float64, device=device))
+        self._dev[key] = st
+        return st
+
+    def _product(self, st, tabs, azm, dtabs=None, dazm=None):
+        q = L.Product()
+        q.nsub = self._nsub
+        for i in range(self._nsub):
+            q.size[i], q.pidx[i], q.tab[i] = st["sizes"][i], st["pidx"][i].data_ptr(), tabs[i].data_ptr()
+            q.dtab[i] = None if dtabs is None else dtabs[i].data_ptr()
+        q.scale = azm.data_ptr()
+        q.dscale = None if dazm is None else dazm.data_ptr()
+        return q
+
+    def _field(self, st, dtype, q, tangent):
+        out = torch.empty(st["npts"], dtype=dtype, device=st["no_pidx"].device)
+        L.check(L.load().nk_product_field(ctypes.byref(q), 1 if tangent else 0, out.data_ptr(), B.dtype_code(out), B._stream()),
+                "nk_product_field")
+        return out
+
+    def _fuse(self, st, field):
+        f = L.Fuse()
+        f.scale, f.mul_scalar, f.addend_scale = self._scale, 1.0, 1.0
+        f.pidx, f.amp, f.damp = st["no_pidx"].data_ptr(), st["one"].data_ptr(), st["one"].data_ptr()
+        f.afield, f.field_octant = field.data_ptr(), 1 if st["octant"] else 0
+        return f
+
+    def _rows(self, field, width=None):
+        """[copies][...] view of a Field's values (one row when the maker has no leading copy domain)."""
+        v = field.val.contiguous()
+        return v.reshape(max(self._copies, 1), -1) if width is None else v.reshape(max(self._copies, 1), width)
+
+    def _inputs(self, v):
+        xi = self._rows(v["xi"])
+        tabs = [self._rows(v[f"a{i}"]).to(torch.float64) for i in range(self._nsub)]
+        azm = self._rows(v["azm"]).to(torch.float64)
+        return xi, tabs, azm
+
+    def apply(self, x):
+        self._check_input(x)
+        lin = is_linearization(x)
+        v = x.val if lin else x
+        xi, tabs, azm = self._inputs(v)
+        st = self._setup(xi.dtype, xi.device)
+        out = torch.empty_like(xi)
+        fields = []
+        for c in range(xi.shape[0]):
+            q = self._product(st, [t[c] for t in tabs], azm[c])
+            fields.append(self._field(st, xi.dtype, q, False))
+            f = self._fuse(st, fields[-1])
+            f.pro, f.in_ = L.PRO_AMP, xi[c].data_ptr()
+            f.epi, f.out, f.offset = L.EPI_AFFINE, out[c].data_ptr(), self._offset
+            B.hartley_fused(st["plan"], f)
+        self.calls["value"] += 1
+        val = Field(self._target, out.reshape(self._target.shape))
+        return x.new(val, _ProductFieldJacobian(self, st, xi, tabs, azm, fields)) if lin else val
+
+    def __repr__(self):
+        return f"_ProductFieldNode(grid={self._grid}, copies={self._copies}, spectra={self._nsub})"
+
+
+class _ProductFieldJacobian(LinearOperator):
+    """Jacobian of `_ProductFieldNode` at one point (TIMES = JVP, ADJOINT_TIMES = VJP)."""
+
+    def __init__(self, node, st, xi, tabs, azm, fields):
+        self._n, self._st = node, st
+        self._domain, self._target = node.domain, node.target
+        self._xi, self._tabs, self._azm, self._fields = xi, tabs, azm, fields
+        self._capability = self.TIMES | self.ADJOINT_TIMES
+
+    def apply(self, x, mode):
+        self._check_input(x, mode)
+        return self._times(x) if mode == self.TIMES else self._adjoint(x)
+
+    def _times(self, x):
+        n, st = self._n, self._st
+        dxi, dtabs, dazm = n._inputs(x)
+        dxi = dxi.to(self._xi.dtype)
+        out = torch.empty_like(self._xi)
+        for c in range(self._xi.shape[0]):
+            q = n._product(st, [t[c] for t in self._tabs], self._azm[c], [t[c] for t in dtabs], dazm[c])
+            dfield = n._field(st, self._xi.dtype, q, True)
+            f = n._fuse(st, self._fields[c])
+            f.pro, f.in_, f.in2, f.dafield = L.PRO_AMP_JVP, dxi[c].data_ptr(), self._xi[c].data_ptr(), dfield.data_ptr()
+            f.epi, f.out, f.offset = L.EPI_AFFINE, out[c].data_ptr(), 0.0
+            B.hartley_fused(st["plan"], f)
+        n.calls["times"] += 1
+        return Field(self._target, out.reshape(self._target.shape))
+
+    def _adjoint(self, x):
+        n, st, lib = self._n, self._st, L.load()
+        w = n._rows(x).to(self._xi.dtype)
+        xi_bar = torch.empty_like(self._xi)
+        tab_bar = [torch.empty_like(t) for t in self._tabs]
+        azm_bar = torch.empty_like(self._azm)
+        sums = torch.empty(st["npts"], dtype=torch.float64, device=w.device)  # per-point xi . t (full grid or octant)
+        for c in range(w.shape[0]):
+            f = n._fuse(st, self._fields[c])
+            f.pro, f.in_ = L.PRO_PLAIN, w[c].data_ptr()
+            f.epi, f.out, f.xi, f.abar = L.EPI_VJP, xi_bar[c].data_ptr(), self._xi[c].data_ptr(), st["sink"].data_ptr()
+            if st["octant"]:
+                f.w8 = sums.data_ptr()
+            else:
+                f.wfull = sums.data_ptr()
+            B.hartley_fused(st["plan"], f)
+            q = n._product(st, [t[c] for t in self._tabs], self._azm[c])
+            for i in range(n._nsub):
+                scratch = torch.empty(max(1, lib.nk_product_marginal_scratch(ctypes.byref(q), i) // 8), dtype=torch.float64,
+                                      device=w.device)
+                marg = torch.empty(st["sizes"][i], dtype=torch.float64, device=w.device)
+                L.check(lib.nk_product_marginal(ctypes.byref(q), i, sums.data_ptr(), scratch.data_ptr(), marg.data_ptr(),
+                                                B._stream()), "nk_product_marginal")
+                tab_bar[i][c] = B.bin_sum(marg, st["bin_plans"][i])
+            # d/d azm of azm * prod_i a_i: the same contraction with every table in place = sum_b a_0[b] abar_0[b] / azm
+            azm_bar[c] = B.vdot(self._tabs[0][c].contiguous(), tab_bar[0][c].contiguous()) / self._azm[c]
+        n.calls["adjoint"] += 1
+        dom, dt = self._domain, self._xi.dtype
+        vals = {"xi": Field(dom["xi"], xi_bar.reshape(dom["xi"].shape)),
+                "azm": Field(dom["azm"], azm_bar.reshape(dom["azm"].shape).to(dt))}
+        for i, t in enumerate(tab_bar):
+            vals[f"a{i}"] = Field(dom[f"a{i}"], t.reshape(dom[f"a{i}"].shape).to(dt))
+        return MultiField.from_dict(vals, dom)
+
+
+class ProductCorrelatedFieldOperator(Operator):
+    """CorrelatedFieldMaker.finalize for several spectra / total_N > 0: the generic operator graph for host fields and for
+    grids the transform planner rejects, `_ProductFieldNode` fed by the amplitude graphs for device fields."""
+
+    def __init__(self, generic_op, node, feeder):
+        self._generic, self._node, self._fused = generic_op, node, node @ feeder
+        self._domain, self._target = generic_op.domain, generic_op.target
+        if self._fused.domain is not self._domain or self._fused.target is not self._target:
+            raise RuntimeError("fused and generic correlated field disagree about their domains")
+
+    def apply(self, x):
+        self._check_input(x)
+        v = x.val if is_linearization(x) else x
+        any_field = next(iter(v.values()))
+        on_device = v.device_id >= 0
+        if on_device and self._node.supported(any_field.val.dtype, any_field.val.device):
+            return self._fused(x)
+        return self._generic(x)
+
+    @property
+    def fused_node(self):
+        return self._node
+
+    def __repr__(self):
+        return f"ProductCorrelatedFieldOperator({self._node!r})"
+
+
 # ------------------------------------------------------------------------------------------------
 # maker
 # ------------------------------------------------------------------------------------------------
@@ -647,13 +854,34 @@ class CorrelatedFieldMaker:
             op = op + float(self._offset_mean)
         return op
 
+    def _product_operator(self, generic):
+        """Several spectra and / or total_N > 0: the amplitude graphs feed one fused node (`_ProductFieldNode`); anything
+        the node does not cover (non-regular sub-spaces, more than three sub-spaces) stays generic."""
+        space = 1 if self._total_N > 0 else 0
+        subs = [sd[space] for sd in self._target_subdomains]
+        if len(self._a) > 3 or not all(isinstance(sd, RGSpace) for sd in subs):
+            return generic
+        lead = [UnstructuredDomain(self._total_N)] if self._total_N > 0 else []
+        hspace = makeDomain(lead + [a.target[space].harmonic_partner for a in self._a])
+        if hspace is not generic.domain[self._prefix + "xi"]:
+            return generic
+        amps = self.get_normalized_amplitudes()
+        node = _ProductFieldNode(hspace, generic.target, [a.target for a in amps], self.azm.target, self._total_N,
+                                 0.0 if self._offset_mean is None else self._offset_mean)
+        feeder = Variable(hspace, self._prefix + "xi").ducktape_left("xi") + self.azm.ducktape_left("azm")
+        for i, a in enumerate(amps):
+            feeder = feeder + a.ducktape_left(f"a{i}")
+        return ProductCorrelatedFieldOperator(generic, node, feeder)
+
     def finalize(self, prior_info=0):
         if len(self._a) < 1 or self._azm is None:
             raise NotImplementedError("add_fluctuations() and set_amplitude_total_offset() must have been called")
         generic = self._generic_graph()
         pos = self._target_subdomains[0][0]
-        if len(self._a) > 1 or self._total_N > 0 or not isinstance(pos, RGSpace) or self._amp_prefix != self._prefix:
-            return generic  # product spectra and total_N > 0 run on the generic operator graph
+        if len(self._a) > 1 or self._total_N > 0 or self._amp_prefix != self._prefix:
+            return self._product_operator(generic)
+        if not isinstance(pos, RGSpace):
+            return generic
         return CorrelatedFieldOperator(pos, generic, self._prefix, 0.0 if self._offset_mean is None else self._offset_mean,
                                        dict(self._hyper))
 

@@ -624,6 +624,37 @@ NK_HD void nk_epi_likelihood4(const NkFuse& f, const int64_t (&o)[4], const T (&
   }
 }
 
+// The running sum of a VJP output (nk_fuse.accumulate / carry1 / carry2): the sample's own contribution g is ROUNDED to the
+// field type first and then added to the partial sums innermost first, out <- [out +] ([carry2 +] ([carry1 +] g)) -- plain
+// additions of stored values, so that a sum over samples gives the same bits whether its partial sums were formed in this
+// epilogue or by a separate addition on another rank (the pairwise order of utilities.py:349-414).
+// nk_settle: the value as it would be stored -- keeps the compiler from contracting the product inside g with the addition
+// that follows (fma(a, t, out) rounds once, a stored a*t plus out rounds twice).
+template <typename T>
+NK_HD T nk_settle(T x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
+NK_HD float nk_fma(float x, float y, float z) { return __builtin_fmaf(x, y, z); }
+NK_HD double nk_fma(double x, double y, double z) { return __builtin_fma(x, y, z); }
+// a sample's own VJP contribution in the generic epilogues (fp64 arithmetic, rounded to T once): a t + s addend, the product
+// a t rounded before the fused multiply-add -- spelled out for the same reason as in nk_final_vjp_apply
+NK_HD double nk_vjp_own(double a, double t, double s, double addend) { return nk_fma(s, addend, nk_settle(a * t)); }
+template <typename T>
+NK_HD T nk_vjp_chain(const NkFuse& f, T g, T c1, T c2, T ov) {
+  T r = nk_settle(g);
+  if (f.carry1) r = c1 + r;
+  if (f.carry2) r = c2 + r;
+  if (f.accumulate) r = ov + r;
+  return r;
+}
+template <typename T>
+NK_HD T nk_carry_at(const void* carry, int64_t o) {
+  return carry ? ((const T*)carry)[o] : (T)0;
+}
+
 template <typename T>
 NK_HD void nk_epilogue(const NkFuse& f, int64_t o, T v, double& acc) {
   T* out = (T*)f.out;
@@ -636,10 +667,9 @@ NK_HD void nk_epilogue(const NkFuse& f, int64_t o, T v, double& acc) {
     case NK_EPI_VJP: {
       const double t = (double)v * f.scale;
       const int32_t p = f.pidx[o];
-      double r = (f.afield ? (double)((const T*)f.afield)[o] : f.amp[p]) * t;
-      if (f.addend) r += f.addend_scale * (double)((const T*)f.addend)[o];
-      if (f.accumulate) r += (double)out[o];
-      out[o] = (T)r;
+      const double r = nk_vjp_own(f.afield ? (double)((const T*)f.afield)[o] : f.amp[p], t, f.addend_scale,
+                                  f.addend ? (double)((const T*)f.addend)[o] : 0.0);
+      out[o] = nk_vjp_chain<T>(f, (T)r, nk_carry_at<T>(f.carry1, o), nk_carry_at<T>(f.carry2, o), f.accumulate ? out[o] : (T)0);
       NK_VJP_SCATTER_AT(f, o, p, (double)((const T*)f.xi)[o] * t);
     } break;
     case NK_EPI_LIKELIHOOD:
@@ -666,17 +696,12 @@ NK_HD void nk_epilogue_pair(const NkFuse& f, int64_t o1, T v1, int64_t o2, T v2,
     const double t1 = (double)v1 * f.scale, t2 = (double)v2 * f.scale;
     const int32_t p = f.pidx[o1];
     const double a = f.afield ? (double)((const T*)f.afield)[o1] : f.amp[p];
-    double r1 = a * t1, r2 = a * t2;
-    if (f.addend) {
-      r1 += f.addend_scale * (double)((const T*)f.addend)[o1];
-      r2 += f.addend_scale * (double)((const T*)f.addend)[o2];
-    }
-    if (f.accumulate) {
-      r1 += (double)out[o1];
-      r2 += (double)out[o2];
-    }
-    out[o1] = (T)r1;
-    out[o2] = (T)r2;
+    const double r1 = nk_vjp_own(a, t1, f.addend_scale, f.addend ? (double)((const T*)f.addend)[o1] : 0.0);
+    const double r2 = nk_vjp_own(a, t2, f.addend_scale, f.addend ? (double)((const T*)f.addend)[o2] : 0.0);
+    const T q1 = nk_vjp_chain<T>(f, (T)r1, nk_carry_at<T>(f.carry1, o1), nk_carry_at<T>(f.carry2, o1), f.accumulate ? out[o1] : (T)0);
+    const T q2 = nk_vjp_chain<T>(f, (T)r2, nk_carry_at<T>(f.carry1, o2), nk_carry_at<T>(f.carry2, o2), f.accumulate ? out[o2] : (T)0);
+    out[o1] = q1;
+    out[o2] = q2;
     const T* xi = (const T*)f.xi;
     NK_VJP_SCATTER_AT(f, o1, p, (double)xi[o1] * t1 + (double)xi[o2] * t2);
     if (f.wfull && o2 != o1) f.wfull[o2] = 0.0;
@@ -693,20 +718,22 @@ NK_HD double nk_vjp_quad(const NkFuse& f, const int64_t (&o)[4], const T (&v)[4]
   T* out = (T*)f.out;
   const T* xi = (const T*)f.xi;
   const T* addend = (const T*)f.addend;
-  T xv[4], av[4], ov[4];
+  T xv[4], av[4], ov[4], c1[4], c2[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const bool on = (mask >> i) & 1;
     xv[i] = on ? xi[o[i]] : (T)0;
     av[i] = (on && addend) ? addend[o[i]] : (T)0;
     ov[i] = (on && f.accumulate) ? out[o[i]] : (T)0;
+    c1[i] = on ? nk_carry_at<T>(f.carry1, o[i]) : (T)0;
+    c2[i] = on ? nk_carry_at<T>(f.carry2, o[i]) : (T)0;
   }
   double s = 0.0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (!((mask >> i) & 1)) continue;
     const double t = (double)v[i] * f.scale;
-    out[o[i]] = (T)(a * t + f.addend_scale * (double)av[i] + (double)ov[i]);
+    out[o[i]] = nk_vjp_chain<T>(f, (T)nk_vjp_own(a, t, f.addend_scale, (double)av[i]), c1[i], c2[i], ov[i]);
     s += (double)xv[i] * t;
   }
   return s;
@@ -722,13 +749,15 @@ NK_HD void nk_epilogue_multi(const NkFuse& f, const int64_t (&o)[8], const T (&v
     const T* afield = (const T*)f.afield;
     const int first = (mask & 15) ? 0 : 4;  // slot 0 of an active half is always valid
     // all loads first (nothing below may be reordered across the stores by the compiler: out may alias)
-    T xv[NOUT], av[NOUT], ov[NOUT];
+    T xv[NOUT], av[NOUT], ov[NOUT], c1[NOUT], c2[NOUT];
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
       const bool on = (mask >> i) & 1;
       xv[i] = on ? xi[o[i]] : (T)0;
       av[i] = (on && addend) ? addend[o[i]] : (T)0;
       ov[i] = (on && f.accumulate) ? out[o[i]] : (T)0;
+      c1[i] = on ? nk_carry_at<T>(f.carry1, o[i]) : (T)0;
+      c2[i] = on ? nk_carry_at<T>(f.carry2, o[i]) : (T)0;
     }
     int32_t p = 0;
     double a;
@@ -744,7 +773,7 @@ NK_HD void nk_epilogue_multi(const NkFuse& f, const int64_t (&o)[8], const T (&v
     for (int i = 0; i < NOUT; ++i) {
       if (!((mask >> i) & 1)) continue;
       const double t = (double)v[i] * f.scale;
-      out[o[i]] = (T)(a * t + f.addend_scale * (double)av[i] + (double)ov[i]);
+      out[o[i]] = nk_vjp_chain<T>(f, (T)nk_vjp_own(a, t, f.addend_scale, (double)av[i]), c1[i], c2[i], ov[i]);
       s += (double)xv[i] * t;
     }
     if (w8slot) {

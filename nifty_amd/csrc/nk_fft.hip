@@ -1367,9 +1367,12 @@ extern "C" int nk_hartley_sandwich_pair(const nk_plan* P, const nk_fuse* fa, con
   if (!vjp || P->hp.g.ndim != 3 || fa->pipe_chunks || fb->pipe_chunks || workspace_a == workspace_b)
     return nk_set_error(NK_ERR_UNSUPPORTED, "nk_hartley_sandwich_pair: two VJP epilogues with octant amplitude fields on a 3-D plan, "
                                              "two workspaces, no slab pipelining");
-  if (fa->out != fb->out || !fb->accumulate || fa->w8 == fb->w8 || (fa->mul_scalar != fb->mul_scalar))
-    return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich_pair: one shared `out` (B accumulates), separate w8 areas, the same "
-                                         "scalar diagonal");
+  // B joins A's fresh lines to its sum: as its running sum (one shared `out`) or as its innermost partial sum (carry1 = A's
+  // out, B's own `out` holding an older partial sum: the pairwise order over samples)
+  const bool joined = (fa->out == fb->out && fb->accumulate) || (fb->carry1 == fa->out && fb->out != fa->out);
+  if (!joined || fa->w8 == fb->w8 || (fa->mul_scalar != fb->mul_scalar))
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_sandwich_pair: B accumulates onto A's `out` or takes it as carry1; separate "
+                                         "w8 areas, the same scalar diagonal");
   hipStream_t st = (hipStream_t)stream;
   if (P->hp.dtype == NK_F32) return nk_run_sandwich_pair<float>(P, *fa, *fb, scale_first, convention, workspace_a, workspace_b, st);
   return nk_run_sandwich_pair<double>(P, *fa, *fb, scale_first, convention, workspace_a, workspace_b, st);

@@ -849,6 +849,7 @@ template <typename T>
 struct FinalCt {
   T* out;
   const T *mul, *xi, *addend, *af;
+  const T *c1, *c2;  // partial sums of other samples that join the running sum (nk_fuse.carry1 / carry2, nk_vjp_chain)
   T sc, off, asc;
   bool accum, dot;  // dot: also accumulate sum addend[o] * out[o] (the CG curvature d.(A d) when addend = d)
   bool keep;        // `out` is read again right away (first sample of a pair launch, k2_final2): plain stores, not streaming ones
@@ -861,6 +862,8 @@ NK_HD FinalCt<T> nk_final_ct(const NkFuse& f) {
   c.xi = (const T*)f.xi;
   c.addend = (const T*)f.addend;
   c.af = (const T*)f.afield;
+  c.c1 = (const T*)f.carry1;
+  c.c2 = (const T*)f.carry2;
   c.sc = (T)(f.scale * (EC == 1 ? f.mul_scalar : 1.0));
   c.off = (T)f.offset;
   c.asc = (T)f.addend_scale;
@@ -881,23 +884,28 @@ NK_HD FinalCt<T> nk_final_ct(const NkFuse& f) {
 // may alias the addend, so no load could move above a store -- and nothing is consumed inside a conditional block (the ISA
 // before the split: one or two loads, s_waitcnt vmcnt(0), branch, per image).  Loads of images that do not exist (self-
 // paired line: om == ok, the addresses are valid) are issued regardless and their values dropped.
-// MODE >= 0: bit 0 = there is an addend, bit 1 = `out` holds a running sum -- compile-time, and every slot of the group
+// MODE >= 0: bit 0 = there is an addend, bit 1 = `out` holds a running sum, bit 2 / 3 = carry1 / carry2 join the sum
+// (nk_vjp_chain) -- compile-time, and every slot of the group
 // active, so the load block has no branch at all (a load under a run-time condition merges with a constant zero, and the
 // compiler moves the first use of the merged value up into the load's block: s_waitcnt per slot again).
 // MODE < 0: the flags are read at run time and inactive slots skipped (edge groups, 2-D launches of the couple kernels).
 template <typename T>
 struct NkVjpOps {
-  T x[4], d[4], o[4];
+  T x[4], d[4], o[4], p[4], q[4];  // xi, addend, running sum, carry1, carry2
 };
 template <typename T, bool BOTH, int MODE>
 NK_HD NkVjpOps<T> nk_final_vjp_load(const FinalCt<T>& c, int64_t ok, int64_t om, int k2, int k2m) {
   NkVjpOps<T> v;
   const bool add = MODE < 0 ? c.addend != nullptr : (MODE & 1) != 0;
   const bool run = MODE < 0 ? c.accum : (MODE & 2) != 0;
+  const bool k1 = MODE < 0 ? c.c1 != nullptr : (MODE & 4) != 0;
+  const bool k2nd = MODE < 0 ? c.c2 != nullptr : (MODE & 8) != 0;
   const int64_t at[4] = {ok + k2, om + k2m, ok + k2m, om + k2};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const bool on = BOTH || i < 2;
+    v.p[i] = (on && k1) ? c.c1[at[i]] : (T)0;
+    v.q[i] = (on && k2nd) ? c.c2[at[i]] : (T)0;
     if constexpr ((NK_NT_LOAD & 8) != 0) {
       v.x[i] = on ? nk_ld_stream(c.xi + at[i]) : (T)0;
       v.d[i] = (on && add) ? nk_ld_stream(c.addend + at[i]) : (T)0;
@@ -911,16 +919,23 @@ NK_HD NkVjpOps<T> nk_final_vjp_load(const FinalCt<T>& c, int64_t ok, int64_t om,
   return v;
 }
 // returns the fp64 bin-sum contribution sum_images xi * t
-template <typename T, bool BOTH>
+template <typename T, bool BOTH, int MODE>
 NK_HD double nk_final_vjp_apply(const FinalCt<T>& c, const NkVjpOps<T>& v, int64_t ok, int64_t om, bool self, T v0, T v1,
                                 T v2, T v3, int k2, int k2m, T a, double& acc) {
   const T t[4] = {v0 * c.sc, v1 * c.sc, v2 * c.sc, v3 * c.sc};
+  const bool k1 = MODE < 0 ? c.c1 != nullptr : (MODE & 4) != 0;
+  const bool k2nd = MODE < 0 ? c.c2 != nullptr : (MODE & 8) != 0;
   T r[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    r[i] = a * t[i];
-    r[i] += c.asc * v.d[i];  // d, o are zero without an addend / a running sum: exact no-ops
-    r[i] += v.o[i];
+    // the sample's own contribution g = fma(asc, d, a t) with a t rounded -- spelled out, so that every instantiation of this
+    // epilogue (compile-time and run-time flags, single and pair launches) rounds alike; d is zero without an addend (an exact
+    // no-op).  Then the partial sums, innermost first (nk_vjp_chain)
+    r[i] = nk_settle(a * t[i]);
+    r[i] = nk_settle(nk_fma(c.asc, v.d[i], r[i]));
+    if (k1) r[i] = v.p[i] + r[i];
+    if (k2nd) r[i] = v.q[i] + r[i];
+    r[i] = v.o[i] + r[i];    // o is zero without a running sum
   }
   if (c.dot) {
     double e = (double)v.d[0] * (double)r[0];
@@ -1032,7 +1047,7 @@ NK_HD void nk_final_vjp_coeffs(const NkFuse& f, const FinalCt<T>& c, const Final
       if (MODE < 0 && !gp.mlo[h]) continue;
       const T fx = pre[gp.base[h] + d1], fy = pim[gp.base[h] + d1];
       const T gx = pre[gp.base[h] + d2], gy = pim[gp.base[h] + d2];
-      ssum += nk_final_vjp_apply<T, BOTH>(c, ops[u][h], gp.okh[h], gp.omh[h], gp.mlo[h] == 1, fx + sg * fy, fx - sg * fy,
+      ssum += nk_final_vjp_apply<T, BOTH, MODE>(c, ops[u][h], gp.okh[h], gp.omh[h], gp.mlo[h] == 1, fx + sg * fy, fx - sg * fy,
                                           gx + sg * gy, gx - sg * gy, k2, k2m, a[u], acc);
     }
     if (w8line) {
@@ -1366,11 +1381,13 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
           bool full = true;
 #pragma unroll
           for (int h = 0; h < NH; ++h) full = full && gp.mlo[h] != 0;
-          switch (full ? (c.addend ? 1 : 0) | (c.accum ? 2 : 0) : -1) {
+          switch (full ? (c.addend ? 1 : 0) | (c.accum ? 2 : 0) | (c.c1 ? 4 : 0) | (c.c2 ? 8 : 0) : -1) {
             case 0: coefficients(std::integral_constant<int, 0>{}); break;
             case 1: coefficients(std::integral_constant<int, 1>{}); break;
             case 2: coefficients(std::integral_constant<int, 2>{}); break;
             case 3: coefficients(std::integral_constant<int, 3>{}); break;
+            case 6: coefficients(std::integral_constant<int, 6>{}); break;    // the sample that closes a subtree of four
+            case 14: coefficients(std::integral_constant<int, 14>{}); break;  // ... of eight (pairwise sum over samples)
             default: coefficients(std::integral_constant<int, -1>{}); break;
           }
         } else if constexpr (nk_ec_lh<EC>()) {  // see nk_epi_likelihood4

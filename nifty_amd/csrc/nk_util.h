@@ -29,12 +29,30 @@ static inline bool nk_first_on_device(unsigned long long& mask) {
 // and leave the ticket at zero; launches on different streams / from different host threads use different scratch, so
 // the C ABI may be driven from several streams at once.
 constexpr int NK_RED_MAX = 4;          // reductions per launch
-constexpr int NK_RED_MAX_BLOCKS = 2048;  // workgroups per launch
+constexpr int NK_RED_MAX_BLOCKS = 16384;  // workgroups per launch (NK_RED_UNITS units x up to 256 workgroups each)
+constexpr int NK_RED_UNITS = 64;          // a long array is reduced as 64 equal contiguous UNITS (see NkRedLayout)
 struct NkRedScratch {
   double* partial;       // [NK_RED_MAX][NK_RED_MAX_BLOCKS]
   unsigned int* ticket;  // zero between launches
 };
 int nk_red_scratch(hipStream_t st, NkRedScratch* out);
+
+// How a reduction launch groups its partial sums.  An array of n elements whose length qualifies (nk_red_unit_elems) is
+// cut into NK_RED_UNITS contiguous units; every unit is reduced by its own sub-grid -- a function of the unit's length
+// only -- and the unit sums are added in unit order.  A SHARD of such an array that consists of whole units (the CG
+// vectors of a multi-rank KL minimisation) therefore yields, unit by unit, the very bits a single process computes for
+// the full array: the ranks exchange the unit sums (every unit lives on exactly one rank, the others hold a zero, so any
+// all-reduce is exact) and add them in the same order (nk_red_finish).  Rank-count-independent dot products
+// (reference utilities.py:349-414 for the sums over samples; this is the counterpart for the sharded vectors).
+struct NkRedLayout {
+  int k_local;         // units in this launch (1: the whole array is one unit)
+  int64_t unit_elems;  // elements per unit (k_local > 1)
+  int k_global;        // units of the full array
+  int seg_units;       // the shard is made of segments of seg_units units ...
+  int seg_stride;      // ... that start every seg_stride units of the full array ...
+  int seg_off;         // ... at unit seg_off of each stride
+  double* units_out;   // [NRED][k_global] unit sums (zeros for units of other ranks) INSTEAD of the result; or nullptr
+};
 
 // Live profiling for bench.py (nk_profile_enable / nk_profile_collect): a scope brackets ONE kernel launch with HIP events
 // on its launch stream.  key = kernel * 25 + pro * 5 + epi:

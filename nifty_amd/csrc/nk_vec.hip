@@ -46,6 +46,27 @@ static inline int nk_grid_red(int64_t nvec) {
   return (int)b;
 }
 
+// ---- grouping of the reductions (NkRedLayout, nk_util.h) -------------------------------------------------------------
+// unit length of an array of n elements, vector width v: n / NK_RED_UNITS when every unit is a whole number of 256-vector
+// rows and long enough to be worth its own sub-grid, else 0 (the array is ONE unit).  NK_RED_UNITS_OFF=1: always 0.
+static inline int64_t nk_red_unit_of(int64_t n, int v) {
+  static const int off = nk_vec_env_int("NK_RED_UNITS_OFF", 0);
+  const int64_t row = (int64_t)v * NK_VEC_THREADS;
+  if (off || n <= 0 || n % (NK_RED_UNITS * row) != 0 || n / (NK_RED_UNITS * row) < 2) return 0;
+  return n / NK_RED_UNITS;
+}
+namespace {
+thread_local NkRedLayout t_red_layout = {0, 0, 0, 0, 0, 0, nullptr};  // k_local == 0: none set (nk_red_layout)
+}
+static inline NkRedLayout nk_red_layout_for(int64_t n, int v) {
+  const NkRedLayout& set = t_red_layout;
+  if (set.k_local > 0 && set.unit_elems > 0 && n == set.k_local * set.unit_elems && set.unit_elems % ((int64_t)v * NK_VEC_THREADS) == 0)
+    return set;  // a shard of whole units, as announced by the caller
+  const int64_t unit = nk_red_unit_of(n, v);
+  if (unit == 0) return NkRedLayout{1, 0, 1, 1, 1, 0, nullptr};
+  return NkRedLayout{NK_RED_UNITS, unit, NK_RED_UNITS, NK_RED_UNITS, NK_RED_UNITS, 0, nullptr};
+}
+
 template <typename T>
 struct VecOf;
 template <>
@@ -97,43 +118,53 @@ static_assert(NK_RED_MAX_BLOCKS >= NK_MAX_BLOCKS, "reduction scratch must cover 
 // ---- generic "map with up to 4 inputs, 3 outputs and 3 reductions" skeleton ---------------------------
 // F::apply(const T* in[..] values, T* outs, double* red) is called per element.
 template <typename T, typename F, bool VEC>
-__global__ void __launch_bounds__(NK_VEC_THREADS) k_map(int64_t n, F f, int cu_max, NkRedScratch rs) {
+__global__ void __launch_bounds__(NK_VEC_THREADS) k_map(int64_t n, F f, int cu_max, NkRedScratch rs, NkRedLayout lay) {
   static_assert(F::NRED <= NK_RED_MAX, "too many reductions for the scratch of nk_red_scratch");
   constexpr int V = VEC ? VecOf<T>::N : 1;
   double red[F::NRED > 0 ? F::NRED : 1];
 #pragma unroll
   for (int r = 0; r < (F::NRED > 0 ? F::NRED : 1); ++r) red[r] = 0.0;
   const int64_t nvec = n / V;
+  // the launch is a row of lay.k_local UNITS (NkRedLayout; one unit = the whole array for maps without reductions and
+  // for short or odd lengths), every unit with gridDim.x / k_local workgroups of its own
+  const int G = (int)gridDim.x / lay.k_local;
+  const int unit = (int)blockIdx.x / G, ub = (int)blockIdx.x - unit * G;
+  const int64_t uvec = lay.unit_elems > 0 ? lay.unit_elems / V : nvec;
+  const int64_t u0 = (int64_t)unit * uvec, u1 = u0 + uvec;
   // block-cyclic over CONTIGUOUS chunks of NK_VEC_CHUNK vectors (64 KiB per stream): a workgroup that walks 64 KiB in
   // a row keeps its DRAM pages open -- a plain 1R+1W copy runs at 5.3 TB/s this way against 4.7-4.85 TB/s grid-stride
   // (tools/micro/copy_bench.hip, 4 GiB arrays)
-  // (small arrays: shorter chunks so that every workgroup of the grid has work; grid and chunk depend on n only)
-  int64_t cu = nvec / ((int64_t)gridDim.x * NK_VEC_THREADS);
+  // (small arrays: shorter chunks so that every workgroup of the grid has work; grid and chunk depend on the unit only)
+  int64_t cu = uvec / ((int64_t)G * NK_VEC_THREADS);
   cu = cu < 1 ? 1 : cu > cu_max ? cu_max : cu;
   const int64_t chunk = cu * NK_VEC_THREADS;
-  const int64_t nchunk = (nvec + chunk - 1) / chunk;
-  for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
-    const int64_t lo = c * chunk + threadIdx.x;
-    if (cu == NK_VEC_CHUNK / NK_VEC_THREADS && lo + (NK_VEC_CHUNK - NK_VEC_THREADS) < nvec) {  // the common, unrolled case
+  const int64_t nchunk = (uvec + chunk - 1) / chunk;
+  for (int64_t c = ub; c < nchunk; c += G) {
+    const int64_t lo = u0 + c * chunk + threadIdx.x;
+    if (cu == NK_VEC_CHUNK / NK_VEC_THREADS && lo + (NK_VEC_CHUNK - NK_VEC_THREADS) < u1) {  // the common, unrolled case
 #pragma unroll 4
       for (int u = 0; u < NK_VEC_CHUNK / NK_VEC_THREADS; ++u) f.template run<V>((lo + u * NK_VEC_THREADS) * V, red);
     } else {
-      const int64_t hi = (c + 1) * chunk < nvec ? (c + 1) * chunk : nvec;
+      const int64_t hi = u0 + (c + 1) * chunk < u1 ? u0 + (c + 1) * chunk : u1;
       for (int64_t i = lo; i < hi; i += NK_VEC_THREADS) f.template run<V>(i * V, red);
     }
   }
-  if (VEC) {  // scalar tail
+  if (VEC) {  // scalar tail (one-unit launches only: units are whole vectors)
     const int64_t tail0 = nvec * V;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < n - tail0) f.template run<1>(tail0 + gid, red);
   }
   if constexpr (F::NRED > 0) {
     // DETERMINISTIC reduction: every workgroup stores its partial sums; the workgroup that takes the last ticket adds
-    // them up in block order with a fixed tree and updates result[].  Identical inputs therefore give identical
-    // bits on every launch and on every GPU of a node (the grid is a function of n only) -- the replicated CG /
-    // line-search scalars of a multi-rank KL minimisation agree without any exchange.  The scratch belongs to the
-    // (device, stream) pair of the launch; launches on one stream are serialised, and every launch leaves the ticket at zero.
+    // them up -- per unit over the unit's workgroups (a wavefront per unit: lanes stride the partials, then a shuffle
+    // tree), then the units in order -- and updates result[].  Identical inputs therefore give identical bits on every
+    // launch and on every GPU of a node (grid and grouping are functions of the length only), and a shard made of whole
+    // units gives the unit sums of the full array (NkRedLayout) -- the replicated CG / line-search scalars of a multi-rank
+    // KL minimisation agree without any exchange, and the sharded ones do not depend on the number of ranks.  The
+    // scratch belongs to the (device, stream) pair of the launch; launches on one stream are serialised, and every launch
+    // leaves the ticket at zero.
     __shared__ bool is_last;
+    __shared__ double usum[NK_RED_MAX][NK_RED_UNITS];
 #pragma unroll
     for (int r = 0; r < F::NRED; ++r) {
       const double s = nk_block_sum(red[r]);
@@ -146,13 +177,32 @@ __global__ void __launch_bounds__(NK_VEC_THREADS) k_map(int64_t n, F f, int cu_m
     __syncthreads();
     if (is_last) {
       __threadfence();
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      for (int u = wave; u < lay.k_local; u += NK_VEC_THREADS / 64) {
 #pragma unroll
-      for (int r = 0; r < F::NRED; ++r) {
-        double v = 0.0;
-        for (int b = threadIdx.x; b < (int)gridDim.x; b += NK_VEC_THREADS)
-          v += __builtin_nontemporal_load(&rs.partial[r * NK_RED_MAX_BLOCKS + b]);
-        const double s = nk_block_sum(v);
-        if (threadIdx.x == 0) f.result[r] += s;
+        for (int r = 0; r < F::NRED; ++r) {
+          double v = 0.0;
+          for (int b = lane; b < G; b += 64) v += __builtin_nontemporal_load(&rs.partial[r * NK_RED_MAX_BLOCKS + u * G + b]);
+          for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+          if (lane == 0) usum[r][u] = v;
+        }
+      }
+      __syncthreads();
+      if (lay.units_out) {
+        for (int g = threadIdx.x; g < lay.k_global; g += NK_VEC_THREADS) {
+          const int seg = g / lay.seg_stride, w = g - seg * lay.seg_stride - lay.seg_off;
+          const int lu = seg * lay.seg_units + w;
+          const bool mine = w >= 0 && w < lay.seg_units && lu < lay.k_local;
+#pragma unroll
+          for (int r = 0; r < F::NRED; ++r) lay.units_out[r * lay.k_global + g] = mine ? usum[r][lu] : 0.0;
+        }
+      } else if (threadIdx.x == 0) {
+#pragma unroll
+        for (int r = 0; r < F::NRED; ++r) {
+          double s = 0.0;
+          for (int u = 0; u < lay.k_local; ++u) s += usum[r][u];
+          f.result[r] += s;
+        }
       }
       if (threadIdx.x == 0) *rs.ticket = 0;
     }
@@ -197,9 +247,11 @@ static int nk_launch_map(int64_t n, const F& f, bool aligned, hipStream_t st, co
   static const int cu_env = nk_vec_env_int("NK_VEC_CU", 0);  // developer sweep: chunk length in units of 256 vectors
   const int cu_max = cu_env > 0 ? cu_env : NkChunkUnits<F>::value;
   NkRedScratch rs{nullptr, nullptr};
+  NkRedLayout lay{1, 0, 1, 1, 1, 0, nullptr};
   if (F::NRED > 0) {
     const int rc = nk_red_scratch(st, &rs);
     if (rc != NK_OK) return rc;
+    if (aligned) lay = nk_red_layout_for(n, VecOf<T>::N);
   }
   // kernels with reductions pay a fixed tail per workgroup (block sums, fence, ticket, ~2 us each, a few rounds of them
   // per CU): below ~10^8 elements that tail, not the streaming part, sets the time.  Their grid therefore gives every
@@ -216,11 +268,15 @@ static int nk_launch_map(int64_t n, const F& f, bool aligned, hipStream_t st, co
         return nk_check_launch(what);
       }
     }
-    const int grid = F::NRED > 0 ? nk_grid_red(nvec) : nk_grid(nvec > 0 ? nvec : 1);
-    hipLaunchKernelGGL((k_map<T, F, true>), dim3(grid), dim3(NK_VEC_THREADS), 0, st, n, f, cu_max, rs);
+    int grid = F::NRED > 0 ? nk_grid_red(nvec) : nk_grid(nvec > 0 ? nvec : 1);
+    if (lay.unit_elems > 0) {  // (a unit has the same sub-grid whether the launch holds one unit or all of them)
+      static const int unit_grid = std::min(std::max(nk_vec_env_int("NK_RED_UNIT_GRID", 64), 1), NK_RED_MAX_BLOCKS / NK_RED_UNITS);
+      grid = lay.k_local * std::min(nk_grid_red(lay.unit_elems / VecOf<T>::N), unit_grid);
+    }
+    hipLaunchKernelGGL((k_map<T, F, true>), dim3(grid), dim3(NK_VEC_THREADS), 0, st, n, f, cu_max, rs, lay);
   } else {
     const int grid = F::NRED > 0 ? nk_grid_red(n) : nk_grid(n);
-    hipLaunchKernelGGL((k_map<T, F, false>), dim3(grid), dim3(NK_VEC_THREADS), 0, st, n, f, cu_max, rs);
+    hipLaunchKernelGGL((k_map<T, F, false>), dim3(grid), dim3(NK_VEC_THREADS), 0, st, n, f, cu_max, rs, lay);
   }
   return nk_check_launch(what);
 }
@@ -551,6 +607,40 @@ static int nk_zero(double* p, int count, hipStream_t st) {
   hipError_t e = hipMemsetAsync(p, 0, sizeof(double) * count, st);
   if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync");
   return NK_OK;
+}
+
+// ---- shards of unit-reduced arrays (NkRedLayout) ------------------------------------------------------------------------
+extern "C" int64_t nk_red_unit(int64_t n, int dtype) {
+  return dtype == NK_F32 ? nk_red_unit_of(n, VecOf<float>::N) : dtype == NK_F64 ? nk_red_unit_of(n, VecOf<double>::N) : 0;
+}
+
+extern "C" int nk_red_layout(int64_t unit_elems, int k_local, int k_global, int seg_units, int seg_stride, int seg_off,
+                             double* units_out) {
+  if (unit_elems == 0) {
+    t_red_layout = NkRedLayout{0, 0, 0, 0, 0, 0, nullptr};
+    return NK_OK;
+  }
+  if (unit_elems < 0 || k_local < 1 || k_local > NK_RED_UNITS || k_global < k_local || k_global > NK_RED_UNITS || seg_units < 1 ||
+      seg_stride < seg_units || seg_off < 0 || seg_off + seg_units > seg_stride || k_local % seg_units != 0 ||
+      (k_local / seg_units) * seg_stride > k_global)
+    return nk_set_error(NK_ERR_INVALID, "nk_red_layout: bad unit layout");
+  t_red_layout = NkRedLayout{k_local, unit_elems, k_global, seg_units, seg_stride, seg_off, units_out};
+  return NK_OK;
+}
+
+__global__ void k_red_finish(const double* units, int k, int nred, double* result, int accumulate) {
+  const int r = threadIdx.x;
+  if (r >= nred) return;
+  double s = 0.0;
+  for (int u = 0; u < k; ++u) s += units[r * k + u];
+  result[r] = accumulate ? result[r] + s : s;
+}
+
+extern "C" int nk_red_finish(const double* units, int k_global, int nred, double* result, int accumulate, void* stream) {
+  if (!units || !result || k_global < 1 || nred < 1 || nred > NK_RED_MAX)
+    return nk_set_error(NK_ERR_INVALID, "nk_red_finish: bad argument");
+  hipLaunchKernelGGL(k_red_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, units, k_global, nred, result, accumulate);
+  return nk_check_launch("nk_red_finish");
 }
 
 extern "C" int nk_vdot(int64_t n, const void* a, const void* b, int dtype, double* result, int accumulate,

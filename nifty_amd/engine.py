@@ -135,12 +135,20 @@ class CgWorkspace:
 
 class ShardedCgWorkspace(CgWorkspace):
     """CG scalars when every rank holds 1/size of xi (and a replicated copy of the small part): the xi partial sums
-    are all-reduced (one 8..24-byte collective per reduction), then the replicated small part is added on every rank."""
+    are all-reduced (one small collective per reduction), then the replicated small part is added on every rank.
 
-    def __init__(self, device, comm):
+    `units` = (unit length, units of this rank, units of the full vector, units per segment, segment stride, segment
+    offset) when the share consists of whole reduction UNITS of the full vector (include/niftyk.h, nk_red_layout): the
+    kernels then deliver the unit sums of this rank, the ranks exchange them (every unit is non-zero on exactly one rank:
+    the all-reduce is exact) and add them in unit order -- the bits of the single-process reduction of the whole vector,
+    whatever the number of ranks.  Without it the per-rank totals are all-reduced (rank-count dependent rounding)."""
+
+    def __init__(self, device, comm, units=None):
         super().__init__(device)
         self.comm = comm
         self._broadcast = parallel._lockstep_mode() == "broadcast"
+        self._units = units
+        self._unit_sums = None if units is None else torch.zeros(4 * units[2], dtype=torch.float64, device=device)
 
     def _agree(self, t):
         """The replicated part of a reduction is computed per rank by fixed-order kernels on identical data: identical bits.
@@ -149,10 +157,28 @@ class ShardedCgWorkspace(CgWorkspace):
         if self._broadcast:
             self.comm.bcast_(t)
 
+    def _over_ranks(self, slot, count, launch):
+        """`launch()` reduces the xi share into scal[slot : slot + count]; afterwards those scalars hold the sums over the
+        full vector on every rank."""
+        res = self.scal[slot:slot + count]
+        if self._units is None:
+            launch()
+            self.comm.allreduce_sum_([res])
+            return res
+        lib, k = L.load(), self._units[2]
+        L.check(lib.nk_red_layout(*self._units, self._unit_sums.data_ptr()), "nk_red_layout")
+        try:
+            launch()
+        finally:
+            lib.nk_red_layout(0, 0, 0, 0, 0, 0, 0)
+        sums = self._unit_sums[:count * k]
+        self.comm.allreduce_sum_([sums])
+        L.check(lib.nk_red_finish(sums.data_ptr(), k, count, res.data_ptr(), 0, B._stream()), "nk_red_finish")
+        return res
+
     def dot(self, u, v, slot):
-        res = self.scal[slot:slot + 1]
-        B.vdot(u.xi.reshape(-1), v.xi.reshape(-1), result=res, accumulate=False)
-        self.comm.allreduce_sum_([res])
+        res = self._over_ranks(slot, 1, lambda: B.vdot(u.xi.reshape(-1), v.xi.reshape(-1), result=self.scal[slot:slot + 1],
+                                                       accumulate=False))
         B.vdot(u.small, v.small, result=res, accumulate=True)
         self._agree(res)  # the replicated small part is reduced per rank
         return res
@@ -160,27 +186,35 @@ class ShardedCgWorkspace(CgWorkspace):
     def curv(self, d, q):
         lib, st = L.load(), B._stream()
         (dx, qx), (ds, qs) = self._segments(d, q)
-        L.check(lib.nk_cg_curv(dx.numel(), dx.data_ptr(), qx.data_ptr(), B.dtype_code(dx), self.scal.data_ptr(), 0, st))
-        self.comm.allreduce_sum_([self.scal[1:2]])
+        self._over_ranks(1, 1, lambda: L.check(lib.nk_cg_curv(dx.numel(), dx.data_ptr(), qx.data_ptr(), B.dtype_code(dx),
+                                                              self.scal.data_ptr(), 0, st)))
         L.check(lib.nk_cg_curv(ds.numel(), ds.data_ptr(), qs.data_ptr(), B.dtype_code(ds), self.scal.data_ptr(), 1, st))
         self._agree(self.scal[1:2])
 
     def update(self, x, r, d, q, b):
         lib, st = L.load(), B._stream()
-        for i, (xx, rr, dd, qq, bb) in enumerate(self._segments(x, r, d, q, b)):
+        xi, small = ([t for t in seg] for seg in self._segments(x, r, d, q, b))
+
+        def run(seg, accumulate):
+            xx, rr, dd, qq, bb = seg
             L.check(lib.nk_cg_update(xx.numel(), xx.data_ptr(), rr.data_ptr(), dd.data_ptr(), qq.data_ptr(), B.ptr(bb),
-                                     B.dtype_code(xx), self.scal.data_ptr(), i, st))
-            if i == 0:
-                self.comm.allreduce_sum_([self.scal[2:5]])
+                                     B.dtype_code(xx), self.scal.data_ptr(), accumulate, st))
+
+        self._over_ranks(2, 3, lambda: run(xi, 0))
+        run(small, 1)
         self._agree(self.scal[2:5])
 
     def update_dr(self, x, r, d, q):
         lib, st = L.load(), B._stream()
-        for i, (xx, rr, dd, qq) in enumerate(self._segments(x, r, d, q)):
+        xi, small = ([t for t in seg] for seg in self._segments(x, r, d, q))
+
+        def run(seg, accumulate):
+            xx, rr, dd, qq = seg
             L.check(lib.nk_cg_update_dr(xx.numel(), xx.data_ptr(), rr.data_ptr(), dd.data_ptr(), qq.data_ptr(),
-                                        B.dtype_code(xx), self.scal.data_ptr(), i, st))
-            if i == 0:
-                self.comm.allreduce_sum_([self.scal[2:4]])
+                                        B.dtype_code(xx), self.scal.data_ptr(), accumulate, st))
+
+        self._over_ranks(2, 2, lambda: run(xi, 0))
+        run(small, 1)
         self._agree(self.scal[2:4])
 
     def refresh(self, x, r, b):
@@ -275,6 +309,69 @@ class LatentVec:
 # ------------------------------------------------------------------------------------------------
 # the fused model
 # ------------------------------------------------------------------------------------------------
+class _Dest:
+    """Where the xi part of ONE sample's contribution to a sum over samples goes (FusedModel._vjp): `xi` is stored into, or
+    -- `accumulate` -- holds a partial sum the contribution joins; `carries` are further partial sums that join on the way,
+    innermost first (nk_fuse.carry1 / carry2).  `small`: list that receives the sample's small part (summed by the caller),
+    or None = the old running sum in the output vector.  `after`: (target, source) additions still to be done explicitly."""
+
+    __slots__ = ("xi", "accumulate", "carries", "small", "after", "fresh")
+
+    def __init__(self, xi, accumulate=False, carries=(), small=None, after=(), fresh=False):
+        self.xi, self.accumulate, self.carries, self.small, self.after, self.fresh = xi, accumulate, carries, small, after, fresh
+
+
+class _PairTree:
+    """Bookkeeping of a sum over this rank's samples in the order of parallel.pair_tree (utilities.py:349-414) WITHOUT
+    keeping the terms: a binary counter of partial sums.  Sample i joins the partial sums that end at i -- one per
+    trailing one-bit of i, the last sample all that are left -- innermost first, inside its own VJP epilogue (`_Dest`:
+    up to MAX_CARRIES partial sums ride along as carries, deeper ones are added explicitly afterwards).  Eight samples
+    need the output and two scratch vectors, and move the bytes of the plain running sum: the even samples store instead
+    of read-modify-write, samples 3 and 7 read one / two partial sums more."""
+
+    MAX_CARRIES = 2
+
+    def __init__(self, out, scratch):
+        self._stack = []        # (number of samples, tensor): sizes decrease towards the top
+        self._first = out       # the first fresh vector is the output: the deepest partial sum ends up there
+        self._pool = scratch    # callable -> a scratch vector shaped like `out`
+        self._free = []
+
+    def place(self, last, small=None):
+        size, joined = 1, []
+        while self._stack and (last or self._stack[-1][0] == size):
+            n, t = self._stack.pop()
+            joined.append(t)
+            size += n
+        if not joined:
+            t = self._first if self._first is not None else (self._free.pop() if self._free else self._pool())
+            self._first = None
+            self._stack.append((1, t))
+            return _Dest(t, small=small, fresh=True)
+        ride = joined[:self.MAX_CARRIES] if len(joined) > 1 else []
+        target = joined[len(ride)] if len(joined) > len(ride) else None
+        if target is None:  # (exactly MAX_CARRIES partial sums: the deepest one is the running sum)
+            target, ride = ride[-1], ride[:-1]
+        rest = joined[len(ride) + 1:]
+        after, inner = [], target
+        for t in rest:  # deeper partial sums than the epilogue can take: t <- t + inner, explicitly
+            after.append((t, inner))
+            inner = t
+        self._free += ride + ([target] + rest[:-1] if rest else [])
+        self._stack.append((size, inner))
+        return _Dest(target, accumulate=True, carries=tuple(ride), small=small, after=tuple(after))
+
+    @staticmethod
+    def settle(dest):
+        for target, source in dest.after:
+            B.axpby(1.0, target, 1.0, source, out=target)
+
+    def total(self):
+        if len(self._stack) != 1:
+            raise RuntimeError("_PairTree.total: the last sample has not been placed")
+        return self._stack[0][1]
+
+
 class LinPoint:
     """Everything cached about one latent point: amplitude tables and the s-space metric weight."""
 
@@ -511,8 +608,9 @@ class FusedModel:
         self.counters["transforms"] += 1
         return (out, d) if want_derivative else out
 
-    def _vjp(self, lp, w, scale, addend, addend_scale, accumulate, out_xi, dot_out=None, w2=None, sandwich=None):
+    def _vjp(self, lp, w, scale, addend, addend_scale, accumulate, out_xi, dot_out=None, w2=None, sandwich=None, carries=()):
         """out_xi (+)= a t + addend_scale*addend,  self.abar += scatter(xi t),  t = scale * HT(w) (HT(w * w2) with w2);
+        carries: up to two partial sums of other samples that join out_xi innermost first (nk_fuse.carry1 / carry2);
         dot_out (device fp64 scalar, needs addend): += sum addend * out_xi, taken in the same epilogue.
         sandwich = (fill_prologue, scale_first, mid, mid_scalar): t = scale * HT(mid_scalar * mid . scale_first *
         HT(prologue)) through nk_hartley_sandwich instead (w is ignored)."""
@@ -539,6 +637,9 @@ class FusedModel:
         f.pidx, f.amp, f.xi = self.pidx.data_ptr(), lp.amp.data_ptr(), lp.x.xi.data_ptr()
         f.afield = B.ptr(lp.afield)
         f.addend, f.addend_scale, f.accumulate = B.ptr(addend), addend_scale, 1 if accumulate else 0
+        if len(carries) > 2:
+            raise ValueError("the VJP epilogue takes at most two carried partial sums")
+        f.carry1, f.carry2 = (B.ptr(c) for c in (tuple(carries) + (None, None))[:2])
         if self.octant_vjp:
             # the final pass stores one merged sum per octant point; nk_octant_scatter reduces them into the bins
             f.abar, f.w8 = self.abar.data_ptr(), self.w8.data_ptr()
@@ -580,10 +681,12 @@ class FusedModel:
                                     lp.state.data_ptr(), self.abar.data_ptr(), self.latbar.data_ptr(), B._stream()),
                 "nk_amp_vjp")
 
-    def linearize(self, x, grad_acc=None, n_total=1, value_acc=None):
+    def linearize(self, x, grad_acc=None, n_total=1, value_acc=None, dest=None):
         """Value and gradient of H = lh + 1/2|x|^2 at x, cached for metric applications.
 
-        With ``grad_acc``/``value_acc`` the sample average is accumulated in place (1/n_total weights).
+        With ``grad_acc``/``value_acc`` the sample average is accumulated in place (1/n_total weights); with ``dest`` (a
+        `_Dest` with a `small` list) the xi part of the weighted gradient goes where the pairwise sum over samples wants
+        it and the small part is appended to the list (FusedKL).
         """
         lp = LinPoint()
         lp.x = x
@@ -593,7 +696,7 @@ class FusedModel:
         value = torch.zeros(1, dtype=torch.float64, device=self.device) if value_acc is None else value_acc
         lhval = torch.zeros(1, dtype=torch.float64, device=self.device)
         if self.response is not None:
-            return self._linearize_response(lp, x, grad_acc, w, value, lhval)
+            return self._linearize_response(lp, x, grad_acc if dest is None else dest, w, value, lhval)
         f = self._fuse()
         f.pro, f.in_, f.pidx, f.amp = L.PRO_AMP, x.xi.data_ptr(), self.pidx.data_ptr(), lp.amp.data_ptr()
         f.afield = lp.afield.data_ptr()
@@ -613,7 +716,7 @@ class FusedModel:
         else:
             B.hartley_fused(self.plan, f)
         self.counters["transforms"] += 1
-        return self._finish_linearize(lp, x, gs, None, grad_acc, w, value, lhval)
+        return self._finish_linearize(lp, x, gs, None, grad_acc if dest is None else dest, w, value, lhval)
 
     # -- lanes: independent scratch sets, so that the chains of several samples run on several streams at once ----------
     _SCRATCH = ("scatter_scratch", "abar_priv", "abar", "damp", "latbar", "tmp", "dafield", "w8", "w8max", "wfull", "k2_dense")
@@ -655,18 +758,25 @@ class FusedModel:
         return self._wide_state
 
     def _finish_linearize(self, lp, x, gs, gs2, grad_acc, w, value, lhval):
-        """Gradient J^T (gs * gs2) + x and the value lh + 1/2 x.x, accumulated with weight w."""
+        """Gradient J^T (gs * gs2) + x and the value lh + 1/2 x.x, accumulated with weight w (grad_acc: a LatentVec that
+        holds the running sum, None, or a `_Dest` of a pairwise sum over samples)."""
         # gradient: J^T gs + x
-        first = grad_acc is None
-        grad = LatentVec(torch.empty_like(x.xi), None) if first else grad_acc
-        self._vjp(lp, gs, w, x.xi, w, not first, grad.xi, w2=gs2)
-        self._amp_vjp(lp)
-        # (abar, hence latbar, already carries the 1/n_total weight)
-        if first:
-            grad.small = B.axpby(1.0, self.latbar, w, x.small)
+        if isinstance(grad_acc, _Dest):
+            dest, grad = grad_acc, None
+            self._vjp(lp, gs, w, x.xi, w, dest.accumulate, dest.xi, w2=gs2, carries=dest.carries)
+            _PairTree.settle(dest)
+            self._amp_vjp(lp)
+            dest.small.append(B.axpby(1.0, self.latbar, w, x.small))  # (abar, hence latbar, carries the 1/n_total weight)
         else:
-            B.axpby(1.0, self.latbar, 1.0, grad.small, out=grad.small)
-            B.axpby(w, x.small, 1.0, grad.small, out=grad.small)
+            first = grad_acc is None
+            grad = LatentVec(torch.empty_like(x.xi), None) if first else grad_acc
+            self._vjp(lp, gs, w, x.xi, w, not first, grad.xi, w2=gs2)
+            self._amp_vjp(lp)
+            if first:
+                grad.small = B.axpby(1.0, self.latbar, w, x.small)
+            else:
+                B.axpby(1.0, self.latbar, 1.0, grad.small, out=grad.small)
+                B.axpby(w, x.small, 1.0, grad.small, out=grad.small)
         # value: lh + 1/2 x.x
         prior = x.sqnorm if x.sqnorm is not None else x.dot_device(x)
         B.axpby(w, lhval, 1.0, value, out=value)
@@ -726,9 +836,10 @@ class FusedModel:
         return self.response.times(self.tmp)
 
     def lh_metric_accumulate(self, lp, d, out, scale, first, identity=0.0, dot_out=None, cg_direction=None, pipe=None,
-                             addend=None):
+                             addend=None, dest=None):
         """out (+)= scale * J^T M J d  (+ identity * d): the likelihood Fisher metric pulled back to latent space;
         the optional multiple of d (prior metric = 1) rides along in the VJP epilogue of the xi part.
+        dest (a `_Dest`, then `out` / `first` are ignored): where a pairwise sum over samples wants this contribution.
         pipe = (chunks, wait_events or None, record_events or None): slab pipelining of the sandwich against an exchange
         on another stream (nk_fuse.pipe_chunks; the arrays are ctypes arrays of hipEvent_t handles).
         addend = (vector, factor): out += factor * vector instead of the identity term (rides in the same epilogue).
@@ -739,10 +850,13 @@ class FusedModel:
         if addend is not None and identity:
             raise ValueError("either the identity term or an explicit addend")
         avec, afac = (d, identity) if addend is None else addend  # the vector the epilogue adds, and its factor
+        if dest is None:
+            dest = _Dest(out.xi, accumulate=not first)
+        where = dict(accumulate=dest.accumulate, out_xi=dest.xi, carries=dest.carries)
         if self.response is not None:
             wsig = self.response.adjoint(self._weigh_data(self._jvp_response(lp, d), lp), self.shape)
-            self._vjp(lp, wsig, scale, avec.xi if afac else None, afac, not first, out.xi, dot_out=dot_out, w2=lp.gp)
-            self._finish_metric(lp, avec, out, first, afac)
+            self._vjp(lp, wsig, scale, avec.xi if afac else None, afac, dot_out=dot_out, w2=lp.gp, **where)
+            self._finish_metric(lp, avec, out, first, afac, dest)
             return
         L.check(L.load().nk_amp_jvp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(),
                                     lp.state.data_ptr(), d.small.data_ptr(), self.damp.data_ptr(), B._stream()), "nk_amp_jvp")
@@ -774,8 +888,8 @@ class FusedModel:
             raise ValueError("slab pipelining needs the sandwich pipeline")
         if self.sandwich:
             # H D H in five passes: the position-space field between the transforms never exists (nk_fft3.h)
-            self._vjp(lp, None, scale, avec.xi if afac else None, afac, not first, out.xi, dot_out=dot_out,
-                      sandwich=(jvp_prologue, self.h_dvol, lp.mid, lp.mid_scalar))
+            self._vjp(lp, None, scale, avec.xi if afac else None, afac, dot_out=dot_out,
+                      sandwich=(jvp_prologue, self.h_dvol, lp.mid, lp.mid_scalar), **where)
             if cg_direction is not None:
                 cg_direction[1].roll()
         else:
@@ -783,9 +897,9 @@ class FusedModel:
             jvp_prologue(f)
             f.epi, f.out, f.mul, f.mul_scalar = L.EPI_MUL, self.tmp.data_ptr(), B.ptr(lp.mid), lp.mid_scalar
             B.hartley_fused(self.plan, f)
-            self._vjp(lp, self.tmp, scale, avec.xi if afac else None, afac, not first, out.xi, dot_out=dot_out)
+            self._vjp(lp, self.tmp, scale, avec.xi if afac else None, afac, dot_out=dot_out, **where)
             self.counters["transforms"] += 1
-        self._finish_metric(lp, avec, out, first, afac)
+        self._finish_metric(lp, avec, out, first, afac, dest)
 
     def pair_ready(self):
         """True when two samples' metric applications can share a final-pass launch (lh_metric_accumulate_pair)."""
@@ -800,18 +914,24 @@ class FusedModel:
                               workspace=torch.empty_like(self.plan.workspace))
         return self._pair
 
-    def lh_metric_accumulate_pair(self, lpa, lpb, d, out, scale, first, identity=0.0, dot_out=None, cg_direction=None):
+    def lh_metric_accumulate_pair(self, lpa, lpb, d, out, scale, first, identity=0.0, dot_out=None, cg_direction=None,
+                                  dests=None, identity_first=0.0):
         """lh_metric_accumulate(lpa, d, out, scale, first, cg_direction=...) followed by lh_metric_accumulate(lpb, d, out,
         scale, False, identity=..., dot_out=...) -- the same bits -- with the two final passes in one launch: sample B's
         accumulation onto `out` meets sample A's freshly written lines in the cache hierarchy (nk_hartley_sandwich_pair).
-        The pending CG direction update rides in A's first pass, the identity term and the curvature dot in B's epilogue."""
+        The pending CG direction update rides in A's first pass, the identity term and the curvature dot in B's epilogue.
+        dests = (`_Dest` of A, `_Dest` of B) of a pairwise sum over samples (then `out` / `first` are ignored): A stores a
+        fresh vector, B joins it to its partial sums; identity_first: the multiple of d that A adds (the prior term of the
+        pairwise sum sits on the first sample)."""
         if cg_direction is not None and not self.fused_direction:
             raise ValueError("cg_direction needs the sandwich pipeline (FusedModel.fused_direction)")
         pb = self._pair_buffers()
         lib = L.load()
         fuses = []
-        for lp, damp, dafield, w8, w8max, accumulate in ((lpa, self.damp, self.dafield, self.w8, self.w8max, not first),
-                                                        (lpb, pb["damp"], pb["dafield"], pb["w8"], pb["w8max"], True)):
+        if dests is None:
+            dests = (_Dest(out.xi, accumulate=not first), _Dest(out.xi, accumulate=True))
+        for lp, damp, dafield, w8, w8max, dest in ((lpa, self.damp, self.dafield, self.w8, self.w8max, dests[0]),
+                                                   (lpb, pb["damp"], pb["dafield"], pb["w8"], pb["w8max"], dests[1])):
             L.check(lib.nk_amp_jvp(self.nb, self.geo.data_ptr(), self.hyp.data_ptr(), lp.x.small.data_ptr(), lp.state.data_ptr(),
                                    d.small.data_ptr(), damp.data_ptr(), B._stream()), "nk_amp_jvp")
             self._amp_field(damp, out=dafield)
@@ -820,15 +940,18 @@ class FusedModel:
             f.pidx, f.amp, f.damp = self.pidx.data_ptr(), lp.amp.data_ptr(), damp.data_ptr()
             f.afield, f.dafield = B.ptr(lp.afield), dafield.data_ptr()
             f.mul, f.mul_scalar = B.ptr(lp.mid), lp.mid_scalar
-            f.epi, f.out, f.scale = L.EPI_VJP, out.xi.data_ptr(), self.h_dvol * scale
+            f.epi, f.out, f.scale = L.EPI_VJP, dest.xi.data_ptr(), self.h_dvol * scale
             f.xi = lp.x.xi.data_ptr()
-            f.addend, f.addend_scale, f.accumulate = None, 0.0, 1 if accumulate else 0
+            f.addend, f.addend_scale, f.accumulate = None, 0.0, 1 if dest.accumulate else 0
+            f.carry1, f.carry2 = (B.ptr(c) for c in (tuple(dest.carries) + (None, None))[:2])
             f.abar, f.w8 = self.abar.data_ptr(), w8.data_ptr()
             if self.scatter_fixed_point:
                 f.w8max = w8max.data_ptr()
             fuses.append(f)
         if cg_direction is not None:
             fuses[0].cg_r, fuses[0].cg_scal = cg_direction[0].xi.data_ptr(), cg_direction[1].scal.data_ptr()
+        if identity_first:
+            fuses[0].addend, fuses[0].addend_scale = d.xi.data_ptr(), identity_first
         if identity:
             fuses[1].addend, fuses[1].addend_scale = d.xi.data_ptr(), identity
             if dot_out is not None:
@@ -836,19 +959,27 @@ class FusedModel:
         elif dot_out is not None:
             raise ValueError("dot_out needs the identity term (the addend of the epilogue)")
         B.hartley_sandwich_pair(self.plan, fuses[0], fuses[1], self.h_dvol, pb["workspace"])
+        _PairTree.settle(dests[1])
         if cg_direction is not None:
             cg_direction[1].roll()
         self.counters["transforms"] += 4
         shp = (ctypes.c_int64 * len(self.shape))(*self.shape)
-        for lp, w8, w8max, is_first in ((lpa, self.w8, self.w8max, first), (lpb, pb["w8"], pb["w8max"], False)):
+        for lp, w8, w8max, is_first, dest, ident in ((lpa, self.w8, self.w8max, first, dests[0], identity_first),
+                                                     (lpb, pb["w8"], pb["w8max"], False, dests[1], identity)):
             L.check(lib.nk_octant_scatter_k2(len(self.shape), shp, w8.data_ptr(), self.pidx.data_ptr(), self.bin_k2.data_ptr(),
                                              self.nb, self.scatter_scratch.data_ptr(), self.abar.data_ptr(),
                                              w8max.data_ptr() if self.scatter_fixed_point else 0, B._stream()),
                     "nk_octant_scatter_k2")
-            self._finish_metric(lp, d, out, is_first, 0.0 if lp is lpa else identity)
+            self._finish_metric(lp, d, out, is_first, ident, dest)
 
-    def _finish_metric(self, lp, d, out, first, identity):
+    def _finish_metric(self, lp, d, out, first, identity, dest=None):
         self._amp_vjp(lp)
+        if dest is not None:
+            _PairTree.settle(dest)
+            if dest.small is not None:  # a pairwise sum over samples: the caller adds the small parts
+                dest.small.append(B.axpby(1.0, self.latbar, identity, d.small) if identity else B.axpby(1.0, self.latbar))
+                self.counters["metric"] += 1
+                return
         if first:
             out.small = B.axpby(1.0, self.latbar, identity, d.small) if identity else B.axpby(1.0, self.latbar)
         else:
@@ -1034,17 +1165,33 @@ class FusedKL(Energy):
     ``comm`` (nifty_amd.parallel.Comm or None) sums value/gradient/metric over ranks.
     """
 
-    def __init__(self, model, position, residuals, negs, n_total=None, comm=None, nanisinf=True):
+    def __init__(self, model, position, residuals, negs, n_total=None, comm=None, nanisinf=True, _shared=None):
         super().__init__(position)
         self.model, self.residuals, self.negs = model, residuals, negs
         self.n_total = len(residuals) if n_total is None else n_total
         self.comm, self.nanisinf = comm, nanisinf
         self.lins = []
         self._lanes = self._pick_lanes(len(residuals))
+        # sums over samples in the pairwise order of the reference (parallel.pair_tree): the same bits for 1, 2, 4, 8 ranks.
+        # Across ranks that takes one complete subtree per rank (equal power-of-two sample counts); any other split keeps
+        # the local tree and falls back to RCCL's all-reduce (rank-count dependent rounding), said once.
+        self._shared = _shared if _shared is not None else {}
+        self._tree = parallel.tree_sum_enabled()
+        self._across = False
+        if comm is not None and self._tree:
+            if "across" not in self._shared:
+                self._shared["across"] = comm.subtree_per_rank(comm.term_counts(len(residuals)))
+                if not self._shared["across"] and comm.rank == 0 and comm.size > 1:
+                    print("nifty_amd: the samples do not split into one power-of-two block per rank; sums over samples "
+                          "depend on the rank count in the last bits", flush=True)
+            self._across = self._shared["across"]
+        self._holds_first = comm is None or comm.rank == 0  # global sample 0 carries the prior term of a pairwise sum
         value = torch.zeros(1, dtype=torch.float64, device=model.device)
         grad = None
         if len(self._lanes) > 1:
             value, grad = self._linearize_on_lanes(position, value)
+        elif self._tree and len(residuals) > 0:
+            value, grad = self._linearize_pairwise(position)
         else:
             for r, neg in zip(residuals, negs):
                 x = position.shifted(-1.0 if neg else 1.0, r)  # p +- r and |p +- r|^2 in one pass
@@ -1054,12 +1201,44 @@ class FusedKL(Energy):
                 self.lins.append(lp)
         if grad is None:  # a rank without samples
             grad = LatentVec.zeros(model)
-        if comm is not None:
-            comm.allreduce_sum_([value, grad.xi, grad.small])
+        self._sum_over_ranks(grad, value)
         self._value = float(value.item())
         if math.isnan(self._value) and nanisinf:
             self._value = math.inf
         self._grad = grad
+
+    def _sum_over_ranks(self, vec, *scalars):
+        """In place: the sum over the ranks of a latent vector (and device scalars) -- the tree over the rank partials when
+        every rank holds one subtree of the pairwise sum (xi slice-wise: an all-to-all and an all-gather, the bytes of an
+        all-reduce), else RCCL's all-reduce."""
+        comm = self.comm
+        if comm is None:
+            return
+        if not self._across:
+            comm.allreduce_sum_(list(scalars) + [vec.xi, vec.small])
+            return
+        comm.tree_allreduce([list(scalars) + [vec.small]], [1] * comm.size)
+        if vec.xi.numel() % comm.size == 0:
+            comm.tree_allreduce_slices_(vec.xi)
+        else:
+            comm.tree_allreduce([[vec.xi]], [1] * comm.size)
+
+    def _scratch_vector(self):
+        return torch.empty(self.model.shape, dtype=self.model.tdtype, device=self.model.device)
+
+    def _linearize_pairwise(self, position):
+        """Value and gradient summed over the local samples in pair_tree order: the xi part inside the VJP epilogues
+        (`_PairTree`), values and small parts as lists."""
+        model, nloc = self.model, len(self.residuals)
+        tree = _PairTree(torch.empty_like(position.xi), self._scratch_vector)
+        values, smalls = [], []
+        for i, (r, neg) in enumerate(zip(self.residuals, self.negs)):
+            x = position.shifted(-1.0 if neg else 1.0, r)  # p +- r and |p +- r|^2 in one pass
+            values.append(torch.zeros(1, dtype=torch.float64, device=model.device))
+            lp = model.linearize(x, n_total=self.n_total, value_acc=values[-1], dest=tree.place(i == nloc - 1, smalls))
+            lp.grad = None
+            self.lins.append(lp)
+        return parallel.tree_fold(values), LatentVec(tree.total(), parallel.tree_fold(smalls))
 
     # -- small grids: the samples' kernel chains side by side on several streams (FusedModel.lanes) -------------------------
     def _pick_lanes(self, nloc):
@@ -1097,41 +1276,44 @@ class FusedKL(Energy):
                 t.record_stream(main)
 
     def _linearize_on_lanes(self, position, value):
-        K = len(self._lanes)
+        """Every sample's weighted gradient in a vector of its own (small grids: memory is no concern), summed afterwards in
+        pair_tree order on the caller's stream."""
+        n = len(self.residuals)
         xs = [position.shifted(-1.0 if neg else 1.0, r) for r, neg in zip(self.residuals, self.negs)]
-        values = [value] + [torch.zeros_like(value) for _ in range(K - 1)]
-        grads, lins = [None] * K, [None] * len(xs)
+        values = [torch.zeros_like(value) for _ in range(n)]
+        grads, lins = [None] * n, [None] * n
 
         def job(k, lane, i):
-            lp = lane.linearize(xs[i], grad_acc=grads[k], n_total=self.n_total, value_acc=values[k])
-            grads[k], lp.grad, lins[i] = lp.grad, None, lp
+            lp = lane.linearize(xs[i], n_total=self.n_total, value_acc=values[i])
+            grads[i], lp.grad, lins[i] = lp.grad, None, lp
 
         main = self._on_lanes(job)
         self.lins = lins
-        grad = grads[0]
-        for k in range(1, K):
-            self._adopt(main, grads[k].xi, grads[k].small)
-            B.axpby(1.0, grad.xi, 1.0, grads[k].xi, out=grad.xi)
-            B.axpby(1.0, grad.small, 1.0, grads[k].small, out=grad.small)
-            B.axpby(1.0, value, 1.0, values[k], out=value)
-        return value, grad
+        for g in grads:
+            self._adopt(main, g.xi, g.small)
+        return parallel.tree_fold(values), self._fold_vectors(grads)
+
+    @staticmethod
+    def _fold_vectors(vecs):
+        def add(a, b):
+            B.axpby(1.0, a.xi, 1.0, b.xi, out=a.xi)
+            B.axpby(1.0, a.small, 1.0, b.small, out=a.small)
+            return a
+        return parallel.tree_fold(vecs, add)
 
     def _apply_metric_on_lanes(self, d):
-        K, nloc, w = len(self._lanes), len(self.lins), 1.0 / self.n_total
-        # the partial sums of the lanes are allocated HERE (the caller's stream owns them); lane 0 also adds the prior term
-        outs = [LatentVec(torch.empty_like(d.xi), None) for _ in range(K)]
-        last_of_lane0 = ((nloc - 1) // K) * K
+        n, w = len(self.lins), 1.0 / self.n_total
+        # one vector per sample, allocated HERE (the caller's stream owns them); the first sample also adds the prior term
+        outs = [LatentVec(torch.empty_like(d.xi), None) for _ in range(n)]
+        prior = (1.0 if self._holds_first else 0.0) if self._tree else n * w
 
         def job(k, lane, i):
-            lane.lh_metric_accumulate(self.lins[i], d, outs[k], w, i < K, identity=nloc * w if i == last_of_lane0 else 0.0)
+            lane.lh_metric_accumulate(self.lins[i], d, outs[i], w, True, identity=prior if i == 0 else 0.0)
 
         main = self._on_lanes(job)
-        out = outs[0]
-        for k in range(1, K):
-            self._adopt(main, outs[k].small)
-            B.axpby(1.0, out.xi, 1.0, outs[k].xi, out=out.xi)
-            B.axpby(1.0, out.small, 1.0, outs[k].small, out=out.small)
-        return out
+        for o in outs:
+            self._adopt(main, o.small)
+        return self._fold_vectors(outs)
 
     @property
     def value(self):
@@ -1142,7 +1324,7 @@ class FusedKL(Energy):
         return self._grad
 
     def at(self, position):
-        return FusedKL(self.model, position, self.residuals, self.negs, self.n_total, self.comm, self.nanisinf)
+        return FusedKL(self.model, position, self.residuals, self.negs, self.n_total, self.comm, self.nanisinf, self._shared)
 
     def _apply_metric_local(self, d, dot_out=None, cg_direction=None, pipe=None):
         """This rank's share of the KL metric applied to d (no communication).  pipe = (chunks, wait, record): the FIRST
@@ -1150,6 +1332,8 @@ class FusedKL(Energy):
         m = self.model
         if len(self._lanes) > 1 and pipe is None and dot_out is None and cg_direction is None:
             return self._apply_metric_on_lanes(d)
+        if self._tree and len(self.lins) > 0:
+            return self._apply_metric_pairwise(d, dot_out, cg_direction, pipe)
         out = LatentVec(torch.empty_like(d.xi), None)
         w = 1.0 / self.n_total
         nloc = len(self.lins)
@@ -1181,18 +1365,52 @@ class FusedKL(Energy):
             out = LatentVec.zeros(m)
         return out
 
+    def _apply_metric_pairwise(self, d, dot_out, cg_direction, pipe):
+        """The local share with the samples added in pair_tree order (`_PairTree`): even samples store a fresh vector, odd
+        ones join the partial sums that end with them -- in one launch with their even neighbour where the model can
+        (lh_metric_accumulate_pair).  The prior term d rides on GLOBAL sample 0, so that the tree is the same for every
+        split; the curvature dot can be taken on the way only when that is also the last sample (one local sample)."""
+        m, nloc, w = self.model, len(self.lins), 1.0 / self.n_total
+        if dot_out is not None and nloc > 1:
+            raise ValueError("the fused curvature dot needs the prior term on the last sample (one local sample)")
+        tree = _PairTree(torch.empty_like(d.xi), self._scratch_vector)
+        smalls = []
+        paired = m.pair_ready()
+        i = 0
+        while i < nloc:
+            last = i == nloc - 1
+            prior = 1.0 if (i == 0 and self._holds_first) else 0.0
+            direction = cg_direction if i == 0 else None
+            staged = pipe is not None and (i == 0 or last)
+            if paired and i % 2 == 0 and not last and not staged and not (pipe is not None and i + 1 == nloc - 1):
+                dests = (tree.place(False, smalls), tree.place(i + 1 == nloc - 1, smalls))
+                m.lh_metric_accumulate_pair(self.lins[i], self.lins[i + 1], d, None, w, True, cg_direction=direction,
+                                            dests=dests, identity_first=prior)
+                i += 2
+                continue
+            stage = None
+            if pipe is not None:
+                stage = (pipe[0], pipe[1] if i == 0 else None, pipe[2] if last else None)
+            dest = tree.place(last, smalls)
+            if stage is not None and stage[2] is not None and dest.after:
+                raise RuntimeError("a staged final pass cannot be followed by explicit partial-sum additions")
+            m.lh_metric_accumulate(self.lins[i], d, None, w, True, identity=prior, dot_out=dot_out, cg_direction=direction,
+                                   pipe=stage, dest=dest)
+            i += 1
+        return LatentVec(tree.total(), parallel.tree_fold(smalls))
+
     def apply_metric(self, d, dot_out=None, cg_direction=None):
         if (dot_out is not None or cg_direction is not None) and self.comm is not None:
             raise ValueError("the fused curvature dot / direction update are single-process shortcuts")
         out = self._apply_metric_local(d, dot_out, cg_direction)
-        if self.comm is not None:
-            self.comm.allreduce_sum_([out.xi, out.small])
+        self._sum_over_ranks(out)
         return out
 
     @property
     def metric(self):
         single = self.comm is None and len(self.lins) > 0 and len(self._lanes) == 1  # (lanes: no fused dot / direction)
-        A = _Callable(self.apply_metric, fused_dot=single and self.model.octant_vjp,
+        # (pairwise sums keep the prior term on the FIRST sample; the dot needs it on the last one)
+        A = _Callable(self.apply_metric, fused_dot=single and self.model.octant_vjp and (not self._tree or len(self.lins) == 1),
                       fused_direction=single and self.model.fused_direction)
         if self.comm is not None and self.comm.can_shard(self.model.N):
             A.sharded = ShardedMetric(self)  # picked up by ConjugateGradient: CG vectors sharded over the ranks
@@ -1230,7 +1448,8 @@ class ShardedMetric:
         model, P = self.model, self.comm.size
         C = int(os.environ.get("NK_PIPE_CHUNKS", "8"))
         ok = (C >= 2 and model.sandwich and len(model.shape) == 3 and len(kl.lins) > 0
-              and bool(L.load().nk_plan_pipe_ok(model.plan.handle, C)) and (model.N // C) % P == 0)
+              and bool(L.load().nk_plan_pipe_ok(model.plan.handle, C)) and (model.N // C) % P == 0
+              and not (kl._tree and len(kl.lins) > 8))  # (beyond 8 local samples the pairwise sum ends with explicit additions)
         # every rank must take the same decision (a rank without samples cannot stage its transform: it has none)
         if P > 1:
             ok = all(self.comm.allgather_object(bool(ok)))
@@ -1267,7 +1486,20 @@ class ShardedMetric:
                          v.small.clone() if copy else v.small)
 
     def workspace(self):
-        return ShardedCgWorkspace(self.model.device, self.comm)
+        return ShardedCgWorkspace(self.model.device, self.comm, self._unit_layout())
+
+    def _unit_layout(self):
+        """How this rank's share [:, rank, :] of the [chunks][size][m] vector sits in the reduction units of the full vector
+        (ShardedCgWorkspace), or None when it is not made of whole units (the dot products then depend on the rank count in
+        their last bits, like without NK_TREE_SUM)."""
+        if not self.kl._tree:
+            return None
+        code = L.NK_F64 if self.model.tdtype == torch.float64 else L.NK_F32
+        unit, k = int(L.load().nk_red_unit(self.model.N, code)), 64
+        per_segment = k // (self.chunks * self.comm.size) if k % (self.chunks * self.comm.size) == 0 else 0
+        if unit == 0 or per_segment == 0 or per_segment * unit != self.m:
+            return None
+        return (unit, k // self.comm.size, k, per_segment, k // self.chunks, self.comm.rank * per_segment)
 
     def _stage_chunks(self):
         """Chunk pairs in the order the kernels' stages need them: (0, C-1), (1, C-2), ..."""
@@ -1293,12 +1525,27 @@ class ShardedMetric:
         staged = self.chunks > 1 and self.overlap
         return self._reduce(self.kl._apply_metric_local(d_full, pipe=(self.chunks, None, None) if staged else None))
 
+    def _scatter_chunk(self, full_chunk, share):
+        """share <- this rank's 1/size of the sum over ranks of one chunk: the tree over the rank partials when every rank
+        holds one subtree of the pairwise sum over samples (an all-to-all: the bytes of the reduce-scatter), else RCCL's
+        reduce-scatter."""
+        if self.kl._across:
+            self.comm.tree_reduce_slices(full_chunk, share)
+        else:
+            self.comm.reduce_scatter_sum(full_chunk, share)
+
+    def _sum_small(self, small):
+        if self.kl._across:
+            self.comm.tree_allreduce([[small]], [1] * self.comm.size)
+        else:
+            self.comm.allreduce_sum_([small])
+
     def _reduce(self, out):
         q_xi = torch.empty(self.chunks * self.m, dtype=out.xi.dtype, device=out.xi.device)
         full = out.xi.reshape(-1).view(self.chunks, -1)
         for c in range(self.chunks):
-            self.comm.reduce_scatter_sum(full[c], q_xi[c * self.m:(c + 1) * self.m])
-        self.comm.allreduce_sum_([out.small])
+            self._scatter_chunk(full[c], q_xi[c * self.m:(c + 1) * self.m])
+        self._sum_small(out.small)
         return LatentVec(q_xi, out.small)
 
     def apply_shard(self, d_shard, d_full):
@@ -1325,9 +1572,9 @@ class ShardedMetric:
             for j, pair in enumerate(pairs):
                 side.wait_event(self._ev_out[j])
                 for c in pair:
-                    self.comm.reduce_scatter_sum(ofull[c], q_xi[c * self.m:(c + 1) * self.m])
+                    self._scatter_chunk(ofull[c], q_xi[c * self.m:(c + 1) * self.m])
         cur.wait_stream(side)
-        self.comm.allreduce_sum_([out.small])
+        self._sum_small(out.small)
         return LatentVec(q_xi, out.small)
 
 

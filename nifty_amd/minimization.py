@@ -465,24 +465,23 @@ class ConjugateGradient(Minimizer):
         value = float(energy.value) if track_energy else None
         fused_dot = bool(getattr(A, "fused_dot", False)) and hasattr(ws, "curv_slot")
         # ... and the first pass of its transform can take over the previous iteration's direction update
-        fused_dir = fused_dot and bool(getattr(A, "fused_direction", False)) and hasattr(ws, "direction_small")
+        # (either shortcut without the other: a KL metric that sums its samples pairwise has no place for the dot)
+        fused_dir = bool(getattr(A, "fused_direction", False)) and hasattr(ws, "direction_small")
 
         def device_iteration(with_direction):
             """All device work of one iteration up to the fused update: [d <- beta d + r;] q = A d; d.q; x, r update."""
+            extra = {}
+            if with_direction and fused_dir:
+                ws.direction_small(d, r)
+                extra["cg_direction"] = (r, ws)
+            elif with_direction:
+                ws.direction(d, r)
             if fused_dot:
                 # the operator's last epilogue takes d.q (xi part) while it writes q: one BLAS-1 pass less
-                if with_direction and fused_dir:
-                    ws.direction_small(d, r)
-                    q = A(d, dot_out=ws.curv_slot(), cg_direction=(r, ws))
-                else:
-                    if with_direction:
-                        ws.direction(d, r)
-                    q = A(d, dot_out=ws.curv_slot())
+                q = A(d, dot_out=ws.curv_slot(), **extra)
                 ws.curv_small(d, q)
             else:
-                if with_direction:
-                    ws.direction(d, r)
-                q = A(d)
+                q = A(d, **extra)
                 ws.curv(d, q)
             if track_energy:
                 ws.update_dr(x, r, d, q)

@@ -476,6 +476,50 @@ def test_product_spectrum_correlated_field(device_id):
     finally:
         ift.random.pop_sseq()
     assert gl.lat_relerr(mean.asnumpy(), _lat(z, "okl_mean")) < 1e-6
+    # device fields run through ONE fused node (nk_product_field / nk_hartley_fused / nk_product_marginal), host fields
+    # through the operator graph
+    calls = cf.fused_node.calls
+    assert (min(calls.values()) > 0) if device_id >= 0 else (max(calls.values()) == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["octant", "matern", "three", "f32"])
+def test_fused_product_field_equals_the_operator_graph(case):
+    """`_ProductFieldNode` against the generic operator graph of the same maker on the device: a power-of-two grid (the
+    register-resident pipeline: OCTANT amplitude fields and octant sums), a Matern amplitude times a standard one, three
+    sub-spaces, and fp32 fields."""
+    cfm = ift.CorrelatedFieldMaker("q")
+    dtype, tol = np.float64, 1e-12
+    if case == "octant" or case == "f32":
+        cfm.add_fluctuations(ift.RGSpace((32, 16), (0.5, 0.25)), (1.0, 0.5), (1.2, 0.4), (0.4, 0.2), (-3.0, 0.5), prefix="s")
+        cfm.add_fluctuations(ift.RGSpace((16,)), (0.8, 0.3), (1.0, 0.3), None, (-2.0, 0.4), prefix="e")
+        if case == "f32":
+            dtype, tol = np.float32, 2e-5
+    elif case == "matern":
+        cfm.add_fluctuations_matern(ift.RGSpace((12, 10), (0.5, 0.25)), (1.0, 0.3), (2.0, 0.5), (-4.0, 0.5), prefix="m")
+        cfm.add_fluctuations(ift.RGSpace((8,)), (0.8, 0.3), (1.0, 0.3), (0.4, 0.2), (-2.0, 0.4), prefix="e")
+    else:
+        for n, name in ((8, "a"), (6, "b"), (10, "c")):
+            cfm.add_fluctuations(ift.RGSpace((n,)), (0.8, 0.3), (1.0, 0.3), (0.4, 0.2), (-2.5, 0.4), prefix=name)
+    cfm.set_amplitude_total_offset(1.5, (1e-1, 3e-2))
+    cf = cfm.finalize()
+    node = cf.fused_node
+    ift.random.push_sseq_from_seed(31)
+    try:
+        x = ift.from_random(cf.domain, dtype=dtype, device_id=0) * 0.5
+        v = ift.from_random(cf.domain, dtype=dtype, device_id=0)
+        w = ift.from_random(cf.target, dtype=dtype, device_id=0)
+    finally:
+        ift.random.pop_sseq()
+    fused = cf(ift.Linearization.make_var(x))
+    assert min(node.calls["value"], 1) == 1
+    generic = cf._generic(ift.Linearization.make_var(x))
+    if case in ("octant", "f32"):
+        assert node._setup(x["qxi"].val.dtype, x["qxi"].val.device)["octant"]
+    assert gl.relerr(fused.val.asnumpy(), generic.val.asnumpy()) < tol
+    assert gl.relerr(fused.jac(v).asnumpy(), generic.jac(v).asnumpy()) < 10 * tol
+    assert gl.lat_relerr(fused.jac.adjoint(w).asnumpy(), generic.jac.adjoint(w).asnumpy()) < 10 * tol
+    assert node.calls["times"] == 1 and node.calls["adjoint"] == 1
 
 
 @pytest.mark.parametrize("device_id", [-1, pytest.param(0, marks=pytest.mark.gpu)])
@@ -703,6 +747,8 @@ def test_total_N_correlated_fields_with_dofdex(device_id):
     assert abs(float(hl.val.asnumpy()) - float(z["ham_value"])) < 1e-11 * abs(float(z["ham_value"]))
     assert gl.lat_relerr(hl.gradient.asnumpy(), _lat(z, "ham_grad")) < 1e-10
     assert gl.lat_relerr(hl.metric(v).asnumpy(), _lat(z, "ham_metric_v")) < 1e-10
+    calls = cf.fused_node.calls  # three field copies through the fused node on the device, none on the host
+    assert (min(calls.values()) > 0) if device_id >= 0 else (max(calls.values()) == 0)
     with pytest.raises(ValueError):
         cfm.add_fluctuations(ift.RGSpace((4,)), (1.0, 0.5), (1.2, 0.4), (0.4, 0.2), (-3.0, 0.5), dofdex=[0, 1])
     with pytest.raises(NotImplementedError):

@@ -392,7 +392,7 @@ def test_two_rank_resume_equals_uninterrupted(tmp_path):
         assert gl.lat_relerr(r, serial) < 1e-9
 
 
-def _pipe_worker(rank, world, port, out, chunks, overlap=1):
+def _pipe_worker(rank, world, port, out, chunks, overlap=1, pairs=2):
     import faulthandler
 
     faulthandler.dump_traceback_later(200, exit=True)
@@ -406,7 +406,7 @@ def _pipe_worker(rank, world, port, out, chunks, overlap=1):
     if world == 1:
         os.environ["NK_FORCE_COMM"] = "1"
     comm, _ = parallel.init(backend)
-    res = _pipe_case(comm)
+    res = _pipe_case(comm, pairs)
     assert res.pop("chunks") == chunks
     if rank == 0:
         torch.save(res, out)
@@ -414,8 +414,9 @@ def _pipe_worker(rank, world, port, out, chunks, overlap=1):
     torch.distributed.destroy_process_group()
 
 
-def _pipe_case(comm):
-    """One MGVI iteration of a 3-D model whose Newton-CG runs on sharded vectors with the chunked exchange."""
+def _pipe_case(comm, pairs=2):
+    """One MGVI iteration (`pairs` mirrored sample pairs) of a 3-D model whose Newton-CG runs on sharded vectors with the
+    chunked exchange."""
     from nifty_amd import random
     from nifty_amd.engine import FusedModel, mgvi_iteration
     from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG
@@ -427,21 +428,26 @@ def _pipe_case(comm):
         mean = 0.1 * model.draw_prior()
         ic = lambda: AbsDeltaEnergyController(0.05, iteration_limit=4)  # noqa: E731
         mini = NewtonCG(AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=2), max_cg_iterations=5)
-        mean, kl = mgvi_iteration(model, mean, 2, ic, mini, mirror_samples=True, comm=comm)
+        mean, kl = mgvi_iteration(model, mean, pairs, ic, mini, mirror_samples=True, comm=comm)
     finally:
         random.pop_sseq()
     sm = getattr(kl.metric, "sharded", None)
     return dict(value=kl.value, xi=mean.xi.cpu(), small=mean.small.cpu(), chunks=1 if sm is None else sm.chunks)
 
 
+def _same_bits(a, b):
+    return a["value"] == b["value"] and torch.equal(a["xi"], b["xi"]) and torch.equal(a["small"], b["small"])
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
 def test_chunked_overlapped_exchange_of_the_sharded_cg(tmp_path):
     """SURVEY 8(e) / VERDICT r2 3a: the slab-pipelined reduce-scatter / all-gather of the sharded CG with 1, 4 and 16
-    chunks.  One rank on real RCCL (side-stream overlap, staged passes): every chunk count gives the bits of the unchunked
-    exchange.  Two ranks sharing the GPU (gloo, synchronous chunks, staged passes): staging on / off is bit-identical for a
-    given chunk count; different chunk counts regroup the per-rank partial sums of the CG's dot products and agree to
-    rounding, like different rank counts do.  Everything agrees with the single-process run to rounding."""
+    chunks.  One rank on real RCCL (side-stream overlap, staged passes) and two ranks sharing the GPU (gloo, synchronous
+    chunks, staged passes): staging on / off, every chunk count and both rank counts give the bits of the plain
+    single-process run -- the sums over samples follow the reference's pairwise tree (utilities.py:349-414) and the dot
+    products of the sharded vectors are reduced unit by unit (nk_red_layout), so neither the ownership of the elements nor
+    the number of ranks enters the rounding."""
     serial = _pipe_case(None)
 
     def run(world, chunks, overlap=1):
@@ -449,21 +455,40 @@ def test_chunked_overlapped_exchange_of_the_sharded_cg(tmp_path):
         mp.spawn(_pipe_worker, args=(world, _free_port(), out, chunks, overlap), nprocs=world, join=True)
         return torch.load(out, weights_only=False)
 
-    def same_bits(a, b):
-        return a["value"] == b["value"] and torch.equal(a["xi"], b["xi"]) and torch.equal(a["small"], b["small"])
-
-    def close(a, b, tol):
-        return (abs(a["value"] - b["value"]) < tol * abs(b["value"])
-                and float((a["xi"] - b["xi"]).abs().max()) < 100 * tol * float(b["xi"].abs().max()))
-
-    one = {c: run(1, c) for c in (1, 4, 16)}
-    assert same_bits(one[4], one[1]) and same_bits(one[16], one[1])
-    assert same_bits(run(1, 4, overlap=0), one[1])
-    assert close(one[1], serial, 1e-10)
-    two = {c: run(2, c) for c in (1, 4, 16)}
-    assert same_bits(run(2, 4, overlap=0), two[4])
     for c in (1, 4, 16):
-        assert close(two[c], serial, 1e-9), c
+        assert _same_bits(run(1, c), serial), c
+    assert _same_bits(run(1, 4, overlap=0), serial)
+    for c in (1, 4, 16):
+        assert _same_bits(run(2, c), serial), c
+    assert _same_bits(run(2, 4, overlap=0), serial)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_fused_engine_bits_do_not_depend_on_the_rank_count(tmp_path):
+    """Reference test_mpi/test_kl.py:104-114 (MPI result == serial result, bit for bit) on the fused engine: one MGVI
+    iteration with eight samples -- sampling, KL value / gradient, Newton-CG on sharded vectors, line search -- on 1, 2 and
+    4 ranks (8, 4, 2 samples per rank: the local part of the pairwise sum runs inside the VJP epilogues with two, one and
+    no carried partial sums) ends at the same mean and KL value, bit for bit.  NK_TREE_SUM=0 (the running sums and
+    RCCL-ordered reductions of rounds 1-3) agrees to rounding only."""
+    serial = _pipe_case(None, 4)
+
+    def run(world, chunks, env=None):
+        out = str(tmp_path / f"w{world}c{chunks}.pt")
+        os.environ.update(env or {})
+        try:
+            mp.spawn(_pipe_worker, args=(world, _free_port(), out, chunks, 1, 4), nprocs=world, join=True)
+        finally:
+            for k in (env or {}):
+                del os.environ[k]
+        return torch.load(out, weights_only=False)
+
+    assert _same_bits(run(2, 4), serial)
+    assert _same_bits(run(4, 4), serial)
+    assert _same_bits(run(4, 1), serial)
+    loose = run(2, 4, env={"NK_TREE_SUM": "0"})
+    assert abs(loose["value"] - serial["value"]) < 1e-9 * abs(serial["value"])
+    assert float((loose["xi"] - serial["xi"]).abs().max()) < 1e-7 * float(serial["xi"].abs().max())
 
 
 def _lockstep_worker(rank, world, port, out):

@@ -281,6 +281,55 @@ def test_sandwich_fused_emulation(shape):
             assert np.max(np.abs(got - ref_abar)) < 1e-10 * max(1.0, np.max(np.abs(ref_abar)))
 
 
+@pytest.mark.parametrize("shape,dtype", [((64, 64, 128), np.float64), ((64, 64, 128), np.float32), ((12, 10), np.float64),
+                                         ((64, 128), np.float32)])
+def test_vjp_carry_chain_is_a_chain_of_plain_additions(shape, dtype):
+    """nk_fuse.carry1 / carry2 / accumulate: out = out + (carry2 + (carry1 + g)) with the sample's own contribution g
+    rounded first -- BIT-identical to storing g and adding the partial sums one by one (what another rank would do):
+    the pairwise sum over samples (utilities.py:349-414) inside the epilogues.  Register-resident final pass (octant
+    fields, compile-time MODE 6 / 14 and the run-time path) and the generic kernels."""
+    rng = np.random.default_rng(11)
+    nb = 5
+    pidx = rng.integers(0, nb, size=shape).astype(np.int32)
+    idx = np.indices(shape)
+    for d in range(len(shape)):
+        flip = tuple((-idx[e]) % shape[e] if e == d else idx[e] for e in range(len(shape)))
+        pidx = np.minimum(pidx, pidx[flip])
+    pidx = pidx.astype(np.int32)
+    amp = rng.normal(size=nb)
+    xi, w, addend, c1, c2, run0 = (rng.normal(size=shape).astype(dtype) for _ in range(6))
+    oct_sl = tuple(slice(0, s // 2 + 1) for s in shape)
+    af8 = np.ascontiguousarray(amp[pidx][oct_sl]).astype(dtype)
+    fast = all(n & (n - 1) == 0 for n in shape)
+
+    def vjp(out, accumulate, carries, with_addend):
+        w8 = np.zeros(af8.shape)
+        abar = np.zeros(nb)
+        f = Fuse()
+        f.pro, f.in_ = 0, w.ctypes.data
+        f.epi, f.out, f.scale = 2, out.ctypes.data, 0.25
+        f.pidx, f.amp, f.xi, f.abar = pidx.ctypes.data, amp.ctypes.data, xi.ctypes.data, abar.ctypes.data
+        if with_addend:
+            f.addend, f.addend_scale = addend.ctypes.data, 0.5
+        f.accumulate = 1 if accumulate else 0
+        f.carry1, f.carry2 = [c.ctypes.data for c in carries] + [None] * (2 - len(carries))
+        if fast:
+            f.afield, f.field_octant, f.w8 = af8.ctypes.data, 1, w8.ctypes.data
+        run(f, shape, dtype, fn=fast_fn(shape) if fast else "emu_hartley_fused")
+        return out
+
+    for with_addend in (False, True):
+        g = vjp(np.full(shape, np.nan, dtype=dtype), False, (), with_addend)  # the sample alone
+        for carries, accumulate in (((c1,), True), ((c1, c2), True), ((c1,), False), ((), True)):
+            want = g.copy()
+            for c in carries:
+                want = c + want
+            if accumulate:
+                want = run0 + want
+            got = vjp(run0.copy(), accumulate, carries, with_addend)
+            assert np.array_equal(got, want), (with_addend, len(carries), accumulate)
+
+
 def test_wide_schedule_emulation():
     """The in-place strided pass of 1024-point fp32 lines runs 256 threads x 64 elements (radix 64 x 16, SchedW): first
     axis of a 3-D strided-first transform and the middle-axis passes of a sandwich."""

@@ -29,3 +29,15 @@ timed("cg_update", 7, lambda: L.check(lib.nk_cg_update(n, x.data_ptr(), r.data_p
 timed("cg_direction", 3, lambda: L.check(lib.nk_cg_direction(n, d.data_ptr(), r.data_ptr(), code, scal.data_ptr(), 0, st)))
 timed("vdot", 2, lambda: B.vdot(x, r))
 timed("axpby", 3, lambda: B.axpby(1.0, x, 0.5, r, out=q))
+
+# the same reductions on the share of one of 8 ranks (8 of the 64 reduction units, nk_red_layout): what a rank of a sharded CG runs
+unit = int(lib.nk_red_unit(n, code))
+if unit:
+    m = n // 8
+    units = torch.zeros(4 * 64, dtype=torch.float64, device=dev)
+    L.check(lib.nk_red_layout(unit, 8, 64, 8, 64, 0, units.data_ptr()))
+    n_full, n = n, m
+    xs, rs, ds, qs, bs_ = (t[:m] for t in (x, r, d, q, b))
+    timed("shard cg_update", 7, lambda: L.check(lib.nk_cg_update(m, xs.data_ptr(), rs.data_ptr(), ds.data_ptr(), qs.data_ptr(), bs_.data_ptr(), code, scal.data_ptr(), 0, st)))
+    timed("shard vdot", 2, lambda: L.check(lib.nk_vdot(m, xs.data_ptr(), rs.data_ptr(), code, scal.data_ptr(), 0, st)))
+    lib.nk_red_layout(0, 0, 0, 0, 0, 0, 0)
