@@ -395,6 +395,15 @@ typedef struct nk_product {
   const double* dscale;
 } nk_product;
 int nk_product_field(const nk_product* p, int tangent, void* out, int dtype, void* stream);
+/* nk_mirror_combine: the SEPARABLE Hartley transform of a product domain -- one Hartley transform per sub-space, which is
+ * what a chain of HarmonicTransformOperators with `space=` computes (library/correlated_fields.py:726-730,
+ * operators/harmonic_operators.py:97-161) -- from the genuine N-D one: cas(a) cas(b) = 1/2 [cas(a+b) + cas(a-b) + cas(-a+b)
+ * - cas(-a-b)], so  out[k] = scale * sum_s coef[s] in[flip_s(k)] + offset  over the 2^nsub sign patterns s (bit i of s set:
+ * the axes of sub-space i are mirrored, k -> (n - k) mod n).  group[ax] = sub-space of grid axis ax.  The combination is
+ * symmetric and commutes with the transform: apply it to the output of nk_hartley_fused in a forward evaluation, to the
+ * input in an adjoint one.  Out of place. */
+int nk_mirror_combine(int ndim, const int64_t* shape, const int* group, int nsub, const double* coef, const void* in,
+                      void* out, double scale, double offset, int dtype, void* stream);
 size_t nk_product_marginal_scratch(const nk_product* p, int which);
 int nk_product_marginal(const nk_product* p, int which, const double* w, double* scratch, double* marg, void* stream);
 

@@ -60,6 +60,7 @@ SIGNATURES = {
     "nk_profile_collect": (_i, [_vp, _vp]),
     "nk_vdot": (_i, [_i64, _vp, _vp, _i, _vp, _i, _vp]),
     "nk_product_field": (_i, [ctypes.POINTER(Product), _i, _vp, _i, _vp]),
+    "nk_mirror_combine": (_i, [_i, ctypes.POINTER(_i64), ctypes.POINTER(_i), _i, ctypes.POINTER(_d), _vp, _vp, _d, _d, _i, _vp]),
     "nk_product_marginal_scratch": (_sz, [ctypes.POINTER(Product), _i]),
     "nk_product_marginal": (_i, [ctypes.POINTER(Product), _i, _vp, _vp, _vp, _vp]),
     "nk_red_unit": (_i64, [_i64, _i]),

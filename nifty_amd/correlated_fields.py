@@ -488,8 +488,16 @@ class _ProductFieldNode(Operator):
       ADJOINT   the VJP epilogue returns a . t and the per-point sums xi . t (nk_fuse.wfull, or the octant sums w8 on plans
                 with the register-resident pipeline); nk_product_marginal contracts them with the other sub-spaces'
                 amplitudes and nk_csr_rowsum adds them bin by bin, all in a fixed order.
+    The harmonic transform of the product domain is one Hartley transform PER SUB-SPACE (a chain of
+    HarmonicTransformOperators with `space=`, reference :726-730) -- the kernel prod_i cas(k_i x_i), not the genuine N-D
+    Hartley kernel cas(sum_i k_i x_i).  cas(a) cas(b) = 1/2 [cas(a+b) + cas(a-b) + cas(-a+b) - cas(-a-b)] (three factors:
+    1/2 [cas(-a+b+c) + cas(a-b+c) + cas(a+b-c) - cas(-a-b-c)]) turns it into ONE fused N-D transform plus a fixed
+    combination of mirrored points (nk_mirror_combine) -- behind the transform in value / TIMES, in front of it in ADJOINT --
+    instead of per-sub-space transforms with permutation copies around them.
     The reference distributes every amplitude over the full grid and multiplies fields (one PowerDistributor +
     ContractionOperator.adjoint per sub-space, six N-sized products per evaluation for two spectra)."""
+
+    MIRROR = {2: (0.5, 0.5, 0.5, -0.5), 3: (0.0, 0.5, 0.5, 0.0, 0.5, 0.0, 0.0, -0.5)}  # index: bit i = sub-space i mirrored
 
     KEYS = ("xi", "azm")
 
@@ -557,6 +565,16 @@ class _ProductFieldNode(Operator):
         f.afield, f.field_octant = field.data_ptr(), 1 if st["octant"] else 0
         return f
 
+    def _separable(self, src, dst, offset=0.0):
+        """dst <- the per-sub-space Hartley combination of src (both one field copy, flat) + offset (two or three
+        sub-spaces; with one the genuine transform is the answer)."""
+        shape = (ctypes.c_int64 * len(self._grid))(*self._grid)
+        group = (ctypes.c_int * len(self._grid))(*[i for i, sp in enumerate(self._subspaces) for _ in sp.shape])
+        coef = (ctypes.c_double * (1 << self._nsub))(*self.MIRROR[self._nsub])
+        L.check(L.load().nk_mirror_combine(len(self._grid), shape, group, self._nsub, coef, src.data_ptr(), dst.data_ptr(), 1.0,
+                                           float(offset), B.dtype_code(src), B._stream()), "nk_mirror_combine")
+        return dst
+
     def _rows(self, field, width=None):
         """[copies][...] view of a Field's values (one row when the maker has no leading copy domain)."""
         v = field.val.contiguous()
@@ -575,14 +593,18 @@ class _ProductFieldNode(Operator):
         xi, tabs, azm = self._inputs(v)
         st = self._setup(xi.dtype, xi.device)
         out = torch.empty_like(xi)
+        single = self._nsub == 1
+        tmp = None if single else torch.empty_like(xi[0])
         fields = []
         for c in range(xi.shape[0]):
             q = self._product(st, [t[c] for t in tabs], azm[c])
             fields.append(self._field(st, xi.dtype, q, False))
             f = self._fuse(st, fields[-1])
             f.pro, f.in_ = L.PRO_AMP, xi[c].data_ptr()
-            f.epi, f.out, f.offset = L.EPI_AFFINE, out[c].data_ptr(), self._offset
+            f.epi, f.out, f.offset = L.EPI_AFFINE, (out[c] if single else tmp).data_ptr(), self._offset if single else 0.0
             B.hartley_fused(st["plan"], f)
+            if not single:
+                self._separable(tmp, out[c], self._offset)
         self.calls["value"] += 1
         val = Field(self._target, out.reshape(self._target.shape))
         return x.new(val, _ProductFieldJacobian(self, st, xi, tabs, azm, fields)) if lin else val
@@ -609,13 +631,17 @@ class _ProductFieldJacobian(LinearOperator):
         dxi, dtabs, dazm = n._inputs(x)
         dxi = dxi.to(self._xi.dtype)
         out = torch.empty_like(self._xi)
+        single = n._nsub == 1
+        tmp = None if single else torch.empty_like(self._xi[0])
         for c in range(self._xi.shape[0]):
             q = n._product(st, [t[c] for t in self._tabs], self._azm[c], [t[c] for t in dtabs], dazm[c])
             dfield = n._field(st, self._xi.dtype, q, True)
             f = n._fuse(st, self._fields[c])
             f.pro, f.in_, f.in2, f.dafield = L.PRO_AMP_JVP, dxi[c].data_ptr(), self._xi[c].data_ptr(), dfield.data_ptr()
-            f.epi, f.out, f.offset = L.EPI_AFFINE, out[c].data_ptr(), 0.0
+            f.epi, f.out, f.offset = L.EPI_AFFINE, (out[c] if single else tmp).data_ptr(), 0.0
             B.hartley_fused(st["plan"], f)
+            if not single:
+                n._separable(tmp, out[c])
         n.calls["times"] += 1
         return Field(self._target, out.reshape(self._target.shape))
 
@@ -626,9 +652,10 @@ class _ProductFieldJacobian(LinearOperator):
         tab_bar = [torch.empty_like(t) for t in self._tabs]
         azm_bar = torch.empty_like(self._azm)
         sums = torch.empty(st["npts"], dtype=torch.float64, device=w.device)  # per-point xi . t (full grid or octant)
+        tmp = None if n._nsub == 1 else torch.empty_like(w[0])
         for c in range(w.shape[0]):
             f = n._fuse(st, self._fields[c])
-            f.pro, f.in_ = L.PRO_PLAIN, w[c].data_ptr()
+            f.pro, f.in_ = L.PRO_PLAIN, (w[c] if tmp is None else n._separable(w[c], tmp)).data_ptr()
             f.epi, f.out, f.xi, f.abar = L.EPI_VJP, xi_bar[c].data_ptr(), self._xi[c].data_ptr(), st["sink"].data_ptr()
             if st["octant"]:
                 f.w8 = sums.data_ptr()

@@ -323,8 +323,13 @@ NK_HD C2<T> nk_prologue_pair(const NkFuse& f, int64_t i) {
       return C2<T>{(T)(f.amp[p0] * (double)a.x), (T)(f.amp[p1] * (double)a.y)};
     }
     case NK_PRO_AMP_JVP: {
-      const int32_t p0 = f.pidx[i], p1 = f.pidx[i + 1];
       const C2<T> x = *reinterpret_cast<const C2<T>*>((const T*)f.in2 + i);
+      if (f.afield && f.dafield) {  // both amplitude factors as fields: no bin index needed (product spectra)
+        const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + i);
+        const C2<T> dm = *reinterpret_cast<const C2<T>*>((const T*)f.dafield + i);
+        return C2<T>{m.x * a.x + dm.x * x.x, m.y * a.y + dm.y * x.y};
+      }
+      const int32_t p0 = f.pidx[i], p1 = f.pidx[i + 1];
       if (f.afield) {
         const C2<T> m = *reinterpret_cast<const C2<T>*>((const T*)f.afield + i);
         const T d0 = f.dampT ? ((const T*)f.dampT)[p0] : (T)f.damp[p0];

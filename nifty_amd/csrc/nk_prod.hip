@@ -117,6 +117,42 @@ __global__ void __launch_bounds__(PROD_THREADS) k_marg_fold(int64_t chunks, int6
   marg[b] = s;
 }
 
+// ---- separable Hartley transforms from the genuine one.  The harmonic transform of a PRODUCT domain is one Hartley
+// transform per sub-space (library/correlated_fields.py:726-730: a chain of HarmonicTransformOperators with `space=`), i.e.
+// the kernel prod_i cas(k_i.x_i), not cas(sum_i k_i.x_i).  cas(a) cas(b) = 1/2 [cas(a+b) + cas(a-b) + cas(-a+b) - cas(-a-b)]
+// (and its three-factor analogue), so the separable transform is a fixed combination of the genuine transform at the
+// points whose sub-space wave vectors are mirrored: out[k] = sum_s coef[s] in[flip_s(k)], s over the 2^nsub sign patterns.
+// The combination commutes with the transform and is symmetric: it is applied to the OUTPUT of a forward evaluation and to
+// the INPUT of an adjoint one, so that prologue and epilogue fusion of the single N-D transform stay what they are.
+struct MirrorArgs {
+  int ndim, nsub;
+  int64_t n[3];
+  int group[3];
+  double coef[8];
+};
+template <typename T>
+__global__ void __launch_bounds__(PROD_THREADS) k_mirror_combine(MirrorArgs m, int64_t total, const T* __restrict__ in,
+                                                                  T* __restrict__ out, double scale, double offset) {
+  const int64_t k = (int64_t)blockIdx.x * PROD_THREADS + threadIdx.x;
+  if (k >= total) return;
+  int64_t idx[3], r = k;
+  for (int ax = m.ndim - 1; ax >= 0; --ax) {
+    idx[ax] = r % m.n[ax];
+    r /= m.n[ax];
+  }
+  double acc = 0.0;
+  for (int s = 0; s < (1 << m.nsub); ++s) {
+    int64_t flat = 0;
+    for (int ax = 0; ax < m.ndim; ++ax) {
+      const bool neg = (s >> m.group[ax]) & 1;
+      const int64_t i = neg && idx[ax] ? m.n[ax] - idx[ax] : idx[ax];
+      flat = flat * m.n[ax] + i;
+    }
+    acc += m.coef[s] * (double)in[flat];
+  }
+  out[k] = (T)(scale * acc + offset);
+}
+
 int prod_args(const nk_product* q, ProdArgs* p, int64_t* n) {
   if (!q || q->nsub < 1 || q->nsub > 3 || !q->scale) return nk_set_error(NK_ERR_INVALID, "nk_product: 1..3 sub-spaces and a scale");
   p->nsub = q->nsub;
@@ -194,4 +230,32 @@ extern "C" int nk_product_marginal(const nk_product* q, int which, const double*
   hipLaunchKernelGGL(k_marg_cols, dim3((unsigned)col_blocks, (unsigned)chunks), dim3(PROD_THREADS), 0, st, A, Bn, tmp, partial);
   hipLaunchKernelGGL(k_marg_fold, dim3((unsigned)col_blocks), dim3(PROD_THREADS), 0, st, chunks, Bn, partial, marg);
   return nk_check_launch("nk_product_marginal");
+}
+
+extern "C" int nk_mirror_combine(int ndim, const int64_t* shape, const int* group, int nsub, const double* coef, const void* in,
+                                 void* out, double scale, double offset, int dtype, void* stream) {
+  if (ndim < 1 || ndim > 3 || nsub < 1 || nsub > 3 || !shape || !group || !coef || !in || !out || in == out)
+    return nk_set_error(NK_ERR_INVALID, "nk_mirror_combine: bad argument (1..3 axes and sub-spaces, out of place)");
+  MirrorArgs m;
+  m.ndim = ndim, m.nsub = nsub;
+  int64_t total = 1;
+  for (int ax = 0; ax < 3; ++ax) {
+    m.n[ax] = ax < ndim ? shape[ax] : 1;
+    m.group[ax] = ax < ndim ? group[ax] : 0;
+    if (m.n[ax] < 1 || m.group[ax] < 0 || m.group[ax] >= nsub) return nk_set_error(NK_ERR_INVALID, "nk_mirror_combine: bad axis");
+    total *= m.n[ax];
+  }
+  for (int s = 0; s < 8; ++s) m.coef[s] = s < (1 << nsub) ? coef[s] : 0.0;
+  const int64_t blocks = (total + PROD_THREADS - 1) / PROD_THREADS;
+  if (blocks > 0x7fffffffLL) return nk_set_error(NK_ERR_UNSUPPORTED, "nk_mirror_combine: grid too large for one launch");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == NK_F32)
+    hipLaunchKernelGGL(k_mirror_combine<float>, dim3((unsigned)blocks), dim3(PROD_THREADS), 0, st, m, total, (const float*)in,
+                       (float*)out, scale, offset);
+  else if (dtype == NK_F64)
+    hipLaunchKernelGGL(k_mirror_combine<double>, dim3((unsigned)blocks), dim3(PROD_THREADS), 0, st, m, total, (const double*)in,
+                       (double*)out, scale, offset);
+  else
+    return nk_set_error(NK_ERR_INVALID, "dtype must be NK_F32 or NK_F64");
+  return nk_check_launch("nk_mirror_combine");
 }

@@ -904,6 +904,9 @@ class DiagonalOperator(EndomorphicOperator):
             return DiagonalOperator._from_ldiag(self, a * b, self._dtype if self._dtype == op._dtype else None, 0, None
                                                 if (self._full() or op._full()) else tuple(set(self._spaces) | set(op._spaces)))
         a, b = self._actual_diag(), op._actual_diag()
+        if a.dtype != b.dtype:  # (numpy semantics: the wider type wins, e.g. an fp32 linearisation point times fp64 tables)
+            wide = torch.promote_types(a.dtype, b.dtype)
+            a, b = a.to(wide), b.to(wide)
         if not a.is_cuda:
             prod = a * b
         else:

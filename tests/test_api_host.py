@@ -491,8 +491,8 @@ def test_fused_product_field_equals_the_operator_graph(case):
     cfm = ift.CorrelatedFieldMaker("q")
     dtype, tol = np.float64, 1e-12
     if case == "octant" or case == "f32":
-        cfm.add_fluctuations(ift.RGSpace((32, 16), (0.5, 0.25)), (1.0, 0.5), (1.2, 0.4), (0.4, 0.2), (-3.0, 0.5), prefix="s")
-        cfm.add_fluctuations(ift.RGSpace((16,)), (0.8, 0.3), (1.0, 0.3), None, (-2.0, 0.4), prefix="e")
+        cfm.add_fluctuations(ift.RGSpace((64, 64), (0.5, 0.25)), (1.0, 0.5), (1.2, 0.4), (0.4, 0.2), (-3.0, 0.5), prefix="s")
+        cfm.add_fluctuations(ift.RGSpace((64,)), (0.8, 0.3), (1.0, 0.3), None, (-2.0, 0.4), prefix="e")
         if case == "f32":
             dtype, tol = np.float32, 2e-5
     elif case == "matern":
