@@ -3,7 +3,7 @@
 Counterpart of reference nifty/cl/library/correlated_fields.py (_SlopeRemover :89-116,
 _TwoLogIntegrations :119-162, _Normalization :165-208, _Amplitude :277-386, CorrelatedFieldMaker
 :389-859), library/correlated_fields_simple.py:36-133 and operators/normal_operators.py:28-72, for the
-single-amplitude, total_N == 0, non-Matern case the BASELINE configs use.
+single-amplitude, total_N == 0, non-Matern case the BASELINE configs use, and for product spectra.
 
 Two realisations share one interface:
 * the GENERIC operator graph built from the small linear operators (host Fields, config 1's
@@ -11,6 +11,9 @@ Two realisations share one interface:
 * ``CorrelatedFieldOperator``: ONE fused Operator node whose forward pass, Jacobian and adjoint
   Jacobian run in the HIP kernels of libniftyk (amplitude kernels + fused Hartley transform) for
   device Fields.  ``finalize()`` returns this node; on host Fields it evaluates the generic graph.
+* several spectra (product spaces) and / or ``total_N > 0``: ``ProductCorrelatedFieldOperator`` -- the
+  amplitude graphs (standard or Matern, shared by ``dofdex``) feed ``_ProductFieldNode``, which does the
+  N-sized half in nk_product_field / nk_hartley_fused / nk_mirror_combine / nk_product_marginal.
 """
 import ctypes
 

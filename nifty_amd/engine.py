@@ -1180,7 +1180,8 @@ class FusedKL(Energy):
         self._across = False
         if comm is not None and self._tree:
             if "across" not in self._shared:
-                self._shared["across"] = comm.subtree_per_rank(comm.term_counts(len(residuals)))
+                self._shared["across"] = (comm.subtree_per_rank(comm.term_counts(len(residuals)))
+                                          and comm.tree_exchange_works(model.device))
                 if not self._shared["across"] and comm.rank == 0 and comm.size > 1:
                     print("nifty_amd: the samples do not split into one power-of-two block per rank; sums over samples "
                           "depend on the rank count in the last bits", flush=True)

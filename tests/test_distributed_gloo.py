@@ -531,3 +531,55 @@ def test_lockstep_verifies_with_one_collective_per_flush(tmp_path):
     for rank in (0, 1):
         res = torch.load(out + str(rank), weights_only=False)
         assert res == dict(agree=True, caught=True, forced=True), (rank, res)
+
+
+def _tree_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from nifty_amd import parallel
+
+    comm, _ = parallel.init("gloo")
+    res = dict(works=comm.tree_exchange_works(torch.device("cpu")))
+    # uneven split: rank r holds r + 1 terms (the last rank none when world > 2), two tensors per term
+    counts = [r + 1 for r in range(world)]
+    if world > 2:
+        counts[-1] = 0
+    first = sum(counts[:rank])
+    gen = lambda i: [torch.randn(5, generator=torch.Generator().manual_seed(100 + i)),  # noqa: E731
+                     torch.randn(1, dtype=torch.float64, generator=torch.Generator().manual_seed(200 + i))]
+    terms = [gen(first + j) for j in range(counts[rank])]
+    like = None if terms else gen(0)
+    res["uneven"] = [t.clone() for t in comm.tree_allreduce(terms, counts, like=like)]
+    # one subtree per rank: the slice-wise exchange
+    partial = torch.randn(4 * world * 3, generator=torch.Generator().manual_seed(300 + rank))
+    res["slices"] = comm.tree_allreduce_slices_(partial.clone())
+    res["partial"] = partial
+    torch.save(res, f"{out}.{rank}")
+    comm.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_tree_collectives_add_in_pair_tree_order(tmp_path, world):
+    """Comm.tree_allreduce (any split of the terms, ranks without terms, point-to-point like utilities.py:349-414) and the
+    slice-wise tree over rank partials: the bits of parallel.tree_fold over all terms in global order, on every rank."""
+    from nifty_amd import parallel
+
+    out = str(tmp_path / "tree")
+    mp.spawn(_tree_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    runs = [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
+    counts = [r + 1 for r in range(world)]
+    if world > 2:
+        counts[-1] = 0
+    n = sum(counts)
+    want0 = parallel.tree_fold([torch.randn(5, generator=torch.Generator().manual_seed(100 + i)) for i in range(n)])
+    want1 = parallel.tree_fold([torch.randn(1, dtype=torch.float64, generator=torch.Generator().manual_seed(200 + i))
+                                for i in range(n)])
+    want_slices = parallel.tree_fold([r["partial"] for r in runs])
+    for r in runs:
+        assert r["works"]
+        assert torch.equal(r["uneven"][0], want0) and torch.equal(r["uneven"][1], want1)
+        assert torch.equal(r["slices"], want_slices)
