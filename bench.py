@@ -38,6 +38,8 @@ from nifty_amd import minimization, parallel, random  # noqa: E402
 from nifty_amd.engine import FusedModel, LatentVec, mgvi_iteration  # noqa: E402
 from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG  # noqa: E402
 
+# streams of the fused CG vector update: x, r (read + write), d, q -- plus b when the energy is re-evaluated from x.b
+CG_STREAMS = 7.0 if os.environ.get("NK_CG_ENERGY_RECURRENCE", "1") == "0" else 6.0
 PMC_TRAFFIC_FILE = os.environ.get("NK_PMC_FILE", "r04_pmc_traffic.json")  # latest committed PMC summary of the bench command
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # transform pass kernels by profile id: strided-first pipeline (A first strided pass with prologue, B in-place strided
@@ -419,8 +421,13 @@ def main():
     mem_before = (int(ms.get("num_device_alloc", 0)), int(ms.get("num_device_free", 0)))
     t0 = time.perf_counter()
     energy = float("nan")
-    for _ in range(args.steps):
+    trace = os.environ.get("NK_BENCH_TRACE", "0") == "1"  # developer: the work of every step (forces a sync per step)
+    for it in range(args.steps):
+        before = (dict(model.counters), minimization.counters["cg_iterations"])
         mean, energy = step(mean)
+        if trace and rank == 0:
+            print(f"step {it}: KL {energy!r} cg {minimization.counters['cg_iterations'] - before[1]} " +
+                  " ".join(f"{k} {model.counters[k] - before[0][k]}" for k in model.counters), file=sys.stderr, flush=True)
     sync()
     elapsed = time.perf_counter() - t0
     lib.nk_profile_enable(0)
@@ -604,12 +611,16 @@ def main():
             "final_kl_energy": energy,
             "samples16": leg16,
             "per_step_counts_rank0": counts,
+            # the WORK of a step is a property of the trajectory (532 ... 657 transforms per step between variants of the
+            # library that differ in last bits only, profiles/r04_trajectory_variants.txt); the time per transform is the
+            # figure that compares implementations
+            "ms_per_transform_rank0": (ms_per_step / counts["transforms"]) if counts.get("transforms") else None,
             "step_algorithmic_GBps_rank0": step_bytes / (ms_per_step * 1e-3) / 1e9,
             # step_algorithmic is SURVEY 8(d)'s model: SIX passes per metric application (two three-pass transforms).  What
             # the kernels of a step really move: the operand bytes of every executed transform pass (a metric application is
-            # a FIVE-pass sandwich) plus the CG vector update's seven streams per iteration, over the same step time
+            # a FIVE-pass sandwich) plus the streams of the CG vector update (CG_STREAMS) per iteration, over the same step time
             "step_hbm_GBps_rank0": ((sum(v["bytes"] for v in by_kernel.values()) / args.steps
-                                     + counts.get("cg_iterations", 0.0) * 7.0 * N * b / world)
+                                     + counts.get("cg_iterations", 0.0) * CG_STREAMS * N * b / world)
                                     / (ms_per_step * 1e-3) / 1e9) if by_kernel else None,
             "roofline": roofline,
             "device_memory_rank0": device_memory,

@@ -46,8 +46,10 @@ int nk_red_scratch(hipStream_t st, NkRedScratch* out) {
     char* p = nullptr;
     e = hipMalloc((void**)&p, bytes);
     if (e != hipSuccess) return nk_set_hip_error(e, "hipMalloc(reduction scratch)");
-    e = hipMemset(p, 0, bytes);
-    if (e != hipSuccess) return nk_set_hip_error(e, "hipMemset(reduction scratch)");
+    // zeroed ON THE LAUNCH STREAM: a plain hipMemset of device memory may still be running when the first kernel of a
+    // non-blocking stream starts, and would then wipe the ticket under it (seen once the scratch grew to 512 KiB)
+    e = hipMemsetAsync(p, 0, bytes, st);
+    if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(reduction scratch)");
     NkRedScratch s;
     s.partial = (double*)p;
     s.ticket = (unsigned int*)(p + sizeof(double) * NK_RED_MAX * NK_RED_MAX_BLOCKS);

@@ -347,14 +347,16 @@ class Minimizer:
 
 
 def _config_track_energy():
-    """Default: the quadratic energy of the iterate is re-evaluated from x.r and x.b every iteration, as the reference
-    does (conjugate_gradient.py:100-101, quadratic_energy.py:31-39) -- the stopping rules then see the energy of the
-    STORED (for fp32 fields: rounded) iterate.  NK_CG_ENERGY_RECURRENCE=1 advances it by dE = -alpha d.r + alpha^2/2 d.q
-    instead (nk_cg_update_dr: one input stream less, -0.8 ms per iteration at 1024^3 fp32); the controllers then make
-    different decisions (measured: 25 -> 28 Newton-CG iterations per step of the benchmark), so it is not the default."""
+    """Default (round 4): the quadratic energy of the iterate advances by dE = -alpha d.r + alpha^2/2 d.q, both dots taken
+    on the way by nk_cg_update_dr -- one input stream less than re-evaluating it from x.r and x.b as the reference does
+    (conjugate_gradient.py:100-101, quadratic_energy.py:31-39; -0.8 ms per iteration at 1024^3 fp32, -1.1 % of a benchmark
+    step).  The same quantity in exact arithmetic, to 1e-16 for fp64 vectors; for fp32 vectors the recurrence is the value the
+    reference's fp64 evaluation would see, while the re-evaluation sees the energy of the ROUNDED iterate.  The controllers
+    took identical decisions both ways in 2 x 25 benchmark steps at 1024^3 fp32 (profiles/r04_trajectory_variants.txt), and
+    every periodic residual refresh (nreset) restarts the recurrence from the vectors.  NK_CG_ENERGY_RECURRENCE=0: re-evaluate."""
     import os
 
-    return os.environ.get("NK_CG_ENERGY_RECURRENCE", "0") == "1"
+    return os.environ.get("NK_CG_ENERGY_RECURRENCE", "1") != "0"
 
 
 class _ScalarEnergyView:
