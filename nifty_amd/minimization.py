@@ -710,24 +710,30 @@ class LineSearch:
         for attempt in range(self.max_iterations):
             if t == 0:
                 return origin.energy, False
+            # only (t, phi, phi') of the previous trial are needed from here on: let its energy go BEFORE the next one is
+            # built (a sampled KL holds one latent vector per sample; three of them alive at once were 57 GB more at
+            # 1024^3 x 8 samples -- 305 of the 309 GB of HBM on the trajectories that probe twice)
+            there = None
             probed = self._probe(origin, t)
             if probed is None:  # not evaluable: come half way back
                 t = 0.5 * (behind[0] + t)
                 continue
             there, phi = probed
             if wolfe.too_high(t, phi) or (attempt > 0 and phi >= behind[1]):
+                there = None
                 return self._zoom(origin, wolfe, behind, (t, phi))
             dphi = there.directional_derivative
             if wolfe.flat_enough(dphi):
                 return there.energy, True
             if dphi >= 0:  # walked past a minimum: it lies between here and the previous point
+                there = None
                 return self._zoom(origin, wolfe, (t, phi, dphi), behind[:2])
             behind, t = (t, phi, dphi), min(2 * t, limit)
             if t == limit:
                 logger.warning("max step size reached")
                 return there.energy, False
         logger.warning("max iterations reached")
-        return there.energy, False
+        return (origin if there is None else there).energy, False
 
     def _zoom(self, origin, wolfe, low, high):
         """Shrinks the bracket between `low` = (t, phi, phi') -- the end with the smaller value, its slope pointing into
@@ -740,6 +746,7 @@ class LineSearch:
         there = None
         for shrink in range(self.max_zoom_iterations):
             t = self._interpolate(lo, phi_lo, dphi_lo, hi, phi_hi, dropped)
+            there = None  # (see perform_line_search: the previous trial's energy goes first)
             there = origin.at(t)
             phi = there.value
             if wolfe.too_high(t, phi) or phi >= phi_lo:
