@@ -100,19 +100,45 @@ NK_HD C2<T> cmul_mi(C2<T> a) {
 // line FFT plan: in-place decimation-in-frequency, mixed radix {8,4,2}; result is left in
 // digit-reversed order and un-reversed by the store phase.
 // ---------------------------------------------------------------------------------------------
+// Division of tile-local indices by a run-time constant: floor(x / d) = (x * ceil(2^32 / d)) >> 32, exact while
+// x * d < 2^32 (indices inside an LDS tile are < 2^16, divisors < 2^13).  The generic kernels decompose an index per
+// element and stage (line / position, butterfly / sub-block, the digits of the reversal): as hardware integer divisions
+// (~40 instructions each) that index arithmetic was most of their run time (mixed-radix grids at 1/5 of the fast path's
+// bandwidth); a multiply-high is one instruction.
+struct NkDiv {
+  uint32_t d, inv;  // inv == 0: d == 1
+};
+static inline NkDiv nk_make_div(int64_t d) {
+  NkDiv v;
+  v.d = (uint32_t)(d < 1 ? 1 : d);
+  v.inv = v.d == 1 ? 0u : (uint32_t)(((uint64_t)1 << 32) / v.d + ((((uint64_t)1 << 32) % v.d) ? 1 : 0));
+  return v;
+}
+NK_HD uint32_t nk_fdiv(uint32_t x, const NkDiv& v) { return v.inv ? (uint32_t)(((uint64_t)x * v.inv) >> 32) : x; }
+// x = q * d + r
+NK_HD void nk_fdivmod(uint32_t x, const NkDiv& v, int& q, int& r) {
+  const uint32_t qq = nk_fdiv(x, v);
+  q = (int)qq;
+  r = (int)(x - qq * v.d);
+}
+
 struct NkLinePlan {
   int n;                       // complex line length (product of radices 8, 4, 2, 3, 5, 7; >= 1)
   int nstage;                  // number of DIF stages
   int radix[NK_MAX_STAGES];    // radices in execution order
+  int span[NK_MAX_STAGES];     // n / (radix[0] * ... * radix[s]): sub-block length AFTER stage s (= Lr of stage s)
+  NkDiv dradix[NK_MAX_STAGES]; // / radix[s]
+  NkDiv dspan[NK_MAX_STAGES];  // / span[s]
+  NkDiv dnbf[NK_MAX_STAGES];   // / (n / radix[s]): butterflies per line of stage s
 };
 
 NK_HD int nk_digit_reverse(const NkLinePlan& lp, int k) {
-  int p = 0, span = lp.n;
+  int p = 0;
   for (int s = 0; s < lp.nstage; ++s) {
-    const int R = lp.radix[s];
-    span /= R;
-    p += (k % R) * span;
-    k /= R;
+    int q, r;
+    nk_fdivmod((uint32_t)k, lp.dradix[s], q, r);
+    p += r * lp.span[s];
+    k = q;
   }
   return p;
 }
@@ -125,6 +151,7 @@ struct NkTile {
   int t_fastest;   // 1: lanes run over t first
   int tstride;     // t_fastest: row pitch (>= tile)
   int lstride;     // !t_fastest: line pitch (>= n + n/16)
+  NkDiv dtile;     // / tile
 };
 
 NK_HD int nk_lds_addr(const NkTile& tl, int pos, int t) {
@@ -244,22 +271,21 @@ struct Butterfly<T, 7> : ButterflyOdd<T, 7> {};
 // one in-place DIF stage of radix R on sub-blocks of length L for all `tile` lines in LDS
 template <typename T, int R>
 NK_HD void nk_dif_stage(C2<T>* lds, int tid, int nthr, const NkLinePlan& lp, const NkTile& tl, int L,
-                        const C2<T>* __restrict__ tw) {
+                        const C2<T>* __restrict__ tw, int stage) {
   const int nbf = lp.n / R;  // butterflies per line
-  const int Lr = L / R;
+  const int Lr = lp.span[stage];  // = L / R
   const int total = nbf * tl.tile;
   const int twstep = lp.n / L;
+  const NkDiv dtile = tl.dtile, dnbf = lp.dnbf[stage], dlr = lp.dspan[stage];
   for (int idx = tid; idx < total; idx += nthr) {
     int t, bf;
     if (tl.t_fastest) {
-      t = idx % tl.tile;
-      bf = idx / tl.tile;
+      nk_fdivmod((uint32_t)idx, dtile, bf, t);
     } else {
-      bf = idx % nbf;
-      t = idx / nbf;
+      nk_fdivmod((uint32_t)idx, dnbf, t, bf);
     }
-    const int blk = bf / Lr;
-    const int j = bf - blk * Lr;
+    int blk, j;
+    nk_fdivmod((uint32_t)bf, dlr, blk, j);
     const int base = blk * L + j;
     C2<T> v[R];
 #pragma unroll

@@ -28,7 +28,7 @@ __device__ __forceinline__ void nk_run_stages(C2<T>* lds, int tid, int nthr, con
   int L = lp.n;
   for (int s = 0; s < lp.nstage; ++s) {
     const int R = lp.radix[s];
-    NK_STAGE_DISPATCH(R, lds, tid, nthr, lp, tl, L, tw)
+    NK_STAGE_DISPATCH(R, lds, tid, nthr, lp, tl, L, tw, s)
     L /= R;
     __syncthreads();
   }
@@ -374,6 +374,7 @@ static int nk_launch_strided_pc(NkPassS ps, const NkFuse& f, const C2<T>* tw, C2
     if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k2_strided)");
   }
   ps.tl.tile = ST::TILE;
+  ps.tl.dtile = nk_make_div(ST::TILE);
   ps.tiles_per_slab = (int)(ps.inner / ST::TILE);
   const int64_t blocks = ps.outer * ps.tiles_per_slab;
   static const int xmap_env = nk_env_int("NK_XMAP", NK_XMAP_DEFAULT);
@@ -585,6 +586,7 @@ static int nk_launch_mid(NkPassM pm, const NkFuse& f, const C2<T>* tw, C2<T>* wo
     if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k3_mid)");
   }
   pm.s.tl.tile = ST::TILE;
+  pm.s.tl.dtile = nk_make_div(ST::TILE);
   pm.s.tiles_per_slab = (int)(pm.s.inner / ST::TILE);
   const int64_t blocks = pm.s.outer * pm.s.tiles_per_slab;
   static const int xmap_env = nk_env_int("NK_XMAP", NK_XMAP_DEFAULT);
@@ -632,6 +634,7 @@ struct NkPassCC {
   int64_t nlines;
   int swap;
   double scale;
+  NkDiv dn;  // / lp.n
 };
 
 template <typename T>
@@ -642,7 +645,8 @@ __global__ void __launch_bounds__(nk_gen_max_threads<T>()) k_c2c_contig(NkPassCC
   const int n = p.lp.n, tile = p.tl.tile;
   const int64_t line0 = (int64_t)blockIdx.x * tile;
   for (int idx = threadIdx.x; idx < tile * n; idx += blockDim.x) {
-    const int j = idx % n, t = idx / n;
+    int j, t;
+    nk_fdivmod((uint32_t)idx, p.dn, t, j);
     C2<T> z{(T)0, (T)0};
     if (line0 + t < p.nlines) z = in[(line0 + t) * n + j];
     if (p.swap) z = C2<T>{z.y, z.x};
@@ -652,7 +656,8 @@ __global__ void __launch_bounds__(nk_gen_max_threads<T>()) k_c2c_contig(NkPassCC
   nk_run_stages<T>(lds, threadIdx.x, blockDim.x, p.lp, p.tl, tw);
   const T sc = (T)p.scale;
   for (int idx = threadIdx.x; idx < tile * n; idx += blockDim.x) {
-    const int k = idx % n, t = idx / n;
+    int k, t;
+    nk_fdivmod((uint32_t)idx, p.dn, t, k);
     if (line0 + t >= p.nlines) continue;
     C2<T> z = lds[nk_lds_addr(p.tl, nk_digit_reverse(p.lp, k), t)];
     if (p.swap) z = C2<T>{z.y, z.x};
@@ -669,19 +674,22 @@ __global__ void __launch_bounds__(nk_gen_max_threads<T>()) k_c2c_strided(NkPassS
   const int64_t o = blockIdx.x / p.tiles_per_slab;
   const int64_t c0 = (blockIdx.x % p.tiles_per_slab) * (int64_t)tile;
   C2<T>* base = data + o * n * p.inner + c0;
+  const int valid = nk_tile_columns(p, c0);
   for (int idx = threadIdx.x; idx < tile * n; idx += blockDim.x) {
-    const int t = idx % tile, j = idx / tile;
-    C2<T> z = base[(int64_t)j * p.inner + t];
+    int t, j;
+    nk_fdivmod((uint32_t)idx, p.tl.dtile, j, t);
+    C2<T> z = t < valid ? base[(int64_t)j * p.inner + t] : C2<T>{(T)0, (T)0};
     if (swap) z = C2<T>{z.y, z.x};
     lds[nk_lds_addr(p.tl, j, t)] = z;
   }
   __syncthreads();
   nk_run_stages<T>(lds, threadIdx.x, blockDim.x, p.lp, p.tl, tw);
   for (int idx = threadIdx.x; idx < tile * n; idx += blockDim.x) {
-    const int t = idx % tile, k = idx / tile;
+    int t, k;
+    nk_fdivmod((uint32_t)idx, p.tl.dtile, k, t);
     C2<T> z = lds[nk_lds_addr(p.tl, nk_digit_reverse(p.lp, k), t)];
     if (swap) z = C2<T>{z.y, z.x};
-    base[(int64_t)k * p.inner + t] = z;
+    if (t < valid) base[(int64_t)k * p.inner + t] = z;
   }
 }
 
@@ -766,6 +774,7 @@ extern "C" int nk_plan_create(nk_plan** out, int ndim, const int64_t* shape, int
       P->cc.lp.n = 0;  // c2c unsupported for this length (Hartley still fine)
     } else {
       P->cc.lp = nk_make_line_plan(g.nl);
+      P->cc.dn = nk_make_div(g.nl);
       const int lstride = g.nl + g.nl / 16 + 1;
       const size_t line_bytes = (size_t)lstride * cs;
       int64_t tile = (int64_t)(32 * 1024 / line_bytes);
@@ -775,6 +784,7 @@ extern "C" int nk_plan_create(nk_plan** out, int ndim, const int64_t* shape, int
       P->cc.nlines = batch * g.na * g.nm;
       if (tile > P->cc.nlines) tile = P->cc.nlines;
       P->cc.tl.tile = (int)tile;
+      P->cc.tl.dtile = nk_make_div((int)tile);
       P->cc.tl.t_fastest = 0;
       P->cc.tl.lstride = lstride;
       P->lds_cc = (size_t)tile * line_bytes;
@@ -789,9 +799,10 @@ extern "C" int nk_plan_create(nk_plan** out, int ndim, const int64_t* shape, int
         ps.inner = inner;
         const int T = nk_pick_strided_tile(n, inner, cs, "NK_TILE_C2C");
         ps.tl.tile = T;
+        ps.tl.dtile = nk_make_div(T);
         ps.tl.t_fastest = 1;
         ps.tl.tstride = T;
-        ps.tiles_per_slab = (int)(inner / T);
+        ps.tiles_per_slab = (int)((inner + T - 1) / T);
         lds = (size_t)n * T * cs;
         threads = nk_round_threads((int64_t)n * T / 4);
       };

@@ -21,6 +21,7 @@ struct NkPassA {
   NkLinePlan lp;   // n = h
   NkTile tl;       // contiguous layout
   int64_t nlines;  // batch * na * nm
+  NkDiv dh, dnk;   // / h, / (h / 2 + 1): index decomposition of the load / store phases
 };
 
 // load `tile` real lines, apply the prologue, store as complex pairs (natural order) in LDS
@@ -30,7 +31,8 @@ NK_HD void nk_passA_load(const NkPassA& p, const NkFuse& f, int64_t blk, int tid
   const int total = p.tl.tile * h;
   const int64_t line0 = blk * p.tl.tile;
   for (int idx = tid; idx < total; idx += nthr) {
-    const int j = idx % h, t = idx / h;
+    int j, t;
+    nk_fdivmod((uint32_t)idx, p.dh, t, j);
     const int64_t line = line0 + t;
     C2<T> z{(T)0, (T)0};
     if (line < p.nlines) {
@@ -64,7 +66,8 @@ NK_HD void nk_passA_store(const NkPassA& p, int64_t blk, int tid, int nthr, cons
   const int total = p.tl.tile * nk;
   const int64_t line0 = blk * p.tl.tile;
   for (int idx = tid; idx < total; idx += nthr) {
-    const int k = idx % nk, t = idx / nk;
+    int k, t;
+    nk_fdivmod((uint32_t)idx, p.dnk, t, k);
     const int64_t line = line0 + t;
     if (line >= p.nlines) continue;
     C2<T>* dst = work + line * h;
@@ -90,7 +93,8 @@ NK_HD void nk_pass1d_store(const NkPassA& p, const NkFuse& f, int64_t blk, int t
   const int total = p.tl.tile * nk;
   const int64_t line0 = blk * p.tl.tile;
   for (int idx = tid; idx < total; idx += nthr) {
-    const int k = idx % nk, t = idx / nk;
+    int k, t;
+    nk_fdivmod((uint32_t)idx, p.dnk, t, k);
     const int64_t line = line0 + t;
     if (line >= p.nlines) continue;
     const int64_t o = line * nl;
@@ -119,6 +123,12 @@ struct NkPassS {
   int64_t ss;          // ... and its slab stride in elements (>= slab size: padding de-aliases the power-of-two strides)
 };
 
+// columns of the tile that starts at column c0 of its slab which exist (tiles need not divide the slab width)
+NK_HD int nk_tile_columns(const NkPassS& p, int64_t c0) {
+  const int64_t left = p.inner - c0;
+  return left < p.tl.tile ? (int)left : p.tl.tile;
+}
+
 template <typename T>
 NK_HD void nk_passS_load(const NkPassS& p, int64_t blk, int tid, int nthr, C2<T>* lds,
                          const C2<T>* __restrict__ work) {
@@ -127,9 +137,11 @@ NK_HD void nk_passS_load(const NkPassS& p, int64_t blk, int tid, int nthr, C2<T>
   const int64_t c0 = (blk % p.tiles_per_slab) * (int64_t)tile;
   const C2<T>* src = work + o * n * p.inner + c0;
   const int total = n * tile;
+  const int valid = nk_tile_columns(p, c0);  // (the last tile of a slab may hang over its end: those columns are zeros)
   for (int idx = tid; idx < total; idx += nthr) {
-    const int t = idx % tile, j = idx / tile;
-    lds[nk_lds_addr(p.tl, j, t)] = src[(int64_t)j * p.inner + t];
+    int t, j;
+    nk_fdivmod((uint32_t)idx, p.tl.dtile, j, t);
+    lds[nk_lds_addr(p.tl, j, t)] = t < valid ? src[(int64_t)j * p.inner + t] : C2<T>{(T)0, (T)0};
   }
 }
 
@@ -141,9 +153,11 @@ NK_HD void nk_passB_store(const NkPassS& p, int64_t blk, int tid, int nthr, cons
   const int64_t c0 = (blk % p.tiles_per_slab) * (int64_t)tile;
   C2<T>* dst = work + o * n * p.inner + c0;
   const int total = n * tile;
+  const int valid = nk_tile_columns(p, c0);
   for (int idx = tid; idx < total; idx += nthr) {
-    const int t = idx % tile, k = idx / tile;
-    dst[(int64_t)k * p.inner + t] = lds[nk_lds_addr(p.tl, nk_digit_reverse(p.lp, k), t)];
+    int t, k;
+    nk_fdivmod((uint32_t)idx, p.tl.dtile, k, t);
+    if (t < valid) dst[(int64_t)k * p.inner + t] = lds[nk_lds_addr(p.tl, nk_digit_reverse(p.lp, k), t)];
   }
 }
 
@@ -156,10 +170,17 @@ NK_HD void nk_passC_store(const NkPassS& p, const NkFuse& f, int64_t blk, int ti
   const int64_t b = blk / p.tiles_per_slab;
   const int64_t c0 = (blk % p.tiles_per_slab) * (int64_t)tile;
   const int total = na * tile;
+  const int m0 = (int)(c0 / h), kl0 = (int)(c0 % h);  // (once per workgroup; the columns of the tile follow by counting)
+  const int valid = nk_tile_columns(p, c0);
   for (int idx = tid; idx < total; idx += nthr) {
-    const int t = idx % tile, k0 = idx / tile;
-    const int64_t c = c0 + t;
-    const int m = (int)(c / h), kl = (int)(c % h);
+    int t, k0;
+    nk_fdivmod((uint32_t)idx, p.tl.dtile, k0, t);
+    if (t >= valid) continue;
+    int m = m0, kl = kl0 + t;
+    while (kl >= h) {
+      kl -= h;
+      ++m;
+    }
     const C2<T> F = lds[nk_lds_addr(p.tl, nk_digit_reverse(p.lp, k0), t)];
     if (kl == 0) {
       scratch[(b * nm + m) * na + k0] = F;

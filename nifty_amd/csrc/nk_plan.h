@@ -32,6 +32,14 @@ static inline NkLinePlan nk_make_line_plan(int n) {
     lp.radix[lp.nstage++] = R;
     rem /= R;
   }
+  int span = n;
+  for (int s = 0; s < lp.nstage; ++s) {  // what the kernels divide by, as multiply-high constants (NkDiv)
+    span /= lp.radix[s];
+    lp.span[s] = span;
+    lp.dradix[s] = nk_make_div(lp.radix[s]);
+    lp.dspan[s] = nk_make_div(span);
+    lp.dnbf[s] = nk_make_div(n / lp.radix[s]);
+  }
   return lp;
 }
 static inline bool nk_factorable(int64_t n) { return n >= 1 && n < ((int64_t)1 << 30) && nk_make_line_plan((int)n).nstage >= 0; }
@@ -76,12 +84,15 @@ static inline int nk_round_threads(int64_t work) {
   return (int)t;
 }
 
-// strided tile: largest power-of-two T <= inner with n*T*csize <= budget and T*csize <= 256 B
+// strided tile: largest power-of-two T <= inner with n*T*csize <= budget and T*csize <= 256 B.  The tile need not divide
+// the slab width (the last tile of a slab is cut short, nk_tile_columns): a width like 500 = 4 * 125 used to end up with
+// rows of four elements (32 B per request).  NK_TILE_DIVIDES=1 restores the old rule.
 static inline int nk_pick_strided_tile(int n, int64_t inner, size_t csize, const char* env) {
   int forced = nk_env_int(env, 0);
   size_t budget = 64 * 1024;
   int T = 1;
-  auto fits = [&](int t) { return (int64_t)t <= inner && inner % t == 0; };  // tiles must divide the row count
+  static const int divides = nk_env_int("NK_TILE_DIVIDES", 0);
+  auto fits = [&](int t) { return (int64_t)t <= inner && (!divides || inner % t == 0); };
   while (fits(T * 2) && (size_t)n * (T * 2) * csize <= budget && (size_t)(T * 2) * csize <= 256) T *= 2;
   if ((size_t)T * csize < 64) {  // rows shorter than 64 B: allow one workgroup per CU
     budget = 128 * 1024;
@@ -163,6 +174,9 @@ static inline int nk_host_plan_init(NkHostPlan& P, int ndim, const int64_t* shap
     P.pa.tl.t_fastest = 0;
     P.pa.tl.tstride = 0;
     P.pa.tl.lstride = lstride;
+    P.pa.tl.dtile = nk_make_div(tile);
+    P.pa.dh = nk_make_div(g.h);
+    P.pa.dnk = nk_make_div(g.h / 2 + 1);
     P.lds_a = (size_t)tile * line_bytes;
     P.threads_a = nk_round_threads(tile * g.h / 4);
     int ft = nk_env_int("NK_THREADS_A", 0);
@@ -183,7 +197,8 @@ static inline int nk_host_plan_init(NkHostPlan& P, int ndim, const int64_t* shap
     ps.tl.t_fastest = 1;
     ps.tl.tstride = T;
     ps.tl.lstride = 0;
-    ps.tiles_per_slab = (int)(inner / T);
+    ps.tl.dtile = nk_make_div(T);
+    ps.tiles_per_slab = (int)((inner + T - 1) / T);
     lds = (size_t)n * T * P.csize;
     threads = nk_round_threads((int64_t)n * T / 4);
     int ft = nk_env_int("NK_THREADS_S", 0);

@@ -23,7 +23,7 @@ static void run_stages(C2<T>* lds, int nthr, const NkLinePlan& lp, const NkTile&
   for (int s = 0; s < lp.nstage; ++s) {
     const int R = lp.radix[s];
     for (int tid = 0; tid < nthr; ++tid) {
-      NK_STAGE_DISPATCH(R, lds, tid, nthr, lp, tl, L, tw)
+      NK_STAGE_DISPATCH(R, lds, tid, nthr, lp, tl, L, tw, s)
     }
     L /= R;
   }
@@ -99,6 +99,7 @@ template <typename T, int N, int MODE>
 static void emu2_strided_m(NkPassS p, const nk_fuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch, double* energy) {
   using ST = StridedTile<T, N, false, MODE>;
   p.tl.tile = ST::TILE;
+  p.tl.dtile = nk_make_div(ST::TILE);
   p.tiles_per_slab = (int)(p.inner / ST::TILE);
   std::vector<T> plane(StridedTile<T, N, true>::LDS_BYTES / sizeof(T));  // room for the complex-plane classes
   const int64_t blocks = p.outer * p.tiles_per_slab;
@@ -231,6 +232,7 @@ static void emu3_mid(NkPassM pm, const nk_fuse& f, const C2<T>* tw, C2<T>* work,
   using STW = StridedTile<T, N, false, 0>;
   const int tile = wide ? STW::TILE : STN::TILE, threads = wide ? STW::THREADS : STN::THREADS;
   pm.s.tl.tile = tile;
+  pm.s.tl.dtile = nk_make_div(tile);
   pm.s.tiles_per_slab = (int)(pm.s.inner / tile);
   std::vector<T> plane(N * STN::TILE * 2 + 16);
   const int64_t blocks = pm.s.outer * pm.s.tiles_per_slab;
