@@ -89,13 +89,15 @@ static inline int nk_round_threads(int64_t work) {
 // rows of four elements (32 B per request).  NK_TILE_DIVIDES=1 restores the old rule.
 static inline int nk_pick_strided_tile(int n, int64_t inner, size_t csize, const char* env) {
   int forced = nk_env_int(env, 0);
-  size_t budget = 64 * 1024;
+  // 128 KiB of LDS per workgroup (one workgroup per CU): rows of 16 columns for lines of 768 ... 1000 fp32 elements beat two
+  // resident workgroups with rows of 8 (768^3: -12 %, profiles/r04_generic_sweep.log)
+  size_t budget = 128 * 1024;
   int T = 1;
   static const int divides = nk_env_int("NK_TILE_DIVIDES", 0);
   auto fits = [&](int t) { return (int64_t)t <= inner && (!divides || inner % t == 0); };
   while (fits(T * 2) && (size_t)n * (T * 2) * csize <= budget && (size_t)(T * 2) * csize <= 256) T *= 2;
-  if ((size_t)T * csize < 64) {  // rows shorter than 64 B: allow one workgroup per CU
-    budget = 128 * 1024;
+  if ((size_t)T * csize < 64) {  // rows shorter than 64 B: all the LDS a workgroup can have
+    budget = 152 * 1024;
     while (fits(T * 2) && (size_t)n * (T * 2) * csize <= budget && (size_t)(T * 2) * csize <= 256) T *= 2;
   }
   if (forced > 0) {
@@ -164,7 +166,7 @@ static inline int nk_host_plan_init(NkHostPlan& P, int ndim, const int64_t* shap
     const int lstride = g.h + g.h / 16 + 1;
     const size_t line_bytes = (size_t)lstride * P.csize;
     int64_t tile = (int64_t)(32 * 1024 / line_bytes);
-    const int64_t want = (2048 + g.h - 1) / g.h;  // at least ~2048 complex elements per workgroup
+    const int64_t want = (3072 + g.h - 1) / g.h;  // ~3072 complex elements per workgroup, 12 per thread (sweep: r04_generic_sweep.log)
     if (tile > want) tile = want;
     if (tile < 1) tile = 1;
     if (tile > P.pa.nlines) tile = P.pa.nlines;
@@ -178,7 +180,8 @@ static inline int nk_host_plan_init(NkHostPlan& P, int ndim, const int64_t* shap
     P.pa.dh = nk_make_div(g.h);
     P.pa.dnk = nk_make_div(g.h / 2 + 1);
     P.lds_a = (size_t)tile * line_bytes;
-    P.threads_a = nk_round_threads(tile * g.h / 4);
+    P.threads_a = nk_round_threads(tile * g.h / 12);
+    if (P.threads_a > 256) P.threads_a = 256;
     int ft = nk_env_int("NK_THREADS_A", 0);
     if (ft >= 64) P.threads_a = ft;
   }
@@ -201,6 +204,7 @@ static inline int nk_host_plan_init(NkHostPlan& P, int ndim, const int64_t* shap
     ps.tiles_per_slab = (int)((inner + T - 1) / T);
     lds = (size_t)n * T * P.csize;
     threads = nk_round_threads((int64_t)n * T / 4);
+    if (threads > 512) threads = 512;  // (1024-thread workgroups: +10 % on the strided passes of 768^3)
     int ft = nk_env_int("NK_THREADS_S", 0);
     if (ft >= 64) threads = ft;
     nk_fill_twiddle(tw, n, n);
