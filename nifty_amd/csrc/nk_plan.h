@@ -7,30 +7,70 @@
 
 #include "nk_fft_phases.h"
 
-// radices 8/4/2 first, then the odd ones; nstage = -1 when n has a prime factor > 7 or needs too many stages
+// The fewest stages with radices from {15, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2} (every stage is an LDS round trip and a
+// barrier), ties broken towards the smaller sum of radices (the odd and composite butterflies are direct O(R^2) DFTs);
+// executed largest radix first.  nstage = -1 when n has a prime factor > 7 or needs too many stages.
+// NK_COMPOSITE_RADIX=0: radices 8 / 4 / 2 first, then 3, 5, 7 (rounds 1-3).
+static inline bool nk_best_radices(int rem, int depth, int cost, int (&cur)[NK_MAX_STAGES], int& best_n, int& best_cost,
+                                   int (&best)[NK_MAX_STAGES]) {
+  static const int R[] = {15, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+  if (rem == 1) {
+    if (depth < best_n || (depth == best_n && cost < best_cost)) {
+      best_n = depth, best_cost = cost;
+      for (int i = 0; i < depth; ++i) best[i] = cur[i];
+    }
+    return true;
+  }
+  if (depth >= NK_MAX_STAGES || depth >= best_n) return false;
+  bool any = false;
+  for (int r : R) {
+    if (rem % r != 0 || (depth > 0 && r > cur[depth - 1])) continue;  // non-increasing: every multiset once
+    cur[depth] = r;
+    any = nk_best_radices(rem / r, depth + 1, cost + r, cur, best_n, best_cost, best) || any;
+  }
+  return any;
+}
 static inline NkLinePlan nk_make_line_plan(int n) {
   NkLinePlan lp{};
   lp.n = n;
   lp.nstage = 0;
-  int rem = n;
-  while (rem > 1) {
-    int R;
-    if (rem % 8 == 0) R = (rem == 16) ? 4 : 8;  // 8*2 -> 4*4
-    else if (rem % 4 == 0) R = 4;
-    else if (rem % 2 == 0) R = 2;
-    else if (rem % 3 == 0) R = 3;
-    else if (rem % 5 == 0) R = 5;
-    else if (rem % 7 == 0) R = 7;
-    else {
-      lp.nstage = -1;
-      return lp;
+  static const int composite = [] { const char* v = getenv("NK_COMPOSITE_RADIX"); return v ? atoi(v) : 1; }();
+  if (composite) {
+    int cur[NK_MAX_STAGES], best[NK_MAX_STAGES], best_n = NK_MAX_STAGES + 1, best_cost = 1 << 30;
+    int rem = n;
+    for (int p : {2, 3, 5, 7})
+      while (rem % p == 0) rem /= p;
+    if (rem != 1 || n < 1 || (n > 1 && !nk_best_radices(n, 0, 0, cur, best_n, best_cost, best)) || best_n > NK_MAX_STAGES) {
+      if (n != 1) {
+        lp.nstage = -1;
+        return lp;
+      }
+      best_n = 0;
     }
-    if (lp.nstage == NK_MAX_STAGES) {
-      lp.nstage = -1;
-      return lp;
+    if (n == 1) best_n = 0;
+    lp.nstage = best_n;
+    for (int i = 0; i < best_n; ++i) lp.radix[i] = best[i];
+  } else {
+    int rem = n;
+    while (rem > 1) {
+      int R;
+      if (rem % 8 == 0) R = (rem == 16) ? 4 : 8;  // 8*2 -> 4*4
+      else if (rem % 4 == 0) R = 4;
+      else if (rem % 2 == 0) R = 2;
+      else if (rem % 3 == 0) R = 3;
+      else if (rem % 5 == 0) R = 5;
+      else if (rem % 7 == 0) R = 7;
+      else {
+        lp.nstage = -1;
+        return lp;
+      }
+      if (lp.nstage == NK_MAX_STAGES) {
+        lp.nstage = -1;
+        return lp;
+      }
+      lp.radix[lp.nstage++] = R;
+      rem /= R;
     }
-    lp.radix[lp.nstage++] = R;
-    rem /= R;
   }
   int span = n;
   for (int s = 0; s < lp.nstage; ++s) {  // what the kernels divide by, as multiply-high constants (NkDiv)
