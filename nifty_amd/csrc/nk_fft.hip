@@ -797,7 +797,7 @@ extern "C" int nk_plan_create(nk_plan** out, int ndim, const int64_t* shape, int
         ps.lp = nk_make_line_plan(n);
         ps.outer = outer;
         ps.inner = inner;
-        const int T = nk_pick_strided_tile(n, inner, cs, "NK_TILE_C2C");
+        const int T = nk_pick_strided_tile(n, inner, cs, "NK_TILE_C2C", outer);
         ps.tl.tile = T;
         ps.tl.dtile = nk_make_div(T);
         ps.tl.t_fastest = 1;

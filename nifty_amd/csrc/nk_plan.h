@@ -7,10 +7,11 @@
 
 #include "nk_fft_phases.h"
 
-// The fewest stages with radices from {15, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2} (every stage is an LDS round trip and a
-// barrier), ties broken towards the smaller sum of radices (the odd and composite butterflies are direct O(R^2) DFTs);
-// executed largest radix first.  nstage = -1 when n has a prime factor > 7 or needs too many stages.
-// NK_COMPOSITE_RADIX=0: radices 8 / 4 / 2 first, then 3, 5, 7 (rounds 1-3).
+// Default: radices 8 / 4 / 2 first, then 3, 5, 7.  NK_COMPOSITE_RADIX=1: the fewest stages with radices from {15, 12, 10, 9, 8,
+// 7, 6, 5, 4, 3, 2}, ties broken towards the smaller sum of radices, largest radix first -- one LDS round trip and barrier
+// less for most mixed-radix lengths, but the composite butterflies are direct O(R^2) DFTs and cost more than they save
+// (768^3 fp32 8.92 -> 8.57 ms, but 960^3 17.4 -> 18.0, 3000^2 fp64 0.25 -> 0.40 ms; profiles/r04_generic_sweep.log): an
+// experiment kept behind the switch.  nstage = -1 when n has a prime factor > 7 or needs too many stages.
 static inline bool nk_best_radices(int rem, int depth, int cost, int (&cur)[NK_MAX_STAGES], int& best_n, int& best_cost,
                                    int (&best)[NK_MAX_STAGES]) {
   static const int R[] = {15, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2};
@@ -34,7 +35,7 @@ static inline NkLinePlan nk_make_line_plan(int n) {
   NkLinePlan lp{};
   lp.n = n;
   lp.nstage = 0;
-  static const int composite = [] { const char* v = getenv("NK_COMPOSITE_RADIX"); return v ? atoi(v) : 1; }();
+  static const int composite = [] { const char* v = getenv("NK_COMPOSITE_RADIX"); return v ? atoi(v) : 0; }();
   if (composite) {
     int cur[NK_MAX_STAGES], best[NK_MAX_STAGES], best_n = NK_MAX_STAGES + 1, best_cost = 1 << 30;
     int rem = n;
@@ -127,7 +128,7 @@ static inline int nk_round_threads(int64_t work) {
 // strided tile: largest power-of-two T <= inner with n*T*csize <= budget and T*csize <= 256 B.  The tile need not divide
 // the slab width (the last tile of a slab is cut short, nk_tile_columns): a width like 500 = 4 * 125 used to end up with
 // rows of four elements (32 B per request).  NK_TILE_DIVIDES=1 restores the old rule.
-static inline int nk_pick_strided_tile(int n, int64_t inner, size_t csize, const char* env) {
+static inline int nk_pick_strided_tile(int n, int64_t inner, size_t csize, const char* env, int64_t outer = 1 << 20) {
   int forced = nk_env_int(env, 0);
   // 128 KiB of LDS per workgroup (one workgroup per CU): rows of 16 columns for lines of 768 ... 1000 fp32 elements beat two
   // resident workgroups with rows of 8 (768^3: -12 %, profiles/r04_generic_sweep.log)
@@ -140,6 +141,8 @@ static inline int nk_pick_strided_tile(int n, int64_t inner, size_t csize, const
     budget = 152 * 1024;
     while (fits(T * 2) && (size_t)n * (T * 2) * csize <= budget && (size_t)(T * 2) * csize <= 256) T *= 2;
   }
+  // small problems: rather narrower tiles than fewer workgroups than CUs (1000^2 fp64: 63 workgroups with rows of 8)
+  while (T > 4 && outer * ((inner + T - 1) / T) < 256) T /= 2;
   if (forced > 0) {
     T = 1;
     while (T * 2 <= forced && fits(T * 2) && (size_t)n * (T * 2) * csize <= 152 * 1024) T *= 2;
@@ -235,7 +238,7 @@ static inline int nk_host_plan_init(NkHostPlan& P, int ndim, const int64_t* shap
     ps.lp = nk_make_line_plan(n);
     ps.outer = outer;
     ps.inner = inner;
-    const int T = nk_pick_strided_tile(n, inner, P.csize, env);
+    const int T = nk_pick_strided_tile(n, inner, P.csize, env, outer);
     ps.tl.tile = T;
     ps.tl.t_fastest = 1;
     ps.tl.tstride = T;
