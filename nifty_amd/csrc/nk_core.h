@@ -123,7 +123,7 @@ NK_HD void nk_fdivmod(uint32_t x, const NkDiv& v, int& q, int& r) {
 }
 
 struct NkLinePlan {
-  int n;                       // complex line length (product of radices 15, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2; >= 1)
+  int n;                       // complex line length (product of radices 8, 4, 2, 3, 5, 7; >= 1)
   int nstage;                  // number of DIF stages
   int radix[NK_MAX_STAGES];    // radices in execution order
   int span[NK_MAX_STAGES];     // n / (radix[0] * ... * radix[s]): sub-block length AFTER stage s (= Lr of stage s)
@@ -230,33 +230,6 @@ struct NkRoot<7> {
   static constexpr double s[7] = {0.0, 0.78183148246802980871, 0.97492791218182360702, 0.43388373911755812048,
                                   -0.43388373911755812048, -0.97492791218182360702, -0.78183148246802980871};
 };
-// composite radices 6, 9, 10, 12, 15 (same direct DFT: the stages are bound by their LDS round trips and barriers, not by
-// arithmetic -- one stage of radix 12 instead of a radix-4 and a radix-3 stage is a barrier and a round trip less)
-template <>
-struct NkRoot<6> {
-  static constexpr double c[6] = {1.0, 0.5, -0.5, -1.0, -0.5, 0.5};
-  static constexpr double s[6] = {0.0, 0.866025403784438646764, 0.866025403784438646764, 0.0, -0.866025403784438646764, -0.866025403784438646764};
-};
-template <>
-struct NkRoot<9> {
-  static constexpr double c[9] = {1.0, 0.766044443118978035202, 0.173648177666930348852, -0.5, -0.939692620785908384054, -0.939692620785908384054, -0.5, 0.173648177666930348852, 0.766044443118978035202};
-  static constexpr double s[9] = {0.0, 0.642787609686539326323, 0.984807753012208059367, 0.866025403784438646764, 0.342020143325668733044, -0.342020143325668733044, -0.866025403784438646764, -0.984807753012208059367, -0.642787609686539326323};
-};
-template <>
-struct NkRoot<10> {
-  static constexpr double c[10] = {1.0, 0.809016994374947424102, 0.309016994374947424102, -0.309016994374947424102, -0.809016994374947424102, -1.0, -0.809016994374947424102, -0.309016994374947424102, 0.309016994374947424102, 0.809016994374947424102};
-  static constexpr double s[10] = {0.0, 0.587785252292473129169, 0.951056516295153572116, 0.951056516295153572116, 0.587785252292473129169, 0.0, -0.587785252292473129169, -0.951056516295153572116, -0.951056516295153572116, -0.587785252292473129169};
-};
-template <>
-struct NkRoot<12> {
-  static constexpr double c[12] = {1.0, 0.866025403784438646764, 0.5, 0.0, -0.5, -0.866025403784438646764, -1.0, -0.866025403784438646764, -0.5, 0.0, 0.5, 0.866025403784438646764};
-  static constexpr double s[12] = {0.0, 0.5, 0.866025403784438646764, 1.0, 0.866025403784438646764, 0.5, 0.0, -0.5, -0.866025403784438646764, -1.0, -0.866025403784438646764, -0.5};
-};
-template <>
-struct NkRoot<15> {
-  static constexpr double c[15] = {1.0, 0.913545457642600895502, 0.669130606358858213826, 0.309016994374947424102, -0.1045284632676534714, -0.5, -0.809016994374947424102, -0.978147600733805637929, -0.978147600733805637929, -0.809016994374947424102, -0.5, -0.1045284632676534714, 0.309016994374947424102, 0.669130606358858213826, 0.913545457642600895502};
-  static constexpr double s[15] = {0.0, 0.406736643075800207754, 0.743144825477394235015, 0.951056516295153572116, 0.994521895368273336923, 0.866025403784438646764, 0.587785252292473129169, 0.207911690817759337102, -0.207911690817759337102, -0.587785252292473129169, -0.866025403784438646764, -0.994521895368273336923, -0.951056516295153572116, -0.743144825477394235015, -0.406736643075800207754};
-};
 template <typename T, int R>
 struct ButterflyOdd {
   static NK_HD void run(C2<T>* v) {
@@ -283,16 +256,6 @@ template <typename T>
 struct Butterfly<T, 5> : ButterflyOdd<T, 5> {};
 template <typename T>
 struct Butterfly<T, 7> : ButterflyOdd<T, 7> {};
-template <typename T>
-struct Butterfly<T, 6> : ButterflyOdd<T, 6> {};
-template <typename T>
-struct Butterfly<T, 9> : ButterflyOdd<T, 9> {};
-template <typename T>
-struct Butterfly<T, 10> : ButterflyOdd<T, 10> {};
-template <typename T>
-struct Butterfly<T, 12> : ButterflyOdd<T, 12> {};
-template <typename T>
-struct Butterfly<T, 15> : ButterflyOdd<T, 15> {};
 
 // run-time radix -> compile-time stage
 #define NK_STAGE_DISPATCH(RADIX, ...)                       \
@@ -302,11 +265,6 @@ struct Butterfly<T, 15> : ButterflyOdd<T, 15> {};
     case 2: nk_dif_stage<T, 2>(__VA_ARGS__); break;         \
     case 3: nk_dif_stage<T, 3>(__VA_ARGS__); break;         \
     case 5: nk_dif_stage<T, 5>(__VA_ARGS__); break;         \
-    case 6: nk_dif_stage<T, 6>(__VA_ARGS__); break;         \
-    case 9: nk_dif_stage<T, 9>(__VA_ARGS__); break;         \
-    case 10: nk_dif_stage<T, 10>(__VA_ARGS__); break;       \
-    case 12: nk_dif_stage<T, 12>(__VA_ARGS__); break;       \
-    case 15: nk_dif_stage<T, 15>(__VA_ARGS__); break;       \
     default: nk_dif_stage<T, 7>(__VA_ARGS__); break;        \
   }
 
@@ -334,17 +292,12 @@ NK_HD void nk_dif_stage(C2<T>* lds, int tid, int nthr, const NkLinePlan& lp, con
     for (int r = 0; r < R; ++r) v[r] = lds[nk_lds_addr(tl, base + r * Lr, t)];
     Butterfly<T, R>::run(v);
     if (Lr > 1) {
-      if constexpr (R > 8) {  // W^(j r) straight from the table (j r twstep < n): no error growth over 8 ... 14 products
+      const C2<T> w1 = tw[j * twstep];
+      C2<T> w = w1;
 #pragma unroll
-        for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[j * twstep * r]);
-      } else {
-        const C2<T> w1 = tw[j * twstep];
-        C2<T> w = w1;
-#pragma unroll
-        for (int r = 1; r < R; ++r) {
-          v[r] = cmul(v[r], w);
-          if (r + 1 < R) w = cmul(w, w1);
-        }
+      for (int r = 1; r < R; ++r) {
+        v[r] = cmul(v[r], w);
+        if (r + 1 < R) w = cmul(w, w1);
       }
     }
 #pragma unroll

@@ -7,71 +7,34 @@
 
 #include "nk_fft_phases.h"
 
-// Default: radices 8 / 4 / 2 first, then 3, 5, 7.  NK_COMPOSITE_RADIX=1: the fewest stages with radices from {15, 12, 10, 9, 8,
-// 7, 6, 5, 4, 3, 2}, ties broken towards the smaller sum of radices, largest radix first -- one LDS round trip and barrier
-// less for most mixed-radix lengths, but the composite butterflies are direct O(R^2) DFTs and cost more than they save
-// (768^3 fp32 8.92 -> 8.57 ms, but 960^3 17.4 -> 18.0, 3000^2 fp64 0.25 -> 0.40 ms; profiles/r04_generic_sweep.log): an
-// experiment kept behind the switch.  nstage = -1 when n has a prime factor > 7 or needs too many stages.
-static inline bool nk_best_radices(int rem, int depth, int cost, int (&cur)[NK_MAX_STAGES], int& best_n, int& best_cost,
-                                   int (&best)[NK_MAX_STAGES]) {
-  static const int R[] = {15, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2};
-  if (rem == 1) {
-    if (depth < best_n || (depth == best_n && cost < best_cost)) {
-      best_n = depth, best_cost = cost;
-      for (int i = 0; i < depth; ++i) best[i] = cur[i];
-    }
-    return true;
-  }
-  if (depth >= NK_MAX_STAGES || depth >= best_n) return false;
-  bool any = false;
-  for (int r : R) {
-    if (rem % r != 0 || (depth > 0 && r > cur[depth - 1])) continue;  // non-increasing: every multiset once
-    cur[depth] = r;
-    any = nk_best_radices(rem / r, depth + 1, cost + r, cur, best_n, best_cost, best) || any;
-  }
-  return any;
-}
+// radices 8/4/2 first, then the odd ones; nstage = -1 when n has a prime factor > 7 or needs too many stages.
+// (Round 4 tried composite radices 6, 9, 10, 12, 15 with a planner that minimises the number of stages -- 768 = 12*8*8 instead
+// of 8*8*4*3: one LDS round trip and barrier less.  The direct O(R^2) butterflies cost more than that saves (960^3 fp32
+// 17.4 -> 18.0 ms, 3000^2 fp64 0.25 -> 0.40 ms), and their mere presence in the stage switch cost every length 6 % through the
+// kernel's register count; removed again, numbers in profiles/r04_generic_sweep.log.)
 static inline NkLinePlan nk_make_line_plan(int n) {
   NkLinePlan lp{};
   lp.n = n;
   lp.nstage = 0;
-  static const int composite = [] { const char* v = getenv("NK_COMPOSITE_RADIX"); return v ? atoi(v) : 0; }();
-  if (composite) {
-    int cur[NK_MAX_STAGES], best[NK_MAX_STAGES], best_n = NK_MAX_STAGES + 1, best_cost = 1 << 30;
-    int rem = n;
-    for (int p : {2, 3, 5, 7})
-      while (rem % p == 0) rem /= p;
-    if (rem != 1 || n < 1 || (n > 1 && !nk_best_radices(n, 0, 0, cur, best_n, best_cost, best)) || best_n > NK_MAX_STAGES) {
-      if (n != 1) {
-        lp.nstage = -1;
-        return lp;
-      }
-      best_n = 0;
+  int rem = n;
+  while (rem > 1) {
+    int R;
+    if (rem % 8 == 0) R = (rem == 16) ? 4 : 8;  // 8*2 -> 4*4
+    else if (rem % 4 == 0) R = 4;
+    else if (rem % 2 == 0) R = 2;
+    else if (rem % 3 == 0) R = 3;
+    else if (rem % 5 == 0) R = 5;
+    else if (rem % 7 == 0) R = 7;
+    else {
+      lp.nstage = -1;
+      return lp;
     }
-    if (n == 1) best_n = 0;
-    lp.nstage = best_n;
-    for (int i = 0; i < best_n; ++i) lp.radix[i] = best[i];
-  } else {
-    int rem = n;
-    while (rem > 1) {
-      int R;
-      if (rem % 8 == 0) R = (rem == 16) ? 4 : 8;  // 8*2 -> 4*4
-      else if (rem % 4 == 0) R = 4;
-      else if (rem % 2 == 0) R = 2;
-      else if (rem % 3 == 0) R = 3;
-      else if (rem % 5 == 0) R = 5;
-      else if (rem % 7 == 0) R = 7;
-      else {
-        lp.nstage = -1;
-        return lp;
-      }
-      if (lp.nstage == NK_MAX_STAGES) {
-        lp.nstage = -1;
-        return lp;
-      }
-      lp.radix[lp.nstage++] = R;
-      rem /= R;
+    if (lp.nstage == NK_MAX_STAGES) {
+      lp.nstage = -1;
+      return lp;
     }
+    lp.radix[lp.nstage++] = R;
+    rem /= R;
   }
   int span = n;
   for (int s = 0; s < lp.nstage; ++s) {  // what the kernels divide by, as multiply-high constants (NkDiv)

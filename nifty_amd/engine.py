@@ -16,6 +16,7 @@ minimization/kl_energies.py:91-159, 299-360, behind the Energy protocol of minim
 Latent vectors are ``LatentVec``: ``xi`` (the harmonic-space excitations, field dtype) and ``small``
 (float64: asperity, flexibility, fluctuations, loglogavgslope, zeromode, spectrum[2, nb-2]).
 """
+import contextlib
 import ctypes
 import math
 import os
@@ -1660,8 +1661,63 @@ def draw_samples(model, position, n_samples, mirror_samples, controller_factory,
         fit, _ = geo_minimizer(FusedGeoEnergy(model, cache["tp"], target, start))
         return fit.position - position, False
 
-    drawn = plan.run(draw, linear_residual if geo_minimizer is None else fitted_residual)
+    finish = linear_residual if geo_minimizer is None else fitted_residual
+    local_pairs = len({i // 2 if plan.mirror else i for i in range(plan.lo, plan.hi)})
+    lanes = _sampling_lanes(model, local_pairs)
+    if lanes is None:
+        drawn = plan.run(draw, finish)
+    else:
+        drawn = plan.run_together(lambda seed: _draw_sources(model, linearisation(), seed, device_rng),
+                                  lambda jobs: _solve_on_lanes(model, lanes, linearisation(), jobs, controller_factory), finish)
     return [r for r, _ in drawn], [n for _, n in drawn], plan.n_total
+
+
+def _sampling_lanes(model, pairs):
+    """Lanes for the linear solves of an MGVI iteration, or None: small grids only (NK_LANE_MAX_POINTS, default 2^25 points;
+    NK_LANES lanes, default 4, 0 / 1 = off), at least two solves, no response operator (it owns scratch of its own)."""
+    want = int(os.environ.get("NK_LANES", "4"))
+    small = model.N <= int(os.environ.get("NK_LANE_MAX_POINTS", str(1 << 25)))
+    if want < 2 or pairs < 2 or not small or model.response is not None:
+        return None
+    return model.lanes(min(want, pairs))
+
+
+def _draw_sources(model, lp, seed, device_rng):
+    """The random inputs of one linear sample (prior draw s, data-space noise pulled back: nj), in the sample's stream."""
+    if device_rng is not None:
+        device_rng.manual_seed(int(seed.generate_state(1, np.uint64)[0] >> np.uint64(1)))
+    return model.draw_prior(device_rng), model.draw_lh_noise(lp, device_rng)
+
+
+def _solve_on_lanes(model, lanes, lp, jobs, controller_factory):
+    """FusedModel.draw_mgvi_sample for several samples at once: solve j runs on lane j mod K (own scratch, own stream), and
+    minimization.ConjugateGradient.solve_many advances the solves of a wave together.  Same kernels, same arithmetic and
+    the same bits as one solve after the other."""
+    main = torch.cuda.current_stream(model.device)
+    pairs = []
+    for w0 in range(0, len(jobs), len(lanes)):
+        wave = jobs[w0:w0 + len(lanes)]
+        problems = []
+        for lane, (s, nj) in zip(lanes, wave):
+            if lane.stream is not None:
+                lane.stream.wait_stream(main)
+            with (torch.cuda.stream(lane.stream) if lane.stream is not None else contextlib.nullcontext()):
+                b = s + nj
+                g0 = lane.lh_metric(lp, s, minus=nj)
+                A = _Callable(lambda v, dot_out=None, cg_direction=None, lane=lane: lane.metric(lp, v, dot_out=dot_out,
+                                                                                                cg_direction=cg_direction),
+                              fused_dot=lane.octant_vjp, fused_direction=lane.fused_direction)
+                energy = QuadraticEnergy(s, A, b, _grad=g0)
+                energy.consumable = True
+            problems.append((energy, controller_factory(), lane.stream, b))
+        solved = ConjugateGradient(None).solve_many([p[:3] for p in problems])
+        for (energy, _), (_, _, stream, b) in zip(solved, problems):
+            if stream is not None:
+                main.wait_stream(stream)
+                for t in (b.xi, b.small, energy.position.xi, energy.position.small):
+                    t.record_stream(main)
+            pairs.append((b, energy.position))
+    return pairs
 
 
 def mgvi_iteration(model, mean, n_samples, controller_factory, kl_minimizer, mirror_samples=True, comm=None,

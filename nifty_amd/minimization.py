@@ -435,14 +435,51 @@ class ConjugateGradient(Minimizer):
             gamma_prev = gamma
 
     def _solve_inplace(self, energy):
-        controller = self._controller
+        A, b = energy._A, energy._b
+        sm = getattr(A, "sharded", None)
+        if sm is not None and b is not None:
+            status = self._controller.start(energy)
+            if status != CONTINUE:
+                return energy, status
+            return self._solve_inplace_sharded(energy, sm)
+        steps = self._inplace_steps(energy, self._controller)
+        while True:
+            try:
+                next(steps)
+            except StopIteration as done:
+                return done.value
+
+    def solve_many(self, problems):
+        """Several independent in-place solves advanced TOGETHER: `problems` = [(energy, controller, stream or None)], one
+        CG each with its own vectors, scalars and stopping rule; returns [(energy, status)].  Every round enqueues one
+        iteration of every unfinished solve on that solve's stream and only then waits for the scalars of the previous
+        round, so the kernel chains of the solves overlap on the device (small grids: one chain leaves most CUs idle --
+        the linear samples of an MGVI iteration are such independent solves).  The arithmetic of every solve is exactly
+        that of a solve on its own."""
+        import contextlib
+
+        import torch
+
+        runs = [self._inplace_steps(energy, controller) for energy, controller, _ in problems]
+        results, active = [None] * len(problems), list(range(len(problems)))
+        while active:
+            for k in list(active):
+                stream = problems[k][2]
+                with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                    try:
+                        next(runs[k])
+                    except StopIteration as done:
+                        results[k] = done.value
+                        active.remove(k)
+        return results
+
+    def _inplace_steps(self, energy, controller):
+        """The in-place iteration as a generator: it yields after the device work of an iteration is enqueued and before
+        the host waits for its scalars; the generator's return value is (energy, status)."""
         status = controller.start(energy)
         if status != CONTINUE:
             return energy, status
         A, b = energy._A, energy._b
-        sm = getattr(A, "sharded", None)
-        if sm is not None and b is not None:
-            return self._solve_inplace_sharded(energy, sm)
         # the iterate and the residual are updated in place: on private copies -- unless the caller has handed the vectors
         # over (QuadraticEnergy.consumable: nobody else holds the start position / gradient, two N-sized copies less)
         if getattr(energy, "consumable", False):
@@ -506,6 +543,7 @@ class ConjugateGradient(Minimizer):
                 ws.refresh(x, r, b)
                 since_reset = 0
                 refreshed = True
+            yield  # (solve_many: the other solves enqueue their iterations here)
             sc = ws.fetch()  # the single host synchronisation of this iteration
             curv, gamma, alpha = sc["curv"], sc["gamma"], sc["alpha"]
             if np.isnan(curv) or curv == 0.0 or np.isnan(alpha) or alpha < 0:

@@ -515,6 +515,25 @@ class SamplePlan:
         check_MPI_synced_random_state(self.comm)
         check_MPI_equality(self.seeds, self.comm)
 
+    def run_together(self, prepare, solve, finish):
+        """run() for linear samples that are solved TOGETHER: `prepare(seed)` (inside the sample's random context) draws
+        what one pair's solve needs, `solve(list of prepared)` returns the pairs, `finish` as in run()."""
+        from . import random
+
+        jobs, job_of = [], {}
+        for i in range(self.lo, self.hi):
+            mirrored = self.mirror and i % 2 == 1
+            if not jobs or not mirrored:
+                with random.Context(self.seeds[i]):
+                    jobs.append(prepare(self.seeds[i]))
+            job_of[i] = len(jobs) - 1
+        pairs = solve(jobs)
+        out = []
+        for i in range(self.lo, self.hi):
+            with random.Context(self.seeds[i]):
+                out.append(finish(pairs[job_of[i]], self.mirror and i % 2 == 1))
+        return out
+
     def run(self, draw, finish):
         """For every sample of this rank, inside the sample's own random context: `draw()` makes the linear sample of the
         pair unless this rank has just drawn it for the pair's first member; `finish(pair, mirrored)` turns it into the

@@ -139,3 +139,42 @@ def test_lanes_keep_the_pairwise_order(monkeypatch):
     kl4 = kl.at(mean)
     assert len(kl4._lanes) == 4
     assert kl4.value == one[0] and torch.equal(kl4.gradient.xi, one[1]) and torch.equal(kl4.apply_metric(d).xi, one[2])
+
+
+@pytest.mark.parametrize("shape,dtype,likelihood", [((256, 128), torch.float64, "poisson"), ((64, 64, 64), torch.float32, "gaussian")])
+def test_linear_samples_solved_together_equal_one_after_the_other(shape, dtype, likelihood, monkeypatch):
+    """engine.draw_samples on small grids: the CGs of the linear samples advance together on up to four streams
+    (ConjugateGradient.solve_many, one lane of scratch per solve) -- the same residuals, bit for bit, as one solve after
+    the other, including a wave of more solves than lanes."""
+    from nifty_amd import random
+    from nifty_amd.engine import FusedModel, draw_samples
+    from nifty_amd.minimization import AbsDeltaEnergyController
+
+    model = FusedModel(shape, offset_mean=2.0, likelihood=likelihood, icov=100.0, nonlin="exp" if likelihood == "poisson" else None,
+                       dtype=dtype, device="cuda:0")
+    random.push_sseq_from_seed(23)
+    try:
+        truth = model.draw_prior()
+        if likelihood == "poisson":
+            model.set_data(torch.poisson(model.signal(truth).double()).to(torch.int64))
+        else:
+            model.set_data(model.signal(truth), 100.0)
+        mean = 0.1 * model.draw_prior()
+    finally:
+        random.pop_sseq()
+
+    def samples(lanes):
+        monkeypatch.setenv("NK_LANES", str(lanes))
+        random.push_sseq_from_seed(5)
+        try:
+            res, negs, n = draw_samples(model, mean, 5, True, lambda: AbsDeltaEnergyController(0.05, iteration_limit=6))
+        finally:
+            random.pop_sseq()
+        torch.cuda.synchronize()
+        return [(r.xi.clone(), r.small.clone()) for r in res], negs, n
+
+    one, negs1, n1 = samples(0)
+    together, negs4, n4 = samples(4)
+    assert n1 == n4 == 10 and negs1 == negs4
+    for (a_xi, a_small), (b_xi, b_small) in zip(one, together):
+        assert torch.equal(a_xi, b_xi) and torch.equal(a_small, b_small)
