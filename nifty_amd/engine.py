@@ -1693,19 +1693,28 @@ def _solve_on_lanes(model, lanes, lp, jobs, controller_factory):
     """FusedModel.draw_mgvi_sample for several samples at once: solve j runs on lane j mod K (own scratch, own stream), and
     minimization.ConjugateGradient.solve_many advances the solves of a wave together.  Same kernels, same arithmetic and
     the same bits as one solve after the other."""
+    import copy
+
     main = torch.cuda.current_stream(model.device)
     pairs = []
+    # the amplitude kernels keep scalars and scan aggregates of a JVP / VJP in the linearisation point's `state`: every lane
+    # gets a copy of it (everything else of the point is read-only)
+    points = []
+    for lane in lanes:
+        own = copy.copy(lp)
+        own.state = lp.state.clone()
+        points.append(own)
     for w0 in range(0, len(jobs), len(lanes)):
         wave = jobs[w0:w0 + len(lanes)]
         problems = []
-        for lane, (s, nj) in zip(lanes, wave):
+        for lane, lp, (s, nj) in zip(lanes, points, wave):
             if lane.stream is not None:
                 lane.stream.wait_stream(main)
             with (torch.cuda.stream(lane.stream) if lane.stream is not None else contextlib.nullcontext()):
                 b = s + nj
                 g0 = lane.lh_metric(lp, s, minus=nj)
-                A = _Callable(lambda v, dot_out=None, cg_direction=None, lane=lane: lane.metric(lp, v, dot_out=dot_out,
-                                                                                                cg_direction=cg_direction),
+                A = _Callable(lambda v, dot_out=None, cg_direction=None, lane=lane, lp=lp: lane.metric(lp, v, dot_out=dot_out,
+                                                                                                       cg_direction=cg_direction),
                               fused_dot=lane.octant_vjp, fused_direction=lane.fused_direction)
                 energy = QuadraticEnergy(s, A, b, _grad=g0)
                 energy.consumable = True

@@ -141,7 +141,8 @@ def test_lanes_keep_the_pairwise_order(monkeypatch):
     assert kl4.value == one[0] and torch.equal(kl4.gradient.xi, one[1]) and torch.equal(kl4.apply_metric(d).xi, one[2])
 
 
-@pytest.mark.parametrize("shape,dtype,likelihood", [((256, 128), torch.float64, "poisson"), ((64, 64, 64), torch.float32, "gaussian")])
+@pytest.mark.parametrize("shape,dtype,likelihood", [((256, 128), torch.float64, "poisson"), ((64, 64, 64), torch.float32, "gaussian"),
+                                                    ((2048, 1024), torch.float64, "poisson")])
 def test_linear_samples_solved_together_equal_one_after_the_other(shape, dtype, likelihood, monkeypatch):
     """engine.draw_samples on small grids: the CGs of the linear samples advance together on up to four streams
     (ConjugateGradient.solve_many, one lane of scratch per solve) -- the same residuals, bit for bit, as one solve after
@@ -167,7 +168,7 @@ def test_linear_samples_solved_together_equal_one_after_the_other(shape, dtype, 
         monkeypatch.setenv("NK_LANES", str(lanes))
         random.push_sseq_from_seed(5)
         try:
-            res, negs, n = draw_samples(model, mean, 5, True, lambda: AbsDeltaEnergyController(0.05, iteration_limit=6))
+            res, negs, n = draw_samples(model, mean, 5, True, lambda: AbsDeltaEnergyController(0.05, iteration_limit=22))
         finally:
             random.pop_sseq()
         torch.cuda.synchronize()
