@@ -1442,8 +1442,10 @@ class ShardedMetric:
     The three passes in between need the whole array, so at most the first (3.3 ms at 1024^3 fp32) and the final pass
     (4.0 ms) hide communication.  The staged passes and the overlap change no arithmetic: for a given C the results are
     bit-identical with and without them (NK_PIPE_OVERLAP=0), and on one rank for every C.  With several ranks C decides
-    which elements a rank owns, i.e. how the CG's dot products are grouped into per-rank partial sums: results for
-    different C agree to rounding, exactly like results for different rank counts (tests/test_distributed_gloo.py)."""
+    which elements a rank owns; since round 4 that does not enter the rounding either -- the dot products of the sharded
+    vectors are sums of 64 unit sums wherever the units live (ShardedCgWorkspace, nk_red_layout) and the sample sum is the
+    reference's pairwise tree (FusedKL) -- so every C and every rank count give the bits of the single-process run
+    (tests/test_distributed_gloo.py; NK_TREE_SUM=0: agreement to rounding, as in rounds 1-3)."""
 
     def __init__(self, kl):
         self.kl, self.comm, self.model = kl, kl.comm, kl.model
