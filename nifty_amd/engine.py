@@ -753,6 +753,8 @@ class FusedModel:
             plan64 = B.get_plan(self.shape, torch.float64, 1, self.device)
             if not L.load().nk_plan_octant_vjp(plan64.handle):
                 raise RuntimeError("the fp64 plan of this grid has no register-resident pipeline")
+            if self.stream is not None:  # a lane (FusedModel.lanes): the cached plan's WORKSPACE belongs to the main chain
+                plan64 = B.PlanView(plan64)
             afield64 = torch.empty(self.field_shape, dtype=torch.float64, device=self.device)
             dense64 = None if self.k2_dense is None else torch.zeros_like(self.k2_dense, dtype=torch.float64)
             self._wide_state = (plan64, afield64, dense64)

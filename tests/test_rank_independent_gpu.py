@@ -129,11 +129,13 @@ def test_pairwise_sum_inside_the_epilogues_equals_the_tree_of_stored_terms(shape
     assert float((old.xi - got.xi).abs().max()) < tol * float(got.xi.abs().max())
 
 
-def test_lanes_keep_the_pairwise_order(monkeypatch):
+@pytest.mark.parametrize("shape,dtype,likelihood", [((256, 128), torch.float64, "poisson"), ((256, 256, 256), torch.float32, "gaussian")])
+def test_lanes_keep_the_pairwise_order(shape, dtype, likelihood, monkeypatch):
     """Small grids run the samples' chains on several streams (FusedModel.lanes) into one vector per sample: the same
-    bits as the single-stream pairwise sum."""
+    bits as the single-stream pairwise sum -- also with fp32 fields, whose fp64 forward transform needs a workspace per lane
+    (the lanes once shared the cached fp64 plan's: wrong gradients on grids large enough to overlap)."""
     monkeypatch.setenv("NK_LANES", "0")
-    model, mean, d, kl = _kl((256, 128), torch.float64, 4, likelihood="poisson")
+    model, mean, d, kl = _kl(shape, dtype, 4, likelihood=likelihood)
     one = (kl.value, kl.gradient.xi.clone(), kl.apply_metric(d).xi.clone())
     monkeypatch.setenv("NK_LANES", "4")
     kl4 = kl.at(mean)
