@@ -26,9 +26,7 @@ from .domains import DomainTuple, MultiDomain, PowerSpace, RGSpace, Unstructured
 from .engine import SMALL_KEYS, lognormal_moments
 from .field import Field, MultiField, full, makeField
 from .operators import (ContractionOperator, DiagonalOperator, EndomorphicOperator, HarmonicTransformOperator,
-                        LinearOperator, Linearization, Operator, PowerDistributor, ScalingOperator, Variable, VdotOperator,
-                        ducktape,
-                        is_linearization, makeOp)
+                        LinearOperator, Operator, PowerDistributor, Variable, VdotOperator, ducktape, is_linearization, makeOp)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -502,8 +500,6 @@ class _ProductFieldNode(Operator):
 
     MIRROR = {2: (0.5, 0.5, 0.5, -0.5), 3: (0.0, 0.5, 0.5, 0.0, 0.5, 0.0, 0.0, -0.5)}  # index: bit i = sub-space i mirrored
 
-    KEYS = ("xi", "azm")
-
     def __init__(self, hspace, target, amp_targets, azm_target, total_N, offset):
         self._hspace, self._target = makeDomain(hspace), makeDomain(target)
         self._copies = int(total_N)
@@ -578,10 +574,9 @@ class _ProductFieldNode(Operator):
                                            float(offset), B.dtype_code(src), B._stream()), "nk_mirror_combine")
         return dst
 
-    def _rows(self, field, width=None):
+    def _rows(self, field):
         """[copies][...] view of a Field's values (one row when the maker has no leading copy domain)."""
-        v = field.val.contiguous()
-        return v.reshape(max(self._copies, 1), -1) if width is None else v.reshape(max(self._copies, 1), width)
+        return field.val.contiguous().reshape(max(self._copies, 1), -1)
 
     def _inputs(self, v):
         xi = self._rows(v["xi"])
