@@ -671,5 +671,25 @@ def main():
     likelihood_cases()
 
 
+def allreduce_order():
+    """The bracketing of the reference's task-count-independent sum (utilities.py:349-414, comm=None) for 1 .. 20 terms, as
+    strings -- pins nifty_amd.parallel.pair_tree / tree_fold (tests/test_oracle_golden.py)."""
+    import json
+
+    from nifty.cl import utilities as U  # (the reference, made importable by _ref_shim.load() above)
+
+    class Term:
+        def __init__(self, s):
+            self.s = s
+
+        def __add__(self, other):
+            return Term(f"({self.s}+{other.s})")
+
+    out = {str(n): U.allreduce_sum([Term(f"t{i}") for i in range(n)], None).s for n in range(1, 21)}
+    json.dump(out, open(os.path.join(HERE, "allreduce_order.json"), "w"), indent=0)
+    print("wrote allreduce_order", out["7"])
+
+
 if __name__ == "__main__":
     main()
+    allreduce_order()

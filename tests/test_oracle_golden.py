@@ -138,3 +138,18 @@ def test_natural_geometry_shortcut_equals_the_direct_restatement():
         assert np.array_equal(a.pindex, b.pindex) and np.array_equal(a.rho, b.rho)
         assert np.max(np.abs(a.k_lengths - b.k_lengths)) < 1e-13 * a.k_lengths.max()
         assert np.allclose(a.dvol, b.dvol, rtol=0, atol=0) and a.h_dvol == b.h_dvol and a.total_volume == b.total_volume
+
+
+def test_pair_tree_is_the_bracketing_of_the_reference_sum():
+    """parallel.pair_tree / tree_fold add in the order of the reference's allreduce_sum (utilities.py:349-414): the bracketed
+    sums of 1 .. 20 symbolic terms recorded from the reference (tests/golden/allreduce_order.json, make_golden.py)."""
+    import json
+    import os
+
+    from nifty_amd import parallel
+
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "allreduce_order.json")))
+    for n in range(1, 21):
+        got = parallel.tree_fold([f"t{i}" for i in range(n)], lambda a, b: f"({a}+{b})")
+        assert got == want[str(n)], n
+
