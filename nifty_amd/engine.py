@@ -1221,7 +1221,7 @@ class FusedKL(Energy):
         if not self._across:
             comm.allreduce_sum_(list(scalars) + [vec.xi, vec.small])
             return
-        comm.tree_allreduce([list(scalars) + [vec.small]], [1] * comm.size)
+        comm.tree_allreduce_gathered_(list(scalars) + [vec.small])
         if vec.xi.numel() % comm.size == 0:
             comm.tree_allreduce_slices_(vec.xi)
         else:
@@ -1542,7 +1542,7 @@ class ShardedMetric:
 
     def _sum_small(self, small):
         if self.kl._across:
-            self.comm.tree_allreduce([[small]], [1] * self.comm.size)
+            self.comm.tree_allreduce_gathered_([small])
         else:
             self.comm.allreduce_sum_([small])
 
