@@ -1722,7 +1722,12 @@ def _solve_on_lanes(model, lanes, lp, jobs, controller_factory):
                               fused_dot=lane.octant_vjp, fused_direction=lane.fused_direction)
                 energy = QuadraticEnergy(s, A, b, _grad=g0)
                 energy.consumable = True
-            problems.append((energy, controller_factory(), lane.stream, b))
+            controller = controller_factory()
+            if any(controller is other[1] for other in problems):
+                # a caller that hands out ONE controller object (optimize_kl passes the user's sampling controller): solves that
+                # run together must not share its iteration count and convergence state
+                controller = copy.deepcopy(controller)
+            problems.append((energy, controller, lane.stream, b))
         solved = ConjugateGradient(None).solve_many([p[:3] for p in problems])
         for (energy, _), (_, _, stream, b) in zip(solved, problems):
             if stream is not None:

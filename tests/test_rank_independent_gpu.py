@@ -166,11 +166,13 @@ def test_linear_samples_solved_together_equal_one_after_the_other(shape, dtype, 
     finally:
         random.pop_sseq()
 
+    shared = AbsDeltaEnergyController(0.05, iteration_limit=22)  # ONE controller object for every solve, as optimize_kl passes it
+
     def samples(lanes):
         monkeypatch.setenv("NK_LANES", str(lanes))
         random.push_sseq_from_seed(5)
         try:
-            res, negs, n = draw_samples(model, mean, 5, True, lambda: AbsDeltaEnergyController(0.05, iteration_limit=22))
+            res, negs, n = draw_samples(model, mean, 5, True, lambda: shared)
         finally:
             random.pop_sseq()
         torch.cuda.synchronize()
