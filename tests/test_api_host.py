@@ -483,14 +483,18 @@ def test_product_spectrum_correlated_field(device_id):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["octant", "matern", "three", "f32"])
+@pytest.mark.parametrize("case", ["octant", "matern", "three", "f32", "copies"])
 def test_fused_product_field_equals_the_operator_graph(case):
     """`_ProductFieldNode` against the generic operator graph of the same maker on the device: a power-of-two grid (the
     register-resident pipeline: OCTANT amplitude fields and octant sums), a Matern amplitude times a standard one, three
     sub-spaces, and fp32 fields."""
-    cfm = ift.CorrelatedFieldMaker("q")
+    cfm = ift.CorrelatedFieldMaker("q", total_N=2 if case == "copies" else 0)
     dtype, tol = np.float64, 1e-12
-    if case == "octant" or case == "f32":
+    if case == "copies":  # two field copies with their own spectra on a power-of-two grid: one octant field per copy
+        cfm.add_fluctuations(ift.RGSpace((64, 64), (0.5, 0.25)), (1.0, 0.5), (1.2, 0.4), (0.4, 0.2), (-3.0, 0.5), prefix="s",
+                             dofdex=[0, 1])
+        cfm.add_fluctuations(ift.RGSpace((64,)), (0.8, 0.3), (1.0, 0.3), None, (-2.0, 0.4), prefix="e", dofdex=[0, 0])
+    elif case == "octant" or case == "f32":
         cfm.add_fluctuations(ift.RGSpace((64, 64), (0.5, 0.25)), (1.0, 0.5), (1.2, 0.4), (0.4, 0.2), (-3.0, 0.5), prefix="s")
         cfm.add_fluctuations(ift.RGSpace((64,)), (0.8, 0.3), (1.0, 0.3), None, (-2.0, 0.4), prefix="e")
         if case == "f32":
@@ -501,7 +505,7 @@ def test_fused_product_field_equals_the_operator_graph(case):
     else:
         for n, name in ((8, "a"), (6, "b"), (10, "c")):
             cfm.add_fluctuations(ift.RGSpace((n,)), (0.8, 0.3), (1.0, 0.3), (0.4, 0.2), (-2.5, 0.4), prefix=name)
-    cfm.set_amplitude_total_offset(1.5, (1e-1, 3e-2))
+    cfm.set_amplitude_total_offset(1.5, (1e-1, 3e-2), dofdex=[0, 1] if case == "copies" else None)
     cf = cfm.finalize()
     node = cf.fused_node
     ift.random.push_sseq_from_seed(31)
@@ -514,7 +518,7 @@ def test_fused_product_field_equals_the_operator_graph(case):
     fused = cf(ift.Linearization.make_var(x))
     assert min(node.calls["value"], 1) == 1
     generic = cf._generic(ift.Linearization.make_var(x))
-    if case in ("octant", "f32"):
+    if case in ("octant", "f32", "copies"):
         assert node._setup(x["qxi"].val.dtype, x["qxi"].val.device)["octant"]
     assert gl.relerr(fused.val.asnumpy(), generic.val.asnumpy()) < tol
     assert gl.relerr(fused.jac(v).asnumpy(), generic.jac(v).asnumpy()) < 10 * tol
