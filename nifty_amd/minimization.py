@@ -528,7 +528,11 @@ class ConjugateGradient(Minimizer):
                 ws.update(x, r, d, q, b)
 
         # (replaying this body as a captured HIP graph was measured on the launch-heavy 2048^2 fp64 Poisson configuration:
-        # 162.1 vs 161.9 ms per MGVI iteration -- the chain of small kernels itself is the limit there, not the launches)
+        # 162.1 vs 161.9 ms per MGVI iteration -- the chain of small kernels itself is the limit there, not the launches.
+        # Round 4, with four chains side by side on lanes (where the Python launch path IS the limit, ~14 us per launch):
+        # capturing the steady-state iteration at iteration 2 and replaying it gave 131 ms against 115 ms per MGVI
+        # iteration -- every solve of this recipe has new vectors and at most 20 iterations, and a capture + instantiation
+        # costs more than 18 replays save.  A graph would have to outlive the solve: persistent CG and linearisation buffers.)
         iteration = 0
         while True:
             iteration += 1
