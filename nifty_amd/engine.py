@@ -1250,7 +1250,8 @@ class FusedKL(Energy):
         chip mostly idle (NK_LANE_MAX_POINTS, default 2^25 points; NK_LANES = number of lanes, default 4, 0 / 1 = off)."""
         want = int(os.environ.get("NK_LANES", "4"))
         small = self.model.N <= int(os.environ.get("NK_LANE_MAX_POINTS", str(1 << 25)))
-        if self.comm is not None or want < 2 or nloc < 2 or not small or self.model.response is not None:
+        held_back = self.model.response is not None and os.environ.get("NK_LANES_RESPONSE", "1") == "0"
+        if self.comm is not None or want < 2 or nloc < 2 or not small or held_back:
             return [self.model]
         return self.model.lanes(min(want, nloc))
 
@@ -1678,10 +1679,11 @@ def draw_samples(model, position, n_samples, mirror_samples, controller_factory,
 
 def _sampling_lanes(model, pairs):
     """Lanes for the linear solves of an MGVI iteration, or None: small grids only (NK_LANE_MAX_POINTS, default 2^25 points;
-    NK_LANES lanes, default 4, 0 / 1 = off), at least two solves, no response operator (it owns scratch of its own)."""
+    NK_LANES lanes, default 4, 0 / 1 = off), at least two solves.  Models with a linear response take part (the sparse
+    response is stateless: static CSR arrays and fresh outputs; NK_LANES_RESPONSE=0 keeps them on one stream)."""
     want = int(os.environ.get("NK_LANES", "4"))
     small = model.N <= int(os.environ.get("NK_LANE_MAX_POINTS", str(1 << 25)))
-    if want < 2 or pairs < 2 or not small or model.response is not None:
+    if want < 2 or pairs < 2 or not small or (model.response is not None and os.environ.get("NK_LANES_RESPONSE", "1") == "0"):
         return None
     return model.lanes(min(want, pairs))
 
