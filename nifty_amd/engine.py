@@ -1672,9 +1672,58 @@ def draw_samples(model, position, n_samples, mirror_samples, controller_factory,
     if lanes is None:
         drawn = plan.run(draw, finish)
     else:
+        together = geo_minimizer is not None and os.environ.get("NK_GEO_THREADS", "1") != "0"
         drawn = plan.run_together(lambda seed: _draw_sources(model, linearisation(), seed, device_rng),
-                                  lambda jobs: _solve_on_lanes(model, lanes, linearisation(), jobs, controller_factory), finish)
+                                  lambda jobs: _solve_on_lanes(model, lanes, linearisation(), jobs, controller_factory),
+                                  (lambda pair, mirrored: (pair, mirrored)) if together else finish)
+        if together:  # geoVI: the non-linear fits of all local samples, one host thread and one lane per fit in flight
+            if "tp" not in cache:
+                cache["tp"] = model.trafo_point(position)
+                cache["g_p"] = model.vjp_data(cache["tp"], cache["tp"].f, addend=position)
+            fits = _fit_on_lanes(model, lanes, cache["tp"], cache["g_p"], position, drawn, geo_minimizer)
+            drawn = [(f, False) for f in fits]
     return [r for r, _ in drawn], [n for _, n in drawn], plan.n_total
+
+
+def _fit_on_lanes(model, lanes, tp, g_p, position, jobs, minimizer):
+    """The geoVI fits g(x) = g(p) +- b of several samples side by side (kl_energies.py:105-124, 148-155): lane k, driven by
+    host thread k on its own stream, takes the samples k, k + K, ...  A fit is a whole Newton-CG minimisation with its own
+    control flow (line searches, inner CGs), so the fits are interleaved by THREADS rather than by a lockstep loop: a thread
+    that waits for its CG scalars lets the others enqueue (the waits release the interpreter lock).  Every lane has its own
+    scratch, minimiser state and copy of the expansion point's amplitude `state`; the arithmetic of a fit is unchanged."""
+    import copy
+    from concurrent.futures import ThreadPoolExecutor
+
+    main = torch.cuda.current_stream(model.device)
+    K = min(len(lanes), len(jobs))
+    points = []
+    for _ in range(K):
+        own = copy.copy(tp)
+        own.state = tp.state.clone()
+        points.append(own)
+    for lane in lanes[1:K]:
+        lane.stream.wait_stream(main)
+    out = [None] * len(jobs)
+
+    def work(k):
+        lane, mine = lanes[k], copy.deepcopy(minimizer)
+        torch.cuda.set_device(model.device)
+        with (torch.cuda.stream(lane.stream) if lane.stream is not None else contextlib.nullcontext()):
+            for j in range(k, len(jobs), K):
+                (b, y), mirrored = jobs[j]
+                target = g_p - b if mirrored else g_p + b
+                start = position - y if mirrored else position + y
+                fit, _ = mine(FusedGeoEnergy(lane, points[k], target, start))
+                out[j] = fit.position - position
+
+    with ThreadPoolExecutor(max_workers=K) as pool:
+        list(pool.map(work, range(K)))
+    for lane in lanes[1:K]:
+        main.wait_stream(lane.stream)
+    for r in out:
+        r.xi.record_stream(main)
+        r.small.record_stream(main)
+    return out
 
 
 def _sampling_lanes(model, pairs):
