@@ -1182,23 +1182,31 @@ class FusedKL(Energy):
         self.lins = []
         self._lanes = self._pick_lanes(len(residuals))
         # sums over samples in the pairwise order of the reference (parallel.pair_tree): the same bits for 1, 2, 4, 8 ranks.
-        # Across ranks that takes one complete subtree per rank (equal power-of-two sample counts); any other split keeps
-        # the local tree and falls back to RCCL's all-reduce (rank-count dependent rounding), said once.
+        # Across ranks: one complete subtree per rank (equal power-of-two sample counts) -> the slice-wise tree over the rank
+        # partials (`_across`); any other split -> every sample keeps its own vector and the terms are added like the
+        # reference adds them, the second summand of a merge travelling to the holder of the first (`_terms`: memory of one
+        # latent vector per local sample and point-to-point traffic -- correct for every split, not the fast path;
+        # NK_TREE_GENERAL=0: the local tree + RCCL's all-reduce, rank-count dependent rounding, said once).
         self._shared = _shared if _shared is not None else {}
         self._tree = parallel.tree_sum_enabled()
-        self._across = False
+        self._across, self._terms = False, None
         if comm is not None and self._tree:
             if "across" not in self._shared:
-                self._shared["across"] = (comm.subtree_per_rank(comm.term_counts(len(residuals)))
-                                          and comm.tree_exchange_works(model.device))
-                if not self._shared["across"] and comm.rank == 0 and comm.size > 1:
+                counts = comm.term_counts(len(residuals))
+                self._shared["across"] = comm.subtree_per_rank(counts) and comm.tree_exchange_works(model.device)
+                general = (not self._shared["across"] and comm.size > 1 and sum(counts) > 0
+                           and os.environ.get("NK_TREE_GENERAL", "1") != "0")
+                self._shared["terms"] = counts if general else None
+                if not self._shared["across"] and not general and comm.rank == 0 and comm.size > 1:
                     print("nifty_amd: the samples do not split into one power-of-two block per rank; sums over samples "
                           "depend on the rank count in the last bits", flush=True)
-            self._across = self._shared["across"]
+            self._across, self._terms = self._shared["across"], self._shared["terms"]
         self._holds_first = comm is None or comm.rank == 0  # global sample 0 carries the prior term of a pairwise sum
         value = torch.zeros(1, dtype=torch.float64, device=model.device)
         grad = None
-        if len(self._lanes) > 1:
+        if self._terms is not None:
+            value, grad = self._linearize_terms(position)
+        elif len(self._lanes) > 1:
             value, grad = self._linearize_on_lanes(position, value)
         elif self._tree and len(residuals) > 0:
             value, grad = self._linearize_pairwise(position)
@@ -1211,7 +1219,8 @@ class FusedKL(Energy):
                 self.lins.append(lp)
         if grad is None:  # a rank without samples
             grad = LatentVec.zeros(model)
-        self._sum_over_ranks(grad, value)
+        if self._terms is None:
+            self._sum_over_ranks(grad, value)
         self._value = float(value.item())
         if math.isnan(self._value) and nanisinf:
             self._value = math.inf
@@ -1232,6 +1241,39 @@ class FusedKL(Energy):
             comm.tree_allreduce_slices_(vec.xi)
         else:
             comm.tree_allreduce([[vec.xi]], [1] * comm.size)
+
+    # -- any split of the samples over the ranks: one vector per sample, added like the reference adds its terms -------------
+    def _tree_over_terms(self, terms):
+        """terms: this rank's [tensors of sample i] in sample order -> the pair_tree sum over ALL ranks' samples, in the
+        tensors of the first local term (a rank without samples: fresh zeros)."""
+        like = None
+        if not terms:
+            m = self.model
+            like = [torch.zeros(1, dtype=torch.float64, device=m.device), torch.zeros(m.shape, dtype=m.tdtype, device=m.device),
+                    LatentVec.zeros(m).small][-len(self._term_shape):]
+        return self.comm.tree_allreduce(terms, self._terms, like=like)
+
+    def _linearize_terms(self, position):
+        self._term_shape = ("value", "xi", "small")
+        terms = []
+        for r, neg in zip(self.residuals, self.negs):
+            v = torch.zeros(1, dtype=torch.float64, device=self.model.device)
+            lp = self.model.linearize(position.shifted(-1.0 if neg else 1.0, r), n_total=self.n_total, value_acc=v)
+            terms.append([v, lp.grad.xi, lp.grad.small])
+            lp.grad = None
+            self.lins.append(lp)
+        value, xi, small = self._tree_over_terms(terms)
+        return value, LatentVec(xi, small)
+
+    def _apply_metric_terms(self, d):
+        self._term_shape = ("xi", "small")
+        w, terms = 1.0 / self.n_total, []
+        for i, lp in enumerate(self.lins):
+            out = LatentVec(torch.empty_like(d.xi), None)
+            self.model.lh_metric_accumulate(lp, d, out, w, True, identity=1.0 if (i == 0 and self._holds_first) else 0.0)
+            terms.append([out.xi, out.small])
+        xi, small = self._tree_over_terms(terms)
+        return LatentVec(xi, small)
 
     def _scratch_vector(self):
         return torch.empty(self.model.shape, dtype=self.model.tdtype, device=self.model.device)
@@ -1415,6 +1457,8 @@ class FusedKL(Energy):
     def apply_metric(self, d, dot_out=None, cg_direction=None):
         if (dot_out is not None or cg_direction is not None) and self.comm is not None:
             raise ValueError("the fused curvature dot / direction update are single-process shortcuts")
+        if self._terms is not None:
+            return self._apply_metric_terms(d)
         out = self._apply_metric_local(d, dot_out, cg_direction)
         self._sum_over_ranks(out)
         return out
@@ -1425,7 +1469,7 @@ class FusedKL(Energy):
         # (pairwise sums keep the prior term on the FIRST sample; the dot needs it on the last one)
         A = _Callable(self.apply_metric, fused_dot=single and self.model.octant_vjp and (not self._tree or len(self.lins) == 1),
                       fused_direction=single and self.model.fused_direction)
-        if self.comm is not None and self.comm.can_shard(self.model.N):
+        if self.comm is not None and self.comm.can_shard(self.model.N) and self._terms is None:
             A.sharded = ShardedMetric(self)  # picked up by ConjugateGradient: CG vectors sharded over the ranks
         return A
 

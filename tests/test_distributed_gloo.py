@@ -486,6 +486,9 @@ def test_fused_engine_bits_do_not_depend_on_the_rank_count(tmp_path):
     assert _same_bits(run(2, 4), serial)
     assert _same_bits(run(4, 4), serial)
     assert _same_bits(run(4, 1), serial)
+    # a split that is NOT one power-of-two block per rank (3 + 3 + 2 samples): every sample keeps its own vector and the
+    # terms are added like the reference adds them, summands travelling between ranks -- the same bits again
+    assert _same_bits(run(3, 1), serial)
     loose = run(2, 4, env={"NK_TREE_SUM": "0"})
     assert abs(loose["value"] - serial["value"]) < 1e-9 * abs(serial["value"])
     assert float((loose["xi"] - serial["xi"]).abs().max()) < 1e-7 * float(serial["xi"].abs().max())
