@@ -13,7 +13,9 @@ model.set_data(model.signal(model.draw_prior()), 100.0)
 mean = 0.1 * model.draw_prior()
 res = 0.01 * model.draw_prior()
 d = model.draw_prior()
-kl = FusedKL(model, mean, [res, res], [False, True], 2)
+import os
+ns = int(os.environ.get('NK_PROBE_SAMPLES', '2'))
+kl = FusedKL(model, mean, [res] * ns, [i % 2 == 1 for i in range(ns)], ns)
 for _ in range(2):
     kl.apply_metric(d)
 torch.cuda.synchronize()
@@ -23,4 +25,5 @@ for _ in range(10):
     kl.apply_metric(d)
 e1.record()
 torch.cuda.synchronize()
-print(f"KL metric application, 2 samples (one pair launch): {e0.elapsed_time(e1) / 10:.3f} ms")
+torch.cuda.synchronize()
+print(f"KL metric application, {ns} samples: {e0.elapsed_time(e1) / 10:.3f} ms")
