@@ -40,3 +40,39 @@ def test_pair_tree_bookkeeping_brackets_like_the_reference(max_carries, monkeypa
         assert out.expr == want, (n, max_carries)
         # the output and at most floor(log2(n - 1)) scratch vectors, whatever the epilogue can carry
         assert len(made) <= max(0, (n - 1).bit_length() - 1)
+
+
+def test_sample_plan_run_together_equals_run():
+    """parallel.SamplePlan.run_together (draw everything a pair needs, solve the pairs together, finish sample by sample)
+    visits the samples, their random contexts and their mirrored flags exactly like run()."""
+    import numpy as np
+
+    from nifty_amd import random
+
+    def recipe(use_together):
+        random.push_sseq_from_seed(77)
+        try:
+            plan = parallel.SamplePlan(3, True)
+            seen = []
+
+            def prepare(seed):
+                return float(random.Random.normal(np.float64, (1,))[0])
+
+            def solve_one(x):
+                return (x, 2.0 * x)
+
+            def finish(pair, mirrored):
+                seen.append(float(random.Random.normal(np.float64, (1,))[0]))  # finish() runs inside the sample's context too
+                return (-pair[1] if mirrored else pair[1], mirrored)
+
+            if use_together:
+                out = plan.run_together(prepare, lambda jobs: [solve_one(j) for j in jobs], finish)
+            else:
+                out = plan.run(lambda seed: solve_one(prepare(seed)), finish)
+            return out, seen, plan.n_total
+        finally:
+            random.pop_sseq()
+
+    a, b = recipe(False), recipe(True)
+    assert a[0] == b[0] and a[2] == b[2] == 6
+    assert len(a[0]) == 6 and [m for _, m in a[0]] == [False, True] * 3
