@@ -114,9 +114,9 @@ class SampleListBase:
         return self._n_total
 
     def local_iterator(self, op=None):
+        op = _as_function(op)
         for i in range(self.n_local_samples()):
-            s = self.local_item(i)
-            yield s if op is None else op(s)
+            yield op(self.local_item(i))
 
     def iterator(self, op=None):
         """All samples in global order on EVERY rank (sample_list.py:186-210): each sample is handed over by the rank that
@@ -126,13 +126,13 @@ class SampleListBase:
         if comm is None or comm.size == 1:
             yield from self.local_iterator(op)
             return
+        op = _as_function(op)
         counts = comm.allgather_object(self.n_local_samples())
         device_id = self._device_id()
         for owner, count in enumerate(counts):
             for i in range(count):
                 mine = _to_host(self.local_item(i)) if owner == comm.rank else None
-                s = comm.bcast_object(mine, root=owner).at(device_id)
-                yield s if op is None else op(s)
+                yield op(comm.bcast_object(mine, root=owner).at(device_id))
 
     def _device_id(self):
         return -1
@@ -162,9 +162,9 @@ class SampleListBase:
                 root = next(r for r, c in enumerate(self._counts) if c)
                 like = _place_like(comm.bcast_object(None, root=root), self._device_id())
             cache = self.__dict__.setdefault("_zeros", {})
-            key = _map(like, lambda o: float if isinstance(o, float) else id(o.domain))
+            key = _map(like, _zero_key)
             if key not in cache:
-                cache[key] = _map(like, lambda o: 0.0 if isinstance(o, float) else o * 0.0)
+                cache[key] = _map(like, lambda o: 0.0 if isinstance(o, float) else _zeros_like(o))
             like = cache[key]
         elif like is None and not all(self._counts):
             root = next(r for r, c in enumerate(self._counts) if c)
@@ -173,8 +173,9 @@ class SampleListBase:
             else:
                 comm.bcast_object(None, root=root)
         if not tree:
-            local = functools.reduce(_add, terms) if terms else like
-            return _map(local, self._allreduce_fields)
+            # running sum of the local terms, then ONE all-reduce of a private copy (the collective writes in place)
+            box = _Flat(functools.reduce(_add, terms) if terms else like, comm)
+            return box.rebuilt(comm.allreduce_sum_(box.tensors))
         boxes = [_Flat(t, comm) for t in terms]
         spare = _Flat(like, comm) if not terms else None
         total = comm.tree_allreduce([b.tensors for b in boxes], self._counts, like=None if spare is None else spare.tensors)
@@ -318,12 +319,16 @@ class ResidualSampleList(SampleListBase):
         return self._m
 
     def save(self, file_name_base, overwrite=False):
-        """One pickle per sample: [residual(host dict), neg] + .mean.pickle (sample_list.py:467-484)."""
+        """``<base>.<global number>.pickle`` = [residual, neg] per sample, written by the rank that holds it, and
+        ``<base>.mean.pickle`` by rank 0 (sample_list.py:467-484; host Fields).  The number of samples of a saved list is the
+        length of the run of consecutive sample files, so a stale ``<base>.<n_samples>.pickle`` of a longer earlier list is
+        removed first (:673-683)."""
         total = self.n_samples
         first = shareRange(total, self._ntask, self._rank)[0]  # global number of this rank's first sample
-        files = {f"{file_name_base}.{first + i}.pickle": [_to_host(res), neg] for i, (res, neg) in enumerate(zip(self._r, self._n))}
+        _end_sample_run(file_name_base, total, overwrite, self._comm, self._rank)
+        files = {_sample_file(file_name_base, first + i): [_to_host(res), neg] for i, (res, neg) in enumerate(zip(self._r, self._n))}
         if self._rank == 0:
-            files.update({f"{file_name_base}.mean.pickle": _to_host(self._m), f"{file_name_base}.nsamples": total})
+            files[f"{file_name_base}.mean.pickle"] = _to_host(self._m)
         for name, content in files.items():
             _dump(name, content, overwrite)
 
@@ -334,13 +339,9 @@ class ResidualSampleList(SampleListBase):
 
     @staticmethod
     def load(file_name_base, comm=None, device_id=-1):
-        with open(f"{file_name_base}.nsamples", "rb") as f:
-            nsample = pickle.load(f)
-        ntask, rank, _ = get_MPI_params_from_comm(comm)
-        lo, hi = shareRange(nsample, ntask, rank)
         res, neg = [], []
-        for i in range(lo, hi):
-            with open(f"{file_name_base}.{i}.pickle", "rb") as f:
+        for name in _local_sample_files(file_name_base, comm):
+            with open(name, "rb") as f:
                 r, n = pickle.load(f)
             res.append(r.at(device_id))
             neg.append(n)
@@ -369,28 +370,79 @@ class SampleList(SampleListBase):
         return self._s[0].device_id if self._s else -1
 
     def save(self, file_name_base, overwrite=False):
-        nsample = self.n_samples
-        lo, _ = shareRange(nsample, self._ntask, self._rank)
+        """``<base>.<global number>.pickle`` per sample (sample_list.py:541-551)."""
+        total = self.n_samples
+        first = shareRange(total, self._ntask, self._rank)[0]
+        _end_sample_run(file_name_base, total, overwrite, self._comm, self._rank)
         for i, s in enumerate(self._s):
-            _dump(f"{file_name_base}.{lo + i}.pickle", _to_host(s), overwrite)
-        if self._rank == 0:
-            _dump(f"{file_name_base}.nsamples", nsample, overwrite)
+            _dump(_sample_file(file_name_base, first + i), _to_host(s), overwrite)
 
     @staticmethod
     def load(file_name_base, comm=None, device_id=-1):
-        with open(f"{file_name_base}.nsamples", "rb") as f:
-            nsample = pickle.load(f)
-        ntask, rank, _ = get_MPI_params_from_comm(comm)
-        lo, hi = shareRange(nsample, ntask, rank)
         samples = []
-        for i in range(lo, hi):
-            with open(f"{file_name_base}.{i}.pickle", "rb") as f:
+        for name in _local_sample_files(file_name_base, comm):
+            with open(name, "rb") as f:
                 samples.append(pickle.load(f).at(device_id))
-        return SampleList(samples, comm)
+        domain = None
+        if comm is not None and comm.size > 1:  # ranks without a sample still need the domain (sample_list.py:563-568)
+            domain = comm.bcast_object(samples[0].domain if comm.rank == 0 else None, root=0)
+        return SampleList(samples, comm, domain)
+
+
+def _sample_file(file_name_base, number):
+    return f"{file_name_base}.{int(number)}.pickle"
+
+
+def _saved_sample_count(file_name_base):
+    """How many samples ``<base>.0.pickle, <base>.1.pickle, ...`` hold: the length of the run of consecutive numbers
+    that starts at 0 (sample_list.py:350-355, 663-670)."""
+    import re
+
+    directory, stem = os.path.split(os.path.abspath(file_name_base))
+    pattern = re.compile(re.escape(stem) + r"\.([0-9]+)\.pickle$")
+    present = {int(m.group(1)) for m in map(pattern.match, os.listdir(directory)) if m}
+    if 0 not in present:
+        raise RuntimeError(f"No files matching `{file_name_base}.*.pickle`")
+    count = 1
+    while count in present:
+        count += 1
+    return count
+
+
+def _local_sample_files(file_name_base, comm):
+    """The sample files of this rank under the shareRange distribution, all ranks looking at complete files."""
+    if comm is not None:
+        comm.barrier()
+    ntask, rank, _ = get_MPI_params_from_comm(comm)
+    names = [_sample_file(file_name_base, i) for i in range(*shareRange(_saved_sample_count(file_name_base), ntask, rank))]
+    missing = [name for name in names if not os.path.isfile(name)]
+    if missing:
+        raise RuntimeError(f"File {missing[0]} not found")
+    return names
+
+
+def _end_sample_run(file_name_base, total, overwrite, comm, rank):
+    """rank 0 removes a left-over ``<base>.<total>.pickle`` so that the files about to be written END the run; nobody
+    writes before that happened."""
+    if overwrite and rank == 0:
+        try:
+            os.remove(_sample_file(file_name_base, total))
+        except FileNotFoundError:
+            pass
+    if comm is not None:
+        comm.barrier()
 
 
 def _to_host(f):
     return f.at(-1)
+
+
+def _as_function(op):
+    """What is applied to every sample: nothing, a callable, or an Operator -- which sees the part of the sample that
+    lies in its domain (`force`), so operators on a sub-domain of the latent space work (sample_list.py:571-581)."""
+    if op is None:
+        return lambda x: x
+    return op.force if isinstance(op, Operator) else op
 
 
 class _Flat:
@@ -436,6 +488,21 @@ def _map(obj, fn):
 
 def _add(a, b):
     return tuple(x + y for x, y in zip(a, b)) if isinstance(a, tuple) else a + b
+
+
+def _zeros_like(o):
+    """A zero Field / MultiField on the domain, dtype and device of `o` (not `o * 0`: that keeps NaN / inf)."""
+    if isinstance(o, MultiField):
+        return MultiField.from_dict({k: _zeros_like(f) for k, f in o.items()}, o.domain)
+    return Field(o.domain, torch.zeros_like(o.val))
+
+
+def _zero_key(o):
+    """What a cached zero term must share with the object it stands in for: domain, dtype and device of every part."""
+    if isinstance(o, float):
+        return float
+    parts = o.values() if isinstance(o, MultiField) else [o]
+    return (id(o.domain),) + tuple((str(f.val.dtype), str(f.val.device)) for f in parts)
 
 
 def _zero_like_host(obj):

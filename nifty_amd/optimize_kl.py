@@ -8,12 +8,20 @@ Fusion pass (``fuse=True``, device runs only): when the likelihood is
 ``GaussianEnergy | PoissonianEnergy  @  [[MaskOperator @] LOSResponse @]  [exp | sigmoid]  @  CorrelatedFieldOperator``
 the iteration runs on the fused engine (engine.py: one forward + one adjoint transform per sample and metric application,
 CG with device-resident scalars) and the results are handed back as MultiFields / ResidualSampleList.
-Everything else walks the generic operator graph.  Plotting and HDF5 export of the
-reference are diagnostics outside the hot path and not implemented.
+Everything else walks the generic operator graph.
+
+Files of a run (``output_directory``; reference optimize_kl.py:300-344, 425-441, 467-525, 571-615, 716-740):
+``pickle/<latest|iteration_N>.*`` sample lists, ``pickle/nifty_random_state`` (the reference's layout),
+``pickle/energy_history_*``, ``pickle/minisanity_history_*``, ``last_finished_iteration``, ``minisanity.txt``,
+``counting_report.txt`` and ``<name>/<latest|iteration_N>.hdf5`` for every entry of ``export_operator_outputs``.
+The PNG plots of the reference (energy / minisanity history) are diagnostics outside the path and not drawn
+(SURVEY 2 #26); ``plot_*`` are accepted and ignored.
 """
 import os
 import pickle
+from datetime import datetime
 from inspect import signature
+from warnings import warn
 
 import numpy as np
 
@@ -24,8 +32,8 @@ from .field import Field, MultiField, from_random, full
 from .kl import EnergyAdapter, ResidualSampleList, SampledKLEnergy, SampleList
 from .minimization import DescentMinimizer, EnergyHistory, IterationController, Minimizer, logger
 from .los_response import LOSResponse, SparseResponse
-from .operators import (ChainOperator, DiagonalOperator, MaskOperator, Operator, ScalingOperator, _FunctionApplier,
-                        _OpChain)
+from .operators import (ChainOperator, CountingOperator, DiagonalOperator, MaskOperator, Operator, ScalingOperator,
+                        _FunctionApplier, _OpChain)
 from .parallel import get_MPI_params_from_comm
 
 
@@ -37,6 +45,13 @@ def _make_callable(obj):
 
 def _nargs(func):
     return len(signature(func).parameters)
+
+
+def _want_metric(minimizer):
+    """first-order minimisers never ask for the metric (optimize_kl.py:769-775)"""
+    from .minimization import L_BFGS, VL_BFGS, SteepestDescent
+
+    return not isinstance(minimizer, (SteepestDescent, L_BFGS, VL_BFGS))
 
 
 def _normal_initialize(mf, domain, std=0.1, device_id=-1):
@@ -179,6 +194,112 @@ def _fused_iteration(model, lh, mean, n_samples, minimizer, ic_sampling, comm, g
     return new_mean, ResidualSampleList(new_mean, res_mf, negs, comm), kl.value
 
 
+
+# ------------------------------------------------------------------------------------------------
+# files of a run
+# ------------------------------------------------------------------------------------------------
+class _RunFiles:
+    """Everything optimize_kl writes below ``output_directory`` (None: nothing is written, reports go to the logger).
+    File names and contents follow the reference (optimize_kl.py:460-525, 571-615, 716-740) so that its tools -- and a
+    resumed reference run, for the random state -- read them."""
+
+    _VALUE_TYPES = ("redchisq", "scmean")
+    _CATEGORIES = ("data_residuals", "latent_variables")
+
+    def __init__(self, directory, save_strategy, exports):
+        self.directory, self.save_strategy, self.exports = directory, save_strategy, dict(exports)
+
+    def tag(self, ig):
+        return "latest" if self.save_strategy == "latest" else f"iteration_{ig}"
+
+    def pickle_path(self, *parts):
+        return os.path.join(self.directory, "pickle", *parts)
+
+    def make_directories(self):
+        for sub in ["pickle"] + list(self.exports):
+            os.makedirs(os.path.join(self.directory, sub), exist_ok=True)
+
+    def dump(self, name, ig, value):
+        with open(self.pickle_path(f"{name}_{self.tag(ig)}"), "wb") as f:
+            pickle.dump(value, f)
+
+    def load(self, name, ig):
+        with open(self.pickle_path(f"{name}_{self.tag(ig)}"), "rb") as f:
+            return pickle.load(f)
+
+    def save_random_state(self):
+        with open(self.pickle_path("nifty_random_state"), "wb") as f:
+            f.write(random.getState())
+
+    def load_random_state(self):
+        with open(self.pickle_path("nifty_random_state"), "rb") as f:
+            random.setState(f.read())
+
+    # ---- reports ---------------------------------------------------------------------------------
+    def report(self, text, file_name, ig, comm, to_logger, every_rank):
+        """`text` to the logger and / or appended to ``file_name`` under a "Finished index" header; `every_rank`: the
+        ranks' texts are collected and written one "Task r" block each (optimize_kl.py:721-740)."""
+        if every_rank and comm is not None:
+            text = "\n".join(f"Task {r}\n{t}" for r, t in enumerate(comm.allgather_object(text)))
+        elif every_rank:
+            text = f"Task 0\n{text}"
+        if not get_MPI_params_from_comm(comm)[2]:
+            return
+        if to_logger:
+            logger.info(text)
+        if self.directory is not None:
+            with open(os.path.join(self.directory, file_name), "a", encoding="utf-8") as f:
+                f.write(f"Finished index: {ig}\nCurrent datetime: {datetime.now()}\n{text}\n\n")
+
+    def minisanity_history(self, ig, values, comm):
+        """Append this iteration's fit-quality numbers to the pickled history: value type -> category -> key ->
+        {index, mean, std} lists (optimize_kl.py:580-613); the history of iteration ig-1 is the starting point."""
+        if self.directory is None or not get_MPI_params_from_comm(comm)[2]:
+            return None
+        try:
+            history = self.load("minisanity_history", ig - 1) if ig > 0 else None
+        except FileNotFoundError:  # a run that started (or was resumed) without one: begin here
+            history = None
+        if history is None:
+            history = {vt: {cat: {} for cat in self._CATEGORIES} for vt in self._VALUE_TYPES}
+        for vt in self._VALUE_TYPES:
+            for cat in self._CATEGORIES:
+                for key, stat in values[vt][cat].items():
+                    track = history[vt][cat].setdefault(key, {"index": [], "mean": [], "std": []})
+                    track["index"].append(ig)
+                    track["mean"].append(stat["mean"])
+                    track["std"].append(stat["std"])
+        self.dump("minisanity_history", ig, history)
+        return history
+
+    def export(self, ig, sample_list):
+        """``<name>/<tag>.hdf5`` with op(sample) for all samples, and mean / standard deviation when there is more than one
+        (optimize_kl.py:500-525); operators whose domain is not part of the sample domain are skipped."""
+        for name, op in self.exports.items():
+            if not _is_subdomain(op.domain, sample_list.domain):
+                continue
+            many = sample_list.n_samples > 1
+            sample_list.save_to_hdf5(os.path.join(self.directory, name, self.tag(ig) + ".hdf5"), op=op, overwrite=True,
+                                     samples=True, mean=many, std=many)
+
+
+def _is_subdomain(sub, total):
+    if isinstance(sub, DomainTuple):
+        return sub == total
+    if not isinstance(sub, MultiDomain):
+        raise TypeError
+    return isinstance(total, MultiDomain) and all(k in total.keys() and total[k] == dom for k, dom in sub.items())
+
+
+def _fused_counting_report(before, after, n_local):
+    """The four rows of CountingOperator.report() for an iteration of the fused engine, from FusedModel.counters: one
+    value/gradient evaluation is one Linearization + one adjoint Jacobian of the likelihood's input, one metric
+    application one Jacobian + one adjoint Jacobian (per local sample; nothing is applied to plain fields)."""
+    vg, met = after["value_grad"] - before["value_grad"], after["metric"] - before["metric"]
+    rows = (("apply: \t\t", 0), ("apply Linearization: \t", vg), ("Jacobian: \t\t", met), ("Adjoint Jacobian: \t", vg + met))
+    return "\n".join(f"* {label}{count:>7}" for label, count in rows) + \
+        f"\n  (fused engine, {n_local} local samples: {after['transforms'] - before['transforms']} transforms)"
+
 # ------------------------------------------------------------------------------------------------
 # driver
 # ------------------------------------------------------------------------------------------------
@@ -204,12 +325,28 @@ def _optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, s
                  sanity_checks=True, dry_run=False, fresh_stochasticity=True, device_id=-1, fuse=True):
     if not isinstance(export_operator_outputs, dict):
         raise TypeError
+    if "pickle" in export_operator_outputs:
+        raise ValueError("The key `pickle` in `export_operator_outputs` is reserved.")
     if not isinstance(initial_index, int):
         raise TypeError
     if save_strategy not in ("all", "latest"):
         raise ValueError(f"Save strategy '{save_strategy}' not supported.")
     if output_directory is None and resume:
         raise ValueError("Can only resume minimization if output_directory is not None")
+    if export_operator_outputs:
+        if output_directory is None:
+            warn("`output_directory=None`, thus no operator outputs will be exported.")
+        else:
+            # the reference skips the export silently when h5py is missing (optimize_kl.py:508-511, 523-525); a run that
+            # asks for files and would get none fails here, before the first iteration is spent
+            try:
+                import h5py  # noqa: F401
+            except ImportError as exc:
+                raise ImportError("optimize_kl(export_operator_outputs=...) writes HDF5 files and needs `h5py`, which is "
+                                  "not importable here; install it or drop the argument") from exc
+            for name, op in export_operator_outputs.items():
+                if not isinstance(name, str) or not isinstance(op, Operator):
+                    raise TypeError("export_operator_outputs maps directory names to Operators")
     likelihood_energy = _make_callable(likelihood_energy)
     kl_minimizer = _make_callable(kl_minimizer)
     sampling_iteration_controller = _make_callable(sampling_iteration_controller)
@@ -241,18 +378,16 @@ def _optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, s
     energy_history = EnergyHistory()
     master = get_MPI_params_from_comm(comm(initial_index))[2]
 
-    def fname(ig):
-        return "latest" if save_strategy == "latest" else f"iteration_{ig}"
-
+    files = _RunFiles(output_directory, save_strategy, export_operator_outputs)
     if output_directory is not None:
         if master:
-            os.makedirs(os.path.join(output_directory, "pickle"), exist_ok=True)
+            files.make_directories()
         lfile = os.path.join(output_directory, "last_finished_iteration")
         if resume and os.path.isfile(lfile):
             with open(lfile) as f:
                 last = int(f.read())
             initial_index = last + 1
-            base = os.path.join(output_directory, "pickle", fname(last))
+            base = files.pickle_path(files.tag(last))
             if os.path.isfile(base + ".mean.pickle"):
                 mean = ResidualSampleList.load_mean(base).at(device_id)
                 sl = ResidualSampleList.load(base, comm=comm(last), device_id=device_id)
@@ -261,13 +396,12 @@ def _optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, s
                 mean = sl.local_item(0)
             if initial_index == total_iterations:
                 return (sl, mean) if return_final_position else sl
-            with open(os.path.join(output_directory, "pickle", "nifty_random_state"), "rb") as f:
-                random.setState(f.read())
-            with open(os.path.join(output_directory, "pickle", "energy_history_" + fname(last)), "rb") as f:
-                energy_history = pickle.load(f)
-        elif master:
-            with open(os.path.join(output_directory, "pickle", "nifty_random_state"), "wb") as f:
-                f.write(random.getState())
+            files.load_random_state()
+            energy_history = files.load("energy_history", last)
+        else:
+            parallel.check_MPI_synced_random_state(comm(initial_index))
+            if master:
+                files.save_random_state()
 
     sseqs = random.spawn_sseq(total_iterations)
     for ig in range(total_iterations):
@@ -302,54 +436,64 @@ def _optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, s
             parallel.check_MPI_equality(repr(lh.domain), c)
             parallel.check_MPI_equality(repr(mean.domain), c)
             parallel.check_MPI_equality(mean, c, hash=True)
+        sl = None  # the old samples go before new ones are drawn (optimize_kl.py:388)
         # partial constants and a preconditioned NewtonCG (napprox) run on the generic graph
         if fuse and device_id >= 0 and ns > 0 and not cst and not pes and getattr(minimizer, "_napprox", 0) <= 1:
             model = _fused_model(lh, device_id, mean_iter["xi"].dtype if "xi" in mean_iter else np.float64)
         if model is not None:
+            tally = dict(model.counters)
             new_mean, sl, value = _fused_iteration(model, lh, mean_iter, ns, minimizer, sampling_iteration_controller(ig),
-                                                   comm(ig), nonlinear_sampling_minimizer(ig))
+                                                   c, nonlinear_sampling_minimizer(ig))
             mean = MultiField.union([mean, new_mean])
             sl = sl.at(mean)
             energy_history.append((ig, value))
+            counting_report = _fused_counting_report(tally, model.counters, sl.n_local_samples())
         else:
-            ham = StandardHamiltonian(lh, sampling_iteration_controller(ig), prior_sampling_dtype=mean_iter.dtype)
+            # the likelihood's input passes a counter (optimize_kl.py:370-373); its tally is this iteration's report
+            count = CountingOperator(lh.domain)
+            ham = StandardHamiltonian(lh @ count, sampling_iteration_controller(ig), prior_sampling_dtype=mean_iter.dtype)
             if ns == 0:
-                e = EnergyAdapter(mean_iter, ham, constants=cst, want_metric=True)
-                with parallel.lockstep(comm(ig)):
+                e = EnergyAdapter(mean_iter, ham, constants=cst, want_metric=_want_metric(minimizer))
+                with parallel.lockstep(c):
                     e, _ = minimizer(e)
                 mean = MultiField.union([mean, e.position])
                 sl = SampleList([mean])
             else:
                 e = SampledKLEnergy(mean_iter, ham, ns, nonlinear_sampling_minimizer(ig), constants=cst,
-                                    point_estimates=pes, comm=comm(ig), device_id=device_id)
-                with parallel.lockstep(comm(ig)):
+                                    point_estimates=pes, comm=c, device_id=device_id)
+                with parallel.lockstep(c):
                     e, _ = minimizer(e)
                 mean = MultiField.union([mean, e.position])
                 sl = e.samples.at(mean)
             energy_history.append((ig, e.value))
+            counting_report = count.report()
+            del e, ham
+        is_master = get_MPI_params_from_comm(c)[2]
         if output_directory is not None:
             # every rank's sample files are complete before rank 0 declares the iteration finished, and the marker is
             # on disk before anybody moves on (optimize_kl.py:425-435: save under ensure_all_tasks_succeed + barriers)
-            c = comm(ig)
-            sl.save(os.path.join(output_directory, "pickle", fname(ig)), overwrite=True)
+            files.export(ig, sl)
+            sl.save(files.pickle_path(files.tag(ig)), overwrite=True)
             if c is not None:
                 c.barrier()
-            if get_MPI_params_from_comm(c)[2]:
-                with open(os.path.join(output_directory, "pickle", "energy_history_" + fname(ig)), "wb") as f:
-                    pickle.dump(energy_history, f)
+            if is_master:
                 with open(os.path.join(output_directory, "last_finished_iteration"), "w") as f:
                     f.write(str(ig))
+                files.dump("energy_history", ig, energy_history)
             if c is not None:
                 c.barrier()
-        # fit-quality table of this iteration (optimize_kl.py:438, 571-578): logged, and appended to minisanity.txt
+        # fit-quality table of this iteration (optimize_kl.py:438, 571-615): logged, appended to minisanity.txt, and its
+        # numbers appended to the pickled minisanity history
         from .extra import minisanity
 
-        table = minisanity(lh, sl, terminal_colors=False)
-        if table and get_MPI_params_from_comm(comm(ig))[2]:
-            logger.info(f"Iteration {ig}: minisanity\n{table}")
-            if output_directory is not None:
-                with open(os.path.join(output_directory, "minisanity.txt"), "a") as f:
-                    f.write(f"Iteration {ig}\n{table}\n\n")
+        checked = minisanity(lh, sl, terminal_colors=False, return_values=True)
+        if checked:  # ("" for an energy without normalised residuals)
+            table, ms_values = checked
+            if c is not None:
+                parallel.check_MPI_equality(repr(ms_values), c)
+            files.report(table, "minisanity.txt", ig, c, to_logger=True, every_rank=False)
+            files.minisanity_history(ig, ms_values, c)
+        files.report(counting_report, "counting_report.txt", ig, c, to_logger=output_directory is None, every_rank=True)
         cb = inspect_callback
         if cb is not None and callable(cb):
             try:
@@ -359,6 +503,8 @@ def _optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, s
             res = cb(sl) if na == 1 else cb(sl, ig)
             del res
         terminate = terminate_callback(ig)
+        if c is not None:
+            parallel.check_MPI_equality(bool(terminate), c)
         random.pop_sseq()
         if terminate:
             break

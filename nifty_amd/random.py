@@ -28,18 +28,24 @@ _frames = [_frame(np.random.SeedSequence(42))]  # the reference starts every pro
 
 # ---- the stack -----------------------------------------------------------------------------------------------------
 def getState():
-    """The whole stack as bytes (for setState, the resume file of optimize_kl and the rank-synchronisation guard)."""
-    return pickle.dumps([tuple(f) for f in _frames])
+    """The whole stack as bytes, in the reference's own layout (random.py:88-96): the pickled pair
+    (list of SeedSequences, list of Generators), bottom frame first -- so a `nifty_random_state` file written here is
+    read by nifty.cl's `setState` and the other way round (resume file of optimize_kl, rank-synchronisation guard)."""
+    return pickle.dumps(([f.sseq for f in _frames], [f.rng for f in _frames]))
 
 
 def setState(state):
-    """Restores what getState returned.  Also reads the layout of earlier versions (and of the reference's own
-    `getState`, random.py:98-110): a pair (list of SeedSequences, list of Generators)."""
+    """Restores what getState (ours or the reference's, random.py:98-110) returned.  Files of rounds 1-4 of this package
+    held a list of (SeedSequence, Generator) frames instead; those are still read."""
     loaded = pickle.loads(state)
     if isinstance(loaded, tuple) and len(loaded) == 2 and all(isinstance(part, list) for part in loaded) \
-            and all(isinstance(q, np.random.SeedSequence) for q in loaded[0]):
+            and len(loaded[0]) == len(loaded[1]) and all(isinstance(q, np.random.SeedSequence) for q in loaded[0]):
         loaded = list(zip(*loaded))
+    elif not isinstance(loaded, list):
+        raise TypeError("setState: not a random state of this module or of nifty.cl")
     frames = [_Frame(*f) for f in loaded]
+    if not frames:
+        raise ValueError("setState: empty generator stack")
     for f in frames:
         if not (isinstance(f.sseq, np.random.SeedSequence) and isinstance(f.rng, np.random.Generator)):
             raise TypeError("setState: not a random state of this module (expected (SeedSequence, Generator) frames)")

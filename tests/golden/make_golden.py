@@ -616,7 +616,70 @@ def likelihood_cases():
     print("wrote likelihoods", {k: float(out[k]) for k in out if k.endswith("value")})
 
 
+def driver_io_case():
+    """What the reference's optimize_kl leaves in its output directory for the g1d model (3 iterations, 2 mirrored sample
+    pairs): the bytes of pickle/nifty_random_state (random.py:88-96) with the draws that follow a setState of them, the
+    pickled minisanity history (optimize_kl.py:580-613), the numbers of counting_report.txt (:716-718) and the final mean.
+    Also checks HERE that a state file written by nifty_amd.random.getState is read by the reference's setState."""
+    import pickle
+    import re
+    import tempfile
+
+    z = np.load(os.path.join(HERE, "model_g1d.npz"))
+    sp = ift.RGSpace(tuple(int(i) for i in z["meta.shape"]))
+    cfm, cf = make_cf(sp)
+    d = ift.makeField(cf.target, z["data"])
+    lh = ift.GaussianEnergy(d, ift.ScalingOperator(cf.target, float(z["icov"]), np.float64)) @ cf
+    ic_s = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=4)
+    mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, iteration_limit=2), max_cg_iterations=5)  # noqa: E731
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        ift.random.push_sseq_from_seed(11)
+        sl, mean = ift.optimize_kl(lh, 3, 2, mk, ic_s, output_directory=tmp, return_final_position=True,
+                                   plot_energy_history=False, plot_minisanity_history=False, save_strategy="latest")
+        ift.random.pop_sseq()
+        state = open(os.path.join(tmp, "pickle", "nifty_random_state"), "rb").read()
+        history = pickle.load(open(os.path.join(tmp, "pickle", "minisanity_history_latest"), "rb"))
+        report = open(os.path.join(tmp, "counting_report.txt"), encoding="utf-8").read()
+        eh = pickle.load(open(os.path.join(tmp, "pickle", "energy_history_latest"), "rb"))
+        out["files"] = np.array(sorted(os.path.relpath(os.path.join(r, f), tmp) for r, _, fs in os.walk(tmp) for f in fs))
+    out["random_state"] = np.frombuffer(state, dtype=np.uint8)
+    before = ift.random.getState()
+    ift.random.setState(state)
+    out["state_depth"] = np.array(len(pickle.loads(state)[0]))
+    out["state_draws"] = ift.random.current_rng().normal(size=4)
+    out["state_child_draws"] = np.random.default_rng(ift.random.spawn_sseq(2)[1]).normal(size=3)
+    ift.random.setState(before)
+    for vt, cats in history.items():
+        for cat, keys in cats.items():
+            for key, track in keys.items():
+                for what in ("index", "mean", "std"):
+                    out[f"mh.{vt}.{cat}.{key}.{what}"] = np.array([np.nan if v is None else v for v in track[what]], dtype=np.float64)
+    counts = re.findall(r"\* (apply|apply Linearization|Jacobian|Adjoint Jacobian): \s*(\d+)", report)
+    out["counting"] = np.array([int(c) for _, c in counts]).reshape(-1, 4)
+    out["energy_history"] = np.array(eh.energy_values)
+    out.update(mf2dict(mean, "okl_mean"))
+    np.savez_compressed(os.path.join(HERE, "driver_io.npz"), **out)
+    print("wrote driver_io", out["counting"].tolist(), list(out["files"]))
+    # the other direction: a state written by the product is a state of the reference
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import nifty_amd
+
+    nifty_amd.random.push_sseq_from_seed(123)
+    nifty_amd.random.current_rng().normal(size=3)
+    ours = nifty_amd.random.getState()
+    expect = nifty_amd.random.current_rng().normal(size=5)
+    nifty_amd.random.pop_sseq()
+    ift.random.setState(ours)
+    got = ift.random.current_rng().normal(size=5)
+    ift.random.setState(before)
+    assert np.array_equal(got, expect), "the reference does not read nifty_amd's random state"
+    print("reference reads nifty_amd.random.getState(): OK")
+
+
 def main():
+    if "--driver-io" in sys.argv:
+        return driver_io_case()
     if "--c1-only" in sys.argv:  # BASELINE configs[0] at its stated size: RGSpace(512), Gaussian, 2 MGVI samples (mirrored)
         return model_case("c1_512", (512,), None, "gaussian", None, 2, False, run_optimize=True)
     if "--lh-only" in sys.argv:
@@ -669,6 +732,7 @@ def main():
     okl1_cases()
     product_cf_case()
     likelihood_cases()
+    driver_io_case()
 
 
 def allreduce_order():

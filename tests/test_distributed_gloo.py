@@ -71,6 +71,28 @@ def test_two_rank_kl_equals_serial(tmp_path):
     assert gl.lat_relerr(par["min_pos"], gl.latent(z, "kl_min_pos")) < 1e-6
 
 
+def _plain_sum_worker(rank, world, port, out):
+    os.environ["NK_TREE_SUM"] = "0"
+    _worker(rank, world, port, out)
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_kl_with_the_plain_allreduce_fallback(tmp_path):
+    """NK_TREE_SUM=0 -- local running sum + ONE all-reduce, the documented fallback of rounds 1-3 --
+    through the generic SampledKLEnergy (value, gradient, apply_metric, a NewtonCG run) on two ranks: equal to the serial
+    run to rounding."""
+    from tests import goldenlib as gl
+
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_plain_sum_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    par = torch.load(out, weights_only=False)
+    z = gl.load("model_g1d")
+    assert abs(par["value"] - float(z["kl_value"])) < 1e-9 * abs(float(z["kl_value"]))
+    assert gl.lat_relerr(par["grad"], gl.latent(z, "kl_grad")) < 1e-8
+    assert gl.lat_relerr(par["met"], gl.latent(z, "kl_metric_v")) < 1e-8
+    assert abs(par["min_value"] - float(z["kl_min_value"])) < 1e-7 * abs(float(z["kl_min_value"]))
+
+
 def _uneven_kl(comm):
     """Generic-graph KL with 3 unmirrored samples (2 + 1 over two ranks), minimised inside the lockstep scope exactly
     like optimize_kl does."""
