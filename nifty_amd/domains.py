@@ -367,6 +367,33 @@ class PowerSpace(StructuredDomain):
         return np.logspace(np.log(float(first_bound)), np.log(float(last_bound)), nbin - 1, base=np.e)
 
 
+    @staticmethod
+    def useful_binbounds(space, logarithmic, nbin=None):
+        """Bin bounds that leave no bin of `space` empty (power_space.py:105-153): `nbin` bins (default: as many as
+        possible) between the middle of the first two and the middle of the last two distinct |k|, equally wide in |k| or
+        -- `logarithmic` -- in log |k|.  (None, None) asks for the natural binning: None."""
+        if not (isinstance(space, StructuredDomain) and space.harmonic):
+            raise ValueError("first argument must be a harmonic space.")
+        if logarithmic is None and nbin is None:
+            return None
+        logarithmic = bool(logarithmic)
+        k = np.array(space.get_unique_k_lengths(), dtype=np.float64)
+        if len(k) < 3:
+            raise ValueError("Space does not have enough unique k lengths")
+        first, last = 0.5 * (k[0] + k[1]), 0.5 * (k[-2] + k[-1])
+        k[0], k[-1] = first, last
+        scale = np.log(k) if logarithmic else k
+        widest_gap = np.max(np.diff(scale))  # a bin narrower than this could fall between two neighbours
+        most = int((scale[-1] - scale[0]) / widest_gap) + 2
+        nbin = most if nbin is None else int(nbin)
+        if nbin < 3:
+            raise ValueError("nbin must be at least 3")
+        if nbin > most:
+            raise ValueError("nbin is too large")
+        make = PowerSpace.logarithmic_binbounds if logarithmic else PowerSpace.linear_binbounds
+        return make(nbin, first, last)
+
+
 def _interned(cache, key, build):
     """cache[key], built on first request: one object per distinct domain, so identity compares domains"""
     if key not in cache:
