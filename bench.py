@@ -290,6 +290,61 @@ def cpu_baseline(counts_per_step, shape_full, cfg="C5", bench_dtype=None, budget
                         f"operations (x{Nf / Ns:.0f}, linear in N)"))
 
 
+def api_leg(shape, dtype, lh_kind, noise_var, data, n_pairs, steps, device, engine_ms_per_transform):
+    """NK_BENCH_API=1: the same workload through the USER-LEVEL driver, `ift.optimize_kl` with its fusion pass (reference
+    minimization/optimize_kl.py:51-453: MultiField positions, ResidualSampleList, minisanity every iteration, counting
+    report) instead of engine.mgvi_iteration -- after the timed region, on the same data.  Returns the time per iteration
+    and per transform of the fused engine underneath, the overhead of the driver layer per transform against the engine
+    leg of this run, and the peak device memory of the leg."""
+    import nifty_amd as ift
+    from nifty_amd import optimize_kl as okl
+    from nifty_amd.field import Field
+
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    sp = ift.RGSpace(shape)
+    cfm = ift.CorrelatedFieldMaker("")
+    cfm.add_fluctuations(sp, (1.0, 5e-1), (1.0, 2e-1), (5e-1, 5e-2), (-3.0, 2e-1))
+    cfm.set_amplitude_total_offset(2.0, (1e-1, 3e-2))
+    cf = cfm.finalize()
+    d = Field(cf.target, data)
+    if lh_kind == "poisson":
+        lh = ift.PoissonianEnergy(d) @ cf.exp()
+    else:
+        lh = ift.GaussianEnergy(d, ift.ScalingOperator(cf.target, 1.0 / noise_var, npdt)) @ cf
+    x0 = 0.1 * ift.from_random(cf.domain, dtype=npdt, device_id=device.index)
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=20)
+    mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=3),  # noqa: E731
+                                max_cg_iterations=20)
+    run = lambda total, start: ift.optimize_kl(lh, total, n_pairs, mk, ic, output_directory=None, initial_position=start,  # noqa: E731
+                                               return_final_position=True, device_id=device.index)
+    torch.cuda.synchronize(device)
+    torch.cuda.reset_peak_memory_stats(device)
+    _, mean = run(1, x0)  # warm-up: builds the fused model of the likelihood (cached by the driver)
+    del x0
+    model = okl._fused_model(lh, device.index, npdt)
+    if model is None:
+        return {"error": "the fusion pass did not take this likelihood"}
+    before = dict(model.counters)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    sl, mean = run(steps, mean)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    transforms = model.counters["transforms"] - before["transforms"]
+    per_transform = 1e3 * dt / max(transforms, 1)
+    out = {"what": "ift.optimize_kl (fusion pass, minisanity and reports included), same data, after the timed region",
+           "steps": steps, "ms_per_step": 1e3 * dt / steps, "value": steps / dt, "unit": "MGVI iters/s",
+           "transforms_per_step": transforms / steps, "ms_per_transform": per_transform,
+           "engine_ms_per_transform": engine_ms_per_transform,
+           "api_overhead_pct": (None if not engine_ms_per_transform
+                                else round(100.0 * (per_transform / engine_ms_per_transform - 1.0), 2)),
+           "peak_allocated_GB": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
+           "peak_allocated_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+           "samples": sl.n_samples}
+    okl._fused_cache.clear()
+    return out
+
+
 RNG_LABEL = {"numpy": "the reference's numpy PCG64 + ziggurat streams (seed 42, one SeedSequence per sample), computed on the "
                       "device from the host generators' states (nk_pcg64_normal)",
              "device": "torch device generator (NK_BENCH_RNG=device)"}
@@ -634,6 +689,20 @@ def main():
                 parity_failed = True
             except Exception as exc:  # the baseline must never take the bench line down
                 line["cpu_baseline"] = {"error": repr(exc)}
+        if world == 1 and os.environ.get("NK_BENCH_API", "0") == "1" and cfg != "C4":
+            # the engine leg's model, vectors and cached blocks go first: the driver builds its own fused model
+            data_keep, ms_tr = model.data, line["ms_per_transform_rank0"]
+            del step, model, mean
+            import gc
+
+            gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                line["api"] = api_leg(shape, dtype, lh_kind, noise_var, data_keep, n_pairs, max(1, min(args.steps, 3)), device,
+                                      ms_tr)
+                line["api_overhead_pct"] = line["api"].get("api_overhead_pct")
+            except Exception as exc:  # the side leg must never take the bench line down
+                line["api"] = {"error": repr(exc)}
     else:
         line = None
     # RCCL writes a version banner to the C-level stdout of a rank when its first communicator is created; through a pipe

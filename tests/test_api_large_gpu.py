@@ -1,0 +1,105 @@
+"""The headline workload -- 1024^3 RGSpace CorrelatedField + Gaussian likelihood, fp32 fields, 4 mirrored sample pairs --
+through the USER-LEVEL driver `ift.optimize_kl` (reference minimization/optimize_kl.py:51-453) at its real size: one
+iteration with short limits (4 CG iterations per sampling solve, one Newton step of 4 CG iterations), the per-iteration
+minisanity included.  Asserts that it fits the device (the driver layer adds MultiField views of the mean and of every
+residual to the engine's own peak) and that the result equals engine.mgvi_iteration on the same seeds."""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+import nifty_amd as ift
+
+pytestmark = pytest.mark.gpu
+
+
+def _controllers():
+    ic = ift.AbsDeltaEnergyController(deltaE=0.05, iteration_limit=4)
+    mk = lambda i: ift.NewtonCG(ift.AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=1),  # noqa: E731
+                                max_cg_iterations=4)
+    return ic, mk
+
+
+def _run_both(n, pairs):
+    from nifty_amd import optimize_kl as okl
+    from nifty_amd import random
+    from nifty_amd.engine import mgvi_iteration
+
+    shape = (n, n, n)
+    ift.random.push_sseq_from_seed(42)
+    try:
+        sp = ift.RGSpace(shape)
+        cfm = ift.CorrelatedFieldMaker("")
+        cfm.add_fluctuations(sp, (1.0, 5e-1), (1.0, 2e-1), (5e-1, 5e-2), (-3.0, 2e-1))
+        cfm.set_amplitude_total_offset(2.0, (1e-1, 3e-2))
+        cf = cfm.finalize()
+        d = ift.from_random(cf.target, dtype=np.float32, device_id=0, mean=2.0, std=0.1)
+        lh = ift.GaussianEnergy(d, ift.ScalingOperator(cf.target, 100.0, np.float32)) @ cf
+        x0 = 0.1 * ift.from_random(cf.domain, dtype=np.float32, device_id=0)
+        ic, mk = _controllers()
+        tables = []
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        # --- the driver
+        ift.random.push_sseq_from_seed(7)
+        try:
+            sl, mean = ift.optimize_kl(lh, 1, pairs, mk, ic, output_directory=None, initial_position=x0,
+                                       return_final_position=True, device_id=0, inspect_callback=lambda s: tables.append(s.n_samples))
+        finally:
+            ift.random.pop_sseq()
+        torch.cuda.synchronize()
+        peak_api = torch.cuda.max_memory_allocated()
+        model = okl._fused_model(lh, 0, np.float32)
+        assert model is not None and model.sandwich and model.wide
+        assert tables == [2 * pairs] and sl.n_samples == 2 * pairs
+        api = {k: mean[k].val.clone() for k in mean.keys()}
+        first_residual = sl._r[0]["xi"].val.clone()
+        del sl, mean
+        gc.collect()
+        torch.cuda.empty_cache()
+        # --- the engine on the same seeds: optimize_kl spawns one SeedSequence per iteration from the top of the stack and
+        #     pushes it for the iteration (optimize_kl.py:346-358)
+        start = okl._mf_to_latent(model, x0)
+        random.push_sseq_from_seed(7)
+        try:
+            random.push_sseq(random.spawn_sseq(1)[0])
+            try:
+                ic2, mk2 = _controllers()
+                pos, kl = mgvi_iteration(model, start, pairs, lambda: ic2, mk2(0))
+            finally:
+                random.pop_sseq()
+        finally:
+            random.pop_sseq()
+        torch.cuda.synchronize()
+        eng = okl._latent_to_mf(lh.domain, pos, np.float32)
+        out = dict(peak_api=peak_api, first_residual_equal=bool(torch.equal(first_residual, kl.residuals[0].xi)))
+        for k in api:
+            out[k] = float((api[k].double() - eng[k].val.double()).abs().max().item()) / max(float(api[k].double().abs().max().item()), 1e-30)
+        return out
+    finally:
+        ift.random.pop_sseq()
+        okl._fused_cache.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def test_optimize_kl_small_cube_equals_the_engine():
+    """the same comparison at 128^3 (seconds): driver == engine on identical seeds, bit for bit"""
+    out = _run_both(128, 2)
+    assert out.pop("first_residual_equal")
+    out.pop("peak_api")
+    assert all(v == 0.0 for v in out.values()), out
+
+
+@pytest.mark.timeout(1800)
+def test_headline_workload_through_optimize_kl():
+    free, total = torch.cuda.mem_get_info()
+    if total < 250 * 2 ** 30:
+        pytest.skip("needs the 288 GB of an MI355X")
+    out = _run_both(1024, 4)
+    peak = out.pop("peak_api")
+    print(f"optimize_kl at 1024^3 fp32, 8 samples: peak device memory {peak / 2 ** 30:.1f} GiB")
+    assert peak < 288 * 2 ** 30
+    assert out.pop("first_residual_equal")
+    assert all(v == 0.0 for v in out.values()), out

@@ -74,7 +74,9 @@ def _check_run_files(outdir, g, device):
     assert [q.entropy for q in ours[0]] == [q.entropy for q in theirs[0]]
     assert [q.spawn_key for q in ours[0]] == [q.spawn_key for q in theirs[0]]
     assert [q.n_children_spawned for q in ours[0]] == [q.n_children_spawned for q in theirs[0]]
-    assert [r.bit_generator.state for r in ours[1]] == [r.bit_generator.state for r in theirs[1]]
+    # (frame 0 is the process-wide default generator: where it stands depends on what ran before in this process)
+    assert [r.bit_generator.state for r in ours[1][1:]] == [r.bit_generator.state for r in theirs[1][1:]] and len(ours[1]) >= 2
+    assert ours[1][0].bit_generator.state["state"]["inc"] == theirs[1][0].bit_generator.state["state"]["inc"]
     with open(os.path.join(outdir, "pickle", "minisanity_history_latest"), "rb") as f:
         history = pickle.load(f)
     checked = 0
