@@ -297,7 +297,9 @@ def api_leg(shape, dtype, lh_kind, noise_var, data, n_pairs, steps, device, engi
     and per transform of the fused engine underneath, the overhead of the driver layer per transform against the engine
     leg of this run, and the peak device memory of the leg."""
     import nifty_amd as ift
-    from nifty_amd import optimize_kl as okl
+    import importlib
+
+    okl = importlib.import_module("nifty_amd.optimize_kl")  # (the package attribute of that name is the function)
     from nifty_amd.field import Field
 
     npdt = np.float32 if dtype == torch.float32 else np.float64

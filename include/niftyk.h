@@ -5,8 +5,12 @@
  * contiguous C order; the caller owns memory and lifetime.  `stream` is a hipStream_t passed as
  * void* (0 = default stream).  Every function returns 0 on success or a negative nk_status code and
  * never throws; nk_last_error() returns a thread-local message for the last failure.
- * Plans are immutable after creation; execution is ordered by the stream.  No entry point allocates
- * device memory after plan creation (workspace is passed in; size from nk_plan_workspace_bytes).
+ * Plans are immutable after creation; execution is ordered by the stream.  The transforms allocate
+ * nothing after plan creation (workspace is passed in; size from nk_plan_workspace_bytes).  The
+ * deterministic reductions (nk_vdot, nk_sum, nk_stats, nk_axpby_sqnorm, nk_cg_*, their *_batch forms)
+ * keep 4 MiB of block partials per (device, stream) pair, allocated with hipMalloc the FIRST time a
+ * reduction runs on that stream and kept for the life of the process: call any of them once on a
+ * stream before capturing it into a graph or timing it.
  */
 #ifndef NIFTYK_H
 #define NIFTYK_H
@@ -451,6 +455,66 @@ int nk_pcg64_uniform(const uint64_t* state, const uint64_t* inc, int64_t n, doub
                      void* scratch, void* stream);
 int nk_pcg64_pm1(const uint64_t* state, const uint64_t* inc, int64_t n, void* out, int dtype, int complex_units, void* scratch,
                  void* stream);
+
+/* ---- batched launches: ONE launch per kernel for up to NK_MAX_BATCH independent members -------------------------------
+ *      On small grids (2048^2: 128 workgroups per transform pass on 256 CUs, amplitude kernels of 5-20 us) one member's
+ *      kernel chain leaves most of the chip idle and the launches themselves set the time.  The members of a batch are
+ *      what the reference loops over: the samples of a KL evaluation / metric application (SampledKLEnergyClass,
+ *      minimization/kl_energies.py:306-350: `for s in samples`), and the independent linear solves that draw the samples
+ *      of one iteration (draw_samples, kl_energies.py:132-158; SamplingEnabler.special_draw_sample,
+ *      operators/sampling_enabler.py:64-86).  Every `*_batch` entry point below is its single-member counterpart for
+ *      `count` members with the second grid dimension running over the members: per-member arguments are HOST arrays of
+ *      `count` device pointers (or an array of `count` nk_fuse records), everything else is shared.  The arithmetic of a
+ *      member -- grid, summation orders, reduction slots -- is exactly that of the single call, so the results are
+ *      bit-identical to `count` single calls.  1 <= count <= NK_MAX_BATCH. */
+#define NK_MAX_BATCH 8
+/* 1 if nk_hartley_fused_batch runs the members of this plan in shared launches (2-D plans of the register-resident
+ * pipeline, nk_plan_octant_vjp != 0); 0: it falls back to one nk_hartley_fused per member (same results) */
+int nk_plan_batch_ok(const nk_plan* plan);
+/* nk_hartley_fused for fuse[0..count) on workspace[0..count) (each nk_plan_workspace_bytes, pairwise distinct).  All
+ * members must select the same kernel classes: same prologue / epilogue, the same of {afield, dafield, field_octant,
+ * io32} set or unset (NK_ERR_INVALID otherwise); pointers, scalars and the optional addend / accumulate / carry / value
+ * may differ per member. */
+int nk_hartley_fused_batch(const nk_plan* plan, const nk_fuse* fuse, int count, int convention, void* const* workspace,
+                           void* stream);
+/* amplitude model (nk_amp_forward / nk_amp_jvp / nk_amp_vjp) for `count` latent points: lat / state / amp / dlat / damp /
+ * abar / latbar are arrays of `count` device pointers (state and the outputs pairwise distinct; lat or dlat may repeat) */
+int nk_amp_forward_batch(int nb, const double* geo, const double* hyp, int count, const double* const* lat,
+                         double* const* state, double* const* amp, void* stream);
+int nk_amp_jvp_batch(int nb, const double* geo, const double* hyp, int count, const double* const* lat, double* const* state,
+                     const double* const* dlat, double* const* damp, void* stream);
+int nk_amp_vjp_batch(int nb, const double* geo, const double* hyp, int count, const double* const* lat, double* const* state,
+                     const double* const* abar, double* const* latbar, void* stream);
+/* nk_gather with one table and one output per member over a shared index; nk_csr_rowsum with one x / y per member over
+ * a shared matrix */
+int nk_gather_batch(int64_t n, int count, const void* const* table, const int32_t* pidx, void* const* out, int dtype,
+                    void* stream);
+int nk_csr_rowsum_batch(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, int count,
+                        const void* const* x, void* const* y, int dtype, int lanes, void* stream);
+/* out[m] = alpha[m] * x[m] + beta[m] * y[m] (y[m] may be NULL); the _sqnorm form also result[m] (+)= sum(out[m]^2) */
+int nk_axpby_batch(int64_t n, int count, const double* alpha, const void* const* x, const double* beta,
+                   const void* const* y, void* const* out, int dtype, void* stream);
+int nk_axpby_sqnorm_batch(int64_t n, int count, const double* alpha, const void* const* x, const double* beta,
+                          const void* const* y, void* const* out, int dtype, double* const* result, int accumulate,
+                          void* stream);
+/* out[m] = a[m] (op) b[m] with the scalar conventions of nk_binary per member (a[m] == NULL: ascalar[m], ...) */
+int nk_binary_batch(int op, int64_t n, int count, const void* const* a, const double* ascalar, const void* const* b,
+                    const double* bscalar, void* const* out, int dtype, void* stream);
+int nk_vdot_batch(int64_t n, int count, const void* const* a, const void* const* b, int dtype, double* const* result,
+                  int accumulate, void* stream);
+/* out = the sum of term[0..count) element by element in the order of the reference's task-count-independent sum
+ * (nifty/cl/utilities.py:349-414: neighbours first, then pairs of pairs, ...; every partial sum rounded to `dtype` like a
+ * stored vector) -- the sum over the samples of a batch; out may be term[0] */
+int nk_sum_tree(int64_t n, int count, const void* const* term, void* out, int dtype, void* stream);
+/* the fused CG updates for `count` independent solves, scal[m] = that solve's device double[8] */
+int nk_cg_curv_batch(int64_t n, int count, const void* const* d, const void* const* q, int dtype, double* const* scal,
+                     int accumulate, void* stream);
+int nk_cg_update_batch(int64_t n, int count, void* const* x, void* const* r, const void* const* d, const void* const* q,
+                       const void* const* b, int dtype, double* const* scal, int accumulate, void* stream);
+int nk_cg_update_dr_batch(int64_t n, int count, void* const* x, void* const* r, const void* const* d,
+                          const void* const* q, int dtype, double* const* scal, int accumulate, void* stream);
+int nk_cg_direction_batch(int64_t n, int count, void* const* d, const void* const* r, int dtype, double* const* scal,
+                          int roll, void* stream);
 
 #ifdef __cplusplus
 }

@@ -101,7 +101,34 @@ SIGNATURES = {
     "nk_amp_forward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nk_amp_jvp": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nk_amp_vjp": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    # batched launches: per-member arguments are host arrays of `count` device pointers (ptr_array)
+    "nk_plan_batch_ok": (_i, [_vp]),
+    "nk_hartley_fused_batch": (_i, [_vp, ctypes.POINTER(Fuse), _i, _i, _vp, _vp]),
+    "nk_amp_forward_batch": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "nk_amp_jvp_batch": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "nk_amp_vjp_batch": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "nk_gather_batch": (_i, [_i64, _i, _vp, _vp, _vp, _i, _vp]),
+    "nk_csr_rowsum_batch": (_i, [_i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
+    "nk_axpby_batch": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "nk_axpby_sqnorm_batch": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "nk_binary_batch": (_i, [_i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "nk_vdot_batch": (_i, [_i64, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "nk_sum_tree": (_i, [_i64, _i, _vp, _vp, _i, _vp]),
+    "nk_cg_curv_batch": (_i, [_i64, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "nk_cg_update_batch": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "nk_cg_update_dr_batch": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "nk_cg_direction_batch": (_i, [_i64, _i, _vp, _vp, _i, _vp, _i, _vp]),
 }
+MAX_BATCH = 8  # NK_MAX_BATCH of include/niftyk.h
+
+
+def ptr_array(tensors):
+    """Host array of device pointers for a `*_batch` entry point (None -> NULL)."""
+    return (_vp * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def double_array(values):
+    return (_d * len(values))(*[float(v) for v in values])
 
 _lib = None
 

@@ -709,6 +709,34 @@ class ProductCorrelatedFieldOperator(Operator):
 # ------------------------------------------------------------------------------------------------
 # maker
 # ------------------------------------------------------------------------------------------------
+class _ProductLayout:
+    """Where the sub-spaces of a (product) correlated field sit: the harmonic product domain -- with a leading
+    UnstructuredDomain(total_N) when several fields share the model -- the axis of every sub-space in it, and the operators
+    that move between a sub-space's power bins, the product domain and position space."""
+
+    def __init__(self, amplitudes, position_subdomains, total_N):
+        lead = [UnstructuredDomain(total_N)] if total_N > 0 else []
+        self.first = len(lead)  # index of the modelled space inside an amplitude's own target (behind the field copies)
+        self.bins = [a.target[self.first] for a in amplitudes]
+        self.harmonic = makeDomain(lead + [b.harmonic_partner for b in self.bins])
+        self.axes = tuple(range(self.first, self.first + len(amplitudes)))
+        self.positions = [sub[self.first] for sub in position_subdomains]
+        self.broadcast = ContractionOperator(self.harmonic, self.axes).adjoint  # field copies -> product domain
+
+    def spread(self, which, amplitude):
+        """the amplitude of sub-space `which` (on its power bins) as a field on the whole product domain: distributed over
+        its own harmonic space, constant along the others"""
+        others = tuple(ax for ax in self.axes if ax != self.axes[which])
+        along_others = ContractionOperator(self.harmonic, others)
+        distribute = PowerDistributor(along_others.target, self.bins[which], self.first)
+        return along_others.adjoint @ distribute @ amplitude
+
+    def to_position(self, op):
+        for axis, position in zip(self.axes, self.positions):
+            op = HarmonicTransformOperator(op.target, position, space=axis) @ op
+        return op
+
+
 class CorrelatedFieldMaker:
     """Construction helper (reference correlated_fields.py:389-859): one or several amplitude spectra (power-law +
     integrated Wiener process, reduced variants, Matern); the single full amplitude is fused into one device operator."""
@@ -853,31 +881,17 @@ class CorrelatedFieldMaker:
 
     def _generic_graph(self):
         """offset + HT( azm * prod_i a_i[pindex_i] * xi ) on the product of the harmonic spaces, with a leading
-        UnstructuredDomain(total_N) when several fields are modelled at once (reference correlated_fields.py:713-764)."""
-        n = len(self._a)
-        if self._total_N > 0:
-            hspace = makeDomain([UnstructuredDomain(self._total_N)] + [a.target[-1].harmonic_partner for a in self._a])
-            spaces, amp_space = tuple(range(1, n + 1)), 1
-        else:
-            hspace = makeDomain([a.target[0].harmonic_partner for a in self._a])
-            spaces, amp_space = tuple(range(n)), 0
-        ht = HarmonicTransformOperator(hspace, self._target_subdomains[0][amp_space], space=spaces[0])
-        for i in range(1, n):
-            ht = HarmonicTransformOperator(ht.target, self._target_subdomains[i][amp_space], space=spaces[i]) @ ht
-        amps = list(self.get_normalized_amplitudes())
-        for i in range(n):
-            co = ContractionOperator(hspace, spaces[:i] + spaces[i + 1:])
-            amps[i] = co.adjoint @ PowerDistributor(co.target, amps[i].target[amp_space], amp_space) @ amps[i]
-        corr = amps[0]
-        for a in amps[1:]:
-            corr = corr * a
-        xi = Variable(hspace, self._prefix + "xi")
-        expander = ContractionOperator(hspace, spaces).adjoint
-        azm = expander @ self.azm
-        op = ht((azm * corr).real * xi)
-        if self._offset_mean is not None:
-            op = op + float(self._offset_mean)
-        return op
+        UnstructuredDomain(total_N) when several fields are modelled at once (reference correlated_fields.py:713-764):
+        every sub-space spreads its amplitude over the whole product domain, the spread amplitudes and the zero mode
+        multiply the excitations, one harmonic transform per sub-space takes the product to position space."""
+        layout = _ProductLayout(self._a, self._target_subdomains, self._total_N)
+        spectrum = None
+        for which, amplitude in enumerate(self.get_normalized_amplitudes()):
+            spread = layout.spread(which, amplitude)
+            spectrum = spread if spectrum is None else spectrum * spread
+        excitations = Variable(layout.harmonic, self._prefix + "xi")
+        field = layout.to_position(((layout.broadcast @ self.azm) * spectrum).real * excitations)
+        return field if self._offset_mean is None else field + float(self._offset_mean)
 
     def _product_operator(self, generic):
         """Several spectra and / or total_N > 0: the amplitude graphs feed one fused node (`_ProductFieldNode`); anything

@@ -12,7 +12,9 @@
 // The double cumulative sum is ONE scan with the associative affine operator
 //   (c, s) -> (c + A, s + c*Dk + B),  compose(l, r) = (Al+Ar, Dl+Dr, Bl+Br+Al*Dr)
 // executed as a two-launch multi-workgroup scan (per-workgroup aggregates, then carry-in + rescan), followed by
-// the element-wise / reduction stages: forward and JVP are 3 launches, VJP 5 (+ one memset) over <= 256 workgroups.
+// the element-wise / reduction stages: forward and JVP are 3 launches, VJP 5 (+ one zeroing launch) over <= 256 workgroups.
+// Every kernel runs a BATCH of latent points (include/niftyk.h, "batched launches"): blockIdx.y = member, the member's
+// latent vector, state and in / out arrays come from a pointer table; the single entry points are batches of one.
 #include <hip/hip_runtime.h>
 
 #include "nk_util.h"
@@ -24,6 +26,13 @@ constexpr int AMP_WAVES = AMP_THREADS / 64;
 
 struct Seg {
   double A, D, B;
+};
+// per-member arrays of a batched launch: lat, state and one more input (dlat / abar) and output (amp / damp / latbar)
+struct AmpBatch {
+  const double* lat[NK_MAX_BATCH];
+  double* state[NK_MAX_BATCH];
+  const double* in[NK_MAX_BATCH];
+  double* out[NK_MAX_BATCH];
 };
 __device__ __forceinline__ Seg seg_combine(const Seg& l, const Seg& r) {  // l first, then r
   return Seg{l.A + r.A, l.D + r.D, l.B + r.B + l.A * r.D};
@@ -77,18 +86,17 @@ __device__ __forceinline__ void amp_store_sums(const double (&v)[NV] /* valid in
                                                double* const (&dst)[NV], double* sh /*[AMP_WAVES]*/, unsigned int* ticket) {
   __shared__ bool is_last;
   if (threadIdx.x == 0) {
+    // partials -> coherence point, then the ticket; the last workgroup reads them from there (nk_util.h, nk_publish_partial)
 #pragma unroll
-    for (int k = 0; k < NV; ++k) part[k * gridDim.x + blockIdx.x] = v[k];
-    __threadfence();
-    is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    for (int k = 0; k < NV; ++k) nk_publish_partial(&part[k * gridDim.x + blockIdx.x], v[k]);
+    is_last = nk_take_last_ticket(ticket, gridDim.x);
   }
   __syncthreads();
   if (!is_last) return;
-  __threadfence();
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     double x = 0.0;
-    for (int g = threadIdx.x; g < (int)gridDim.x; g += AMP_THREADS) x += __builtin_nontemporal_load(&part[k * gridDim.x + g]);
+    for (int g = threadIdx.x; g < (int)gridDim.x; g += AMP_THREADS) x += nk_read_partial(&part[k * gridDim.x + g]);
     const double t = block_sum(x, sh);
     if (threadIdx.x == 0) *dst[k] = t;
   }
@@ -233,9 +241,10 @@ __device__ __forceinline__ Seg fwd_elem(const AmpPtrs& a, const Hyper& h, const 
 }
 
 __global__ void __launch_bounds__(AMP_THREADS) k_fwd_agg(int nb, ScanGeom sg, const double* __restrict__ geo,
-                                                         const double* __restrict__ hyp, const double* __restrict__ lat,
-                                                         double* __restrict__ state) {
+                                                         const double* __restrict__ hyp, AmpBatch mb) {
   __shared__ Seg sh_seg[AMP_WAVES + 1];
+  const double* __restrict__ lat = mb.lat[blockIdx.y];
+  double* __restrict__ state = mb.state[blockIdx.y];
   const AmpPtrs a = amp_ptrs(nb, geo, state);
   const Hyper h = hyper_from_lat(hyp, lat);
   const double *xs0 = lat + 5, *xs1 = lat + 5 + sg.m;
@@ -251,10 +260,11 @@ __global__ void __launch_bounds__(AMP_THREADS) k_fwd_agg(int nb, ScanGeom sg, co
 }
 
 __global__ void __launch_bounds__(AMP_THREADS) k_fwd_apply(int nb, ScanGeom sg, const double* __restrict__ geo,
-                                                           const double* __restrict__ hyp, const double* __restrict__ lat,
-                                                           double* __restrict__ state) {
+                                                           const double* __restrict__ hyp, AmpBatch mb) {
   __shared__ Seg sh_seg[AMP_WAVES + 1];
   __shared__ double sh_d[AMP_WAVES];
+  const double* __restrict__ lat = mb.lat[blockIdx.y];
+  double* __restrict__ state = mb.state[blockIdx.y];
   const AmpPtrs a = amp_ptrs(nb, geo, state);
   const Hyper h = hyper_from_lat(hyp, lat);
   const double *xs0 = lat + 5, *xs1 = lat + 5 + sg.m;
@@ -278,7 +288,9 @@ __global__ void __launch_bounds__(AMP_THREADS) k_fwd_apply(int nb, ScanGeom sg, 
   amp_store_sums<1>(v, a.part, dst, sh_d, amp_ticket(state));
 }
 
-__global__ void k_fwd_final(int nb, const double* __restrict__ hyp, double* __restrict__ state, double* __restrict__ amp) {
+__global__ void k_fwd_final(int nb, const double* __restrict__ hyp, AmpBatch mb) {
+  double* __restrict__ state = mb.state[blockIdx.y];
+  double* __restrict__ amp = mb.out[blockIdx.y];
   const double S = state[5], V = hyp[10], zm = state[3], fluct = state[2];
   const double* spec = state + 16;
   double* ahat = state + 16 + nb;
@@ -307,9 +319,11 @@ __device__ __forceinline__ Seg jvp_elem(const AmpPtrs& a, const JvpScal& q, cons
 }
 
 __global__ void __launch_bounds__(AMP_THREADS) k_jvp_agg(int nb, ScanGeom sg, const double* __restrict__ geo,
-                                                         const double* __restrict__ hyp, const double* __restrict__ lat,
-                                                         double* __restrict__ state, const double* __restrict__ dlat) {
+                                                         const double* __restrict__ hyp, AmpBatch mb) {
   __shared__ Seg sh_seg[AMP_WAVES + 1];
+  const double* __restrict__ lat = mb.lat[blockIdx.y];
+  double* __restrict__ state = mb.state[blockIdx.y];
+  const double* __restrict__ dlat = mb.in[blockIdx.y];
   const AmpPtrs a = amp_ptrs(nb, geo, state);
   const JvpScal q{state[0], state[1], state[0] * hyp[3] * dlat[1], state[1] * hyp[5] * dlat[0]};
   const Seg c = chunk_aggregate(
@@ -321,10 +335,12 @@ __global__ void __launch_bounds__(AMP_THREADS) k_jvp_agg(int nb, ScanGeom sg, co
 }
 
 __global__ void __launch_bounds__(AMP_THREADS) k_jvp_apply(int nb, ScanGeom sg, const double* __restrict__ geo,
-                                                           const double* __restrict__ hyp, const double* __restrict__ lat,
-                                                           double* __restrict__ state, const double* __restrict__ dlat) {
+                                                           const double* __restrict__ hyp, AmpBatch mb) {
   __shared__ Seg sh_seg[AMP_WAVES + 1];
   __shared__ double sh_d[AMP_WAVES];
+  const double* __restrict__ lat = mb.lat[blockIdx.y];
+  double* __restrict__ state = mb.state[blockIdx.y];
+  const double* __restrict__ dlat = mb.in[blockIdx.y];
   const AmpPtrs a = amp_ptrs(nb, geo, state);
   const JvpScal q{state[0], state[1], state[0] * hyp[3] * dlat[1], state[1] * hyp[5] * dlat[0]};
   const double dslope = hyp[9] * dlat[3];
@@ -348,8 +364,10 @@ __global__ void __launch_bounds__(AMP_THREADS) k_jvp_apply(int nb, ScanGeom sg, 
   amp_store_sums<1>(v, a.part, dst, sh_d, amp_ticket(state));
 }
 
-__global__ void k_jvp_final(int nb, const double* __restrict__ hyp, const double* __restrict__ state,
-                            const double* __restrict__ dlat, double* __restrict__ damp) {
+__global__ void k_jvp_final(int nb, const double* __restrict__ hyp, AmpBatch mb) {
+  const double* __restrict__ state = mb.state[blockIdx.y];
+  const double* __restrict__ dlat = mb.in[blockIdx.y];
+  double* __restrict__ damp = mb.out[blockIdx.y];
   const double S = state[5], dS = state[7], V = hyp[10], fluct = state[2], zm = state[3];
   const double dfluct = fluct * hyp[1] * dlat[2], dzm = zm * hyp[7] * dlat[4];
   const double* ahat = state + 16 + nb;
@@ -361,9 +379,10 @@ __global__ void k_jvp_final(int nb, const double* __restrict__ hyp, const double
 }
 
 // ---- VJP --------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(AMP_THREADS) k_vjp_red1(int nb, const double* __restrict__ hyp, double* __restrict__ state,
-                                                          const double* __restrict__ abar) {
+__global__ void __launch_bounds__(AMP_THREADS) k_vjp_red1(int nb, const double* __restrict__ hyp, AmpBatch mb) {
   __shared__ double sh_d[AMP_WAVES];
+  double* __restrict__ state = mb.state[blockIdx.y];
+  const double* __restrict__ abar = mb.in[blockIdx.y];
   const double V = hyp[10], fluct = state[2];
   const double* ahat = state + 16 + nb;
   double p_fl = 0.0, p_q = 0.0;
@@ -380,8 +399,10 @@ __global__ void __launch_bounds__(AMP_THREADS) k_vjp_red1(int nb, const double* 
 }
 
 __global__ void __launch_bounds__(AMP_THREADS) k_vjp_red2(int nb, const double* __restrict__ geo, const double* __restrict__ hyp,
-                                                          double* __restrict__ state, const double* __restrict__ abar) {
+                                                          AmpBatch mb) {
   __shared__ double sh_d[AMP_WAVES];
+  double* __restrict__ state = mb.state[blockIdx.y];
+  const double* __restrict__ abar = mb.in[blockIdx.y];
   const AmpPtrs a = amp_ptrs(nb, geo, state);
   const double V = hyp[10], fluct = state[2], S = state[5], Q = state[9];
   double p_sl = 0.0, p_sc = 0.0;
@@ -408,20 +429,21 @@ __device__ __forceinline__ Seg vjp_elem(const AmpPtrs& a, int nb, int m, double 
   return Seg{y, 0.5 * (dj + dn), 0.5 * y * dj};
 }
 
-__global__ void __launch_bounds__(AMP_THREADS) k_vjp_agg(int nb, ScanGeom sg, const double* __restrict__ geo,
-                                                         double* __restrict__ state) {
+__global__ void __launch_bounds__(AMP_THREADS) k_vjp_agg(int nb, ScanGeom sg, const double* __restrict__ geo, AmpBatch mb) {
   __shared__ Seg sh_seg[AMP_WAVES + 1];
+  double* __restrict__ state = mb.state[blockIdx.y];
   const AmpPtrs a = amp_ptrs(nb, geo, state);
   const double sc_dot = state[11];
   const Seg c = chunk_aggregate(sg, true, [&](int j) { return vjp_elem(a, nb, sg.m, sc_dot, j); }, sh_seg);
   if (threadIdx.x == 0) a.segs[3 * blockIdx.x] = c.A, a.segs[3 * blockIdx.x + 1] = c.D, a.segs[3 * blockIdx.x + 2] = c.B;
 }
 
-__global__ void __launch_bounds__(AMP_THREADS) k_vjp_apply(int nb, ScanGeom sg, const double* __restrict__ geo,
-                                                           const double* __restrict__ lat, double* __restrict__ state,
-                                                           double* __restrict__ latbar) {
+__global__ void __launch_bounds__(AMP_THREADS) k_vjp_apply(int nb, ScanGeom sg, const double* __restrict__ geo, AmpBatch mb) {
   __shared__ Seg sh_seg[AMP_WAVES + 1];
   __shared__ double sh_d[AMP_WAVES];
+  const double* __restrict__ lat = mb.lat[blockIdx.y];
+  double* __restrict__ state = mb.state[blockIdx.y];
+  double* __restrict__ latbar = mb.out[blockIdx.y];
   const AmpPtrs a = amp_ptrs(nb, geo, state);
   const double flex = state[0], asp = state[1], sc_dot = state[11];
   const double *xs0 = lat + 5, *xs1 = lat + 5 + sg.m;
@@ -449,8 +471,10 @@ __global__ void __launch_bounds__(AMP_THREADS) k_vjp_apply(int nb, ScanGeom sg, 
   amp_store_sums<2>(v, a.part, dst, sh_d, amp_ticket(state));
 }
 
-__global__ void k_vjp_final(const double* __restrict__ hyp, const double* __restrict__ state, const double* __restrict__ abar,
-                            double* __restrict__ latbar) {
+__global__ void k_vjp_final(const double* __restrict__ hyp, AmpBatch mb) {
+  const double* __restrict__ state = mb.state[blockIdx.y];
+  const double* __restrict__ abar = mb.in[blockIdx.y];
+  double* __restrict__ latbar = mb.out[blockIdx.y];
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const double flex = state[0], asp = state[1], fluct = state[2], zm = state[3], V = hyp[10];
     latbar[0] = state[13] * asp * hyp[5];
@@ -461,6 +485,11 @@ __global__ void k_vjp_final(const double* __restrict__ hyp, const double* __rest
   }
 }
 
+// state[8 .. 13] of every member <- 0 (the VJP reductions start from zero)
+__global__ void k_vjp_zero(AmpBatch mb) {
+  if (threadIdx.x < 6) mb.state[blockIdx.x][8 + threadIdx.x] = 0.0;
+}
+
 }  // namespace
 
 static inline int amp_grid(int nb) {
@@ -468,41 +497,79 @@ static inline int amp_grid(int nb) {
   return g < 1 ? 1 : (g > MAXG ? MAXG : g);
 }
 
-extern "C" int nk_amp_forward(int nb, const double* geo, const double* hyp, const double* lat, double* state,
-                              double* amp, void* stream) {
-  if (nb < 3 || !geo || !hyp || !lat || !state || !amp) return nk_set_error(NK_ERR_INVALID, "nk_amp_forward: bad argument");
+static int amp_batch(AmpBatch& mb, int count, const double* const* lat, double* const* state, const double* const* in,
+                     double* const* out, const char* who) {
+  if (count < 1 || count > NK_MAX_BATCH || !lat || !state || !out) return nk_set_error(NK_ERR_INVALID, who);
+  for (int m = 0; m < NK_MAX_BATCH; ++m) {
+    const int k = m < count ? m : 0;
+    if (!lat[k] || !state[k] || !out[k] || (in && !in[k])) return nk_set_error(NK_ERR_INVALID, who);
+    mb.lat[m] = lat[k], mb.state[m] = state[k], mb.in[m] = in ? in[k] : nullptr, mb.out[m] = out[k];
+  }
+  for (int a = 0; a < count; ++a)  // every member scribbles on its state and output: they must not be shared
+    for (int b = a + 1; b < count; ++b)
+      if (state[a] == state[b] || out[a] == out[b]) return nk_set_error(NK_ERR_INVALID, who);
+  return NK_OK;
+}
+
+extern "C" int nk_amp_forward_batch(int nb, const double* geo, const double* hyp, int count, const double* const* lat,
+                                    double* const* state, double* const* amp, void* stream) {
+  AmpBatch mb;
+  if (nb < 3 || !geo || !hyp) return nk_set_error(NK_ERR_INVALID, "nk_amp_forward: bad argument");
+  int rc = amp_batch(mb, count, lat, state, nullptr, amp, "nk_amp_forward: bad argument");
+  if (rc != NK_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   const ScanGeom sg = make_scan_geom(nb - 2);
-  hipLaunchKernelGGL(k_fwd_agg, dim3(sg.ngroups), dim3(AMP_THREADS), 0, st, nb, sg, geo, hyp, lat, state);
-  hipLaunchKernelGGL(k_fwd_apply, dim3(sg.ngroups), dim3(AMP_THREADS), 0, st, nb, sg, geo, hyp, lat, state);
-  hipLaunchKernelGGL(k_fwd_final, dim3(amp_grid(nb)), dim3(AMP_THREADS), 0, st, nb, hyp, state, amp);
+  hipLaunchKernelGGL(k_fwd_agg, dim3(sg.ngroups, count), dim3(AMP_THREADS), 0, st, nb, sg, geo, hyp, mb);
+  hipLaunchKernelGGL(k_fwd_apply, dim3(sg.ngroups, count), dim3(AMP_THREADS), 0, st, nb, sg, geo, hyp, mb);
+  hipLaunchKernelGGL(k_fwd_final, dim3(amp_grid(nb), count), dim3(AMP_THREADS), 0, st, nb, hyp, mb);
   return nk_check_launch("nk_amp_forward");
 }
 
-extern "C" int nk_amp_jvp(int nb, const double* geo, const double* hyp, const double* lat, double* state,
-                          const double* dlat, double* damp, void* stream) {
-  if (nb < 3 || !geo || !hyp || !lat || !state || !dlat || !damp)
-    return nk_set_error(NK_ERR_INVALID, "nk_amp_jvp: bad argument");
+extern "C" int nk_amp_jvp_batch(int nb, const double* geo, const double* hyp, int count, const double* const* lat,
+                                double* const* state, const double* const* dlat, double* const* damp, void* stream) {
+  AmpBatch mb;
+  if (nb < 3 || !geo || !hyp || !dlat) return nk_set_error(NK_ERR_INVALID, "nk_amp_jvp: bad argument");
+  int rc = amp_batch(mb, count, lat, state, dlat, damp, "nk_amp_jvp: bad argument");
+  if (rc != NK_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   const ScanGeom sg = make_scan_geom(nb - 2);
-  hipLaunchKernelGGL(k_jvp_agg, dim3(sg.ngroups), dim3(AMP_THREADS), 0, st, nb, sg, geo, hyp, lat, state, dlat);
-  hipLaunchKernelGGL(k_jvp_apply, dim3(sg.ngroups), dim3(AMP_THREADS), 0, st, nb, sg, geo, hyp, lat, state, dlat);
-  hipLaunchKernelGGL(k_jvp_final, dim3(amp_grid(nb)), dim3(AMP_THREADS), 0, st, nb, hyp, state, dlat, damp);
+  hipLaunchKernelGGL(k_jvp_agg, dim3(sg.ngroups, count), dim3(AMP_THREADS), 0, st, nb, sg, geo, hyp, mb);
+  hipLaunchKernelGGL(k_jvp_apply, dim3(sg.ngroups, count), dim3(AMP_THREADS), 0, st, nb, sg, geo, hyp, mb);
+  hipLaunchKernelGGL(k_jvp_final, dim3(amp_grid(nb), count), dim3(AMP_THREADS), 0, st, nb, hyp, mb);
   return nk_check_launch("nk_amp_jvp");
 }
 
-extern "C" int nk_amp_vjp(int nb, const double* geo, const double* hyp, const double* lat, double* state,
-                          const double* abar, double* latbar, void* stream) {
-  if (nb < 3 || !geo || !hyp || !lat || !state || !abar || !latbar)
-    return nk_set_error(NK_ERR_INVALID, "nk_amp_vjp: bad argument");
+extern "C" int nk_amp_vjp_batch(int nb, const double* geo, const double* hyp, int count, const double* const* lat,
+                                double* const* state, const double* const* abar, double* const* latbar, void* stream) {
+  AmpBatch mb;
+  if (nb < 3 || !geo || !hyp || !abar) return nk_set_error(NK_ERR_INVALID, "nk_amp_vjp: bad argument");
+  int rc = amp_batch(mb, count, lat, state, abar, latbar, "nk_amp_vjp: bad argument");
+  if (rc != NK_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   const ScanGeom sg = make_scan_geom(nb - 2);
-  hipError_t e = hipMemsetAsync(state + 8, 0, 6 * sizeof(double), st);
-  if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(amp vjp scalars)");
-  hipLaunchKernelGGL(k_vjp_red1, dim3(amp_grid(nb)), dim3(AMP_THREADS), 0, st, nb, hyp, state, abar);
-  hipLaunchKernelGGL(k_vjp_red2, dim3(amp_grid(nb)), dim3(AMP_THREADS), 0, st, nb, geo, hyp, state, abar);
-  hipLaunchKernelGGL(k_vjp_agg, dim3(sg.ngroups), dim3(AMP_THREADS), 0, st, nb, sg, geo, state);
-  hipLaunchKernelGGL(k_vjp_apply, dim3(sg.ngroups), dim3(AMP_THREADS), 0, st, nb, sg, geo, lat, state, latbar);
-  hipLaunchKernelGGL(k_vjp_final, dim3(1), dim3(64), 0, st, hyp, state, abar, latbar);
+  hipLaunchKernelGGL(k_vjp_zero, dim3(count), dim3(64), 0, st, mb);
+  hipLaunchKernelGGL(k_vjp_red1, dim3(amp_grid(nb), count), dim3(AMP_THREADS), 0, st, nb, hyp, mb);
+  hipLaunchKernelGGL(k_vjp_red2, dim3(amp_grid(nb), count), dim3(AMP_THREADS), 0, st, nb, geo, hyp, mb);
+  hipLaunchKernelGGL(k_vjp_agg, dim3(sg.ngroups, count), dim3(AMP_THREADS), 0, st, nb, sg, geo, mb);
+  hipLaunchKernelGGL(k_vjp_apply, dim3(sg.ngroups, count), dim3(AMP_THREADS), 0, st, nb, sg, geo, mb);
+  hipLaunchKernelGGL(k_vjp_final, dim3(1, count), dim3(64), 0, st, hyp, mb);
   return nk_check_launch("nk_amp_vjp");
+}
+
+extern "C" int nk_amp_forward(int nb, const double* geo, const double* hyp, const double* lat, double* state, double* amp,
+                              void* stream) {
+  if (!lat || !state || !amp) return nk_set_error(NK_ERR_INVALID, "nk_amp_forward: bad argument");
+  return nk_amp_forward_batch(nb, geo, hyp, 1, &lat, &state, &amp, stream);
+}
+
+extern "C" int nk_amp_jvp(int nb, const double* geo, const double* hyp, const double* lat, double* state, const double* dlat,
+                          double* damp, void* stream) {
+  if (!lat || !state || !dlat || !damp) return nk_set_error(NK_ERR_INVALID, "nk_amp_jvp: bad argument");
+  return nk_amp_jvp_batch(nb, geo, hyp, 1, &lat, &state, &dlat, &damp, stream);
+}
+
+extern "C" int nk_amp_vjp(int nb, const double* geo, const double* hyp, const double* lat, double* state, const double* abar,
+                          double* latbar, void* stream) {
+  if (!lat || !state || !abar || !latbar) return nk_set_error(NK_ERR_INVALID, "nk_amp_vjp: bad argument");
+  return nk_amp_vjp_batch(nb, geo, hyp, 1, &lat, &state, &abar, &latbar, stream);
 }

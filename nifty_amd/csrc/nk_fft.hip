@@ -8,9 +8,7 @@
 #include <cstring>
 #include <new>
 
-#include "nk_plan.h"
-#include "nk_fft2.h"
-#include "nk_util.h"
+#include "nk_fft_batch.h"
 
 // ------------------------------------------------------------------------------------------------
 // optional live profiling: HIP events around every pass-kernel launch, on the launch stream
@@ -18,6 +16,7 @@
 #include <mutex>
 #include <vector>
 using ProfScope = NkProfScope;  // live per-kernel HIP events (nk_util.h)
+thread_local const NkBatchCtx* t_batch = nullptr;  // set by nk_hartley_fused_batch around its launches
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
@@ -31,32 +30,6 @@ __device__ __forceinline__ void nk_run_stages(C2<T>* lds, int tid, int nthr, con
     NK_STAGE_DISPATCH(R, lds, tid, nthr, lp, tl, L, tw, s)
     L /= R;
     __syncthreads();
-  }
-}
-
-// fp64 sum of `acc` over the workgroup (only when the epilogue produces an energy).  With slots (set up by the library for
-// the final pass of the pipelines): every WAVEFRONT stores its partial sum to its own slot -- no LDS hop, no barrier at
-// the end of the kernel (a barrier there kept the workgroup's LDS and wave slots busy until its last wave arrived: 4 % of
-// the scatter pass) -- and the slots are folded in a fixed order afterwards: bit-reproducible, no atomics.  Without slots
-// (the generic kernels): one atomic per workgroup on *value.
-__device__ __forceinline__ void nk_flush_energy(const NkFuse& f, double acc, void* lds_raw) {
-  if ((f.epi != NK_EPI_LIKELIHOOD && f.epi != NK_EPI_VJP) || f.value == nullptr) return;
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nw = (blockDim.x + 63) >> 6;
-  if (f.value_slots > 0) {
-    const int64_t slot = (int64_t)blockIdx.x * nw + wave;
-    if (lane == 0 && slot < f.value_slots) f.value[slot] = acc;
-    return;
-  }
-  __syncthreads();  // LDS tile is dead from here on
-  double* red = (double*)lds_raw;
-  if (lane == 0) red[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int w = 0; w < nw; ++w) s += red[w];
-    atomicAdd(f.value, s);
   }
 }
 
@@ -151,12 +124,6 @@ __global__ void __launch_bounds__((ContigTile<T, H>::THREADS))
 
 // first pass (MODE 3): two workgroups per CU (<= 128 VGPRs at 512 threads); the in-place pass keeps the whole
 // register file for its loads in flight
-#ifndef NK_S0_WAVES
-#define NK_S0_WAVES 1
-#endif
-#ifndef NK_S1_TWO_WG
-#define NK_S1_TWO_WG 0
-#endif
 template <typename T, int N, int MODE, int PC>
 __global__ void __launch_bounds__((StridedTile<T, N, nk_strided_cx<MODE, PC>(), MODE>::THREADS),
                                   (StridedTile<T, N, nk_strided_cx<MODE, PC>(), MODE>::SC::E == 64
@@ -228,6 +195,14 @@ static int nk_launch_final_c(NkPassF pf, const NkFuse& f, const C2<T>* tw, const
   // every wavefront owns one slot of the energy / |w8| areas (nk_final_with_slots sized them): never drop a partial silently
   if (fs.value_slots > 0 && blocks * ((CT::THREADS + 63) / 64) > fs.value_slots)
     return nk_set_error(NK_ERR_RUNTIME, "final pass: more wavefronts than reduction slots (nk_value_slot_count)");
+  if (t_batch != nullptr) {
+    if constexpr (nk_twin_final<NL, COUPLES, EC, PAIR>()) {
+      if (pf.a_cnt > 0 || pf.g.batch != 1) return nk_set_error(NK_ERR_UNSUPPORTED, "batched final pass: one unstaged grid per member");
+      return nk_twin_launch_final<T, NL, COUPLES, EC>(pf, blocks, tw, xmap_env & 4, st);
+    } else {
+      return nk_set_error(NK_ERR_UNSUPPORTED, "batched final pass: no batched twin of this kernel class");
+    }
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CT::THREADS), CT::LDS_BYTES, st, pf, fs, tw, work, xmap_env & 4);
   return nk_check_launch("k2_final");
 }
@@ -381,6 +356,13 @@ static int nk_launch_strided_pc(NkPassS ps, const NkFuse& f, const C2<T>* tw, C2
   // in-place pass: bit 1 for every layout, bit 3 for the middle-axis pass of the sandwich only (blo > 0: 1.66 -> 1.62 ms at
   // 1024^3 fp32, while the in-place pass of the six-pass pipeline loses 8 % with it)
   const int xmap = MODE == 3 ? (xmap_env & 1) : ((xmap_env & 2) | ((xmap_env & 8) && ps.blo > 0 ? 2 : 0));
+  if (t_batch != nullptr) {
+    if constexpr (MODE != 3 || !nk_twin_strided<N, PC>()) {
+      return nk_set_error(NK_ERR_UNSUPPORTED, "batched strided pass: no batched twin of this kernel class");
+    } else {
+      return nk_twin_launch_strided<T, N, PC>(ps, blocks, tw, xmap, st);
+    }
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ST::THREADS), ST::LDS_TOTAL, st, ps, f, tw, work, scratch, xmap);
   return nk_check_launch("k2_strided");
 }
@@ -1163,8 +1145,7 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
   return rc != NK_OK ? rc : fold_slots();
 }
 
-extern "C" int nk_hartley_fused(const nk_plan* P, const nk_fuse* fuse, int convention, void* workspace,
-                                void* stream) {
+static int nk_fused_check(const nk_plan* P, const nk_fuse* fuse, int convention) {
   if (!P || !fuse) return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: null argument");
   if (!fuse->in || !fuse->out) return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused: in/out must be set");
   if (convention != NK_HARTLEY_NON_CANONICAL && convention != NK_HARTLEY_CANONICAL)
@@ -1195,9 +1176,154 @@ extern "C" int nk_hartley_fused(const nk_plan* P, const nk_fuse* fuse, int conve
     if ((int64_t)(g.na / 2 + 1) * (g.nm / 2 + 1) * (g.nl / 2 + 1) >= ((int64_t)1 << 31))
       return nk_set_error(NK_ERR_UNSUPPORTED, "nk_hartley_fused: octant field too large (>= 2^31 elements)");
   }
+  return NK_OK;
+}
+
+extern "C" int nk_hartley_fused(const nk_plan* P, const nk_fuse* fuse, int convention, void* workspace,
+                                void* stream) {
+  const int rc = nk_fused_check(P, fuse, convention);
+  if (rc != NK_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (P->hp.dtype == NK_F32) return nk_run_hartley<float>(P, *fuse, convention, workspace, st);
   return nk_run_hartley<double>(P, *fuse, convention, workspace, st);
+}
+
+// ---- nk_hartley_fused for a batch of members (include/niftyk.h) ---------------------------------------------------------
+struct NkSlotArr {
+  double* slots[NK_MAX_BATCH];  // nullptr: the member has no reduction
+  double* value[NK_MAX_BATCH];
+};
+__global__ void __launch_bounds__(256) k_zero_slots_b(NkSlotArr sa, int64_t n) {
+  double* p = sa.slots[blockIdx.y];
+  if (!p) return;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.0;
+}
+__global__ void __launch_bounds__(256) k_fold_slots_a_b(NkSlotArr sa, int64_t n) {
+  __shared__ double red[4];
+  const double* slots = sa.slots[blockIdx.y];
+  if (!slots) return;
+  double* part = sa.slots[blockIdx.y] + n;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double v = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) v += slots[i];
+  const double s = nk_fold_block_sum(v, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(NK_FOLD_BLOCKS) k_fold_slots_b_b(NkSlotArr sa, int64_t n) {
+  __shared__ double red[NK_FOLD_BLOCKS / 64];
+  if (!sa.slots[blockIdx.y]) return;
+  const double* part = sa.slots[blockIdx.y] + n;
+  const double s = nk_fold_block_sum(part[threadIdx.x], red);
+  if (threadIdx.x == 0) *sa.value[blockIdx.y] += s;
+}
+
+static bool nk_same_class(const nk_fuse& a, const nk_fuse& b) {
+  return a.pro == b.pro && a.epi == b.epi && !a.afield == !b.afield && !a.dafield == !b.dafield && !a.dampT == !b.dampT &&
+         a.field_octant == b.field_octant && !a.io32 == !b.io32 && !a.w8 == !b.w8 && !a.wfull == !b.wfull &&
+         a.abar_copies == b.abar_copies && !a.pidx_octant == !b.pidx_octant;
+}
+
+extern "C" int nk_plan_batch_ok(const nk_plan* P) {
+  if (!P || !nk_plan_uses_pipeline2(P) || !nk_fast_enabled()) return 0;
+  const NkHostPlan& hp = P->hp;
+  static const int pipeline = nk_env_int("NK_PIPELINE", 2);
+  if (hp.g.ndim != 2 || hp.g.batch != 1 || pipeline != 2 || !nk_fast_size(hp.g.nl)) return 0;
+  return P->hp.dtype == NK_F32 ? nk_fast_strided_ok<float>(hp.g.na, hp.pc.inner) : nk_fast_strided_ok<double>(hp.g.na, hp.pc.inner);
+}
+
+template <typename T>
+static int nk_run_hartley_batch(const nk_plan* P, const nk_fuse* fuse, int count, int convention, void* const* workspace,
+                                hipStream_t st) {
+  const NkHostPlan& hp = P->hp;
+  NkBatchCtx bc;
+  bc.count = count;
+  bc.fuse = fuse;
+  for (int m = 0; m < NK_MAX_BATCH; ++m) {
+    const int k = m < count ? m : 0;
+    bc.wa.work[m] = workspace[k];
+    bc.wa.scratch[m] = (char*)workspace[k] + (hp.work_bytes + 255) / 256 * 256;
+  }
+  static const int work_blo = nk_env_int("NK_WORK_BLO", 0), work_pad = nk_env_int("NK_WORK_PAD", 2080);
+  NkPipe2 q = nk_pipe2_setup(hp, convention == NK_HARTLEY_CANONICAL ? -1 : 1, work_blo, work_pad);
+  {
+    const int64_t smax = q.s1.ss > q.s0.inner ? q.s1.ss : q.s0.inner;
+    if (128 * (smax > q.s1.inner ? smax : q.s1.inner) * (int64_t)sizeof(C2<T>) >= ((int64_t)1 << 32))
+      return nk_set_error(NK_ERR_UNSUPPORTED, "transform too large for the 32-bit thread offsets of the strided passes");
+  }
+  // reduction slots of the final pass, member by member (nk_final_with_slots: energy / curvature sums; 2-D plans have no
+  // max |w8|)
+  const int64_t n = nk_value_slot_count(hp);
+  NkSlotArr sa;
+  bool any = false;
+  for (int m = 0; m < NK_MAX_BATCH; ++m) {
+    sa.slots[m] = nullptr, sa.value[m] = nullptr;
+    if (m >= count) {
+      bc.final_fuse[m] = fuse[0];
+      continue;
+    }
+    NkFuse f2 = fuse[m];
+    if (f2.w8max && f2.w8 && f2.epi == NK_EPI_VJP)
+      return nk_set_error(NK_ERR_UNSUPPORTED, "nk_fuse.w8max: only the 3-D final pass reports max |w8|");
+    f2.w8max = nullptr;
+    if (f2.value && (f2.epi == NK_EPI_LIKELIHOOD || f2.epi == NK_EPI_VJP)) {
+      sa.slots[m] = nk_value_slots(hp, workspace[m]);
+      sa.value[m] = f2.value;
+      f2.value = sa.slots[m];
+      f2.value_slots = (int)std::min<int64_t>(n, 0x7fffffff);
+      any = true;
+    }
+    bc.final_fuse[m] = f2;
+  }
+  struct Scope {  // the launchers see the batch only inside this call
+    Scope(const NkBatchCtx* b) { t_batch = b; }
+    ~Scope() { t_batch = nullptr; }
+  } scope(&bc);
+  int rc;
+  {
+    NkProfScope ps(st, 1, fuse[0].pro, fuse[0].epi, count);
+    rc = nk_dispatch_strided<T, 3>(hp.g.na, q.s1, fuse[0], (const C2<T>*)P->d_tw_c, (C2<T>*)bc.wa.work[0], (C2<T>*)bc.wa.scratch[0], st);
+  }
+  if (rc != NK_OK) return rc;
+  if (any) {
+    hipLaunchKernelGGL(k_zero_slots_b, dim3(64, count), dim3(256), 0, st, sa, n);
+    rc = nk_check_launch("k_zero_slots_b");
+    if (rc != NK_OK) return rc;
+  }
+  {
+    NkProfScope ps(st, 3, fuse[0].pro, fuse[0].epi, count);
+    rc = nk_dispatch_final<T>(hp.g.nl, q.pf, bc.final_fuse[0], (const C2<T>*)P->d_tw_f, (const C2<T>*)bc.wa.work[0], st);
+  }
+  if (rc != NK_OK || !any) return rc;
+  hipLaunchKernelGGL(k_fold_slots_a_b, dim3(NK_FOLD_BLOCKS, count), dim3(256), 0, st, sa, n);
+  hipLaunchKernelGGL(k_fold_slots_b_b, dim3(1, count), dim3(NK_FOLD_BLOCKS), 0, st, sa, n);
+  return nk_check_launch("k_fold_slots_b");
+}
+
+extern "C" int nk_hartley_fused_batch(const nk_plan* P, const nk_fuse* fuse, int count, int convention, void* const* workspace,
+                                      void* stream) {
+  if (!P || !fuse || !workspace || count < 1 || count > NK_MAX_BATCH)
+    return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused_batch: bad argument (1 <= count <= NK_MAX_BATCH)");
+  for (int m = 0; m < count; ++m) {
+    const int rc = nk_fused_check(P, fuse + m, convention);
+    if (rc != NK_OK) return rc;
+    if (!workspace[m]) return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused_batch: every member needs a workspace");
+    for (int k = 0; k < m; ++k)
+      if (workspace[k] == workspace[m]) return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused_batch: members share a workspace");
+    if (!nk_same_class(fuse[0], fuse[m]))
+      return nk_set_error(NK_ERR_INVALID, "nk_hartley_fused_batch: the members select different kernel classes");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (count == 1 || !nk_plan_batch_ok(P) || !nk_batch_class_ok(P->hp.g, fuse[0])) {  // one launch set per member: same results
+    for (int m = 0; m < count; ++m) {
+      const int rc = P->hp.dtype == NK_F32 ? nk_run_hartley<float>(P, fuse[m], convention, workspace[m], st)
+                                           : nk_run_hartley<double>(P, fuse[m], convention, workspace[m], st);
+      if (rc != NK_OK) return rc;
+    }
+    return NK_OK;
+  }
+  if (P->hp.dtype == NK_F32) return nk_run_hartley_batch<float>(P, fuse, count, convention, workspace, st);
+  return nk_run_hartley_batch<double>(P, fuse, count, convention, workspace, st);
 }
 
 // sandwich: out = EPI( scale * H( scale_first * mul_scalar * mul . H( PRO(in) ) ) ), five passes (nk_fft3.h)

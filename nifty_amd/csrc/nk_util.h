@@ -32,10 +32,35 @@ constexpr int NK_RED_MAX = 4;          // reductions per launch
 constexpr int NK_RED_MAX_BLOCKS = 16384;  // workgroups per launch (NK_RED_UNITS units x up to 256 workgroups each)
 constexpr int NK_RED_UNITS = 64;          // a long array is reduced as 64 equal contiguous UNITS (see NkRedLayout)
 struct NkRedScratch {
-  double* partial;       // [NK_RED_MAX][NK_RED_MAX_BLOCKS]
-  unsigned int* ticket;  // zero between launches
+  double* partial;       // [NK_MAX_BATCH][NK_RED_MAX][NK_RED_MAX_BLOCKS]: one set per member of a batched launch
+  unsigned int* ticket;  // [NK_MAX_BATCH], zero between launches
 };
+constexpr size_t NK_RED_MEMBER_STRIDE = (size_t)NK_RED_MAX * NK_RED_MAX_BLOCKS;  // partials of one batch member
 int nk_red_scratch(hipStream_t st, NkRedScratch* out);
+
+// Publishing a workgroup's partial sum to the LAST workgroup of the launch (ticket-ordered deterministic reductions) without
+// a device-scope fence.  The eight XCDs' L2s are not coherent with each other, so `__threadfence()` makes the workgroup
+// write back its XCD's whole L2 -- with one fence per workgroup a launch then costs time in proportion to its number of
+// workgroups (round 5: k_vjp_red2 15 us alone, 100 us for a batch of eight members; 23 us with this).  Instead the partial
+// is stored by an atomic EXCHANGE at agent scope: a read-modify-write is performed at the device's coherence point (past
+// the L2s), and once its old value has come back it HAS been performed.  Only then is the ticket taken (another agent-scope
+// RMW at the same point), so whoever draws the last ticket finds every partial there; it reads them with agent-scope
+// atomic loads, which bypass its own L2 as well.  No cache maintenance anywhere.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void nk_publish_partial(double* slot, double v) {
+  const unsigned long long old = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double_as_longlong(v),
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the returned value is consumed: the exchange has completed before anything that follows in program order is issued
+  asm volatile("" ::"v"(old) : "memory");
+}
+__device__ __forceinline__ bool nk_take_last_ticket(unsigned int* ticket, unsigned int count) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (waits for the outstanding memory operations of this wavefront)
+  return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == count - 1;
+}
+__device__ __forceinline__ double nk_read_partial(const double* slot) {
+  return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
 
 // How a reduction launch groups its partial sums.  An array of n elements whose length qualifies (nk_red_unit_elems) is
 // cut into NK_RED_UNITS contiguous units; every unit is reduced by its own sub-grid -- a function of the unit's length
@@ -64,7 +89,8 @@ struct NkProfScope {
   hipStream_t st;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int key;
+  int weight;  // members of a batched launch: it counts as `weight` launches of the key
   bool on;
-  NkProfScope(hipStream_t s, int kernel, int pro, int epi);
+  NkProfScope(hipStream_t s, int kernel, int pro, int epi, int weight = 1);
   ~NkProfScope();
 };

@@ -42,7 +42,7 @@ int nk_red_scratch(hipStream_t st, NkRedScratch* out) {
   auto key = std::make_pair(dev, st);
   auto it = g_red_map.find(key);
   if (it == g_red_map.end()) {
-    const size_t bytes = sizeof(double) * NK_RED_MAX * NK_RED_MAX_BLOCKS + 256;
+    const size_t bytes = sizeof(double) * NK_RED_MEMBER_STRIDE * NK_MAX_BATCH + 256;
     char* p = nullptr;
     e = hipMalloc((void**)&p, bytes);
     if (e != hipSuccess) return nk_set_hip_error(e, "hipMalloc(reduction scratch)");
@@ -52,7 +52,7 @@ int nk_red_scratch(hipStream_t st, NkRedScratch* out) {
     if (e != hipSuccess) return nk_set_hip_error(e, "hipMemsetAsync(reduction scratch)");
     NkRedScratch s;
     s.partial = (double*)p;
-    s.ticket = (unsigned int*)(p + sizeof(double) * NK_RED_MAX * NK_RED_MAX_BLOCKS);
+    s.ticket = (unsigned int*)(p + sizeof(double) * NK_RED_MEMBER_STRIDE * NK_MAX_BATCH);
     it = g_red_map.emplace(key, s).first;
   }
   t_red_dev = dev, t_red_stream = st, t_red_last = it->second;
@@ -64,7 +64,7 @@ int nk_red_scratch(hipStream_t st, NkRedScratch* out) {
 namespace {
 struct ProfRec {
   hipEvent_t e0, e1;
-  int key;
+  int key, weight;
 };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof_recs;
@@ -84,8 +84,8 @@ hipEvent_t prof_event() {
 }
 }  // namespace
 
-NkProfScope::NkProfScope(hipStream_t s, int kernel, int pro, int epi)
-    : st(s), key(kernel * 25 + pro * 5 + epi), on(g_prof_on) {
+NkProfScope::NkProfScope(hipStream_t s, int kernel, int pro, int epi, int w)
+    : st(s), key(kernel * 25 + pro * 5 + epi), weight(w), on(g_prof_on) {
   if (!on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (g_prof_recs.size() >= NK_PROF_MAX) {
@@ -105,7 +105,7 @@ NkProfScope::~NkProfScope() {
   if (!on) return;
   (void)hipEventRecord(e1, st);
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof_recs.push_back(ProfRec{e0, e1, key});
+  g_prof_recs.push_back(ProfRec{e0, e1, key, weight});
 }
 
 extern "C" int nk_profile_enable(int on) {
@@ -123,7 +123,7 @@ extern "C" int nk_profile_collect(double* ms, int64_t* count) {
     if (e == hipSuccess) e = hipEventElapsedTime(&t, r.e0, r.e1);
     if (e == hipSuccess && r.key >= 0 && r.key < NK_PROF_KEYS) {
       ms[r.key] += t;
-      count[r.key] += 1;
+      count[r.key] += r.weight;
     }
     g_prof_pool.push_back(r.e0);
     g_prof_pool.push_back(r.e1);

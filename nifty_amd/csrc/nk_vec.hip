@@ -118,7 +118,7 @@ static_assert(NK_RED_MAX_BLOCKS >= NK_MAX_BLOCKS, "reduction scratch must cover 
 // ---- generic "map with up to 4 inputs, 3 outputs and 3 reductions" skeleton ---------------------------
 // F::apply(const T* in[..] values, T* outs, double* red) is called per element.
 template <typename T, typename F, bool VEC>
-__global__ void __launch_bounds__(NK_VEC_THREADS) k_map(int64_t n, F f, int cu_max, NkRedScratch rs, NkRedLayout lay) {
+__device__ __forceinline__ void nk_map_body(int64_t n, const F& f, int cu_max, NkRedScratch rs, NkRedLayout lay) {
   static_assert(F::NRED <= NK_RED_MAX, "too many reductions for the scratch of nk_red_scratch");
   constexpr int V = VEC ? VecOf<T>::N : 1;
   double red[F::NRED > 0 ? F::NRED : 1];
@@ -168,21 +168,18 @@ __global__ void __launch_bounds__(NK_VEC_THREADS) k_map(int64_t n, F f, int cu_m
 #pragma unroll
     for (int r = 0; r < F::NRED; ++r) {
       const double s = nk_block_sum(red[r]);
-      if (threadIdx.x == 0) rs.partial[r * NK_RED_MAX_BLOCKS + blockIdx.x] = s;
+      // (no __threadfence(): the partial goes to the device's coherence point by an atomic exchange, nk_util.h)
+      if (threadIdx.x == 0) nk_publish_partial(&rs.partial[r * NK_RED_MAX_BLOCKS + blockIdx.x], s);
     }
-    if (threadIdx.x == 0) {
-      __threadfence();
-      is_last = atomicAdd(rs.ticket, 1u) == gridDim.x - 1;
-    }
+    if (threadIdx.x == 0) is_last = nk_take_last_ticket(rs.ticket, gridDim.x);
     __syncthreads();
     if (is_last) {
-      __threadfence();
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       for (int u = wave; u < lay.k_local; u += NK_VEC_THREADS / 64) {
 #pragma unroll
         for (int r = 0; r < F::NRED; ++r) {
           double v = 0.0;
-          for (int b = lane; b < G; b += 64) v += __builtin_nontemporal_load(&rs.partial[r * NK_RED_MAX_BLOCKS + u * G + b]);
+          for (int b = lane; b < G; b += 64) v += nk_read_partial(&rs.partial[r * NK_RED_MAX_BLOCKS + u * G + b]);
           for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
           if (lane == 0) usum[r][u] = v;
         }
@@ -208,6 +205,23 @@ __global__ void __launch_bounds__(NK_VEC_THREADS) k_map(int64_t n, F f, int cu_m
     }
   }
 }
+template <typename T, typename F, bool VEC>
+__global__ void __launch_bounds__(NK_VEC_THREADS) k_map(int64_t n, F f, int cu_max, NkRedScratch rs, NkRedLayout lay) {
+  nk_map_body<T, F, VEC>(n, f, cu_max, rs, lay);
+}
+// BATCHED launch (include/niftyk.h, "batched launches"): blockIdx.y = member; every member has its own functor (pointers,
+// scalars), its own block partials and ticket, and the grid / chunking of the single launch -- the same bits per member
+template <typename F>
+struct NkBatchOf {
+  F f[NK_MAX_BATCH];
+};
+template <typename T, typename F, bool VEC>
+__global__ void __launch_bounds__(NK_VEC_THREADS) k_map_b(int64_t n, NkBatchOf<F> fb, int cu_max, NkRedScratch rs, NkRedLayout lay) {
+  const int m = blockIdx.y;
+  rs.partial += (size_t)m * NK_RED_MEMBER_STRIDE;
+  rs.ticket += m;
+  nk_map_body<T, F, VEC>(n, fb.f[m], cu_max, rs, lay);
+}
 
 // Element-wise maps WITHOUT reductions, 16-byte vectors: one vector per thread, one 4 KiB piece per workgroup, as many
 // workgroups as pieces (no persistent loop).  The dispatcher hands the workgroups out in order, so at any moment the chip works
@@ -224,6 +238,16 @@ __global__ void __launch_bounds__(NK_VEC_THREADS) k_map_flat(int64_t n, F f) {
   const int64_t i = (int64_t)blockIdx.x * NK_VEC_THREADS + threadIdx.x;
   if (i < nvec) f.template run<V>(i * V, nullptr);
   if (i < n - nvec * V) f.template run<1>(nvec * V + i, nullptr);  // scalar tail (< V elements)
+}
+template <typename T, typename F>
+__global__ void __launch_bounds__(NK_VEC_THREADS) k_map_flat_b(int64_t n, NkBatchOf<F> fb) {
+  static_assert(F::NRED == 0, "k_map_flat: maps without reductions only");
+  constexpr int V = VecOf<T>::N;
+  const F& f = fb.f[blockIdx.y];
+  const int64_t nvec = n / V;
+  const int64_t i = (int64_t)blockIdx.x * NK_VEC_THREADS + threadIdx.x;
+  if (i < nvec) f.template run<V>(i * V, nullptr);
+  if (i < n - nvec * V) f.template run<1>(nvec * V + i, nullptr);
 }
 
 template <typename T, int V>
@@ -278,6 +302,50 @@ static int nk_launch_map(int64_t n, const F& f, bool aligned, hipStream_t st, co
     const int grid = F::NRED > 0 ? nk_grid_red(n) : nk_grid(n);
     hipLaunchKernelGGL((k_map<T, F, false>), dim3(grid), dim3(NK_VEC_THREADS), 0, st, n, f, cu_max, rs, lay);
   }
+  return nk_check_launch(what);
+}
+
+// nk_launch_map for `count` members in one launch (grid.y = member).  The members of a batch run the kernel the single
+// call would pick for each of them -- which needs every operand of every member 16-byte aligned; a batch with an unaligned
+// member goes through the single launches instead (same bits, just not batched).  Reductions: no rank-sharded layouts
+// (nk_red_layout) inside a batch.
+template <typename T, typename F>
+static int nk_launch_map_b(int64_t n, const F* fs, int count, bool aligned, hipStream_t st, const char* what) {
+  if (n <= 0) return NK_OK;
+  if (count < 1 || count > NK_MAX_BATCH) return nk_set_error(NK_ERR_INVALID, "batched launch: 1 <= count <= NK_MAX_BATCH");
+  if (count == 1 || !aligned || t_red_layout.k_local > 0) {
+    for (int m = 0; m < count; ++m) {
+      const int rc = nk_launch_map<T>(n, fs[m], aligned, st, what);
+      if (rc != NK_OK) return rc;
+    }
+    return NK_OK;
+  }
+  static const int cu_env = nk_vec_env_int("NK_VEC_CU", 0);
+  const int cu_max = cu_env > 0 ? cu_env : NkChunkUnits<F>::value;
+  NkRedScratch rs{nullptr, nullptr};
+  NkRedLayout lay{1, 0, 1, 1, 1, 0, nullptr};
+  if (F::NRED > 0) {
+    const int rc = nk_red_scratch(st, &rs);
+    if (rc != NK_OK) return rc;
+    lay = nk_red_layout_for(n, VecOf<T>::N);
+  }
+  NkBatchOf<F> fb;
+  for (int m = 0; m < NK_MAX_BATCH; ++m) fb.f[m] = fs[m < count ? m : 0];
+  const int64_t nvec = n / VecOf<T>::N;
+  if constexpr (F::NRED == 0) {
+    static const int flat_env = nk_vec_env_int("NK_VEC_FLAT", 1);
+    const int64_t pieces = (nvec + NK_VEC_THREADS - 1) / NK_VEC_THREADS;
+    if (flat_env && pieces > NK_MAX_BLOCKS && pieces < ((int64_t)1 << 31)) {
+      hipLaunchKernelGGL((k_map_flat_b<T, F>), dim3((unsigned)pieces, (unsigned)count), dim3(NK_VEC_THREADS), 0, st, n, fb);
+      return nk_check_launch(what);
+    }
+  }
+  int grid = F::NRED > 0 ? nk_grid_red(nvec) : nk_grid(nvec > 0 ? nvec : 1);
+  if (lay.unit_elems > 0) {
+    static const int unit_grid = std::min(std::max(nk_vec_env_int("NK_RED_UNIT_GRID", 64), 1), NK_RED_MAX_BLOCKS / NK_RED_UNITS);
+    grid = lay.k_local * std::min(nk_grid_red(lay.unit_elems / VecOf<T>::N), unit_grid);
+  }
+  hipLaunchKernelGGL((k_map_b<T, F, true>), dim3((unsigned)grid, (unsigned)count), dim3(NK_VEC_THREADS), 0, st, n, fb, cu_max, rs, lay);
   return nk_check_launch(what);
 }
 
@@ -898,6 +966,236 @@ extern "C" int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, dou
   return nk_check_launch("k_cg_roll");
 }
 
+// ---- batched launches (include/niftyk.h): the single entry points above for `count` members --------------------------
+struct NkPtrs {
+  void* p[NK_MAX_BATCH];
+};
+static inline bool nk_batch_count_ok(int count) { return count >= 1 && count <= NK_MAX_BATCH; }
+template <typename P>
+static inline bool nk_all_set(P const* ptrs, int count) {
+  if (!ptrs) return false;
+  for (int m = 0; m < count; ++m)
+    if (!ptrs[m]) return false;
+  return true;
+}
+template <typename P>
+static inline bool nk_all_aligned16(P const* ptrs, int count) {
+  if (!ptrs) return true;
+  for (int m = 0; m < count; ++m)
+    if (!nk_aligned16(ptrs[m])) return false;
+  return true;
+}
+// cnt doubles at off of every member's scalar block <- 0 (one launch instead of `count` memsets)
+__global__ void k_zero_ptrs(NkPtrs ptrs, int off, int cnt) {
+  double* p = (double*)ptrs.p[blockIdx.x];
+  if ((int)threadIdx.x < cnt) p[off + threadIdx.x] = 0.0;
+}
+static int nk_zero_b(double* const* ptrs, int count, int off, int cnt, hipStream_t st) {
+  NkPtrs pp;
+  for (int m = 0; m < NK_MAX_BATCH; ++m) pp.p[m] = ptrs[m < count ? m : 0];
+  hipLaunchKernelGGL(k_zero_ptrs, dim3(count), dim3(64), 0, st, pp, off, cnt);
+  return nk_check_launch("k_zero_ptrs");
+}
+
+extern "C" int nk_axpby_batch(int64_t n, int count, const double* alpha, const void* const* x, const double* beta,
+                              const void* const* y, void* const* out, int dtype, void* stream) {
+  if (n < 0 || !nk_batch_count_ok(count) || !alpha || !beta || !nk_all_set(x, count) || !nk_all_set(out, count) || !y)
+    return nk_set_error(NK_ERR_INVALID, "nk_axpby_batch: bad argument");
+  NK_DISPATCH_DTYPE(dtype, {
+    FAxpby<T> fs[NK_MAX_BATCH];
+    for (int m = 0; m < count; ++m) fs[m] = FAxpby<T>{alpha[m], beta[m], (const T*)x[m], (const T*)y[m], (T*)out[m], nullptr};
+    return nk_launch_map_b<T>(n, fs, count, nk_all_aligned16(x, count) && nk_all_aligned16(y, count) && nk_all_aligned16(out, count),
+                              (hipStream_t)stream, "nk_axpby_batch");
+  })
+}
+
+extern "C" int nk_axpby_sqnorm_batch(int64_t n, int count, const double* alpha, const void* const* x, const double* beta,
+                                     const void* const* y, void* const* out, int dtype, double* const* result, int accumulate,
+                                     void* stream) {
+  if (n < 0 || !nk_batch_count_ok(count) || !alpha || !beta || !nk_all_set(x, count) || !nk_all_set(y, count) ||
+      !nk_all_set(out, count) || !nk_all_set(result, count))
+    return nk_set_error(NK_ERR_INVALID, "nk_axpby_sqnorm_batch: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    const int rc = nk_zero_b(result, count, 0, 1, st);
+    if (rc != NK_OK) return rc;
+  }
+  NK_DISPATCH_DTYPE(dtype, {
+    FAxpbySq<T> fs[NK_MAX_BATCH];
+    for (int m = 0; m < count; ++m) fs[m] = FAxpbySq<T>{alpha[m], beta[m], (const T*)x[m], (const T*)y[m], (T*)out[m], result[m]};
+    return nk_launch_map_b<T>(n, fs, count, nk_all_aligned16(x, count) && nk_all_aligned16(y, count) && nk_all_aligned16(out, count), st,
+                              "nk_axpby_sqnorm_batch");
+  })
+}
+
+extern "C" int nk_binary_batch(int op, int64_t n, int count, const void* const* a, const double* ascalar, const void* const* b,
+                               const double* bscalar, void* const* out, int dtype, void* stream) {
+  if (n < 0 || !nk_batch_count_ok(count) || op < 0 || op > 3 || !a || !b || !ascalar || !bscalar || !nk_all_set(out, count))
+    return nk_set_error(NK_ERR_INVALID, "nk_binary_batch: bad argument");
+  for (int m = 0; m < count; ++m)
+    if (!a[m] && !b[m]) return nk_set_error(NK_ERR_INVALID, "nk_binary_batch: a member without an array operand");
+  NK_DISPATCH_DTYPE(dtype, {
+    FBinary<T> fs[NK_MAX_BATCH];
+    for (int m = 0; m < count; ++m) fs[m] = FBinary<T>{op, (const T*)a[m], (const T*)b[m], ascalar[m], bscalar[m], (T*)out[m], nullptr};
+    return nk_launch_map_b<T>(n, fs, count, nk_all_aligned16(a, count) && nk_all_aligned16(b, count) && nk_all_aligned16(out, count),
+                              (hipStream_t)stream, "nk_binary_batch");
+  })
+}
+
+extern "C" int nk_vdot_batch(int64_t n, int count, const void* const* a, const void* const* b, int dtype, double* const* result,
+                             int accumulate, void* stream) {
+  if (n < 0 || !nk_batch_count_ok(count) || !nk_all_set(a, count) || !nk_all_set(b, count) || !nk_all_set(result, count))
+    return nk_set_error(NK_ERR_INVALID, "nk_vdot_batch: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    const int rc = nk_zero_b(result, count, 0, 1, st);
+    if (rc != NK_OK) return rc;
+  }
+  NK_DISPATCH_DTYPE(dtype, {
+    FDot<T> fs[NK_MAX_BATCH];
+    for (int m = 0; m < count; ++m) fs[m] = FDot<T>{(const T*)a[m], (const T*)b[m], result[m]};
+    return nk_launch_map_b<T>(n, fs, count, nk_all_aligned16(a, count) && nk_all_aligned16(b, count), st, "nk_vdot_batch");
+  })
+}
+
+extern "C" int nk_gather_batch(int64_t n, int count, const void* const* table, const int32_t* pidx, void* const* out, int dtype,
+                               void* stream) {
+  if (n < 0 || !nk_batch_count_ok(count) || !pidx || !nk_all_set(table, count) || !nk_all_set(out, count))
+    return nk_set_error(NK_ERR_INVALID, "nk_gather_batch: bad argument");
+  NK_DISPATCH_DTYPE(dtype, {
+    FGather<T> fs[NK_MAX_BATCH];
+    for (int m = 0; m < count; ++m) fs[m] = FGather<T>{(const T*)table[m], pidx, (T*)out[m], nullptr};
+    return nk_launch_map_b<T>(n, fs, count, nk_all_aligned16(out, count) && nk_aligned16(pidx), (hipStream_t)stream, "nk_gather_batch");
+  })
+}
+
+extern "C" int nk_cg_curv_batch(int64_t n, int count, const void* const* d, const void* const* q, int dtype, double* const* scal,
+                                int accumulate, void* stream) {
+  if (n < 0 || !nk_batch_count_ok(count) || !nk_all_set(d, count) || !nk_all_set(q, count) || !nk_all_set(scal, count))
+    return nk_set_error(NK_ERR_INVALID, "nk_cg_curv_batch: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    const int rc = nk_zero_b(scal, count, 1, 1, st);
+    if (rc != NK_OK) return rc;
+  }
+  NK_DISPATCH_DTYPE(dtype, {
+    FCgCurv<T> fs[NK_MAX_BATCH];
+    for (int m = 0; m < count; ++m) fs[m] = FCgCurv<T>{(const T*)d[m], (const T*)q[m], scal[m] + 1};
+    return nk_launch_map_b<T>(n, fs, count, nk_all_aligned16(d, count) && nk_all_aligned16(q, count), st, "nk_cg_curv_batch");
+  })
+}
+
+extern "C" int nk_cg_update_batch(int64_t n, int count, void* const* x, void* const* r, const void* const* d, const void* const* q,
+                                  const void* const* b, int dtype, double* const* scal, int accumulate, void* stream) {
+  if (n < 0 || !nk_batch_count_ok(count) || !nk_all_set(x, count) || !nk_all_set(r, count) || !nk_all_set(d, count) ||
+      !nk_all_set(q, count) || !b || !nk_all_set(scal, count))
+    return nk_set_error(NK_ERR_INVALID, "nk_cg_update_batch: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    const int rc = nk_zero_b(scal, count, 2, 3, st);
+    if (rc != NK_OK) return rc;
+  }
+  NK_DISPATCH_DTYPE(dtype, {
+    FCgUpdate<T> fs[NK_MAX_BATCH];
+    for (int m = 0; m < count; ++m)
+      fs[m] = FCgUpdate<T>{(T*)x[m], (T*)r[m], (const T*)d[m], (const T*)q[m], (const T*)b[m], scal[m], scal[m] + 2};
+    return nk_launch_map_b<T>(n, fs, count,
+                              nk_all_aligned16(x, count) && nk_all_aligned16(r, count) && nk_all_aligned16(d, count) &&
+                                  nk_all_aligned16(q, count) && nk_all_aligned16(b, count),
+                              st, "nk_cg_update_batch");
+  })
+}
+
+extern "C" int nk_cg_update_dr_batch(int64_t n, int count, void* const* x, void* const* r, const void* const* d,
+                                     const void* const* q, int dtype, double* const* scal, int accumulate, void* stream) {
+  if (n < 0 || !nk_batch_count_ok(count) || !nk_all_set(x, count) || !nk_all_set(r, count) || !nk_all_set(d, count) ||
+      !nk_all_set(q, count) || !nk_all_set(scal, count))
+    return nk_set_error(NK_ERR_INVALID, "nk_cg_update_dr_batch: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    const int rc = nk_zero_b(scal, count, 2, 2, st);
+    if (rc != NK_OK) return rc;
+  }
+  NK_DISPATCH_DTYPE(dtype, {
+    FCgUpdateDr<T> fs[NK_MAX_BATCH];
+    for (int m = 0; m < count; ++m) fs[m] = FCgUpdateDr<T>{(T*)x[m], (T*)r[m], (const T*)d[m], (const T*)q[m], scal[m], scal[m] + 2};
+    return nk_launch_map_b<T>(n, fs, count,
+                              nk_all_aligned16(x, count) && nk_all_aligned16(r, count) && nk_all_aligned16(d, count) &&
+                                  nk_all_aligned16(q, count),
+                              st, "nk_cg_update_dr_batch");
+  })
+}
+
+__global__ void k_cg_roll_b(NkPtrs scals) {
+  double* scal = (double*)scals.p[blockIdx.x];
+  scal[5] = scal[0] / scal[1];
+  const double beta = scal[2] / scal[0];
+  scal[6] = beta > 0.0 ? beta : 0.0;
+  scal[0] = scal[2];
+}
+
+extern "C" int nk_cg_direction_batch(int64_t n, int count, void* const* d, const void* const* r, int dtype, double* const* scal,
+                                     int roll, void* stream) {
+  if (n < 0 || !nk_batch_count_ok(count) || (n > 0 && (!nk_all_set(d, count) || !nk_all_set(r, count))) || !nk_all_set(scal, count))
+    return nk_set_error(NK_ERR_INVALID, "nk_cg_direction_batch: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = NK_OK;
+  if (n > 0) {
+    NK_DISPATCH_DTYPE(dtype, {
+      FCgDir<T> fs[NK_MAX_BATCH];
+      for (int m = 0; m < count; ++m) fs[m] = FCgDir<T>{(T*)d[m], (const T*)r[m], scal[m], nullptr};
+      rc = nk_launch_map_b<T>(n, fs, count, nk_all_aligned16(d, count) && nk_all_aligned16(r, count), st, "nk_cg_direction_batch");
+    })
+  }
+  if (rc != NK_OK || !roll) return rc;
+  NkPtrs pp;
+  for (int m = 0; m < NK_MAX_BATCH; ++m) pp.p[m] = scal[m < count ? m : 0];
+  hipLaunchKernelGGL(k_cg_roll_b, dim3(count), dim3(1), 0, st, pp);
+  return nk_check_launch("k_cg_roll_b");
+}
+
+// the sum of `count` vectors in the order of parallel.pair_tree (reference utilities.py:349-414): neighbours at distance 1
+// first, then 2, then 4; every partial sum rounded to T exactly like the stored result of nk_axpby(1, a, 1, b)
+template <typename T>
+struct FSumTree {
+  static constexpr int NRED = 0;
+  const T* term[NK_MAX_BATCH];
+  int count;
+  T* out;
+  double* result;
+  template <int V>
+  __device__ __forceinline__ void run(int64_t i, double*) const {
+    T v[NK_MAX_BATCH][V];
+#pragma unroll
+    for (int m = 0; m < NK_MAX_BATCH; ++m)
+      if (m < count) nk_ld<T, V>(term[m], i, v[m]);
+#pragma unroll
+    for (int gap = 1; gap < NK_MAX_BATCH; gap *= 2) {
+#pragma unroll
+      for (int left = 0; left + gap < NK_MAX_BATCH; left += 2 * gap) {
+        if (left + gap < count) {
+#pragma unroll
+          for (int k = 0; k < V; ++k) v[left][k] = (T)((double)v[left][k] + (double)v[left + gap][k]);
+        }
+      }
+    }
+    nk_st<T, V>(out, i, v[0]);
+  }
+};
+
+extern "C" int nk_sum_tree(int64_t n, int count, const void* const* term, void* out, int dtype, void* stream) {
+  if (n < 0 || !nk_batch_count_ok(count) || !nk_all_set(term, count) || !out)
+    return nk_set_error(NK_ERR_INVALID, "nk_sum_tree: bad argument");
+  NK_DISPATCH_DTYPE(dtype, {
+    FSumTree<T> f;
+    for (int m = 0; m < NK_MAX_BATCH; ++m) f.term[m] = (const T*)term[m < count ? m : 0];
+    f.count = count;
+    f.out = (T*)out;
+    f.result = nullptr;
+    return nk_launch_map<T>(n, f, nk_all_aligned16(term, count) && nk_aligned16(out), (hipStream_t)stream, "nk_sum_tree");
+  })
+}
+
 // ---- power-bin index straight from integer k^2 (PowerSpace pindex for equal harmonic distances,
 //      nifty/cl/domains/power_space.py:172-180 + rg_space.py:116-128 without the 8 N-byte int64 array) ----
 struct NkShape3 {
@@ -1445,6 +1743,57 @@ extern "C" int nk_csr_rowsum(int64_t nrows, const int64_t* rowptr, const int32_t
       case 4: return nk_launch_rowsum<T, 4>(nrows, rowptr, col, wgt, x, y, st);
       case 16: return nk_launch_rowsum<T, 16>(nrows, rowptr, col, wgt, x, y, st);
       default: return nk_launch_rowsum<T, 64>(nrows, rowptr, col, wgt, x, y, st);
+    }
+  })
+}
+
+template <typename T, int LANES>
+__global__ void __launch_bounds__(256) k_csr_rowsum_b(int64_t nrows, const int64_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ col, const float* __restrict__ wgt, NkPtrs xs,
+                                                      NkPtrs ys) {
+  const T* __restrict__ x = (const T*)xs.p[blockIdx.y];
+  T* __restrict__ y = (T*)ys.p[blockIdx.y];
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = gid / LANES;
+  const int lane = (int)(gid % LANES);
+  int64_t lo = 0, hi = 0;
+  if (row < nrows) lo = rowptr[row], hi = rowptr[row + 1];
+  double acc = 0.0;
+  if (wgt) {
+    for (int64_t j = lo + lane; j < hi; j += LANES) acc += (double)wgt[j] * (double)x[col[j]];
+  } else {
+    for (int64_t j = lo + lane; j < hi; j += LANES) acc += (double)x[col[j]];
+  }
+#pragma unroll
+  for (int off = LANES / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, LANES);
+  if (lane == 0 && row < nrows) y[row] = (T)acc;
+}
+template <typename T, int LANES>
+static int nk_launch_rowsum_b(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, int count,
+                              const void* const* x, void* const* y, hipStream_t st) {
+  const int64_t blocks = (nrows * LANES + 255) / 256;
+  if (blocks > 0x7fffffffLL) return nk_set_error(NK_ERR_UNSUPPORTED, "nk_csr_rowsum_batch: too many rows for one launch");
+  NkPtrs xs, ys;
+  for (int m = 0; m < NK_MAX_BATCH; ++m) xs.p[m] = const_cast<void*>(x[m < count ? m : 0]), ys.p[m] = y[m < count ? m : 0];
+  hipLaunchKernelGGL((k_csr_rowsum_b<T, LANES>), dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, st, nrows, rowptr, col, wgt, xs, ys);
+  return nk_check_launch("k_csr_rowsum_b");
+}
+
+extern "C" int nk_csr_rowsum_batch(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, int count,
+                                   const void* const* x, void* const* y, int dtype, int lanes, void* stream) {
+  if (nrows < 0 || !rowptr || !nk_batch_count_ok(count) || (nrows > 0 && (!nk_all_set(x, count) || !nk_all_set(y, count) || !col)))
+    return nk_set_error(NK_ERR_INVALID, "nk_csr_rowsum_batch: bad argument");
+  if (lanes != 1 && lanes != 4 && lanes != 16 && lanes != 64)
+    return nk_set_error(NK_ERR_INVALID, "nk_csr_rowsum_batch: lanes must be 1, 4, 16 or 64");
+  if (nrows == 0) return NK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  NkProfScope ps(st, 8, lanes == 1 ? 0 : lanes == 4 ? 1 : lanes == 16 ? 2 : 3, wgt ? 0 : 1, count);
+  NK_DISPATCH_DTYPE(dtype, {
+    switch (lanes) {
+      case 1: return nk_launch_rowsum_b<T, 1>(nrows, rowptr, col, wgt, count, x, y, st);
+      case 4: return nk_launch_rowsum_b<T, 4>(nrows, rowptr, col, wgt, count, x, y, st);
+      case 16: return nk_launch_rowsum_b<T, 16>(nrows, rowptr, col, wgt, count, x, y, st);
+      default: return nk_launch_rowsum_b<T, 64>(nrows, rowptr, col, wgt, count, x, y, st);
     }
   })
 }

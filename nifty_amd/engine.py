@@ -27,7 +27,7 @@ import torch
 
 from . import _lib as L
 from . import backend as B
-from . import parallel, random
+from . import batched, parallel, random
 from .domains import PowerSpace, RGSpace
 from .minimization import ConjugateGradient, Energy, QuadraticEnergy
 
@@ -124,9 +124,20 @@ class CgWorkspace:
             L.check(lib.nk_cg_direction(dd.numel(), dd.data_ptr(), rr.data_ptr(), B.dtype_code(dd), self.scal.data_ptr(),
                                         1 if i == len(segs) - 1 else 0, st))
 
-    def fetch(self):
+    def fetch_begin(self):
+        """Enqueue the copy of the scalars to the host and mark the spot in the stream: kernels enqueued after this call
+        (the next iteration's direction update) run while the host waits for and looks at the scalars in fetch_end()."""
         self._host.copy_(self.scal, non_blocking=True)
-        torch.cuda.current_stream(self.scal.device).synchronize()
+        if getattr(self, "_landed", None) is None:
+            self._landed = torch.cuda.Event()
+        self._landed.record(torch.cuda.current_stream(self.scal.device))
+
+    def fetch(self):
+        self.fetch_begin()
+        return self.fetch_end()
+
+    def fetch_end(self):
+        self._landed.synchronize()
         s = self._host.numpy()
         # inside a lockstep scope: these five scalars steer the CG -- ONE agreement check per iteration (parallel.lockstep_flush)
         parallel.lockstep_note(s[:5])
@@ -1095,11 +1106,16 @@ class FusedModel:
         for k in LATENT_KEYS:  # alphabetical = the reference's draw order
             if k == "xi":  # the numpy stream, computed on the device from the host generator's state
                 xi = random.Random.normal_on_device(self.npdtype, self.shape, 0.0, 1.0, self.device)
-                continue
-            shp = (2, nb - 2) if k == "spectrum" else ()
-            parts[k] = random.current_rng().normal(0.0, 1.0, shp)
-        small = np.concatenate([[parts[k] for k in SMALL_KEYS], parts["spectrum"].ravel()])
-        return LatentVec(xi, self._upload(small, torch.float64))
+            elif k == "spectrum":
+                # (2, nb - 2) values: 6 x 10^5 on a 2048^2 grid -- 5 ms of numpy per draw with the GPU idle, four draws per
+                # iteration; the same stream from the device like xi (small tables stay on the host: Random.normal_on_device)
+                spectrum = random.Random.normal_on_device(np.float64, (2, nb - 2), 0.0, 1.0, self.device)
+            else:
+                parts[k] = random.current_rng().normal(0.0, 1.0, ())
+        small = torch.empty(self.nsmall, dtype=torch.float64, device=self.device)
+        small[:5].copy_(torch.from_numpy(np.array([parts[k] for k in SMALL_KEYS], dtype=np.float64)), non_blocking=False)
+        small[5:].copy_(spectrum.reshape(-1))
+        return LatentVec(xi, small)
 
     def draw_lh_noise(self, lp, device_rng=None):
         """J^T M_d^{1/2} eta with eta ~ N(0,1) in data space."""
@@ -1181,6 +1197,9 @@ class FusedKL(Energy):
         self.comm, self.nanisinf = comm, nanisinf
         self.lins = []
         self._lanes = self._pick_lanes(len(residuals))
+        # small grids: ONE launch set for all local samples instead of one kernel chain per sample on stream lanes
+        # (nifty_amd/batched.py; single process, >= 2 samples; NK_BATCH=0: the lanes)
+        self._batched = comm is None and len(residuals) >= 2 and batched.ready(model)
         # sums over samples in the pairwise order of the reference (parallel.pair_tree): the same bits for 1, 2, 4, 8 ranks.
         # Across ranks: one complete subtree per rank (equal power-of-two sample counts) -> the slice-wise tree over the rank
         # partials (`_across`); any other split -> every sample keeps its own vector and the terms are added like the
@@ -1206,6 +1225,8 @@ class FusedKL(Energy):
         grad = None
         if self._terms is not None:
             value, grad = self._linearize_terms(position)
+        elif self._batched:
+            value, grad = batched.kl_linearize(self, position)
         elif len(self._lanes) > 1:
             value, grad = self._linearize_on_lanes(position, value)
         elif self._tree and len(residuals) > 0:
@@ -1385,6 +1406,8 @@ class FusedKL(Energy):
         """This rank's share of the KL metric applied to d (no communication).  pipe = (chunks, wait, record): the FIRST
         local sample's transform waits chunk by chunk for d, the LAST one records chunk by chunk that `out` is final."""
         m = self.model
+        if self._batched and pipe is None and dot_out is None and cg_direction is None:
+            return batched.kl_apply_metric(self, d)
         if len(self._lanes) > 1 and pipe is None and dot_out is None and cg_direction is None:
             return self._apply_metric_on_lanes(d)
         if self._tree and len(self.lins) > 0:
@@ -1465,7 +1488,8 @@ class FusedKL(Energy):
 
     @property
     def metric(self):
-        single = self.comm is None and len(self.lins) > 0 and len(self._lanes) == 1  # (lanes: no fused dot / direction)
+        # (lanes / batched launches: no fused dot / direction)
+        single = self.comm is None and len(self.lins) > 0 and len(self._lanes) == 1 and not self._batched
         # (pairwise sums keep the prior term on the FIRST sample; the dot needs it on the last one)
         A = _Callable(self.apply_metric, fused_dot=single and self.model.octant_vjp and (not self._tree or len(self.lins) == 1),
                       fused_direction=single and self.model.fused_direction)
@@ -1721,12 +1745,17 @@ def draw_samples(model, position, n_samples, mirror_samples, controller_factory,
     finish = linear_residual if geo_minimizer is None else fitted_residual
     local_pairs = len({i // 2 if plan.mirror else i for i in range(plan.lo, plan.hi)})
     lanes = _sampling_lanes(model, local_pairs)
-    if lanes is None:
+    # the linear solves of the iteration advance together: as batched launches (nifty_amd/batched.py) or on stream lanes
+    in_batch = local_pairs >= 2 and batched.ready(model)
+    if lanes is None and not in_batch:
         drawn = plan.run(draw, finish)
     else:
-        together = geo_minimizer is not None and os.environ.get("NK_GEO_THREADS", "1") != "0"
-        drawn = plan.run_together(lambda seed: _draw_sources(model, linearisation(), seed, device_rng),
-                                  lambda jobs: _solve_on_lanes(model, lanes, linearisation(), jobs, controller_factory),
+        together = geo_minimizer is not None and lanes is not None and os.environ.get("NK_GEO_THREADS", "1") != "0"
+        if in_batch:
+            solve = lambda jobs: batched.solve_together(model, linearisation(), jobs, controller_factory)  # noqa: E731
+        else:
+            solve = lambda jobs: _solve_on_lanes(model, lanes, linearisation(), jobs, controller_factory)  # noqa: E731
+        drawn = plan.run_together(lambda seed: _draw_sources(model, linearisation(), seed, device_rng), solve,
                                   (lambda pair, mirrored: (pair, mirrored)) if together else finish)
         if together:  # geoVI: the non-linear fits of all local samples, one host thread and one lane per fit in flight
             if "tp" not in cache:

@@ -366,6 +366,66 @@ class _ScalarEnergyView:
         self.value, self.gradient_norm = value, gradnorm
 
 
+class _HostCg:
+    """State of a conjugate-gradient solve on IMMUTABLE vectors (every update makes new ones): residual r = A x - b,
+    preconditioned residual s = P r (P = identity without a preconditioner), search direction d, and gamma = <r, s>.
+    One `iterate` = one metric application; it returns None to go on, or the status that ends the solve."""
+
+    def __init__(self, energy, preconditioner, refresh_every):
+        self.energy, self._precondition = energy, (lambda v: v) if preconditioner is None else preconditioner
+        self._refresh_every, self._since_refresh = refresh_every, 0
+        self.r = energy.gradient
+        self.d = self._precondition(self.r)
+        self.gamma = None
+
+    @staticmethod
+    def _dot(u, v):
+        return _ls(np.real(u.s_vdot(v)))
+
+    def _bad(self, what):
+        logger.error(f"ConjugateGradient stops: {what}")
+        return ERROR
+
+    def begin(self):
+        self.gamma = self._dot(self.r, self.d)
+        if np.isnan(self.gamma):
+            return self._bad("the first <r, P r> is not a number")
+        return CONVERGED if self.gamma == 0 else None
+
+    def iterate(self, controller):
+        q = self.energy.apply_metric(self.d)
+        counters["cg_iterations"] += 1
+        curvature = self._dot(self.d, q)
+        if np.isnan(curvature) or curvature == 0.0:
+            return self._bad("the curvature <d, A d> is zero or not a number")
+        step = self.gamma / curvature
+        if step < 0:
+            return self._bad("negative step length: the operator is not positive definite along the search direction")
+        where = self.energy.position - step * self.d
+        self._since_refresh += 1
+        if self._since_refresh < self._refresh_every:
+            self.r = self.r - q * step  # the recurrence; every `refresh_every` iterations the residual is recomputed instead
+            self.energy = self.energy.at_with_grad(where, self.r)
+        else:
+            self.energy = self.energy.at(where)
+            self.r, self._since_refresh = self.energy.gradient, 0
+        s = self._precondition(self.r)
+        gamma = self._dot(self.r, s)
+        if np.isnan(gamma):
+            return self._bad("<r, P r> is not a number")
+        if gamma < 0:
+            return self._bad("<r, P r> < 0: the preconditioner is not positive definite")
+        if gamma == 0:
+            return CONVERGED
+        _lockstep_flush()
+        status = controller.check(self.energy)
+        if status != CONTINUE:
+            return status
+        self.d = self.d * max(0, gamma / self.gamma) + s
+        self.gamma = gamma
+        return None
+
+
 class ConjugateGradient(Minimizer):
     """Linear CG on a QuadraticEnergy (reference conjugate_gradient.py:48-126).
 
@@ -384,55 +444,17 @@ class ConjugateGradient(Minimizer):
         return self._solve_generic(energy, preconditioner)
 
     def _solve_generic(self, energy, preconditioner):
-        controller = self._controller
-        status = controller.start(energy)
+        """Vectors without in-place kernels (host Fields, MultiFields of the generic graph) or a preconditioned solve: the
+        same iteration on a `_HostCg` state object -- curvature, step, residual, new direction -- whose checks end the
+        solve with a status instead of an exception (conjugate_gradient.py:76-96)."""
+        status = self._controller.start(energy)
         if status != CONTINUE:
             return energy, status
-        r = energy.gradient
-        d = r if preconditioner is None else preconditioner(r)
-        gamma_prev = _ls(np.real(r.s_vdot(d)))
-        if np.isnan(gamma_prev):
-            logger.error("Error: ConjugateGradient: previous_gamma==NaN")
-            return energy, ERROR
-        if gamma_prev == 0:
-            return energy, CONVERGED
-        since_reset = 0
-        while True:
-            q = energy.apply_metric(d)
-            counters["cg_iterations"] += 1
-            curv = _ls(np.real(d.s_vdot(q)))
-            if np.isnan(curv) or curv == 0.0:
-                logger.error("Error: ConjugateGradient: curv==NaN or 0")
-                return energy, ERROR
-            alpha = gamma_prev / curv
-            if alpha < 0:
-                logger.error("Error: ConjugateGradient: alpha<0.")
-                return energy, ERROR
-            since_reset += 1
-            new_pos = energy.position - alpha * d
-            if since_reset < self._nreset:
-                r = r - q * alpha
-                energy = energy.at_with_grad(new_pos, r)
-            else:
-                energy = energy.at(new_pos)
-                r = energy.gradient
-                since_reset = 0
-            s = r if preconditioner is None else preconditioner(r)
-            gamma = _ls(np.real(r.s_vdot(s)))
-            if np.isnan(gamma):
-                logger.error("Error: ConjugateGradient: gamma==NaN")
-                return energy, ERROR
-            if gamma < 0:
-                logger.error("Positive definiteness of preconditioner violated!")
-                return energy, ERROR
-            if gamma == 0:
-                return energy, CONVERGED
-            _lockstep_flush()
-            status = controller.check(energy)
-            if status != CONTINUE:
-                return energy, status
-            d = d * max(0, gamma / gamma_prev) + s
-            gamma_prev = gamma
+        cg = _HostCg(energy, preconditioner, self._nreset)
+        status = cg.begin()
+        while status is None:
+            status = cg.iterate(self._controller)
+        return cg.energy, status
 
     def _solve_inplace(self, energy):
         A, b = energy._A, energy._b
@@ -533,10 +555,17 @@ class ConjugateGradient(Minimizer):
         # capturing the steady-state iteration at iteration 2 and replaying it gave 131 ms against 115 ms per MGVI
         # iteration -- every solve of this recipe has new vectors and at most 20 iterations, and a capture + instantiation
         # costs more than 18 replays save.  A graph would have to outlive the solve: persistent CG and linearisation buffers.)
+        # Without the fused direction update the NEXT iteration's d <- beta d + r is enqueued before the host waits for
+        # this iteration's scalars (it reads beta from the device scalars and steers nothing): the device works through it
+        # while the host decides whether to go on -- on small grids that wait was 65 us of idle GPU per iteration.  A solve
+        # that stops has updated a direction nobody reads any more.
+        ahead = hasattr(ws, "fetch_begin") and not fused_dir
+        direction_done = False
         iteration = 0
         while True:
             iteration += 1
-            device_iteration(iteration > 1)
+            device_iteration(iteration > 1 and not direction_done)
+            direction_done = False
             counters["cg_iterations"] += 1
             since_reset += 1
             refreshed = False
@@ -547,8 +576,12 @@ class ConjugateGradient(Minimizer):
                 ws.refresh(x, r, b)
                 since_reset = 0
                 refreshed = True
+            if ahead:
+                ws.fetch_begin()
+                ws.direction(d, r)
+                direction_done = True
             yield  # (solve_many: the other solves enqueue their iterations here)
-            sc = ws.fetch()  # the single host synchronisation of this iteration
+            sc = ws.fetch_end() if ahead else ws.fetch()  # the single host synchronisation of this iteration
             curv, gamma, alpha = sc["curv"], sc["gamma"], sc["alpha"]
             if np.isnan(curv) or curv == 0.0 or np.isnan(alpha) or alpha < 0:
                 logger.error("Error: ConjugateGradient: bad curvature / step")

@@ -22,7 +22,9 @@ def _controllers():
 
 
 def _run_both(n, pairs):
-    from nifty_amd import optimize_kl as okl
+    import importlib
+
+    okl = importlib.import_module("nifty_amd.optimize_kl")  # (the package attribute of that name is the function)
     from nifty_amd import random
     from nifty_amd.engine import mgvi_iteration
 
