@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 from nifty_amd import _lib as L  # noqa: E402
 from nifty_amd import backend as B  # noqa: E402
 from nifty_amd import minimization, parallel, random  # noqa: E402
-from nifty_amd.engine import FusedModel, LatentVec, mgvi_iteration  # noqa: E402
+from nifty_amd.engine import FusedKL, FusedModel, LatentVec, draw_samples, mgvi_iteration  # noqa: E402
 from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG  # noqa: E402
 
 # streams of the fused CG vector update: x, r (read + write), d, q -- plus b when the energy is re-evaluated from x.b
@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 KERNEL_NAMES = {0: "k_pass1d", 1: "k_passA", 2: "k_passB", 3: "k_passC", 4: "k_passD", 5: "k_passS1", 6: "k_passS2",
                 7: "k_passSM", 8: "k_csr_rowsum", 9: "k_passC2"}  # C2: the final passes of two samples in one launch
 NK_PROF_KEYS = 250
-PRO_NAMES = {0: "plain", 1: "amp", 2: "amp_jvp", 3: "mul"}
+PRO_NAMES = {0: "plain", 1: "amp", 2: "amp_jvp", 3: "mul", 4: "amp_jvp+cg_direction"}
 EPI_NAMES = {0: "affine", 1: "mul", 2: "vjp", 3: "likelihood", 4: "nonlin"}
 
 
@@ -61,7 +61,7 @@ def kernel_symbol(kern, pro, epi, shape, dt_name, octant=True, wide=False, const
     (nifty_amd/csrc/nk_fft.hip; what rocprofv3 --kernel-trace lists), for 2-D / 3-D power-of-two grids."""
     T = "float" if dt_name == "f32" else "double"
     A, M, NL = (shape[0], shape[1], shape[2]) if len(shape) == 3 else (1, shape[0], shape[-1])
-    pc_first = {0: "0", 1: "4" if octant else "1", 2: "5" if octant else "3", 3: "6"}[pro]   # prologue class of a first pass
+    pc_first = {0: "0", 1: "4" if octant else "1", 2: "5" if octant else "3", 3: "6", 4: "8"}[pro]  # prologue class of a first pass
     ec = {0: "0", 1: "1", 2: "2", 3: "3", 4: "-1"}[epi]                                    # epilogue class of a final pass
     couples = "true" if epi == 2 else "false"
     if kern == 1:
@@ -76,7 +76,7 @@ def kernel_symbol(kern, pro, epi, shape, dt_name, octant=True, wide=False, const
         pair = "1" if (pro == 2 and epi == 2 and len(shape) == 3) else "0"   # a sandwich's final pass: row-mirror pairing
         return f"k2_final<{T},{NL},{couples},{ec},{pair}>"
     if kern == 5:
-        return f"k3_contig_quad<{T},{NL // 2},{'5|8' if pro == 2 else pc_first}>"  # 8 = 5 with the CG direction update
+        return f"k3_contig_quad<{T},{NL // 2},{pc_first}>"  # (8 = 5 with the CG direction update: profile key pro 4)
     if kern == 6:
         return f"k2_strided<{T},{M},0,-1>"
     if kern == 7:
@@ -92,25 +92,33 @@ def rowsum_bytes(nnz, nrows, b, weighted=True):
     return nnz * (4 + (4 if weighted else 0) + b) + nrows * (8 + b)
 
 
-def algorithmic_bytes(kernel, pro, epi, N, b, const_mid):
-    """Algorithmic HBM bytes of ONE launch of a transform pass kernel (DESIGN.md 'roofline').
+def algorithmic_bytes(kernel, pro, epi, N, b, const_mid, octant=True, ndim=3):
+    """Algorithmic HBM bytes of ONE launch of a transform pass kernel: the operand arrays the launch reads
+    and writes, each once, at their real size.
 
-    Every pass reads and writes the array once (2*N*b, SURVEY 8(d) per-axis-pass model); fused operands
-    are counted once where they are consumed: prologue operands in pass A, epilogue operands in pass C.
-    Optional operands (addend / accumulate in the VJP epilogue) are NOT counted (conservative).
-    """
+    Every pass reads and writes the work array once (2*N*b, SURVEY 8(d) per-axis-pass model); fused operands are counted
+    where they are consumed -- prologue operands in the first pass, epilogue operands in the final pass:
+      * amplitude fields a[pidx], da[pidx] of the register-resident pipelines are OCTANT arrays (N*b / 2^ndim each, the 2^ndim
+        sign-flip images of a coefficient share their bin) and there is NO 4-byte index stream (`octant`); the generic
+        kernels gather through pidx (4*N) instead;
+      * prologue key 4 = AMP_JVP with the CG direction update riding along (nk_fuse.cg_r): reads r, writes the new d;
+      * the VJP epilogue reads xi and the amplitude field and writes the octant sums w8 (fp64, N*8 / 2^ndim).
+    The optional addend / running sum / carried partial sums of a VJP epilogue vary from launch to launch inside a step and
+    are NOT counted (conservative: the kernel moves up to 3*N*b more)."""
     if kernel == 4:  # pass D touches 2 planes only
         return 0.0
     if kernel == 9:  # nk_hartley_sandwich_pair: two final passes in one launch
-        return 2.0 * algorithmic_bytes(3, pro, epi, N, b, const_mid)
+        return 2.0 * algorithmic_bytes(3, pro, epi, N, b, const_mid, octant, ndim)
+    field = N * b / 2 ** ndim if octant else 4.0 * N  # one amplitude field operand: octant array, or the index stream
     total = 2.0 * N * b
     if kernel == 7 and not const_mid:  # the diagonal between the two transforms of a sandwich
         total += N * b
     if kernel in (0, 1, 5):
-        total += {0: 0, 1: 4 * N, 2: N * b + 4 * N, 3: N * b}[pro]
+        total += {0: 0.0, 1: field, 2: N * b + 2 * field if octant else N * b + field, 3: N * b,
+                  4: 3 * N * b + 2 * field}[pro]  # (4: xi, r in, d out on top of the work array's 2 N b)
     if kernel in (0, 3):
-        total += {0: 0, 1: 0 if const_mid else N * b, 2: N * b + 4 * N, 3: N * b + (0 if const_mid else N * b),
-                  4: 0}[epi]
+        vjp = N * b + field + (N * 8.0 / 2 ** ndim if octant else 0.0)
+        total += {0: 0.0, 1: 0.0 if const_mid else N * b, 2: vjp, 3: N * b + (0.0 if const_mid else N * b), 4: 0.0}[epi]
     return total
 
 
@@ -450,14 +458,35 @@ def main():
     mean = 0.1 * model.draw_prior(gen)
     rng_draws = torch.Generator(device=device).manual_seed(1234 + rank) if rng_mode == "device" else None
 
+    phases = {}
+    phase_timing = os.environ.get("NK_BENCH_PHASES", "1" if (world > 1 or N >= (1 << 27)) else "0") == "1"
+
     def step(mean, pairs=n_pairs):
         ic = lambda: AbsDeltaEnergyController(0.05, iteration_limit=20)  # noqa: E731
         mini = NewtonCG(AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=3), max_cg_iterations=20)
         # C4: geoVI, the non-linear sample fit of demos/cl/getting_started_3.py:125-127
         geo = NewtonCG(AbsDeltaEnergyController(0.5, iteration_limit=5, convergence_level=2)) if cfg == "C4" else None
-        new_mean, kl = mgvi_iteration(model, mean, pairs, ic, mini, mirror_samples=True, comm=comm,
-                                      device_rng=rng_draws, geo_minimizer=geo)
-        return new_mean, kl.value
+        if not phase_timing:
+            new_mean, kl = mgvi_iteration(model, mean, pairs, ic, mini, mirror_samples=True, comm=comm,
+                                          device_rng=rng_draws, geo_minimizer=geo)
+            return new_mean, kl.value
+        # the three phases of engine.mgvi_iteration with a device synchronisation between them (NK_BENCH_PHASES, default on
+        # for world > 1 and for grids >= 2^27 points, where three extra synchronisations per step are noise): sampling has no
+        # exchange, the KL construction one all-reduce, the Newton-CG one exchange per CG iteration
+        marks = [time.perf_counter()]
+        residuals, negs, n_total = draw_samples(model, mean, pairs, True, ic, comm, rng_draws, geo)
+        torch.cuda.synchronize(device)
+        marks.append(time.perf_counter())
+        kl = FusedKL(model, mean, residuals, negs, n_total, comm)
+        torch.cuda.synchronize(device)
+        marks.append(time.perf_counter())
+        with parallel.lockstep(comm):
+            kl, _ = mini(kl)
+        torch.cuda.synchronize(device)
+        marks.append(time.perf_counter())
+        for name, a, b in zip(("sampling", "kl_construction", "newton_cg"), marks[:-1], marks[1:]):
+            phases[name] = phases.get(name, 0.0) + (b - a)
+        return kl.position, kl.value
 
     def sync():
         if comm is not None:
@@ -466,6 +495,9 @@ def main():
 
     for _ in range(args.warmup):
         mean, _ = step(mean)
+    phases.clear()
+    if world > 1 and os.environ.get("NK_BENCH_EXCHANGE_TIMER", "1") != "0":
+        parallel.exchange_timer.enable(True)  # device events around every exchange of the sharded CG (a few per iteration)
     for k in model.counters:  # in place: the lanes of small grids (FusedModel.lanes) count into the same dictionary
         model.counters[k] = 0
     minimization.counters["cg_iterations"] = 0
@@ -489,6 +521,10 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     lib.nk_profile_enable(0)
+    exchange = parallel.exchange_timer.summary() if parallel.exchange_timer.on else None
+    parallel.exchange_timer.enable(False)
+    phase_seconds = {k: v / args.steps for k, v in phases.items()} if phases else None
+    phases = {}  # (the side legs below do not add to the timed region's phases)
     # allocator behaviour of the timed region (peak footprint; hipMalloc calls after the warm-up: the peak still grows now
     # and then -- an A/B against one up-front segment showed no time difference, gpurun_out/r3q)
     ms = torch.cuda.memory_stats(device)
@@ -555,10 +591,11 @@ def main():
             ent["cnt"] += cnt
             # (the wide forward of an fp32 model, FusedModel.wide: float arrays at the ends, fp64 work array in between)
             wide_fwd = model.wide and pro == 1 and epi == 3
-            nbytes = cnt * algorithmic_bytes(kern, pro, epi, N, b, model.const_mid)
+            nbytes = cnt * algorithmic_bytes(kern, pro, epi, N, b, model.const_mid, octant=model.octant_vjp, ndim=len(shape))
             if wide_fwd:
-                nbytes += cnt * {2: 2 * N * b, 3: N * b}.get(kern, 0)  # fp64 work array: written by pass 1 (instead of the
-                # index stream the model prices), read + written by pass 2, read by the final pass
+                # the fp64 work array (and fp64 octant amplitude field) of that transform: written by pass 1, read + written
+                # by pass 2, read by the final pass -- at twice the bytes of the fp32 arrays the model above prices
+                nbytes += cnt * {1: N * b + N * b / 2 ** len(shape), 2: 2 * N * b, 3: N * b}.get(kern, 0)
             ent["bytes"] += nbytes
             sym = kernel_symbol(kern, pro, epi, shape, dt_name, octant=model.octant_vjp, wide=model.wide,
                                 const_mid=model.const_mid)
@@ -682,6 +719,15 @@ def main():
                                     / (ms_per_step * 1e-3) / 1e9) if by_kernel else None,
             "roofline": roofline,
             "device_memory_rank0": device_memory,
+            # seconds per step of the three phases (rank 0; None when NK_BENCH_PHASES=0): sampling runs without any exchange,
+            # the KL construction ends in one all-reduce, every CG iteration of the Newton-CG in one exchange
+            "phase_seconds_per_step_rank0": phase_seconds,
+            # world > 1: per sharded metric application (= per CG iteration of the KL minimisation) on rank 0, device-event
+            # times: all-gather of the direction, reduce-scatter of the output, the local metric application, what the
+            # compute stream still waits for at the end (exposed), and exchange - exposed (hidden) -- DESIGN 5's table
+            "exchange_per_cg_iteration_rank0": exchange,
+            "comm_ms_per_cg_iteration": None if exchange is None else exchange["exchange_ms"],
+            "overlap_ms": None if exchange is None else exchange["hidden_ms"],
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -370,8 +370,9 @@ int nk_cg_update(int64_t n, void* x, void* r, const void* d, const void* q, cons
  * x, r, b every iteration: conjugate_gradient.py:100-101) advances by dE = -alpha d.r + alpha^2/2 d.q */
 int nk_cg_update_dr(int64_t n, void* x, void* r, const void* d, const void* q, int dtype, double* scal, int accumulate,
                     void* stream);
-/* roll != 0: after the update also do scal[5]=alpha, scal[6]=beta, scal[0]=scal[2] (call once per iteration,
- * on the last segment of a multi-segment vector; n == 0 with d = r = NULL only rolls) */
+/* roll != 0: after the update also do scal[5]=alpha, scal[6]=beta, scal[0]=scal[2], scal[2..4]=0 (call once per iteration,
+ * on the last segment of a multi-segment vector; n == 0 with d = r = NULL only rolls).  The slots of the vector update are
+ * then clean: the next nk_cg_update[_dr] may pass accumulate != 0 for every segment */
 int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, double* scal, int roll, void* stream);
 
 /* ---- amplitude fields of PRODUCT spectra (library/correlated_fields.py:713-764: CorrelatedFieldMaker.finalize multiplies

@@ -514,15 +514,17 @@ def solve_together(model, lp, jobs, controller_factory):
             metric(model, Scratch(model, k), pts, d_a, qs, 1.0, [(v, 1.0) for v in d_a], dot_outs=slots)
             _check(lib.nk_cg_curv_batch(d_a[0].small.numel(), k, _ptrs([v.small for v in d_a]), _ptrs([v.small for v in qs]),
                                         L.NK_F64, _ptrs(rows), 1, st_), "nk_cg_curv_batch")
-            for i, seg in enumerate(("xi", "small")):
+            # (the slots of the update's reductions are zero here: fresh scalars at first, then left so by the roll that
+            # follows every update below -- accumulate = 1 for both segments, no zeroing launch)
+            for seg in ("xi", "small"):
                 xx, rr, dd, qq = ([getattr(v, seg).reshape(-1) for v in vs] for vs in (x_a, r_a, d_a, qs))
                 if track:
                     _check(lib.nk_cg_update_dr_batch(xx[0].numel(), k, _ptrs(xx), _ptrs(rr), _ptrs(dd), _ptrs(qq),
-                                                     B.dtype_code(xx[0]), _ptrs(rows), i, st_), "nk_cg_update_dr_batch")
+                                                     B.dtype_code(xx[0]), _ptrs(rows), 1, st_), "nk_cg_update_dr_batch")
                 else:
                     bb = [getattr(v, seg).reshape(-1) for v in b_a]
                     _check(lib.nk_cg_update_batch(xx[0].numel(), k, _ptrs(xx), _ptrs(rr), _ptrs(dd), _ptrs(qq), _ptrs(bb),
-                                                  B.dtype_code(xx[0]), _ptrs(rows), i, st_), "nk_cg_update_batch")
+                                                  B.dtype_code(xx[0]), _ptrs(rows), 1, st_), "nk_cg_update_batch")
             M.counters["cg_iterations"] += k
             since_reset += 1
             refreshed = False

@@ -12,7 +12,8 @@
 // The double cumulative sum is ONE scan with the associative affine operator
 //   (c, s) -> (c + A, s + c*Dk + B),  compose(l, r) = (Al+Ar, Dl+Dr, Bl+Br+Al*Dr)
 // executed as a two-launch multi-workgroup scan (per-workgroup aggregates, then carry-in + rescan), followed by
-// the element-wise / reduction stages: forward and JVP are 3 launches, VJP 5 (+ one zeroing launch) over <= 256 workgroups.
+// the element-wise / reduction stages: forward and JVP are 3 launches, VJP 5 over <= 256 workgroups (every reduction
+// STORES its result, amp_store_sums: nothing needs zeroing in between).
 // Every kernel runs a BATCH of latent points (include/niftyk.h, "batched launches"): blockIdx.y = member, the member's
 // latent vector, state and in / out arrays come from a pointer table; the single entry points are batches of one.
 #include <hip/hip_runtime.h>
@@ -485,11 +486,6 @@ __global__ void k_vjp_final(const double* __restrict__ hyp, AmpBatch mb) {
   }
 }
 
-// state[8 .. 13] of every member <- 0 (the VJP reductions start from zero)
-__global__ void k_vjp_zero(AmpBatch mb) {
-  if (threadIdx.x < 6) mb.state[blockIdx.x][8 + threadIdx.x] = 0.0;
-}
-
 }  // namespace
 
 static inline int amp_grid(int nb) {
@@ -547,7 +543,6 @@ extern "C" int nk_amp_vjp_batch(int nb, const double* geo, const double* hyp, in
   if (rc != NK_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   const ScanGeom sg = make_scan_geom(nb - 2);
-  hipLaunchKernelGGL(k_vjp_zero, dim3(count), dim3(64), 0, st, mb);
   hipLaunchKernelGGL(k_vjp_red1, dim3(amp_grid(nb), count), dim3(AMP_THREADS), 0, st, nb, hyp, mb);
   hipLaunchKernelGGL(k_vjp_red2, dim3(amp_grid(nb), count), dim3(AMP_THREADS), 0, st, nb, geo, hyp, mb);
   hipLaunchKernelGGL(k_vjp_agg, dim3(sg.ngroups, count), dim3(AMP_THREADS), 0, st, nb, sg, geo, mb);

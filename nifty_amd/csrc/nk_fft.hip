@@ -1393,12 +1393,12 @@ static int nk_run_sandwich(const nk_plan* P, const NkFuse& f, double scale_first
       const int a_lo = j * wc, a_hi = (j == C / 2 - 1) ? hp.g.na / 2 + 1 : (j + 1) * wc;
       p1.blk0 = (int64_t)a_lo * Mh;
       p1.nblk = (int64_t)(a_hi - a_lo) * Mh;
-      ProfScope ps(st, 5, f.pro, f.epi);
+      ProfScope ps(st, 5, f.cg_r ? 4 : f.pro, f.epi);  // (prologue key 4: AMP_JVP with the CG direction update riding along)
       rc = nk_dispatch_contig3<T>(hp.g.h, p1, f, (const C2<T>*)P->d_tw_a, (const C2<T>*)P->d_twr_a, work, st);
       if (rc != NK_OK) return rc;
     }
   } else {
-    ProfScope ps(st, 5, f.pro, f.epi);
+    ProfScope ps(st, 5, f.cg_r ? 4 : f.pro, f.epi);
     rc = nk_dispatch_contig3<T>(hp.g.h, q.p1, f, (const C2<T>*)P->d_tw_a, (const C2<T>*)P->d_twr_a, work, st);
     if (rc != NK_OK) return rc;
   }

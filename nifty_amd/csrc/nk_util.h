@@ -82,7 +82,8 @@ struct NkRedLayout {
 // Live profiling for bench.py (nk_profile_enable / nk_profile_collect): a scope brackets ONE kernel launch with HIP events
 // on its launch stream.  key = kernel * 25 + pro * 5 + epi:
 //   kernel 0 pass1d, 1 passA, 2 passB, 3 passC, 4 passD; sandwich: 5 contiguous first pass, 6 in-place middle-axis pass,
-//   7 fused first-axis pass (pro / epi = prologue / epilogue class of the launch);
+//   7 fused first-axis pass (pro / epi = prologue / epilogue class of the launch; pro 4 = the sandwich's first pass with
+//   the AMP_JVP prologue AND the pending CG direction update, nk_fuse.cg_r: two more streams);
 //   kernel 8 = nk_csr_rowsum (pro = lanes class 0..3 for 1 / 4 / 16 / 64 lanes per row, epi = 0 weighted, 1 unweighted).
 constexpr int NK_PROF_KEYS = 250;
 struct NkProfScope {

@@ -652,12 +652,18 @@ struct FCgDir {
   }
 };
 
-__global__ void k_cg_roll(double* scal) {  // after the direction update: gamma_prev <- gamma
+// after the direction update: gamma_prev <- gamma; the slots of the vector update's reductions (r.r, x.r | d.r, x.b) are
+// left at zero, so that the next nk_cg_update[_dr] may be called with accumulate != 0 for every segment (one memset launch
+// less).  The curvature slot is NOT touched: with the fused direction update the roll runs after the metric application has
+// deposited d.q there.
+__device__ __forceinline__ void nk_roll_scalars(double* scal) {
   scal[5] = scal[0] / scal[1];
   const double beta = scal[2] / scal[0];
   scal[6] = beta > 0.0 ? beta : 0.0;
   scal[0] = scal[2];
+  scal[2] = scal[3] = scal[4] = 0.0;
 }
+__global__ void k_cg_roll(double* scal) { nk_roll_scalars(scal); }
 
 // ---- C ABI --------------------------------------------------------------------------------------
 #define NK_DISPATCH_DTYPE(dtype, ...)                                      \
@@ -1126,13 +1132,7 @@ extern "C" int nk_cg_update_dr_batch(int64_t n, int count, void* const* x, void*
   })
 }
 
-__global__ void k_cg_roll_b(NkPtrs scals) {
-  double* scal = (double*)scals.p[blockIdx.x];
-  scal[5] = scal[0] / scal[1];
-  const double beta = scal[2] / scal[0];
-  scal[6] = beta > 0.0 ? beta : 0.0;
-  scal[0] = scal[2];
-}
+__global__ void k_cg_roll_b(NkPtrs scals) { nk_roll_scalars((double*)scals.p[blockIdx.x]); }
 
 extern "C" int nk_cg_direction_batch(int64_t n, int count, void* const* d, const void* const* r, int dtype, double* const* scal,
                                      int roll, void* stream) {

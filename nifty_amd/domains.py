@@ -369,29 +369,27 @@ class PowerSpace(StructuredDomain):
 
     @staticmethod
     def useful_binbounds(space, logarithmic, nbin=None):
-        """Bin bounds that leave no bin of `space` empty (power_space.py:105-153): `nbin` bins (default: as many as
-        possible) between the middle of the first two and the middle of the last two distinct |k|, equally wide in |k| or
-        -- `logarithmic` -- in log |k|.  (None, None) asks for the natural binning: None."""
+        """Bin bounds that leave no bin of `space` empty (power_space.py:105-153).  The outermost bounds sit half-way into
+        the first and the last gap between distinct |k|; in between the bins are equally wide in |k| -- or, `logarithmic`,
+        in log |k| -- and at most so many that the widest gap on that scale still catches a point.  `nbin` None: as many as
+        possible.  (logarithmic, nbin) = (None, None) asks for the natural binning: returns None."""
         if not (isinstance(space, StructuredDomain) and space.harmonic):
             raise ValueError("first argument must be a harmonic space.")
-        if logarithmic is None and nbin is None:
+        if (logarithmic, nbin) == (None, None):
             return None
-        logarithmic = bool(logarithmic)
-        k = np.array(space.get_unique_k_lengths(), dtype=np.float64)
-        if len(k) < 3:
+        lengths = np.asarray(space.get_unique_k_lengths(), dtype=np.float64)
+        if lengths.size < 3:
             raise ValueError("Space does not have enough unique k lengths")
-        first, last = 0.5 * (k[0] + k[1]), 0.5 * (k[-2] + k[-1])
-        k[0], k[-1] = first, last
-        scale = np.log(k) if logarithmic else k
-        widest_gap = np.max(np.diff(scale))  # a bin narrower than this could fall between two neighbours
-        most = int((scale[-1] - scale[0]) / widest_gap) + 2
-        nbin = most if nbin is None else int(nbin)
-        if nbin < 3:
+        outer = (lengths[:2].mean(), lengths[-2:].mean())
+        marks = np.concatenate(([outer[0]], lengths[1:-1], [outer[1]]))
+        on_scale = np.log(marks) if logarithmic else marks
+        finest = int((on_scale[-1] - on_scale[0]) / np.diff(on_scale).max()) + 2
+        wanted = finest if nbin is None else int(nbin)
+        if wanted < 3:
             raise ValueError("nbin must be at least 3")
-        if nbin > most:
+        if wanted > finest:
             raise ValueError("nbin is too large")
-        make = PowerSpace.logarithmic_binbounds if logarithmic else PowerSpace.linear_binbounds
-        return make(nbin, first, last)
+        return (PowerSpace.logarithmic_binbounds if logarithmic else PowerSpace.linear_binbounds)(wanted, *outer)
 
 
 def _interned(cache, key, build):

@@ -34,6 +34,8 @@ from .minimization import ConjugateGradient, Energy, QuadraticEnergy
 SMALL_KEYS = ("asperity", "flexibility", "fluctuations", "loglogavgslope", "zeromode")
 LATENT_KEYS = ("asperity", "flexibility", "fluctuations", "loglogavgslope", "spectrum", "xi", "zeromode")
 _NONLIN = {None: L.NL_ID, "": L.NL_ID, "exp": L.NL_EXP, "sigmoid": L.NL_SIGMOID}
+# grids up to this size draw the spectrum excitations of a prior sample on the device (FusedModel.draw_prior)
+SPECTRUM_DEVICE_DRAW_MAX_POINTS = int(os.environ.get("NK_SPECTRUM_DEVICE_DRAW_MAX_POINTS", str(1 << 25)))
 
 
 def lognormal_moments(mean, sigma):
@@ -57,9 +59,17 @@ class CgWorkspace:
     def __init__(self, device):
         self.scal = torch.zeros(8, dtype=torch.float64, device=device)
         self._host = torch.empty(8, dtype=torch.float64, pin_memory=True) if device.type == "cuda" else None
+        # which reduction slots are known to be zero (fresh; the update's slots also after the roll of nk_cg_direction):
+        # their next reduction accumulates instead of paying a memset launch first
+        self._clean = {"curv": True, "update": True}
 
     def set_gamma(self, gamma):
         self.scal[0] = gamma
+
+    def _first(self, which):
+        """`accumulate` flag of the FIRST segment of a reduction into the slots `which` (0: the kernel zeroes them first)"""
+        clean, self._clean[which] = self._clean[which], False
+        return 1 if clean else 0
 
     def _segments(self, *vecs):
         return [[v.xi.reshape(-1) if v is not None else None for v in vecs],
@@ -68,13 +78,15 @@ class CgWorkspace:
     def curv(self, d, q):
         lib, st = L.load(), B._stream()
         for i, (dd, qq) in enumerate(self._segments(d, q)):
-            L.check(lib.nk_cg_curv(dd.numel(), dd.data_ptr(), qq.data_ptr(), B.dtype_code(dd), self.scal.data_ptr(), i, st))
+            L.check(lib.nk_cg_curv(dd.numel(), dd.data_ptr(), qq.data_ptr(), B.dtype_code(dd), self.scal.data_ptr(),
+                                   i if i else self._first("curv"), st))
         parallel.lockstep_sync_(self.scal[1:2])
 
     def curv_slot(self):
         """Zeroed device slot of d.q for an operator that deposits the xi part itself (``fused_dot``)."""
         slot = self.scal[1:2]
-        slot.zero_()
+        if not self._first("curv"):
+            slot.zero_()
         return slot
 
     def curv_small(self, d, q):
@@ -87,7 +99,7 @@ class CgWorkspace:
         lib, st = L.load(), B._stream()
         for i, (xx, rr, dd, qq, bb) in enumerate(self._segments(x, r, d, q, b)):
             L.check(lib.nk_cg_update(xx.numel(), xx.data_ptr(), rr.data_ptr(), dd.data_ptr(), qq.data_ptr(), B.ptr(bb),
-                                     B.dtype_code(xx), self.scal.data_ptr(), i, st))
+                                     B.dtype_code(xx), self.scal.data_ptr(), i if i else self._first("update"), st))
         parallel.lockstep_sync_(self.scal[2:5])
 
     def update_dr(self, x, r, d, q):
@@ -95,11 +107,12 @@ class CgWorkspace:
         lib, st = L.load(), B._stream()
         for i, (xx, rr, dd, qq) in enumerate(self._segments(x, r, d, q)):
             L.check(lib.nk_cg_update_dr(xx.numel(), xx.data_ptr(), rr.data_ptr(), dd.data_ptr(), qq.data_ptr(),
-                                        B.dtype_code(xx), self.scal.data_ptr(), i, st))
+                                        B.dtype_code(xx), self.scal.data_ptr(), i if i else self._first("update"), st))
         parallel.lockstep_sync_(self.scal[2:4])
 
     def refresh(self, x, r, b):
         """After a residual refresh: gamma = r.r, x.r and x.b recomputed (device side)."""
+        self._clean["update"] = False
         for slot, (u, v) in ((2, (r, r)), (3, (x, r)), (4, (x, b))):
             if v is None:
                 continue
@@ -116,6 +129,7 @@ class CgWorkspace:
 
     def roll(self):
         L.check(L.load().nk_cg_direction(0, 0, 0, L.NK_F64, self.scal.data_ptr(), 1, B._stream()))
+        self._clean["update"] = True  # (the roll leaves the slots of the vector update at zero)
 
     def direction(self, d, r):
         lib, st = L.load(), B._stream()
@@ -123,6 +137,7 @@ class CgWorkspace:
         for i, (dd, rr) in enumerate(segs):
             L.check(lib.nk_cg_direction(dd.numel(), dd.data_ptr(), rr.data_ptr(), B.dtype_code(dd), self.scal.data_ptr(),
                                         1 if i == len(segs) - 1 else 0, st))
+        self._clean["update"] = True
 
     def fetch_begin(self):
         """Enqueue the copy of the scalars to the host and mark the spot in the stream: kernels enqueued after this call
@@ -1108,8 +1123,13 @@ class FusedModel:
                 xi = random.Random.normal_on_device(self.npdtype, self.shape, 0.0, 1.0, self.device)
             elif k == "spectrum":
                 # (2, nb - 2) values: 6 x 10^5 on a 2048^2 grid -- 5 ms of numpy per draw with the GPU idle, four draws per
-                # iteration; the same stream from the device like xi (small tables stay on the host: Random.normal_on_device)
-                spectrum = random.Random.normal_on_device(np.float64, (2, nb - 2), 0.0, 1.0, self.device)
+                # iteration, a fifth of a step there: small grids take the same stream from the device like xi (identical
+                # values outside the ziggurat tail, tests/test_rng.py).  On large grids the host draw is noise (1.2 x 10^6
+                # values = 9 ms per draw of a 5 s step at 1024^3) and stays numpy's own, bit for bit.
+                if self.N <= SPECTRUM_DEVICE_DRAW_MAX_POINTS:
+                    spectrum = random.Random.normal_on_device(np.float64, (2, nb - 2), 0.0, 1.0, self.device)
+                else:
+                    spectrum = self._upload(random.current_rng().normal(0.0, 1.0, (2, nb - 2)), torch.float64)
             else:
                 parts[k] = random.current_rng().normal(0.0, 1.0, ())
         small = torch.empty(self.nsmall, dtype=torch.float64, device=self.device)
@@ -1606,7 +1626,11 @@ class ShardedMetric:
         """q share = this rank's part of (sum over ranks of the local metric applied to the FULL d): unpipelined entry
         (residual refresh; callers that hold the full vector already)."""
         staged = self.chunks > 1 and self.overlap
-        return self._reduce(self.kl._apply_metric_local(d_full, pipe=(self.chunks, None, None) if staged else None))
+        timer = parallel.exchange_timer
+        with timer.span("local_metric"):
+            out = self.kl._apply_metric_local(d_full, pipe=(self.chunks, None, None) if staged else None)
+        with timer.span("exposed_wait"), timer.span("reduce_scatter"):  # (blocking on the compute stream)
+            return self._reduce(out)
 
     def _scatter_chunk(self, full_chunk, share):
         """share <- this rank's 1/size of the sum over ranks of one chunk: the tree over the rank partials when every rank
@@ -1634,30 +1658,38 @@ class ShardedMetric:
     def apply_shard(self, d_shard, d_full):
         """q share for the search direction held as a share: all-gather d into `d_full`, apply the local metric, reduce-
         scatter -- with the exchange overlapped chunk by chunk when RCCL runs it on the side stream."""
+        timer = parallel.exchange_timer
+        P, nbytes = self.comm.size, d_full.xi.numel() * d_full.xi.element_size()
+        timer.count(2 * (P - 1) * nbytes // P)  # per rank: all-gather in + reduce-scatter out, (P-1)/P of the vector each
         if self._side is None:  # one chunk, or a backend that stages through the host (gloo: tests)
-            self.gather(d_shard, d_full)
-            return self.apply(d_full)
+            with timer.span("iteration"):
+                with timer.span("exposed_wait"), timer.span("all_gather"):  # (blocking: nothing of it is hidden)
+                    self.gather(d_shard, d_full)
+                return self.apply(d_full)
         cur = torch.cuda.current_stream(self.model.device)
         side, pairs = self._side, self._stage_chunks()
         full = d_full.xi.reshape(-1).view(self.chunks, -1)
         mine = d_shard.xi.view(self.chunks, self.m)
-        d_full.small.copy_(d_shard.small)
-        side.wait_stream(cur)  # the share of d is final
-        with torch.cuda.stream(side):
-            for j, pair in enumerate(pairs):
-                for c in pair:
-                    self.comm.all_gather(mine[c], full[c])
-                self._ev_in[j].record(side)
-        out = self.kl._apply_metric_local(d_full, pipe=(self.chunks, self._h_in, self._h_out))
-        q_xi = torch.empty(self.chunks * self.m, dtype=out.xi.dtype, device=out.xi.device)
-        ofull = out.xi.reshape(-1).view(self.chunks, -1)
-        with torch.cuda.stream(side):
-            for j, pair in enumerate(pairs):
-                side.wait_event(self._ev_out[j])
-                for c in pair:
-                    self._scatter_chunk(ofull[c], q_xi[c * self.m:(c + 1) * self.m])
-        cur.wait_stream(side)
-        self._sum_small(out.small)
+        with timer.span("iteration", cur):
+            d_full.small.copy_(d_shard.small)
+            side.wait_stream(cur)  # the share of d is final
+            with torch.cuda.stream(side), timer.span("all_gather", side):
+                for j, pair in enumerate(pairs):
+                    for c in pair:
+                        self.comm.all_gather(mine[c], full[c])
+                    self._ev_in[j].record(side)
+            with timer.span("local_metric", cur):
+                out = self.kl._apply_metric_local(d_full, pipe=(self.chunks, self._h_in, self._h_out))
+            q_xi = torch.empty(self.chunks * self.m, dtype=out.xi.dtype, device=out.xi.device)
+            ofull = out.xi.reshape(-1).view(self.chunks, -1)
+            with torch.cuda.stream(side), timer.span("reduce_scatter", side):
+                for j, pair in enumerate(pairs):
+                    side.wait_event(self._ev_out[j])
+                    for c in pair:
+                        self._scatter_chunk(ofull[c], q_xi[c * self.m:(c + 1) * self.m])
+            with timer.span("exposed_wait", cur):  # what the compute stream still waits for once its own work is done
+                cur.wait_stream(side)
+            self._sum_small(out.small)
         return LatentVec(q_xi, out.small)
 
 

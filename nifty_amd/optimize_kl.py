@@ -134,6 +134,7 @@ def _fused_model(lh, device_id, dtype):
     from . import backend as B
     from .engine import FusedModel
 
+    dtype = np.dtype(dtype)  # (np.float32 and dtype('float32') must find the same model)
     key = (id(lh), device_id, dtype)
     if key not in _fused_cache:
         while len(_fused_cache) >= _FUSED_CACHE_MAX:  # oldest first (dicts keep insertion order)

@@ -272,6 +272,76 @@ class Comm:
         return self.rank == 0
 
 
+class ExchangeTimer:
+    """Where the time of a sharded CG iteration goes (bench.py, world > 1): device-event pairs around the all-gather of the
+    search direction and the reduce-scatter of the metric output (on the exchange stream), around the local metric
+    application and around the compute stream's final wait for the exchange -- what remains EXPOSED of it.
+    hidden = exchange - exposed.  Off unless `enable()`d; recording costs a few events per iteration."""
+
+    KINDS = ("all_gather", "reduce_scatter", "local_metric", "exposed_wait", "iteration")
+
+    def __init__(self):
+        self.on, self._pairs, self._pool, self.iterations, self.bytes = False, [], [], 0, 0
+
+    def enable(self, on=True):
+        self.on = bool(on)
+        self.reset()
+
+    def reset(self):
+        self._pool += [e for _, a, b in self._pairs for e in (a, b)]
+        self._pairs, self.iterations, self.bytes = [], 0, 0
+
+    class _Span:
+        def __init__(self, timer, kind, stream):
+            self.t, self.kind, self.stream = timer, kind, stream
+
+        def __enter__(self):
+            if self.t.on:
+                self.a = self.t._event()
+                self.a.record(self.stream)
+            return self
+
+        def __exit__(self, *exc):
+            if self.t.on:
+                b = self.t._event()
+                b.record(self.stream)
+                self.t._pairs.append((self.kind, self.a, b))
+            return False
+
+    def _event(self):
+        return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
+
+    def span(self, kind, stream=None):
+        """``with timer.span("all_gather", side_stream):`` -- the enclosed work of that stream (default: the current one)"""
+        if self.on and stream is None:
+            stream = torch.cuda.current_stream()
+        return self._Span(self, kind, stream)
+
+    def count(self, nbytes):
+        if self.on:
+            self.iterations += 1
+            self.bytes += int(nbytes)
+
+    def summary(self):
+        """ms per sharded metric application by kind (synchronises the device), bytes through the links per application"""
+        if not self._pairs:
+            return None
+        torch.cuda.synchronize()
+        total = dict.fromkeys(self.KINDS, 0.0)
+        for kind, a, b in self._pairs:
+            total[kind] += a.elapsed_time(b)
+        n = max(self.iterations, 1)
+        out = {f"{k}_ms": round(v / n, 4) for k, v in total.items()}
+        exchange = total["all_gather"] + total["reduce_scatter"]
+        out.update(applications=self.iterations, exchange_ms=round(exchange / n, 4),
+                   hidden_ms=round(max(exchange - total["exposed_wait"], 0.0) / n, 4),
+                   link_bytes_per_application=self.bytes // n)
+        return out
+
+
+exchange_timer = ExchangeTimer()
+
+
 def tree_sum_enabled():
     """NK_TREE_SUM (default 1): sums over samples follow `pair_tree` -- locally and across ranks."""
     return os.environ.get("NK_TREE_SUM", "1") != "0"
