@@ -40,7 +40,7 @@ from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG  # noqa: E
 
 # streams of the fused CG vector update: x, r (read + write), d, q -- plus b when the energy is re-evaluated from x.b
 CG_STREAMS = 7.0 if os.environ.get("NK_CG_ENERGY_RECURRENCE", "1") == "0" else 6.0
-PMC_TRAFFIC_FILE = os.environ.get("NK_PMC_FILE", "r04_pmc_traffic.json")  # latest committed PMC summary of the bench command
+PMC_TRAFFIC_FILE = os.environ.get("NK_PMC_FILE", "r05_pmc_traffic.json")  # latest committed PMC summary of the bench command
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # transform pass kernels by profile id: strided-first pipeline (A first strided pass with prologue, B in-place strided
 # pass, C final contiguous pass with epilogue) and the five-pass sandwich H D H of a metric application (S1 contiguous

@@ -525,7 +525,7 @@ def solve_together(model, lp, jobs, controller_factory):
                     bb = [getattr(v, seg).reshape(-1) for v in b_a]
                     _check(lib.nk_cg_update_batch(xx[0].numel(), k, _ptrs(xx), _ptrs(rr), _ptrs(dd), _ptrs(qq), _ptrs(bb),
                                                   B.dtype_code(xx[0]), _ptrs(rows), 1, st_), "nk_cg_update_batch")
-            M.counters["cg_iterations"] += k
+            M.counters.add("cg_iterations", k)
             since_reset += 1
             refreshed = False
             if since_reset >= 20:  # (ConjugateGradient's nreset) r = A x - b

@@ -1821,7 +1821,8 @@ def _fit_on_lanes(model, lanes, tp, g_p, position, jobs, minimizer):
     def work(k):
         lane, mine = lanes[k], copy.deepcopy(minimizer)
         torch.cuda.set_device(model.device)
-        with (torch.cuda.stream(lane.stream) if lane.stream is not None else contextlib.nullcontext()):
+        # (a worker thread starts on the DEFAULT stream: the lane without a stream of its own works on the caller's)
+        with torch.cuda.stream(lane.stream if lane.stream is not None else main):
             for j in range(k, len(jobs), K):
                 (b, y), mirrored = jobs[j]
                 target = g_p - b if mirrored else g_p + b

@@ -16,7 +16,22 @@ import numpy as np
 logger = logging.getLogger("nifty_amd")
 
 CONVERGED, CONTINUE, ERROR = 0, 1, 2
-counters = {"cg_iterations": 0}  # work counters (bench.py): CG iterations = metric applications inside ConjugateGradient
+class _Counters(dict):
+    """work counters (bench.py): CG iterations = metric applications inside ConjugateGradient.  `counters[k] += n` from
+    several host threads (the geoVI fits of engine._fit_on_lanes) must not lose increments: use `add`."""
+
+    def __init__(self, *a, **kw):
+        import threading
+
+        super().__init__(*a, **kw)
+        self._lock = threading.Lock()
+
+    def add(self, key, n=1):
+        with self._lock:
+            self[key] += n
+
+
+counters = _Counters(cg_iterations=0)
 
 
 def _lockstep_flush():
@@ -394,7 +409,7 @@ class _HostCg:
 
     def iterate(self, controller):
         q = self.energy.apply_metric(self.d)
-        counters["cg_iterations"] += 1
+        counters.add("cg_iterations")
         curvature = self._dot(self.d, q)
         if np.isnan(curvature) or curvature == 0.0:
             return self._bad("the curvature <d, A d> is zero or not a number")
@@ -566,7 +581,7 @@ class ConjugateGradient(Minimizer):
             iteration += 1
             device_iteration(iteration > 1 and not direction_done)
             direction_done = False
-            counters["cg_iterations"] += 1
+            counters.add("cg_iterations")
             since_reset += 1
             refreshed = False
             if since_reset >= self._nreset:
@@ -631,7 +646,7 @@ class ConjugateGradient(Minimizer):
                 ws.update_dr(x, r, d, q)
             else:
                 ws.update(x, r, d, q, b)
-            counters["cg_iterations"] += 1
+            counters.add("cg_iterations")
             since_reset += 1
             refreshed = False
             if since_reset >= self._nreset:

@@ -13,6 +13,7 @@ plain all-reduce of rounds 1-3 (RCCL's order: results agree between rank counts 
 """
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -424,9 +425,7 @@ def lockstep_float(value, device=None):
         t = torch.tensor([value], dtype=torch.float64, device=comm.scalar_device())
         comm.bcast_(t)
         return float(t.item())
-    _pending.append(float(value))
-    if len(_pending) >= 256:
-        lockstep_flush()
+    _pending.append(float(value))  # (no flush from here: the flush points are fixed places of the minimisers, lockstep_flush)
     return value
 
 
@@ -440,12 +439,20 @@ def lockstep_flush():
     """ONE collective: do all ranks hold the same steering scalars since the last flush?  max(v) and max(-v) over the ranks
     agree with the local values iff they do.  Every rank reaches the same verdict (RuntimeError everywhere or nowhere)."""
     comm = lockstep_comm()
-    if comm is None or not _pending:
+    if comm is None:
         del _pending[:]
         return
-    mine = torch.tensor(_pending, dtype=torch.float64)
+    # A FIXED-SIZE digest, so that the collective has the same shape on every rank even when the ranks disagree on HOW
+    # MANY decisions they took since the last flush (one more line-search probe on one rank -- exactly the kind of slip this
+    # check exists for; with a message of 2 * len(_pending) values the all-reduce itself would have hung or failed):
+    # [count, sum of the scalars, sum of their squares, an order-sensitive fold], each with its negative under MAX.
+    vals = np.nan_to_num(np.asarray(_pending, dtype=np.float64), nan=1.23456789e300, posinf=1.7e308, neginf=-1.7e308)
     del _pending[:]
-    mine = torch.nan_to_num(mine, nan=1.23456789e300, posinf=1.7e308, neginf=-1.7e308)  # comparable stand-ins
+    scaled = vals * 2.0 ** -520  # (squares of the inf stand-ins stay finite)
+    fold = 0.0
+    for k, v in enumerate(scaled):
+        fold = 0.61803398875 * fold + (k % 7 + 1) * v
+    mine = torch.tensor([float(len(vals)), float(scaled.sum()), float((scaled * scaled).sum()), fold], dtype=torch.float64)
     both = torch.cat([mine, -mine]).to(comm.scalar_device())
     comm._staged(both, lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX, group=comm.group))
     both = both.cpu()
@@ -601,7 +608,10 @@ class SamplePlan:
 
     def run_together(self, prepare, solve, finish):
         """run() for linear samples that are solved TOGETHER: `prepare(seed)` (inside the sample's random context) draws
-        what one pair's solve needs, `solve(list of prepared)` returns the pairs, `finish` as in run()."""
+        what one pair's solve needs, `solve(list of prepared)` returns the pairs, `finish` as in run() -- except that it
+        runs in a FRESH context on the sample's seed (the generator restarts there, while run() lets it continue after the
+        draw): `finish` must not draw random numbers, or the two paths give different samples (today's callers: the
+        identity and the geoVI fit, which draw nothing)."""
         from . import random
 
         jobs, job_of = [], {}
