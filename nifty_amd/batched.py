@@ -528,7 +528,9 @@ def solve_together(model, lp, jobs, controller_factory):
             M.counters.add("cg_iterations", k)
             since_reset += 1
             refreshed = False
-            if since_reset >= 20:  # (ConjugateGradient's nreset) r = A x - b
+            # (ConjugateGradient's nreset) r = A x - b -- unless every solve stops at its iteration limit now anyway
+            # (minimization._forced_stop: the residual of a final iterate is never read)
+            if since_reset >= 20 and not all(M._forced_stop(controllers[m]) for m in active):
                 axs = [LatentVec(torch.empty_like(v.xi), None) for v in x_a]
                 metric(model, Scratch(model, k), pts, x_a, axs, 1.0, [(v, 1.0) for v in x_a])
                 for r, ax, b in zip(r_a, axs, b_a):

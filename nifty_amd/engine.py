@@ -411,6 +411,7 @@ class LinPoint:
         self.mid_scalar = 1.0
         self.f = self.tf = None
         self.gp = self.wd = self.tfd = None  # response models: g'(s) [grid], data-space metric weight, df/dmu [data]
+        self.value = self.grad = None  # (stay None for a FusedModel.metric_point)
 
 
 class FusedModel:
@@ -714,12 +715,28 @@ class FusedModel:
                                     lp.state.data_ptr(), self.abar.data_ptr(), self.latbar.data_ptr(), B._stream()),
                 "nk_amp_vjp")
 
-    def linearize(self, x, grad_acc=None, n_total=1, value_acc=None, dest=None):
+    def metric_point(self, x):
+        """What metric applications at x need and nothing else -- amplitude tables / field / state and the s-space (or
+        data-space) weights: the linearisation point of the SAMPLING solves (kl_energies.py:105-128 builds the metric at the
+        mean there; its value and gradient are never asked for).  A Gaussian likelihood on the field itself has a constant
+        weight: no transform at all; otherwise the forward transform with the likelihood epilogue fills the weight field and
+        the adjoint transform of the gradient is skipped."""
+        if self.response is None and self.const_mid:
+            lp = LinPoint()
+            lp.x = x
+            lp.amp, lp.state = self._amp_forward(x.small)
+            lp.afield = self._amp_field(lp.amp)
+            lp.mid_scalar = self.icov_scalar
+            return lp
+        return self.linearize(x, want_gradient=False)
+
+    def linearize(self, x, grad_acc=None, n_total=1, value_acc=None, dest=None, want_gradient=True):
         """Value and gradient of H = lh + 1/2|x|^2 at x, cached for metric applications.
 
         With ``grad_acc``/``value_acc`` the sample average is accumulated in place (1/n_total weights); with ``dest`` (a
         `_Dest` with a `small` list) the xi part of the weighted gradient goes where the pairwise sum over samples wants
-        it and the small part is appended to the list (FusedKL).
+        it and the small part is appended to the list (FusedKL).  want_gradient=False: only what metric applications need
+        (`metric_point`): the adjoint transform of the gradient is not run, `value` / `grad` stay None.
         """
         lp = LinPoint()
         lp.x = x
@@ -729,7 +746,7 @@ class FusedModel:
         value = torch.zeros(1, dtype=torch.float64, device=self.device) if value_acc is None else value_acc
         lhval = torch.zeros(1, dtype=torch.float64, device=self.device)
         if self.response is not None:
-            return self._linearize_response(lp, x, grad_acc if dest is None else dest, w, value, lhval)
+            return self._linearize_response(lp, x, grad_acc if dest is None else dest, w, value, lhval, want_gradient)
         f = self._fuse()
         f.pro, f.in_, f.pidx, f.amp = L.PRO_AMP, x.xi.data_ptr(), self.pidx.data_ptr(), lp.amp.data_ptr()
         f.afield = lp.afield.data_ptr()
@@ -749,6 +766,8 @@ class FusedModel:
         else:
             B.hartley_fused(self.plan, f)
         self._count("transforms", 1)
+        if not want_gradient:
+            return lp
         return self._finish_linearize(lp, x, gs, None, grad_acc if dest is None else dest, w, value, lhval)
 
     # -- lanes: independent scratch sets, so that the chains of several samples run on several streams at once ----------
@@ -837,7 +856,7 @@ class FusedModel:
             return B.axpby(self.icov_scalar, u)
         return B.binary(L.OP_MUL, u, self.icov_field if self.lh_kind == L.LH_GAUSS else lp.wd)
 
-    def _linearize_response(self, lp, x, grad_acc, w, value, lhval):
+    def _linearize_response(self, lp, x, grad_acc, w, value, lhval, want_gradient=True):
         """energy_operators.py:517-595 / :617-640 composed with R o g o cf: mu = R g(s) lives on the data space."""
         self._forward_nonlin(lp, x, self.tmp)
         mu = self.response.times(self.tmp)
@@ -853,6 +872,8 @@ class FusedModel:
             B.axpby(1.0, lhval, -1.0, ld, out=lhval)
             lp.wd = B.pointwise("reciprocal", mu)
             ir = B.binary(L.OP_SUB, 1.0, B.binary(L.OP_MUL, dat, lp.wd))  # 1 - d / mu
+        if not want_gradient:  # (lp.gp and lp.wd are what the metric needs)
+            return lp
         gs = self.response.adjoint(ir, self.shape)
         return self._finish_linearize(lp, x, gs, lp.gp, grad_acc, w, value, lhval)
 
@@ -1749,7 +1770,7 @@ def draw_samples(model, position, n_samples, mirror_samples, controller_factory,
 
     def linearisation():
         if "lp" not in cache:
-            cache["lp"] = model.linearize(position)
+            cache["lp"] = model.metric_point(position)  # (the sampling solves apply the metric there; no value, no gradient)
         return cache["lp"]
 
     def draw(seed):

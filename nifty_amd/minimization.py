@@ -252,6 +252,10 @@ class _LevelController(IterationController):
     def _on_start(self, energy):
         pass
 
+    def stops_at_next_check(self):
+        """True when the next check() ends the iteration whatever the energy is: the iteration limit is reached then."""
+        return self._iteration_limit is not None and self._itcount + 1 >= self._iteration_limit
+
     @_logged
     def check(self, energy):
         self._itcount += 1
@@ -359,6 +363,12 @@ class StochasticAbsDeltaEnergyController(_LevelController):
 class Minimizer:
     def __call__(self, energy, preconditioner=None):
         raise NotImplementedError
+
+
+def _forced_stop(controller):
+    """Will the controller's next check end the solve at its iteration limit, whatever the energy (see _inplace_steps)?"""
+    probe = getattr(controller, "stops_at_next_check", None)
+    return bool(probe()) if probe is not None else False
 
 
 def _config_track_energy():
@@ -584,8 +594,11 @@ class ConjugateGradient(Minimizer):
             counters.add("cg_iterations")
             since_reset += 1
             refreshed = False
-            if since_reset >= self._nreset:
-                # periodic residual refresh (conjugate_gradient.py:103-106): r = A x - b
+            # periodic residual refresh (conjugate_gradient.py:103-106): r = A x - b -- except when the controller is about to
+            # stop at its iteration limit anyway (20 iterations, refresh every 20: the recipe of the sampling solves ends on
+            # exactly this case): the iterate is final, nobody reads that residual, and the refresh is a whole metric
+            # application (1 of 22 per sampling solve)
+            if since_reset >= self._nreset and not _forced_stop(controller):
                 Ax = A(x)
                 r = Ax - b if b is not None else Ax
                 ws.refresh(x, r, b)
@@ -649,7 +662,7 @@ class ConjugateGradient(Minimizer):
             counters.add("cg_iterations")
             since_reset += 1
             refreshed = False
-            if since_reset >= self._nreset:
+            if since_reset >= self._nreset and not _forced_stop(controller):
                 Ax = sm.apply(sm.gather(x))
                 r = Ax - b
                 ws.refresh(x, r, b)
