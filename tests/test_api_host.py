@@ -757,3 +757,18 @@ def test_total_N_correlated_fields_with_dofdex(device_id):
         cfm.add_fluctuations(ift.RGSpace((4,)), (1.0, 0.5), (1.2, 0.4), (0.4, 0.2), (-3.0, 0.5), dofdex=[0, 1])
     with pytest.raises(NotImplementedError):
         cfm.add_fluctuations_matern(ift.RGSpace((4,)), (1.0, 0.3), (2.0, 0.5), (-4.0, 0.5))
+
+
+def test_controller_announces_a_forced_stop():
+    """_LevelController.stops_at_next_check: True exactly when the next check() hits the iteration limit -- what lets the
+    in-place CG skip a residual refresh whose result nobody would read (minimization._inplace_steps)."""
+    from nifty_amd.minimization import CONTINUE, CONVERGED, _ScalarEnergyView, _forced_stop
+
+    ctrl = ift.AbsDeltaEnergyController(deltaE=1e-30, iteration_limit=3)
+    e = _ScalarEnergyView(1.0, 1.0)
+    assert ctrl.start(e) == CONTINUE and not ctrl.stops_at_next_check()
+    assert ctrl.check(_ScalarEnergyView(0.5, 1.0)) == CONTINUE and not _forced_stop(ctrl)
+    assert ctrl.check(_ScalarEnergyView(0.25, 1.0)) == CONTINUE and _forced_stop(ctrl)
+    assert ctrl.check(_ScalarEnergyView(0.125, 1.0)) == CONVERGED
+    assert not _forced_stop(ift.GradientNormController(tol_abs_gradnorm=1e-3))  # no iteration limit: never forced
+    assert not _forced_stop(object())

@@ -538,6 +538,28 @@ def _lockstep_worker(rank, world, port, out):
         res["caught"] = False
     except RuntimeError as exc:
         res["caught"] = "left lockstep" in str(exc)
+    # ranks that took a different NUMBER of decisions since the last flush (one more line-search probe on rank 1: ADVICE r4)
+    # still meet in a collective of the same shape -- the digest is fixed-size -- and both raise instead of hanging
+    try:
+        with parallel.lockstep(comm):
+            for v in (1.0, 2.0, 3.0)[:2 + rank]:
+                parallel.lockstep_float(v)
+        res["count_caught"] = False
+    except RuntimeError as exc:
+        res["count_caught"] = "left lockstep" in str(exc)
+    # ... and the same scalars in another order are a disagreement too (the digest folds them in order)
+    try:
+        with parallel.lockstep(comm):
+            for v in ((1.0, 2.0) if rank == 0 else (2.0, 1.0)):
+                parallel.lockstep_float(v)
+        res["order_caught"] = False
+    except RuntimeError as exc:
+        res["order_caught"] = "left lockstep" in str(exc)
+    # many decisions between two flushes need no intermediate collective
+    with parallel.lockstep(comm):
+        for k in range(1000):
+            parallel.lockstep_float(0.5 * k)
+    res["many"] = True
     # broadcast mode (rounds 1-3): rank 0's value everywhere
     os.environ["NK_LOCKSTEP"] = "broadcast"
     with parallel.lockstep(comm):
@@ -555,7 +577,7 @@ def test_lockstep_verifies_with_one_collective_per_flush(tmp_path):
     mp.spawn(_lockstep_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     for rank in (0, 1):
         res = torch.load(out + str(rank), weights_only=False)
-        assert res == dict(agree=True, caught=True, forced=True), (rank, res)
+        assert res == dict(agree=True, caught=True, count_caught=True, order_caught=True, many=True, forced=True), (rank, res)
 
 
 def _tree_worker(rank, world, port, out):
