@@ -459,7 +459,7 @@ def main():
     rng_draws = torch.Generator(device=device).manual_seed(1234 + rank) if rng_mode == "device" else None
 
     phases = {}
-    phase_timing = os.environ.get("NK_BENCH_PHASES", "1" if (world > 1 or N >= (1 << 27)) else "0") == "1"
+    phase_timing = os.environ.get("NK_BENCH_PHASES", "1" if (comm is not None or N >= (1 << 27)) else "0") == "1"
 
     def step(mean, pairs=n_pairs):
         ic = lambda: AbsDeltaEnergyController(0.05, iteration_limit=20)  # noqa: E731
@@ -496,7 +496,7 @@ def main():
     for _ in range(args.warmup):
         mean, _ = step(mean)
     phases.clear()
-    if world > 1 and os.environ.get("NK_BENCH_EXCHANGE_TIMER", "1") != "0":
+    if comm is not None and os.environ.get("NK_BENCH_EXCHANGE_TIMER", "1") != "0":  # (world > 1, or NK_FORCE_COMM=1)
         parallel.exchange_timer.enable(True)  # device events around every exchange of the sharded CG (a few per iteration)
     for k in model.counters:  # in place: the lanes of small grids (FusedModel.lanes) count into the same dictionary
         model.counters[k] = 0

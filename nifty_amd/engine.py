@@ -1703,11 +1703,12 @@ class ShardedMetric:
                 out = self.kl._apply_metric_local(d_full, pipe=(self.chunks, self._h_in, self._h_out))
             q_xi = torch.empty(self.chunks * self.m, dtype=out.xi.dtype, device=out.xi.device)
             ofull = out.xi.reshape(-1).view(self.chunks, -1)
-            with torch.cuda.stream(side), timer.span("reduce_scatter", side):
+            with torch.cuda.stream(side):
                 for j, pair in enumerate(pairs):
-                    side.wait_event(self._ev_out[j])
-                    for c in pair:
-                        self._scatter_chunk(ofull[c], q_xi[c * self.m:(c + 1) * self.m])
+                    side.wait_event(self._ev_out[j])  # (outside the timed span: this is waiting for the final pass, not exchange)
+                    with timer.span("reduce_scatter", side):
+                        for c in pair:
+                            self._scatter_chunk(ofull[c], q_xi[c * self.m:(c + 1) * self.m])
             with timer.span("exposed_wait", cur):  # what the compute stream still waits for once its own work is done
                 cur.wait_stream(side)
             self._sum_small(out.small)
