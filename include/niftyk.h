@@ -372,7 +372,9 @@ int nk_cg_update_dr(int64_t n, void* x, void* r, const void* d, const void* q, i
                     void* stream);
 /* roll != 0: after the update also do scal[5]=alpha, scal[6]=beta, scal[0]=scal[2], scal[2..4]=0 (call once per iteration,
  * on the last segment of a multi-segment vector; n == 0 with d = r = NULL only rolls).  The slots of the vector update are
- * then clean: the next nk_cg_update[_dr] may pass accumulate != 0 for every segment */
+ * then clean: the next nk_cg_update[_dr] may pass accumulate != 0 for every segment.  roll == 2 also clears scal[1], for a
+ * caller whose next d.q is ACCUMULATED into the slot after this call (an epilogue deposit followed by nk_cg_curv with
+ * accumulate != 0); roll == 1 leaves it alone, for the fused direction update that runs after the deposit */
 int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, double* scal, int roll, void* stream);
 
 /* ---- amplitude fields of PRODUCT spectra (library/correlated_fields.py:713-764: CorrelatedFieldMaker.finalize multiplies

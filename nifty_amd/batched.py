@@ -509,8 +509,7 @@ def solve_together(model, lp, jobs, controller_factory):
             # (d <- beta d + r of this iteration was enqueued at the end of the previous one, ahead of the host's wait)
             # q = (J^T M J + 1) d with d.q (xi part) taken in the epilogue, like the single solve's fused dot
             qs = [LatentVec(torch.empty_like(v.xi), None) for v in d_a]
-            slots = [row[1:2] for row in rows]
-            ws.scal[:, 1].zero_()
+            slots = [row[1:2] for row in rows]  # (zero: fresh at first, then cleared by the roll -- roll = 2 below)
             metric(model, Scratch(model, k), pts, d_a, qs, 1.0, [(v, 1.0) for v in d_a], dot_outs=slots)
             _check(lib.nk_cg_curv_batch(d_a[0].small.numel(), k, _ptrs([v.small for v in d_a]), _ptrs([v.small for v in qs]),
                                         L.NK_F64, _ptrs(rows), 1, st_), "nk_cg_curv_batch")
@@ -545,7 +544,7 @@ def solve_together(model, lp, jobs, controller_factory):
             ws.fetch_begin()
             # the next iteration's d <- beta d + r (xi, then the small part with the roll of the scalars), enqueued before the
             # host waits for this iteration's scalars: it steers nothing, and a solve that stops now never reads its d again
-            for seg, roll in (("xi", 0), ("small", 1)):
+            for seg, roll in (("xi", 0), ("small", 2)):
                 dd = [getattr(v, seg).reshape(-1) for v in d_a]
                 rr = [getattr(v, seg).reshape(-1) for v in r_a]
                 _check(lib.nk_cg_direction_batch(dd[0].numel(), k, _ptrs(dd), _ptrs(rr), B.dtype_code(dd[0]), _ptrs(rows),

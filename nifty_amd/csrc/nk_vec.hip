@@ -654,16 +654,17 @@ struct FCgDir {
 
 // after the direction update: gamma_prev <- gamma; the slots of the vector update's reductions (r.r, x.r | d.r, x.b) are
 // left at zero, so that the next nk_cg_update[_dr] may be called with accumulate != 0 for every segment (one memset launch
-// less).  The curvature slot is NOT touched: with the fused direction update the roll runs after the metric application has
-// deposited d.q there.
-__device__ __forceinline__ void nk_roll_scalars(double* scal) {
+// less).  The curvature slot is NOT touched by roll == 1: with the fused direction update the roll runs after the metric
+// application has deposited d.q there.  roll == 2 (a caller whose roll precedes the next application) clears it as well.
+__device__ __forceinline__ void nk_roll_scalars(double* scal, int roll) {
   scal[5] = scal[0] / scal[1];
   const double beta = scal[2] / scal[0];
   scal[6] = beta > 0.0 ? beta : 0.0;
   scal[0] = scal[2];
   scal[2] = scal[3] = scal[4] = 0.0;
+  if (roll == 2) scal[1] = 0.0;
 }
-__global__ void k_cg_roll(double* scal) { nk_roll_scalars(scal); }
+__global__ void k_cg_roll(double* scal, int roll) { nk_roll_scalars(scal, roll); }
 
 // ---- C ABI --------------------------------------------------------------------------------------
 #define NK_DISPATCH_DTYPE(dtype, ...)                                      \
@@ -968,7 +969,7 @@ extern "C" int nk_cg_direction(int64_t n, void* d, const void* r, int dtype, dou
     rc = nk_launch_map<T>(n, f, nk_aligned16(d) && nk_aligned16(r), st, "nk_cg_direction");
   })
   if (rc != NK_OK || !roll) return rc;
-  hipLaunchKernelGGL(k_cg_roll, dim3(1), dim3(1), 0, st, scal);
+  hipLaunchKernelGGL(k_cg_roll, dim3(1), dim3(1), 0, st, scal, roll);
   return nk_check_launch("k_cg_roll");
 }
 
@@ -1132,7 +1133,7 @@ extern "C" int nk_cg_update_dr_batch(int64_t n, int count, void* const* x, void*
   })
 }
 
-__global__ void k_cg_roll_b(NkPtrs scals) { nk_roll_scalars((double*)scals.p[blockIdx.x]); }
+__global__ void k_cg_roll_b(NkPtrs scals, int roll) { nk_roll_scalars((double*)scals.p[blockIdx.x], roll); }
 
 extern "C" int nk_cg_direction_batch(int64_t n, int count, void* const* d, const void* const* r, int dtype, double* const* scal,
                                      int roll, void* stream) {
@@ -1150,7 +1151,7 @@ extern "C" int nk_cg_direction_batch(int64_t n, int count, void* const* d, const
   if (rc != NK_OK || !roll) return rc;
   NkPtrs pp;
   for (int m = 0; m < NK_MAX_BATCH; ++m) pp.p[m] = scal[m < count ? m : 0];
-  hipLaunchKernelGGL(k_cg_roll_b, dim3(count), dim3(1), 0, st, pp);
+  hipLaunchKernelGGL(k_cg_roll_b, dim3(count), dim3(1), 0, st, pp, roll);
   return nk_check_launch("k_cg_roll_b");
 }
 
@@ -1747,26 +1748,46 @@ extern "C" int nk_csr_rowsum(int64_t nrows, const int64_t* rowptr, const int32_t
   })
 }
 
-template <typename T, int LANES>
+// One thread (group) walks ITS row's entries once and gathers from every member's x: the row pointers, column indices and
+// weights are read once per launch instead of once per member (short rows -- the bin sums of a static index map, a few
+// entries each -- spend most of their bytes on that index).  Per member the additions run in the order of k_csr_rowsum: the
+// same bits.  MB = members handled by one launch slice (compile-time, the tail slice zero-pads).
+template <typename T, int LANES, int MB>
 __global__ void __launch_bounds__(256) k_csr_rowsum_b(int64_t nrows, const int64_t* __restrict__ rowptr,
                                                       const int32_t* __restrict__ col, const float* __restrict__ wgt, NkPtrs xs,
-                                                      NkPtrs ys) {
-  const T* __restrict__ x = (const T*)xs.p[blockIdx.y];
-  T* __restrict__ y = (T*)ys.p[blockIdx.y];
+                                                      NkPtrs ys, int count) {
+  const int m0 = blockIdx.y * MB;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = gid / LANES;
   const int lane = (int)(gid % LANES);
   int64_t lo = 0, hi = 0;
   if (row < nrows) lo = rowptr[row], hi = rowptr[row + 1];
-  double acc = 0.0;
+  double acc[MB];
+#pragma unroll
+  for (int k = 0; k < MB; ++k) acc[k] = 0.0;
+  // (two loops, written like k_csr_rowsum's: the weighted one contracts to the same fused multiply-add)
   if (wgt) {
-    for (int64_t j = lo + lane; j < hi; j += LANES) acc += (double)wgt[j] * (double)x[col[j]];
+    for (int64_t j = lo + lane; j < hi; j += LANES) {
+      const int32_t c = col[j];
+      const double w = (double)wgt[j];
+#pragma unroll
+      for (int k = 0; k < MB; ++k)
+        if (m0 + k < count) acc[k] += w * (double)((const T*)xs.p[m0 + k])[c];
+    }
   } else {
-    for (int64_t j = lo + lane; j < hi; j += LANES) acc += (double)x[col[j]];
+    for (int64_t j = lo + lane; j < hi; j += LANES) {
+      const int32_t c = col[j];
+#pragma unroll
+      for (int k = 0; k < MB; ++k)
+        if (m0 + k < count) acc[k] += (double)((const T*)xs.p[m0 + k])[c];
+    }
   }
 #pragma unroll
-  for (int off = LANES / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, LANES);
-  if (lane == 0 && row < nrows) y[row] = (T)acc;
+  for (int k = 0; k < MB; ++k) {
+#pragma unroll
+    for (int off = LANES / 2; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off, LANES);
+    if (lane == 0 && row < nrows && m0 + k < count) ((T*)ys.p[m0 + k])[row] = (T)acc[k];
+  }
 }
 template <typename T, int LANES>
 static int nk_launch_rowsum_b(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, int count,
@@ -1775,7 +1796,15 @@ static int nk_launch_rowsum_b(int64_t nrows, const int64_t* rowptr, const int32_
   if (blocks > 0x7fffffffLL) return nk_set_error(NK_ERR_UNSUPPORTED, "nk_csr_rowsum_batch: too many rows for one launch");
   NkPtrs xs, ys;
   for (int m = 0; m < NK_MAX_BATCH; ++m) xs.p[m] = const_cast<void*>(x[m < count ? m : 0]), ys.p[m] = y[m < count ? m : 0];
-  hipLaunchKernelGGL((k_csr_rowsum_b<T, LANES>), dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, st, nrows, rowptr, col, wgt, xs, ys);
+  // short rows (one lane per row: bin sums) take four members per thread; long rows keep one member per grid row (their time
+  // is the gather itself, and four accumulators per lane would only cost registers)
+  if constexpr (LANES == 1) {
+    hipLaunchKernelGGL((k_csr_rowsum_b<T, LANES, 4>), dim3((unsigned)blocks, (unsigned)((count + 3) / 4)), dim3(256), 0, st, nrows,
+                       rowptr, col, wgt, xs, ys, count);
+  } else {
+    hipLaunchKernelGGL((k_csr_rowsum_b<T, LANES, 1>), dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, st, nrows, rowptr, col,
+                       wgt, xs, ys, count);
+  }
   return nk_check_launch("k_csr_rowsum_b");
 }
 
