@@ -188,7 +188,10 @@ int nk_hartley_sandwich(const nk_plan* plan, const nk_fuse* fuse, double scale_f
  * B's read-modify-write of `out` meets A's lines in L2 instead of HBM.  Same arithmetic, same bits as
  * nk_hartley_sandwich(A) followed by nk_hartley_sandwich(B).  Requirements: 3-D plan, both epilogues VJP with octant
  * amplitude fields (field_octant, afield), fuse_b->accumulate != 0, fuse_a->out == fuse_b->out, separate w8 (and w8max, value)
- * areas, the same mul_scalar, no slab pipelining, workspace_a != workspace_b (each nk_plan_workspace_bytes). */
+ * areas, the same mul_scalar, no slab pipelining, workspace_a != workspace_b (each nk_plan_workspace_bytes).
+ * (Or fuse_b->carry1 == fuse_a->out with a different fuse_b->out: B joins A's fresh lines as its innermost partial sum.  A
+ * build with -DNK_PAIR_HAND_BUILD=1 run with NK_PAIR_HAND=1 hands A's lines to B inside the workgroup and then leaves A's
+ * `out` unwritten in this form; the product build always stores it.) */
 int nk_hartley_sandwich_pair(const nk_plan* plan, const nk_fuse* fuse_a, const nk_fuse* fuse_b, double scale_first,
                              int convention, void* workspace_a, void* workspace_b, void* stream);
 /* complex-to-complex: in/out interleaved (re,im) of the plan dtype; inverse != 0 uses exp(+i..);

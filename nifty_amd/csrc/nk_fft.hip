@@ -33,18 +33,6 @@ __device__ __forceinline__ void nk_run_stages(C2<T>* lds, int tid, int nthr, con
   }
 }
 
-// maximum of |w8| (octant sums of the VJP epilogue) of this wavefront -> its slot; folded by the library afterwards
-__device__ __forceinline__ void nk_flush_wmax(const NkFuse& f, float wmax) {
-#ifdef NK_WMAX_OFF
-  return;
-#endif
-  if (f.w8max == nullptr || f.w8 == nullptr || f.epi != NK_EPI_VJP || f.value_slots <= 0) return;
-  for (int off = 32; off > 0; off >>= 1) wmax = nk_wmax_join(wmax, __shfl_down(wmax, off, 64));  // NaN / inf survive
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t slot = (int64_t)blockIdx.x * ((blockDim.x + 63) >> 6) + wave;
-  if (lane == 0 && slot < f.value_slots) f.w8max[slot] = (double)wmax;
-}
-
 // generic LDS kernels: any thread count works (loops stride by blockDim.x).  fp64 is capped at 512 threads so that the
 // compiler may use 256 VGPRs -- with the default 1024-thread bound (128 VGPRs) every fp64 kernel spilled 52-68 B / lane
 template <typename T>
@@ -247,55 +235,6 @@ static int nk_dispatch_final3(int nl, const NkPassF& pf, const NkFuse& f, const 
 #undef NK_CASE
   }
   return nk_set_error(NK_ERR_UNSUPPORTED, "no fast final pass for this length");
-}
-
-// TWO sandwich final passes (scatter class, row-mirror pairing) in ONE launch: every workgroup runs the final pass of its
-// line pairs for sample A and then for sample B, whose epilogue accumulates onto the output lines the same workgroup has
-// just written -- B's read of `out` and A's write of it stay in L2 instead of costing an HBM read and write of the whole
-// array per extra sample (nk_hartley_sandwich_pair).  Two inlined bodies, no loop around the phases.
-template <typename T, int NL>
-__global__ void __launch_bounds__((FinalTile<T, NL, 2, 2>::THREADS), (FinalTile<T, NL, 2, 2>::THREADS > 256 ? 1 : 3))
-    k2_final2(NkPassF p, NkFuse fa, NkFuse fb, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ worka,
-              const C2<T>* __restrict__ workb) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  DeviceExec<T, SchedF<T, NL>::E> ex;
-  const int64_t blk = (int64_t)blockIdx.x;
-  fa.pipe_chunks = -1;  // A's output lines are read again by B below: keep them in the cache hierarchy (FinalCt::keep)
-  {
-    double acc = 0.0;
-    float wmax = 0.0f;
-    nk_final_body<T, NL, FinalTile<T, NL, 2, 2>::TILE, true, 2, 1>(ex, p, fa, blk, (T*)smem, tw, worka, &acc, &wmax);
-    nk_flush_energy(fa, acc, smem);
-    nk_flush_wmax(fa, wmax);
-  }
-  __syncthreads();  // A's output lines are written (and visible to this workgroup) before B's epilogue reads them
-  {
-    double acc = 0.0;
-    float wmax = 0.0f;
-    nk_final_body<T, NL, FinalTile<T, NL, 2, 2>::TILE, true, 2, 1>(ex, p, fb, blk, (T*)smem, tw, workb, &acc, &wmax);
-    nk_flush_energy(fb, acc, smem);
-    nk_flush_wmax(fb, wmax);
-  }
-}
-
-template <typename T, int NL>
-static int nk_launch_final_pair(NkPassF pf, const NkFuse& fa, const NkFuse& fb, const C2<T>* tw, const C2<T>* worka,
-                                const C2<T>* workb, hipStream_t st) {
-  using CT = FinalTile<T, NL, 2, 2>;
-  auto kern = k2_final2<T, NL>;
-  static unsigned long long attr_mask = 0;  // per-device attribute
-  if (CT::LDS_BYTES > 64 * 1024 && nk_first_on_device(attr_mask)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CT::LDS_BYTES);
-    if (e != hipSuccess) return nk_set_hip_error(e, "hipFuncSetAttribute(k2_final2)");
-  }
-  pf.tiles_per_a = (pf.A > 1 && CT::TILE >= 2) ? (pf.M / 2 + 1 + CT::TILE / 2 - 1) / (CT::TILE / 2) : (pf.M + CT::TILE - 1) / CT::TILE;
-  pf.blk0 = 0;
-  const int64_t blocks = (int64_t)pf.g.batch * (pf.A / 2 + 1) * pf.tiles_per_a;
-  const int64_t waves = blocks * ((CT::THREADS + 63) / 64);
-  if ((fa.value_slots > 0 && waves > fa.value_slots) || (fb.value_slots > 0 && waves > fb.value_slots))
-    return nk_set_error(NK_ERR_RUNTIME, "final pass: more wavefronts than reduction slots (nk_value_slot_count)");
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(CT::THREADS), CT::LDS_BYTES, st, pf, fa, fb, tw, worka, workb);
-  return nk_check_launch("k2_final2");
 }
 
 template <typename T>

@@ -853,9 +853,10 @@ struct FinalCt {
   T sc, off, asc;
   bool accum, dot;  // dot: also accumulate sum addend[o] * out[o] (the CG curvature d.(A d) when addend = d)
   bool keep;        // `out` is read again right away (first sample of a pair launch, k2_final2): plain stores, not streaming ones
+  T* stash;         // pair launch with the hand-over in LDS (STASH != 0 below): this group's [NH][4][NL/2 + 1] values
 };
 template <typename T, int EC>
-NK_HD FinalCt<T> nk_final_ct(const NkFuse& f) {
+NK_HD FinalCt<T> nk_final_ct(const NkFuse& f, T* stash = nullptr) {
   FinalCt<T> c;
   c.out = (T*)f.out;
   c.mul = (const T*)f.mul;
@@ -870,6 +871,7 @@ NK_HD FinalCt<T> nk_final_ct(const NkFuse& f) {
   c.accum = f.accumulate != 0;
   c.dot = EC == 2 && f.value != nullptr && f.addend != nullptr;
   c.keep = f.pipe_chunks < 0;  // host-side field otherwise; k2_final2 marks its first sample with -1
+  c.stash = stash;
   return c;
 }
 
@@ -893,8 +895,13 @@ template <typename T>
 struct NkVjpOps {
   T x[4], d[4], o[4], p[4], q[4];  // xi, addend, running sum, carry1, carry2
 };
-template <typename T, bool BOTH, int MODE>
-NK_HD NkVjpOps<T> nk_final_vjp_load(const FinalCt<T>& c, int64_t ok, int64_t om, int k2, int k2m) {
+// STASH (pair launch k2_final2, both samples run by the same threads on the same coefficients): 1 = sample A, whose output
+// values go to the slot's LDS stash st[image * nkp] INSTEAD of memory; 2 / 3 = sample B, which takes them from there as its
+// running sum (2: one shared `out`) or as its innermost partial sum carry1 (3) -- A's lines never travel to HBM and back.
+// The values are the stored ones (rounded to T): the same bits as through memory.
+template <typename T, bool BOTH, int MODE, int STASH = 0>
+NK_HD NkVjpOps<T> nk_final_vjp_load(const FinalCt<T>& c, int64_t ok, int64_t om, int k2, int k2m, const T* st = nullptr,
+                                    int nkp = 0) {
   NkVjpOps<T> v;
   const bool add = MODE < 0 ? c.addend != nullptr : (MODE & 1) != 0;
   const bool run = MODE < 0 ? c.accum : (MODE & 2) != 0;
@@ -904,26 +911,35 @@ NK_HD NkVjpOps<T> nk_final_vjp_load(const FinalCt<T>& c, int64_t ok, int64_t om,
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const bool on = BOTH || i < 2;
-    v.p[i] = (on && k1) ? c.c1[at[i]] : (T)0;
+    if constexpr (STASH == 3)
+      v.p[i] = on ? st[i * nkp] : (T)0;
+    else
+      v.p[i] = (on && k1) ? c.c1[at[i]] : (T)0;
     v.q[i] = (on && k2nd) ? c.c2[at[i]] : (T)0;
     if constexpr ((NK_NT_LOAD & 8) != 0) {
       v.x[i] = on ? nk_ld_stream(c.xi + at[i]) : (T)0;
       v.d[i] = (on && add) ? nk_ld_stream(c.addend + at[i]) : (T)0;
-      v.o[i] = (on && run) ? nk_ld_stream(c.out + at[i]) : (T)0;
+      if constexpr (STASH == 2)
+        v.o[i] = on ? st[i * nkp] : (T)0;
+      else
+        v.o[i] = (on && run) ? nk_ld_stream(c.out + at[i]) : (T)0;
     } else {
       v.x[i] = on ? c.xi[at[i]] : (T)0;
       v.d[i] = (on && add) ? c.addend[at[i]] : (T)0;
-      v.o[i] = (on && run) ? c.out[at[i]] : (T)0;
+      if constexpr (STASH == 2)
+        v.o[i] = on ? st[i * nkp] : (T)0;
+      else
+        v.o[i] = (on && run) ? c.out[at[i]] : (T)0;
     }
   }
   return v;
 }
 // returns the fp64 bin-sum contribution sum_images xi * t
-template <typename T, bool BOTH, int MODE>
+template <typename T, bool BOTH, int MODE, int STASH = 0>
 NK_HD double nk_final_vjp_apply(const FinalCt<T>& c, const NkVjpOps<T>& v, int64_t ok, int64_t om, bool self, T v0, T v1,
-                                T v2, T v3, int k2, int k2m, T a, double& acc) {
+                                T v2, T v3, int k2, int k2m, T a, double& acc, T* st = nullptr, int nkp = 0) {
   const T t[4] = {v0 * c.sc, v1 * c.sc, v2 * c.sc, v3 * c.sc};
-  const bool k1 = MODE < 0 ? c.c1 != nullptr : (MODE & 4) != 0;
+  const bool k1 = STASH == 3 || (MODE < 0 ? c.c1 != nullptr : (MODE & 4) != 0);
   const bool k2nd = MODE < 0 ? c.c2 != nullptr : (MODE & 8) != 0;
   T r[4];
 #pragma unroll
@@ -945,21 +961,23 @@ NK_HD double nk_final_vjp_apply(const FinalCt<T>& c, const NkVjpOps<T>& v, int64
   }
   T* outk = c.out + ok;
   T* outm = c.out + om;
-  auto put = [&](T* p, T val) {
-    if (c.keep)
+  auto put = [&](T* p, T val, int image) {
+    if constexpr (STASH == 1)
+      st[image * nkp] = val;
+    else if (c.keep)
       *p = val;
     else
       nk_store_stream_s(p, val);
   };
-  put(outk + k2, r[0]);
-  if (BOTH) put(outk + k2m, r[2]);
+  put(outk + k2, r[0], 0);
+  if (BOTH) put(outk + k2m, r[2], 2);
   double s = (double)v.x[0] * (double)t[0];
   if (BOTH) s += (double)v.x[2] * (double)t[2];
   if (!self) {
-    put(outm + k2m, r[1]);
+    put(outm + k2m, r[1], 1);
     s += (double)v.x[1] * (double)t[1];
     if (BOTH) {
-      put(outm + k2, r[3]);
+      put(outm + k2, r[3], 3);
       s += (double)v.x[3] * (double)t[3];
     }
   }
@@ -1022,10 +1040,11 @@ NK_HD double nk_final_slot(const NkFuse& f, const FinalCt<T>& c, int64_t ok, int
 
 // EC 2: all slots of a group for the coefficients k2[0 .. n_on-1] (k2[u >= n_on] repeat a valid one: loaded, not applied) --
 // the loads of all U coefficients ahead of the first store
-template <typename T, int NL, int NH, bool BOTH, int MODE, int U>
+template <typename T, int NL, int NH, bool BOTH, int MODE, int U, int STASH = 0>
 NK_HD void nk_final_vjp_coeffs(const NkFuse& f, const FinalCt<T>& c, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg,
                                const int (&k2s)[U], int n_on, int hv, const T* afline, double* w8line, double& acc,
                                float& wmax) {
+  constexpr int NKP = NL / 2 + 1;  // stash: [NH][4 images][NKP] per group
   NkVjpOps<T> ops[U][NH];
   T a[U];
 #pragma unroll
@@ -1034,7 +1053,12 @@ NK_HD void nk_final_vjp_coeffs(const NkFuse& f, const FinalCt<T>& c, const Final
     a[u] = afline[k2];
 #pragma unroll
     for (int h = 0; h < NH; ++h)
-      if (MODE >= 0 || gp.mlo[h]) ops[u][h] = nk_final_vjp_load<T, BOTH, MODE>(c, gp.okh[h], gp.omh[h], k2, k2m);
+      if (MODE >= 0 || gp.mlo[h]) {
+        if constexpr (STASH >= 2)
+          ops[u][h] = nk_final_vjp_load<T, BOTH, MODE, STASH>(c, gp.okh[h], gp.omh[h], k2, k2m, c.stash + h * 4 * NKP + k2, NKP);
+        else
+          ops[u][h] = nk_final_vjp_load<T, BOTH, MODE>(c, gp.okh[h], gp.omh[h], k2, k2m);
+      }
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -1047,8 +1071,13 @@ NK_HD void nk_final_vjp_coeffs(const NkFuse& f, const FinalCt<T>& c, const Final
       if (MODE < 0 && !gp.mlo[h]) continue;
       const T fx = pre[gp.base[h] + d1], fy = pim[gp.base[h] + d1];
       const T gx = pre[gp.base[h] + d2], gy = pim[gp.base[h] + d2];
-      ssum += nk_final_vjp_apply<T, BOTH, MODE>(c, ops[u][h], gp.okh[h], gp.omh[h], gp.mlo[h] == 1, fx + sg * fy, fx - sg * fy,
-                                          gx + sg * gy, gx - sg * gy, k2, k2m, a[u], acc);
+      if constexpr (STASH != 0)
+        ssum += nk_final_vjp_apply<T, BOTH, MODE, STASH>(c, ops[u][h], gp.okh[h], gp.omh[h], gp.mlo[h] == 1, fx + sg * fy,
+                                                         fx - sg * fy, gx + sg * gy, gx - sg * gy, k2, k2m, a[u], acc,
+                                                         c.stash + h * 4 * NKP + k2, NKP);
+      else
+        ssum += nk_final_vjp_apply<T, BOTH, MODE>(c, ops[u][h], gp.okh[h], gp.omh[h], gp.mlo[h] == 1, fx + sg * fy, fx - sg * fy,
+                                                  gx + sg * gy, gx - sg * gy, k2, k2m, a[u], acc);
     }
     if (w8line) {
       w8line[k2] = ssum;
@@ -1096,12 +1125,12 @@ NK_HD void nk_final_lh_coeffs(const NkFuse& f, const FinalGroup<NH>& gp, const T
 }
 
 // all slots of a group for coefficient k2
-template <typename T, int NL, int NH, int EC, bool BOTH, int MODE = -1>
+template <typename T, int NL, int NH, int EC, bool BOTH, int MODE = -1, int STASH = 0>
 NK_HD void nk_final_coeff(const NkFuse& f, const FinalCt<T>& c, const FinalGroup<NH>& gp, const T* pre, const T* pim, T sg,
                           int k2, int hv, const T* afline, double* w8line, double& acc, float& wmax) {
   if constexpr (EC == 2) {
     const int one[1] = {k2};
-    nk_final_vjp_coeffs<T, NL, NH, BOTH, MODE, 1>(f, c, gp, pre, pim, sg, one, 1, hv, afline, w8line, acc, wmax);
+    nk_final_vjp_coeffs<T, NL, NH, BOTH, MODE, 1, STASH>(f, c, gp, pre, pim, sg, one, 1, hv, afline, w8line, acc, wmax);
   } else {
     const int k2m = (NL - k2) & (NL - 1);
     const int d1 = k2 + (k2 >> 5), d2 = k2m + (k2m >> 5);
@@ -1149,10 +1178,11 @@ struct NkPassF {
 //        G_c(k) = X(k, c) + i X(-k, NL - c),  X(-k, c) = conj X(k, c)   (x real)
 //      =>  2 X(k, c)      = G_c(k) + conj G_c(-k)                  c = 0 .. NL/2
 //          2 X(k, NL - c) = conj( (G_c(k) - conj G_c(-k)) / i )    c = 1 .. NL/2 - 1
-template <typename T, int NL, int TILE, bool COUPLES, int EC, int PAIR = 0, typename Exec>
+// STASH / stash: see nk_final_vjp_load (k2_final2 only; TILE * 4 * (NL/2 + 1) values behind the planes)
+template <typename T, int NL, int TILE, bool COUPLES, int EC, int PAIR = 0, int STASH = 0, typename Exec>
 NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t blk, T* planes,
                          const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, double* acc_out,
-                         float* wmax_out = nullptr) {
+                         float* wmax_out = nullptr, T* stash = nullptr) {
   // the line FFT runs on 2A / 2B (see the load phase): fold the 1/2 into the output scale every epilogue applies first
   NkFuse f = f_in;
   f.scale = 0.5 * f_in.scale;
@@ -1332,7 +1362,7 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
     }
     if constexpr (EC >= 0) {
       if (any) {
-        const FinalCt<T> c = nk_final_ct<T, EC>(f);
+        const FinalCt<T> c = nk_final_ct<T, EC>(f, STASH != 0 ? stash + u * (NH * 4 * (NL / 2 + 1)) : nullptr);
         int hv = 0;
 #pragma unroll
         for (int h = NH - 1; h >= 0; --h)
@@ -1345,7 +1375,7 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
         auto coefficients = [&](auto mode_c) {
           constexpr int MODE = decltype(mode_c)::value;
           if (lane < 2)
-            nk_final_coeff<T, NL, NH, EC, false, MODE>(f, c, gp, pre, pim, sg, lane ? NL / 2 : 0, hv, afline, w8line, acc, wmax);
+            nk_final_coeff<T, NL, NH, EC, false, MODE, STASH>(f, c, gp, pre, pim, sg, lane ? NL / 2 : 0, hv, afline, w8line, acc, wmax);
           if constexpr (nk_ec_lh<EC>() && MODE > 0) {
             constexpr int U = sizeof(T) == 8 ? (NK_LH_UNROLL + 1) / 2 : NK_LH_UNROLL;  // fp64: 168 VGPRs + 116 B / lane of spills with four
             for (int k2 = 1 + lane; k2 < NL / 2; k2 += U * tps) {
@@ -1370,11 +1400,11 @@ NK_HD void nk_final_body(Exec& ex, const NkPassF& p, const NkFuse& f_in, int64_t
                 ks[u] = on ? k : k2;
                 n_on += on;
               }
-              nk_final_vjp_coeffs<T, NL, NH, true, MODE, U>(f, c, gp, pre, pim, sg, ks, n_on, hv, afline, w8line, acc, wmax);
+              nk_final_vjp_coeffs<T, NL, NH, true, MODE, U, STASH>(f, c, gp, pre, pim, sg, ks, n_on, hv, afline, w8line, acc, wmax);
             }
           } else {
             for (int k2 = 1 + lane; k2 < NL / 2; k2 += tps)
-              nk_final_coeff<T, NL, NH, EC, true, MODE>(f, c, gp, pre, pim, sg, k2, hv, afline, w8line, acc, wmax);
+              nk_final_coeff<T, NL, NH, EC, true, MODE, STASH>(f, c, gp, pre, pim, sg, k2, hv, afline, w8line, acc, wmax);
           }
         };
         if constexpr (EC == 2) {  // see nk_final_vjp_load

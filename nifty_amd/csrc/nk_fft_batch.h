@@ -8,6 +8,9 @@
 #ifndef NK_S0_WAVES
 #define NK_S0_WAVES 1
 #endif
+#ifndef NK_PAIR_HAND_LDS_KB
+#define NK_PAIR_HAND_LDS_KB 64  // k2_final2 hands A's lines to B through LDS while planes + stash fit this (nk_fft_p.hip)
+#endif
 #ifndef NK_S1_TWO_WG
 #define NK_S1_TWO_WG 0
 #endif
@@ -36,6 +39,18 @@ __device__ __forceinline__ void nk_flush_energy(const NkFuse& f, double acc, voi
     for (int w = 0; w < nw; ++w) s += red[w];
     atomicAdd(f.value, s);
   }
+}
+
+// maximum of |w8| (octant sums of the VJP epilogue) of this wavefront -> its slot; folded by the library afterwards
+__device__ __forceinline__ void nk_flush_wmax(const NkFuse& f, float wmax) {
+#ifdef NK_WMAX_OFF
+  return;
+#endif
+  if (f.w8max == nullptr || f.w8 == nullptr || f.epi != NK_EPI_VJP || f.value_slots <= 0) return;
+  for (int off = 32; off > 0; off >>= 1) wmax = nk_wmax_join(wmax, __shfl_down(wmax, off, 64));  // NaN / inf survive
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t slot = (int64_t)blockIdx.x * ((blockDim.x + 63) >> 6) + wave;
+  if (lane == 0 && slot < f.value_slots) f.w8max[slot] = (double)wmax;
 }
 
 
@@ -87,3 +102,8 @@ template <typename T, int N, int PC>
 int nk_twin_launch_strided(const NkPassS& ps, int64_t blocks, const C2<T>* tw, int xmap, hipStream_t st);
 template <typename T, int NL, bool COUPLES, int EC>
 int nk_twin_launch_final(const NkPassF& pf, int64_t blocks, const C2<T>* tw, int xmap, hipStream_t st);
+
+// nk_hartley_sandwich_pair's final-pass launch (k2_final2): defined and explicitly instantiated in nk_fft_p.hip
+template <typename T, int NL>
+int nk_launch_final_pair(NkPassF pf, const NkFuse& fa, const NkFuse& fb, const C2<T>* tw, const C2<T>* worka, const C2<T>* workb,
+                         hipStream_t st);
