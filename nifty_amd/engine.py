@@ -540,6 +540,12 @@ class FusedModel:
             # every transform of a metric application stay fp32 (their error is not amplified: 1e-7).  NK_WIDE_FORWARD=0: the
             # all-fp32 evaluation, for A/B.
             self.wide = (dtype == torch.float32 and self.octant_vjp and os.environ.get("NK_WIDE_FORWARD", "1") != "0")
+            # ... and on grids WITHOUT the register-resident pipeline (mixed radix, short axes) the same transform runs on the
+            # generic fp64 plan with fp64 COPIES at both ends (xi widened, residual and metric weight rounded back): four
+            # N x 8-byte arrays more, three extra streaming passes -- next to generic kernels at a third of the fast
+            # path's bandwidth
+            self.wide_generic = (dtype == torch.float32 and not self.octant_vjp
+                                 and os.environ.get("NK_WIDE_FORWARD", "1") != "0")
             self._wide_state = None
             # plans WITHOUT the octant pipeline (mixed-radix grids, short axes): the generic kernels deposit xi . t per grid
             # point in a full-grid fp64 array (nk_fuse.wfull) that is summed bin by bin in a fixed order -- instead of fp64
@@ -559,7 +565,7 @@ class FusedModel:
             if int(response.n_pix) != self.N:
                 raise ValueError("response does not act on this grid")
             self.sandwich = self.fused_direction = False  # the middle of J^T M J is not diagonal in position space
-            self.wide = False  # (the likelihood lives behind the response: no likelihood epilogue to widen)
+            self.wide = self.wide_generic = False  # (the likelihood lives behind the response: no likelihood epilogue to widen)
         if data is not None:
             self.set_data(data, icov)
         self.counters = dict(value_grad=0, metric=0, transforms=0, cg_iterations=0)
@@ -584,6 +590,11 @@ class FusedModel:
                 self.icov_field = torch.as_tensor(icov).to(self.tdtype).to(self.device).contiguous()
         self.const_mid = (self.lh_kind == L.LH_GAUSS and self.nonlin == L.NL_ID and self.icov_field is None
                           and self.response is None)
+        # (static operands of the generic wide forward transform, shared by the lanes)
+        self._data64 = self._icov64 = None
+        if self.wide_generic and self.lh_kind == L.LH_GAUSS:
+            self._data64 = self.data.double()
+            self._icov64 = None if self.icov_field is None else self.icov_field.double()
         # data-space metric weight of a Gaussian with scalar N^-1: a number, not a field (response models)
         self.const_wd = self.lh_kind == L.LH_GAUSS and self.icov_field is None
 
@@ -763,6 +774,18 @@ class FusedModel:
             plan64, afield64, dense64 = self._wide_buffers()
             f.afield, f.io32 = self._amp_field(lp.amp, out=afield64, dense=dense64).data_ptr(), 1
             B.hartley_fused(plan64, f)
+        elif self.wide_generic:
+            # the same on the generic fp64 plan: xi widened, a(k) gathered from the fp64 table, fp64 likelihood operands;
+            # the residual gradient and the metric weight come back rounded to the field type
+            plan64, xi64, gs64, mid64 = self._wide_generic_buffers(lp.mid is not None)
+            xi64.copy_(x.xi)
+            f.in_, f.afield, f.out, f.out2 = xi64.data_ptr(), None, gs64.data_ptr(), B.ptr(mid64)
+            if self.lh_kind == L.LH_GAUSS:
+                f.data, f.icov = self._data64.data_ptr(), B.ptr(self._icov64)
+            B.hartley_fused(plan64, f)
+            gs.copy_(gs64)
+            if lp.mid is not None:
+                lp.mid.copy_(mid64)
         else:
             B.hartley_fused(self.plan, f)
         self._count("transforms", 1)
@@ -810,6 +833,19 @@ class FusedModel:
             dense64 = None if self.k2_dense is None else torch.zeros_like(self.k2_dense, dtype=torch.float64)
             self._wide_state = (plan64, afield64, dense64)
         return self._wide_state
+
+    def _wide_generic_buffers(self, with_mid):
+        """fp64 plan and the fp64 copies at both ends of the wide forward transform on a grid without the register-resident
+        pipeline (`wide_generic`), created at the first value / gradient evaluation."""
+        if self._wide_state is None:
+            plan64 = B.get_plan(self.shape, torch.float64, 1, self.device)
+            if self.stream is not None:  # a lane: the cached plan's workspace belongs to the main chain
+                plan64 = B.PlanView(plan64)
+            xi64, gs64 = (torch.empty(self.shape, dtype=torch.float64, device=self.device) for _ in range(2))
+            self._wide_state = [plan64, xi64, gs64, None]
+        if with_mid and self._wide_state[3] is None:
+            self._wide_state[3] = torch.empty(self.shape, dtype=torch.float64, device=self.device)
+        return self._wide_state[0], self._wide_state[1], self._wide_state[2], self._wide_state[3] if with_mid else None
 
     def _finish_linearize(self, lp, x, gs, gs2, grad_acc, w, value, lhval):
         """Gradient J^T (gs * gs2) + x and the value lh + 1/2 x.x, accumulated with weight w (grad_acc: a LatentVec that

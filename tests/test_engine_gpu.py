@@ -141,6 +141,7 @@ def test_geovi_energy_vs_oracle(shape):
                                                ((32, 16, 64), "gaussian", "sigmoid"), ((64, 64, 64), "gaussian", None),
                                                # non-power-of-two grids (mixed radix 2/3/5/7, generic kernels)
                                                ((30, 50), "gaussian", None), ((12, 10, 14), "poisson", "exp"),
+                                               ((768, 768), "gaussian", None), ((96, 160, 96), "gaussian", "sigmoid"),
                                                # strided-first pipeline with unequal axes
                                                ((128, 64, 256), "gaussian", None),
                                                # long last axis: the final pass runs its smallest tiles (one line pair
@@ -181,10 +182,14 @@ def test_engine_vs_oracle_seeded(shape, kind, nonlin, dtype):
     mv = lin.metric(v)
     xl, vl = LatentVec.from_dict(model, x), LatentVec.from_dict(model, v)
     lp = model.linearize(xl)
-    # fp32 fields: value + gradient within the 1e-5 of north_star (their forward transform runs in fp64, FusedModel.wide);
+    # fp32 fields: value + gradient within the 1e-5 of north_star on every grid (their forward transform runs in fp64:
+    # FusedModel.wide on the register-resident pipelines, FusedModel.wide_generic on mixed-radix grids and short axes);
     # a metric application is two fp32 transforms with a pointwise weight in between
-    # (grids without the register-resident pipeline -- mixed radix, short axes -- keep the all-fp32 evaluation)
-    tol, mtol = (1e-10, 1e-10) if dtype == torch.float64 else ((1e-5 if model.wide else 2e-4), 2e-4)
+    if dtype == torch.float32:
+        assert model.wide or model.wide_generic
+    # (12 x 10 x 14 Poisson: 1.8e-5 -- the residual lambda - d cancels, and on 1680 points the fp32 ADJOINT transform's rounding,
+    # relative to lambda, is not averaged down; the generic Gaussian cases and every register-resident case hold 1e-5)
+    tol, mtol = (1e-10, 1e-10) if dtype == torch.float64 else (1e-5 if (model.wide or kind == "gaussian") else 5e-5, 2e-4)
     e_val = abs(float(lp.value.item()) - val) / abs(val)
     e_grad, e_met = gl.lat_relerr(lp.grad.to_dict(), grad), gl.lat_relerr(model.metric(lp, vl).to_dict(), mv)
     print(f"{shape} {kind} {nonlin} {dtype}: value {e_val:.1e} gradient {e_grad:.1e} metric {e_met:.1e}")

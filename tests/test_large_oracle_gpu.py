@@ -227,3 +227,29 @@ def test_config2_full_size_against_the_oracle():
     e_s = gl.lat_relerr(res[0].to_dict(), ores[0])
     print(f"2048^2 fp64 Poisson MGVI sample vs oracle: {e_s:.2e}")
     assert e_s < 1e-7
+
+
+@pytest.mark.timeout(900)
+def test_fp32_fields_on_a_mixed_radix_grid_against_the_fp64_oracle(monkeypatch):
+    """A grid WITHOUT the register-resident pipeline (240 x 384 x 320: radices 2, 3, 5; generic kernels) with fp32 fields:
+    the forward transform of value / gradient runs on the generic fp64 plan with fp64 copies at both ends
+    (FusedModel.wide_generic), which brings the gradient inside the 1e-5 of north_star globally and per key -- A/B against the
+    all-fp32 evaluation (NK_WIDE_FORWARD=0) on the same inputs."""
+    from nifty_amd.engine import FusedModel
+
+    shape = (240, 384, 320)
+    cf, lh, x, v, data = _setup(shape, 23)
+    lin = orc.Linearized(cf, lh, x)
+    monkeypatch.setenv("NK_WIDE_FORWARD", "0")
+    narrow = FusedModel(shape, offset_mean=2.0, likelihood="gaussian", data=data, icov=100.0, dtype=torch.float32, device="cuda:0")
+    assert not narrow.octant_vjp and not narrow.wide_generic
+    n_val, n_grad, n_met, n_key = _errors(narrow, lin, x, v, "240x384x320 all-fp32")
+    del narrow
+    monkeypatch.setenv("NK_WIDE_FORWARD", "1")
+    wide = FusedModel(shape, offset_mean=2.0, likelihood="gaussian", data=data, icov=100.0, dtype=torch.float32, device="cuda:0")
+    assert wide.wide_generic and not wide.wide
+    w_val, w_grad, w_met, w_key = _errors(wide, lin, x, v, "240x384x320 wide forward")
+    print(f"240x384x320 fp32 gradient vs fp64 oracle: all-fp32 {n_grad:.2e} (per key {n_key:.2e}), wide forward {w_grad:.2e} "
+          f"(per key {w_key:.2e}); value {n_val:.2e} -> {w_val:.2e}; metric {w_met:.2e}")
+    assert w_val < 1e-10 and w_grad < 1e-5 and w_key < 1e-5 and w_met < 1e-5
+    assert n_key > 3 * w_key  # the coherent gain error of the fp32 forward transform
