@@ -137,7 +137,7 @@ __global__ void __launch_bounds__((StridedTile<T, N, nk_strided_cx<MODE, PC>(), 
 // and likelihood kernels spilled (fp64 512^3 affine pass 0.61 -> 0.42 ms without the spills)
 template <typename T, int NL, bool COUPLES, int EC, int PAIR>
 __global__ void __launch_bounds__((FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS),
-                                  (FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS > 256 ? 1 : ((!COUPLES && sizeof(T) == 4 && (EC == 0 || EC == 1)) ? 4 : 3)))
+                                  (nk_final_waves<T, COUPLES, EC, FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS>()))
     k2_final(NkPassF p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ work, int xmap) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, SchedF<T, NL>::E> ex;

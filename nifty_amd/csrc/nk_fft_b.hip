@@ -28,7 +28,7 @@ __global__ void __launch_bounds__((StridedTile<T, N, nk_strided_cx<MODE, PC>(), 
 
 template <typename T, int NL, bool COUPLES, int EC, int PAIR>
 __global__ void __launch_bounds__((FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS),
-                                  (FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS > 256 ? 1 : ((!COUPLES && sizeof(T) == 4 && (EC == 0 || EC == 1)) ? 4 : 3)))
+                                  (nk_final_waves<T, COUPLES, EC, FinalTile<T, NL, EC, COUPLES ? 2 : 1>::THREADS>()))
     k2_final_b(NkPassF p, NkFuseArr fa, const C2<T>* __restrict__ tw, NkWorkArr wa, int xmap) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, SchedF<T, NL>::E> ex;

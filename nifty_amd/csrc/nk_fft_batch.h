@@ -15,6 +15,16 @@
 #define NK_S1_TWO_WG 0
 #endif
 
+// Wavefronts per SIMD a final-pass kernel is compiled for (the second argument of __launch_bounds__ = its register budget:
+// 3 -> 168 VGPRs, 2 -> 256).  fp64 kernels on line couples keep 2 x TILE x PITCH x 8 bytes of planes with TILE >= 2: their
+// LDS admits two waves per SIMD whatever the register count, so a tighter budget only buys spills -- k2_final2<double,512>
+// 168 VGPRs + 184 spilled -> 234 + 0: 1.87 -> 1.54 ms per pair launch at 512^3 (round 5).  The fp32 pair kernel at 1024 is
+// the opposite case (six resident workgroups at 168 VGPRs beat four at 175: 51.9 vs 54.0 ms per four-sample application).
+template <typename T, bool COUPLES, int EC, int THREADS>
+constexpr int nk_final_waves() {
+  return THREADS > 256 ? 1 : (sizeof(T) == 8 && COUPLES) ? 2 : ((!COUPLES && sizeof(T) == 4 && (EC == 0 || EC == 1)) ? 4 : 3);
+}
+
 // fp64 sum of `acc` over the workgroup (only when the epilogue produces an energy).  With slots (set up by the library for
 // the final pass of the pipelines): every WAVEFRONT stores its partial sum to its own slot -- no LDS hop, no barrier at
 // the end of the kernel (a barrier there kept the workgroup's LDS and wave slots busy until its last wave arrived: 4 % of

@@ -37,15 +37,13 @@ struct PairTile {
   static constexpr bool HAND_OK = NK_PAIR_HAND_BUILD != 0 && LDS_HAND <= NK_PAIR_HAND_LDS_KB * 1024;
 };
 
-#ifndef NK_PAIR_WAVES
-#define NK_PAIR_WAVES 3
-#endif
 #ifndef NK_PAIR_HAND_WAVES
 #define NK_PAIR_HAND_WAVES 3  // wavefronts per SIMD the hand-over variants are compiled for
 #endif
 template <typename T, int NL, int HAND>
 __global__ void __launch_bounds__((FinalTile<T, NL, 2, 2>::THREADS),
-                                  (FinalTile<T, NL, 2, 2>::THREADS > 256 ? 1 : (HAND ? NK_PAIR_HAND_WAVES : NK_PAIR_WAVES)))
+                                  (HAND ? (FinalTile<T, NL, 2, 2>::THREADS > 256 ? 1 : NK_PAIR_HAND_WAVES)
+                                        : nk_final_waves<T, true, 2, FinalTile<T, NL, 2, 2>::THREADS>()))
     k2_final2(NkPassF p, NkFuse fa, NkFuse fb, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ worka,
               const C2<T>* __restrict__ workb) {
   extern __shared__ __align__(16) unsigned char smem[];
