@@ -108,6 +108,64 @@ def test_gather_and_rowsum_batches():
         assert torch.equal(y, B.bin_sum(o, plan))
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_short_row_sums_of_a_batch_for_every_member_count(dtype, weighted):
+    """nk_csr_rowsum_batch with ONE lane per row (short rows: the bin sums of a static index map) handles four members per
+    thread, the index read once (nk_vec.hip, k_csr_rowsum_b): every count 1 .. 8 -- full and ragged slices of four -- gives
+    the bits of `count` single nk_csr_rowsum launches, unweighted and with float weights (the fused multiply-add kept)."""
+    from nifty_amd import _lib as L
+    from nifty_amd import backend as B
+
+    lib = L.load()
+    nrows, ncols = 70001, 50000
+    g = torch.Generator(device=DEV).manual_seed(3)
+    counts = torch.randint(0, 6, (nrows,), device=DEV, generator=g)  # 0 .. 5 entries per row (empty rows included)
+    rowptr = torch.zeros(nrows + 1, dtype=torch.int64, device=DEV)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    nnz = int(rowptr[-1].item())
+    col = torch.randint(0, ncols, (nnz,), dtype=torch.int32, device=DEV, generator=g)
+    wgt = torch.rand(nnz, dtype=torch.float32, device=DEV, generator=g) if weighted else None
+    code = L.NK_F64 if dtype == torch.float64 else L.NK_F32
+    xs = [_rand(ncols, dtype, 10 + m) for m in range(8)]
+    single = []
+    for x in xs:
+        y = torch.empty(nrows, dtype=dtype, device=DEV)
+        L.check(lib.nk_csr_rowsum(nrows, rowptr.data_ptr(), col.data_ptr(), B.ptr(wgt), x.data_ptr(), y.data_ptr(), code, 1,
+                                  B._stream()), "nk_csr_rowsum")
+        single.append(y)
+    for count in range(1, 9):
+        ys = [torch.full((nrows,), float("nan"), dtype=dtype, device=DEV) for _ in range(count)]
+        L.check(lib.nk_csr_rowsum_batch(nrows, rowptr.data_ptr(), col.data_ptr(), B.ptr(wgt), count, L.ptr_array(xs[:count]),
+                                        L.ptr_array(ys), code, 1, B._stream()), "nk_csr_rowsum_batch")
+        for m in range(count):
+            assert torch.equal(ys[m], single[m]), (count, m)
+
+
+def test_roll_of_the_cg_scalars_can_clear_the_curvature_slot():
+    """nk_cg_direction(roll): 1 leaves scal[1] (the fused direction update rolls AFTER the next d.q was deposited), 2 clears
+    it as well (a caller that accumulates the next d.q afterwards: batched.solve_together) -- single and batched entry."""
+    from nifty_amd import _lib as L
+    from nifty_amd import backend as B
+
+    lib = L.load()
+    start = torch.tensor([4.0, 8.0, 2.0, 0.25, 0.125, 0.0, 0.0, 0.0], dtype=torch.float64, device=DEV)
+    for roll, slot1 in ((1, 8.0), (2, 0.0)):
+        sc = start.clone()
+        L.check(lib.nk_cg_direction(0, None, None, L.NK_F64, sc.data_ptr(), roll, B._stream()), "nk_cg_direction")
+        # gamma_prev <- gamma, alpha = 4 / 8, beta = 2 / 4, reduction slots cleared
+        assert sc.tolist() == [2.0, slot1, 0.0, 0.0, 0.0, 0.5, 0.5, 0.0]
+        rows = [start.clone() for _ in range(3)]
+        d = [_rand(4096, torch.float64, 40 + m) for m in range(3)]
+        r = [_rand(4096, torch.float64, 50 + m) for m in range(3)]
+        want = [0.5 * a + b for a, b in zip(d, r)]
+        L.check(lib.nk_cg_direction_batch(4096, 3, L.ptr_array(d), L.ptr_array(r), L.NK_F64, L.ptr_array(rows), roll,
+                                          B._stream()), "nk_cg_direction_batch")
+        for row, got, ref in zip(rows, d, want):
+            assert row.tolist() == [2.0, slot1, 0.0, 0.0, 0.0, 0.5, 0.5, 0.0]
+            assert torch.equal(got, ref)
+
+
 def test_amplitude_batches_equal_single_calls():
     from nifty_amd import _lib as L
     from nifty_amd import backend as B
