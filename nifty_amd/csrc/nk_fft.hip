@@ -125,9 +125,11 @@ __global__ void __launch_bounds__((StridedTile<T, N, nk_strided_cx<MODE, PC>(), 
   using ST = StridedTile<T, N, nk_strided_cx<MODE, PC>(), MODE>;
   DeviceExec<T, ST::SC::E> ex;
   double acc = 0.0;
-  // the octant prologues bring their own XCD-aware order (nk_oct_block_remap)
+  // the octant prologues bring their own XCD-aware order on 3-D grids (nk_oct_block_remap); in 2-D they take the
+  // XCD-contiguous one like every other class: neighbouring column tiles -- 64-byte row segments at 4096 fp64 -- on ONE XCD,
+  // whose L2 then fetches each 128-byte line once instead of two XCDs fetching it each
   constexpr bool OCT = MODE == 3 && (PC == 4 || PC == 5 || PC == 9);
-  const int64_t blk = (xmap && !OCT) ? nk_xcd_contig(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t blk = (xmap && (!OCT || p.g.ndim != 3)) ? nk_xcd_contig(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
   C2<T>* tw_lds = ST::TWLDS ? reinterpret_cast<C2<T>*>(smem + ST::LDS_BYTES) : nullptr;
   nk_strided_body<T, N, ST::TILE, MODE, PC, nk_strided_cx<MODE, PC>()>(ex, p, f, blk, (T*)smem, tw, work, scratch, &acc, tw_lds);
   (void)acc;

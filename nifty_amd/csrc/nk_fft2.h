@@ -456,6 +456,13 @@ NK_HD void nk_xread_c2(C2<T>* dst, const C2<T>* plane, int pp, int t) {
 // A bijection of [0, nblocks); placement only matters for speed.
 NK_HD int64_t nk_oct_block_remap(int64_t v, const NkPassS& p) {
   const int na = p.g.na, tiles = p.tiles_per_slab;
+  if (p.g.ndim == 2 && tiles % 2 == 0) {
+    // 2-D (the caller hands in the XCD-contiguous order): column tile j and its last-axis mirror tiles-1-j read the same
+    // columns of the octant fields -- run them back to back, 0, T-1, 1, T-2, ...; neighbouring tiles stay two steps apart
+    const int64_t bat = v / tiles;
+    const int u = (int)(v - bat * tiles);
+    return bat * tiles + ((u & 1) ? tiles - 1 - u / 2 : u / 2);
+  }
   if (p.g.ndim != 3 || (na / 2) % 8 != 0) return v;
   const int64_t per = (int64_t)na * tiles;
   const int64_t bat = v / per;

@@ -19,7 +19,7 @@ __global__ void __launch_bounds__((StridedTile<T, N, nk_strided_cx<MODE, PC>(), 
   double acc = 0.0;
   const int m = blockIdx.y;
   constexpr bool OCT = MODE == 3 && (PC == 4 || PC == 5 || PC == 9);
-  const int64_t blk = (xmap && !OCT) ? nk_xcd_contig(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t blk = (xmap && (!OCT || p.g.ndim != 3)) ? nk_xcd_contig(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
   C2<T>* tw_lds = ST::TWLDS ? reinterpret_cast<C2<T>*>(smem + ST::LDS_BYTES) : nullptr;
   nk_strided_body<T, N, ST::TILE, MODE, PC, nk_strided_cx<MODE, PC>()>(ex, p, fa.f[m], blk, (T*)smem, tw, (C2<T>*)wa.work[m],
                                                                        (C2<T>*)wa.scratch[m], &acc, tw_lds);
