@@ -367,6 +367,40 @@ def test_pair_final_pass_is_bit_identical(shape, dtype):
         assert results[0][2] == results[1][2]
 
 
+def test_fp32_fields_on_a_generic_grid_across_lanes(monkeypatch):
+    """fp32 fields on a mixed-radix grid (48 x 80: generic kernels): every lane of a KL evaluation owns its fp64 copies for
+    the wide forward transform (FusedModel.wide_generic; the Gaussian data in fp64 is shared) -- the lanes' sample sum agrees
+    with the one-stream evaluation to fp32 rounding of the sum, and a second evaluation reproduces the first bit for bit."""
+    from nifty_amd import random
+    from nifty_amd.engine import FusedKL, FusedModel, LatentVec, draw_samples
+    from nifty_amd.minimization import AbsDeltaEnergyController
+
+    shape = (48, 80)
+    rng = np.random.default_rng(8)
+    cf = orc.CFModel(shape, None, orc.CFParams(offset_mean=1.0))
+    x = {k: 0.2 * v for k, v in cf.draw_latent(rng).items()}
+    data = cf.forward(cf.draw_latent(rng)) + 0.1 * rng.normal(size=shape)
+    monkeypatch.setenv("NK_LANES", "0")
+    model = FusedModel(shape, offset_mean=1.0, dtype=torch.float32, device="cuda:0", likelihood="gaussian", data=data, icov=100.0)
+    assert model.wide_generic and not model.octant_vjp
+    xl = LatentVec.from_dict(model, x)
+    random.push_sseq_from_seed(12)
+    res, negs, _ = draw_samples(model, xl, 2, True, lambda: AbsDeltaEnergyController(0.05, iteration_limit=3))
+    random.pop_sseq()
+    ref = FusedKL(model, xl, res, negs)
+    assert len(ref._lanes) == 1
+    ref_g = ref.gradient.to_dict()
+    monkeypatch.setenv("NK_LANES", "4")
+    kl = FusedKL(model, xl, res, negs)
+    assert len(kl._lanes) == 4 and all(lane.wide_generic for lane in kl._lanes)
+    assert abs(kl.value - ref.value) < 1e-6 * abs(ref.value)
+    got = kl.gradient.to_dict()
+    for k in ref_g:
+        assert np.max(np.abs(got[k] - ref_g[k])) <= 1e-5 * max(np.max(np.abs(ref_g[k])), 1e-30)
+    again = FusedKL(model, xl, res, negs)
+    assert again.value == kl.value and all(np.array_equal(again.gradient.to_dict()[k], got[k]) for k in got)
+
+
 @pytest.mark.parametrize("shape,lh", [((128, 256), "poisson"), ((64, 64, 128), "gaussian")])
 def test_sample_lanes_agree_with_the_single_stream_path(shape, lh, monkeypatch):
     """Small grids: the chains of the local samples of a KL run side by side on several streams (FusedModel.lanes).  Same
