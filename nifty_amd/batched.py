@@ -38,7 +38,8 @@ def ready(model):
         small = model.N <= int(os.environ.get("NK_LANE_MAX_POINTS", str(1 << 25)))
         cached = bool(os.environ.get("NK_BATCH", "1") != "0" and small and model.octant_vjp and not model.sandwich
                       and model.pidx8 is not None and model.k2_dense is None and model.seg_plan is not None
-                      and model.full_plan is None and not model.wide and L.load().nk_plan_batch_ok(model.plan.handle))
+                      and model.full_plan is None and not (model.wide or model.wide_response)
+                      and L.load().nk_plan_batch_ok(model.plan.handle))
         model.__dict__["_batch_ready"] = cached
     return cached
 

@@ -560,12 +560,18 @@ class FusedModel:
         self.nonlin = _NONLIN[nonlin]
         self.icov_field, self.icov_scalar = None, 1.0
         self.response = response
+        self.wide_response = False
         self.data_shape = self.shape if response is None else (int(response.n_data),)
         if response is not None:
             if int(response.n_pix) != self.N:
                 raise ValueError("response does not act on this grid")
             self.sandwich = self.fused_direction = False  # the middle of J^T M J is not diagonal in position space
-            self.wide = self.wide_generic = False  # (the likelihood lives behind the response: no likelihood epilogue to widen)
+            # the likelihood lives behind the response: no likelihood epilogue to widen.  fp32 fields take the same step
+            # with fp64 copies instead (`_linearize_response`): xi widened, g(s) from the fp64 transform, the response, the
+            # residual and the energy in fp64 on the data space; g'(s), the data-space weight and the residual that enters the
+            # adjoint come back rounded to fp32
+            self.wide_response = self.wide or self.wide_generic
+            self.wide = self.wide_generic = False
         if data is not None:
             self.set_data(data, icov)
         self.counters = dict(value_grad=0, metric=0, transforms=0, cg_iterations=0)
@@ -592,7 +598,7 @@ class FusedModel:
                           and self.response is None)
         # (static operands of the generic wide forward transform, shared by the lanes)
         self._data64 = self._icov64 = None
-        if self.wide_generic and self.lh_kind == L.LH_GAUSS:
+        if (self.wide_generic or self.wide_response) and self.lh_kind == L.LH_GAUSS:
             self._data64 = self.data.double()
             self._icov64 = None if self.icov_field is None else self.icov_field.double()
         # data-space metric weight of a Gaussian with scalar N^-1: a number, not a field (response models)
@@ -886,6 +892,32 @@ class FusedModel:
         B.hartley_fused(self.plan, f)
         self._count("transforms", 1)
 
+    def _forward_nonlin_wide(self, lp, x):
+        """g(s) as an fp64 tensor for a model with fp32 fields (`wide_response`): the transform runs on the fp64 plan of the
+        grid with xi widened and the fp64 amplitude (octant field where both plans have the register-resident pipeline, the
+        table gathered by pidx otherwise); g'(s) -> lp.gp rounded to the field type."""
+        if self._wide_state is None:
+            plan64 = B.get_plan(self.shape, torch.float64, 1, self.device)
+            if self.stream is not None:  # a lane: the cached plan's workspace belongs to the main chain
+                plan64 = B.PlanView(plan64)
+            octant = self.octant_vjp and bool(L.load().nk_plan_octant_vjp(plan64.handle))
+            afield64 = torch.empty(self.field_shape, dtype=torch.float64, device=self.device) if octant else None
+            dense64 = None if (self.k2_dense is None or not octant) else torch.zeros_like(self.k2_dense, dtype=torch.float64)
+            self._wide_state = (plan64, octant, afield64, dense64)
+        plan64, octant, afield64, dense64 = self._wide_state
+        xi64 = x.xi.to(torch.float64)
+        g = torch.empty(self.shape, dtype=torch.float64, device=self.device)
+        gp = torch.empty_like(g)
+        f = self._fuse()
+        f.field_octant = 1 if octant else 0
+        f.pro, f.in_, f.pidx, f.amp = L.PRO_AMP, xi64.data_ptr(), self.pidx.data_ptr(), lp.amp.data_ptr()
+        f.afield = self._amp_field(lp.amp, out=afield64, dense=dense64).data_ptr() if octant else None
+        f.epi, f.out, f.out2, f.offset, f.nonlin = L.EPI_NONLIN, g.data_ptr(), gp.data_ptr(), self.offset_mean, self.nonlin
+        B.hartley_fused(plan64, f)
+        self._count("transforms", 1)
+        lp.gp = gp.to(self.tdtype)
+        return g
+
     def _weigh_data(self, u, lp):
         """u * M_d (data-space Fisher metric: N^-1, or 1/mu for counts)."""
         if self.const_wd:
@@ -894,20 +926,28 @@ class FusedModel:
 
     def _linearize_response(self, lp, x, grad_acc, w, value, lhval, want_gradient=True):
         """energy_operators.py:517-595 / :617-640 composed with R o g o cf: mu = R g(s) lives on the data space."""
-        self._forward_nonlin(lp, x, self.tmp)
-        mu = self.response.times(self.tmp)
+        if self.wide_response:
+            # fp32 fields: everything up to the residual in fp64 (see __init__), like the reference's promoted arithmetic
+            mu = self.response.times(self._forward_nonlin_wide(lp, x))
+            data, icov, wide = self._data64, self._icov64, torch.float64
+        else:
+            self._forward_nonlin(lp, x, self.tmp)
+            mu = self.response.times(self.tmp)
+            data, icov, wide = self.data, self.icov_field, self.tdtype
         if self.lh_kind == L.LH_GAUSS:
-            r = B.axpby(1.0, mu, -1.0, self.data)
-            ir = self._weigh_data(r, lp)
+            r = B.axpby(1.0, mu, -1.0, data)
+            ir = B.axpby(self.icov_scalar, r) if self.const_wd else B.binary(L.OP_MUL, r, icov)
             B.vdot(r, ir, result=lhval, accumulate=False)
             B.axpby(0.5, lhval, out=lhval)
         else:
-            dat = self.data.to(self.tdtype)
+            dat = self.data.to(wide)
             B.vsum(mu, result=lhval, accumulate=False)
             ld = B.vdot(B.pointwise("log", mu), dat)
             B.axpby(1.0, lhval, -1.0, ld, out=lhval)
             lp.wd = B.pointwise("reciprocal", mu)
             ir = B.binary(L.OP_SUB, 1.0, B.binary(L.OP_MUL, dat, lp.wd))  # 1 - d / mu
+            lp.wd = lp.wd.to(self.tdtype)
+        ir = ir.to(self.tdtype)
         if not want_gradient:  # (lp.gp and lp.wd are what the metric needs)
             return lp
         gs = self.response.adjoint(ir, self.shape)

@@ -59,13 +59,13 @@ def full():
     return _api_model(4096)
 
 
-def _fused(lh):
+def _fused(lh, dtype=torch.float64):
     from nifty_amd.engine import FusedModel
     from nifty_amd.optimize_kl import match_fused
 
     kw = match_fused(lh)
     assert kw is not None and kw["response"] is not None, "config 4 must be recognised by the fusion pass"
-    return FusedModel(kw.pop("shape"), kw.pop("distances"), dtype=torch.float64, device="cuda:0", **kw)
+    return FusedModel(kw.pop("shape"), kw.pop("distances"), dtype=dtype, device="cuda:0", **kw)
 
 
 def test_sparse_products_of_the_full_matrix_against_scipy(full):
@@ -180,6 +180,42 @@ def test_same_lines_on_512_squared_against_the_oracle():
     assert n_total == 2 and len(res) == len(ores) == 2
     for r, o in zip(res, ores):
         assert gl.lat_relerr(r.to_dict(), o) < 1e-6
+
+
+def test_fp32_fields_behind_the_response_against_the_fp64_oracle(monkeypatch):
+    """The 512^2 model with FP32 fields: the forward transform, the response, the residual and the energy run in fp64 with the
+    fp32 arrays at both ends (FusedModel.wide_response) -- what the reference's promoted arithmetic does -- so value and
+    gradient stay inside the 1e-5 of north_star; A/B against the all-fp32 evaluation (NK_WIDE_FORWARD=0) on the same inputs."""
+    from nifty_amd.engine import LatentVec
+
+    n = 512
+    starts, ends, flags = _lines()
+    cf, resp, lh, d, R, Mk = _api_model(n)
+    mat = orc.los_sparse((n, n), (1.0 / n, 1.0 / n), starts, ends)[np.logical_not(flags)]
+    ocf = orc.CFModel((n, n), None, orc.CFParams(**CF))
+    data32 = d.asnumpy().astype(np.float32).astype(np.float64)
+    olh = orc.Likelihood("gaussian", data32, icov=1.0 / NOISE_VAR, nonlin="sigmoid", response=mat)
+    rng = np.random.default_rng(4)
+    x = {k: 0.1 * a for k, a in ocf.draw_latent(rng).items()}
+    v = ocf.draw_latent(rng)
+    x["xi"] = x["xi"].astype(np.float32).astype(np.float64)
+    v["xi"] = v["xi"].astype(np.float32).astype(np.float64)
+    lin = orc.Linearized(ocf, olh, x)
+    val, grad = lin.value_grad()
+    mv = lin.metric(v)
+    errs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("NK_WIDE_FORWARD", flag)
+        model = _fused(lh, torch.float32)
+        assert model.wide_response == (flag == "1") and not model.wide
+        lp = model.linearize(LatentVec.from_dict(model, x))
+        errs[flag] = (abs(float(lp.value.item()) - val) / abs(val), gl.lat_relerr(lp.grad.to_dict(), grad),
+                      gl.lat_relerr(model.metric(lp, LatentVec.from_dict(model, v)).to_dict(), mv))
+        del model
+    print("512^2 + LOS response, fp32 fields vs fp64 oracle (value, gradient, metric): all-fp32 %.1e %.1e %.1e | wide %.1e %.1e %.1e"
+          % (errs["0"] + errs["1"]))
+    assert errs["1"][0] < 1e-9 and errs["1"][1] < 1e-5 and errs["1"][2] < 2e-4
+    assert errs["1"][0] < errs["0"][0]
 
 
 def _run_okl(lh, fuse, ic, mk, nl):
