@@ -1207,15 +1207,38 @@ class FusedModel:
     def _upload(self, arr, dtype):
         return torch.from_numpy(np.ascontiguousarray(arr)).to(dtype).to(self.device)
 
-    def draw_prior(self, device_rng=None):
-        """One standard-normal latent draw, keys in alphabetical order like MultiField.from_random."""
+    def host_draws_before_xi(self, sseq):
+        """What `draw_prior` takes from the HOST generator before the device draws xi -- the scalars and the (2, nb - 2)
+        spectrum excitations that sort before `xi` -- drawn from a generator of its own on `sseq`, with the generator's state
+        afterwards: (values by key, state).  `draw_prior(ahead=...)` continues from there; the same numbers as drawing them
+        in place (same seed, same calls), but a host thread can make them while the GPU solves the previous sample
+        (`_HostDrawAhead`)."""
+        rng = np.random.default_rng(sseq)
+        vals = {}
+        for k in LATENT_KEYS:
+            if k == "xi":
+                break
+            vals[k] = rng.normal(0.0, 1.0, (2, self.nb - 2) if k == "spectrum" else ())
+        return vals, rng.bit_generator.state
+
+    def draw_prior(self, device_rng=None, ahead=None):
+        """One standard-normal latent draw, keys in alphabetical order like MultiField.from_random.  ahead: the result of
+        `host_draws_before_xi` on the seed of the CURRENT random context (its draws are taken, its state continued)."""
         if device_rng is not None:
             xi = torch.randn(self.shape, dtype=self.tdtype, device=self.device, generator=device_rng)
             small = torch.randn(self.nsmall, dtype=torch.float64, device=self.device, generator=device_rng)
             return LatentVec(xi, small)
         nb = self.nb
         parts = {}
+        if ahead is not None:
+            random.current_rng().bit_generator.state = ahead[1]
         for k in LATENT_KEYS:  # alphabetical = the reference's draw order
+            if ahead is not None and k in ahead[0]:
+                if k == "spectrum":
+                    spectrum = self._upload(ahead[0][k], torch.float64)
+                else:
+                    parts[k] = ahead[0][k]
+                continue
             if k == "xi":  # the numpy stream, computed on the device from the host generator's state
                 xi = random.Random.normal_on_device(self.npdtype, self.shape, 0.0, 1.0, self.device)
             elif k == "spectrum":
@@ -1268,9 +1291,9 @@ class FusedModel:
         out.small = B.axpby(1.0, self.latbar)
         return out
 
-    def draw_mgvi_sample(self, lp, controller, device_rng=None):
+    def draw_mgvi_sample(self, lp, controller, device_rng=None, ahead=None):
         """Returns (b, y): y solves (J^T M J + 1) y = b = s + nj by CG started at the prior draw s."""
-        s = self.draw_prior(device_rng)
+        s = self.draw_prior(device_rng, ahead=ahead)
         nj = self.draw_lh_noise(lp, device_rng)
         b = s + nj
         g0 = self.lh_metric(lp, s, minus=nj)  # J^T M J s - nj: the subtraction rides in the transform's epilogue
@@ -1850,12 +1873,20 @@ def draw_samples(model, position, n_samples, mirror_samples, controller_factory,
             cache["lp"] = model.metric_point(position)  # (the sampling solves apply the metric there; no value, no gradient)
         return cache["lp"]
 
+    # large grids take the spectrum excitations from the host generator (draw_prior): 9 ms of numpy per sample with the GPU
+    # idle -- made by a host thread while the GPU solves the previous sample instead (same seed, same calls: same numbers)
+    drawn_seeds = [plan.seeds[i] for i in range(plan.lo, plan.hi) if not (plan.mirror and i % 2 == 1 and i > plan.lo)]
+    ahead = None
+    want_ahead = (device_rng is None and model.N > SPECTRUM_DEVICE_DRAW_MAX_POINTS and bool(drawn_seeds)
+                  and os.environ.get("NK_DRAW_AHEAD", "1") != "0")
+
     def draw(seed):
         if device_rng is not None:
             # synthetic-draw mode: still one stream per sample seed, so both members of a mirrored pair
             # see identical draws even when they live on different ranks (kl_energies.py:132-146)
             device_rng.manual_seed(int(seed.generate_state(1, np.uint64)[0] >> np.uint64(1)))
-        return model.draw_mgvi_sample(linearisation(), controller_factory(), device_rng)
+        lp = linearisation()
+        return model.draw_mgvi_sample(lp, controller_factory(), device_rng, ahead=ahead.take(seed) if ahead else None)
 
     def linear_residual(pair, mirrored):
         return pair[1], mirrored
@@ -1878,6 +1909,8 @@ def draw_samples(model, position, n_samples, mirror_samples, controller_factory,
     # the linear solves of the iteration advance together: as batched launches (nifty_amd/batched.py) or on stream lanes
     in_batch = local_pairs >= 2 and batched.ready(model)
     if lanes is None and not in_batch:
+        if want_ahead:
+            ahead = _HostDrawAhead(model, drawn_seeds)
         drawn = plan.run(draw, finish)
     else:
         together = geo_minimizer is not None and lanes is not None and os.environ.get("NK_GEO_THREADS", "1") != "0"
@@ -1894,6 +1927,33 @@ def draw_samples(model, position, n_samples, mirror_samples, controller_factory,
             fits = _fit_on_lanes(model, lanes, cache["tp"], cache["g_p"], position, drawn, geo_minimizer)
             drawn = [(f, False) for f in fits]
     return [r for r, _ in drawn], [n for _, n in drawn], plan.n_total
+
+
+class _HostDrawAhead:
+    """The host part of the prior draws (FusedModel.host_draws_before_xi) of a rank's samples, one sample ahead: `take(seed)`
+    hands out the draws of `seed` -- started at construction for the first sample, at the previous `take` for the others --
+    and starts the next sample's on a worker thread (numpy fills arrays without the interpreter lock)."""
+
+    def __init__(self, model, seeds):
+        from concurrent.futures import ThreadPoolExecutor
+
+        self._model, self._seeds = model, list(seeds)
+        self._pool = ThreadPoolExecutor(max_workers=1)
+        self._pending = {}
+        self._start(0)
+
+    def _start(self, k):
+        if k < len(self._seeds):
+            self._pending[k] = self._pool.submit(self._model.host_draws_before_xi, self._seeds[k])
+
+    def take(self, seed):
+        k = next((j for j, sq in enumerate(self._seeds) if sq is seed), None)
+        fut = self._pending.pop(k, None) if k is not None else None
+        if k is not None:
+            self._start(k + 1)
+        if k is not None and k + 1 >= len(self._seeds):
+            self._pool.shutdown(wait=False)
+        return fut.result() if fut is not None else None
 
 
 def _fit_on_lanes(model, lanes, tp, g_p, position, jobs, minimizer):
