@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/da
-for a in 1 0; do
+for a in ${NK_AB_LIST:-1 0}; do
 NK_DRAW_AHEAD=$a python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/da/ahead$a.log 2>&1
 python - <<P
 import json
