@@ -36,6 +36,61 @@ from .optimize_kl import optimize_kl  # noqa: F401
 from .parallel import shareRange  # noqa: F401
 
 
+_nthreads = 1
+
+
 def set_nthreads(n):
-    """Accepted for source compatibility with nifty.cl (ducc_dispatch.py:35-46); the device kernels ignore it."""
-    return None
+    """Accepted for source compatibility with nifty.cl (ducc_dispatch.py:35-46): remembered for `nthreads()`, ignored by the
+    device kernels."""
+    global _nthreads
+    _nthreads = int(n)
+
+
+def nthreads():
+    """ducc_dispatch.py:31-32."""
+    return _nthreads
+
+
+# ---- small helpers of the reference's top level that user scripts lean on ------------------------------------------
+from .minimization import logger  # noqa: E402,F401  (one logger for the package; the reference's is "NIFTy", logger.py:21-33)
+
+
+def logger_init(level=None):
+    """logger.py:21-31: the package logger with a stream handler at `level` (default INFO), not propagating."""
+    import logging
+
+    level = logging.INFO if level is None else level
+    logger.setLevel(level)
+    logger.propagate = False
+    if not any(isinstance(h, logging.StreamHandler) for h in logger.handlers):
+        handler = logging.StreamHandler()
+        logger.addHandler(handler)
+    for h in logger.handlers:
+        h.setLevel(level)
+    return logger
+
+
+def myassert(val):
+    """utilities.py:516-520: an assertion that stays active under ``python -O``."""
+    if not val:
+        raise AssertionError
+
+
+def is_operator(obj):
+    """operators/operator.py:659-668: operator-like and neither a field nor a linearization (here those are separate
+    classes; in the reference they derive from Operator, hence the helper)."""
+    return isinstance(obj, Operator) and not isinstance(obj, Linearization) and not is_fieldlike(obj)
+
+
+def is_linearization(obj):
+    """operators/operator.py:671-673."""
+    return isinstance(obj, Linearization)
+
+
+def is_likelihood_energy(obj):
+    """operators/operator.py:653-656: an operator that knows its variance-stabilising transformation."""
+    get = getattr(obj, "get_transformation", None)
+    return isinstance(obj, Operator) and callable(get) and get() is not None
+
+
+from .kl import SampleListBase  # noqa: E402,F401

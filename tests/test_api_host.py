@@ -772,3 +772,24 @@ def test_controller_announces_a_forced_stop():
     assert ctrl.check(_ScalarEnergyView(0.125, 1.0)) == CONVERGED
     assert not _forced_stop(ift.GradientNormController(tol_abs_gradnorm=1e-3))  # no iteration limit: never forced
     assert not _forced_stop(object())
+
+
+def test_top_level_helpers_of_the_reference():
+    """Small names of nifty.cl's top level that user scripts lean on (operators/operator.py:653-673, utilities.py:516-520,
+    ducc_dispatch.py:31-46, logger.py:21-33): same meaning here, where Field / Linearization are not Operator subclasses."""
+    import logging
+
+    sp = ift.RGSpace(8)
+    op, f = ift.ScalingOperator(sp, 2.0), ift.Field.full(sp, 1.0)
+    lh, lin = ift.GaussianEnergy(data=f), ift.Linearization.make_var(f)
+    assert ift.is_operator(op) and ift.is_operator(lh) and not ift.is_operator(f) and not ift.is_operator(lin)
+    assert ift.is_linearization(lin) and not ift.is_linearization(op) and not ift.is_linearization(f)
+    assert ift.is_likelihood_energy(lh) and not ift.is_likelihood_energy(op) and not ift.is_likelihood_energy(f)
+    assert ift.is_fieldlike(f) and not ift.is_fieldlike(op)
+    ift.set_nthreads(3)
+    assert ift.nthreads() == 3
+    ift.set_nthreads(1)
+    with pytest.raises(AssertionError):
+        ift.myassert(0)
+    ift.myassert(1)
+    assert isinstance(ift.logger, logging.Logger) and issubclass(ift.ResidualSampleList, ift.SampleListBase)
