@@ -21,7 +21,7 @@ from .kl import (EnergyAdapter, ResidualSampleList, SampledKLEnergy, SampledKLEn
                  draw_samples)
 from .minimization import (AbsDeltaEnergyController, ConjugateGradient, DeltaEnergyController, DescentMinimizer,  # noqa: F401
                            Energy, EnergyHistory, GradientNormController, GradInfNormController, IterationController,
-                           L_BFGS, LineSearch, NewtonCG, QuadraticEnergy, RelaxedNewton, SteepestDescent,
+                           L_BFGS, LineSearch, Minimizer, NewtonCG, QuadraticEnergy, RelaxedNewton, SteepestDescent,
                            StochasticAbsDeltaEnergyController, VL_BFGS)
 from .probing import StatCalculator, approximation2endo  # noqa: F401
 from .operators import PrependKey  # noqa: F401
