@@ -474,19 +474,18 @@ def solve_together(model, lp, jobs, controller_factory):
         # the energy of the start exactly as QuadraticEnergy._compute_value forms it: A s = r0 + b, E = 1/2 s.(A s) - b.s
         # (the controllers read it at start(), whether or not the recurrence tracks it afterwards)
         track = M._config_track_energy()
-        if True:
-            e0 = scalars(2 * count, model.device)
-            e_ax, e_b = e0[:count], e0[count:]
-            a_s = [LatentVec(a, b) for a, b in zip(axpby([1.0] * count, [r.xi for r in rs], [1.0] * count, [b.xi for b in bs]),
-                                                   axpby([1.0] * count, [r.small for r in rs], [1.0] * count,
-                                                         [b.small for b in bs]))]
-            vdot([x.xi.reshape(-1) for x in xs], [v.xi.reshape(-1) for v in a_s], e_ax)
-            vdot([x.small for x in xs], [v.small for v in a_s], e_ax, accumulate=True)
-            vdot([b.xi.reshape(-1) for b in bs], [x.xi.reshape(-1) for x in xs], e_b)
-            vdot([b.small for b in bs], [x.small for x in xs], e_b, accumulate=True)
-            del a_s
-            host = torch.stack(e_ax + e_b).cpu().numpy().reshape(2, count)
-            values = [float(0.5 * host[0, m] - host[1, m]) for m in range(count)]
+        e0 = scalars(2 * count, model.device)
+        e_ax, e_b = e0[:count], e0[count:]
+        a_s = [LatentVec(a, b) for a, b in zip(axpby([1.0] * count, [r.xi for r in rs], [1.0] * count, [b.xi for b in bs]),
+                                               axpby([1.0] * count, [r.small for r in rs], [1.0] * count,
+                                                     [b.small for b in bs]))]
+        vdot([x.xi.reshape(-1) for x in xs], [v.xi.reshape(-1) for v in a_s], e_ax)
+        vdot([x.small for x in xs], [v.small for v in a_s], e_ax, accumulate=True)
+        vdot([b.xi.reshape(-1) for b in bs], [x.xi.reshape(-1) for x in xs], e_b)
+        vdot([b.small for b in bs], [x.small for x in xs], e_b, accumulate=True)
+        del a_s
+        host = torch.stack(e_ax + e_b).cpu().numpy().reshape(2, count)
+        values = [float(0.5 * host[0, m] - host[1, m]) for m in range(count)]
         status = [None] * count
         active = []
         for m in range(count):
