@@ -379,7 +379,7 @@ __global__ void __launch_bounds__((Contig3Tile<T, H>::QTHREADS))
     k3_contig_quad(NkPass3 p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr, C2<T>* __restrict__ work) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, Contig3Tile<T, H>::SC::E> ex;
-  nk_contig3_body<T, H, 4, PC, true>(ex, p, f, (int64_t)blockIdx.x + p.blk0, (T*)smem, tw, twr, work);
+  nk_contig3_body<T, H, 4, PC, true>(ex, p, f, (int64_t)blockIdx.x + p.blk0, (T*)smem, tw, twr, work, (int)blockIdx.y);
 }
 
 template <typename T, int H, int PC>
@@ -406,8 +406,14 @@ static int nk_launch_contig3(const NkPass3& p3, const NkFuse& f, const C2<T>* tw
         if (batch != 1 || p3.blk0 < 0 || p3.blk0 + p3.nblk > qblocks) return nk_set_error(NK_ERR_INVALID, "k3_contig_quad: bad stage range");
         qblocks = p3.nblk;
       }
-      if (qblocks > 0x7fffffffLL) return nk_set_error(NK_ERR_UNSUPPORTED, "too many lines for one launch");
-      hipLaunchKernelGGL(qkern, dim3((unsigned)qblocks), dim3(CT::QTHREADS), CT::QLDS_BYTES, st, p3, f, tw, twr, work);
+      // grid: x = the (a8, b8) index inside a batch member (stage ranges: batch 1), y = the batch member
+      const int64_t per = (int64_t)(p3.g.na / 2 + 1) * (p3.g.nm / 2 + 1);
+      const int64_t gx = p3.nblk > 0 ? qblocks : per;
+      if (gx > 0x7fffffffLL || batch > 65535) return nk_set_error(NK_ERR_UNSUPPORTED, "too many lines for one launch");
+      NkPass3 pq = p3;
+      pq.dmh = nk_make_div(p3.g.nm / 2 + 1);
+      hipLaunchKernelGGL(qkern, dim3((unsigned)gx, (unsigned)(p3.nblk > 0 ? 1 : batch)), dim3(CT::QTHREADS), CT::QLDS_BYTES, st, pq, f,
+                         tw, twr, work);
       return nk_check_launch("k3_contig_quad");
     }
   }

@@ -33,6 +33,7 @@ struct NkPass3 {
   int rows_per_slab;  // lines per work slab (3-D: nm, 2-D: na)
   int64_t rs, ss;     // work row stride / slab stride in complex elements
   int64_t blk0, nblk; // QUAD launches of one pipeline stage: workgroups blk0 .. blk0 + nblk - 1 (nblk == 0: all)
+  NkDiv dmh;          // QUAD launches: / (nm / 2 + 1) of the workgroup's index inside its batch member (set by the launcher)
 };
 
 // thread id -> line thread pp = tid % P, line t = tid / P; LDS: two scalar planes (re, im) of TILE * PITCH elements
@@ -77,9 +78,14 @@ struct Contig3Tile {
 // 15.2 GB against 9.7 GB of operands, profiles/r02g_pmc_traffic.json); here the first wavefront's request brings the line
 // in and the other rows hit the CU's vector cache.  Rows that coincide with their mirror (a8 or b8 equal to 0 or n/2) stay
 // idle in their duplicate slots (0.4 % of the slots at 1024^2 rows).
+// QUAD: blk = (a8, b8) index of the workgroup inside batch member `bat` (< (na/2 + 1) * (nm/2 + 1): the octant of the first two
+// axes), taken apart with a multiply-high (NkPass3::dmh) -- the rows, their work-array addresses and the octant line follow
+// from (bat, a8, b8) without a single integer division (round 5: the per-wave index bookkeeping of this straight-line kernel
+// -- 64-bit divisions by run-time values, repeated in the store loop -- was a fifth of its vector instructions, and the pass
+// keeps its vector pipes 64 % busy).
 template <typename T, int H, int TILE, int PC, bool QUAD = false, typename Exec>
 NK_HD void nk_contig3_body(Exec& ex, const NkPass3& p, const NkFuse& f, int64_t blk, T* planes,
-                           const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr, C2<T>* __restrict__ work) {
+                           const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr, C2<T>* __restrict__ work, int bat = 0) {
   using SC = typename Contig3Tile<T, H>::SC;
   using LY = ContigLayout<H, SC::P>;
   constexpr int E = SC::E, S = SC::S, P = SC::P;
@@ -88,19 +94,24 @@ NK_HD void nk_contig3_body(Exec& ex, const NkPass3& p, const NkFuse& f, int64_t 
   T* pim = planes + TILE * LY::PITCH;
   const int64_t line0 = blk * TILE;
   const int nl = p.g.nl;
+  [[maybe_unused]] int a8 = 0, b8 = 0;
+  if constexpr (QUAD) nk_fdivmod((uint32_t)blk, p.dmh, a8, b8);
+  // QUAD: first / middle index of tile slot t (its mirror images of (a8, b8)), and whether the slot exists
+  auto quad_ab = [&](int t, int& a, int& b) -> bool {
+    const bool ma = (t & 2) != 0, mb = (t & 1) != 0;
+    a = ma ? p.g.na - a8 : a8;
+    b = mb ? p.g.nm - b8 : b8;
+    return !((ma && (a8 == 0 || 2 * a8 == p.g.na)) || (mb && (b8 == 0 || 2 * b8 == p.g.nm)));
+  };
   // row of tile slot t, or -1 for an idle slot
   auto line_of = [&](int t) -> int64_t {
     if constexpr (!QUAD) {
       const int64_t l = line0 + t;
       return l < p.nlines ? l : -1;
     } else {
-      const int Mh = p.g.nm / 2 + 1, Ah = p.g.na / 2 + 1;
-      const int64_t bat = blk / ((int64_t)Ah * Mh);
-      const int r = (int)(blk % ((int64_t)Ah * Mh));
-      const int a8 = r / Mh, b8 = r % Mh;
-      const bool ma = (t & 2) != 0, mb = (t & 1) != 0;
-      if ((ma && (a8 == 0 || 2 * a8 == p.g.na)) || (mb && (b8 == 0 || 2 * b8 == p.g.nm))) return -1;
-      return (bat * p.g.na + (ma ? p.g.na - a8 : a8)) * p.g.nm + (mb ? p.g.nm - b8 : b8);
+      int a, b;
+      if (!quad_ab(t, a, b)) return -1;
+      return ((int64_t)bat * p.g.na + a) * p.g.nm + b;
     }
   };
 
@@ -113,7 +124,9 @@ NK_HD void nk_contig3_body(Exec& ex, const NkPass3& p, const NkFuse& f, int64_t 
     [[maybe_unused]] uint32_t o8 = 0;
     if constexpr (OCT) {
       const uint32_t ch = nl / 2 + 1;
-      if (p.g.ndim == 3) {
+      if constexpr (QUAD) {
+        o8 = ((uint32_t)a8 * (uint32_t)(p.g.nm / 2 + 1) + (uint32_t)b8) * ch;  // all four rows fold onto (a8, b8)
+      } else if (p.g.ndim == 3) {
         const int b = (int)(line % p.g.nm), a = (int)((line / p.g.nm) % p.g.na);
         o8 = ((uint32_t)nk_fold(a, p.g.na) * (p.g.nm / 2 + 1) + (uint32_t)nk_fold(b, p.g.nm)) * ch;
       } else {
@@ -233,16 +246,12 @@ NK_HD void nk_contig3_body(Exec& ex, const NkPass3& p, const NkFuse& f, int64_t 
     constexpr int NK = H / 2 + 1;
     constexpr int NT = P * TILE;
     auto row_of = [&](int64_t line) { return work + (line / p.rows_per_slab) * p.ss + (line % p.rows_per_slab) * p.rs; };
-    for (int idx = tid; idx < TILE * NK; idx += NT) {
-      const int k = idx % NK, t = idx / NK;
-      const int64_t line = line_of(t);
-      if (line < 0) continue;
-      C2<T>* dst = row_of(line);
+    auto untangle = [&](C2<T>* dst, int t, int k) {
       if (k == 0) {
         const T zx = pre[LY::addr(t, 0)], zy = pim[LY::addr(t, 0)];
         nk_store_stream(dst, C2<T>{zx + zy, (T)0});
         nk_store_stream(dst + H, C2<T>{zx - zy, (T)0});
-        continue;
+        return;
       }
       const int a1 = LY::addr(t, k), a2 = LY::addr(t, H - k);
       const C2<T> Zk{pre[a1], pim[a1]}, Zm{pre[a2], pim[a2]};
@@ -251,11 +260,30 @@ NK_HD void nk_contig3_body(Exec& ex, const NkPass3& p, const NkFuse& f, int64_t 
       const C2<T> G = cmul(twr[k], Od);
       nk_store_stream(dst + k, C2<T>{Ev.x + G.y, Ev.y - G.x});
       if (k != H - k) nk_store_stream(dst + (H - k), C2<T>{Ev.x - G.y, -Ev.y - G.x});
-    }
+    };
     const int npad = (int)(p.rs - (H + 1));
-    for (int idx = tid; idx < TILE * npad; idx += NT) {
-      const int64_t line = line_of(idx / npad);
-      if (line >= 0) row_of(line)[H + 1 + idx % npad] = C2<T>{(T)0, (T)0};
+    if constexpr (QUAD) {
+      // slot by slot: the row's address is workgroup-uniform (3-D work layout: slab (bat, a), row b), the threads run over k
+#pragma unroll
+      for (int t = 0; t < TILE; ++t) {
+        int a, b;
+        if (!quad_ab(t, a, b)) continue;
+        C2<T>* dst = work + ((int64_t)bat * p.g.na + a) * p.ss + (int64_t)b * p.rs;
+        for (int k = tid + 1; k < NK; k += NT) untangle(dst, t, k);
+        if (tid == 0) untangle(dst, t, 0);
+        for (int c = tid; c < npad; c += NT) dst[H + 1 + c] = C2<T>{(T)0, (T)0};
+      }
+    } else {
+      for (int idx = tid; idx < TILE * NK; idx += NT) {
+        const int k = idx % NK, t = idx / NK;
+        const int64_t line = line_of(t);
+        if (line < 0) continue;
+        untangle(row_of(line), t, k);
+      }
+      for (int idx = tid; idx < TILE * npad; idx += NT) {
+        const int64_t line = line_of(idx / npad);
+        if (line >= 0) row_of(line)[H + 1 + idx % npad] = C2<T>{(T)0, (T)0};
+      }
     }
   });
 }

@@ -183,15 +183,19 @@ static void emu3_contig(const NkPass3& p, const nk_fuse& f, const C2<T>* tw, con
   if constexpr (CT::QUAD_OK) {
     if (f.field_octant && p.g.ndim == 3 && (f.pro == NK_PRO_AMP || f.pro == NK_PRO_AMP_JVP) && !(qenv && atoi(qenv) == 0)) {
       std::vector<T> qplanes(CT::QLDS_BYTES / sizeof(T));
+      // the launch grid of nk_launch_contig3: x = the (a8, b8) index inside a batch member, y = the member
       const int64_t batch = p.nlines / ((int64_t)p.g.na * p.g.nm);
-      const int64_t qblocks = batch * (p.g.na / 2 + 1) * (p.g.nm / 2 + 1);
-      for (int64_t blk = 0; blk < qblocks; ++blk) {
-        HostExec<T, CT::SC::E> ex(CT::QTHREADS);
-        if (f.pro == NK_PRO_AMP) nk_contig3_body<T, H, 4, 4, true>(ex, p, f, blk, qplanes.data(), tw, twr, work);
-        else if (f.cg_r && f.dafield) nk_contig3_body<T, H, 4, 8, true>(ex, p, f, blk, qplanes.data(), tw, twr, work);
-        else if (f.pidx_octant && f.dampT) nk_contig3_body<T, H, 4, 7, true>(ex, p, f, blk, qplanes.data(), tw, twr, work);
-        else nk_contig3_body<T, H, 4, 5, true>(ex, p, f, blk, qplanes.data(), tw, twr, work);
-      }
+      const int64_t per = (int64_t)(p.g.na / 2 + 1) * (p.g.nm / 2 + 1);
+      NkPass3 pq = p;
+      pq.dmh = nk_make_div(p.g.nm / 2 + 1);
+      for (int bat = 0; bat < (int)batch; ++bat)
+        for (int64_t blk = 0; blk < per; ++blk) {
+          HostExec<T, CT::SC::E> ex(CT::QTHREADS);
+          if (f.pro == NK_PRO_AMP) nk_contig3_body<T, H, 4, 4, true>(ex, pq, f, blk, qplanes.data(), tw, twr, work, bat);
+          else if (f.cg_r && f.dafield) nk_contig3_body<T, H, 4, 8, true>(ex, pq, f, blk, qplanes.data(), tw, twr, work, bat);
+          else if (f.pidx_octant && f.dampT) nk_contig3_body<T, H, 4, 7, true>(ex, pq, f, blk, qplanes.data(), tw, twr, work, bat);
+          else nk_contig3_body<T, H, 4, 5, true>(ex, pq, f, blk, qplanes.data(), tw, twr, work, bat);
+        }
       return;
     }
   }
