@@ -374,12 +374,47 @@ __global__ void __launch_bounds__((Contig3Tile<T, H>::THREADS)) NK_CONTIG3_ATTR
 }
 
 // QUAD variant: one workgroup per octant row pair of pairs (nk_fft3.h)
+// Occupancy the compiler aims at (= its register budget): a row pass lives on the loads it keeps in flight, and with a free
+// hand the compiler trades registers for resident waves (k3_contig_quad<double,256,5>: 88 VGPRs, five waves per SIMD --
+// 0.69 ms; capped at four waves it takes 144 VGPRs and 0.62 ms).  Per field type and prologue class, from measurements.
+#ifndef NK_QUAD_MAXW_F64_5
+#define NK_QUAD_MAXW_F64_5 4
+#endif
+#ifndef NK_QUAD_MAXW_F64_8
+#define NK_QUAD_MAXW_F64_8 8
+#endif
+#ifndef NK_QUAD_MAXW_F32_5
+#define NK_QUAD_MAXW_F32_5 8
+#endif
+#ifndef NK_QUAD_MAXW_F32_8
+#define NK_QUAD_MAXW_F32_8 8
+#endif
+template <typename T, int PC>
+constexpr int nk_quad_max_waves() {
+  return sizeof(T) == 8 ? (PC == 8 ? NK_QUAD_MAXW_F64_8 : NK_QUAD_MAXW_F64_5) : (PC == 8 ? NK_QUAD_MAXW_F32_8 : NK_QUAD_MAXW_F32_5);
+}
 template <typename T, int H, int PC>
 __global__ void __launch_bounds__((Contig3Tile<T, H>::QTHREADS))
     k3_contig_quad(NkPass3 p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr, C2<T>* __restrict__ work) {
   extern __shared__ __align__(16) unsigned char smem[];
   DeviceExec<T, Contig3Tile<T, H>::SC::E> ex;
   nk_contig3_body<T, H, 4, PC, true>(ex, p, f, (int64_t)blockIdx.x + p.blk0, (T*)smem, tw, twr, work, (int)blockIdx.y);
+}
+// the same kernel under an occupancy cap (only the classes that want one are launched through it: the attribute changes the
+// compiler's scheduling even when its bound is not binding -- k3_contig_quad<double,256,8> 0.95 -> 1.06 ms under (1, 8))
+template <typename T, int H, int PC, int MAXW>
+__global__ void __launch_bounds__((Contig3Tile<T, H>::QTHREADS)) __attribute__((amdgpu_waves_per_eu(1, MAXW)))
+    k3_contig_quad_w(NkPass3 p, NkFuse f, const C2<T>* __restrict__ tw, const C2<T>* __restrict__ twr, C2<T>* __restrict__ work) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  DeviceExec<T, Contig3Tile<T, H>::SC::E> ex;
+  nk_contig3_body<T, H, 4, PC, true>(ex, p, f, (int64_t)blockIdx.x + p.blk0, (T*)smem, tw, twr, work, (int)blockIdx.y);
+}
+template <typename T, int H, int PC>
+static auto nk_quad_kernel() {
+  if constexpr (nk_quad_max_waves<T, PC>() < 8)
+    return k3_contig_quad_w<T, H, PC, nk_quad_max_waves<T, PC>()>;
+  else
+    return k3_contig_quad<T, H, PC>;
 }
 
 template <typename T, int H, int PC>
@@ -394,7 +429,7 @@ static int nk_launch_contig3(const NkPass3& p3, const NkFuse& f, const C2<T>* tw
     // while its RCCL exchange runs beside the pass.
     static const int quad = nk_env_int("NK_CONTIG_QUAD", 1);
     if ((quad == 1 || (quad == 2 && p3.nblk > 0)) && p3.g.ndim == 3) {
-      auto qkern = k3_contig_quad<T, H, PC>;
+      auto qkern = nk_quad_kernel<T, H, PC>();
       static unsigned long long qattr_mask = 0;
       if (CT::QLDS_BYTES > 64 * 1024 && nk_first_on_device(qattr_mask)) {
         hipError_t e = hipFuncSetAttribute((const void*)qkern, hipFuncAttributeMaxDynamicSharedMemorySize, CT::QLDS_BYTES);

@@ -93,7 +93,7 @@ NK_HD void nk_contig3_body(Exec& ex, const NkPass3& p, const NkFuse& f, int64_t 
   T* pre = planes;
   T* pim = planes + TILE * LY::PITCH;
   const int64_t line0 = blk * TILE;
-  const int nl = p.g.nl;
+  constexpr int nl = 2 * H;  // (= p.g.nl: the launcher dispatches on H = nl / 2; a constant lets the mirror selects of the prologue fold)
   [[maybe_unused]] int a8 = 0, b8 = 0;
   if constexpr (QUAD) nk_fdivmod((uint32_t)blk, p.dmh, a8, b8);
   // QUAD: first / middle index of tile slot t (its mirror images of (a8, b8)), and whether the slot exists
