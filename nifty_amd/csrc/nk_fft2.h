@@ -914,29 +914,33 @@ NK_HD NkVjpOps<T> nk_final_vjp_load(const FinalCt<T>& c, int64_t ok, int64_t om,
   const bool run = MODE < 0 ? c.accum : (MODE & 2) != 0;
   const bool k1 = MODE < 0 ? c.c1 != nullptr : (MODE & 4) != 0;
   const bool k2nd = MODE < 0 ? c.c2 != nullptr : (MODE & 8) != 0;
-  const int64_t at[4] = {ok + k2, om + k2m, ok + k2m, om + k2};
+  // image i lives at row base (ok for i = 0, 2; om for i = 1, 3) + column (k2 for i = 0, 3; k2m for i = 1, 2): the row bases are
+  // workgroup-uniform where a whole wave serves one slot (scalar registers), the column a 32-bit lane offset -- spelled as
+  // base[column], not as one 64-bit sum per operand, so that the loads can take the scalar-base addressing form
+  const int64_t rowb[4] = {ok, om, ok, om};
+  const uint32_t colb[4] = {(uint32_t)k2, (uint32_t)k2m, (uint32_t)k2m, (uint32_t)k2};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const bool on = BOTH || i < 2;
     if constexpr (STASH == 3)
       v.p[i] = on ? st[i * nkp] : (T)0;
     else
-      v.p[i] = (on && k1) ? c.c1[at[i]] : (T)0;
-    v.q[i] = (on && k2nd) ? c.c2[at[i]] : (T)0;
+      v.p[i] = (on && k1) ? (c.c1 + rowb[i])[colb[i]] : (T)0;
+    v.q[i] = (on && k2nd) ? (c.c2 + rowb[i])[colb[i]] : (T)0;
     if constexpr ((NK_NT_LOAD & 8) != 0) {
-      v.x[i] = on ? nk_ld_stream(c.xi + at[i]) : (T)0;
-      v.d[i] = (on && add) ? nk_ld_stream(c.addend + at[i]) : (T)0;
+      v.x[i] = on ? nk_ld_stream((c.xi + rowb[i]) + colb[i]) : (T)0;
+      v.d[i] = (on && add) ? nk_ld_stream((c.addend + rowb[i]) + colb[i]) : (T)0;
       if constexpr (STASH == 2)
         v.o[i] = on ? st[i * nkp] : (T)0;
       else
-        v.o[i] = (on && run) ? nk_ld_stream(c.out + at[i]) : (T)0;
+        v.o[i] = (on && run) ? nk_ld_stream((c.out + rowb[i]) + colb[i]) : (T)0;
     } else {
-      v.x[i] = on ? c.xi[at[i]] : (T)0;
-      v.d[i] = (on && add) ? c.addend[at[i]] : (T)0;
+      v.x[i] = on ? (c.xi + rowb[i])[colb[i]] : (T)0;
+      v.d[i] = (on && add) ? (c.addend + rowb[i])[colb[i]] : (T)0;
       if constexpr (STASH == 2)
         v.o[i] = on ? st[i * nkp] : (T)0;
       else
-        v.o[i] = (on && run) ? c.out[at[i]] : (T)0;
+        v.o[i] = (on && run) ? (c.out + rowb[i])[colb[i]] : (T)0;
     }
   }
   return v;
@@ -976,15 +980,15 @@ NK_HD double nk_final_vjp_apply(const FinalCt<T>& c, const NkVjpOps<T>& v, int64
     else
       nk_store_stream_s(p, val);
   };
-  put(outk + k2, r[0], 0);
-  if (BOTH) put(outk + k2m, r[2], 2);
+  put(outk + (uint32_t)k2, r[0], 0);
+  if (BOTH) put(outk + (uint32_t)k2m, r[2], 2);
   double s = (double)v.x[0] * (double)t[0];
   if (BOTH) s += (double)v.x[2] * (double)t[2];
   if (!self) {
-    put(outm + k2m, r[1], 1);
+    put(outm + (uint32_t)k2m, r[1], 1);
     s += (double)v.x[1] * (double)t[1];
     if (BOTH) {
-      put(outm + k2, r[3], 3);
+      put(outm + (uint32_t)k2, r[3], 3);
       s += (double)v.x[3] * (double)t[3];
     }
   }
