@@ -4,7 +4,7 @@
 set -e
 LIB=${2:-$(dirname $0)/../nifty_amd/csrc/libniftyk.so}
 D=$(mktemp -d)
-/opt/rocm/lib/llvm/bin/llvm-objcopy --dump-section .hip_fatbin=$D/fat.bin $LIB
+/opt/rocm/lib/llvm/bin/llvm-objcopy --dump-section .hip_fatbin=$D/fat.bin $LIB $D/copy.out  # (an output file: without one objcopy rewrites its input in place)
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input=$D/fat.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$D/dev.co
 /opt/rocm/lib/llvm/bin/llvm-readelf --notes $D/dev.co > $D/notes.txt
 python3 - "$D/notes.txt" "$1" <<'P'
