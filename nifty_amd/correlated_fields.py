@@ -368,7 +368,11 @@ class _CFJacobian(LinearOperator):
             f.pro, f.in_, f.in2 = L.PRO_AMP_JVP, dxi.data_ptr(), self._xi.data_ptr()
             f.pidx, f.amp, f.damp = dev["pidx"].data_ptr(), self._amp.data_ptr(), damp.data_ptr()
             f.epi, f.out, f.offset = L.EPI_AFFINE, out.data_ptr(), 0.0
-            B.hartley_fused(p._plan(dxi), f)
+            plan = p._plan(dxi)
+            fields = p._octant_fields(plan, dxi, dev, self._amp, damp)  # (kept alive until the launch is enqueued)
+            if fields is not None:
+                f.afield, f.dafield, f.field_octant = fields[0].data_ptr(), fields[1].data_ptr(), 1
+            B.hartley_fused(plan, f)
             return Field(self._target, out)
         w = x.val.contiguous()
         out = torch.empty_like(w)
@@ -427,6 +431,25 @@ class CorrelatedFieldOperator(Operator):
         f.scale, f.mul_scalar, f.addend_scale = self._hsp.scalar_dvol, 1.0, 1.0
         return f
 
+    def _octant_fields(self, plan, like, dev, *tables):
+        """The bin tables (a, da, ...) as OCTANT fields in the field type of `like`, streamed by the first pass (its compile-time
+        prologue classes; the arithmetic of the fused engine's transforms) instead of table gathers per grid point through the
+        4-byte bin index (the run-time class: 9.1 ms instead of 2.3 ms for the first pass at 1024^3 fp32 -- `minisanity`
+        evaluates the model once per sample and iteration through this node).  None where the plan has no octant pipeline
+        (mixed radix, short axes) or with NK_CF_OCTANT_FORWARD=0."""
+        if not L.load().nk_plan_octant_vjp(plan.handle) or os.environ.get("NK_CF_OCTANT_FORWARD", "1") == "0":
+            return None
+        shape = tuple(int(n) for n in like.shape)
+        shp = (ctypes.c_int64 * len(shape))(*shape)
+        out = []
+        for table in tables:
+            t = table if like.dtype == torch.float64 else table.to(like.dtype)
+            field = torch.empty(int(np.prod([n // 2 + 1 for n in shape])), dtype=like.dtype, device=like.device)
+            L.check(L.load().nk_octant_expand(len(shape), shp, t.data_ptr(), dev["pidx"].data_ptr(), field.data_ptr(),
+                                              B.dtype_code(field), 1, B._stream()), "nk_octant_expand")
+            out.append(field)
+        return out
+
     def _pack_small(self, x):
         pre = self._prefix
         parts = [x[pre + k].val.reshape(1).to(torch.float64) for k in SMALL_KEYS]
@@ -463,18 +486,9 @@ class CorrelatedFieldOperator(Operator):
         f.pro, f.in_, f.pidx, f.amp = L.PRO_AMP, xi.data_ptr(), dev["pidx"].data_ptr(), amp.data_ptr()
         f.epi, f.out, f.offset = L.EPI_AFFINE, out.data_ptr(), self._offset
         plan = self._plan(xi)
-        if L.load().nk_plan_octant_vjp(plan.handle) and os.environ.get("NK_CF_OCTANT_FORWARD", "1") != "0":
-            # a(k) as an OCTANT field in the field type, streamed by the first pass (its compile-time class; the arithmetic of
-            # the fused engine's forward transform) instead of a table gather per grid point through the 4-byte bin index (the
-            # run-time class: 9.1 ms instead of 1.8 ms for the first pass at 1024^3 fp32 -- `minisanity` evaluates the model
-            # once per sample and iteration through this node)
-            shape = tuple(int(n) for n in xi.shape)
-            table = amp if xi.dtype == torch.float64 else amp.to(xi.dtype)
-            afield = torch.empty(int(np.prod([n // 2 + 1 for n in shape])), dtype=xi.dtype, device=xi.device)
-            shp = (ctypes.c_int64 * len(shape))(*shape)
-            L.check(L.load().nk_octant_expand(len(shape), shp, table.data_ptr(), dev["pidx"].data_ptr(), afield.data_ptr(),
-                                              B.dtype_code(afield), 1, B._stream()), "nk_octant_expand")
-            f.afield, f.field_octant = afield.data_ptr(), 1
+        fields = self._octant_fields(plan, xi, dev, amp)  # (kept alive until the launch is enqueued)
+        if fields is not None:
+            f.afield, f.field_octant = fields[0].data_ptr(), 1
         B.hartley_fused(plan, f)
         val = Field(self._target, out)
         if not lin:
