@@ -381,7 +381,21 @@ class _CFJacobian(LinearOperator):
         f.pro, f.in_ = L.PRO_PLAIN, w.data_ptr()
         f.epi, f.out = L.EPI_VJP, out.data_ptr()
         f.pidx, f.amp, f.xi, f.abar = dev["pidx"].data_ptr(), self._amp.data_ptr(), self._xi.data_ptr(), abar.data_ptr()
-        B.hartley_fused(p._plan(w), f)
+        plan = p._plan(w)
+        fields = p._octant_fields(plan, w, dev, self._amp)
+        if fields is not None:
+            # the final pass multiplies by the octant field and stores ONE merged sum xi . t per octant point (all sign-flip
+            # images of a coefficient share their bin); nk_octant_scatter reduces those into the bins -- instead of one fp64
+            # atomic per grid point through the bin index
+            shape = tuple(int(n) for n in w.shape)
+            w8 = torch.empty(int(np.prod([n // 2 + 1 for n in shape])), dtype=torch.float64, device=w.device)
+            f.afield, f.field_octant, f.w8 = fields[0].data_ptr(), 1, w8.data_ptr()
+            B.hartley_fused(plan, f)
+            shp = (ctypes.c_int64 * len(shape))(*shape)
+            L.check(lib.nk_octant_scatter(len(shape), shp, w8.data_ptr(), dev["pidx"].data_ptr(), abar.data_ptr(), 0,
+                                          B._stream()), "nk_octant_scatter")
+        else:
+            B.hartley_fused(plan, f)
         latbar = torch.empty(p._nsmall, dtype=torch.float64, device=w.device)
         L.check(lib.nk_amp_vjp(p._nb, dev["geo"].data_ptr(), dev["hyp"].data_ptr(), self._small.data_ptr(),
                                self._state.data_ptr(), abar.data_ptr(), latbar.data_ptr(), B._stream()), "nk_amp_vjp")
