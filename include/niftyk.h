@@ -293,6 +293,33 @@ int nk_spmv(int64_t nrows, const int64_t* rowptr, const int32_t* col, const floa
 int nk_spmv_t(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, const void* y, double* x64,
               int dtype, void* stream);
 
+/* nk_tiled_rowsum: y = R x for a response whose COLUMNS are the points of a grid [outer][ny][nx] and whose rows are long
+ * (TIMES of LOSResponse: thousands of pixels per line of sight), with the matrix re-ordered once at set-up by TILES of
+ * th x tw grid points (nifty_amd.los_response.tiled_plan builds these arrays on the host):
+ *   item     one non-empty tile; item_tile = (outer * nty + ty) * ntx + tx, item_blk[n_items + 1] = its blocks
+ *   block    8 entries of ONE row inside the tile (a row's entries there are padded with zero weights to whole blocks, and
+ *            cut after 128): loc[8 n_blocks] = position inside the tile (ly * tw + lx, uint16), wgt[8 n_blocks] = float32
+ *            weight (the reference's storage type), both 16-byte aligned; blk_slot[n_blocks] = where the partial sum of
+ *            the block's PIECE goes -- a piece = the consecutive blocks of one row inside one 64-block step of the tile
+ *            (at most 16) -- with the slots of a row consecutive: row_slot[n_rows + 1]
+ * Launch 1: a workgroup loads its tile of x into LDS with whole-line reads; a lane multiplies and adds one block in order,
+ * the lanes of a piece are joined by shuffle steps 1, 2, 4, 8, one partial sum per piece into `scratch` (count * n_slots
+ * doubles, caller-owned); launch 2: every row adds its partial sums in slot order (16 lanes + tree).  fp64 accumulation,
+ * fixed order, no atomics: bit-reproducible.  `count` members (1 .. NK_MAX_BATCH) share the matrix: x / y are host arrays
+ * of device pointers. */
+typedef struct nk_tiled_csr {
+  int64_t n_rows, n_slots;
+  int32_t n_items, ny, nx, th, tw;
+  const int32_t* item_tile;
+  const int64_t* item_blk;
+  const int32_t* blk_slot;
+  const int64_t* row_slot;
+  const uint16_t* loc;
+  const float* wgt;
+} nk_tiled_csr;
+int nk_tiled_rowsum(const nk_tiled_csr* m, int count, const void* const* x, void* const* y, double* scratch, int dtype,
+                    void* stream);
+
 /* inclusive prefix sums out[i] = sum_{j<=i} in[j] (reverse != 0: suffix sums), fp64 accumulation: the cumulative sums of
  * _TwoLogIntegrations in the GENERIC amplitude graph (library/correlated_fields.py:147-161); in and out may not overlap
  * partially (in == out is fine) */

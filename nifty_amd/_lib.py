@@ -42,6 +42,14 @@ class Product(ctypes.Structure):
                 ("dscale", _vp)]
 
 
+class TiledCsr(ctypes.Structure):
+    """Mirror of ``struct nk_tiled_csr`` (include/niftyk.h)."""
+
+    _fields_ = [("n_rows", _i64), ("n_slots", _i64), ("n_items", ctypes.c_int32), ("ny", ctypes.c_int32), ("nx", ctypes.c_int32),
+                ("th", ctypes.c_int32), ("tw", ctypes.c_int32), ("item_tile", _vp), ("item_blk", _vp), ("blk_slot", _vp),
+                ("row_slot", _vp), ("loc", _vp), ("wgt", _vp)]
+
+
 # name -> (restype, argtypes); the list is checked against include/niftyk.h by tests/test_abi.py
 SIGNATURES = {
     "nk_last_error": (ctypes.c_char_p, []),
@@ -86,6 +94,7 @@ SIGNATURES = {
     "nk_cumsum": (_i, [_i64, _vp, _vp, _i, _i, _vp]),
     "nk_cplx_rows": (_i, [_i64, _i64, _i64, _vp, _vp, _vp, _i, _d, _i, _i, _vp]),
     "nk_csr_rowsum": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "nk_tiled_rowsum": (_i, [ctypes.POINTER(TiledCsr), _i, _vp, _vp, _vp, _i, _vp]),
     "nk_spmv": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "nk_spmv_t": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "nk_pindex_from_k2": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp]),

@@ -8,6 +8,7 @@ fallback: a CPU tensor handed to these functions raises.
 import ctypes
 import math
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -437,6 +438,42 @@ def spmv(rowptr, col, wgt, x, nrows, lanes=64):
     L.check(L.load().nk_csr_rowsum(nrows, rowptr.data_ptr(), col.data_ptr(), wgt.data_ptr(), x.data_ptr(), y.data_ptr(),
                                    dtype_code(x), lanes, _stream()), "nk_csr_rowsum")
     return y
+
+
+class TiledMatrix:
+    """Device copy of a ``los_response.tiled_plan`` (the arrays of ``nk_tiled_csr``) + the partial-sum scratch of its launches
+    (one set per member of a batched call, grown on demand; launches on ONE stream at a time, like every workspace here)."""
+
+    _keys = ("item_tile", "item_blk", "blk_slot", "row_slot", "loc", "wgt")
+
+    def __init__(self, plan, device):
+        self.n_rows, self.n_slots = int(plan["n_rows"]), int(plan["n_slots"])
+        self.nnz, self.n_padded = int(plan["nnz"]), int(len(plan["loc"]))
+        self._arrays = {}
+        for k in self._keys:
+            a = plan[k]
+            if a.dtype == np.uint16:  # (torch has no uint16 arithmetic; the bytes are what the kernel reads)
+                a = a.view(np.int16)
+            self._arrays[k] = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.c = L.TiledCsr(n_rows=self.n_rows, n_slots=self.n_slots, n_items=int(plan["n_items"]), ny=int(plan["ny"]),
+                            nx=int(plan["nx"]), th=int(plan["th"]), tw=int(plan["tw"]),
+                            **{k: ptr(self._arrays[k]) for k in self._keys})
+        self._scratch = {}
+
+    def _scratch_for(self, count, device):
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        buf = self._scratch.get(key)
+        if buf is None or buf.numel() < count * max(self.n_slots, 1):
+            buf = self._scratch[key] = torch.empty(count * max(self.n_slots, 1), dtype=torch.float64, device=device)
+        return buf
+
+    def rowsum(self, xs, ys):
+        """ys[m] = R xs[m] for up to MAX_BATCH members sharing the matrix."""
+        _require_device(*xs)
+        scratch = self._scratch_for(len(xs), xs[0].device)
+        L.check(L.load().nk_tiled_rowsum(ctypes.byref(self.c), len(xs), L.ptr_array(xs), L.ptr_array(ys), scratch.data_ptr(),
+                                         dtype_code(xs[0]), _stream()), "nk_tiled_rowsum")
+        return ys
 
 
 def spmv_t(rowptr, col, wgt, y, ncols):

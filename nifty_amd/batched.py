@@ -255,7 +255,11 @@ def _through_response(model, points, grids):
     nnz = resp.host_matrix.nnz
     flat = [g.reshape(-1) for g in grids]
     us = [torch.empty(resp.n_data, dtype=g.dtype, device=g.device) for g in grids]
-    rowsum((a[0], a[1], a[2]), flat, us, weighted=True, lanes=B.lanes_for(nnz, resp.n_data), nrows=resp.n_data)
+    tm = resp.tiled(grids[0].device)
+    if tm is not None:
+        tm.rowsum(flat, us)
+    else:
+        rowsum((a[0], a[1], a[2]), flat, us, weighted=True, lanes=B.lanes_for(nnz, resp.n_data), nrows=resp.n_data)
     if model.const_wd:
         irs = axpby([model.icov_scalar] * count, us)
     else:

@@ -94,6 +94,7 @@ __device__ __forceinline__ void amp_store_sums(const double (&v)[NV] /* valid in
   }
   __syncthreads();
   if (!is_last) return;
+  nk_acquire_partials();
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     double x = 0.0;
@@ -101,7 +102,7 @@ __device__ __forceinline__ void amp_store_sums(const double (&v)[NV] /* valid in
     const double t = block_sum(x, sh);
     if (threadIdx.x == 0) *dst[k] = t;
   }
-  if (threadIdx.x == 0) *ticket = 0;
+  if (threadIdx.x == 0) nk_reset_ticket(ticket);
 }
 
 // geo layout: rel[nb] | sc[nb] | mult[nb] | delta[nb]

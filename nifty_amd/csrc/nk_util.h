@@ -46,19 +46,51 @@ int nk_red_scratch(hipStream_t st, NkRedScratch* out);
 // the L2s), and once its old value has come back it HAS been performed.  Only then is the ticket taken (another agent-scope
 // RMW at the same point), so whoever draws the last ticket finds every partial there; it reads them with agent-scope
 // atomic loads, which bypass its own L2 as well.  No cache maintenance anywhere.
+// This path leans on where agent-scope read-modify-writes and loads are performed on THIS chip, not on a happens-before edge
+// of the HIP memory model.  -DNK_RED_FENCE=1 builds the textbook protocol instead -- plain stores, a device-scope
+// fence before the ticket and after it -- as `make fence` -> build/libniftyk_fence.so; tests/test_kernels_gpu.py holds the two
+// libraries against each other over many launches and grid sizes (same order of additions: same bits).
+#ifndef NK_RED_FENCE
+#define NK_RED_FENCE 0
+#endif
 #if defined(__HIPCC__)
 __device__ __forceinline__ void nk_publish_partial(double* slot, double v) {
+#if NK_RED_FENCE
+  *slot = v;
+#else
   const unsigned long long old = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double_as_longlong(v),
                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // the returned value is consumed: the exchange has completed before anything that follows in program order is issued
   asm volatile("" ::"v"(old) : "memory");
+#endif
 }
 __device__ __forceinline__ bool nk_take_last_ticket(unsigned int* ticket, unsigned int count) {
+#if NK_RED_FENCE
+  __threadfence();
+  const bool last = atomicAdd(ticket, 1u) == count - 1;
+  __threadfence();
+  return last;
+#else
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (waits for the outstanding memory operations of this wavefront)
   return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == count - 1;
+#endif
 }
 __device__ __forceinline__ double nk_read_partial(const double* slot) {
+#if NK_RED_FENCE
+  return *reinterpret_cast<const volatile double*>(slot);
+#else
   return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// every thread of the LAST workgroup, after the barrier that tells it so and before its first nk_read_partial
+__device__ __forceinline__ void nk_acquire_partials() {
+#if NK_RED_FENCE
+  __threadfence();
+#endif
+}
+// the last workgroup leaves the ticket at zero for the next launch on the stream: an agent-scope store, like its increments
+__device__ __forceinline__ void nk_reset_ticket(unsigned int* ticket) {
+  __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif
 

@@ -174,6 +174,7 @@ __device__ __forceinline__ void nk_map_body(int64_t n, const F& f, int cu_max, N
     if (threadIdx.x == 0) is_last = nk_take_last_ticket(rs.ticket, gridDim.x);
     __syncthreads();
     if (is_last) {
+      nk_acquire_partials();
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       for (int u = wave; u < lay.k_local; u += NK_VEC_THREADS / 64) {
 #pragma unroll
@@ -201,7 +202,7 @@ __device__ __forceinline__ void nk_map_body(int64_t n, const F& f, int cu_max, N
           f.result[r] += s;
         }
       }
-      if (threadIdx.x == 0) *rs.ticket = 0;
+      if (threadIdx.x == 0) nk_reset_ticket(rs.ticket);
     }
   }
 }
@@ -1719,6 +1720,106 @@ __global__ void k_spmv_t(int64_t nrows, const int64_t* __restrict__ rowptr, cons
   for (int64_t j = lo + lane; j < hi; j += 64) atomicAdd(x + col[j], (double)wgt[j] * yv);
 }
 
+
+// SHORT rows (LANES == 1: the transposed response -- a few lines per pixel --, the bin sums of a static index map), STAGED.
+// With one thread per row every thread walks a chain of dependent loads -- row pointer -> (column, weight) -> gathered
+// operand -- a few entries long: the launch is bound by those latencies, not by its bytes (4096^2 transposed line-of-sight
+// matrix, 2.6e7 entries: 0.24 ms for 0.48 GB).  Here a workgroup owns ROWS_PER_WG consecutive rows, i.e. ONE contiguous
+// range of entries: all threads stream that range in windows of W entries -- coalesced, independent loads, the operands
+// gathered right behind them -- into LDS, and only then does every thread add up the runs of ITS rows, reading LDS.  The
+// additions of a row run in the order of k_csr_rowsum<T, 1> (ascending entry, one fused multiply-add each): same bits.
+// MB members of a batched launch share the index and weight loads (k_csr_rowsum_b's MB).
+constexpr int NK_STAGED_RPT = 4;                          // rows per thread
+constexpr int NK_STAGED_ROWS = 256 * NK_STAGED_RPT;       // rows per workgroup
+template <typename T, int MB>
+__global__ void __launch_bounds__(256) k_csr_rowsum_staged(int64_t nrows, const int64_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col, const float* __restrict__ wgt,
+                                                           NkPtrs xs, NkPtrs ys, int count) {
+  constexpr int W = 2048 / MB, U = W / 256;
+  __shared__ double sx[MB][W];
+  __shared__ float sw[W];
+  const int tid = threadIdx.x, m0 = blockIdx.y * MB;
+  const int64_t r0 = (int64_t)blockIdx.x * NK_STAGED_ROWS;
+  const int64_t r1 = r0 + NK_STAGED_ROWS < nrows ? r0 + NK_STAGED_ROWS : nrows;
+  const int64_t e0 = rowptr[r0], e1 = rowptr[r1];
+  int64_t lo[NK_STAGED_RPT], hi[NK_STAGED_RPT];
+  double acc[NK_STAGED_RPT][MB];
+#pragma unroll
+  for (int k = 0; k < NK_STAGED_RPT; ++k) {
+    const int64_t row = r0 + k * 256 + tid;
+    lo[k] = hi[k] = e1;
+    if (row < r1) lo[k] = rowptr[row], hi[k] = rowptr[row + 1];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[k][m] = 0.0;
+  }
+  for (int64_t base = e0; base < e1; base += W) {
+    const int cnt = e1 - base < W ? (int)(e1 - base) : W;
+    // stage: every load of the window is issued before the first one is used
+    int32_t c[U];
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = tid + u * 256;
+      c[u] = j < cnt ? col[base + j] : -1;
+      w[u] = (wgt && j < cnt) ? wgt[base + j] : 1.0f;
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      if (m0 + m >= count) break;
+      const T* __restrict__ x = (const T*)xs.p[m0 + m];
+      T v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = c[u] >= 0 ? x[c[u]] : (T)0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) sx[m][tid + u * 256] = (double)v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) sw[tid + u * 256] = w[u];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NK_STAGED_RPT; ++k) {
+      const int a = (int)((lo[k] > base ? lo[k] : base) - base);
+      const int b = (int)((hi[k] < base + cnt ? hi[k] : base + cnt) - base);
+      if (wgt) {
+        for (int j = a; j < b; ++j) {
+          const double wj = (double)sw[j];
+#pragma unroll
+          for (int m = 0; m < MB; ++m) acc[k][m] = __builtin_fma(wj, sx[m][j], acc[k][m]);
+        }
+      } else {
+        for (int j = a; j < b; ++j)
+#pragma unroll
+          for (int m = 0; m < MB; ++m) acc[k][m] += sx[m][j];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < NK_STAGED_RPT; ++k) {
+    const int64_t row = r0 + k * 256 + tid;
+    if (row < r1)
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+        if (m0 + m < count) ((T*)ys.p[m0 + m])[row] = (T)acc[k][m];
+  }
+}
+// NK_ROWSUM_STAGED=0: one thread per row for the short rows again (A/B; same bits)
+static inline bool nk_rowsum_staged() {
+  static const int on = nk_vec_env_int("NK_ROWSUM_STAGED", 1);
+  return on != 0;
+}
+template <typename T, int MB>
+static int nk_launch_rowsum_staged(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, int count,
+                                   const void* const* x, void* const* y, hipStream_t st) {
+  const int64_t blocks = (nrows + NK_STAGED_ROWS - 1) / NK_STAGED_ROWS;
+  if (blocks > 0x7fffffffLL) return nk_set_error(NK_ERR_UNSUPPORTED, "nk_csr_rowsum: too many rows for one launch");
+  NkPtrs xs, ys;
+  for (int m = 0; m < NK_MAX_BATCH; ++m) xs.p[m] = const_cast<void*>(x[m < count ? m : 0]), ys.p[m] = y[m < count ? m : 0];
+  hipLaunchKernelGGL((k_csr_rowsum_staged<T, MB>), dim3((unsigned)blocks, (unsigned)((count + MB - 1) / MB)), dim3(256), 0, st, nrows,
+                     rowptr, col, wgt, xs, ys, count);
+  return nk_check_launch("k_csr_rowsum_staged");
+}
+
 template <typename T, int LANES>
 static int nk_launch_rowsum(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, const void* x, void* y,
                             hipStream_t st) {
@@ -1740,7 +1841,9 @@ extern "C" int nk_csr_rowsum(int64_t nrows, const int64_t* rowptr, const int32_t
   NkProfScope ps(st, 8, lanes == 1 ? 0 : lanes == 4 ? 1 : lanes == 16 ? 2 : 3, wgt ? 0 : 1);
   NK_DISPATCH_DTYPE(dtype, {
     switch (lanes) {
-      case 1: return nk_launch_rowsum<T, 1>(nrows, rowptr, col, wgt, x, y, st);
+      case 1:
+        if (nk_rowsum_staged()) return nk_launch_rowsum_staged<T, 1>(nrows, rowptr, col, wgt, 1, &x, &y, st);
+        return nk_launch_rowsum<T, 1>(nrows, rowptr, col, wgt, x, y, st);
       case 4: return nk_launch_rowsum<T, 4>(nrows, rowptr, col, wgt, x, y, st);
       case 16: return nk_launch_rowsum<T, 16>(nrows, rowptr, col, wgt, x, y, st);
       default: return nk_launch_rowsum<T, 64>(nrows, rowptr, col, wgt, x, y, st);
@@ -1799,6 +1902,7 @@ static int nk_launch_rowsum_b(int64_t nrows, const int64_t* rowptr, const int32_
   // short rows (one lane per row: bin sums) take four members per thread; long rows keep one member per grid row (their time
   // is the gather itself, and four accumulators per lane would only cost registers)
   if constexpr (LANES == 1) {
+    if (nk_rowsum_staged()) return nk_launch_rowsum_staged<T, 4>(nrows, rowptr, col, wgt, count, x, y, st);
     hipLaunchKernelGGL((k_csr_rowsum_b<T, LANES, 4>), dim3((unsigned)blocks, (unsigned)((count + 3) / 4)), dim3(256), 0, st, nrows,
                        rowptr, col, wgt, xs, ys, count);
   } else {
@@ -1842,6 +1946,153 @@ extern "C" int nk_spmv_t(int64_t nrows, const int64_t* rowptr, const int32_t* co
     hipLaunchKernelGGL(k_spmv_t<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nrows, rowptr, col, wgt, (const T*)y, x);
   })
   return nk_check_launch("k_spmv_t");
+}
+
+// ---- LONG rows over a grid: the response re-ordered by TILES of the grid (nk_tiled_rowsum, include/niftyk.h) -----------
+// A line of sight that runs across the rows of the image touches a new cache line per pixel: with one wavefront per line
+// (k_csr_rowsum<T, 64>) every gathered operand costs a 64-byte sector of fabric traffic for 8 bytes used, and the launch runs
+// at 1.4 TB/s of algorithmic bytes (4096^2, 1e4 lines: 0.29 ms).  Here the entries are sorted by (tile of th x tw grid
+// points, row) once at set-up: a workgroup loads ITS tile of x into LDS with whole-line reads -- every point of x is read
+// once per launch -- and streams the tile's entries (uint16 position inside the tile + float32 weight: 6 bytes instead of
+// 8).  The entries of one row inside the tile, a SEGMENT, are padded to whole BLOCKS of 8: a lane loads one block with three
+// 16-byte requests, multiplies and adds its eight products in order, and the lanes of a segment -- at most 16 neighbours --
+// are joined by four shuffle steps among lanes with the same partial-sum slot; the first lane of the run stores the sum.  No
+// LDS traffic besides the gathers, no barrier after the tile is loaded: every wavefront walks its own 64-block STEPS of the
+// tile, the loads of its next step in flight while it reduces the current one.  (Measured on the way, same matrix: products
+// staged through LDS with 16 lanes per segment, 30 narrow loads per 512 entries: 0.155 ms whatever the tile shape, barriers
+// or bank conflicts -- bound by the instruction count per entry, not by bytes or latency.)  A second small launch adds a
+// row's partial sums in slot order.  No atomics; the order of every addition is a function of the plan only.
+static_assert(sizeof(uint4) == 8 * sizeof(uint16_t), "a block is eight uint16 positions = one 16-byte request");
+constexpr int NK_TILED_WAVES = 4;      // wavefronts per workgroup, each walking its own steps of the tile
+struct NkTiledArgs {
+  nk_tiled_csr m;
+  NkPtrs xs, ys;
+  double* scratch;
+};
+struct NkTiledBlock {
+  uint4 l;      // eight uint16 positions
+  float4 w0, w1;
+  int slot;
+};
+template <typename T>
+__global__ void __launch_bounds__(64 * NK_TILED_WAVES) k_tiled_partials(NkTiledArgs a) {
+  extern __shared__ __align__(16) unsigned char nk_tiled_lds[];
+  const nk_tiled_csr& m = a.m;
+  const int tile_elems = m.th * m.tw;
+  // rows of the LDS tile are one element longer than tw when tw is a power of two: the positions of a line that runs ACROSS
+  // the rows are tw apart -- a multiple of the bank period -- and would all hit one bank
+  const int pad_shift = (m.tw & (m.tw - 1)) == 0 ? 31 - __clz(m.tw) : 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, item = blockIdx.x;
+  T* tile = reinterpret_cast<T*>(nk_tiled_lds);
+  const T* __restrict__ x = (const T*)a.xs.p[blockIdx.y];
+  double* __restrict__ partial = a.scratch + (int64_t)blockIdx.y * m.n_slots;
+  const int64_t b1 = m.item_blk[item + 1];
+  int64_t blk = m.item_blk[item] + wave * 64 + lane;  // this lane's block of the wavefront's first step
+  const uint4* __restrict__ locv = reinterpret_cast<const uint4*>(m.loc);
+  const float4* __restrict__ wgtv = reinterpret_cast<const float4*>(m.wgt);
+  auto request = [&](int64_t bb) {
+    NkTiledBlock r;
+    r.slot = -1 - lane;  // (distinct negative values: lanes beyond the tile join nobody)
+    r.l = uint4{0, 0, 0, 0};
+    r.w0 = r.w1 = float4{0.f, 0.f, 0.f, 0.f};
+    if (bb < b1) r.l = locv[bb], r.w0 = wgtv[2 * bb], r.w1 = wgtv[2 * bb + 1], r.slot = m.blk_slot[bb];
+    return r;
+  };
+  NkTiledBlock cur = request(blk);
+  {  // the tile: (outer, ty, tx)
+    const int t = m.item_tile[item];
+    const int ntx = (m.nx + m.tw - 1) / m.tw, nty = (m.ny + m.th - 1) / m.th;
+    const int tx = t % ntx, ty = (t / ntx) % nty;
+    const int64_t o = t / (ntx * nty);
+    const int64_t origin = (o * m.ny + (int64_t)ty * m.th) * m.nx + (int64_t)tx * m.tw;
+    const int hh = m.ny - ty * m.th < m.th ? m.ny - ty * m.th : m.th;
+    const int ww = m.nx - tx * m.tw < m.tw ? m.nx - tx * m.tw : m.tw;
+    for (int i = tid; i < tile_elems; i += 64 * NK_TILED_WAVES) {
+      const int ly = i / m.tw, lx = i - ly * m.tw;
+      tile[i + (i >> pad_shift)] = (ly < hh && lx < ww) ? x[origin + (int64_t)ly * m.nx + lx] : (T)0;
+    }
+  }
+  __syncthreads();
+  const int64_t first = blk - lane;  // (uniform) first block of the wavefront's current step
+  for (int64_t s = first; s < b1; s += 64 * NK_TILED_WAVES) {
+    const NkTiledBlock nxt = request(s + lane + 64 * NK_TILED_WAVES);  // in flight while this step is reduced
+    const unsigned lw[4] = {cur.l.x, cur.l.y, cur.l.z, cur.l.w};
+    const float ww[8] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w, cur.w1.x, cur.w1.y, cur.w1.z, cur.w1.w};
+    double xv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int p = (int)((lw[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
+      xv[i] = (double)tile[p + (p >> pad_shift)];
+    }
+    double acc = 0.0;
+    {
+#pragma clang fp contract(off)  // rounded products, added in order: what tiled_rowsum_host states (__dmul_rn is a plain `*` here)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const double pr = (double)ww[i] * xv[i];
+        acc = acc + pr;
+      }
+    }
+    const int slot = cur.slot;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const double other = __shfl_down(acc, off, 64);
+      const int oslot = __shfl_down(slot, off, 64);
+      acc += (lane + off < 64 && oslot == slot) ? other : 0.0;
+    }
+    const int prev = __shfl_up(slot, 1, 64);
+    if (slot >= 0 && (lane == 0 || prev != slot)) partial[slot] = acc;
+    cur = nxt;
+  }
+}
+// y[row] = the row's partial sums in slot order (16 lanes per row, the lanes' sums joined by a fixed tree)
+template <typename T>
+__global__ void __launch_bounds__(256) k_tiled_rows(NkTiledArgs a) {
+  const nk_tiled_csr& m = a.m;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = gid >> 4;
+  const int q = (int)(gid & 15);
+  const double* __restrict__ partial = a.scratch + (int64_t)blockIdx.y * m.n_slots;
+  int64_t lo = 0, hi = 0;
+  if (row < m.n_rows) lo = m.row_slot[row], hi = m.row_slot[row + 1];
+  double acc = 0.0;
+  for (int64_t j = lo + q; j < hi; j += 16) acc += partial[j];
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 16);
+  if (q == 0 && row < m.n_rows) ((T*)a.ys.p[blockIdx.y])[row] = (T)acc;
+}
+
+extern "C" int nk_tiled_rowsum(const nk_tiled_csr* m, int count, const void* const* x, void* const* y, double* scratch, int dtype,
+                               void* stream) {
+  if (!m || !nk_batch_count_ok(count) || m->n_rows < 0 || m->n_items < 0 || m->n_slots < 0)
+    return nk_set_error(NK_ERR_INVALID, "nk_tiled_rowsum: bad argument");
+  if (m->n_rows == 0) return NK_OK;
+  if (!nk_all_set(x, count) || !nk_all_set(y, count) || !m->row_slot || (m->n_slots > 0 && !scratch))
+    return nk_set_error(NK_ERR_INVALID, "nk_tiled_rowsum: bad argument");
+  if (m->th < 1 || m->tw < 1 || m->th * m->tw > 32768 || m->ny < 1 || m->nx < 1)
+    return nk_set_error(NK_ERR_INVALID, "nk_tiled_rowsum: a tile holds at most 32768 grid points");
+  if (m->n_items > 0 && (!m->item_tile || !m->item_blk || !m->blk_slot || !m->loc || !m->wgt))
+    return nk_set_error(NK_ERR_INVALID, "nk_tiled_rowsum: bad argument");
+  if ((reinterpret_cast<uintptr_t>(m->loc) | reinterpret_cast<uintptr_t>(m->wgt)) & 15)
+    return nk_set_error(NK_ERR_INVALID, "nk_tiled_rowsum: loc and wgt must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  NkTiledArgs a;
+  a.m = *m;
+  a.scratch = scratch;
+  for (int k = 0; k < NK_MAX_BATCH; ++k) a.xs.p[k] = const_cast<void*>(x[k < count ? k : 0]), a.ys.p[k] = y[k < count ? k : 0];
+  NkProfScope ps(st, 8, 3, 0, count);
+  NK_DISPATCH_DTYPE(dtype, {
+    const size_t lds = sizeof(T) * (size_t)m->th * (m->tw + 1);
+    if (lds > 64 * 1024) return nk_set_error(NK_ERR_UNSUPPORTED, "nk_tiled_rowsum: tile too large for the LDS budget");
+    if (m->n_items > 0) {
+      hipLaunchKernelGGL(k_tiled_partials<T>, dim3((unsigned)m->n_items, (unsigned)count), dim3(64 * NK_TILED_WAVES), lds, st, a);
+      const int rc = nk_check_launch("k_tiled_partials");
+      if (rc != NK_OK) return rc;
+    }
+    const int64_t blocks = (m->n_rows * 16 + 255) / 256;
+    hipLaunchKernelGGL(k_tiled_rows<T>, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, st, a);
+    return nk_check_launch("k_tiled_rows");
+  })
 }
 
 // ---- inclusive prefix sum of a vector (the two log-integrations of the generic amplitude graph, reference

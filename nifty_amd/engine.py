@@ -565,6 +565,8 @@ class FusedModel:
         if response is not None:
             if int(response.n_pix) != self.N:
                 raise ValueError("response does not act on this grid")
+            if getattr(response, "grid_shape", 0) is None:
+                response.grid_shape = tuple(self.shape)  # its columns are the points of THIS grid: TIMES may run tile by tile
             self.sandwich = self.fused_direction = False  # the middle of J^T M J is not diagonal in position space
             # the likelihood lives behind the response: no likelihood epilogue to widen.  fp32 fields take the same step
             # with fp64 copies instead (`_linearize_response`): xi widened, g(s) from the fp64 transform, the response, the

@@ -435,24 +435,34 @@ def lockstep_note(values):
         _pending.extend(float(v) for v in values)
 
 
+def _steering_digest(vals):
+    """[count, d0 .. d7]: the number of scalars and the 128-bit BLAKE2b digest of their bytes as eight integers < 2^16 (exact
+    in fp64).  NaNs are canonicalised first (one quiet-NaN pattern), so that "NaN on every rank" agrees; -0.0 and +0.0 stay
+    different, like every other pair of bit patterns."""
+    import hashlib
+
+    v = np.array(vals, dtype=np.float64, copy=True)
+    v[np.isnan(v)] = np.nan
+    dig = hashlib.blake2b(v.tobytes(), digest_size=16).digest()
+    return [float(v.size)] + [float(int.from_bytes(dig[i:i + 2], "little")) for i in range(0, 16, 2)]
+
+
 def lockstep_flush():
-    """ONE collective: do all ranks hold the same steering scalars since the last flush?  max(v) and max(-v) over the ranks
-    agree with the local values iff they do.  Every rank reaches the same verdict (RuntimeError everywhere or nowhere)."""
+    """ONE collective: do all ranks hold the same steering scalars since the last flush?  max(v) and max(-v) of a digest of
+    their BYTES over the ranks agree with the local digest iff the digests are equal on all ranks.  Every rank reaches the same verdict (RuntimeError everywhere or nowhere)."""
     comm = lockstep_comm()
     if comm is None:
         del _pending[:]
         return
-    # A FIXED-SIZE digest, so that the collective has the same shape on every rank even when the ranks disagree on HOW
+    # A FIXED-SIZE message, so that the collective has the same shape on every rank even when the ranks disagree on HOW
     # MANY decisions they took since the last flush (one more line-search probe on one rank -- exactly the kind of slip this
-    # check exists for; with a message of 2 * len(_pending) values the all-reduce itself would have hung or failed):
-    # [count, sum of the scalars, sum of their squares, an order-sensitive fold], each with its negative under MAX.
-    vals = np.nan_to_num(np.asarray(_pending, dtype=np.float64), nan=1.23456789e300, posinf=1.7e308, neginf=-1.7e308)
+    # check exists for; with a message of 2 * len(_pending) values the all-reduce itself would have hung or failed).  It is
+    # EXACT in the scalars' bits (ADVICE r5: sums and folds of the values absorb a last-bit difference in their own
+    # rounding): the count and a 128-bit BLAKE2b digest of the raw fp64 bytes, cut into eight 16-bit integers that fp64
+    # carries exactly, each with its negative under MAX.
+    vals = np.ascontiguousarray(_pending, dtype=np.float64)
     del _pending[:]
-    scaled = vals * 2.0 ** -520  # (squares of the inf stand-ins stay finite)
-    fold = 0.0
-    for k, v in enumerate(scaled):
-        fold = 0.61803398875 * fold + (k % 7 + 1) * v
-    mine = torch.tensor([float(len(vals)), float(scaled.sum()), float((scaled * scaled).sum()), fold], dtype=torch.float64)
+    mine = torch.tensor(_steering_digest(vals), dtype=torch.float64)
     both = torch.cat([mine, -mine]).to(comm.scalar_device())
     comm._staged(both, lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX, group=comm.group))
     both = both.cpu()

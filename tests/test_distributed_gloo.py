@@ -555,6 +555,22 @@ def _lockstep_worker(rank, world, port, out):
         res["order_caught"] = False
     except RuntimeError as exc:
         res["order_caught"] = "left lockstep" in str(exc)
+    # one scalar moved by ONE ulp next to large ones (a sum / sum of squares / fold of the values rounds that
+    # away; the digest of the bytes does not), and tiny values whose squares underflow
+    try:
+        with parallel.lockstep(comm):
+            import numpy as np
+            for v in (3.2e6, float(np.nextafter(117.3, 1e9)) if rank else 117.3, 2.9e6, -4.1e5, 8.8e5):
+                parallel.lockstep_float(v)
+        res["ulp_caught"] = False
+    except RuntimeError as exc:
+        res["ulp_caught"] = "left lockstep" in str(exc)
+    try:
+        with parallel.lockstep(comm):
+            parallel.lockstep_note([1e-6, 1e-6 * (1 + 2.0 ** -52 * rank), 5e8])
+        res["tiny_caught"] = False
+    except RuntimeError as exc:
+        res["tiny_caught"] = "left lockstep" in str(exc)
     # many decisions between two flushes need no intermediate collective
     with parallel.lockstep(comm):
         for k in range(1000):
@@ -577,7 +593,8 @@ def test_lockstep_verifies_with_one_collective_per_flush(tmp_path):
     mp.spawn(_lockstep_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     for rank in (0, 1):
         res = torch.load(out + str(rank), weights_only=False)
-        assert res == dict(agree=True, caught=True, count_caught=True, order_caught=True, many=True, forced=True), (rank, res)
+        assert res == dict(agree=True, caught=True, count_caught=True, order_caught=True, ulp_caught=True, tiny_caught=True,
+                           many=True, forced=True), (rank, res)
 
 
 def _tree_worker(rank, world, port, out):

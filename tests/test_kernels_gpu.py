@@ -373,6 +373,56 @@ print("RESULT", repr(float(kl.value)), repr(float(mean.xi.double().sum())), repr
     assert a == b
 
 
+def test_fence_free_reductions_equal_the_fenced_build():
+    """The ticket-ordered reductions publish their block partials with agent-scope atomics instead of device-scope fences
+    (nk_util.h; ADVICE r5: that leans on where this chip performs them).  `make fence` builds the same library with the
+    textbook fence protocol (-DNK_RED_FENCE=1); both run a stress mix -- dot products, CG updates and amplitude sums over
+    many launches, lengths (1 ... 2^24 + 5: one workgroup ... the full unit grid) and both dtypes, interleaved on one
+    stream so that a stale partial or ticket of the previous launch would show -- and must give the same bits."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fence = os.path.join(root, "build", "libniftyk_fence.so")
+    srcs = [os.path.join(root, "nifty_amd", "csrc", f) for f in ("nk_vec.hip", "nk_amp.hip", "nk_util.h", "libniftyk.so")]
+    if not os.path.exists(fence) or os.path.getmtime(fence) < max(os.path.getmtime(f) for f in srcs):
+        made = subprocess.run(["make", "-C", os.path.join(root, "nifty_amd", "csrc"), "fence", "ARCH=gfx950"], capture_output=True,
+                              text=True, timeout=900)
+        assert made.returncode == 0, made.stderr[-2000:]
+    code = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, %r)
+from nifty_amd import backend as B
+from nifty_amd.engine import FusedModel
+h = hashlib.sha256()
+gen = torch.Generator(device="cuda").manual_seed(11)
+for rep in range(6):
+    for n in (1, 100, 4097, 65539, 1 << 20, (1 << 22) + 5, 1 << 24, (1 << 24) + 5):
+        for dt in (torch.float64, torch.float32):
+            a = torch.randn(n, generator=gen, device="cuda", dtype=dt)
+            b = torch.randn(n, generator=gen, device="cuda", dtype=dt)
+            h.update(B.vdot(a, b).cpu().numpy().tobytes())
+            h.update(B.vdot(b, b).cpu().numpy().tobytes())
+model = FusedModel((256, 320), offset_mean=2.0, likelihood="gaussian", icov=100.0, dtype=torch.float64, device="cuda:0")
+for rep in range(20):
+    x = 0.1 * model.draw_prior(gen)
+    model.set_data(model.signal(x), 100.0)
+    lp = model.linearize(x)
+    q = model.metric(lp, model.draw_prior(gen))
+    h.update(lp.value.cpu().numpy().tobytes()); h.update(lp.grad.small.cpu().numpy().tobytes()); h.update(q.small.cpu().numpy().tobytes())
+print("RESULT", h.hexdigest())
+""" % root
+
+    def run(lib=None):
+        env = dict(os.environ, **({"NK_LIB_PATH": lib} if lib else {}))
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1]
+
+    assert run() == run(fence)
+
+
 def test_launch_variants_of_the_metric_agree():
     """One metric application of a 3-D model through every selectable variant of its kernels -- QUAD / row-tile launches of the
     contiguous first pass (NK_CONTIG_QUAD 1 / 0 / 2: library statics, hence child processes), `da` expanded in sorted or

@@ -184,3 +184,129 @@ def test_spmv_kernels_against_scipy_on_a_larger_response():
         got = R.adjoint(ift.makeField(R.target, y.astype(dt), 0)).asnumpy()
         ref = (m.T @ y.astype(dt).astype(np.float64)).reshape(sp.shape)
         assert gl.relerr(got, ref) < tol
+
+
+# ---- the response re-ordered by grid tiles (round 6: nk_tiled_rowsum) and the staged short-row sums -----------------------
+def _random_csr(rng, n_rows, n_cols, lengths):
+    rowptr = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    col = np.concatenate([np.sort(rng.choice(n_cols, size=k, replace=False)) for k in lengths] + [np.zeros(0, dtype=np.int64)])
+    return rowptr, col.astype(np.int32), rng.normal(size=len(col)).astype(np.float32)
+
+
+@pytest.mark.parametrize("shape,tile", [((150, 200), (32, 64)), ((150, 200), (16, 16)), ((37,), (None, None)),
+                                        ((5, 40, 70), (32, 64)), ((64, 64), (64, 64)), ((300, 20), (8, 4))])
+def test_tiled_plan_reproduces_the_matrix(shape, tile):
+    """los_response.tiled_plan (the set-up side of nk_tiled_rowsum): the two-launch sum of its segments equals the CSR
+    product for ragged tiles, 1-D / 3-D grids, empty rows, rows longer than a segment and tiles with more blocks than a
+    wavefront step."""
+    from scipy.sparse import csr_matrix
+
+    from nifty_amd import los_response as lr
+
+    rng = np.random.default_rng(3)
+    n = int(np.prod(shape))
+    lengths = rng.integers(0, min(n, 900), size=23)
+    lengths[[2, 7]] = 0                     # empty rows
+    lengths[3] = min(n, 5000)               # a row that fills whole tiles: segments are split, tiles overflow one window
+    rowptr, col, wgt = _random_csr(rng, len(lengths), n, lengths)
+    plan = lr.tiled_plan(rowptr, col, wgt, shape, *tile)
+    x = rng.normal(size=shape)
+    ref = csr_matrix((wgt, col, rowptr), shape=(len(lengths), n)) @ x.reshape(-1)
+    assert gl.relerr(lr.tiled_rowsum_host(plan, x), ref) < 1e-13
+    # every slot is used, a piece (one slot) is at most 16 consecutive blocks, padding carries weight zero
+    slots = plan["blk_slot"]
+    assert sorted(set(slots.tolist())) == list(range(plan["n_slots"])) and plan["row_slot"][-1] == plan["n_slots"]
+    runs = np.diff(np.concatenate([[0], np.nonzero(np.diff(slots))[0] + 1, [len(slots)]]))
+    assert runs.max() <= lr.TILED_SEGMAX // lr.TILED_BLOCK and len(runs) == plan["n_slots"]
+    assert len(plan["loc"]) == lr.TILED_BLOCK * len(slots) == len(plan["wgt"]) and plan["item_blk"][-1] == len(slots)
+    assert np.count_nonzero(plan["wgt"]) == np.count_nonzero(wgt)
+    # an empty matrix is a valid plan
+    empty = lr.tiled_plan(np.zeros(4, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.float32), shape, *tile)
+    assert empty["n_items"] == 0 and np.array_equal(lr.tiled_rowsum_host(empty, x), np.zeros(3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,tile", [((150, 200), (32, 64)), ((37,), (None, None)), ((5, 40, 70), (16, 32)), ((256, 192), (64, 64))])
+def test_tiled_rowsum_device_equals_its_host_emulation_bit_for_bit(shape, tile):
+    """nk_tiled_rowsum against tiled_rowsum_host (the same additions in the same order: identical bits in fp64), against
+    scipy (fp32 fields), batched = single calls, same bits on every call."""
+    import torch
+    from scipy.sparse import csr_matrix
+
+    from nifty_amd import backend as B
+    from nifty_amd import los_response as lr
+
+    rng = np.random.default_rng(4)
+    n = int(np.prod(shape))
+    lengths = rng.integers(0, min(n, 2500), size=57)
+    lengths[5] = 0
+    lengths[11] = min(n, 9000)
+    rowptr, col, wgt = _random_csr(rng, len(lengths), n, lengths)
+    plan = lr.tiled_plan(rowptr, col, wgt, shape, *tile)
+    tm = B.TiledMatrix(plan, torch.device("cuda:0"))
+    xs = [rng.normal(size=shape) for _ in range(5)]
+    want = [lr.tiled_rowsum_host(plan, x) for x in xs[:2]]
+    dev = [torch.from_numpy(x).cuda() for x in xs]
+    single = [tm.rowsum([d.reshape(-1)], [torch.empty(len(lengths), dtype=torch.float64, device="cuda")])[0] for d in dev]
+    assert np.array_equal(single[0].cpu().numpy(), want[0]) and np.array_equal(single[1].cpu().numpy(), want[1])
+    outs = tm.rowsum([d.reshape(-1) for d in dev], [torch.empty(len(lengths), dtype=torch.float64, device="cuda") for _ in dev])
+    assert all(torch.equal(a, b) for a, b in zip(outs, single))
+    m = csr_matrix((wgt, col, rowptr), shape=(len(lengths), n))
+    x32 = torch.from_numpy(xs[0].astype(np.float32)).cuda()
+    y32 = tm.rowsum([x32.reshape(-1)], [torch.empty(len(lengths), dtype=torch.float32, device="cuda")])[0]
+    assert gl.relerr(y32.cpu().numpy(), m @ xs[0].astype(np.float32).astype(np.float64).reshape(-1)) < 2e-6
+
+
+def _fma_rowsum(rowptr, col, wgt, x):
+    """Per row the sequential fused multiply-adds of k_csr_rowsum<T, 1>, exactly (rational arithmetic, one rounding each)."""
+    from fractions import Fraction
+
+    out = np.zeros(len(rowptr) - 1)
+    for r in range(len(out)):
+        acc = 0.0
+        for j in range(rowptr[r], rowptr[r + 1]):
+            w = 1.0 if wgt is None else float(wgt[j])
+            acc = float(Fraction(w) * Fraction(float(x[col[j]])) + Fraction(acc))
+        out[r] = acc
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weighted", [True, False])
+def test_staged_short_row_sums_keep_the_order_of_one_thread_per_row(weighted):
+    """nk_csr_rowsum with lanes = 1 (the transposed response, bin sums) runs staged through LDS since round 6: the additions of
+    a row are still the sequential fused multiply-adds in entry order -- checked exactly -- for rows of 0 ... 5000 entries
+    (runs that span several windows and workgroups), single and batched, fp64 and fp32."""
+    import torch
+
+    from nifty_amd import _lib as L
+    from nifty_amd import backend as B
+    from nifty_amd import batched
+
+    rng = np.random.default_rng(6)
+    n_cols = 3000
+    lengths = np.concatenate([rng.integers(0, 5, size=2600), [5000, 0, 2300], rng.integers(0, 40, size=300)])
+    rowptr = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    col = rng.integers(0, n_cols, size=rowptr[-1]).astype(np.int32)
+    wgt = rng.normal(size=rowptr[-1]).astype(np.float32) if weighted else None
+    xs = [rng.normal(size=n_cols) for _ in range(5)]
+    dev = lambda a: None if a is None else torch.from_numpy(a).cuda()  # noqa: E731
+    rp, cl, wg = dev(rowptr), dev(col), dev(wgt)
+    nrows = len(lengths)
+
+    def run(x):
+        y = torch.empty(nrows, dtype=x.dtype, device="cuda")
+        L.check(L.load().nk_csr_rowsum(nrows, rp.data_ptr(), cl.data_ptr(), B.ptr(wg), x.data_ptr(), y.data_ptr(),
+                                       B.dtype_code(x), 1, B._stream()), "nk_csr_rowsum")
+        return y
+
+    got = run(dev(xs[0]))
+    assert np.array_equal(got.cpu().numpy(), _fma_rowsum(rowptr, col, wgt, xs[0]))
+    singles = [run(dev(x)) for x in xs]
+    ys = [torch.empty(nrows, dtype=torch.float64, device="cuda") for _ in xs]
+    batched.rowsum((rp, cl, wg) if weighted else (rp, cl, 1), [dev(x) for x in xs], ys, weighted=True if weighted else None,
+                   lanes=1, nrows=nrows)
+    assert all(torch.equal(a, b) for a, b in zip(ys, singles))
+    x32 = dev(xs[1].astype(np.float32))
+    ref = _fma_rowsum(rowptr, col, wgt, xs[1].astype(np.float32).astype(np.float64)).astype(np.float32)
+    assert np.array_equal(run(x32).cpu().numpy(), ref)
