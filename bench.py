@@ -40,7 +40,22 @@ from nifty_amd.minimization import AbsDeltaEnergyController, NewtonCG  # noqa: E
 
 # streams of the fused CG vector update: x, r (read + write), d, q -- plus b when the energy is re-evaluated from x.b
 CG_STREAMS = 7.0 if os.environ.get("NK_CG_ENERGY_RECURRENCE", "1") == "0" else 6.0
-PMC_TRAFFIC_FILE = os.environ.get("NK_PMC_FILE", "r05_pmc_traffic.json")  # latest committed PMC summary of the bench command
+PMC_TRAFFIC_FILE = os.environ.get("NK_PMC_FILE", "r06_pmc_traffic.json")  # latest committed PMC summary of the bench command
+
+
+def kernel_source_digest():
+    """sha256 over the kernel sources (nifty_amd/csrc/*.hip, *.h and include/niftyk.h, sorted by name): what a PMC summary
+    under profiles/ must have been taken at to be quoted as THIS run's traffic (there is no .git on the GPU box; VERDICT r5
+    item 2: the round-5 line quoted counters of a kernel generation older than the one it timed)."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in sorted(glob.glob(os.path.join(ROOT, "nifty_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "nifty_amd", "csrc", "*.h"))
+                       + [os.path.join(ROOT, "include", "niftyk.h")]):
+        h.update(os.path.basename(name).encode())
+        h.update(open(name, "rb").read())
+    return h.hexdigest()[:16]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # transform pass kernels by profile id: strided-first pipeline (A first strided pass with prologue, B in-place strided
 # pass, C final contiguous pass with epilogue) and the five-pass sandwich H D H of a metric application (S1 contiguous
@@ -86,10 +101,12 @@ def kernel_symbol(kern, pro, epi, shape, dt_name, octant=True, wide=False, const
     return KERNEL_NAMES.get(kern, str(kern))
 
 
-def rowsum_bytes(nnz, nrows, b, weighted=True):
-    """Algorithmic bytes of one nk_csr_rowsum launch (gather-bound SpMV): per entry the int32 column, the float32 weight
-    and ONE gathered operand value; per row the int64 row pointer and the stored sum."""
-    return nnz * (4 + (4 if weighted else 0) + b) + nrows * (8 + b)
+def rowsum_bytes(nnz, nrows, ncols, b, idx_bytes=4, ptr_bytes=8, weighted=True):
+    """Algorithmic bytes of one sparse product y = R x of the response: per entry its index and float32 weight as stored
+    (int32 column for the CSR launches, a uint16 position inside the tile for nk_tiled_rowsum: `idx_bytes`), the operand x ONCE
+    (ncols values -- round 6: until round 5 one gathered value per ENTRY was credited, which is what the wavefront-per-row
+    kernel moved, not what the product needs), per row the row pointer and the stored sum."""
+    return nnz * (idx_bytes + (4 if weighted else 0)) + ncols * b + nrows * (ptr_bytes + b)
 
 
 def algorithmic_bytes(kernel, pro, epi, N, b, const_mid, octant=True, ndim=3):
@@ -466,27 +483,20 @@ def main():
         mini = NewtonCG(AbsDeltaEnergyController(0.5, convergence_level=2, iteration_limit=3), max_cg_iterations=20)
         # C4: geoVI, the non-linear sample fit of demos/cl/getting_started_3.py:125-127
         geo = NewtonCG(AbsDeltaEnergyController(0.5, iteration_limit=5, convergence_level=2)) if cfg == "C4" else None
-        if not phase_timing:
-            new_mean, kl = mgvi_iteration(model, mean, pairs, ic, mini, mirror_samples=True, comm=comm,
-                                          device_rng=rng_draws, geo_minimizer=geo)
-            return new_mean, kl.value
-        # the three phases of engine.mgvi_iteration with a device synchronisation between them (NK_BENCH_PHASES, default on
-        # for world > 1 and for grids >= 2^27 points, where three extra synchronisations per step are noise): sampling has no
-        # exchange, the KL construction one all-reduce, the Newton-CG one exchange per CG iteration
+        # the timed code is the engine's own entry point; with NK_BENCH_PHASES (default on for world > 1 and for grids >= 2^27
+        # points, where three extra synchronisations per step are noise) a hook at its phase boundaries synchronises the
+        # device and reads the clock: sampling has no exchange, the KL construction one all-reduce, the Newton-CG one exchange
+        # per CG iteration
         marks = [time.perf_counter()]
-        residuals, negs, n_total = draw_samples(model, mean, pairs, True, ic, comm, rng_draws, geo)
-        torch.cuda.synchronize(device)
-        marks.append(time.perf_counter())
-        kl = FusedKL(model, mean, residuals, negs, n_total, comm)
-        torch.cuda.synchronize(device)
-        marks.append(time.perf_counter())
-        with parallel.lockstep(comm):
-            kl, _ = mini(kl)
-        torch.cuda.synchronize(device)
-        marks.append(time.perf_counter())
-        for name, a, b in zip(("sampling", "kl_construction", "newton_cg"), marks[:-1], marks[1:]):
-            phases[name] = phases.get(name, 0.0) + (b - a)
-        return kl.position, kl.value
+
+        def on_phase(name):
+            torch.cuda.synchronize(device)
+            marks.append(time.perf_counter())
+            phases[name] = phases.get(name, 0.0) + (marks[-1] - marks[-2])
+
+        new_mean, kl = mgvi_iteration(model, mean, pairs, ic, mini, mirror_samples=True, comm=comm, device_rng=rng_draws,
+                                      geo_minimizer=geo, on_phase=on_phase if phase_timing else None)
+        return new_mean, kl.value
 
     def sync():
         if comm is not None:
@@ -579,12 +589,13 @@ def main():
                 # per row: a few lines per pixel) of the response; the unweighted launches are bin sums of static index maps
                 if c4 is None or epi != 0:
                     continue
-                name = "k_csr_rowsum<R>" if pro >= 2 else "k_csr_rowsum<R^T>"
-                nrows = c4["n_data"] if pro >= 2 else N
+                tiled = pro >= 2 and response.tiled(device) is not None
+                name = ("nk_tiled_rowsum<R>" if tiled else "k_csr_rowsum<R>") if pro >= 2 else "k_csr_rowsum<R^T>"
                 ent = spmv.setdefault(name, dict(ms=0.0, cnt=0, bytes=0.0))
                 ent["ms"] += ms
                 ent["cnt"] += cnt
-                ent["bytes"] += cnt * rowsum_bytes(c4["nnz"], nrows, b)
+                ent["bytes"] += cnt * (rowsum_bytes(c4["nnz"], c4["n_data"], N, b, idx_bytes=2 if tiled else 4) if pro >= 2
+                                       else rowsum_bytes(c4["nnz"], N, c4["n_data"], b))
                 continue
             ent = by_kernel.setdefault(kern, dict(ms=0.0, cnt=0, bytes=0.0))
             ent["ms"] += ms
@@ -612,14 +623,18 @@ def main():
             achieved = ent["bytes"] / ent["cnt"] / (avg_ms * 1e-3) / 1e9
             # PMC counters cannot be read from inside the run: they come from separate rocprofv3 --pmc passes of this
             # very command (tools/pmc_bench.sh), whose summary is committed under profiles/ -- named in traffic_source
-            traffic, traffic_source = None, None
+            traffic, traffic_source, traffic_stale = None, None, None
             tfile = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
             if os.path.exists(tfile) and world == 1:
                 tj = json.load(open(tfile))
                 if tj.get("workload") == f"{'x'.join(map(str, shape))}:{dt_name}":
-                    traffic = tj["kernels"].get(KERNEL_NAMES[kern], {}).get("bytes")
-                    traffic_source = (f"profiles/{PMC_TRAFFIC_FILE} (separate rocprofv3 --pmc passes of this command at "
-                                      f"commit {tj.get('commit', '?')}, not this run)")
+                    # only counters taken on THESE kernel sources are this run's traffic
+                    traffic_stale = tj.get("kernel_source_digest") != kernel_source_digest()
+                    if not traffic_stale:
+                        traffic = tj["kernels"].get(KERNEL_NAMES[kern], {}).get("bytes")
+                    traffic_source = (f"profiles/{PMC_TRAFFIC_FILE} (separate rocprofv3 --pmc passes of this command on kernel "
+                                      f"sources {tj.get('kernel_source_digest', '?')}, commit {tj.get('commit', '?')}; this run: "
+                                      f"{kernel_source_digest()}" + (" -- STALE, not quoted)" if traffic_stale else ")"))
             # the same launches by DEVICE SYMBOL (what rocprofv3 --kernel-trace lists): a symbol can serve several families
             # (the in-place strided pass is one symbol for the sandwich's middle-axis passes and the second pass of a
             # value / gradient transform)
@@ -633,6 +648,7 @@ def main():
                                                 frac=round(tse["bytes"] / max(tse["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4)),
                             achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                             unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
+                            traffic_stale=traffic_stale,
                             avg_launch_ms=round(avg_ms, 4), launches=int(ent["cnt"]),
                             algorithmic_bytes_per_launch=ent["bytes"] / ent["cnt"],
                             all_pass_kernels={KERNEL_NAMES[k]: dict(ms_total=round(v["ms"], 2), launches=int(v["cnt"]),
@@ -642,9 +658,9 @@ def main():
                                                       GBps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
                                               for k, v in sorted(by_symbol.items(), key=lambda kv: -kv[1]["ms"])})
             if spmv:
-                # gather-bound sparse products of the response (C4): algorithmic bytes = per entry column + weight + one
-                # gathered operand, per row pointer + result (rowsum_bytes); against the same 8 TB/s peak
-                roofline["spmv"] = {k: dict(bound="hbm (gather)", ms_total=round(v["ms"], 2), launches=int(v["cnt"]),
+                # sparse products of the response (C4): algorithmic bytes = per entry index + weight, the operand once, per
+                # row pointer + result (rowsum_bytes); against the same 8 TB/s peak
+                roofline["spmv"] = {k: dict(bound="hbm", ms_total=round(v["ms"], 2), launches=int(v["cnt"]),
                                             avg_launch_ms=round(v["ms"] / v["cnt"], 4),
                                             algorithmic_bytes_per_launch=v["bytes"] / v["cnt"],
                                             achieved=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1), peak=HBM_PEAK_GBS,
@@ -680,8 +696,8 @@ def main():
             # geoVI with a response: energy evaluations and metric applications of the sample fits are transform pairs that
             # are neither `metric` nor `value_grad` of the KL -- price every transform pair like a metric application
             # (2 x 2DNb + 4Nb + 8N) plus its two sparse products
-            step_bytes = 0.5 * counts["transforms"] * (B_met + rowsum_bytes(c4["nnz"], c4["n_data"], b)
-                                                       + rowsum_bytes(c4["nnz"], N, b))
+            step_bytes = 0.5 * counts["transforms"] * (B_met + rowsum_bytes(c4["nnz"], c4["n_data"], N, b)
+                                                       + rowsum_bytes(c4["nnz"], N, c4["n_data"], b))
         line = {
             "metric": f"MGVI iters/sec on {shape_label} RGSpace CorrelatedField, {2 * n_pairs} samples; achieved HBM GB/s",
             "value": args.steps / elapsed,

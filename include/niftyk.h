@@ -320,6 +320,21 @@ typedef struct nk_tiled_csr {
 int nk_tiled_rowsum(const nk_tiled_csr* m, int count, const void* const* x, void* const* y, double* scratch, int dtype,
                     void* stream);
 
+/* nk_roll: out[(i_0 + shift_0) mod n_0, ..., (i_{d-1} + shift_{d-1}) mod n_{d-1}] = in[i_0, ..., i_{d-1}] for a contiguous
+ * C-ordered array of `ndim` <= 6 axes (any integer shifts); elements are opaque units of elem_bytes = 4, 8 or 16.  Replaces
+ * np.fft.fftshift / ifftshift of FFTShiftOperator.apply (operators/harmonic_operators.py:420-423).  in != out. */
+int nk_roll(int ndim, const int64_t* shape, const int64_t* shift, int elem_bytes, const void* in, void* out, void* stream);
+
+/* nk_bluestein_rows: out[r][k] = scale * sum_j in[r][j] exp(-+ 2 pi i j k / n) for `rows` contiguous rows of ANY length n in
+ * one launch (chirp-z; what ducc0's c2c does for the prime lengths of test_fft_operator.py:58-103): w[n] = the chirp
+ * exp(-+ i pi j^2 / n) (its sign is the transform's direction), bhat_br[m] = the length-m FFT of the filter
+ * b[j] = conj(w)[|j|] (cyclic) in BIT-REVERSED order, tw[m/2] = exp(-2 pi i k / m); m = a power of two >= max(4, 2 n - 1)
+ * with m * sizeof(complex) <= 64 KiB.  dtype NK_F32 / NK_F64 = complex64 / complex128.  in_real != 0: the input rows are
+ * real (promotion of the first axis of a real transform); out_hartley = +-1: the output rows are real, Re X + out_hartley Im X
+ * (the Hartley combination behind the last axis; ducc_dispatch.py:88-100), else complex.  in may equal out for complex ends. */
+int nk_bluestein_rows(int64_t rows, int n, int m, const void* in, const void* w, const void* bhat_br, const void* tw, void* out,
+                      double scale, int in_real, int out_hartley, int dtype, void* stream);
+
 /* inclusive prefix sums out[i] = sum_{j<=i} in[j] (reverse != 0: suffix sums), fp64 accumulation: the cumulative sums of
  * _TwoLogIntegrations in the GENERIC amplitude graph (library/correlated_fields.py:147-161); in and out may not overlap
  * partially (in == out is fine) */

@@ -27,8 +27,8 @@ from .probing import StatCalculator, approximation2endo  # noqa: F401
 from .operators import PrependKey  # noqa: F401
 from .operators import (Adder, BlockDiagonalOperator, ChainOperator, ContractionOperator, CountingOperator,  # noqa: F401
                         DiagonalOperator, HarmonicSmoothingOperator, IntegrationOperator,
-                        DOFDistributor, EndomorphicOperator, FFTOperator, FieldAdapter, HarmonicTransformOperator,
-                        HartleyOperator, Linearization, LinearOperator, MaskOperator, NullOperator, Operator, OperatorAdapter,
+                        DOFDistributor, EndomorphicOperator, FFTOperator, FFTShiftOperator, FieldAdapter,
+                        HarmonicTransformOperator, HartleyOperator, InversionEnabler, Linearization, LinearOperator, MaskOperator, NullOperator, Operator, OperatorAdapter,
                         PowerDistributor, Realizer, SamplingEnabler, SandwichOperator, ScalingOperator, SumOperator,
                         Variable, VdotOperator, ducktape, makeOp)
 from .los_response import LOSResponse  # noqa: F401

@@ -95,6 +95,8 @@ SIGNATURES = {
     "nk_cplx_rows": (_i, [_i64, _i64, _i64, _vp, _vp, _vp, _i, _d, _i, _i, _vp]),
     "nk_csr_rowsum": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "nk_tiled_rowsum": (_i, [ctypes.POINTER(TiledCsr), _i, _vp, _vp, _vp, _i, _vp]),
+    "nk_bluestein_rows": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp]),
+    "nk_roll": (_i, [_i, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _i, _vp, _vp, _vp]),
     "nk_spmv": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "nk_spmv_t": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "nk_pindex_from_k2": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp]),

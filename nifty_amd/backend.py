@@ -7,6 +7,7 @@ fallback: a CPU tensor handed to these functions raises.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -154,6 +155,33 @@ def _chirp(n, cdt, inverse, device):
     return ent
 
 
+BLUESTEIN_LDS_BYTES = 64 * 1024  # nk_bluestein_rows keeps one padded row of m complex values in LDS
+_blu_tables = {}
+
+
+def _bluestein_tables(n, m, cdt, inverse, device):
+    """(chirp w[n], spectrum of the chirp filter in bit-reversed order [m], twiddles exp(-2 pi i k / m) [m/2]) of
+    nk_bluestein_rows -- host set-up in complex128 (angles from k^2 mod 2n in integers), rounded to the field's precision."""
+    key = (n, m, cdt, bool(inverse), device.index)
+    ent = _blu_tables.get(key)
+    if ent is None:
+        k = np.arange(n, dtype=np.int64)
+        ang = (k * k % (2 * n)).astype(np.float64) * (np.pi / n)
+        w = np.exp(1j * ang if inverse else -1j * ang)
+        b = np.zeros(m, dtype=np.complex128)
+        b[:n] = w.conj()
+        b[m - n + 1:] = w.conj()[1:][::-1]
+        bhat = np.fft.fft(b)
+        bits = m.bit_length() - 1
+        rev = np.zeros(m, dtype=np.int64)
+        for bit in range(bits):
+            rev |= ((np.arange(m) >> bit) & 1) << (bits - 1 - bit)
+        tw = np.exp(-2j * np.pi * np.arange(m // 2) / m)
+        npdt = np.complex64 if cdt == torch.complex64 else np.complex128
+        ent = _blu_tables[key] = tuple(torch.from_numpy(np.ascontiguousarray(a.astype(npdt))).to(device) for a in (w, bhat[rev], tw))
+    return ent
+
+
 def cplx_rows(a, w, in_cols, out_cols, mode, scale=1.0, sgn=1):
     """nk_cplx_rows on a contiguous tensor viewed as rows x in_cols: chirp multiply with zero padding / cropping
     (mode 0), real -> complex promotion (mode 1), Hartley combine Re + sgn Im (mode 2)."""
@@ -171,29 +199,47 @@ def cplx_rows(a, w, in_cols, out_cols, mode, scale=1.0, sgn=1):
     return out
 
 
-def _fft_last_axis_any(z, inverse):
-    """Unnormalised c2c transform over the last axis of a contiguous complex tensor, any length."""
+def _fft_last_axis_any(z, inverse, real_in=False, hartley=0, scale=1.0):
+    """Unnormalised c2c transform over the last axis of a contiguous tensor, any length.  real_in: z is real (the first axis
+    of a real transform); hartley = +-1: return the real Hartley combination Re + hartley Im times `scale` (the last axis).
+    Axes served by nk_bluestein_rows take these ends inside the launch, the others through nk_cplx_rows."""
     n = z.shape[-1]
-    rdt = torch.float32 if z.dtype == torch.complex64 else torch.float64
+    rdt = z.dtype if real_in else (torch.float32 if z.dtype == torch.complex64 else torch.float64)
+    cdt = torch.complex64 if rdt == torch.float32 else torch.complex128
     batch = z.numel() // max(1, n)
+    m = 1 << max(2, (2 * n - 2).bit_length())
+    native = n == 1 or z.numel() == 0 or plan_supported((n,), rdt, batch, z.device)
+    if (not native and m * (8 if rdt == torch.float32 else 16) <= BLUESTEIN_LDS_BYTES and os.environ.get("NK_BLUESTEIN", "1") != "0"):
+        # ONE launch: the padded rows stay in LDS through both transforms of the convolution (nk_bluestein_rows)
+        w, bhat_br, tw = _bluestein_tables(n, m, cdt, inverse, z.device)
+        out = torch.empty(z.shape, dtype=rdt if hartley else cdt, device=z.device)
+        L.check(L.load().nk_bluestein_rows(batch, n, m, z.data_ptr(), w.data_ptr(), bhat_br.data_ptr(), tw.data_ptr(), out.data_ptr(),
+                                           float(scale) if hartley else 1.0, 1 if real_in else 0, int(hartley),
+                                           0 if rdt == torch.float32 else 1, _stream()), "nk_bluestein_rows")
+        return out
+    if real_in:
+        z = cplx_rows(z, None, n, n, 1)
     if n == 1 or z.numel() == 0:
-        return z.clone()
-    if plan_supported((n,), rdt, batch, z.device):
-        return fftn(z, ndim=1, inverse=inverse)
-    m = 1 << (2 * n - 2).bit_length()
-    # check BEFORE anything of length m is built: an unsupported m must end here, not re-enter this fallback
-    if m > _CHIRP_MAX or not plan_supported((m,), rdt, batch, z.device) or not plan_supported((m,), rdt, 1, z.device):
-        raise NotImplementedError(f"axis of length {n} is too long for the chirp-z fallback")
-    m, w, fb = _chirp(n, z.dtype, inverse, z.device)
-    a = cplx_rows(z, w, n, m, 0)                       # x[k] w[k], zero-padded to m
-    p = cplx_rows(fftn(a, ndim=1), fb, m, m, 0)        # times the transformed chirp
-    c = fftn(p, ndim=1, inverse=True, scale=1.0 / m)   # cyclic convolution
-    return cplx_rows(c, w, m, n, 0)                    # first n entries, times w[j]
+        res = z.clone()
+    elif native:
+        res = fftn(z, ndim=1, inverse=inverse)
+    else:
+        # check BEFORE anything of length m is built: an unsupported m must end here, not re-enter this fallback
+        if m > _CHIRP_MAX or not plan_supported((m,), rdt, batch, z.device) or not plan_supported((m,), rdt, 1, z.device):
+            raise NotImplementedError(f"axis of length {n} is too long for the chirp-z fallback")
+        m, w, fb = _chirp(n, z.dtype, inverse, z.device)
+        a = cplx_rows(z, w, n, m, 0)                       # x[k] w[k], zero-padded to m
+        p = cplx_rows(fftn(a, ndim=1), fb, m, m, 0)        # times the transformed chirp
+        c = fftn(p, ndim=1, inverse=True, scale=1.0 / m)   # cyclic convolution
+        res = cplx_rows(c, w, m, n, 0)                     # first n entries, times w[j]
+    return cplx_rows(res, None, n, n, 2, scale, hartley) if hartley else res
 
 
-def _fft_any(z, ndim, inverse):
-    for ax in range(z.dim() - ndim, z.dim()):
-        z = _fft_last_axis_any(z.movedim(ax, -1).contiguous(), inverse).movedim(-1, ax)
+def _fft_any(z, ndim, inverse, real_in=False, hartley=0, scale=1.0):
+    first, last = z.dim() - ndim, z.dim() - 1
+    for ax in range(first, z.dim()):
+        z = _fft_last_axis_any(z.movedim(ax, -1).contiguous(), inverse, real_in=real_in and ax == first,
+                               hartley=hartley if ax == last else 0, scale=scale).movedim(-1, ax)
     return z.contiguous()
 
 
@@ -209,9 +255,7 @@ def hartley(x, ndim=None, scale=1.0, out=None):
     shape = x.shape[x.dim() - ndim:]
     batch = x.numel() // max(1, int(torch.Size(shape).numel()))
     if not plan_supported(shape, x.dtype, batch, x.device):
-        nl = x.shape[-1]
-        f = _fft_any(cplx_rows(x, None, nl, nl, 1), ndim, False)
-        h = cplx_rows(f, None, nl, nl, 2, scale, 1 if _convention() == 0 else -1)
+        h = _fft_any(x, ndim, False, real_in=True, hartley=1 if _convention() == 0 else -1, scale=scale)
         return h if out is None else out.copy_(h)
     plan = get_plan(shape, x.dtype, batch, x.device)
     out = torch.empty_like(x) if out is None else out
@@ -484,6 +528,20 @@ def spmv_t(rowptr, col, wgt, y, ncols):
     L.check(L.load().nk_spmv_t(y.numel(), rowptr.data_ptr(), col.data_ptr(), wgt.data_ptr(), y.data_ptr(), x64.data_ptr(),
                                dtype_code(y), _stream()), "nk_spmv_t")
     return x64.to(y.dtype)  # dtype conversion copy only (same convention as scatter_add's callers)
+
+
+def roll(x, shifts):
+    """numpy.roll(x, shifts, axes=all) for a device tensor of any element type of 4, 8 or 16 bytes (real or complex): one
+    nk_roll launch, a fresh array."""
+    _require_device(x)
+    x = x.contiguous()
+    if x.dim() == 0 or x.dim() > 6 or x.element_size() not in (4, 8, 16):
+        raise NotImplementedError("roll: 1 to 6 axes, elements of 4, 8 or 16 bytes")
+    out = torch.empty_like(x)
+    nd = x.dim()
+    L.check(L.load().nk_roll(nd, (ctypes.c_int64 * nd)(*x.shape), (ctypes.c_int64 * nd)(*[int(v) for v in shifts]), x.element_size(),
+                             x.data_ptr(), out.data_ptr(), _stream()), "nk_roll")
+    return out
 
 
 def stats(x):

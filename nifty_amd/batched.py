@@ -439,7 +439,7 @@ class BatchCgScalars:
         return self.fetch_end()
 
 
-def solve_together(model, lp, jobs, controller_factory):
+def solve_together(model, lp, jobs, controller_factory, nreset=None):
     """engine._solve_on_lanes as batched launches: the solves (J^T M J + 1) y_j = b_j = s_j + nj_j at ONE linearisation point
     (kl_energies.py:132-158), started at the prior draws s_j, advance together -- one launch set per CG iteration for all
     unfinished solves, one host synchronisation per iteration for all of them.  Per solve the arithmetic, the stopping
@@ -533,7 +533,7 @@ def solve_together(model, lp, jobs, controller_factory):
             refreshed = False
             # (ConjugateGradient's nreset) r = A x - b -- unless every solve stops at its iteration limit now anyway
             # (minimization._forced_stop: the residual of a final iterate is never read)
-            if since_reset >= 20 and not all(M._forced_stop(controllers[m]) for m in active):
+            if since_reset >= (M.CG_NRESET if nreset is None else nreset) and not all(M._forced_stop(controllers[m]) for m in active):
                 axs = [LatentVec(torch.empty_like(v.xi), None) for v in x_a]
                 metric(model, Scratch(model, k), pts, x_a, axs, 1.0, [(v, 1.0) for v in x_a])
                 for r, ax, b in zip(r_a, axs, b_a):

@@ -670,6 +670,7 @@ struct nk_plan {
   void* d_tw_b = nullptr;
   void* d_tw_c = nullptr;
   void* d_tw_f = nullptr;   // full-length table of the last axis (final pass of the strided-first pipeline)
+  void* d_tw_t64 = nullptr, *d_tw_t32 = nullptr;  // sub-line tables of the two-level first-axis pass (2-D plans)
   // c2c: full-length contiguous-axis plan
   NkPassCC cc{};
   int threads_cc = 256;
@@ -730,6 +731,8 @@ extern "C" int nk_plan_create(nk_plan** out, int ndim, const int64_t* shape, int
   if (rc == NK_OK && ndim == 3) rc = nk_upload_twiddle(&P->d_tw_b, hp.tw_b, dtype);
   if (rc == NK_OK && ndim >= 2) rc = nk_upload_twiddle(&P->d_tw_c, hp.tw_c, dtype);
   if (rc == NK_OK && ndim >= 2) rc = nk_upload_twiddle(&P->d_tw_f, hp.tw_f, dtype);
+  if (rc == NK_OK && ndim == 2) rc = nk_upload_twiddle(&P->d_tw_t64, hp.tw_t64, dtype);
+  if (rc == NK_OK && ndim == 2) rc = nk_upload_twiddle(&P->d_tw_t32, hp.tw_t32, dtype);
   // c2c plan pieces: contiguous last axis of full length nl, strided middle/first axes with inner = nl
   if (rc == NK_OK) {
     const NkGeom& g = hp.g;
@@ -802,7 +805,7 @@ extern "C" int nk_plan_create(nk_plan** out, int ndim, const int64_t* shape, int
 
 extern "C" int nk_plan_destroy(nk_plan* P) {
   if (!P) return NK_OK;
-  void* ptrs[] = {P->d_tw_a, P->d_twr_a, P->d_tw_b, P->d_tw_c, P->d_tw_cc, P->d_tw_f};
+  void* ptrs[] = {P->d_tw_a, P->d_twr_a, P->d_tw_b, P->d_tw_c, P->d_tw_cc, P->d_tw_f, P->d_tw_t64, P->d_tw_t32};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete P;
@@ -1066,8 +1069,13 @@ static int nk_run_hartley(const nk_plan* P, const NkFuse& f, int convention, voi
       ProfScope ps(st, 2, f.pro, f.epi);
       rc = nk_dispatch_strided<T, 0>(hp.g.na, q.s0, f, (const C2<T>*)P->d_tw_c, work, scratch, st);
     } else {
-      ProfScope ps(st, 1, f.pro, f.epi);
-      rc = nk_dispatch_strided<T, 3>(hp.g.na, q.s1, f, (const C2<T>*)P->d_tw_c, work, scratch, st);
+      ProfScope ps(st, 1, f.pro, f.epi);  // (the two launches of a two-level pass count as ONE first-axis pass)
+      int n1, n2;
+      if (nk_tl_split<T>(hp.g, n1, n2))
+        rc = nk_tl_first_axis<T>(q.s1, n1, n2, f, (const C2<T>*)P->d_tw_t64, (const C2<T>*)(n2 == 64 ? P->d_tw_t64 : P->d_tw_t32),
+                                 (const C2<T>*)P->d_tw_c, work, st);
+      else
+        rc = nk_dispatch_strided<T, 3>(hp.g.na, q.s1, f, (const C2<T>*)P->d_tw_c, work, scratch, st);
     }
     if (rc != NK_OK) return rc;
     const NkPassF& pf = q.pf;
@@ -1264,7 +1272,12 @@ static int nk_run_hartley_batch(const nk_plan* P, const nk_fuse* fuse, int count
   int rc;
   {
     NkProfScope ps(st, 1, fuse[0].pro, fuse[0].epi, count);
-    rc = nk_dispatch_strided<T, 3>(hp.g.na, q.s1, fuse[0], (const C2<T>*)P->d_tw_c, (C2<T>*)bc.wa.work[0], (C2<T>*)bc.wa.scratch[0], st);
+    int n1, n2;
+    if (nk_tl_split<T>(hp.g, n1, n2))
+      rc = nk_tl_first_axis<T>(q.s1, n1, n2, fuse[0], (const C2<T>*)P->d_tw_t64, (const C2<T>*)(n2 == 64 ? P->d_tw_t64 : P->d_tw_t32),
+                               (const C2<T>*)P->d_tw_c, (C2<T>*)bc.wa.work[0], st);
+    else
+      rc = nk_dispatch_strided<T, 3>(hp.g.na, q.s1, fuse[0], (const C2<T>*)P->d_tw_c, (C2<T>*)bc.wa.work[0], (C2<T>*)bc.wa.scratch[0], st);
   }
   if (rc != NK_OK) return rc;
   if (any) {

@@ -158,6 +158,7 @@ struct Sched;
 #define NK_SCHED(TT, NN, EE, SS, A, B, C) \
   template <>                              \
   struct Sched<TT, NN> : SchedDef<NN, EE, SS, A, B, C> {}
+NK_SCHED(float, 32, 8, 2, 8, 4, 1);  // (sub-lines of the two-level first-axis pass only)
 NK_SCHED(float, 64, 8, 2, 8, 8, 1);
 NK_SCHED(float, 128, 16, 2, 16, 8, 1);
 NK_SCHED(float, 256, 16, 2, 16, 16, 1);
@@ -165,6 +166,7 @@ NK_SCHED(float, 512, 32, 2, 32, 16, 1);
 NK_SCHED(float, 1024, 32, 2, 32, 32, 1);
 NK_SCHED(float, 2048, 32, 3, 32, 32, 2);
 NK_SCHED(float, 4096, 32, 3, 32, 32, 4);
+NK_SCHED(double, 32, 8, 2, 8, 4, 1);
 NK_SCHED(double, 64, 8, 2, 8, 8, 1);
 NK_SCHED(double, 128, 16, 2, 16, 8, 1);
 NK_SCHED(double, 256, 16, 2, 16, 16, 1);
@@ -236,7 +238,7 @@ template <typename T, int N, bool CX = false, int MODE = 3>
 struct StridedTile {
   using SC = StridedSched<T, N, MODE>;
   static constexpr int P = SC::P;
-  static constexpr int want = 128 / (2 * (int)sizeof(T));
+  static constexpr int want = (N <= 32 ? 256 : 128) / (2 * (int)sizeof(T));  // (32-point sub-lines: rows of 256 B fill a wavefront)
   static constexpr int by_threads = 1024 / P;
   static constexpr int by_lds = (128 * 1024) / (N * (int)sizeof(T));
   static constexpr int m1 = want < by_threads ? want : by_threads;
@@ -517,6 +519,9 @@ NK_HD int64_t nk_xcd_contig(int64_t blk, int64_t nb) {
 }
 
 // ---------------------------------------------------------------------------------------------
+#ifndef NK_TL_PLAIN_STORE
+#define NK_TL_PLAIN_STORE 1  // bit 0 / 1: plain instead of non-temporal stores in the first / second launch of the two-level pass
+#endif
 #ifndef NK_STRIDED_TWC
 #define NK_STRIDED_TWC 0  // experiment: composed twiddles in the strided passes (see nk_stage_compute)
 #endif
@@ -527,19 +532,36 @@ NK_HD int64_t nk_xcd_contig(int64_t blk, int64_t nb) {
 // MODE 3: FIRST pass of the strided-first pipeline: the real input (through the fused prologue) is read as
 //         complex pairs along the contiguous axis, transformed along this strided axis and written to `work`
 // MODE 0: plain in-place c2c
+// MODE 4 / 5: the TWO-LEVEL first-axis pass of 2-D grids (long fp64 lines, nk_tl_split): a line of F = N * p.sub points,
+//         j = j1 * p.sub + j2, is transformed as N-point sub-lines over j1 (MODE 4: first pass with the fused prologue, rows
+//         p.sub apart; the result X1(k1; j2) times the inter-level twiddle w_F^(j2 k1) goes to row j2 * N + k1 of `work`) and
+//         then, with the roles of the factors swapped (MODE 5, in place: N = the other factor, sub-line k1 at rows
+//         k1 + p.sub * j2), which leaves X(k1 + p.sub * k2) at row k1 + p.sub * k2: natural order for the final pass.  A tile is
+//         N <= 64 rows of 128 ... 256 bytes -- 64 threads and 4 KiB of LDS instead of 1024 threads and 128 KiB that hold
+//         4096 rows of 64 bytes -- so that many workgroups share a CU and one's arithmetic hides the other's loads.
 template <typename T, int N, int TILE, int MODE, int PC, bool CX = false, typename Exec>
 NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t blk, T* plane,
                            const C2<T>* __restrict__ tw_global, C2<T>* __restrict__ work, C2<T>* __restrict__ scratch,
-                           double* acc_out, C2<T>* tw_lds = nullptr) {
+                           double* acc_out, C2<T>* tw_lds = nullptr, const C2<T>* __restrict__ tw_full = nullptr) {
   using SC = StridedSched<T, N, MODE>;
   constexpr int E = SC::E, S = SC::S;
+  constexpr bool FIRST = MODE == 3 || MODE == 4, TL = MODE == 4 || MODE == 5;
   constexpr bool CPLX = StridedTile<T, N, CX, MODE>::CPLX && TILE == StridedTile<T, N, CX, MODE>::TILE;
   // twiddles of the later stages: from the workgroup's LDS copy when the caller provides the room (StridedTile::TWLDS)
   const C2<T>* tw = tw_lds ? tw_lds : tw_global;
   [[maybe_unused]] C2<T>* cplane = reinterpret_cast<C2<T>*>(plane);
-  if constexpr (MODE == 3 && (PC == 4 || PC == 5 || PC == 9)) blk = nk_oct_block_remap(blk, p);
-  const int64_t o = blk / p.tiles_per_slab;
+  if constexpr (FIRST && (PC == 4 || PC == 5 || PC == 9)) blk = nk_oct_block_remap(blk, p);
+  int64_t o = blk / p.tiles_per_slab;
   const int64_t c0 = (blk % p.tiles_per_slab) * (int64_t)TILE;
+  // two-level passes: o = (batch, sub-line); the sub-lines j2 and p.sub - j2 read the same rows of the octant amplitude fields
+  // (their rows are mirror images): they run back to back, 0, sub/2, 1, sub-1, 2, sub-2, ...
+  [[maybe_unused]] int tl_sub = 0;
+  [[maybe_unused]] int64_t tl_bat = 0;
+  if constexpr (TL) {
+    tl_bat = o / p.sub;
+    const int i = (int)(o - tl_bat * p.sub);
+    tl_sub = i == 0 ? 0 : i == 1 ? p.sub / 2 : ((i & 1) ? p.sub - i / 2 : i / 2);
+  }
   // MODE 3 reads the user array: line element j of column c0 at (o*N + j)*inner, and writes the work array.
   // MODE 0 runs in place on the work array.  Work layouts of the strided-first pipeline (3-D; p.ss = slab stride):
   //   blo == 0 : [batch][first] slabs of ss >= mid*last/2 elements, natural order inside
@@ -547,8 +569,12 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
   // (2-D, or ss == 0: plain natural layout)
   // Every address is split into a WAVE-UNIFORM 64-bit part (scalar registers) and a small per-thread 32-bit offset:
   // row(pp, q, r) = row(pp, 0, 0) + row(0, q, r) for both the input and the output order of a stage.
-  const int64_t in_off = o * N * p.inner + c0;
+  int64_t in_off = o * N * p.inner + c0;
   int64_t rstride = p.inner;
+  if constexpr (TL) {
+    in_off = (tl_bat * N * p.sub + tl_sub) * p.inner + c0;
+    rstride = (int64_t)p.sub * p.inner;
+  }
   C2<T>* base = work + in_off;
   if (MODE == 0 && p.ss > 0) {
     if (p.blo > 0) {  // lines over the first axis, o = batch*mid + b
@@ -562,7 +588,7 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
   ex.phase([&](int tid, PassRegs<T, E>& rg) {
     const int t = tid % TILE, pp = tid / TILE;
     constexpr int R = SC::radix(0), Q = E / R;
-    constexpr bool OCT = MODE == 3 && (PC == 4 || PC == 5 || PC == 9);
+    constexpr bool OCT = FIRST && (PC == 4 || PC == 5 || PC == 9);
     // octant amplitude fields [A/2+1][N/2+1][nl/2+1] (this axis is the middle one; A = 1 in 2-D): the two reals of
     // a pair sit at folded last-axis offsets c8a, c8b of the folded row
     [[maybe_unused]] uint32_t o8 = 0, ch = 0, c8 = 0;
@@ -581,9 +607,13 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
       for (int r = 0; r < R; ++r) {
         const int64_t uoff = (int64_t)nk_in_row<SC, 0>(0, q, r) * rstride;  // uniform part
         if constexpr (OCT) {
-          const uint32_t j8 = (o8 + (uint32_t)nk_fold(nk_in_row<SC, 0>(pp, q, r), N)) * ch + c8;  // < 2^31 elements
+          uint32_t j8;
+          if constexpr (TL)  // row of the whole line: tl_sub + p.sub * (row of the sub-line)   (2-D: o8 == 0)
+            j8 = (uint32_t)nk_fold(tl_sub + p.sub * nk_in_row<SC, 0>(pp, q, r), N * p.sub) * ch + c8;
+          else
+            j8 = (o8 + (uint32_t)nk_fold(nk_in_row<SC, 0>(pp, q, r), N)) * ch + c8;  // < 2^31 elements
           rg.v[q * R + r] = nk_prologue_oct<T, PC>(f, 2 * (in_off + uoff), 2 * toff, j8, desc);
-        } else if (MODE == 3) {
+        } else if (FIRST) {
           rg.v[q * R + r] = nk_prologue_ct<T, PC>(f, 2 * (in_off + uoff), 2 * toff);
         } else {
           rg.v[q * R + r] = (NK_NT_LOAD & 1) ? nk_ld_stream(&nk_at32<C2<T>>(base, uoff, toff)) : nk_at32<C2<T>>(base, uoff, toff);
@@ -606,6 +636,19 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
     // [batch][this axis][first][last/2]: row b -> slab b, position a
     C2<T>* obase = base;
     int64_t ostride = rstride;
+    if constexpr (MODE == 4) {
+      // sub-line tl_sub -> the N consecutive rows tl_sub * N + k1, each value times w_F^(tl_sub k1), F = N * p.sub
+      obase = work + (tl_bat * p.sub + tl_sub) * N * p.inner + c0;
+      ostride = p.inner;
+      const int fmask = N * p.sub - 1;
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int k1 = nk_out_row<SC, LS>(pp, q, r);
+          rg.v[q * R + r] = cmul(rg.v[q * R + r], tw_full[(tl_sub * k1) & fmask]);
+        }
+    }
     if (MODE == 3 && p.ss > 0) {
       if (p.blo > 0) {
         const int64_t bat = o / p.g.na, a = o % p.g.na;
@@ -621,7 +664,9 @@ NK_HD void nk_strided_body(Exec& ex, const NkPassS& p, const NkFuse& f, int64_t 
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int64_t uo = (int64_t)nk_out_row<SC, LS>(0, q, r) * ostride;
-        if constexpr (S == 2)  // thread part = pp * ostride + t (small): 32-bit byte offset from a scalar base
+        if constexpr ((MODE == 4 && (NK_TL_PLAIN_STORE & 1)) || (MODE == 5 && (NK_TL_PLAIN_STORE & 2)))  // (the next launch reads these rows: leave them to the cache)
+          *nk_ptr32<C2<T>>(obase, uo, toff) = rg.v[q * R + r];
+        else if constexpr (S == 2)  // thread part = pp * ostride + t (small): 32-bit byte offset from a scalar base
           nk_store_stream(nk_ptr32<C2<T>>(obase, uo, toff), rg.v[q * R + r]);
         else
           nk_store_stream((obase + uo) + toff, rg.v[q * R + r]);
@@ -1545,6 +1590,30 @@ static inline bool nk_fast_contig_ok(int h) { return nk_fast_size(h); }
 // pass parameters of the strided-first pipeline (shared by the HIP driver and the host emulation)
 // ---------------------------------------------------------------------------------------------
 #include "nk_plan.h"
+// Two-level first-axis pass of 2-D grids (nk_strided_body MODE 4 / 5): n = n1 * n2, n1-point sub-lines in the first launch,
+// n2-point ones in the second.  The single-kernel pass holds a whole line per workgroup: at 4096 fp64 points that is 1024 threads
+// with rows of 64 bytes and ONE workgroup per CU (the register file admits 4 columns), whose loads, arithmetic and stores do
+// not overlap: 112 us per plain pass at 4096^2 where its access pattern alone takes 57 (tools/micro/col_tile_bench.hip).
+// Measured, round 6 (rocprofv3 on tools/gpu_fused_probe.py 4096,4096 f64; profiles/r06_two_level_*): two launches of 64-row
+// tiles take 54 + 48 = 102 us plain (-9 %), 109 + 48 against 177 with the JVP prologue (-11 %), 69 + 48 against 125 with the
+// amplitude prologue -- each launch streams at the 5 TB/s of an HBM copy, the second one partly out of the Infinity Cache
+// when the first leaves its rows there (plain instead of non-temporal stores: 63 -> 54 us for the first, 52 -> 48 us for the
+// second launch; NK_TL_PLAIN_STORE).  At 2048 fp64 points (rows of 128 bytes already, 32 MiB fields that live in the cache)
+// the second launch costs more than the overlap gains: 29 against 22 us per member -- single kernel kept.  Default: fp64
+// lines of 4096 points; NK_TWO_LEVEL=0: never, =2: also 2048 (fp64) and 4096 (fp32).  The two schedules round differently.
+template <typename T>
+static inline bool nk_tl_split(const NkGeom& g, int& n1, int& n2) {
+#ifdef NK_HOST_EMU
+  const int on = nk_env_int("NK_TWO_LEVEL", 1);  // (tests switch it per call)
+#else
+  static const int on = nk_env_int("NK_TWO_LEVEL", 1);
+#endif
+  n1 = n2 = 0;
+  if (!on || g.ndim != 2) return false;
+  if (g.na == 4096 && (sizeof(T) == 8 || on >= 2)) n1 = 64, n2 = 64;
+  else if (g.na == 2048 && sizeof(T) == 8 && on >= 2) n1 = 64, n2 = 32;
+  return n1 > 0;
+}
 #define NK_WORK_PAD_MAX 8192  // elements; the plan's workspace reserves this much per slab
 #include "nk_fft3.h"
 struct NkPipe2 {

@@ -113,6 +113,13 @@ int nk_twin_launch_strided(const NkPassS& ps, int64_t blocks, const C2<T>* tw, i
 template <typename T, int NL, bool COUPLES, int EC>
 int nk_twin_launch_final(const NkPassF& pf, int64_t blocks, const C2<T>* tw, int xmap, hipStream_t st);
 
+// the two launches of the two-level first-axis pass (nk_fft2.h: nk_tl_split, nk_strided_body MODE 4 / 5), defined in
+// nk_fft_t.hip: sub-lines of n1 points through the prologue class of `f` (run-time class for the rare ones), then n2-point
+// sub-lines in place.  Inside nk_hartley_fused_batch (t_batch set) both launches cover all members (grid.y).
+template <typename T>
+int nk_tl_first_axis(const NkPassS& s1, int n1, int n2, const NkFuse& f, const C2<T>* tw_n1, const C2<T>* tw_n2, const C2<T>* tw_full,
+                     C2<T>* work, hipStream_t st);
+
 // nk_hartley_sandwich_pair's final-pass launch (k2_final2): defined and explicitly instantiated in nk_fft_p.hip
 template <typename T, int NL>
 int nk_launch_final_pair(NkPassF pf, const NkFuse& fa, const NkFuse& fb, const C2<T>* tw, const C2<T>* worka, const C2<T>* workb,

@@ -121,6 +121,7 @@ struct NkPassS {
   int tiles_per_slab;  // inner / tile
   int blo;             // strided-first pipeline, 3-D: work array blocked as [batch][mid/blo][first][blo][last/2] (0: natural)
   int64_t ss;          // ... and its slab stride in elements (>= slab size: padding de-aliases the power-of-two strides)
+  int sub;             // two-level first-axis pass (nk_strided_body MODE 4 / 5): the OTHER factor of the line length, else 0
 };
 
 // columns of the tile that starts at column c0 of its slab which exist (tiles need not divide the slab width)

@@ -67,6 +67,7 @@ struct NkHostPlan {
   size_t lds_b = 0, lds_c = 0;
   // twiddles (as double pairs; converted to the plan dtype when uploaded)
   std::vector<double> tw_a, twr_a, tw_b, tw_c, tw_f;  // tw_f: full-length table of the last axis (final pass)
+  std::vector<double> tw_t64, tw_t32;                 // sub-line tables of the two-level first-axis pass (2-D)
   size_t work_bytes = 0, scratch_bytes = 0;
 };
 
@@ -194,6 +195,7 @@ static inline int nk_host_plan_init(NkHostPlan& P, int ndim, const int64_t* shap
   nk_fill_twiddle(P.tw_a, g.h, g.h);
   nk_fill_twiddle(P.twr_a, g.h / 2 + 1, g.nl);
   nk_fill_twiddle(P.tw_f, g.nl, g.nl);
+  if (ndim == 2) nk_fill_twiddle(P.tw_t64, 64, 64), nk_fill_twiddle(P.tw_t32, 32, 32);
   // ---- pass B / C
   auto setup_strided = [&](NkPassS& ps, int n, int64_t outer, int64_t inner, const char* env, int& threads,
                            size_t& lds, std::vector<double>& tw) {

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "nk_core.h"
 #include "nk_util.h"
 
 static constexpr int NK_VEC_THREADS = 256;
@@ -1278,6 +1279,148 @@ extern "C" int nk_cplx_rows(int64_t rows, int64_t in_cols, int64_t out_cols, con
   })
 }
 
+// ---- any-length c2c over the last axis in ONE launch (chirp-z / Bluestein; nk_bluestein_rows, niftyk.h) --------------------
+// X[k] = w[k] sum_j (x[j] w[j]) conj(w)[k-j], w[j] = exp(-+ i pi j^2 / n): a cyclic convolution of power-of-two length
+// m >= 2n - 1.  The composition in backend.py spends three c2c transforms and three element-wise launches of m-sized rows on
+// it; here a workgroup keeps its padded rows in LDS for the whole trip: chirp on the way in, decimation in frequency in place
+// (natural -> bit-reversed order), times the filter's spectrum stored in bit-reversed order, decimation in time in place
+// (bit-reversed -> natural order, conjugate twiddles), chirp and 1/m on the way out -- no reordering pass, global traffic =
+// the rows in, the rows out.  Two radix-2 levels per barrier (radix-4 butterflies in registers; one radix-2 level when
+// log2 m is odd); short rows share a workgroup (R rows of m points, R m <= 4096).  The ends of an N-D transform ride along:
+// real input rows (in_real) for the first axis, the Hartley combination Re + sgn Im (out_hartley) for the last.
+template <typename T>
+__device__ __forceinline__ C2<T> nk_cconj(C2<T> a) { return C2<T>{a.x, -a.y}; }
+template <typename T, bool INV>
+__device__ __forceinline__ C2<T> nk_blu_tw(const C2<T>* __restrict__ tw, int k) {
+  const C2<T> t = tw[k];
+  return INV ? nk_cconj(t) : t;
+}
+// rotate by -i (forward) / +i (inverse)
+template <typename T, bool INV>
+__device__ __forceinline__ C2<T> nk_blu_rot(C2<T> a) { return INV ? C2<T>{-a.y, a.x} : C2<T>{a.y, -a.x}; }
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_bluestein_rows(int64_t rows, int n, int m, int R, const void* __restrict__ in_raw,
+                                                        const C2<T>* __restrict__ w, const C2<T>* __restrict__ bhat_br,
+                                                        const C2<T>* __restrict__ tw, void* __restrict__ out_raw, T scale, int in_real,
+                                                        int out_hartley) {
+  extern __shared__ __align__(16) unsigned char nk_blu_lds[];
+  C2<T>* lds = reinterpret_cast<C2<T>*>(nk_blu_lds);
+  const int tid = threadIdx.x;
+  const int half_m = m >> 1, quarter_m = m >> 2;
+  int lg = 0;
+  while ((1 << lg) < m) ++lg;
+  const int64_t groups = (rows + R - 1) / R;
+  for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int64_t row0 = g * R;
+    const int nr = rows - row0 < R ? (int)(rows - row0) : R;
+    for (int i = tid; i < nr * m; i += 256) {
+      const int r = i / m, j = i - r * m;
+      C2<T> v{(T)0, (T)0};
+      if (j < n) {
+        const int64_t src = (row0 + r) * n + j;
+        v = in_real ? C2<T>{reinterpret_cast<const T*>(in_raw)[src], (T)0} : reinterpret_cast<const C2<T>*>(in_raw)[src];
+        v = cmul(v, w[j]);
+      }
+      lds[i] = v;
+    }
+    __syncthreads();
+    // ---- forward, decimation in frequency: spans m/2, m/4, ..., 1 -- two levels per trip
+    int span = half_m;
+    for (; span >= 2; span >>= 2) {
+      const int q = span >> 1;  // the second level's span
+      const int s1 = half_m / span, s2 = half_m / q;
+      for (int i = tid; i < nr * quarter_m; i += 256) {
+        const int r = i / quarter_m, b = i - r * quarter_m;
+        const int j = b & (q - 1), base = ((b - j) << 2) + j;
+        C2<T>* a = lds + r * m + base;
+        const C2<T> x0 = a[0], x1 = a[q], x2 = a[span], x3 = a[span + q];
+        const C2<T> t1 = nk_blu_tw<T, false>(tw, j * s1), t2 = nk_blu_tw<T, false>(tw, j * s2);
+        const C2<T> y0 = cadd(x0, x2), y1 = cadd(x1, x3);
+        const C2<T> y2 = cmul(csub(x0, x2), t1), y3 = cmul(nk_blu_rot<T, false>(csub(x1, x3)), t1);
+        a[0] = cadd(y0, y1);
+        a[q] = cmul(csub(y0, y1), t2);
+        a[span] = cadd(y2, y3);
+        a[span + q] = cmul(csub(y2, y3), t2);
+      }
+      __syncthreads();
+    }
+    if (span == 1) {  // log2 m odd: one radix-2 level is left (twiddle 1)
+      for (int i = tid; i < nr * half_m; i += 256) {
+        const int r = i / half_m, b = i - r * half_m;
+        C2<T>* a = lds + r * m + (b << 1);
+        const C2<T> u = a[0], v = a[1];
+        a[0] = cadd(u, v);
+        a[1] = csub(u, v);
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < nr * m; i += 256) lds[i] = cmul(lds[i], bhat_br[i % m]);
+    __syncthreads();
+    // ---- inverse, decimation in time from bit-reversed order: spans 1, 2, ..., m/2; conjugate twiddles
+    span = 1;
+    if (lg & 1) {
+      for (int i = tid; i < nr * half_m; i += 256) {
+        const int r = i / half_m, b = i - r * half_m;
+        C2<T>* a = lds + r * m + (b << 1);
+        const C2<T> u = a[0], v = a[1];
+        a[0] = cadd(u, v);
+        a[1] = csub(u, v);
+      }
+      __syncthreads();
+      span = 2;
+    }
+    for (; span <= quarter_m; span <<= 2) {
+      const int q = span, big = span << 1;  // levels with spans q and 2q
+      const int s1 = half_m / q, s2 = half_m / big;
+      for (int i = tid; i < nr * quarter_m; i += 256) {
+        const int r = i / quarter_m, b = i - r * quarter_m;
+        const int j = b & (q - 1), base = ((b - j) << 2) + j;
+        C2<T>* a = lds + r * m + base;
+        const C2<T> t1 = nk_blu_tw<T, true>(tw, j * s1), t2 = nk_blu_tw<T, true>(tw, j * s2);
+        // level 1 (span q): pairs (0, q) and (2q, 3q), both with twiddle t1
+        const C2<T> x0 = a[0], x1 = cmul(a[q], t1), x2 = a[big], x3 = cmul(a[big + q], t1);
+        const C2<T> y0 = cadd(x0, x1), y1 = csub(x0, x1), y2 = cadd(x2, x3), y3 = csub(x2, x3);
+        // level 2 (span 2q): pairs (0, 2q) with twiddle t2 and (q, 3q) with twiddle t2 * (+i)
+        const C2<T> z2 = cmul(y2, t2), z3 = nk_blu_rot<T, true>(cmul(y3, t2));
+        a[0] = cadd(y0, z2);
+        a[big] = csub(y0, z2);
+        a[q] = cadd(y1, z3);
+        a[big + q] = csub(y1, z3);
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < nr * n; i += 256) {
+      const int r = i / n, k = i - r * n;
+      const C2<T> v = cmul(lds[r * m + k], w[k]);
+      const int64_t dst = (row0 + r) * n + k;
+      if (out_hartley) reinterpret_cast<T*>(out_raw)[dst] = scale * (v.x + (T)out_hartley * v.y);
+      else reinterpret_cast<C2<T>*>(out_raw)[dst] = C2<T>{scale * v.x, scale * v.y};
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int nk_bluestein_rows(int64_t rows, int n, int m, const void* in, const void* w, const void* bhat_br, const void* tw, void* out,
+                                 double scale, int in_real, int out_hartley, int dtype, void* stream) {
+  if (rows < 0 || n < 1 || m < 4 || (m & (m - 1)) != 0 || m < 2 * n - 1 || !w || !bhat_br || !tw || (rows > 0 && (!in || !out)) ||
+      out_hartley < -1 || out_hartley > 1)
+    return nk_set_error(NK_ERR_INVALID, "nk_bluestein_rows: bad argument (m: a power of two >= max(4, 2 n - 1))");
+  if (rows == 0) return NK_OK;
+  if ((in_real || out_hartley) && in == out) return nk_set_error(NK_ERR_INVALID, "nk_bluestein_rows: real ends need distinct arrays");
+  NK_DISPATCH_DTYPE(dtype, {
+    if (sizeof(C2<T>) * (size_t)m > 64 * 1024)
+      return nk_set_error(NK_ERR_UNSUPPORTED, "nk_bluestein_rows: the padded row does not fit 64 KiB of LDS");
+    int R = (int)std::max<int64_t>(1, std::min<int64_t>(4096 / m, rows));  // rows per workgroup: R m <= 4096 points
+    const size_t lds = sizeof(C2<T>) * (size_t)m * R;
+    const int64_t groups = (rows + R - 1) / R;
+    const unsigned blocks = (unsigned)std::min<int64_t>(groups, 256 * 8);
+    hipLaunchKernelGGL(k_bluestein_rows<T>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, rows, n, m, R, in, (const C2<T>*)w,
+                       (const C2<T>*)bhat_br, (const C2<T>*)tw, out, (T)(scale / m), in_real, out_hartley);
+    return nk_check_launch("k_bluestein_rows");
+  })
+}
+
 // ---- fold the per-XCD private VJP accumulators ------------------------------------------------------------------
 __global__ void k_fold_copies(int64_t n, int copies, int64_t stride, const double* __restrict__ src, double* __restrict__ dst) {
   const int64_t gs = (int64_t)gridDim.x * blockDim.x;
@@ -2093,6 +2236,51 @@ extern "C" int nk_tiled_rowsum(const nk_tiled_csr* m, int count, const void* con
     hipLaunchKernelGGL(k_tiled_rows<T>, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, st, a);
     return nk_check_launch("k_tiled_rows");
   })
+}
+
+// ---- cyclic shift of a C-ordered array along any of its (<= 6) axes: out[(i_d + shift_d) mod n_d ...] = in[i ...]
+//      (FFTShiftOperator, reference operators/harmonic_operators.py:383-423: numpy's fftshift / ifftshift).  Elements are moved
+//      as opaque units of 4, 8 or 16 bytes (float, double / complex64, complex128); a thread walks elements of the LAST axis,
+//      so loads are contiguous runs and stores are contiguous up to the one wrap-around of that axis.
+struct NkRollArgs {
+  int ndim;
+  int64_t n[6], shift[6];  // shift already reduced to [0, n)
+};
+template <typename U>
+__global__ void __launch_bounds__(256) k_roll(NkRollArgs a, int64_t total, const U* __restrict__ in, U* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t rem = i, dst = 0, stride = 1;
+    for (int d = a.ndim - 1; d >= 0; --d) {
+      const int64_t c = rem % a.n[d];
+      rem /= a.n[d];
+      int64_t t = c + a.shift[d];
+      if (t >= a.n[d]) t -= a.n[d];
+      dst += t * stride;
+      stride *= a.n[d];
+    }
+    out[dst] = in[i];
+  }
+}
+extern "C" int nk_roll(int ndim, const int64_t* shape, const int64_t* shift, int elem_bytes, const void* in, void* out, void* stream) {
+  if (ndim < 1 || ndim > 6 || !shape || !shift || (elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16))
+    return nk_set_error(NK_ERR_INVALID, "nk_roll: 1 <= ndim <= 6, elements of 4, 8 or 16 bytes");
+  NkRollArgs a;
+  a.ndim = ndim;
+  int64_t total = 1;
+  for (int d = 0; d < ndim; ++d) {
+    if (shape[d] < 0) return nk_set_error(NK_ERR_INVALID, "nk_roll: negative axis length");
+    a.n[d] = shape[d];
+    a.shift[d] = shape[d] > 0 ? ((shift[d] % shape[d]) + shape[d]) % shape[d] : 0;
+    total *= shape[d];
+  }
+  if (total == 0) return NK_OK;
+  if (!in || !out || in == out) return nk_set_error(NK_ERR_INVALID, "nk_roll: in and out must be distinct arrays");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 64);
+  if (elem_bytes == 4) hipLaunchKernelGGL(k_roll<uint32_t>, dim3(blocks), dim3(256), 0, st, a, total, (const uint32_t*)in, (uint32_t*)out);
+  else if (elem_bytes == 8) hipLaunchKernelGGL(k_roll<uint64_t>, dim3(blocks), dim3(256), 0, st, a, total, (const uint64_t*)in, (uint64_t*)out);
+  else hipLaunchKernelGGL(k_roll<uint4>, dim3(blocks), dim3(256), 0, st, a, total, (const uint4*)in, (uint4*)out);
+  return nk_check_launch("k_roll");
 }
 
 // ---- inclusive prefix sum of a vector (the two log-integrations of the generic amplitude graph, reference

@@ -1216,12 +1216,13 @@ class FusedModel:
         in place (same seed, same calls), but a host thread can make them while the GPU solves the previous sample
         (`_HostDrawAhead`)."""
         rng = np.random.default_rng(sseq)
+        fresh = rng.bit_generator.state
         vals = {}
         for k in LATENT_KEYS:
             if k == "xi":
                 break
             vals[k] = rng.normal(0.0, 1.0, (2, self.nb - 2) if k == "spectrum" else ())
-        return vals, rng.bit_generator.state
+        return vals, rng.bit_generator.state, fresh
 
     def draw_prior(self, device_rng=None, ahead=None):
         """One standard-normal latent draw, keys in alphabetical order like MultiField.from_random.  ahead: the result of
@@ -1233,6 +1234,11 @@ class FusedModel:
         nb = self.nb
         parts = {}
         if ahead is not None:
+            # the worker drew from a FRESH generator on the context's seed: adopt its state only if the context's own generator
+            # is still there (a draw made earlier in this context would otherwise be silently undone: ADVICE r5)
+            if random.current_rng().bit_generator.state != ahead[2]:
+                raise RuntimeError("draw_prior(ahead=...): the random context has advanced since its seed was handed to the "
+                                   "draw-ahead worker")
             random.current_rng().bit_generator.state = ahead[1]
         for k in LATENT_KEYS:  # alphabetical = the reference's draw order
             if ahead is not None and k in ahead[0]:
@@ -1913,7 +1919,11 @@ def draw_samples(model, position, n_samples, mirror_samples, controller_factory,
     if lanes is None and not in_batch:
         if want_ahead:
             ahead = _HostDrawAhead(model, drawn_seeds)
-        drawn = plan.run(draw, finish)
+        try:
+            drawn = plan.run(draw, finish)
+        finally:
+            if ahead is not None:  # (a solve that raises must not leave the worker and its pending draw behind: ADVICE r5)
+                ahead.close()
     else:
         together = geo_minimizer is not None and lanes is not None and os.environ.get("NK_GEO_THREADS", "1") != "0"
         if in_batch:
@@ -1956,6 +1966,11 @@ class _HostDrawAhead:
         if k is not None and k + 1 >= len(self._seeds):
             self._pool.shutdown(wait=False)
         return fut.result() if fut is not None else None
+
+    def close(self):
+        """Drop what was started and not taken (an exception between two samples, a seed that was never asked for)."""
+        self._pending.clear()
+        self._pool.shutdown(wait=False, cancel_futures=True)
 
 
 def _fit_on_lanes(model, lanes, tp, g_p, position, jobs, minimizer):
@@ -2064,11 +2079,19 @@ def _solve_on_lanes(model, lanes, lp, jobs, controller_factory):
 
 
 def mgvi_iteration(model, mean, n_samples, controller_factory, kl_minimizer, mirror_samples=True, comm=None,
-                   device_rng=None, geo_minimizer=None):
-    """One pass of the optimize_kl loop body (optimize_kl.py:357-451, no I/O): sample, then minimise."""
+                   device_rng=None, geo_minimizer=None, on_phase=None):
+    """One pass of the optimize_kl loop body (optimize_kl.py:357-451, no I/O): sample, then minimise.  on_phase(name): called
+    after "sampling", "kl_construction" and "newton_cg" (bench.py hangs its per-phase clock there -- the timed code IS this
+    function)."""
     residuals, negs, n_total = draw_samples(model, mean, n_samples, mirror_samples, controller_factory, comm, device_rng,
                                             geo_minimizer)
+    if on_phase is not None:
+        on_phase("sampling")
     kl = FusedKL(model, mean, residuals, negs, n_total, comm)
+    if on_phase is not None:
+        on_phase("kl_construction")
     with parallel.lockstep(comm):  # replicated minimiser: identical decisions on every rank
         kl, _ = kl_minimizer(kl)
+    if on_phase is not None:
+        on_phase("newton_cg")
     return kl.position, kl

@@ -424,13 +424,20 @@ def _local_sample_files(file_name_base, comm):
 def _end_sample_run(file_name_base, total, overwrite, comm, rank):
     """rank 0 removes a left-over ``<base>.<total>.pickle`` so that the files about to be written END the run; nobody
     writes before that happened."""
-    if overwrite and rank == 0:
-        try:
-            os.remove(_sample_file(file_name_base, total))
-        except FileNotFoundError:
-            pass
+    nxt = _sample_file(file_name_base, total)
+    clash = False
+    if rank == 0:
+        if overwrite:
+            try:
+                os.remove(nxt)
+            except FileNotFoundError:
+                pass
+        else:  # the "next" sample of a longer, older run must not exist (sample_list.py:673-690)
+            clash = os.path.isfile(nxt)
     if comm is not None:
-        comm.barrier()
+        clash = bool(comm.bcast_object(clash if rank == 0 else None, root=0))  # every rank learns the verdict (and waits for it)
+    if clash:
+        raise RuntimeError(f"{nxt} already exists. You may want to remove it or specify overwrite=True")
 
 
 def _to_host(f):

@@ -451,6 +451,12 @@ class _HostCg:
         return None
 
 
+# residual refresh period of every conjugate-gradient solve of the package (reference conjugate_gradient.py:38: nreset = 20): ONE
+# constant for ConjugateGradient's default, the batched sampling solves (batched.solve_together) and the sharded CG, whose
+# bit-identity with each other depends on refreshing at the same iterations
+CG_NRESET = 20
+
+
 class ConjugateGradient(Minimizer):
     """Linear CG on a QuadraticEnergy (reference conjugate_gradient.py:48-126).
 
@@ -459,7 +465,8 @@ class ConjugateGradient(Minimizer):
     the quadratic energy value stay on the device and are fetched with ONE copy per iteration.
     """
 
-    def __init__(self, controller, nreset=20):
+    def __init__(self, controller, nreset=None):
+        nreset = CG_NRESET if nreset is None else nreset
         self._controller = controller
         self._nreset = nreset
 

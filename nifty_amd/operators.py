@@ -1482,6 +1482,79 @@ def _gaussian_convolution(domain, width, space):
     return ChainOperator.make([to_harmonic.inverse, DiagonalOperator(damping, to_harmonic.target, space), to_harmonic])
 
 
+
+class FFTShiftOperator(EndomorphicOperator):
+    """Cyclic shift by half the grid along the axes of the selected RGSpaces -- numpy's ``fftshift`` forwards (TIMES,
+    ADJOINT_INVERSE_TIMES), ``ifftshift`` backwards: a permutation, so adjoint = inverse (reference
+    operators/harmonic_operators.py:383-423; same arguments).  On a GPU one nk_roll launch moves the data."""
+
+    def __init__(self, domain, spaces=None):
+        self._domain = DomainTuple.make(domain)
+        self._capability = self._all_ops
+        nsp = len(self._domain)
+        if spaces is None:
+            spaces = tuple(range(nsp))
+        elif isinstance(spaces, (int, np.integer)):
+            spaces = (int(spaces),)
+        spaces = tuple(spaces)
+        if not all(isinstance(i, (int, np.integer)) and -nsp <= i < nsp for i in spaces):
+            raise ValueError("spaces: indices into the domain tuple")
+        picked = sorted({int(i) % nsp for i in spaces})
+        for i in picked:
+            if not isinstance(self._domain[i], RGSpace):
+                raise TypeError("FFTShiftOperator only shifts RGSpaces")
+        self._axes = tuple(ax for i in picked for ax in self._domain.axes[i])
+
+    def apply(self, x, mode):
+        self._check_input(x, mode)
+        forward = bool(mode & (self.TIMES | self.ADJOINT_INVERSE_TIMES))
+        v = x.val
+        shifts = [0] * v.dim()
+        for ax in self._axes:
+            n = v.shape[ax]
+            shifts[ax] = n // 2 if forward else -(n // 2)  # fftshift rolls by n // 2, ifftshift by -(n // 2)
+        if v.is_cuda:
+            return Field(self._tgt(mode), B.roll(v, shifts))
+        return Field(self._tgt(mode), torch.roll(v, shifts=shifts, dims=tuple(range(v.dim()))))
+
+
+class InversionEnabler(EndomorphicOperator):
+    """`op` plus the modes it lacks, those computed by a conjugate-gradient solve of ``op_flipped(y) = x`` from y = 0
+    (reference operators/inversion_enabler.py:28-80; same arguments).  `approximation`: a linear operator close to `op` that
+    HAS the missing modes, used as the preconditioner.  A solve that does not converge logs a warning and returns its last
+    iterate, like the reference.  On a GPU the solve is minimization.ConjugateGradient on the nk_cg_* kernels."""
+
+    def __init__(self, op, iteration_controller, approximation=None):
+        if not isinstance(op, LinearOperator):
+            raise TypeError("Operator needs to be linear.")
+        if op.domain is not op.target and op.domain != op.target:
+            raise TypeError("Operator needs to be endomorphic.")
+        self._op, self._ic, self._approximation = op, iteration_controller, approximation
+        self._domain = op.domain
+        self._capability = self._add_inverse_capability(op.capability)
+
+    def apply(self, x, mode):
+        self._check_mode(mode)
+        if self._op.capability & mode:
+            return self._op.apply(x, mode)
+        from .minimization import ConjugateGradient, IterationController, QuadraticEnergy, logger
+
+        # the mode asked for is the inverse of one `op` has: solve  op|that mode (y) = x
+        have = self._op._flip_modes(_mode_index(mode) ^ self.INVERSE_BIT)
+        prec = None if self._approximation is None else self._approximation._flip_modes(_mode_index(mode))
+        start = x * 0.0
+        solved, status = ConjugateGradient(self._ic)(QuadraticEnergy(start, have, x), preconditioner=prec)
+        if status != IterationController.CONVERGED:
+            logger.warning("Error detected during operator inversion")
+        return solved.position
+
+    def draw_sample(self, from_inverse=False, device_id=-1):
+        return self._op.draw_sample(from_inverse, device_id)
+
+    def __repr__(self):
+        return "InversionEnabler:\n  " + repr(self._op).replace("\n", "\n  ")
+
+
 class _JacCountingOperator(EndomorphicOperator):
     """Identity whose applications are tallied per mode in the owner's counter table."""
 

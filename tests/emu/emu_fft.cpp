@@ -120,6 +120,34 @@ static void emu2_strided_m(NkPassS p, const nk_fuse& f, const C2<T>* tw, C2<T>* 
     }
   }
 }
+// one launch of the two-level first-axis pass (k2_tl of nk_fft_t.hip): MODE 4 with the prologue classes of nk_tl_first, MODE 5
+template <typename T, int N, int MODE>
+static void emu_tl(NkPassS p, int other, const nk_fuse& f, const C2<T>* tw, const C2<T>* tw_full, C2<T>* work) {
+  using ST = StridedTile<T, N, false, MODE>;
+  p.tl.tile = ST::TILE;
+  p.tl.dtile = nk_make_div(ST::TILE);
+  p.tiles_per_slab = (int)(p.inner / ST::TILE);
+  p.sub = other;
+  std::vector<T> plane(ST::LDS_BYTES / sizeof(T));
+  double energy = 0.0;
+  const int64_t blocks = (int64_t)p.g.batch * other * p.tiles_per_slab;
+  for (int64_t blk = 0; blk < blocks; ++blk) {
+    HostExec<T, ST::SC::E> ex(ST::THREADS);
+    const int64_t b = nk_xcd_contig(blk, blocks);
+#define NK_TL(PC) nk_strided_body<T, N, ST::TILE, MODE, PC>(ex, p, f, b, plane.data(), tw, work, (C2<T>*)nullptr, &energy, nullptr, tw_full)
+    if constexpr (MODE == 4) {
+      if (sizeof(T) == 8 && f.field_octant && f.pro == NK_PRO_AMP && f.io32) NK_TL(9);
+      else if (f.field_octant && f.pro == NK_PRO_AMP) NK_TL(4);
+      else if (f.field_octant && f.pro == NK_PRO_AMP_JVP) NK_TL(5);
+      else if (f.pro == NK_PRO_PLAIN) NK_TL(0);
+      else if (f.pro == NK_PRO_MUL) NK_TL(6);
+      else NK_TL(-1);
+    } else {
+      NK_TL(-1);
+    }
+#undef NK_TL
+  }
+}
 template <typename T, int N>
 static void emu2_strided(NkPassS p, int mode, const nk_fuse& f, const C2<T>* tw, C2<T>* work, C2<T>* scratch,
                          double* energy) {
@@ -359,6 +387,14 @@ static int emu3_run(int ndim, const int64_t* shape, int dtype, int64_t batch, co
 #undef NK_CASE
     }
   }
+  int tl_n1 = 0, tl_n2 = 0;
+  if (nk_tl_split<T>(g, tl_n1, tl_n2)) {
+    // two-level first-axis pass (nk_fft_t.hip: nk_tl_first_axis): n1-point sub-lines with the prologue, n2-point ones in place
+    auto tw1 = conv_tw<T>(hp.tw_t64), tw2 = conv_tw<T>(tl_n2 == 64 ? hp.tw_t64 : hp.tw_t32);
+    emu_tl<T, 64, 4>(pc, tl_n2, *f, tw1.data(), tw_c.data(), work.data());
+    if (tl_n2 == 64) emu_tl<T, 64, 5>(pc, tl_n1, *f, tw2.data(), tw_c.data(), work.data());
+    else emu_tl<T, 32, 5>(pc, tl_n1, *f, tw2.data(), tw_c.data(), work.data());
+  } else
   switch (g.na) {
 #define NK_CASE(NN) \
   case NN:          \

@@ -677,7 +677,65 @@ def driver_io_case():
     print("reference reads nifty_amd.random.getState(): OK")
 
 
+def small_ops_cases():
+    """FFTShiftOperator (operators/harmonic_operators.py:383-423), InversionEnabler (operators/inversion_enabler.py:28-80:
+    inverse modes of a sandwich without them, plain and preconditioned) and integer `uniform` draws (random.py:240-257:
+    power-of-two and other ranges, int64 / int32) from the reference."""
+    out = {}
+    rng = np.random.default_rng(17)
+    for tag, dom, spaces in (("a", ift.RGSpace((8,)), None), ("b", ift.RGSpace((7, 6)), None),
+                             ("c", ift.DomainTuple.make((ift.RGSpace((4, 5)), ift.UnstructuredDomain(3), ift.RGSpace(6))), (0, -1)),
+                             ("d", ift.DomainTuple.make((ift.UnstructuredDomain(2), ift.RGSpace((5, 4, 3)))), 1)):
+        dom = ift.DomainTuple.make(dom)
+        op = ift.FFTShiftOperator(dom, spaces)
+        x = rng.normal(size=dom.shape)
+        xc = x + 1j * rng.normal(size=dom.shape)
+        out[f"shift.{tag}.x"], out[f"shift.{tag}.xc"] = x, xc
+        out[f"shift.{tag}.times"] = op(ift.makeField(dom, x)).asnumpy()
+        out[f"shift.{tag}.inverse"] = op.inverse(ift.makeField(dom, x)).asnumpy()
+        out[f"shift.{tag}.adjoint"] = op.adjoint(ift.makeField(dom, x)).asnumpy()
+        out[f"shift.{tag}.times_c"] = op(ift.makeField(dom, xc)).asnumpy()
+    # InversionEnabler: S = HT^dagger D HT has TIMES / ADJOINT_TIMES only behind this wrapper
+    sp = ift.RGSpace((16, 12), (0.3, 0.2))
+    HT = ift.HartleyOperator(sp)
+    diag = 1.0 + rng.uniform(size=sp.shape) ** 2
+    D = ift.DiagonalOperator(ift.makeField(HT.target, diag))
+
+    class TimesOnly(ift.EndomorphicOperator):
+        def __init__(self, op):
+            self._op, self._domain, self._capability = op, op.domain, self.TIMES | self.ADJOINT_TIMES
+
+        def apply(self, x, mode):
+            self._check_input(x, mode)
+            return self._op.apply(x, mode)
+
+    S = TimesOnly(ift.SandwichOperator.make(HT, D))
+    y = rng.normal(size=sp.shape)
+    out["inv.diag"], out["inv.y"] = diag, y
+    ic = lambda: ift.GradientNormController(tol_abs_gradnorm=1e-10, iteration_limit=40)  # noqa: E731
+    plain = ift.InversionEnabler(S, ic())
+    out["inv.inverse_times"] = plain.inverse_times(ift.makeField(sp, y)).asnumpy()
+    out["inv.adjoint_inverse_times"] = plain.adjoint_inverse_times(ift.makeField(sp, y)).asnumpy()
+    out["inv.times"] = plain(ift.makeField(sp, y)).asnumpy()
+    approx = ift.ScalingOperator(sp, float(np.mean(diag)) * sp.size * sp.scalar_dvol ** 2, np.float64)
+    pre = ift.InversionEnabler(S, ift.GradientNormController(tol_abs_gradnorm=1e-10, iteration_limit=3), approximation=approx)
+    out["inv.preconditioned_3_steps"] = pre.inverse_times(ift.makeField(sp, y)).asnumpy()
+    out["inv.approx_factor"] = np.array(float(np.mean(diag)) * sp.size * sp.scalar_dvol ** 2)
+    # integer uniform draws
+    for tag, dt, low, high, shape in (("u7", np.int64, 0, 6, (5, 9)), ("u8", np.int64, 0, 7, (33,)), ("un", np.int64, -3, 11, (4, 4, 4)),
+                                     ("u32", np.int32, 10, 1000, (77,)), ("big", np.int64, 0, 2 ** 40, (19,)), ("one", np.int64, 5, 5, (6,))):
+        with ift.random.Context(123):
+            out[f"uni.{tag}"] = ift.random.current_rng() and ift.Field.from_random(ift.UnstructuredDomain(shape), "uniform", dtype=dt,
+                                                                                     low=low, high=high).asnumpy()
+            out[f"uni.{tag}.after"] = ift.random.current_rng().normal(size=3)  # the generator state after the draw
+        out[f"uni.{tag}.args"] = np.array([low, high])
+    np.savez_compressed(os.path.join(HERE, "small_ops.npz"), **out)
+    print("wrote small_ops", sorted(out)[:6], "...")
+
+
 def main():
+    if "--small-ops" in sys.argv:
+        return small_ops_cases()
     if "--driver-io" in sys.argv:
         return driver_io_case()
     if "--c1-only" in sys.argv:  # BASELINE configs[0] at its stated size: RGSpace(512), Gaussian, 2 MGVI samples (mirrored)
@@ -733,6 +791,7 @@ def main():
     product_cf_case()
     likelihood_cases()
     driver_io_case()
+    small_ops_cases()
 
 
 def allreduce_order():

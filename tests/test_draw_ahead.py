@@ -18,8 +18,9 @@ def test_draws_ahead_are_the_in_place_draws():
     before_xi = list(E.LATENT_KEYS[:E.LATENT_KEYS.index("xi")])
     assert before_xi == ["asperity", "flexibility", "fluctuations", "loglogavgslope", "spectrum"]
     for sq in seeds:
-        vals, state = ahead.take(sq)
+        vals, state, fresh = ahead.take(sq)
         rng = np.random.default_rng(sq)  # what random.Context(sq) puts on the stack
+        assert fresh == rng.bit_generator.state  # (draw_prior adopts `state` only from a context generator still in this state)
         for k in before_xi:
             ref = rng.normal(0.0, 1.0, (2, model.nb - 2) if k == "spectrum" else ())
             assert np.array_equal(vals[k], ref)
@@ -30,3 +31,10 @@ def test_draws_ahead_are_the_in_place_draws():
         assert cont.normal() == rng.normal()
     # a seed that was not announced gets nothing (the caller then draws in place)
     assert ahead.take(np.random.SeedSequence(99)) is None
+
+
+def test_close_drops_the_pending_draw():
+    """An exception between two samples must not leave the worker behind: close() cancels what was not taken."""
+    ahead = E._HostDrawAhead(_Model(), np.random.SeedSequence(6).spawn(3))
+    ahead.close()
+    assert not ahead._pending and ahead._pool._shutdown

@@ -21,9 +21,19 @@ def lib():
 
 
 def run(f, shape, dtype, conv=0, batch=1, fn="emu_hartley_fused"):
-    """fn: emu_hartley_fused = generic kernels; emu2_/emu3_ = register-resident fast path (1-D / strided-first)."""
+    """fn: emu_hartley_fused = generic kernels; emu2_/emu3_ = register-resident fast path (1-D / strided-first).  Long first
+    axes of 2-D grids run the two-level pass in every split the library has (NK_TWO_LEVEL=2: 64 x 64 and 64 x 32, both
+    dtypes; the emulation reads the switch per call)."""
     shp = (ctypes.c_int64 * len(shape))(*shape)
-    rc = getattr(lib(), fn)(len(shape), shp, 0 if dtype == np.float32 else 1, batch, ctypes.byref(f), conv)
+    old = os.environ.get("NK_TWO_LEVEL")
+    os.environ["NK_TWO_LEVEL"] = "2"
+    try:
+        rc = getattr(lib(), fn)(len(shape), shp, 0 if dtype == np.float32 else 1, batch, ctypes.byref(f), conv)
+    finally:
+        if old is None:
+            del os.environ["NK_TWO_LEVEL"]
+        else:
+            os.environ["NK_TWO_LEVEL"] = old
     assert rc == 0, rc
 
 
@@ -50,7 +60,8 @@ def test_hartley_emulation(shape, dtype):
         assert err < (1e-12 if dtype == np.float64 else 2e-5)
 
 
-@pytest.mark.parametrize("shape", [(128,), (64, 128), (128, 64), (64, 64, 64), (64, 128, 64)])
+@pytest.mark.parametrize("shape", [(128,), (64, 128), (128, 64), (64, 64, 64), (64, 128, 64),
+                                   (2048, 64), (4096, 64)])  # long first axes of 2-D grids: the two-level pass (nk_tl_split)
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_fast_path_emulation(shape, dtype):
     rng = np.random.default_rng(3)
@@ -68,7 +79,8 @@ def test_fast_path_emulation(shape, dtype):
 FUSED_SHAPES = [((64,), "emu_hartley_fused"), ((16, 8), "emu_hartley_fused"), ((8, 4, 16), "emu_hartley_fused"),
                 ((30,), "emu_hartley_fused"), ((10, 12), "emu_hartley_fused"), ((6, 5, 14), "emu_hartley_fused"),
                 ((256,), "emu2_hartley_fused"), ((64, 128), "emu3_hartley_fused"), ((64, 64, 64), "emu3_hartley_fused"),
-                ((64, 64, 1024), "emu3_hartley_fused")]  # last axis 1024 in fp64: the smallest final-pass tile
+                ((64, 64, 1024), "emu3_hartley_fused"),  # last axis 1024 in fp64: the smallest final-pass tile
+                ((2048, 64), "emu3_hartley_fused"), ((4096, 128), "emu3_hartley_fused")]  # two-level first-axis pass (64 x 32, 64 x 64)
 
 
 @pytest.mark.parametrize("shape,fn", FUSED_SHAPES)

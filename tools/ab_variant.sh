@@ -1,6 +1,6 @@
 # usage: bash tools/ab_variant.sh <variant tag> [C3|C2|C4|main ...] -- bench lines of the product library and of build/libniftyk_<tag>.so
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 tag=$1; shift; mkdir -p gpurun_out/ab_$tag
 for cfg in "$@"; do
 for lib in product $tag; do

@@ -1,6 +1,6 @@
 # rocprofv3 kernel trace of the headline workload through ift.optimize_kl (tools/run_c5_api.py, 2 iterations): per-kernel summary
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 mkdir -p gpurun_out/apiprof; rm -rf gpurun_out/prof_api
 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_api -- python3 tools/run_c5_api.py 1024 2 > gpurun_out/apiprof/run.log 2>&1
 tail -2 gpurun_out/apiprof/run.log

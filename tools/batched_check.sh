@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 tag=${1:-batched}; mkdir -p gpurun_out/$tag
 # batched small-grid path after the bin-sum / roll changes: parity, then C2 twice
 python -m pytest tests/test_batched_gpu.py tests/test_kernels_gpu.py tests/test_api_gpu.py tests/test_engine_gpu.py -q -x 2>&1 | tail -30

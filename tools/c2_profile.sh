@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 mkdir -p gpurun_out/r4e
 NK_BENCH_CONFIG=C2 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r4e/c2_line.log 2>&1
 rm -rf gpurun_out/prof_c2

@@ -1,5 +1,5 @@
 # side configurations C2 / C4 of bench.py with and without the sample lanes -> gpurun_out/<tag>/
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 tag=${1:-r4f}; mkdir -p gpurun_out/$tag
 for cfg in C2 C4; do
   for lanes in 0 4; do

@@ -1,6 +1,6 @@
 # A/B of the host draw-ahead (NK_DRAW_AHEAD): judged bench command, sampling phase seconds and final energy (must agree)
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 mkdir -p gpurun_out/da
 for a in ${NK_AB_LIST:-1 0}; do
 NK_DRAW_AHEAD=$a python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/da/ahead$a.log 2>&1

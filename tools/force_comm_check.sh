@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 tag=${1:-force_comm}; mkdir -p gpurun_out/$tag
 # a ONE-rank RCCL communicator: the sharded CG with its side-stream exchange, staged passes and the exchange timer
 NK_FORCE_COMM=1 timeout 1200 python bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/$tag/bench_force_comm.log 2>&1

@@ -1,6 +1,6 @@
 # sweep of the generic kernels' launch parameters (tile / threads of the contiguous pass A and of the strided passes) on one
 # mixed-radix grid.  usage: bash tools/generic_sweep.sh "768,768,768" f32
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 shape=${1:-768,768,768}; dt=${2:-f32}
 run() { env "$@" python - <<PY 2>/dev/null
 import sys, torch

@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 run() { shape=$1; dt=$2; shift 2; env "$@" python - <<PY 2>/dev/null
 import sys, torch
 sys.path.insert(0, ".")

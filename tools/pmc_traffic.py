@@ -1,7 +1,9 @@
 """HBM bytes per launch of the transform pass kernels (k_passB includes the in-place middle-axis passes of the sandwich) from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
 of the SAME bench.py command.  FETCH_SIZE is doubled (gfx950 correction of MI355X_MICROARCH.md); both counters are KiB.
 Usage: pmc_traffic.py <fetch_dir> <write_dir> <workload> > profiles/<name>_pmc_traffic.json"""
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def family(name):
     if "k2_final2" in name or "k_passC2" in name:
@@ -41,6 +43,14 @@ wt, wc, wv = collect(sys.argv[2], "WRITE_SIZE")
 out = {"note": "HBM bytes per launch (average over all launches of the pass kernel family in one bench step) from separate "
                "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the bench command; FETCH_SIZE doubled per the gfx950 "
                "correction of MI355X_MICROARCH.md; KiB units", "workload": sys.argv[3], "kernels": {}}
+try:  # the kernel sources these counters belong to (bench.py quotes them only for the same digest)
+    import bench
+    out["kernel_source_digest"] = bench.kernel_source_digest()
+except Exception as exc:
+    out["kernel_source_digest"] = None
+    out["digest_error"] = repr(exc)
+if len(sys.argv) > 4:
+    out["commit"] = sys.argv[4]
 for fam in sorted(ft):
     f_kb, w_kb = ft[fam] / fc[fam], wt[fam] / max(1, wc[fam])
     out["kernels"][fam] = {"launches": fc[fam], "fetch_kb": round(f_kb, 1), "write_kb": round(w_kb, 1),

@@ -1,6 +1,6 @@
 # usage: bash tools/prof_bench.sh <tag> [bench args]  -- rocprofv3 kernel trace of bench.py, summary to gpurun_out/<tag>_stats.txt
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 tag=$1; shift
 rm -rf gpurun_out/prof_$tag
 timeout 800 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -- python3 bench.py "$@" > gpurun_out/bench_$tag.log 2>&1

@@ -1,6 +1,6 @@
 # usage: bash tools/round_end_profile.sh <tag>  -- the judged command (driver style, with the NK_BENCH_API leg), the default
 # command, its kernel trace and its PMC traffic -> gpurun_out/<tag>/ (copy what is to be judged to profiles/)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 tag=${1:-r05}
 mkdir -p gpurun_out/$tag
 NK_BENCH_API=1 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/$tag/bench_driver_style.log 2>&1

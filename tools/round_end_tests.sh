@@ -1,7 +1,7 @@
 # usage: bash tools/round_end_tests.sh <tag> -- the driver's round-end checks on one box: pytest -m gpu (incl. the full-size
 # oracle tests), smoke(), then the judged bench command
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 tag=${1:-r05end}; mkdir -p gpurun_out/$tag
 NK_REQUIRE_FULL=1 python -m pytest tests -q -m gpu -x 2>&1 | tail -5 | tee gpurun_out/$tag/pytest_gpu_tail.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/$tag/smoke_tail.txt

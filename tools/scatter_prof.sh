@@ -1,6 +1,6 @@
 # kernel-only times of the octant scatter kernels (rocprofv3 on tools/gpu_scatter_probe.py) and the digest of the bin sums
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 for shape in ${NK_SCATTER_SHAPES:-1024,1024,1024 512,512,512}; do
 rm -rf gpurun_out/prof_sc
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_sc -- python3 tools/gpu_scatter_probe.py $shape > gpurun_out/prof_sc.log 2>&1

@@ -1,6 +1,6 @@
 # usage: bash tools/side_configs.sh <tag> [steps] -- NK_BENCH_CONFIG=C2 / C3 / C4 lines with the per-kernel averages
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 tag=${1:-side}; steps=${2:-3}; mkdir -p gpurun_out/$tag
 for c in ${NK_SIDE_CONFIGS:-C2 C3 C4}; do
   NK_BENCH_CONFIG=$c timeout 900 python bench.py --steps $steps --warmup 1 --no-cpu-baseline > gpurun_out/$tag/$c.log 2>&1
