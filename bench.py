@@ -308,6 +308,12 @@ def cpu_baseline(counts_per_step, shape_full, cfg="C5", bench_dtype=None, budget
                 parity_rel_err_vs_hip_f32=max(parity["f32"].values()) if "f32" in parity else None,
                 parity_detail=parity or None,
                 value_one_thread=1.0 / sec1,
+                # where the in-run parity was taken (the timed grid is larger than this sample; the timed grid itself
+                # is held against the oracle by tests/test_large_oracle_gpu.py::test_config5_full_size_against_the_oracle)
+                parity_sample=(f"HIP engine vs oracle (value, gradient, metric application; fp64 and the bench dtype) at "
+                               f"{'x'.join(map(str, sample_shape))}"
+                               + ("" if tuple(sample_shape) == tuple(shape_full) else
+                                  f" -- NOT the {'x'.join(map(str, shape_full))} grid the line times")) if parity else None,
                 sample=(f"oracle (numpy+scipy.fft, workers={cores}) metric apply {t_met * 1e3:.1f} ms and value+gradient "
                         f"{t_vg * 1e3:.1f} ms per sample at {'x'.join(map(str, sample_shape))} fp64 ({n} reps), "
                         f"scaled x{scale:.1f} (N log N) to {'x'.join(map(str, shape_full))} and multiplied by the {priced} "

@@ -504,6 +504,17 @@ int nk_pcg64_uniform(const uint64_t* state, const uint64_t* inc, int64_t n, doub
 int nk_pcg64_pm1(const uint64_t* state, const uint64_t* inc, int64_t n, void* out, int dtype, int complex_units, void* scratch,
                  void* stream);
 
+/* nk_pcg64_integers: numpy's Generator.integers(low, low + rng + 1, size = n) on a PCG64 stream (Random.uniform of integer
+ * fields, reference random.py:252-256; numpy's random_bounded_uint64_fill without masking: Lemire's method on 32-bit words
+ * for rng < 2^32, on 64-bit draws beyond, rejected words skipped) as int64 values.  state / inc as for nk_pcg64_normal (the
+ * caller has consumed a buffered 32-bit half itself); `nthreads` threads of 32 raw draws each are walked -- the caller sizes
+ * them for the expected number of rejections and retries with more when status[1] reports NK_RNG_ERR_SHORT (bit 1).
+ * status[0] = words consumed through output n - 1 (32-bit words for rng < 2^32 - 1... see nk_rng.h; 64-bit draws beyond).
+ * scratch: nk_pcg64_integers_scratch_bytes(nthreads) bytes. */
+int64_t nk_pcg64_integers_scratch_bytes(int64_t nthreads);
+int nk_pcg64_integers(const uint64_t* state, const uint64_t* inc, int64_t n, int64_t low, uint64_t rng, int64_t nthreads, int64_t* out,
+                      void* scratch, uint64_t* status, void* stream);
+
 /* ---- batched launches: ONE launch per kernel for up to NK_MAX_BATCH independent members -------------------------------
  *      On small grids (2048^2: 128 workgroups per transform pass on 256 CUs, amplitude kernels of 5-20 us) one member's
  *      kernel chain leaves most of the chip idle and the launches themselves set the time.  The members of a batch are

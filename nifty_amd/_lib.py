@@ -108,6 +108,8 @@ SIGNATURES = {
     "nk_pcg64_fixed_scratch_bytes": (_i64, []),
     "nk_pcg64_uniform": (_i, [_vp, _vp, _i64, _d, _d, _vp, _i, _vp, _vp]),
     "nk_pcg64_pm1": (_i, [_vp, _vp, _i64, _vp, _i, _i, _vp, _vp]),
+    "nk_pcg64_integers_scratch_bytes": (_i64, [_i64]),
+    "nk_pcg64_integers": (_i, [_vp, _vp, _i64, _i64, ctypes.c_uint64, _i64, _vp, _vp, _vp, _vp]),
     "nk_cg_direction": (_i, [_i64, _vp, _vp, _i, _vp, _i, _vp]),
     "nk_amp_forward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nk_amp_jvp": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -581,6 +581,94 @@ def _pcg64_advanced(state, inc, delta):
     return (am * state + ap) & _M128
 
 
+def _pcg64_output(state):
+    """PCG64's output function (XSL-RR 128/64) of a state."""
+    hi, lo = state >> 64, state & (2**64 - 1)
+    x, rot = hi ^ lo, hi >> 58
+    return ((x >> rot) | (x << ((64 - rot) & 63))) & (2**64 - 1)
+
+
+def _bounded_integers(rng, low, high, n, draw):
+    """numpy's `rng.integers(low, high + 1, n)` (int64; the reference's Random.uniform of integer fields, random.py:252-256)
+    with the words of the stream supplied by `draw(state, inc, n, low, span, nthreads) -> (values, words_used, short)`:
+    the device kernels (pcg64_integers) or their host emulation (tests).  Handles what is not stream arithmetic: the empty
+    range, PCG64's buffered 32-bit half (next_uint32 returns the cached high half of the previous draw first), the sizing /
+    retry of the walk for rejected words, and the generator state afterwards -- `rng` is left exactly as numpy leaves it.
+    Returns (first, rest): `first` = values produced on the host from the cached half-word (0 or 1), `rest` from `draw`."""
+    bg = rng.bit_generator
+    st = bg.state
+    if st.get("bit_generator") != "PCG64":
+        raise TypeError("needs a numpy Generator over PCG64 (np.random.default_rng)")
+    low, high = int(low), int(high)
+    if high < low:
+        raise ValueError("low > high")
+    span = high - low
+    if span >= 2**64:
+        raise ValueError("range too large")
+    if n == 0 or span == 0:
+        return [low] * (0 if span else n), None
+    state, inc = int(st["state"]["state"]), int(st["state"]["inc"])
+    wide = span > 0xFFFFFFFF
+    first = []
+    if not wide and st["has_uint32"]:
+        # the cached half-word is the first 32-bit word of this call
+        st["has_uint32"], word = 0, int(st["uinteger"])
+        if span == 0xFFFFFFFF:
+            first.append(low + word)
+        else:
+            m = word * (span + 1)
+            if (m & 0xFFFFFFFF) >= (0xFFFFFFFF - span) % (span + 1):
+                first.append(low + (m >> 32))
+    need = n - len(first)
+    rest, words = None, 0
+    if need > 0:
+        full = 2**64 if wide else 2**32
+        p_rej = 0.0 if span + 1 == full else ((full - 1 - span) % (span + 1)) / full
+        per = 32 if wide else 64  # words per thread (NK_RNG_FIX raw draws)
+        for attempt in range(12):
+            expect = need / (1.0 - p_rej)
+            nwords = int(expect + (2 ** attempt) * (8.0 * (expect * p_rej) ** 0.5 + 64))
+            rest, words, short = draw(state, inc, need, low, span, -(-nwords // per))
+            if not short:
+                break
+        else:
+            raise RuntimeError("bounded integers: the walk stayed short of the requested count")
+    raws = words if wide else -(-words // 2)
+    st["state"]["state"] = _pcg64_advanced(state, inc, raws)
+    if not wide and raws > 0:
+        # next_uint32 parks the high half of every draw it takes; after an odd number of words that half is still pending
+        # (even: the field keeps the stale value, like numpy's state dict does)
+        st["has_uint32"], st["uinteger"] = words % 2, _pcg64_output(st["state"]["state"]) >> 32
+    bg.state = st
+    return first, rest
+
+
+def pcg64_integers(rng, low, high, shape, device):
+    """`rng.integers(low, high + 1, shape)` (int64) of a numpy Generator over PCG64 on `device`: the same values, the same
+    generator state afterwards (nk_pcg64_integers; one host sync for the number of words consumed)."""
+    n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
+    out = torch.empty(n, dtype=torch.int64, device=device)
+    _require_device(out)
+    lib = L.load()
+    status = torch.empty(2, dtype=torch.int64, device=device)
+
+    def draw(state, inc, need, lo, span, nthreads):
+        words = (ctypes.c_uint64 * 4)(state >> 64, state & (2**64 - 1), inc >> 64, inc & (2**64 - 1))
+        scratch = torch.empty(lib.nk_pcg64_integers_scratch_bytes(nthreads), dtype=torch.uint8, device=device)
+        dst = out[n - need:]
+        L.check(lib.nk_pcg64_integers(ctypes.addressof(words), ctypes.addressof(words) + 16, need, lo, span, nthreads, dst.data_ptr(),
+                                      scratch.data_ptr(), status.data_ptr(), _stream()), "nk_pcg64_integers")
+        used, err = status.cpu().tolist()
+        return dst, int(used), bool(err & 2)
+
+    first, _ = _bounded_integers(rng, low, high, n, draw)
+    if n and int(high) == int(low):
+        out.fill_(int(low))
+    elif first:
+        out[:len(first)] = torch.tensor(first, dtype=torch.int64)
+    return out.reshape(tuple(shape))
+
+
 def pcg64_normal(rng, mean, std, shape, dtype, device):
     """`rng.normal(mean, std, shape)` of a numpy Generator over PCG64 (the reference's generator: nifty/cl/random.py:146-206
     push_sseq -> np.random.default_rng), computed on `device` from the generator's current state: the same values draw for

@@ -258,3 +258,81 @@ NK_HD void nk_rng_fixed_body(NkU128 state, NkU128 inc, const NkPcgJump& jt, int6
     }
   }
 }
+
+// ---- bounded integers: numpy's Generator.integers(low, high + 1, size) (reference random.py:252-256, Random.uniform of
+// integer fields; numpy/random/src/distributions/distributions.c: random_bounded_uint64_fill, use_masked = false) ------------
+// rng = high - low:  0 < rng < 2^32 - 1  -> Lemire's method on 32-bit WORDS, rng >= 2^32 (and < 2^64 - 1) on 64-bit draws:
+//     m = word * (rng + 1);  leftover = low half of m;  accept iff leftover >= threshold = (MAX - rng) % (rng + 1);  value = high half
+// (numpy tests leftover < rng + 1 first -- threshold < rng + 1, so "leftover >= threshold" is the same decision).  A rejected
+// word is skipped, so output i is the i-th ACCEPTED word: a thread walks NK_RNG_FIX raw draws (64 words in 32-bit mode: low
+// half first, then the high half, PCG64's next_uint32 buffering), pass 1 counts its accepted words, pass 2 writes them behind
+// the exclusive sum of the counts; the thread that writes output n - 1 reports how many words the draw consumed.
+// rng + 1 a power of two never rejects.  (rng = 2^32 - 1 and 2^64 - 1 take the raw words themselves: threshold 0.)
+struct NkIntArgs {
+  NkU128 state, inc;
+  int64_t n;        // outputs wanted
+  uint64_t rng;     // high - low
+  int64_t low;
+  int wide;         // 0: 32-bit words, 1: 64-bit draws
+  uint64_t threshold;
+};
+NK_HD bool nk_int_accept(const NkIntArgs& a, uint64_t word, int64_t& value) {
+  if (!a.wide) {
+    const uint32_t excl = (uint32_t)a.rng + 1u;
+    if (excl == 0u) {  // rng = 2^32 - 1
+      value = a.low + (int64_t)word;
+      return true;
+    }
+    const uint64_t m = word * (uint64_t)excl;
+    value = a.low + (int64_t)(m >> 32);
+    return (uint32_t)m >= (uint32_t)a.threshold;
+  }
+  const uint64_t excl = a.rng + 1ull;
+  if (excl == 0ull) {
+    value = (int64_t)((uint64_t)a.low + word);
+    return true;
+  }
+  const uint64_t lo = word * excl, hi = nk_mulhi64(word, excl);
+  value = (int64_t)((uint64_t)a.low + hi);
+  return lo >= a.threshold;
+}
+// words of thread k: accepted count (out == nullptr) or the accepted values written from output index `off` on
+template <typename F>
+NK_HD void nk_int_thread_words(const NkIntArgs& a, const NkPcgJump& jt, int64_t k, F f) {
+  NkRaw g;
+  g.s = nk_pcg_advance(a.state, (uint64_t)k * NK_RNG_FIX, jt);
+  g.inc = a.inc;
+  g.pos = 0;
+  const int per = a.wide ? NK_RNG_FIX : 2 * NK_RNG_FIX;
+  uint64_t raw = 0;
+  for (int i = 0; i < per; ++i) {
+    uint64_t word;
+    if (a.wide) {
+      word = g.next();
+    } else {
+      if ((i & 1) == 0) raw = g.next();
+      word = (i & 1) ? (raw >> 32) : (raw & 0xffffffffull);
+    }
+    int64_t v;
+    const bool ok = nk_int_accept(a, word, v);  // (before the call: the order of argument evaluation is unspecified)
+    if (!f(k * per + i, ok, v)) return;
+  }
+}
+NK_HD int nk_int_count(const NkIntArgs& a, const NkPcgJump& jt, int64_t k) {
+  int c = 0;
+  nk_int_thread_words(a, jt, k, [&](int64_t, bool ok, int64_t) {
+    c += ok ? 1 : 0;
+    return true;
+  });
+  return c;
+}
+NK_HD void nk_int_write(const NkIntArgs& a, const NkPcgJump& jt, int64_t k, int64_t off, int64_t* out, uint64_t* words_used) {
+  nk_int_thread_words(a, jt, k, [&](int64_t word_index, bool ok, int64_t v) {
+    if (!ok) return true;
+    if (off >= a.n) return false;
+    out[off] = v;
+    if (off == a.n - 1) *words_used = (uint64_t)word_index + 1;
+    ++off;
+    return true;
+  });
+}

@@ -121,6 +121,51 @@ __global__ void __launch_bounds__(RNG_THREADS) k_rng_write(NkRngArgs a, const Nk
   nk_rng_pass_b<T>(a, l.jt, z, k, entry, off, out, &status[0]);
 }
 
+// ---- bounded integers (nk_rng.h: NkIntArgs) ----------------------------------------------------------------------------------
+// pass 1: accepted words per thread -> per-block sums (the scan is k_rng_scan's); pass 2: the accepted values behind the
+// exclusive sum.  cnt[] holds at most 64 per thread.
+__global__ void __launch_bounds__(RNG_THREADS) k_int_count(NkIntArgs a, const NkPcgJump* jt, int64_t nthreads, uint8_t* cnt, uint32_t* bsum) {
+  __shared__ NkPcgJump l_jt;
+  __shared__ int s_sum[RNG_THREADS / 64];
+  for (int i = threadIdx.x; i < (int)(sizeof(NkPcgJump) / sizeof(uint64_t)); i += blockDim.x)
+    reinterpret_cast<uint64_t*>(&l_jt)[i] = reinterpret_cast<const uint64_t*>(jt)[i];
+  __syncthreads();
+  const int64_t k = (int64_t)blockIdx.x * RNG_THREADS + threadIdx.x;
+  int c = 0;
+  if (k < nthreads) {
+    c = nk_int_count(a, l_jt, k);
+    cnt[k] = (uint8_t)c;
+  }
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < RNG_THREADS / 64; ++w) t += s_sum[w];
+    bsum[blockIdx.x] = (uint32_t)t;
+  }
+}
+__global__ void __launch_bounds__(RNG_THREADS) k_int_write(NkIntArgs a, const NkPcgJump* jt, int64_t nthreads, const uint8_t* cnt,
+                                                           const int64_t* boff, int64_t* out, uint64_t* status) {
+  __shared__ NkPcgJump l_jt;
+  __shared__ int s_scan[RNG_THREADS];
+  for (int i = threadIdx.x; i < (int)(sizeof(NkPcgJump) / sizeof(uint64_t)); i += blockDim.x)
+    reinterpret_cast<uint64_t*>(&l_jt)[i] = reinterpret_cast<const uint64_t*>(jt)[i];
+  const int64_t k = (int64_t)blockIdx.x * RNG_THREADS + threadIdx.x;
+  const int c = k < nthreads ? cnt[k] : 0;
+  s_scan[threadIdx.x] = c;
+  __syncthreads();
+  for (int d = 1; d < RNG_THREADS; d <<= 1) {
+    const int v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
+    __syncthreads();
+    s_scan[threadIdx.x] += v;
+    __syncthreads();
+  }
+  if (k >= nthreads) return;
+  const int64_t off = boff[blockIdx.x] + s_scan[threadIdx.x] - c;
+  if (off < a.n) nk_int_write(a, l_jt, k, off, out, &status[0]);
+}
+
 struct RngLayout {
   int64_t nchunks, nblk;
   int64_t o_over, o_cnt, o_bsum, o_boff, o_table, total;
@@ -183,6 +228,45 @@ extern "C" int nk_pcg64_pm1(const uint64_t* state, const uint64_t* inc, int64_t 
   if (complex_units)
     return rng_fixed_launch<2>(state, inc, n, 0.0, 0.0, out, dtype, scratch, (hipStream_t)stream, "nk_pcg64_pm1");
   return rng_fixed_launch<1>(state, inc, n, 0.0, 0.0, out, dtype, scratch, (hipStream_t)stream, "nk_pcg64_pm1");
+}
+
+extern "C" int64_t nk_pcg64_integers_scratch_bytes(int64_t nthreads) {
+  if (nthreads < 0) return 0;
+  auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
+  const int64_t nblk = (nthreads + RNG_THREADS - 1) / RNG_THREADS;
+  return up(nthreads) + up(4 * nblk) + up(8 * nblk) + up((int64_t)sizeof(NkPcgJump));
+}
+
+extern "C" int nk_pcg64_integers(const uint64_t* state, const uint64_t* inc, int64_t n, int64_t low, uint64_t rng, int64_t nthreads,
+                                 int64_t* out, void* scratch, uint64_t* status, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!state || !inc || n < 0 || nthreads < 0 || !status || (n > 0 && (!out || !scratch || nthreads < 1)) || rng == 0)
+    return nk_set_error(NK_ERR_INVALID, "nk_pcg64_integers: bad argument (rng = high - low > 0)");
+  if (!(inc[1] & 1)) return nk_set_error(NK_ERR_INVALID, "nk_pcg64_integers: the increment of a PCG64 stream is odd");
+  hipError_t e = hipMemsetAsync(status, 0, 2 * sizeof(uint64_t), stream);
+  if (e != hipSuccess) return nk_set_hip_error(e, "nk_pcg64_integers: hipMemsetAsync");
+  if (n == 0) return NK_OK;
+  NkIntArgs a;
+  a.state = NkU128{state[0], state[1]};
+  a.inc = NkU128{inc[0], inc[1]};
+  a.n = n;
+  a.rng = rng;
+  a.low = low;
+  a.wide = rng > 0xFFFFFFFFull ? 1 : 0;
+  if (a.wide) a.threshold = rng == ~0ull ? 0 : (~0ull - rng) % (rng + 1ull);
+  else a.threshold = rng == 0xFFFFFFFFull ? 0 : (0xFFFFFFFFull - rng) % (rng + 1ull);
+  auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
+  const int64_t nblk = (nthreads + RNG_THREADS - 1) / RNG_THREADS;
+  unsigned char* sc = (unsigned char*)scratch;
+  uint8_t* cnt = sc;
+  uint32_t* bsum = (uint32_t*)(sc + up(nthreads));
+  int64_t* boff = (int64_t*)(sc + up(nthreads) + up(4 * nblk));
+  NkPcgJump* jt = (NkPcgJump*)(sc + up(nthreads) + up(4 * nblk) + up(8 * nblk));
+  hipLaunchKernelGGL(k_rng_table, dim3(1), dim3(1), 0, stream, a.inc, jt);
+  hipLaunchKernelGGL(k_int_count, dim3((unsigned)nblk), dim3(RNG_THREADS), 0, stream, a, jt, nthreads, cnt, bsum);
+  hipLaunchKernelGGL(k_rng_scan, dim3(1), dim3(1024), 0, stream, bsum, nblk, n, boff, status);
+  hipLaunchKernelGGL(k_int_write, dim3((unsigned)nblk), dim3(RNG_THREADS), 0, stream, a, jt, nthreads, cnt, boff, out, status);
+  return nk_check_launch("nk_pcg64_integers");
 }
 
 extern "C" int64_t nk_pcg64_normal_scratch_bytes(int64_t n, int attempt) {

@@ -1872,13 +1872,18 @@ __global__ void k_spmv_t(int64_t nrows, const int64_t* __restrict__ rowptr, cons
 // gathered right behind them -- into LDS, and only then does every thread add up the runs of ITS rows, reading LDS.  The
 // additions of a row run in the order of k_csr_rowsum<T, 1> (ascending entry, one fused multiply-add each): same bits.
 // MB members of a batched launch share the index and weight loads (k_csr_rowsum_b's MB).
-constexpr int NK_STAGED_RPT = 4;                          // rows per thread
-constexpr int NK_STAGED_ROWS = 256 * NK_STAGED_RPT;       // rows per workgroup
+// rows per thread / entries per window: one member 4 / 2048 (24 KiB of LDS); four members 1 / 1024 (36 KiB: the bin sums of a
+// batch -- 3.3 entries per row -- then fit ONE window per workgroup; with 4 / 512 they took seven, and the launch was slower
+// than one thread per row: 105 against 85 us for eight members at 2048^2)
+template <int MB>
+struct NkStaged {
+  static constexpr int RPT = MB == 1 ? 4 : 1, W = MB == 1 ? 2048 : 1024, ROWS = 256 * RPT;
+};
 template <typename T, int MB>
 __global__ void __launch_bounds__(256) k_csr_rowsum_staged(int64_t nrows, const int64_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col, const float* __restrict__ wgt,
                                                            NkPtrs xs, NkPtrs ys, int count) {
-  constexpr int W = 2048 / MB, U = W / 256;
+  constexpr int W = NkStaged<MB>::W, U = W / 256, NK_STAGED_RPT = NkStaged<MB>::RPT, NK_STAGED_ROWS = NkStaged<MB>::ROWS;
   __shared__ double sx[MB][W];
   __shared__ float sw[W];
   const int tid = threadIdx.x, m0 = blockIdx.y * MB;
@@ -1954,7 +1959,7 @@ static inline bool nk_rowsum_staged() {
 template <typename T, int MB>
 static int nk_launch_rowsum_staged(int64_t nrows, const int64_t* rowptr, const int32_t* col, const float* wgt, int count,
                                    const void* const* x, void* const* y, hipStream_t st) {
-  const int64_t blocks = (nrows + NK_STAGED_ROWS - 1) / NK_STAGED_ROWS;
+  const int64_t blocks = (nrows + NkStaged<MB>::ROWS - 1) / NkStaged<MB>::ROWS;
   if (blocks > 0x7fffffffLL) return nk_set_error(NK_ERR_UNSUPPORTED, "nk_csr_rowsum: too many rows for one launch");
   NkPtrs xs, ys;
   for (int m = 0; m < NK_MAX_BATCH; ++m) xs.p[m] = const_cast<void*>(x[m < count ? m : 0]), ys.p[m] = y[m < count ? m : 0];

@@ -173,8 +173,15 @@ class Random:
         n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
         real_dt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
                    np.dtype(np.complex64): torch.float32, np.dtype(np.complex128): torch.float64}.get(dt)
-        host = (config.get("sampling_rng") == "numpy_host" or n < DEVICE_DRAW_MIN or real_dt is None
-                or torch.device(device).type != "cuda")
+        on_gpu = config.get("sampling_rng") != "numpy_host" and n >= DEVICE_DRAW_MIN and torch.device(device).type == "cuda"
+        host = not on_gpu or real_dt is None
+        if random_type == "uniform" and kind == "int" and on_gpu and set(kwargs) <= {"low", "high"}:
+            # integer fields: numpy's bounded-integer stream (Lemire's method, rejected words skipped) on the device
+            low, high = kwargs.get("low", 0), kwargs.get("high", 1)
+            if not (np.issubdtype(type(low), np.integer) and np.issubdtype(type(high), np.integer)):
+                raise TypeError("low and high must be integer")
+            from .field import _NP2T
+            return backend.pcg64_integers(current_rng(), int(low), int(high), shape, device).to(_NP2T.get(dt, torch.int64))
         if random_type == "normal":
             return Random.normal_on_device(dtype, shape, kwargs.pop("mean", 0.0), kwargs.pop("std", 1.0), device, **kwargs)
         rng = current_rng()

@@ -97,3 +97,28 @@ extern "C" int emu_pcg64_fixed(const uint64_t* state, const uint64_t* inc, int64
   }
   return 0;
 }
+
+// bounded integers (nk_pcg64_integers): pass 1 and pass 2 thread after thread.  Returns the status bits; *words = words consumed
+extern "C" unsigned emu_pcg64_integers(const uint64_t* state, const uint64_t* inc, int64_t n, int64_t low, uint64_t rng, int64_t nthreads,
+                                       int64_t* out, uint64_t* words) {
+  NkIntArgs a;
+  a.state = NkU128{state[0], state[1]};
+  a.inc = NkU128{inc[0], inc[1]};
+  a.n = n;
+  a.rng = rng;
+  a.low = low;
+  a.wide = rng > 0xFFFFFFFFull ? 1 : 0;
+  if (a.wide) a.threshold = rng == ~0ull ? 0 : (~0ull - rng) % (rng + 1ull);
+  else a.threshold = rng == 0xFFFFFFFFull ? 0 : (0xFFFFFFFFull - rng) % (rng + 1ull);
+  NkPcgJump jt;
+  nk_pcg_jump_table(a.inc, jt);
+  std::vector<int> cnt(nthreads);
+  for (int64_t k = 0; k < nthreads; ++k) cnt[k] = nk_int_count(a, jt, k);
+  int64_t off = 0;
+  *words = 0;
+  for (int64_t k = 0; k < nthreads; ++k) {
+    if (off < n) nk_int_write(a, jt, k, off, out, words);
+    off += cnt[k];
+  }
+  return off < n ? NK_RNG_ERR_SHORT : 0u;
+}

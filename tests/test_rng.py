@@ -332,3 +332,85 @@ def test_uniform_and_pm1_on_the_device_equal_numpy_including_generator_state():
             assert np.allclose(nrm.asnumpy(), ref_rng.normal(0.0, 1.0, n).astype(dt), rtol=1e-6, atol=0)
         finally:
             ift.random.pop_sseq()
+
+
+# ---- bounded integers: Random.uniform of integer fields (nk_pcg64_integers; reference random.py:252-256) --------------------
+INT_RANGES = [(0, 6), (0, 7), (-3, 11), (10, 1000), (0, 2 ** 31), (0, 2 ** 32 - 2), (0, 2 ** 32 - 1), (0, 2 ** 32), (0, 2 ** 40),
+              (-2 ** 62, 2 ** 62), (0, 2 ** 63 - 1), (-2 ** 63, 2 ** 63 - 1), (5, 5)]
+
+
+def _int_emu_draw(state, inc, need, lo, span, nthreads):
+    lib = _emu()
+    lib.emu_pcg64_integers.restype = ctypes.c_uint
+    lib.emu_pcg64_integers.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int64,
+                                       ctypes.c_void_p, ctypes.c_void_p]
+    words = (ctypes.c_uint64 * 4)(state >> 64, state & (2 ** 64 - 1), inc >> 64, inc & (2 ** 64 - 1))
+    out, used = np.zeros(need, dtype=np.int64), ctypes.c_uint64(0)
+    err = lib.emu_pcg64_integers(ctypes.addressof(words), ctypes.addressof(words) + 16, need, lo, span, nthreads, out.ctypes.data,
+                                 ctypes.addressof(used))
+    return out, int(used.value), bool(err & 2)
+
+
+@pytest.mark.parametrize("low,high", INT_RANGES)
+@pytest.mark.parametrize("n,pre", [(1, 0), (45, 1), (5000, 0), (5000, 3)])
+def test_bounded_integer_bodies_equal_numpy(low, high, n, pre):
+    """The two passes of nk_pcg64_integers (host emulation) + the host bookkeeping around them (backend._bounded_integers:
+    PCG64's buffered 32-bit half, retry sizing, the state afterwards) against numpy's Generator.integers, bit for bit --
+    values AND generator state: 32-bit Lemire with rejections (ranges near 2^31 reject every other word), the raw-word
+    ranges 2^32 - 1 and 2^64 - 1, 64-bit Lemire, the empty range; `pre` bounded draws before set the buffered half."""
+    from nifty_amd import backend as B
+
+    a, b = np.random.default_rng(123), np.random.default_rng(123)
+    for r in (a, b):
+        for _ in range(pre):
+            r.integers(0, 4)
+    ref = a.integers(low, high, n, endpoint=True)
+    first, rest = B._bounded_integers(b, low, high, n, _int_emu_draw)
+    got = np.array(list(first) + ([] if rest is None else list(rest)), dtype=np.int64)
+    assert np.array_equal(got, ref)
+    assert a.bit_generator.state == b.bit_generator.state
+    assert a.normal() == b.normal()  # ... and the streams continue together
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("low,high", INT_RANGES)
+def test_device_bounded_integers_equal_numpy(low, high):
+    """backend.pcg64_integers on the GPU against numpy: values, generator state, a following draw."""
+    import torch
+
+    from nifty_amd import backend as B
+
+    for n, pre in ((1, 0), (77, 1), (300000, 0), (300001, 1)):
+        a, b = np.random.default_rng(9), np.random.default_rng(9)
+        for r in (a, b):
+            for _ in range(pre):
+                r.integers(0, 4)
+        ref = a.integers(low, high, n, endpoint=True)
+        got = B.pcg64_integers(b, low, high, (n,), torch.device("cuda:0"))
+        assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), ref)
+        assert a.bit_generator.state == b.bit_generator.state
+
+
+@pytest.mark.gpu
+def test_integer_uniform_fields_on_the_device_equal_the_reference():
+    """Field.from_random(..., 'uniform', dtype=int) on a GPU (random.Random.on_device -> nk_pcg64_integers) against what the
+    REFERENCE drew for the same seed (tests/golden/small_ops.npz: ranges 7, 8, 15, 991, 2^40 + 1 and the empty range; int64
+    and int32) -- small fields on the host path, large ones on the device, both the reference's numbers."""
+    import nifty_amd as ift
+    from nifty_amd import random as R
+    from tests import goldenlib as gl
+
+    z = gl.load("small_ops")
+    for tag, dt, shape in (("u7", np.int64, (5, 9)), ("u8", np.int64, (33,)), ("un", np.int64, (4, 4, 4)), ("u32", np.int32, (77,)),
+                           ("big", np.int64, (19,)), ("one", np.int64, (6,))):
+        low, high = (int(v) for v in z[f"uni.{tag}.args"])
+        for min_n in (1 << 15, 1):  # the package's threshold, then every draw on the device
+            old, R.DEVICE_DRAW_MIN = R.DEVICE_DRAW_MIN, min_n
+            try:
+                with ift.random.Context(123):
+                    f = ift.Field.from_random(ift.UnstructuredDomain(shape), "uniform", dtype=dt, low=low, high=high, device_id=0)
+                    after = ift.random.current_rng().normal(size=3)
+            finally:
+                R.DEVICE_DRAW_MIN = old
+            assert f.device_id == 0 and f.dtype == np.dtype(dt)
+            assert np.array_equal(f.asnumpy(), z[f"uni.{tag}"]) and np.array_equal(after, z[f"uni.{tag}.after"])
