@@ -205,7 +205,15 @@ static int nk_launch_final(const NkPassF& pf, const NkFuse& f, const C2<T>* tw, 
     if (f.epi == NK_EPI_VJP) return nk_launch_final_c<T, NL, true, -1>(pf, f, tw, work, st);
     return nk_launch_final_c<T, NL, false, -1>(pf, f, tw, work, st);
   }
-  if (f.epi == NK_EPI_VJP && f.afield) return nk_launch_final_c<T, NL, true, 2>(pf, f, tw, work, st);
+  if (f.epi == NK_EPI_VJP && f.afield) {
+    // 2-D grids have no couples of lines (A == 1: the slots are single pairs anyway), yet the couple tile of two pairs is what
+    // the COUPLES kernels are built on -- at 4096 fp64 points 135 KiB of LDS, ONE workgroup per CU.  For such lines the
+    // single-pair build runs instead (half the LDS, twice the resident workgroups): the same slots, lanes and reduction-slot
+    // order, i.e. the same bits
+    if constexpr (nk_final_single_2d<T, NL>())
+      if (pf.A == 1) return nk_launch_final_c<T, NL, false, 2>(pf, f, tw, work, st);
+    return nk_launch_final_c<T, NL, true, 2>(pf, f, tw, work, st);
+  }
   if (f.epi == NK_EPI_VJP) return nk_launch_final_c<T, NL, true, -1>(pf, f, tw, work, st);
   if (f.epi == NK_EPI_AFFINE) return nk_launch_final_c<T, NL, false, 0>(pf, f, tw, work, st);
   if (f.epi == NK_EPI_MUL) return nk_launch_final_c<T, NL, false, 1>(pf, f, tw, work, st);

@@ -297,6 +297,16 @@ struct FinalTile {
   static constexpr int LDS_BYTES = 2 * TILE * PITCH * (int)sizeof(T);
 };
 
+#ifndef NK_FINAL_SINGLE_2D_KB
+#define NK_FINAL_SINGLE_2D_KB 60  // fp64 lines of 2048 / 4096 and fp32 lines of 4096 points: couple tiles of 68 / 135 KiB
+#endif
+// VJP final pass of 2-D grids on single line pairs instead of the couple tile, where the couple tile leaves one or two
+// workgroups per CU (measured: 4096^2 fp64 195 -> 150 us per launch, C4 1.59 -> 1.64 it/s; 2048^2 fp64 C2 14.39 -> 14.76 it/s)
+template <typename T, int NL>
+constexpr bool nk_final_single_2d() {
+  return FinalTile<T, NL, 2, 2>::LDS_BYTES > NK_FINAL_SINGLE_2D_KB * 1024;
+}
+
 // store of a streamed element (written once, read by a later kernel from HBM anyway): non-temporal stores keep the
 // write stream out of the way of the reads -- in one bench step at 1024^3 fp32: first-pass family 2.53 -> 2.49 ms, in-place
 // pass 2.03 -> 1.96 ms, final-pass family unchanged within noise, step -0.5 % (non-temporal LOADS of the streamed inputs

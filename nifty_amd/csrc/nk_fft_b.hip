@@ -99,3 +99,7 @@ int nk_twin_launch_final(const NkPassF& pf, int64_t blocks, const C2<T>* tw, int
   template int nk_twin_launch_final<double, NN, false, 3>(const NkPassF&, int64_t, const C2<double>*, int, hipStream_t);         \
   template int nk_twin_launch_final<double, NN, false, -1>(const NkPassF&, int64_t, const C2<double>*, int, hipStream_t);
 NK_TWIN_SIZES(NK_TWINS)
+// the single-pair VJP final pass of 2-D grids (nk_final_single_2d)
+template int nk_twin_launch_final<double, 4096, false, 2>(const NkPassF&, int64_t, const C2<double>*, int, hipStream_t);
+template int nk_twin_launch_final<double, 2048, false, 2>(const NkPassF&, int64_t, const C2<double>*, int, hipStream_t);
+template int nk_twin_launch_final<float, 4096, false, 2>(const NkPassF&, int64_t, const C2<float>*, int, hipStream_t);

@@ -22,7 +22,7 @@
 // the opposite case (six resident workgroups at 168 VGPRs beat four at 175: 51.9 vs 54.0 ms per four-sample application).
 template <typename T, bool COUPLES, int EC, int THREADS>
 constexpr int nk_final_waves() {
-  return THREADS > 256 ? 1 : (sizeof(T) == 8 && COUPLES) ? 2 : ((!COUPLES && sizeof(T) == 4 && (EC == 0 || EC == 1)) ? 4 : 3);
+  return THREADS > 256 ? 1 : (sizeof(T) == 8 && (COUPLES || EC == 2)) ? 2 : ((!COUPLES && sizeof(T) == 4 && (EC == 0 || EC == 1)) ? 4 : 3);
 }
 
 // fp64 sum of `acc` over the workgroup (only when the epilogue produces an energy).  With slots (set up by the library for
@@ -94,8 +94,10 @@ constexpr bool nk_twin_strided() {
 }
 template <int NL, bool COUPLES, int EC, int PAIR>
 constexpr bool nk_twin_final() {
-  return NL >= 512 && PAIR == 0 && ((COUPLES && EC == 2) || (!COUPLES && (EC == 1 || EC == 3 || EC == -1)));
+  return NL >= 512 && PAIR == 0 && ((COUPLES && EC == 2) || (!COUPLES && (EC == 1 || EC == 3 || EC == -1)) ||
+                                    (!COUPLES && EC == 2 && NL >= 2048));  // (the single-pair VJP build of 2-D grids, nk_final_single_2d)
 }
+
 static bool nk_batch_class_ok(const NkGeom& g, const nk_fuse& f) {
   static const int generic = nk_env_int("NK_EC_GENERIC", 0);
   if (generic || g.na < 512 || g.nl < 512) return false;

@@ -185,7 +185,8 @@ static void emu2_final_ec(const NkPassF& pf0, const nk_fuse& f, const C2<T>* tw,
 template <typename T, int NL>
 static void emu2_final(const NkPassF& pf, const nk_fuse& f, const C2<T>* tw, const C2<T>* work, double* energy) {
   const bool couples = f.epi == NK_EPI_VJP;  // same dispatch as nk_launch_final
-  if (couples && f.afield) emu2_final_ec<T, NL, true, 2>(pf, f, tw, work, energy);
+  if (couples && f.afield && nk_final_single_2d<T, NL>() && pf.A == 1) emu2_final_ec<T, NL, false, 2>(pf, f, tw, work, energy);  // as nk_launch_final
+  else if (couples && f.afield) emu2_final_ec<T, NL, true, 2>(pf, f, tw, work, energy);
   else if (couples) emu2_final_ec<T, NL, true, -1>(pf, f, tw, work, energy);
   else if (f.epi == NK_EPI_AFFINE) emu2_final_ec<T, NL, false, 0>(pf, f, tw, work, energy);
   else if (f.epi == NK_EPI_MUL) emu2_final_ec<T, NL, false, 1>(pf, f, tw, work, energy);

@@ -80,7 +80,8 @@ FUSED_SHAPES = [((64,), "emu_hartley_fused"), ((16, 8), "emu_hartley_fused"), ((
                 ((30,), "emu_hartley_fused"), ((10, 12), "emu_hartley_fused"), ((6, 5, 14), "emu_hartley_fused"),
                 ((256,), "emu2_hartley_fused"), ((64, 128), "emu3_hartley_fused"), ((64, 64, 64), "emu3_hartley_fused"),
                 ((64, 64, 1024), "emu3_hartley_fused"),  # last axis 1024 in fp64: the smallest final-pass tile
-                ((2048, 64), "emu3_hartley_fused"), ((4096, 128), "emu3_hartley_fused")]  # two-level first-axis pass (64 x 32, 64 x 64)
+                ((2048, 64), "emu3_hartley_fused"), ((4096, 128), "emu3_hartley_fused"),  # two-level first-axis pass (64 x 32, 64 x 64)
+                ((64, 4096), "emu3_hartley_fused")]  # 2-D VJP final pass on single line pairs (nk_final_single_2d: 4096 fp64)
 
 
 @pytest.mark.parametrize("shape,fn", FUSED_SHAPES)
