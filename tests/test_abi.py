@@ -108,6 +108,7 @@ def test_chirp_z_fallback_terminates_and_is_exact(monkeypatch):
         out[..., :k] = scale * (src if w is None else src * w[:k])
         return out
 
+    monkeypatch.setenv("NK_BLUESTEIN", "0")  # the COMPOSITION (rows too long for the one-launch kernel's LDS take it on a GPU too)
     monkeypatch.setattr(B, "cplx_rows", glue)
     monkeypatch.setattr(B, "plan_supported", pow2_only)
     monkeypatch.setattr(B, "get_plan", plan)
