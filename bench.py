@@ -79,9 +79,12 @@ def kernel_symbol(kern, pro, epi, shape, dt_name, octant=True, wide=False, const
     pc_first = {0: "0", 1: "4" if octant else "1", 2: "5" if octant else "3", 3: "6", 4: "8"}[pro]  # prologue class of a first pass
     ec = {0: "0", 1: "1", 2: "2", 3: "3", 4: "-1"}[epi]                                    # epilogue class of a final pass
     couples = "true" if epi == 2 else "false"
+    two_level = len(shape) == 2 and M == 4096 and T == "double" and os.environ.get("NK_TWO_LEVEL", "1") != "0"  # nk_tl_split
     if kern == 1:
         if wide and pro == 1 and epi == 3:  # value / gradient forward of an fp32 model: fp64 kernels, float arrays at the ends
             return f"k2_strided<double,{M},3,9>"
+        if two_level:  # the two launches of the two-level first-axis pass, timed together
+            return f"k2_tl<{T},64,4,{pc_first}> + k2_tl<{T},64,5,-1>"
         return f"k2_strided<{T},{M},3,{pc_first}>"
     if kern == 2:
         return f"k2_strided<{'double' if wide and pro == 1 and epi == 3 else T},{A if len(shape) == 3 else M},0,-1>"
@@ -89,6 +92,8 @@ def kernel_symbol(kern, pro, epi, shape, dt_name, octant=True, wide=False, const
         if wide and pro == 1 and epi == 3:
             return f"k2_final<double,{NL},false,5,0>"
         pair = "1" if (pro == 2 and epi == 2 and len(shape) == 3) else "0"   # a sandwich's final pass: row-mirror pairing
+        if epi == 2 and len(shape) == 2 and NL * (8 if T == "double" else 4) >= 16384:
+            couples = "false"  # 2-D VJP on single line pairs where the couple tile limits residency (nk_final_single_2d)
         return f"k2_final<{T},{NL},{couples},{ec},{pair}>"
     if kern == 5:
         return f"k3_contig_quad<{T},{NL // 2},{pc_first}>"  # (8 = 5 with the CG direction update: profile key pro 4)
