@@ -1491,19 +1491,21 @@ class FFTShiftOperator(EndomorphicOperator):
     def __init__(self, domain, spaces=None):
         self._domain = DomainTuple.make(domain)
         self._capability = self._all_ops
-        nsp = len(self._domain)
-        if spaces is None:
-            spaces = tuple(range(nsp))
-        elif isinstance(spaces, (int, np.integer)):
-            spaces = (int(spaces),)
-        spaces = tuple(spaces)
-        if not all(isinstance(i, (int, np.integer)) and -nsp <= i < nsp for i in spaces):
-            raise ValueError("spaces: indices into the domain tuple")
-        picked = sorted({int(i) % nsp for i in spaces})
+        self._axes = tuple(ax for i in self._selected(spaces) for ax in self._domain.axes[i])
+
+    def _selected(self, spaces):
+        """Sorted, unique, non-negative positions in the domain tuple; every one of them an RGSpace."""
+        count = len(self._domain)
+        wanted = range(count) if spaces is None else ([spaces] if isinstance(spaces, (int, np.integer)) else list(spaces))
+        picked = set()
+        for entry in wanted:
+            if not isinstance(entry, (int, np.integer)) or not -count <= entry < count:
+                raise ValueError("spaces: indices into the domain tuple")
+            picked.add(int(entry) % count)
         for i in picked:
             if not isinstance(self._domain[i], RGSpace):
                 raise TypeError("FFTShiftOperator only shifts RGSpaces")
-        self._axes = tuple(ax for i in picked for ax in self._domain.axes[i])
+        return sorted(picked)
 
     def apply(self, x, mode):
         self._check_input(x, mode)
@@ -1525,34 +1527,40 @@ class InversionEnabler(EndomorphicOperator):
     iterate, like the reference.  On a GPU the solve is minimization.ConjugateGradient on the nk_cg_* kernels."""
 
     def __init__(self, op, iteration_controller, approximation=None):
-        if not isinstance(op, LinearOperator):
-            raise TypeError("Operator needs to be linear.")
-        if op.domain is not op.target and op.domain != op.target:
-            raise TypeError("Operator needs to be endomorphic.")
-        self._op, self._ic, self._approximation = op, iteration_controller, approximation
+        problems = {"Operator needs to be linear.": not isinstance(op, LinearOperator),
+                    "Operator needs to be endomorphic.": isinstance(op, LinearOperator) and op.domain is not op.target
+                    and op.domain != op.target}
+        for text, bad in problems.items():
+            if bad:
+                raise TypeError(text)
         self._domain = op.domain
+        self._wrapped = dict(op=op, controller=iteration_controller, preconditioner=approximation)
         self._capability = self._add_inverse_capability(op.capability)
+
+    def _by_solve(self, rhs, mode):
+        """y with  op|mode^-1 (y) = rhs : `mode` is the inverse of a mode `op` has, so flip the inverse bit and run CG from 0."""
+        from .minimization import ConjugateGradient, IterationController, QuadraticEnergy, logger
+
+        which = _mode_index(mode)
+        forward = self._wrapped["op"]._flip_modes(which ^ self.INVERSE_BIT)
+        approx = self._wrapped["preconditioner"]
+        problem = QuadraticEnergy(rhs * 0.0, forward, rhs)
+        result, status = ConjugateGradient(self._wrapped["controller"])(
+            problem, preconditioner=None if approx is None else approx._flip_modes(which))
+        if status != IterationController.CONVERGED:
+            logger.warning("Error detected during operator inversion")
+        return result.position
 
     def apply(self, x, mode):
         self._check_mode(mode)
-        if self._op.capability & mode:
-            return self._op.apply(x, mode)
-        from .minimization import ConjugateGradient, IterationController, QuadraticEnergy, logger
-
-        # the mode asked for is the inverse of one `op` has: solve  op|that mode (y) = x
-        have = self._op._flip_modes(_mode_index(mode) ^ self.INVERSE_BIT)
-        prec = None if self._approximation is None else self._approximation._flip_modes(_mode_index(mode))
-        start = x * 0.0
-        solved, status = ConjugateGradient(self._ic)(QuadraticEnergy(start, have, x), preconditioner=prec)
-        if status != IterationController.CONVERGED:
-            logger.warning("Error detected during operator inversion")
-        return solved.position
+        op = self._wrapped["op"]
+        return op.apply(x, mode) if op.capability & mode else self._by_solve(x, mode)
 
     def draw_sample(self, from_inverse=False, device_id=-1):
-        return self._op.draw_sample(from_inverse, device_id)
+        return self._wrapped["op"].draw_sample(from_inverse, device_id)
 
     def __repr__(self):
-        return "InversionEnabler:\n  " + repr(self._op).replace("\n", "\n  ")
+        return "InversionEnabler:\n  " + repr(self._wrapped["op"]).replace("\n", "\n  ")
 
 
 class _JacCountingOperator(EndomorphicOperator):
