@@ -11,7 +11,7 @@ __version__ = "0.1.0"
 from . import config, extra, parallel, random  # noqa: F401
 from .correlated_fields import (CorrelatedFieldMaker, CorrelatedFieldOperator, LognormalTransform,  # noqa: F401
                                 NormalTransform, SimpleCorrelatedField)
-from .domains import (DomainTuple, MultiDomain, PowerSpace, RGSpace, StructuredDomain, UnstructuredDomain,  # noqa: F401
+from .domains import (DomainTuple, GLSpace, HPSpace, LMSpace, MultiDomain, PowerSpace, RGSpace, StructuredDomain, UnstructuredDomain,  # noqa: F401
                       makeDomain)
 from .energy_operators import (AveragedEnergy, BernoulliEnergy, CategoricalEnergy, EnergyOperator, GaussianEnergy, InverseGammaEnergy, LikelihoodEnergyOperator, PoissonianEnergy,  # noqa: F401
                                QuadraticFormOperator, Squared2NormOperator, StandardHamiltonian, StudentTEnergy,
@@ -34,6 +34,7 @@ from .operators import (Adder, BlockDiagonalOperator, ChainOperator, Contraction
 from .los_response import LOSResponse  # noqa: F401
 from .optimize_kl import optimize_kl  # noqa: F401
 from .parallel import shareRange  # noqa: F401
+from . import utilities  # noqa: E402,F401
 
 
 _nthreads = 1

@@ -3,7 +3,9 @@
 Counterpart of reference nifty/cl/domains/{domain,structured_domain,unstructured_domain,rg_space,
 power_space}.py, nifty/cl/domain_tuple.py and nifty/cl/multi_domain.py.  DomainTuple / MultiDomain
 objects are interned so that identity (``is``) is the equality test, as in the reference
-(domain_tuple.py:74-85, multi_domain.py:38-60).  Spherical domains are out of scope.
+(domain_tuple.py:74-85, multi_domain.py:38-60).  The spherical domains (LMSpace, HPSpace, GLSpace) are geometry descriptors
+only -- sizes, volumes, |k| tables, so that fields, diagonal / selection operators and power spaces over them work; the
+spherical harmonic transforms between them are out of scope and HarmonicTransformOperator says so.
 """
 from functools import reduce
 
@@ -390,6 +392,134 @@ class PowerSpace(StructuredDomain):
         if wanted > finest:
             raise ValueError("nbin is too large")
         return (PowerSpace.logarithmic_binbounds if logarithmic else PowerSpace.linear_binbounds)(wanted, *outer)
+
+
+class LMSpace(StructuredDomain):
+    """Spherical-harmonic coefficients a_lm up to lmax / mmax, stored as reals: the m = 0 column (lmax+1 values), then for
+    every m >= 1 the (real, imaginary) pairs of l = m..lmax (reference domains/lm_space.py:24-165).  Geometry only."""
+
+    def __init__(self, lmax, mmax=None):
+        self._lmax = int(lmax)
+        if self._lmax < 0:
+            raise ValueError("lmax must be >=0.")
+        self._mmax = self._lmax if mmax is None else int(mmax)
+        if not 0 <= self._mmax <= self._lmax:
+            raise ValueError("mmax must be >=0 and <=lmax.")
+
+    def _key(self):
+        return (self._lmax, self._mmax)
+
+    def __repr__(self):
+        return f"LMSpace(lmax={self._lmax}, mmax={self._mmax})"
+
+    harmonic = property(lambda self: True)
+    lmax = property(lambda self: self._lmax)
+    mmax = property(lambda self: self._mmax)
+    scalar_dvol = property(lambda self: 1.0)
+
+    @property
+    def size(self):
+        # one real per (l, m = 0), two per (l, m >= 1): sum over m of the column lengths lmax + 1 - m
+        cols = self._lmax + 1 - np.arange(self._mmax + 1)
+        return int(2 * cols.sum() - cols[0])
+
+    @property
+    def shape(self):
+        return (self.size,)
+
+    def _dist_array(self):
+        """l of every stored coefficient (float64)"""
+        ls = np.arange(self._lmax + 1, dtype=np.float64)
+        return np.concatenate([ls] + [np.repeat(ls[m:], 2) for m in range(1, self._mmax + 1)])
+
+    def get_k_length_array(self):
+        from .field import Field
+
+        return Field.from_raw(self, self._dist_array())
+
+    def get_unique_k_lengths(self):
+        return np.arange(self._lmax + 1, dtype=np.float64)
+
+    def get_fft_smoothing_kernel_function(self, sigma):
+        """l -> exp(-sigma^2 l (l+1) / 2), the spherical image of a Gaussian beam (lm_space.py:86-94)"""
+        return lambda x: ((x + 1.0) * x * (-0.5 * sigma * sigma)).ptw("exp")
+
+    def get_default_codomain(self):
+        return GLSpace(self._lmax + 1, 2 * self._mmax + 1)
+
+    def check_codomain(self, codomain):
+        if not isinstance(codomain, (GLSpace, HPSpace)):
+            raise TypeError("codomain must be a GLSpace or HPSpace.")
+
+
+class HPSpace(StructuredDomain):
+    """The sphere in 12 nside^2 equal-area HEALPix pixels (reference domains/hp_space.py:23-93).  Geometry only."""
+
+    def __init__(self, nside):
+        self._nside = int(nside)
+        if self._nside < 1:
+            raise ValueError("nside must be >=1.")
+
+    def _key(self):
+        return (self._nside,)
+
+    def __repr__(self):
+        return f"HPSpace(nside={self._nside})"
+
+    harmonic = property(lambda self: False)
+    nside = property(lambda self: self._nside)
+    size = property(lambda self: 12 * self._nside * self._nside)
+    shape = property(lambda self: (self.size,))
+    scalar_dvol = property(lambda self: np.pi / (3 * self._nside * self._nside))
+
+    def get_default_codomain(self):
+        return LMSpace(lmax=2 * self._nside)
+
+    def check_codomain(self, codomain):
+        if not isinstance(codomain, LMSpace):
+            raise TypeError("codomain must be a LMSpace.")
+
+
+class GLSpace(StructuredDomain):
+    """The sphere on nlat Gauss-Legendre rings of nlon pixels each (reference domains/gl_space.py:23-126).  Geometry only;
+    the ring weights are numpy's Gauss-Legendre weights times the azimuthal pixel width 2 pi / nlon."""
+
+    def __init__(self, nlat, nlon=None):
+        self._nlat = int(nlat)
+        if self._nlat < 1:
+            raise ValueError("nlat must be a positive number.")
+        self._nlon = 2 * self._nlat - 1 if nlon is None else int(nlon)
+        if self._nlon < 1:
+            raise ValueError("nlon must be a positive number.")
+        self._ring_weights = None
+
+    def _key(self):
+        return (self._nlat, self._nlon)
+
+    def __repr__(self):
+        return f"GLSpace(nlat={self._nlat}, nlon={self._nlon})"
+
+    harmonic = property(lambda self: False)
+    nlat = property(lambda self: self._nlat)
+    nlon = property(lambda self: self._nlon)
+    size = property(lambda self: self._nlat * self._nlon)
+    shape = property(lambda self: (self.size,))
+    scalar_dvol = property(lambda self: None)
+    total_volume = property(lambda self: 4 * np.pi)
+
+    @property
+    def dvol(self):
+        if self._ring_weights is None:
+            self._ring_weights = np.polynomial.legendre.leggauss(self._nlat)[1] * (2 * np.pi / self._nlon)
+        return np.repeat(self._ring_weights, self._nlon)
+
+    def get_default_codomain(self):
+        mmax = self._nlon // 2
+        return LMSpace(lmax=max(mmax, self._nlat - 1), mmax=mmax)
+
+    def check_codomain(self, codomain):
+        if not isinstance(codomain, LMSpace):
+            raise TypeError("codomain must be a LMSpace.")
 
 
 def _interned(cache, key, build):
