@@ -35,6 +35,13 @@ from .los_response import LOSResponse  # noqa: F401
 from .optimize_kl import optimize_kl  # noqa: F401
 from .parallel import shareRange  # noqa: F401
 from . import utilities  # noqa: E402,F401
+from . import sugar  # noqa: E402,F401
+from .sugar import (PS_field, calculate_position, create_harmonic_smoothing_operator, create_power_operator, exec_time,  # noqa: E402,F401
+                    get_default_codomain, get_signal_variance, power_analyze)
+from .sugar import (abs, absolute, arctan, clip, cos, cosh, exp, expm1, exponentiate, log, log10, log1p, power, reciprocal,  # noqa: E402,F401,A004
+                    sigmoid, sign, sin, sinc, sinh, softplus, sqrt, tan, tanh, unitstep)
+from .domains import Domain  # noqa: E402,F401
+from .operators import domain_union  # noqa: E402,F401
 
 
 _nthreads = 1
@@ -95,3 +102,10 @@ def is_likelihood_energy(obj):
 
 
 from .kl import SampleListBase  # noqa: E402,F401
+from .field import is_fieldlike as _is_field_or_multifield  # noqa: E402
+
+
+def is_fieldlike(obj):  # noqa: F811
+    """operators/operator.py:676-684: Fields, MultiFields and Linearizations -- what an operator can be applied to and that
+    carries a value (inside the package `field.is_fieldlike` keeps meaning Field / MultiField)."""
+    return _is_field_or_multifield(obj) or isinstance(obj, Linearization)

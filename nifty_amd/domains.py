@@ -595,6 +595,34 @@ class DomainTuple:
     def axes(self):
         return self._axes
 
+    def _chosen(self, spaces):
+        n = len(self._dom)
+        if spaces is None:
+            return tuple(range(n))
+        chosen = (int(spaces),) if np.isscalar(spaces) else tuple(int(x) for x in spaces)
+        if any(c < 0 or c >= n for c in chosen) or len(set(chosen)) != len(chosen):
+            raise ValueError("invalid sub-domain index")
+        return tuple(sorted(chosen))
+
+    def scalar_weight(self, spaces=None):
+        """The uniform pixel volume over the sub-domains `spaces`, None when one of them has individual volumes
+        (domain_tuple.py:137-147)"""
+        vol = 1.0
+        for c in self._chosen(spaces):
+            one = self._dom[c].scalar_dvol
+            if one is None:
+                return None
+            vol *= one
+        return vol
+
+    def total_volume(self, spaces=None):
+        """domain_tuple.py:149-159"""
+        vol = 1.0
+        for c in self._chosen(spaces):
+            vol *= self._dom[c].total_volume
+        return vol
+
+
     def __hash__(self):
         return hash(self._dom)
 

@@ -6,7 +6,7 @@ import numpy as np
 from .field import Field, MultiField, device_available, from_random
 from .operators import Linearization, LinearOperator, Operator
 
-__all__ = ["check_linear_operator", "check_operator", "assert_allclose", "minisanity"]
+__all__ = ["check_linear_operator", "check_operator", "assert_allclose", "assert_equal", "minisanity"]
 
 
 def assert_allclose(f1, f2, atol=0, rtol=1e-7):
@@ -19,6 +19,17 @@ def assert_allclose(f1, f2, atol=0, rtol=1e-7):
         pairs = [(f1, f2)]
     for a, b in pairs:
         np.testing.assert_allclose(a.asnumpy(), b.asnumpy(), atol=atol, rtol=rtol)
+
+
+def assert_equal(f1, f2, *, atol=0.0, rtol=0.0):
+    """Exact agreement by default (reference extra.py:198-204)."""
+    assert_allclose(f1, f2, atol=atol, rtol=rtol)
+
+
+def _same_answer_twice(op, x):
+    """An operator is a pure function of its input: applying it twice gives the same bits (extra.py:368-380; the device
+    reductions of libniftyk are built in a fixed order, so this holds on the GPU too)."""
+    assert_equal(op(x), op(x))
 
 
 def _device_ids(force_device_ids):
@@ -44,6 +55,7 @@ def _check_one(op, dt_dom, dt_tgt, atol, rtol, only_r_linear, dev):
     rnd = lambda dom, dt: from_random(dom, "normal", dtype=dt, device_id=dev)  # noqa: E731
     if _has(op, op.TIMES):
         x, y = rnd(op.domain, dt_dom), rnd(op.domain, dt_dom)
+        _same_answer_twice(op, x)
         res = op(x)
         if res.domain is not op.target or x.domain is not op.domain:
             raise AssertionError("operator does not map its domain to its target")
@@ -94,6 +106,7 @@ def check_operator(op, loc, tol=1e-12, ntries=100, only_r_differentiable=True, f
     ftol = np.sqrt(tol)
     for dev in _device_ids(force_device_ids):
         pos = loc.at(dev)
+        _same_answer_twice(op, pos)
         for wm in (False, True):
             lin = op(Linearization.make_var(pos, wm))
             assert_allclose(op(pos), lin.val, 0, 1e-7)

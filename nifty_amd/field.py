@@ -274,14 +274,122 @@ class Field:
         uniform = uniform ** power
         return out * uniform if uniform != 1.0 else (out if out is not self else Field(self._domain, self._val.clone()))
 
+    # ---- volumes and statistics (reference field.py:257-283, 419-664).  Small diagnostics: whole-field scalars of device
+    # fields go through the fixed-order device sums (s_sum / s_vdot); partial reductions through ContractionOperator.
+    def scalar_weight(self, spaces=None):
+        return self._domain.scalar_weight(spaces)
+
+    def total_volume(self, spaces=None):
+        return self._domain.total_volume(spaces)
+
+    def integrate(self, spaces=None):
+        uniform = self.scalar_weight(spaces)
+        if uniform is not None:
+            return self.sum(spaces) * uniform
+        return self.weight(1, spaces=spaces).sum(spaces)
+
+    def s_integrate(self):
+        uniform = self.scalar_weight()
+        return self.s_sum() * uniform if uniform is not None else self.weight(1).s_sum()
+
+    def mean(self, spaces=None):
+        """integrate(spaces) / total_volume(spaces): the plain mean for uniform pixels"""
+        if self.scalar_weight(spaces) is not None:
+            count = int(np.prod([self._domain[c].size for c in self._domain._chosen(spaces)], dtype=np.int64))
+            return self.sum(spaces) * (1.0 / count)
+        return self.integrate(spaces) * (1.0 / self.total_volume(spaces))
+
     def s_mean(self):
-        return self.s_sum() / self.size
+        return self.s_integrate() / self.total_volume()
+
+    def _spread(self, spaces):
+        """|self - mean|^2 with the mean over `spaces` broadcast back"""
+        from .operators import ContractionOperator
+
+        centre = self.mean(spaces)
+        if len(self._domain._chosen(spaces)) != len(self._domain) or centre.domain is not self._domain:
+            centre = ContractionOperator(self._domain, spaces).adjoint_times(centre)
+        dev = self - centre
+        return (dev.conjugate() * dev).real if self._val.is_complex() else dev * dev
+
+    def var(self, spaces=None):
+        return self._spread(spaces).mean(spaces)
+
+    def s_var(self):
+        return self._spread(None).s_mean()
+
+    def std(self, spaces=None):
+        return self.var(spaces).ptw("sqrt")
+
+    def s_std(self):
+        return float(np.sqrt(self.s_var()))
+
+    def _host_contraction(self, name, spaces):
+        """prod / all / any over sub-domains: diagnostics, evaluated by torch on whatever device holds the data"""
+        chosen = self._domain._chosen(spaces)
+        if len(chosen) == len(self._domain):
+            return Field.scalar(getattr(self, "s_" + name)()).at(self.device_id)
+        axes = tuple(a for c in chosen for a in self._domain.axes[c])
+        out = self._val
+        for ax in sorted(axes, reverse=True):
+            out = getattr(torch, name)(out, dim=ax)
+        from .domains import DomainTuple
+
+        return Field(DomainTuple.make([d for i, d in enumerate(self._domain) if i not in chosen]), out)
+
+    def prod(self, spaces=None):
+        return self._host_contraction("prod", spaces)
+
+    def s_prod(self):
+        r = self._val.prod()
+        return complex(r) if r.is_complex() else float(r)
+
+    def all(self, spaces=None):
+        return self._host_contraction("all", spaces)
+
+    def any(self, spaces=None):
+        return self._host_contraction("any", spaces)
 
     def s_all(self):
         return bool(self._val.all())
 
     def s_any(self):
         return bool(self._val.any())
+
+    def outer(self, x):
+        """The field self (x) x on the product of both domains (field.py:324-341)"""
+        if not isinstance(x, Field):
+            raise TypeError("The multiplier must be an instance of the Field class")
+        from .domains import DomainTuple
+
+        a = self._val.reshape(self._val.shape + (1,) * x._val.dim())
+        return Field(DomainTuple.make(tuple(self._domain) + tuple(x._domain)), _binary("mul", a.expand(self._val.shape + x._val.shape).contiguous(), x._val.expand(self._val.shape + x._val.shape).contiguous()))
+
+    def scale(self, factor):
+        return self if factor == 1 else factor * self
+
+    def ducktape(self, name):
+        raise RuntimeError("ducktape works only on operators")
+
+    def ducktape_left(self, name):
+        """The MultiField {name: self} (operator.py:364-373)"""
+        if not isinstance(name, str):
+            raise NotImplementedError("ducktape_left to a new domain is not implemented")
+        return MultiField.from_dict({name: self})
+
+    def broadcast(self, index, space):
+        """self repeated along a new sub-domain `space` at position `index` (field.py:434-441)"""
+        from .operators import ContractionOperator
+
+        tgt = list(self._domain)
+        tgt.insert(index, space)
+        return ContractionOperator(tgt, index).adjoint_times(self)
+
+    def abs(self):
+        return self.ptw("abs")
+
+    def __bool__(self):
+        raise TypeError("Field does not support implicit conversion to bool")
 
     # ---- arithmetic -----------------------------------------------------------------------
     def _bin(self, other, op, reverse=False):
@@ -315,9 +423,12 @@ class Field:
         return self.ptw("abs")
 
     def __pow__(self, p):
-        if not np.isscalar(p):
-            return NotImplemented
-        return self.ptw("power", p)
+        if np.isscalar(p):
+            return self.ptw("power", p)
+        return (p * self.ptw("log")).ptw("exp") if isinstance(p, Field) else NotImplemented  # operator.py:288-293
+
+    def __rpow__(self, base):
+        return (self * float(np.log(base))).ptw("exp") if np.isscalar(base) else NotImplemented
 
     def _inplace(self, *a, **k):
         raise TypeError("In-place operations are deliberately not supported")
@@ -372,6 +483,8 @@ def _host_ptw(x, op, deriv, *args):
         f = torch.abs(x)
         if not deriv:
             return f
+        if x.is_complex():
+            raise TypeError("Argument must not be complex because abs(z) is not holomorphic")
         d = torch.sign(x); d = torch.where(x == 0, torch.full_like(d, float("nan")), d)
         return f, d
     if op == "log1p":
@@ -379,6 +492,8 @@ def _host_ptw(x, op, deriv, *args):
     if op == "expm1":
         f = torch.expm1(x); return (f, f + 1.0) if deriv else f
     if op == "clip":
+        if x.is_complex():
+            raise TypeError("Argument must not be complex")
         lo, hi = args
         f = torch.clamp(x, lo, hi)
         if not deriv:
@@ -396,6 +511,41 @@ def _host_ptw(x, op, deriv, *args):
         if not deriv:
             return f
         return f, (torch.cos(x) if op == "sin" else -torch.sin(x))
+    if op == "tan":
+        f = torch.tan(x); return (f, 1.0 / torch.cos(x) ** 2) if deriv else f
+    if op in ("sinh", "cosh"):
+        f = getattr(torch, op)(x)
+        return (f, torch.cosh(x) if op == "sinh" else torch.sinh(x)) if deriv else f
+    if op == "log10":
+        return (torch.log10(x), (1.0 / np.log(10.0)) / x) if deriv else torch.log10(x)
+    if op == "sinc":  # sin(pi x) / (pi x); the derivative (cos(pi x) - sinc x) / x, 0 at the origin
+        f = torch.sinc(x)
+        if not deriv:
+            return f
+        safe = torch.where(x == 0, torch.ones_like(x), x)
+        return f, torch.where(x == 0, torch.zeros_like(x), (torch.cos(np.pi * safe) - f) / safe)
+    if op == "sign":
+        if x.is_complex():
+            raise TypeError("Argument must not be complex")
+        f = torch.sign(x)
+        return (f, torch.where(x == 0, torch.full_like(x, float("nan")), torch.zeros_like(x))) if deriv else f
+    if op == "unitstep":
+        if x.is_complex():
+            raise TypeError("Argument must not be complex")
+        f = (x >= 0).to(x.dtype)
+        return (f, torch.zeros_like(x)) if deriv else f
+    if op == "softplus":  # log(1 + e^x), linear above 33 and zero below -33 (pointwise.py:99-122); complex: by the real part
+        re = x.real if x.is_complex() else x
+        mid = torch.where((re > 33) | (re < -33), torch.zeros_like(x), x)
+        f = torch.where(re > 33, x, torch.where(re < -33, torch.zeros_like(x), torch.log(1 + torch.exp(mid))))
+        if not deriv:
+            return f
+        d = torch.where(re > 33, torch.ones_like(x), torch.where(re < -33, torch.zeros_like(x), 1 / (1 + torch.exp(-mid))))
+        return f, d
+    if op == "exponentiate":
+        base = args[0]
+        f = torch.pow(torch.as_tensor(base, dtype=x.dtype), x)
+        return (f, np.log(base) * f) if deriv else f
     raise NotImplementedError(f"pointwise operation {op!r}")
 
 
@@ -412,7 +562,8 @@ def _ptw(x, op, deriv, *args, **kwargs):
     return B.pointwise(op, x.contiguous(), param, want_derivative=deriv)
 
 
-for _name in ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "sin", "cos", "absolute", "arctan"):
+for _name in ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "sin", "cos", "absolute", "arctan", "tan",
+              "sinh", "cosh", "log10", "sinc", "sign", "unitstep", "softplus"):
     def _make(name):
         def fn(self):
             return self.ptw(name)
@@ -517,6 +668,10 @@ class MultiField:
     @property
     def real(self):
         return MultiField(self._domain, tuple(v.real for v in self._val))
+
+    @property
+    def imag(self):
+        return self._map(lambda v: v.imag)
 
     def conjugate(self):
         return MultiField(self._domain, tuple(v.conjugate() for v in self._val))

@@ -158,10 +158,24 @@ class Operator:
         kind = _operand_kind(x)
         if kind == "number":
             return self.scale(1.0 / x)
-        return self * x.reciprocal() if kind == "op" else NotImplemented
+        return self * x.reciprocal() if kind in ("op", "field") else NotImplemented
+
+    def __rtruediv__(self, x):
+        return self.reciprocal() * x
+
+    def __abs__(self):
+        return self.ptw("abs")
 
     def __pow__(self, power):
-        return self.ptw("power", power) if isinstance(power, Number) else NotImplemented
+        """op ** number pointwise; op ** op = exp(power * log(op)) (operator.py:288-300)"""
+        if isinstance(power, Number):
+            return self.ptw("power", power)
+        return (power * self.log()).exp() if _operand_kind(power) in ("op", "field") else NotImplemented
+
+    def __rpow__(self, base):
+        if isinstance(base, Number):
+            return self.scale(np.log(base)).exp()
+        return (base.log() * self).exp() if _operand_kind(base) in ("op", "field") else NotImplemented
 
     def __getitem__(self, key):
         if not isinstance(self.target, MultiDomain):
@@ -249,7 +263,8 @@ _ARITHMETIC = {
     ("-", "field"): lambda op, o: _shifted(op, o, True),
 }
 
-_POINTWISE_METHODS = ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "abs", "sin", "cos", "arctan")
+_POINTWISE_METHODS = ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "abs", "sin", "cos", "arctan", "tan",
+                      "sinh", "cosh", "log10", "sinc", "sign", "unitstep", "softplus", "absolute")
 
 
 def _install_pointwise(cls, names):
@@ -469,7 +484,32 @@ class Linearization:
         return self.ptw("reciprocal")._times(other)
 
     def __pow__(self, power):
-        return self.ptw("power", power) if np.isscalar(power) else NotImplemented
+        if np.isscalar(power):
+            return self.ptw("power", power)
+        return (power * self.log()).exp() if _operand_kind(power) in ("lin", "field") else NotImplemented
+
+    def __rpow__(self, base):
+        if np.isscalar(base):
+            return (self * float(np.log(base))).exp()
+        return (base.log() * self).exp() if _operand_kind(base) == "field" else NotImplemented
+
+    def __abs__(self):
+        return self.ptw("abs")
+
+    def ducktape(self, name):
+        raise RuntimeError("ducktape works only on operators")
+
+    def ducktape_left(self, name):
+        if not isinstance(name, str):
+            raise NotImplementedError("ducktape_left to a new domain is not implemented")
+        return ducktape(None, self.target, name)(self)
+
+    def broadcast(self, index, space):
+        if not isinstance(self.target, DomainTuple):
+            raise RuntimeError("Broadcasting works only on DomainTuples")
+        tgt = list(self.target)
+        tgt.insert(index, space)
+        return ContractionOperator(tgt, index).adjoint(self)
 
     # -- structure -----------------------------------------------------------------------------------
     def __getitem__(self, name):
@@ -495,8 +535,11 @@ class Linearization:
         f, df = self._val.ptw_with_deriv(op, *args, **kwargs)
         return self.new(f, makeOp(df)(self._jac))
 
+    def clip(self, a_min=None, a_max=None):
+        return self.ptw("clip", a_min, a_max)
 
-_install_pointwise(Linearization, ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "abs", "arctan"))
+
+_install_pointwise(Linearization, _POINTWISE_METHODS)
 
 
 # ================================================================================================
@@ -944,8 +987,24 @@ class BlockDiagonalOperator(EndomorphicOperator):
     def __init__(self, domain, operators):
         if not isinstance(domain, MultiDomain):
             raise TypeError("MultiDomain expected")
-        self._domain, self._ops = domain, tuple(operators[k] for k in domain.keys())
+        # a key without operator (missing or None) is the identity on that key
+        self._domain, self._ops = domain, tuple(operators.get(k) for k in domain.keys())
+        for op in self._ops:
+            if op is not None and not isinstance(op, LinearOperator):
+                raise TypeError("LinearOperator expected")
+            if op is not None and op.target is not op.domain:
+                raise TypeError("domain and target mismatch")
         self._capability = _common_capability([op for op in self._ops if op is not None], self._all_ops)
+
+    def _blockwise(self, other, combine):
+        """BlockDiagonalOperator of combine(own block, other's block) per key (block_diagonal_operator.py:88-103)"""
+        _same_domain(self._domain, other._domain)
+        blocks = {}
+        for key, a, b in zip(self._domain.keys(), self._ops, other._ops):
+            a = ScalingOperator(self._domain[key], 1.0) if a is None else a
+            b = ScalingOperator(self._domain[key], 1.0) if b is None else b
+            blocks[key] = combine(a, b)
+        return BlockDiagonalOperator(self._domain, blocks)
 
     def apply(self, x, mode):
         self._check_input(x, mode)
@@ -957,11 +1016,14 @@ class BlockDiagonalOperator(EndomorphicOperator):
                                                     for k, op in zip(self._domain.keys(), self._ops)})
 
     def draw_sample(self, from_inverse=False, device_id=-1):
+        if any(op is None for op in self._ops):
+            raise RuntimeError("Need to specify dtype for all operators that are set to None.")
         vals = tuple(op.draw_sample(from_inverse, device_id) for op in self._ops)
         return MultiField(self._domain, vals)
 
     def get_sqrt(self):
-        return BlockDiagonalOperator(self._domain, {k: op.get_sqrt() for k, op in zip(self._domain.keys(), self._ops)})
+        return BlockDiagonalOperator(self._domain, {k: op.get_sqrt() for k, op in zip(self._domain.keys(), self._ops)
+                                                    if op is not None})
 
     @property
     def sampling_dtype(self):
@@ -1025,8 +1087,11 @@ class ChainOperator(LinearOperator):
                 number_dtype = number_dtype if link._dtype is None else link._dtype
                 continue
             mergeable = bool(kept) and all(isinstance(o, DiagonalOperator) and o._full() for o in (kept[-1], link))
+            blocks = bool(kept) and all(isinstance(o, BlockDiagonalOperator) for o in (kept[-1], link))
             if mergeable:
                 kept[-1] = kept[-1]._combine_prod(link)
+            elif blocks and kept[-1].domain is link.domain:
+                kept[-1] = kept[-1]._blockwise(link, lambda a, b: a @ b)
             else:
                 kept.append(link)
         if number == 1 and kept:
@@ -1103,6 +1168,17 @@ class SumOperator(LinearOperator):
                 terms.append((op, minus))
         if identity is not None:
             terms.append((ScalingOperator(identity["domain"], identity["factor"], identity["dtype"]), False))
+        # block-diagonal terms on one MultiDomain add block by block (sum_operator.py:141-152)
+        first = next((i for i, (op, _) in enumerate(terms) if isinstance(op, BlockDiagonalOperator)), None)
+        if first is not None:
+            merged, others = terms[first], []
+            for op, minus in terms[first + 1:]:
+                if isinstance(op, BlockDiagonalOperator) and op.domain is merged[0].domain:
+                    signs = (merged[1], minus)
+                    merged = (merged[0]._blockwise(op, lambda a, b: SumOperator.make((a, b), signs)), False)
+                else:
+                    others.append((op, minus))
+            terms = terms[:first] + [merged] + others
         if len(terms) == 1:
             op, minus = terms[0]
             return op.scale(-1) if minus else op

@@ -26,6 +26,22 @@ def _frame(sseq):
 _frames = [_frame(np.random.SeedSequence(42))]  # the reference starts every process on SeedSequence(42) too (:83-85)
 
 
+class _StackView:
+    """The reference keeps two parallel module lists `_sseq` / `_rng` (random.py:83-85); here they are views of one stack"""
+
+    def __init__(self, field):
+        self._field = field
+
+    def __len__(self):
+        return len(_frames)
+
+    def __getitem__(self, i):
+        return getattr(_frames[i], self._field)
+
+
+_sseq, _rng = _StackView("sseq"), _StackView("rng")
+
+
 # ---- the stack -----------------------------------------------------------------------------------------------------
 def getState():
     """The whole stack as bytes, in the reference's own layout (random.py:88-96): the pickled pair

@@ -1,6 +1,6 @@
 """Run the REFERENCE's own test files against nifty_amd, unmodified (build container only: needs /root/reference).
 
-`import nifty.cl as ift` inside them resolves to nifty_amd through a two-line alias module; the files are read where they lie,
+`import nifty.cl as ift` inside them resolves to nifty_amd through nifty_amd.compat.install(); the files are read where they lie,
 nothing is copied into this repository and nothing is written under /root/reference (no bytecode, no pytest cache).  Host fields
 (device_id = -1): what is checked is the API surface and the host arithmetic of the nifty.cl-shaped layer -- names, argument
 meaning, error behaviour, adjointness / Jacobian consistency checks of the reference's extra.py -- next to the GPU parity tests
@@ -17,11 +17,10 @@ import tempfile
 
 REF = "/root/reference/test/test_cl"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ALIAS = '''import sys, types
+ALIAS = '''import sys
 sys.path.insert(0, %r)
-import nifty_amd
-pkg = types.ModuleType("nifty"); pkg.__path__ = []; pkg.cl = nifty_amd
-sys.modules["nifty"] = pkg; sys.modules["nifty.cl"] = nifty_amd
+import nifty_amd.compat
+nifty_amd.compat.install()
 ''' % ROOT
 
 
