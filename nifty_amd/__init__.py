@@ -41,6 +41,15 @@ from .sugar import (PS_field, calculate_position, create_harmonic_smoothing_oper
 from .sugar import (abs, absolute, arctan, clip, cos, cosh, exp, expm1, exponentiate, log, log10, log1p, power, reciprocal,  # noqa: E402,F401,A004
                     sigmoid, sign, sin, sinc, sinh, softplus, sqrt, tan, tanh, unitstep)
 from .domains import Domain  # noqa: E402,F401
+from .selection_operators import (ConjugationOperator, DomainChangerAndReshaper, DomainTupleFieldInserter, ExtractAtIndices,  # noqa: E402,F401
+                                  FieldZeroPadder, GeometryRemover, Imaginizer, OuterProduct, PartialExtractor, SliceOperator,
+                                  SqueezeOperator, TransposeOperator, ValueInserter)
+from . import correlated_fields as _cf, energy_operators as _eo, los_response as _los, operators as _ops  # noqa: E402
+import types as _types  # noqa: E402
+
+# the reference's `ift.library.<module>` / `ift.operators.energy_operators` attribute paths (compat.py has the import paths)
+library = _types.SimpleNamespace(correlated_fields=_cf, correlated_fields_simple=_cf, los_response=_los)
+_ops.energy_operators = _eo
 from .operators import domain_union  # noqa: E402,F401
 
 

@@ -34,6 +34,9 @@ for _name in ("adder", "block_diagonal_operator", "chain_operator", "contraction
               "scaling_operator", "simple_linear_operators", "simplify_for_const", "sum_operator"):
     LAYOUT["operators." + _name] = "operators"
 LAYOUT["operators.energy_operators"] = "energy_operators"
+for _name in ("selection_operators", "transpose_operator", "outer_product_operator", "value_inserter", "field_zero_padder",
+              "domain_tuple_field_inserter"):
+    LAYOUT["operators." + _name] = "selection_operators"
 LAYOUT["operators.normal_operators"] = "correlated_fields"
 
 

@@ -26,6 +26,7 @@ from . import backend as B
 from .domains import DomainTuple, MultiDomain, PowerSpace, RGSpace, UnstructuredDomain, makeDomain
 from .engine import SMALL_KEYS, lognormal_moments
 from .field import Field, MultiField, full, makeField
+from .minimization import logger
 from .operators import (ContractionOperator, DiagonalOperator, EndomorphicOperator, HarmonicTransformOperator,
                         LinearOperator, Operator, PowerDistributor, Variable, VdotOperator, ducktape, is_linearization, makeOp)
 
@@ -870,8 +871,16 @@ class CorrelatedFieldMaker:
         self._register(_AmplitudeMatern(bins, *latent, subdomain[-1].total_volume if adjust_for_volume else 1.0), subdomain)
 
     def set_amplitude_total_offset(self, offset_mean, offset_std, dofdex=None):
+        """Mean and zero-mode amplitude of the field (correlated_fields.py:659-711).  `offset_std`: a (mean, std) pair -- a
+        log-normal zero-mode amplitude, the learnable case the fused device operator covers; a number -- a fixed amplitude
+        (None or 0: no zero mode at all, the k = 0 coefficient is masked out); an Operator -- a user-built amplitude.  The
+        last two run on the generic operator graph."""
+        if self._offset_mean is not None and self._azm is not None:
+            logger.warning("Overwriting the previous mean offset and zero-mode")
+        self._hyper.pop("offset_std", None)
         if offset_std is None or np.isscalar(offset_std) or isinstance(offset_std, Operator):
-            raise NotImplementedError("only a (mean, std) tuple is supported for offset_std")
+            self._azm, self._offset_mean = (0.0 if offset_std is None else offset_std), offset_mean
+            return
         if len(offset_std) != 2:
             raise TypeError("`offset_std` of invalid type and/or shape; expected a 2D tuple of floats")
         dofdex, copies = self._copies(dofdex)
@@ -893,15 +902,33 @@ class CorrelatedFieldMaker:
     def fluctuations(self):
         return tuple(self._a)
 
+    def _fixed_zero_mode(self):
+        """the zero-mode amplitude when it is a plain number, else None"""
+        return self.azm if np.isscalar(self.azm) else None
+
     def get_normalized_amplitudes(self):
         """Amplitudes corrected for the otherwise degenerate zero mode: a_i * (1/azm on k != 0, 1 on k = 0)
-        (reference correlated_fields.py:809-858)."""
+        (reference correlated_fields.py:809-858).  A fixed zero mode of 0 removes the k = 0 entry instead (one spectrum
+        only), a fixed 1 leaves the amplitudes as they are."""
         space = 1 if self._total_N > 0 else 0
+        fixed = self._fixed_zero_mode()
+        if fixed is not None and fixed == 0:
+            if len(self._a) != 1:
+                raise RuntimeError("Zeromode can not be disabled for product spectra")
+            keep = np.ones(self._a[0].target.shape)
+            keep[(slice(None),) * space + (0,)] = 0.0
+            return (makeOp(makeField(self._a[0].target, keep)) @ self._a[0],)
+        if fixed is not None and fixed == 1:
+            return self.fluctuations
         out = []
         for amp in self._a:
             pspace = amp.target[space]
             mask, unmask = np.zeros(pspace.shape), np.zeros(pspace.shape)
             mask[1:] = unmask[0] = 1.0
+            if fixed is not None:  # one constant factor per bin
+                factor = np.broadcast_to(mask / fixed + unmask, amp.target.shape)
+                out.append(makeOp(makeField(amp.target, np.ascontiguousarray(factor))) @ amp)
+                continue
             zm_mask = DiagonalOperator(makeField(pspace, mask), amp.target, space)
             zm_unmask = DiagonalOperator(makeField(pspace, unmask), amp.target, space)(full(amp.target, 1.0))
             na = ContractionOperator(amp.target, space).adjoint @ self.azm.reciprocal()
@@ -915,11 +942,150 @@ class CorrelatedFieldMaker:
                                       "because only the relative scale is determined.")
         space = 1 if self._total_N > 0 else 0
         na = self.get_normalized_amplitudes()[0]
+        if self._fixed_zero_mode() is not None:
+            return na
         return na * (ContractionOperator(na.target, space).adjoint @ self.azm)
 
     @property
     def power_spectrum(self):
         return self.amplitude ** 2
+
+    # -- fluctuation statistics: operators on latent samples, and the same quantities measured on field realisations
+    # (correlated_fields.py:941-1064) ---------------------------------------------------------------------------------
+    def _relative_fluctuation(self, which):
+        return self._a[which].fluctuation_amplitude / self.azm
+
+    def average_fluctuation(self, space):
+        if not self._a:
+            raise NotImplementedError
+        if space >= len(self._a):
+            raise ValueError(f"invalid space specified; got {space!r}")
+        return self._a[0 if len(self._a) == 1 else space].fluctuation_amplitude
+
+    def slice_fluctuation(self, space):
+        if not self._a:
+            raise NotImplementedError
+        if space >= len(self._a):
+            raise ValueError(f"invalid space specified; got {space!r}")
+        if len(self._a) == 1:
+            return self.average_fluctuation(0)
+        q = 1.0
+        for j in range(len(self._a)):
+            sq = self._relative_fluctuation(j) ** 2
+            q = q * (sq if j == space else 1 + sq)
+        return q.sqrt() * self.azm
+
+    @property
+    def total_fluctuation(self):
+        if not self._a:
+            raise NotImplementedError
+        if len(self._a) == 1:
+            return self.average_fluctuation(0)
+        q = 1.0
+        for j in range(len(self._a)):
+            q = q * (1 + self._relative_fluctuation(j) ** 2)
+        return (q - 1).sqrt() * self.azm
+
+    def moment_slice_to_average(self, fluctuations_slice_mean, nsamples=1000):
+        """The mean of the `fluctuations` prior of a sub-space still to be added such that its slice fluctuations come out
+        as `fluctuations_slice_mean`, estimated from `nsamples` prior draws of the sub-spaces added so far"""
+        fluctuations_slice_mean = float(fluctuations_slice_mean)
+        if not fluctuations_slice_mean > 0:
+            raise ValueError(f"fluctuations_slice_mean must be greater zero; got {fluctuations_slice_mean!r}")
+        from .field import from_random
+
+        scm = 1.0
+        for j in range(len(self._a)):
+            op = self._relative_fluctuation(j)
+            draws = np.array([op(from_random(op.domain, "normal")).asnumpy() for _ in range(nsamples)])
+            scm = scm * (draws ** 2 + 1.0)
+        return fluctuations_slice_mean / np.mean(np.sqrt(scm))
+
+    def statistics_summary(self, prior_info):
+        """Logs mean and standard deviation over `prior_info` prior draws of the offset amplitude and the fluctuation
+        amplitudes that are sampled (correlated_fields.py:766-803)"""
+        from .field import from_random
+        from .probing import StatCalculator
+
+        rows = []
+        try:
+            rows.append(("Offset amplitude", self.amplitude_total_offset))
+        except NotImplementedError:
+            pass
+        rows.append(("Total fluctuation amplitude", self.total_fluctuation))
+        if len(self._a) > 1:
+            for i in range(len(self._a)):
+                rows.append((f"Average fluctuation (space {i})", self.average_fluctuation(i)))
+                try:
+                    rows.append((f"Slice fluctuation (space {i})", self.slice_fluctuation(i)))
+                except NotImplementedError:
+                    pass
+        for name, op in rows:
+            if not isinstance(op, Operator):
+                continue
+            stats = StatCalculator()
+            for _ in range(prior_info):
+                stats.add(op(from_random(op.domain, "normal")))
+            for m, sd in zip(stats.mean.asnumpy().ravel(), stats.var.ptw("sqrt").asnumpy().ravel()):
+                logger.info(f"{name}: {m:.02E} ± {sd:.02E}")
+
+    @staticmethod
+    def _geometry_axes(domain):
+        """indices of the sub-domains with geometry: all but a leading UnstructuredDomain (the total_N axis)"""
+        return tuple(range(1 if isinstance(domain[0], UnstructuredDomain) else 0, len(domain)))
+
+    @staticmethod
+    def _as_numbers(res):
+        return np.sqrt(res if np.isscalar(res) else res.asnumpy())
+
+    @staticmethod
+    def offset_amplitude_realized(samples):
+        spaces = CorrelatedFieldMaker._geometry_axes(samples[0].domain)
+        acc = 0.0
+        for smp in samples:
+            acc = acc + smp.mean(spaces) ** 2
+        return CorrelatedFieldMaker._as_numbers(acc / len(samples))
+
+    @staticmethod
+    def total_fluctuation_realized(samples):
+        spaces = CorrelatedFieldMaker._geometry_axes(samples[0].domain)
+        contract = ContractionOperator(samples[0].domain, spaces)
+        acc = 0.0
+        for smp in samples:
+            acc = acc + (smp - contract.adjoint_times(smp.mean(spaces))) ** 2
+        return CorrelatedFieldMaker._as_numbers(acc.mean(spaces) / len(samples))
+
+    @staticmethod
+    def slice_fluctuation_realized(samples, space):
+        spaces = CorrelatedFieldMaker._geometry_axes(samples[0].domain)
+        if space >= len(spaces):
+            raise ValueError(f"invalid space specified; got {space!r}")
+        if len(spaces) == 1:
+            return CorrelatedFieldMaker.total_fluctuation_realized(samples)
+        space = space + spaces[0]
+        sq, sq_of_mean = 0.0, 0.0
+        for smp in samples:
+            sq = sq + smp ** 2
+            sq_of_mean = sq_of_mean + smp.mean(space) ** 2
+        res = (sq / len(samples)).mean(spaces) - (sq_of_mean / len(samples)).mean(spaces[:-1])
+        return CorrelatedFieldMaker._as_numbers(res)
+
+    @staticmethod
+    def average_fluctuation_realized(samples, space):
+        spaces = CorrelatedFieldMaker._geometry_axes(samples[0].domain)
+        if space >= len(spaces):
+            raise ValueError(f"invalid space specified; got {space!r}")
+        if len(spaces) == 1:
+            return CorrelatedFieldMaker.total_fluctuation_realized(samples)
+        space = space + spaces[0]
+        others = tuple(sp for sp in spaces if sp != space)
+        acc, contract = 0.0, None
+        for smp in samples:
+            r = smp.mean(others)
+            if contract is None:
+                contract = ContractionOperator(r.domain, len(r.domain) - 1)
+            acc = acc + (r - contract.adjoint_times(r.mean(len(r.domain) - 1))) ** 2
+        return CorrelatedFieldMaker._as_numbers(acc.mean(len(acc.domain) - 1) / len(samples))
 
     def _generic_graph(self):
         """offset + HT( azm * prod_i a_i[pindex_i] * xi ) on the product of the harmonic spaces, with a leading
@@ -932,7 +1098,9 @@ class CorrelatedFieldMaker:
             spread = layout.spread(which, amplitude)
             spectrum = spread if spectrum is None else spectrum * spread
         excitations = Variable(layout.harmonic, self._prefix + "xi")
-        field = layout.to_position(((layout.broadcast @ self.azm) * spectrum).real * excitations)
+        if self._fixed_zero_mode() is None:
+            spectrum = (layout.broadcast @ self.azm) * spectrum
+        field = layout.to_position(spectrum.real * excitations)
         return field if self._offset_mean is None else field + float(self._offset_mean)
 
     def _product_operator(self, generic):
@@ -958,6 +1126,8 @@ class CorrelatedFieldMaker:
         if len(self._a) < 1 or self._azm is None:
             raise NotImplementedError("add_fluctuations() and set_amplitude_total_offset() must have been called")
         generic = self._generic_graph()
+        if "offset_std" not in self._hyper:  # a fixed or user-built zero mode: the generic graph
+            return generic
         pos = self._target_subdomains[0][0]
         if len(self._a) > 1 or self._total_N > 0 or self._amp_prefix != self._prefix:
             return self._product_operator(generic)
@@ -973,4 +1143,6 @@ def SimpleCorrelatedField(target, offset_mean, offset_std, fluctuations, flexibi
     cfm = CorrelatedFieldMaker(prefix)
     cfm.add_fluctuations(target, fluctuations, flexibility, asperity, loglogavgslope, harmonic_partner=harmonic_partner)
     cfm.set_amplitude_total_offset(offset_mean, offset_std)
-    return cfm.finalize()
+    op = cfm.finalize()
+    op.amplitude, op.power_spectrum = cfm.amplitude, cfm.power_spectrum  # correlated_fields_simple.py:130-131
+    return op

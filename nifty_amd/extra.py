@@ -76,9 +76,11 @@ def _check_one(op, dt_dom, dt_tgt, atol, rtol, only_r_linear, dev):
 
 
 def check_linear_operator(op, domain_dtype=np.float64, target_dtype=np.float64, atol=1e-14, rtol=1e-14,
-                          only_r_linear=False, force_device_ids=[-1], _device_ids_override=None):
+                          only_r_linear=False, force_device_ids=[-1], assert_fixed_device=True, no_device_copies=True,
+                          _device_ids_override=None):
     """Algebraic consistency of every capability of a LinearOperator on the host and, if present, on GPU 0
-    (same arguments as the reference, extra.py:41-131)."""
+    (same arguments as the reference, extra.py:41-131; `assert_fixed_device` / `no_device_copies` are accepted and not
+    needed: an operator that moved a field to another device fails the device check of every application here)."""
     if not isinstance(op, LinearOperator):
         raise TypeError("This test tests only linear operators.")
     devs = _device_ids(force_device_ids) if _device_ids_override is None else _device_ids_override
@@ -96,7 +98,8 @@ def check_linear_operator(op, domain_dtype=np.float64, target_dtype=np.float64, 
             _check_one(view, dts[swap], dts[1 - swap], atol, rtol, only_r_linear, dev)
 
 
-def check_operator(op, loc, tol=1e-12, ntries=100, only_r_differentiable=True, force_device_ids=[-1]):
+def check_operator(op, loc, tol=1e-12, ntries=100, perf_check=True, only_r_differentiable=True, metric_sampling=True,
+                   force_device_ids=[-1], assert_fixed_device=True, no_device_copies=True):
     """Value consistency of ``op(Linearization)`` and Jacobian against finite differences at ``loc``, then
     ``check_linear_operator`` on the Jacobian (reference extra.py:134-183, 411-496)."""
     if not isinstance(op, Operator):

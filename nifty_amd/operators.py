@@ -776,6 +776,8 @@ class ScalingOperator(EndomorphicOperator):
     def __init__(self, domain, factor, sampling_dtype=None):
         if isinstance(factor, Field) and factor.shape == ():
             factor = factor.asnumpy()[()]
+        if isinstance(factor, (torch.Tensor, np.ndarray)) and tuple(factor.shape) == ():  # field.val[()] of a scalar field
+            factor = factor.item()
         if not np.isscalar(factor):
             raise TypeError("Scalar required")
         self._domain, self._factor, self._dtype = makeDomain(domain), factor, sampling_dtype
@@ -1289,7 +1291,8 @@ class VdotOperator(LinearOperator):
             self._field = self._field.at(x.device_id)
         if mode == self.TIMES:
             return Field.scalar(self._field.s_vdot(x)).at(x.device_id)
-        return self._field * float(np.real(x.asnumpy()[()]))
+        scalar = x.asnumpy()[()]
+        return self._field * (complex(scalar) if np.iscomplexobj(scalar) else float(scalar))
 
 
 class Realizer(EndomorphicOperator):
@@ -1428,6 +1431,16 @@ def _space_index(domain, space, what="space"):
     return space
 
 
+def _host_fftn(v, axes, inverse=False):
+    """FFT of a HOST tensor over `axes` by scipy.fft (pocketfft) -- the library the reference falls back to without ducc0
+    (ducc_dispatch.py:70-118), so host fields agree with the reference's numpy path to its own 1e-14 test tolerances;
+    device tensors never come here (libniftyk's plans)."""
+    import scipy.fft
+
+    fn = scipy.fft.ifftn if inverse else scipy.fft.fftn
+    return torch.from_numpy(fn(v.numpy(), axes=axes))
+
+
 class _RGTransformBase(LinearOperator):
     def __init__(self, domain, target=None, space=None):
         self._domain = DomainTuple.make(domain)
@@ -1480,7 +1493,7 @@ class HartleyOperator(_RGTransformBase):
         from . import config
 
         def host(v, axes):
-            f = torch.fft.fftn(v, dim=axes)
+            f = _host_fftn(v, axes)
             h = f.real + f.imag if config.get("hartley_convention") == "non_canonical_hartley" else f.real - f.imag
             return h if fct == 1 else h * fct
 
@@ -1504,7 +1517,7 @@ class FFTOperator(_RGTransformBase):
             v = v.to(torch.complex64 if v.dtype == torch.float32 else torch.complex128)
 
         def host(a, axes):
-            res = torch.fft.ifftn(a, dim=axes) if inverse else torch.fft.fftn(a, dim=axes)
+            res = _host_fftn(a, axes, inverse)
             return res if fct == 1 else res * fct
 
         # ifftn carries 1/N: N * ifftn = unnormalised backward transform
@@ -1756,6 +1769,9 @@ class DOFDistributor(LinearOperator):
         return moved.permute([order.index(ax) for ax in range(len(dst.shape))]).contiguous()
 
     def _apply1(self, v, mode, tshape):
+        if v.is_complex():  # real and imaginary parts are distributed / collected separately (the kernels are real)
+            parts = [self._apply1(part.contiguous(), mode, tshape) for part in (v.real, v.imag)]
+            return torch.complex(*parts)
         if mode == self.TIMES:
             if v.is_cuda:
                 return B.gather(v.contiguous(), self._device_index(v.device), tshape)

@@ -137,10 +137,10 @@ def calculate_position(operator, output):
         dtype, peak = output.dtype, np.max(np.abs(output.asnumpy()))
     noise = ScalingOperator(output.domain, 1e-3 * peak ** 2, dtype)
     data = output + noise.draw_sample()
-    hamiltonian = StandardHamiltonian(GaussianEnergy(data, noise.inverse) @ operator,
-                                      ic_samp=GradientNormController(iteration_limit=200))
-    minimizer = NewtonCG(GradientNormController(iteration_limit=10, name="findpos"))
     pos = 0.1 * from_random(operator.domain)
+    hamiltonian = StandardHamiltonian(GaussianEnergy(data, noise.inverse) @ operator,
+                                      ic_samp=GradientNormController(iteration_limit=200), prior_sampling_dtype=pos.dtype)
+    minimizer = NewtonCG(GradientNormController(iteration_limit=10, name="findpos"))
     for it in range(3):
         logger.info(f"Start iteration {it + 1}/3")
         kl, _ = minimizer(SampledKLEnergy(pos, hamiltonian, 3, None))
