@@ -263,8 +263,11 @@ int nk_axpby_sqnorm(int64_t n, double alpha, const void* x, double beta, const v
                     int accumulate, void* stream);
 /* pointwise nonlinearity with optional derivative output (pointwise.py:134-159):
  * fn: 0 exp, 1 log, 2 sqrt, 3 tanh, 4 sigmoid(0.5+0.5tanh), 5 reciprocal, 6 power(p), 7 abs, 8 log1p, 9 expm1,
- *     10 arctan, 11 sin, 12 cos */
+ *     10 arctan, 11 sin, 12 cos, 13 tan, 14 sinc (sin(pi x)/(pi x)), 15 log10, 16 sinh, 17 cosh, 18 sign (derivative 0, NaN at
+ *     0), 19 softplus (identity above 33, zero below -33), 20 exponentiate (param ** x), 21 unitstep (1 for x >= 0) */
 int nk_pointwise(int fn, double param, int64_t n, const void* x, void* fx, void* dfx, int dtype, void* stream);
+/* fx = min(max(x, lo), hi), dfx = 0 where fx sits on a bound, else 1 (pointwise.py:76-88); -INFINITY / INFINITY: no bound */
+int nk_clip(double lo, double hi, int64_t n, const void* x, void* fx, void* dfx, int dtype, void* stream);
 /* gather / scatter-add by bin index (DOFDistributor, distributors.py:106-127): table/in/out are of `dtype`;
  * the scatter accumulates into DOUBLE bins (np.bincount semantics, utilities.py:222-246), caller zeroes them.
  * nk_scatter_add uses fp64 atomics: with colliding indices the sums depend on the order of the atomics in the last bit.

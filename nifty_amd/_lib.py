@@ -82,6 +82,7 @@ SIGNATURES = {
     "nk_axpby": (_i, [_i64, _d, _vp, _d, _vp, _vp, _i, _vp]),
     "nk_axpby_sqnorm": (_i, [_i64, _d, _vp, _d, _vp, _vp, _i, _vp, _i, _vp]),
     "nk_pointwise": (_i, [_i, _d, _i64, _vp, _vp, _vp, _i, _vp]),
+    "nk_clip": (_i, [_d, _d, _i64, _vp, _vp, _vp, _i, _vp]),
     "nk_gather": (_i, [_i64, _vp, _vp, _vp, _i, _vp]),
     "nk_scatter_add": (_i, [_i64, _vp, _vp, _i64, _vp, _i, _vp]),
     "nk_octant_expand": (_i, [_i, ctypes.POINTER(_i64), _vp, _vp, _vp, _i, _i, _vp]),

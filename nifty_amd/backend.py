@@ -412,15 +412,22 @@ def axpby_sqnorm(alpha, x, beta, y, result, accumulate=False):
 
 
 POINTWISE = {"exp": 0, "log": 1, "sqrt": 2, "tanh": 3, "sigmoid": 4, "reciprocal": 5, "power": 6, "abs": 7,
-             "absolute": 7, "log1p": 8, "expm1": 9, "arctan": 10, "sin": 11, "cos": 12}
+             "absolute": 7, "log1p": 8, "expm1": 9, "arctan": 10, "sin": 11, "cos": 12, "tan": 13, "sinc": 14, "log10": 15,
+             "sinh": 16, "cosh": 17, "sign": 18, "softplus": 19, "exponentiate": 20, "unitstep": 21, "clip": 22}
 
 
-def pointwise(name, x, param=0.0, want_derivative=False):
+def pointwise(name, x, param=0.0, want_derivative=False, param2=None):
+    """Pointwise function (and derivative) of a real device tensor; `clip` takes its bounds in (param, param2), None = open"""
     _require_device(x)
     fx = torch.empty_like(x)
     dfx = torch.empty_like(x) if want_derivative else None
-    L.check(L.load().nk_pointwise(POINTWISE[name], float(param), x.numel(), x.data_ptr(), fx.data_ptr(), ptr(dfx),
-                                  dtype_code(x), _stream()), "nk_pointwise")
+    if name == "clip":
+        lo = -math.inf if param is None else float(param)
+        hi = math.inf if param2 is None else float(param2)
+        L.check(L.load().nk_clip(lo, hi, x.numel(), x.data_ptr(), fx.data_ptr(), ptr(dfx), dtype_code(x), _stream()), "nk_clip")
+    else:
+        L.check(L.load().nk_pointwise(POINTWISE[name], float(param), x.numel(), x.data_ptr(), fx.data_ptr(), ptr(dfx),
+                                      dtype_code(x), _stream()), "nk_pointwise")
     return (fx, dfx) if want_derivative else fx
 
 

@@ -471,7 +471,7 @@ template <typename T>
 struct FPointwise {
   static constexpr int NRED = 0;
   int fn;
-  double param;
+  double param, param2;
   const T* x;
   T *fx, *dfx;
   double* result;
@@ -496,7 +496,28 @@ struct FPointwise {
         case 9: fv = expm1(v); dv = fv + 1.0; break;
         case 10: fv = atan(v); dv = 1.0 / (1.0 + v * v); break;
         case 11: fv = sin(v); dv = cos(v); break;
-        default: fv = cos(v); dv = -sin(v); break;
+        case 12: fv = cos(v); dv = -sin(v); break;
+        case 13: { fv = tan(v); const double c = cos(v); dv = 1.0 / (c * c); } break;
+        case 14: {  // sin(pi v) / (pi v); derivative (cos(pi v) - sinc v) / v, 0 at the origin
+          const double y = M_PI * v;
+          fv = v == 0.0 ? 1.0 : sin(y) / y;
+          dv = v == 0.0 ? 0.0 : (cos(y) - fv) / v;
+        } break;
+        case 15: fv = log10(v); dv = (1.0 / M_LN10) / v; break;
+        case 16: fv = sinh(v); dv = cosh(v); break;
+        case 17: fv = cosh(v); dv = sinh(v); break;
+        case 18: fv = v > 0.0 ? 1.0 : (v < 0.0 ? -1.0 : v); dv = v == 0.0 ? (double)NAN : 0.0; break;
+        case 19:  // softplus log(1 + e^v): the identity above 33, zero below -33 (pointwise.py:99-122)
+          if (v > 33.0) fv = v, dv = 1.0;
+          else if (v < -33.0) fv = 0.0, dv = 0.0;
+          else fv = log(1.0 + exp(v)), dv = 1.0 / (1.0 + exp(-v));
+          break;
+        case 20: fv = pow(param, v); dv = log(param) * fv; break;
+        case 21: fv = v >= 0.0 ? 1.0 : 0.0; dv = 0.0; break;
+        default: {  // 22 clip to [param, param2]; an absent bound is -inf / +inf.  Derivative 0 where the value sits on a bound
+          fv = v < param ? param : (v > param2 ? param2 : v);
+          dv = (fv == param || fv == param2) ? 0.0 : 1.0;
+        } break;
       }
       f[k] = (T)fv;
       d[k] = (T)dv;
@@ -892,11 +913,19 @@ extern "C" int nk_axpby_sqnorm(int64_t n, double alpha, const void* x, double be
 
 extern "C" int nk_pointwise(int fn, double param, int64_t n, const void* x, void* fx, void* dfx, int dtype,
                             void* stream) {
-  if (n < 0 || !x || (!fx && !dfx) || fn < 0 || fn > 12) return nk_set_error(NK_ERR_INVALID, "nk_pointwise: bad argument");
+  if (n < 0 || !x || (!fx && !dfx) || fn < 0 || fn > 21) return nk_set_error(NK_ERR_INVALID, "nk_pointwise: bad argument");
   NK_DISPATCH_DTYPE(dtype, {
-    FPointwise<T> f{fn, param, (const T*)x, (T*)fx, (T*)dfx, nullptr};
+    FPointwise<T> f{fn, param, 0.0, (const T*)x, (T*)fx, (T*)dfx, nullptr};
     return nk_launch_map<T>(n, f, nk_aligned16(x) && nk_aligned16(fx) && nk_aligned16(dfx), (hipStream_t)stream,
                             "nk_pointwise");
+  })
+}
+
+extern "C" int nk_clip(double lo, double hi, int64_t n, const void* x, void* fx, void* dfx, int dtype, void* stream) {
+  if (n < 0 || !x || (!fx && !dfx) || !(lo <= hi)) return nk_set_error(NK_ERR_INVALID, "nk_clip: bad argument");
+  NK_DISPATCH_DTYPE(dtype, {
+    FPointwise<T> f{22, lo, hi, (const T*)x, (T*)fx, (T*)dfx, nullptr};
+    return nk_launch_map<T>(n, f, nk_aligned16(x) && nk_aligned16(fx) && nk_aligned16(dfx), (hipStream_t)stream, "nk_clip");
   })
 }
 

@@ -558,7 +558,9 @@ def _ptw(x, op, deriv, *args, **kwargs):
         return B.cplx_pointwise(op, x)
     if op not in B.POINTWISE:
         raise NotImplementedError(f"pointwise operation {op!r} has no device kernel yet")
-    param = float(args[0]) if op == "power" else 0.0
+    if op == "clip":
+        return B.pointwise(op, x.contiguous(), args[0], want_derivative=deriv, param2=args[1])
+    param = float(args[0]) if op in ("power", "exponentiate") else 0.0
     return B.pointwise(op, x.contiguous(), param, want_derivative=deriv)
 
 

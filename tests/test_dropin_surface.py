@@ -306,3 +306,42 @@ def test_selection_operators_and_statistics_on_the_device():
     for name in ("integrate", "mean", "var", "std"):
         for sp in (0, 1):
             np.testing.assert_allclose(getattr(d, name)(sp).asnumpy(), getattr(f, name)(sp).asnumpy(), rtol=1e-13)
+
+
+@pytest.mark.gpu
+@pmp("dtype,tol", [(np.float64, 2e-14), (np.float32, 2e-6)])
+def test_every_pointwise_function_has_a_device_kernel(dtype, tol):
+    """device value and derivative against the host definitions above, for the whole dictionary of pointwise.py:134-159"""
+    rng = np.random.default_rng(9)
+    v = np.concatenate([rng.normal(size=4093) * 2.0, [0.0, -40.0, 40.0]]).astype(dtype)
+    dom = ift.UnstructuredDomain(v.size)
+    cases = [(n, ()) for n in ("tan", "sinc", "sinh", "cosh", "sign", "softplus", "unitstep", "exp", "tanh", "sigmoid", "sin", "cos",
+                               "arctan", "expm1", "abs")]
+    cases += [("exponentiate", (1.7,)), ("power", (3.0,)), ("clip", (-0.5, 1.25)), ("clip", (None, 0.3)), ("clip", (0.1, None))]
+    cases += [(n, ()) for n in ("log", "log10", "log1p", "sqrt", "reciprocal")]
+    for name, args in cases:
+        x = np.abs(v) + dtype(0.1) if name in ("log", "log10", "log1p", "sqrt", "reciprocal") else v
+        if name in ("sinh", "cosh", "exp", "expm1", "tan", "exponentiate", "power"):
+            x = np.clip(x, -5, 5)
+        host = ift.makeField(dom, x)
+        fh, dh = host.ptw_with_deriv(name, *args)
+        fd, dd = host.at(0).ptw_with_deriv(name, *args)
+        scale_f = np.maximum(np.abs(fh.asnumpy()), 1.0)
+        scale_d = np.maximum(np.abs(dh.asnumpy()), 1.0)
+        # tan near its poles amplifies the argument's rounding: compare where the function is moderate
+        ok = np.abs(fh.asnumpy()) < 50 if name == "tan" else np.ones(v.size, bool)
+        np.testing.assert_array_less((np.abs(fd.asnumpy() - fh.asnumpy()) / scale_f)[ok], tol * 8, err_msg=name)
+        same_nan = np.isnan(dd.asnumpy()) == np.isnan(dh.asnumpy())
+        assert same_nan.all(), name
+        fin = ok & ~np.isnan(dh.asnumpy())
+        np.testing.assert_array_less((np.abs(dd.asnumpy() - dh.asnumpy()) / scale_d)[fin], tol * 64, err_msg=name + " derivative")
+        np.testing.assert_array_equal(host.at(0).ptw(name, *args).asnumpy(), fd.asnumpy())
+
+
+@pytest.mark.gpu
+def test_complex_adjoints_on_the_device():
+    dom = ift.RGSpace((6, 5))
+    ift.extra.check_linear_operator(ift.VdotOperator(ift.from_random(dom, dtype=np.complex128)), np.complex128, np.complex128,
+                                    force_device_ids=[0])
+    dofdex = ift.Field.from_raw(dom, np.arange(30).reshape(6, 5) % 4)
+    ift.extra.check_linear_operator(ift.DOFDistributor(dofdex), np.complex128, np.complex128, force_device_ids=[0])
