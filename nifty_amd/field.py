@@ -465,6 +465,8 @@ class Field:
 
 
 def _host_ptw(x, op, deriv, *args):
+    if not (x.is_floating_point() or x.is_complex()):
+        x = x.to(torch.float64)  # numpy evaluates integer input in float64; torch would pick float32
     if op == "exp":
         f = torch.exp(x); return (f, f) if deriv else f
     if op == "log":

@@ -817,7 +817,10 @@ class ScalingOperator(EndomorphicOperator):
                            std=float(self._get_fct(from_inverse)))
 
     def get_sqrt(self):
-        return ScalingOperator(self._domain, self._get_fct(False))
+        fct = self._get_fct(False)
+        if np.iscomplexobj(fct) or fct < 0:  # a complex-TYPED factor has no real square-root operator, even 2 + 0j
+            raise ValueError("get_sqrt() works only for positive definite operators.")
+        return ScalingOperator(self._domain, fct)
 
     def __call__(self, other):
         res = EndomorphicOperator.__call__(self, other)
@@ -862,6 +865,8 @@ class DiagonalOperator(EndomorphicOperator):
         return spaces, diagonal.val.reshape([n if axis in covered else 1 for axis, n in enumerate(dom.shape)])
 
     def _setup(self, dom, ldiag, sampling_dtype, trafo, spaces):
+        if not (ldiag.is_floating_point() or ldiag.is_complex()):
+            ldiag = ldiag.to(torch.float64)  # integer-valued diagonals (ift.full(dom, 2)): torch would take their sqrt in fp32
         self._domain, self._ldiag, self._dtype, self._trafo, self._spaces = dom, ldiag, sampling_dtype, trafo, spaces
         self._complex = ldiag.is_complex()
         self._capability = self._all_ops
@@ -940,6 +945,32 @@ class DiagonalOperator(EndomorphicOperator):
         else:
             d = B.binary(2, d, float(fct))
         return DiagonalOperator._from_ldiag(self, d, self._dtype, 0, self._spaces)
+
+    def _add(self, number):
+        """this operator + number * identity (diagonal_operator.py:149-155)"""
+        d = self._actual_diag()
+        if not d.is_cuda:
+            d = d + number
+        elif d.is_complex() or isinstance(number, complex):
+            raise NotImplementedError
+        else:
+            d = B.binary(0, d, float(number))
+        return DiagonalOperator._from_ldiag(self, d, self._dtype, 0, self._spaces)
+
+    def _combine_sum(self, op, selfneg, opneg):
+        """(+-) self (+-) op as one diagonal (diagonal_operator.py:157-163); both on the same sub-spaces"""
+        a, b = self._actual_diag(), op._actual_diag()
+        if a.dtype != b.dtype:
+            wide = torch.promote_types(a.dtype, b.dtype)
+            a, b = a.to(wide), b.to(wide)
+        if a.is_cuda and (a.is_complex() or b.is_complex()):
+            raise NotImplementedError
+        if not a.is_cuda:
+            total = (-a if selfneg else a) + (-b if opneg else b)
+        else:
+            a = B.binary(2, a, -1.0) if selfneg else a
+            total = B.binary(1 if opneg else 0, a.contiguous(), b.contiguous())
+        return DiagonalOperator._from_ldiag(self, total, self._dtype if self._dtype == op._dtype else None, 0, self._spaces)
 
     def _combine_prod(self, op):
         if self._spaces != op._spaces and not (self._full() and op._full()):
@@ -1168,8 +1199,34 @@ class SumOperator(LinearOperator):
                 identity["dtype"] = identity["dtype"] if op._dtype is None else op._dtype
             else:
                 terms.append((op, minus))
-        if identity is not None:
+        def mergeable(op, other=None):
+            """a real or host diagonal (on the sub-spaces and domain of `other`, with its sampling dtype)"""
+            if not isinstance(op, DiagonalOperator) or (op._ldiag.is_cuda and op._complex):
+                return False
+            return other is None or (op.domain is other.domain and op._spaces == other._spaces and op._dtype == other._dtype)
+
+        # a multiple of the identity goes into the first diagonal on its domain with the same sampling dtype; diagonals on the
+        # same sub-spaces add up to one (sum_operator.py:107-140) -- the merged sum draws ONE sample, like the reference's
+        if identity is not None and identity["factor"] != 0:
+            host = next((i for i, (op, _) in enumerate(terms) if mergeable(op) and op.domain is identity["domain"]
+                         and op._dtype == identity["dtype"] and not isinstance(identity["factor"], complex)), None)
+            if host is not None:
+                op, minus = terms[host]
+                terms[host] = (op._add(-identity["factor"] if minus else identity["factor"]), minus)
+                identity = None
+        if identity is not None and (identity["factor"] != 0 or not terms):
             terms.append((ScalingOperator(identity["domain"], identity["factor"], identity["dtype"]), False))
+        merged_terms, used = [], set()
+        for i, (op, minus) in enumerate(terms):
+            if i in used:
+                continue
+            if mergeable(op):
+                for j in range(i + 1, len(terms)):
+                    if j not in used and mergeable(terms[j][0], op):
+                        op, minus = op._combine_sum(terms[j][0], minus, terms[j][1]), False
+                        used.add(j)
+            merged_terms.append((op, minus))
+        terms = merged_terms
         # block-diagonal terms on one MultiDomain add block by block (sum_operator.py:141-152)
         first = next((i for i, (op, _) in enumerate(terms) if isinstance(op, BlockDiagonalOperator)), None)
         if first is not None:

@@ -345,3 +345,20 @@ def test_complex_adjoints_on_the_device():
                                     force_device_ids=[0])
     dofdex = ift.Field.from_raw(dom, np.arange(30).reshape(6, 5) % 4)
     ift.extra.check_linear_operator(ift.DOFDistributor(dofdex), np.complex128, np.complex128, force_device_ids=[0])
+
+
+def test_sums_of_diagonals_merge_like_the_reference():
+    """sum_operator.py:107-140: scalings go into a diagonal, diagonals add up; integer-valued diagonals keep fp64 roots"""
+    dom = ift.RGSpace(5)
+    op1, op2 = ift.makeOp(ift.Field.full(dom, 2.0)), ift.ScalingOperator(dom, 3.0)
+    total = op1 + op2 - (op2 - op1) + op1 + op1 + op2
+    assert isinstance(total, ift.DiagonalOperator)
+    np.testing.assert_allclose(total(ift.full(dom, 1.0)).asnumpy(), 11.0, rtol=1e-15)
+    mixed = op1(op2 + op2)(op1)(op1) - op1(op2)
+    assert isinstance(mixed, ift.DiagonalOperator)
+    np.testing.assert_allclose(mixed(ift.full(dom, 1.0)).asnumpy(), 42.0, rtol=1e-15)
+    whole = ift.makeOp(ift.full(dom, 2))  # int64 values
+    x = ift.from_random(dom)
+    ift.extra.assert_allclose((whole.get_sqrt().adjoint @ whole.get_sqrt())(x), whole(x), rtol=1e-15)
+    with pytest.raises(ValueError):
+        ift.makeOp(2.0 + 0j, ift.makeDomain(dom)).get_sqrt()
