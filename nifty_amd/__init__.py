@@ -43,13 +43,17 @@ from .sugar import (abs, absolute, arctan, clip, cos, cosh, exp, expm1, exponent
 from .domains import Domain  # noqa: E402,F401
 from .selection_operators import (ConjugationOperator, DomainChangerAndReshaper, DomainTupleFieldInserter, ExtractAtIndices,  # noqa: E402,F401
                                   FieldZeroPadder, GeometryRemover, Imaginizer, OuterProduct, PartialExtractor, SliceOperator,
-                                  SqueezeOperator, TransposeOperator, ValueInserter)
+                                  SplitOperator, SqueezeOperator, TransposeOperator, ValueInserter)
 from . import correlated_fields as _cf, energy_operators as _eo, los_response as _los, operators as _ops  # noqa: E402
 import types as _types  # noqa: E402
 
 # the reference's `ift.library.<module>` / `ift.operators.energy_operators` attribute paths (compat.py has the import paths)
 library = _types.SimpleNamespace(correlated_fields=_cf, correlated_fields_simple=_cf, los_response=_los)
 _ops.energy_operators = _eo
+from . import selection_operators as _sel  # noqa: E402
+for _name in ("selection_operators", "transpose_operator", "outer_product_operator", "value_inserter", "field_zero_padder",
+              "domain_tuple_field_inserter", "simple_linear_operators"):
+    setattr(_ops, _name, _sel if _name != "simple_linear_operators" else _ops)
 from .operators import domain_union  # noqa: E402,F401
 
 

@@ -372,10 +372,26 @@ class Field:
         raise RuntimeError("ducktape works only on operators")
 
     def ducktape_left(self, name):
-        """The MultiField {name: self} (operator.py:364-373)"""
-        if not isinstance(name, str):
-            raise NotImplementedError("ducktape_left to a new domain is not implemented")
-        return MultiField.from_dict({name: self})
+        """The MultiField {name: self}, or -- a domain instead of a string -- the same values on that domain
+        (operator.py:364-373)"""
+        if isinstance(name, str):
+            return MultiField.from_dict({name: self})
+        from .domains import DomainTuple
+
+        new = DomainTuple.make(name)
+        if new.size != self._domain.size:
+            raise ValueError("Domain and target do not have the same number of pixels")
+        return Field(new, self._val.reshape(new.shape))
+
+    def transpose(self, indices):
+        from .selection_operators import TransposeOperator
+
+        return TransposeOperator(self._domain, indices)(self)
+
+    def squeeze(self, aggressive=False):
+        from .selection_operators import SqueezeOperator
+
+        return SqueezeOperator(self._domain, aggressive)(self)
 
     def broadcast(self, index, space):
         """self repeated along a new sub-domain `space` at position `index` (field.py:434-441)"""

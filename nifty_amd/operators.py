@@ -206,6 +206,12 @@ class Operator:
     def real(self):
         return Realizer(self.target)(self)
 
+    @property
+    def imag(self):
+        from .selection_operators import Imaginizer
+
+        return Imaginizer(self.target)(self)
+
     def sum(self, spaces=None):
         return ContractionOperator(self.target, spaces)(self)
 
@@ -222,14 +228,38 @@ class Operator:
         return ContractionOperator(tgt, index).adjoint(self)
 
     def ducktape(self, name):
+        """input from key `name` of a MultiField, or -- a domain instead of a string -- from a reshaped field on that domain
+        (operator.py:351-373)"""
         if isinstance(name, str):
             return self @ ducktape(self, None, name)
-        raise NotImplementedError("ducktape to a new domain is not implemented")
+        from .selection_operators import DomainChangerAndReshaper
+
+        return self @ DomainChangerAndReshaper(makeDomain(name), self.domain)
 
     def ducktape_left(self, name):
         if isinstance(name, str):
             return ducktape(None, self.target, name)(self)
-        raise NotImplementedError
+        from .selection_operators import DomainChangerAndReshaper
+
+        return DomainChangerAndReshaper(self.target, DomainTuple.make(name))(self)
+
+    def transpose(self, indices):
+        from .selection_operators import TransposeOperator
+
+        return TransposeOperator(self.target, indices)(self)
+
+    def conjugate(self):
+        from .selection_operators import ConjugationOperator
+
+        return ConjugationOperator(self.target)(self)
+
+    def integrate(self, spaces=None):
+        return IntegrationOperator(self.target, spaces)(self)
+
+    def squeeze(self, aggressive=False):
+        from .selection_operators import SqueezeOperator
+
+        return SqueezeOperator(self.target, aggressive)(self)
 
     def __repr__(self):
         return self.__class__.__name__
@@ -500,9 +530,11 @@ class Linearization:
         raise RuntimeError("ducktape works only on operators")
 
     def ducktape_left(self, name):
-        if not isinstance(name, str):
-            raise NotImplementedError("ducktape_left to a new domain is not implemented")
-        return ducktape(None, self.target, name)(self)
+        if isinstance(name, str):
+            return ducktape(None, self.target, name)(self)
+        from .selection_operators import DomainChangerAndReshaper
+
+        return DomainChangerAndReshaper(self.target, DomainTuple.make(name))(self)
 
     def broadcast(self, index, space):
         if not isinstance(self.target, DomainTuple):
@@ -510,6 +542,19 @@ class Linearization:
         tgt = list(self.target)
         tgt.insert(index, space)
         return ContractionOperator(tgt, index).adjoint(self)
+
+    def transpose(self, indices):
+        from .selection_operators import TransposeOperator
+
+        return TransposeOperator(self.target, indices)(self)
+
+    def conjugate(self):
+        from .selection_operators import ConjugationOperator
+
+        return ConjugationOperator(self.target)(self)
+
+    def integrate(self, spaces=None):
+        return IntegrationOperator(self.target, spaces)(self)
 
     # -- structure -----------------------------------------------------------------------------------
     def __getitem__(self, name):
@@ -520,6 +565,12 @@ class Linearization:
     @property
     def real(self):
         return self.new(self._val.real, Realizer(self._jac.target)(self._jac))
+
+    @property
+    def imag(self):
+        from .selection_operators import Imaginizer
+
+        return self.new(self._val.imag, Imaginizer(self._jac.target)(self._jac))
 
     def vdot(self, other):
         if is_fieldlike(other):

@@ -356,3 +356,68 @@ class SliceOperator(LinearOperator):
 
     def __str__(self):
         return f"{type(self).__name__}({self._domain.shape} -> {self._target.shape})"
+
+
+class SplitOperator(LinearOperator):
+    """One Field into a MultiField of selections: per key a tuple with one selector per sub-domain -- None (everything), a
+    slice, a boolean mask, a list of indices (each turns the sub-domain into an UnstructuredDomain of the selected length) or
+    an integer (drops the sub-domain).  Selections of different keys may overlap: the adjoint adds them up
+    (selection_operators.py:124-222; selectors address the first axis of their sub-domain, as there)."""
+
+    def __init__(self, domain, slices_by_key, intersecting_slices=True):
+        self._domain = DomainTuple.make(domain)
+        self._overlap = bool(intersecting_slices)
+        targets, self._select = {}, {}
+        for key, sel in slices_by_key.items():
+            if len(sel) > len(self._domain):
+                raise ValueError(f"slice at key {key!r} has more dimensions than the input")
+            subs, index = [], []
+            for i, sub in enumerate(self._domain):
+                one = sel[i] if i < len(sel) else None
+                rest = (slice(None),) * (len(sub.shape) - 1)
+                if one is None or (isinstance(one, slice) and one == slice(None)):
+                    subs.append(sub)
+                    index += [slice(None)] * len(sub.shape)
+                    continue
+                if isinstance(one, slice):
+                    count = len(range(*one.indices(sub.shape[0])))
+                elif isinstance(one, np.ndarray) and one.dtype == np.dtype(bool):
+                    if one.size != sub.size:
+                        raise ValueError(f"shape mismatch between desired slice {one} and the shape of the domain {sub.size}")
+                    count = int(one.sum())
+                    one = torch.as_tensor(np.flatnonzero(one), dtype=torch.int64)
+                elif isinstance(one, (tuple, list, np.ndarray)):
+                    count = len(one)
+                    one = torch.as_tensor(np.asarray(one), dtype=torch.int64)
+                elif isinstance(one, (int, np.integer)):
+                    count, one = None, int(one)
+                else:
+                    raise ValueError(f"invalid type for specifying a slice; got {one}")
+                if count is not None:
+                    subs.append(UnstructuredDomain((count,) + tuple(sub.shape[1:])))
+                index += [one, *rest]
+            targets[key] = DomainTuple.make(subs)
+            self._select[key] = tuple(index)
+        self._target = MultiDomain.make(targets)
+        self._capability = self.TIMES | self.ADJOINT_TIMES
+
+    @staticmethod
+    def _on(index, device):
+        return tuple(ix.to(device) if isinstance(ix, torch.Tensor) else ix for ix in index)
+
+    def apply(self, x, mode):
+        self._check_input(x, mode)
+        if mode == self.TIMES:
+            v = x.val
+            return MultiField.from_dict({key: Field(self._target[key], v[self._on(ix, v.device)].reshape(self._target[key].shape))
+                                         for key, ix in self._select.items()}, self._target)
+        first = next(iter(x.values())).val
+        out = torch.zeros(self._domain.shape, dtype=first.dtype, device=first.device)
+        for key, ix in self._select.items():
+            ix = self._on(ix, first.device)
+            part = x[key].val.reshape(out[ix].shape)
+            out[ix] = out[ix] + part if self._overlap else part
+        return Field(self._domain, out)
+
+    def __str__(self):
+        return f"{type(self).__name__} {self._target.keys()!r} <-"
