@@ -57,9 +57,26 @@ class _Alias(types.ModuleType):
                                  f"(looked in {self.__dict__['_backing'].__name__})") from None
 
 
+def _anyarray_conveniences():
+    """`Field.val` is a torch tensor here, an `AnyArray` in the reference (any_array.py): give tensors the three AnyArray
+    methods scripts call on it -- `asnumpy()`, `device_id`, `at(device_id)`.  (numpy FUNCTIONS on `field.val`, e.g.
+    `np.mean(field.val)`, cannot be provided this way: use `field.asnumpy()`.)"""
+    import torch
+
+    from .field import device_of
+
+    if hasattr(torch.Tensor, "asnumpy"):
+        return
+    torch.Tensor.asnumpy = lambda self: self.detach().cpu().numpy()
+    torch.Tensor.device_id = property(lambda self: self.device.index if self.is_cuda else -1)
+    torch.Tensor.at = lambda self, device_id: self.to(device_of(device_id))
+
+
 def install(top="nifty"):
     """Register the aliases in sys.modules (idempotent).  Returns the nifty_amd package."""
     import nifty_amd
+
+    _anyarray_conveniences()
 
     if top in sys.modules and getattr(sys.modules[top], "_nifty_amd_alias", False):
         return nifty_amd

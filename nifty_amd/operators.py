@@ -191,6 +191,10 @@ class Operator:
             raise ValueError("partially constant input needs a MultiDomain")
         if not set(c_inp.keys()) <= set(self.domain.keys()):
             raise ValueError
+        from .energy_operators import EnergyOperator
+
+        if c_inp.domain is self.domain and not isinstance(self, EnergyOperator):
+            return None, ConstantOperator(self(c_inp))  # nothing variable is left (operator.py:413-422)
         return self._simplify_for_constant_input_nontrivial(c_inp)
 
     def _simplify_for_constant_input_nontrivial(self, c_inp):
@@ -808,6 +812,24 @@ class InsertionOperator(Operator):
 
     def __repr__(self):
         return f"InsertionOperator\n  Constant: {self._cst.keys()}\n  Variable: {self._domain.keys()}"
+
+
+class ConstantOperator(Operator):
+    """Returns `output` whatever it is given; zero Jacobian (reference simplify_for_const.py:28-46)."""
+
+    def __init__(self, output, domain={}):
+        self._domain, self._target, self._output = makeDomain(domain), output.domain, output
+        if isinstance(self._domain, dict):
+            self._domain = MultiDomain.make(self._domain)
+
+    def apply(self, x):
+        self._check_input(x)
+        out = self._output.at(x.device_id)
+        return x.new(out, NullOperator(self._domain, self._target)) if is_linearization(x) else out
+
+    def __repr__(self):
+        tgt = self.target.keys() if isinstance(self.target, MultiDomain) else "()"
+        return f"{tgt} <- ConstantOperator"
 
 
 class NullOperator(LinearOperator):
@@ -1697,11 +1719,11 @@ class FFTShiftOperator(EndomorphicOperator):
         picked = set()
         for entry in wanted:
             if not isinstance(entry, (int, np.integer)) or not -count <= entry < count:
-                raise ValueError("spaces: indices into the domain tuple")
+                raise AssertionError("spaces: indices into the domain tuple")  # (the reference asserts, :408-415)
             picked.add(int(entry) % count)
         for i in picked:
             if not isinstance(self._domain[i], RGSpace):
-                raise TypeError("FFTShiftOperator only shifts RGSpaces")
+                raise AssertionError("FFTShiftOperator only shifts RGSpaces")
         return sorted(picked)
 
     def apply(self, x, mode):

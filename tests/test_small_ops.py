@@ -40,9 +40,9 @@ def test_fftshift_device(tag):
 
 def test_fftshift_argument_errors():
     sp = ift.RGSpace((4, 4))
-    with pytest.raises(TypeError):
+    with pytest.raises(AssertionError):  # the reference asserts its arguments (harmonic_operators.py:408-415)
         ift.FFTShiftOperator(ift.UnstructuredDomain(5))
-    with pytest.raises(ValueError):
+    with pytest.raises(AssertionError):
         ift.FFTShiftOperator(sp, spaces=3)
     op = ift.FFTShiftOperator(sp)
     with pytest.raises(ValueError):
