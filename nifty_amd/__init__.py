@@ -16,7 +16,7 @@ from .domains import (DomainTuple, GLSpace, HPSpace, LMSpace, MultiDomain, Power
 from .energy_operators import (AveragedEnergy, BernoulliEnergy, CategoricalEnergy, EnergyOperator, GaussianEnergy, InverseGammaEnergy, LikelihoodEnergyOperator, PoissonianEnergy,  # noqa: F401
                                QuadraticFormOperator, Squared2NormOperator, StandardHamiltonian, StudentTEnergy,
                                VariableCovarianceGaussianEnergy)
-from .field import Field, MultiField, device_available, from_random, full, is_fieldlike, makeField  # noqa: F401
+from .field import AnyArray, Field, MultiField, device_available, from_random, full, is_fieldlike, makeField  # noqa: F401
 from .kl import (EnergyAdapter, ResidualSampleList, SampledKLEnergy, SampledKLEnergyClass, SampleList,  # noqa: F401
                  draw_samples)
 from .minimization import (AbsDeltaEnergyController, ConjugateGradient, DeltaEnergyController, DescentMinimizer,  # noqa: F401

@@ -54,6 +54,20 @@ _BIN = {"add": L.OP_ADD, "sub": L.OP_SUB, "mul": L.OP_MUL, "div": L.OP_DIV}
 _HOST_BIN = {"add": torch.add, "sub": torch.sub, "mul": torch.mul, "div": torch.true_divide}
 
 
+class _AnyArrayMeta(type):
+    def __instancecheck__(cls, obj):
+        return isinstance(obj, torch.Tensor)
+
+
+class AnyArray(metaclass=_AnyArrayMeta):
+    """The array type behind `Field.val`.  The reference wraps numpy / cupy arrays in its own `AnyArray` (any_array.py); here
+    the values ARE torch tensors (host or GPU), so `AnyArray(x)` converts `x` to one and `isinstance(field.val, AnyArray)` holds.
+    The numpy-function protocol of the reference's class is not provided: `np.mean(field.val)` must read `field.asnumpy()`."""
+
+    def __new__(cls, arr):
+        return _as_tensor(arr.val if isinstance(arr, Field) else arr)
+
+
 def _binary(op, a, b):
     """a (op) b where a, b are tensors of equal shape or python scalars (at least one tensor)."""
     ref = a if torch.is_tensor(a) else b
@@ -231,8 +245,43 @@ class Field:
         # scalars that steer them, minimization._ls)
         return float(B.vdot(_cast(a, dt).contiguous(), _cast(b, dt).contiguous()).item())
 
-    def vdot(self, x):
-        return Field.scalar(self.s_vdot(x)).at(self.device_id)
+    def vdot(self, x, spaces=None):
+        """conj(self).x over all sub-domains (a scalar Field) or over `spaces` only (field.py:343-372)"""
+        if spaces is None or len(self._domain._chosen(spaces)) == len(self._domain):
+            return Field.scalar(self.s_vdot(x)).at(self.device_id)
+        if not isinstance(x, Field):
+            raise TypeError("The dot-partner must be an instance of the Field class")
+        if x._domain is not self._domain:
+            raise ValueError("domain mismatch")
+        return (self.conjugate() * x).sum(spaces)
+
+    def cast_domain(self, new_domain):
+        """The same values on another domain of the same shape (field.py:110-126)"""
+        from .domains import DomainTuple
+
+        return Field(DomainTuple.make(new_domain), self._val)
+
+    def map(self, func):
+        """`func` (a numpy function keeping the shape) applied to the values; device fields go through the host"""
+        return Field.from_raw(self._domain, func(self.asnumpy())).at(self.device_id)
+
+    def _compare(self, other, name):
+        """element-wise comparison -> boolean Field (a predicate, not arithmetic: evaluated by torch where the data lives)"""
+        if isinstance(other, Field):
+            if other._domain is not self._domain:
+                raise ValueError("domains are incompatible.")
+            other = other._val
+        elif not np.isscalar(other):
+            return NotImplemented
+        return Field(self._domain, getattr(torch, name)(self._val, other))
+
+    def __eq__(self, o): return self._compare(o, "eq")  # element-wise like numpy's (field.py:783-800); `is` compares objects
+    def __ne__(self, o): return self._compare(o, "ne")
+    __hash__ = object.__hash__
+    def __gt__(self, o): return self._compare(o, "gt")
+    def __ge__(self, o): return self._compare(o, "ge")
+    def __lt__(self, o): return self._compare(o, "lt")
+    def __le__(self, o): return self._compare(o, "le")
 
     def norm(self, ord=2):
         if ord == 2:

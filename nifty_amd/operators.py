@@ -1047,11 +1047,17 @@ class DiagonalOperator(EndomorphicOperator):
 
     def _combine_prod(self, op):
         if self._spaces != op._spaces and not (self._full() and op._full()):
+            # diagonals on different sub-spaces: the product lives on their union (diagonal_operator.py:118-147)
             a, b = self._actual_diag(), op._actual_diag()
             if a.is_cuda:
                 raise NotImplementedError
-            return DiagonalOperator._from_ldiag(self, a * b, self._dtype if self._dtype == op._dtype else None, 0, None
-                                                if (self._full() or op._full()) else tuple(set(self._spaces) | set(op._spaces)))
+            union = None if (self._full() or op._full()) else tuple(sorted(set(self._spaces) | set(op._spaces)))
+            if union == tuple(range(len(self._domain))):
+                union = None
+            prod = a * b
+            if union is None:
+                prod = prod.expand(self._domain.shape).contiguous()
+            return DiagonalOperator._from_ldiag(self, prod, self._dtype if self._dtype == op._dtype else None, 0, union)
         a, b = self._actual_diag(), op._actual_diag()
         if a.dtype != b.dtype:  # (numpy semantics: the wider type wins, e.g. an fp32 linearisation point times fp64 tables)
             wide = torch.promote_types(a.dtype, b.dtype)
@@ -1192,7 +1198,9 @@ class ChainOperator(LinearOperator):
                 number = number * link._factor
                 number_dtype = number_dtype if link._dtype is None else link._dtype
                 continue
-            mergeable = bool(kept) and all(isinstance(o, DiagonalOperator) and o._full() for o in (kept[-1], link))
+            mergeable = bool(kept) and all(isinstance(o, DiagonalOperator) for o in (kept[-1], link)) \
+                and kept[-1].domain is link.domain \
+                and (all(o._full() for o in (kept[-1], link)) or not (kept[-1]._ldiag.is_cuda or link._ldiag.is_cuda))
             blocks = bool(kept) and all(isinstance(o, BlockDiagonalOperator) for o in (kept[-1], link))
             if mergeable:
                 kept[-1] = kept[-1]._combine_prod(link)
