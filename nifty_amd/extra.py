@@ -117,7 +117,7 @@ def check_operator(op, loc, tol=1e-12, ntries=100, perf_check=True, only_r_diffe
                 raise AssertionError("Jacobian domain/target mismatch")
         for _ in range(ntries):
             lin = op(Linearization.make_var(pos))
-            direction = from_random(pos.domain, dtype=np.float64, device_id=dev)
+            direction = from_random(pos.domain, dtype=pos.dtype, device_id=dev)  # (complex points move in complex directions)
             dirder = lin.jac(direction)
             scale = lin.val.norm() * 1e-6 / dirder.norm() if dirder.norm() != 0 else lin.val.norm() * 1e-6
             direction = direction * scale
@@ -137,8 +137,8 @@ def check_operator(op, loc, tol=1e-12, ntries=100, perf_check=True, only_r_diffe
             else:
                 raise ValueError("gradient and value seem inconsistent")
             pos = nxt
-            check_linear_operator(linmid.jac, only_r_linear=only_r_differentiable, atol=tol, rtol=tol,
-                                  _device_ids_override=[dev])
+            check_linear_operator(linmid.jac, domain_dtype=pos.dtype, target_dtype=dirder.dtype,
+                                  only_r_linear=only_r_differentiable, atol=tol, rtol=tol, _device_ids_override=[dev])
 
 
 # ------------------------------------------------------------------------------------------------

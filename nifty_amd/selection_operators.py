@@ -120,21 +120,24 @@ class ExtractAtIndices(LinearOperator):
         self._target = makeDomain([UnstructuredDomain(len(indices[0])) if i == space else sub
                                    for i, sub in enumerate(self._domain)])
         grid = self._domain[space].shape
-        self._lead = int(np.prod(self._domain.shape[:_first_axis(self._domain, space)], dtype=np.int64))
+        nlead = _first_axis(self._domain, space)
+        self._lead = int(np.prod(self._domain.shape[:nlead], dtype=np.int64))
         self._cells = int(np.prod(grid, dtype=np.int64))
+        self._trail = int(np.prod(self._domain.shape[nlead + len(grid):], dtype=np.int64))
         # one linear index per requested pixel of the sub-domain
-        self._linear = torch.as_tensor(np.ravel_multi_index(tuple(np.asarray(ix) for ix in indices), grid), dtype=torch.int64)
+        self._linear = torch.as_tensor(np.ravel_multi_index(tuple(np.asarray(ix, dtype=np.int64) for ix in indices), grid),
+                                       dtype=torch.int64)
         self._capability = self.TIMES | self.ADJOINT_TIMES
 
     def apply(self, x, mode):
         self._check_input(x, mode)
         v = x.val
         if mode == self.TIMES:
-            rows = v.reshape(self._lead, self._cells, -1)
+            rows = v.reshape(self._lead, self._cells, self._trail)
             return Field(self._target, rows[:, self._linear.to(v.device)].reshape(self._target.shape))
         # colliding indices: summed on the host in index order, so the result does not depend on the device's atomics
-        rows = v.cpu().reshape(self._lead, len(self._linear), -1)
-        out = torch.zeros((self._lead, self._cells, rows.shape[2]), dtype=v.dtype)
+        rows = v.cpu().reshape(self._lead, len(self._linear), self._trail)
+        out = torch.zeros((self._lead, self._cells, self._trail), dtype=v.dtype)
         out.index_add_(1, self._linear, rows)
         return Field(self._domain, out.reshape(self._domain.shape).to(v.device))
 
