@@ -30,7 +30,7 @@ from .operators import (Adder, BlockDiagonalOperator, ChainOperator, Contraction
                         DOFDistributor, EndomorphicOperator, FFTOperator, FFTShiftOperator, FieldAdapter,
                         HarmonicTransformOperator, HartleyOperator, InversionEnabler, Linearization, LinearOperator, MaskOperator, NullOperator, Operator, OperatorAdapter,
                         PowerDistributor, Realizer, SamplingEnabler, SandwichOperator, ScalingOperator, SumOperator,
-                        Variable, VdotOperator, ducktape, makeOp)
+                        Variable, VdotOperator, WienerFilterCurvature, ducktape, makeOp)
 from .los_response import LOSResponse  # noqa: F401
 from .optimize_kl import optimize_kl  # noqa: F401
 from .parallel import shareRange  # noqa: F401

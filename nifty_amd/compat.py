@@ -26,6 +26,7 @@ LAYOUT = {
     "minimization.optimize_kl": "optimize_kl",
     "library": "correlated_fields", "library.correlated_fields": "correlated_fields",
     "library.correlated_fields_simple": "correlated_fields", "library.los_response": "los_response",
+    "library.wiener_filter_curvature": "operators",
 }
 # every file of the reference's operators/ package whose classes live in operators.py / energy_operators.py here
 for _name in ("adder", "block_diagonal_operator", "chain_operator", "contraction_operator", "counting_operator",

@@ -2050,3 +2050,18 @@ class SamplingEnabler(EndomorphicOperator):
 
     def __repr__(self):
         return "SamplingEnabler:\n  Likelihood:\n    " + repr(self._likelihood) + "\n  Prior:\n    " + repr(self._prior)
+
+
+def WienerFilterCurvature(R, N, S, iteration_controller=None, iteration_controller_sampling=None):
+    """R^dagger N^-1 R + S^-1, the inverse of the Wiener-filter propagator, invertible by conjugate gradient with S^-1 as
+    preconditioner and -- with `iteration_controller_sampling` -- able to draw from its inverse (reference
+    library/wiener_filter_curvature.py:25-66; `N` and `S` must implement `draw_sample` for that)."""
+    for cov in (N, S):
+        if not isinstance(cov, EndomorphicOperator):
+            raise TypeError("noise and signal covariance must be endomorphic operators")
+    data_term, prior_term = SandwichOperator.make(R, N.inverse), S.inverse
+    if iteration_controller_sampling is not None:
+        curvature = SamplingEnabler(data_term, prior_term, iteration_controller_sampling, prior_term)
+    else:
+        curvature = data_term + prior_term
+    return InversionEnabler(curvature, iteration_controller, prior_term)
