@@ -60,8 +60,8 @@ class _Alias(types.ModuleType):
 
 def _anyarray_conveniences():
     """`Field.val` is a torch tensor here, an `AnyArray` in the reference (any_array.py): give tensors the three AnyArray
-    methods scripts call on it -- `asnumpy()`, `device_id`, `at(device_id)`.  (numpy FUNCTIONS on `field.val`, e.g.
-    `np.mean(field.val)`, cannot be provided this way: use `field.asnumpy()`.)"""
+    methods scripts call on it -- `asnumpy()`, `device_id`, `at(device_id)` -- and numpy's function protocol, so that
+    `np.mean(field.val)` works (on a host copy).  Opt-in: only `install()` touches torch.Tensor."""
     import torch
 
     from .field import device_of
@@ -71,6 +71,22 @@ def _anyarray_conveniences():
     torch.Tensor.asnumpy = lambda self: self.detach().cpu().numpy()
     torch.Tensor.device_id = property(lambda self: self.device.index if self.is_cuda else -1)
     torch.Tensor.at = lambda self, device_id: self.to(device_of(device_id))
+
+    def as_arrays(obj):
+        if isinstance(obj, torch.Tensor):
+            return obj.detach().cpu().numpy()
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(as_arrays(o) for o in obj)
+        if isinstance(obj, dict):
+            return {k: as_arrays(v) for k, v in obj.items()}
+        return obj
+
+    def array_function(self, func, types, args, kwargs):
+        """numpy FUNCTIONS on `field.val` (`np.mean(f.val)`, `np.nansum(...)`): evaluated by numpy on host copies, returning
+        numpy results -- what scripts written against the reference's AnyArray expect from diagnostics"""
+        return func(*as_arrays(args), **as_arrays(kwargs))
+
+    torch.Tensor.__array_function__ = array_function
 
 
 def install(top="nifty"):

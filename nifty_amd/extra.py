@@ -157,7 +157,8 @@ class _Running:
         self.m2 += d * (v - self.mean)
 
     def result(self):
-        return {"mean": self.mean, "std": float(np.sqrt(self.m2 / (self.n - 1))) if self.n > 1 else None}
+        std = np.sqrt(self.m2 / (self.n - 1)) if self.n > 1 else None  # (complex residuals: the reference's complex "variance")
+        return {"mean": self.mean, "std": float(std) if std is not None and np.isrealobj(std) else std}
 
 
 def _key_stats(field):
