@@ -16,6 +16,7 @@ Two realisations share one interface:
   N-sized half in nk_product_field / nk_hartley_fused / nk_mirror_combine / nk_product_marginal.
 """
 import ctypes
+import functools
 import os
 
 import numpy as np
@@ -951,55 +952,70 @@ class CorrelatedFieldMaker:
         return self.amplitude ** 2
 
     # -- fluctuation statistics: operators on latent samples, and the same quantities measured on field realisations
-    # (correlated_fields.py:941-1064) ---------------------------------------------------------------------------------
+    # (correlated_fields.py:941-1064).  With f_j = (fluctuation amplitude of sub-space j) / (zero-mode amplitude) the variance of
+    # the field, in units of the squared zero mode, is prod_j (1 + f_j^2) - 1; a slice along sub-space i keeps f_i^2 instead of
+    # 1 + f_i^2. ------------------------------------------------------------------------------------------------------------
     def _relative_fluctuation(self, which):
         return self._a[which].fluctuation_amplitude / self.azm
 
-    def average_fluctuation(self, space):
+    def _variance_factor(self, bare=None):
+        """prod_j (1 + f_j^2), the factor of sub-space `bare` without its 1"""
+        factors = [self._relative_fluctuation(j) ** 2 for j in range(len(self._a))]
+        factors = [sq if j == bare else sq + 1 for j, sq in enumerate(factors)]
+        return functools.reduce(lambda x, y: x * y, factors)
+
+    def _need_subspace(self, space=0):
         if not self._a:
             raise NotImplementedError
         if space >= len(self._a):
             raise ValueError(f"invalid space specified; got {space!r}")
-        return self._a[0 if len(self._a) == 1 else space].fluctuation_amplitude
+
+    def average_fluctuation(self, space):
+        self._need_subspace(space)
+        return self._a[space if len(self._a) > 1 else 0].fluctuation_amplitude
 
     def slice_fluctuation(self, space):
-        if not self._a:
-            raise NotImplementedError
-        if space >= len(self._a):
-            raise ValueError(f"invalid space specified; got {space!r}")
+        self._need_subspace(space)
         if len(self._a) == 1:
             return self.average_fluctuation(0)
-        q = 1.0
-        for j in range(len(self._a)):
-            sq = self._relative_fluctuation(j) ** 2
-            q = q * (sq if j == space else 1 + sq)
-        return q.sqrt() * self.azm
+        return self._variance_factor(bare=space).sqrt() * self.azm
 
     @property
     def total_fluctuation(self):
-        if not self._a:
-            raise NotImplementedError
+        self._need_subspace()
         if len(self._a) == 1:
             return self.average_fluctuation(0)
-        q = 1.0
-        for j in range(len(self._a)):
-            q = q * (1 + self._relative_fluctuation(j) ** 2)
-        return (q - 1).sqrt() * self.azm
+        return (self._variance_factor() - 1).sqrt() * self.azm
 
     def moment_slice_to_average(self, fluctuations_slice_mean, nsamples=1000):
         """The mean of the `fluctuations` prior of a sub-space still to be added such that its slice fluctuations come out
-        as `fluctuations_slice_mean`, estimated from `nsamples` prior draws of the sub-spaces added so far"""
-        fluctuations_slice_mean = float(fluctuations_slice_mean)
-        if not fluctuations_slice_mean > 0:
-            raise ValueError(f"fluctuations_slice_mean must be greater zero; got {fluctuations_slice_mean!r}")
+        as `fluctuations_slice_mean`: that value over the prior mean of sqrt(prod_j (1 + f_j^2)) of the sub-spaces added so
+        far, estimated from `nsamples` draws per sub-space (sub-space by sub-space, like the reference draws them)."""
+        wanted = float(fluctuations_slice_mean)
+        if not wanted > 0:
+            raise ValueError(f"fluctuations_slice_mean must be greater zero; got {wanted!r}")
         from .field import from_random
 
-        scm = 1.0
-        for j in range(len(self._a)):
-            op = self._relative_fluctuation(j)
-            draws = np.array([op(from_random(op.domain, "normal")).asnumpy() for _ in range(nsamples)])
-            scm = scm * (draws ** 2 + 1.0)
-        return fluctuations_slice_mean / np.mean(np.sqrt(scm))
+        def prior_draws(op):
+            return np.array([op(from_random(op.domain, "normal")).asnumpy() for _ in range(nsamples)])
+
+        inflation = np.prod([1.0 + prior_draws(self._relative_fluctuation(j)) ** 2 for j in range(len(self._a))], axis=0)
+        return wanted / np.mean(np.sqrt(inflation))
+
+    def _summary_rows(self):
+        """(label, statistic) of everything statistics_summary reports; statistics that are not defined are left out"""
+        def maybe(label, getter):
+            try:
+                return [(label, getter())]
+            except NotImplementedError:
+                return []
+
+        rows = maybe("Offset amplitude", lambda: self.amplitude_total_offset)
+        rows.append(("Total fluctuation amplitude", self.total_fluctuation))
+        for i in range(len(self._a) if len(self._a) > 1 else 0):
+            rows.append((f"Average fluctuation (space {i})", self.average_fluctuation(i)))
+            rows += maybe(f"Slice fluctuation (space {i})", lambda i=i: self.slice_fluctuation(i))
+        return [(label, op) for label, op in rows if isinstance(op, Operator)]  # fixed numbers are not sampled
 
     def statistics_summary(self, prior_info):
         """Logs mean and standard deviation over `prior_info` prior draws of the offset amplitude and the fluctuation
@@ -1007,85 +1023,70 @@ class CorrelatedFieldMaker:
         from .field import from_random
         from .probing import StatCalculator
 
-        rows = []
-        try:
-            rows.append(("Offset amplitude", self.amplitude_total_offset))
-        except NotImplementedError:
-            pass
-        rows.append(("Total fluctuation amplitude", self.total_fluctuation))
-        if len(self._a) > 1:
-            for i in range(len(self._a)):
-                rows.append((f"Average fluctuation (space {i})", self.average_fluctuation(i)))
-                try:
-                    rows.append((f"Slice fluctuation (space {i})", self.slice_fluctuation(i)))
-                except NotImplementedError:
-                    pass
-        for name, op in rows:
-            if not isinstance(op, Operator):
-                continue
+        for label, op in self._summary_rows():
             stats = StatCalculator()
             for _ in range(prior_info):
                 stats.add(op(from_random(op.domain, "normal")))
-            for m, sd in zip(stats.mean.asnumpy().ravel(), stats.var.ptw("sqrt").asnumpy().ravel()):
-                logger.info(f"{name}: {m:.02E} ± {sd:.02E}")
+            spread = stats.var.ptw("sqrt").asnumpy().ravel()
+            for m, sd in zip(stats.mean.asnumpy().ravel(), spread):
+                logger.info(f"{label}: {m:.02E} ± {sd:.02E}")
 
+    # realised statistics of signal-space samples: root of the sample average of a per-sample second moment
     @staticmethod
     def _geometry_axes(domain):
         """indices of the sub-domains with geometry: all but a leading UnstructuredDomain (the total_N axis)"""
         return tuple(range(1 if isinstance(domain[0], UnstructuredDomain) else 0, len(domain)))
 
     @staticmethod
-    def _as_numbers(res):
-        return np.sqrt(res if np.isscalar(res) else res.asnumpy())
+    def _root_of_average(moments):
+        """sqrt of the mean of a list of Fields (or scalar Fields), as numbers"""
+        total = functools.reduce(lambda x, y: x + y, moments) * (1.0 / len(moments))
+        return np.sqrt(total.asnumpy())
 
     @staticmethod
     def offset_amplitude_realized(samples):
-        spaces = CorrelatedFieldMaker._geometry_axes(samples[0].domain)
-        acc = 0.0
-        for smp in samples:
-            acc = acc + smp.mean(spaces) ** 2
-        return CorrelatedFieldMaker._as_numbers(acc / len(samples))
+        where = CorrelatedFieldMaker._geometry_axes(samples[0].domain)
+        return CorrelatedFieldMaker._root_of_average([smp.mean(where) ** 2 for smp in samples])
 
     @staticmethod
     def total_fluctuation_realized(samples):
-        spaces = CorrelatedFieldMaker._geometry_axes(samples[0].domain)
-        contract = ContractionOperator(samples[0].domain, spaces)
-        acc = 0.0
-        for smp in samples:
-            acc = acc + (smp - contract.adjoint_times(smp.mean(spaces))) ** 2
-        return CorrelatedFieldMaker._as_numbers(acc.mean(spaces) / len(samples))
+        where = CorrelatedFieldMaker._geometry_axes(samples[0].domain)
+        return CorrelatedFieldMaker._root_of_average([smp.var(where) for smp in samples])
+
+    @staticmethod
+    def _one_of(samples, space):
+        """(geometry axes, the absolute index of geometry sub-space `space`) -- or None when there is only one"""
+        where = CorrelatedFieldMaker._geometry_axes(samples[0].domain)
+        if space >= len(where):
+            raise ValueError(f"invalid space specified; got {space!r}")
+        return where, (where[space] if len(where) > 1 else None)
 
     @staticmethod
     def slice_fluctuation_realized(samples, space):
-        spaces = CorrelatedFieldMaker._geometry_axes(samples[0].domain)
-        if space >= len(spaces):
-            raise ValueError(f"invalid space specified; got {space!r}")
-        if len(spaces) == 1:
+        """total second moment minus the part that survives averaging over sub-space `space`"""
+        where, along = CorrelatedFieldMaker._one_of(samples, space)
+        if along is None:
             return CorrelatedFieldMaker.total_fluctuation_realized(samples)
-        space = space + spaces[0]
-        sq, sq_of_mean = 0.0, 0.0
-        for smp in samples:
-            sq = sq + smp ** 2
-            sq_of_mean = sq_of_mean + smp.mean(space) ** 2
-        res = (sq / len(samples)).mean(spaces) - (sq_of_mean / len(samples)).mean(spaces[:-1])
-        return CorrelatedFieldMaker._as_numbers(res)
+
+        def moment(smp):
+            collapsed = smp.mean(along) ** 2
+            return (smp ** 2).mean(where) - collapsed.mean(CorrelatedFieldMaker._geometry_axes(collapsed.domain))
+
+        return CorrelatedFieldMaker._root_of_average([moment(smp) for smp in samples])
 
     @staticmethod
     def average_fluctuation_realized(samples, space):
-        spaces = CorrelatedFieldMaker._geometry_axes(samples[0].domain)
-        if space >= len(spaces):
-            raise ValueError(f"invalid space specified; got {space!r}")
-        if len(spaces) == 1:
+        """variance along sub-space `space` of the sample averaged over the other geometry sub-spaces"""
+        where, along = CorrelatedFieldMaker._one_of(samples, space)
+        if along is None:
             return CorrelatedFieldMaker.total_fluctuation_realized(samples)
-        space = space + spaces[0]
-        others = tuple(sp for sp in spaces if sp != space)
-        acc, contract = 0.0, None
-        for smp in samples:
-            r = smp.mean(others)
-            if contract is None:
-                contract = ContractionOperator(r.domain, len(r.domain) - 1)
-            acc = acc + (r - contract.adjoint_times(r.mean(len(r.domain) - 1))) ** 2
-        return CorrelatedFieldMaker._as_numbers(acc.mean(len(acc.domain) - 1) / len(samples))
+        others = tuple(sp for sp in where if sp != along)
+
+        def moment(smp):
+            profile = smp.mean(others)
+            return profile.var(len(profile.domain) - 1)
+
+        return CorrelatedFieldMaker._root_of_average([moment(smp) for smp in samples])
 
     def _generic_graph(self):
         """offset + HT( azm * prod_i a_i[pindex_i] * xi ) on the product of the harmonic spaces, with a leading
