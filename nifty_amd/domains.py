@@ -485,13 +485,12 @@ class GLSpace(StructuredDomain):
     the ring weights are numpy's Gauss-Legendre weights times the azimuthal pixel width 2 pi / nlon."""
 
     def __init__(self, nlat, nlon=None):
-        self._nlat = int(nlat)
-        if self._nlat < 1:
-            raise ValueError("nlat must be a positive number.")
-        self._nlon = 2 * self._nlat - 1 if nlon is None else int(nlon)
-        if self._nlon < 1:
-            raise ValueError("nlon must be a positive number.")
-        self._ring_weights = None
+        counts = dict(nlat=int(nlat))
+        counts["nlon"] = 2 * counts["nlat"] - 1 if nlon is None else int(nlon)  # default: just enough pixels per ring
+        for name, n in counts.items():
+            if n < 1:
+                raise ValueError(f"{name} must be a positive number.")
+        self._nlat, self._nlon, self._ring_weights = counts["nlat"], counts["nlon"], None
 
     def _key(self):
         return (self._nlat, self._nlon)

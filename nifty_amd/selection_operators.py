@@ -15,6 +15,18 @@ def _first_axis(domain, space):
     return sum(len(sub.shape) for sub in domain[:space])
 
 
+def _embedded(domain, where, values):
+    """A Field of zeros on `domain` with `values` written at index / slice tuple `where`"""
+    out = torch.zeros(domain.shape, dtype=values.dtype, device=values.device)
+    out[where] = values
+    return Field(domain, out)
+
+
+def _selected(domain, where, values):
+    """The Field on `domain` holding a copy of values[where]"""
+    return Field(domain, values[where].clone())
+
+
 class ConjugationOperator(EndomorphicOperator):
     """x -> conj(x): its own adjoint and inverse as a real-linear map (simple_linear_operators.py:59-74)"""
 
@@ -235,12 +247,8 @@ class ValueInserter(LinearOperator):
 
     def apply(self, x, mode):
         self._check_input(x, mode)
-        v = x.val
-        if mode == self.TIMES:
-            out = torch.zeros(self._target.shape, dtype=v.dtype, device=v.device)
-            out[self._index] = v
-            return Field(self._target, out)
-        return Field(self._domain, v[self._index].clone())
+        move = _embedded if mode == self.TIMES else _selected
+        return move(self._tgt(mode), self._index, x.val)
 
 
 class DomainTupleFieldInserter(LinearOperator):
@@ -263,12 +271,8 @@ class DomainTupleFieldInserter(LinearOperator):
 
     def apply(self, x, mode):
         self._check_input(x, mode)
-        v = x.val
-        if mode == self.TIMES:
-            out = torch.zeros(self._target.shape, dtype=v.dtype, device=v.device)
-            out[self._slice] = v
-            return Field(self._target, out)
-        return Field(self._domain, v[self._slice].contiguous())
+        move = _embedded if mode == self.TIMES else _selected
+        return move(self._tgt(mode), self._slice, x.val)
 
 
 class FieldZeroPadder(LinearOperator):
@@ -350,12 +354,8 @@ class SliceOperator(LinearOperator):
 
     def apply(self, x, mode):
         self._check_input(x, mode)
-        v = x.val
-        if mode == self.TIMES:
-            return Field(self._target, v[self._cuts].contiguous())
-        out = torch.zeros(self._domain.shape, dtype=v.dtype, device=v.device)
-        out[self._cuts] = v
-        return Field(self._domain, out)
+        move = _selected if mode == self.TIMES else _embedded
+        return move(self._tgt(mode), self._cuts, x.val)
 
     def __str__(self):
         return f"{type(self).__name__}({self._domain.shape} -> {self._target.shape})"

@@ -148,66 +148,74 @@ def calculate_position(operator, output):
     return pos
 
 
-def exec_time(obj, want_metric=True, verbose=False, domain_dtype=np.float64, ntries=1, device_id=-1, dump_prefix=None):
-    """Wall-clock seconds per call of the pieces of an Operator (value, linearisation, Jacobian, adjoint, gradient, metric) or
-    of an Energy (at, value, gradient, metric), logged and returned as a dict (sugar.py:606-693).  Device work is
-    synchronised before the clock is read.  `verbose` / `dump_prefix`: a cProfile of the timed calls, logged / written."""
-    import cProfile
-    import io
-    import pstats
+class _Stopwatch:
+    """Times callables: three untimed calls, then `ntries` timed ones with the device synchronised after each; optionally a
+    cProfile of the timed calls (logged / dumped)."""
 
-    import torch
+    def __init__(self, ntries, device_id, verbose, dump_prefix):
+        self.ntries, self.device_id, self.verbose, self.dump_prefix = ntries, device_id, verbose, dump_prefix
+        self.seconds = {}
 
-    from .minimization import Energy
+    def _sync(self):
+        if self.device_id > -1:
+            import torch
 
-    def sync():
-        if device_id > -1:
-            torch.cuda.synchronize(device_id)
+            torch.cuda.synchronize(self.device_id)
 
-    results = {}
+    def __call__(self, key, label, call):
+        import cProfile
+        import io
+        import pstats
 
-    def timed(func, arg, what, key):
         for _ in range(3):
-            out = func(arg)
-        sync()
-        profile = cProfile.Profile() if (verbose or dump_prefix is not None) else None
-        t0 = time.time()
+            out = call()
+        self._sync()
+        profile = cProfile.Profile() if (self.verbose or self.dump_prefix is not None) else None
+        start = time.time()
         if profile is not None:
             profile.enable()
-        for _ in range(ntries):
-            out = func(arg)
-            sync()
+        for _ in range(self.ntries):
+            out = call()
+            self._sync()
         if profile is not None:
             profile.disable()
-        results[key] = (time.time() - t0) / ntries
-        logger.info(f"{what}: {results[key] * 1000:>8.3f} ms")
-        if verbose:
+        self.seconds[key] = (time.time() - start) / self.ntries
+        logger.info(f"{label.ljust(33)}: {self.seconds[key] * 1000:>8.3f} ms")
+        if self.verbose:
             text = io.StringIO()
             pstats.Stats(profile, stream=text).sort_stats(pstats.SortKey.TIME).print_stats(5)
             logger.info(text.getvalue())
-        if dump_prefix is not None:
-            profile.dump_stats(f"{dump_prefix}_{key}.prof")
+        if self.dump_prefix is not None:
+            profile.dump_stats(f"{self.dump_prefix}_{key}.prof")
         return out
 
+
+def exec_time(obj, want_metric=True, verbose=False, domain_dtype=np.float64, ntries=1, device_id=-1, dump_prefix=None):
+    """Wall-clock seconds per call of the pieces of an Operator (value, linearisation, Jacobian, adjoint, gradient, metric) or
+    of an Energy (at, value, gradient, metric), logged and returned as a dict under the reference's keys (sugar.py:606-693)."""
+    from .minimization import Energy
+
+    watch = _Stopwatch(ntries, device_id, verbose, dump_prefix)
     if isinstance(obj, Energy):
-        moved = 0.99 * obj.position
-        timed(lambda e: e.at(moved), obj, "Energy.at()\t\t\t\t", "energy.at")
-        for attr in ("value", "gradient", "metric"):
-            timed(lambda name: getattr(obj, name), attr, f"Energy.{attr}\t\t\t\t", attr)
+        nearby = 0.99 * obj.position
+        pieces = [("energy.at", "Energy.at()", lambda: obj.at(nearby)), ("value", "Energy.value", lambda: obj.value),
+                  ("gradient", "Energy.gradient", lambda: obj.gradient), ("metric", "Energy.metric", lambda: obj.metric)]
         if obj.metric is not None:
-            timed(lambda e: e.apply_metric(e.position), obj, "Energy.apply_metric\t\t\t", "apply_metric")
-            timed(lambda e: e.metric(e.position), obj, "Energy.metric(position)\t\t\t", "metric()")
+            pieces += [("apply_metric", "Energy.apply_metric", lambda: obj.apply_metric(obj.position)),
+                       ("metric()", "Energy.metric(position)", lambda: obj.metric(obj.position))]
+        for piece in pieces:
+            watch(*piece)
     elif isinstance(obj, Operator):
         pos = from_random(obj.domain, "normal", dtype=domain_dtype, device_id=device_id)
-        lin = Linearization.make_var(pos, want_metric=bool(want_metric))
-        timed(lambda op: op(pos), obj, "Operator call with field\t\t", "apply")
-        res = timed(lambda op: op(lin), obj, "Operator call with linearization\t", "apply_lin")
-        timed(lambda x: res.jac(x), pos, "Apply linearization\t\t\t", "jac")
-        timed(lambda y: res.jac.adjoint(y), res.val, "Apply linearization (adjoint)\t\t", "jac.adjoint")
+        at_pos = Linearization.make_var(pos, want_metric=bool(want_metric))
+        watch("apply", "Operator call with field", lambda: obj(pos))
+        lin = watch("apply_lin", "Operator call with linearization", lambda: obj(at_pos))
+        watch("jac", "Apply linearization", lambda: lin.jac(pos))
+        watch("jac.adjoint", "Apply linearization (adjoint)", lambda: lin.jac.adjoint(lin.val))
         if obj.target is DomainTuple.scalar_domain():
-            timed(lambda name: getattr(res, name), "gradient", "Gradient evaluation\t\t\t", "gradient")
+            watch("gradient", "Gradient evaluation", lambda: lin.gradient)
             if want_metric:
-                timed(lambda x: res.metric(x), pos, "Metric apply\t\t\t\t", "metric_apply")
+                watch("metric_apply", "Metric apply", lambda: lin.metric(pos))
     else:
         raise TypeError("Operator or Energy expected")
-    return results
+    return watch.seconds
