@@ -271,6 +271,10 @@ def test_reference_import_paths_resolve_after_compat_install():
             "from nifty.cl.utilities import allreduce_sum\n"
             "import nifty.cl.operators.energy_operators as eo\n"
             "assert eo.GaussianEnergy is nifty_amd.GaussianEnergy and allreduce_sum([1.0, 2.0, 4.0], None) == 7.0\n"
+            "import numpy as np\n"
+            "f = ift.full(ift.RGSpace(4), 2.5)\n"
+            "assert isinstance(f.val, ift.AnyArray) and f.val.device_id == -1 and f.val.asnumpy().shape == (4,)\n"
+            "assert np.mean(f.val) == 2.5 and np.nansum(f.val.conj() * f.val) == 25.0   # numpy functions on field.val\n"
             "try:\n    from nifty.cl.operators.operator import NoSuchName\n"
             "except ImportError as e:\n    print('missing name reported:', e)\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(__import__("pathlib").Path(__file__).parents[1]))
