@@ -46,6 +46,8 @@ def _as_tensor(val, device=None):
     arr = np.asarray(val)
     if arr.dtype == np.float16:
         arr = arr.astype(np.float32)
+    if arr.ndim and not arr.flags.writeable:
+        arr = arr.copy()  # (read-only tables such as PowerSpace.pindex: a tensor must not alias memory numpy protects)
     t = torch.from_numpy(np.ascontiguousarray(arr)) if arr.ndim else torch.tensor(arr.item(), dtype=torch_dtype(arr.dtype))
     return t if device is None else t.to(device)
 
