@@ -633,14 +633,17 @@ def _ptw(x, op, deriv, *args, **kwargs):
     return B.pointwise(op, x.contiguous(), param, want_derivative=deriv)
 
 
+def _pointwise_method(name):
+    def method(self, *args, **kwargs):
+        return self.ptw(name, *args, **kwargs)
+
+    method.__name__ = name
+    return method
+
+
 for _name in ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "sin", "cos", "absolute", "arctan", "tan",
-              "sinh", "cosh", "log10", "sinc", "sign", "unitstep", "softplus"):
-    def _make(name):
-        def fn(self):
-            return self.ptw(name)
-        fn.__name__ = name
-        return fn
-    setattr(Field, _name, _make(_name))
+              "sinh", "cosh", "log10", "sinc", "sign", "unitstep", "softplus", "power", "exponentiate"):
+    setattr(Field, _name, _pointwise_method(_name))
 
 
 class MultiField:
@@ -799,9 +802,6 @@ class MultiField:
         return (MultiField(self._domain, tuple(p[0] for p in pairs)),
                 MultiField(self._domain, tuple(p[1] for p in pairs)))
 
-    def exp(self): return self.ptw("exp")
-    def log(self): return self.ptw("log")
-    def sqrt(self): return self.ptw("sqrt")
 
     # ---- key plumbing (multi_field.py:281-376) --------------------------------------------------
     def extract(self, subset):
@@ -861,3 +861,9 @@ def makeField(domain, arr, device_id=None):
     domain = makeDomain(domain)
     cls = MultiField if isinstance(domain, MultiDomain) else Field
     return cls.from_raw(domain, arr, device_id)
+
+
+for _name in ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "sin", "cos", "absolute", "arctan", "tan",
+              "sinh", "cosh", "log10", "sinc", "sign", "unitstep", "softplus", "power", "exponentiate", "abs"):
+    if _name not in MultiField.__dict__:
+        setattr(MultiField, _name, _pointwise_method(_name))

@@ -298,16 +298,21 @@ _ARITHMETIC = {
 }
 
 _POINTWISE_METHODS = ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "expm1", "abs", "sin", "cos", "arctan", "tan",
-                      "sinh", "cosh", "log10", "sinc", "sign", "unitstep", "softplus", "absolute")
+                      "sinh", "cosh", "log10", "sinc", "sign", "unitstep", "softplus", "absolute", "power", "clip", "exponentiate")
 
 
 def _install_pointwise(cls, names):
     """cls.exp(), cls.log(), ... = cls.ptw("exp"), ..."""
-    for name in names:
-        def method(self, _name=name):
-            return self.ptw(_name)
+    def bound_to(name):
+        def method(self, *args, **kwargs):
+            return self.ptw(name, *args, **kwargs)
+
         method.__name__ = name
-        setattr(cls, name, method)
+        return method
+
+    for name in names:
+        if name not in cls.__dict__:  # (an explicit method, e.g. Linearization.clip, stays)
+            setattr(cls, name, bound_to(name))
 
 
 _install_pointwise(Operator, _POINTWISE_METHODS)

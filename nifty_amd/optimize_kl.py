@@ -304,18 +304,31 @@ def _fused_counting_report(before, after, n_local):
 # ------------------------------------------------------------------------------------------------
 # driver
 # ------------------------------------------------------------------------------------------------
-def optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sampling_iteration_controller, *,
-                device_id=-1, **kwargs):
-    """reference optimize_kl.py:51-453.  With ``device_id >= 0`` the whole run executes with that GPU as torch's
-    current device: every libniftyk kernel is launched on the current device's current stream (backend._stream)."""
-    if device_id is not None and device_id >= 0:
-        import torch
+def optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sampling_iteration_controller,
+                nonlinear_sampling_minimizer=None, constants=[], point_estimates=[], transitions=None,
+                export_operator_outputs={}, output_directory=None, initial_position=None, initial_index=0, comm=None,
+                inspect_callback=None, terminate_callback=None, plot_energy_history=True, plot_minisanity_history=True,
+                save_strategy="latest", return_final_position=False, resume=False, sanity_checks=True, dry_run=False,
+                fresh_stochasticity=True, device_id=-1, fuse=True):
+    """reference optimize_kl.py:51-453 -- same arguments in the same order (they may be passed positionally), plus `fuse`.
+    With ``device_id >= 0`` the whole run executes with that GPU as torch's current device: every libniftyk kernel is launched
+    on the current device's current stream (backend._stream)."""
+    import contextlib
 
-        with torch.cuda.device(device_id):
-            return _optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer,
-                                sampling_iteration_controller, device_id=device_id, **kwargs)
-    return _optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sampling_iteration_controller,
-                        device_id=device_id, **kwargs)
+    options = dict(nonlinear_sampling_minimizer=nonlinear_sampling_minimizer, constants=constants,
+                   point_estimates=point_estimates, transitions=transitions, export_operator_outputs=export_operator_outputs,
+                   output_directory=output_directory, initial_position=initial_position, initial_index=initial_index, comm=comm,
+                   inspect_callback=inspect_callback, terminate_callback=terminate_callback,
+                   plot_energy_history=plot_energy_history, plot_minisanity_history=plot_minisanity_history,
+                   save_strategy=save_strategy, return_final_position=return_final_position, resume=resume,
+                   sanity_checks=sanity_checks, dry_run=dry_run, fresh_stochasticity=fresh_stochasticity, device_id=device_id,
+                   fuse=fuse)
+    on_gpu = device_id is not None and device_id >= 0
+    if on_gpu:
+        import torch
+    with (torch.cuda.device(device_id) if on_gpu else contextlib.nullcontext()):
+        return _optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sampling_iteration_controller,
+                            **options)
 
 
 def _optimize_kl(likelihood_energy, total_iterations, n_samples, kl_minimizer, sampling_iteration_controller, *,
