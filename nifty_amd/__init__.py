@@ -60,11 +60,11 @@ from .operators import domain_union  # noqa: E402,F401
 _nthreads = 1
 
 
-def set_nthreads(n):
+def set_nthreads(nthr):
     """Accepted for source compatibility with nifty.cl (ducc_dispatch.py:35-46): remembered for `nthreads()`, ignored by the
     device kernels."""
     global _nthreads
-    _nthreads = int(n)
+    _nthreads = int(nthr)
 
 
 def nthreads():

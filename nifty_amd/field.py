@@ -128,8 +128,8 @@ class Field:
         return Field(domain, t.reshape(domain.shape))
 
     @staticmethod
-    def scalar(val):
-        return Field(DomainTuple.scalar_domain(), _as_tensor(np.asarray(val)))
+    def scalar(val, device_id=-1):
+        return Field(DomainTuple.scalar_domain(), _as_tensor(np.asarray(val))).at(device_id)
 
     @staticmethod
     def full(domain, val, device_id=-1, dtype=None):
@@ -180,7 +180,8 @@ class Field:
     def device_id(self):
         return self._val.device.index if self._val.is_cuda else -1
 
-    def at(self, device_id):
+    def at(self, device_id, *, check_fail=True):
+        """This field on device `device_id` (-1: the host); `check_fail` is accepted for the reference's signature (field.py:185)"""
         if device_id == self.device_id:
             return self
         return Field(self._domain, self._val.to(device_of(device_id)))

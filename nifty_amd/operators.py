@@ -838,7 +838,8 @@ class ConstantOperator(Operator):
 
 
 class NullOperator(LinearOperator):
-    def __init__(self, domain, target):
+    def __init__(self, domain, target, default_domain_device_id=-1, default_target_device_id=-1):
+        # (the zero field is made on the device of the input: the reference's default device ids are accepted, not needed)
         self._domain, self._target = makeDomain(domain), makeDomain(target)
         self._capability = self.TIMES | self.ADJOINT_TIMES
 
@@ -1451,9 +1452,9 @@ class Realizer(EndomorphicOperator):
 class FieldAdapter(LinearOperator):
     """Extract one key of a MultiField (reference simple_linear_operators.py:152-214)."""
 
-    def __init__(self, tgt, name):
+    def __init__(self, target, name):
         self._name = name
-        self._target = DomainTuple.make(tgt)
+        self._target = DomainTuple.make(target)
         self._domain = MultiDomain.make({name: self._target})
         self._capability = self.TIMES | self.ADJOINT_TIMES
 
@@ -1494,8 +1495,8 @@ def IntegrationOperator(domain, spaces):
     return ContractionOperator(domain, spaces, 1)
 
 
-def Variable(domain, key):
-    return ducktape(makeDomain(domain), None, key)
+def Variable(target, key):
+    return ducktape(makeDomain(target), None, key)
 
 
 class ContractionOperator(LinearOperator):
