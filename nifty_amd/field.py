@@ -751,6 +751,29 @@ class MultiField:
     def conjugate(self):
         return MultiField(self._domain, tuple(v.conjugate() for v in self._val))
 
+    def astype(self, dtype):
+        """every component cast to `dtype`, or to dtype[key] for a dict (multi_field.py:98-113)"""
+        per_key = dtype if isinstance(dtype, dict) else dict.fromkeys(self.keys(), dtype)
+        return MultiField(self._domain, tuple(v.astype(per_key[k]) for k, v in self.items()))
+
+    def clip(self, a_min=None, a_max=None):
+        return self.ptw("clip", a_min, a_max)
+
+    def scale(self, factor):
+        return self if factor == 1 else self * factor
+
+    def s_all(self):
+        return all(v.s_all() for v in self._val)
+
+    def s_any(self):
+        return any(v.s_any() for v in self._val)
+
+    def val_rw(self):
+        return {k: v.val_rw() for k, v in self.items()}
+
+    def asnumpy_rw(self):
+        return {k: v.asnumpy_rw() for k, v in self.items()}
+
     def s_vdot(self, x):
         if x._domain is not self._domain:
             raise ValueError("domain mismatch")

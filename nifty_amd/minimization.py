@@ -364,6 +364,11 @@ class Minimizer:
     def __call__(self, energy, preconditioner=None):
         raise NotImplementedError
 
+    @property
+    def controller(self):
+        """the iteration controller that steers this minimiser (minimizer.py:40-42)"""
+        return self._controller
+
 
 def _forced_stop(controller):
     """Will the controller's next check end the solve at its iteration limit, whatever the energy (see _inplace_steps)?"""

@@ -206,6 +206,16 @@ class Operator:
     def ptw_pre(self, op, *args, **kwargs):
         return _OpChain.make((self, _FunctionApplier(self.domain, op, *args, **kwargs)))
 
+    def apply_to_random_sample(self, **kwargs):
+        """self(from_random(self.domain, **kwargs)) (operator.py:440-460)"""
+        from .field import from_random
+
+        return self(from_random(self.domain, **kwargs))
+
+    # a plain operator carries no value (Fields and Linearizations do: operator.py:43-75)
+    val = jac = metric = None
+    want_metric = False
+
     @property
     def real(self):
         return Realizer(self.target)(self)
@@ -316,6 +326,22 @@ def _install_pointwise(cls, names):
 
 
 _install_pointwise(Operator, _POINTWISE_METHODS)
+
+
+def _install_pointwise_pre(cls, names):
+    """cls.exp_pre(), ... = cls.ptw_pre("exp"), ...: the function applied to the INPUT (operator.py:525-535)"""
+    def bound_to(name):
+        def method(self, *args, **kwargs):
+            return self.ptw_pre(name, *args, **kwargs)
+
+        method.__name__ = name + "_pre"
+        return method
+
+    for name in names:
+        setattr(cls, name + "_pre", bound_to(name))
+
+
+_install_pointwise_pre(Operator, _POINTWISE_METHODS)
 
 
 class _FunctionApplier(Operator):
@@ -457,6 +483,26 @@ class Linearization:
     @staticmethod
     def make_const(field, want_metric=False):
         return Linearization(field, NullOperator(field.domain, field.domain), want_metric=want_metric)
+
+    @staticmethod
+    def make_const_empty_input(field, want_metric=False):
+        """constant w.r.t. NOTHING: the Jacobian's input domain is the empty MultiDomain (linearization.py:375-400)"""
+        return Linearization(field, NullOperator(MultiDomain.make({}), field.domain), want_metric=want_metric)
+
+    @staticmethod
+    def make_partial_var(field, constants, want_metric=False):
+        """variable in every key of a MultiField except `constants` (unit / zero blocks; linearization.py:403-438)"""
+        if len(constants) == 0:
+            return Linearization.make_var(field, want_metric)
+        blocks = {key: ScalingOperator(dom, 0.0 if key in constants else 1.0) for key, dom in field.domain.items()}
+        return Linearization(field, BlockDiagonalOperator(field.domain, blocks), want_metric=want_metric)
+
+    def at(self, device_id):
+        """the value moved to `device_id`; the Jacobian is not changed (linearization.py:150-164)"""
+        return self.new(self._val.at(device_id), self._jac)
+
+    def scale(self, factor):
+        return self if factor == 1 else self._times(factor)
 
     def trivial_jac(self):
         return Linearization.make_var(self._val, self._want_metric)
