@@ -36,6 +36,8 @@ from .optimize_kl import optimize_kl  # noqa: F401
 from .parallel import shareRange  # noqa: F401
 from . import utilities  # noqa: E402,F401
 from . import sugar  # noqa: E402,F401
+from . import plot  # noqa: E402,F401
+from .plot import Plot, plot_priorsamples, single_plot  # noqa: E402,F401
 from .sugar import (PS_field, calculate_position, create_harmonic_smoothing_operator, create_power_operator, exec_time,  # noqa: E402,F401
                     get_default_codomain, get_signal_variance, power_analyze)
 from .sugar import (abs, absolute, arctan, clip, cos, cosh, exp, expm1, exponentiate, log, log10, log1p, power, reciprocal,  # noqa: E402,F401,A004
@@ -50,6 +52,12 @@ import types as _types  # noqa: E402
 # the reference's `ift.library.<module>` / `ift.operators.energy_operators` attribute paths (compat.py has the import paths)
 library = _types.SimpleNamespace(correlated_fields=_cf, correlated_fields_simple=_cf, los_response=_los)
 _ops.energy_operators = _eo
+from . import kl as _kl, minimization as _min  # noqa: E402
+for _name in ("conjugate_gradient", "descent_minimizers", "energy", "iteration_controllers", "line_search", "minimizer",
+              "quadratic_energy"):
+    setattr(_min, _name, _min)
+for _name in ("kl_energies", "sample_list", "energy_adapter"):
+    setattr(_min, _name, _kl)
 from . import selection_operators as _sel  # noqa: E402
 for _name in ("selection_operators", "transpose_operator", "outer_product_operator", "value_inserter", "field_zero_padder",
               "domain_tuple_field_inserter", "simple_linear_operators"):

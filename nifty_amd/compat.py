@@ -12,7 +12,7 @@ import types
 # reference module path (below nifty.cl) -> module of this package (below nifty_amd) holding those names
 LAYOUT = {
     "field": "field", "multi_field": "field", "linearization": "operators", "sugar": "sugar", "utilities": "utilities",
-    "random": "random", "extra": "extra", "probing": "probing", "logger": "minimization", "pointwise": "sugar",
+    "random": "random", "extra": "extra", "probing": "probing", "logger": "minimization", "pointwise": "sugar", "plot": "plot",
     "domain_tuple": "domains", "multi_domain": "domains",
     "domains": "domains", "domains.domain": "domains", "domains.structured_domain": "domains",
     "domains.unstructured_domain": "domains", "domains.rg_space": "domains", "domains.power_space": "domains",

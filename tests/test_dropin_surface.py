@@ -366,3 +366,38 @@ def test_sums_of_diagonals_merge_like_the_reference():
     ift.extra.assert_allclose((whole.get_sqrt().adjoint @ whole.get_sqrt())(x), whole(x), rtol=1e-15)
     with pytest.raises(ValueError):
         ift.makeOp(2.0 + 0j, ift.makeDomain(dom)).get_sqrt()
+
+
+def test_plot_writes_the_panels_the_path_produces(tmp_path):
+    pytest.importorskip("matplotlib")
+    import matplotlib
+
+    matplotlib.use("Agg")
+    line, image = ift.RGSpace(10), ift.RGSpace((8, 6), distances=1.0)
+    power = ift.power_analyze(ift.FFTOperator(image)(ift.from_random(image)))
+    history = ift.EnergyHistory()
+    for i in range(5):
+        history.append((i, (i + 1.0) ** -2))
+    p = ift.Plot()
+    p.add(ift.from_random(image), title="2d rg", vmin=-1, vmax=1)
+    p.add([ift.from_random(line), ift.from_random(line)], title="list 1d rg", label=["1", "2"], alpha=[1, 0.3])
+    p.add(power, title="power spectrum")
+    p.add(ift.from_random(ift.UnstructuredDomain(10)), title="histogram")
+    p.add(history, title="energy")
+    p.add(None)
+    p.add(ift.from_random(ift.makeDomain({"a": line, "b": line})), title="per key")   # two panels
+    p.add(ift.from_random(ift.DomainTuple.make([image, ift.UnstructuredDomain(2)])))   # two image panels
+    assert len(p._panels) == 10
+    target = tmp_path / "panels.png"
+    p.output(title="ten panels", name=str(target), nx=4, ny=3)
+    assert target.stat().st_size > 10000
+    ift.single_plot(ift.from_random(image), title="one", name=str(tmp_path / "one.png"))
+    cf = ift.SimpleCorrelatedField(image, 0.0, (1e-2, 1e-3), (1.0, 0.5), (1.0, 0.5), (0.5, 0.2), (-3.0, 0.5))
+    ift.plot_priorsamples(cf, n_samples=2, name=str(tmp_path / "prior.png"))
+    assert (tmp_path / "one.png").exists() and (tmp_path / "prior.png").exists()
+    with pytest.raises(NotImplementedError):
+        q = ift.Plot()
+        q.add(ift.from_random(ift.HPSpace(4)))
+        q.output(name=str(tmp_path / "sphere.png"))
+    with pytest.raises(ValueError):
+        ift.Plot().output(name=str(tmp_path / "empty.png"))
