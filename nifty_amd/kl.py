@@ -96,6 +96,11 @@ class SampleListBase:
         return self._comm
 
     @property
+    def MPI_master(self):
+        """True on the rank that writes files (sample_list.py:95-97)"""
+        return get_MPI_params_from_comm(self._comm)[2]
+
+    @property
     def domain(self):
         return self._domain
 
