@@ -28,7 +28,7 @@ from .domains import DomainTuple, MultiDomain, PowerSpace, RGSpace, Unstructured
 from .engine import SMALL_KEYS, lognormal_moments
 from .field import Field, MultiField, full, makeField
 from .minimization import logger
-from .operators import (ContractionOperator, DiagonalOperator, EndomorphicOperator, HarmonicTransformOperator,
+from .operators import (ContractionOperator, DiagonalOperator, EndomorphicOperator, HarmonicTransformOperator, Linearization,
                         LinearOperator, Operator, PowerDistributor, Variable, VdotOperator, ducktape, is_linearization, makeOp)
 
 
@@ -723,15 +723,108 @@ class _ProductFieldJacobian(LinearOperator):
         return MultiField.from_dict(vals, dom)
 
 
+def _packed_copy(tensors, device):
+    """The tensors (all of one dtype) on `device`, moved as ONE buffer: one concatenation and one transfer instead of a
+    transfer -- and, from a GPU, a synchronisation -- per tensor."""
+    if not tensors:
+        return []
+    flat = torch.cat([t.reshape(-1) for t in tensors]).to(device)
+    sizes = [t.numel() for t in tensors]
+    return [part.reshape(t.shape) for part, t in zip(torch.split(flat, sizes), tensors)]
+
+
+class _one_host_thread:
+    """torch's CPU kernels on ONE thread while small host graphs run: with a pool of many threads some element-wise kernels take
+    milliseconds on a few hundred numbers (torch.sqrt of 127 doubles: 4.5 ms with 8 threads, 1.6 us with one)"""
+
+    def __enter__(self):
+        self._threads = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self._threads)
+        return False
+
+
+class _HostedAmplitudes(Operator):
+    """{xi, hyper-parameters and spectrum excitations} -> {xi, azm, a_0, a_1, ...} for device fields: the excitations pass through,
+    the amplitude MODELS -- operator graphs over a few hundred power bins each -- are evaluated on the HOST.  On the device every
+    one of their ~100 element-wise steps is a kernel launch on a few hundred numbers (2-3 us of work behind ~25 us of launch
+    path: a metric application of a 256 x 128 x 64 model spent 3.7 ms of which 0.3 ms in the transforms, the GPU idle 81 % of
+    an optimize_kl iteration); here the small inputs come to the host in one packed copy, the graphs run in torch's CPU
+    kernels, and the tables go back in one packed copy.  Same arithmetic, fp64, summation order of the host."""
+
+    def __init__(self, excitation_key, models, domain):
+        self._key, self._domain = excitation_key, domain
+        self._models = models  # host graph: small keys -> {azm, a_0, ...}
+        self._small = models.domain
+        self._target = MultiDomain.make({"xi": domain[excitation_key], **{k: models.target[k] for k in models.target.keys()}})
+        self._dtype = None
+
+    def _to_host(self, mf, dom):
+        keys = list(dom.keys())
+        parts = _packed_copy([mf[k].val.to(torch.float64) for k in keys], "cpu")
+        return MultiField.from_dict({k: Field(dom[k], p) for k, p in zip(keys, parts)}, dom)
+
+    @staticmethod
+    def _to_device(mf, dom, like):
+        keys = list(dom.keys())
+        parts = _packed_copy([mf[k].val.to(torch.float64) for k in keys], like.device)
+        return {k: Field(dom[k], p) for k, p in zip(keys, parts)}
+
+    def apply(self, x):
+        self._check_input(x)
+        lin = is_linearization(x)
+        v = x.val if lin else x
+        xi = v[self._key]
+        small = self._to_host(v, self._small)
+        with _one_host_thread():
+            out = self._models(Linearization.make_var(small) if lin else small)
+        tables = self._to_device(out.val if lin else out, self._models.target, xi.val)
+        value = MultiField.from_dict({"xi": Field(self._target["xi"], xi.val), **tables}, self._target)
+        if not lin:
+            return value
+        return x.new(value, _HostedAmplitudesJacobian(self, out.jac, xi.val))
+
+
+class _HostedAmplitudesJacobian(LinearOperator):
+    """Jacobian of `_HostedAmplitudes`: identity on the excitations, the host Jacobian of the amplitude models on the rest"""
+
+    def __init__(self, op, host_jac, like):
+        self._op, self._jac, self._like = op, host_jac, like
+        self._domain, self._target = op.domain, op.target
+        self._capability = self.TIMES | self.ADJOINT_TIMES
+
+    def apply(self, x, mode):
+        self._check_input(x, mode)
+        op = self._op
+        if mode == self.TIMES:
+            small = op._to_host(x, op._small)
+            with _one_host_thread():
+                moved = self._jac(small)
+            tables = op._to_device(moved, op._models.target, self._like)
+            return MultiField.from_dict({"xi": Field(self._target["xi"], x[op._key].val), **tables}, self._target)
+        bars = op._to_host(x, op._models.target)
+        with _one_host_thread():
+            small_bar = self._jac.adjoint_times(bars)
+        parts = op._to_device(small_bar, op._small, self._like)
+        parts = {k: f.astype(x["xi"].dtype) if f.dtype != x["xi"].dtype else f for k, f in parts.items()}
+        return MultiField.from_dict({op._key: Field(self._domain[op._key], x["xi"].val), **parts}, self._domain)
+
+
 class ProductCorrelatedFieldOperator(Operator):
     """CorrelatedFieldMaker.finalize for several spectra / total_N > 0: the generic operator graph for host fields and for
     grids the transform planner rejects, `_ProductFieldNode` fed by the amplitude graphs for device fields."""
 
-    def __init__(self, generic_op, node, feeder):
+    def __init__(self, generic_op, node, feeder, hosted=None):
         self._generic, self._node, self._fused = generic_op, node, node @ feeder
         self._domain, self._target = generic_op.domain, generic_op.target
         if self._fused.domain is not self._domain or self._fused.target is not self._target:
             raise RuntimeError("fused and generic correlated field disagree about their domains")
+        # NK_HOSTED_AMPLITUDES=0: the amplitude graphs on the device as well (rounds 4-5, for A/B)
+        self._feeder, self._hosted = feeder, hosted
+        if hosted is not None and os.environ.get("NK_HOSTED_AMPLITUDES", "1") != "0":
+            self._fused = node @ hosted
 
     def apply(self, x):
         self._check_input(x)
@@ -1118,10 +1211,14 @@ class CorrelatedFieldMaker:
         amps = self.get_normalized_amplitudes()
         node = _ProductFieldNode(hspace, generic.target, [a.target for a in amps], self.azm.target, self._total_N,
                                  0.0 if self._offset_mean is None else self._offset_mean)
-        feeder = Variable(hspace, self._prefix + "xi").ducktape_left("xi") + self.azm.ducktape_left("azm")
+        models = self.azm.ducktape_left("azm")
         for i, a in enumerate(amps):
-            feeder = feeder + a.ducktape_left(f"a{i}")
-        return ProductCorrelatedFieldOperator(generic, node, feeder)
+            models = models + a.ducktape_left(f"a{i}")
+        feeder = Variable(hspace, self._prefix + "xi").ducktape_left("xi") + models
+        hosted = None
+        if isinstance(models.domain, MultiDomain) and self._prefix + "xi" not in models.domain.keys():
+            hosted = _HostedAmplitudes(self._prefix + "xi", models, generic.domain)
+        return ProductCorrelatedFieldOperator(generic, node, feeder, hosted)
 
     def finalize(self, prior_info=0):
         if len(self._a) < 1 or self._azm is None:

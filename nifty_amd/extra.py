@@ -32,6 +32,12 @@ def _same_answer_twice(op, x):
     assert_equal(op(x), op(x))
 
 
+def _largest_entry(f):
+    """max |f| over all entries (and keys) of a Field / MultiField"""
+    arrays = f.asnumpy().values() if isinstance(f, MultiField) else [f.asnumpy()]
+    return max((float(np.abs(a).max()) for a in arrays if a.size), default=0.0)
+
+
 def _device_ids(force_device_ids):
     ids = {-1, *force_device_ids}
     if device_available():
@@ -130,7 +136,7 @@ def check_operator(op, loc, tol=1e-12, ntries=100, perf_check=True, only_r_diffe
                 dirder = linmid.jac(direction)
                 numgrad = lin2.val - lin.val
                 xtol = ftol * dirder.norm() / np.sqrt(dirder.size)
-                if float(abs(numgrad - dirder).asnumpy().max()) <= xtol:
+                if _largest_entry(numgrad - dirder) <= xtol:
                     break
                 direction = direction * 0.5
                 pos2, lin2 = mid, linmid

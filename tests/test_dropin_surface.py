@@ -401,3 +401,50 @@ def test_plot_writes_the_panels_the_path_produces(tmp_path):
         q.output(name=str(tmp_path / "sphere.png"))
     with pytest.raises(ValueError):
         ift.Plot().output(name=str(tmp_path / "empty.png"))
+
+
+@pmp("total_n", [0, 3])
+def test_hosted_amplitude_models_equal_the_operator_graph(total_n):
+    """the feeder of the fused product node with the amplitude models evaluated on the host (device fields: one packed copy
+    each way) against the same graphs evaluated in place: values, JVP, VJP"""
+    cfm = ift.CorrelatedFieldMaker("p", total_N=total_n)
+    cfm.add_fluctuations(ift.RGSpace((16,), (0.5,)), (1.0, 5e-1), (1.0, 2e-1), (5e-1, 5e-2), (-3.0, 2e-1), prefix="t")
+    cfm.add_fluctuations(ift.RGSpace((8, 6)), (0.7, 3e-1), (1.2, 2e-1), (4e-1, 5e-2), (-2.5, 2e-1), prefix="s")
+    cfm.set_amplitude_total_offset(2.0, (1e-1, 3e-2))
+    cf = cfm.finalize()
+    assert cf._hosted is not None and cf._hosted.domain is cf._feeder.domain and cf._hosted.target is cf._feeder.target
+    x = ift.from_random(cf.domain) * 0.5
+    ift.extra.assert_equal(cf._hosted(x), cf._feeder(x))
+    ift.extra.check_operator(cf._hosted, x, ntries=2, tol=1e-9)
+    graph, hosted = (op(ift.Linearization.make_var(x)) for op in (cf._feeder, cf._hosted))
+    v, w = ift.from_random(cf.domain), ift.from_random(graph.target)
+    ift.extra.assert_allclose(hosted.jac(v), graph.jac(v), rtol=1e-13, atol=1e-15)
+    ift.extra.assert_allclose(hosted.jac.adjoint(w), graph.jac.adjoint(w), rtol=1e-13, atol=1e-15)
+
+
+@pytest.mark.gpu
+def test_hosted_amplitude_models_on_the_device(monkeypatch):
+    """a product-spectrum field on the GPU with the amplitude models on the host (default) and on the device
+    (NK_HOSTED_AMPLITUDES=0): value, JVP and VJP of the whole operator through the fused product node"""
+    def build():
+        cfm = ift.CorrelatedFieldMaker("p")
+        cfm.add_fluctuations(ift.RGSpace((64,), (0.5,)), (1.0, 5e-1), (1.0, 2e-1), (5e-1, 5e-2), (-3.0, 2e-1), prefix="t")
+        cfm.add_fluctuations(ift.RGSpace((64, 64)), (0.7, 3e-1), (1.2, 2e-1), (4e-1, 5e-2), (-2.5, 2e-1), prefix="s")
+        cfm.set_amplitude_total_offset(2.0, (1e-1, 3e-2))
+        return cfm.finalize()
+
+    hosted = build()
+    monkeypatch.setenv("NK_HOSTED_AMPLITUDES", "0")
+    on_device = build()
+    assert hosted._fused is not on_device._fused and hosted.domain is on_device.domain
+    x = (0.5 * ift.from_random(hosted.domain)).at(0)
+    v, w = ift.from_random(hosted.domain).at(0), ift.from_random(hosted.target).at(0)
+    a, b = hosted(ift.Linearization.make_var(x)), on_device(ift.Linearization.make_var(x))
+    ift.extra.assert_allclose(a.val.at(-1), b.val.at(-1), rtol=1e-12, atol=1e-12)
+    ift.extra.assert_allclose(a.jac(v).at(-1), b.jac(v).at(-1), rtol=1e-11, atol=1e-11)
+    ga, gb = a.jac.adjoint(w).at(-1), b.jac.adjoint(w).at(-1)
+    for key in ga.keys():
+        scale = max(np.abs(gb[key].asnumpy()).max(), 1e-300)
+        np.testing.assert_array_less(np.abs(ga[key].asnumpy() - gb[key].asnumpy()).max() / scale, 1e-10, err_msg=key)
+        assert ga[key].dtype == gb[key].dtype
+    assert ga.device_id == -1 and a.jac.adjoint(w).device_id == 0
