@@ -650,16 +650,50 @@ for _name in ("exp", "log", "sqrt", "tanh", "sigmoid", "reciprocal", "log1p", "e
 class MultiField:
     """Dictionary key -> Field over a MultiDomain (reference multi_field.py)."""
 
-    __slots__ = ("_domain", "_val")
+    __slots__ = ("_domain", "_val", "_flat")
 
-    def __init__(self, domain, val):
+    # Element-wise arithmetic of DEVICE MultiFields runs on one packed buffer per operand when the whole MultiField is at most
+    # this many numbers: a product-spectrum model has a dozen keys, eleven of them a few hundred numbers long, and an operation
+    # per key is a kernel launch per key (the CG of the generic graph: ~70 launches per iteration for six vector updates; the
+    # GPU idle 80 % of the time, tools/gpu_product_probe.py).  Beyond it the packing copy costs more than the launches.
+    # The values of the result are views into its buffer; element-wise results are the same bits either way.
+    PACK_MAX = 1 << 23
+    PACK_MIN_KEYS = 3
+
+    def __init__(self, domain, val, _flat=None):
         if not isinstance(domain, MultiDomain):
             raise TypeError("domain must be of type MultiDomain")
         if not (isinstance(val, tuple) and len(val) == len(domain)):
             raise ValueError("length mismatch")
         if not all(isinstance(f, Field) and f.domain is sub for f, sub in zip(val, domain.domains())):
             raise ValueError("domain mismatch")  # one Field per key, each on that key's (interned) DomainTuple
-        self._domain, self._val = domain, val
+        self._domain, self._val, self._flat = domain, val, _flat
+
+    def __reduce__(self):
+        return (MultiField, (self._domain, self._val))  # (the packed buffer is a cache: never written to files)
+
+    @staticmethod
+    def _from_flat(domain, flat):
+        """the MultiField whose values are consecutive views of `flat` (key order)"""
+        vals, at = [], 0
+        for sub in domain.domains():
+            vals.append(Field(sub, flat[at:at + sub.size].reshape(sub.shape)))
+            at += sub.size
+        return MultiField(domain, tuple(vals), _flat=flat)
+
+    def _packed(self):
+        """all values as ONE contiguous device buffer (made once: MultiFields are immutable), or None: host data, mixed or
+        complex dtypes, few keys, or more than PACK_MAX numbers"""
+        if self._flat is None:
+            vals = self._val
+            if len(vals) < MultiField.PACK_MIN_KEYS or self._domain.size > MultiField.PACK_MAX:
+                return None
+            first = vals[0]._val
+            if not (first.is_cuda and first.is_floating_point()) or any(v._val.dtype != first.dtype or not v._val.is_cuda
+                                                                        for v in vals):
+                return None
+            self._flat = torch.cat([v._val.reshape(-1) for v in vals])
+        return self._flat
 
     @staticmethod
     def from_dict(dct, domain=None):
@@ -777,6 +811,19 @@ class MultiField:
     def s_vdot(self, x):
         if x._domain is not self._domain:
             raise ValueError("domain mismatch")
+        pairs = [(a._val, b._val) for a, b in zip(self._val, x._val)]
+        plain = all(u.is_cuda and v.is_cuda and u.dtype == v.dtype and u.is_floating_point() for u, v in pairs)
+        if plain and len(pairs) > 1:
+            # one dot kernel per key into ONE device buffer, one transfer for all of them (a read-back per key costs a
+            # synchronisation each: twelve per dot product of a product-spectrum model); added up in key order on the host
+            # like the per-key results were: the same bits
+            slots = torch.zeros(len(pairs), dtype=torch.float64, device=pairs[0][0].device)
+            for k, (u, v) in enumerate(pairs):
+                B.vdot(u.contiguous(), v.contiguous(), result=slots[k:k + 1])
+            res = 0.0
+            for part in slots.cpu().tolist():
+                res = res + part
+            return res
         res = 0.0
         for a, b in zip(self._val, x._val):
             res = res + a.s_vdot(b)
@@ -797,23 +844,37 @@ class MultiField:
     def _map(self, fn):
         return MultiField(self._domain, tuple(fn(v) for v in self._val))
 
-    def _bin(self, other, op):
+    def _bin(self, other, op, name=None, reverse=False):
+        """op(value, other value) per key -- or, for packable device MultiFields and a named operation, ONE launch on the
+        packed buffers (`reverse`: other (op) self)"""
         if isinstance(other, MultiField):
             if other._domain is not self._domain:
                 raise ValueError("domain mismatch")
+            if name is not None:
+                mine = self._packed()
+                theirs = other._packed() if mine is not None else None
+                if theirs is not None and theirs.dtype == mine.dtype:
+                    a, b = (theirs, mine) if reverse else (mine, theirs)
+                    return MultiField._from_flat(self._domain, _binary(name, a, b))
             return MultiField(self._domain, tuple(op(a, b) for a, b in zip(self._val, other._val)))
         if np.isscalar(other):
+            if name is not None and not isinstance(other, complex):
+                mine = self._packed()
+                if mine is not None:
+                    number = other.item() if isinstance(other, np.generic) else other
+                    a, b = (number, mine) if reverse else (mine, number)
+                    return MultiField._from_flat(self._domain, _binary(name, a, b))
             return self._map(lambda v: op(v, other))
         return NotImplemented
 
-    def __add__(self, o): return self._bin(o, lambda a, b: a + b)
-    def __radd__(self, o): return self._bin(o, lambda a, b: b + a)
-    def __sub__(self, o): return self._bin(o, lambda a, b: a - b)
-    def __rsub__(self, o): return self._bin(o, lambda a, b: b - a)
-    def __mul__(self, o): return self._bin(o, lambda a, b: a * b)
-    def __rmul__(self, o): return self._bin(o, lambda a, b: b * a)
-    def __truediv__(self, o): return self._bin(o, lambda a, b: a / b)
-    def __rtruediv__(self, o): return self._bin(o, lambda a, b: b / a)
+    def __add__(self, o): return self._bin(o, lambda a, b: a + b, "add")
+    def __radd__(self, o): return self._bin(o, lambda a, b: b + a, "add", True)
+    def __sub__(self, o): return self._bin(o, lambda a, b: a - b, "sub")
+    def __rsub__(self, o): return self._bin(o, lambda a, b: b - a, "sub", True)
+    def __mul__(self, o): return self._bin(o, lambda a, b: a * b, "mul")
+    def __rmul__(self, o): return self._bin(o, lambda a, b: b * a, "mul", True)
+    def __truediv__(self, o): return self._bin(o, lambda a, b: a / b, "div")
+    def __rtruediv__(self, o): return self._bin(o, lambda a, b: b / a, "div", True)
     def __pow__(self, p): return self._map(lambda v: v ** p)
     def __neg__(self): return self._map(lambda v: -v)
     def __abs__(self): return self._map(abs)

@@ -448,3 +448,27 @@ def test_hosted_amplitude_models_on_the_device(monkeypatch):
         np.testing.assert_array_less(np.abs(ga[key].asnumpy() - gb[key].asnumpy()).max() / scale, 1e-10, err_msg=key)
         assert ga[key].dtype == gb[key].dtype
     assert ga.device_id == -1 and a.jac.adjoint(w).device_id == 0
+
+
+@pytest.mark.gpu
+def test_packed_arithmetic_of_device_multifields_is_exact():
+    """element-wise arithmetic on one packed buffer per operand (MultiField.PACK_MAX) gives the bits of the per-key kernels"""
+    dom = ift.MultiDomain.make({"a": ift.RGSpace((16, 8)), "b": ift.UnstructuredDomain(5), "c": ift.RGSpace(3),
+                                "d": ift.DomainTuple.scalar_domain()})
+    for dtype in (np.float64, np.float32):
+        x, y = (ift.from_random(dom, dtype=dtype).at(0) for _ in range(2))
+        for fn in (lambda u, v: u + v, lambda u, v: u - v, lambda u, v: u * v, lambda u, v: u / v, lambda u, v: 2.5 * u - v * 0.3,
+                   lambda u, v: 1.0 / u + (3 - v), lambda u, v: u - 0.25 * v):
+            packed = fn(x, y)
+            plain = ift.MultiField.from_dict({k: fn(x[k], y[k]) for k in dom.keys()})
+            assert packed._flat is not None and packed["a"].dtype == np.dtype(dtype)
+            ift.extra.assert_equal(packed.at(-1), plain.at(-1))
+        assert x.s_vdot(y) == sum(x[k].s_vdot(y[k]) for k in dom.keys())
+        import pickle
+
+        back = pickle.loads(pickle.dumps((x + y).at(-1)))
+        ift.extra.assert_equal(back, (x + y).at(-1))
+    mixed = ift.MultiField.from_dict({"a": ift.from_random(dom["a"]).at(0), "b": ift.from_random(dom["b"], dtype=np.float32).at(0),
+                                      "c": ift.from_random(dom["c"]).at(0), "d": ift.from_random(dom["d"]).at(0)})
+    assert (mixed + mixed)._flat is None  # mixed dtypes: per key
+    ift.extra.assert_equal((mixed + mixed).at(-1), (2.0 * mixed).at(-1))
