@@ -64,13 +64,14 @@ def _anyarray_conveniences():
     `np.mean(field.val)` works (on a host copy).  Opt-in: only `install()` touches torch.Tensor."""
     import torch
 
-    from .field import device_of
+    from .field import device_of, torch_dtype
 
     if hasattr(torch.Tensor, "asnumpy"):
         return
     torch.Tensor.asnumpy = lambda self: self.detach().cpu().numpy()
     torch.Tensor.device_id = property(lambda self: self.device.index if self.is_cuda else -1)
     torch.Tensor.at = lambda self, device_id: self.to(device_of(device_id))
+    torch.Tensor.astype = lambda self, dtype: self.to(torch_dtype(dtype))
 
     def as_arrays(obj):
         if isinstance(obj, torch.Tensor):
