@@ -18,6 +18,7 @@ Two realisations share one interface:
 import ctypes
 import functools
 import os
+import threading
 
 import numpy as np
 import torch
@@ -735,14 +736,25 @@ def _packed_copy(tensors, device):
 
 class _one_host_thread:
     """torch's CPU kernels on ONE thread while small host graphs run: with a pool of many threads some element-wise kernels take
-    milliseconds on a few hundred numbers (torch.sqrt of 127 doubles: 4.5 ms with 8 threads, 1.6 us with one)"""
+    milliseconds on a few hundred numbers (torch.sqrt of 127 doubles: 4.5 ms with 8 threads, 1.6 us with one).  The setting is
+    process-wide: nested / concurrent users are counted, the first one in saves the pool size and the last one out restores it."""
+
+    _lock, _users, _saved = threading.Lock(), 0, None
 
     def __enter__(self):
-        self._threads = torch.get_num_threads()
-        torch.set_num_threads(1)
+        cls = _one_host_thread
+        with cls._lock:
+            if cls._users == 0:
+                cls._saved = torch.get_num_threads()
+                torch.set_num_threads(1)
+            cls._users += 1
 
     def __exit__(self, *exc):
-        torch.set_num_threads(self._threads)
+        cls = _one_host_thread
+        with cls._lock:
+            cls._users -= 1
+            if cls._users == 0:
+                torch.set_num_threads(cls._saved)
         return False
 
 
